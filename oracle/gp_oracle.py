@@ -1,0 +1,472 @@
+"""TEST INFRASTRUCTURE — CPU restatement (oracle) of GAPPadder's recruit + local-assembly hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product (gappadder_amd/) never does.  Every function cites the reference file:line it restates
+(paths relative to /root/reference).
+
+Parity status
+  * a-1..a-5 (gap scan, flanks, alignment-record tagging, second hop, FASTQ join, library merge):
+    PINNED — checked bit-for-bit against outputs of the reference itself (tests/golden/*/expected.tar.gz,
+    produced by tests/golden/make_golden.py which runs the 2to3-converted reference in the build container).
+  * a-7 (2-bit k-mer layout): PINNED — checked against known answers dumped from the reference's own
+    KmerUtils.cpp compiled from /root/reference (tests/golden/kmerutils_kat.json).
+  * a-6 (k-mer counting + de-Bruijn assembly): PARITY UNPINNED — the arithmetic lives in third-party KMC
+    and Velvet (un-vendored, un-pinned: assemble_gaps.py:96-118 only shells out to them).  The functions
+    below restate the documented behaviour for the flags the reference passes and DEFINE the tie-breaks;
+    see DESIGN.md "Assembly semantics".
+"""
+import bisect
+
+# ----------------------------------------------------------------------------- a-1: gaps & flanks
+
+
+def scan_gaps(seq, min_gap):
+    """gnrt_pos_true_seqs.py:17-56.  Gap = first 'N' .. next UPPER-case A/C/G/T; kept if len >= min_gap;
+    search resumes at min_pos+2; an N-run reaching the end of the sequence is dropped (:50-51)."""
+    out = []
+    pos = 0
+    while True:
+        start = seq.find("N", pos)
+        if start == -1:
+            break
+        pos = start + 1
+        ends = [e for e in (seq.find(c, pos) for c in "ACGT") if e != -1]
+        if not ends:
+            break
+        min_pos = min(ends)
+        if min_pos - start >= min_gap:
+            out.append((start, min_pos))
+        pos = min_pos + 2
+    return out
+
+
+def gap_positions(records, min_gap):
+    """gnrt_pos_true_seqs.py:12-57 -> lines 'start end len scaffold' in FASTA order."""
+    return [(s, e, e - s, name) for name, seq in records for (s, e) in scan_gaps(seq, min_gap)]
+
+
+def flank_seqs(seq, start, end, flank):
+    """gnrt_pos_true_seqs.py:94-99 incl. the Python slice semantics of start-5 < 0."""
+    left = seq[0:start - 5] if start < flank else seq[start - flank:start - 5]
+    right = seq[end + 5:end + flank]
+    return left, right
+
+
+def gap_ids(fai_names, gaps):
+    """'{scaffoldIdx}_{n}', n 1-based per scaffold (gnrt_pos_true_seqs.py:71-83, merge_reads.py:27-41,
+    assemble_gaps.py:255-271).  Assumes gap lines grouped by scaffold, as the reference's scan writes them."""
+    idx = {n: i for i, n in enumerate(fai_names)}
+    out, cnt, pre = [], 1, None
+    for (_, _, _, scf) in gaps:
+        if scf != pre:
+            cnt = 1
+        out.append("%d_%d" % (idx[scf], cnt))
+        cnt += 1
+        pre = scf
+    return out
+
+
+# ----------------------------------------------------------------------------- a-2: alignment-record tagging
+
+
+def is_clipped(cigar):
+    """collect_reads_for_gaps.py:13-26: +2 if last char is S/H, +1 if the first op is S/H."""
+    cnt = 2 if cigar[-1] in "SH" else 0
+    for ch in cigar:
+        if "0" <= ch <= "9":
+            continue
+        if ch in "SH":
+            cnt += 1
+        break
+    return cnt
+
+
+def focal_tags(gaps_of_scaffold, pos, dist2, clip_dist):
+    """collect_reads_for_gaps.py:31-65 as a closed form: tags [(gapIdx1based, '0c'|'0d'|'1c'|'1d')] at `pos`.
+    left window  start-i (i in [0,dist2), start-i >= 0), 'c' when i <= clip_dist;
+    right window end+i, same rule.  0-based gap coordinates are compared with the 1-based POS un-shifted."""
+    tags = []
+    for j, (start, end) in enumerate(gaps_of_scaffold, 1):
+        i = start - pos
+        if 0 <= i < dist2 and pos >= 0:
+            tags.append((j, "0c" if i <= clip_dist else "0d"))
+        i = pos - end
+        if 0 <= i < dist2:
+            tags.append((j, "1c" if i <= clip_dist else "1d"))
+    return tags
+
+
+def tag_record(fields, gaps_of_scaffold, IS, sd, clip_dist, anchor_mapq):
+    """collect_reads_for_gaps.py:76-159 (long-IS) / :174-259 (short-IS; switch at IS >= 750, :275).
+    fields = first 9 SAM columns (strings).  Returns [(list 'left'|'right', line)]."""
+    dist1, dist2 = IS - 3 * sd, IS + 3 * sd
+    short_is = IS < 750
+    qname, flag, ref, map_pos, mapq_s, cigar, mate_ref, mate_pos = (
+        fields[0], int(fields[1]), fields[2], int(fields[3]), fields[4], fields[5], fields[6], int(fields[7]))
+    bfirst = (flag & 0x40) != 0
+    own, mate = ("left", "right") if bfirst else ("right", "left")
+    out = []
+    for (j, sflag) in focal_tags(gaps_of_scaffold, map_pos, dist2, clip_dist):
+        start, end = gaps_of_scaffold[j - 1]
+        gap_len = end - start
+        clip_flag = is_clipped(cigar)
+        if (sflag == "0c" and clip_flag >= 2) or (sflag == "1c" and clip_flag in (1, 3)):
+            out.append((own, "%s %d %s clip" % (qname, j, mapq_s)))
+        if (flag & 0x4) == 0 and (flag & 0x8) == 0 and int(mapq_s) >= anchor_mapq:
+            line = "%s %d %s discordant %d %s %d %d" % (qname, j, mapq_s, map_pos, mate_ref, mate_pos, gap_len)
+            if mate_ref != "=":
+                out.append((mate, line))
+            else:
+                t = abs(int(fields[8]))
+                if t >= dist2 or (short_is and t <= dist1):
+                    out.append((mate, line))
+        elif (flag & 0x4) == 0 and (flag & 0x8) != 0:
+            out.append((mate, "%s %d %s unmap" % (qname, j, mapq_s)))
+    return out
+
+
+def collect_reads_for_gaps(sam_lines, gaps, IS, sd, clip_dist=250, anchor_mapq=30):
+    """One pass over SAM text for every scaffold that has gaps (run_multi_threads_collect_reads.py:17-33).
+    Returns {scaffold: {'left': [lines], 'right': [lines]}} = scaffold_reads_list_all/*."""
+    by_scf = {}
+    for (s, e, _, scf) in gaps:
+        by_scf.setdefault(scf, []).append((s, e))
+    out = {scf: {"left": [], "right": []} for scf in by_scf}
+    for line in sam_lines:
+        f = line.split()
+        if f[2] not in by_scf:
+            continue
+        for side, txt in tag_record(f[:9], by_scf[f[2]], IS, sd, clip_dist, anchor_mapq):
+            out[f[2]][side].append(txt)
+    return out
+
+
+# ----------------------------------------------------------------------------- a-3: discordant second hop
+
+
+def collect_discordant_regions(fai_names, scaffold_lists):
+    """run_multi_threads_discordant.py:19-122.  Returns the sorted rows [(mIdx, mPos, sIdx, gIdx)]
+    (= discordant_reads_pos.txt.sorted.txt, `sort -k1n -k2n -k3n -k4n`) — duplicates are kept."""
+    idx = {n: i for i, n in enumerate(fai_names)}
+    rows = []
+    for scf in fai_names:
+        if scf not in scaffold_lists:
+            continue
+        for side in ("left", "right"):
+            for rec in scaffold_lists[scf][side]:
+                f = rec.split()
+                if f[3] != "discordant":
+                    continue
+                m = scf if f[5] == "=" else f[5]
+                rows.append((idx[m], int(f[6]), idx[scf], int(f[1])))
+    rows.sort()
+    return rows
+
+
+def low_mapq_focal(rows_of_scaffold):
+    """collect_discordant_low_mapq_reads.py:4-28 as a closed form.  rows sorted by mPos.
+    focal_region[p] = LAST mPos (file order) with mPos-199 <= p <= mPos+299 (later entries overwrite, :21-25);
+    m_pos_gaps[mPos] = every 'sIdx_gIdx' of that position, duplicates kept (:15-19)."""
+    poss = sorted(set(r[1] for r in rows_of_scaffold))
+    groups = {}
+    for (_, mpos, sidx, gidx) in rows_of_scaffold:
+        groups.setdefault(mpos, []).append("%d_%d" % (sidx, gidx))
+
+    def lookup(p):
+        k = bisect.bisect_right(poss, p + 199) - 1     # largest mPos <= p+199
+        if k < 0:
+            return None
+        mpos = poss[k]
+        if mpos + 299 < p or p < 0:
+            return None
+        return mpos
+    return lookup, groups
+
+
+def collect_discordant_low_mapq(sam_lines, fai_names, rows):
+    """collect_discordant_low_mapq_reads.py:31-84 for every scaffold (run_multi_threads_discordant.py:125-138).
+    Returns {scaffold: {'left': [...], 'right': [...]}} only for scaffolds that own a discordant_temp file
+    AND saw at least one MAPQ-0 record (the file pair is opened on the first such record, :55-65)."""
+    per = {}
+    for r in rows:
+        per.setdefault(fai_names[r[0]], []).append(r)
+    cache, out = {}, {}
+    for line in sam_lines:
+        f = line.split()
+        if int(f[4]) > 0:
+            continue
+        scf = f[2]
+        if scf not in per:
+            continue
+        if scf not in cache:
+            cache[scf] = low_mapq_focal(per[scf])
+            out[scf] = {"left": [], "right": []}
+        lookup, groups = cache[scf]
+        src = lookup(int(f[3]))
+        if src is None:
+            continue
+        side = "left" if (int(f[1]) & 0x40) else "right"
+        for b in groups[src]:
+            out[scf][side].append("%s %s %d" % (f[0], b, int(f[4])))
+    return out
+
+
+# ----------------------------------------------------------------------------- a-4: FASTQ join
+
+
+def read_gap_map(fai_names, scaffold_lists, discordant_lists, side, high_quality=False):
+    """run_multi_threads_discordant.py:153-185 (all) / :464-485 (MAPQ == 60 only, no discordant lists).
+    {readId: set(gapKey)}."""
+    idx = {n: i for i, n in enumerate(fai_names)}
+    m = {}
+    if not high_quality:
+        for scf in fai_names:
+            for line in discordant_lists.get(scf, {}).get(side, []):
+                f = line.split()
+                m.setdefault(f[0], set()).add(f[1])
+    for scf in fai_names:
+        for line in scaffold_lists.get(scf, {}).get(side, []):
+            f = line.split()
+            if high_quality and int(f[2]) != 60:
+                continue
+            m.setdefault(f[0], set()).add("%d_%s" % (idx[scf], f[1]))
+    return m
+
+
+def fastq_records(text):
+    lines = text.split("\n")
+    for i in range(0, len(lines) - 3, 4):
+        yield lines[i], lines[i + 1], lines[i + 3]
+
+
+def fastq_read_id(header):
+    """run_multi_threads_discordant.py:212-214: first whitespace token, text before the first '/', minus '@'."""
+    return header.split()[0].split("/")[0][1:].rstrip()
+
+
+def dispatch_reads(fq_left, fq_right, left_map, right_map):
+    """run_multi_threads_discordant.py:209-241, 283-316 -> {gapKey: fastq text}: left-file stream order
+    then right-file stream order; header '@{id}_1' / '@{id}_2', bare '+' line."""
+    out = {}
+    for (text, m, suffix) in ((fq_left, left_map, "_1"), (fq_right, right_map, "_2")):
+        for h, s, q in fastq_records(text):
+            rid = fastq_read_id(h)
+            if rid in m:
+                rec = "@%s%s\n%s\n+\n%s\n" % (rid, suffix, s.rstrip(), q.rstrip())
+                for key in m[rid]:
+                    out.setdefault(key, []).append(rec)
+    return {k: "".join(v) for k, v in out.items()}
+
+
+def collect_library(sam_lines, fq_left, fq_right, fai_names, gaps, IS, sd, clip_dist=250, anchor_mapq=30):
+    """main.py:243-259 for one library.  Returns dict with every intermediate the reference writes."""
+    lists = collect_reads_for_gaps(sam_lines, gaps, IS, sd, clip_dist, anchor_mapq)
+    rows = collect_discordant_regions(fai_names, lists)
+    dlists = collect_discordant_low_mapq(sam_lines, fai_names, rows)
+    gap_reads = dispatch_reads(fq_left, fq_right, read_gap_map(fai_names, lists, dlists, "left"),
+                               read_gap_map(fai_names, lists, dlists, "right"))
+    hq = dispatch_reads(fq_left, fq_right, read_gap_map(fai_names, lists, dlists, "left", True),
+                        read_gap_map(fai_names, lists, dlists, "right", True))
+    return {"lists": lists, "rows": rows, "dlists": dlists, "gap_reads": gap_reads, "gap_reads_high_quality": hq}
+
+
+def merge_libraries(per_library, ids):
+    """merge_reads.py:12-56: per gap id, `cat` the per-library files in library order."""
+    out = {}
+    for gid in ids:
+        parts = [lib[gid] for lib in per_library if gid in lib]
+        if parts:
+            out[gid] = "".join(parts)
+    return out
+
+
+# ----------------------------------------------------------------------------- a-7: 2-bit k-mers
+
+_CODE = {"C": 1, "c": 1, "G": 2, "g": 2, "T": 3, "t": 3}
+
+
+def base_code(ch):
+    """KmerUtils.cpp:25-41: A=00 C=01 G=10 T=11, anything else -> A."""
+    return _CODE.get(ch, 0)
+
+
+def pack_kmer64(seq, pos, k):
+    """KmerUtils.cpp:61-69 (FormKmerTypeShortSeg): base i at bits 63-2i,62-2i (MSB-first, left-aligned)."""
+    v = 0
+    for i in range(k):
+        v |= base_code(seq[pos + i]) << (62 - 2 * i)
+    return v
+
+
+def all_kmers64(seq, k):
+    """KmerUtils.cpp:90-115 (GetAllKmersFromSeq) by shift-and-set (:72-87)."""
+    out = [pack_kmer64(seq, 0, k)]
+    for i in range(1, len(seq) - k + 1):
+        v = (out[-1] << 2) & 0xFFFFFFFFFFFFFFFF
+        v &= ~(3 << (62 - 2 * (k - 1))) & 0xFFFFFFFFFFFFFFFF
+        v |= base_code(seq[i + k - 1]) << (62 - 2 * (k - 1))
+        out.append(v)
+    return out
+
+
+def kmer_to_string(v, k):
+    """KmerUtils.cpp:127-169 (ConvKmerToString)."""
+    return "".join("ACGT"[(v >> (62 - 2 * i)) & 3] for i in range(k))
+
+
+def read_contains_freq_kmers(src_kmers, read, k, thr):
+    """KmerUtils.cpp:215-241 (IsReadContainingFreqKmers)."""
+    s = set(src_kmers)
+    return sum(1 for v in all_kmers64(read, k) if v in s) >= thr
+
+
+# wide (k <= 64) left-aligned 128-bit value, same layout extended: base i at bits 127-2i,126-2i
+def pack_kmer128(seq, pos, k):
+    v = 0
+    for i in range(k):
+        v |= base_code(seq[pos + i]) << (126 - 2 * i)
+    return v
+
+
+def revcomp_kmer128(v, k):
+    r = 0
+    for i in range(k):
+        b = (v >> (126 - 2 * i)) & 3
+        r |= (3 - b) << (126 - 2 * (k - 1 - i))
+    return r
+
+
+def canonical_kmers(seq, k, skip_n=True):
+    """[(pos, canonical 128-bit value)] of every k-mer of `seq` whose bases are all ACGT (KMC skips k-mers
+    with non-ACGT symbols); canonical = min(fwd, revcomp) on the left-aligned value (A<C<G<T)."""
+    out = []
+    bad = -1
+    for i, ch in enumerate(seq):
+        if ch not in "ACGT":
+            bad = i
+        p = i - k + 1
+        if p < 0:
+            continue
+        if skip_n and bad >= p:
+            continue
+        f = pack_kmer128(seq, p, k)
+        out.append((p, min(f, revcomp_kmer128(f, k))))
+    return out
+
+
+# ----------------------------------------------------------------------------- north-star k-mer screen
+
+
+def flank_kmer_index(flanks, k):
+    """{canonical k-mer: set(gap index)} over the left+right flank of every gap (north_star: 'canonical k-mer
+    extract of flanking contigs').  flanks = [(left, right)] upper-case; k-mers touching N are skipped."""
+    idx = {}
+    for g, (l, r) in enumerate(flanks):
+        for s in (l, r):
+            for _, c in canonical_kmers(s, k):
+                idx.setdefault(c, set()).add(g)
+    return idx
+
+
+def screen_reads(reads, flanks, k, min_hits=1):
+    """Sorted [(gap, read idx)] such that >= min_hits k-mer POSITIONS of the read are in the gap's flank set."""
+    idx = flank_kmer_index(flanks, k)
+    hits = []
+    for r, seq in enumerate(reads):
+        cnt = {}
+        for _, c in canonical_kmers(seq, k):
+            for g in idx.get(c, ()):
+                cnt[g] = cnt.get(g, 0) + 1
+        hits.extend((g, r) for g, n in cnt.items() if n >= min_hits)
+    hits.sort()
+    return hits
+
+
+# ----------------------------------------------------------------------------- a-6: count + de Bruijn walk
+
+
+def count_kmers(reads, k, min_count=2, max_count=10000000):
+    """KMC as invoked at assemble_gaps.py:96-102: canonical k-mers, k-mers with non-ACGT skipped, counts kept
+    when >= min_count (KMC default -ci2), capped at -cs; dump sorted ascending on the canonical form."""
+    cnt = {}
+    for seq in reads:
+        for _, c in canonical_kmers(seq, k):
+            cnt[c] = cnt.get(c, 0) + 1
+    return sorted((c, min(n, max_count)) for c, n in cnt.items() if n >= min_count)
+
+
+def kmer128_to_string(v, k):
+    return "".join("ACGT"[(v >> (126 - 2 * i)) & 3] for i in range(k))
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def assemble_kmers(kmer_strings, kv, min_contig=40):
+    """Stage 2 of the reference's 'two stage local assembly' (assemble_gaps.py:104-118: every surviving k-mer
+    becomes one Velvet read at hash length kv).  PARITY UNPINNED; this build DEFINES:
+      nodes  = distinct canonical kv-mers of the k-mer strings;
+      edges  = distinct (kv+1)-mers of the k-mer strings (both orientations);
+      unitig = maximal path whose inner junctions have exactly one out-edge and one in-edge;
+      each unitig is reported once, in the orientation min(seq, revcomp(seq)); unitigs shorter than
+      min_contig bp are dropped; output sorted by (-length, sequence).
+    Returns [sequence]."""
+    succ, pred = {}, {}
+    nodes = set()
+    for s in kmer_strings:
+        for t in (s, _rc(s)):
+            for i in range(len(t) - kv + 1):
+                nodes.add(t[i:i + kv])
+            for i in range(len(t) - kv):
+                a, b = t[i:i + kv], t[i + 1:i + 1 + kv]
+                succ.setdefault(a, set()).add(b)
+                pred.setdefault(b, set()).add(a)
+
+    def out1(a):
+        s = succ.get(a, ())
+        return next(iter(s)) if len(s) == 1 else None
+
+    def in1(a):
+        return len(pred.get(a, ())) == 1
+
+    seen, contigs = set(), []
+    for start in sorted(nodes):
+        if start in seen:
+            continue
+        # is `start` a unitig head?  (no unique predecessor whose only successor is start)
+        p = pred.get(start, ())
+        is_head = not (len(p) == 1 and len(succ.get(next(iter(p)), ())) == 1)
+        if not is_head:
+            continue
+        path, cur = [start], start
+        while True:
+            nx = out1(cur)
+            if nx is None or not in1(nx) or nx == start or nx == _rc(cur):
+                break
+            if nx in path:
+                break
+            path.append(nx)
+            cur = nx
+        seq = path[0] + "".join(n[-1] for n in path[1:])
+        for n in path:
+            seen.add(n)
+            seen.add(_rc(n))
+        contigs.append(min(seq, _rc(seq)))
+    # isolated cycles (no head): walk from the smallest unseen node
+    for start in sorted(nodes):
+        if start in seen:
+            continue
+        path, cur = [start], start
+        seen.add(start); seen.add(_rc(start))
+        while True:
+            nx = out1(cur)
+            if nx is None or nx in seen:
+                break
+            path.append(nx)
+            seen.add(nx); seen.add(_rc(nx))
+            cur = nx
+        seq = path[0] + "".join(n[-1] for n in path[1:])
+        contigs.append(min(seq, _rc(seq)))
+    contigs = sorted(set(c for c in contigs if len(c) >= min_contig), key=lambda c: (-len(c), c))
+    return contigs

@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, read-only).  Nothing of the
+reference is copied into the repo: its Python-2 sources are converted with lib2to3 into a
+temp dir, three tiny shims are placed beside them (`user`, `Bio.SeqIO`, a `samtools`
+stand-in that serves pre-made SAM text), `main.py -c Preprocess` and `-c Collect` are run on
+seeded synthetic input, and only DATA is captured: the synthetic inputs and the files the
+reference wrote (gap positions, flank FASTA, read lists, per-gap FASTQ).
+
+Also builds the reference's own KmerUtils.cpp (via oracle/Makefile -> oracle/_ref/) and
+dumps its known answers into tests/golden/kmerutils_kat.json.
+
+usage: python tests/golden/make_golden.py            (re-creates every fixture)
+"""
+import gzip
+import io
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tarfile
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+from synth_text import make_case  # noqa: E402  (text-level synthetic generator, this repo's own)
+
+REF_PY = ["main.py", "Utility.py", "gnrt_pos_true_seqs.py", "run_multi_threads_collect_reads.py",
+          "collect_reads_for_gaps.py", "run_multi_threads_discordant.py",
+          "collect_discordant_low_mapq_reads.py", "merge_reads.py", "assemble_gaps.py",
+          "MergeContigs.py", "pick_contigs.py", "collect_both_unmapped_reads.py"]
+
+SEQIO_SHIM = '''
+class _Seq(str):
+    pass
+class _Rec(object):
+    def __init__(self, id, seq):
+        self.id = id
+        self.seq = _Seq(seq)
+def parse(path, fmt):
+    if fmt == "fasta":
+        name, chunks = None, []
+        with open(path) as f:
+            for line in f:
+                line = line.rstrip("\\n")
+                if line.startswith(">"):
+                    if name is not None:
+                        yield _Rec(name, "".join(chunks))
+                    name, chunks = line[1:].split()[0], []
+                else:
+                    chunks.append(line)
+        if name is not None:
+            yield _Rec(name, "".join(chunks))
+    elif fmt == "fastq":
+        with open(path) as f:
+            while True:
+                h = f.readline()
+                if not h:
+                    break
+                s = f.readline().rstrip("\\n"); f.readline(); f.readline()
+                yield _Rec(h[1:].split()[0], s)
+    else:
+        raise ValueError(fmt)
+'''
+
+SAMTOOLS_SHIM = '''#!/usr/bin/env python3
+# stand-in for `samtools view <bam> "<scaffold>"` / `samtools faidx <fa>`: serves <bam>.sam text
+import sys
+if sys.argv[1] == "view":
+    bam, scf = sys.argv[2], sys.argv[3]
+    with open(bam + ".sam") as f:
+        for line in f:
+            if line.split("\\t")[2] == scf:
+                sys.stdout.write(line)
+elif sys.argv[1] == "faidx":
+    pass  # the generator writes the .fai itself
+'''
+
+
+def convert_reference(dst):
+    for f in REF_PY:
+        shutil.copy(os.path.join(REF, f), os.path.join(dst, f))
+        os.chmod(os.path.join(dst, f), 0o644)
+    subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", "-j", "4", dst],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    open(os.path.join(dst, "user.py"), "w").close()
+    os.mkdir(os.path.join(dst, "Bio"))
+    open(os.path.join(dst, "Bio", "__init__.py"), "w").close()
+    with open(os.path.join(dst, "Bio", "SeqIO.py"), "w") as f:
+        f.write(SEQIO_SHIM)
+    st = os.path.join(dst, "samtools_shim.py")
+    with open(st, "w") as f:
+        f.write(SAMTOOLS_SHIM)
+    os.chmod(st, 0o755)
+    # `python` must resolve to this interpreter inside the reference's shell pipelines
+    bindir = os.path.join(dst, "bin")
+    os.mkdir(bindir)
+    os.symlink(sys.executable, os.path.join(bindir, "python"))
+    return st, bindir
+
+
+def run_reference(case, out_tar, in_dir):
+    """case: dict from synth_text.make_case.  Writes inputs to in_dir, expected tree to out_tar."""
+    tmp = tempfile.mkdtemp(prefix="gp_golden_")
+    try:
+        code = os.path.join(tmp, "code")
+        os.mkdir(code)
+        samtools, bindir = convert_reference(code)
+        data = os.path.join(tmp, "data")
+        wf = os.path.join(tmp, "wf")
+        os.mkdir(data)
+        os.mkdir(wf)
+        with open(os.path.join(data, "draft.fa"), "w") as f:
+            f.write(case["draft_fa"])
+        with open(os.path.join(data, "draft.fa.fai"), "w") as f:
+            f.write(case["fai"])
+        libs = []
+        for i, lib in enumerate(case["libs"]):
+            bam = os.path.join(data, "lib%d.bam" % i)
+            open(bam, "w").close()
+            with open(bam + ".sam", "w") as f:
+                f.write(lib["sam"])
+            lfq, rfq = os.path.join(data, "lib%d_1.fq" % i), os.path.join(data, "lib%d_2.fq" % i)
+            with open(lfq, "w") as f:
+                f.write(lib["fq1"])
+            with open(rfq, "w") as f:
+                f.write(lib["fq2"])
+            libs.append((bam, lfq, rfq, lib["is"], lib["sd"]))
+        cfg = {
+            "draft_genome": {"fa": os.path.join(data, "draft.fa")},
+            "raw_reads": [{"left": l, "right": r} for (_, l, r, _, _) in libs],
+            "alignments": [{"bam": b, "is": str(i), "std": str(s)} for (b, _, _, i, s) in libs],
+            "software_path": {"bwa": "bwa", "samtools": samtools, "velvet": "/nonexistent/velvet/",
+                              "kmc": "/nonexistent/kmc/", "TERefiner": "./TERefiner_1",
+                              "ContigsMerger": "./ContigsMerger"},
+            "parameters": {"working_folder": wf, "min_gap_size": str(case["min_gap"]),
+                           "flank_length": str(case["flank"]), "nthreads": "2", "verbose": "0"},
+            "kmer_length": [{"k": 31, "k_velvet": [{"k": 29}]}],
+        }
+        cfgp = os.path.join(tmp, "cfg.json")
+        with open(cfgp, "w") as f:
+            json.dump(cfg, f)
+        env = dict(os.environ)
+        env["PATH"] = bindir + ":" + env["PATH"]
+        env["LC_ALL"] = "C"
+        for stage in ("Preprocess", "Collect"):
+            subprocess.check_call([sys.executable, "main.py", "-c", stage, "-g", cfgp], cwd=code, env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # ---- capture inputs (data only) ----
+        os.makedirs(in_dir, exist_ok=True)
+        def gz(name, text):
+            with gzip.GzipFile(os.path.join(in_dir, name + ".gz"), "wb", mtime=0) as g:
+                g.write(text.encode())
+        gz("draft.fa", case["draft_fa"])
+        with open(os.path.join(in_dir, "draft.fa.fai"), "w") as f:
+            f.write(case["fai"])
+        for i, lib in enumerate(case["libs"]):
+            gz("lib%d.sam" % i, lib["sam"])
+            gz("lib%d_1.fq" % i, lib["fq1"])
+            gz("lib%d_2.fq" % i, lib["fq2"])
+        meta = {"min_gap": case["min_gap"], "flank": case["flank"], "anchor_mapq": 30, "clip_dist": 250,
+                "libs": [{"is": l["is"], "sd": l["sd"]} for l in case["libs"]], "seed": case["seed"]}
+        with open(os.path.join(in_dir, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        # ---- capture what the reference wrote ----
+        keep = []
+        for root, _, files in os.walk(wf):
+            for fn in files:
+                p = os.path.join(root, fn)
+                rel = os.path.relpath(p, wf)
+                top = rel.split(os.sep)[0]
+                if top in ("empty_dir",):
+                    continue
+                keep.append(rel)
+        keep.sort()
+        buf = io.BytesIO()
+        with tarfile.open(fileobj=buf, mode="w") as tf:
+            for rel in keep:
+                ti = tf.gettarinfo(os.path.join(wf, rel), arcname=rel)
+                ti.mtime = 0; ti.uid = ti.gid = 0; ti.uname = ti.gname = ""
+                with open(os.path.join(wf, rel), "rb") as fh:
+                    tf.addfile(ti, fh)
+        with gzip.GzipFile(out_tar, "wb", mtime=0) as g:
+            g.write(buf.getvalue())
+        return keep
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def kmerutils_kat():
+    """Known answers from the reference's own KmerUtils.cpp, built into oracle/_ref/ (never committed)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "ref"])
+    exe = os.path.join(REPO, "oracle", "_ref", "kmerutils_kat")
+    cases = [("ACGT", 4), ("CGTN", 4), ("ACGTACGTTTGACCA", 5), ("ACGT" * 8 + "TG", 32),
+             ("acgtnNacgtTTGGCCAAxyzACGT", 7), ("TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT", 31),
+             ("GATTACAGATTACAGATTACAGATTACAGATTACAGATTACA", 31), ("A" * 40, 32), ("C", 1)]
+    out = {"pack": [], "predicate": []}
+    for seq, k in cases:
+        r = subprocess.check_output([exe, "kmers", seq, str(k)]).decode().split()
+        out["pack"].append({"seq": seq, "k": k, "kmers_hex": r})
+    for kh in ("1b00000000000000", "fe00000000000000"):
+        r = subprocess.check_output([exe, "tostr", kh, "5"]).decode().strip()
+        out.setdefault("tostr", []).append({"kmer_hex": kh, "k": 5, "str": r})
+    # IsReadContainingFreqKmers truth table: map = kmers of `src`; read; threshold
+    src = "ACGTACGTTTGACCAGGATTACATTTGACCA"
+    for read, k, thr in [("TTTGACCAGG", 5, 1), ("TTTGACCAGG", 5, 6), ("TTTGACCAGG", 5, 7), ("GGGGGGGGGG", 5, 1),
+                         ("GGGGGGGGGG", 5, 0), ("ACGTACGTTTGACCAGGATTACATTTGACCA", 9, 23),
+                         ("ACGTACGTTTGACCAGGATTACATTTGACCA", 9, 24), ("TGGTCAAATG", 5, 1)]:
+        r = subprocess.check_output([exe, "pred", src, read, str(k), str(thr)]).decode().strip()
+        out["predicate"].append({"src": src, "read": read, "k": k, "thr": thr, "result": int(r)})
+    with open(os.path.join(HERE, "kmerutils_kat.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
+    kmerutils_kat()
+    for name, seed in (("twolib", 20260001), ("edge", 20260011)):
+        case = make_case(name, seed)
+        d = os.path.join(HERE, name)
+        if os.path.isdir(d):
+            shutil.rmtree(d)
+        os.makedirs(d)
+        kept = run_reference(case, os.path.join(d, "expected.tar.gz"), os.path.join(d, "inputs"))
+        print(name, "captured", len(kept), "reference output files")
+
+
+if __name__ == "__main__":
+    main()

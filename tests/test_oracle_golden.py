@@ -1,0 +1,108 @@
+"""The oracle (oracle/gp_oracle.py) against outputs of the REFERENCE ITSELF (tests/golden/*/expected.tar.gz)
+and against known answers of the reference's own KmerUtils.cpp (tests/golden/kmerutils_kat.json)."""
+import json
+import os
+
+import pytest
+
+from golden_util import CASES, GOLDEN, Case
+from oracle import gp_oracle as O
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request):
+    return Case(request.param)
+
+
+def _gaps(case):
+    return O.gap_positions(case.fasta_records(), case.meta["min_gap"])
+
+
+def test_gap_positions(case):
+    got = ["%d %d %d %s" % g for g in _gaps(case)]
+    assert got == case.exp_lines("gap_positions.txt")
+
+
+def test_flank_regions(case):
+    gaps = _gaps(case)
+    ids = O.gap_ids(case.fai_names, gaps)
+    seqs = dict(case.fasta_records())
+    exp = case.exp_dir("flank_regions/")
+    assert sorted(exp) == sorted(i + ".fa" for i in ids)
+    for gid, (s, e, _, scf) in zip(ids, gaps):
+        l, r = O.flank_seqs(seqs[scf], s, e, case.meta["flank"])
+        assert exp[gid + ".fa"] == ">%s_left\n%s\n>%s_right\n%s\n" % (gid, l, gid, r)
+
+
+def _collect(case, lib):
+    return O.collect_library(lib["sam"].splitlines(), lib["fq1"], lib["fq2"], case.fai_names, _gaps(case),
+                             lib["is"], lib["sd"], case.meta["clip_dist"], case.meta["anchor_mapq"])
+
+
+def test_scaffold_lists_multiset(case):
+    for lib in case.libs:
+        got = _collect(case, lib)["lists"]
+        exp = case.exp_dir(lib["folder"] + "/scaffold_reads_list_all/")
+        assert sorted(exp) == sorted("%s_cluster_by_gap_reads_%s.list" % (s, side) for s in got for side in ("left", "right"))
+        for scf in got:
+            for side in ("left", "right"):
+                e = exp["%s_cluster_by_gap_reads_%s.list" % (scf, side)].splitlines()
+                assert sorted(got[scf][side]) == sorted(e), (scf, side)
+                # the reference iterates SAM order; only the order of tags inside one record is dict-defined
+                assert [l.split()[0] for l in got[scf][side]] == [l.split()[0] for l in e]
+
+
+def test_discordant_positions(case):
+    for lib in case.libs:
+        got = ["%d %d %d %d" % r for r in _collect(case, lib)["rows"]]
+        assert got == case.exp_lines(lib["folder"] + "/discordant_reads_pos.txt.sorted.txt")
+
+
+def test_low_mapq_lists(case):
+    for lib in case.libs:
+        got = _collect(case, lib)["dlists"]
+        exp = case.exp_dir(lib["folder"] + "/discordant_reads_list/")
+        assert sorted(exp) == sorted("%s_cluster_by_discordant_reads_%s.list" % (s, side) for s in got for side in ("left", "right"))
+        for scf in got:
+            for side in ("left", "right"):
+                e = exp["%s_cluster_by_discordant_reads_%s.list" % (scf, side)].splitlines()
+                assert got[scf][side] == e, (scf, side)
+
+
+def test_gap_fastq_byte_exact(case):
+    per_lib = {"gap_reads": [], "gap_reads_high_quality": []}
+    for lib in case.libs:
+        got = _collect(case, lib)
+        for kind in per_lib:
+            exp = case.exp_dir("%s/%s/" % (lib["folder"], kind))
+            assert sorted(exp) == sorted(k + ".fastq" for k in got[kind])
+            for k, txt in got[kind].items():
+                assert txt == exp[k + ".fastq"], (lib["folder"], kind, k)
+            per_lib[kind].append(got[kind])
+    ids = O.gap_ids(case.fai_names, _gaps(case))
+    for kind in per_lib:
+        merged = O.merge_libraries(per_lib[kind], ids)
+        exp = case.exp_dir("merged/%s/" % kind)
+        assert sorted(exp) == sorted(k + ".fastq" for k in merged)
+        for k, txt in merged.items():
+            assert txt == exp[k + ".fastq"]
+
+
+def test_kmerutils_known_answers():
+    kat = json.load(open(os.path.join(GOLDEN, "kmerutils_kat.json")))
+    for c in kat["pack"]:
+        assert ["%016x" % v for v in O.all_kmers64(c["seq"], c["k"])] == c["kmers_hex"], c["seq"]
+        assert O.pack_kmer64(c["seq"], 0, c["k"]) == int(c["kmers_hex"][0], 16)
+    for c in kat["tostr"]:
+        assert O.kmer_to_string(int(c["kmer_hex"], 16), c["k"]) == c["str"]
+    for c in kat["predicate"]:
+        src = O.all_kmers64(c["src"], c["k"])
+        assert int(O.read_contains_freq_kmers(src, c["read"], c["k"], c["thr"])) == c["result"], c
+
+
+def test_wide_kmer_layout_extends_kmerutils():
+    s = "GATTACAGATTACAGATTACAGATTACAGATTACAGATTACA"
+    for k in (1, 5, 31, 32):
+        assert O.pack_kmer128(s, 3, k) >> 64 == O.pack_kmer64(s, 3, k)
+    f = O.pack_kmer128(s, 0, 41)
+    assert O.kmer128_to_string(O.revcomp_kmer128(f, 41), 41) == O._rc(s[:41])
