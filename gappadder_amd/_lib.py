@@ -1,0 +1,80 @@
+"""ctypes binding of libgapfill_hip.so (include/gapfill_hip.h).  There is NO fallback: if the HIP library is
+missing or fails to load, importing any compute entry point raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgapfill_hip.so")
+
+GAP = np.dtype([("scaffold", "<u4"), ("start", "<u4"), ("end", "<u4"), ("idx_in_scaffold", "<u4")])
+ALNREC = np.dtype([("pos", "<u4"), ("mate_pos", "<u4"), ("tlen", "<i4"), ("ref", "<u4"), ("mate_ref", "<u4"),
+                   ("flag", "<u2"), ("mapq", "u1"), ("clipflag", "u1"), ("read", "<u8")])
+TAGHIT = np.dtype([("rec", "<u4"), ("gap", "<u4"), ("kind", "<u2"), ("to_mate", "<u2")])
+DPOS = np.dtype([("mate_scaffold", "<u4"), ("mate_pos", "<u4"), ("src_scaffold", "<u4"), ("src_gap", "<u4")])
+HIT = np.dtype([("gap", "<u4"), ("read", "<u4")])
+assert GAP.itemsize == 16 and ALNREC.itemsize == 32 and TAGHIT.itemsize == 12 and DPOS.itemsize == 16 and HIT.itemsize == 8
+
+GF_OK, GF_E_INVAL, GF_E_NODEV, GF_E_NOMEM, GF_E_NOSPACE, GF_E_STATE, GF_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+KIND_CLIP, KIND_DISCORDANT, KIND_UNMAP, KIND_LOWMAPQ = 0, 1, 2, 3
+KIND_NAMES = {KIND_CLIP: "clip", KIND_DISCORDANT: "discordant", KIND_UNMAP: "unmap"}
+KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_SYNTH, KERNEL_COUNT, KERNEL_VERIFY = range(8)
+
+_lib = None
+
+
+class GapFillError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        self.code = code
+        RuntimeError.__init__(self, "%s failed: %s (%d)%s" % (what, lib().gf_strerror(code).decode(), code,
+                                                            (" — " + detail) if detail else ""))
+
+
+def lib():
+    """The loaded library; raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libgapfill_hip.so not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C gappadder_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32, u32, u64p = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)
+    szp = C.POINTER(C.c_size_t)
+    sig = {
+        "gf_init": (i32, [i32, C.POINTER(vp)]),
+        "gf_destroy": (None, [vp]),
+        "gf_strerror": (C.c_char_p, [i32]),
+        "gf_last_error": (C.c_char_p, [vp]),
+        "gf_set_stream": (i32, [vp, vp]),
+        "gf_sync": (i32, [vp]),
+        "gf_set_option": (i32, [vp, C.c_char_p, C.c_long]),
+        "gf_set_gaps": (i32, [vp, vp, sz, u32, C.c_char_p, vp]),
+        "gf_pack_reads": (i32, [C.c_char_p, sz, i32, vp, vp]),
+        "gf_packed_read_bytes": (sz, [i32]),
+        "gf_screen_reads": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, szp]),
+        "gf_screen_reads_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, vp]),
+        "gf_tag_alignments": (i32, [vp, vp, sz, i32, i32, i32, i32, vp, sz, szp]),
+        "gf_tag_alignments_dev": (i32, [vp, vp, sz, i32, i32, i32, i32, vp, sz, vp]),
+        "gf_tag_low_mapq": (i32, [vp, vp, sz, vp, sz, vp, sz, szp]),
+        "gf_tag_low_mapq_dev": (i32, [vp, vp, sz, vp, sz, vp, sz, vp]),
+        "gf_dev_alloc": (i32, [vp, sz, C.POINTER(vp)]),
+        "gf_dev_free": (i32, [vp, vp]),
+        "gf_memcpy_h2d": (i32, [vp, vp, vp, sz]),
+        "gf_memcpy_d2h": (i32, [vp, vp, vp, sz]),
+        "gf_memset_dev": (i32, [vp, vp, i32, sz]),
+        "gf_timing_enable": (i32, [vp, i32]),
+        "gf_timing_read": (i32, [vp, i32, C.POINTER(C.c_double), u64p]),
+        "gf_timing_reset": (i32, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None

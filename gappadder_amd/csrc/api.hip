@@ -1,0 +1,331 @@
+// api.hip — the C ABI of libgapfill_hip.so (include/gapfill_hip.h): context, staging, host/device variants.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "gf_internal.hpp"
+
+namespace gf {
+
+int set_hip_error(gf_ctx* ctx, hipError_t e, const char* what) {
+    if (ctx) ctx->last_error = std::string(hipGetErrorString(e)) + " in " + what;
+    return e == hipErrorOutOfMemory ? GF_E_NOMEM : GF_E_NODEV;
+}
+
+int ensure(gf_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return GF_OK;
+    if (b.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    GF_HIP(ctx, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return GF_OK;
+}
+
+static void drain_timing(gf_ctx* ctx) {
+    for (auto& l : ctx->launches) {
+        float ms = 0;
+        if (hipEventSynchronize(l.b) == hipSuccess && hipEventElapsedTime(&ms, l.a, l.b) == hipSuccess) {
+            ctx->t_total[l.which] += ms;
+            ctx->t_count[l.which] += 1;
+        }
+        (void)hipEventDestroy(l.a);
+        (void)hipEventDestroy(l.b);
+    }
+    ctx->launches.clear();
+}
+
+}  // namespace gf
+
+using namespace gf;
+
+static bool taghit_less(const gf_taghit& a, const gf_taghit& b) {
+    if (a.rec != b.rec) return a.rec < b.rec;
+    if (a.gap != b.gap) return a.gap < b.gap;
+    return a.kind < b.kind;
+}
+
+template <typename F>
+static int tag_host(gf_ctx* ctx, const gf_alnrec* recs, size_t n, gf_taghit* out, size_t cap, size_t* n_out, F launch) {
+    if (!ctx || !n_out || (n && !recs) || (cap && !out)) return GF_E_INVAL;
+    *n_out = 0;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->stage_in, n * sizeof(gf_alnrec) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, cap * sizeof(gf_taghit) + 64))) return rc;
+    uint32_t* d_n = (uint32_t*)((uint8_t*)ctx->stage_out.p + cap * sizeof(gf_taghit));
+    d_n = (uint32_t*)(((uintptr_t)d_n + 15) & ~(uintptr_t)15);
+    if (n) GF_HIP(ctx, hipMemcpyAsync(ctx->stage_in.p, recs, n * sizeof(gf_alnrec), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch(ctx->stage_in.p, ctx->stage_out.p, d_n))) return rc;
+    uint32_t cnt = 0;
+    GF_HIP(ctx, hipMemcpyAsync(&cnt, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = cnt;
+    if (cnt > cap) return GF_E_NOSPACE;
+    if (cnt) GF_HIP(ctx, hipMemcpy(out, ctx->stage_out.p, (size_t)cnt * sizeof(gf_taghit), hipMemcpyDeviceToHost));
+    std::sort(out, out + cnt, taghit_less);
+    return GF_OK;
+}
+
+
+extern "C" {
+
+const char* gf_strerror(int code) {
+    switch (code) {
+        case GF_OK: return "ok";
+        case GF_E_INVAL: return "invalid argument";
+        case GF_E_NODEV: return "HIP device/runtime error";
+        case GF_E_NOMEM: return "out of memory";
+        case GF_E_NOSPACE: return "output capacity too small";
+        case GF_E_STATE: return "call order violated";
+        case GF_E_UNSUPPORTED: return "unsupported parameter";
+        default: return "unknown error";
+    }
+}
+
+int gf_init(int device_ordinal, gf_ctx** out) {
+    if (!out) return GF_E_INVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return GF_E_NODEV;
+    gf_ctx* ctx = new (std::nothrow) gf_ctx();
+    if (!ctx) return GF_E_NOMEM;
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
+        delete ctx;
+        return GF_E_NODEV;
+    }
+    ctx->stream = ctx->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->n_cu = prop.multiProcessorCount;
+    if (const char* e = getenv("GF_BITMAP_LOG2")) ctx->bitmap_log2_override = atoi(e);
+    *out = ctx;
+    return GF_OK;
+}
+
+void gf_destroy(gf_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_timing(ctx);
+    for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
+    for (DevBuf* b : {&ctx->cand, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->d_gaps) (void)hipFree(ctx->d_gaps);
+    if (ctx->d_scaf_off) (void)hipFree(ctx->d_scaf_off);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* gf_last_error(gf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int gf_set_stream(gf_ctx* ctx, void* s) {
+    if (!ctx) return GF_E_INVAL;
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return GF_OK;
+}
+
+int gf_sync(gf_ctx* ctx) {
+    if (!ctx) return GF_E_INVAL;
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GF_OK;
+}
+
+int gf_set_option(gf_ctx* ctx, const char* name, long value) {
+    if (!ctx || !name) return GF_E_INVAL;
+    if (!strcmp(name, "max_gaps_per_kmer")) { ctx->max_gaps_per_kmer = value < 0 ? 0 : (uint32_t)value; return GF_OK; }
+    if (!strcmp(name, "bitmap_log2")) {
+        ctx->bitmap_log2_override = (int)value;
+        for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
+        ctx->index.clear();
+        return GF_OK;
+    }
+    return GF_E_INVAL;
+}
+
+int gf_set_gaps(gf_ctx* ctx, const gf_gap* gaps, size_t n_gaps, uint32_t n_scaffolds, const char* flank_ascii,
+                const uint64_t* flank_off) {
+    if (!ctx || (n_gaps && !gaps) || n_scaffolds == 0) return GF_E_INVAL;
+    for (size_t g = 0; g < n_gaps; ++g) {
+        if (gaps[g].scaffold >= n_scaffolds || gaps[g].end < gaps[g].start) return GF_E_INVAL;
+        if (g && (gaps[g].scaffold < gaps[g - 1].scaffold ||
+                  (gaps[g].scaffold == gaps[g - 1].scaffold && gaps[g].start < gaps[g - 1].end)))
+            return GF_E_INVAL;  // grouped by scaffold, ascending, non-overlapping — as the reference's scan writes them
+    }
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
+    ctx->index.clear();
+    ctx->gaps.assign(gaps, gaps + n_gaps);
+    ctx->n_scaffolds = n_scaffolds;
+    ctx->flank_left.assign(n_gaps, std::string());
+    ctx->flank_right.assign(n_gaps, std::string());
+    if (flank_ascii && flank_off) {
+        for (size_t g = 0; g < n_gaps; ++g) {
+            if (flank_off[2 * g] > flank_off[2 * g + 1] || flank_off[2 * g + 1] > flank_off[2 * g + 2]) return GF_E_INVAL;
+            ctx->flank_left[g].assign(flank_ascii + flank_off[2 * g], flank_ascii + flank_off[2 * g + 1]);
+            ctx->flank_right[g].assign(flank_ascii + flank_off[2 * g + 1], flank_ascii + flank_off[2 * g + 2]);
+        }
+    }
+    if (ctx->d_gaps) { (void)hipFree(ctx->d_gaps); ctx->d_gaps = nullptr; }
+    if (ctx->d_scaf_off) { (void)hipFree(ctx->d_scaf_off); ctx->d_scaf_off = nullptr; }
+    std::vector<uint32_t> off(n_scaffolds + 1, 0);
+    for (size_t g = 0; g < n_gaps; ++g) off[gaps[g].scaffold + 1]++;
+    for (uint32_t s = 0; s < n_scaffolds; ++s) off[s + 1] += off[s];
+    GF_HIP(ctx, hipMalloc((void**)&ctx->d_gaps, std::max<size_t>(1, n_gaps) * sizeof(gf_gap)));
+    GF_HIP(ctx, hipMalloc((void**)&ctx->d_scaf_off, off.size() * 4));
+    if (n_gaps) GF_HIP(ctx, hipMemcpy(ctx->d_gaps, gaps, n_gaps * sizeof(gf_gap), hipMemcpyHostToDevice));
+    GF_HIP(ctx, hipMemcpy(ctx->d_scaf_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    return GF_OK;
+}
+
+size_t gf_packed_read_bytes(int read_len) { return read_len <= 0 ? 0 : (size_t)(read_len + 3) / 4; }
+
+int gf_pack_reads(const char* ascii, size_t n_reads, int read_len, uint8_t* packed, uint32_t* n_mask) {
+    if (read_len <= 0 || (n_reads && (!ascii || !packed))) return GF_E_INVAL;
+    const size_t rb = gf_packed_read_bytes(read_len), nmw = (size_t)(read_len + 31) / 32;
+    for (size_t r = 0; r < n_reads; ++r) {
+        const char* s = ascii + r * (size_t)read_len;
+        uint8_t* o = packed + r * rb;
+        memset(o, 0, rb);
+        if (n_mask) memset(n_mask + r * nmw, 0, nmw * 4);
+        for (int i = 0; i < read_len; ++i) {
+            const char c = s[i];
+            o[i >> 2] |= (uint8_t)(base_code(c) << (6 - 2 * (i & 3)));
+            const bool acgt = c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't';
+            if (n_mask && !acgt) n_mask[r * nmw + (i >> 5)] |= 1u << (i & 31);
+        }
+    }
+    return GF_OK;
+}
+
+// ---- screen ------------------------------------------------------------------------------------------
+int gf_screen_reads_dev(gf_ctx* ctx, const void* d_reads, const void* d_nmask, size_t n_reads, int read_len, int k,
+                        int min_hits, void* d_out, size_t cap, void* d_n_out) {
+    if (!ctx || !d_n_out || (n_reads && !d_reads) || (cap && !d_out)) return GF_E_INVAL;
+    if (ctx->gaps.empty() && ctx->n_scaffolds == 0) return GF_E_STATE;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    FlankIndex* ix = nullptr;
+    int rc = build_flank_index(ctx, k, &ix);
+    if (rc) return rc;
+    return launch_screen(ctx, *ix, d_reads, d_nmask, n_reads, read_len, min_hits, d_out, cap, d_n_out);
+}
+
+int gf_screen_reads(gf_ctx* ctx, const uint8_t* packed, const uint32_t* n_mask, size_t n_reads, int read_len, int k,
+                    int min_hits, gf_hit* out, size_t cap, size_t* n_out) {
+    if (!ctx || !n_out || (n_reads && !packed) || (cap && !out) || read_len <= 0) return GF_E_INVAL;
+    *n_out = 0;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t rb = gf_packed_read_bytes(read_len), nmw = (size_t)(read_len + 31) / 32;
+    int rc;
+    if ((rc = ensure(ctx, ctx->stage_in, n_reads * rb + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, cap * sizeof(gf_hit) + 64))) return rc;
+    if (n_mask && (rc = ensure(ctx, ctx->stage_aux, n_reads * nmw * 4 + 64))) return rc;
+    uint32_t* d_n = (uint32_t*)((uint8_t*)ctx->stage_out.p + cap * sizeof(gf_hit));
+    d_n = (uint32_t*)(((uintptr_t)d_n + 15) & ~(uintptr_t)15);
+    if (n_reads) GF_HIP(ctx, hipMemcpyAsync(ctx->stage_in.p, packed, n_reads * rb, hipMemcpyHostToDevice, ctx->stream));
+    if (n_mask && n_reads)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->stage_aux.p, n_mask, n_reads * nmw * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = gf_screen_reads_dev(ctx, ctx->stage_in.p, n_mask ? ctx->stage_aux.p : nullptr, n_reads, read_len, k, min_hits,
+                             ctx->stage_out.p, cap, d_n);
+    if (rc) return rc;
+    uint32_t cnt[2] = {0, 0};
+    GF_HIP(ctx, hipMemcpyAsync(&cnt[0], d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(&cnt[1], (uint32_t*)ctx->counters.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (cnt[1]) return GF_E_UNSUPPORTED;  // a read matched more (position, gap) pairs than the verify list holds
+    *n_out = cnt[0];
+    if (cnt[0] > cap) return GF_E_NOSPACE;
+    if (cnt[0]) GF_HIP(ctx, hipMemcpy(out, ctx->stage_out.p, (size_t)cnt[0] * sizeof(gf_hit), hipMemcpyDeviceToHost));
+    std::sort(out, out + cnt[0], [](const gf_hit& a, const gf_hit& b) { return a.gap < b.gap || (a.gap == b.gap && a.read < b.read); });
+    return GF_OK;
+}
+
+// ---- tagger --------------------------------------------------------------------------------------------
+int gf_tag_alignments_dev(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist,
+                          int anchor_mapq, void* d_out, size_t cap, void* d_n_out) {
+    if (!ctx || !d_n_out || (n && !d_recs) || (cap && !d_out)) return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_tag(ctx, d_recs, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n_out);
+}
+
+int gf_tag_alignments(gf_ctx* ctx, const gf_alnrec* recs, size_t n, int insert_size, int sd, int clip_dist,
+                      int anchor_mapq, gf_taghit* out, size_t cap, size_t* n_out) {
+    return tag_host(ctx, recs, n, out, cap, n_out, [&](void* d_in, void* d_out, void* d_n) {
+        return launch_tag(ctx, d_in, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n);
+    });
+}
+
+int gf_tag_low_mapq_dev(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* table, size_t n_rows, void* d_out,
+                        size_t cap, void* d_n_out) {
+    if (!ctx || !d_n_out || (n && !d_recs) || (cap && !d_out) || (n_rows && !table)) return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_low_mapq(ctx, d_recs, n, table, n_rows, d_out, cap, d_n_out);
+}
+
+int gf_tag_low_mapq(gf_ctx* ctx, const gf_alnrec* recs, size_t n, const gf_dpos* table, size_t n_rows, gf_taghit* out,
+                    size_t cap, size_t* n_out) {
+    if (n_rows && !table) return GF_E_INVAL;
+    return tag_host(ctx, recs, n, out, cap, n_out, [&](void* d_in, void* d_out, void* d_n) {
+        return launch_low_mapq(ctx, d_in, n, table, n_rows, d_out, cap, d_n);
+    });
+}
+
+// ---- memory + timing helpers -------------------------------------------------------------------------
+int gf_dev_alloc(gf_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return GF_OK;
+}
+int gf_dev_free(gf_ctx* ctx, void* d_ptr) {
+    if (!ctx) return GF_E_INVAL;
+    if (d_ptr) GF_HIP(ctx, hipFree(d_ptr));
+    return GF_OK;
+}
+int gf_memcpy_h2d(gf_ctx* ctx, void* d, const void* h, size_t bytes) {
+    if (!ctx) return GF_E_INVAL;
+    GF_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GF_OK;
+}
+int gf_memcpy_d2h(gf_ctx* ctx, void* h, const void* d, size_t bytes) {
+    if (!ctx) return GF_E_INVAL;
+    GF_HIP(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GF_OK;
+}
+int gf_memset_dev(gf_ctx* ctx, void* d, int value, size_t bytes) {
+    if (!ctx) return GF_E_INVAL;
+    GF_HIP(ctx, hipMemsetAsync(d, value, bytes, ctx->stream));
+    return GF_OK;
+}
+
+int gf_timing_enable(gf_ctx* ctx, int on) {
+    if (!ctx) return GF_E_INVAL;
+    ctx->timing = on != 0;
+    return GF_OK;
+}
+int gf_timing_reset(gf_ctx* ctx) {
+    if (!ctx) return GF_E_INVAL;
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_timing(ctx);
+    for (int i = 0; i < N_KERNEL_SLOTS; ++i) { ctx->t_total[i] = 0; ctx->t_count[i] = 0; }
+    return GF_OK;
+}
+int gf_timing_read(gf_ctx* ctx, int which, double* total_ms, uint64_t* launches) {
+    if (!ctx || which < 0 || which >= N_KERNEL_SLOTS) return GF_E_INVAL;
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timing(ctx);
+    if (total_ms) *total_ms = ctx->t_total[which];
+    if (launches) *launches = ctx->t_count[which];
+    return GF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// gf_internal.hpp — context and launch plumbing shared by the translation units of libgapfill_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gapfill_hip.h"
+#include "kmer_dev.hpp"
+
+namespace gf {
+
+constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
+constexpr int TILE_READS = 256;  // reads staged per workgroup pass of the screen filter
+constexpr int N_KERNEL_SLOTS = 8;
+
+// flank k-mer index for one k: three levels, all read-only on the device
+struct FlankIndex {
+    int k = 0;
+    int stride = 0;          // distance between probed 16-mers of a read (= k-15)
+    // level 1: bitmap over hashed canonical 16-mers (L2-resident filter)
+    int bm_log2 = 0;
+    uint32_t* d_bitmap = nullptr;
+    // level 2: exact set of canonical 16-mers (open addressing, EMPTY32)
+    int s_log2 = 0;
+    uint32_t* d_sset = nullptr;
+    // level 3: canonical k-mer -> gap, one slot per (k-mer, gap) pair
+    int t_log2 = 0;
+    uint64_t* d_thi = nullptr;
+    uint64_t* d_tlo = nullptr;   // only for k > 32
+    uint32_t* d_tgap = nullptr;  // EMPTY32 = free slot
+    size_t n_kmers = 0, n_s16 = 0;
+    uint32_t max_gaps_per_kmer = 0;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+    int which;
+};
+
+}  // namespace gf
+
+struct gf_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int n_cu = 256;
+
+    // gaps
+    std::vector<gf_gap> gaps;
+    uint32_t n_scaffolds = 0;
+    std::vector<std::string> flank_left, flank_right;
+    gf_gap* d_gaps = nullptr;           // sorted as given (grouped by scaffold, ascending start)
+    uint32_t* d_scaf_off = nullptr;     // n_scaffolds+1 offsets into d_gaps
+    std::map<int, gf::FlankIndex> index;  // by k
+    uint32_t max_gaps_per_kmer = 0;     // 0 = unlimited
+    int bitmap_log2_override = 0;
+
+    // scratch
+    gf::DevBuf cand, counters, stage_in, stage_out, stage_aux, table;
+    // timing
+    bool timing = false;
+    std::vector<gf::TimedLaunch> launches;
+    double t_total[gf::N_KERNEL_SLOTS] = {0};
+    uint64_t t_count[gf::N_KERNEL_SLOTS] = {0};
+};
+
+namespace gf {
+
+int set_hip_error(gf_ctx* ctx, hipError_t e, const char* what);
+int ensure(gf_ctx* ctx, DevBuf& b, size_t bytes);
+
+#define GF_HIP(ctx, call)                                          \
+    do {                                                           \
+        hipError_t e__ = (call);                                   \
+        if (e__ != hipSuccess) return gf::set_hip_error(ctx, e__, #call); \
+    } while (0)
+
+struct LaunchTimer {
+    gf_ctx* ctx;
+    int which;
+    hipEvent_t a = nullptr, b = nullptr;
+    LaunchTimer(gf_ctx* c, int w) : ctx(c), which(w) {
+        if (ctx->timing) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~LaunchTimer() {
+        if (a) {
+            (void)hipEventRecord(b, ctx->stream);
+            ctx->launches.push_back({a, b, which});
+        }
+    }
+};
+
+// index.cpp
+int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out);
+void free_flank_index(gf_ctx* ctx, FlankIndex& ix);
+
+// screen.hip
+int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const void* d_nmask, size_t n_reads,
+                  int read_len, int min_hits, void* d_out, size_t cap, void* d_n_out);
+// tagger.hip
+int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist, int anchor_mapq,
+               void* d_out, size_t cap, void* d_n_out);
+int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* table, size_t n_rows, void* d_out,
+                    size_t cap, void* d_n_out);
+
+}  // namespace gf

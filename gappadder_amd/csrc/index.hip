@@ -1,0 +1,170 @@
+// index.hip — host-side construction of the flank k-mer index (canonical k-mer extract/hash of the flanking
+// contigs, north_star) and its upload.  Flank sequences are tiny (2 x 295 bp per gap: gnrt_pos_true_seqs.py:94-99),
+// so this runs on the host once per k; the read side is what the GPU streams.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "gf_internal.hpp"
+
+namespace gf {
+
+namespace {
+
+struct Entry {
+    K128 key;
+    uint32_t gap;
+};
+
+inline bool is_acgt(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+
+int ceil_log2(size_t v) {
+    int l = 0;
+    while (((size_t)1 << l) < v) ++l;
+    return l;
+}
+
+// canonical k-mers (and canonical 16-mers inside them) of one flank; k-mers touching a non-ACGT byte are skipped
+void extract(const std::string& s, int k, uint32_t gap, std::vector<Entry>& kmers, std::vector<uint32_t>& s16) {
+    const int n = (int)s.size();
+    int run = 0;  // length of the current ACGT run ending at i
+    for (int i = 0; i < n; ++i) {
+        run = is_acgt(s[i]) ? run + 1 : 0;
+        if (run >= k) {
+            K128 f{0, 0};
+            const int p = i - k + 1;
+            for (int j = 0; j < k; ++j) {
+                uint64_t c = base_code(s[p + j]);
+                if (j < 32) f.hi |= c << (62 - 2 * j);
+                else f.lo |= c << (62 - 2 * (j - 32));
+            }
+            kmers.push_back({canonical(f, k), gap});
+        }
+    }
+    // 16-mers: every 16-mer fully inside a maximal ACGT run of length >= k
+    int i = 0;
+    while (i < n) {
+        if (!is_acgt(s[i])) { ++i; continue; }
+        int j = i;
+        while (j < n && is_acgt(s[j])) ++j;
+        if (j - i >= k) {
+            uint32_t w = 0;
+            for (int q = i; q < j; ++q) {
+                w = (w << 2) | base_code(s[q]);
+                if (q - i + 1 >= 16) s16.push_back(canon16(w));
+            }
+        }
+        i = j;
+    }
+}
+
+}  // namespace
+
+void free_flank_index(gf_ctx*, FlankIndex& ix) {
+    if (ix.d_bitmap) (void)hipFree(ix.d_bitmap);
+    if (ix.d_sset) (void)hipFree(ix.d_sset);
+    if (ix.d_thi) (void)hipFree(ix.d_thi);
+    if (ix.d_tlo) (void)hipFree(ix.d_tlo);
+    if (ix.d_tgap) (void)hipFree(ix.d_tgap);
+    ix = FlankIndex();
+}
+
+int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
+    auto it = ctx->index.find(k);
+    if (it != ctx->index.end() && it->second.max_gaps_per_kmer == ctx->max_gaps_per_kmer) {
+        *out = &it->second;
+        return GF_OK;
+    }
+    if (it != ctx->index.end()) {
+        free_flank_index(ctx, it->second);
+        ctx->index.erase(it);
+    }
+    if (k < 16 || k > 64) return GF_E_UNSUPPORTED;
+
+    std::vector<Entry> ent;
+    std::vector<uint32_t> s16;
+    const size_t ng = ctx->gaps.size();
+    ent.reserve(ng * 600);
+    for (size_t g = 0; g < ng; ++g) {
+        extract(ctx->flank_left[g], k, (uint32_t)g, ent, s16);
+        extract(ctx->flank_right[g], k, (uint32_t)g, ent, s16);
+    }
+    std::sort(ent.begin(), ent.end(), [](const Entry& a, const Entry& b) {
+        return a.key < b.key || (a.key == b.key && a.gap < b.gap);
+    });
+    ent.erase(std::unique(ent.begin(), ent.end(), [](const Entry& a, const Entry& b) { return a.key == b.key && a.gap == b.gap; }),
+              ent.end());
+    if (ctx->max_gaps_per_kmer) {  // drop k-mers shared by more than max_gaps_per_kmer gaps (repeat mask)
+        std::vector<Entry> kept;
+        kept.reserve(ent.size());
+        size_t i = 0;
+        while (i < ent.size()) {
+            size_t j = i;
+            while (j < ent.size() && ent[j].key == ent[i].key) ++j;
+            if (j - i <= ctx->max_gaps_per_kmer) kept.insert(kept.end(), ent.begin() + i, ent.begin() + j);
+            i = j;
+        }
+        ent.swap(kept);
+    }
+    std::sort(s16.begin(), s16.end());
+    s16.erase(std::unique(s16.begin(), s16.end()), s16.end());
+
+    FlankIndex ix;
+    ix.k = k;
+    ix.stride = k - 15;
+    ix.n_kmers = ent.size();
+    ix.n_s16 = s16.size();
+    ix.max_gaps_per_kmer = ctx->max_gaps_per_kmer;
+
+    // level 3 table
+    ix.t_log2 = std::max(8, ceil_log2(2 * ent.size() + 2));
+    const size_t tcap = (size_t)1 << ix.t_log2;
+    std::vector<uint64_t> thi(tcap, 0), tlo(k > 32 ? tcap : 0, 0);
+    std::vector<uint32_t> tgap(tcap, EMPTY32);
+    for (const Entry& e : ent) {
+        uint32_t s = hash_kmer(e.key, ix.t_log2);
+        while (tgap[s] != EMPTY32) s = (s + 1) & (tcap - 1);
+        thi[s] = e.key.hi;
+        if (k > 32) tlo[s] = e.key.lo;
+        tgap[s] = e.gap;
+    }
+    // level 2 set
+    ix.s_log2 = std::max(8, ceil_log2(2 * s16.size() + 2));
+    const size_t scap = (size_t)1 << ix.s_log2;
+    std::vector<uint32_t> sset(scap, EMPTY32);
+    for (uint32_t key : s16) {
+        uint32_t s = hash_s16_set(key, ix.s_log2);
+        while (sset[s] != EMPTY32) s = (s + 1) & (scap - 1);
+        sset[s] = key;
+    }
+    // level 1 bitmap: ~32 bits per key keeps the per-probe false-positive rate near 3 %
+    int bl = ceil_log2(32 * s16.size() + 1);
+    bl = std::min(30, std::max(15, bl));
+    if (ctx->bitmap_log2_override) bl = std::min(31, std::max(10, ctx->bitmap_log2_override));
+    ix.bm_log2 = bl;
+    const size_t bwords = ((size_t)1 << bl) / 32;
+    std::vector<uint32_t> bm(bwords, 0);
+    for (uint32_t key : s16) {
+        uint32_t h = hash_s16_bitmap(key, bl);
+        bm[h >> 5] |= 1u << (h & 31);
+    }
+
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_bitmap, bwords * 4));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_sset, scap * 4));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_thi, tcap * 8));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_tgap, tcap * 4));
+    GF_HIP(ctx, hipMemcpy(ix.d_bitmap, bm.data(), bwords * 4, hipMemcpyHostToDevice));
+    GF_HIP(ctx, hipMemcpy(ix.d_sset, sset.data(), scap * 4, hipMemcpyHostToDevice));
+    GF_HIP(ctx, hipMemcpy(ix.d_thi, thi.data(), tcap * 8, hipMemcpyHostToDevice));
+    GF_HIP(ctx, hipMemcpy(ix.d_tgap, tgap.data(), tcap * 4, hipMemcpyHostToDevice));
+    if (k > 32) {
+        GF_HIP(ctx, hipMalloc((void**)&ix.d_tlo, tcap * 8));
+        GF_HIP(ctx, hipMemcpy(ix.d_tlo, tlo.data(), tcap * 8, hipMemcpyHostToDevice));
+    }
+    auto ins = ctx->index.emplace(k, ix);
+    *out = &ins.first->second;
+    return GF_OK;
+}
+
+}  // namespace gf

@@ -1,0 +1,120 @@
+"""Host-side object over the C ABI (include/gapfill_hip.h): numpy in, numpy out, HIP underneath."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as B
+
+
+class GapFill:
+    """One context per device (gf_init / gf_destroy)."""
+
+    def __init__(self, device=0):
+        self._L = B.lib()
+        h = C.c_void_p()
+        rc = self._L.gf_init(int(device), C.byref(h))
+        if rc:
+            raise B.GapFillError(rc, "gf_init(device=%d)" % device)
+        self._h = h
+        self.n_gaps = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gf_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, rc, what):
+        if rc:
+            raise B.GapFillError(rc, what, self._L.gf_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_option(self, name, value):
+        self._chk(self._L.gf_set_option(self._h, name.encode(), int(value)), "gf_set_option")
+
+    def set_gaps(self, gaps, n_scaffolds, flanks=None):
+        """gaps: structured array (B.GAP); flanks: list of (left, right) ASCII strings or None."""
+        gaps = np.ascontiguousarray(gaps, dtype=B.GAP)
+        if flanks is not None:
+            parts, off = [], [0]
+            for l, r in flanks:
+                for s in (l, r):
+                    parts.append(s)
+                    off.append(off[-1] + len(s))
+            blob = "".join(parts).encode()
+            offs = np.asarray(off, dtype=np.uint64)
+            rc = self._L.gf_set_gaps(self._h, B._p(gaps), len(gaps), int(n_scaffolds), blob, B._p(offs))
+        else:
+            rc = self._L.gf_set_gaps(self._h, B._p(gaps), len(gaps), int(n_scaffolds), None, None)
+        self._chk(rc, "gf_set_gaps")
+        self.n_gaps = len(gaps)
+
+    @staticmethod
+    def pack_reads(seqs, read_len, with_mask=False):
+        """seqs: list of equal-length str/bytes or one bytes blob.  Returns (packed uint8 [n, rb], n_mask or None)."""
+        L = B.lib()
+        blob = seqs if isinstance(seqs, (bytes, bytearray)) else "".join(seqs).encode()
+        n = len(blob) // read_len
+        assert n * read_len == len(blob)
+        rb = L.gf_packed_read_bytes(read_len)
+        packed = np.zeros((n, rb), dtype=np.uint8)
+        nm = np.zeros((n, (read_len + 31) // 32), dtype=np.uint32) if with_mask else None
+        rc = L.gf_pack_reads(bytes(blob), n, read_len, B._p(packed), B._p(nm))
+        if rc:
+            raise B.GapFillError(rc, "gf_pack_reads")
+        return packed, nm
+
+    def _grow(self, call, dtype, cap):
+        while True:
+            out = np.zeros(max(cap, 1), dtype=dtype)
+            n = C.c_size_t(0)
+            rc = call(out, len(out), n)
+            if rc == B.GF_E_NOSPACE:
+                cap = n.value
+                continue
+            return rc, out[:n.value]
+
+    def screen_reads(self, packed, read_len, k, min_hits=1, n_mask=None, cap=None):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        n = packed.shape[0] if packed.ndim == 2 else packed.size // B.lib().gf_packed_read_bytes(read_len)
+        if n_mask is not None:
+            n_mask = np.ascontiguousarray(n_mask, dtype=np.uint32)
+        rc, out = self._grow(lambda o, c, cnt: self._L.gf_screen_reads(self._h, B._p(packed), B._p(n_mask), n, read_len, k,
+                                                                        min_hits, B._p(o), c, C.byref(cnt)),
+                             B.HIT, cap if cap is not None else max(1024, n // 16))
+        self._chk(rc, "gf_screen_reads")
+        return out
+
+    def tag_alignments(self, recs, insert_size, sd, clip_dist=250, anchor_mapq=30, cap=None):
+        recs = np.ascontiguousarray(recs, dtype=B.ALNREC)
+        rc, out = self._grow(lambda o, c, cnt: self._L.gf_tag_alignments(self._h, B._p(recs), len(recs), insert_size, sd,
+                                                                          clip_dist, anchor_mapq, B._p(o), c, C.byref(cnt)),
+                             B.TAGHIT, cap if cap is not None else max(1024, len(recs) // 8))
+        self._chk(rc, "gf_tag_alignments")
+        return out
+
+    def tag_low_mapq(self, recs, table, cap=None):
+        recs = np.ascontiguousarray(recs, dtype=B.ALNREC)
+        table = np.ascontiguousarray(table, dtype=B.DPOS)
+        rc, out = self._grow(lambda o, c, cnt: self._L.gf_tag_low_mapq(self._h, B._p(recs), len(recs), B._p(table), len(table),
+                                                                        B._p(o), c, C.byref(cnt)),
+                             B.TAGHIT, cap if cap is not None else max(1024, len(recs) // 8))
+        self._chk(rc, "gf_tag_low_mapq")
+        return out
+
+    # ---- timing -------------------------------------------------------------------------------------
+    def timing(self, on=True):
+        self._chk(self._L.gf_timing_enable(self._h, 1 if on else 0), "gf_timing_enable")
+        self._chk(self._L.gf_timing_reset(self._h), "gf_timing_reset")
+
+    def kernel_time(self, which):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._chk(self._L.gf_timing_read(self._h, which, C.byref(ms), C.byref(n)), "gf_timing_read")
+        return ms.value, n.value
+
+    def sync(self):
+        self._chk(self._L.gf_sync(self._h), "gf_sync")

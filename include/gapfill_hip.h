@@ -1,0 +1,158 @@
+/* gapfill_hip.h — C ABI of libgapfill_hip.so: the MI355X (gfx950) implementation of GAPPadder's
+ * read-recruitment + per-gap local-assembly hot path.
+ *
+ * The reference (simoncchu/GAPPadder) has no FFI for this path; its seams are process + file contracts
+ * (SURVEY.md §8b).  Each entry point below names the reference interface whose arithmetic it replaces
+ * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions: return 0 (GF_OK) or a negative GF_E_* code; never throws, never exits.  The caller owns
+ * every buffer.  Plain entry points take HOST pointers and stage through HBM; the *_dev entry points take
+ * DEVICE pointers, enqueue on the context's stream and do not synchronise (they are what bench.py times
+ * with inputs already resident in HBM).  Output goes into caller-provided capacity; on overflow the call
+ * returns GF_E_NOSPACE and *n_out holds the required element count.  One gf_ctx per device; a ctx is not
+ * thread-safe; different ctxs may be driven from different threads/processes.
+ */
+#ifndef GAPFILL_HIP_H
+#define GAPFILL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_OK 0
+#define GF_E_INVAL (-1)    /* bad argument */
+#define GF_E_NODEV (-2)    /* no usable HIP device / HIP runtime error (see gf_last_error) */
+#define GF_E_NOMEM (-3)    /* host or device allocation failed */
+#define GF_E_NOSPACE (-4)  /* output capacity too small; *n_out = required count */
+#define GF_E_STATE (-5)    /* call order violated (e.g. screen before gf_set_gaps) */
+#define GF_E_UNSUPPORTED (-6)
+
+typedef struct gf_ctx gf_ctx;
+
+/* One gap of the draft (one line of gap_positions.txt: gnrt_pos_true_seqs.py:54).  Gaps are passed grouped
+ * by scaffold in file order; idx_in_scaffold is the reference's 1-based per-scaffold counter
+ * (collect_reads_for_gaps.py:34-63, merge_reads.py:27-41). */
+typedef struct {
+    uint32_t scaffold;        /* index of the scaffold in the .fai (0-based) */
+    uint32_t start;           /* 0-based position of the first N */
+    uint32_t end;             /* position of the first upper-case ACGT after the run */
+    uint32_t idx_in_scaffold; /* 1-based */
+} gf_gap;
+
+/* One alignment record = the 9 SAM columns the reference reads (collect_reads_for_gaps.py:76-91),
+ * decoded: 32 bytes. */
+typedef struct {
+    uint32_t pos;      /* SAM POS (1-based, un-shifted as the reference uses it) */
+    uint32_t mate_pos; /* SAM PNEXT */
+    int32_t tlen;      /* SAM TLEN */
+    uint32_t ref;      /* RNAME as .fai index; 0xFFFFFFFF for '*' */
+    uint32_t mate_ref; /* RNEXT as .fai index ('=' -> same value as ref); 0xFFFFFFFF for '*' */
+    uint16_t flag;     /* SAM FLAG */
+    uint8_t mapq;      /* SAM MAPQ */
+    uint8_t clipflag;  /* GapReadsCollector.is_clipped(CIGAR): +2 right S/H, +1 left S/H (:13-26) */
+    uint64_t read;     /* caller's read id: 2*pair + (mate number - 1) */
+} gf_alnrec;
+
+/* kinds of a tagger hit = the 4th column of the reference's list lines */
+#define GF_KIND_CLIP 0       /* collect_reads_for_gaps.py:119-123  -> the read's OWN left/right list */
+#define GF_KIND_DISCORDANT 1 /* :126-150                           -> the MATE's list */
+#define GF_KIND_UNMAP 2      /* :153-159                           -> the MATE's list */
+#define GF_KIND_LOWMAPQ 3    /* collect_discordant_low_mapq_reads.py:74-79 -> the read's OWN list */
+
+typedef struct {
+    uint32_t rec;  /* index of the record in the batch */
+    uint32_t gap;  /* gf_tag_alignments: index into the gf_set_gaps array; gf_tag_low_mapq: row of the table */
+    uint16_t kind; /* GF_KIND_* */
+    uint16_t to_mate; /* 1: the line goes to the list of the read's mate, 0: to its own list */
+} gf_taghit;
+
+/* One row of discordant_reads_pos.txt.sorted.txt (run_multi_threads_discordant.py:87-103). */
+typedef struct {
+    uint32_t mate_scaffold; /* scaffold index the discordant mate maps to */
+    uint32_t mate_pos;
+    uint32_t src_scaffold;
+    uint32_t src_gap;       /* 1-based gap index inside src_scaffold */
+} gf_dpos;
+
+typedef struct {
+    uint32_t gap;  /* index into the gf_set_gaps array */
+    uint32_t read; /* index of the read in the batch */
+} gf_hit;
+
+/* ---- context ------------------------------------------------------------------------------------- */
+int gf_init(int device_ordinal, gf_ctx** out);
+void gf_destroy(gf_ctx* ctx);
+const char* gf_strerror(int code);
+const char* gf_last_error(gf_ctx* ctx);       /* text of the last HIP error seen by this ctx */
+int gf_set_stream(gf_ctx* ctx, void* hip_stream); /* adopt a caller's hipStream_t (NULL: back to the ctx's own) */
+int gf_sync(gf_ctx* ctx);
+/* options: "max_gaps_per_kmer" (0 = unlimited; flank k-mers shared by more gaps are dropped from the index),
+ * "bitmap_log2" (size of the screen's 16-mer filter bitmap, 0 = automatic). */
+int gf_set_option(gf_ctx* ctx, const char* name, long value);
+
+/* ---- gaps + flanks (gnrt_pos_true_seqs.py:12-100 defines them; host-side there and here) ----------- */
+/* flank_ascii: concatenated flank sequences, left then right per gap; flank_off[2*g], [2*g+1], ... are the
+ * start offsets, flank_off[2*n_gaps] the total length.  Bases other than upper-case ACGT break k-mers. */
+int gf_set_gaps(gf_ctx* ctx, const gf_gap* gaps, size_t n_gaps, uint32_t n_scaffolds,
+                const char* flank_ascii, const uint64_t* flank_off);
+
+/* ---- a-7: 2-bit packing (KmerUtils.cpp:22-58 layout: A=00 C=01 G=10 T=11, base i MSB-first) --------- */
+/* Packs n_reads fixed-length reads (ASCII, read_len bases each, contiguous) into ceil(read_len/4) bytes per
+ * read, base i in byte i/4 at bits 7-2(i%4)..6-2(i%4); non-ACGT -> A (KmerUtils.cpp:25) and, when n_mask is
+ * non-NULL, bit (i%32) of word n_mask[r*ceil(read_len/32) + i/32] is set. */
+int gf_pack_reads(const char* ascii, size_t n_reads, int read_len, uint8_t* packed, uint32_t* n_mask);
+size_t gf_packed_read_bytes(int read_len);
+
+/* ---- north-star flank-k-mer screen ("flank-k-mer lookup to tag reads") ------------------------------
+ * Emits (gap, read) for every read that has >= min_hits k-mer positions whose canonical k-mer occurs in the
+ * gap's flank k-mer set (predicate shape of IsReadContainingFreqKmers, KmerUtils.cpp:215-241, on canonical
+ * k-mers, per gap).  16 <= k <= 64.  Host variant returns hits sorted by (gap, read). */
+int gf_screen_reads(gf_ctx* ctx, const uint8_t* packed_reads, const uint32_t* n_mask_or_null, size_t n_reads,
+                    int read_len, int k, int min_hits, gf_hit* out, size_t cap, size_t* n_out);
+/* device variant: d_out order is unspecified; *d_n_out (device u32, zeroed by the call) = hits produced. */
+int gf_screen_reads_dev(gf_ctx* ctx, const void* d_packed_reads, const void* d_n_mask_or_null, size_t n_reads,
+                        int read_len, int k, int min_hits, void* d_out, size_t cap, void* d_n_out);
+
+/* ---- a-2: alignment-record tagger (GapReadsCollector.parse_reads_fall_in_gaps_one_scaffold[_short_is],
+ * collect_reads_for_gaps.py:68-263; mode switch at IS >= 750, :275).  Host variant: sorted by
+ * (rec, gap, kind). */
+int gf_tag_alignments(gf_ctx* ctx, const gf_alnrec* recs, size_t n, int insert_size, int sd, int clip_dist,
+                      int anchor_mapq, gf_taghit* out, size_t cap, size_t* n_out);
+int gf_tag_alignments_dev(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist,
+                          int anchor_mapq, void* d_out, size_t cap, void* d_n_out);
+
+/* ---- a-3: second hop (collect_discordant_low_mapq_reads.py:4-84).  table = rows sorted by
+ * (mate_scaffold, mate_pos, src_scaffold, src_gap), duplicates kept; a MAPQ==0 record at POS p on scaffold s
+ * is linked to the LAST position q of s with q-199 <= p <= q+299 and emits one hit per row of q
+ * (hit.gap = row index).  Host variant: sorted by (rec, row). */
+int gf_tag_low_mapq(gf_ctx* ctx, const gf_alnrec* recs, size_t n, const gf_dpos* table, size_t n_rows,
+                    gf_taghit* out, size_t cap, size_t* n_out);
+int gf_tag_low_mapq_dev(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* table, size_t n_rows,
+                        void* d_out, size_t cap, void* d_n_out);
+
+/* ---- device memory + timing helpers (so a ctypes host needs no other HIP binding) ---------------------- */
+int gf_dev_alloc(gf_ctx* ctx, size_t bytes, void** d_ptr);
+int gf_dev_free(gf_ctx* ctx, void* d_ptr);
+int gf_memcpy_h2d(gf_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int gf_memcpy_d2h(gf_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int gf_memset_dev(gf_ctx* ctx, void* d_ptr, int value, size_t bytes);
+/* per-kernel HIP-event timing on the ctx's stream: enable, run, gf_sync, then read totals. */
+#define GF_KERNEL_SCREEN 0
+#define GF_KERNEL_TAG 1
+#define GF_KERNEL_LOWMAPQ 2
+#define GF_KERNEL_ASSEMBLE 3
+#define GF_KERNEL_POOL 4
+#define GF_KERNEL_SYNTH 5
+#define GF_KERNEL_COUNT 6
+#define GF_KERNEL_VERIFY 7  /* second kernel of the screen: exact per-candidate verification */
+int gf_timing_enable(gf_ctx* ctx, int on);
+int gf_timing_read(gf_ctx* ctx, int which, double* total_ms, uint64_t* launches);
+int gf_timing_reset(gf_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAPFILL_HIP_H */

@@ -1,0 +1,94 @@
+"""TEST INFRASTRUCTURE — ctypes loader of oracle/liboracle.so (gp_oracle.c).  tests/, smoke() and bench.py's
+cpu_baseline leg only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+GAP = np.dtype([("scaffold", "<u4"), ("start", "<u4"), ("end", "<u4"), ("idx_in_scaffold", "<u4")])
+ALNREC = np.dtype([("pos", "<u4"), ("mate_pos", "<u4"), ("tlen", "<i4"), ("ref", "<u4"), ("mate_ref", "<u4"),
+                   ("flag", "<u2"), ("mapq", "u1"), ("clipflag", "u1"), ("read", "<u8")])
+TAGHIT = np.dtype([("rec", "<u4"), ("gap", "<u4"), ("kind", "<u2"), ("to_mate", "<u2")])
+DPOS = np.dtype([("mate_scaffold", "<u4"), ("mate_pos", "<u4"), ("src_scaffold", "<u4"), ("src_gap", "<u4")])
+HIT = np.dtype([("gap", "<u4"), ("read", "<u4")])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = [os.path.join(_HERE, f) for f in ("gp_oracle.c", "gp_oracle.h")]
+        if not os.path.exists(_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_PATH) for s in src):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+        L = C.CDLL(_PATH)
+        vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
+        L.or_tag_alignments.restype = sz
+        L.or_tag_alignments.argtypes = [vp, sz, vp, sz, i32, i32, i32, i32, vp, sz]
+        L.or_tag_low_mapq.restype = sz
+        L.or_tag_low_mapq.argtypes = [vp, sz, vp, sz, vp, sz]
+        L.or_screen_reads.restype = sz
+        L.or_screen_reads.argtypes = [C.c_char_p, sz, i32, C.c_char_p, vp, sz, i32, i32, u32, vp, sz, i32]
+        L.or_pack_kmer64.restype = C.c_uint64
+        L.or_pack_kmer64.argtypes = [C.c_char_p, i32]
+        L.or_unpack_reads.restype = None
+        L.or_unpack_reads.argtypes = [vp, sz, i32, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def tag_alignments(recs, gaps, insert_size, sd, clip_dist=250, anchor_mapq=30):
+    recs = np.ascontiguousarray(recs, dtype=ALNREC)
+    gaps = np.ascontiguousarray(gaps, dtype=GAP)
+    cap = max(1024, 4 * len(recs))
+    out = np.zeros(cap, dtype=TAGHIT)
+    n = lib().or_tag_alignments(_p(recs), len(recs), _p(gaps), len(gaps), insert_size, sd, clip_dist, anchor_mapq, _p(out), cap)
+    assert n <= cap
+    return out[:n]
+
+
+def tag_low_mapq(recs, table):
+    recs = np.ascontiguousarray(recs, dtype=ALNREC)
+    table = np.ascontiguousarray(table, dtype=DPOS)
+    cap = max(1024, 8 * len(recs))
+    while True:
+        out = np.zeros(cap, dtype=TAGHIT)
+        n = lib().or_tag_low_mapq(_p(recs), len(recs), _p(table), len(table), _p(out), cap)
+        if n <= cap:
+            return out[:n]
+        cap = n
+
+
+def screen_reads(reads_blob, read_len, flanks, k, min_hits=1, max_gaps_per_kmer=0, threads=0):
+    """reads_blob: bytes of n*read_len ASCII bases; flanks: [(left, right)]."""
+    n = len(reads_blob) // read_len
+    parts, off = [], [0]
+    for l, r in flanks:
+        for s in (l, r):
+            parts.append(s)
+            off.append(off[-1] + len(s))
+    fblob = "".join(parts).encode()
+    offs = np.asarray(off, dtype=np.uint64)
+    cap = max(1024, n)
+    while True:
+        out = np.zeros(cap, dtype=HIT)
+        cnt = lib().or_screen_reads(bytes(reads_blob), n, read_len, fblob, _p(offs), len(flanks), k, min_hits,
+                                    max_gaps_per_kmer, _p(out), cap, threads)
+        if cnt <= cap:
+            return out[:cnt]
+        cap = cnt
+
+
+def unpack_reads(packed, read_len):
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    n = packed.shape[0]
+    out = np.zeros(n * read_len, dtype=np.uint8)
+    lib().or_unpack_reads(_p(packed), n, read_len, _p(out))
+    return out.tobytes()

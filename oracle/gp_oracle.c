@@ -1,0 +1,192 @@
+/* TEST INFRASTRUCTURE — see gp_oracle.h.  Each function cites the reference file:line it restates
+ * (paths relative to /root/reference). */
+#include "gp_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ a-7: KmerUtils layout */
+static inline unsigned code_of(char c) { /* KmerUtils.cpp:25-41: non-CGT -> A */
+    return (c == 'C' || c == 'c') ? 1u : (c == 'G' || c == 'g') ? 2u : (c == 'T' || c == 't') ? 3u : 0u;
+}
+
+uint64_t or_pack_kmer64(const char* seq, int k) { /* KmerUtils.cpp:61-69 */
+    uint64_t v = 0;
+    for (int i = 0; i < k; ++i) v |= (uint64_t)code_of(seq[i]) << (62 - 2 * i);
+    return v;
+}
+
+void or_unpack_reads(const uint8_t* packed, size_t n_reads, int read_len, char* ascii) {
+    size_t rb = (size_t)(read_len + 3) / 4;
+    for (size_t r = 0; r < n_reads; ++r)
+        for (int i = 0; i < read_len; ++i)
+            ascii[r * read_len + i] = "ACGT"[(packed[r * rb + (i >> 2)] >> (6 - 2 * (i & 3))) & 3];
+}
+
+/* ------------------------------------------------------------------ a-2: tagger */
+static int put(or_taghit* out, size_t cap, size_t* n, uint32_t rec, uint32_t gap, int kind, int to_mate) {
+    if (*n < cap) { out[*n].rec = rec; out[*n].gap = gap; out[*n].kind = (uint16_t)kind; out[*n].to_mate = (uint16_t)to_mate; }
+    ++*n;
+    return 0;
+}
+
+size_t or_tag_alignments(const or_alnrec* recs, size_t n, const or_gap* gaps, size_t n_gaps, int insert_size, int sd,
+                         int clip_dist, int anchor_mapq, or_taghit* out, size_t cap) {
+    const long dist1 = insert_size - 3L * sd, dist2 = insert_size + 3L * sd; /* collect_reads_for_gaps.py:5-6 */
+    const int short_is = insert_size < 750;                                  /* :275 */
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const or_alnrec* r = &recs[i];
+        for (size_t g = 0; g < n_gaps; ++g) { /* every gap of the record's scaffold (:36-63) */
+            if (gaps[g].scaffold != r->ref) continue;
+            const long start = gaps[g].start, end = gaps[g].end, pos = r->pos;
+            int tag = -1; /* 0:0c 1:0d 2:1c 3:1d */
+            /* focal_region keys start-i, i in range(dist2), start-i >= 0 (:47-55); end+i (:57-62) */
+            if (start - pos >= 0 && start - pos < dist2 && pos >= 0) tag = (start - pos) <= clip_dist ? 0 : 1;
+            else if (pos - end >= 0 && pos - end < dist2) tag = (pos - end) <= clip_dist ? 2 : 3;
+            if (tag < 0) continue;
+            if ((tag == 0 && r->clipflag >= 2) || (tag == 2 && (r->clipflag == 1 || r->clipflag == 3))) /* :119 */
+                put(out, cap, &cnt, (uint32_t)i, (uint32_t)g, 0, 0);
+            if ((r->flag & 0x4) == 0 && (r->flag & 0x8) == 0 && (int)r->mapq >= anchor_mapq) { /* :126 */
+                if (r->mate_ref != r->ref) put(out, cap, &cnt, (uint32_t)i, (uint32_t)g, 1, 1); /* :127-133 */
+                else {
+                    long t = r->tlen < 0 ? -(long)r->tlen : (long)r->tlen;
+                    if (t >= dist2 || (short_is && t <= dist1)) put(out, cap, &cnt, (uint32_t)i, (uint32_t)g, 1, 1); /* :143 / :243 */
+                }
+            } else if ((r->flag & 0x4) == 0 && (r->flag & 0x8) != 0) { /* :153 */
+                put(out, cap, &cnt, (uint32_t)i, (uint32_t)g, 2, 1);
+            }
+        }
+    }
+    return cnt;
+}
+
+/* ------------------------------------------------------------------ a-3: second hop */
+size_t or_tag_low_mapq(const or_alnrec* recs, size_t n, const or_dpos* table, size_t n_rows, or_taghit* out, size_t cap) {
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const or_alnrec* r = &recs[i];
+        if (r->mapq > 0) continue; /* collect_discordant_low_mapq_reads.py:52 */
+        /* focal_region[p] = last q in file order with q-199 <= p <= q+299 (:21-25) */
+        long best = -1;
+        for (size_t t = 0; t < n_rows; ++t) {
+            if (table[t].mate_scaffold != r->ref) continue;
+            long q = table[t].mate_pos, p = r->pos;
+            if (q - 199 <= p && p <= q + 299) best = q; /* later rows overwrite */
+        }
+        if (best < 0) continue;
+        for (size_t t = 0; t < n_rows; ++t) /* m_pos_gaps[q]: every row of q, duplicates kept (:15-19) */
+            if (table[t].mate_scaffold == r->ref && (long)table[t].mate_pos == best)
+                put(out, cap, &cnt, (uint32_t)i, (uint32_t)t, 3, 0);
+    }
+    return cnt;
+}
+
+/* ------------------------------------------------------------------ north-star screen */
+typedef struct { uint64_t hi, lo; uint32_t gap; } kent;
+
+static int kent_cmp(const void* a, const void* b) {
+    const kent *x = a, *y = b;
+    if (x->hi != y->hi) return x->hi < y->hi ? -1 : 1;
+    if (x->lo != y->lo) return x->lo < y->lo ? -1 : 1;
+    if (x->gap != y->gap) return x->gap < y->gap ? -1 : 1;
+    return 0;
+}
+
+/* canonical left-aligned 128-bit k-mer of seq[0..k); returns 0 if a non-ACGT (upper-case) byte occurs */
+static int canon_kmer(const char* s, int k, uint64_t* hi, uint64_t* lo) {
+    uint64_t fh = 0, fl = 0, rh = 0, rl = 0;
+    for (int i = 0; i < k; ++i) {
+        char c = s[i];
+        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) return 0;
+        uint64_t f = code_of(c), r = 3 - code_of(s[k - 1 - i]);
+        if (i < 32) { fh |= f << (62 - 2 * i); rh |= r << (62 - 2 * i); }
+        else { fl |= f << (62 - 2 * (i - 32)); rl |= r << (62 - 2 * (i - 32)); }
+    }
+    if (rh < fh || (rh == fh && rl < fl)) { *hi = rh; *lo = rl; } else { *hi = fh; *lo = fl; }
+    return 1;
+}
+
+static int hit_cmp(const void* a, const void* b) {
+    const or_hit *x = a, *y = b;
+    if (x->gap != y->gap) return x->gap < y->gap ? -1 : 1;
+    if (x->read != y->read) return x->read < y->read ? -1 : 1;
+    return 0;
+}
+
+size_t or_screen_reads(const char* reads, size_t n_reads, int L, const char* flank, const uint64_t* foff, size_t n_gaps,
+                       int k, int min_hits, uint32_t max_occ, or_hit* out, size_t cap, int threads) {
+    /* flank k-mer set per gap: canonical k-mers of left+right flank, k-mers with non-ACGT skipped */
+    size_t total = 0;
+    for (size_t g = 0; g < 2 * n_gaps; ++g) { uint64_t len = foff[g + 1] - foff[g]; if (len >= (uint64_t)k) total += len - k + 1; }
+    kent* tab = malloc((total + 1) * sizeof(kent));
+    size_t nt = 0;
+    for (size_t g = 0; g < n_gaps; ++g)
+        for (int side = 0; side < 2; ++side) {
+            const char* s = flank + foff[2 * g + side];
+            long len = (long)(foff[2 * g + side + 1] - foff[2 * g + side]);
+            for (long p = 0; p + k <= len; ++p)
+                if (canon_kmer(s + p, k, &tab[nt].hi, &tab[nt].lo)) tab[nt++].gap = (uint32_t)g;
+        }
+    qsort(tab, nt, sizeof(kent), kent_cmp);
+    size_t w = 0; /* unique (k-mer, gap), then the max_occ repeat rule */
+    for (size_t i = 0; i < nt; ++i) if (i == 0 || kent_cmp(&tab[i], &tab[i - 1]) != 0) tab[w++] = tab[i];
+    nt = w;
+    if (max_occ) {
+        w = 0;
+        for (size_t i = 0; i < nt;) {
+            size_t j = i;
+            while (j < nt && tab[j].hi == tab[i].hi && tab[j].lo == tab[i].lo) ++j;
+            if (j - i <= max_occ) for (size_t t = i; t < j; ++t) tab[w++] = tab[t];
+            i = j;
+        }
+        nt = w;
+    }
+    if (min_hits < 1) min_hits = 1;
+    size_t cnt = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel
+    {
+        uint32_t* glist = malloc(sizeof(uint32_t) * 65536);
+#pragma omp for schedule(dynamic, 1024)
+        for (long r = 0; r < (long)n_reads; ++r) {
+            size_t ng = 0;
+            const char* s = reads + (size_t)r * L;
+            for (int p = 0; p + k <= L; ++p) {
+                uint64_t hi, lo;
+                if (!canon_kmer(s + p, k, &hi, &lo)) continue;
+                size_t a = 0, b = nt; /* lower bound */
+                while (a < b) {
+                    size_t m = (a + b) / 2;
+                    if (tab[m].hi < hi || (tab[m].hi == hi && tab[m].lo < lo)) a = m + 1; else b = m;
+                }
+                for (; a < nt && tab[a].hi == hi && tab[a].lo == lo && ng < 65536; ++a) glist[ng++] = tab[a].gap;
+            }
+            if (!ng) continue;
+            /* count positions per gap */
+            for (size_t i = 1; i < ng; ++i) { uint32_t v = glist[i]; size_t j = i; while (j && glist[j - 1] > v) { glist[j] = glist[j - 1]; --j; } glist[j] = v; }
+            for (size_t i = 0; i < ng;) {
+                size_t j = i;
+                while (j < ng && glist[j] == glist[i]) ++j;
+                if ((int)(j - i) >= min_hits) {
+                    size_t o;
+#pragma omp atomic capture
+                    o = cnt++;
+                    if (o < cap) { out[o].gap = glist[i]; out[o].read = (uint32_t)r; }
+                }
+                i = j;
+            }
+        }
+        free(glist);
+    }
+    free(tab);
+    qsort(out, cnt < cap ? cnt : cap, sizeof(or_hit), hit_cmp);
+    return cnt;
+}

@@ -1,0 +1,29 @@
+/* TEST INFRASTRUCTURE — C restatement (oracle) of GAPPadder's recruit + local-assembly hot path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so; the product
+ * never does.  Semantics and parity status: see the header of oracle/gp_oracle.py (a-1..a-5, a-7 pinned on
+ * reference-generated fixtures; a-6 PARITY UNPINNED).  Plain C, straightforward algorithms (sorted arrays +
+ * binary search, per-record loops over every gap) chosen to differ from the GPU implementation. */
+#ifndef GP_ORACLE_H
+#define GP_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct { uint32_t scaffold, start, end, idx_in_scaffold; } or_gap;
+typedef struct { uint32_t pos, mate_pos; int32_t tlen; uint32_t ref, mate_ref; uint16_t flag; uint8_t mapq, clipflag; uint64_t read; } or_alnrec;
+typedef struct { uint32_t rec, gap; uint16_t kind, to_mate; } or_taghit;
+typedef struct { uint32_t mate_scaffold, mate_pos, src_scaffold, src_gap; } or_dpos;
+typedef struct { uint32_t gap, read; } or_hit;
+
+/* collect_reads_for_gaps.py:68-263 on decoded records; hits in (rec, gap, kind) order. returns count (may exceed cap) */
+size_t or_tag_alignments(const or_alnrec* recs, size_t n, const or_gap* gaps, size_t n_gaps, int insert_size, int sd,
+                         int clip_dist, int anchor_mapq, or_taghit* out, size_t cap);
+/* collect_discordant_low_mapq_reads.py:4-84; table sorted; hit.gap = row index; (rec,row) order */
+size_t or_tag_low_mapq(const or_alnrec* recs, size_t n, const or_dpos* table, size_t n_rows, or_taghit* out, size_t cap);
+/* north-star screen on ASCII reads (fixed length) and ASCII flanks; hits sorted (gap, read). threads: OpenMP */
+size_t or_screen_reads(const char* reads_ascii, size_t n_reads, int read_len, const char* flank_ascii,
+                       const uint64_t* flank_off, size_t n_gaps, int k, int min_hits, uint32_t max_gaps_per_kmer,
+                       or_hit* out, size_t cap, int threads);
+/* KmerUtils.cpp:61-69 */
+uint64_t or_pack_kmer64(const char* seq, int k);
+void or_unpack_reads(const uint8_t* packed, size_t n_reads, int read_len, char* ascii);
+#endif

@@ -1,0 +1,199 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the oracle and the reference-generated
+golden fixtures.  Bit-exact (integer / index work)."""
+import numpy as np
+import pytest
+
+from golden_util import CASES, Case
+from oracle import c_oracle as CO
+from oracle import gp_oracle as O
+import records_util as RU
+import synth_small as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gf():
+    from gappadder_amd.hip_api import GapFill
+    g = GapFill(0)
+    yield g
+    g.close()
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request):
+    return Case(request.param)
+
+
+def _same(a, b):
+    return len(a) == len(b) and a.tobytes() == np.ascontiguousarray(b).astype(a.dtype).tobytes()
+
+
+# ---------------------------------------------------------------------------------- golden: tagger
+def test_tagger_equals_reference_lists(gf, case):
+    gaps = O.gap_positions(case.fasta_records(), case.meta["min_gap"])
+    garr = RU.gaps_array(case.fai_names, gaps)
+    gf.set_gaps(garr, len(case.fai_names))
+    for lib in case.libs:
+        recs, fields = RU.sam_to_records(lib["sam"], case.fai_names)
+        hits = gf.tag_alignments(recs, lib["is"], lib["sd"], case.meta["clip_dist"], case.meta["anchor_mapq"])
+        assert _same(hits, CO.tag_alignments(recs, garr, lib["is"], lib["sd"], case.meta["clip_dist"], case.meta["anchor_mapq"]))
+        got = RU.hits_to_lines(hits, recs, fields, garr, case.fai_names)
+        exp = case.exp_dir(lib["folder"] + "/scaffold_reads_list_all/")
+        for scf in set(g[3] for g in gaps):
+            for side in ("left", "right"):
+                e = exp["%s_cluster_by_gap_reads_%s.list" % (scf, side)].splitlines()
+                assert sorted(got.get(scf, {}).get(side, [])) == sorted(e), (lib["folder"], scf, side)
+
+
+def test_low_mapq_equals_reference_lists(gf, case):
+    gaps = O.gap_positions(case.fasta_records(), case.meta["min_gap"])
+    gf.set_gaps(RU.gaps_array(case.fai_names, gaps), len(case.fai_names))
+    for lib in case.libs:
+        rows = [tuple(int(x) for x in l.split()) for l in case.exp_lines(lib["folder"] + "/discordant_reads_pos.txt.sorted.txt")]
+        table = RU.dpos_array(rows)
+        recs, fields = RU.sam_to_records(lib["sam"], case.fai_names)
+        hits = gf.tag_low_mapq(recs, table)
+        assert _same(hits, CO.tag_low_mapq(recs, table))
+        got = RU.lowmapq_hits_to_lines(hits, fields, table, case.fai_names)
+        exp = case.exp_dir(lib["folder"] + "/discordant_reads_list/")
+        for name, txt in exp.items():
+            scf, side = name.rsplit("_cluster_by_discordant_reads_", 1)
+            assert got.get(scf, {}).get(side.split(".")[0], []) == txt.splitlines(), (lib["folder"], name)
+
+
+# ---------------------------------------------------------------------------------- golden inputs: screen
+@pytest.mark.parametrize("k,min_hits", [(31, 1), (41, 1), (51, 2), (30, 1), (16, 1), (64, 1)])
+def test_screen_on_golden_reads(gf, case, k, min_hits):
+    from gappadder_amd.hip_api import GapFill
+    gaps = O.gap_positions(case.fasta_records(), case.meta["min_gap"])
+    seqs = dict(case.fasta_records())
+    flanks = [O.flank_seqs(seqs[scf], s, e, case.meta["flank"]) for (s, e, _, scf) in gaps]
+    gf.set_gaps(RU.gaps_array(case.fai_names, gaps), len(case.fai_names), flanks)
+    lib = case.libs[0]
+    reads = RU.fastq_seqs(lib["fq1"]) + RU.fastq_seqs(lib["fq2"])
+    L = len(reads[0])
+    blob = "".join(reads).encode()
+    packed, _ = GapFill.pack_reads(blob, L)
+    hits = gf.screen_reads(packed, L, k, min_hits)
+    exp = CO.screen_reads(blob, L, flanks, k, min_hits)
+    assert _same(hits, exp)
+    if k <= 51:
+        assert len(exp) > 0
+
+
+# ---------------------------------------------------------------------------------- seeded synthetic, larger
+@pytest.mark.parametrize("seed,n_pairs,L,k", [(1, 30000, 150, 31), (2, 20000, 150, 41), (3, 20000, 100, 31), (4, 8000, 250, 51)])
+def test_screen_and_tagger_synthetic(gf, seed, n_pairs, L, k):
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=seed, n_pairs=n_pairs, L=L, insert=max(300, L + 100))
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    packed, _ = GapFill.pack_reads(c["reads_blob"], L)
+    hits = gf.screen_reads(packed, L, k)
+    exp = CO.screen_reads(c["reads_blob"], L, c["flanks"], k)
+    assert _same(hits, exp) and len(exp) > 100
+    for (IS, sd) in ((max(300, L + 100), 30), (5000, 500)):
+        th = gf.tag_alignments(c["recs"], IS, sd)
+        assert _same(th, CO.tag_alignments(c["recs"], c["gaps"], IS, sd))
+        assert len(th) > 50
+
+
+def test_reads_with_N_use_the_mask(gf):
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=9, n_pairs=6000, n_frac=0.3)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    packed, nm = GapFill.pack_reads(c["reads_blob"], c["L"], with_mask=True)
+    hits = gf.screen_reads(packed, c["L"], 31, 1, n_mask=nm)
+    exp = CO.screen_reads(c["reads_blob"], c["L"], c["flanks"], 31)
+    assert _same(hits, exp)
+    # without the mask N is read as A (KmerUtils.cpp:25): a superset, never a subset
+    loose = gf.screen_reads(packed, c["L"], 31, 1)
+    assert set(map(tuple, exp.tolist())) <= set(map(tuple, loose.tolist()))
+
+
+def test_max_gaps_per_kmer_rule(gf):
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=11, n_pairs=3000)
+    flanks = list(c["flanks"])
+    flanks[1] = flanks[0]          # two gaps share every flank k-mer
+    flanks[2] = (flanks[0][0], flanks[2][1])
+    gf.set_option("max_gaps_per_kmer", 2)
+    try:
+        gf.set_gaps(c["gaps"], c["n_scaffolds"], flanks)
+        packed, _ = GapFill.pack_reads(c["reads_blob"], c["L"])
+        hits = gf.screen_reads(packed, c["L"], 31)
+        assert _same(hits, CO.screen_reads(c["reads_blob"], c["L"], flanks, 31, 1, 2))
+    finally:
+        gf.set_option("max_gaps_per_kmer", 0)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], flanks)
+    packed, _ = GapFill.pack_reads(c["reads_blob"], c["L"])
+    assert _same(gf.screen_reads(packed, c["L"], 31), CO.screen_reads(c["reads_blob"], c["L"], flanks, 31))
+
+
+# ---------------------------------------------------------------------------------- edges
+def test_empty_and_ragged_inputs(gf):
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=5, n_pairs=700)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    L = c["L"]
+    assert len(gf.screen_reads(np.zeros((0, 38), np.uint8), L, 31)) == 0
+    assert len(gf.tag_alignments(np.zeros(0, B.ALNREC), 300, 30)) == 0
+    assert len(gf.tag_low_mapq(c["recs"], np.zeros(0, B.DPOS))) == 0
+    for n in (1, 63, 64, 255, 256, 257, 1399):     # tails of the 256-read tile and of the 64-lane wave
+        blob = c["reads_blob"][:n * L]
+        packed, _ = GapFill.pack_reads(blob, L)
+        assert _same(gf.screen_reads(packed, L, 31), CO.screen_reads(blob, L, c["flanks"], 31)), n
+        assert _same(gf.tag_alignments(c["recs"][:n], 300, 30), CO.tag_alignments(c["recs"][:n], c["gaps"], 300, 30)), n
+    # no gaps at all
+    gf.set_gaps(np.zeros(0, B.GAP), c["n_scaffolds"], [])
+    packed, _ = GapFill.pack_reads(c["reads_blob"], L)
+    assert len(gf.screen_reads(packed, L, 31)) == 0
+    assert len(gf.tag_alignments(c["recs"], 300, 30)) == 0
+
+
+def test_nospace_reports_required_count(gf):
+    import ctypes as C
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=6, n_pairs=3000)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    packed, _ = GapFill.pack_reads(c["reads_blob"], c["L"])
+    full = gf.screen_reads(packed, c["L"], 31)
+    out = np.zeros(3, dtype=B.HIT)
+    n = C.c_size_t(0)
+    rc = B.lib().gf_screen_reads(gf.handle, B._p(packed), None, len(packed), c["L"], 31, 1, B._p(out), 3, C.byref(n))
+    assert rc == B.GF_E_NOSPACE and n.value == len(full)
+    rc = B.lib().gf_screen_reads(gf.handle, B._p(packed), None, len(packed), c["L"], 8, 1, B._p(out), 3, C.byref(n))
+    assert rc == B.GF_E_UNSUPPORTED
+
+
+def test_screen_properties_at_scale(gf):
+    """Size-independent properties on 2 M reads (the oracle would take minutes): every read cut from a flank is
+    recruited to its gap; reads from an unrelated random genome are never recruited; results are idempotent and
+    independent of the read order."""
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=21, n_pairs=10)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    L, k = 150, 31
+    rng = np.random.RandomState(3)
+    n = 2_000_000
+    arr = rng.randint(0, 4, (n, L)).astype(np.uint8)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    planted = {}
+    for g, (l, r) in enumerate(c["flanks"]):
+        for f in (l, r):
+            for off in (0, 17, len(f) - 60):
+                i = rng.randint(n)
+                seg = np.frombuffer(f[off:off + 60].encode(), np.uint8)
+                arr[i, 40:100] = np.searchsorted(lut, seg)
+                planted[i] = g
+    blob = lut[arr].tobytes()
+    packed, _ = GapFill.pack_reads(blob, L)
+    hits = gf.screen_reads(packed, L, k)
+    got = {(int(h["gap"]), int(h["read"])) for h in hits}
+    assert got == {(g, i) for i, g in planted.items()}
+    perm = rng.permutation(n)
+    hits2 = gf.screen_reads(packed[perm], L, k)
+    assert {(int(h["gap"]), int(perm[h["read"]])) for h in hits2} == got
+    assert _same(gf.screen_reads(packed, L, k), hits)
