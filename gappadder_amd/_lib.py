@@ -39,6 +39,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libgapfill_hip.so not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C gappadder_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    try:
+        import torch  # noqa: F401  -- load torch's HIP runtime first: one libamdhip64 per process
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, i32, u32, u64p = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)
     szp = C.POINTER(C.c_size_t)

@@ -146,6 +146,8 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         ctx->index.clear();
         return GF_OK;
     }
+    if (!strcmp(name, "screen_variant")) { ctx->screen_variant = (int)value; return GF_OK; }
+    if (!strcmp(name, "screen_wg_per_cu")) { ctx->screen_wg_per_cu = (int)value; return GF_OK; }
     return GF_E_INVAL;
 }
 

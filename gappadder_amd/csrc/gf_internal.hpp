@@ -63,6 +63,8 @@ struct gf_ctx {
     std::map<int, gf::FlankIndex> index;  // by k
     uint32_t max_gaps_per_kmer = 0;     // 0 = unlimited
     int bitmap_log2_override = 0;
+    int screen_variant = 0;     // tuning: load mode / unroll of the filter kernel
+    int screen_wg_per_cu = 0;
 
     // scratch
     gf::DevBuf cand, counters, stage_in, stage_out, stage_aux, table;

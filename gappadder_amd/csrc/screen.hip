@@ -27,8 +27,20 @@ struct FilterParams {
     uint32_t* n_cand;
 };
 
-constexpr int PU = 3;  // probes issued back-to-back before their results are consumed
+// how the filter's bitmap words are fetched: every probe is a 4-byte read of a random 128-B line of an
+// L2-resident table, so the L2->CU transfer per probe is what bounds the kernel
+enum { LOAD_PLAIN = 0, LOAD_NT = 1, LOAD_SC1 = 2, LOAD_SC01 = 3 };
 
+template <int MODE>
+__device__ __forceinline__ uint32_t probe_load(const uint32_t* p) {
+    if (MODE == LOAD_NT) return __builtin_nontemporal_load(p);
+    if (MODE == LOAD_SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (MODE == LOAD_SC01) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return *p;
+}
+
+// PU = probes issued back-to-back before their results are consumed
+template <int MODE, int PU>
 __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
     extern __shared__ uint32_t tile[];  // TILE_READS * rb bytes + 16 B pad
     const uint32_t tid = threadIdx.x;
@@ -38,6 +50,7 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
     const uint64_t n_tiles = (P.n_reads + TILE_READS - 1) / TILE_READS;
     uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
     const uint32_t smask = (1u << P.s_log2) - 1;
+    constexpr uint32_t GROUP = (32 / PU) * PU;  // probes whose results fit one 32-bit mask
 
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t byte0 = t * tile_bytes;
@@ -51,49 +64,50 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
         __syncthreads();
 
         const uint64_t r = t * TILE_READS + tid;
-        uint32_t mask = 0;
+        bool cand = false;
         if (r < P.n_reads) {
             const uint32_t bit0 = tid * P.rb * 8;
-            for (uint32_t j0 = 0; j0 < P.np; j0 += PU) {
-                uint32_t word[PU], hb[PU];
+            for (uint32_t g0 = 0; g0 < P.np && !cand; g0 += GROUP) {
+                const uint32_t g1 = g0 + GROUP < P.np ? g0 + GROUP : P.np;
+                uint32_t mask = 0;
+                for (uint32_t j0 = g0; j0 < g1; j0 += PU) {
+                    uint32_t word[PU], hb[PU];
 #pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    const uint32_t j = j0 + u;
-                    word[u] = 0;
-                    hb[u] = 0;
-                    if (j < P.np) {
-                        const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
-                        const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
-                        hb[u] = h & 31;
-                        word[u] = P.bitmap[h >> 5];
+                    for (int u = 0; u < PU; ++u) {
+                        const uint32_t j = j0 + u;
+                        word[u] = 0;
+                        hb[u] = 0;
+                        if (j < g1) {
+                            const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
+                            const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
+                            hb[u] = h & 31;
+                            word[u] = probe_load<MODE>(P.bitmap + (h >> 5));
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) mask |= ((word[u] >> hb[u]) & 1u) << (j0 - g0 + u);
+                }
+                // level 2: confirm each bitmap hit in the exact canonical-16-mer set
+                while (mask && !cand) {
+                    const uint32_t j = g0 + __ffs(mask) - 1;
+                    mask &= mask - 1;
+                    const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
+                    uint32_t s = hash_s16_set(key, P.s_log2);
+                    uint32_t v;
+                    while ((v = P.sset[s]) != EMPTY32) {
+                        if (v == key) { cand = true; break; }
+                        s = (s + 1) & smask;
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < PU; ++u) mask |= ((word[u] >> hb[u]) & 1u) << (j0 + u);
-            }
-            // level 2: confirm each bitmap hit in the exact canonical-16-mer set
-            uint32_t m = mask;
-            mask = 0;
-            while (m) {
-                const uint32_t j = __ffs(m) - 1;
-                m &= m - 1;
-                const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
-                uint32_t s = hash_s16_set(key, P.s_log2);
-                uint32_t v;
-                while ((v = P.sset[s]) != EMPTY32) {
-                    if (v == key) { mask = 1; break; }
-                    s = (s + 1) & smask;
-                }
-                if (mask) break;
             }
         }
         // wave ballot + prefix count compaction of candidate reads
-        const unsigned long long bal = __ballot(mask != 0);
+        const unsigned long long bal = __ballot(cand);
         if (bal) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(P.n_cand, (uint32_t)__popcll(bal));
             base = __shfl(base, 0);
-            if (mask) P.cand[base + __popcll(bal & ((1ull << lane) - 1))] = (uint32_t)r;
+            if (cand) P.cand[base + __popcll(bal & ((1ull << lane) - 1))] = (uint32_t)r;
         }
         __syncthreads();
     }
@@ -216,7 +230,6 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     F.rb = rb;
     F.stride2 = 2 * ix.stride;
     F.np = (uint32_t)((read_len - 16) / ix.stride + 1);
-    if (F.np > 32) return GF_E_UNSUPPORTED;
     F.bitmap = ix.d_bitmap;
     F.sset = ix.d_sset;
     F.bm_log2 = ix.bm_log2;
@@ -225,10 +238,21 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     F.n_cand = d_cnt;
     const size_t n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
     const size_t lds = TILE_READS * rb + 16;
-    const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * 8);
+    const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * (ctx->screen_wg_per_cu > 0 ? ctx->screen_wg_per_cu : 8));
     {
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        hipLaunchKernelGGL(screen_filter_kernel, dim3(grid), dim3(256), lds, ctx->stream, F);
+        void (*kern)(FilterParams) = screen_filter_kernel<LOAD_PLAIN, 9>;
+        switch (ctx->screen_variant) {
+            case 1: kern = screen_filter_kernel<LOAD_NT, 3>; break;
+            case 2: kern = screen_filter_kernel<LOAD_SC1, 3>; break;
+            case 3: kern = screen_filter_kernel<LOAD_SC01, 3>; break;
+            case 4: kern = screen_filter_kernel<LOAD_PLAIN, 3>; break;
+            case 5: kern = screen_filter_kernel<LOAD_NT, 9>; break;
+            case 6: kern = screen_filter_kernel<LOAD_SC1, 9>; break;
+            case 7: kern = screen_filter_kernel<LOAD_PLAIN, 1>; break;
+            default: break;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, F);
     }
     GF_HIP(ctx, hipGetLastError());
 
@@ -255,7 +279,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.n_out = (uint32_t*)d_n_out;
     V.overflow = d_cnt + 1;
     const size_t lds2 = (80 + V.list_cap) * 4;
-    const unsigned grid2 = (unsigned)ctx->n_cu * 8;
+    const unsigned grid2 = (unsigned)ctx->n_cu * 32;  // one wave per block: fill every wave slot
     {
         LaunchTimer tm(ctx, GF_KERNEL_VERIFY);
         if (ix.k > 32)

@@ -21,8 +21,11 @@ gaps["idx_in_scaffold"] = np.arange(n_gaps) % 20 + 1
 lut = np.frombuffer(b"ACGT", np.uint8)
 flanks = [(lut[rng.randint(0, 4, 295)].tobytes().decode(), lut[rng.randint(0, 4, 295)].tobytes().decode()) for _ in range(n_gaps)]
 gf = GapFill(0)
-for bl in ([0] if len(sys.argv) <= 4 else [int(x) for x in sys.argv[4].split(",")]):
+variants = [0] if len(sys.argv) <= 5 else [int(x) for x in sys.argv[5].split(",")]
+import itertools
+for bl, var in itertools.product(([0] if len(sys.argv) <= 4 else [int(x) for x in sys.argv[4].split(",")]), variants):
     gf.set_option("bitmap_log2", bl)
+    gf.set_option("screen_variant", var)
     t = time.time()
     gf.set_gaps(gaps, int(gaps["scaffold"].max()) + 1, flanks)
     dev = torch.device("cuda:0")
@@ -43,6 +46,6 @@ for bl in ([0] if len(sys.argv) <= 4 else [int(x) for x in sys.argv[4].split(","
     dt = (time.time() - t) / 5
     ms, nl = gf.kernel_time(B.KERNEL_SCREEN)
     ms2, nl2 = gf.kernel_time(B.KERNEL_VERIFY)
-    print("bitmap_log2=%d reads=%d gaps=%d k=%d: wall %.3f ms/iter; filter %.3f ms (%.1f GB/s, %.2e reads/s) verify %.3f ms; hits=%d"
-          % (bl, n_reads, n_gaps, k, dt * 1e3, ms / nl, n_reads * 38 / (ms / nl * 1e-3) / 1e9, n_reads / (ms / nl * 1e-3), ms2 / nl2, int(nout[0])))
+    print("var=%d bitmap_log2=%d reads=%d gaps=%d k=%d: wall %.3f ms/iter; filter %.3f ms (%.1f GB/s, %.2e reads/s) verify %.3f ms; hits=%d"
+          % (var, bl, n_reads, n_gaps, k, dt * 1e3, ms / nl, n_reads * 38 / (ms / nl * 1e-3) / 1e9, n_reads / (ms / nl * 1e-3), ms2 / nl2, int(nout[0])))
     gf.timing(False)
