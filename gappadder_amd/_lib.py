@@ -14,6 +14,9 @@ ALNREC = np.dtype([("pos", "<u4"), ("mate_pos", "<u4"), ("tlen", "<i4"), ("ref",
 TAGHIT = np.dtype([("rec", "<u4"), ("gap", "<u4"), ("kind", "<u2"), ("to_mate", "<u2")])
 DPOS = np.dtype([("mate_scaffold", "<u4"), ("mate_pos", "<u4"), ("src_scaffold", "<u4"), ("src_gap", "<u4")])
 HIT = np.dtype([("gap", "<u4"), ("read", "<u4")])
+SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", "<u4"), ("gaps_per_scaffold", "<u4"),
+                      ("gap_len", "<u4"), ("read_len", "<u4"), ("insert_mean", "<u4"), ("insert_sd", "<u4"),
+                      ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4")])
 assert GAP.itemsize == 16 and ALNREC.itemsize == 32 and TAGHIT.itemsize == 12 and DPOS.itemsize == 16 and HIT.itemsize == 8
 
 GF_OK, GF_E_INVAL, GF_E_NODEV, GF_E_NOMEM, GF_E_NOSPACE, GF_E_STATE, GF_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
@@ -71,6 +74,8 @@ def lib():
         "gf_timing_enable": (i32, [vp, i32]),
         "gf_timing_read": (i32, [vp, i32, C.POINTER(C.c_double), u64p]),
         "gf_timing_reset": (i32, [vp]),
+        "gf_synth_pairs_dev": (i32, [vp, vp, C.c_uint64, sz, vp, vp]),
+        "gf_synth_layout": (i32, [vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = header/library mismatch: fail loudly

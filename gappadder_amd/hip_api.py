@@ -118,3 +118,30 @@ class GapFill:
 
     def sync(self):
         self._chk(self._L.gf_sync(self._h), "gf_sync")
+
+    # ---- synthetic workload (include/gf_synth.h) ----------------------------------------------------
+    @staticmethod
+    def synth_cfg(seed=20260002, scaffold_len=5_000_000, n_scaffolds=50, gaps_per_scaffold=20, gap_len=2000,
+                  read_len=150, insert_mean=300, insert_sd=30, err=0.005, mapq0=0.02, chimeric=0.01, flank_len=300):
+        c = np.zeros(1, dtype=B.SYNTH_CFG)
+        c[0] = (seed, scaffold_len, n_scaffolds, gaps_per_scaffold, gap_len, read_len, insert_mean, insert_sd,
+                int(round(err * 65536)), int(round(mapq0 * 65536)), int(round(chimeric * 65536)), flank_len)
+        return c
+
+    @staticmethod
+    def synth_layout(cfg):
+        n = int(cfg["n_scaffolds"][0]) * int(cfg["gaps_per_scaffold"][0])
+        fl = int(cfg["flank_len"][0]) - 5
+        gaps = np.zeros(n, dtype=B.GAP)
+        blob = np.zeros(2 * n * fl, dtype=np.uint8)
+        off = np.zeros(2 * n + 1, dtype=np.uint64)
+        rc = B.lib().gf_synth_layout(B._p(cfg), B._p(gaps), B._p(blob), B._p(off))
+        if rc:
+            raise B.GapFillError(rc, "gf_synth_layout")
+        b = blob.tobytes().decode()
+        flanks = [(b[int(off[2 * g]):int(off[2 * g + 1])], b[int(off[2 * g + 1]):int(off[2 * g + 2])]) for g in range(n)]
+        return gaps, flanks
+
+    def synth_pairs_dev(self, cfg, first_pair, n_pairs, d_packed, d_recs=None):
+        self._chk(self._L.gf_synth_pairs_dev(self._h, B._p(cfg), int(first_pair), int(n_pairs), d_packed, d_recs),
+                  "gf_synth_pairs_dev")

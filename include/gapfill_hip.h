@@ -152,6 +152,14 @@ int gf_timing_enable(gf_ctx* ctx, int on);
 int gf_timing_read(gf_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 int gf_timing_reset(gf_ctx* ctx);
 
+/* ---- synthetic workload (bench/test utility, not part of the reference's path; definition: include/gf_synth.h,
+ * shared bit-for-bit with oracle/gp_oracle.c).  gf_synth_pairs_dev fills 2*n_pairs packed reads (read 2p+m =
+ * mate m+1 of pair first_pair+p) and, optionally, 2*n_pairs gf_alnrec (record 2p+e = forward/reverse end).
+ * gf_synth_layout writes the n_scaffolds*gaps_per_scaffold gaps and their flanks (2*(flank_len-5) bases per gap). */
+int gf_synth_pairs_dev(gf_ctx* ctx, const void* cfg /* gf_synth_cfg */, uint64_t first_pair, size_t n_pairs,
+                       void* d_packed_reads, void* d_alnrecs_or_null);
+int gf_synth_layout(const void* cfg /* gf_synth_cfg */, gf_gap* gaps, char* flank_ascii, uint64_t* flank_off);
+
 #ifdef __cplusplus
 }
 #endif

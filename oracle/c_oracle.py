@@ -16,12 +16,15 @@ ALNREC = np.dtype([("pos", "<u4"), ("mate_pos", "<u4"), ("tlen", "<i4"), ("ref",
 TAGHIT = np.dtype([("rec", "<u4"), ("gap", "<u4"), ("kind", "<u2"), ("to_mate", "<u2")])
 DPOS = np.dtype([("mate_scaffold", "<u4"), ("mate_pos", "<u4"), ("src_scaffold", "<u4"), ("src_gap", "<u4")])
 HIT = np.dtype([("gap", "<u4"), ("read", "<u4")])
+SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", "<u4"), ("gaps_per_scaffold", "<u4"),
+                      ("gap_len", "<u4"), ("read_len", "<u4"), ("insert_mean", "<u4"), ("insert_sd", "<u4"),
+                      ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4")])
 
 
 def lib():
     global _lib
     if _lib is None:
-        src = [os.path.join(_HERE, f) for f in ("gp_oracle.c", "gp_oracle.h")]
+        src = [os.path.join(_HERE, f) for f in ("gp_oracle.c", "gp_oracle.h", "../include/gf_synth.h")]
         if not os.path.exists(_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_PATH) for s in src):
             subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
         L = C.CDLL(_PATH)
@@ -36,6 +39,10 @@ def lib():
         L.or_pack_kmer64.argtypes = [C.c_char_p, i32]
         L.or_unpack_reads.restype = None
         L.or_unpack_reads.argtypes = [vp, sz, i32, vp]
+        L.or_synth_pairs.restype = None
+        L.or_synth_pairs.argtypes = [vp, C.c_uint64, sz, vp, vp]
+        L.or_synth_layout.restype = None
+        L.or_synth_layout.argtypes = [vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -92,3 +99,31 @@ def unpack_reads(packed, read_len):
     out = np.zeros(n * read_len, dtype=np.uint8)
     lib().or_unpack_reads(_p(packed), n, read_len, _p(out))
     return out.tobytes()
+
+
+def synth_cfg(seed=20260002, scaffold_len=5_000_000, n_scaffolds=50, gaps_per_scaffold=20, gap_len=2000, read_len=150,
+              insert_mean=300, insert_sd=30, err=0.005, mapq0=0.02, chimeric=0.01, flank_len=300):
+    c = np.zeros(1, dtype=SYNTH_CFG)
+    c[0] = (seed, scaffold_len, n_scaffolds, gaps_per_scaffold, gap_len, read_len, insert_mean, insert_sd,
+            int(round(err * 65536)), int(round(mapq0 * 65536)), int(round(chimeric * 65536)), flank_len)
+    return c
+
+
+def synth_pairs(cfg, first_pair, n_pairs, with_records=True):
+    rb = (int(cfg["read_len"][0]) + 3) // 4
+    packed = np.zeros((2 * n_pairs, rb), dtype=np.uint8)
+    recs = np.zeros(2 * n_pairs, dtype=ALNREC) if with_records else None
+    lib().or_synth_pairs(_p(cfg), first_pair, n_pairs, _p(packed), _p(recs) if with_records else None)
+    return packed, recs
+
+
+def synth_layout(cfg):
+    n = int(cfg["n_scaffolds"][0]) * int(cfg["gaps_per_scaffold"][0])
+    fl = int(cfg["flank_len"][0]) - 5
+    gaps = np.zeros(n, dtype=GAP)
+    blob = np.zeros(2 * n * fl, dtype=np.uint8)
+    off = np.zeros(2 * n + 1, dtype=np.uint64)
+    lib().or_synth_layout(_p(cfg), _p(gaps), _p(blob), _p(off))
+    b = blob.tobytes().decode()
+    flanks = [(b[int(off[2 * g]):int(off[2 * g + 1])], b[int(off[2 * g + 1]):int(off[2 * g + 2])]) for g in range(n)]
+    return gaps, flanks

@@ -33,12 +33,12 @@ static int put(or_taghit* out, size_t cap, size_t* n, uint32_t rec, uint32_t gap
     return 0;
 }
 
-size_t or_tag_alignments(const or_alnrec* recs, size_t n, const or_gap* gaps, size_t n_gaps, int insert_size, int sd,
-                         int clip_dist, int anchor_mapq, or_taghit* out, size_t cap) {
+static size_t tag_range(const or_alnrec* recs, size_t i0, size_t i1, const or_gap* gaps, size_t n_gaps, int insert_size,
+                        int sd, int clip_dist, int anchor_mapq, or_taghit* out, size_t cap) {
     const long dist1 = insert_size - 3L * sd, dist2 = insert_size + 3L * sd; /* collect_reads_for_gaps.py:5-6 */
     const int short_is = insert_size < 750;                                  /* :275 */
     size_t cnt = 0;
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t i = i0; i < i1; ++i) {
         const or_alnrec* r = &recs[i];
         for (size_t g = 0; g < n_gaps; ++g) { /* every gap of the record's scaffold (:36-63) */
             if (gaps[g].scaffold != r->ref) continue;
@@ -60,6 +60,40 @@ size_t or_tag_alignments(const or_alnrec* recs, size_t n, const or_gap* gaps, si
                 put(out, cap, &cnt, (uint32_t)i, (uint32_t)g, 2, 1);
             }
         }
+    }
+    return cnt;
+}
+
+/* records are independent (the reference runs one pipeline per scaffold, run_multi_threads_collect_reads.py:35-38):
+ * contiguous chunks per OpenMP thread, concatenated in record order */
+size_t or_tag_alignments(const or_alnrec* recs, size_t n, const or_gap* gaps, size_t n_gaps, int insert_size, int sd,
+                         int clip_dist, int anchor_mapq, or_taghit* out, size_t cap) {
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+#endif
+    if (nt > 64) nt = 64;
+    if (n < 4096) nt = 1;
+    size_t cnts[64];
+    or_taghit* bufs[64];
+    size_t caps[64];
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+    for (int t = 0; t < nt; ++t) {
+        size_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+        caps[t] = 4 * (i1 - i0) + 64;
+        bufs[t] = malloc(caps[t] * sizeof(or_taghit));
+        cnts[t] = tag_range(recs, i0, i1, gaps, n_gaps, insert_size, sd, clip_dist, anchor_mapq, bufs[t], caps[t]);
+        if (cnts[t] > caps[t]) { /* dense overlap of windows: redo with exact room */
+            free(bufs[t]);
+            caps[t] = cnts[t];
+            bufs[t] = malloc(caps[t] * sizeof(or_taghit));
+            cnts[t] = tag_range(recs, i0, i1, gaps, n_gaps, insert_size, sd, clip_dist, anchor_mapq, bufs[t], caps[t]);
+        }
+    }
+    size_t cnt = 0;
+    for (int t = 0; t < nt; ++t) {
+        for (size_t i = 0; i < cnts[t]; ++i) { if (cnt < cap) out[cnt] = bufs[t][i]; ++cnt; }
+        free(bufs[t]);
     }
     return cnt;
 }
@@ -189,4 +223,48 @@ size_t or_screen_reads(const char* reads, size_t n_reads, int L, const char* fla
     free(tab);
     qsort(out, cnt < cap ? cnt : cap, sizeof(or_hit), hit_cmp);
     return cnt;
+}
+
+/* ------------------------------------------------------------------ synthetic workload (definition: include/gf_synth.h) */
+#include "../include/gf_synth.h"
+
+void or_synth_pairs(const void* c_, uint64_t first_pair, size_t n_pairs, uint8_t* packed, or_alnrec* recs) {
+    const gf_synth_cfg* c = (const gf_synth_cfg*)c_;
+    const size_t rb = (c->read_len + 3) / 4;
+#pragma omp parallel for schedule(static)
+    for (long lp = 0; lp < (long)n_pairs; ++lp) {
+        gfs_pair p;
+        gfs_make_pair(c, first_pair + lp, &p);
+        for (int end = 0; end < 2; ++end) {
+            gfs_errs er;
+            gfs_make_errs(c, p.err[end], &er);
+            const uint32_t mate_no = ((end == 0) != (p.flip != 0)) ? 0u : 1u;
+            uint8_t* o = packed + (2 * (size_t)lp + mate_no) * rb;
+            memset(o, 0, rb);
+            for (uint32_t i = 0; i < c->read_len; ++i)
+                o[i >> 2] |= (uint8_t)(gfs_read_base(c, &p, &er, end, i) << (6 - 2 * (i & 3)));
+        }
+        if (recs) {
+            uint32_t r[2][8];
+            gfs_make_records(c, first_pair + lp, &p, r);
+            memcpy(&recs[2 * lp], r[0], 32);
+            memcpy(&recs[2 * lp + 1], r[1], 32);
+        }
+    }
+}
+
+void or_synth_layout(const void* c_, or_gap* gaps, char* flank_ascii, uint64_t* flank_off) {
+    const gf_synth_cfg* c = (const gf_synth_cfg*)c_;
+    uint64_t off = 0;
+    size_t g = 0;
+    for (uint32_t s = 0; s < c->n_scaffolds; ++s)
+        for (uint32_t j = 0; j < c->gaps_per_scaffold; ++j, ++g) {
+            const uint64_t st = gfs_gap_start(c, j), en = st + c->gap_len;
+            gaps[g].scaffold = s; gaps[g].start = (uint32_t)st; gaps[g].end = (uint32_t)en; gaps[g].idx_in_scaffold = j + 1;
+            flank_off[2 * g] = off;
+            for (uint64_t x = st - c->flank_len; x < st - 5; ++x) flank_ascii[off++] = "ACGT"[gfs_base(c, s, x)];
+            flank_off[2 * g + 1] = off;
+            for (uint64_t x = en + 5; x < en + c->flank_len; ++x) flank_ascii[off++] = "ACGT"[gfs_base(c, s, x)];
+        }
+    flank_off[2 * g] = off;
 }

@@ -26,4 +26,7 @@ size_t or_screen_reads(const char* reads_ascii, size_t n_reads, int read_len, co
 /* KmerUtils.cpp:61-69 */
 uint64_t or_pack_kmer64(const char* seq, int k);
 void or_unpack_reads(const uint8_t* packed, size_t n_reads, int read_len, char* ascii);
+/* synthetic workload, definition in include/gf_synth.h (cfg = gf_synth_cfg) */
+void or_synth_pairs(const void* cfg, uint64_t first_pair, size_t n_pairs, uint8_t* packed, or_alnrec* recs_or_null);
+void or_synth_layout(const void* cfg, or_gap* gaps, char* flank_ascii, uint64_t* flank_off);
 #endif

@@ -197,3 +197,28 @@ def test_screen_properties_at_scale(gf):
     hits2 = gf.screen_reads(packed[perm], L, k)
     assert {(int(h["gap"]), int(perm[h["read"]])) for h in hits2} == got
     assert _same(gf.screen_reads(packed, L, k), hits)
+
+
+def test_synthetic_generator_matches_oracle_bit_for_bit(gf):
+    """The HIP generator of the bench workload and the oracle's C generator share include/gf_synth.h."""
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    cfg = GapFill.synth_cfg(scaffold_len=300000, n_scaffolds=5, gaps_per_scaffold=4, chimeric=0.05, mapq0=0.1)
+    n_pairs, first = 70001, 12345
+    d_reads = torch.zeros(2 * n_pairs * 38, dtype=torch.uint8, device="cuda:0")
+    d_recs = torch.zeros(2 * n_pairs * 32, dtype=torch.uint8, device="cuda:0")
+    gf.synth_pairs_dev(cfg, first, n_pairs, d_reads.data_ptr(), d_recs.data_ptr())
+    gf.sync()
+    ocfg = np.frombuffer(cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
+    packed, recs = CO.synth_pairs(ocfg, first, n_pairs)
+    assert d_reads.cpu().numpy().tobytes() == packed.tobytes()
+    assert d_recs.cpu().numpy().tobytes() == recs.tobytes()
+    g1, f1 = GapFill.synth_layout(cfg)
+    g2, f2 = CO.synth_layout(ocfg)
+    assert g1.tobytes() == g2.tobytes() and f1 == f2
+    # and the hot path on it
+    gf.set_gaps(g1, 5, f1)
+    blob = CO.unpack_reads(packed, 150)
+    assert _same(gf.screen_reads(packed, 150, 31), CO.screen_reads(blob, 150, f2, 31))
+    assert _same(gf.tag_alignments(recs, 300, 30), CO.tag_alignments(recs, g2, 300, 30))
