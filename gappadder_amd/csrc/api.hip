@@ -115,7 +115,7 @@ void gf_destroy(gf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
-    for (DevBuf* b : {&ctx->cand, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->binmap, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
         if (b->p) (void)hipFree(b->p);
     if (ctx->d_gaps) (void)hipFree(ctx->d_gaps);
     if (ctx->d_scaf_off) (void)hipFree(ctx->d_scaf_off);
@@ -165,6 +165,7 @@ int gf_set_gaps(gf_ctx* ctx, const gf_gap* gaps, size_t n_gaps, uint32_t n_scaff
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
     ctx->index.clear();
     ctx->gaps.assign(gaps, gaps + n_gaps);
+    ctx->bin_dist2 = -1;
     ctx->n_scaffolds = n_scaffolds;
     ctx->flank_left.assign(n_gaps, std::string());
     ctx->flank_right.assign(n_gaps, std::string());

@@ -28,9 +28,9 @@ struct FlankIndex {
     uint32_t* d_sset = nullptr;
     // level 3: canonical k-mer -> gap, one slot per (k-mer, gap) pair
     int t_log2 = 0;
-    uint64_t* d_thi = nullptr;
-    uint64_t* d_tlo = nullptr;   // only for k > 32
-    uint32_t* d_tgap = nullptr;  // EMPTY32 = free slot
+    // slot = one uint4 {hi.lo32, hi.hi32, gap, 0} for k <= 32, two uint4 {hi, lo}, {gap, 0, 0, 0} for k > 32;
+    // gap == EMPTY32 marks a free slot
+    void* d_table = nullptr;
     size_t n_kmers = 0, n_s16 = 0;
     uint32_t max_gaps_per_kmer = 0;
 };
@@ -65,9 +65,13 @@ struct gf_ctx {
     int bitmap_log2_override = 0;
     int screen_variant = 0;     // tuning: load mode / unroll of the filter kernel
     int screen_wg_per_cu = 0;
+    // tagger coarse bin map (rebuilt when dist2 changes)
+    std::vector<uint32_t> bin_host;
+    int bin_dist2 = -1, bin_shift = 0;
+    uint32_t bin_words = 0;
 
     // scratch
-    gf::DevBuf cand, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, binmap, counters, stage_in, stage_out, stage_aux, table;
     // timing
     bool timing = false;
     std::vector<gf::TimedLaunch> launches;

@@ -43,8 +43,14 @@ __device__ __forceinline__ uint32_t probe_load(const uint32_t* p) {
 template <int MODE, int PU>
 __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
     extern __shared__ uint32_t tile[];  // TILE_READS * rb bytes + 16 B pad
+    // candidates are buffered per workgroup and appended to the global list with ONE atomic per ~768 of them:
+    // a single global counter serialises returning atomics at ~11 ns each (MI355X_MICROARCH.md "dequeue" row)
+    constexpr uint32_t CBUF = 1024;
+    __shared__ uint32_t cbuf[CBUF];
+    __shared__ uint32_t cbuf_n, cbuf_base;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
+    if (tid == 0) cbuf_n = 0;
     const uint32_t tile_bytes = TILE_READS * P.rb;
     const uint64_t total_bytes = P.n_reads * P.rb;
     const uint64_t n_tiles = (P.n_reads + TILE_READS - 1) / TILE_READS;
@@ -101,112 +107,259 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
                 }
             }
         }
-        // wave ballot + prefix count compaction of candidate reads
+        // wave ballot + prefix count compaction of candidate reads into the workgroup buffer
         const unsigned long long bal = __ballot(cand);
         if (bal) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(P.n_cand, (uint32_t)__popcll(bal));
+            if (lane == 0) base = atomicAdd(&cbuf_n, (uint32_t)__popcll(bal));
             base = __shfl(base, 0);
-            if (cand) P.cand[base + __popcll(bal & ((1ull << lane) - 1))] = (uint32_t)r;
+            if (cand) cbuf[base + __popcll(bal & ((1ull << lane) - 1))] = (uint32_t)r;
         }
         __syncthreads();
+        if (cbuf_n > CBUF - TILE_READS) {  // uniform: no room for another tile's worth -> flush
+            const uint32_t n = cbuf_n;
+            if (tid == 0) cbuf_base = atomicAdd(P.n_cand, n);
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += 256) P.cand[cbuf_base + i] = cbuf[i];
+            __syncthreads();
+            if (tid == 0) cbuf_n = 0;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t n = cbuf_n;
+        if (n) {
+            if (tid == 0) cbuf_base = atomicAdd(P.n_cand, n);
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += 256) P.cand[cbuf_base + i] = cbuf[i];
+        }
     }
 }
 
 struct VerifyParams {
-    const uint8_t* reads;
-    const uint32_t* nmask;  // may be null
+    const uint32_t* reads32;  // packed reads viewed as little-endian words
+    uint64_t n_words;         // whole words of the packed array
+    uint32_t tail_bytes;      // bytes after the last whole word (0..3)
+    const uint32_t* nmask;    // may be null
     uint32_t rb, read_len, k, nmw;
     const uint32_t* cand;
     const uint32_t* n_cand;
-    const uint64_t* thi;
-    const uint64_t* tlo;
-    const uint32_t* tgap;
+    const uint4* table;       // k <= 32: one uint4 per slot {hi.lo32, hi.hi32, gap, 0}; k > 32: two {hi, lo}, {gap,0,0,0}
     uint32_t t_log2;
     uint32_t min_hits;
     uint32_t list_cap;
     gf_hit* out;
     uint32_t cap;
     uint32_t* n_out;
-    uint32_t* overflow;
+    uint32_t* overflow;      // counter: candidates whose (position, gap) list exceeded list_cap
+    uint32_t* overflow_list; // their read ids (re-verified by a second launch with a large list), or null
 };
 
+__device__ __forceinline__ uint32_t packed_word(const VerifyParams& P, uint64_t w) {
+    if (w < P.n_words) return P.reads32[w];
+    uint32_t v = 0;
+    if (w == P.n_words) {
+        const uint8_t* t = reinterpret_cast<const uint8_t*>(P.reads32 + P.n_words);
+        for (uint32_t i = 0; i < P.tail_bytes; ++i) v |= (uint32_t)t[i] << (8 * i);
+    }
+    return v;
+}
+
+// One wavefront per workgroup.  A wave takes 64 candidates at a time: lane j fetches candidate j's packed read
+// into LDS (one round of global latency for 64 reads), then the whole wave verifies the candidates one by one —
+// lane = k-mer position, two positions per lane in flight, one 16-B (32-B for k > 32) slot load per probe step.
 template <bool WIDE>
 __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
-    extern __shared__ uint32_t sm[];  // [0..63] read words (<= 252 bytes + pad) | [64..71] n-mask | list
-    __shared__ uint32_t s_n;
-    uint32_t* rw = sm;
-    uint32_t* nm = sm + 72;
-    uint32_t* list = sm + 80;
+    extern __shared__ uint32_t sm[];  // [64][rw] read words | list[list_cap]
+    constexpr uint32_t OBUF = 128;    // hits buffered per wave: one global atomic per >= 64 hits (see filter kernel)
+    __shared__ gf_hit obuf[OBUF];
+    __shared__ uint32_t obuf_n;
     const uint32_t lane = threadIdx.x;
+    if (lane == 0) obuf_n = 0;
+    const uint32_t rw = (P.rb + 24) / 4 + 1;  // words per staged read, zero padded (stream_kmer reads past the end)
+    uint32_t* list = sm + 64 * rw;
     const uint32_t n_cand = *P.n_cand;
     const uint32_t npos = P.read_len - P.k + 1;
     const uint32_t tmask = (1u << P.t_log2) - 1;
-    uint8_t* rb8 = reinterpret_cast<uint8_t*>(rw);
 
-    for (uint32_t c = blockIdx.x; c < n_cand; c += gridDim.x) {
-        const uint32_t r = P.cand[c];
-        const uint8_t* src = P.reads + (uint64_t)r * P.rb;
-        for (uint32_t i = lane; i < P.rb + 24; i += 64) rb8[i] = i < P.rb ? src[i] : 0;
-        if (lane < 8) nm[lane] = (P.nmask && lane < P.nmw) ? P.nmask[(uint64_t)r * P.nmw + lane] : 0;
-        if (lane == 0) s_n = 0;
-        __syncthreads();
-        for (uint32_t p = lane; p < npos; p += 64) {
-            bool ok = true;
-            if (P.nmask) {  // any N inside [p, p+k) ?
-                for (uint32_t q = p; q < p + P.k; q += 1) {
-                    if ((nm[q >> 5] >> (q & 31)) & 1u) { ok = false; break; }
-                }
-            }
-            if (!ok) continue;
-            const K128 f = stream_kmer(rw, 2 * p, (int)P.k);
-            const K128 cn = canonical(f, (int)P.k);
-            uint32_t s = hash_kmer(cn, (int)P.t_log2);
-            uint32_t g;
-            while ((g = P.tgap[s]) != EMPTY32) {
-                bool eq = P.thi[s] == cn.hi;
-                if (WIDE) eq = eq && P.tlo[s] == cn.lo;
-                if (eq) {
-                    const uint32_t idx = atomicAdd(&s_n, 1u);
-                    if (idx < P.list_cap) list[idx] = g;
-                }
-                s = (s + 1) & tmask;
+    for (uint32_t c0 = blockIdx.x * 64; c0 < n_cand; c0 += gridDim.x * 64) {
+        const uint32_t nb = n_cand - c0 < 64 ? n_cand - c0 : 64;
+        const uint32_t my_r = lane < nb ? P.cand[c0 + lane] : 0;
+        {   // stage my candidate's read, re-aligned to a word boundary
+            const uint64_t o = (uint64_t)my_r * P.rb;
+            const uint64_t w0 = o >> 2;
+            const uint32_t sh = (uint32_t)(o & 3) * 8;
+            const uint32_t nw = (P.rb + 3) / 4;
+            uint32_t prev = lane < nb ? packed_word(P, w0) : 0;
+            for (uint32_t i = 0; i < rw; ++i) {
+                uint32_t next = 0;
+                if (lane < nb && i < nw) next = packed_word(P, w0 + i + 1);
+                uint32_t v = sh ? (prev >> sh) | (next << (32 - sh)) : prev;
+                if (i >= nw) v = 0;
+                else if (i == nw - 1 && (P.rb & 3)) v &= (1u << ((P.rb & 3) * 8)) - 1;  // drop the next read's bytes
+                sm[lane * rw + i] = v;
+                prev = next;
             }
         }
         __syncthreads();
-        uint32_t n = s_n;
-        if (n > P.list_cap) {
-            if (lane == 0) atomicAdd(P.overflow, 1u);
-            n = P.list_cap;
-        }
-        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            bool emit = false;
-            uint32_t g = 0;
-            if (i < n) {
-                g = list[i];
-                uint32_t cnt = 0;
-                bool first = true;
-                for (uint32_t j = 0; j < n; ++j) {
-                    if (list[j] == g) {
-                        ++cnt;
-                        if (j < i) first = false;
+        for (uint32_t j = 0; j < nb; ++j) {
+            const uint32_t r = __shfl(my_r, j);
+            const uint32_t* rwp = sm + j * rw;
+            uint32_t n = 0;  // (position, gap) matches of this read; wave-uniform, appended by ballot + prefix count
+            for (uint32_t pp = 0; pp < npos; pp += 128) {
+                K128 cn[2];
+                uint32_t slot[2];
+                bool act[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t p = pp + lane + 64 * u;
+                    act[u] = p < npos;
+                    if (act[u] && P.nmask) {  // any N inside [p, p+k) ?
+                        for (uint32_t q = p; q < p + P.k; ++q)
+                            if ((P.nmask[(uint64_t)r * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { act[u] = false; break; }
+                    }
+                    cn[u] = K128{0, 0};
+                    slot[u] = 0;
+                    if (act[u]) {
+                        cn[u] = canonical(stream_kmer(rwp, 2 * p, (int)P.k), (int)P.k);
+                        slot[u] = hash_kmer(cn[u], (int)P.t_log2);
                     }
                 }
-                emit = first && cnt >= P.min_hits;
-            }
-            const unsigned long long bal = __ballot(emit);
-            if (bal) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(P.n_out, (uint32_t)__popcll(bal));
-                base = __shfl(base, 0);
-                if (emit) {
-                    const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
-                    if (o < P.cap) P.out[o] = gf_hit{g, r};
+                while (__any(act[0] || act[1])) {  // wave-uniform probe steps; finished lanes idle
+                    uint4 a[2], b[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        a[u] = make_uint4(0, 0, EMPTY32, 0);
+                        b[u] = make_uint4(EMPTY32, 0, 0, 0);
+                        if (act[u]) {
+                            if (WIDE) { a[u] = P.table[2 * (uint64_t)slot[u]]; b[u] = P.table[2 * (uint64_t)slot[u] + 1]; }
+                            else a[u] = P.table[slot[u]];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const uint32_t g = WIDE ? b[u].x : a[u].z;
+                        bool eq = false;
+                        if (act[u]) {
+                            if (g == EMPTY32) act[u] = false;
+                            else {
+                                eq = (((uint64_t)a[u].y << 32) | a[u].x) == cn[u].hi;
+                                if (WIDE) eq = eq && (((uint64_t)a[u].w << 32) | a[u].z) == cn[u].lo;
+                                slot[u] = (slot[u] + 1) & tmask;
+                            }
+                        }
+                        const unsigned long long bal = __ballot(eq);
+                        if (bal) {
+                            const uint32_t o = n + __popcll(bal & ((1ull << lane) - 1));
+                            if (eq && o < P.list_cap) list[o] = g;
+                            n += (uint32_t)__popcll(bal);
+                        }
+                    }
                 }
             }
+            __syncthreads();
+            if (n > P.list_cap) {  // rare (repeat-rich flanks): defer this read to the large-list launch
+                if (lane == 0) {
+                    const uint32_t o = atomicAdd(P.overflow, 1u);
+                    if (P.overflow_list) P.overflow_list[o] = r;
+                }
+                n = 0;
+            }
+            // distinct gaps and their position counts.  Up to 256 matches: entries held in registers, one wave
+            // step per DISTINCT gap (ballot + popcount); longer lists (pass 2 only): quadratic scan in LDS.
+            if (n <= 256) {
+                uint32_t v[4];
+                bool todo[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = lane + 64 * u;
+                    todo[u] = i < n;
+                    v[u] = todo[u] ? list[i] : 0;
+                }
+                while (true) {
+                    const unsigned long long b0 = __ballot(todo[0]), b1 = __ballot(todo[1]), b2 = __ballot(todo[2]),
+                                             b3 = __ballot(todo[3]);
+                    if (!(b0 | b1 | b2 | b3)) break;
+                    uint32_t g;
+                    if (b0) g = __shfl(v[0], __ffsll((long long)b0) - 1);
+                    else if (b1) g = __shfl(v[1], __ffsll((long long)b1) - 1);
+                    else if (b2) g = __shfl(v[2], __ffsll((long long)b2) - 1);
+                    else g = __shfl(v[3], __ffsll((long long)b3) - 1);
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool m = todo[u] && v[u] == g;
+                        cnt += (uint32_t)__popcll(__ballot(m));
+                        if (m) todo[u] = false;
+                    }
+                    if (cnt >= P.min_hits) {
+                        if (lane == 0) obuf[obuf_n] = gf_hit{g, r};
+                        __syncthreads();
+                        if (lane == 0) obuf_n = obuf_n + 1;
+                        __syncthreads();
+                    }
+                    if (obuf_n >= OBUF - 64) {
+                        const uint32_t nn = obuf_n;
+                        uint32_t gb = 0;
+                        if (lane == 0) gb = atomicAdd(P.n_out, nn);
+                        gb = __shfl(gb, 0);
+                        for (uint32_t q = lane; q < nn; q += 64)
+                            if (gb + q < P.cap) P.out[gb + q] = obuf[q];
+                        __syncthreads();
+                        if (lane == 0) obuf_n = 0;
+                        __syncthreads();
+                    }
+                }
+            } else
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                bool emit = false;
+                uint32_t g = 0;
+                if (i < n) {
+                    g = list[i];
+                    uint32_t cnt = 0;
+                    bool first = true;
+                    for (uint32_t q = 0; q < n; ++q) {
+                        if (list[q] == g) {
+                            ++cnt;
+                            if (q < i) first = false;
+                        }
+                    }
+                    emit = first && cnt >= P.min_hits;
+                }
+                const unsigned long long bal = __ballot(emit);
+                if (bal) {  // single wave per block: obuf_n is only touched here, in lock-step
+                    const uint32_t base = obuf_n;
+                    if (emit) obuf[base + __popcll(bal & ((1ull << lane) - 1))] = gf_hit{g, r};
+                    __syncthreads();
+                    if (lane == 0) obuf_n = base + (uint32_t)__popcll(bal);
+                    __syncthreads();
+                    if (obuf_n >= OBUF - 64) {
+                        const uint32_t nn = obuf_n;
+                        uint32_t gb = 0;
+                        if (lane == 0) gb = atomicAdd(P.n_out, nn);
+                        gb = __shfl(gb, 0);
+                        for (uint32_t q = lane; q < nn; q += 64)
+                            if (gb + q < P.cap) P.out[gb + q] = obuf[q];
+                        __syncthreads();
+                        if (lane == 0) obuf_n = 0;
+                        __syncthreads();
+                    }
+                }
+            }
+            __syncthreads();
         }
         __syncthreads();
+    }
+    __syncthreads();
+    if (obuf_n) {
+        const uint32_t nn = obuf_n;
+        uint32_t gb = 0;
+        if (lane == 0) gb = atomicAdd(P.n_out, nn);
+        gb = __shfl(gb, 0);
+        for (uint32_t q = lane; q < nn; q += 64)
+            if (gb + q < P.cap) P.out[gb + q] = obuf[q];
     }
 }
 
@@ -220,7 +373,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     if ((rc = ensure(ctx, ctx->cand, std::max<size_t>(n_reads, 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
     uint32_t* d_cnt = (uint32_t*)ctx->counters.p;  // [0] n_cand, [1] overflow
-    GF_HIP(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    GF_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));  // [0] n_cand [1] error overflow [2] n_cand2
     GF_HIP(ctx, hipMemsetAsync(d_n_out, 0, 4, ctx->stream));
     if (n_reads == 0) return GF_OK;
 
@@ -257,7 +410,9 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     GF_HIP(ctx, hipGetLastError());
 
     VerifyParams V;
-    V.reads = (const uint8_t*)d_reads;
+    V.reads32 = (const uint32_t*)d_reads;
+    V.n_words = ((uint64_t)n_reads * rb) / 4;
+    V.tail_bytes = (uint32_t)(((uint64_t)n_reads * rb) & 3);
     V.nmask = (const uint32_t*)d_nmask;
     V.rb = rb;
     V.read_len = read_len;
@@ -266,27 +421,37 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     if (V.nmw > 8) return GF_E_UNSUPPORTED;
     V.cand = F.cand;
     V.n_cand = d_cnt;
-    V.thi = ix.d_thi;
-    V.tlo = ix.d_tlo;
-    V.tgap = ix.d_tgap;
+    V.table = (const uint4*)ix.d_table;
     V.t_log2 = ix.t_log2;
     V.min_hits = min_hits < 1 ? 1 : min_hits;
     const uint32_t npos = read_len - ix.k + 1;
-    size_t want = ix.max_gaps_per_kmer ? (size_t)npos * ix.max_gaps_per_kmer : (size_t)npos * 64;
-    V.list_cap = (uint32_t)std::min<size_t>(std::max<size_t>(want, 256), 15000);
     V.out = (gf_hit*)d_out;
     V.cap = (uint32_t)cap;
     V.n_out = (uint32_t*)d_n_out;
-    V.overflow = d_cnt + 1;
-    const size_t lds2 = (80 + V.list_cap) * 4;
-    const unsigned grid2 = (unsigned)ctx->n_cu * 32;  // one wave per block: fill every wave slot
-    {
+    const unsigned grid2 = (unsigned)ctx->n_cu * 32;  // one wave per block, every wave slot of the chip
+    auto launch_verify = [&](const VerifyParams& VP) {
+        const size_t lds2 = (64 * ((rb + 24) / 4 + 1) + VP.list_cap) * 4;
         LaunchTimer tm(ctx, GF_KERNEL_VERIFY);
         if (ix.k > 32)
-            hipLaunchKernelGGL(screen_verify_kernel<true>, dim3(grid2), dim3(64), lds2, ctx->stream, V);
+            hipLaunchKernelGGL(screen_verify_kernel<true>, dim3(grid2), dim3(64), lds2, ctx->stream, VP);
         else
-            hipLaunchKernelGGL(screen_verify_kernel<false>, dim3(grid2), dim3(64), lds2, ctx->stream, V);
-    }
+            hipLaunchKernelGGL(screen_verify_kernel<false>, dim3(grid2), dim3(64), lds2, ctx->stream, VP);
+    };
+    // pass 1: small per-wave list (keeps every wave slot of the chip busy); reads that overflow it are queued
+    if ((rc = ensure(ctx, ctx->cand2, std::max<size_t>(n_reads, 1) * 4))) return rc;
+    V.list_cap = std::max<uint32_t>(256, 2 * npos);
+    V.overflow = d_cnt + 2;
+    V.overflow_list = (uint32_t*)ctx->cand2.p;
+    launch_verify(V);
+    GF_HIP(ctx, hipGetLastError());
+    // pass 2: the queued reads with a list as large as LDS allows; overflowing that is an error (d_cnt[1])
+    size_t want = ix.max_gaps_per_kmer ? (size_t)npos * ix.max_gaps_per_kmer : 15000;
+    V.list_cap = (uint32_t)std::min<size_t>(std::max<size_t>(want, 1024), 15000);
+    V.cand = (const uint32_t*)ctx->cand2.p;
+    V.n_cand = d_cnt + 2;
+    V.overflow = d_cnt + 1;
+    V.overflow_list = nullptr;
+    launch_verify(V);
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
 }

@@ -19,41 +19,104 @@ struct TagParams {
     uint32_t n_scaffolds;
     int32_t dist1, dist2, clip_dist, anchor_mapq;
     int32_t short_is;
+    // coarse bin map: bit (bin_off[s] + (POS >> bin_shift)) is set iff some window of scaffold s touches that bin
+    const uint32_t* bin_bits;
+    const uint32_t* bin_off;  // n_scaffolds + 1
+    uint32_t bin_shift, bin_words;
     gf_taghit* out;
     uint32_t cap;
     uint32_t* n_out;
 };
 
-__device__ __forceinline__ void emit_hit(bool want, const gf_taghit& h, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
+// Hits are rare and a single global counter serialises returning atomics at ~11 ns each (MI355X_MICROARCH.md
+// "dequeue"/"fanin" rows), so they are first collected in a per-workgroup LDS buffer: wave ballot + prefix count,
+// one LDS atomic per wave, and ONE global atomic per workgroup when the kernel ends.  A full buffer falls back to
+// direct global appends (correct, just slower).
+constexpr uint32_t HITBUF = 1024;
+
+struct HitBuf {
+    gf_taghit h[HITBUF];
+    uint32_t n;       // slots handed out (may run past HITBUF)
+    uint32_t stored;  // end of the contiguous prefix actually written
+};
+
+__device__ __forceinline__ void emit_hit(bool want, const gf_taghit& h, HitBuf& hb, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
     const unsigned long long bal = __ballot(want);
     if (!bal) return;
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t base = 0;
+    const uint32_t cnt = (uint32_t)__popcll(bal);
     const uint32_t leader = __ffsll((long long)bal) - 1;
-    if (lane == leader) base = atomicAdd(n_out, (uint32_t)__popcll(bal));
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&hb.n, cnt);
     base = __shfl(base, leader);
-    if (want) {
-        const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
-        if (o < cap) out[o] = h;
+    const uint32_t off = __popcll(bal & ((1ull << lane) - 1));
+    if (base + cnt <= HITBUF) {
+        if (want) hb.h[base + off] = h;
+        if (lane == leader) atomicMax(&hb.stored, base + cnt);
+    } else {  // buffer full: this wave's hits go straight to the global list
+        uint32_t gb = 0;
+        if (lane == leader) gb = atomicAdd(n_out, cnt);
+        gb = __shfl(gb, leader);
+        if (want && gb + off < cap) out[gb + off] = h;
     }
 }
 
+__device__ __forceinline__ void flush_hits(HitBuf& hb, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
+    __shared__ uint32_t s_base;
+    __syncthreads();
+    const uint32_t n = hb.stored;  // slots are handed out in order, so the stored entries are the prefix [0, stored)
+    if (threadIdx.x == 0) s_base = n ? atomicAdd(n_out, n) : 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (s_base + i < cap) out[s_base + i] = hb.h[i];
+}
+
+// Records are streamed as whole 1-KiB wave loads (16 B per lane, consecutive lanes = consecutive 16-B halves):
+// the even lane of a pair holds {pos, mate_pos, tlen, ref}, the odd lane {mate_ref, flag|mapq|clip, read id}.
+// Even lanes run the coarse bin test; the rare survivors pull their second half from the neighbour lane.
+constexpr int TAG_UNROLL = 4;  // 4 KiB (128 records) in flight per wave
+
 __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    // every lane of a wave must reach the ballots together: iterate whole waves
-    const uint64_t n_round = (P.n + 63) & ~63ull;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        bool live = i < P.n;
-        gf_alnrec r = {};
-        uint32_t g = 0, g_end = 0;
-        if (live) {
-            const uint4* p = reinterpret_cast<const uint4*>(P.recs + i);
-            const uint4 a = p[0], b = p[1];
-            r.pos = a.x; r.mate_pos = a.y; r.tlen = (int32_t)a.z; r.ref = a.w;
-            r.mate_ref = b.x; r.flag = (uint16_t)(b.y & 0xFFFF); r.mapq = (uint8_t)((b.y >> 16) & 0xFF);
-            r.clipflag = (uint8_t)(b.y >> 24);
-            live = r.ref < P.n_scaffolds;
+    extern __shared__ uint32_t bins[];  // the whole bin map (<= 16 KiB), staged once per workgroup
+    __shared__ HitBuf hb;
+    if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
+    for (uint32_t i = threadIdx.x; i < P.bin_words; i += blockDim.x) bins[i] = P.bin_bits[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n_half = 2 * P.n;                       // 16-byte halves
+    const uint64_t chunk = 64ull * TAG_UNROLL;             // halves per wave iteration
+    const uint4* src = reinterpret_cast<const uint4*>(P.recs);
+    for (uint64_t h0 = wave * chunk; h0 < n_half; h0 += n_waves * chunk) {
+        uint4 v[TAG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TAG_UNROLL; ++u) {
+            const uint64_t h = h0 + 64ull * u + lane;
+            v[u] = h < n_half ? src[h] : make_uint4(0, 0, 0, 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for (int u = 0; u < TAG_UNROLL; ++u) {
+            const uint64_t h = h0 + 64ull * u + lane;
+            // neighbour's half (odd lane -> second half of the even lane's record)
+            uint4 nb;
+            nb.x = __shfl_down(v[u].x, 1);
+            nb.y = __shfl_down(v[u].y, 1);
+            bool live = !(lane & 1) && h < n_half;
+            gf_alnrec r = {};
+            uint32_t g = 0, g_end = 0;
             if (live) {
+                r.pos = v[u].x; r.mate_pos = v[u].y; r.tlen = (int32_t)v[u].z; r.ref = v[u].w;
+                live = r.ref < P.n_scaffolds;
+            }
+            if (live) {  // coarse test first: almost every record lies far from every gap
+                const uint32_t b0 = P.bin_off[r.ref], nbin = P.bin_off[r.ref + 1] - b0, bi = r.pos >> P.bin_shift;
+                live = bi < nbin && ((bins[(b0 + bi) >> 5] >> ((b0 + bi) & 31)) & 1u);
+            }
+            if (!__any(live)) continue;
+            if (live) {
+                r.mate_ref = nb.x; r.flag = (uint16_t)(nb.y & 0xFFFF); r.mapq = (uint8_t)((nb.y >> 16) & 0xFF);
+                r.clipflag = (uint8_t)(nb.y >> 24);
                 g = P.scaf_off[r.ref];
                 g_end = P.scaf_off[r.ref + 1];
                 // first gap whose right window can still reach POS: end + dist2 > pos  (ends ascend)
@@ -64,42 +127,44 @@ __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
                 }
                 g = lo;
             }
-        }
-        const int64_t pos = r.pos;
-        // walk the (few) gaps whose windows can contain POS; lanes without work idle through the ballots
-        while (true) {
-            bool more = live && g < g_end && (int64_t)P.gaps[g].start - P.dist2 < pos;
-            if (!__any(more)) break;
-            bool clip = false, pair = false, unmap = false;
-            if (more) {
-                const gf_gap gp = P.gaps[g];
-                const int64_t il = (int64_t)gp.start - pos, ir = pos - (int64_t)gp.end;
-                int tag = -1;  // 0: 0c, 1: 0d, 2: 1c, 3: 1d
-                if (il >= 0 && il < P.dist2) tag = il <= P.clip_dist ? 0 : 1;
-                else if (ir >= 0 && ir < P.dist2) tag = ir <= P.clip_dist ? 2 : 3;
-                if (tag >= 0) {
-                    clip = (tag == 0 && r.clipflag >= 2) || (tag == 2 && (r.clipflag == 1 || r.clipflag == 3));
-                    const bool mapped = (r.flag & 0x4) == 0, mate_mapped = (r.flag & 0x8) == 0;
-                    if (mapped && mate_mapped && (int)r.mapq >= P.anchor_mapq) {
-                        if (r.mate_ref != r.ref) pair = true;
-                        else {
-                            const int64_t t = r.tlen < 0 ? -(int64_t)r.tlen : (int64_t)r.tlen;
-                            pair = t >= P.dist2 || (P.short_is && t <= P.dist1);
+            const int64_t pos = r.pos;
+            const uint32_t rec = (uint32_t)(h >> 1);
+            // walk the (few) gaps whose windows can contain POS; lanes without work idle through the ballots
+            while (true) {
+                bool more = live && g < g_end && (int64_t)P.gaps[g].start - P.dist2 < pos;
+                if (!__any(more)) break;
+                bool clip = false, pair = false, unmap = false;
+                if (more) {
+                    const gf_gap gp = P.gaps[g];
+                    const int64_t il = (int64_t)gp.start - pos, ir = pos - (int64_t)gp.end;
+                    int tag = -1;  // 0: 0c, 1: 0d, 2: 1c, 3: 1d
+                    if (il >= 0 && il < P.dist2) tag = il <= P.clip_dist ? 0 : 1;
+                    else if (ir >= 0 && ir < P.dist2) tag = ir <= P.clip_dist ? 2 : 3;
+                    if (tag >= 0) {
+                        clip = (tag == 0 && r.clipflag >= 2) || (tag == 2 && (r.clipflag == 1 || r.clipflag == 3));
+                        const bool mapped = (r.flag & 0x4) == 0, mate_mapped = (r.flag & 0x8) == 0;
+                        if (mapped && mate_mapped && (int)r.mapq >= P.anchor_mapq) {
+                            if (r.mate_ref != r.ref) pair = true;
+                            else {
+                                const int64_t t = r.tlen < 0 ? -(int64_t)r.tlen : (int64_t)r.tlen;
+                                pair = t >= P.dist2 || (P.short_is && t <= P.dist1);
+                            }
+                        } else if (mapped && !mate_mapped) {
+                            unmap = true;
                         }
-                    } else if (mapped && !mate_mapped) {
-                        unmap = true;
                     }
                 }
+                gf_taghit hit;
+                hit.rec = rec; hit.gap = g;
+                hit.kind = GF_KIND_CLIP; hit.to_mate = 0;
+                emit_hit(clip, hit, hb, P.out, P.cap, P.n_out);
+                hit.kind = pair ? GF_KIND_DISCORDANT : GF_KIND_UNMAP; hit.to_mate = 1;
+                emit_hit(pair || unmap, hit, hb, P.out, P.cap, P.n_out);
+                if (more) ++g;
             }
-            gf_taghit h;
-            h.rec = (uint32_t)i; h.gap = g;
-            h.kind = GF_KIND_CLIP; h.to_mate = 0;
-            emit_hit(clip, h, P.out, P.cap, P.n_out);
-            h.kind = pair ? GF_KIND_DISCORDANT : GF_KIND_UNMAP; h.to_mate = 1;
-            emit_hit(pair || unmap, h, P.out, P.cap, P.n_out);
-            if (more) ++g;
         }
     }
+    flush_hits(hb, P.out, P.cap, P.n_out);
 }
 
 struct LowParams {
@@ -115,45 +180,99 @@ struct LowParams {
 };
 
 __global__ __launch_bounds__(256) void low_mapq_kernel(LowParams P) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t n_round = (P.n + 63) & ~63ull;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        uint32_t row = 0, row_end = 0;
-        if (i < P.n) {
-            const uint4* p = reinterpret_cast<const uint4*>(P.recs + i);
-            const uint4 a = p[0], b = p[1];
-            const uint32_t pos = a.x, ref = a.w, mapq = (b.y >> 16) & 0xFF;
-            if (mapq == 0 && ref < P.n_scaffolds) {
-                uint32_t lo = P.scaf_off[ref], hi = P.scaf_off[ref + 1];
-                const uint32_t first = lo;
-                const uint64_t lim = (uint64_t)pos + 199;  // largest q <= pos+199
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if ((uint64_t)P.upos[mid] <= lim) lo = mid + 1; else hi = mid;
-                }
-                if (lo > first) {
-                    const uint32_t u = lo - 1;
-                    if ((uint64_t)P.upos[u] + 299 >= pos) {
-                        row = P.urow[u];
-                        row_end = P.urow[u + 1];
+    __shared__ HitBuf hb;
+    if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n_half = 2 * P.n;
+    const uint64_t chunk = 64ull * TAG_UNROLL;
+    const uint4* src = reinterpret_cast<const uint4*>(P.recs);
+    for (uint64_t h0 = wave * chunk; h0 < n_half; h0 += n_waves * chunk) {
+        uint4 v[TAG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TAG_UNROLL; ++u) {
+            const uint64_t h = h0 + 64ull * u + lane;
+            v[u] = h < n_half ? src[h] : make_uint4(0, 0xFFFFFFFFu, 0, 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for (int u = 0; u < TAG_UNROLL; ++u) {
+            const uint64_t h = h0 + 64ull * u + lane;
+            const uint32_t nb_y = __shfl_down(v[u].y, 1);  // flag | mapq<<16 | clip<<24 of the even lane's record
+            uint32_t row = 0, row_end = 0;
+            if (!(lane & 1) && h < n_half) {
+                const uint32_t pos = v[u].x, ref = v[u].w, mapq = (nb_y >> 16) & 0xFF;
+                if (mapq == 0 && ref < P.n_scaffolds) {
+                    uint32_t lo = P.scaf_off[ref], hi = P.scaf_off[ref + 1];
+                    const uint32_t first = lo;
+                    const uint64_t lim = (uint64_t)pos + 199;  // largest q <= pos+199
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((uint64_t)P.upos[mid] <= lim) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo > first) {
+                        const uint32_t uq = lo - 1;
+                        if ((uint64_t)P.upos[uq] + 299 >= pos) {
+                            row = P.urow[uq];
+                            row_end = P.urow[uq + 1];
+                        }
                     }
                 }
             }
-        }
-        while (true) {
-            const bool more = row < row_end;
-            if (!__any(more)) break;
-            gf_taghit h;
-            h.rec = (uint32_t)i; h.gap = row; h.kind = GF_KIND_LOWMAPQ; h.to_mate = 0;
-            emit_hit(more, h, P.out, P.cap, P.n_out);
-            if (more) ++row;
+            while (true) {
+                const bool more = row < row_end;
+                if (!__any(more)) break;
+                gf_taghit hit;
+                hit.rec = (uint32_t)(h >> 1); hit.gap = row; hit.kind = GF_KIND_LOWMAPQ; hit.to_mate = 0;
+                emit_hit(more, hit, hb, P.out, P.cap, P.n_out);
+                if (more) ++row;
+            }
         }
     }
+    flush_hits(hb, P.out, P.cap, P.n_out);
 }
 
 static unsigned stream_grid(gf_ctx* ctx, size_t n) {
     size_t blocks = (n + 255) / 256;
     return (unsigned)std::max<size_t>(1, std::min<size_t>(blocks, (size_t)ctx->n_cu * 8));
+}
+
+// Coarse bin map of the gap windows for one dist2 (host build: n_gaps work; cached until gaps or dist2 change).
+// Bits cover, per scaffold, positions 0 .. last window end; everything beyond has no window.
+static int ensure_bin_map(gf_ctx* ctx, int dist2) {
+    if (ctx->bin_dist2 == dist2 && ctx->binmap.p) return GF_OK;
+    const int64_t d2 = dist2 > 0 ? dist2 : 0;
+    std::vector<uint64_t> span(ctx->n_scaffolds, 0);  // exclusive end of the covered positions per scaffold
+    for (const gf_gap& g : ctx->gaps) span[g.scaffold] = std::max<uint64_t>(span[g.scaffold], (uint64_t)g.end + d2);
+    uint64_t total = 0;
+    for (uint64_t v : span) total += v;
+    int shift = 6;
+    auto nbits = [&](int sh) { uint64_t t = 0; for (uint64_t v : span) t += (v >> sh) + (v ? 1 : 0); return t; };
+    while (nbits(shift) > (1u << 17)) ++shift;  // <= 16 KiB of LDS: keeps 8 workgroups per CU
+    std::vector<uint32_t> off(ctx->n_scaffolds + 1, 0);
+    for (uint32_t s = 0; s < ctx->n_scaffolds; ++s) off[s + 1] = off[s] + (uint32_t)((span[s] >> shift) + (span[s] ? 1 : 0));
+    const uint32_t words = (off[ctx->n_scaffolds] + 31) / 32 + 1;
+    std::vector<uint32_t>& h = ctx->bin_host;
+    h.assign(words + off.size(), 0);
+    for (const gf_gap& g : ctx->gaps) {
+        if (d2 == 0) break;
+        const int64_t lo = std::max<int64_t>(0, (int64_t)g.start - d2 + 1), hi = (int64_t)g.end + d2 - 1;
+        for (int64_t b = lo >> shift; b <= (hi >> shift); ++b) {
+            const uint32_t bit = off[g.scaffold] + (uint32_t)b;
+            h[bit >> 5] |= 1u << (bit & 31);
+        }
+    }
+    for (size_t i = 0; i < off.size(); ++i) h[words + i] = off[i];
+    int rc = ensure(ctx, ctx->binmap, h.size() * 4);
+    if (rc) return rc;
+    GF_HIP(ctx, hipMemcpyAsync(ctx->binmap.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->bin_dist2 = dist2;
+    ctx->bin_shift = shift;
+    ctx->bin_words = words;
+    (void)total;
+    return GF_OK;
 }
 
 int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist, int anchor_mapq,
@@ -176,9 +295,15 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
     P.out = (gf_taghit*)d_out;
     P.cap = (uint32_t)cap;
     P.n_out = (uint32_t*)d_n_out;
+    int rc = ensure_bin_map(ctx, P.dist2);
+    if (rc) return rc;
+    P.bin_bits = (const uint32_t*)ctx->binmap.p;
+    P.bin_off = P.bin_bits + ctx->bin_words;
+    P.bin_shift = ctx->bin_shift;
+    P.bin_words = ctx->bin_words;
     {
         LaunchTimer tm(ctx, GF_KERNEL_TAG);
-        hipLaunchKernelGGL(tag_kernel, dim3(stream_grid(ctx, n)), dim3(256), 0, ctx->stream, P);
+        hipLaunchKernelGGL(tag_kernel, dim3(stream_grid(ctx, n)), dim3(256), (size_t)ctx->bin_words * 4, ctx->stream, P);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
