@@ -14,10 +14,12 @@ ALNREC = np.dtype([("pos", "<u4"), ("mate_pos", "<u4"), ("tlen", "<i4"), ("ref",
 TAGHIT = np.dtype([("rec", "<u4"), ("gap", "<u4"), ("kind", "<u2"), ("to_mate", "<u2")])
 DPOS = np.dtype([("mate_scaffold", "<u4"), ("mate_pos", "<u4"), ("src_scaffold", "<u4"), ("src_gap", "<u4")])
 HIT = np.dtype([("gap", "<u4"), ("read", "<u4")])
+CONTIG = np.dtype([("gap", "<u4"), ("k", "<u2"), ("kv", "<u2"), ("n_nodes", "<u4"), ("length", "<u4"), ("cov_sum", "<u4"),
+                   ("reserved", "<u4"), ("seq_off", "<u8")])
 SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", "<u4"), ("gaps_per_scaffold", "<u4"),
                       ("gap_len", "<u4"), ("read_len", "<u4"), ("insert_mean", "<u4"), ("insert_sd", "<u4"),
                       ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4")])
-assert GAP.itemsize == 16 and ALNREC.itemsize == 32 and TAGHIT.itemsize == 12 and DPOS.itemsize == 16 and HIT.itemsize == 8
+assert CONTIG.itemsize == 32 and GAP.itemsize == 16 and ALNREC.itemsize == 32 and TAGHIT.itemsize == 12 and DPOS.itemsize == 16 and HIT.itemsize == 8
 
 GF_OK, GF_E_INVAL, GF_E_NODEV, GF_E_NOMEM, GF_E_NOSPACE, GF_E_STATE, GF_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 KIND_CLIP, KIND_DISCORDANT, KIND_UNMAP, KIND_LOWMAPQ = 0, 1, 2, 3
@@ -66,6 +68,9 @@ def lib():
         "gf_tag_alignments_dev": (i32, [vp, vp, sz, i32, i32, i32, i32, vp, sz, vp]),
         "gf_tag_low_mapq": (i32, [vp, vp, sz, vp, sz, vp, sz, szp]),
         "gf_tag_low_mapq_dev": (i32, [vp, vp, sz, vp, sz, vp, sz, vp]),
+        "gf_assemble": (i32, [vp, vp, vp, vp, sz, i32, vp, vp, i32, i32, i32, vp, sz, szp, vp, sz, szp]),
+        "gf_assemble_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, i32, i32, i32, i32, vp, sz, vp, vp, sz, vp, vp]),
+        "gf_count_kmers": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp, sz, szp]),
         "gf_dev_alloc": (i32, [vp, sz, C.POINTER(vp)]),
         "gf_dev_free": (i32, [vp, vp]),
         "gf_memcpy_h2d": (i32, [vp, vp, vp, sz]),

@@ -115,7 +115,7 @@ void gf_destroy(gf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
-    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->binmap, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->binmap, &ctx->asm_table, &ctx->asm_surv, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
         if (b->p) (void)hipFree(b->p);
     if (ctx->d_gaps) (void)hipFree(ctx->d_gaps);
     if (ctx->d_scaf_off) (void)hipFree(ctx->d_scaf_off);
@@ -147,6 +147,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         return GF_OK;
     }
     if (!strcmp(name, "screen_variant")) { ctx->screen_variant = (int)value; return GF_OK; }
+    if (!strcmp(name, "asm_lds_pool_kb")) { ctx->asm_lds_pool_kb = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_wg_per_cu")) { ctx->screen_wg_per_cu = (int)value; return GF_OK; }
     return GF_E_INVAL;
 }
@@ -278,6 +279,147 @@ int gf_tag_low_mapq(gf_ctx* ctx, const gf_alnrec* recs, size_t n, const gf_dpos*
     return tag_host(ctx, recs, n, out, cap, n_out, [&](void* d_in, void* d_out, void* d_n) {
         return launch_low_mapq(ctx, d_in, n, table, n_rows, d_out, cap, d_n);
     });
+}
+
+
+// ---- assembly ----------------------------------------------------------------------------------------
+int gf_assemble_dev(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
+                    size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig, void* d_contigs,
+                    size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len, void* d_gap_error) {
+    if (!ctx || !d_n_contigs || !d_seq_len || (n_pools && (!d_pool_off || !d_gap_error)) || (total_reads && !d_pool) ||
+        (contig_cap && !d_contigs) || (seq_cap && !d_seq))
+        return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_assemble(ctx, d_pool, d_nmask, d_pool_off, n_pools, total_reads, read_len, k, kv, min_count, min_contig,
+                           d_contigs, contig_cap, d_n_contigs, d_seq, seq_cap, d_seq_len, d_gap_error, nullptr, nullptr, 0);
+}
+
+int gf_assemble(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, const uint64_t* pool_off, size_t n_pools,
+                int read_len, const int* k_list, const int* kv_list, int n_k, int min_count, int min_contig,
+                gf_contig* contigs, size_t contig_cap, size_t* n_contigs, char* seq, size_t seq_cap, size_t* seq_len) {
+    if (!ctx || !n_contigs || !seq_len || (n_pools && !pool_off) || n_k < 0 || (n_k && (!k_list || !kv_list)) ||
+        (contig_cap && !contigs) || (seq_cap && !seq) || read_len <= 0)
+        return GF_E_INVAL;
+    *n_contigs = 0;
+    *seq_len = 0;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t total = n_pools ? (size_t)pool_off[n_pools] : 0;
+    if (total && !pool) return GF_E_INVAL;
+    for (size_t g = 0; g < n_pools; ++g) if (pool_off[g] > pool_off[g + 1]) return GF_E_INVAL;
+    const size_t rb = gf_packed_read_bytes(read_len), nmw = (size_t)(read_len + 31) / 32;
+    int rc;
+    // device staging: [pool | pool_off | gap_error | counters | contigs | seq]
+    const size_t b_pool = (total * rb + 63) & ~(size_t)63, b_off = ((n_pools + 1) * 8 + 63) & ~(size_t)63,
+                 b_err = (n_pools * 4 + 63) & ~(size_t)63, b_ctg = (contig_cap * sizeof(gf_contig) + 63) & ~(size_t)63;
+    if ((rc = ensure(ctx, ctx->stage_in, b_pool + b_off + b_err + 64 + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, b_ctg + seq_cap + 64))) return rc;
+    if (n_mask && (rc = ensure(ctx, ctx->stage_aux, total * nmw * 4 + 64))) return rc;
+    uint8_t* d_pool = (uint8_t*)ctx->stage_in.p;
+    uint8_t* d_off = d_pool + b_pool;
+    uint8_t* d_err = d_off + b_off;
+    uint8_t* d_cnt = d_err + b_err;  // u32 n_contigs @0, u64 seq_len @8
+    uint8_t* d_ctg = (uint8_t*)ctx->stage_out.p;
+    uint8_t* d_seq = d_ctg + b_ctg;
+    if (total) GF_HIP(ctx, hipMemcpyAsync(d_pool, pool, total * rb, hipMemcpyHostToDevice, ctx->stream));
+    if (n_pools) GF_HIP(ctx, hipMemcpyAsync(d_off, pool_off, (n_pools + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n_mask && total) GF_HIP(ctx, hipMemcpyAsync(ctx->stage_aux.p, n_mask, total * nmw * 4, hipMemcpyHostToDevice, ctx->stream));
+    size_t nc_total = 0, seq_total = 0;
+    bool nospace = false;
+    std::vector<gf_contig> tmp;
+    std::vector<char> tseq;
+    std::vector<uint32_t> errs(n_pools);
+    for (int i = 0; i < n_k; ++i) {
+        rc = launch_assemble(ctx, d_pool, n_mask ? ctx->stage_aux.p : nullptr, d_off, n_pools, total, read_len, k_list[i],
+                             kv_list[i], min_count, min_contig, d_ctg, contig_cap, d_cnt, d_seq, seq_cap, d_cnt + 8, d_err,
+                             nullptr, nullptr, 0);
+        if (rc) return rc;
+        uint32_t nc = 0;
+        unsigned long long sl = 0;
+        GF_HIP(ctx, hipMemcpyAsync(&nc, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+        GF_HIP(ctx, hipMemcpyAsync(&sl, d_cnt + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_pools) GF_HIP(ctx, hipMemcpyAsync(errs.data(), d_err, n_pools * 4, hipMemcpyDeviceToHost, ctx->stream));
+        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t e : errs) if (e) return GF_E_UNSUPPORTED;  // a pool overflowed its tables (ids/slots are 32-bit)
+        if (nc > contig_cap || sl > seq_cap || nc_total + nc > contig_cap || seq_total + sl > seq_cap) {
+            nospace = true;
+            nc_total += nc;
+            seq_total += sl;
+            continue;
+        }
+        tmp.resize(nc);
+        tseq.resize(sl);
+        if (nc) GF_HIP(ctx, hipMemcpy(tmp.data(), d_ctg, nc * sizeof(gf_contig), hipMemcpyDeviceToHost));
+        if (sl) GF_HIP(ctx, hipMemcpy(tseq.data(), d_seq, sl, hipMemcpyDeviceToHost));
+        // deterministic order inside this (k, kv): gap, length descending, sequence ascending
+        std::sort(tmp.begin(), tmp.end(), [&](const gf_contig& a, const gf_contig& b) {
+            if (a.gap != b.gap) return a.gap < b.gap;
+            if (a.length != b.length) return a.length > b.length;
+            return memcmp(tseq.data() + a.seq_off, tseq.data() + b.seq_off, a.length) < 0;
+        });
+        for (const gf_contig& c : tmp) {
+            gf_contig o = c;
+            o.seq_off = seq_total;
+            memcpy(seq + seq_total, tseq.data() + c.seq_off, c.length);
+            contigs[nc_total++] = o;
+            seq_total += c.length;
+        }
+    }
+    *n_contigs = nc_total;
+    *seq_len = seq_total;
+    if (nospace) return GF_E_NOSPACE;
+    // final order: (gap, pair index, ...) — stable sort by gap keeps the per-pair order
+    std::stable_sort(contigs, contigs + nc_total, [](const gf_contig& a, const gf_contig& b) { return a.gap < b.gap; });
+    return GF_OK;
+}
+
+int gf_count_kmers(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, size_t n_reads, int read_len, int k,
+                   int min_count, uint64_t* kmers, uint32_t* counts, size_t cap, size_t* n_out) {
+    if (!ctx || !n_out || (n_reads && !pool) || (cap && (!kmers || !counts)) || read_len <= 0) return GF_E_INVAL;
+    *n_out = 0;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t rb = gf_packed_read_bytes(read_len), nmw = (size_t)(read_len + 31) / 32;
+    int rc;
+    const size_t b_pool = (n_reads * rb + 63) & ~(size_t)63;
+    if ((rc = ensure(ctx, ctx->stage_in, b_pool + 256))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, cap * 20 + 256))) return rc;
+    if (n_mask && (rc = ensure(ctx, ctx->stage_aux, n_reads * nmw * 4 + 64))) return rc;
+    uint8_t* d_pool = (uint8_t*)ctx->stage_in.p;
+    uint8_t* d_off = d_pool + b_pool;   // 2 x u64
+    uint8_t* d_err = d_off + 64;
+    uint8_t* d_cnt = d_err + 64;
+    uint8_t* d_keys = (uint8_t*)ctx->stage_out.p;
+    uint8_t* d_counts = d_keys + ((cap * 16 + 63) & ~(size_t)63);
+    const uint64_t off[2] = {0, n_reads};
+    if (n_reads) GF_HIP(ctx, hipMemcpyAsync(d_pool, pool, n_reads * rb, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(d_off, off, 16, hipMemcpyHostToDevice, ctx->stream));
+    if (n_mask && n_reads) GF_HIP(ctx, hipMemcpyAsync(ctx->stage_aux.p, n_mask, n_reads * nmw * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_assemble(ctx, d_pool, n_mask ? ctx->stage_aux.p : nullptr, d_off, 1, n_reads, read_len, k, 0, min_count, 0,
+                         nullptr, 0, d_cnt, nullptr, 0, d_cnt + 8, d_err, d_keys, d_counts, cap);
+    if (rc) return rc;
+    uint32_t n = 0, err = 0;
+    GF_HIP(ctx, hipMemcpyAsync(&n, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (err) return GF_E_UNSUPPORTED;
+    *n_out = n;
+    if (n > cap) return GF_E_NOSPACE;
+    std::vector<uint64_t> hk(2 * (size_t)n);
+    std::vector<uint32_t> hc(n);
+    if (n) {
+        GF_HIP(ctx, hipMemcpy(hk.data(), d_keys, (size_t)n * 16, hipMemcpyDeviceToHost));
+        GF_HIP(ctx, hipMemcpy(hc.data(), d_counts, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return hk[2 * a] < hk[2 * b] || (hk[2 * a] == hk[2 * b] && hk[2 * a + 1] < hk[2 * b + 1]);
+    });
+    for (uint32_t i = 0; i < n; ++i) {
+        kmers[2 * (size_t)i] = hk[2 * (size_t)order[i]];
+        kmers[2 * (size_t)i + 1] = hk[2 * (size_t)order[i] + 1];
+        counts[i] = hc[order[i]];
+    }
+    return GF_OK;
 }
 
 // ---- memory + timing helpers -------------------------------------------------------------------------

@@ -1,0 +1,468 @@
+// assemble.hip — per-gap local assembly: what `run_assembly` (assemble_gaps.py:82-136) obtains from
+// `kmc -k{k}` | `kmc_dump` | `velveth {kv}` | `velvetg -min_contig_lgth 40`, for one (k, kv) pair per launch.
+// Semantics (PARITY UNPINNED, defined by this build): oracle/gp_oracle.c `or_assemble_pool`, DESIGN.md.
+//
+// One workgroup per gap.  The gap's packed read pool is staged in LDS when it fits; the two open-addressing tables
+// (canonical k-mer -> count, canonical kv-mer -> adjacency/multiplicity) live in a per-gap slice of a global
+// workspace and store 32-bit INSTANCE ids (read-in-pool * L + offset) instead of keys, so one 32-bit CAS claims a
+// slot for any k <= 64 and a key is re-derived from the staged reads when slots are compared.
+//   P1 count      every k-mer position of every read -> canonical -> table (CAS id, add count)
+//   P2 survivors  slots with count >= min_count -> compacted instance list; table cleared
+//   P3 graph      each survivor contributes k-kv+1 kv-mer nodes and k-kv edges (4+4 adjacency bits per node)
+//   P4 starts     oriented nodes whose in-degree != 1, or whose predecessor branches, start a unitig
+//   P5 walk       each start walks its unitig; the walk whose first kv-mer <= the opposite walk's is emitted
+#include "gf_internal.hpp"
+
+namespace gf {
+
+constexpr uint32_t ASM_THREADS = 256;
+constexpr uint32_t ASM_POOL_LDS_MAX_WORDS = 36 * 1024;  // at most 144 KiB of staged reads per workgroup
+
+struct AsmParams {
+    const uint32_t* reads32;   // packed pool reads as little-endian words
+    uint64_t n_words;          // whole words of the packed array
+    uint32_t tail_bytes;
+    const uint32_t* nmask;     // may be null
+    const uint64_t* pool_off;  // n_pools + 1, in reads
+    uint32_t n_pools;
+    uint32_t rb, read_len, k, kv, nmw;
+    uint32_t min_count, min_contig;
+    unsigned long long* table; // 4 slots per k-mer instance: low 32 = instance id, high 32 = count / node meta
+    uint32_t* surv;            // 2 words per instance: survivor list, then (start, n_nodes) records of emitted walks
+    gf_contig* contigs;
+    uint32_t contig_cap;
+    uint32_t* n_contigs;
+    char* seq;
+    uint64_t seq_cap;
+    unsigned long long* seq_len;
+    uint32_t* gap_error;       // per pool: 1 = a table or list overflowed (results of that pool incomplete)
+    // count-only mode (gf_count_kmers): survivors of pool 0 are written here instead of being assembled
+    uint64_t* cnt_keys;        // 2 x u64 per k-mer (hi, lo), or null
+    uint32_t* cnt_counts;
+    uint32_t cnt_cap;
+    uint32_t lds_words;        // dynamic LDS given to the staged pool
+};
+
+// node meta bits (high word of a table slot in the graph phases)
+constexpr uint32_t M_OUT = 0xFu, M_IN = 0xF0u, M_START0 = 1u << 8, M_START1 = 1u << 9, M_MULT_SHIFT = 12;
+
+struct PoolView {
+    const uint32_t* w;  // words of the pool's reads staged in LDS, read r at byte r*rb (when lds)
+    uint32_t rb, L;
+    bool lds;
+    uint64_t first_byte;  // global byte offset of the pool (global view only)
+    const uint32_t* g32;  // the whole packed array in global memory
+    uint64_t g_words;
+    uint32_t g_tail;
+};
+
+__device__ __forceinline__ uint32_t asm_word(const uint32_t* g32, uint64_t n_words, uint32_t tail_bytes, uint64_t w) {
+    if (w < n_words) return g32[w];
+    uint32_t v = 0;
+    if (w == n_words) {
+        const uint8_t* t = reinterpret_cast<const uint8_t*>(g32 + n_words);
+        for (uint32_t i = 0; i < tail_bytes; ++i) v |= (uint32_t)t[i] << (8 * i);
+    }
+    return v;
+}
+
+// 32 bits of the pool's base stream starting at bit `bit` (first base in the top bits)
+__device__ __forceinline__ uint32_t pv_stream32(const PoolView& V, uint64_t bit) {
+    if (V.lds) {
+        const uint32_t d = (uint32_t)(bit >> 5), sh = (uint32_t)bit & 31;
+        const uint64_t v = ((uint64_t)bswap32(V.w[d]) << 32) | bswap32(V.w[d + 1]);
+        return (uint32_t)((v << sh) >> 32);
+    }
+    const uint64_t gb = V.first_byte * 8 + bit;
+    const uint64_t d = gb >> 5;
+    const uint32_t sh = (uint32_t)gb & 31;
+    const uint64_t v = ((uint64_t)bswap32(asm_word(V.g32, V.g_words, V.g_tail, d)) << 32) |
+                       bswap32(asm_word(V.g32, V.g_words, V.g_tail, d + 1));
+    return (uint32_t)((v << sh) >> 32);
+}
+
+// left-aligned `len`-mer at instance id (read * L + off)
+__device__ __forceinline__ K128 pv_kmer(const PoolView& V, uint32_t inst, int len) {
+    const uint32_t r = inst / V.L, off = inst - r * V.L;
+    const uint64_t bit = (uint64_t)r * V.rb * 8 + 2ull * off;
+    K128 v;
+    v.hi = ((uint64_t)pv_stream32(V, bit) << 32) | pv_stream32(V, bit + 32);
+    v.lo = 0;
+    if (len > 32) v.lo = ((uint64_t)pv_stream32(V, bit + 64) << 32) | pv_stream32(V, bit + 96);
+    return mask_k(v, len);
+}
+
+__device__ __forceinline__ uint32_t slot_of(K128 key, uint32_t cap) {
+    uint64_t x = key.hi ^ (key.lo * 0x9E3779B97F4A7C15ull) ^ (key.lo >> 29);
+    x ^= x >> 31;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return (uint32_t)(((x & 0xFFFFFFFFull) * cap) >> 32);
+}
+
+__device__ __forceinline__ uint32_t* slot_id(unsigned long long* t, uint32_t s) { return reinterpret_cast<uint32_t*>(t + s); }
+__device__ __forceinline__ uint32_t* slot_meta(unsigned long long* t, uint32_t s) { return reinterpret_cast<uint32_t*>(t + s) + 1; }
+__device__ __forceinline__ unsigned long long slot_load(const unsigned long long* t, uint32_t s) {
+    return __hip_atomic_load(t + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// find-or-insert the canonical `len`-mer `key` (instance `inst`); returns the slot or EMPTY32 when the table is full
+__device__ __forceinline__ uint32_t table_insert(unsigned long long* t, uint32_t cap, const PoolView& V, K128 key, uint32_t inst,
+                                                 int len) {
+    uint32_t s = slot_of(key, cap);
+    for (uint32_t probes = 0; probes < cap; ++probes) {
+        uint32_t cur = __hip_atomic_load(slot_id(t, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == EMPTY32) {
+            cur = atomicCAS(slot_id(t, s), EMPTY32, inst);
+            if (cur == EMPTY32) return s;
+        }
+        if (cur == inst || canonical(pv_kmer(V, cur, len), len) == key) return s;
+        s = s + 1 == cap ? 0 : s + 1;
+    }
+    return EMPTY32;
+}
+
+__device__ __forceinline__ uint32_t table_find(const unsigned long long* t, uint32_t cap, const PoolView& V, K128 key, int len,
+                                               uint32_t* meta) {
+    uint32_t s = slot_of(key, cap);
+    for (uint32_t probes = 0; probes < cap; ++probes) {
+        const unsigned long long v = slot_load(t, s);
+        const uint32_t cur = (uint32_t)v;
+        if (cur == EMPTY32) return EMPTY32;
+        if (canonical(pv_kmer(V, cur, len), len) == key) { *meta = (uint32_t)(v >> 32); return s; }
+        s = s + 1 == cap ? 0 : s + 1;
+    }
+    return EMPTY32;
+}
+
+__device__ __forceinline__ uint32_t rev4(uint32_t b) {  // bit c -> bit 3-c
+    return ((b & 1) << 3) | ((b & 2) << 1) | ((b & 4) >> 1) | ((b & 8) >> 3);
+}
+__device__ __forceinline__ uint32_t out_bits(uint32_t meta, uint32_t d) { return d ? rev4((meta & M_IN) >> 4) : (meta & M_OUT); }
+__device__ __forceinline__ uint32_t in_bits(uint32_t meta, uint32_t d) { return d ? rev4(meta & M_OUT) : ((meta & M_IN) >> 4); }
+
+__device__ __forceinline__ uint32_t kbase(K128 v, int i) {
+    return i < 32 ? (uint32_t)(v.hi >> (62 - 2 * i)) & 3u : (uint32_t)(v.lo >> (62 - 2 * (i - 32))) & 3u;
+}
+// append base c after dropping the first base of a left-aligned len-mer
+__device__ __forceinline__ K128 shift_in(K128 v, uint32_t c, int len) {
+    K128 r;
+    r.hi = (v.hi << 2) | (v.lo >> 62);
+    r.lo = v.lo << 2;
+    const int i = len - 1;
+    if (i < 32) r.hi |= (uint64_t)c << (62 - 2 * i); else r.lo |= (uint64_t)c << (62 - 2 * (i - 32));
+    return mask_k(r, len);
+}
+// prepend base c, dropping the last base
+__device__ __forceinline__ K128 shift_in_front(K128 v, uint32_t c, int len) {
+    K128 r;
+    r.lo = (v.lo >> 2) | (v.hi << 62);
+    r.hi = (v.hi >> 2) | ((uint64_t)c << 62);
+    return mask_k(r, len);
+}
+
+__global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
+    extern __shared__ uint32_t pool_lds[];  // P.lds_words words: the gap's packed reads when they fit
+    __shared__ uint32_t s_cnt[4];  // [0] survivors  [1] emitted walks  [2] contig base  [3] error
+    __shared__ unsigned long long s_seq[2];  // [0] bases to emit  [1] global base offset
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t npos = P.read_len - P.k + 1;
+    const int k = (int)P.k, kv = (int)P.kv;
+    const uint32_t per = P.k - P.kv + 1;
+
+    for (uint32_t g = blockIdx.x; g < P.n_pools; g += gridDim.x) {
+        const uint64_t r0 = P.pool_off[g], r1 = P.pool_off[g + 1];
+        const uint32_t n_r = (uint32_t)(r1 - r0);
+        if (n_r == 0) continue;
+        const uint64_t n_inst64 = (uint64_t)n_r * npos;
+        const uint64_t inst_off = r0 * npos;
+        if (n_inst64 >= (1ull << 30) || (uint64_t)n_r * P.read_len >= 0xFFFFFFF0ull) {  // ids are 32-bit
+            if (tid == 0) P.gap_error[g] = 1;
+            continue;
+        }
+        const uint32_t n_inst = (uint32_t)n_inst64;
+        const uint32_t cap = 4 * n_inst;
+        unsigned long long* tab = P.table + 4 * inst_off;
+        uint32_t* surv = P.surv + 2 * inst_off;
+
+        // ---- stage the pool (LDS when it fits) and clear the tables
+        PoolView V;
+        V.rb = P.rb; V.L = P.read_len;
+        V.g32 = P.reads32; V.g_words = P.n_words; V.g_tail = P.tail_bytes;
+        V.first_byte = r0 * P.rb;
+        const uint64_t pool_bytes = (uint64_t)n_r * P.rb;
+        V.lds = pool_bytes + 24 <= (uint64_t)P.lds_words * 4;
+        V.w = pool_lds;
+        if (V.lds) {
+            const uint64_t w0 = V.first_byte >> 2;
+            const uint32_t sh = (uint32_t)(V.first_byte & 3) * 8;
+            const uint32_t nw = (uint32_t)((pool_bytes + 3) / 4);
+            for (uint32_t i = tid; i < nw + 6; i += ASM_THREADS) {
+                uint32_t v = 0;
+                if (i < nw) {
+                    const uint32_t a = asm_word(P.reads32, P.n_words, P.tail_bytes, w0 + i);
+                    const uint32_t b = sh ? asm_word(P.reads32, P.n_words, P.tail_bytes, w0 + i + 1) : 0;
+                    v = sh ? (a >> sh) | (b << (32 - sh)) : a;
+                    if (i == nw - 1 && (pool_bytes & 3)) v &= (1u << ((pool_bytes & 3) * 8)) - 1;
+                }
+                pool_lds[i] = v;
+            }
+        }
+        for (uint32_t i = tid; i < cap; i += ASM_THREADS) tab[i] = 0x00000000FFFFFFFFull;  // id EMPTY, meta 0
+        if (tid < 4) s_cnt[tid] = 0;
+        if (tid < 2) s_seq[tid] = 0;
+        __threadfence();
+        __syncthreads();
+
+        // ---- P1: count canonical k-mers
+        for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
+            const uint32_t r = inst_i / npos, p = inst_i - r * npos;
+            if (P.nmask) {
+                bool bad = false;
+                for (uint32_t q = p; q < p + P.k; ++q)
+                    if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
+                if (bad) continue;
+            }
+            const uint32_t inst = r * P.read_len + p;
+            const K128 key = canonical(pv_kmer(V, inst, k), k);
+            const uint32_t s = table_insert(tab, cap, V, key, inst, k);
+            if (s == EMPTY32) { s_cnt[3] = 1; continue; }
+            atomicAdd(slot_meta(tab, s), 1u);
+        }
+        __threadfence();
+        __syncthreads();
+
+        // ---- P2: survivors (count >= min_count) -> list; clear the table for the graph
+        for (uint32_t i0 = 0; i0 < cap; i0 += ASM_THREADS) {
+            const uint32_t i = i0 + tid;
+            bool keep = false;
+            uint32_t id = 0;
+            if (i < cap) {
+                const unsigned long long v = slot_load(tab, i);
+                id = (uint32_t)v;
+                keep = id != EMPTY32 && (uint32_t)(v >> 32) >= P.min_count;
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (bal) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_cnt[0], (uint32_t)__popcll(bal));
+                base = __shfl(base, 0);
+                if (keep) {
+                    const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
+                    surv[o] = id;
+                    if (P.cnt_keys && o < P.cnt_cap) {
+                        const K128 key = canonical(pv_kmer(V, id, k), k);
+                        const uint32_t c = (uint32_t)(slot_load(tab, i) >> 32);
+                        P.cnt_keys[2 * (uint64_t)o] = key.hi;
+                        P.cnt_keys[2 * (uint64_t)o + 1] = key.lo;
+                        P.cnt_counts[o] = c > 10000000u ? 10000000u : c;  // kmc -cs10000000 (assemble_gaps.py:96)
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (P.cnt_keys) {
+            if (tid == 0) { *P.n_contigs = s_cnt[0]; if (s_cnt[3]) P.gap_error[g] = 1; }
+            continue;
+        }
+        for (uint32_t i = tid; i < cap; i += ASM_THREADS) tab[i] = 0x00000000FFFFFFFFull;
+        __threadfence();
+        __syncthreads();
+        const uint32_t n_surv = s_cnt[0];
+
+        // ---- P3: nodes + edges
+        for (uint32_t j = tid; j < n_surv; j += ASM_THREADS) {
+            const uint32_t inst = surv[j];
+            const K128 tf = pv_kmer(V, inst, k);
+            K128 t = tf;
+            {   // use the canonical k-mer string (what kmc_dump lists); either strand yields the same graph
+                const K128 rc = revcomp(t, k);
+                if (rc < t) t = rc;
+            }
+            const bool fwd = tf == t;
+            uint32_t ps = EMPTY32, pd = 0;
+            for (uint32_t o = 0; o < per; ++o) {
+                // kv-mer at offset o of t
+                K128 a;
+                {
+                    const int sh = 2 * (int)o;
+                    a.hi = sh ? (t.hi << sh) | (t.lo >> (64 - sh)) : t.hi;
+                    a.lo = sh ? (t.lo << sh) : t.lo;
+                    a = mask_k(a, kv);
+                }
+                const K128 rc = revcomp(a, kv);
+                const uint32_t d = rc < a ? 1u : 0u;
+                const K128 A = d ? rc : a;
+                // instance id of this kv-mer: same read, offset shifted (orientation does not matter for the key)
+                const uint32_t ninst = fwd ? inst + o : inst + (per - 1 - o);
+                const uint32_t s = table_insert(tab, cap, V, A, ninst, kv);
+                if (s == EMPTY32) { s_cnt[3] = 1; break; }
+                atomicAdd(slot_meta(tab, s), 1u << M_MULT_SHIFT);
+                if (ps != EMPTY32) {  // edge prev -> this
+                    const uint32_t c_out = kbase(t, (int)(o - 1) + kv), c_in = kbase(t, (int)o - 1);
+                    atomicOr(slot_meta(tab, ps), pd ? (1u << (4 + (3 - c_out))) : (1u << c_out));
+                    atomicOr(slot_meta(tab, s), d ? (1u << (3 - c_in)) : (1u << (4 + c_in)));
+                }
+                ps = s; pd = d;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+
+        // ---- P4: unitig starts.  (a) in-degree != 1;  (b) successors of nodes with out-degree != 1
+        for (uint32_t i = tid; i < cap; i += ASM_THREADS) {
+            const unsigned long long v = slot_load(tab, i);
+            const uint32_t id = (uint32_t)v, meta = (uint32_t)(v >> 32);
+            if (id == EMPTY32) continue;
+            const K128 x = canonical(pv_kmer(V, id, kv), kv);
+            for (uint32_t d = 0; d < 2; ++d) {
+                if (__popc(in_bits(meta, d)) != 1) atomicOr(slot_meta(tab, i), d ? M_START1 : M_START0);
+                const uint32_t ob = out_bits(meta, d);
+                if (__popc(ob) > 1) {
+                    const K128 cur = d ? revcomp(x, kv) : x;
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        if (!(ob & (1u << c))) continue;
+                        const K128 y = shift_in(cur, c, kv);
+                        const K128 yr = revcomp(y, kv);
+                        const uint32_t dy = yr < y ? 1u : 0u;
+                        uint32_t m2;
+                        const uint32_t sy = table_find(tab, cap, V, dy ? yr : y, kv, &m2);
+                        if (sy != EMPTY32) atomicOr(slot_meta(tab, sy), dy ? M_START1 : M_START0);
+                    }
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+
+        // ---- P5a: walk every start; keep the walks that are emitted
+        for (uint32_t i = tid; i < cap; i += ASM_THREADS) {
+            const unsigned long long v = slot_load(tab, i);
+            const uint32_t id = (uint32_t)v, meta0 = (uint32_t)(v >> 32);
+            if (id == EMPTY32 || !(meta0 & (M_START0 | M_START1))) continue;
+            const K128 x = canonical(pv_kmer(V, id, kv), kv);
+            for (uint32_t d = 0; d < 2; ++d) {
+                if (!(meta0 & (d ? M_START1 : M_START0))) continue;
+                const K128 first = d ? revcomp(x, kv) : x;
+                K128 cur = first;
+                uint32_t meta = meta0, cd = d, nodes = 1;
+                for (;;) {
+                    const uint32_t ob = out_bits(meta, cd);
+                    if (__popc(ob) != 1) break;
+                    const uint32_t c = __ffs(ob) - 1;
+                    const K128 y = shift_in(cur, c, kv);
+                    const K128 yr = revcomp(y, kv);
+                    const uint32_t dy = yr < y ? 1u : 0u;
+                    uint32_t m2 = 0;
+                    const uint32_t sy = table_find(tab, cap, V, dy ? yr : y, kv, &m2);
+                    if (sy == EMPTY32 || __popc(in_bits(m2, dy)) != 1) break;
+                    cur = y; meta = m2; cd = dy; ++nodes;
+                }
+                const K128 opp = revcomp(cur, kv);
+                if (opp < first || nodes + P.kv - 1 < P.min_contig) continue;
+                const uint32_t e = atomicAdd(&s_cnt[1], 1u);
+                if (e >= n_inst) { s_cnt[3] = 1; continue; }
+                surv[2 * e] = (i << 1) | d;
+                surv[2 * e + 1] = nodes;
+                atomicAdd(&s_seq[0], (unsigned long long)(nodes + P.kv - 1));
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        const uint32_t n_emit = s_cnt[1] < n_inst ? s_cnt[1] : n_inst;
+        if (tid == 0) {
+            s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
+            s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
+            s_seq[0] = 0;
+            if (s_cnt[3]) P.gap_error[g] = 1;
+        }
+        __syncthreads();
+
+        // ---- P5b: re-walk the kept starts and write sequences
+        for (uint32_t e = tid; e < n_emit; e += ASM_THREADS) {
+            const uint32_t si = surv[2 * e] >> 1, d = surv[2 * e] & 1, nodes = surv[2 * e + 1];
+            const uint32_t len = nodes + P.kv - 1;
+            const unsigned long long off = s_seq[1] + atomicAdd(&s_seq[0], (unsigned long long)len);
+            const unsigned long long v = slot_load(tab, si);
+            const K128 x = canonical(pv_kmer(V, (uint32_t)v, kv), kv);
+            K128 cur = d ? revcomp(x, kv) : x;
+            uint32_t meta = (uint32_t)(v >> 32), cd = d, cov = meta >> M_MULT_SHIFT;
+            const bool room = off + len <= P.seq_cap;
+            if (room)
+                for (int q = 0; q < kv; ++q) P.seq[off + q] = "ACGT"[kbase(cur, q)];
+            for (uint32_t n = 1; n < nodes; ++n) {
+                const uint32_t c = __ffs(out_bits(meta, cd)) - 1;
+                const K128 y = shift_in(cur, c, kv);
+                const K128 yr = revcomp(y, kv);
+                const uint32_t dy = yr < y ? 1u : 0u;
+                uint32_t m2 = 0;
+                table_find(tab, cap, V, dy ? yr : y, kv, &m2);
+                if (room) P.seq[off + kv - 1 + n] = "ACGT"[c];
+                cur = y; meta = m2; cd = dy; cov += m2 >> M_MULT_SHIFT;
+            }
+            const uint32_t ci = s_cnt[2] + e;
+            if (ci < P.contig_cap) {
+                gf_contig ct;
+                ct.gap = g; ct.k = (uint16_t)P.k; ct.kv = (uint16_t)P.kv; ct.n_nodes = nodes; ct.length = len;
+                ct.cov_sum = cov; ct.reserved = 0; ct.seq_off = off;
+                P.contigs[ci] = ct;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
+                    size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig, void* d_contigs,
+                    size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len, void* d_gap_error,
+                    void* d_cnt_keys, void* d_cnt_counts, size_t cnt_cap) {
+    if (k < 16 || k > 64 || read_len < k || read_len > 1000) return GF_E_UNSUPPORTED;
+    if (!d_cnt_keys && (kv < 15 || kv >= k || !(kv & 1))) return GF_E_UNSUPPORTED;
+    if (n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull) return GF_E_INVAL;
+    const uint32_t npos = read_len - k + 1;
+    const uint64_t n_inst = (uint64_t)total_reads * npos;
+    int rc;
+    if ((rc = ensure(ctx, ctx->asm_table, std::max<uint64_t>(n_inst, 1) * 4 * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->asm_surv, std::max<uint64_t>(n_inst, 1) * 2 * 4))) return rc;
+    GF_HIP(ctx, hipMemsetAsync(d_n_contigs, 0, 4, ctx->stream));
+    GF_HIP(ctx, hipMemsetAsync(d_seq_len, 0, 8, ctx->stream));
+    if (n_pools) GF_HIP(ctx, hipMemsetAsync(d_gap_error, 0, n_pools * 4, ctx->stream));
+    if (n_pools == 0) return GF_OK;
+    AsmParams P;
+    const uint32_t rb = (uint32_t)((read_len + 3) / 4);
+    P.reads32 = (const uint32_t*)d_pool;
+    P.n_words = ((uint64_t)total_reads * rb) / 4;
+    P.tail_bytes = (uint32_t)(((uint64_t)total_reads * rb) & 3);
+    P.nmask = (const uint32_t*)d_nmask;
+    P.pool_off = (const uint64_t*)d_pool_off;
+    P.n_pools = (uint32_t)n_pools;
+    P.rb = rb; P.read_len = read_len; P.k = k; P.kv = kv; P.nmw = (read_len + 31) / 32;
+    P.min_count = min_count < 1 ? 1 : min_count;
+    P.min_contig = min_contig < 0 ? 0 : min_contig;
+    P.table = (unsigned long long*)ctx->asm_table.p;
+    P.surv = (uint32_t*)ctx->asm_surv.p;
+    P.contigs = (gf_contig*)d_contigs;
+    P.contig_cap = (uint32_t)contig_cap;
+    P.n_contigs = (uint32_t*)d_n_contigs;
+    P.seq = (char*)d_seq;
+    P.seq_cap = seq_cap;
+    P.seq_len = (unsigned long long*)d_seq_len;
+    P.gap_error = (uint32_t*)d_gap_error;
+    P.cnt_keys = (uint64_t*)d_cnt_keys;
+    P.cnt_counts = (uint32_t*)d_cnt_counts;
+    P.cnt_cap = (uint32_t)std::min<size_t>(cnt_cap, 0xFFFFFFFFu);
+    // staged-pool LDS: option asm_lds_pool_kb (default 36 KiB = ~970 reads of 150 bp, 4 workgroups per CU); larger pools
+    // are read from global memory
+    P.lds_words = std::min<uint32_t>(ASM_POOL_LDS_MAX_WORDS, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
+    const unsigned per_cu = std::max(1u, std::min(4u, (160u * 1024u) / (P.lds_words * 4 + 1024)));
+    const unsigned grid = (unsigned)std::min<size_t>(n_pools, (size_t)ctx->n_cu * per_cu);
+    {
+        LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
+        hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(ASM_THREADS), (size_t)P.lds_words * 4, ctx->stream, P);
+    }
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+}  // namespace gf

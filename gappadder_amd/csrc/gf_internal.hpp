@@ -65,13 +65,14 @@ struct gf_ctx {
     int bitmap_log2_override = 0;
     int screen_variant = 0;     // tuning: load mode / unroll of the filter kernel
     int screen_wg_per_cu = 0;
+    int asm_lds_pool_kb = 36;
     // tagger coarse bin map (rebuilt when dist2 changes)
     std::vector<uint32_t> bin_host;
     int bin_dist2 = -1, bin_shift = 0;
     uint32_t bin_words = 0;
 
     // scratch
-    gf::DevBuf cand, cand2, binmap, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, binmap, asm_table, asm_surv, counters, stage_in, stage_out, stage_aux, table;
     // timing
     bool timing = false;
     std::vector<gf::TimedLaunch> launches;
@@ -121,5 +122,11 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
                void* d_out, size_t cap, void* d_n_out);
 int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* table, size_t n_rows, void* d_out,
                     size_t cap, void* d_n_out);
+
+// assemble.hip
+int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
+                    size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig, void* d_contigs,
+                    size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len, void* d_gap_error,
+                    void* d_cnt_keys, void* d_cnt_counts, size_t cnt_cap);
 
 }  // namespace gf

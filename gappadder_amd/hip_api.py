@@ -106,6 +106,48 @@ class GapFill:
         self._chk(rc, "gf_tag_low_mapq")
         return out
 
+    def assemble(self, pool_packed, pool_off, read_len, kk, min_count=2, min_contig=40, n_mask=None):
+        """pool_packed: uint8 [total_reads, rb]; pool_off: n_pools+1 read offsets; kk: [(k, kv), ...].
+        Returns (contigs structured array (B.CONTIG), sequence bytes)."""
+        pool_packed = np.ascontiguousarray(pool_packed, dtype=np.uint8)
+        pool_off = np.ascontiguousarray(pool_off, dtype=np.uint64)
+        ks = np.asarray([a for a, _ in kk], dtype=np.int32)
+        kvs = np.asarray([b for _, b in kk], dtype=np.int32)
+        if n_mask is not None:
+            n_mask = np.ascontiguousarray(n_mask, dtype=np.uint32)
+        ccap, scap = 1024, 1 << 16
+        while True:
+            ctg = np.zeros(ccap, dtype=B.CONTIG)
+            seq = np.zeros(scap, dtype=np.uint8)
+            nc, sl = C.c_size_t(0), C.c_size_t(0)
+            rc = self._L.gf_assemble(self._h, B._p(pool_packed), B._p(n_mask), B._p(pool_off), len(pool_off) - 1, read_len,
+                                     B._p(ks), B._p(kvs), len(kk), min_count, min_contig, B._p(ctg), ccap, C.byref(nc),
+                                     B._p(seq), scap, C.byref(sl))
+            if rc == B.GF_E_NOSPACE:
+                ccap, scap = max(ccap, nc.value), max(scap, sl.value)
+                continue
+            self._chk(rc, "gf_assemble")
+            return ctg[:nc.value], seq[:sl.value].tobytes()
+
+    def count_kmers(self, pool_packed, read_len, k, min_count=2, n_mask=None):
+        """(kmers uint64 [n, 2] (hi, lo), counts uint32 [n]) ascending — the `kmc -k{k}` | `kmc_dump` listing."""
+        pool_packed = np.ascontiguousarray(pool_packed, dtype=np.uint8)
+        n = pool_packed.shape[0]
+        if n_mask is not None:
+            n_mask = np.ascontiguousarray(n_mask, dtype=np.uint32)
+        cap = 4096
+        while True:
+            km = np.zeros((cap, 2), dtype=np.uint64)
+            cn = np.zeros(cap, dtype=np.uint32)
+            m = C.c_size_t(0)
+            rc = self._L.gf_count_kmers(self._h, B._p(pool_packed), B._p(n_mask), n, read_len, k, min_count, B._p(km), B._p(cn),
+                                        cap, C.byref(m))
+            if rc == B.GF_E_NOSPACE:
+                cap = m.value
+                continue
+            self._chk(rc, "gf_count_kmers")
+            return km[:m.value], cn[:m.value]
+
     # ---- timing -------------------------------------------------------------------------------------
     def timing(self, on=True):
         self._chk(self._L.gf_timing_enable(self._h, 1 if on else 0), "gf_timing_enable")

@@ -133,6 +133,40 @@ int gf_tag_low_mapq(gf_ctx* ctx, const gf_alnrec* recs, size_t n, const gf_dpos*
 int gf_tag_low_mapq_dev(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* table, size_t n_rows,
                         void* d_out, size_t cap, void* d_n_out);
 
+/* ---- a-6: per-gap local assembly (run_assembly, assemble_gaps.py:82-136: `kmc -k{k}` | `kmc_dump` | `velveth {kv}` |
+ * `velvetg -min_contig_lgth 40`).  Pools are packed reads (gf_pack_reads layout) concatenated per gap: pool g owns
+ * reads pool_off[g] .. pool_off[g+1]-1.  The k-mer counting and graph arithmetic of the reference live in un-vendored
+ * KMC and Velvet, so the semantics are DEFINED by this build (DESIGN.md "Assembly semantics", oracle/gp_oracle.c):
+ * canonical k-mers with count >= min_count; nodes = their canonical kv-mers (kv odd, 15 <= kv < k <= 64); contigs =
+ * unitigs of >= min_contig bases, each reported once in the orientation min(seq, revcomp(seq)). */
+typedef struct {
+    uint32_t gap;      /* index of the pool */
+    uint16_t k, kv;
+    uint32_t n_nodes;  /* kv-mers in the contig (Velvet's NODE_n_length_{n_nodes}) */
+    uint32_t length;   /* bases = n_nodes + kv - 1 */
+    uint32_t cov_sum;  /* sum over the contig's nodes of their multiplicity among the surviving k-mers (cov = cov_sum / n_nodes) */
+    uint32_t reserved;
+    uint64_t seq_off;  /* offset of the contig's ASCII bases in the sequence buffer */
+} gf_contig;
+
+/* host variant: every (k_list[i], kv_list[i]) pair in turn (assemble_gaps.py:87-122); contigs sorted by
+ * (gap, pair index, length descending, sequence ascending).  Returns GF_E_NOSPACE with the needed counts in
+ * *n_contigs / *seq_len when a capacity is too small. */
+int gf_assemble(gf_ctx* ctx, const uint8_t* pool_packed, const uint32_t* pool_n_mask_or_null, const uint64_t* pool_off,
+                size_t n_pools, int read_len, const int* k_list, const int* kv_list, int n_k, int min_count, int min_contig,
+                gf_contig* contigs, size_t contig_cap, size_t* n_contigs, char* seq, size_t seq_cap, size_t* seq_len);
+/* device variant, one (k, kv) pair: total_reads = pool_off[n_pools] (upper bound used to size the workspace);
+ * d_n_contigs: u32, d_seq_len: u64, d_gap_error: n_pools x u32 (1 = that pool overflowed an internal table).
+ * Contig order is unspecified. */
+int gf_assemble_dev(gf_ctx* ctx, const void* d_pool_packed, const void* d_pool_n_mask_or_null, const void* d_pool_off,
+                    size_t n_pools, size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig,
+                    void* d_contigs, size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len,
+                    void* d_gap_error);
+/* counted canonical k-mers of ONE pool, ascending (what `kmc_dump -ci0` lists after `kmc -k{k}`, assemble_gaps.py:96-102).
+ * kmers: 2 x uint64 per k-mer (hi, lo), left-aligned KmerUtils layout; counts capped at 10^7 (-cs10000000). */
+int gf_count_kmers(gf_ctx* ctx, const uint8_t* pool_packed, const uint32_t* pool_n_mask_or_null, size_t n_reads,
+                   int read_len, int k, int min_count, uint64_t* kmers, uint32_t* counts, size_t cap, size_t* n_out);
+
 /* ---- device memory + timing helpers (so a ctypes host needs no other HIP binding) ---------------------- */
 int gf_dev_alloc(gf_ctx* ctx, size_t bytes, void** d_ptr);
 int gf_dev_free(gf_ctx* ctx, void* d_ptr);

@@ -39,6 +39,10 @@ def lib():
         L.or_pack_kmer64.argtypes = [C.c_char_p, i32]
         L.or_unpack_reads.restype = None
         L.or_unpack_reads.argtypes = [vp, sz, i32, vp]
+        L.or_count_kmers.restype = sz
+        L.or_count_kmers.argtypes = [C.c_char_p, sz, i32, i32, i32, vp, vp, vp, sz]
+        L.or_assemble_pool.restype = sz
+        L.or_assemble_pool.argtypes = [C.c_char_p, sz, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
         L.or_synth_pairs.restype = None
         L.or_synth_pairs.argtypes = [vp, C.c_uint64, sz, vp, vp]
         L.or_synth_layout.restype = None
@@ -127,3 +131,31 @@ def synth_layout(cfg):
     b = blob.tobytes().decode()
     flanks = [(b[int(off[2 * g]):int(off[2 * g + 1])], b[int(off[2 * g + 1]):int(off[2 * g + 2])]) for g in range(n)]
     return gaps, flanks
+
+
+def count_kmers(reads_blob, read_len, k, min_count=2):
+    """[(hi, lo, count)] ascending = the `kmc -k{k}` | `kmc_dump` listing."""
+    n = len(reads_blob) // read_len
+    cap = max(16, n * (read_len - k + 1))
+    hi = np.zeros(cap, np.uint64); lo = np.zeros(cap, np.uint64); cnt = np.zeros(cap, np.uint32)
+    m = lib().or_count_kmers(bytes(reads_blob), n, read_len, k, min_count, _p(hi), _p(lo), _p(cnt), cap)
+    return hi[:m], lo[:m], cnt[:m]
+
+
+def assemble_pool(reads_blob, read_len, k, kv, min_count=2, min_contig=40):
+    """[(sequence, n_nodes, cov_sum)] sorted by (-length, sequence)."""
+    n = len(reads_blob) // read_len
+    cap = max(16, n * (read_len - k + 1))
+    nn = np.zeros(cap, np.uint32); ln = np.zeros(cap, np.uint32); cv = np.zeros(cap, np.uint32)
+    scap = max(1024, 8 * n * read_len)
+    seq = np.zeros(scap, np.uint8)
+    need = C.c_size_t(0)
+    m = lib().or_assemble_pool(bytes(reads_blob), n, read_len, k, kv, min_count, min_contig, _p(nn), _p(ln), _p(cv), cap,
+                               _p(seq), scap, C.byref(need))
+    assert m <= cap and need.value <= scap
+    out, off = [], 0
+    b = seq.tobytes()
+    for i in range(m):
+        out.append((b[off:off + int(ln[i])].decode(), int(nn[i]), int(cv[i])))
+        off += int(ln[i])
+    return out

@@ -268,3 +268,193 @@ void or_synth_layout(const void* c_, or_gap* gaps, char* flank_ascii, uint64_t* 
         }
     flank_off[2 * g] = off;
 }
+
+/* ------------------------------------------------------------------ a-6: count + de Bruijn unitigs (PARITY UNPINNED)
+ * Data flow of run_assembly (assemble_gaps.py:82-136): `kmc -k{k}` (canonical k-mers, k-mers with non-ACGT skipped,
+ * default min count 2) | `kmc_dump` (ascending) | every surviving k-mer becomes one Velvet read | `velveth {kv}`,
+ * `velvetg -min_contig_lgth 40`.  KMC and Velvet are not in the reference tree, so this build DEFINES stage 2
+ * (DESIGN.md "Assembly semantics"):
+ *   nodes  = canonical kv-mers of the surviving k-mers (kv odd), multiplicity = number of (k-mer, offset) occurrences;
+ *   edges  = consecutive kv-mers inside a surviving k-mer;
+ *   oriented node (x,d): sequence x (d=0) or revcomp(x) (d=1); it is a unitig START iff its in-degree != 1 or its
+ *            unique predecessor has out-degree != 1; a walk extends while out-degree == 1 and the successor's in-degree == 1;
+ *   each unitig is found from both ends; the walk whose first kv-mer is <= the first kv-mer of the opposite walk is
+ *   emitted (so the contig is min(seq, revcomp(seq)) whenever the two first kv-mers differ);
+ *   contigs shorter than min_contig bases are dropped; isolated cycles (no start) are not reported; no tip clipping,
+ *   no bubble popping (v1).  Output order: length descending, then sequence ascending.
+ */
+typedef struct { uint64_t hi, lo; } k128;
+static inline int k128_lt(k128 a, k128 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+static inline int k128_eq(k128 a, k128 b) { return a.hi == b.hi && a.lo == b.lo; }
+static int k128_cmp(const void* a, const void* b) {
+    const k128 *x = a, *y = b;
+    return k128_lt(*x, *y) ? -1 : k128_lt(*y, *x) ? 1 : 0;
+}
+static inline unsigned k128_base(k128 v, int i) { return i < 32 ? (unsigned)(v.hi >> (62 - 2 * i)) & 3u : (unsigned)(v.lo >> (62 - 2 * (i - 32))) & 3u; }
+static inline void k128_set(k128* v, int i, unsigned b) {
+    if (i < 32) v->hi |= (uint64_t)b << (62 - 2 * i); else v->lo |= (uint64_t)b << (62 - 2 * (i - 32));
+}
+static k128 k128_rc(k128 v, int len) {
+    k128 r = {0, 0};
+    for (int i = 0; i < len; ++i) k128_set(&r, len - 1 - i, 3u - k128_base(v, i));
+    return r;
+}
+static k128 k128_sub(k128 v, int off, int len) { /* bases off .. off+len-1 */
+    k128 r = {0, 0};
+    for (int i = 0; i < len; ++i) k128_set(&r, i, k128_base(v, off + i));
+    return r;
+}
+static k128 k128_canon(k128 v, int len, int* flipped) {
+    k128 r = k128_rc(v, len);
+    if (k128_lt(r, v)) { if (flipped) *flipped = 1; return r; }
+    if (flipped) *flipped = 0;
+    return v;
+}
+
+/* canonical k-mers with count >= min_count, ascending; returns the number (may exceed cap) */
+size_t or_count_kmers(const char* reads, size_t n_reads, int L, int k, int min_count, uint64_t* hi, uint64_t* lo,
+                      uint32_t* cnt, size_t cap) {
+    size_t tot = n_reads * (size_t)(L - k + 1), n = 0;
+    k128* a = malloc((tot + 1) * sizeof(k128));
+    for (size_t r = 0; r < n_reads; ++r)
+        for (int p = 0; p + k <= L; ++p)
+            if (canon_kmer(reads + r * L + p, k, &a[n].hi, &a[n].lo)) ++n;
+    qsort(a, n, sizeof(k128), k128_cmp);
+    size_t w = 0;
+    for (size_t i = 0; i < n;) {
+        size_t j = i;
+        while (j < n && k128_eq(a[j], a[i])) ++j;
+        if ((long)(j - i) >= min_count) {
+            if (w < cap) { hi[w] = a[i].hi; lo[w] = a[i].lo; cnt[w] = (uint32_t)((j - i) > 10000000 ? 10000000 : (j - i)); }
+            ++w;
+        }
+        i = j;
+    }
+    free(a);
+    return w;
+}
+
+typedef struct { k128 key; uint32_t mult; uint8_t out, in; } or_node;
+static long node_find(const or_node* nd, size_t n, k128 key) {
+    size_t a = 0, b = n;
+    while (a < b) { size_t m = (a + b) / 2; if (k128_lt(nd[m].key, key)) a = m + 1; else b = m; }
+    return (a < n && k128_eq(nd[a].key, key)) ? (long)a : -1;
+}
+static inline unsigned bits_out(const or_node* nd, long i, int d) { /* oriented out-edges, bit c = next base c */
+    if (!d) return nd[i].out;
+    unsigned r = 0;
+    for (int c = 0; c < 4; ++c) if (nd[i].in & (1u << (3 - c))) r |= 1u << c;
+    return r;
+}
+static inline unsigned bits_in(const or_node* nd, long i, int d) {
+    if (!d) return nd[i].in;
+    unsigned r = 0;
+    for (int c = 0; c < 4; ++c) if (nd[i].out & (1u << (3 - c))) r |= 1u << c;
+    return r;
+}
+static inline int popc4(unsigned b) { return (b & 1) + ((b >> 1) & 1) + ((b >> 2) & 1) + ((b >> 3) & 1); }
+static inline int ctz4(unsigned b) { return (b & 1) ? 0 : (b & 2) ? 1 : (b & 4) ? 2 : 3; }
+
+typedef struct { uint32_t n_nodes, length, cov_sum; char* seq; } or_ctg;
+static int ctg_cmp(const void* a, const void* b) {
+    const or_ctg *x = a, *y = b;
+    if (x->length != y->length) return x->length > y->length ? -1 : 1;
+    return strcmp(x->seq, y->seq);
+}
+
+/* contigs of one pool.  seq_out receives the sequences back to back (no terminators); per contig n_nodes[], length[],
+ * cov_sum[].  Returns the number of contigs (may exceed cap; *seq_need = bytes needed). */
+size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig,
+                        uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
+                        size_t* seq_need) {
+    *seq_need = 0;
+    if (kv >= k || !(kv & 1) || k > 64 || L < k) return 0;
+    size_t tot = n_reads * (size_t)(L - k + 1);
+    uint64_t* hi = malloc((tot + 1) * 8); uint64_t* lo = malloc((tot + 1) * 8); uint32_t* cn = malloc((tot + 1) * 4);
+    size_t ns = or_count_kmers(reads, n_reads, L, k, min_count, hi, lo, cn, tot + 1);
+    const int per = k - kv + 1;
+    k128* keys = malloc((ns * per + 1) * sizeof(k128));
+    size_t nk = 0;
+    for (size_t s = 0; s < ns; ++s) {
+        k128 t = {hi[s], lo[s]};
+        for (int o = 0; o < per; ++o) keys[nk++] = k128_canon(k128_sub(t, o, kv), kv, NULL);
+    }
+    qsort(keys, nk, sizeof(k128), k128_cmp);
+    or_node* nd = malloc((nk + 1) * sizeof(or_node));
+    size_t nn = 0;
+    for (size_t i = 0; i < nk;) {
+        size_t j = i;
+        while (j < nk && k128_eq(keys[j], keys[i])) ++j;
+        nd[nn].key = keys[i]; nd[nn].mult = (uint32_t)(j - i); nd[nn].out = nd[nn].in = 0; ++nn;
+        i = j;
+    }
+    for (size_t s = 0; s < ns; ++s) { /* edges */
+        k128 t = {hi[s], lo[s]};
+        for (int o = 0; o + 1 < per; ++o) {
+            int da, db;
+            k128 A = k128_canon(k128_sub(t, o, kv), kv, &da), B = k128_canon(k128_sub(t, o + 1, kv), kv, &db);
+            unsigned c_out = k128_base(t, o + kv), c_in = k128_base(t, o);
+            long ia = node_find(nd, nn, A), ib = node_find(nd, nn, B);
+            if (!da) nd[ia].out |= 1u << c_out; else nd[ia].in |= 1u << (3 - c_out);
+            if (!db) nd[ib].in |= 1u << c_in; else nd[ib].out |= 1u << (3 - c_in);
+        }
+    }
+    or_ctg* ctg = malloc((2 * nn + 1) * sizeof(or_ctg));
+    size_t nc = 0;
+    for (size_t i = 0; i < nn; ++i)
+        for (int d = 0; d < 2; ++d) {
+            /* start? */
+            unsigned ib = bits_in(nd, (long)i, d);
+            int start = popc4(ib) != 1;
+            k128 cur = d ? k128_rc(nd[i].key, kv) : nd[i].key;
+            if (!start) {
+                k128 p = {0, 0};
+                k128_set(&p, 0, (unsigned)ctz4(ib));
+                for (int q = 1; q < kv; ++q) k128_set(&p, q, k128_base(cur, q - 1));
+                int dp;
+                k128 P = k128_canon(p, kv, &dp);
+                long ip = node_find(nd, nn, P);
+                start = popc4(bits_out(nd, ip, dp)) != 1;
+            }
+            if (!start) continue;
+            /* walk */
+            size_t capb = 64;
+            char* seq = malloc(capb + kv + 2);
+            size_t len = 0;
+            for (int q = 0; q < kv; ++q) seq[len++] = "ACGT"[k128_base(cur, q)];
+            uint32_t nodes = 1, cov = nd[i].mult;
+            long ci = (long)i; int cd = d;
+            for (;;) {
+                unsigned ob = bits_out(nd, ci, cd);
+                if (popc4(ob) != 1) break;
+                unsigned c = (unsigned)ctz4(ob);
+                k128 y = {0, 0};
+                for (int q = 0; q + 1 < kv; ++q) k128_set(&y, q, k128_base(cur, q + 1));
+                k128_set(&y, kv - 1, c);
+                int dy;
+                k128 Y = k128_canon(y, kv, &dy);
+                long iy = node_find(nd, nn, Y);
+                if (popc4(bits_in(nd, iy, dy)) != 1) break;
+                if (len + 2 > capb + kv) { capb *= 2; seq = realloc(seq, capb + kv + 2); }
+                seq[len++] = "ACGT"[c];
+                ++nodes; cov += nd[iy].mult;
+                ci = iy; cd = dy; cur = y;
+            }
+            seq[len] = 0;
+            /* emit rule: first kv-mer of this walk <= first kv-mer of the opposite walk (= revcomp of the last kv-mer) */
+            k128 opp = k128_rc(cur, kv), first = d ? k128_rc(nd[i].key, kv) : nd[i].key;
+            if (k128_lt(opp, first) || (int)len < min_contig) { free(seq); continue; }
+            ctg[nc].n_nodes = nodes; ctg[nc].length = (uint32_t)len; ctg[nc].cov_sum = cov; ctg[nc].seq = seq; ++nc;
+        }
+    qsort(ctg, nc, sizeof(or_ctg), ctg_cmp);
+    size_t off = 0;
+    for (size_t c = 0; c < nc; ++c) {
+        if (c < cap) { n_nodes[c] = ctg[c].n_nodes; length[c] = ctg[c].length; cov_sum[c] = ctg[c].cov_sum; }
+        if (off + ctg[c].length <= seq_cap && c < cap) memcpy(seq_out + off, ctg[c].seq, ctg[c].length);
+        off += ctg[c].length;
+        free(ctg[c].seq);
+    }
+    *seq_need = off;
+    free(ctg); free(nd); free(keys); free(hi); free(lo); free(cn);
+    return nc;
+}

@@ -26,6 +26,12 @@ size_t or_screen_reads(const char* reads_ascii, size_t n_reads, int read_len, co
 /* KmerUtils.cpp:61-69 */
 uint64_t or_pack_kmer64(const char* seq, int k);
 void or_unpack_reads(const uint8_t* packed, size_t n_reads, int read_len, char* ascii);
+/* a-6 (PARITY UNPINNED, semantics in gp_oracle.c): counted canonical k-mers (kmc | kmc_dump), and the contigs of one pool */
+size_t or_count_kmers(const char* reads, size_t n_reads, int L, int k, int min_count, uint64_t* hi, uint64_t* lo,
+                      uint32_t* cnt, size_t cap);
+size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig,
+                        uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
+                        size_t* seq_need);
 /* synthetic workload, definition in include/gf_synth.h (cfg = gf_synth_cfg) */
 void or_synth_pairs(const void* cfg, uint64_t first_pair, size_t n_pairs, uint8_t* packed, or_alnrec* recs_or_null);
 void or_synth_layout(const void* cfg, or_gap* gaps, char* flank_ascii, uint64_t* flank_off);
