@@ -71,6 +71,10 @@ def lib():
         "gf_assemble": (i32, [vp, vp, vp, vp, sz, i32, vp, vp, i32, i32, i32, vp, sz, szp, vp, sz, szp]),
         "gf_assemble_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, i32, i32, i32, i32, vp, sz, vp, vp, sz, vp, vp]),
         "gf_count_kmers": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp, sz, szp]),
+        "gf_pool_keys_reset": (i32, [vp, vp]),
+        "gf_pool_keys_from_screen_dev": (i32, [vp, vp, vp, sz, i32, vp, sz, vp]),
+        "gf_pool_keys_from_tags_dev": (i32, [vp, vp, vp, vp, sz, vp, sz, vp, sz, vp]),
+        "gf_build_pools_dev": (i32, [vp, vp, sz, i32, vp, vp, sz, vp, sz, vp, vp, vp]),
         "gf_dev_alloc": (i32, [vp, sz, C.POINTER(vp)]),
         "gf_dev_free": (i32, [vp, vp]),
         "gf_memcpy_h2d": (i32, [vp, vp, vp, sz]),

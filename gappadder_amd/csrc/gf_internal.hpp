@@ -72,7 +72,7 @@ struct gf_ctx {
     uint32_t bin_words = 0;
 
     // scratch
-    gf::DevBuf cand, cand2, binmap, asm_table, asm_surv, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, binmap, asm_table, asm_surv, rowgap, pool_ws, counters, stage_in, stage_out, stage_aux, table;
     // timing
     bool timing = false;
     std::vector<gf::TimedLaunch> launches;

@@ -1,0 +1,276 @@
+// pools.hip — per-gap read pools on the device.
+//
+// The reference joins read IDs against whole FASTQ files: {readId -> set(gapKey)} from the discordant lists and ALL
+// lines of the scaffold lists (run_multi_threads_discordant.py:153-185), then streams left.fq and right.fq and appends
+// matching records to gap_reads/{gapKey}.fastq (:209-241, 283-316).  With reads addressed by index (read = 2*pair + mate)
+// that is: the SET of (gap, read) keys, per gap ordered by (mate, pair) = left-file stream order then right-file order,
+// and a gather of the packed reads.  Keys come from the k-mer screen (gf_hit), the alignment tagger and the second hop
+// (gf_taghit: target read = record's read, or its mate when to_mate is set).
+//
+//   keys -> per-gap histogram -> exclusive scan -> scatter into gap segments -> per-gap LDS bitonic sort + unique
+//        -> exclusive scan of the unique counts (= pool_off) -> gather of packed reads
+#include "gf_internal.hpp"
+
+namespace gf {
+
+constexpr uint32_t POOL_SORT_MAX = 16384;  // keys of one gap sorted in LDS (64 KiB)
+
+__global__ void keys_from_screen_kernel(const gf_hit* hits, const uint32_t* n_hits, uint32_t hit_cap, int pairs,
+                                        unsigned long long* keys, uint32_t key_cap, uint32_t* n_keys) {
+    const uint32_t n = *n_hits < hit_cap ? *n_hits : hit_cap;
+    const uint32_t per = pairs ? 2 : 1;
+    __shared__ uint32_t s_base;
+    // one block-wide reservation per pass: hits are dense here, no per-element global atomics
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const uint32_t cnt = (n - i0 < blockDim.x ? n - i0 : blockDim.x) * per;
+        if (threadIdx.x == 0) s_base = atomicAdd(n_keys, cnt);
+        __syncthreads();
+        const uint32_t i = i0 + threadIdx.x;
+        if (i < n) {
+            const gf_hit h = hits[i];
+            const uint32_t o = s_base + threadIdx.x * per;
+            if (o < key_cap) keys[o] = ((unsigned long long)h.gap << 32) | h.read;
+            if (pairs && o + 1 < key_cap) keys[o + 1] = ((unsigned long long)h.gap << 32) | (h.read ^ 1u);
+        }
+        __syncthreads();
+    }
+}
+
+// tagger hits: gap = index into the gap array (row_gap == null) or via the second hop's row -> gap map
+__global__ void keys_from_tags_kernel(const gf_alnrec* recs, const gf_taghit* hits, const uint32_t* n_hits, uint32_t hit_cap,
+                                      const uint32_t* row_gap, unsigned long long* keys, uint32_t key_cap, uint32_t* n_keys) {
+    const uint32_t n = *n_hits < hit_cap ? *n_hits : hit_cap;
+    __shared__ uint32_t s_base;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const uint32_t cnt = n - i0 < blockDim.x ? n - i0 : blockDim.x;
+        if (threadIdx.x == 0) s_base = atomicAdd(n_keys, cnt);
+        __syncthreads();
+        const uint32_t i = i0 + threadIdx.x;
+        if (i < n) {
+            const gf_taghit h = hits[i];
+            const uint32_t read = (uint32_t)recs[h.rec].read ^ (h.to_mate ? 1u : 0u);
+            const uint32_t gap = row_gap ? row_gap[h.gap] : h.gap;
+            const uint32_t o = s_base + threadIdx.x;
+            if (o < key_cap) keys[o] = ((unsigned long long)gap << 32) | read;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void pool_hist_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap, uint32_t n_gaps,
+                                 uint32_t* cnt) {
+    const uint32_t n = *n_keys < key_cap ? *n_keys : key_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t g = (uint32_t)(keys[i] >> 32);
+        if (g < n_gaps) atomicAdd(&cnt[g], 1u);
+    }
+}
+
+// single-block exclusive scan of cnt[0..n) into off[0..n] (64-bit when OUT64); optionally zeroes `zero`
+template <bool OUT64>
+__global__ __launch_bounds__(1024) void pool_scan_kernel(const uint32_t* cnt, uint32_t n, void* off_out, uint32_t* zero) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (n + 1023) / 1024;
+    const uint32_t a = tid * chunk, b = a + chunk < n ? a + chunk : n;
+    unsigned long long s = 0;
+    for (uint32_t i = a; i < b; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const unsigned long long v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = tid ? part[tid - 1] : 0;
+    for (uint32_t i = a; i < b; ++i) {
+        if (OUT64) ((unsigned long long*)off_out)[i] = run; else ((uint32_t*)off_out)[i] = (uint32_t)run;
+        run += cnt[i];
+        if (zero) zero[i] = 0;
+    }
+    if (tid == 1023) {
+        if (OUT64) ((unsigned long long*)off_out)[n] = part[1023]; else ((uint32_t*)off_out)[n] = (uint32_t)part[1023];
+    }
+}
+
+__global__ void pool_scatter_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap, uint32_t n_gaps,
+                                    const uint32_t* seg_off, uint32_t* cursor, uint32_t* seg) {
+    const uint32_t n = *n_keys < key_cap ? *n_keys : key_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i];
+        const uint32_t g = (uint32_t)(k >> 32), read = (uint32_t)k;
+        if (g >= n_gaps) continue;
+        const uint32_t p = seg_off[g] + atomicAdd(&cursor[g], 1u);
+        seg[p] = ((read & 1u) << 31) | (read >> 1);  // (mate, pair): left-file order, then right-file order
+    }
+}
+
+// one workgroup per gap: bitonic sort of the gap's keys in LDS, duplicates dropped, written back in place
+__global__ __launch_bounds__(256) void pool_sort_unique_kernel(uint32_t n_gaps, const uint32_t* seg_off, uint32_t* seg,
+                                                              uint32_t* ucnt, uint32_t* error) {
+    extern __shared__ uint32_t sk[];
+    __shared__ uint32_t s_n;
+    for (uint32_t g = blockIdx.x; g < n_gaps; g += gridDim.x) {
+        const uint32_t a = seg_off[g], n = seg_off[g + 1] - a;
+        if (n == 0) { if (threadIdx.x == 0) ucnt[g] = 0; continue; }
+        if (n > POOL_SORT_MAX) { if (threadIdx.x == 0) { ucnt[g] = 0; atomicAdd(error, 1u); } continue; }
+        uint32_t m = 1;
+        while (m < n) m <<= 1;
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) sk[i] = i < n ? seg[a + i] : 0xFFFFFFFFu;
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        for (uint32_t size = 2; size <= m; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
+                    const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const uint32_t x = sk[lo], y = sk[hi];
+                    if ((x > y) == up) { sk[lo] = y; sk[hi] = x; }
+                }
+                __syncthreads();
+            }
+        // unique (sorted): keep sk[i] if it differs from sk[i-1]; order-preserving compaction by prefix count
+        for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+            const uint32_t i = i0 + threadIdx.x;
+            const bool keep = i < n && (i == 0 || sk[i] != sk[i - 1]);
+            // block-wide exclusive count of `keep` below this thread, in wave order
+            const unsigned long long bal = __ballot(keep);
+            __shared__ uint32_t wcnt[4];
+            const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            if (lane == 0) wcnt[w] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t base = s_n;
+            for (uint32_t q = 0; q < w; ++q) base += wcnt[q];
+            if (keep) seg[a + base + __popcll(bal & ((1ull << lane) - 1))] = sk[i];
+            __syncthreads();
+            if (threadIdx.x == 0) s_n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) ucnt[g] = s_n;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_gather_kernel(uint32_t n_gaps, const uint32_t* seg_off, const uint32_t* seg,
+                                                         const unsigned long long* pool_off, const uint8_t* reads, uint32_t rb,
+                                                         uint64_t n_reads, uint8_t* pool, uint64_t pool_cap_reads,
+                                                         uint32_t* pool_ids) {
+    // one wave per pooled read: rb bytes copied by the lanes
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned long long total = pool_off[n_gaps];
+    for (unsigned long long j = wave; j < total && j < pool_cap_reads; j += n_waves) {
+        // gap of pooled read j: binary search in pool_off
+        uint32_t lo = 0, hi = n_gaps;
+        while (lo + 1 < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pool_off[mid] <= j) lo = mid; else hi = mid;
+        }
+        const uint32_t key = seg[seg_off[lo] + (uint32_t)(j - pool_off[lo])];
+        const uint32_t read = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
+        if (read < n_reads) {
+            const uint8_t* src = reads + (uint64_t)read * rb;
+            uint8_t* dst = pool + j * rb;
+            for (uint32_t b = lane; b < rb; b += 64) dst[b] = src[b];
+        }
+        if (lane == 0 && pool_ids) pool_ids[j] = read;
+    }
+}
+
+}  // namespace gf
+
+using namespace gf;
+
+extern "C" {
+
+int gf_pool_keys_reset(gf_ctx* ctx, void* d_n_keys) {
+    if (!ctx || !d_n_keys) return GF_E_INVAL;
+    GF_HIP(ctx, hipMemsetAsync(d_n_keys, 0, 4, ctx->stream));
+    return GF_OK;
+}
+
+int gf_pool_keys_from_screen_dev(gf_ctx* ctx, const void* d_hits, const void* d_n_hits, size_t hit_cap, int pairs, void* d_keys,
+                                 size_t key_cap, void* d_n_keys) {
+    if (!ctx || !d_hits || !d_n_hits || !d_keys || !d_n_keys || hit_cap > 0xFFFFFFFFull || key_cap > 0xFFFFFFFFull) return GF_E_INVAL;
+    LaunchTimer tm(ctx, GF_KERNEL_POOL);
+    hipLaunchKernelGGL(keys_from_screen_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_hit*)d_hits,
+                       (const uint32_t*)d_n_hits, (uint32_t)hit_cap, pairs, (unsigned long long*)d_keys, (uint32_t)key_cap,
+                       (uint32_t*)d_n_keys);
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_pool_keys_from_tags_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits, size_t hit_cap,
+                               const gf_dpos* lowmapq_table_or_null, size_t n_rows, void* d_keys, size_t key_cap, void* d_n_keys) {
+    if (!ctx || !d_recs || !d_taghits || !d_n_taghits || !d_keys || !d_n_keys || hit_cap > 0xFFFFFFFFull || key_cap > 0xFFFFFFFFull)
+        return GF_E_INVAL;
+    const uint32_t* d_row_gap = nullptr;
+    if (lowmapq_table_or_null) {  // second-hop rows name (src_scaffold, 1-based gap in scaffold) -> index into the gap array
+        std::vector<uint32_t> off(ctx->n_scaffolds + 1, 0), rg(n_rows);
+        for (const gf_gap& g : ctx->gaps) off[g.scaffold + 1]++;
+        for (uint32_t s = 0; s < ctx->n_scaffolds; ++s) off[s + 1] += off[s];
+        for (size_t r = 0; r < n_rows; ++r) {
+            const gf_dpos& t = lowmapq_table_or_null[r];
+            if (t.src_scaffold >= ctx->n_scaffolds || t.src_gap == 0 || off[t.src_scaffold] + t.src_gap - 1 >= off[t.src_scaffold + 1])
+                return GF_E_INVAL;
+            rg[r] = off[t.src_scaffold] + t.src_gap - 1;
+        }
+        int rc = ensure(ctx, ctx->rowgap, n_rows * 4 + 64);
+        if (rc) return rc;
+        GF_HIP(ctx, hipMemcpyAsync(ctx->rowgap.p, rg.data(), n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
+        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        d_row_gap = (const uint32_t*)ctx->rowgap.p;
+    }
+    LaunchTimer tm(ctx, GF_KERNEL_POOL);
+    hipLaunchKernelGGL(keys_from_tags_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_alnrec*)d_recs,
+                       (const gf_taghit*)d_taghits, (const uint32_t*)d_n_taghits, (uint32_t)hit_cap, d_row_gap,
+                       (unsigned long long*)d_keys, (uint32_t)key_cap, (uint32_t*)d_n_keys);
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, int read_len, const void* d_keys,
+                       const void* d_n_keys, size_t key_cap, void* d_pool_packed, size_t pool_cap_reads, void* d_pool_off,
+                       void* d_pool_read_ids, void* d_error) {
+    if (!ctx || !d_keys || !d_n_keys || !d_pool_off || !d_error || (n_reads && !d_packed_reads) ||
+        (pool_cap_reads && !d_pool_packed) || key_cap > 0xFFFFFFFFull || read_len <= 0)
+        return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t ng = (uint32_t)ctx->gaps.size();
+    const uint32_t rb = (uint32_t)gf_packed_read_bytes(read_len);
+    int rc;
+    // workspace: cnt[ng] cursor[ng] ucnt[ng] seg_off[ng+1] | seg[key_cap]
+    const size_t w_small = ((size_t)(4 * (size_t)ng + 8) * 4 + 255) & ~(size_t)255;
+    if ((rc = ensure(ctx, ctx->pool_ws, w_small + key_cap * 4 + 256))) return rc;
+    uint32_t* cnt = (uint32_t*)ctx->pool_ws.p;
+    uint32_t* cursor = cnt + ng;
+    uint32_t* ucnt = cursor + ng;
+    uint32_t* seg_off = ucnt + ng;
+    uint32_t* seg = (uint32_t*)((uint8_t*)ctx->pool_ws.p + w_small);
+    GF_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)ng * 4 + 4, ctx->stream));
+    GF_HIP(ctx, hipMemsetAsync(d_error, 0, 4, ctx->stream));
+    LaunchTimer tm(ctx, GF_KERNEL_POOL);
+    const unsigned blocks = ctx->n_cu * 4;
+    if (ng) {
+        hipLaunchKernelGGL(pool_hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_keys,
+                           (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, cnt);
+    }
+    hipLaunchKernelGGL(pool_scan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, cnt, ng, (void*)seg_off, cursor);
+    if (ng) {
+        hipLaunchKernelGGL(pool_scatter_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_keys,
+                           (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, seg_off, cursor, seg);
+        hipLaunchKernelGGL(pool_sort_unique_kernel, dim3(std::min<unsigned>(ng, ctx->n_cu * 2)), dim3(256), POOL_SORT_MAX * 4,
+                           ctx->stream, ng, seg_off, seg, ucnt, (uint32_t*)d_error);
+    }
+    hipLaunchKernelGGL(pool_scan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, ucnt, ng, d_pool_off, (uint32_t*)nullptr);
+    if (ng && pool_cap_reads) {
+        hipLaunchKernelGGL(pool_gather_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ng, seg_off, seg,
+                           (const unsigned long long*)d_pool_off, (const uint8_t*)d_packed_reads, rb, (uint64_t)n_reads,
+                           (uint8_t*)d_pool_packed, (uint64_t)pool_cap_reads, (uint32_t*)d_pool_read_ids);
+    }
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+}  // extern "C"

@@ -167,6 +167,28 @@ int gf_assemble_dev(gf_ctx* ctx, const void* d_pool_packed, const void* d_pool_n
 int gf_count_kmers(gf_ctx* ctx, const uint8_t* pool_packed, const uint32_t* pool_n_mask_or_null, size_t n_reads,
                    int read_len, int k, int min_count, uint64_t* kmers, uint32_t* counts, size_t cap, size_t* n_out);
 
+/* ---- a-4 / a-5 on the device: per-gap read pools.  The reference joins read IDs against whole FASTQ files
+ * ({readId -> set(gapKey)}, run_multi_threads_discordant.py:153-185; stream + append, :209-241, 283-316; `cat` across
+ * libraries, merge_reads.py:43-51).  With reads addressed by index (read = 2*pair + mate) that is the SET of (gap, read)
+ * keys, per gap ordered by (mate, pair) = left-file stream order then right-file stream order, and a gather.
+ * Keys are uint64 (gap << 32 | read); *d_n_keys is a device u32 that the key producers advance. */
+int gf_pool_keys_reset(gf_ctx* ctx, void* d_n_keys);
+/* screen hits -> keys; pairs != 0 also adds each hit's mate ("pulls candidate read pairs", north_star) */
+int gf_pool_keys_from_screen_dev(gf_ctx* ctx, const void* d_hits, const void* d_n_hits, size_t hit_cap, int pairs,
+                                 void* d_keys, size_t key_cap, void* d_n_keys);
+/* tagger hits -> keys (target read = the record's read, or its mate when to_mate is set: the reference writes
+ * discordant/unmap lines to the MATE's list, collect_reads_for_gaps.py:126-159).  For second-hop hits pass the row
+ * table so that hit.gap (a row) resolves to its (src_scaffold, src_gap). */
+int gf_pool_keys_from_tags_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits,
+                               size_t hit_cap, const gf_dpos* lowmapq_table_or_null, size_t n_rows, void* d_keys,
+                               size_t key_cap, void* d_n_keys);
+/* keys -> d_pool_off (n_gaps+1 x u64), d_pool_packed (pool_cap_reads reads), d_pool_read_ids (u32 per pooled read, or
+ * null); *d_error (u32) counts gaps whose key list exceeded the LDS sort (16384 keys).  d_pool_off[n_gaps] > pool_cap_reads
+ * means the pool buffer was too small (reads beyond it are not written). */
+int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, int read_len, const void* d_keys,
+                       const void* d_n_keys, size_t key_cap, void* d_pool_packed, size_t pool_cap_reads, void* d_pool_off,
+                       void* d_pool_read_ids, void* d_error);
+
 /* ---- device memory + timing helpers (so a ctypes host needs no other HIP binding) ---------------------- */
 int gf_dev_alloc(gf_ctx* ctx, size_t bytes, void** d_ptr);
 int gf_dev_free(gf_ctx* ctx, void* d_ptr);

@@ -222,3 +222,77 @@ def test_synthetic_generator_matches_oracle_bit_for_bit(gf):
     blob = CO.unpack_reads(packed, 150)
     assert _same(gf.screen_reads(packed, 150, 31), CO.screen_reads(blob, 150, f2, 31))
     assert _same(gf.tag_alignments(recs, 300, 30), CO.tag_alignments(recs, g2, 300, 30))
+
+
+def test_device_pools_follow_the_reference_fastq_join_order(gf):
+    """gf_build_pools_dev: keys from screen (+mates), tagger and second hop -> per-gap pools ordered (mate, pair)."""
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=31, n_pairs=9000)
+    L, n = c["L"], c["n_reads"]
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    packed, _ = GapFill.pack_reads(c["reads_blob"], L)
+    recs = c["recs"]
+    shits = gf.screen_reads(packed, L, 31)
+    thits = gf.tag_alignments(recs, 300, 30)
+    # second hop table from the discordant tagger hits (run_multi_threads_discordant.py:47-103)
+    rows = sorted((int(recs[h["rec"]]["mate_ref"]), int(recs[h["rec"]]["mate_pos"]), int(c["gaps"][h["gap"]]["scaffold"]),
+                   int(c["gaps"][h["gap"]]["idx_in_scaffold"])) for h in thits if h["kind"] == B.KIND_DISCORDANT)
+    table = RU.dpos_array(rows).astype(B.DPOS)
+    lhits = gf.tag_low_mapq(recs, table)
+    assert len(lhits) > 0
+    # expected: the set of (gap, read) keys, per gap sorted by (mate, pair)
+    keys = set()
+    for h in shits:
+        keys.add((int(h["gap"]), int(h["read"])))
+        keys.add((int(h["gap"]), int(h["read"]) ^ 1))
+    for h in thits:
+        keys.add((int(h["gap"]), int(recs[h["rec"]]["read"]) ^ int(h["to_mate"])))
+    gidx = {(int(g["scaffold"]), int(g["idx_in_scaffold"])): i for i, g in enumerate(c["gaps"])}
+    for h in lhits:
+        keys.add((gidx[(int(table[h["gap"]]["src_scaffold"]), int(table[h["gap"]]["src_gap"]))], int(recs[h["rec"]]["read"])))
+    exp = {}
+    for g, r in keys:
+        exp.setdefault(g, []).append(r)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.frombuffer(a.tobytes(), dtype=np.uint8).copy()).to(dev)
+    d_reads, d_recs = t(packed), t(recs)
+    d_sh, d_th, d_lh = t(shits), t(thits), t(lhits)
+    cnts = torch.tensor([len(shits), len(thits), len(lhits), 0], dtype=torch.int32, device=dev)
+    key_cap = 4 * (2 * len(shits) + len(thits) + len(lhits)) + 16
+    d_keys = torch.zeros(key_cap, dtype=torch.int64, device=dev)
+    d_nk = torch.zeros(4, dtype=torch.int32, device=dev)
+    pool_cap = len(keys) + 8
+    d_pool = torch.zeros(pool_cap * 38, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(len(c["gaps"]) + 1, dtype=torch.int64, device=dev)
+    d_ids = torch.zeros(pool_cap, dtype=torch.int32, device=dev)
+    d_err = torch.zeros(4, dtype=torch.int32, device=dev)
+    Lb, h = B.lib(), gf.handle
+    assert Lb.gf_pool_keys_reset(h, d_nk.data_ptr()) == 0
+    assert Lb.gf_pool_keys_from_screen_dev(h, d_sh.data_ptr(), cnts.data_ptr(), len(shits), 1, d_keys.data_ptr(), key_cap, d_nk.data_ptr()) == 0
+    assert Lb.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_th.data_ptr(), cnts.data_ptr() + 4, len(thits), None, 0,
+                                         d_keys.data_ptr(), key_cap, d_nk.data_ptr()) == 0
+    assert Lb.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_lh.data_ptr(), cnts.data_ptr() + 8, len(lhits), B._p(table), len(table),
+                                         d_keys.data_ptr(), key_cap, d_nk.data_ptr()) == 0
+    assert Lb.gf_build_pools_dev(h, d_reads.data_ptr(), n, L, d_keys.data_ptr(), d_nk.data_ptr(), key_cap, d_pool.data_ptr(), pool_cap,
+                                 d_off.data_ptr(), d_ids.data_ptr(), d_err.data_ptr()) == 0
+    gf.sync()
+    torch.cuda.synchronize()
+    assert int(d_err[0]) == 0 and int(d_nk[0]) == 2 * len(shits) + len(thits) + len(lhits)
+    off = d_off.cpu().numpy()
+    ids = d_ids.cpu().numpy().astype(np.uint32)
+    pool = d_pool.cpu().numpy().reshape(pool_cap, 38)
+    assert off[-1] == len(keys)
+    for g in range(len(c["gaps"])):
+        want = sorted(exp.get(g, []), key=lambda r: (r & 1, r >> 1))
+        got = ids[off[g]:off[g + 1]].tolist()
+        assert got == want, g
+        assert (pool[off[g]:off[g + 1]] == packed[want]).all()
+    # and the pools assemble like the oracle says
+    ctg, seq = gf.assemble(pool[:off[-1]], off.astype(np.uint64), L, [(31, 29)])
+    blob = CO.unpack_reads(pool[:off[-1]], L)
+    for g in range(len(c["gaps"])):
+        e = CO.assemble_pool(blob[int(off[g]) * L:int(off[g + 1]) * L], L, 31, 29)
+        gseqs = [seq[int(x["seq_off"]):int(x["seq_off"]) + int(x["length"])].decode() for x in ctg if x["gap"] == g]
+        assert gseqs == [x[0] for x in e]
