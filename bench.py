@@ -74,15 +74,59 @@ def main():
     hit_cap = max(1 << 20, n_reads // 8)
     d_hits = torch.empty(hit_cap * 8, dtype=torch.uint8, device=dev)
     d_thits = torch.empty(hit_cap * 12, dtype=torch.uint8, device=dev)
-    d_cnt = torch.zeros(16, dtype=torch.int32, device=dev)
+    d_lhits = torch.empty(hit_cap * 12, dtype=torch.uint8, device=dev)
+    key_cap = 4 * hit_cap
+    d_keys = torch.empty(key_cap, dtype=torch.int64, device=dev)
+    pool_cap = 2 * hit_cap
+    d_pool = torch.empty(pool_cap * rb + 64, dtype=torch.uint8, device=dev)
+    d_pool_off = torch.zeros(len(gaps) + 1, dtype=torch.int64, device=dev)
+    d_pool_ids = torch.empty(pool_cap, dtype=torch.int32, device=dev)
+    contig_cap, seq_cap = 64 * len(gaps) + 1024, 16384 * len(gaps) + (1 << 20)
+    d_ctg = torch.empty(contig_cap * 32, dtype=torch.uint8, device=dev)
+    d_seq = torch.empty(seq_cap, dtype=torch.uint8, device=dev)
+    d_gap_err = torch.zeros(len(gaps), dtype=torch.int32, device=dev)
+    # counters (device u32 unless noted): 0 screen hits, 4 tagger hits, 8 second-hop hits, 12 keys, 16 contigs,
+    # 20 (u64) contig bases, 24 pool-sort overflow
+    d_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
+    cp = d_cnt.data_ptr()
     gf.sync()
+    kv = k - 2
+    h = gf.handle
+
+    def recruit():
+        rc = lib.gf_screen_reads_dev(h, d_reads.data_ptr(), None, n_reads, L, k, 1, d_hits.data_ptr(), hit_cap, cp)
+        assert rc == 0, rc
+        rc = lib.gf_tag_alignments_dev(h, d_recs.data_ptr(), n_reads, 300, 30, 250, 30, d_thits.data_ptr(), hit_cap, cp + 16)
+        assert rc == 0, rc
+
+    # second-hop table (run_multi_threads_discordant.py:19-122 inverts the discordant lines and runs sort(1) on the host;
+    # the table depends only on the batch, so it is built once here and re-used by every step)
+    recruit()
+    gf.sync()
+    n_th = int(d_cnt[4])
+    th = np.frombuffer(d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
+    disc = th[th["kind"] == B.KIND_DISCORDANT]
+    recs_d = np.frombuffer(d_recs.view(torch.int64).view(-1, 4)[torch.from_numpy(disc["rec"].astype(np.int64)).to(dev)]
+                           .cpu().numpy().tobytes(), dtype=B.ALNREC)
+    rows = np.zeros(len(disc), dtype=B.DPOS)
+    rows["mate_scaffold"], rows["mate_pos"] = recs_d["mate_ref"], recs_d["mate_pos"]
+    rows["src_scaffold"], rows["src_gap"] = gaps["scaffold"][disc["gap"]], gaps["idx_in_scaffold"][disc["gap"]]
+    rows = np.sort(rows, order=["mate_scaffold", "mate_pos", "src_scaffold", "src_gap"])
 
     def step():
-        rc = lib.gf_screen_reads_dev(gf.handle, d_reads.data_ptr(), None, n_reads, L, k, 1, d_hits.data_ptr(), hit_cap,
-                                     d_cnt.data_ptr())
+        recruit()
+        rc = lib.gf_tag_low_mapq_dev(h, d_recs.data_ptr(), n_reads, B._p(rows), len(rows), d_lhits.data_ptr(), hit_cap, cp + 32)
         assert rc == 0, rc
-        rc = lib.gf_tag_alignments_dev(gf.handle, d_recs.data_ptr(), n_reads, 300, 30, 250, 30, d_thits.data_ptr(),
-                                       hit_cap, d_cnt.data_ptr() + 16)
+        assert lib.gf_pool_keys_reset(h, cp + 48) == 0
+        assert lib.gf_pool_keys_from_screen_dev(h, d_hits.data_ptr(), cp, hit_cap, 1, d_keys.data_ptr(), key_cap, cp + 48) == 0
+        assert lib.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_thits.data_ptr(), cp + 16, hit_cap, None, 0,
+                                              d_keys.data_ptr(), key_cap, cp + 48) == 0
+        assert lib.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_lhits.data_ptr(), cp + 32, hit_cap, B._p(rows), len(rows),
+                                              d_keys.data_ptr(), key_cap, cp + 48) == 0
+        assert lib.gf_build_pools_dev(h, d_reads.data_ptr(), n_reads, L, d_keys.data_ptr(), cp + 48, key_cap, d_pool.data_ptr(),
+                                      pool_cap, d_pool_off.data_ptr(), d_pool_ids.data_ptr(), cp + 96) == 0
+        rc = lib.gf_assemble_dev(h, d_pool.data_ptr(), None, d_pool_off.data_ptr(), len(gaps), pool_cap, L, k, kv, 2, 40,
+                                 d_ctg.data_ptr(), contig_cap, cp + 64, d_seq.data_ptr(), seq_cap, cp + 80, d_gap_err.data_ptr())
         assert rc == 0, rc
 
     def barrier():
@@ -101,50 +145,73 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    t_filter, n_filter = gf.kernel_time(B.KERNEL_SCREEN)
-    t_verify, _ = gf.kernel_time(B.KERNEL_VERIFY)
-    t_tag, n_tag = gf.kernel_time(B.KERNEL_TAG)
+    kt = {name: gf.kernel_time(idx) for name, idx in (("screen_filter", B.KERNEL_SCREEN), ("screen_verify", B.KERNEL_VERIFY),
+                                                      ("tag_alignments", B.KERNEL_TAG), ("tag_low_mapq", B.KERNEL_LOWMAPQ),
+                                                      ("pools", B.KERNEL_POOL), ("assemble", B.KERNEL_ASSEMBLE))}
+    t_filter, n_filter = kt["screen_filter"]
     gf.timing(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     cnt = d_cnt.cpu().numpy()
-    n_hits, n_thits = int(cnt[0]), int(cnt[4])
+    n_hits, n_thits, n_lhits, n_keys, n_ctg = int(cnt[0]), int(cnt[4]), int(cnt[8]), int(cnt[12]), int(cnt[16])
+    n_seq = int(cnt[20:22].view(np.uint64)[0])
+    pool_off = d_pool_off.cpu().numpy()
+    assert int(cnt[24]) == 0 and int(d_gap_err.sum()) == 0 and pool_off[-1] <= pool_cap and n_ctg <= contig_cap and n_seq <= seq_cap
+    ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
+    if world > 1:
+        # the only collective of the path: gather the assembled sequences of every rank's shard on rank 0 (RCCL)
+        nb = torch.tensor([n_seq], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, nb)
+        mx = int(max(int(x.item()) for x in sizes))
+        buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+        buf[:n_seq] = d_seq[:n_seq]
+        parts = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, parts, dst=0)
 
     out = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         filt_ms = t_filter / max(1, n_filter)
         achieved = n_reads * rb / (filt_ms * 1e-3) / 1e9
+        phases = {name: t / max(1, n_filter) for name, (t, _) in kt.items()}
+        gaps_with_contig = int(len(np.unique(ctg["gap"])))
         out = {
             "metric": "reads_screened_per_s", "value": world * n_reads / (dt / args.steps), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: 1000 gaps x 2 kb in 50 x 5 Mb scaffolds, %d x %d-bp read records (+ as many "
-                                   "32-B alignment records) per GPU, k=%d, IS 300/30; step = k-mer screen + alignment tagger"
-                                   % (n_reads, L, k),
-                       "reads_per_gpu": n_reads, "gaps": int(len(gaps)), "k": k, "sharding": "reads sharded, gaps replicated"},
+            "config": {"workload": "C2: 1000 gaps x 2 kb in 50 x 5 Mb scaffolds, %d x %d-bp read records (+ as many 32-B alignment "
+                                   "records) per GPU, k=%d kv=%d, IS 300/30; step = k-mer screen + alignment tagger + second hop + "
+                                   "per-gap pools + per-gap assembly" % (n_reads, L, k, kv),
+                       "reads_per_gpu": n_reads, "gaps": int(len(gaps)), "k": k, "kv": kv,
+                       "sharding": "reads sharded over ranks, gaps replicated; RCCL only gathers the assembled sequences"},
+            "gaps_per_s": world * len(gaps) / (dt / args.steps),
             "roofline": {"bound": "hbm", "kernel": "screen_filter_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": n_reads * rb, "avg_launch_ms": filt_ms,
                          "frac_of_measured_copy_6290": achieved / 6290.0},
-            "phases_ms": {"screen_filter": filt_ms, "screen_verify": t_verify / max(1, n_filter),
-                          "tag_alignments": t_tag / max(1, n_tag)},
-            "tagger_gbs": n_reads * 32 / (t_tag / max(1, n_tag) * 1e-3) / 1e9,
-            "hits": {"screen": n_hits, "tagger": n_thits},
+            "phases_ms": phases,
+            "tagger_gbs": n_reads * 32 / (phases["tag_alignments"] * 1e-3) / 1e9,
+            "counts": {"screen_hits": n_hits, "tagger_hits": n_thits, "second_hop_hits": n_lhits, "pool_keys": n_keys,
+                       "pooled_reads": int(pool_off[-1]), "contigs": n_ctg, "contig_bases": n_seq,
+                       "gaps_with_contig": gaps_with_contig},
         }
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, d_hits, n_hits, gf, B)
+            out["cpu_baseline"] = cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, d_pool, pool_off,
+                                               ctg, d_seq, n_seq, dt / args.steps, n_reads, B)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, d_hits, n_hits, gf, B):
-    """The oracle (C restatement, OpenMP over all host cores) on the first --cpu-sample-reads reads of rank 0's
-    shard: same screen + tagger work per read.  Also the checker: GPU hits on that prefix must equal the oracle's."""
+def cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, d_pool, pool_off, ctg, d_seq, n_seq, gpu_step_s,
+                 n_reads, B):
+    """The oracle (oracle/gp_oracle.c, OpenMP over all host cores; kind "port") on a bounded sample of the same step:
+    k-mer screen + alignment tagger on the first --cpu-sample-reads reads of rank 0's shard, and the assembly of the first
+    gaps' pools.  Also the checker: the GPU's hits on that prefix and its contigs for those gaps must equal the oracle's."""
     from oracle import c_oracle as CO
     n_s = min(args.cpu_sample_reads, args.reads) // 2 * 2
     cores = os.cpu_count() or 1
@@ -154,15 +221,34 @@ def cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, d_hits, n_hits, gf, 
     t0 = time.perf_counter()
     ohits = CO.screen_reads(blob, L, flanks, k, 1, 0, cores)
     t1 = time.perf_counter()
-    othits = CO.tag_alignments(recs, gaps, 300, 30)
+    CO.tag_alignments(recs, gaps, 300, 30)
     t2 = time.perf_counter()
     hits = np.frombuffer(d_hits[:n_hits * 8].cpu().numpy().tobytes(), dtype=B.HIT)
     sub = np.sort(hits[hits["read"] < n_s], order=["gap", "read"])
     ok = len(sub) == len(ohits) and sub.tobytes() == ohits.astype(B.HIT).tobytes()
-    return {"value": n_s / (t2 - t0), "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of rank 0's shard: k-mer screen %.2f s + alignment tagger %.2f s, "
-                      "OpenMP %d threads, oracle/gp_oracle.c" % (n_s, t1 - t0, t2 - t1, cores),
-            "parity_on_sample": bool(ok), "sample_hits": int(len(ohits))}
+    # assembly sample: the first gaps' pools exactly as the GPU built them
+    n_g = min(len(gaps), 64)
+    rb = (L + 3) // 4
+    pool = d_pool[:int(pool_off[n_g]) * rb].cpu().numpy().reshape(-1, rb)
+    pblob = CO.unpack_reads(pool, L)
+    seq = d_seq[:n_seq].cpu().numpy().tobytes()
+    t3 = time.perf_counter()
+    exp = [CO.assemble_pool(pblob[int(pool_off[g]) * L:int(pool_off[g + 1]) * L], L, k, kv) for g in range(n_g)]
+    t4 = time.perf_counter()
+    ok_asm = True
+    for g in range(n_g):
+        mine = sorted((seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode(), int(c["n_nodes"]), int(c["cov_sum"]))
+                      for c in ctg[ctg["gap"] == g])
+        ok_asm = ok_asm and mine == sorted(exp[g])
+    # whole-step CPU time extrapolated from the two samples (recruit scales with reads, assembly with gaps)
+    cpu_step = (t2 - t0) * (n_reads / n_s) + (t4 - t3) * (len(gaps) / n_g)
+    return {"value": n_reads / cpu_step, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "recruit: first %d reads of rank 0's shard (k-mer screen %.2f s + alignment tagger %.2f s, OpenMP %d threads); "
+                      "assembly: pools of the first %d gaps (%.2f s, 1 thread); value = reads / (sample times scaled to the whole "
+                      "step); oracle/gp_oracle.c" % (n_s, t1 - t0, t2 - t1, cores, n_g, t4 - t3),
+            "recruit_reads_per_s": n_s / (t2 - t0), "assembly_gaps_per_s": n_g / (t4 - t3),
+            "parity_on_sample": bool(ok and ok_asm), "parity_recruit": bool(ok), "parity_assembly": bool(ok_asm),
+            "sample_hits": int(len(ohits)), "sample_contigs": int(sum(len(e) for e in exp))}
 
 
 if __name__ == "__main__":

@@ -115,7 +115,7 @@ void gf_destroy(gf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
-    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->binmap, &ctx->asm_table, &ctx->asm_surv, &ctx->rowgap, &ctx->pool_ws, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->binmap, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->rowgap, &ctx->pool_ws, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
         if (b->p) (void)hipFree(b->p);
     if (ctx->d_gaps) (void)hipFree(ctx->d_gaps);
     if (ctx->d_scaf_off) (void)hipFree(ctx->d_scaf_off);
@@ -147,6 +147,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         return GF_OK;
     }
     if (!strcmp(name, "screen_variant")) { ctx->screen_variant = (int)value; return GF_OK; }
+    if (!strcmp(name, "asm_dbg_ptr")) { ctx->asm_dbg = (void*)(uintptr_t)value; return GF_OK; }
     if (!strcmp(name, "asm_lds_pool_kb")) { ctx->asm_lds_pool_kb = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_wg_per_cu")) { ctx->screen_wg_per_cu = (int)value; return GF_OK; }
     return GF_E_INVAL;
@@ -167,6 +168,8 @@ int gf_set_gaps(gf_ctx* ctx, const gf_gap* gaps, size_t n_gaps, uint32_t n_scaff
     ctx->index.clear();
     ctx->gaps.assign(gaps, gaps + n_gaps);
     ctx->bin_dist2 = -1;
+    ctx->low_rows.clear();
+    ctx->rowgap_rows.clear();
     ctx->n_scaffolds = n_scaffolds;
     ctx->flank_left.assign(n_gaps, std::string());
     ctx->flank_right.assign(n_gaps, std::string());

@@ -15,8 +15,8 @@
 
 namespace gf {
 
-constexpr uint32_t ASM_THREADS = 256;
-constexpr uint32_t ASM_POOL_LDS_MAX_WORDS = 36 * 1024;  // at most 144 KiB of staged reads per workgroup
+constexpr uint32_t ASM_THREADS = 1024;  // one workgroup per CU: the phases are latency-bound loops over the gap's items
+constexpr uint32_t ASM_LDS_MAX_WORDS = 38 * 1024;  // 152 KiB of dynamic LDS: staged reads, then per-node arrays
 
 struct AsmParams {
     const uint32_t* reads32;   // packed pool reads as little-endian words
@@ -28,7 +28,8 @@ struct AsmParams {
     uint32_t rb, read_len, k, kv, nmw;
     uint32_t min_count, min_contig;
     unsigned long long* table; // 4 slots per k-mer instance: low 32 = instance id, high 32 = count / node meta
-    uint32_t* surv;            // 2 words per instance: survivor list, then (start, n_nodes) records of emitted walks
+    uint32_t* surv;            // 2 words per instance: slot lists, survivor list, node instance ids, emitted-walk records
+    uint32_t* nodes;           // 3 words per instance: per-node meta + succ[2] when they do not fit in LDS
     gf_contig* contigs;
     uint32_t contig_cap;
     uint32_t* n_contigs;
@@ -41,6 +42,7 @@ struct AsmParams {
     uint32_t* cnt_counts;
     uint32_t cnt_cap;
     uint32_t lds_words;        // dynamic LDS given to the staged pool
+    unsigned long long* dbg;   // diagnostic builds only: 8 wall-clock stamps per gap (100 MHz), or null
 };
 
 // node meta bits (high word of a table slot in the graph phases)
@@ -108,13 +110,14 @@ __device__ __forceinline__ unsigned long long slot_load(const unsigned long long
 
 // find-or-insert the canonical `len`-mer `key` (instance `inst`); returns the slot or EMPTY32 when the table is full
 __device__ __forceinline__ uint32_t table_insert(unsigned long long* t, uint32_t cap, const PoolView& V, K128 key, uint32_t inst,
-                                                 int len) {
+                                                 int len, bool* fresh) {
     uint32_t s = slot_of(key, cap);
+    *fresh = false;
     for (uint32_t probes = 0; probes < cap; ++probes) {
         uint32_t cur = __hip_atomic_load(slot_id(t, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == EMPTY32) {
             cur = atomicCAS(slot_id(t, s), EMPTY32, inst);
-            if (cur == EMPTY32) return s;
+            if (cur == EMPTY32) { *fresh = true; return s; }
         }
         if (cur == inst || canonical(pv_kmer(V, cur, len), len) == key) return s;
         s = s + 1 == cap ? 0 : s + 1;
@@ -161,9 +164,11 @@ __device__ __forceinline__ K128 shift_in_front(K128 v, uint32_t c, int len) {
     return mask_k(r, len);
 }
 
+#define ASM_STAMP(n) do { if (P.dbg && tid == 0) P.dbg[(uint64_t)g * 8 + (n)] = wall_clock64(); } while (0)
+
 __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
     extern __shared__ uint32_t pool_lds[];  // P.lds_words words: the gap's packed reads when they fit
-    __shared__ uint32_t s_cnt[4];  // [0] survivors  [1] emitted walks  [2] contig base  [3] error
+    __shared__ uint32_t s_cnt[8];  // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes
     __shared__ unsigned long long s_seq[2];  // [0] bases to emit  [1] global base offset
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         V.g32 = P.reads32; V.g_words = P.n_words; V.g_tail = P.tail_bytes;
         V.first_byte = r0 * P.rb;
         const uint64_t pool_bytes = (uint64_t)n_r * P.rb;
-        V.lds = pool_bytes + 24 <= (uint64_t)P.lds_words * 4;
+        V.lds = pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / 3;  // at most a third: the node arrays want the rest
         V.w = pool_lds;
         if (V.lds) {
             const uint64_t w0 = V.first_byte >> 2;
@@ -209,13 +214,15 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 pool_lds[i] = v;
             }
         }
-        for (uint32_t i = tid; i < cap; i += ASM_THREADS) tab[i] = 0x00000000FFFFFFFFull;  // id EMPTY, meta 0
-        if (tid < 4) s_cnt[tid] = 0;
+        ASM_STAMP(0);
+        // the table slice is all-EMPTY here: the workspace is cleared when allocated and every gap resets the slots it used
+        if (tid < 8) s_cnt[tid] = 0;
         if (tid < 2) s_seq[tid] = 0;
-        __threadfence();
         __syncthreads();
+        uint32_t* list_a = surv;           // P1: slots of distinct k-mers   P3..P5: slots of nodes
+        uint32_t* list_b = surv + n_inst;  // P2: surviving instances        P5: (start, n_nodes) of emitted walks
 
-        // ---- P1: count canonical k-mers
+        // ---- P1: count canonical k-mers; remember each distinct k-mer's slot
         for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
             const uint32_t r = inst_i / npos, p = inst_i - r * npos;
             if (P.nmask) {
@@ -226,22 +233,29 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             }
             const uint32_t inst = r * P.read_len + p;
             const K128 key = canonical(pv_kmer(V, inst, k), k);
-            const uint32_t s = table_insert(tab, cap, V, key, inst, k);
+            bool fresh;
+            const uint32_t s = table_insert(tab, cap, V, key, inst, k, &fresh);
             if (s == EMPTY32) { s_cnt[3] = 1; continue; }
+            if (fresh) list_a[atomicAdd(&s_cnt[4], 1u)] = s;
             atomicAdd(slot_meta(tab, s), 1u);
         }
         __threadfence();
         __syncthreads();
+        const uint32_t n_dist = s_cnt[4];
+        ASM_STAMP(1);
 
-        // ---- P2: survivors (count >= min_count) -> list; clear the table for the graph
-        for (uint32_t i0 = 0; i0 < cap; i0 += ASM_THREADS) {
+        // ---- P2: survivors (count >= min_count) -> list; the used slots are reset for the graph phase
+        for (uint32_t i0 = 0; i0 < n_dist; i0 += ASM_THREADS) {
             const uint32_t i = i0 + tid;
             bool keep = false;
-            uint32_t id = 0;
-            if (i < cap) {
-                const unsigned long long v = slot_load(tab, i);
+            uint32_t id = 0, c = 0;
+            if (i < n_dist) {
+                const uint32_t sl = list_a[i];
+                const unsigned long long v = slot_load(tab, sl);
                 id = (uint32_t)v;
-                keep = id != EMPTY32 && (uint32_t)(v >> 32) >= P.min_count;
+                c = (uint32_t)(v >> 32);
+                keep = c >= P.min_count;
+                tab[sl] = 0x00000000FFFFFFFFull;
             }
             const unsigned long long bal = __ballot(keep);
             if (bal) {
@@ -250,10 +264,9 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 base = __shfl(base, 0);
                 if (keep) {
                     const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
-                    surv[o] = id;
+                    list_b[o] = id;
                     if (P.cnt_keys && o < P.cnt_cap) {
                         const K128 key = canonical(pv_kmer(V, id, k), k);
-                        const uint32_t c = (uint32_t)(slot_load(tab, i) >> 32);
                         P.cnt_keys[2 * (uint64_t)o] = key.hi;
                         P.cnt_keys[2 * (uint64_t)o + 1] = key.lo;
                         P.cnt_counts[o] = c > 10000000u ? 10000000u : c;  // kmc -cs10000000 (assemble_gaps.py:96)
@@ -261,19 +274,19 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 }
             }
         }
+        __threadfence();
         __syncthreads();
         if (P.cnt_keys) {
             if (tid == 0) { *P.n_contigs = s_cnt[0]; if (s_cnt[3]) P.gap_error[g] = 1; }
+            __syncthreads();
             continue;
         }
-        for (uint32_t i = tid; i < cap; i += ASM_THREADS) tab[i] = 0x00000000FFFFFFFFull;
-        __threadfence();
-        __syncthreads();
         const uint32_t n_surv = s_cnt[0];
+        ASM_STAMP(2);
 
-        // ---- P3: nodes + edges
+        // ---- P3: nodes + edges; remember each node's slot
         for (uint32_t j = tid; j < n_surv; j += ASM_THREADS) {
-            const uint32_t inst = surv[j];
+            const uint32_t inst = list_b[j];
             const K128 tf = pv_kmer(V, inst, k);
             K128 t = tf;
             {   // use the canonical k-mer string (what kmc_dump lists); either strand yields the same graph
@@ -296,8 +309,13 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const K128 A = d ? rc : a;
                 // instance id of this kv-mer: same read, offset shifted (orientation does not matter for the key)
                 const uint32_t ninst = fwd ? inst + o : inst + (per - 1 - o);
-                const uint32_t s = table_insert(tab, cap, V, A, ninst, kv);
+                bool fresh;
+                const uint32_t s = table_insert(tab, cap, V, A, ninst, kv, &fresh);
                 if (s == EMPTY32) { s_cnt[3] = 1; break; }
+                if (fresh) {
+                    const uint32_t q = atomicAdd(&s_cnt[5], 1u);
+                    if (q < n_inst) list_a[q] = s; else s_cnt[3] = 1;
+                }
                 atomicAdd(slot_meta(tab, s), 1u << M_MULT_SHIFT);
                 if (ps != EMPTY32) {  // edge prev -> this
                     const uint32_t c_out = kbase(t, (int)(o - 1) + kv), c_in = kbase(t, (int)o - 1);
@@ -309,68 +327,90 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
         __threadfence();
         __syncthreads();
+        const uint32_t n_nodes = s_cnt[5] < n_inst ? s_cnt[5] : n_inst;
+        ASM_STAMP(3);
 
-        // ---- P4: unitig starts.  (a) in-degree != 1;  (b) successors of nodes with out-degree != 1
-        for (uint32_t i = tid; i < cap; i += ASM_THREADS) {
-            const unsigned long long v = slot_load(tab, i);
-            const uint32_t id = (uint32_t)v, meta = (uint32_t)(v >> 32);
-            if (id == EMPTY32) continue;
-            const K128 x = canonical(pv_kmer(V, id, kv), kv);
-            for (uint32_t d = 0; d < 2; ++d) {
-                if (__popc(in_bits(meta, d)) != 1) atomicOr(slot_meta(tab, i), d ? M_START1 : M_START0);
-                const uint32_t ob = out_bits(meta, d);
-                if (__popc(ob) > 1) {
-                    const K128 cur = d ? revcomp(x, kv) : x;
-                    for (uint32_t c = 0; c < 4; ++c) {
-                        if (!(ob & (1u << c))) continue;
-                        const K128 y = shift_in(cur, c, kv);
-                        const K128 yr = revcomp(y, kv);
-                        const uint32_t dy = yr < y ? 1u : 0u;
-                        uint32_t m2;
-                        const uint32_t sy = table_find(tab, cap, V, dy ? yr : y, kv, &m2);
-                        if (sy != EMPTY32) atomicOr(slot_meta(tab, sy), dy ? M_START1 : M_START0);
-                    }
-                }
-            }
+        // ---- P3.5: nodes get dense indices.  slot.id <- node index, inst_of[index] <- instance id; the per-node arrays
+        //      (succ[2], meta) live in LDS behind the staged pool when they fit, else in the global workspace
+        uint32_t* inst_of = list_b;                       // [n_nodes]
+        uint32_t* rec = list_b + n_nodes;                 // emitted-walk records, 2 words each
+        const uint32_t rec_cap = (n_inst - n_nodes) / 2;
+        const uint32_t pool_words_used = V.lds ? (uint32_t)((pool_bytes + 3) / 4) + 8 : 0;
+        const bool nodes_lds = (uint64_t)pool_words_used + 3ull * n_nodes <= P.lds_words;
+        uint32_t* nmeta = nodes_lds ? pool_lds + pool_words_used : P.nodes + 3 * inst_off;
+        uint32_t* succ0 = nmeta + n_nodes;
+        uint32_t* succ1 = succ0 + n_nodes;
+        for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
+            const uint32_t sl = list_a[ni];
+            const unsigned long long v = slot_load(tab, sl);
+            inst_of[ni] = (uint32_t)v;
+            nmeta[ni] = (uint32_t)(v >> 32);
+            succ0[ni] = EMPTY32;
+            succ1[ni] = EMPTY32;
+            *slot_id(tab, sl) = ni;
         }
         __threadfence();
         __syncthreads();
 
-        // ---- P5a: walk every start; keep the walks that are emitted
-        for (uint32_t i = tid; i < cap; i += ASM_THREADS) {
-            const unsigned long long v = slot_load(tab, i);
-            const uint32_t id = (uint32_t)v, meta0 = (uint32_t)(v >> 32);
-            if (id == EMPTY32 || !(meta0 & (M_START0 | M_START1))) continue;
-            const K128 x = canonical(pv_kmer(V, id, kv), kv);
+        // ---- P4: unitig-internal edges.  (x,d) -> (y,dy) is internal iff out-degree(x,d) == 1 and in-degree(y,dy) == 1;
+        //      an oriented node that no internal edge enters is a unitig START.
+        for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
+            const uint32_t meta = nmeta[ni] & 0xFFu;   // adjacency bits are final after P3
+            const K128 x = canonical(pv_kmer(V, inst_of[ni], kv), kv);
             for (uint32_t d = 0; d < 2; ++d) {
-                if (!(meta0 & (d ? M_START1 : M_START0))) continue;
-                const K128 first = d ? revcomp(x, kv) : x;
-                K128 cur = first;
-                uint32_t meta = meta0, cd = d, nodes = 1;
-                for (;;) {
-                    const uint32_t ob = out_bits(meta, cd);
-                    if (__popc(ob) != 1) break;
-                    const uint32_t c = __ffs(ob) - 1;
-                    const K128 y = shift_in(cur, c, kv);
-                    const K128 yr = revcomp(y, kv);
-                    const uint32_t dy = yr < y ? 1u : 0u;
-                    uint32_t m2 = 0;
-                    const uint32_t sy = table_find(tab, cap, V, dy ? yr : y, kv, &m2);
-                    if (sy == EMPTY32 || __popc(in_bits(m2, dy)) != 1) break;
-                    cur = y; meta = m2; cd = dy; ++nodes;
+                const uint32_t ob = out_bits(meta, d);
+                if (__popc(ob) != 1) continue;
+                const K128 cur = d ? revcomp(x, kv) : x;
+                const K128 y = shift_in(cur, __ffs(ob) - 1, kv);
+                const K128 yr = revcomp(y, kv);
+                const uint32_t dy = yr < y ? 1u : 0u;
+                const K128 Y = dy ? yr : y;
+                // find y's node index (slot.id is a node index now)
+                uint32_t sl = slot_of(Y, cap), yi = EMPTY32;
+                for (uint32_t probes = 0; probes < cap; ++probes) {
+                    const uint32_t cand = __hip_atomic_load(slot_id(tab, sl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cand == EMPTY32) break;
+                    if (canonical(pv_kmer(V, inst_of[cand], kv), kv) == Y) { yi = cand; break; }
+                    sl = sl + 1 == cap ? 0 : sl + 1;
                 }
-                const K128 opp = revcomp(cur, kv);
-                if (opp < first || nodes + P.kv - 1 < P.min_contig) continue;
-                const uint32_t e = atomicAdd(&s_cnt[1], 1u);
-                if (e >= n_inst) { s_cnt[3] = 1; continue; }
-                surv[2 * e] = (i << 1) | d;
-                surv[2 * e + 1] = nodes;
+                if (yi == EMPTY32) continue;
+                if (__popc(in_bits(nmeta[yi] & 0xFFu, dy)) != 1) continue;
+                (d ? succ1 : succ0)[ni] = (yi << 1) | dy;
+                atomicOr(&nmeta[yi], dy ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        ASM_STAMP(4);
+
+        // ---- P5a: walk every start along the succ pointers; keep the walks that are emitted
+        for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
+            const uint32_t meta0 = nmeta[ni];
+            for (uint32_t d = 0; d < 2; ++d) {
+                if (meta0 & (d ? M_START1 : M_START0)) continue;  // has an internal predecessor: not a start
+                uint32_t cur = (ni << 1) | d, nodes = 1;
+                for (;;) {
+                    const uint32_t nx = ((cur & 1) ? succ1 : succ0)[cur >> 1];
+                    if (nx == EMPTY32) break;
+                    cur = nx;
+                    ++nodes;
+                }
+                if (nodes + P.kv - 1 < P.min_contig) continue;
+                const K128 x = canonical(pv_kmer(V, inst_of[ni], kv), kv);
+                const K128 first = d ? revcomp(x, kv) : x;
+                const K128 e = canonical(pv_kmer(V, inst_of[cur >> 1], kv), kv);
+                const K128 opp = (cur & 1) ? e : revcomp(e, kv);  // first kv-mer of the opposite walk = revcomp(last kv-mer)
+                if (opp < first) continue;
+                const uint32_t q = atomicAdd(&s_cnt[1], 1u);
+                if (q >= rec_cap) { s_cnt[3] = 1; continue; }
+                rec[2 * q] = (ni << 1) | d;
+                rec[2 * q + 1] = nodes;
                 atomicAdd(&s_seq[0], (unsigned long long)(nodes + P.kv - 1));
             }
         }
         __threadfence();
         __syncthreads();
-        const uint32_t n_emit = s_cnt[1] < n_inst ? s_cnt[1] : n_inst;
+        const uint32_t n_emit = s_cnt[1] < rec_cap ? s_cnt[1] : rec_cap;
         if (tid == 0) {
             s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
             s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
@@ -378,30 +418,26 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             if (s_cnt[3]) P.gap_error[g] = 1;
         }
         __syncthreads();
+        ASM_STAMP(5);
 
         // ---- P5b: re-walk the kept starts and write sequences
-        for (uint32_t e = tid; e < n_emit; e += ASM_THREADS) {
-            const uint32_t si = surv[2 * e] >> 1, d = surv[2 * e] & 1, nodes = surv[2 * e + 1];
+        for (uint32_t q = tid; q < n_emit; q += ASM_THREADS) {
+            const uint32_t st = rec[2 * q], nodes = rec[2 * q + 1];
             const uint32_t len = nodes + P.kv - 1;
             const unsigned long long off = s_seq[1] + atomicAdd(&s_seq[0], (unsigned long long)len);
-            const unsigned long long v = slot_load(tab, si);
-            const K128 x = canonical(pv_kmer(V, (uint32_t)v, kv), kv);
-            K128 cur = d ? revcomp(x, kv) : x;
-            uint32_t meta = (uint32_t)(v >> 32), cd = d, cov = meta >> M_MULT_SHIFT;
+            const K128 x = canonical(pv_kmer(V, inst_of[st >> 1], kv), kv);
+            const K128 firstk = (st & 1) ? revcomp(x, kv) : x;
             const bool room = off + len <= P.seq_cap;
             if (room)
-                for (int q = 0; q < kv; ++q) P.seq[off + q] = "ACGT"[kbase(cur, q)];
+                for (int b = 0; b < kv; ++b) P.seq[off + b] = "ACGT"[kbase(firstk, b)];
+            uint32_t cur = st, cov = nmeta[st >> 1] >> M_MULT_SHIFT;
             for (uint32_t n = 1; n < nodes; ++n) {
-                const uint32_t c = __ffs(out_bits(meta, cd)) - 1;
-                const K128 y = shift_in(cur, c, kv);
-                const K128 yr = revcomp(y, kv);
-                const uint32_t dy = yr < y ? 1u : 0u;
-                uint32_t m2 = 0;
-                table_find(tab, cap, V, dy ? yr : y, kv, &m2);
+                const uint32_t c = __ffs(out_bits(nmeta[cur >> 1] & 0xFFu, cur & 1)) - 1;
+                cur = ((cur & 1) ? succ1 : succ0)[cur >> 1];
                 if (room) P.seq[off + kv - 1 + n] = "ACGT"[c];
-                cur = y; meta = m2; cd = dy; cov += m2 >> M_MULT_SHIFT;
+                cov += nmeta[cur >> 1] >> M_MULT_SHIFT;
             }
-            const uint32_t ci = s_cnt[2] + e;
+            const uint32_t ci = s_cnt[2] + q;
             if (ci < P.contig_cap) {
                 gf_contig ct;
                 ct.gap = g; ct.k = (uint16_t)P.k; ct.kv = (uint16_t)P.kv; ct.n_nodes = nodes; ct.length = len;
@@ -410,7 +446,18 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             }
         }
         __syncthreads();
+        ASM_STAMP(6);
+        for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) tab[list_a[ni]] = 0x00000000FFFFFFFFull;  // leave the slice EMPTY
+        if (s_cnt[3])  // an overflow may have left slots outside the lists: clear the whole slice
+            for (uint32_t i = tid; i < cap; i += ASM_THREADS) tab[i] = 0x00000000FFFFFFFFull;
+        __threadfence();
+        __syncthreads();
     }
+}
+
+__global__ void fill_empty_kernel(unsigned long long* t, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        t[i] = 0x00000000FFFFFFFFull;
 }
 
 int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
@@ -423,8 +470,17 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     const uint32_t npos = read_len - k + 1;
     const uint64_t n_inst = (uint64_t)total_reads * npos;
     int rc;
-    if ((rc = ensure(ctx, ctx->asm_table, std::max<uint64_t>(n_inst, 1) * 4 * 8))) return rc;
+    {   // the table must be all-EMPTY (id 0xFFFFFFFF, meta 0) on entry; kernels leave it so, a fresh buffer is filled once
+        void* before = ctx->asm_table.p;
+        if ((rc = ensure(ctx, ctx->asm_table, std::max<uint64_t>(n_inst, 1) * 4 * 8))) return rc;
+        if (ctx->asm_table.p != before) {
+            const size_t words = ctx->asm_table.bytes / 8;
+            hipLaunchKernelGGL(fill_empty_kernel, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream,
+                               (unsigned long long*)ctx->asm_table.p, (uint64_t)words);
+        }
+    }
     if ((rc = ensure(ctx, ctx->asm_surv, std::max<uint64_t>(n_inst, 1) * 2 * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->asm_nodes, std::max<uint64_t>(n_inst, 1) * 3 * 4))) return rc;
     GF_HIP(ctx, hipMemsetAsync(d_n_contigs, 0, 4, ctx->stream));
     GF_HIP(ctx, hipMemsetAsync(d_seq_len, 0, 8, ctx->stream));
     if (n_pools) GF_HIP(ctx, hipMemsetAsync(d_gap_error, 0, n_pools * 4, ctx->stream));
@@ -442,6 +498,7 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.min_contig = min_contig < 0 ? 0 : min_contig;
     P.table = (unsigned long long*)ctx->asm_table.p;
     P.surv = (uint32_t*)ctx->asm_surv.p;
+    P.nodes = (uint32_t*)ctx->asm_nodes.p;
     P.contigs = (gf_contig*)d_contigs;
     P.contig_cap = (uint32_t)contig_cap;
     P.n_contigs = (uint32_t*)d_n_contigs;
@@ -452,11 +509,11 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.cnt_keys = (uint64_t*)d_cnt_keys;
     P.cnt_counts = (uint32_t*)d_cnt_counts;
     P.cnt_cap = (uint32_t)std::min<size_t>(cnt_cap, 0xFFFFFFFFu);
-    // staged-pool LDS: option asm_lds_pool_kb (default 36 KiB = ~970 reads of 150 bp, 4 workgroups per CU); larger pools
-    // are read from global memory
-    P.lds_words = std::min<uint32_t>(ASM_POOL_LDS_MAX_WORDS, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
-    const unsigned per_cu = std::max(1u, std::min(4u, (160u * 1024u) / (P.lds_words * 4 + 1024)));
-    const unsigned grid = (unsigned)std::min<size_t>(n_pools, (size_t)ctx->n_cu * per_cu);
+    P.dbg = (unsigned long long*)ctx->asm_dbg;
+    // dynamic LDS (option asm_lds_kb, default all 152 KiB): the gap's packed reads, then meta + succ[2] of its nodes;
+    // whatever does not fit is read from / kept in global memory
+    P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
+    const unsigned grid = (unsigned)std::min<size_t>(n_pools, (size_t)ctx->n_cu);
     {
         LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
         hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(ASM_THREADS), (size_t)P.lds_words * 4, ctx->stream, P);

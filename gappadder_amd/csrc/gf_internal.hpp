@@ -65,14 +65,18 @@ struct gf_ctx {
     int bitmap_log2_override = 0;
     int screen_variant = 0;     // tuning: load mode / unroll of the filter kernel
     int screen_wg_per_cu = 0;
-    int asm_lds_pool_kb = 36;
+    int asm_lds_pool_kb = 152;
+    void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)
     // tagger coarse bin map (rebuilt when dist2 changes)
     std::vector<uint32_t> bin_host;
     int bin_dist2 = -1, bin_shift = 0;
     uint32_t bin_words = 0;
+    // second-hop table cache
+    std::vector<uint32_t> low_rows, rowgap_rows;
+    size_t low_b1 = 0, low_b2 = 0;
 
     // scratch
-    gf::DevBuf cand, cand2, binmap, asm_table, asm_surv, rowgap, pool_ws, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, binmap, asm_table, asm_surv, asm_nodes, rowgap, pool_ws, counters, stage_in, stage_out, stage_aux, table;
     // timing
     bool timing = false;
     std::vector<gf::TimedLaunch> launches;

@@ -9,6 +9,8 @@
 //
 //   keys -> per-gap histogram -> exclusive scan -> scatter into gap segments -> per-gap LDS bitonic sort + unique
 //        -> exclusive scan of the unique counts (= pool_off) -> gather of packed reads
+#include <cstring>
+
 #include "gf_internal.hpp"
 
 namespace gf {
@@ -206,7 +208,10 @@ int gf_pool_keys_from_tags_dev(gf_ctx* ctx, const void* d_recs, const void* d_ta
     if (!ctx || !d_recs || !d_taghits || !d_n_taghits || !d_keys || !d_n_keys || hit_cap > 0xFFFFFFFFull || key_cap > 0xFFFFFFFFull)
         return GF_E_INVAL;
     const uint32_t* d_row_gap = nullptr;
-    if (lowmapq_table_or_null) {  // second-hop rows name (src_scaffold, 1-based gap in scaffold) -> index into the gap array
+    const bool cached = lowmapq_table_or_null && ctx->rowgap.p && ctx->rowgap_rows.size() == n_rows * 4 &&
+                        memcmp(ctx->rowgap_rows.data(), lowmapq_table_or_null, n_rows * sizeof(gf_dpos)) == 0;
+    if (cached) d_row_gap = (const uint32_t*)ctx->rowgap.p;
+    if (lowmapq_table_or_null && !cached) {  // second-hop rows name (src_scaffold, 1-based gap) -> index into the gap array
         std::vector<uint32_t> off(ctx->n_scaffolds + 1, 0), rg(n_rows);
         for (const gf_gap& g : ctx->gaps) off[g.scaffold + 1]++;
         for (uint32_t s = 0; s < ctx->n_scaffolds; ++s) off[s + 1] += off[s];
@@ -221,6 +226,7 @@ int gf_pool_keys_from_tags_dev(gf_ctx* ctx, const void* d_recs, const void* d_ta
         GF_HIP(ctx, hipMemcpyAsync(ctx->rowgap.p, rg.data(), n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
         GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         d_row_gap = (const uint32_t*)ctx->rowgap.p;
+        ctx->rowgap_rows.assign((const uint32_t*)lowmapq_table_or_null, (const uint32_t*)lowmapq_table_or_null + n_rows * 4);
     }
     LaunchTimer tm(ctx, GF_KERNEL_POOL);
     hipLaunchKernelGGL(keys_from_tags_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_alnrec*)d_recs,

@@ -7,6 +7,8 @@
 //   right window: 0 <= POS-end   < dist2  (keys end+i)
 // low_mapq_kernel restates collect_discordant_low_mapq_reads.py:4-84: MAPQ==0 records, focal_region[p] = the
 // LAST discordant mate position q (sorted file order) with q-199 <= p <= q+299, one hit per row of q.
+#include <cstring>
+
 #include "gf_internal.hpp"
 
 namespace gf {
@@ -315,32 +317,42 @@ int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* ta
     if (ctx->n_scaffolds == 0) return GF_E_STATE;
     GF_HIP(ctx, hipMemsetAsync(d_n_out, 0, 4, ctx->stream));
     if (n == 0 || n_rows == 0) return GF_OK;
-    // host: unique positions per scaffold + row offsets (the table is tiny next to the record stream)
-    std::vector<uint32_t> upos, urow, soff(ctx->n_scaffolds + 1, 0);
-    uint32_t cur_s = 0;
-    for (size_t r = 0; r < n_rows; ++r) {
-        if (r) {
-            const gf_dpos &a = table[r - 1], &b = table[r];
-            if (a.mate_scaffold > b.mate_scaffold || (a.mate_scaffold == b.mate_scaffold && a.mate_pos > b.mate_pos))
-                return GF_E_INVAL;  // must be sorted (run_multi_threads_discordant.py:103)
+    // host: unique positions per scaffold + row offsets (the table is tiny next to the record stream); the device copy
+    // is cached and re-used while the caller passes the same rows (a pipeline calls this once per batch of records)
+    const bool cached = ctx->low_rows.size() == n_rows * 4 && ctx->table.p &&
+                        memcmp(ctx->low_rows.data(), table, n_rows * sizeof(gf_dpos)) == 0;
+    if (!cached) {
+        std::vector<uint32_t> upos, urow, soff(ctx->n_scaffolds + 1, 0);
+        uint32_t cur_s = 0;
+        for (size_t r = 0; r < n_rows; ++r) {
+            if (r) {
+                const gf_dpos &a = table[r - 1], &b = table[r];
+                if (a.mate_scaffold > b.mate_scaffold || (a.mate_scaffold == b.mate_scaffold && a.mate_pos > b.mate_pos))
+                    return GF_E_INVAL;  // must be sorted (run_multi_threads_discordant.py:103)
+            }
+            if (table[r].mate_scaffold >= ctx->n_scaffolds) return GF_E_INVAL;
+            if (r == 0 || table[r].mate_scaffold != table[r - 1].mate_scaffold || table[r].mate_pos != table[r - 1].mate_pos) {
+                while (cur_s < table[r].mate_scaffold) soff[++cur_s] = (uint32_t)upos.size();
+                upos.push_back(table[r].mate_pos);
+                urow.push_back((uint32_t)r);
+            }
         }
-        if (table[r].mate_scaffold >= ctx->n_scaffolds) return GF_E_INVAL;
-        if (r == 0 || table[r].mate_scaffold != table[r - 1].mate_scaffold || table[r].mate_pos != table[r - 1].mate_pos) {
-            while (cur_s < table[r].mate_scaffold) soff[++cur_s] = (uint32_t)upos.size();
-            upos.push_back(table[r].mate_pos);
-            urow.push_back((uint32_t)r);
-        }
+        urow.push_back((uint32_t)n_rows);
+        while (cur_s < ctx->n_scaffolds) soff[++cur_s] = (uint32_t)upos.size();
+        const size_t b1 = upos.size() * 4, b2 = urow.size() * 4, b3 = soff.size() * 4;
+        int rc;
+        if ((rc = ensure(ctx, ctx->table, b1 + b2 + b3 + 64))) return rc;
+        uint8_t* base = (uint8_t*)ctx->table.p;
+        GF_HIP(ctx, hipMemcpyAsync(base, upos.data(), b1, hipMemcpyHostToDevice, ctx->stream));
+        GF_HIP(ctx, hipMemcpyAsync(base + b1, urow.data(), b2, hipMemcpyHostToDevice, ctx->stream));
+        GF_HIP(ctx, hipMemcpyAsync(base + b1 + b2, soff.data(), b3, hipMemcpyHostToDevice, ctx->stream));
+        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+        ctx->low_rows.assign((const uint32_t*)table, (const uint32_t*)table + n_rows * 4);
+        ctx->low_b1 = b1;
+        ctx->low_b2 = b2;
     }
-    urow.push_back((uint32_t)n_rows);
-    while (cur_s < ctx->n_scaffolds) soff[++cur_s] = (uint32_t)upos.size();
-    const size_t b1 = upos.size() * 4, b2 = urow.size() * 4, b3 = soff.size() * 4;
-    int rc;
-    if ((rc = ensure(ctx, ctx->table, b1 + b2 + b3 + 64))) return rc;
+    const size_t b1 = ctx->low_b1, b2 = ctx->low_b2;
     uint8_t* base = (uint8_t*)ctx->table.p;
-    GF_HIP(ctx, hipMemcpyAsync(base, upos.data(), b1, hipMemcpyHostToDevice, ctx->stream));
-    GF_HIP(ctx, hipMemcpyAsync(base + b1, urow.data(), b2, hipMemcpyHostToDevice, ctx->stream));
-    GF_HIP(ctx, hipMemcpyAsync(base + b1 + b2, soff.data(), b3, hipMemcpyHostToDevice, ctx->stream));
-    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
     LowParams P;
     P.recs = (const gf_alnrec*)d_recs;
     P.n = n;

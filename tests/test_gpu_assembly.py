@@ -86,18 +86,19 @@ def test_pool_larger_than_the_lds_stage_uses_global_reads(gf):
     rng = np.random.RandomState(12)
     g = LUT[rng.randint(0, 4, 5000)].tobytes()
     L = 150
-    reads = tiled_reads(g, L, 2500, rng)      # 2500 x 38 B = 95 KB > the 36 KiB stage
+    reads = tiled_reads(g, L, 2500, rng)      # 2500 x 38 B = 95 KB > the LDS share of the staged pool
     for i in (3, 77, 500):
         b = bytearray(reads[i]); b[40] = ord("A") if b[40] != ord("A") else ord("G"); reads[i] = bytes(b)
     pool = b"".join(reads)
     got, _ = _gpu_assemble(gf, [pool], L, [(31, 29)])
     assert got[(0, 31, 29)] == CO.assemble_pool(pool, L, 31, 29)
-    gf.set_option("asm_lds_pool_kb", 144)
-    try:
-        got2, _ = _gpu_assemble(gf, [pool], L, [(31, 29)])
-    finally:
-        gf.set_option("asm_lds_pool_kb", 36)
-    assert got2 == got
+    for kb in (8, 64):      # nothing fits in LDS / only the node arrays do
+        gf.set_option("asm_lds_pool_kb", kb)
+        try:
+            got2, _ = _gpu_assemble(gf, [pool], L, [(31, 29)])
+        finally:
+            gf.set_option("asm_lds_pool_kb", 152)
+        assert got2 == got
 
 
 def test_count_kmers_matches_oracle(gf):

@@ -1,0 +1,37 @@
+"""Diagnostic: per-gap phase times of the assembly kernel (wall_clock64 stamps, 100 MHz) on the bench workload."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gappadder_amd import _lib as B
+from gappadder_amd.hip_api import GapFill
+from oracle import c_oracle as CO
+
+n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+cfg = GapFill.synth_cfg(scaffold_len=400_000, n_scaffolds=50, gaps_per_scaffold=20 // 10, gap_len=2000)
+gaps, flanks = GapFill.synth_layout(cfg)
+gf = GapFill(0)
+gf.set_gaps(gaps, 50, flanks)
+ocfg = np.frombuffer(cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
+packed, recs = CO.synth_pairs(ocfg, 0, n_pairs)
+hits = gf.screen_reads(packed, 150, 31)
+ids = {}
+for h in hits:
+    ids.setdefault(int(h["gap"]), set()).update((int(h["read"]), int(h["read"]) ^ 1))
+order = [sorted(ids.get(g, [])) for g in range(len(gaps))]
+off = np.cumsum([0] + [len(o) for o in order]).astype(np.uint64)
+pool = packed[np.concatenate([np.array(o, dtype=np.int64) for o in order if o])]
+print("gaps", len(gaps), "pooled reads", len(pool), "mean/gap", len(pool) / len(gaps))
+dev = torch.device("cuda:0")
+dbg = torch.zeros(len(gaps) * 8, dtype=torch.int64, device=dev)
+gf.set_option("asm_dbg_ptr", dbg.data_ptr())
+gf.timing(True)
+for _ in range(3):
+    ctg, seq = gf.assemble(pool, off, 150, [(31, 29)])
+ms, n = gf.kernel_time(B.KERNEL_ASSEMBLE)
+print("assemble kernel %.3f ms avg, contigs %d" % (ms / n, len(ctg)))
+d = dbg.cpu().numpy().reshape(-1, 8)
+ph = np.diff(d[:, :7], axis=1) / 100.0  # us
+names = ["P1 count", "P2 survivors", "P3 graph", "P4 starts", "P5a walk", "P5b write"]
+for i, nm in enumerate(names):
+    print("%-14s mean %8.1f us   max %8.1f us" % (nm, ph[:, i].mean(), ph[:, i].max()))
+print("total/gap mean %.1f us max %.1f us; kernel span %.1f us" % (ph.sum(1).mean(), ph.sum(1).max(), (d[:, 6].max() - d[:, 0].min()) / 100.0))
