@@ -1,0 +1,101 @@
+"""Assembly stage, first round (mirrors assemble_gaps.py:82-136, 244-299): for every gap that has a read pool and every
+(k, k_velvet) pair, count canonical k-mers (KMC's role) and assemble the surviving k-mers at hash length k_velvet
+(Velvet's role); write contigs_{k}_{kv}.fa and the merged contigs.fa with '>{k}_{kv}_' headers.  All gaps of a batch go
+through ONE gf_assemble call per pair instead of >= 5 process launches per (gap, k, kv).
+
+The later rounds of the reference's assemble_pipeline (contig merging with TERefiner/ContigsMerger, bwa-based picking,
+both-unmapped recruitment) are outside this build's scope."""
+import os
+
+from . import fastq_io
+from . import sam_io
+from .hip_api import GapFill
+
+kmer_len_list = []
+working_folder = ""
+min_count = 2        # KMC's default -ci (the reference passes none, assemble_gaps.py:96)
+min_contig = 40      # velvetg -min_contig_lgth 40 (:117)
+_gf = None
+
+
+def _ctx():
+    global _gf
+    if _gf is None:
+        _gf = GapFill(int(os.environ.get("GF_DEVICE", "0")))
+    return _gf
+
+
+def velvet_kv(kv):
+    """velveth runs at an odd hash length: an even value is lowered by one (Velvet's documented behaviour)."""
+    return kv if kv & 1 else kv - 1
+
+
+def format_contigs(contigs):
+    """[(seq, n_nodes, cov_sum)] -> Velvet-style FASTA: NODE_{n}_length_{kmers}_cov_{cov:.6f}, 60 columns."""
+    out = []
+    for n, (seq, nodes, cov) in enumerate(contigs, 1):
+        out.append(">NODE_%d_length_%d_cov_%.6f\n" % (n, nodes, cov / float(nodes)))
+        out.extend(seq[i:i + 60] + "\n" for i in range(0, len(seq), 60))
+    return "".join(out)
+
+
+def assemble_ids(ids, gf=None):
+    """run_assembly for a batch of gap ids (assemble_gaps.py:82-136)."""
+    gf = gf or _ctx()
+    ids = [i for i in ids if os.path.exists("%sgap_reads/%s.fastq" % (working_folder, i))]   # :272-274
+    if not ids:
+        return
+    pools = [fastq_io.read_fastq_seqs("%sgap_reads/%s.fastq" % (working_folder, i)) for i in ids]
+    packed, nm, off, L = fastq_io.pack_pools(pools)
+    pairs = [(int(k), int(kv)) for k, kv in kmer_len_list]
+    usable = [(k, velvet_kv(kv)) for k, kv in pairs if 16 <= k <= min(64, L) and 15 <= velvet_kv(kv) < k]
+    per = {}
+    if usable:
+        ctg, seq = gf.assemble(packed, off, L, usable, min_count, min_contig, n_mask=nm)
+        for c in ctg:
+            per.setdefault((int(c["gap"]), int(c["k"]), int(c["kv"])), []).append(
+                (seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode(), int(c["n_nodes"]), int(c["cov_sum"])))
+    for g, gid in enumerate(ids):
+        d = "%svelvet_temp/%s" % (working_folder, gid)
+        os.makedirs(d, exist_ok=True)
+        merged = []
+        for (k, kv) in pairs:
+            txt = format_contigs(per.get((g, k, velvet_kv(kv)), [])) if (k, velvet_kv(kv)) in usable else ""
+            with open("%s/contigs_%d_%d.fa" % (d, k, kv), "w") as f:   # always created: a missing file kills the reference (:130)
+                f.write(txt)
+            merged.append("".join((">%d_%d_%s" % (k, kv, line[1:]) if line.startswith(">") else line)
+                                  for line in txt.splitlines(True)))
+        with open(d + "/contigs.fa", "w") as f:
+            f.write("".join(merged))
+
+
+def run_assembly(id):
+    assemble_ids([id])
+
+
+class GapAssembler:
+    def __init__(self, sf_fai, sf_pos, n_jobs, working_space, kmer_list=None, gf=None):
+        global kmer_len_list, working_folder, _gf
+        if kmer_list is not None:
+            kmer_len_list = list(kmer_list)
+        self.sf_fai = sf_fai
+        self.sf_pos = sf_pos
+        self.n_jobs = int(n_jobs)
+        working_folder = working_space
+        if gf is not None:
+            _gf = gf
+
+    def prepare_list(self):
+        sidx = {n: i for i, n in enumerate(sam_io.read_fai(self.sf_fai))}
+        _, keys = sam_io.read_gap_positions(self.sf_pos, sidx)
+        return [k for k in keys if os.path.exists("%sgap_reads/%s.fastq" % (working_folder, k))]
+
+    def assembly(self, id_list):
+        for sub in ("kmc_temp", "temp", "kmers", "velvet_temp"):
+            os.makedirs(working_folder + sub, exist_ok=True)
+        assemble_ids(id_list)
+
+    assembly_given_list = assembly
+
+    def assemble_pipeline(self):
+        self.assembly(self.prepare_list())

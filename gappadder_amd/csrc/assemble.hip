@@ -180,14 +180,18 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         const uint64_t r0 = P.pool_off[g], r1 = P.pool_off[g + 1];
         const uint32_t n_r = (uint32_t)(r1 - r0);
         if (n_r == 0) continue;
-        const uint64_t n_inst64 = (uint64_t)n_r * npos;
-        const uint64_t inst_off = r0 * npos;
-        if (n_inst64 >= (1ull << 30) || (uint64_t)n_r * P.read_len >= 0xFFFFFFF0ull) {  // ids are 32-bit
+        // workspace unit: every k-mer AND every kv-mer of the gap is a window of one of its reads, so
+        // n_r * (L - kv + 1) bounds the distinct k-mers, the nodes and every list below
+        const uint32_t unit = P.cnt_keys ? npos : P.read_len - P.kv + 1;
+        const uint64_t n_unit64 = (uint64_t)n_r * unit;
+        const uint64_t inst_off = r0 * unit;
+        if (n_unit64 >= (1ull << 30) || (uint64_t)n_r * P.read_len >= 0xFFFFFFF0ull) {  // ids are 32-bit
             if (tid == 0) P.gap_error[g] = 1;
             continue;
         }
-        const uint32_t n_inst = (uint32_t)n_inst64;
-        const uint32_t cap = 4 * n_inst;
+        const uint32_t n_inst = (uint32_t)((uint64_t)n_r * npos);   // k-mer positions
+        const uint32_t n_unit = (uint32_t)n_unit64;
+        const uint32_t cap = 4 * n_unit;
         unsigned long long* tab = P.table + 4 * inst_off;
         uint32_t* surv = P.surv + 2 * inst_off;
 
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         if (tid < 2) s_seq[tid] = 0;
         __syncthreads();
         uint32_t* list_a = surv;           // P1: slots of distinct k-mers   P3..P5: slots of nodes
-        uint32_t* list_b = surv + n_inst;  // P2: surviving instances        P5: (start, n_nodes) of emitted walks
+        uint32_t* list_b = surv + n_unit;  // P2: surviving instances        P5: (start, n_nodes) of emitted walks
 
         // ---- P1: count canonical k-mers; remember each distinct k-mer's slot
         for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 if (s == EMPTY32) { s_cnt[3] = 1; break; }
                 if (fresh) {
                     const uint32_t q = atomicAdd(&s_cnt[5], 1u);
-                    if (q < n_inst) list_a[q] = s; else s_cnt[3] = 1;
+                    if (q < n_unit) list_a[q] = s; else s_cnt[3] = 1;
                 }
                 atomicAdd(slot_meta(tab, s), 1u << M_MULT_SHIFT);
                 if (ps != EMPTY32) {  // edge prev -> this
@@ -327,14 +331,14 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
         __threadfence();
         __syncthreads();
-        const uint32_t n_nodes = s_cnt[5] < n_inst ? s_cnt[5] : n_inst;
+        const uint32_t n_nodes = s_cnt[5] < n_unit ? s_cnt[5] : n_unit;
         ASM_STAMP(3);
 
         // ---- P3.5: nodes get dense indices.  slot.id <- node index, inst_of[index] <- instance id; the per-node arrays
         //      (succ[2], meta) live in LDS behind the staged pool when they fit, else in the global workspace
         uint32_t* inst_of = list_b;                       // [n_nodes]
         uint32_t* rec = list_b + n_nodes;                 // emitted-walk records, 2 words each
-        const uint32_t rec_cap = (n_inst - n_nodes) / 2;
+        const uint32_t rec_cap = (n_unit - n_nodes) / 2;
         const uint32_t pool_words_used = V.lds ? (uint32_t)((pool_bytes + 3) / 4) + 8 : 0;
         const bool nodes_lds = (uint64_t)pool_words_used + 3ull * n_nodes <= P.lds_words;
         uint32_t* nmeta = nodes_lds ? pool_lds + pool_words_used : P.nodes + 3 * inst_off;
@@ -467,8 +471,8 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     if (k < 16 || k > 64 || read_len < k || read_len > 1000) return GF_E_UNSUPPORTED;
     if (!d_cnt_keys && (kv < 15 || kv >= k || !(kv & 1))) return GF_E_UNSUPPORTED;
     if (n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull) return GF_E_INVAL;
-    const uint32_t npos = read_len - k + 1;
-    const uint64_t n_inst = (uint64_t)total_reads * npos;
+    const uint32_t unit = d_cnt_keys ? read_len - k + 1 : read_len - kv + 1;
+    const uint64_t n_inst = (uint64_t)total_reads * unit;  // workspace units (see the kernel)
     int rc;
     {   // the table must be all-EMPTY (id 0xFFFFFFFF, meta 0) on entry; kernels leave it so, a fresh buffer is filled once
         void* before = ctx->asm_table.p;

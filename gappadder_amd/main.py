@@ -1,0 +1,111 @@
+"""CLI with the reference's interface (main.py:26-275): python -m gappadder_amd.main -c {Clean,All,Preprocess,Collect,Assembly}
+-g config.json, same JSON keys, same working-folder layout.  Collect and the first assembly round run on the GPU."""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+from . import assemble_gaps
+from .gnrt_pos_true_seqs import DGProcessor
+from .hip_api import GapFill
+from .merge_reads import ReadsMerger
+from .run_multi_threads_collect_reads import MultiThrdReadsCollector
+from .run_multi_threads_discordant import DiscordantReadsCollector
+
+MERGE_FOLDER = "merged/"
+SUB = ("scaffold_reads_list_all", "gap_reads", "gap_reads_for_alignment", "gap_reads_high_quality", "discordant_reads_list",
+       "discordant_temp")
+SUB_MERGED = ("gap_reads", "gap_reads_for_alignment", "gap_reads_high_quality", "kmc_temp", "temp", "kmers", "velvet_temp",
+              "both_unmapped", "unmapped_reads")
+
+
+def parse_configuration(path):
+    with open(path) as f:
+        data = json.load(f)
+    for key in ("draft_genome", "alignments", "raw_reads"):
+        if key not in data:
+            raise SystemExit("configuration lacks '%s'" % key)
+    cfg = {"draft": data["draft_genome"]["fa"],
+           "alignments": [(r["bam"], int(r["is"]), int(r["std"])) for r in data["alignments"]],
+           "raw_reads": [(r["left"], r["right"]) for r in data["raw_reads"]],
+           "kmers": [(int(r["k"]), int(s["k"])) for r in data.get("kmer_length", []) for s in r["k_velvet"]]}
+    p = data.get("parameters", {})
+    cfg["min_gap"] = int(p.get("min_gap_size", 100))
+    cfg["flank"] = int(p.get("flank_length", 300))
+    cfg["nthreads"] = int(p.get("nthreads", 15))
+    cfg["wf"] = p.get("working_folder", "./GAPPadder_Output/")
+    cfg["samtools"] = data.get("software_path", {}).get("samtools", "samtools")
+    for path_, what in [(cfg["draft"], "draft genome")] + [(a[0], "bam") for a in cfg["alignments"]] + \
+                       [(x, "raw reads") for pair in cfg["raw_reads"] for x in pair] + [(cfg["wf"], "working folder")]:
+        if not os.path.exists(path_):
+            raise SystemExit("The provided %s %s does not exist, please check!!!" % (what, path_))
+    if not cfg["wf"].endswith("/"):
+        cfg["wf"] += "/"
+    return cfg
+
+
+def prepare_folders(alignments, wf):
+    folders = []
+    for n, (_, is_, _) in enumerate(alignments, 1):
+        p = "%s%d_is%d/" % (wf, n, is_)
+        folders.append(p)
+        for s in SUB:
+            os.makedirs(p + s, exist_ok=True)
+    for s in SUB_MERGED:
+        os.makedirs(wf + MERGE_FOLDER + s, exist_ok=True)
+    return folders
+
+
+def main_func(command, sf_config):
+    cfg = parse_configuration(sf_config)
+    wf = cfg["wf"]
+    sf_fai = cfg["draft"] + ".fai"
+    if not os.path.exists(sf_fai):
+        subprocess.call([cfg["samtools"], "faidx", cfg["draft"]])
+    sf_gap_pos = wf + "gap_positions.txt"
+    anchor_mapq, clip_dist = 30, 250      # main.py:215-216
+    if command in ("Clean", "All"):
+        for fn in os.listdir(wf):
+            p = os.path.join(wf, fn)
+            shutil.rmtree(p) if os.path.isdir(p) else os.remove(p)
+    if command in ("Preprocess", "All"):
+        dgp = DGProcessor(cfg["draft"], sf_gap_pos)
+        dgp.gnrt_gap_positions(cfg["min_gap"])
+        dgp.get_gap_flank_seqs(cfg["draft"], sf_gap_pos, cfg["flank"], sf_fai, wf)
+    gf = GapFill(int(os.environ.get("GF_DEVICE", "0"))) if command in ("Collect", "Assembly", "All") else None
+    if command in ("Collect", "All"):
+        folders = prepare_folders(cfg["alignments"], wf)
+        if len(cfg["alignments"]) != len(cfg["raw_reads"]):
+            raise SystemExit("# of alignment files and # of raw reads do not match!!!!!")
+        for (bam, is_, sd), folder, (left, right) in zip(cfg["alignments"], folders, cfg["raw_reads"]):
+            MultiThrdReadsCollector(sf_fai, bam, sf_gap_pos, anchor_mapq, gf).dispath_collect_jobs(
+                cfg["nthreads"], cfg["samtools"], is_, sd, clip_dist, folder)
+            drc = DiscordantReadsCollector(sf_fai, bam, folder, cfg["nthreads"], gf, cfg["samtools"])
+            drc.collect_discordant_regions_v2(folder + "discordant_reads_pos.txt")
+            drc.dispath_collect_jobs()
+            drc.merge_dispatch_reads_for_gaps_v2(left, right)
+            drc.dispatch_high_quality_reads_for_gaps(left, right)
+        rm = ReadsMerger()
+        for name in ("gap_reads", "gap_reads_alignment", "gap_reads_high_quality"):
+            rm.merge_reads_v2(sf_fai, sf_gap_pos, folders, name, wf + MERGE_FOLDER, cfg["nthreads"])
+    if command in ("Assembly", "All"):
+        for s in SUB_MERGED:
+            os.makedirs(wf + MERGE_FOLDER + s, exist_ok=True)
+        ga = assemble_gaps.GapAssembler(sf_fai, sf_gap_pos, cfg["nthreads"], wf + MERGE_FOLDER, cfg["kmers"], gf)
+        ga.assemble_pipeline()
+        print("first-round assembly written to %svelvet_temp/*/contigs.fa (contig merging / picking: reference's later rounds, "
+              "not part of this build)" % (wf + MERGE_FOLDER))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Run the GAPPadder recruit + local-assembly hot path on MI355X")
+    ap.add_argument("-g", "--config", type=str, required=True, help="Configuration file name")
+    ap.add_argument("-c", "--command", type=str, required=True, help="Clean | All | Preprocess | Collect | Assembly")
+    a = ap.parse_args(argv)
+    main_func(a.command, a.config)
+
+
+if __name__ == "__main__":
+    main()

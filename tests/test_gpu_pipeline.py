@@ -1,0 +1,91 @@
+"""End-to-end on the GPU through the reference's own CLI surface: `main -c Preprocess`, `-c Collect` on the golden inputs
+must reproduce the files the reference wrote; `-c Assembly` and the kmc/kmc_dump/velveth/velvetg executables must agree
+with the oracle's definition of the assembly."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from golden_util import CASES, Case
+from oracle import c_oracle as CO
+import pipeline_util as PU
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", params=CASES)
+def run(request, tmp_path_factory):
+    from gappadder_amd import main as M
+    case = Case(request.param)
+    root = str(tmp_path_factory.mktemp(request.param))
+    cfgp, wf, st = PU.materialise(case, root, kmers=((31, 29), (41, 39), (41, 38)))
+    for stage in ("Preprocess", "Collect", "Assembly"):
+        M.main(["-c", stage, "-g", cfgp])
+    return case, wf, PU.tree(wf)
+
+
+def test_collect_reproduces_the_reference_tree(run):
+    case, wf, got = run
+    checked = 0
+    for rel, txt in case.expected.items():
+        exact = (rel.endswith(".fastq") or rel.endswith(".sorted.txt") or "discordant_temp/" in rel or rel.endswith(".fa")
+                 or rel == "gap_positions.txt" or "/discordant_reads_list/" in rel)
+        if exact:
+            assert got.get(rel) == txt, rel
+        else:   # list files whose line order is dict-defined in the reference: same lines
+            assert sorted(got[rel].splitlines()) == sorted(txt.splitlines()), rel
+        checked += 1
+    assert checked == len(case.expected) and checked > 40
+    extra = [k for k in got if k not in case.expected and not k.startswith("merged/velvet_temp/")]
+    assert not extra, extra
+
+
+def test_scaffold_lists_keep_sam_record_order(run):
+    case, wf, got = run
+    for rel, txt in case.expected.items():
+        if "/scaffold_reads_list_all/" in rel:
+            assert [l.split()[0] for l in got[rel].splitlines()] == [l.split()[0] for l in txt.splitlines()], rel
+
+
+def test_assembly_stage_files(run):
+    from gappadder_amd.assemble_gaps import format_contigs
+    case, wf, got = run
+    ids = [k[len("merged/gap_reads/"):-len(".fastq")] for k in got if k.startswith("merged/gap_reads/")]
+    assert ids
+    n_ctg = 0
+    for gid in ids:
+        seqs = [l for i, l in enumerate(got["merged/gap_reads/%s.fastq" % gid].splitlines()) if i % 4 == 1]
+        L = max(len(s) for s in seqs)
+        blob = "".join(s.ljust(L, "N") for s in seqs).encode()
+        merged = ""
+        for (k, kv_cfg, kv) in ((31, 29, 29), (41, 39, 39), (41, 38, 37)):     # an even k_velvet runs at kv-1
+            exp = format_contigs(CO.assemble_pool(blob, L, k, kv)) if L >= k else ""
+            assert got["merged/velvet_temp/%s/contigs_%d_%d.fa" % (gid, k, kv_cfg)] == exp, (gid, k, kv_cfg)
+            merged += "".join((">%d_%d_%s" % (k, kv_cfg, l[1:]) if l.startswith(">") else l) for l in exp.splitlines(True))
+            n_ctg += exp.count(">")
+        assert got["merged/velvet_temp/%s/contigs.fa" % gid] == merged
+    assert n_ctg > 0
+
+
+def test_kmc_velvet_executables_follow_the_reference_command_lines(run, tmp_path):
+    """The command lines of assemble_gaps.py:96-118, the reference's cvtFaToFq step restated in between."""
+    case, wf, got = run
+    gid = sorted(k for k in got if k.startswith("merged/gap_reads/"))[0][len("merged/gap_reads/"):-len(".fastq")]
+    bind = os.path.join(ROOT, "gappadder_amd", "bin")
+    t = str(tmp_path)
+    fq = "%smerged/gap_reads/%s.fastq" % (wf, gid)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    sh = lambda *a: subprocess.check_call([sys.executable] + list(a), env=env)
+    sh(bind + "/kmc", "-k31", "-cs10000000", "-m52", fq, t + "/x.res", t + "/kmc_tmp")
+    sh(bind + "/kmc_dump", "-ci0", t + "/x.res", t + "/x.dump")
+    dump = open(t + "/x.dump").read().splitlines()
+    assert dump and all(len(l.split("\t")[0]) == 31 and int(l.split("\t")[1]) >= 2 for l in dump)
+    assert [l.split("\t")[0] for l in dump] == sorted(l.split("\t")[0] for l in dump)
+    with open(t + "/kmers.fq", "w") as f:        # cvtFaToFq (assemble_gaps.py:56-79): the whole dump line is the "sequence"
+        for i, l in enumerate(dump):
+            f.write("@%d\n%s\n+\n%s\n" % (i, l, "5" * len(l)))
+    sh(bind + "/velveth", t + "/vdir", "29", "-fastq", "-short", t + "/kmers.fq")
+    sh(bind + "/velvetg", t + "/vdir", "-min_contig_lgth", "40")
+    assert open(t + "/vdir/contigs.fa").read() == got["merged/velvet_temp/%s/contigs_31_29.fa" % gid]

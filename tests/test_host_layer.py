@@ -1,0 +1,75 @@
+"""Host-side mirror of the reference's stage interfaces (gappadder_amd/*.py) on CPU: Preprocess end-to-end, and the
+FASTQ join / library merge fed with the REFERENCE's own list files — all against the reference-generated golden trees."""
+import os
+
+import pytest
+
+from golden_util import CASES, Case
+import pipeline_util as PU
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request):
+    return Case(request.param)
+
+
+def test_preprocess_cli_matches_reference(case, tmp_path):
+    from gappadder_amd import main as M
+    cfgp, wf, _ = PU.materialise(case, str(tmp_path))
+    M.main(["-c", "Preprocess", "-g", cfgp])
+    got = PU.tree(wf)
+    assert got["gap_positions.txt"] == case.expected["gap_positions.txt"]
+    exp = case.exp_dir("flank_regions/")
+    assert {k: v for k, v in got.items() if k.startswith("flank_regions/")} == {"flank_regions/" + k: v for k, v in exp.items()}
+
+
+def test_join_and_merge_from_reference_lists(case, tmp_path):
+    """collect_discordant_regions_v2, merge_dispatch_reads_for_gaps_v2, dispatch_high_quality_reads_for_gaps and
+    merge_reads_v2 given the reference's scaffold/discordant lists reproduce its position file and per-gap FASTQ files."""
+    from gappadder_amd import main as M
+    from gappadder_amd.merge_reads import ReadsMerger
+    from gappadder_amd.run_multi_threads_discordant import DiscordantReadsCollector
+    cfgp, wf, st = PU.materialise(case, str(tmp_path))
+    M.main(["-c", "Preprocess", "-g", cfgp])
+    cfg = M.parse_configuration(cfgp)
+    folders = M.prepare_folders(cfg["alignments"], wf)
+    sf_fai = cfg["draft"] + ".fai"
+    for lib, folder, (bam, _, _), (l, r) in zip(case.libs, folders, cfg["alignments"], cfg["raw_reads"]):
+        for sub in ("scaffold_reads_list_all/", "discordant_reads_list/"):
+            for name, txt in case.exp_dir(lib["folder"] + "/" + sub).items():
+                open(folder + sub + name, "w").write(txt)
+        drc = DiscordantReadsCollector(sf_fai, bam, folder, 2, gf=object(), samtools_path=st)
+        drc.collect_discordant_regions_v2(folder + "discordant_reads_pos.txt")
+        drc.merge_dispatch_reads_for_gaps_v2(l, r)
+        drc.dispatch_high_quality_reads_for_gaps(l, r)
+    for name in ("gap_reads", "gap_reads_alignment", "gap_reads_high_quality"):
+        ReadsMerger().merge_reads_v2(sf_fai, wf + "gap_positions.txt", folders, name, wf + "merged/", 2)
+    got = PU.tree(wf)
+    for rel, txt in case.expected.items():
+        top = rel.split("/")[0]
+        if rel.endswith(".fastq") or rel.endswith("discordant_reads_pos.txt.sorted.txt") or "discordant_temp/" in rel:
+            assert got.get(rel) == txt, rel
+        elif rel.endswith("_reads.list") or rel.endswith("discordant_reads_pos.txt"):
+            assert sorted(got[rel].splitlines()) == sorted(txt.splitlines()), rel   # dict-ordered in the reference
+    assert not [k for k in got if k.endswith(".fastq") and k not in case.expected]
+
+
+def test_velvet_style_fasta_format():
+    from gappadder_amd.assemble_gaps import format_contigs, velvet_kv
+    txt = format_contigs([("ACGT" * 20, 52, 150), ("TTTT", 1, 3)])
+    lines = txt.splitlines()
+    assert lines[0] == ">NODE_1_length_52_cov_2.884615" and len(lines[1]) == 60 and lines[2] == "ACGT" * 5
+    assert lines[3] == ">NODE_2_length_1_cov_3.000000"
+    assert "-" not in lines[0] and " " not in lines[0]      # names flow into '-'/'_' split protocols downstream
+    assert velvet_kv(29) == 29 and velvet_kv(28) == 27
+
+
+def test_gap_scan_quirks():
+    from gappadder_amd.gnrt_pos_true_seqs import flanks, scan_gaps
+    from oracle import gp_oracle as O
+    for seq in ("ACGT" + "N" * 120 + "acgtACGT" + "N" * 99 + "A" + "NNNN", "N" * 200, "ACGTNNNNnnnnNNNNA" * 10, "NACGT" + "N" * 100 + "C"):
+        assert scan_gaps(seq, 100) == O.scan_gaps(seq, 100)
+        assert scan_gaps(seq, 3) == O.scan_gaps(seq, 3)
+    s = "ACGTACGTAC" * 100
+    for start in (3, 5, 299, 300, 301):
+        assert flanks(s, start, start + 50, 300) == O.flank_seqs(s, start, start + 50, 300)
