@@ -162,14 +162,13 @@ def main():
     ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
     if world > 1:
         # the only collective of the path: gather the assembled sequences of every rank's shard on rank 0 (RCCL)
-        nb = torch.tensor([n_seq], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, nb)
-        mx = int(max(int(x.item()) for x in sizes))
-        buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
-        buf[:n_seq] = d_seq[:n_seq]
-        parts = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, parts, dst=0)
+        from gappadder_amd import sharding as SH
+        seq_local = d_seq[:n_seq].cpu().numpy().tobytes()
+        payload = SH.encode_contigs([(int(c["gap"]), int(c["k"]), int(c["kv"]), int(c["n_nodes"]), int(c["cov_sum"]),
+                                      seq_local[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode()) for c in ctg])
+        gathered = SH.gather_bytes(payload, dst=0, device=dev)
+        if rank == 0:
+            assert len(gathered) == world and all(len(g) > 0 for g in gathered)
 
     out = None
     if rank == 0:
