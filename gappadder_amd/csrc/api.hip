@@ -149,6 +149,14 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "screen_variant")) { ctx->screen_variant = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_dbg_ptr")) { ctx->asm_dbg = (void*)(uintptr_t)value; return GF_OK; }
     if (!strcmp(name, "asm_lds_pool_kb")) { ctx->asm_lds_pool_kb = (int)value; return GF_OK; }
+    if (!strcmp(name, "screen_lds_log2_max")) {
+        ctx->screen_lds_log2_max = std::max(15, std::min(20, (int)value));
+        for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
+        ctx->index.clear();
+        return GF_OK;
+    }
+    if (!strcmp(name, "screen_np_override")) { ctx->screen_np_override = (int)value; return GF_OK; }
+    if (!strcmp(name, "screen_lds_direct")) { ctx->screen_lds_direct = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_wg_per_cu")) { ctx->screen_wg_per_cu = (int)value; return GF_OK; }
     return GF_E_INVAL;
 }

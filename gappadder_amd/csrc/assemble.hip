@@ -108,31 +108,26 @@ __device__ __forceinline__ unsigned long long slot_load(const unsigned long long
     return __hip_atomic_load(t + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// find-or-insert the canonical `len`-mer `key` (instance `inst`); returns the slot or EMPTY32 when the table is full
-__device__ __forceinline__ uint32_t table_insert(unsigned long long* t, uint32_t cap, const PoolView& V, K128 key, uint32_t inst,
-                                                 int len, bool* fresh) {
+constexpr unsigned long long EMPTY64 = 0x00000000FFFFFFFFull;  // id EMPTY32, count / meta 0
+
+// Find-or-insert the canonical `len`-mer `key` (instance `inst`) and add `inc` to the slot's high word, with ONE
+// 64-bit CAS when the slot is free (id and first count land together) or one 64-bit add when the key is already there.
+// `t` may point to LDS or to global memory (generic address).  Returns the slot, EMPTY32 when the table is full.
+__device__ __forceinline__ uint32_t table_upsert(unsigned long long* t, uint32_t cap, const PoolView& V, K128 key, uint32_t inst,
+                                                 int len, uint32_t inc, bool* fresh) {
     uint32_t s = slot_of(key, cap);
     *fresh = false;
     for (uint32_t probes = 0; probes < cap; ++probes) {
-        uint32_t cur = __hip_atomic_load(slot_id(t, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == EMPTY32) {
-            cur = atomicCAS(slot_id(t, s), EMPTY32, inst);
-            if (cur == EMPTY32) { *fresh = true; return s; }
+        unsigned long long v = __hip_atomic_load(t + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)v == EMPTY32) {
+            v = atomicCAS(t + s, EMPTY64, ((unsigned long long)inc << 32) | inst);
+            if (v == EMPTY64) { *fresh = true; return s; }
         }
-        if (cur == inst || canonical(pv_kmer(V, cur, len), len) == key) return s;
-        s = s + 1 == cap ? 0 : s + 1;
-    }
-    return EMPTY32;
-}
-
-__device__ __forceinline__ uint32_t table_find(const unsigned long long* t, uint32_t cap, const PoolView& V, K128 key, int len,
-                                               uint32_t* meta) {
-    uint32_t s = slot_of(key, cap);
-    for (uint32_t probes = 0; probes < cap; ++probes) {
-        const unsigned long long v = slot_load(t, s);
         const uint32_t cur = (uint32_t)v;
-        if (cur == EMPTY32) return EMPTY32;
-        if (canonical(pv_kmer(V, cur, len), len) == key) { *meta = (uint32_t)(v >> 32); return s; }
+        if (cur == inst || canonical(pv_kmer(V, cur, len), len) == key) {
+            atomicAdd(t + s, (unsigned long long)inc << 32);
+            return s;
+        }
         s = s + 1 == cap ? 0 : s + 1;
     }
     return EMPTY32;
@@ -166,9 +161,13 @@ __device__ __forceinline__ K128 shift_in_front(K128 v, uint32_t c, int len) {
 
 #define ASM_STAMP(n) do { if (P.dbg && tid == 0) P.dbg[(uint64_t)g * 8 + (n)] = wall_clock64(); } while (0)
 
+// LDS plan of one gap (dynamic LDS = P.lds_words words):  [ staged pool | region R ]
+//   count phase   R = k-mer table (8-B slots) when the distinct k-mers keep it under 3/4 full, else the global slice
+//   graph phase   R = node table (2 slots per possible node) + inst_of/meta/succ0/succ1 arrays, else global
+// Every pointer below is generic (LDS or global); the code path is the same.
 __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
-    extern __shared__ uint32_t pool_lds[];  // P.lds_words words: the gap's packed reads when they fit
-    __shared__ uint32_t s_cnt[8];  // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t s_cnt[8];  // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes [6] LDS table overflow
     __shared__ unsigned long long s_seq[2];  // [0] bases to emit  [1] global base offset
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
@@ -191,23 +190,27 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
         const uint32_t n_inst = (uint32_t)((uint64_t)n_r * npos);   // k-mer positions
         const uint32_t n_unit = (uint32_t)n_unit64;
-        const uint32_t cap = 4 * n_unit;
-        unsigned long long* tab = P.table + 4 * inst_off;
+        unsigned long long* gtab = P.table + 4 * inst_off;   // global slice, 4 * n_unit slots, all EMPTY on entry
+        const uint32_t gcap = 4 * n_unit;
         uint32_t* surv = P.surv + 2 * inst_off;
+        uint32_t* list_a = surv;           // slots of the distinct k-mers, later of the nodes
+        uint32_t* list_b = surv + n_unit;  // surviving instances, later node instance ids (global mode) + walk records
 
-        // ---- stage the pool (LDS when it fits) and clear the tables
+        // ---- stage the pool
         PoolView V;
         V.rb = P.rb; V.L = P.read_len;
         V.g32 = P.reads32; V.g_words = P.n_words; V.g_tail = P.tail_bytes;
         V.first_byte = r0 * P.rb;
         const uint64_t pool_bytes = (uint64_t)n_r * P.rb;
-        V.lds = pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / 3;  // at most a third: the node arrays want the rest
-        V.w = pool_lds;
+        V.lds = pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / 3;  // at most a third of the LDS
+        V.w = lds;
+        uint32_t pool_words = 0;
         if (V.lds) {
             const uint64_t w0 = V.first_byte >> 2;
             const uint32_t sh = (uint32_t)(V.first_byte & 3) * 8;
             const uint32_t nw = (uint32_t)((pool_bytes + 3) / 4);
-            for (uint32_t i = tid; i < nw + 6; i += ASM_THREADS) {
+            pool_words = (nw + 8) & ~1u;   // keeps region R 8-byte aligned
+            for (uint32_t i = tid; i < pool_words; i += ASM_THREADS) {
                 uint32_t v = 0;
                 if (i < nw) {
                     const uint32_t a = asm_word(P.reads32, P.n_words, P.tail_bytes, w0 + i);
@@ -215,40 +218,62 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     v = sh ? (a >> sh) | (b << (32 - sh)) : a;
                     if (i == nw - 1 && (pool_bytes & 3)) v &= (1u << ((pool_bytes & 3) * 8)) - 1;
                 }
-                pool_lds[i] = v;
+                lds[i] = v;
             }
         }
-        ASM_STAMP(0);
-        // the table slice is all-EMPTY here: the workspace is cleared when allocated and every gap resets the slots it used
+        uint32_t* R = lds + pool_words;
+        const uint32_t r_words = P.lds_words - pool_words;
         if (tid < 8) s_cnt[tid] = 0;
         if (tid < 2) s_seq[tid] = 0;
         __syncthreads();
-        uint32_t* list_a = surv;           // P1: slots of distinct k-mers   P3..P5: slots of nodes
-        uint32_t* list_b = surv + n_unit;  // P2: surviving instances        P5: (start, n_nodes) of emitted walks
+        ASM_STAMP(0);
 
-        // ---- P1: count canonical k-mers; remember each distinct k-mer's slot
-        for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
-            const uint32_t r = inst_i / npos, p = inst_i - r * npos;
-            if (P.nmask) {
-                bool bad = false;
-                for (uint32_t q = p; q < p + P.k; ++q)
-                    if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
-                if (bad) continue;
+        // ---- P1: count canonical k-mers; remember each distinct k-mer's slot.  Optimistic LDS table first.
+        unsigned long long* tab = gtab;
+        uint32_t cap = gcap;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool use_lds = attempt == 0 && r_words / 2 >= 1024;
+            if (attempt == 0 && !use_lds) continue;
+            tab = use_lds ? reinterpret_cast<unsigned long long*>(R) : gtab;
+            cap = use_lds ? r_words / 2 : gcap;
+            const uint32_t limit = use_lds ? cap - cap / 4 : 0xFFFFFFFFu;
+            if (use_lds) {
+                for (uint32_t i = tid; i < cap; i += ASM_THREADS) tab[i] = EMPTY64;
+                __syncthreads();
             }
-            const uint32_t inst = r * P.read_len + p;
-            const K128 key = canonical(pv_kmer(V, inst, k), k);
-            bool fresh;
-            const uint32_t s = table_insert(tab, cap, V, key, inst, k, &fresh);
-            if (s == EMPTY32) { s_cnt[3] = 1; continue; }
-            if (fresh) list_a[atomicAdd(&s_cnt[4], 1u)] = s;
-            atomicAdd(slot_meta(tab, s), 1u);
+            for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
+                if (use_lds && s_cnt[6]) break;
+                const uint32_t r = inst_i / npos, p = inst_i - r * npos;
+                if (P.nmask) {
+                    bool bad = false;
+                    for (uint32_t q = p; q < p + P.k; ++q)
+                        if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
+                    if (bad) continue;
+                }
+                const uint32_t inst = r * P.read_len + p;
+                const K128 key = canonical(pv_kmer(V, inst, k), k);
+                bool fresh;
+                const uint32_t s = table_upsert(tab, cap, V, key, inst, k, 1u, &fresh);
+                if (s == EMPTY32) { if (use_lds) s_cnt[6] = 1; else s_cnt[3] = 1; continue; }
+                if (fresh) {
+                    const uint32_t q = atomicAdd(&s_cnt[4], 1u);
+                    if (q >= limit) s_cnt[6] = 1;
+                    if (q < n_unit) list_a[q] = s;
+                }
+            }
+            __threadfence();
+            __syncthreads();
+            if (!(use_lds && s_cnt[6])) break;
+            // the LDS table got too full: start over in the global slice (nothing global was touched yet)
+            __syncthreads();
+            if (tid == 0) { s_cnt[4] = 0; s_cnt[6] = 0; }
+            __syncthreads();
         }
-        __threadfence();
-        __syncthreads();
-        const uint32_t n_dist = s_cnt[4];
+        const bool tab_global = tab == gtab;
+        const uint32_t n_dist = s_cnt[4] < n_unit ? s_cnt[4] : n_unit;
         ASM_STAMP(1);
 
-        // ---- P2: survivors (count >= min_count) -> list; the used slots are reset for the graph phase
+        // ---- P2: survivors (count >= min_count) -> list_b; a global table gets its used slots reset
         for (uint32_t i0 = 0; i0 < n_dist; i0 += ASM_THREADS) {
             const uint32_t i = i0 + tid;
             bool keep = false;
@@ -259,7 +284,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 id = (uint32_t)v;
                 c = (uint32_t)(v >> 32);
                 keep = c >= P.min_count;
-                tab[sl] = 0x00000000FFFFFFFFull;
+                if (tab_global) tab[sl] = EMPTY64;
             }
             const unsigned long long bal = __ballot(keep);
             if (bal) {
@@ -288,70 +313,92 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         const uint32_t n_surv = s_cnt[0];
         ASM_STAMP(2);
 
-        // ---- P3: nodes + edges; remember each node's slot
-        for (uint32_t j = tid; j < n_surv; j += ASM_THREADS) {
-            const uint32_t inst = list_b[j];
-            const K128 tf = pv_kmer(V, inst, k);
-            K128 t = tf;
-            {   // use the canonical k-mer string (what kmc_dump lists); either strand yields the same graph
-                const K128 rc = revcomp(t, k);
-                if (rc < t) t = rc;
+        // ---- graph-phase memory: node table + 4 arrays.  Optimistic LDS plan first: room for `nb` nodes (7 words each:
+        //      4/3 table slots + inst_of/meta/succ0/succ1); if the gap has more nodes the phase is redone in global memory.
+        const uint64_t node_bound = (uint64_t)per * n_surv < n_unit ? (uint64_t)per * n_surv : n_unit;
+        bool graph_lds = false;
+        uint32_t nb = 0, ncap = gcap, n_nodes = 0;
+        unsigned long long* ntab = gtab;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            graph_lds = false;
+            if (attempt == 0) {
+                nb = (uint32_t)(node_bound < r_words / 7 ? node_bound : r_words / 7);
+                if (nb < n_surv || nb < 64) continue;       // cannot even hold one node per survivor: go global
+                graph_lds = true;
             }
-            const bool fwd = tf == t;
-            uint32_t ps = EMPTY32, pd = 0;
-            for (uint32_t o = 0; o < per; ++o) {
-                // kv-mer at offset o of t
-                K128 a;
-                {
-                    const int sh = 2 * (int)o;
-                    a.hi = sh ? (t.hi << sh) | (t.lo >> (64 - sh)) : t.hi;
-                    a.lo = sh ? (t.lo << sh) : t.lo;
-                    a = mask_k(a, kv);
-                }
-                const K128 rc = revcomp(a, kv);
-                const uint32_t d = rc < a ? 1u : 0u;
-                const K128 A = d ? rc : a;
-                // instance id of this kv-mer: same read, offset shifted (orientation does not matter for the key)
-                const uint32_t ninst = fwd ? inst + o : inst + (per - 1 - o);
-                bool fresh;
-                const uint32_t s = table_insert(tab, cap, V, A, ninst, kv, &fresh);
-                if (s == EMPTY32) { s_cnt[3] = 1; break; }
-                if (fresh) {
-                    const uint32_t q = atomicAdd(&s_cnt[5], 1u);
-                    if (q < n_unit) list_a[q] = s; else s_cnt[3] = 1;
-                }
-                atomicAdd(slot_meta(tab, s), 1u << M_MULT_SHIFT);
-                if (ps != EMPTY32) {  // edge prev -> this
-                    const uint32_t c_out = kbase(t, (int)(o - 1) + kv), c_in = kbase(t, (int)o - 1);
-                    atomicOr(slot_meta(tab, ps), pd ? (1u << (4 + (3 - c_out))) : (1u << c_out));
-                    atomicOr(slot_meta(tab, s), d ? (1u << (3 - c_in)) : (1u << (4 + c_in)));
-                }
-                ps = s; pd = d;
+            ntab = graph_lds ? reinterpret_cast<unsigned long long*>(R + 4 * nb) : gtab;
+            ncap = graph_lds ? (r_words - 4 * nb) / 2 : gcap;
+            if (graph_lds) {
+                for (uint32_t i = tid; i < ncap; i += ASM_THREADS) ntab[i] = EMPTY64;
+                __syncthreads();
             }
+            // ---- P3: nodes + edges; remember each node's slot
+            for (uint32_t j = tid; j < n_surv; j += ASM_THREADS) {
+                if (graph_lds && s_cnt[6]) break;
+                const uint32_t inst = list_b[j];
+                const K128 tf = pv_kmer(V, inst, k);
+                K128 t = tf;
+                {   // use the canonical k-mer string (what kmc_dump lists); either strand yields the same graph
+                    const K128 rc = revcomp(t, k);
+                    if (rc < t) t = rc;
+                }
+                const bool fwd = tf == t;
+                uint32_t ps = EMPTY32, pd = 0;
+                for (uint32_t o = 0; o < per; ++o) {
+                    K128 a;  // kv-mer at offset o of t
+                    {
+                        const int sh = 2 * (int)o;
+                        a.hi = sh ? (t.hi << sh) | (t.lo >> (64 - sh)) : t.hi;
+                        a.lo = sh ? (t.lo << sh) : t.lo;
+                        a = mask_k(a, kv);
+                    }
+                    const K128 rc = revcomp(a, kv);
+                    const uint32_t d = rc < a ? 1u : 0u;
+                    const K128 A = d ? rc : a;
+                    const uint32_t ninst = fwd ? inst + o : inst + (per - 1 - o);  // same read, shifted offset
+                    bool fresh;
+                    const uint32_t sl = table_upsert(ntab, ncap, V, A, ninst, kv, 1u << M_MULT_SHIFT, &fresh);
+                    if (sl == EMPTY32) { if (graph_lds) s_cnt[6] = 1; else s_cnt[3] = 1; break; }
+                    if (fresh) {
+                        const uint32_t q = atomicAdd(&s_cnt[5], 1u);
+                        if (graph_lds && q >= nb) { s_cnt[6] = 1; break; }
+                        if (q < n_unit) list_a[q] = sl; else s_cnt[3] = 1;
+                    }
+                    if (ps != EMPTY32) {  // edge prev -> this
+                        const uint32_t c_out = kbase(t, (int)(o - 1) + kv), c_in = kbase(t, (int)o - 1);
+                        atomicOr(slot_meta(ntab, ps), pd ? (1u << (4 + (3 - c_out))) : (1u << c_out));
+                        atomicOr(slot_meta(ntab, sl), d ? (1u << (3 - c_in)) : (1u << (4 + c_in)));
+                    }
+                    ps = sl; pd = d;
+                }
+            }
+            __threadfence();
+            __syncthreads();
+            if (!(graph_lds && s_cnt[6])) break;
+            __syncthreads();
+            if (tid == 0) { s_cnt[5] = 0; s_cnt[6] = 0; }   // too many nodes for the LDS plan: redo in the global slice
+            __syncthreads();
         }
-        __threadfence();
-        __syncthreads();
-        const uint32_t n_nodes = s_cnt[5] < n_unit ? s_cnt[5] : n_unit;
+        n_nodes = s_cnt[5] < n_unit ? s_cnt[5] : n_unit;
+        uint32_t* arr = graph_lds ? R : P.nodes + 3 * inst_off;
+        const uint32_t astride = graph_lds ? nb : n_nodes;
         ASM_STAMP(3);
 
-        // ---- P3.5: nodes get dense indices.  slot.id <- node index, inst_of[index] <- instance id; the per-node arrays
-        //      (succ[2], meta) live in LDS behind the staged pool when they fit, else in the global workspace
-        uint32_t* inst_of = list_b;                       // [n_nodes]
-        uint32_t* rec = list_b + n_nodes;                 // emitted-walk records, 2 words each
-        const uint32_t rec_cap = (n_unit - n_nodes) / 2;
-        const uint32_t pool_words_used = V.lds ? (uint32_t)((pool_bytes + 3) / 4) + 8 : 0;
-        const bool nodes_lds = (uint64_t)pool_words_used + 3ull * n_nodes <= P.lds_words;
-        uint32_t* nmeta = nodes_lds ? pool_lds + pool_words_used : P.nodes + 3 * inst_off;
-        uint32_t* succ0 = nmeta + n_nodes;
-        uint32_t* succ1 = succ0 + n_nodes;
+        // ---- P3.5: dense node indices.  slot.id <- node index; inst_of / meta / succ arrays
+        uint32_t* inst_of = graph_lds ? arr : list_b;
+        uint32_t* nmeta = graph_lds ? arr + astride : arr;
+        uint32_t* succ0 = nmeta + astride;
+        uint32_t* succ1 = succ0 + astride;
+        uint32_t* rec = list_b + (graph_lds ? 0 : n_nodes);           // emitted-walk records, 2 words each
+        const uint32_t rec_cap = (n_unit - (graph_lds ? 0 : n_nodes)) / 2;
         for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
             const uint32_t sl = list_a[ni];
-            const unsigned long long v = slot_load(tab, sl);
+            const unsigned long long v = slot_load(ntab, sl);
             inst_of[ni] = (uint32_t)v;
             nmeta[ni] = (uint32_t)(v >> 32);
             succ0[ni] = EMPTY32;
             succ1[ni] = EMPTY32;
-            *slot_id(tab, sl) = ni;
+            *slot_id(ntab, sl) = ni;
         }
         __threadfence();
         __syncthreads();
@@ -369,13 +416,12 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const K128 yr = revcomp(y, kv);
                 const uint32_t dy = yr < y ? 1u : 0u;
                 const K128 Y = dy ? yr : y;
-                // find y's node index (slot.id is a node index now)
-                uint32_t sl = slot_of(Y, cap), yi = EMPTY32;
-                for (uint32_t probes = 0; probes < cap; ++probes) {
-                    const uint32_t cand = __hip_atomic_load(slot_id(tab, sl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t sl = slot_of(Y, ncap), yi = EMPTY32;   // slot.id is a node index now
+                for (uint32_t probes = 0; probes < ncap; ++probes) {
+                    const uint32_t cand = __hip_atomic_load(slot_id(ntab, sl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cand == EMPTY32) break;
-                    if (canonical(pv_kmer(V, inst_of[cand], kv), kv) == Y) { yi = cand; break; }
-                    sl = sl + 1 == cap ? 0 : sl + 1;
+                    if (cand < n_nodes && canonical(pv_kmer(V, inst_of[cand], kv), kv) == Y) { yi = cand; break; }
+                    sl = sl + 1 == ncap ? 0 : sl + 1;
                 }
                 if (yi == EMPTY32) continue;
                 if (__popc(in_bits(nmeta[yi] & 0xFFu, dy)) != 1) continue;
@@ -451,9 +497,12 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
         __syncthreads();
         ASM_STAMP(6);
-        for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) tab[list_a[ni]] = 0x00000000FFFFFFFFull;  // leave the slice EMPTY
+        // leave the global slice EMPTY for the next gap / launch
+        if (!graph_lds) {
+            for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) gtab[list_a[ni]] = EMPTY64;
+        }
         if (s_cnt[3])  // an overflow may have left slots outside the lists: clear the whole slice
-            for (uint32_t i = tid; i < cap; i += ASM_THREADS) tab[i] = 0x00000000FFFFFFFFull;
+            for (uint32_t i = tid; i < gcap; i += ASM_THREADS) gtab[i] = EMPTY64;
         __threadfence();
         __syncthreads();
     }

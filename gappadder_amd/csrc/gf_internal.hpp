@@ -23,6 +23,10 @@ struct FlankIndex {
     // level 1: bitmap over hashed canonical 16-mers (L2-resident filter)
     int bm_log2 = 0;
     uint32_t* d_bitmap = nullptr;
+    // coarse copy for the LDS pre-filter (2^lds_log2 bits, lds_log2 <= 20), its fill ratio
+    uint32_t* d_bitmap_lds = nullptr;
+    int lds_log2 = 0;
+    double lds_fill = 1.0;
     // level 2: exact set of canonical 16-mers (open addressing, EMPTY32)
     int s_log2 = 0;
     uint32_t* d_sset = nullptr;
@@ -65,6 +69,9 @@ struct gf_ctx {
     int bitmap_log2_override = 0;
     int screen_variant = 0;     // tuning: load mode / unroll of the filter kernel
     int screen_wg_per_cu = 0;
+    int screen_lds_direct = 0;
+    int screen_np_override = -1;
+    int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)
     int asm_lds_pool_kb = 152;
     void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)
     // tagger coarse bin map (rebuilt when dist2 changes)

@@ -62,6 +62,7 @@ void extract(const std::string& s, int k, uint32_t gap, std::vector<Entry>& kmer
 
 void free_flank_index(gf_ctx*, FlankIndex& ix) {
     if (ix.d_bitmap) (void)hipFree(ix.d_bitmap);
+    if (ix.d_bitmap_lds) (void)hipFree(ix.d_bitmap_lds);
     if (ix.d_sset) (void)hipFree(ix.d_sset);
     if (ix.d_table) (void)hipFree(ix.d_table);
     ix = FlankIndex();
@@ -152,7 +153,21 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
         bm[h >> 5] |= 1u << (h & 31);
     }
 
+    // coarse copy for the LDS pre-filter: bit c = OR of the level-1 bits h with (h >> (bl - lds_log2)) == c
+    ix.lds_log2 = std::min(ctx->screen_lds_log2_max, bl);
+    const size_t cwords = ((size_t)1 << ix.lds_log2) / 32;
+    std::vector<uint32_t> cbm(cwords, 0);
+    size_t cset = 0;
+    for (uint32_t key : s16) {
+        const uint32_t c = hash_s16_bitmap(key, bl) >> (bl - ix.lds_log2);
+        if (!((cbm[c >> 5] >> (c & 31)) & 1u)) ++cset;
+        cbm[c >> 5] |= 1u << (c & 31);
+    }
+    ix.lds_fill = (double)cset / (double)((size_t)1 << ix.lds_log2);
+
     GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_bitmap_lds, cwords * 4));
+    GF_HIP(ctx, hipMemcpy(ix.d_bitmap_lds, cbm.data(), cwords * 4, hipMemcpyHostToDevice));
     GF_HIP(ctx, hipMalloc((void**)&ix.d_bitmap, bwords * 4));
     GF_HIP(ctx, hipMalloc((void**)&ix.d_sset, scap * 4));
     GF_HIP(ctx, hipMalloc(&ix.d_table, tab.size() * 4));

@@ -121,6 +121,18 @@ GF_HD uint32_t stream32(P words, uint32_t bitoff) {
     return (uint32_t)((v << sh) >> 32);
 }
 
+// same for a BYTE-aligned offset: on the device the unaligned fetch and the byte swap collapse into one v_perm_b32
+template <typename P>
+GF_HD uint32_t stream32_bytes(P words, uint32_t byteoff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t d = byteoff >> 2, o = byteoff & 3;
+    const uint32_t sel = 0x00010203u + o * 0x01010101u;   // output bytes (MSB..LSB) = stream bytes o, o+1, o+2, o+3
+    return __builtin_amdgcn_perm(words[d + 1], words[d], sel);
+#else
+    return stream32(words, byteoff * 8);
+#endif
+}
+
 // the k-mer starting at bit offset `bitoff` (k <= 64), left-aligned and masked
 template <typename P>
 GF_HD K128 stream_kmer(P words, uint32_t bitoff, int k) {

@@ -25,11 +25,17 @@ struct FilterParams {
     uint32_t bm_log2, s_log2;
     uint32_t* cand;
     uint32_t* n_cand;
+    // LDS pre-filter variant: a coarser copy of the bitmap (bit i = OR of the 2^(bm_log2-lds_log2) bits it covers)
+    const uint32_t* bitmap_lds;
+    uint32_t lds_log2;
+    uint32_t lds_direct;   // 1: probes that pass the LDS bitmap go straight to the exact set (no L2 bitmap hop)
 };
 
 // how the filter's bitmap words are fetched: every probe is a 4-byte read of a random 128-B line of an
 // L2-resident table, so the L2->CU transfer per probe is what bounds the kernel
-enum { LOAD_PLAIN = 0, LOAD_NT = 1, LOAD_SC1 = 2, LOAD_SC01 = 3 };
+enum { LOAD_PLAIN = 0, LOAD_NT = 1, LOAD_SC1 = 2, LOAD_SC01 = 3,
+       LOAD_ABL_STREAM = 10,   // ablation builds (timing only, wrong results): tile staging + one LDS word per probe
+       LOAD_ABL_COMPUTE = 11 };  // ... + key/hash arithmetic, no bitmap load
 
 template <int MODE>
 __device__ __forceinline__ uint32_t probe_load(const uint32_t* p) {
@@ -84,10 +90,14 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
                         word[u] = 0;
                         hb[u] = 0;
                         if (j < g1) {
-                            const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
-                            const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
-                            hb[u] = h & 31;
-                            word[u] = probe_load<MODE>(P.bitmap + (h >> 5));
+                            if (MODE == LOAD_ABL_STREAM) {
+                                word[u] = tile[(bit0 + j * P.stride2) >> 5] == 0x12345678u;
+                            } else {
+                                const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
+                                const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
+                                hb[u] = h & 31;
+                                word[u] = MODE == LOAD_ABL_COMPUTE ? (uint32_t)(h == 0x12345u) : probe_load<MODE>(P.bitmap + (h >> 5));
+                            }
                         }
                     }
 #pragma unroll
@@ -134,6 +144,330 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
             __syncthreads();
             for (uint32_t i = tid; i < n; i += 256) P.cand[cbuf_base + i] = cbuf[i];
         }
+    }
+}
+
+// Variant with an LDS-resident pre-filter.  The L2-resident bitmap is what bounds the plain kernel (one random L2 request
+// per probe); here every workgroup first copies a coarse version of that bitmap (<= 2^20 bits = 128 KiB) into LDS and
+// only probes that pass it go on to L2.  One workgroup per CU (the coarse bitmap fills most of the LDS); tile = one read
+// per thread.  Worth it while the coarse bitmap stays sparse (host decides, see launch_screen).
+constexpr uint32_t LDSF_CBUF = 512;
+
+// NCH = 16-byte chunks of a tile each thread fetches (ceil(rb/16)); the NEXT tile is fetched into registers while the
+// current one is processed (one workgroup per CU: nothing else would overlap the global->LDS latency).  NCH = 0: no prefetch.
+template <int NCH>
+__global__ __launch_bounds__(1024) void screen_filter_lds_kernel(FilterParams P) {
+    extern __shared__ uint32_t sm[];  // [coarse bitmap: 2^lds_log2 bits][tile: blockDim.x reads + 16 B]
+    __shared__ uint32_t cbuf[LDSF_CBUF];
+    __shared__ uint32_t cbuf_n, cbuf_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const uint32_t bm_words = 1u << (P.lds_log2 - 5);
+    uint32_t* tile = sm + bm_words;
+    uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
+    for (uint32_t i = tid * 4; i < bm_words; i += nthr * 4)
+        *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap_lds + i);
+    if (tid == 0) cbuf_n = 0;
+    const uint32_t tile_bytes = nthr * P.rb;
+    const uint64_t total_bytes = P.n_reads * P.rb;
+    const uint64_t n_tiles = (P.n_reads + nthr - 1) / nthr;
+    const uint32_t smask = (1u << P.s_log2) - 1;
+    const uint32_t coarse_shift = P.bm_log2 - P.lds_log2;
+    const bool same = coarse_shift == 0;   // the LDS bitmap IS the level-1 bitmap
+    constexpr int NPF = NCH > 0 ? NCH : 1;
+    uint4 pf[NPF];
+    auto prefetch = [&](uint64_t t) {   // 16-B chunks tid, tid+nthr, ... of tile t (whole chunks only)
+        if (NCH == 0 || t >= n_tiles) return;
+        const uint64_t byte0 = t * tile_bytes;
+        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+        const uint32_t n16 = nbytes >> 4;
+#pragma unroll
+        for (int c = 0; c < NPF; ++c) {
+            const uint32_t i = tid + c * nthr;
+            pf[c] = i < n16 ? *reinterpret_cast<const uint4*>(P.reads + byte0 + (uint64_t)i * 16) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    prefetch(blockIdx.x);
+    __syncthreads();
+
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t byte0 = t * tile_bytes;
+        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+        const uint32_t n16 = nbytes & ~15u;
+        const uint8_t* src = P.reads + byte0;
+        if (NCH > 0) {
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) {
+                const uint32_t i = tid + c * nthr;
+                if (i < (n16 >> 4)) *reinterpret_cast<uint4*>(tb + (uint64_t)i * 16) = pf[c];
+            }
+        } else {
+            for (uint32_t i = tid * 16; i < n16; i += nthr * 16)
+                *reinterpret_cast<uint4*>(tb + i) = *reinterpret_cast<const uint4*>(src + i);
+        }
+        for (uint32_t i = n16 + tid; i < nbytes; i += nthr) tb[i] = src[i];
+        if (tid < 16) tb[nbytes + tid] = 0;
+        __syncthreads();
+        prefetch(t + gridDim.x);
+
+        const uint64_t r = t * nthr + tid;
+        bool cand = false;
+        if (r < P.n_reads) {
+            const uint32_t bit0 = tid * P.rb * 8;
+            for (uint32_t g0 = 0; g0 < P.np && !cand; g0 += 32) {
+                const uint32_t g1 = g0 + 32 < P.np ? g0 + 32 : P.np;
+                uint32_t m1 = 0;   // probes that pass the LDS bitmap
+                for (uint32_t j = g0; j < g1; ++j) {
+                    const uint32_t h = hash_s16_bitmap(canon16(stream32(tile, bit0 + j * P.stride2)), P.bm_log2);
+                    const uint32_t c = h >> coarse_shift;
+                    m1 |= ((sm[c >> 5] >> (c & 31)) & 1u) << (j - g0);
+                }
+                // level 1 in L2 for the survivors (skipped when the LDS bitmap is the level-1 bitmap itself)
+                uint32_t mask = m1;
+                if (!same && m1) {
+                    mask = 0;
+                    uint32_t m = m1;
+                    while (m) {   // up to 5 L2 probes in flight
+                        uint32_t jj[5], word[5], hb[5];
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            word[u] = 0; hb[u] = 0; jj[u] = 0;
+                            if (m) {
+                                jj[u] = __ffs(m) - 1;
+                                m &= m - 1;
+                                const uint32_t h = hash_s16_bitmap(canon16(stream32(tile, bit0 + (g0 + jj[u]) * P.stride2)), P.bm_log2);
+                                hb[u] = h & 31;
+                                word[u] = P.bitmap[h >> 5];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) mask |= ((word[u] >> hb[u]) & 1u) << jj[u];
+                    }
+                }
+                // level 2: confirm in the exact canonical-16-mer set
+                while (mask && !cand) {
+                    const uint32_t j = g0 + __ffs(mask) - 1;
+                    mask &= mask - 1;
+                    const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
+                    uint32_t s = hash_s16_set(key, P.s_log2);
+                    uint32_t v;
+                    while ((v = P.sset[s]) != EMPTY32) {
+                        if (v == key) { cand = true; break; }
+                        s = (s + 1) & smask;
+                    }
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(cand);
+        if (bal) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&cbuf_n, (uint32_t)__popcll(bal));
+            base = __shfl(base, 0);
+            const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
+            if (cand) {
+                if (o < LDSF_CBUF) cbuf[o] = (uint32_t)r;
+                else P.cand[atomicAdd(P.n_cand, 1u)] = (uint32_t)r;   // buffer full (candidate-dense tile): direct append
+            }
+        }
+        __syncthreads();
+        if (cbuf_n > LDSF_CBUF / 2) {
+            const uint32_t n = cbuf_n < LDSF_CBUF ? cbuf_n : LDSF_CBUF;
+            if (tid == 0) cbuf_base = atomicAdd(P.n_cand, n);
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += nthr) P.cand[cbuf_base + i] = cbuf[i];
+            __syncthreads();
+            if (tid == 0) cbuf_n = 0;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t n = cbuf_n < LDSF_CBUF ? cbuf_n : LDSF_CBUF;
+        if (n) {
+            if (tid == 0) cbuf_base = atomicAdd(P.n_cand, n);
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += nthr) P.cand[cbuf_base + i] = cbuf[i];
+        }
+    }
+}
+
+// Wave-autonomous variant of the LDS pre-filter kernel: every wavefront streams its own 64-read mini-tiles through a
+// private LDS slice (no workgroup barrier in the loop, so one wave waiting on an L2 chain never stalls the other eleven),
+// prefetches its next mini-tile into registers, and appends candidates through a private LDS buffer.
+constexpr uint32_t WOBUF = 96;   // candidates buffered per wave; flushed with one global atomic when >= 32
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // LDS ops of one wave execute in order: only the compiler must not reorder
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NCH>
+__global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P, uint32_t slice_words) {
+    extern __shared__ uint32_t sm[];  // [coarse bitmap][per wave: 64 reads + pad | WOBUF candidate ids]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthr = blockDim.x, nw = nthr >> 6;
+    const uint32_t bm_words = 1u << (P.lds_log2 - 5);
+    for (uint32_t i = tid * 4; i < bm_words; i += nthr * 4)
+        *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap_lds + i);
+    uint32_t* tile = sm + bm_words + w * (slice_words + WOBUF);
+    uint32_t* obuf = tile + slice_words;
+    uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
+    uint32_t obuf_n = 0;   // wave-uniform
+    const uint32_t tile_bytes = 64 * P.rb;
+    const uint64_t total_bytes = P.n_reads * P.rb;
+    const uint64_t n_tiles = (P.n_reads + 63) / 64;
+    const uint32_t smask = (1u << P.s_log2) - 1;
+    const uint32_t coarse_shift = P.bm_log2 - P.lds_log2;
+    const bool same = coarse_shift == 0 || P.lds_direct;
+    const bool bytes_ok = (P.stride2 & 7) == 0;   // probes start on byte boundaries (k = 31, 35, 39, ...)
+    constexpr int NPF = NCH > 0 ? NCH : 1;
+    // three mini-tiles in flight per wave: with ~11 waves per CU a single outstanding 2.4-KB fetch per wave leaves the
+    // kernel bound by memory latency x concurrency, not by bandwidth
+    uint4 pfA[NPF], pfB[NPF], pfC[NPF];
+    auto prefetch = [&](uint4 (&pf)[NPF], uint64_t t) {
+        if (NCH == 0 || t >= n_tiles) return;
+        const uint64_t byte0 = t * tile_bytes;
+        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+        const uint32_t n16 = nbytes >> 4;
+#pragma unroll
+        for (int c = 0; c < NPF; ++c) {
+            const uint32_t i = lane + c * 64;
+            pf[c] = i < n16 ? *reinterpret_cast<const uint4*>(P.reads + byte0 + (uint64_t)i * 16) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    const uint64_t t0 = (uint64_t)blockIdx.x * nw + w, tstride = (uint64_t)gridDim.x * nw;
+    prefetch(pfA, t0);
+    prefetch(pfB, t0 + tstride);
+    prefetch(pfC, t0 + 2 * tstride);
+    __syncthreads();   // coarse bitmap staged
+
+    auto process = [&](uint4 (&pf)[NPF], uint64_t t) {
+        const uint64_t byte0 = t * tile_bytes;
+        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+        const uint32_t n16 = nbytes & ~15u;
+        const uint8_t* src = P.reads + byte0;
+        if (NCH > 0) {
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) {
+                const uint32_t i = lane + c * 64;
+                if (i < (n16 >> 4)) *reinterpret_cast<uint4*>(tb + (uint64_t)i * 16) = pf[c];
+            }
+        } else {
+            for (uint32_t i = lane * 16; i < n16; i += 64 * 16)
+                *reinterpret_cast<uint4*>(tb + i) = *reinterpret_cast<const uint4*>(src + i);
+        }
+        for (uint32_t i = n16 + lane; i < nbytes; i += 64) tb[i] = src[i];
+        if (lane < 16) tb[nbytes + lane] = 0;
+        wave_lds_sync();
+        prefetch(pf, t + 3 * tstride);
+
+        const uint64_t r = t * 64 + lane;
+        bool cand = false;
+        if (r < P.n_reads) {
+            const uint32_t bit0 = lane * P.rb * 8;
+            for (uint32_t g0 = 0; g0 < P.np && !cand; g0 += 32) {
+                const uint32_t g1 = g0 + 32 < P.np ? g0 + 32 : P.np;
+                uint32_t m1 = 0;   // probes that pass the LDS bitmap; three probes' LDS reads in flight at a time
+                for (uint32_t j0 = g0; j0 < g1; j0 += 3) {
+                    uint32_t w32[3], c[3], bw[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const uint32_t j = j0 + u < g1 ? j0 + u : g1 - 1;
+                        w32[u] = bytes_ok ? stream32_bytes(tile, (bit0 + j * P.stride2) >> 3) : stream32(tile, bit0 + j * P.stride2);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        c[u] = hash_s16_bitmap(canon16(w32[u]), P.bm_log2) >> coarse_shift;
+                        bw[u] = sm[c[u] >> 5];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+                        if (j0 + u < g1) m1 |= ((bw[u] >> (c[u] & 31)) & 1u) << (j0 + u - g0);
+                }
+                uint32_t mask = m1;
+                if (!same && m1) {
+                    mask = 0;
+                    uint32_t m = m1;
+                    while (m) {   // up to 5 L2 probes in flight
+                        uint32_t jj[5], word[5], hb[5];
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            word[u] = 0; hb[u] = 0; jj[u] = 0;
+                            if (m) {
+                                jj[u] = __ffs(m) - 1;
+                                m &= m - 1;
+                                const uint32_t h = hash_s16_bitmap(canon16(stream32(tile, bit0 + (g0 + jj[u]) * P.stride2)), P.bm_log2);
+                                hb[u] = h & 31;
+                                word[u] = P.bitmap[h >> 5];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) mask |= ((word[u] >> hb[u]) & 1u) << jj[u];
+                    }
+                }
+                while (mask && !cand) {   // level 2: exact canonical-16-mer set, up to 3 lookups in flight
+                    uint32_t key[3], sl[3], v[3];
+                    bool on[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        on[u] = mask != 0;
+                        key[u] = 0; sl[u] = 0; v[u] = EMPTY32;
+                        if (on[u]) {
+                            const uint32_t j = g0 + __ffs(mask) - 1;
+                            mask &= mask - 1;
+                            key[u] = canon16(stream32(tile, bit0 + j * P.stride2));
+                            sl[u] = hash_s16_set(key[u], P.s_log2);
+                            v[u] = P.sset[sl[u]];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        while (on[u] && v[u] != EMPTY32) {   // rare: walk the collision chain
+                            if (v[u] == key[u]) { cand = true; break; }
+                            sl[u] = (sl[u] + 1) & smask;
+                            v[u] = P.sset[sl[u]];
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(cand);
+        if (bal) {
+            const uint32_t cnt = (uint32_t)__popcll(bal);
+            if (obuf_n + cnt > WOBUF) {   // cannot happen with the >= 32 flush below and cnt <= 64, kept for safety
+                uint32_t gb = 0;
+                if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
+                gb = __shfl(gb, 0);
+                for (uint32_t i = lane; i < obuf_n; i += 64) P.cand[gb + i] = obuf[i];
+                obuf_n = 0;
+                wave_lds_sync();
+            }
+            if (cand) obuf[obuf_n + __popcll(bal & ((1ull << lane) - 1))] = (uint32_t)r;
+            obuf_n += cnt;
+            wave_lds_sync();
+            if (obuf_n >= 32) {
+                uint32_t gb = 0;
+                if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
+                gb = __shfl(gb, 0);
+                for (uint32_t i = lane; i < obuf_n; i += 64) P.cand[gb + i] = obuf[i];
+                obuf_n = 0;
+            }
+        }
+        wave_lds_sync();   // all lanes are done with the slice before it is overwritten
+    };
+    for (uint64_t t = t0; t < n_tiles;) {
+        process(pfA, t);
+        t += tstride;
+        if (t >= n_tiles) break;
+        process(pfB, t);
+        t += tstride;
+        if (t >= n_tiles) break;
+        process(pfC, t);
+        t += tstride;
+    }
+    if (obuf_n) {
+        uint32_t gb = 0;
+        if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
+        gb = __shfl(gb, 0);
+        for (uint32_t i = lane; i < obuf_n; i += 64) P.cand[gb + i] = obuf[i];
     }
 }
 
@@ -383,16 +717,63 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     F.rb = rb;
     F.stride2 = 2 * ix.stride;
     F.np = (uint32_t)((read_len - 16) / ix.stride + 1);
+    if (ctx->screen_np_override >= 0) F.np = (uint32_t)ctx->screen_np_override;  // diagnostic (timing only)
     F.bitmap = ix.d_bitmap;
     F.sset = ix.d_sset;
     F.bm_log2 = ix.bm_log2;
     F.s_log2 = ix.s_log2;
     F.cand = (uint32_t*)ctx->cand.p;
     F.n_cand = d_cnt;
+    F.bitmap_lds = ix.d_bitmap_lds;
+    F.lds_log2 = ix.lds_log2;
+    F.lds_direct = ctx->screen_lds_direct;
     const size_t n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
     const size_t lds = TILE_READS * rb + 16;
     const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * (ctx->screen_wg_per_cu > 0 ? ctx->screen_wg_per_cu : 8));
-    {
+    // LDS pre-filter variant: pays while the coarse bitmap is sparse enough to stop most probes before L2
+    // (screen_variant 8 forces it, 9 forbids it)
+    const bool lds_ok = ix.d_bitmap_lds && ix.lds_fill <= 0.6 && ctx->screen_variant != 9;
+    if ((lds_ok && ctx->screen_variant == 0) || (ctx->screen_variant == 12 && ix.d_bitmap_lds)) {
+        // wave-autonomous LDS pre-filter kernel: as many waves per CU as fit next to the coarse bitmap
+        const size_t bm_bytes = ((size_t)1 << ix.lds_log2) / 8;
+        const size_t slice_words = ((size_t)64 * rb + 16 + 15) / 16 * 4;
+        const size_t per_wave = (slice_words + WOBUF) * 4;
+        size_t nw = (160 * 1024 - 512 - bm_bytes) / per_wave;
+        nw = std::min<size_t>(16, nw);
+        if (nw < 4) return GF_E_UNSUPPORTED;
+        const size_t tiles2 = (n_reads + 63) / 64;
+        void (*wk)(FilterParams, uint32_t) = screen_filter_wave_kernel<0>;
+        switch ((rb + 15) / 16) {
+            case 1: wk = screen_filter_wave_kernel<1>; break;
+            case 2: wk = screen_filter_wave_kernel<2>; break;
+            case 3: wk = screen_filter_wave_kernel<3>; break;
+            case 4: wk = screen_filter_wave_kernel<4>; break;
+            default: break;
+        }
+        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
+        hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles2 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
+                           bm_bytes + nw * per_wave, ctx->stream, F, (uint32_t)slice_words);
+    } else if (ctx->screen_variant == 8 && ix.d_bitmap_lds) {
+        const size_t bm_bytes = ((size_t)1 << ix.lds_log2) / 8;
+        size_t thr = (160 * 1024 - 2600 - bm_bytes - 16) / rb;
+        thr = std::min<size_t>(1024, thr / 64 * 64);
+        if (thr >= 256) {
+            const size_t tiles2 = (n_reads + thr - 1) / thr;
+            LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
+            void (*lk)(FilterParams) = screen_filter_lds_kernel<0>;
+            switch ((rb + 15) / 16) {
+                case 1: lk = screen_filter_lds_kernel<1>; break;
+                case 2: lk = screen_filter_lds_kernel<2>; break;
+                case 3: lk = screen_filter_lds_kernel<3>; break;
+                case 4: lk = screen_filter_lds_kernel<4>; break;
+                default: break;
+            }
+            hipLaunchKernelGGL(lk, dim3((unsigned)std::min<size_t>(tiles2, ctx->n_cu)), dim3((unsigned)thr),
+                               bm_bytes + thr * rb + 16, ctx->stream, F);
+        } else {
+            return GF_E_UNSUPPORTED;
+        }
+    } else {
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         void (*kern)(FilterParams) = screen_filter_kernel<LOAD_PLAIN, 9>;
         switch (ctx->screen_variant) {
@@ -403,6 +784,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
             case 5: kern = screen_filter_kernel<LOAD_NT, 9>; break;
             case 6: kern = screen_filter_kernel<LOAD_SC1, 9>; break;
             case 7: kern = screen_filter_kernel<LOAD_PLAIN, 1>; break;
+            case 10: kern = screen_filter_kernel<LOAD_ABL_STREAM, 9>; break;
+            case 11: kern = screen_filter_kernel<LOAD_ABL_COMPUTE, 9>; break;
             default: break;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, F);

@@ -296,3 +296,25 @@ def test_device_pools_follow_the_reference_fastq_join_order(gf):
         e = CO.assemble_pool(blob[int(off[g]) * L:int(off[g + 1]) * L], L, 31, 29)
         gseqs = [seq[int(x["seq_off"]):int(x["seq_off"]) + int(x["length"])].decode() for x in ctg if x["gap"] == g]
         assert gseqs == [x[0] for x in e]
+
+
+@pytest.mark.parametrize("variant", [12, 8, 9, 2, 4])
+def test_screen_filter_variants_agree(gf, variant):
+    """Both filter kernels (LDS pre-filter = 8, plain L2 bitmap = 9, plus load-mode/unroll builds) give the oracle's hits."""
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=41, n_pairs=25000)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    packed, _ = GapFill.pack_reads(c["reads_blob"], c["L"])
+    exp31 = CO.screen_reads(c["reads_blob"], c["L"], c["flanks"], 31)
+    exp51 = CO.screen_reads(c["reads_blob"], c["L"], c["flanks"], 51)
+    gf.set_option("screen_variant", variant)
+    try:
+        for n in (len(packed), 1000, 769, 1):
+            assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (variant, n)
+        assert _same(gf.screen_reads(packed, c["L"], 51), exp51)
+        for bl in (16, 19, 22):
+            gf.set_option("bitmap_log2", bl)
+            assert _same(gf.screen_reads(packed, c["L"], 31), exp31), (variant, bl)
+    finally:
+        gf.set_option("screen_variant", 0)
+        gf.set_option("bitmap_log2", 0)
