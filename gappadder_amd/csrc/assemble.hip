@@ -48,8 +48,11 @@ struct AsmParams {
 // node meta bits (high word of a table slot in the graph phases)
 constexpr uint32_t M_OUT = 0xFu, M_IN = 0xF0u, M_START0 = 1u << 8, M_START1 = 1u << 9, M_MULT_SHIFT = 12;
 
+// the kernel's dynamic LDS, at file scope so that every helper addresses it as LDS (ds_* instructions) instead of through
+// a generic pointer (flat_* instructions, several times the latency)
+extern __shared__ uint32_t g_lds[];
+
 struct PoolView {
-    const uint32_t* w;  // words of the pool's reads staged in LDS, read r at byte r*rb (when lds)
     uint32_t rb, L;
     bool lds;
     uint64_t first_byte;  // global byte offset of the pool (global view only)
@@ -70,9 +73,9 @@ __device__ __forceinline__ uint32_t asm_word(const uint32_t* g32, uint64_t n_wor
 
 // 32 bits of the pool's base stream starting at bit `bit` (first base in the top bits)
 __device__ __forceinline__ uint32_t pv_stream32(const PoolView& V, uint64_t bit) {
-    if (V.lds) {
+    if (V.lds) {   // staged at the start of the dynamic LDS
         const uint32_t d = (uint32_t)(bit >> 5), sh = (uint32_t)bit & 31;
-        const uint64_t v = ((uint64_t)bswap32(V.w[d]) << 32) | bswap32(V.w[d + 1]);
+        const uint64_t v = ((uint64_t)bswap32(g_lds[d]) << 32) | bswap32(g_lds[d + 1]);
         return (uint32_t)((v << sh) >> 32);
     }
     const uint64_t gb = V.first_byte * 8 + bit;
@@ -110,25 +113,62 @@ __device__ __forceinline__ unsigned long long slot_load(const unsigned long long
 
 constexpr unsigned long long EMPTY64 = 0x00000000FFFFFFFFull;  // id EMPTY32, count / meta 0
 
-// Find-or-insert the canonical `len`-mer `key` (instance `inst`) and add `inc` to the slot's high word, with ONE
-// 64-bit CAS when the slot is free (id and first count land together) or one 64-bit add when the key is already there.
-// `t` may point to LDS or to global memory (generic address).  Returns the slot, EMPTY32 when the table is full.
-__device__ __forceinline__ uint32_t table_upsert(unsigned long long* t, uint32_t cap, const PoolView& V, K128 key, uint32_t inst,
-                                                 int len, uint32_t inc, bool* fresh) {
-    uint32_t s = slot_of(key, cap);
+// A hash table of 8-byte slots (low word = instance id or node index, high word = count / node meta) that lives either in
+// the dynamic LDS (word offset `off`) or in global memory (`g`).  Every access branches on the wave-uniform `lds` flag so
+// that the LDS side compiles to ds_* instructions.
+struct Tab {
+    bool lds;
+    uint32_t off;             // word offset in g_lds (8-byte aligned)
+    unsigned long long* g;
+    uint32_t cap;
+    __device__ __forceinline__ unsigned long long* l() const { return reinterpret_cast<unsigned long long*>(&g_lds[off]); }
+    __device__ __forceinline__ unsigned long long load(uint32_t s) const {
+        return lds ? __hip_atomic_load(l() + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                   : __hip_atomic_load(g + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void store(uint32_t s, unsigned long long v) const { if (lds) l()[s] = v; else g[s] = v; }
+    __device__ __forceinline__ unsigned long long cas(uint32_t s, unsigned long long e, unsigned long long d) const {
+        return lds ? atomicCAS(l() + s, e, d) : atomicCAS(g + s, e, d);
+    }
+    __device__ __forceinline__ void add(uint32_t s, unsigned long long v) const { if (lds) atomicAdd(l() + s, v); else atomicAdd(g + s, v); }
+    __device__ __forceinline__ void or_meta(uint32_t s, uint32_t bits) const {
+        if (lds) atomicOr(&g_lds[off + 2 * s + 1], bits); else atomicOr(reinterpret_cast<uint32_t*>(g + s) + 1, bits);
+    }
+    __device__ __forceinline__ void set_id(uint32_t s, uint32_t id) const {
+        if (lds) g_lds[off + 2 * s] = id; else *reinterpret_cast<uint32_t*>(g + s) = id;
+    }
+    __device__ __forceinline__ uint32_t id(uint32_t s) const { return (uint32_t)load(s); }
+};
+
+// a uint32 array in LDS (word offset) or global memory
+struct Arr {
+    bool lds;
+    uint32_t off;
+    uint32_t* g;
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return lds ? g_lds[off + i] : __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { if (lds) g_lds[off + i] = v; else g[i] = v; }
+    __device__ __forceinline__ void or_(uint32_t i, uint32_t v) const { if (lds) atomicOr(&g_lds[off + i], v); else atomicOr(g + i, v); }
+};
+
+// Find-or-insert the canonical `len`-mer `key` (instance `inst`) and add `inc` to the slot's high word, with ONE 64-bit
+// CAS when the slot is free (id and first count land together) or one 64-bit add when the key is already there.
+// Returns the slot, EMPTY32 when the table is full.
+__device__ __forceinline__ uint32_t table_upsert(const Tab& t, const PoolView& V, K128 key, uint32_t inst, int len, uint32_t inc,
+                                                 bool* fresh) {
+    uint32_t s = slot_of(key, t.cap);
     *fresh = false;
-    for (uint32_t probes = 0; probes < cap; ++probes) {
-        unsigned long long v = __hip_atomic_load(t + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t probes = 0; probes < t.cap; ++probes) {
+        unsigned long long v = t.load(s);
         if ((uint32_t)v == EMPTY32) {
-            v = atomicCAS(t + s, EMPTY64, ((unsigned long long)inc << 32) | inst);
+            v = t.cas(s, EMPTY64, ((unsigned long long)inc << 32) | inst);
             if (v == EMPTY64) { *fresh = true; return s; }
         }
         const uint32_t cur = (uint32_t)v;
         if (cur == inst || canonical(pv_kmer(V, cur, len), len) == key) {
-            atomicAdd(t + s, (unsigned long long)inc << 32);
+            t.add(s, (unsigned long long)inc << 32);
             return s;
         }
-        s = s + 1 == cap ? 0 : s + 1;
+        s = s + 1 == t.cap ? 0 : s + 1;
     }
     return EMPTY32;
 }
@@ -159,6 +199,19 @@ __device__ __forceinline__ K128 shift_in_front(K128 v, uint32_t c, int len) {
     return mask_k(r, len);
 }
 
+// Phase boundary inside one workgroup whose phases hand data to each other through GLOBAL memory (lists, per-node arrays
+// in the global fallback): the vector L1 is write-through, so after every wave's vmcnt(0) (part of the barrier) the stores
+// are in L2; one lane then invalidates this CU's L1 (acquire, agent scope = buffer_inv sc1, ~1.7 us) so that lines cached
+// before an atomic or a rewrite are not served stale.  Replaces 1024 x __threadfence() (L2 write-back + invalidate each).
+__device__ __forceinline__ void wg_phase_sync() {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
 #define ASM_STAMP(n) do { if (P.dbg && tid == 0) P.dbg[(uint64_t)g * 8 + (n)] = wall_clock64(); } while (0)
 
 // LDS plan of one gap (dynamic LDS = P.lds_words words):  [ staged pool | region R ]
@@ -166,7 +219,6 @@ __device__ __forceinline__ K128 shift_in_front(K128 v, uint32_t c, int len) {
 //   graph phase   R = node table (2 slots per possible node) + inst_of/meta/succ0/succ1 arrays, else global
 // Every pointer below is generic (LDS or global); the code path is the same.
 __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
-    extern __shared__ uint32_t lds[];
     __shared__ uint32_t s_cnt[8];  // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes [6] LDS table overflow
     __shared__ unsigned long long s_seq[2];  // [0] bases to emit  [1] global base offset
     const uint32_t tid = threadIdx.x;
@@ -203,7 +255,6 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         V.first_byte = r0 * P.rb;
         const uint64_t pool_bytes = (uint64_t)n_r * P.rb;
         V.lds = pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / 3;  // at most a third of the LDS
-        V.w = lds;
         uint32_t pool_words = 0;
         if (V.lds) {
             const uint64_t w0 = V.first_byte >> 2;
@@ -218,10 +269,10 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     v = sh ? (a >> sh) | (b << (32 - sh)) : a;
                     if (i == nw - 1 && (pool_bytes & 3)) v &= (1u << ((pool_bytes & 3) * 8)) - 1;
                 }
-                lds[i] = v;
+                g_lds[i] = v;
             }
         }
-        uint32_t* R = lds + pool_words;
+        const uint32_t R = pool_words;   // word offset of region R in the dynamic LDS
         const uint32_t r_words = P.lds_words - pool_words;
         if (tid < 8) s_cnt[tid] = 0;
         if (tid < 2) s_seq[tid] = 0;
@@ -229,16 +280,17 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         ASM_STAMP(0);
 
         // ---- P1: count canonical k-mers; remember each distinct k-mer's slot.  Optimistic LDS table first.
-        unsigned long long* tab = gtab;
-        uint32_t cap = gcap;
+        Tab tab;
+        tab.g = gtab;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool use_lds = attempt == 0 && r_words / 2 >= 1024;
             if (attempt == 0 && !use_lds) continue;
-            tab = use_lds ? reinterpret_cast<unsigned long long*>(R) : gtab;
-            cap = use_lds ? r_words / 2 : gcap;
-            const uint32_t limit = use_lds ? cap - cap / 4 : 0xFFFFFFFFu;
+            tab.lds = use_lds;
+            tab.off = R;
+            tab.cap = use_lds ? r_words / 2 : gcap;
+            const uint32_t limit = use_lds ? tab.cap - tab.cap / 4 : 0xFFFFFFFFu;
             if (use_lds) {
-                for (uint32_t i = tid; i < cap; i += ASM_THREADS) tab[i] = EMPTY64;
+                for (uint32_t i = tid; i < tab.cap; i += ASM_THREADS) tab.store(i, EMPTY64);
                 __syncthreads();
             }
             for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
@@ -253,7 +305,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const uint32_t inst = r * P.read_len + p;
                 const K128 key = canonical(pv_kmer(V, inst, k), k);
                 bool fresh;
-                const uint32_t s = table_upsert(tab, cap, V, key, inst, k, 1u, &fresh);
+                const uint32_t s = table_upsert(tab, V, key, inst, k, 1u, &fresh);
                 if (s == EMPTY32) { if (use_lds) s_cnt[6] = 1; else s_cnt[3] = 1; continue; }
                 if (fresh) {
                     const uint32_t q = atomicAdd(&s_cnt[4], 1u);
@@ -261,15 +313,14 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     if (q < n_unit) list_a[q] = s;
                 }
             }
-            __threadfence();
-            __syncthreads();
+            wg_phase_sync();
             if (!(use_lds && s_cnt[6])) break;
             // the LDS table got too full: start over in the global slice (nothing global was touched yet)
             __syncthreads();
             if (tid == 0) { s_cnt[4] = 0; s_cnt[6] = 0; }
             __syncthreads();
         }
-        const bool tab_global = tab == gtab;
+        const bool tab_global = !tab.lds;
         const uint32_t n_dist = s_cnt[4] < n_unit ? s_cnt[4] : n_unit;
         ASM_STAMP(1);
 
@@ -280,11 +331,11 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             uint32_t id = 0, c = 0;
             if (i < n_dist) {
                 const uint32_t sl = list_a[i];
-                const unsigned long long v = slot_load(tab, sl);
+                const unsigned long long v = tab.load(sl);
                 id = (uint32_t)v;
                 c = (uint32_t)(v >> 32);
                 keep = c >= P.min_count;
-                if (tab_global) tab[sl] = EMPTY64;
+                if (tab_global) tab.store(sl, EMPTY64);
             }
             const unsigned long long bal = __ballot(keep);
             if (bal) {
@@ -303,8 +354,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 }
             }
         }
-        __threadfence();
-        __syncthreads();
+        wg_phase_sync();
         if (P.cnt_keys) {
             if (tid == 0) { *P.n_contigs = s_cnt[0]; if (s_cnt[3]) P.gap_error[g] = 1; }
             __syncthreads();
@@ -317,8 +367,9 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         //      4/3 table slots + inst_of/meta/succ0/succ1); if the gap has more nodes the phase is redone in global memory.
         const uint64_t node_bound = (uint64_t)per * n_surv < n_unit ? (uint64_t)per * n_surv : n_unit;
         bool graph_lds = false;
-        uint32_t nb = 0, ncap = gcap, n_nodes = 0;
-        unsigned long long* ntab = gtab;
+        uint32_t nb = 0, n_nodes = 0;
+        Tab ntab;
+        ntab.g = gtab;
         for (int attempt = 0; attempt < 2; ++attempt) {
             graph_lds = false;
             if (attempt == 0) {
@@ -326,10 +377,11 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 if (nb < n_surv || nb < 64) continue;       // cannot even hold one node per survivor: go global
                 graph_lds = true;
             }
-            ntab = graph_lds ? reinterpret_cast<unsigned long long*>(R + 4 * nb) : gtab;
-            ncap = graph_lds ? (r_words - 4 * nb) / 2 : gcap;
+            ntab.lds = graph_lds;
+            ntab.off = R + 4 * nb;
+            ntab.cap = graph_lds ? (r_words - 4 * nb) / 2 : gcap;
             if (graph_lds) {
-                for (uint32_t i = tid; i < ncap; i += ASM_THREADS) ntab[i] = EMPTY64;
+                for (uint32_t i = tid; i < ntab.cap; i += ASM_THREADS) ntab.store(i, EMPTY64);
                 __syncthreads();
             }
             // ---- P3: nodes + edges; remember each node's slot
@@ -357,7 +409,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     const K128 A = d ? rc : a;
                     const uint32_t ninst = fwd ? inst + o : inst + (per - 1 - o);  // same read, shifted offset
                     bool fresh;
-                    const uint32_t sl = table_upsert(ntab, ncap, V, A, ninst, kv, 1u << M_MULT_SHIFT, &fresh);
+                    const uint32_t sl = table_upsert(ntab, V, A, ninst, kv, 1u << M_MULT_SHIFT, &fresh);
                     if (sl == EMPTY32) { if (graph_lds) s_cnt[6] = 1; else s_cnt[3] = 1; break; }
                     if (fresh) {
                         const uint32_t q = atomicAdd(&s_cnt[5], 1u);
@@ -366,48 +418,47 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     }
                     if (ps != EMPTY32) {  // edge prev -> this
                         const uint32_t c_out = kbase(t, (int)(o - 1) + kv), c_in = kbase(t, (int)o - 1);
-                        atomicOr(slot_meta(ntab, ps), pd ? (1u << (4 + (3 - c_out))) : (1u << c_out));
-                        atomicOr(slot_meta(ntab, sl), d ? (1u << (3 - c_in)) : (1u << (4 + c_in)));
+                        ntab.or_meta(ps, pd ? (1u << (4 + (3 - c_out))) : (1u << c_out));
+                        ntab.or_meta(sl, d ? (1u << (3 - c_in)) : (1u << (4 + c_in)));
                     }
                     ps = sl; pd = d;
                 }
             }
-            __threadfence();
-            __syncthreads();
+            wg_phase_sync();
             if (!(graph_lds && s_cnt[6])) break;
             __syncthreads();
             if (tid == 0) { s_cnt[5] = 0; s_cnt[6] = 0; }   // too many nodes for the LDS plan: redo in the global slice
             __syncthreads();
         }
         n_nodes = s_cnt[5] < n_unit ? s_cnt[5] : n_unit;
-        uint32_t* arr = graph_lds ? R : P.nodes + 3 * inst_off;
         const uint32_t astride = graph_lds ? nb : n_nodes;
+        uint32_t* garr = P.nodes + 3 * inst_off;
         ASM_STAMP(3);
 
         // ---- P3.5: dense node indices.  slot.id <- node index; inst_of / meta / succ arrays
-        uint32_t* inst_of = graph_lds ? arr : list_b;
-        uint32_t* nmeta = graph_lds ? arr + astride : arr;
-        uint32_t* succ0 = nmeta + astride;
-        uint32_t* succ1 = succ0 + astride;
+        // LDS: [inst_of | meta | succ0 | succ1] at R;  global: inst_of = list_b, [meta | succ0 | succ1] in the node workspace
+        const Arr inst_of{graph_lds, R, list_b};
+        const Arr nmeta{graph_lds, R + astride, garr};
+        const Arr succ0{graph_lds, R + 2 * astride, garr + astride};
+        const Arr succ1{graph_lds, R + 3 * astride, garr + 2 * astride};
         uint32_t* rec = list_b + (graph_lds ? 0 : n_nodes);           // emitted-walk records, 2 words each
         const uint32_t rec_cap = (n_unit - (graph_lds ? 0 : n_nodes)) / 2;
         for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
             const uint32_t sl = list_a[ni];
-            const unsigned long long v = slot_load(ntab, sl);
-            inst_of[ni] = (uint32_t)v;
-            nmeta[ni] = (uint32_t)(v >> 32);
-            succ0[ni] = EMPTY32;
-            succ1[ni] = EMPTY32;
-            *slot_id(ntab, sl) = ni;
+            const unsigned long long v = ntab.load(sl);
+            inst_of.set(ni, (uint32_t)v);
+            nmeta.set(ni, (uint32_t)(v >> 32));
+            succ0.set(ni, EMPTY32);
+            succ1.set(ni, EMPTY32);
+            ntab.set_id(sl, ni);
         }
-        __threadfence();
-        __syncthreads();
+        wg_phase_sync();
 
         // ---- P4: unitig-internal edges.  (x,d) -> (y,dy) is internal iff out-degree(x,d) == 1 and in-degree(y,dy) == 1;
         //      an oriented node that no internal edge enters is a unitig START.
         for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
-            const uint32_t meta = nmeta[ni] & 0xFFu;   // adjacency bits are final after P3
-            const K128 x = canonical(pv_kmer(V, inst_of[ni], kv), kv);
+            const uint32_t meta = nmeta.get(ni) & 0xFFu;   // adjacency bits are final after P3
+            const K128 x = canonical(pv_kmer(V, inst_of.get(ni), kv), kv);
             for (uint32_t d = 0; d < 2; ++d) {
                 const uint32_t ob = out_bits(meta, d);
                 if (__popc(ob) != 1) continue;
@@ -416,86 +467,229 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const K128 yr = revcomp(y, kv);
                 const uint32_t dy = yr < y ? 1u : 0u;
                 const K128 Y = dy ? yr : y;
-                uint32_t sl = slot_of(Y, ncap), yi = EMPTY32;   // slot.id is a node index now
-                for (uint32_t probes = 0; probes < ncap; ++probes) {
-                    const uint32_t cand = __hip_atomic_load(slot_id(ntab, sl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t sl = slot_of(Y, ntab.cap), yi = EMPTY32;   // slot.id is a node index now
+                for (uint32_t probes = 0; probes < ntab.cap; ++probes) {
+                    const uint32_t cand = ntab.id(sl);
                     if (cand == EMPTY32) break;
-                    if (cand < n_nodes && canonical(pv_kmer(V, inst_of[cand], kv), kv) == Y) { yi = cand; break; }
-                    sl = sl + 1 == ncap ? 0 : sl + 1;
+                    if (cand < n_nodes && canonical(pv_kmer(V, inst_of.get(cand), kv), kv) == Y) { yi = cand; break; }
+                    sl = sl + 1 == ntab.cap ? 0 : sl + 1;
                 }
                 if (yi == EMPTY32) continue;
-                if (__popc(in_bits(nmeta[yi] & 0xFFu, dy)) != 1) continue;
-                (d ? succ1 : succ0)[ni] = (yi << 1) | dy;
-                atomicOr(&nmeta[yi], dy ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
+                if (__popc(in_bits(nmeta.get(yi) & 0xFFu, dy)) != 1) continue;
+                (d ? succ1 : succ0).set(ni, (yi << 1) | dy);
+                nmeta.or_(yi, dy ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
             }
         }
-        __threadfence();
-        __syncthreads();
+        wg_phase_sync();
         ASM_STAMP(4);
 
-        // ---- P5a: walk every start along the succ pointers; keep the walks that are emitted
-        for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
-            const uint32_t meta0 = nmeta[ni];
-            for (uint32_t d = 0; d < 2; ++d) {
-                if (meta0 & (d ? M_START1 : M_START0)) continue;  // has an internal predecessor: not a start
-                uint32_t cur = (ni << 1) | d, nodes = 1;
-                for (;;) {
-                    const uint32_t nx = ((cur & 1) ? succ1 : succ0)[cur >> 1];
-                    if (nx == EMPTY32) break;
-                    cur = nx;
-                    ++nodes;
+        // ---- P5 (parallel form): when the graph lives in LDS and the dead node-table region can hold one 8-byte
+        //      {ancestor, distance} pair per oriented node, unitigs are ranked by pointer jumping instead of being walked:
+        //      every oriented node learns its unitig's head and its rank in ~log2(longest unitig) rounds; tails tell heads
+        //      the length; heads decide emission; then every node writes its own base.  Pairs are read and written as single
+        //      64-bit LDS accesses, so the asynchronous in-place update keeps the invariant "ancestor at that distance".
+        const uint32_t Toff = R + 4 * nb, Twords = graph_lds ? r_words - 4 * nb : 0;
+        const bool par_ok = graph_lds && (uint64_t)4 * n_nodes + 64 <= Twords;
+        if (par_ok) {
+            unsigned long long* J = reinterpret_cast<unsigned long long*>(&g_lds[Toff]);
+            uint32_t* cacc = &g_lds[Toff + 4 * n_nodes];                       // per-contig coverage sums
+            const uint32_t cacc_cap = Twords - 4 * n_nodes;
+            const uint32_t n_or = 2 * n_nodes;
+            auto has_pred = [&](uint32_t o) { return (nmeta.get(o >> 1) & ((o & 1) ? M_START1 : M_START0)) != 0; };
+            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                unsigned long long pr = o;                                      // heads: {self, 0}
+                if (has_pred(o)) {
+                    const uint32_t back = ((o & 1) ? succ0 : succ1).get(o >> 1);  // walking the other way from this node
+                    pr = (1ull << 32) | (back ^ 1u);                            // its internal predecessor, one step away
                 }
-                if (nodes + P.kv - 1 < P.min_contig) continue;
-                const K128 x = canonical(pv_kmer(V, inst_of[ni], kv), kv);
-                const K128 first = d ? revcomp(x, kv) : x;
-                const K128 e = canonical(pv_kmer(V, inst_of[cur >> 1], kv), kv);
-                const K128 opp = (cur & 1) ? e : revcomp(e, kv);  // first kv-mer of the opposite walk = revcomp(last kv-mer)
-                if (opp < first) continue;
-                const uint32_t q = atomicAdd(&s_cnt[1], 1u);
-                if (q >= rec_cap) { s_cnt[3] = 1; continue; }
-                rec[2 * q] = (ni << 1) | d;
-                rec[2 * q + 1] = nodes;
-                atomicAdd(&s_seq[0], (unsigned long long)(nodes + P.kv - 1));
+                J[o] = pr;
             }
-        }
-        __threadfence();
-        __syncthreads();
-        const uint32_t n_emit = s_cnt[1] < rec_cap ? s_cnt[1] : rec_cap;
-        if (tid == 0) {
-            s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
-            s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
-            s_seq[0] = 0;
-            if (s_cnt[3]) P.gap_error[g] = 1;
-        }
-        __syncthreads();
-        ASM_STAMP(5);
+            __syncthreads();
+            for (int round = 0; round < 18; ++round) {
+                if (tid == 0) s_cnt[7] = 0;
+                __syncthreads();
+                bool changed = false;
+                for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                    const unsigned long long a0 = J[o];
+                    const uint32_t pa = (uint32_t)a0;
+                    if (pa == o) continue;
+                    const unsigned long long a1 = J[pa];
+                    const uint32_t pb = (uint32_t)a1;
+                    if (pb == pa) continue;                                     // parent is a head (or this is a finished cycle hop)
+                    J[o] = ((unsigned long long)((uint32_t)(a0 >> 32) + (uint32_t)(a1 >> 32)) << 32) | pb;
+                    changed = true;
+                }
+                if (changed) s_cnt[7] = 1;
+                __syncthreads();
+                if (!s_cnt[7]) break;
+            }
+            __syncthreads();
+            // S1: tails publish {tail, length} in their head's pair (heads are not read as ancestors any more)
+            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                if (((o & 1) ? succ1 : succ0).get(o >> 1) != EMPTY32) continue;
+                const unsigned long long a0 = J[o];
+                const uint32_t h = has_pred(o) ? (uint32_t)a0 : o;
+                if (has_pred(h)) continue;                                      // part of an isolated cycle: never reported
+                const uint32_t rank = has_pred(o) ? (uint32_t)(a0 >> 32) : 0;
+                g_lds[Toff + 2 * h] = o;                                        // written as two words: no reader until the barrier
+                g_lds[Toff + 2 * h + 1] = rank + 1;
+            }
+            __syncthreads();
+            // S2: heads decide
+            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                if (has_pred(o)) continue;
+                const uint32_t tail = g_lds[Toff + 2 * o], len = g_lds[Toff + 2 * o + 1];
+                uint32_t q = EMPTY32;
+                if (len + P.kv - 1 >= P.min_contig) {
+                    const K128 x = canonical(pv_kmer(V, inst_of.get(o >> 1), kv), kv);
+                    const K128 first = (o & 1) ? revcomp(x, kv) : x;
+                    const K128 e = canonical(pv_kmer(V, inst_of.get(tail >> 1), kv), kv);
+                    const K128 opp = (tail & 1) ? e : revcomp(e, kv);
+                    if (!(opp < first)) {
+                        q = atomicAdd(&s_cnt[1], 1u);
+                        if (q >= rec_cap / 2 || q >= cacc_cap) { s_cnt[3] = 1; q = EMPTY32; }
+                        else {
+                            rec[4 * q] = o;
+                            rec[4 * q + 1] = len;
+                            cacc[q] = 0;
+                            atomicAdd(&s_seq[0], (unsigned long long)(len + P.kv - 1));
+                        }
+                    }
+                }
+                g_lds[Toff + 2 * o] = q;
+            }
+            wg_phase_sync();
+            const uint32_t n_emit = s_cnt[1] < rec_cap / 2 ? s_cnt[1] : rec_cap / 2;
+            if (tid == 0) {
+                s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
+                s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
+                s_seq[0] = 0;
+                if (s_cnt[3]) P.gap_error[g] = 1;
+            }
+            __syncthreads();
+            ASM_STAMP(5);
+            for (uint32_t q = tid; q < n_emit; q += ASM_THREADS)                // relative offsets of the contigs
+                rec[4 * q + 2] = (uint32_t)atomicAdd(&s_seq[0], (unsigned long long)(rec[4 * q + 1] + P.kv - 1));
+            wg_phase_sync();
+            // S4: every oriented node of an emitted unitig writes its own base
+            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                uint32_t h = o, rank = 0;
+                if (has_pred(o)) {
+                    const unsigned long long a0 = J[o];
+                    h = (uint32_t)a0;
+                    rank = (uint32_t)(a0 >> 32);
+                    if (has_pred(h)) continue;
+                }
+                const uint32_t q = g_lds[Toff + 2 * h];
+                if (q == EMPTY32 || q >= n_emit) continue;
+                const unsigned long long off = s_seq[1] + rec[4 * q + 2];
+                const uint32_t len = rec[4 * q + 1] + P.kv - 1;
+                atomicAdd(&cacc[q], nmeta.get(o >> 1) >> M_MULT_SHIFT);
+                if (off + len > P.seq_cap) continue;
+                const K128 x = canonical(pv_kmer(V, inst_of.get(o >> 1), kv), kv);
+                const K128 ok = (o & 1) ? revcomp(x, kv) : x;
+                if (rank == 0) {
+                    for (int bq = 0; bq < kv; ++bq) P.seq[off + bq] = "ACGT"[kbase(ok, bq)];
+                } else {
+                    P.seq[off + kv - 1 + rank] = "ACGT"[kbase(ok, kv - 1)];
+                }
+            }
+            __syncthreads();
+            for (uint32_t q = tid; q < n_emit; q += ASM_THREADS) {
+                const uint32_t ci = s_cnt[2] + q;
+                if (ci < P.contig_cap) {
+                    gf_contig ct;
+                    ct.gap = g; ct.k = (uint16_t)P.k; ct.kv = (uint16_t)P.kv; ct.n_nodes = rec[4 * q + 1];
+                    ct.length = rec[4 * q + 1] + P.kv - 1; ct.cov_sum = cacc[q]; ct.reserved = 0;
+                    ct.seq_off = s_seq[1] + rec[4 * q + 2];
+                    P.contigs[ci] = ct;
+                }
+            }
+            __syncthreads();
+        } else {
+            // ---- P5a: walk every start along the succ pointers; keep the walks that are emitted
+            for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
+                const uint32_t meta0 = nmeta.get(ni);
+                for (uint32_t d = 0; d < 2; ++d) {
+                    if (meta0 & (d ? M_START1 : M_START0)) continue;  // has an internal predecessor: not a start
+                    uint32_t cur = (ni << 1) | d, nodes = 1;
+                    for (;;) {
+                        const uint32_t nx = ((cur & 1) ? succ1 : succ0).get(cur >> 1);
+                        if (nx == EMPTY32) break;
+                        cur = nx;
+                        ++nodes;
+                    }
+                    if (nodes + P.kv - 1 < P.min_contig) continue;
+                    const K128 x = canonical(pv_kmer(V, inst_of.get(ni), kv), kv);
+                    const K128 first = d ? revcomp(x, kv) : x;
+                    const K128 e = canonical(pv_kmer(V, inst_of.get(cur >> 1), kv), kv);
+                    const K128 opp = (cur & 1) ? e : revcomp(e, kv);  // first kv-mer of the opposite walk = revcomp(last kv-mer)
+                    if (opp < first) continue;
+                    const uint32_t q = atomicAdd(&s_cnt[1], 1u);
+                    if (q >= rec_cap) { s_cnt[3] = 1; continue; }
+                    rec[2 * q] = (ni << 1) | d;
+                    rec[2 * q + 1] = nodes;
+                    atomicAdd(&s_seq[0], (unsigned long long)(nodes + P.kv - 1));
+                }
+            }
+            wg_phase_sync();
+            const uint32_t n_emit = s_cnt[1] < rec_cap ? s_cnt[1] : rec_cap;
+            if (tid == 0) {
+                s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
+                s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
+                s_seq[0] = 0;
+                if (s_cnt[3]) P.gap_error[g] = 1;
+            }
+            __syncthreads();
+            ASM_STAMP(5);
 
-        // ---- P5b: re-walk the kept starts and write sequences
-        for (uint32_t q = tid; q < n_emit; q += ASM_THREADS) {
-            const uint32_t st = rec[2 * q], nodes = rec[2 * q + 1];
-            const uint32_t len = nodes + P.kv - 1;
-            const unsigned long long off = s_seq[1] + atomicAdd(&s_seq[0], (unsigned long long)len);
-            const K128 x = canonical(pv_kmer(V, inst_of[st >> 1], kv), kv);
-            const K128 firstk = (st & 1) ? revcomp(x, kv) : x;
-            const bool room = off + len <= P.seq_cap;
-            if (room)
-                for (int b = 0; b < kv; ++b) P.seq[off + b] = "ACGT"[kbase(firstk, b)];
-            uint32_t cur = st, cov = nmeta[st >> 1] >> M_MULT_SHIFT;
-            for (uint32_t n = 1; n < nodes; ++n) {
-                const uint32_t c = __ffs(out_bits(nmeta[cur >> 1] & 0xFFu, cur & 1)) - 1;
-                cur = ((cur & 1) ? succ1 : succ0)[cur >> 1];
-                if (room) P.seq[off + kv - 1 + n] = "ACGT"[c];
-                cov += nmeta[cur >> 1] >> M_MULT_SHIFT;
+            // ---- P5b: re-walk the kept starts and write sequences
+            for (uint32_t q = tid; q < n_emit; q += ASM_THREADS) {
+                const uint32_t st = rec[2 * q], nodes = rec[2 * q + 1];
+                const uint32_t len = nodes + P.kv - 1;
+                const unsigned long long off = s_seq[1] + atomicAdd(&s_seq[0], (unsigned long long)len);
+                const K128 x = canonical(pv_kmer(V, inst_of.get(st >> 1), kv), kv);
+                const K128 firstk = (st & 1) ? revcomp(x, kv) : x;
+                const bool room = off + len <= P.seq_cap;
+                if (room)
+                    for (int b = 0; b < kv; ++b) P.seq[off + b] = "ACGT"[kbase(firstk, b)];
+                uint32_t cur = st, cov = nmeta.get(st >> 1) >> M_MULT_SHIFT;
+                uint32_t acc = 0;   // up to 4 bases gathered for one aligned 32-bit store
+                for (uint32_t n = 1; n < nodes; ++n) {
+                    const uint32_t c = __ffs(out_bits(nmeta.get(cur >> 1) & 0xFFu, cur & 1)) - 1;
+                    cur = ((cur & 1) ? succ1 : succ0).get(cur >> 1);
+                    cov += nmeta.get(cur >> 1) >> M_MULT_SHIFT;
+                    if (!room) continue;
+                    const unsigned long long pos = off + kv - 1 + n;
+                    const uint32_t ch = (0x54474341u >> (8 * c)) & 0xFFu;   // "ACGT"[c]
+                    const uint32_t b = (uint32_t)(reinterpret_cast<uintptr_t>(P.seq) + pos) & 3;   // byte lane of the ADDRESS
+                    acc |= ch << (8 * b);
+                    if (b == 3) {
+                        if (acc >> 24 && (acc & 0xFF) && ((acc >> 8) & 0xFF) && ((acc >> 16) & 0xFF)) {
+                            *reinterpret_cast<uint32_t*>(P.seq + pos - 3) = acc;     // all four bytes are this contig's
+                        } else {
+                            for (uint32_t q = 0; q < 4; ++q)
+                                if ((acc >> (8 * q)) & 0xFF) P.seq[pos - 3 + q] = (char)((acc >> (8 * q)) & 0xFF);
+                        }
+                        acc = 0;
+                    }
+                }
+                if (room && acc) {   // trailing partial word
+                    const unsigned long long last = off + kv - 1 + nodes - 1;
+                    const uint32_t bl = (uint32_t)(reinterpret_cast<uintptr_t>(P.seq) + last) & 3;
+                    for (uint32_t q = 0; q <= bl; ++q)
+                        if ((acc >> (8 * q)) & 0xFF) P.seq[last - bl + q] = (char)((acc >> (8 * q)) & 0xFF);
+                }
+                const uint32_t ci = s_cnt[2] + q;
+                if (ci < P.contig_cap) {
+                    gf_contig ct;
+                    ct.gap = g; ct.k = (uint16_t)P.k; ct.kv = (uint16_t)P.kv; ct.n_nodes = nodes; ct.length = len;
+                    ct.cov_sum = cov; ct.reserved = 0; ct.seq_off = off;
+                    P.contigs[ci] = ct;
+                }
             }
-            const uint32_t ci = s_cnt[2] + q;
-            if (ci < P.contig_cap) {
-                gf_contig ct;
-                ct.gap = g; ct.k = (uint16_t)P.k; ct.kv = (uint16_t)P.kv; ct.n_nodes = nodes; ct.length = len;
-                ct.cov_sum = cov; ct.reserved = 0; ct.seq_off = off;
-                P.contigs[ci] = ct;
-            }
+            __syncthreads();
         }
-        __syncthreads();
         ASM_STAMP(6);
         // leave the global slice EMPTY for the next gap / launch
         if (!graph_lds) {
@@ -503,8 +697,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
         if (s_cnt[3])  // an overflow may have left slots outside the lists: clear the whole slice
             for (uint32_t i = tid; i < gcap; i += ASM_THREADS) gtab[i] = EMPTY64;
-        __threadfence();
-        __syncthreads();
+        wg_phase_sync();
     }
 }
 
