@@ -75,6 +75,8 @@ def main():
     d_hits = torch.empty(hit_cap * 8, dtype=torch.uint8, device=dev)
     d_thits = torch.empty(hit_cap * 12, dtype=torch.uint8, device=dev)
     d_lhits = torch.empty(hit_cap * 12, dtype=torch.uint8, device=dev)
+    low_cap = max(1 << 20, n_reads // 8)          # MAPQ==0 records compacted by the tagger pass (2 % of the records here)
+    d_low = torch.empty(low_cap * 12, dtype=torch.uint8, device=dev)
     key_cap = 4 * hit_cap
     d_keys = torch.empty(key_cap, dtype=torch.int64, device=dev)
     pool_cap = 2 * hit_cap
@@ -86,7 +88,7 @@ def main():
     d_seq = torch.empty(seq_cap, dtype=torch.uint8, device=dev)
     d_gap_err = torch.zeros(len(gaps), dtype=torch.int32, device=dev)
     # counters (device u32 unless noted): 0 screen hits, 4 tagger hits, 8 second-hop hits, 12 keys, 16 contigs,
-    # 20 (u64) contig bases, 24 pool-sort overflow
+    # 20 (u64) contig bases, 24 pool-sort overflow, 28 MAPQ==0 records
     d_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
     cp = d_cnt.data_ptr()
     gf.sync()
@@ -96,7 +98,8 @@ def main():
     def recruit():
         rc = lib.gf_screen_reads_dev(h, d_reads.data_ptr(), None, n_reads, L, k, 1, d_hits.data_ptr(), hit_cap, cp)
         assert rc == 0, rc
-        rc = lib.gf_tag_alignments_dev(h, d_recs.data_ptr(), n_reads, 300, 30, 250, 30, d_thits.data_ptr(), hit_cap, cp + 16)
+        rc = lib.gf_tag_alignments_low_dev(h, d_recs.data_ptr(), n_reads, 300, 30, 250, 30, d_thits.data_ptr(), hit_cap, cp + 16,
+                                           d_low.data_ptr(), low_cap, cp + 112)
         assert rc == 0, rc
 
     # second-hop table (run_multi_threads_discordant.py:19-122 inverts the discordant lines and runs sort(1) on the host;
@@ -115,7 +118,8 @@ def main():
 
     def step():
         recruit()
-        rc = lib.gf_tag_low_mapq_dev(h, d_recs.data_ptr(), n_reads, B._p(rows), len(rows), d_lhits.data_ptr(), hit_cap, cp + 32)
+        rc = lib.gf_tag_low_mapq_compact_dev(h, d_low.data_ptr(), cp + 112, low_cap, B._p(rows), len(rows), d_lhits.data_ptr(),
+                                             hit_cap, cp + 32)
         assert rc == 0, rc
         assert lib.gf_pool_keys_reset(h, cp + 48) == 0
         assert lib.gf_pool_keys_from_screen_dev(h, d_hits.data_ptr(), cp, hit_cap, 1, d_keys.data_ptr(), key_cap, cp + 48) == 0
@@ -158,6 +162,7 @@ def main():
     n_hits, n_thits, n_lhits, n_keys, n_ctg = int(cnt[0]), int(cnt[4]), int(cnt[8]), int(cnt[12]), int(cnt[16])
     n_seq = int(cnt[20:22].view(np.uint64)[0])
     pool_off = d_pool_off.cpu().numpy()
+    assert int(cnt[28]) <= low_cap
     assert int(cnt[24]) == 0 and int(d_gap_err.sum()) == 0 and pool_off[-1] <= pool_cap and n_ctg <= contig_cap and n_seq <= seq_cap
     ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
     if world > 1:

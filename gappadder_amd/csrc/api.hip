@@ -267,13 +267,27 @@ int gf_tag_alignments_dev(gf_ctx* ctx, const void* d_recs, size_t n, int insert_
                           int anchor_mapq, void* d_out, size_t cap, void* d_n_out) {
     if (!ctx || !d_n_out || (n && !d_recs) || (cap && !d_out)) return GF_E_INVAL;
     GF_HIP(ctx, hipSetDevice(ctx->device));
-    return launch_tag(ctx, d_recs, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n_out);
+    return launch_tag(ctx, d_recs, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n_out, nullptr, 0, nullptr);
+}
+
+int gf_tag_alignments_low_dev(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist, int anchor_mapq,
+                              void* d_out, size_t cap, void* d_n_out, void* d_low, size_t low_cap, void* d_n_low) {
+    if (!ctx || !d_n_out || !d_n_low || (n && !d_recs) || (cap && !d_out) || (low_cap && !d_low)) return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_tag(ctx, d_recs, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n_out, d_low, low_cap, d_n_low);
+}
+
+int gf_tag_low_mapq_compact_dev(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const gf_dpos* table,
+                                size_t n_rows, void* d_out, size_t cap, void* d_n_out) {
+    if (!ctx || !d_n_out || !d_low || !d_n_low || (cap && !d_out) || (n_rows && !table)) return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_low_mapq(ctx, nullptr, 0, table, n_rows, d_out, cap, d_n_out, d_low, d_n_low, low_cap);
 }
 
 int gf_tag_alignments(gf_ctx* ctx, const gf_alnrec* recs, size_t n, int insert_size, int sd, int clip_dist,
                       int anchor_mapq, gf_taghit* out, size_t cap, size_t* n_out) {
     return tag_host(ctx, recs, n, out, cap, n_out, [&](void* d_in, void* d_out, void* d_n) {
-        return launch_tag(ctx, d_in, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n);
+        return launch_tag(ctx, d_in, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n, nullptr, 0, nullptr);
     });
 }
 
@@ -281,14 +295,14 @@ int gf_tag_low_mapq_dev(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos
                         size_t cap, void* d_n_out) {
     if (!ctx || !d_n_out || (n && !d_recs) || (cap && !d_out) || (n_rows && !table)) return GF_E_INVAL;
     GF_HIP(ctx, hipSetDevice(ctx->device));
-    return launch_low_mapq(ctx, d_recs, n, table, n_rows, d_out, cap, d_n_out);
+    return launch_low_mapq(ctx, d_recs, n, table, n_rows, d_out, cap, d_n_out, nullptr, nullptr, 0);
 }
 
 int gf_tag_low_mapq(gf_ctx* ctx, const gf_alnrec* recs, size_t n, const gf_dpos* table, size_t n_rows, gf_taghit* out,
                     size_t cap, size_t* n_out) {
     if (n_rows && !table) return GF_E_INVAL;
     return tag_host(ctx, recs, n, out, cap, n_out, [&](void* d_in, void* d_out, void* d_n) {
-        return launch_low_mapq(ctx, d_in, n, table, n_rows, d_out, cap, d_n);
+        return launch_low_mapq(ctx, d_in, n, table, n_rows, d_out, cap, d_n, nullptr, nullptr, 0);
     });
 }
 

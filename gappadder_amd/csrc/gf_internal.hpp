@@ -130,9 +130,9 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
                   int read_len, int min_hits, void* d_out, size_t cap, void* d_n_out);
 // tagger.hip
 int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist, int anchor_mapq,
-               void* d_out, size_t cap, void* d_n_out);
+               void* d_out, size_t cap, void* d_n_out, void* d_low, size_t low_cap, void* d_n_low);
 int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* table, size_t n_rows, void* d_out,
-                    size_t cap, void* d_n_out);
+                    size_t cap, void* d_n_out, const void* d_low, const void* d_n_low, size_t low_cap);
 
 // assemble.hip
 int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,

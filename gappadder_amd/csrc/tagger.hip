@@ -28,6 +28,10 @@ struct TagParams {
     gf_taghit* out;
     uint32_t cap;
     uint32_t* n_out;
+    // optional by-product for the second hop: every MAPQ==0 record as {pos, ref, record index}
+    gf_lowrec* low;
+    uint32_t low_cap;
+    uint32_t* n_low;
 };
 
 // Hits are rare and a single global counter serialises returning atomics at ~11 ns each (MI355X_MICROARCH.md
@@ -81,10 +85,22 @@ constexpr int TAG_UNROLL = 4;  // 4 KiB (128 records) in flight per wave
 __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
     extern __shared__ uint32_t bins[];  // the whole bin map (<= 16 KiB), staged once per workgroup
     __shared__ HitBuf hb;
+    constexpr uint32_t LOWBUF = 128;    // MAPQ==0 records buffered per wave (one global atomic per ~64-128 of them)
+    __shared__ gf_lowrec lowbuf[4][LOWBUF];
+    uint32_t low_n = 0;                 // wave-uniform
     if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
     for (uint32_t i = threadIdx.x; i < P.bin_words; i += blockDim.x) bins[i] = P.bin_bits[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
+    gf_lowrec* wlow = lowbuf[threadIdx.x >> 6];
+    auto flush_low = [&]() {
+        uint32_t gb = 0;
+        if (lane == 0) gb = atomicAdd(P.n_low, low_n);
+        gb = __shfl(gb, 0);
+        for (uint32_t i = lane; i < low_n; i += 64)
+            if (gb + i < P.low_cap) P.low[gb + i] = wlow[i];
+        low_n = 0;
+    };
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n_half = 2 * P.n;                       // 16-byte halves
@@ -110,6 +126,16 @@ __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
             if (live) {
                 r.pos = v[u].x; r.mate_pos = v[u].y; r.tlen = (int32_t)v[u].z; r.ref = v[u].w;
                 live = r.ref < P.n_scaffolds;
+            }
+            if (P.low) {   // wave-uniform: compact the MAPQ==0 records for the second hop
+                const bool z = live && ((nb.y >> 16) & 0xFF) == 0;
+                const unsigned long long zb = __ballot(z);
+                if (zb) {
+                    const uint32_t cnt = (uint32_t)__popcll(zb);
+                    if (low_n + cnt > LOWBUF) flush_low();
+                    if (z) wlow[low_n + __popcll(zb & ((1ull << lane) - 1))] = gf_lowrec{r.pos, r.ref, (uint32_t)(h >> 1)};
+                    low_n += cnt;
+                }
             }
             if (live) {  // coarse test first: almost every record lies far from every gap
                 const uint32_t b0 = P.bin_off[r.ref], nbin = P.bin_off[r.ref + 1] - b0, bi = r.pos >> P.bin_shift;
@@ -166,12 +192,16 @@ __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
             }
         }
     }
+    if (P.low && low_n) flush_low();
     flush_hits(hb, P.out, P.cap, P.n_out);
 }
 
 struct LowParams {
-    const gf_alnrec* recs;
+    const gf_alnrec* recs;     // full records ...
     uint64_t n;
+    const gf_lowrec* low;      // ... or the compacted MAPQ==0 list with its device-side count
+    const uint32_t* n_low;
+    uint32_t low_cap;
     const uint32_t* upos;      // unique (scaffold-grouped) mate positions, ascending inside a scaffold
     const uint32_t* urow;      // n_unique+1 offsets into the row table
     const uint32_t* scaf_off;  // n_scaffolds+1 offsets into upos
@@ -235,6 +265,47 @@ __global__ __launch_bounds__(256) void low_mapq_kernel(LowParams P) {
     flush_hits(hb, P.out, P.cap, P.n_out);
 }
 
+// second hop over the compacted list (2 % of the records, 12 B each) instead of a second pass over every record
+__global__ __launch_bounds__(256) void low_mapq_compact_kernel(LowParams P) {
+    __shared__ HitBuf hb;
+    if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
+    __syncthreads();
+    const uint32_t n = *P.n_low < P.low_cap ? *P.n_low : P.low_cap;
+    const uint32_t n_round = (n + 63) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        uint32_t row = 0, row_end = 0, rec = 0;
+        if (i < n) {
+            const gf_lowrec e = P.low[i];
+            rec = e.rec;
+            if (e.ref < P.n_scaffolds) {
+                uint32_t lo = P.scaf_off[e.ref], hi = P.scaf_off[e.ref + 1];
+                const uint32_t first = lo;
+                const uint64_t lim = (uint64_t)e.pos + 199;  // largest q <= pos+199
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint64_t)P.upos[mid] <= lim) lo = mid + 1; else hi = mid;
+                }
+                if (lo > first) {
+                    const uint32_t uq = lo - 1;
+                    if ((uint64_t)P.upos[uq] + 299 >= e.pos) {
+                        row = P.urow[uq];
+                        row_end = P.urow[uq + 1];
+                    }
+                }
+            }
+        }
+        while (true) {
+            const bool more = row < row_end;
+            if (!__any(more)) break;
+            gf_taghit hit;
+            hit.rec = rec; hit.gap = row; hit.kind = GF_KIND_LOWMAPQ; hit.to_mate = 0;
+            emit_hit(more, hit, hb, P.out, P.cap, P.n_out);
+            if (more) ++row;
+        }
+    }
+    flush_hits(hb, P.out, P.cap, P.n_out);
+}
+
 static unsigned stream_grid(gf_ctx* ctx, size_t n) {
     size_t blocks = (n + 255) / 256;
     return (unsigned)std::max<size_t>(1, std::min<size_t>(blocks, (size_t)ctx->n_cu * 8));
@@ -278,12 +349,17 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
 }
 
 int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist, int anchor_mapq,
-               void* d_out, size_t cap, void* d_n_out) {
+               void* d_out, size_t cap, void* d_n_out, void* d_low, size_t low_cap, void* d_n_low) {
     if (!ctx->d_gaps) return GF_E_STATE;
     if (n >= 0xFFFFFFFFull || cap > 0xFFFFFFFFull) return GF_E_INVAL;
     GF_HIP(ctx, hipMemsetAsync(d_n_out, 0, 4, ctx->stream));
+    if (d_n_low) GF_HIP(ctx, hipMemsetAsync(d_n_low, 0, 4, ctx->stream));
     if (n == 0) return GF_OK;
     TagParams P;
+    P.low = (gf_lowrec*)d_low;
+    P.low_cap = (uint32_t)std::min<size_t>(low_cap, 0xFFFFFFFFu);
+    P.n_low = (uint32_t*)d_n_low;
+    if (!d_low || !d_n_low) { P.low = nullptr; P.n_low = nullptr; }
     P.recs = (const gf_alnrec*)d_recs;
     P.n = n;
     P.gaps = ctx->d_gaps;
@@ -312,11 +388,11 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
 }
 
 int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* table, size_t n_rows, void* d_out,
-                    size_t cap, void* d_n_out) {
-    if (n >= 0xFFFFFFFFull || cap > 0xFFFFFFFFull || n_rows >= 0xFFFFFFFFull) return GF_E_INVAL;
+                    size_t cap, void* d_n_out, const void* d_low, const void* d_n_low, size_t low_cap) {
+    if (n >= 0xFFFFFFFFull || cap > 0xFFFFFFFFull || n_rows >= 0xFFFFFFFFull || low_cap > 0xFFFFFFFFull) return GF_E_INVAL;
     if (ctx->n_scaffolds == 0) return GF_E_STATE;
     GF_HIP(ctx, hipMemsetAsync(d_n_out, 0, 4, ctx->stream));
-    if (n == 0 || n_rows == 0) return GF_OK;
+    if ((n == 0 && !d_low) || n_rows == 0) return GF_OK;
     // host: unique positions per scaffold + row offsets (the table is tiny next to the record stream); the device copy
     // is cached and re-used while the caller passes the same rows (a pipeline calls this once per batch of records)
     const bool cached = ctx->low_rows.size() == n_rows * 4 && ctx->table.p &&
@@ -356,6 +432,9 @@ int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* ta
     LowParams P;
     P.recs = (const gf_alnrec*)d_recs;
     P.n = n;
+    P.low = (const gf_lowrec*)d_low;
+    P.n_low = (const uint32_t*)d_n_low;
+    P.low_cap = (uint32_t)low_cap;
     P.upos = (const uint32_t*)base;
     P.urow = (const uint32_t*)(base + b1);
     P.scaf_off = (const uint32_t*)(base + b1 + b2);
@@ -365,7 +444,10 @@ int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* ta
     P.n_out = (uint32_t*)d_n_out;
     {
         LaunchTimer tm(ctx, GF_KERNEL_LOWMAPQ);
-        hipLaunchKernelGGL(low_mapq_kernel, dim3(stream_grid(ctx, n)), dim3(256), 0, ctx->stream, P);
+        if (d_low)
+            hipLaunchKernelGGL(low_mapq_compact_kernel, dim3(stream_grid(ctx, std::max<size_t>(low_cap, 1))), dim3(256), 0, ctx->stream, P);
+        else
+            hipLaunchKernelGGL(low_mapq_kernel, dim3(stream_grid(ctx, n)), dim3(256), 0, ctx->stream, P);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;

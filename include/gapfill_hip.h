@@ -167,6 +167,20 @@ int gf_assemble_dev(gf_ctx* ctx, const void* d_pool_packed, const void* d_pool_n
 int gf_count_kmers(gf_ctx* ctx, const uint8_t* pool_packed, const uint32_t* pool_n_mask_or_null, size_t n_reads,
                    int read_len, int k, int min_count, uint64_t* kmers, uint32_t* counts, size_t cap, size_t* n_out);
 
+/* One-pass form of the two hops for device-resident pipelines: the tagger also compacts every MAPQ==0 record (2 % of a
+ * typical BAM) into {pos, ref, record index}, and the second hop scans that list instead of re-reading every record
+ * (the reference makes a second full `samtools view` pass, run_multi_threads_discordant.py:125-138).  Same hits. */
+typedef struct {
+    uint32_t pos;
+    uint32_t ref;
+    uint32_t rec;
+} gf_lowrec;
+int gf_tag_alignments_low_dev(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist,
+                              int anchor_mapq, void* d_out, size_t cap, void* d_n_out, void* d_low /* gf_lowrec */,
+                              size_t low_cap, void* d_n_low /* u32 */);
+int gf_tag_low_mapq_compact_dev(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const gf_dpos* table,
+                                size_t n_rows, void* d_out, size_t cap, void* d_n_out);
+
 /* ---- a-4 / a-5 on the device: per-gap read pools.  The reference joins read IDs against whole FASTQ files
  * ({readId -> set(gapKey)}, run_multi_threads_discordant.py:153-185; stream + append, :209-241, 283-316; `cat` across
  * libraries, merge_reads.py:43-51).  With reads addressed by index (read = 2*pair + mate) that is the SET of (gap, read)

@@ -318,3 +318,37 @@ def test_screen_filter_variants_agree(gf, variant):
     finally:
         gf.set_option("screen_variant", 0)
         gf.set_option("bitmap_log2", 0)
+
+
+def test_one_pass_tagger_with_mapq0_compaction_equals_two_passes(gf):
+    """gf_tag_alignments_low_dev + gf_tag_low_mapq_compact_dev give the hits of gf_tag_alignments + gf_tag_low_mapq."""
+    import torch
+    from gappadder_amd import _lib as B
+    c = S.small_case(seed=51, n_pairs=40000)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    recs = c["recs"]
+    thits = gf.tag_alignments(recs, 300, 30)
+    rows = sorted((int(recs[h["rec"]]["mate_ref"]), int(recs[h["rec"]]["mate_pos"]), int(c["gaps"][h["gap"]]["scaffold"]),
+                   int(c["gaps"][h["gap"]]["idx_in_scaffold"])) for h in thits if h["kind"] == B.KIND_DISCORDANT)
+    table = RU.dpos_array(rows).astype(B.DPOS)
+    lhits = gf.tag_low_mapq(recs, table)
+    dev = torch.device("cuda:0")
+    d_recs = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy()).to(dev)
+    n = len(recs)
+    cap = 4 * (len(thits) + len(lhits)) + 64
+    d_t = torch.zeros(cap * 12, dtype=torch.uint8, device=dev)
+    d_l = torch.zeros(cap * 12, dtype=torch.uint8, device=dev)
+    low_cap = n
+    d_low = torch.zeros(low_cap * 12, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(8, dtype=torch.int32, device=dev)
+    L, h, cp = B.lib(), gf.handle, d_cnt.data_ptr()
+    assert L.gf_tag_alignments_low_dev(h, d_recs.data_ptr(), n, 300, 30, 250, 30, d_t.data_ptr(), cap, cp, d_low.data_ptr(), low_cap, cp + 4) == 0
+    assert L.gf_tag_low_mapq_compact_dev(h, d_low.data_ptr(), cp + 4, low_cap, B._p(table), len(table), d_l.data_ptr(), cap, cp + 8) == 0
+    gf.sync()
+    torch.cuda.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    valid = recs["ref"] < c["n_scaffolds"]
+    assert int(cnt[1]) == int(((recs["mapq"] == 0) & valid).sum())
+    got_t = np.sort(np.frombuffer(d_t[:int(cnt[0]) * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT), order=["rec", "gap", "kind"])
+    got_l = np.sort(np.frombuffer(d_l[:int(cnt[2]) * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT), order=["rec", "gap", "kind"])
+    assert _same(got_t, thits) and _same(got_l, lhits) and len(lhits) > 0
