@@ -59,12 +59,23 @@ __global__ void keys_from_tags_kernel(const gf_alnrec* recs, const gf_taghit* hi
     }
 }
 
+// keys arrive in runs of equal gap (hits of neighbouring reads), so a plain atomicAdd per key hammers one address;
+// each wave first groups its lanes by gap: one atomic per distinct gap per wave
 __global__ void pool_hist_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap, uint32_t n_gaps,
                                  uint32_t* cnt) {
     const uint32_t n = *n_keys < key_cap ? *n_keys : key_cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t g = (uint32_t)(keys[i] >> 32);
-        if (g < n_gaps) atomicAdd(&cnt[g], 1u);
+    const uint32_t n_round = (n + 63) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        uint32_t g = i < n ? (uint32_t)(keys[i] >> 32) : 0xFFFFFFFFu;
+        bool todo = g < n_gaps;
+        while (true) {
+            const unsigned long long act = __ballot(todo);
+            if (!act) break;
+            const uint32_t g0 = __shfl(g, __ffsll((long long)act) - 1);
+            const unsigned long long same = __ballot(todo && g == g0);
+            if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&cnt[g0], (uint32_t)__popcll(same));
+            if (g == g0) todo = false;
+        }
     }
 }
 
@@ -99,12 +110,27 @@ __global__ __launch_bounds__(1024) void pool_scan_kernel(const uint32_t* cnt, ui
 __global__ void pool_scatter_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap, uint32_t n_gaps,
                                     const uint32_t* seg_off, uint32_t* cursor, uint32_t* seg) {
     const uint32_t n = *n_keys < key_cap ? *n_keys : key_cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned long long k = keys[i];
+    const uint32_t n_round = (n + 63) & ~63u;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = i < n ? keys[i] : ~0ull;
         const uint32_t g = (uint32_t)(k >> 32), read = (uint32_t)k;
-        if (g >= n_gaps) continue;
-        const uint32_t p = seg_off[g] + atomicAdd(&cursor[g], 1u);
-        seg[p] = ((read & 1u) << 31) | (read >> 1);  // (mate, pair): left-file order, then right-file order
+        bool todo = g < n_gaps;
+        while (true) {   // one cursor atomic per distinct gap per wave
+            const unsigned long long act = __ballot(todo);
+            if (!act) break;
+            const uint32_t g0 = __shfl(g, __ffsll((long long)act) - 1);
+            const bool mine = todo && g == g0;
+            const unsigned long long same = __ballot(mine);
+            const uint32_t leader = __ffsll((long long)same) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&cursor[g0], (uint32_t)__popcll(same));
+            base = __shfl(base, leader);
+            if (mine) {
+                seg[seg_off[g0] + base + __popcll(same & ((1ull << lane) - 1))] = ((read & 1u) << 31) | (read >> 1);  // (mate, pair)
+                todo = false;
+            }
+        }
     }
 }
 
@@ -154,29 +180,29 @@ __global__ __launch_bounds__(256) void pool_sort_unique_kernel(uint32_t n_gaps, 
     }
 }
 
+// one workgroup per gap: the gap's pooled reads are copied as one contiguous run of bytes
 __global__ __launch_bounds__(256) void pool_gather_kernel(uint32_t n_gaps, const uint32_t* seg_off, const uint32_t* seg,
                                                          const unsigned long long* pool_off, const uint8_t* reads, uint32_t rb,
                                                          uint64_t n_reads, uint8_t* pool, uint64_t pool_cap_reads,
                                                          uint32_t* pool_ids) {
-    // one wave per pooled read: rb bytes copied by the lanes
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned long long total = pool_off[n_gaps];
-    for (unsigned long long j = wave; j < total && j < pool_cap_reads; j += n_waves) {
-        // gap of pooled read j: binary search in pool_off
-        uint32_t lo = 0, hi = n_gaps;
-        while (lo + 1 < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (pool_off[mid] <= j) lo = mid; else hi = mid;
+    for (uint32_t g = blockIdx.x; g < n_gaps; g += gridDim.x) {
+        const unsigned long long p0 = pool_off[g], p1 = pool_off[g + 1];
+        const uint32_t n = (uint32_t)(p1 - p0);
+        const uint32_t s0 = seg_off[g];
+        const uint64_t nbytes = (uint64_t)n * rb;
+        for (uint64_t i = threadIdx.x; i < nbytes; i += blockDim.x) {
+            const uint32_t j = (uint32_t)(i / rb), b = (uint32_t)(i - (uint64_t)j * rb);
+            if (p0 + j >= pool_cap_reads) break;
+            const uint32_t key = seg[s0 + j];
+            const uint32_t read = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
+            if (read < n_reads) pool[(p0 + j) * rb + b] = reads[(uint64_t)read * rb + b];
         }
-        const uint32_t key = seg[seg_off[lo] + (uint32_t)(j - pool_off[lo])];
-        const uint32_t read = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
-        if (read < n_reads) {
-            const uint8_t* src = reads + (uint64_t)read * rb;
-            uint8_t* dst = pool + j * rb;
-            for (uint32_t b = lane; b < rb; b += 64) dst[b] = src[b];
-        }
-        if (lane == 0 && pool_ids) pool_ids[j] = read;
+        if (pool_ids)
+            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+                if (p0 + j >= pool_cap_reads) break;
+                const uint32_t key = seg[s0 + j];
+                pool_ids[p0 + j] = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
+            }
     }
 }
 

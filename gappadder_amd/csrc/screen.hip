@@ -517,8 +517,11 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
     const uint32_t npos = P.read_len - P.k + 1;
     const uint32_t tmask = (1u << P.t_log2) - 1;
 
-    for (uint32_t c0 = blockIdx.x * 64; c0 < n_cand; c0 += gridDim.x * 64) {
-        const uint32_t nb = n_cand - c0 < 64 ? n_cand - c0 : 64;
+    // 64 candidates per wave and pass.  (Measured: smaller batches on more concurrent waves are SLOWER — the pass is bound by
+    // random 16-B table loads served from the Infinity Cache, not by wave count.)
+    const uint32_t bsz = 64;
+    for (uint32_t c0 = blockIdx.x * bsz; c0 < n_cand; c0 += gridDim.x * bsz) {
+        const uint32_t nb = n_cand - c0 < bsz ? n_cand - c0 : bsz;
         const uint32_t my_r = lane < nb ? P.cand[c0 + lane] : 0;
         {   // stage my candidate's read, re-aligned to a word boundary
             const uint64_t o = (uint64_t)my_r * P.rb;
