@@ -37,20 +37,29 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=50_000_000, help="read records per GPU (C2: 50 M)")
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # GF_BENCH_BACKEND=gloo + GF_BENCH_ONE_GPU=1: smoke-test of the multi-rank code path with every rank on cuda:0
+    # (single-GPU boxes); the real runs use nccl (= RCCL) with one GPU per rank
+    backend = os.environ.get("GF_BENCH_BACKEND", "nccl")
+    if os.environ.get("GF_BENCH_ONE_GPU"):
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from gappadder_amd import _lib as B
     from gappadder_amd.hip_api import GapFill
@@ -155,7 +164,7 @@ def main():
     t_filter, n_filter = kt["screen_filter"]
     gf.timing(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     cnt = d_cnt.cpu().numpy()
@@ -171,7 +180,7 @@ def main():
         seq_local = d_seq[:n_seq].cpu().numpy().tobytes()
         payload = SH.encode_contigs([(int(c["gap"]), int(c["k"]), int(c["kv"]), int(c["n_nodes"]), int(c["cov_sum"]),
                                       seq_local[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode()) for c in ctg])
-        gathered = SH.gather_bytes(payload, dst=0, device=dev)
+        gathered = SH.gather_bytes(payload, dst=0, device=coll_dev)
         if rank == 0:
             assert len(gathered) == world and all(len(g) > 0 for g in gathered)
 
@@ -218,8 +227,15 @@ def cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, 
     gaps' pools.  Also the checker: the GPU's hits on that prefix and its contigs for those gaps must equal the oracle's."""
     from oracle import c_oracle as CO
     n_s = min(args.cpu_sample_reads, args.reads) // 2 * 2
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:   # a cgroup CPU quota (cpu.max "quota period") caps the usable cores below the visible ones
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(q) // int(per)))
+    except Exception:
+        pass
     ocfg = np.frombuffer(cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
+    CO.set_threads(cores)
     packed, recs = CO.synth_pairs(ocfg, first_pair, n_s // 2)
     blob = CO.unpack_reads(packed, L)
     t0 = time.perf_counter()
@@ -231,13 +247,15 @@ def cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, 
     sub = np.sort(hits[hits["read"] < n_s], order=["gap", "read"])
     ok = len(sub) == len(ohits) and sub.tobytes() == ohits.astype(B.HIT).tobytes()
     # assembly sample: the first gaps' pools exactly as the GPU built them
-    n_g = min(len(gaps), 64)
+    n_g = min(len(gaps), 256)
     rb = (L + 3) // 4
     pool = d_pool[:int(pool_off[n_g]) * rb].cpu().numpy().reshape(-1, rb)
     pblob = CO.unpack_reads(pool, L)
     seq = d_seq[:n_seq].cpu().numpy().tobytes()
+    from concurrent.futures import ThreadPoolExecutor
     t3 = time.perf_counter()
-    exp = [CO.assemble_pool(pblob[int(pool_off[g]) * L:int(pool_off[g + 1]) * L], L, k, kv) for g in range(n_g)]
+    with ThreadPoolExecutor(max_workers=cores) as ex:   # gaps are independent (assemble_gaps.py:296-299 uses a process pool)
+        exp = list(ex.map(lambda g: CO.assemble_pool(pblob[int(pool_off[g]) * L:int(pool_off[g + 1]) * L], L, k, kv), range(n_g)))
     t4 = time.perf_counter()
     ok_asm = True
     for g in range(n_g):
@@ -248,7 +266,7 @@ def cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, 
     cpu_step = (t2 - t0) * (n_reads / n_s) + (t4 - t3) * (len(gaps) / n_g)
     return {"value": n_reads / cpu_step, "unit": "reads/s", "cores": cores, "kind": "port",
             "sample": "recruit: first %d reads of rank 0's shard (k-mer screen %.2f s + alignment tagger %.2f s, OpenMP %d threads); "
-                      "assembly: pools of the first %d gaps (%.2f s, 1 thread); value = reads / (sample times scaled to the whole "
+                      "assembly: pools of the first %d gaps (%.2f s, same thread count); value = reads / (sample times scaled to the whole "
                       "step); oracle/gp_oracle.c" % (n_s, t1 - t0, t2 - t1, cores, n_g, t4 - t3),
             "recruit_reads_per_s": n_s / (t2 - t0), "assembly_gaps_per_s": n_g / (t4 - t3),
             "parity_on_sample": bool(ok and ok_asm), "parity_recruit": bool(ok), "parity_assembly": bool(ok_asm),

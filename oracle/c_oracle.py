@@ -35,6 +35,8 @@ def lib():
         L.or_tag_low_mapq.argtypes = [vp, sz, vp, sz, vp, sz]
         L.or_screen_reads.restype = sz
         L.or_screen_reads.argtypes = [C.c_char_p, sz, i32, C.c_char_p, vp, sz, i32, i32, u32, vp, sz, i32]
+        L.or_set_threads.restype = None
+        L.or_set_threads.argtypes = [i32]
         L.or_pack_kmer64.restype = C.c_uint64
         L.or_pack_kmer64.argtypes = [C.c_char_p, i32]
         L.or_unpack_reads.restype = None
@@ -53,6 +55,10 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def set_threads(n):
+    lib().or_set_threads(int(n))
 
 
 def tag_alignments(recs, gaps, insert_size, sd, clip_dist=250, anchor_mapq=30):

@@ -8,6 +8,14 @@
 #include <omp.h>
 #endif
 
+void or_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------ a-7: KmerUtils layout */
 static inline unsigned code_of(char c) { /* KmerUtils.cpp:25-41: non-CGT -> A */
     return (c == 'C' || c == 'c') ? 1u : (c == 'G' || c == 'g') ? 2u : (c == 'T' || c == 't') ? 3u : 0u;
@@ -181,6 +189,27 @@ size_t or_screen_reads(const char* reads, size_t n_reads, int L, const char* fla
     }
     if (min_hits < 1) min_hits = 1;
     size_t cnt = 0;
+    /* distinct k-mers -> run [first, last) in tab, through an open-addressing index (keys right-aligned in 128 bits) */
+    typedef unsigned __int128 u128;
+    size_t nd = 0;
+    for (size_t i = 0; i < nt; ++i) if (i == 0 || tab[i].hi != tab[i - 1].hi || tab[i].lo != tab[i - 1].lo) ++nd;
+    size_t hcap = 1024;
+    while (hcap < 2 * nd + 2) hcap <<= 1;
+    u128* hkey = malloc(hcap * sizeof(u128));
+    uint32_t* hfirst = malloc(hcap * sizeof(uint32_t));
+    uint32_t* hlast = malloc(hcap * sizeof(uint32_t));
+    for (size_t i = 0; i < hcap; ++i) hfirst[i] = 0xFFFFFFFFu;
+    const int sh = 128 - 2 * k;
+    for (size_t i = 0; i < nt;) {
+        size_t j = i;
+        while (j < nt && tab[j].hi == tab[i].hi && tab[j].lo == tab[i].lo) ++j;
+        u128 key = (((u128)tab[i].hi << 64) | tab[i].lo) >> sh;
+        size_t hs = (size_t)((uint64_t)(key ^ (key >> 61)) * 0x9E3779B97F4A7C15ull >> 20) & (hcap - 1);
+        while (hfirst[hs] != 0xFFFFFFFFu) hs = (hs + 1) & (hcap - 1);
+        hkey[hs] = key; hfirst[hs] = (uint32_t)i; hlast[hs] = (uint32_t)j;
+        i = j;
+    }
+    const u128 kmask = k == 64 ? ~(u128)0 : (((u128)1 << (2 * k)) - 1);
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #else
@@ -189,19 +218,28 @@ size_t or_screen_reads(const char* reads, size_t n_reads, int L, const char* fla
 #pragma omp parallel
     {
         uint32_t* glist = malloc(sizeof(uint32_t) * 65536);
-#pragma omp for schedule(dynamic, 1024)
+#pragma omp for schedule(dynamic, 4096)
         for (long r = 0; r < (long)n_reads; ++r) {
             size_t ng = 0;
             const char* s = reads + (size_t)r * L;
-            for (int p = 0; p + k <= L; ++p) {
-                uint64_t hi, lo;
-                if (!canon_kmer(s + p, k, &hi, &lo)) continue;
-                size_t a = 0, b = nt; /* lower bound */
-                while (a < b) {
-                    size_t m = (a + b) / 2;
-                    if (tab[m].hi < hi || (tab[m].hi == hi && tab[m].lo < lo)) a = m + 1; else b = m;
+            u128 f = 0, rc = 0;   /* forward k-mer and its reverse complement, rolled base by base */
+            int run = 0;          /* ACGT bases since the last other symbol */
+            for (int i = 0; i < L; ++i) {
+                const char c = s[i];
+                if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { run = 0; f = 0; rc = 0; continue; }
+                const u128 b = code_of(c);
+                f = ((f << 2) | b) & kmask;
+                rc = (rc >> 2) | ((u128)(3 - b) << (2 * (k - 1)));
+                if (++run < k) continue;
+                const u128 key = f < rc ? f : rc;
+                size_t hs = (size_t)((uint64_t)(key ^ (key >> 61)) * 0x9E3779B97F4A7C15ull >> 20) & (hcap - 1);
+                while (hfirst[hs] != 0xFFFFFFFFu) {
+                    if (hkey[hs] == key) {
+                        for (uint32_t a = hfirst[hs]; a < hlast[hs] && ng < 65536; ++a) glist[ng++] = tab[a].gap;
+                        break;
+                    }
+                    hs = (hs + 1) & (hcap - 1);
                 }
-                for (; a < nt && tab[a].hi == hi && tab[a].lo == lo && ng < 65536; ++a) glist[ng++] = tab[a].gap;
             }
             if (!ng) continue;
             /* count positions per gap */
@@ -220,6 +258,7 @@ size_t or_screen_reads(const char* reads, size_t n_reads, int L, const char* fla
         }
         free(glist);
     }
+    free(hkey); free(hfirst); free(hlast);
     free(tab);
     qsort(out, cnt < cap ? cnt : cap, sizeof(or_hit), hit_cmp);
     return cnt;
