@@ -201,8 +201,8 @@ def main():
                        "reads_per_gpu": n_reads, "gaps": int(len(gaps)), "k": k, "kv": kv,
                        "sharding": "reads sharded over ranks, gaps replicated; RCCL only gathers the assembled sequences"},
             "gaps_per_s": world * len(gaps) / (dt / args.steps),
-            "roofline": {"bound": "hbm", "kernel": "screen_filter_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "screen_filter_wave_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n_reads, L, k),
                          "algorithmic_bytes_per_launch": n_reads * rb, "avg_launch_ms": filt_ms,
                          "frac_of_measured_copy_6290": achieved / 6290.0},
             "phases_ms": phases,
@@ -218,6 +218,19 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(n_reads, L, k):
+    """Bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE and WRITE_SIZE in separate runs of this same command, gfx950 x2 correction applied to FETCH_SIZE).  Counters
+    cannot be collected from inside the timed run; null when no profile matches this configuration."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if t["reads_per_launch"] == n_reads and t["read_len"] == L and t["k"] == k:
+            return t["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, d_pool, pool_off, ctg, d_seq, n_seq, gpu_step_s,

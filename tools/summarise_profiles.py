@@ -1,0 +1,41 @@
+"""gpurun_out/prof_final -> profiles/r01_kernel_stats.csv, profiles/r01_pmc_summary.csv, profiles/r01_traffic.json"""
+import collections, csv, glob, json, os, sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_final"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+os.makedirs(dst, exist_ok=True)
+stats = glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(stats)))
+with open(dst + "/r01_kernel_stats.csv", "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu   (MI355X, C2 workload)\n")
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        if r["Name"].startswith(("gf::", "void gf::")):
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].startswith(("gf::", "void gf::")):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(dst + "/r01_pmc_summary.csv", "w") as f:
+    f.write("# rocprofv3 --pmc <one group per pass> -- python3 bench.py --steps 3 --warmup 1 --no-cpu; mean counter value per dispatch\n")
+    w = csv.writer(f)
+    w.writerow(["Kernel", "Counter", "Dispatches", "MeanPerDispatch"])
+    for k in sorted(acc):
+        for c in sorted(acc[k]):
+            v = acc[k][c]
+            w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
+name = [k for k in acc if "screen_filter" in k][0]
+fetch = sum(acc[name]["FETCH_SIZE"]) / len(acc[name]["FETCH_SIZE"])
+write = sum(acc[name]["WRITE_SIZE"]) / len(acc[name]["WRITE_SIZE"])
+avg_ns = [float(r["AverageNs"]) for r in rows if r["Name"] == name][0]
+out = {"kernel": name, "reads_per_launch": 50000000, "read_len": 150, "k": 31,
+       "FETCH_SIZE_kb_per_launch": fetch, "WRITE_SIZE_kb_per_launch": write,
+       "traffic_bytes_per_launch": (2 * fetch + write) * 1024.0,
+       "correction": "gfx950: FETCH_SIZE counts 128-B fabric requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; "
+                     "Infinity-Cache hits are included, so this is fabric traffic, an upper bound of HBM traffic",
+       "rocprof_avg_launch_ns": avg_ns,
+       "cmd": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu"}
+json.dump(out, open(dst + "/r01_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
