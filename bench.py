@@ -191,6 +191,16 @@ def main():
         achieved = n_reads * rb / (filt_ms * 1e-3) / 1e9
         phases = {name: t / max(1, n_filter) for name, (t, _) in kt.items()}
         gaps_with_contig = int(len(np.unique(ctg["gap"])))
+        # "closed" = a contig anchored by both flanks (gappadder_amd/pick_contigs.py, anchor 30 then 15 like the reference's two
+        # bwa scores); host-side, outside the timed region.  With one 300-bp library the recruited reads reach ~450 bp into a
+        # 2-kb gap from each side, so the reference's first round cannot close these gaps either.
+        from gappadder_amd.pick_contigs import pick_gap_sequence
+        seq_all = d_seq[:n_seq].cpu().numpy().tobytes().decode()
+        by_gap = {}
+        for c in ctg:
+            by_gap.setdefault(int(c["gap"]), []).append(("c", seq_all[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])]))
+        gaps_closed = sum(1 for g, cs in by_gap.items()
+                          if pick_gap_sequence(cs, flanks[g][0], flanks[g][1], 30) or pick_gap_sequence(cs, flanks[g][0], flanks[g][1], 15))
         out = {
             "metric": "reads_screened_per_s", "value": world * n_reads / (dt / args.steps), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -201,6 +211,7 @@ def main():
                        "reads_per_gpu": n_reads, "gaps": int(len(gaps)), "k": k, "kv": kv,
                        "sharding": "reads sharded over ranks, gaps replicated; RCCL only gathers the assembled sequences"},
             "gaps_per_s": world * len(gaps) / (dt / args.steps),
+            "gaps_closed_per_s": world * gaps_closed / (dt / args.steps),
             "roofline": {"bound": "hbm", "kernel": "screen_filter_wave_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n_reads, L, k),
                          "algorithmic_bytes_per_launch": n_reads * rb, "avg_launch_ms": filt_ms,
@@ -209,7 +220,7 @@ def main():
             "tagger_gbs": n_reads * 32 / (phases["tag_alignments"] * 1e-3) / 1e9,
             "counts": {"screen_hits": n_hits, "tagger_hits": n_thits, "second_hop_hits": n_lhits, "pool_keys": n_keys,
                        "pooled_reads": int(pool_off[-1]), "contigs": n_ctg, "contig_bases": n_seq,
-                       "gaps_with_contig": gaps_with_contig},
+                       "gaps_with_contig": gaps_with_contig, "gaps_closed": gaps_closed},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, d_pool, pool_off,

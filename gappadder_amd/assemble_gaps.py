@@ -97,5 +97,20 @@ class GapAssembler:
 
     assembly_given_list = assembly
 
+    def pick_already_constructed(self, contigs_select, fa_list, sf_picked):
+        picked = contigs_select.get_already_picked(sf_picked)
+        return [k for k in fa_list if k not in picked]
+
     def assemble_pipeline(self):
-        self.assembly(self.prepare_list())
+        """First round of the reference's pipeline (assemble_gaps.py:328-339): assemble, then pick the gaps whose contigs are
+        anchored by both flanks (anchor length 30 = the reference's first bwa_min_score), then a second pick at 15 (:365-366).
+        The rounds in between (contig merging, both-unmapped recruitment) are outside this build."""
+        from .pick_contigs import ContigsSelection
+        fa_list = self.prepare_list()
+        self.assembly(fa_list)
+        sf_picked = working_folder + "../picked_seqs.fa"
+        cs = ContigsSelection(working_folder)
+        n30 = cs.pick_full_constructed_contigs(30, fa_list, sf_picked)
+        remain = self.pick_already_constructed(cs, fa_list, sf_picked)
+        n15 = cs.pick_full_constructed_contigs(15, remain, sf_picked)
+        return {"gaps": len(fa_list), "closed": n30 + n15}

@@ -94,9 +94,9 @@ def main_func(command, sf_config):
         for s in SUB_MERGED:
             os.makedirs(wf + MERGE_FOLDER + s, exist_ok=True)
         ga = assemble_gaps.GapAssembler(sf_fai, sf_gap_pos, cfg["nthreads"], wf + MERGE_FOLDER, cfg["kmers"], gf)
-        ga.assemble_pipeline()
-        print("first-round assembly written to %svelvet_temp/*/contigs.fa (contig merging / picking: reference's later rounds, "
-              "not part of this build)" % (wf + MERGE_FOLDER))
+        res = ga.assemble_pipeline()
+        print("assembled %d gaps, %d closed (picked_seqs.fa); contigs in %svelvet_temp/*/contigs.fa; the reference's later rounds "
+              "(contig merging, both-unmapped recruitment) are not part of this build" % (res["gaps"], res["closed"], wf + MERGE_FOLDER))
 
 
 def main(argv=None):

@@ -1,0 +1,102 @@
+"""Flank anchoring -> gap sequence selection (SURVEY.md §8f "next" rank 1; mirrors ContigsSelection, pick_contigs.py:64-358,
+542-581).  The reference aligns the two flanks to the gap's contigs with `bwa mem -T {score} -a` and keeps the contig both
+flanks hit on the same strand; bwa is out of scope here, so the anchors are EXACT matches: the last `score` bases of the left
+flank and the first `score` bases of the right flank (score = the reference's bwa_min_score: 30, later 15).  Among the
+qualifying contigs the longest span wins (pick_contigs.py:300-321); the picked slice is contig[left_end : right_start + 1]
+in flank orientation — the +1 reproduces the reference's 1-based/0-based slice (:341-349); header '>{gapId}_{contigName}'
+(:352).  A gap with a picked sequence is what this build reports as "closed"."""
+import os
+
+_COMP = str.maketrans("ACGTacgt", "TGCAtgca")
+
+
+def revcomp(s):
+    return s.translate(_COMP)[::-1]
+
+
+def read_fasta(path):
+    out, name, chunks = [], None, []
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                if name is not None:
+                    out.append((name, "".join(chunks)))
+                name, chunks = line[1:].split()[0], []
+            elif line:
+                chunks.append(line)
+    if name is not None:
+        out.append((name, "".join(chunks)))
+    return out
+
+
+def pick_gap_sequence(contigs, left_flank, right_flank, anchor_len):
+    """contigs: [(name, seq)].  Returns (name, gap_seq, oriented_contig) or None."""
+    if len(left_flank) < anchor_len or len(right_flank) < anchor_len:
+        return None
+    la, ra = left_flank[-anchor_len:], right_flank[:anchor_len]
+    if any(c not in "ACGT" for c in la + ra):
+        return None
+    best = None
+    for name, seq in contigs:
+        for oriented in (seq, revcomp(seq)):
+            i = oriented.find(la)
+            if i < 0:
+                continue
+            left_end = i + anchor_len
+            j = oriented.find(ra, left_end)
+            if j < 0:
+                continue
+            span = j - left_end
+            if best is None or span > best[0]:
+                best = (span, name, oriented[left_end:j + 1], oriented)
+            break
+    return None if best is None else best[1:]
+
+
+class ContigsSelection:
+    def __init__(self, working_space):
+        self.working_folder = working_space
+
+    def _pick_one(self, gid, anchor_len):
+        wf = self.working_folder
+        sf_flank = wf + "../flank_regions/%s.fa" % gid
+        sf_contig = wf + "velvet_temp/%s/contigs.fa" % gid
+        for p in (wf + "velvet_temp/%s/picked_seqs.fa" % gid, wf + "velvet_temp/%s/picked_contigs.fa" % gid):
+            if os.path.exists(p):
+                os.remove(p)
+        if not (os.path.exists(sf_flank) and os.path.exists(sf_contig)):
+            return False
+        fl = dict(read_fasta(sf_flank))
+        res = pick_gap_sequence(read_fasta(sf_contig), fl.get(gid + "_left", ""), fl.get(gid + "_right", ""), anchor_len)
+        if res is None:
+            return False
+        name, gap_seq, oriented = res
+        if gap_seq:
+            with open(wf + "velvet_temp/%s/picked_seqs.fa" % gid, "w") as f:
+                f.write(">%s_%s\n%s\n" % (gid, name, gap_seq))
+        with open(wf + "velvet_temp/%s/picked_contigs.fa" % gid, "w") as f:
+            f.write(">%s_%s\n%s\n" % (gid, name, oriented))
+        return bool(gap_seq)
+
+    def pick_full_constructed_contigs(self, bwa_score, fa_list, sf_picked):
+        n = 0
+        for gid in fa_list:
+            if self._pick_one(gid, int(bwa_score)):
+                n += 1
+            for src, dst in (("picked_seqs.fa", sf_picked), ("picked_contigs.fa", sf_picked + "_ori.txt")):
+                p = self.working_folder + "velvet_temp/%s/%s" % (gid, src)
+                if os.path.exists(p):
+                    with open(dst, "a") as out, open(p) as f:   # the reference appends with `cat >>` (:564-572)
+                        out.write(f.read())
+        return n
+
+    def get_already_picked(self, sf_picked):
+        picked = {}
+        if os.path.exists(sf_picked):
+            with open(sf_picked) as f:
+                for line in f:
+                    if line[0] == ">":
+                        fl = line[1:].split("_")
+                        picked[fl[0] + "_" + fl[1]] = 1
+        return picked

@@ -56,6 +56,12 @@ CASES = {
         "libs": [(300, 30, 1700), (5000, 500, 500)],
         "min_gap": 100, "flank": 300, "L": 150,
     },
+    # not a golden case: error-free reads over short gaps, used by the end-to-end closure test (tests/test_gpu_pipeline.py)
+    "closable": {
+        "scaffolds": [("c0", 12000, [(3000, 120), (6000, 140), (9000, 110)]), ("c1", 9000, [(4000, 130)])],
+        "libs": [(300, 30, 2800)],
+        "min_gap": 100, "flank": 300, "L": 150, "no_err": True,
+    },
     "edge": {
         "scaffolds": [
             ("ctgA", 6000, [(3, 120), (2000, 100), (2250, 99), (2500, 300), (5890, 110)]),  # start<5; ==min; <min; trailing N-run
@@ -142,7 +148,9 @@ def make_case(name, seed):
                 for _ in range(2):
                     if rng.chance(3, 8):
                         j = rng.below(L)
-                        t[j] = "ACGT"[("ACGT".index(t[j]) + 1 + rng.below(3)) % 4]
+                        sub = "ACGT"[("ACGT".index(t[j]) + 1 + rng.below(3)) % 4]
+                        if not spec.get("no_err"):
+                            t[j] = sub
                 t = "".join(t)
                 seqs.append(revcomp(t) if rev else t)
             first_is_fwd = not rng.chance(1, 2)   # which mate number the forward read gets
@@ -198,4 +206,4 @@ def make_case(name, seed):
         libs.append({"is": IS, "sd": sd, "sam": "".join(r[3] for r in recs),
                      "fq1": "".join(fq1), "fq2": "".join(fq2)})
     return {"name": name, "seed": seed, "draft_fa": draft_fa, "fai": fai, "libs": libs,
-            "min_gap": spec["min_gap"], "flank": spec["flank"]}
+            "min_gap": spec["min_gap"], "flank": spec["flank"], "true_seqs": true_seqs}

@@ -38,7 +38,7 @@ def test_collect_reproduces_the_reference_tree(run):
             assert sorted(got[rel].splitlines()) == sorted(txt.splitlines()), rel
         checked += 1
     assert checked == len(case.expected) and checked > 40
-    extra = [k for k in got if k not in case.expected and not k.startswith("merged/velvet_temp/")]
+    extra = [k for k in got if k not in case.expected and not k.startswith("merged/velvet_temp/") and not k.startswith("picked_seqs.fa")]
     assert not extra, extra
 
 
@@ -89,3 +89,36 @@ def test_kmc_velvet_executables_follow_the_reference_command_lines(run, tmp_path
     sh(bind + "/velveth", t + "/vdir", "29", "-fastq", "-short", t + "/kmers.fq")
     sh(bind + "/velvetg", t + "/vdir", "-min_contig_lgth", "40")
     assert open(t + "/vdir/contigs.fa").read() == got["merged/velvet_temp/%s/contigs_31_29.fa" % gid]
+
+
+def test_short_gaps_are_closed_end_to_end(tmp_path):
+    """Preprocess -> Collect -> Assembly -> flank anchoring on error-free reads over 110-140 bp gaps: every gap is closed
+    and the picked sequence is the true sequence between the flanks (+ the one right-flank base the reference's slice keeps)."""
+    import sys as _s
+    _s.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from synth_text import make_case
+    from gappadder_amd import main as M
+
+    class C:      # shaped like golden_util.Case for pipeline_util.materialise
+        pass
+    raw = make_case("closable", 20260021)
+    c = C()
+    c.draft_fa, c.fai = raw["draft_fa"], raw["fai"]
+    c.libs = [{"sam": l["sam"], "fq1": l["fq1"], "fq2": l["fq2"], "is": l["is"], "sd": l["sd"]} for l in raw["libs"]]
+    c.meta = {"min_gap": raw["min_gap"], "flank": raw["flank"]}
+    cfgp, wf, _ = PU.materialise(c, str(tmp_path), kmers=((31, 29),))
+    for stage in ("Preprocess", "Collect", "Assembly"):
+        M.main(["-c", stage, "-g", cfgp])
+    picked = {}
+    for line in open(wf + "picked_seqs.fa").read().split(">")[1:]:
+        h, s = line.split("\n", 1)
+        picked["_".join(h.split("_")[:2])] = s.strip()
+    names = [l.split()[0] for l in raw["fai"].splitlines()]
+    gaps = [l.split() for l in open(wf + "gap_positions.txt")]
+    assert len(gaps) == 4 and len(picked) == 4
+    cnt = {}
+    for st, en, _, scf in gaps:
+        cnt[scf] = cnt.get(scf, 0) + 1
+        gid = "%d_%d" % (names.index(scf), cnt[scf])
+        truth = raw["true_seqs"][scf]
+        assert picked[gid] == truth[int(st) - 5:int(en) + 6], gid

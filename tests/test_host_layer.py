@@ -73,3 +73,20 @@ def test_gap_scan_quirks():
     s = "ACGTACGTAC" * 100
     for start in (3, 5, 299, 300, 301):
         assert flanks(s, start, start + 50, 300) == O.flank_seqs(s, start, start + 50, 300)
+
+
+def test_pick_gap_sequence_anchors_and_quirks():
+    from gappadder_amd.pick_contigs import pick_gap_sequence, revcomp
+    import numpy as np
+    rng = np.random.RandomState(3)
+    g = "".join("ACGT"[i] for i in rng.randint(0, 4, 1200))
+    left, gap, right = g[100:395], g[395:605], g[605:900]      # flanks exclude 5 bp next to the gap (gnrt_pos_true_seqs.py:94-99)
+    contig = g[50:950]
+    for c in (contig, revcomp(contig)):
+        name, seq, oriented = pick_gap_sequence([("short", g[380:500]), ("NODE_1", c)], left, right, 30)
+        assert name == "NODE_1" and oriented == contig
+        assert seq == gap + right[0]                             # the reference's slice keeps one base of the right flank
+    assert pick_gap_sequence([("a", g[50:600])], left, right, 30) is None          # right anchor missing
+    assert pick_gap_sequence([("a", contig)], left[:20], right, 30) is None        # flank shorter than the anchor
+    two = [("a", g[300:700]), ("b", g[300:395] + "ACGT" * 70 + g[605:700])]        # longest span wins (pick_contigs.py:300-321)
+    assert pick_gap_sequence(two, left, right, 30)[0] == "b"
