@@ -137,6 +137,19 @@ int gf_sync(gf_ctx* ctx) {
     return GF_OK;
 }
 
+int gf_stream_wait(gf_ctx* waiter, gf_ctx* producer) {
+    if (!waiter || !producer) return GF_E_INVAL;
+    if (waiter->device != producer->device) return GF_E_INVAL;
+    GF_HIP(waiter, hipSetDevice(waiter->device));
+    hipEvent_t ev;
+    GF_HIP(waiter, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, producer->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(waiter->stream, ev, 0);
+    (void)hipEventDestroy(ev);   // destruction is deferred until the event has completed
+    if (e != hipSuccess) return gf::set_hip_error(waiter, e, "gf_stream_wait");
+    return GF_OK;
+}
+
 int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!ctx || !name) return GF_E_INVAL;
     if (!strcmp(name, "max_gaps_per_kmer")) { ctx->max_gaps_per_kmer = value < 0 ? 0 : (uint32_t)value; return GF_OK; }

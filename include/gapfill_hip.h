@@ -89,6 +89,10 @@ const char* gf_strerror(int code);
 const char* gf_last_error(gf_ctx* ctx);       /* text of the last HIP error seen by this ctx */
 int gf_set_stream(gf_ctx* ctx, void* hip_stream); /* adopt a caller's hipStream_t (NULL: back to the ctx's own) */
 int gf_sync(gf_ctx* ctx);
+/* Two contexts on one device run their work on two streams (e.g. the k-mer screen on one, the alignment tagger on the
+ * other: they are independent until the pools are built).  gf_stream_wait makes everything enqueued on `waiter` after
+ * this call wait for everything enqueued on `producer` before it — no host synchronisation. */
+int gf_stream_wait(gf_ctx* waiter, gf_ctx* producer);
 /* options: "max_gaps_per_kmer" (0 = unlimited; flank k-mers shared by more gaps are dropped from the index),
  * "bitmap_log2" (size of the screen's 16-mer filter bitmap, 0 = automatic). */
 int gf_set_option(gf_ctx* ctx, const char* name, long value);

@@ -352,3 +352,22 @@ def test_one_pass_tagger_with_mapq0_compaction_equals_two_passes(gf):
     got_t = np.sort(np.frombuffer(d_t[:int(cnt[0]) * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT), order=["rec", "gap", "kind"])
     got_l = np.sort(np.frombuffer(d_l[:int(cnt[2]) * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT), order=["rec", "gap", "kind"])
     assert _same(got_t, thits) and _same(got_l, lhits) and len(lhits) > 0
+
+
+def test_c3_full_size_recruit_matches_oracle(gf):
+    """BASELINE.json configs[2] at full size (E. coli-scale: 1 scaffold of 4.6 Mb, 200 gaps x 1 kb, 5 M 150-bp reads, k=41):
+    every screen hit and every tagger hit of the GPU equals the oracle's."""
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    cfg = GapFill.synth_cfg(seed=20260003, scaffold_len=4_600_000, n_scaffolds=1, gaps_per_scaffold=200, gap_len=1000)
+    gaps, flanks = GapFill.synth_layout(cfg)
+    gf.set_gaps(gaps, 1, flanks)
+    n_pairs = 2_500_000
+    ocfg = np.frombuffer(cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
+    packed, recs = CO.synth_pairs(ocfg, 0, n_pairs)
+    hits = gf.screen_reads(packed, 150, 41, cap=1 << 21)
+    exp = CO.screen_reads(CO.unpack_reads(packed, 150), 150, flanks, 41)
+    assert _same(hits, exp) and len(exp) > 50_000
+    th = gf.tag_alignments(recs, 300, 30, cap=1 << 21)
+    assert _same(th, CO.tag_alignments(recs, gaps, 300, 30)) and len(th) > 20_000
