@@ -735,15 +735,15 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * (ctx->screen_wg_per_cu > 0 ? ctx->screen_wg_per_cu : 8));
     // LDS pre-filter variant: pays while the coarse bitmap is sparse enough to stop most probes before L2
     // (screen_variant 8 forces it, 9 forbids it)
-    const bool lds_ok = ix.d_bitmap_lds && ix.lds_fill <= 0.6 && ctx->screen_variant != 9;
-    if ((lds_ok && ctx->screen_variant == 0) || (ctx->screen_variant == 12 && ix.d_bitmap_lds)) {
+    const size_t w_bm_bytes = ix.d_bitmap_lds ? ((size_t)1 << ix.lds_log2) / 8 : 0;
+    const size_t w_slice_words = ((size_t)64 * rb + 16 + 15) / 16 * 4;
+    const size_t w_per_wave = (w_slice_words + WOBUF) * 4;
+    const size_t w_nw = std::min<size_t>(16, (160 * 1024 - 512 - w_bm_bytes) / w_per_wave);
+    // the wave kernel needs a handful of waves per CU next to the coarse bitmap (long reads leave too few: plain kernel then)
+    const bool lds_ok = ix.d_bitmap_lds && ix.lds_fill <= 0.6 && ctx->screen_variant != 9 && w_nw >= 6;
+    if ((lds_ok && ctx->screen_variant == 0) || (ctx->screen_variant == 12 && ix.d_bitmap_lds && w_nw >= 2)) {
         // wave-autonomous LDS pre-filter kernel: as many waves per CU as fit next to the coarse bitmap
-        const size_t bm_bytes = ((size_t)1 << ix.lds_log2) / 8;
-        const size_t slice_words = ((size_t)64 * rb + 16 + 15) / 16 * 4;
-        const size_t per_wave = (slice_words + WOBUF) * 4;
-        size_t nw = (160 * 1024 - 512 - bm_bytes) / per_wave;
-        nw = std::min<size_t>(16, nw);
-        if (nw < 4) return GF_E_UNSUPPORTED;
+        const size_t bm_bytes = w_bm_bytes, slice_words = w_slice_words, per_wave = w_per_wave, nw = w_nw;
         const size_t tiles2 = (n_reads + 63) / 64;
         void (*wk)(FilterParams, uint32_t) = screen_filter_wave_kernel<0>;
         switch ((rb + 15) / 16) {
@@ -804,7 +804,6 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.read_len = read_len;
     V.k = ix.k;
     V.nmw = (read_len + 31) / 32;
-    if (V.nmw > 8) return GF_E_UNSUPPORTED;
     V.cand = F.cand;
     V.n_cand = d_cnt;
     V.table = (const uint4*)ix.d_table;

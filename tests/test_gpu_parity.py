@@ -83,7 +83,7 @@ def test_screen_on_golden_reads(gf, case, k, min_hits):
 
 
 # ---------------------------------------------------------------------------------- seeded synthetic, larger
-@pytest.mark.parametrize("seed,n_pairs,L,k", [(1, 30000, 150, 31), (2, 20000, 150, 41), (3, 20000, 100, 31), (4, 8000, 250, 51)])
+@pytest.mark.parametrize("seed,n_pairs,L,k", [(1, 30000, 150, 31), (2, 20000, 150, 41), (3, 20000, 100, 31), (4, 8000, 250, 51), (5, 2500, 600, 31), (6, 1500, 1000, 64)])
 def test_screen_and_tagger_synthetic(gf, seed, n_pairs, L, k):
     from gappadder_amd.hip_api import GapFill
     c = S.small_case(seed=seed, n_pairs=n_pairs, L=L, insert=max(300, L + 100))
