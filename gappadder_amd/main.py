@@ -37,6 +37,7 @@ def parse_configuration(path):
     cfg["nthreads"] = int(p.get("nthreads", 15))
     cfg["wf"] = p.get("working_folder", "./GAPPadder_Output/")
     cfg["samtools"] = data.get("software_path", {}).get("samtools", "samtools")
+    cfg["kmer_screen"] = int(p.get("kmer_screen", 0))   # extension: flank-k-mer recruitment from the FASTQ files (0 = off)
     for path_, what in [(cfg["draft"], "draft genome")] + [(a[0], "bam") for a in cfg["alignments"]] + \
                        [(x, "raw reads") for pair in cfg["raw_reads"] for x in pair] + [(cfg["wf"], "working folder")]:
         if not os.path.exists(path_):
@@ -85,7 +86,11 @@ def main_func(command, sf_config):
             drc = DiscordantReadsCollector(sf_fai, bam, folder, cfg["nthreads"], gf, cfg["samtools"])
             drc.collect_discordant_regions_v2(folder + "discordant_reads_pos.txt")
             drc.dispath_collect_jobs()
-            drc.merge_dispatch_reads_for_gaps_v2(left, right)
+            extra = None
+            if cfg["kmer_screen"]:
+                from .kmer_recruit import screen_fastq_pair
+                extra = screen_fastq_pair(gf, sf_fai, sf_gap_pos, wf, left, right, cfg["kmer_screen"])
+            drc.merge_dispatch_reads_for_gaps_v2(left, right, extra)
             drc.dispatch_high_quality_reads_for_gaps(left, right)
         rm = ReadsMerger()
         for name in ("gap_reads", "gap_reads_alignment", "gap_reads_high_quality"):

@@ -110,25 +110,32 @@ class DiscordantReadsCollector:
             with open("%s%s/%s.fastq" % (self.working_folder, folder, key), "a") as f:
                 f.write("".join(recs))
 
-    def _join(self, sf_raw_left, sf_raw_right, folder, high_quality):
+    def _join(self, sf_raw_left, sf_raw_right, folder, high_quality, extra=None):
         names = sam_io.read_fai(self.sf_fai)
         d = self.working_folder + folder
         os.makedirs(d, exist_ok=True)
         for fn in os.listdir(d):          # the reference wipes the folder with rsync --delete (:199)
             os.remove(os.path.join(d, fn))
         left = self._read_gap_map(names, "left", high_quality)
+        if extra and not high_quality:
+            for rid, ks in extra[0].items():
+                left.setdefault(rid, {}).update((kk, 1) for kk in ks)
         if not high_quality:
             with open(self.working_folder + "left_reads.list", "w") as f:
                 f.write("".join("%s %s\n" % (g, r) for r, gs in left.items() for g in gs))
         self._dispatch(sf_raw_left, left, "_1", folder)
         right = self._read_gap_map(names, "right", high_quality)
+        if extra and not high_quality:
+            for rid, ks in extra[1].items():
+                right.setdefault(rid, {}).update((kk, 1) for kk in ks)
         if not high_quality:
             with open(self.working_folder + "right_reads.list", "w") as f:
                 f.write("".join("%s %s\n" % (g, r) for r, gs in right.items() for g in gs))
         self._dispatch(sf_raw_right, right, "_2", folder)
 
-    def merge_dispatch_reads_for_gaps_v2(self, sf_raw_left, sf_raw_right):
-        self._join(sf_raw_left, sf_raw_right, "gap_reads", False)
+    def merge_dispatch_reads_for_gaps_v2(self, sf_raw_left, sf_raw_right, extra=None):
+        """extra: optional ({readId: set(gapKey)}, same for the right file) from the flank-k-mer screen (kmer_recruit.py)."""
+        self._join(sf_raw_left, sf_raw_right, "gap_reads", False, extra)
 
     def dispatch_high_quality_reads_for_gaps(self, sf_raw_left, sf_raw_right):
         self._join(sf_raw_left, sf_raw_right, "gap_reads_high_quality", True)

@@ -14,7 +14,7 @@ if sys.argv[1] == "view":
 '''
 
 
-def materialise(case, root, kmers=((31, 29),)):
+def materialise(case, root, kmers=((31, 29),), kmer_screen=0):
     data, wf = os.path.join(root, "data"), os.path.join(root, "wf")
     os.makedirs(data)
     os.makedirs(wf)
@@ -41,7 +41,7 @@ def materialise(case, root, kmers=((31, 29),)):
            "alignments": [{"bam": b, "is": str(i), "std": str(s)} for (b, _, _, i, s) in libs],
            "software_path": {"bwa": "bwa", "samtools": st, "velvet": "/x/", "kmc": "/x/", "TERefiner": "x", "ContigsMerger": "x"},
            "parameters": {"working_folder": wf, "min_gap_size": str(case.meta["min_gap"]), "flank_length": str(case.meta["flank"]),
-                          "nthreads": "2", "verbose": "0"},
+                          "nthreads": "2", "verbose": "0", "kmer_screen": kmer_screen},
            "kmer_length": [{"k": k, "k_velvet": [{"k": kv} for kv in kvs]} for k, kvs in by_k.items()]}
     cfgp = os.path.join(root, "cfg.json")
     json.dump(cfg, open(cfgp, "w"))

@@ -122,3 +122,38 @@ def test_short_gaps_are_closed_end_to_end(tmp_path):
         gid = "%d_%d" % (names.index(scf), cnt[scf])
         truth = raw["true_seqs"][scf]
         assert picked[gid] == truth[int(st) - 5:int(en) + 6], gid
+
+
+def test_kmer_screen_mode_adds_the_flank_matching_pairs(tmp_path):
+    """`"kmer_screen": 31` in the config: gap_reads/{id}.fastq = the reference's alignment-recruited reads UNION the reads (and
+    mates) whose canonical 31-mers hit the gap's flanks — checked against the oracle's screen of the same FASTQ files."""
+    from gappadder_amd import main as M
+    from oracle import gp_oracle as O
+    case = Case("twolib")
+    cfgp, wf, _ = PU.materialise(case, str(tmp_path), kmer_screen=31)
+    for stage in ("Preprocess", "Collect"):
+        M.main(["-c", stage, "-g", cfgp])
+    got = PU.tree(wf)
+    gaps = O.gap_positions(case.fasta_records(), case.meta["min_gap"])
+    ids = O.gap_ids(case.fai_names, gaps)
+    seqs = dict(case.fasta_records())
+    flanks = [O.flank_seqs(seqs[scf], s, e, case.meta["flank"]) for (s, e, _, scf) in gaps]
+    lib = case.libs[0]
+    recs = {1: list(O.fastq_records(lib["fq1"])), 2: list(O.fastq_records(lib["fq2"]))}
+    L = len(recs[1][0][1])
+    want = {gid: set() for gid in ids}
+    for m in (1, 2):
+        blob = "".join(r[1] for r in recs[m]).encode()
+        for h in CO.screen_reads(blob, L, flanks, 31):
+            rid = O.fastq_read_id(recs[m][int(h["read"])][0])
+            want[ids[int(h["gap"])]].update({rid + "_1", rid + "_2"})
+    n_new = 0
+    for gid in ids:
+        ref = case.expected.get("1_is300/gap_reads/%s.fastq" % gid, "")
+        ref_ids = {l[1:] for i, l in enumerate(ref.splitlines()) if i % 4 == 0}
+        mine = got.get("1_is300/gap_reads/%s.fastq" % gid, "")
+        mine_ids = [l[1:] for i, l in enumerate(mine.splitlines()) if i % 4 == 0]
+        assert set(mine_ids) == ref_ids | want[gid], gid
+        assert len(mine_ids) == len(set(mine_ids))
+        n_new += len(set(mine_ids) - ref_ids)
+    assert n_new > 50
