@@ -38,7 +38,7 @@ struct TagParams {
 // "dequeue"/"fanin" rows), so they are first collected in a per-workgroup LDS buffer: wave ballot + prefix count,
 // one LDS atomic per wave, and ONE global atomic per workgroup when the kernel ends.  A full buffer falls back to
 // direct global appends (correct, just slower).
-constexpr uint32_t HITBUF = 1024;
+constexpr uint32_t HITBUF = 512;
 
 struct HitBuf {
     gf_taghit h[HITBUF];
@@ -80,7 +80,7 @@ __device__ __forceinline__ void flush_hits(HitBuf& hb, gf_taghit* out, uint32_t 
 // Records are streamed as whole 1-KiB wave loads (16 B per lane, consecutive lanes = consecutive 16-B halves):
 // the even lane of a pair holds {pos, mate_pos, tlen, ref}, the odd lane {mate_ref, flag|mapq|clip, read id}.
 // Even lanes run the coarse bin test; the rare survivors pull their second half from the neighbour lane.
-constexpr int TAG_UNROLL = 4;  // 4 KiB (128 records) in flight per wave
+constexpr int TAG_UNROLL = 8;  // 8 KiB (256 records) per wave and stage, two stages in flight
 
 __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
     extern __shared__ uint32_t bins[];  // the whole bin map (<= 16 KiB), staged once per workgroup
@@ -106,13 +106,21 @@ __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
     const uint64_t n_half = 2 * P.n;                       // 16-byte halves
     const uint64_t chunk = 64ull * TAG_UNROLL;             // halves per wave iteration
     const uint4* src = reinterpret_cast<const uint4*>(P.recs);
-    for (uint64_t h0 = wave * chunk; h0 < n_half; h0 += n_waves * chunk) {
-        uint4 v[TAG_UNROLL];
+    // software pipeline: the next chunk's loads are issued before the current chunk is processed
+    uint4 vn[TAG_UNROLL];
+    auto fetch = [&](uint64_t h0) {
 #pragma unroll
         for (int u = 0; u < TAG_UNROLL; ++u) {
             const uint64_t h = h0 + 64ull * u + lane;
-            v[u] = h < n_half ? src[h] : make_uint4(0, 0, 0, 0xFFFFFFFFu);
+            vn[u] = h < n_half ? src[h] : make_uint4(0, 0, 0, 0xFFFFFFFFu);
         }
+    };
+    fetch(wave * chunk);
+    for (uint64_t h0 = wave * chunk; h0 < n_half; h0 += n_waves * chunk) {
+        uint4 v[TAG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TAG_UNROLL; ++u) v[u] = vn[u];
+        fetch(h0 + n_waves * chunk);
 #pragma unroll
         for (int u = 0; u < TAG_UNROLL; ++u) {
             const uint64_t h = h0 + 64ull * u + lane;
@@ -322,7 +330,7 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
     for (uint64_t v : span) total += v;
     int shift = 6;
     auto nbits = [&](int sh) { uint64_t t = 0; for (uint64_t v : span) t += (v >> sh) + (v ? 1 : 0); return t; };
-    while (nbits(shift) > (1u << 17)) ++shift;  // <= 16 KiB of LDS: keeps 8 workgroups per CU
+    while (nbits(shift) > (1u << 17)) ++shift;  // <= 16 KiB of LDS (measured: an 8 KiB map sends more records down the slow path and loses)
     std::vector<uint32_t> off(ctx->n_scaffolds + 1, 0);
     for (uint32_t s = 0; s < ctx->n_scaffolds; ++s) off[s + 1] = off[s] + (uint32_t)((span[s] >> shift) + (span[s] ? 1 : 0));
     const uint32_t words = (off[ctx->n_scaffolds] + 31) / 32 + 1;
