@@ -371,3 +371,20 @@ def test_c3_full_size_recruit_matches_oracle(gf):
     assert _same(hits, exp) and len(exp) > 50_000
     th = gf.tag_alignments(recs, 300, 30, cap=1 << 21)
     assert _same(th, CO.tag_alignments(recs, gaps, 300, 30)) and len(th) > 20_000
+
+
+def test_reads_matching_many_gaps_take_the_large_list_pass(gf):
+    """Six gaps share one flank: a read inside it matches > 256 (position, gap) pairs, overflows the per-wave list of the
+    first verify pass and is re-verified by the large-list pass; min_hits counts positions per gap."""
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=61, n_pairs=4000)
+    flanks = [(c["flanks"][0][0], f[1]) for f in c["flanks"][:6]] + list(c["flanks"][6:])
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], flanks)
+    packed, _ = GapFill.pack_reads(c["reads_blob"], c["L"])
+    for mh in (1, 50, 121):
+        hits = gf.screen_reads(packed, c["L"], 31, mh)
+        exp = CO.screen_reads(c["reads_blob"], c["L"], flanks, 31, mh)
+        assert _same(hits, exp), mh
+    full = CO.screen_reads(c["reads_blob"], c["L"], flanks, 31, 1)
+    per_read = np.bincount(full["read"])
+    assert per_read.max() >= 6          # some read is recruited by all six gaps (>= 6 x 100 matches in the verify list)
