@@ -220,7 +220,7 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
     kmerutils_kat()
-    for name, seed in (("twolib", 20260001), ("edge", 20260011)):
+    for name, seed in (("twolib", 20260001), ("edge", 20260011), ("bounds", 20260031)):
         case = make_case(name, seed)
         d = os.path.join(HERE, name)
         if os.path.isdir(d):

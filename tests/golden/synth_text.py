@@ -56,6 +56,14 @@ CASES = {
         "libs": [(300, 30, 1700), (5000, 500, 500)],
         "min_gap": 100, "flank": 300, "L": 150,
     },
+    # IS exactly at the 750 mode switch (collect_reads_for_gaps.py:275) and one below; |TLEN| crafted at dist1/dist2 +- 1;
+    # non-default min_gap_size / flank_length
+    "bounds": {
+        "scaffolds": [("s1", 15000, [(2500, 60), (2600, 49), (7000, 900)]), ("s2", 10000, [(5000, 300)])],
+        "libs": [(750, 20, 900), (749, 20, 700)],
+        "min_gap": 50, "flank": 150, "L": 120,
+        "craft_inserts": [808, 809, 810, 811, 688, 689, 690, 691, 121, 2000],
+    },
     # not a golden case: error-free reads over short gaps, used by the end-to-end closure test (tests/test_gpu_pipeline.py)
     "closable": {
         "scaffolds": [("c0", 12000, [(3000, 120), (6000, 140), (9000, 110)]), ("c1", 9000, [(4000, 130)])],
@@ -131,10 +139,13 @@ def make_case(name, seed):
             sname = names[rng.below(len(names))]
             ins = max(L + 1, rng.gauss_int(IS, sd))
             kind = rng.below(100)
+            crafted = spec.get("craft_inserts")
             if kind < 3:
                 ins = ins * 3          # too long  (>= dist2)
             elif kind < 6:
                 ins = L + 10 + rng.below(40)   # too short (<= dist1 in the short-IS branch)
+            if crafted and p < 40 * len(crafted):
+                ins, kind = crafted[p % len(crafted)], 50      # an ordinary same-scaffold pair with an exact insert
             ins = min(ins, lens[sname] - 1)
             s1 = rng.below(lens[sname] - ins)
             s2 = s1 + ins - L

@@ -56,4 +56,4 @@ class Case:
         return {k[len(prefix):]: v for k, v in self.expected.items() if k.startswith(prefix)}
 
 
-CASES = ["twolib", "edge"]
+CASES = ["twolib", "edge", "bounds"]
