@@ -102,7 +102,7 @@ def main():
     d_low = torch.empty(low_cap * 12, dtype=torch.uint8, device=dev)
     key_cap = 4 * hit_cap
     d_keys = torch.empty(key_cap, dtype=torch.int64, device=dev)
-    pool_cap = 2 * hit_cap
+    pool_cap = max(1 << 20, n_reads // 32)    # pooled reads (also sizes the assembly workspace: ~6.5 KB per pooled read)
     d_pool = torch.empty(pool_cap * rb + 64, dtype=torch.uint8, device=dev)
     d_pool_off = torch.zeros(len(gaps) + 1, dtype=torch.int64, device=dev)
     d_pool_ids = torch.empty(pool_cap, dtype=torch.int32, device=dev)
