@@ -87,14 +87,35 @@ __device__ __forceinline__ uint32_t pv_stream32(const PoolView& V, uint64_t bit)
 }
 
 // left-aligned `len`-mer at instance id (read * L + off)
+// W = false: the launch has k <= 32, so every key is one 64-bit word (lo == 0) and the 128-bit halves compile away
+template <bool W>
 __device__ __forceinline__ K128 pv_kmer(const PoolView& V, uint32_t inst, int len) {
     const uint32_t r = inst / V.L, off = inst - r * V.L;
     const uint64_t bit = (uint64_t)r * V.rb * 8 + 2ull * off;
     K128 v;
     v.hi = ((uint64_t)pv_stream32(V, bit) << 32) | pv_stream32(V, bit + 32);
     v.lo = 0;
+    if (!W) {
+        v.hi &= ~0ull << (64 - 2 * len);
+        return v;
+    }
     if (len > 32) v.lo = ((uint64_t)pv_stream32(V, bit + 64) << 32) | pv_stream32(V, bit + 96);
     return mask_k(v, len);
+}
+template <bool W>
+__device__ __forceinline__ K128 revcomp_w(K128 v, int len) {
+    if (W) return revcomp(v, len);
+    K128 r;
+    r.hi = revpairs64(~v.hi) << (64 - 2 * len);
+    r.lo = 0;
+    return r;
+}
+template <bool W>
+__device__ __forceinline__ K128 canonical_w(K128 f, int len) {
+    if (W) return canonical(f, len);
+    K128 r = revcomp_w<false>(f, len);
+    r.hi = r.hi < f.hi ? r.hi : f.hi;
+    return r;
 }
 
 __device__ __forceinline__ uint32_t slot_of(K128 key, uint32_t cap) {
@@ -153,6 +174,7 @@ struct Arr {
 // Find-or-insert the canonical `len`-mer `key` (instance `inst`) and add `inc` to the slot's high word, with ONE 64-bit
 // CAS when the slot is free (id and first count land together) or one 64-bit add when the key is already there.
 // Returns the slot, EMPTY32 when the table is full.
+template <bool W>
 __device__ __forceinline__ uint32_t table_upsert(const Tab& t, const PoolView& V, K128 key, uint32_t inst, int len, uint32_t inc,
                                                  bool* fresh) {
     uint32_t s = slot_of(key, t.cap);
@@ -164,7 +186,7 @@ __device__ __forceinline__ uint32_t table_upsert(const Tab& t, const PoolView& V
             if (v == EMPTY64) { *fresh = true; return s; }
         }
         const uint32_t cur = (uint32_t)v;
-        if (cur == inst || canonical(pv_kmer(V, cur, len), len) == key) {
+        if (cur == inst || canonical_w<W>(pv_kmer<W>(V, cur, len), len) == key) {
             t.add(s, (unsigned long long)inc << 32);
             return s;
         }
@@ -218,6 +240,7 @@ __device__ __forceinline__ void wg_phase_sync() {
 //   count phase   R = k-mer table (8-B slots) when the distinct k-mers keep it under 3/4 full, else the global slice
 //   graph phase   R = node table (2 slots per possible node) + inst_of/meta/succ0/succ1 arrays, else global
 // Every pointer below is generic (LDS or global); the code path is the same.
+template <bool W>
 __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
     __shared__ uint32_t s_cnt[8];  // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes [6] LDS table overflow
     __shared__ unsigned long long s_seq[2];  // [0] bases to emit  [1] global base offset
@@ -303,9 +326,9 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     if (bad) continue;
                 }
                 const uint32_t inst = r * P.read_len + p;
-                const K128 key = canonical(pv_kmer(V, inst, k), k);
+                const K128 key = canonical_w<W>(pv_kmer<W>(V, inst, k), k);
                 bool fresh;
-                const uint32_t s = table_upsert(tab, V, key, inst, k, 1u, &fresh);
+                const uint32_t s = table_upsert<W>(tab, V, key, inst, k, 1u, &fresh);
                 if (s == EMPTY32) { if (use_lds) s_cnt[6] = 1; else s_cnt[3] = 1; continue; }
                 if (fresh) {
                     const uint32_t q = atomicAdd(&s_cnt[4], 1u);
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
                     list_b[o] = id;
                     if (P.cnt_keys && o < P.cnt_cap) {
-                        const K128 key = canonical(pv_kmer(V, id, k), k);
+                        const K128 key = canonical_w<W>(pv_kmer<W>(V, id, k), k);
                         P.cnt_keys[2 * (uint64_t)o] = key.hi;
                         P.cnt_keys[2 * (uint64_t)o + 1] = key.lo;
                         P.cnt_counts[o] = c > 10000000u ? 10000000u : c;  // kmc -cs10000000 (assemble_gaps.py:96)
@@ -388,10 +411,10 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             for (uint32_t j = tid; j < n_surv; j += ASM_THREADS) {
                 if (graph_lds && s_cnt[6]) break;
                 const uint32_t inst = list_b[j];
-                const K128 tf = pv_kmer(V, inst, k);
+                const K128 tf = pv_kmer<W>(V, inst, k);
                 K128 t = tf;
                 {   // use the canonical k-mer string (what kmc_dump lists); either strand yields the same graph
-                    const K128 rc = revcomp(t, k);
+                    const K128 rc = revcomp_w<W>(t, k);
                     if (rc < t) t = rc;
                 }
                 const bool fwd = tf == t;
@@ -404,12 +427,12 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         a.lo = sh ? (t.lo << sh) : t.lo;
                         a = mask_k(a, kv);
                     }
-                    const K128 rc = revcomp(a, kv);
+                    const K128 rc = revcomp_w<W>(a, kv);
                     const uint32_t d = rc < a ? 1u : 0u;
                     const K128 A = d ? rc : a;
                     const uint32_t ninst = fwd ? inst + o : inst + (per - 1 - o);  // same read, shifted offset
                     bool fresh;
-                    const uint32_t sl = table_upsert(ntab, V, A, ninst, kv, 1u << M_MULT_SHIFT, &fresh);
+                    const uint32_t sl = table_upsert<W>(ntab, V, A, ninst, kv, 1u << M_MULT_SHIFT, &fresh);
                     if (sl == EMPTY32) { if (graph_lds) s_cnt[6] = 1; else s_cnt[3] = 1; break; }
                     if (fresh) {
                         const uint32_t q = atomicAdd(&s_cnt[5], 1u);
@@ -458,20 +481,20 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         //      an oriented node that no internal edge enters is a unitig START.
         for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
             const uint32_t meta = nmeta.get(ni) & 0xFFu;   // adjacency bits are final after P3
-            const K128 x = canonical(pv_kmer(V, inst_of.get(ni), kv), kv);
+            const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(ni), kv), kv);
             for (uint32_t d = 0; d < 2; ++d) {
                 const uint32_t ob = out_bits(meta, d);
                 if (__popc(ob) != 1) continue;
-                const K128 cur = d ? revcomp(x, kv) : x;
+                const K128 cur = d ? revcomp_w<W>(x, kv) : x;
                 const K128 y = shift_in(cur, __ffs(ob) - 1, kv);
-                const K128 yr = revcomp(y, kv);
+                const K128 yr = revcomp_w<W>(y, kv);
                 const uint32_t dy = yr < y ? 1u : 0u;
                 const K128 Y = dy ? yr : y;
                 uint32_t sl = slot_of(Y, ntab.cap), yi = EMPTY32;   // slot.id is a node index now
                 for (uint32_t probes = 0; probes < ntab.cap; ++probes) {
                     const uint32_t cand = ntab.id(sl);
                     if (cand == EMPTY32) break;
-                    if (cand < n_nodes && canonical(pv_kmer(V, inst_of.get(cand), kv), kv) == Y) { yi = cand; break; }
+                    if (cand < n_nodes && canonical_w<W>(pv_kmer<W>(V, inst_of.get(cand), kv), kv) == Y) { yi = cand; break; }
                     sl = sl + 1 == ntab.cap ? 0 : sl + 1;
                 }
                 if (yi == EMPTY32) continue;
@@ -541,10 +564,10 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const uint32_t tail = g_lds[Toff + 2 * o], len = g_lds[Toff + 2 * o + 1];
                 uint32_t q = EMPTY32;
                 if (len + P.kv - 1 >= P.min_contig) {
-                    const K128 x = canonical(pv_kmer(V, inst_of.get(o >> 1), kv), kv);
-                    const K128 first = (o & 1) ? revcomp(x, kv) : x;
-                    const K128 e = canonical(pv_kmer(V, inst_of.get(tail >> 1), kv), kv);
-                    const K128 opp = (tail & 1) ? e : revcomp(e, kv);
+                    const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(o >> 1), kv), kv);
+                    const K128 first = (o & 1) ? revcomp_w<W>(x, kv) : x;
+                    const K128 e = canonical_w<W>(pv_kmer<W>(V, inst_of.get(tail >> 1), kv), kv);
+                    const K128 opp = (tail & 1) ? e : revcomp_w<W>(e, kv);
                     if (!(opp < first)) {
                         q = atomicAdd(&s_cnt[1], 1u);
                         if (q >= rec_cap / 2 || q >= cacc_cap) { s_cnt[3] = 1; q = EMPTY32; }
@@ -586,8 +609,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const uint32_t len = rec[4 * q + 1] + P.kv - 1;
                 atomicAdd(&cacc[q], nmeta.get(o >> 1) >> M_MULT_SHIFT);
                 if (off + len > P.seq_cap) continue;
-                const K128 x = canonical(pv_kmer(V, inst_of.get(o >> 1), kv), kv);
-                const K128 ok = (o & 1) ? revcomp(x, kv) : x;
+                const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(o >> 1), kv), kv);
+                const K128 ok = (o & 1) ? revcomp_w<W>(x, kv) : x;
                 if (rank == 0) {
                     for (int bq = 0; bq < kv; ++bq) P.seq[off + bq] = "ACGT"[kbase(ok, bq)];
                 } else {
@@ -620,10 +643,10 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         ++nodes;
                     }
                     if (nodes + P.kv - 1 < P.min_contig) continue;
-                    const K128 x = canonical(pv_kmer(V, inst_of.get(ni), kv), kv);
-                    const K128 first = d ? revcomp(x, kv) : x;
-                    const K128 e = canonical(pv_kmer(V, inst_of.get(cur >> 1), kv), kv);
-                    const K128 opp = (cur & 1) ? e : revcomp(e, kv);  // first kv-mer of the opposite walk = revcomp(last kv-mer)
+                    const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(ni), kv), kv);
+                    const K128 first = d ? revcomp_w<W>(x, kv) : x;
+                    const K128 e = canonical_w<W>(pv_kmer<W>(V, inst_of.get(cur >> 1), kv), kv);
+                    const K128 opp = (cur & 1) ? e : revcomp_w<W>(e, kv);  // first kv-mer of the opposite walk = revcomp_w<W>(last kv-mer)
                     if (opp < first) continue;
                     const uint32_t q = atomicAdd(&s_cnt[1], 1u);
                     if (q >= rec_cap) { s_cnt[3] = 1; continue; }
@@ -648,8 +671,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const uint32_t st = rec[2 * q], nodes = rec[2 * q + 1];
                 const uint32_t len = nodes + P.kv - 1;
                 const unsigned long long off = s_seq[1] + atomicAdd(&s_seq[0], (unsigned long long)len);
-                const K128 x = canonical(pv_kmer(V, inst_of.get(st >> 1), kv), kv);
-                const K128 firstk = (st & 1) ? revcomp(x, kv) : x;
+                const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(st >> 1), kv), kv);
+                const K128 firstk = (st & 1) ? revcomp_w<W>(x, kv) : x;
                 const bool room = off + len <= P.seq_cap;
                 if (room)
                     for (int b = 0; b < kv; ++b) P.seq[off + b] = "ACGT"[kbase(firstk, b)];
@@ -762,7 +785,7 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     const unsigned grid = (unsigned)std::min<size_t>(n_pools, (size_t)ctx->n_cu);
     {
         LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
-        hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(ASM_THREADS), (size_t)P.lds_words * 4, ctx->stream, P);
+        hipLaunchKernelGGL(k <= 32 ? assemble_kernel<false> : assemble_kernel<true>, dim3(grid), dim3(ASM_THREADS), (size_t)P.lds_words * 4, ctx->stream, P);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
