@@ -133,12 +133,13 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
     // level 2 set
     ix.s_log2 = std::max(8, ceil_log2(2 * s16.size() + 2));
     const size_t scap = (size_t)1 << ix.s_log2;
-    std::vector<uint32_t> sset(scap, EMPTY32);
+    std::vector<uint32_t> sset(scap + 4, EMPTY32);
     for (uint32_t key : s16) {
         uint32_t s = hash_s16_set(key, ix.s_log2);
         while (sset[s] != EMPTY32) s = (s + 1) & (scap - 1);
         sset[s] = key;
     }
+    for (int i = 0; i < 4; ++i) sset[scap + i] = sset[i];   // wrap-around copy: a 4-slot read never needs the modulo
     // level 1 bitmap: ~32 bits per key keeps the per-probe false-positive rate near 3 %
     // level 1 bitmap: 16-32 bits per key (3-6 % false positives per probe, resolved by level 2); measured on
     // MI355X a 2 MiB bitmap (2^24 bits) that stays in every XCD's L2 beats a sparser 4 MiB one
@@ -169,10 +170,10 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
     GF_HIP(ctx, hipMalloc((void**)&ix.d_bitmap_lds, cwords * 4));
     GF_HIP(ctx, hipMemcpy(ix.d_bitmap_lds, cbm.data(), cwords * 4, hipMemcpyHostToDevice));
     GF_HIP(ctx, hipMalloc((void**)&ix.d_bitmap, bwords * 4));
-    GF_HIP(ctx, hipMalloc((void**)&ix.d_sset, scap * 4));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_sset, (scap + 4) * 4));
     GF_HIP(ctx, hipMalloc(&ix.d_table, tab.size() * 4));
     GF_HIP(ctx, hipMemcpy(ix.d_bitmap, bm.data(), bwords * 4, hipMemcpyHostToDevice));
-    GF_HIP(ctx, hipMemcpy(ix.d_sset, sset.data(), scap * 4, hipMemcpyHostToDevice));
+    GF_HIP(ctx, hipMemcpy(ix.d_sset, sset.data(), (scap + 4) * 4, hipMemcpyHostToDevice));
     GF_HIP(ctx, hipMemcpy(ix.d_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     auto ins = ctx->index.emplace(k, ix);
     *out = &ins.first->second;

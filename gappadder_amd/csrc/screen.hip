@@ -300,7 +300,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int NCH>
+template <int NCH, int FU>
 __global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P, uint32_t slice_words) {
     extern __shared__ uint32_t sm[];  // [coarse bitmap][per wave: 64 reads + pad | WOBUF candidate ids]
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthr = blockDim.x, nw = nthr >> 6;
@@ -366,6 +366,30 @@ __global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P
             for (uint32_t g0 = 0; g0 < P.np && !cand; g0 += 32) {
                 const uint32_t g1 = g0 + 32 < P.np ? g0 + 32 : P.np;
                 uint32_t m1 = 0;   // probes that pass the LDS bitmap; three probes' LDS reads in flight at a time
+                if (FU > 0) {
+                    // fused: a probe that passes the coarse LDS bitmap issues its L2 bitmap load at once, while its hash is
+                    // live, instead of being re-derived in a second (divergent) loop; FU probes in flight per lane
+                    constexpr int U = FU > 0 ? FU : 1;
+                    for (uint32_t j0 = g0; j0 < g1; j0 += U) {
+                        uint32_t h[U], bw[U], word[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t j = j0 + u < g1 ? j0 + u : g1 - 1;
+                            const uint32_t w32 = bytes_ok ? stream32_bytes(tile, (bit0 + j * P.stride2) >> 3) : stream32(tile, bit0 + j * P.stride2);
+                            h[u] = hash_s16_bitmap(canon16(w32), P.bm_log2);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) bw[u] = sm[h[u] >> (coarse_shift + 5)];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const bool pass = ((bw[u] >> ((h[u] >> coarse_shift) & 31)) & 1u) && j0 + u < g1;
+                            word[u] = pass ? 0xFFFFFFFFu : 0u;
+                            if (pass && !same) word[u] = P.bitmap[h[u] >> 5];
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) m1 |= ((word[u] >> (h[u] & 31)) & 1u) << (j0 + u - g0);
+                    }
+                } else
                 for (uint32_t j0 = g0; j0 < g1; j0 += 3) {
                     uint32_t w32[3], c[3], bw[3];
 #pragma unroll
@@ -383,7 +407,7 @@ __global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P
                         if (j0 + u < g1) m1 |= ((bw[u] >> (c[u] & 31)) & 1u) << (j0 + u - g0);
                 }
                 uint32_t mask = m1;
-                if (!same && m1) {
+                if (FU == 0 && !same && m1) {
                     mask = 0;
                     uint32_t m = m1;
                     while (m) {   // up to 5 L2 probes in flight
@@ -463,6 +487,272 @@ __global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P
         process(pfC, t);
         t += tstride;
     }
+    if (obuf_n) {
+        uint32_t gb = 0;
+        if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
+        gb = __shfl(gb, 0);
+        for (uint32_t i = lane; i < obuf_n; i += 64) P.cand[gb + i] = obuf[i];
+    }
+}
+
+// ---- software-pipelined wave kernel ---------------------------------------------------------------------------------
+// The two-loop wave kernel above pays two dependent L2 round trips per 64-read tile (level-1 bitmap word, then the exact
+// set), ~2.5 us a tile and wave whatever the probe count; with 11 waves per CU that chain, not bandwidth, set its floor
+// (measured: 0.31 ms with no probes, 0.73 ms with one).  Here each wave keeps THREE tiles in flight in registers:
+//   stage A (tile t)    stage the tile in LDS, scramble its NP 16-mers, test the coarse LDS bitmap, ISSUE the level-1 loads
+//   stage B (tile t-1)  level-1 words have arrived: pick the (up to two) passing probes, ISSUE their exact-set loads
+//   stage C (tile t-2)  exact-set slots have arrived: candidate or not, append
+// so no iteration waits for a load issued in the same iteration.  A probe is carried as its scrambled key p = key * M
+// (bijective): every bitmap index is a shift of p, and key = p * M^-1 when the exact set is consulted.  The exact set is
+// read four consecutive slots at a time (linear probing, table padded by three wrap-around slots), which settles almost
+// every lookup in one request; the leftovers (3rd+ passing probe of a lane, a run of four foreign keys) take a serial path.
+constexpr uint32_t S16_MUL = 0x9E3779B1u;   // multiplier of hash_s16_bitmap
+constexpr uint32_t mul_inverse_u32(uint32_t a) {
+    uint32_t x = a;   // Newton: x <- x (2 - a x) doubles the correct low bits
+    for (int i = 0; i < 6; ++i) x *= 2u - a * x;
+    return x;
+}
+constexpr uint32_t S16_MUL_INV = mul_inverse_u32(S16_MUL);
+static_assert(S16_MUL * S16_MUL_INV == 1u, "inverse of the level-1 multiplier");
+
+struct __attribute__((packed, aligned(4))) Slots4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ bool sset_walk(const FilterParams& P, uint32_t key, uint32_t sl) {
+    const uint32_t smask = (1u << P.s_log2) - 1;
+    for (;;) {
+        const uint32_t v = P.sset[sl & smask];
+        if (v == key) return true;
+        if (v == EMPTY32) return false;
+        ++sl;
+    }
+}
+
+// Loads of the pipelined kernel are issued through inline asm and awaited with explicit s_waitcnt: the compiler's own
+// counter bookkeeping falls back to vmcnt(0) for loop-carried loads, which would drain the pipeline every step.  vmcnt
+// counts vector-memory operations in issue order, so "wait until at most N are outstanding" is safe whenever at least N
+// operations were issued after the awaited one; every step therefore issues the same number of loads (idle slots read a
+// dummy address), and anything the compiler issues on its own only makes a wait longer, never shorter.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// global loads with a scalar base and a 32-bit per-lane byte offset
+__device__ __forceinline__ void vm_load128(u32x4& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void vm_load32(uint32_t& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase));
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// after a wait: uses of x are ordered behind it
+__device__ __forceinline__ void vm_ready(uint32_t& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void vm_ready(u32x4& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));   // the builtin returns int
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    return (const void*)(((uint64_t)hi << 32) | lo);
+}
+
+template <int NP>
+struct PipeW {   // stage A -> B: scrambled keys, level-1 words, coarse-pass bits of one tile
+    uint32_t p[NP], w[NP], pm;
+    uint32_t t;  // tile index, PIPE_NONE when empty (tiles < 2^26 since reads < 2^32)
+};
+struct PipeS {   // stage B -> C: the (up to two) exact-set lookups of one tile
+    uint32_t key0, key1;
+    u32x4 v0, v1;
+    uint32_t fl;  // bit 0/1: lookup 0/1 in use, bit 2: already a candidate (slow path)
+    uint32_t t;
+};
+constexpr uint32_t PIPE_NONE = 0xFFFFFFFFu;
+
+template <int NCH, int NP>
+__global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P, uint32_t slice_words) {
+    static_assert(NCH >= 1, "whole 16-byte chunks per lane");
+    extern __shared__ uint32_t sm[];  // [coarse bitmap][per wave: 64 reads + pad | WOBUF candidate ids]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x, nw = nthr >> 6;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, kept scalar
+    const uint32_t bm_words = 1u << (P.lds_log2 - 5);
+    for (uint32_t i = tid * 4; i < bm_words; i += nthr * 4)
+        *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap_lds + i);
+    uint32_t* tile = sm + bm_words + w * (slice_words + WOBUF);
+    uint32_t* obuf = tile + slice_words;
+    uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
+    uint32_t obuf_n = 0;   // wave-uniform
+    const uint32_t tile_bytes = 64 * P.rb;
+    const uint64_t total_bytes = P.n_reads * P.rb;
+    const uint32_t n_tiles = (uint32_t)((P.n_reads + 63) / 64);
+    const bool same = P.bm_log2 == P.lds_log2;
+    const bool bytes_ok = (P.stride2 & 7) == 0;
+    const uint32_t sh_lds = 32 - P.lds_log2, sh_bm = 32 - P.bm_log2;
+    const uint32_t l2mask = same ? 0u : ~3u;
+    const void* dummy = P.bitmap_lds;   // >= 16 readable bytes
+    u32x4 pfA[NCH], pfB[NCH], pfC[NCH];
+    auto prefetch = [&](u32x4 (&pf)[NCH], uint32_t t) {   // always NCH loads
+        uint32_t n16 = 0;
+        const void* base = dummy;
+        if (t < n_tiles) {
+            const uint64_t byte0 = (uint64_t)t * tile_bytes;
+            n16 = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes) >> 4;
+            if (n16) base = P.reads + byte0;
+        }
+        base = uniform_ptr(base);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t i = lane + c * 64;
+            vm_load128(pf[c], i < n16 ? i * 16 : 0u, base);
+        }
+    };
+    const uint32_t tstride = gridDim.x * nw;   // < 2^26
+    uint32_t t = blockIdx.x * nw + w;
+    auto next_tile = [&](uint32_t x, uint32_t steps) {   // x + steps * tstride, saturating at n_tiles
+        const uint64_t y = (uint64_t)x + (uint64_t)steps * tstride;
+        return y < n_tiles ? (uint32_t)y : n_tiles;
+    };
+    prefetch(pfA, t);
+    prefetch(pfB, next_tile(t, 1));
+    prefetch(pfC, next_tile(t, 2));
+
+    PipeW<NP> W0, W1, W2;
+    PipeS S0, S1, S2;
+    W0.t = W1.t = W2.t = PIPE_NONE;
+    S0.t = S1.t = S2.t = PIPE_NONE;
+    __syncthreads();   // coarse bitmap staged
+
+    // loads issued per step, in order: NCH (prefetch), NP (level-1 words), 2 (exact-set slots)
+    constexpr int YOUNGER_THAN_PF = 3 * NP + 6 + 2 * NCH;   // issued between a tile's prefetch and its use three steps later
+    constexpr int YOUNGER_THAN_W = 2 + NCH + NP;            // issued after the level-1 loads of the previous step
+    static_assert(YOUNGER_THAN_PF + NCH <= 63, "vmcnt is a 6-bit counter");
+    uint32_t n_steps = 0;
+    const uint32_t rbase = lane * P.rb;
+
+    // one step: stage A on tile t (fills WA), stage C on the tile of SC (filled two steps ago), stage B on WB -> SB
+    auto step = [&](u32x4 (&pf)[NCH], PipeW<NP>& WA, PipeW<NP>& WB, PipeS& SB, PipeS& SC) {
+        const bool have = t < n_tiles;
+        if (n_steps >= 3) vm_wait<YOUNGER_THAN_PF>(); else vm_wait<0>();
+        ++n_steps;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) vm_ready(pf[c]);
+        if (have) {
+            const uint64_t byte0 = (uint64_t)t * tile_bytes;
+            const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+            const uint32_t n16 = nbytes >> 4;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t i = lane + c * 64;
+                if (i < n16) *reinterpret_cast<u32x4*>(tb + i * 16) = pf[c];
+            }
+            if (nbytes & 15u) {   // only the very last tile of the array
+                const uint8_t* src = P.reads + byte0;
+                for (uint32_t i = n16 * 16 + lane; i < nbytes; i += 64) tb[i] = src[i];
+            }
+            if (lane < 16) tb[nbytes + lane] = 0;
+        }
+        wave_lds_sync();
+        prefetch(pf, next_tile(t, 3));
+        {
+            const uint32_t en = (have && (uint64_t)t * 64 + lane < P.n_reads) ? 0xFFFFFFFFu : 0u;
+            uint32_t bw[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const uint32_t jj = (uint32_t)j < P.np ? (uint32_t)j : 0u;
+                const uint32_t w32 = bytes_ok ? stream32_bytes(tile, rbase + ((jj * P.stride2) >> 3)) : stream32(tile, rbase * 8 + jj * P.stride2);
+                WA.p[j] = canon16(w32) * S16_MUL;
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) bw[j] = sm[WA.p[j] >> (sh_lds + 5)];
+            uint32_t pm = 0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                uint32_t pass = (uint32_t)__builtin_amdgcn_sbfe((int)bw[j], WA.p[j] >> sh_lds, 1);   // 0 or all ones
+                pass &= (uint32_t)j < P.np ? en : 0u;
+                pm |= pass & (1u << j);
+                vm_load32(WA.w[j], (WA.p[j] >> (sh_bm + 3)) & (pass & l2mask), P.bitmap);   // offset 0 when idle
+            }
+            WA.pm = pm;
+            WA.t = have ? t : PIPE_NONE;
+            wave_lds_sync();   // all lanes are done with the slice before the next step overwrites it
+        }
+        // ---- at most this step's loads and the previous step's exact-set loads may still be in flight
+        vm_wait<YOUNGER_THAN_W>();
+        // ---- stage C
+        if (SC.t != PIPE_NONE) {
+            vm_ready(SC.v0); vm_ready(SC.v1);
+            const bool hit0 = SC.v0.x == SC.key0 || SC.v0.y == SC.key0 || SC.v0.z == SC.key0 || SC.v0.w == SC.key0;
+            const bool hit1 = SC.v1.x == SC.key1 || SC.v1.y == SC.key1 || SC.v1.z == SC.key1 || SC.v1.w == SC.key1;
+            const bool open0 = SC.v0.x == EMPTY32 || SC.v0.y == EMPTY32 || SC.v0.z == EMPTY32 || SC.v0.w == EMPTY32;
+            const bool open1 = SC.v1.x == EMPTY32 || SC.v1.y == EMPTY32 || SC.v1.z == EMPTY32 || SC.v1.w == EMPTY32;
+            const bool on0 = SC.fl & 1u, on1 = SC.fl & 2u;
+            bool cand = (SC.fl & 4u) || (on0 && hit0) || (on1 && hit1);
+            const bool walk0 = on0 && !hit0 && !open0, walk1 = on1 && !hit1 && !open1;
+            if ((walk0 || walk1) && !cand) {   // rare: four foreign keys in a row
+                if (walk0) cand = sset_walk(P, SC.key0, hash_s16_set(SC.key0, P.s_log2) + 4);
+                if (walk1 && !cand) cand = sset_walk(P, SC.key1, hash_s16_set(SC.key1, P.s_log2) + 4);
+            }
+            const unsigned long long bal = __ballot(cand);
+            if (bal) {
+                const uint32_t cnt = (uint32_t)__popcll(bal);
+                if (cand) obuf[obuf_n + __popcll(bal & ((1ull << lane) - 1))] = SC.t * 64 + lane;
+                obuf_n += cnt;   // <= 31 + 64 <= WOBUF
+                wave_lds_sync();
+                if (obuf_n >= 32) {
+                    uint32_t gb = 0;
+                    if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
+                    gb = __shfl(gb, 0);
+                    for (uint32_t i = lane; i < obuf_n; i += 64) P.cand[gb + i] = obuf[i];
+                    obuf_n = 0;
+                    wave_lds_sync();
+                }
+            }
+            SC.t = PIPE_NONE;
+        }
+        // ---- stage B (always two loads)
+        uint32_t p0 = 0, p1 = 0, fl = 0;
+        if (WB.t != PIPE_NONE) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) vm_ready(WB.w[j]);
+            uint32_t mask = 0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mask |= __builtin_amdgcn_ubfe(WB.w[j], WB.p[j] >> sh_bm, 1) << j;
+            mask = same ? WB.pm : (mask & WB.pm);
+            const uint32_t m2 = mask & (mask - 1), m3 = m2 & (m2 - 1);
+            const int j0 = __ffs(mask) - 1, j1 = __ffs(m2) - 1;   // -1 when absent
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                p0 = j0 == j ? WB.p[j] : p0;
+                p1 = j1 == j ? WB.p[j] : p1;
+            }
+            fl = (mask ? 1u : 0u) | (m2 ? 2u : 0u);
+            if (m3) {   // rare: third and later passing probes of a lane, looked up on the spot
+                bool slow = false;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    if (((m3 >> j) & 1u) && !slow) {
+                        const uint32_t key = WB.p[j] * S16_MUL_INV;
+                        slow = sset_walk(P, key, hash_s16_set(key, P.s_log2));
+                    }
+                }
+                fl |= slow ? 4u : 0u;
+            }
+        }
+        SB.fl = fl;
+        SB.key0 = p0 * S16_MUL_INV; SB.key1 = p1 * S16_MUL_INV;
+        vm_load128(SB.v0, (fl & 1u) ? hash_s16_set(SB.key0, P.s_log2) * 4 : 0u, P.sset);
+        vm_load128(SB.v1, (fl & 2u) ? hash_s16_set(SB.key1, P.s_log2) * 4 : 0u, P.sset);
+        SB.t = WB.t;
+        WB.t = PIPE_NONE;
+        t = next_tile(t, 1);
+    };
+    auto done = [&]() { return t >= n_tiles && W0.t == PIPE_NONE && W1.t == PIPE_NONE && W2.t == PIPE_NONE && S0.t == PIPE_NONE && S1.t == PIPE_NONE && S2.t == PIPE_NONE; };
+    for (;;) {
+        //   prefetch regs, A fills, B reads, B fills, C reads
+        if (done()) break;
+        step(pfA, W0, W2, S2, S0);
+        if (done()) break;
+        step(pfB, W1, W0, S0, S1);
+        if (done()) break;
+        step(pfC, W2, W1, S1, S2);
+    }
+    vm_wait<0>();
     if (obuf_n) {
         uint32_t gb = 0;
         if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
@@ -741,18 +1031,33 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     const size_t w_nw = std::min<size_t>(16, (160 * 1024 - 512 - w_bm_bytes) / w_per_wave);
     // the wave kernel needs a handful of waves per CU next to the coarse bitmap (long reads leave too few: plain kernel then)
     const bool lds_ok = ix.d_bitmap_lds && ix.lds_fill <= 0.6 && ctx->screen_variant != 9 && w_nw >= 6;
-    if ((lds_ok && ctx->screen_variant == 0) || (ctx->screen_variant == 12 && ix.d_bitmap_lds && w_nw >= 2)) {
+    const bool pipe_ok = F.np >= 1 && F.np <= 10 && ix.lds_log2 >= 7 && (rb + 15) / 16 <= 4;
+    if (((lds_ok && ctx->screen_variant == 0) || (ctx->screen_variant == 13 && ix.d_bitmap_lds && w_nw >= 2)) && pipe_ok) {
+        // software-pipelined wave kernel (three tiles in flight per wave)
+        size_t nw = std::min<size_t>(w_nw, 8);
+        if (ctx->screen_wg_per_cu > 0) nw = std::min<size_t>(nw, (size_t)ctx->screen_wg_per_cu);   // diagnostic: fewer waves per CU
+        const size_t tiles2 = (n_reads + 63) / 64;
+        const int nch = (rb + 15) / 16 <= 4 ? (int)((rb + 15) / 16) : 0;
+        const int npt = 10;
+        void (*wk)(FilterParams, uint32_t) = nullptr;
+#define GF_PK(N, Q) if (nch == N && npt == Q) wk = screen_filter_pipe_kernel<N, Q>;
+        GF_PK(1, 10) GF_PK(2, 10) GF_PK(3, 10) GF_PK(4, 10)
+#undef GF_PK
+        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
+        hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles2 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
+                           w_bm_bytes + nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
+    } else if ((lds_ok && ctx->screen_variant == 0) || (ctx->screen_variant == 12 && ix.d_bitmap_lds && w_nw >= 2)) {
         // wave-autonomous LDS pre-filter kernel: as many waves per CU as fit next to the coarse bitmap
         const size_t bm_bytes = w_bm_bytes, slice_words = w_slice_words, per_wave = w_per_wave, nw = w_nw;
         const size_t tiles2 = (n_reads + 63) / 64;
-        void (*wk)(FilterParams, uint32_t) = screen_filter_wave_kernel<0>;
-        switch ((rb + 15) / 16) {
-            case 1: wk = screen_filter_wave_kernel<1>; break;
-            case 2: wk = screen_filter_wave_kernel<2>; break;
-            case 3: wk = screen_filter_wave_kernel<3>; break;
-            case 4: wk = screen_filter_wave_kernel<4>; break;
-            default: break;
-        }
+        void (*wk)(FilterParams, uint32_t) = screen_filter_wave_kernel<0, 0>;
+        const int nch = (rb + 15) / 16 <= 4 ? (int)((rb + 15) / 16) : 0;
+        const int fu = ctx->screen_fuse;
+#define GF_WK(N, F) if (nch == N && fu == F) wk = screen_filter_wave_kernel<N, F>;
+#define GF_WKN(N) GF_WK(N, 0) GF_WK(N, 3) GF_WK(N, 5) GF_WK(N, 10)
+        GF_WKN(0) GF_WKN(1) GF_WKN(2) GF_WKN(3) GF_WKN(4)
+#undef GF_WKN
+#undef GF_WK
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles2 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
                            bm_bytes + nw * per_wave, ctx->stream, F, (uint32_t)slice_words);

@@ -23,7 +23,10 @@ flanks = [(lut[rng.randint(0, 4, 295)].tobytes().decode(), lut[rng.randint(0, 4,
 gf = GapFill(0)
 variants = [0] if len(sys.argv) <= 5 else [int(x) for x in sys.argv[5].split(",")]
 import itertools
-for bl, var in itertools.product(([0] if len(sys.argv) <= 4 else [int(x) for x in sys.argv[4].split(",")]), variants):
+fuses = [int(x) for x in os.environ.get("FUSE", "0").split(",")]
+for bl, var, fuse in itertools.product(([0] if len(sys.argv) <= 4 else [int(x) for x in sys.argv[4].split(",")]), variants, fuses):
+    gf.set_option("screen_fuse", fuse)
+    gf.set_option("screen_wg_per_cu", int(os.environ.get("WG", "0")))
     gf.set_option("bitmap_log2", bl)
     gf.set_option("screen_lds_log2_max", int(os.environ.get("LDSMAX", "20")))
     gf.set_option("screen_variant", var % 100)
@@ -49,6 +52,6 @@ for bl, var in itertools.product(([0] if len(sys.argv) <= 4 else [int(x) for x i
     dt = (time.time() - t) / 5
     ms, nl = gf.kernel_time(B.KERNEL_SCREEN)
     ms2, nl2 = gf.kernel_time(B.KERNEL_VERIFY)
-    print("var=%d bitmap_log2=%d reads=%d gaps=%d k=%d: wall %.3f ms/iter; filter %.3f ms (%.1f GB/s, %.2e reads/s) verify %.3f ms; hits=%d"
-          % (var, bl, n_reads, n_gaps, k, dt * 1e3, ms / nl, n_reads * 38 / (ms / nl * 1e-3) / 1e9, n_reads / (ms / nl * 1e-3), ms2 / nl2, int(nout[0])))
+    print("fuse=%d var=%d bitmap_log2=%d reads=%d gaps=%d k=%d: wall %.3f ms/iter; filter %.3f ms (%.1f GB/s, %.2e reads/s) verify %.3f ms; hits=%d"
+          % (fuse, var, bl, n_reads, n_gaps, k, dt * 1e3, ms / nl, n_reads * 38 / (ms / nl * 1e-3) / 1e9, n_reads / (ms / nl * 1e-3), ms2 / nl2, int(nout[0])))
     gf.timing(False)
