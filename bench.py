@@ -234,7 +234,7 @@ def main():
                        "sharding": "reads sharded over ranks, gaps replicated; RCCL only gathers the assembled sequences"},
             "gaps_per_s": world * len(gaps) / (dt / args.steps),
             "gaps_closed_per_s": world * gaps_closed / (dt / args.steps),
-            "roofline": {"bound": "hbm", "kernel": "screen_filter (wave kernel with LDS pre-filter when the key set allows it)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "screen_filter (software-pipelined wave kernel with LDS pre-filter when the key set allows it)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n_reads, L, k),
                          "algorithmic_bytes_per_launch": n_reads * rb, "avg_launch_ms": filt_ms,
                          "frac_of_measured_copy_6290": achieved / 6290.0},

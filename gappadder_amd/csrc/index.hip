@@ -140,11 +140,13 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
         sset[s] = key;
     }
     for (int i = 0; i < 4; ++i) sset[scap + i] = sset[i];   // wrap-around copy: a 4-slot read never needs the modulo
-    // level 1 bitmap: ~32 bits per key keeps the per-probe false-positive rate near 3 %
-    // level 1 bitmap: 16-32 bits per key (3-6 % false positives per probe, resolved by level 2); measured on
-    // MI355X a 2 MiB bitmap (2^24 bits) that stays in every XCD's L2 beats a sparser 4 MiB one
-    int bl = ceil_log2(16 * s16.size() + 1);
-    bl = std::min(30, std::max(15, bl));
+    // level 1 bitmap: at least 16 bits per key (<= 6 % false positives per probe, resolved by level 2) and never
+    // fewer than 2^24 bits: the filter kernels test a 2^20-bit coarse copy in LDS first, and a level-1 bitmap only a few
+    // times finer than that copy stops too little of what the copy lets through (measured on MI355X, 50 M reads:
+    // 100-400 gaps 1.5-1.6 ms with 16 bits per key, 0.9-1.1 ms with 2^24 bits).  A 2 MiB bitmap stays in every XCD's
+    // L2; a sparser 4 MiB one measured slower.
+    int bl = std::max(24, ceil_log2(16 * s16.size() + 1));
+    bl = std::min(30, bl);
     if (ctx->bitmap_log2_override) bl = std::min(31, std::max(10, ctx->bitmap_log2_override));
     ix.bm_log2 = bl;
     const size_t bwords = ((size_t)1 << bl) / 32;

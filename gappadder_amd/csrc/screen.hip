@@ -586,7 +586,7 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
     const uint32_t sh_lds = 32 - P.lds_log2, sh_bm = 32 - P.bm_log2;
     const uint32_t l2mask = same ? 0u : ~3u;
     const void* dummy = P.bitmap_lds;   // >= 16 readable bytes
-    u32x4 pfA[NCH], pfB[NCH], pfC[NCH];
+    u32x4 pfA[NCH], pfB[NCH];
     auto prefetch = [&](u32x4 (&pf)[NCH], uint32_t t) {   // always NCH loads
         uint32_t n16 = 0;
         const void* base = dummy;
@@ -610,25 +610,29 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
     };
     prefetch(pfA, t);
     prefetch(pfB, next_tile(t, 1));
-    prefetch(pfC, next_tile(t, 2));
 
-    PipeW<NP> W0, W1, W2;
-    PipeS S0, S1, S2;
-    W0.t = W1.t = W2.t = PIPE_NONE;
-    S0.t = S1.t = S2.t = PIPE_NONE;
+    PipeW<NP> W0, W1;
+    PipeS S0, S1;
+    W0.t = W1.t = PIPE_NONE;
+    S0.t = S1.t = PIPE_NONE;
     __syncthreads();   // coarse bitmap staged
 
-    // loads issued per step, in order: NCH (prefetch), NP (level-1 words), 2 (exact-set slots)
-    constexpr int YOUNGER_THAN_PF = 3 * NP + 6 + 2 * NCH;   // issued between a tile's prefetch and its use three steps later
-    constexpr int YOUNGER_THAN_W = 2 + NCH + NP;            // issued after the level-1 loads of the previous step
-    static_assert(YOUNGER_THAN_PF + NCH <= 63, "vmcnt is a 6-bit counter");
+    // Loads issued per step, in order: NP (level-1 words), 2 (exact-set slots), NCH (prefetch of the tile two steps on).
+    // vmcnt retires in issue order; every wait below names how many loads were issued after the one it needs.
+    //   prefetch issued at the end of step s-2   -> staged at the top of step s
+    //   level-1 words issued in stage A of s-1   -> tested in stage B of step s
+    //   exact-set slots issued in stage B of s-1 -> tested in stage C of step s
+    constexpr int PER_STEP = NP + 2 + NCH;
+    constexpr int YOUNGER_THAN_PF = PER_STEP;      // all of step s-1
+    constexpr int YOUNGER_THAN_S = NCH + NP;       // prefetch of step s-1, stage A of step s
+    static_assert(YOUNGER_THAN_PF + PER_STEP <= 63, "vmcnt is a 6-bit counter");
     uint32_t n_steps = 0;
     const uint32_t rbase = lane * P.rb;
 
-    // one step: stage A on tile t (fills WA), stage C on the tile of SC (filled two steps ago), stage B on WB -> SB
+    // one step: stage A on tile t (fills WA), stage C on SC and stage B on WB -> SB (both filled one step ago)
     auto step = [&](u32x4 (&pf)[NCH], PipeW<NP>& WA, PipeW<NP>& WB, PipeS& SB, PipeS& SC) {
         const bool have = t < n_tiles;
-        if (n_steps >= 3) vm_wait<YOUNGER_THAN_PF>(); else vm_wait<0>();
+        if (n_steps >= 2) vm_wait<YOUNGER_THAN_PF>(); else vm_wait<0>();
         ++n_steps;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) vm_ready(pf[c]);
@@ -648,7 +652,6 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
             if (lane < 16) tb[nbytes + lane] = 0;
         }
         wave_lds_sync();
-        prefetch(pf, next_tile(t, 3));
         {
             const uint32_t en = (have && (uint64_t)t * 64 + lane < P.n_reads) ? 0xFFFFFFFFu : 0u;
             uint32_t bw[NP];
@@ -672,8 +675,8 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
             WA.t = have ? t : PIPE_NONE;
             wave_lds_sync();   // all lanes are done with the slice before the next step overwrites it
         }
-        // ---- at most this step's loads and the previous step's exact-set loads may still be in flight
-        vm_wait<YOUNGER_THAN_W>();
+        // ---- everything issued up to stage B of the previous step has arrived
+        vm_wait<YOUNGER_THAN_S>();
         // ---- stage C
         if (SC.t != PIPE_NONE) {
             vm_ready(SC.v0); vm_ready(SC.v1);
@@ -740,17 +743,16 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
         vm_load128(SB.v1, (fl & 2u) ? hash_s16_set(SB.key1, P.s_log2) * 4 : 0u, P.sset);
         SB.t = WB.t;
         WB.t = PIPE_NONE;
+        prefetch(pf, next_tile(t, 2));
         t = next_tile(t, 1);
     };
-    auto done = [&]() { return t >= n_tiles && W0.t == PIPE_NONE && W1.t == PIPE_NONE && W2.t == PIPE_NONE && S0.t == PIPE_NONE && S1.t == PIPE_NONE && S2.t == PIPE_NONE; };
+    auto done = [&]() { return t >= n_tiles && W0.t == PIPE_NONE && W1.t == PIPE_NONE && S0.t == PIPE_NONE && S1.t == PIPE_NONE; };
     for (;;) {
         //   prefetch regs, A fills, B reads, B fills, C reads
         if (done()) break;
-        step(pfA, W0, W2, S2, S0);
+        step(pfA, W0, W1, S0, S1);
         if (done()) break;
-        step(pfB, W1, W0, S0, S1);
-        if (done()) break;
-        step(pfC, W2, W1, S1, S2);
+        step(pfB, W1, W0, S1, S0);
     }
     vm_wait<0>();
     if (obuf_n) {
@@ -1034,14 +1036,16 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     const bool pipe_ok = F.np >= 1 && F.np <= 10 && ix.lds_log2 >= 7 && (rb + 15) / 16 <= 4;
     if (((lds_ok && ctx->screen_variant == 0) || (ctx->screen_variant == 13 && ix.d_bitmap_lds && w_nw >= 2)) && pipe_ok) {
         // software-pipelined wave kernel (three tiles in flight per wave)
-        size_t nw = std::min<size_t>(w_nw, 8);
+        size_t nw = std::min<size_t>(w_nw, 8);   // measured: 8 waves x 256 VGPRs beat 11 x 168
         if (ctx->screen_wg_per_cu > 0) nw = std::min<size_t>(nw, (size_t)ctx->screen_wg_per_cu);   // diagnostic: fewer waves per CU
         const size_t tiles2 = (n_reads + 63) / 64;
         const int nch = (rb + 15) / 16 <= 4 ? (int)((rb + 15) / 16) : 0;
-        const int npt = 10;
+        const int npt = std::max(5, (int)F.np);   // probes per read, unrolled
         void (*wk)(FilterParams, uint32_t) = nullptr;
 #define GF_PK(N, Q) if (nch == N && npt == Q) wk = screen_filter_pipe_kernel<N, Q>;
-        GF_PK(1, 10) GF_PK(2, 10) GF_PK(3, 10) GF_PK(4, 10)
+#define GF_PKN(Q) GF_PK(1, Q) GF_PK(2, Q) GF_PK(3, Q) GF_PK(4, Q)
+        GF_PKN(5) GF_PKN(6) GF_PKN(7) GF_PKN(8) GF_PKN(9) GF_PKN(10)
+#undef GF_PKN
 #undef GF_PK
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles2 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
