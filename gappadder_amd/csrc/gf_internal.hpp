@@ -70,6 +70,7 @@ struct gf_ctx {
     int screen_variant = 0;     // tuning: load mode / unroll of the filter kernel
     int screen_wg_per_cu = 0;
     int screen_lds_direct = 0;
+    int screen_verify_gate = 1;  // verify kernel: consult the k-mer table only around exact 16-mer hits
     int screen_fuse = 0;         // wave kernel: 0 = two-loop form, 3/5/10 = fused L2 probes with that many in flight per lane
     int screen_np_override = -1;
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)

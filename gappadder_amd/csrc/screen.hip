@@ -778,6 +778,9 @@ struct VerifyParams {
     gf_hit* out;
     uint32_t cap;
     uint32_t* n_out;
+    // window gate: the exact canonical-16-mer set and the filter's probe geometry (sset null = gate off)
+    const uint32_t* sset;
+    uint32_t s_log2, stride, np;
     uint32_t* overflow;      // counter: candidates whose (position, gap) list exceeded list_cap
     uint32_t* overflow_list; // their read ids (re-verified by a second launch with a large list), or null
 };
@@ -808,6 +811,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
     const uint32_t n_cand = *P.n_cand;
     const uint32_t npos = P.read_len - P.k + 1;
     const uint32_t tmask = (1u << P.t_log2) - 1;
+    const bool gate = P.sset != nullptr && P.np >= 1 && P.np <= 32;
 
     // 64 candidates per wave and pass.  (Measured: smaller batches on more concurrent waves are SLOWER — the pass is bound by
     // random 16-B table loads served from the Infinity Cache, not by wave count.)
@@ -832,8 +836,46 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
             }
         }
         __syncthreads();
+        // Window gate.  A k-mer of the read can only equal a flank k-mer if the ONE stride-aligned 16-mer it contains
+        // (offset q * stride, q = ceil(p / stride); stride = k - 15) is a flank 16-mer.  Every lane looks its own
+        // candidate's np aligned 16-mers up in the exact set (three lookups in flight, four slots per request), so the
+        // table below is only consulted around real 16-mer hits: a chance candidate costs ~k-15 table reads, not L-k+1.
+        uint32_t my_gate = 0xFFFFFFFFu;
+        if (gate) {
+            my_gate = 0;
+            if (lane < nb) {
+                const uint32_t* row = sm + lane * rw;
+                for (uint32_t q0 = 0; q0 < P.np; q0 += 3) {
+                    uint32_t key[3];
+                    Slots4 v[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const uint32_t q = q0 + u < P.np ? q0 + u : P.np - 1;
+                        key[u] = canon16(stream32(row, 2 * q * P.stride));
+                        v[u] = *reinterpret_cast<const Slots4*>(P.sset + hash_s16_set(key[u], (int)P.s_log2));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        if (q0 + u >= P.np) continue;
+                        bool hit = v[u].x == key[u] || v[u].y == key[u] || v[u].z == key[u] || v[u].w == key[u];
+                        const bool open = v[u].x == EMPTY32 || v[u].y == EMPTY32 || v[u].z == EMPTY32 || v[u].w == EMPTY32;
+                        if (!hit && !open) {   // rare: four foreign keys in a row
+                            uint32_t sl = hash_s16_set(key[u], (int)P.s_log2) + 4;
+                            for (;;) {
+                                const uint32_t x = P.sset[sl & ((1u << P.s_log2) - 1)];
+                                if (x == key[u]) { hit = true; break; }
+                                if (x == EMPTY32) break;
+                                ++sl;
+                            }
+                        }
+                        my_gate |= (uint32_t)hit << (q0 + u);
+                    }
+                }
+            }
+        }
         for (uint32_t j = 0; j < nb; ++j) {
             const uint32_t r = __shfl(my_r, j);
+            const uint32_t gate_j = __shfl(my_gate, j);
             const uint32_t* rwp = sm + j * rw;
             uint32_t n = 0;  // (position, gap) matches of this read; wave-uniform, appended by ballot + prefix count
             for (uint32_t pp = 0; pp < npos; pp += 128) {
@@ -844,6 +886,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
                 for (int u = 0; u < 2; ++u) {
                     const uint32_t p = pp + lane + 64 * u;
                     act[u] = p < npos;
+                    if (gate && act[u]) act[u] = (gate_j >> ((p + P.stride - 1) / P.stride)) & 1u;
                     if (act[u] && P.nmask) {  // any N inside [p, p+k) ?
                         for (uint32_t q = p; q < p + P.k; ++q)
                             if ((P.nmask[(uint64_t)r * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { act[u] = false; break; }
@@ -1118,6 +1161,10 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.table = (const uint4*)ix.d_table;
     V.t_log2 = ix.t_log2;
     V.min_hits = min_hits < 1 ? 1 : min_hits;
+    V.sset = ctx->screen_verify_gate ? ix.d_sset : nullptr;
+    V.s_log2 = ix.s_log2;
+    V.stride = ix.stride;
+    V.np = (uint32_t)((read_len - 16) / ix.stride + 1);
     const uint32_t npos = read_len - ix.k + 1;
     V.out = (gf_hit*)d_out;
     V.cap = (uint32_t)cap;
