@@ -71,6 +71,7 @@ struct gf_ctx {
     int screen_wg_per_cu = 0;
     int screen_lds_direct = 0;
     int screen_verify_gate = 1;  // verify kernel: consult the k-mer table only around exact 16-mer hits
+    int screen_stream_policy = 1;  // pipelined filter: read stream loaded non-temporal (nt): keeps the L2 for the bitmap, -8 % fabric fetches
     int screen_fuse = 0;         // wave kernel: 0 = two-loop form, 3/5/10 = fused L2 probes with that many in flight per lane
     int screen_np_override = -1;
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)

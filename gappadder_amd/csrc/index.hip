@@ -154,6 +154,7 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
     for (uint32_t key : s16) {
         uint32_t h = hash_s16_bitmap(key, bl);
         bm[h >> 5] |= 1u << (h & 31);
+        bm[h >> 5] |= 1u << hash_s16_bit2(key);   // second bit in the same word (blocked Bloom): kernels may test it too
     }
 
     // coarse copy for the LDS pre-filter: bit c = OR of the level-1 bits h with (h >> (bl - lds_log2)) == c

@@ -99,6 +99,9 @@ GF_HD uint32_t hash_kmer(K128 v, int log2cap) {
 }
 
 GF_HD uint32_t hash_s16_bitmap(uint32_t key, int log2bits) { return (key * 0x9E3779B1u) >> (32 - log2bits); }
+// second bit of a key inside its level-1 bitmap word: the low product bits, which no word or first-bit index uses while
+// the bitmap has <= 2^27 bits (beyond that the two overlap: still exact, only less selective)
+GF_HD uint32_t hash_s16_bit2(uint32_t key) { return (key * 0x9E3779B1u) & 31u; }
 GF_HD uint32_t hash_s16_set(uint32_t key, int log2cap) {
     uint32_t x = key * 0x85EBCA6Bu;
     x ^= x >> 15;

@@ -29,6 +29,7 @@ struct FilterParams {
     const uint32_t* bitmap_lds;
     uint32_t lds_log2;
     uint32_t lds_direct;   // 1: probes that pass the LDS bitmap go straight to the exact set (no L2 bitmap hop)
+    uint32_t stream_policy; // pipelined kernel: cache policy of the read stream (0 default, 1 nt, 2 sc1, 3 sc0 sc1 nt)
 };
 
 // how the filter's bitmap words are fetched: every probe is a 4-byte read of a random 128-B line of an
@@ -95,13 +96,16 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
                             } else {
                                 const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
                                 const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
-                                hb[u] = h & 31;
+                                hb[u] = (h & 31) | (hash_s16_bit2(key) << 8);   // both bits of the key in its word
                                 word[u] = MODE == LOAD_ABL_COMPUTE ? (uint32_t)(h == 0x12345u) : probe_load<MODE>(P.bitmap + (h >> 5));
                             }
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < PU; ++u) mask |= ((word[u] >> hb[u]) & 1u) << (j0 - g0 + u);
+                    for (int u = 0; u < PU; ++u) {
+                        const uint32_t both = MODE >= LOAD_ABL_STREAM ? (word[u] >> (hb[u] & 31)) : (word[u] >> (hb[u] & 31)) & (word[u] >> (hb[u] >> 8));
+                        mask |= (both & 1u) << (j0 - g0 + u);
+                    }
                 }
                 // level 2: confirm each bitmap hit in the exact canonical-16-mer set
                 while (mask && !cand) {
@@ -234,13 +238,14 @@ __global__ __launch_bounds__(1024) void screen_filter_lds_kernel(FilterParams P)
                             if (m) {
                                 jj[u] = __ffs(m) - 1;
                                 m &= m - 1;
-                                const uint32_t h = hash_s16_bitmap(canon16(stream32(tile, bit0 + (g0 + jj[u]) * P.stride2)), P.bm_log2);
-                                hb[u] = h & 31;
+                                const uint32_t key = canon16(stream32(tile, bit0 + (g0 + jj[u]) * P.stride2));
+                                const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
+                                hb[u] = (h & 31) | (hash_s16_bit2(key) << 8);   // both bits of the key in its word
                                 word[u] = P.bitmap[h >> 5];
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 5; ++u) mask |= ((word[u] >> hb[u]) & 1u) << jj[u];
+                        for (int u = 0; u < 5; ++u) mask |= ((word[u] >> (hb[u] & 31)) & (word[u] >> (hb[u] >> 8)) & 1u) << jj[u];
                     }
                 }
                 // level 2: confirm in the exact canonical-16-mer set
@@ -418,13 +423,14 @@ __global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P
                             if (m) {
                                 jj[u] = __ffs(m) - 1;
                                 m &= m - 1;
-                                const uint32_t h = hash_s16_bitmap(canon16(stream32(tile, bit0 + (g0 + jj[u]) * P.stride2)), P.bm_log2);
-                                hb[u] = h & 31;
+                                const uint32_t key = canon16(stream32(tile, bit0 + (g0 + jj[u]) * P.stride2));
+                                const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
+                                hb[u] = (h & 31) | (hash_s16_bit2(key) << 8);   // both bits of the key in its word
                                 word[u] = P.bitmap[h >> 5];
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 5; ++u) mask |= ((word[u] >> hb[u]) & 1u) << jj[u];
+                        for (int u = 0; u < 5; ++u) mask |= ((word[u] >> (hb[u] & 31)) & (word[u] >> (hb[u] >> 8)) & 1u) << jj[u];
                     }
                 }
                 while (mask && !cand) {   // level 2: exact canonical-16-mer set, up to 3 lookups in flight
@@ -537,6 +543,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void vm_load128(u32x4& d, uint32_t voff, const void* sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase));
 }
+__device__ __forceinline__ void vm_load128_nt(u32x4& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(d) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void vm_load128_sc1(u32x4& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(d) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void vm_load128_sc01nt(u32x4& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1 nt" : "=v"(d) : "v"(voff), "s"(sbase));
+}
 __device__ __forceinline__ void vm_load32(uint32_t& d, uint32_t voff, const void* sbase) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase));
 }
@@ -599,7 +614,11 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const uint32_t i = lane + c * 64;
-            vm_load128(pf[c], i < n16 ? i * 16 : 0u, base);
+            const uint32_t off = i < n16 ? i * 16 : 0u;
+            if (P.stream_policy == 1) vm_load128_nt(pf[c], off, base);
+            else if (P.stream_policy == 2) vm_load128_sc1(pf[c], off, base);
+            else if (P.stream_policy == 3) vm_load128_sc01nt(pf[c], off, base);
+            else vm_load128(pf[c], off, base);
         }
     };
     const uint32_t tstride = gridDim.x * nw;   // < 2^26
@@ -715,7 +734,8 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
             for (int j = 0; j < NP; ++j) vm_ready(WB.w[j]);
             uint32_t mask = 0;
 #pragma unroll
-            for (int j = 0; j < NP; ++j) mask |= __builtin_amdgcn_ubfe(WB.w[j], WB.p[j] >> sh_bm, 1) << j;
+            for (int j = 0; j < NP; ++j)   // both bits of the key in its word (index.hip sets two per key)
+                mask |= (__builtin_amdgcn_ubfe(WB.w[j], WB.p[j] >> sh_bm, 1) & __builtin_amdgcn_ubfe(WB.w[j], WB.p[j], 1)) << j;
             mask = same ? WB.pm : (mask & WB.pm);
             const uint32_t m2 = mask & (mask - 1), m3 = m2 & (m2 - 1);
             const int j0 = __ffs(mask) - 1, j1 = __ffs(m2) - 1;   // -1 when absent
@@ -1065,6 +1085,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     F.bitmap_lds = ix.d_bitmap_lds;
     F.lds_log2 = ix.lds_log2;
     F.lds_direct = ctx->screen_lds_direct;
+    F.stream_policy = (uint32_t)ctx->screen_stream_policy;
     const size_t n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
     const size_t lds = TILE_READS * rb + 16;
     const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * (ctx->screen_wg_per_cu > 0 ? ctx->screen_wg_per_cu : 8));

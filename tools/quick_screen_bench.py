@@ -27,6 +27,7 @@ fuses = [int(x) for x in os.environ.get("FUSE", "0").split(",")]
 for bl, var, fuse in itertools.product(([0] if len(sys.argv) <= 4 else [int(x) for x in sys.argv[4].split(",")]), variants, fuses):
     gf.set_option("screen_fuse", fuse)
     gf.set_option("screen_wg_per_cu", int(os.environ.get("WG", "0")))
+    gf.set_option("screen_stream_policy", int(os.environ.get("POL", "0")))
     gf.set_option("bitmap_log2", bl)
     gf.set_option("screen_lds_log2_max", int(os.environ.get("LDSMAX", "20")))
     gf.set_option("screen_variant", var % 100)

@@ -4,7 +4,8 @@ import collections, csv, glob, json, os, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_final"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True)[0]
+newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)   # gpurun merges runs: keep the latest
+stats = newest(src + "/trace/**/*kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 with open(dst + "/r01_kernel_stats.csv", "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu   (MI355X, C2 workload)\n")
@@ -14,7 +15,8 @@ with open(dst + "/r01_kernel_stats.csv", "w") as f:
         if r["Name"].startswith(("gf::", "void gf::")):
             w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True):
+for d in sorted(glob.glob(src + "/pmc_*/")):
+    f = newest(d + "**/*counter_collection.csv")
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"].startswith(("gf::", "void gf::")):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -26,7 +28,7 @@ with open(dst + "/r01_pmc_summary.csv", "w") as f:
         for c in sorted(acc[k]):
             v = acc[k][c]
             w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
-name = [k for k in acc if "screen_filter" in k][0]
+name = [r["Name"] for r in rows if "screen_filter" in r["Name"]][0]
 fetch = sum(acc[name]["FETCH_SIZE"]) / len(acc[name]["FETCH_SIZE"])
 write = sum(acc[name]["WRITE_SIZE"]) / len(acc[name]["WRITE_SIZE"])
 avg_ns = [float(r["AverageNs"]) for r in rows if r["Name"] == name][0]
