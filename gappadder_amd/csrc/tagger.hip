@@ -80,6 +80,12 @@ __device__ __forceinline__ void flush_hits(HitBuf& hb, gf_taghit* out, uint32_t 
 // Records are streamed as whole 1-KiB wave loads (16 B per lane, consecutive lanes = consecutive 16-B halves):
 // the even lane of a pair holds {pos, mate_pos, tlen, ref}, the odd lane {mate_ref, flag|mapq|clip, read id}.
 // Even lanes run the coarse bin test; the rare survivors pull their second half from the neighbour lane.
+struct LiveRec { uint32_t pos, ref, mate_ref, meta; int32_t tlen; uint32_t rec; };   // a record that passed the bin map
+constexpr uint32_t LIVEQ = 96;   // per wave: < 64 waiting + <= 32 from one 1-KiB load
+__device__ __forceinline__ void tag_wave_sync() {   // LDS hand-off between lanes of ONE wave (in-order LDS: compiler fence only)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 constexpr int TAG_UNROLL = 8;  // 8 KiB (256 records) per wave and stage, two stages in flight
 
 __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
@@ -87,6 +93,7 @@ __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
     __shared__ HitBuf hb;
     constexpr uint32_t LOWBUF = 128;    // MAPQ==0 records buffered per wave (one global atomic per ~64-128 of them)
     __shared__ gf_lowrec lowbuf[4][LOWBUF];
+    __shared__ LiveRec liveq[4][LIVEQ];
     uint32_t low_n = 0;                 // wave-uniform
     if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
     for (uint32_t i = threadIdx.x; i < P.bin_words; i += blockDim.x) bins[i] = P.bin_bits[i];
@@ -100,6 +107,66 @@ __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
         for (uint32_t i = lane; i < low_n; i += 64)
             if (gb + i < P.low_cap) P.low[gb + i] = wlow[i];
         low_n = 0;
+    };
+    // ---- per-wave queue of records that passed the bin map
+    LiveRec* wlive = liveq[threadIdx.x >> 6];
+    uint32_t live_n = 0;   // wave-uniform
+    auto drain = [&]() {   // window search + tagging of the last min(64, live_n) queued records, one per lane
+        const uint32_t base = live_n > 64 ? live_n - 64 : 0;
+        bool live = base + lane < live_n;
+        gf_alnrec r = {};
+        uint32_t rec = 0, g = 0, g_end = 0;
+        if (live) {
+            const LiveRec q = wlive[base + lane];
+            r.pos = q.pos; r.ref = q.ref; r.tlen = q.tlen; r.mate_ref = q.mate_ref;
+            r.flag = (uint16_t)(q.meta & 0xFFFF); r.mapq = (uint8_t)((q.meta >> 16) & 0xFF); r.clipflag = (uint8_t)(q.meta >> 24);
+            rec = q.rec;
+            g = P.scaf_off[r.ref];
+            g_end = P.scaf_off[r.ref + 1];
+            // first gap whose right window can still reach POS: end + dist2 > pos  (ends ascend)
+            uint32_t lo = g, hi = g_end;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((int64_t)P.gaps[mid].end + P.dist2 > (int64_t)r.pos) hi = mid; else lo = mid + 1;
+            }
+            g = lo;
+        }
+        const int64_t pos = r.pos;
+        // walk the (few) gaps whose windows can contain POS; lanes without work idle through the ballots
+        while (true) {
+            bool more = live && g < g_end && (int64_t)P.gaps[g].start - P.dist2 < pos;
+            if (!__any(more)) break;
+            bool clip = false, pair = false, unmap = false;
+            if (more) {
+                const gf_gap gp = P.gaps[g];
+                const int64_t il = (int64_t)gp.start - pos, ir = pos - (int64_t)gp.end;
+                int tag = -1;  // 0: 0c, 1: 0d, 2: 1c, 3: 1d
+                if (il >= 0 && il < P.dist2) tag = il <= P.clip_dist ? 0 : 1;
+                else if (ir >= 0 && ir < P.dist2) tag = ir <= P.clip_dist ? 2 : 3;
+                if (tag >= 0) {
+                    clip = (tag == 0 && r.clipflag >= 2) || (tag == 2 && (r.clipflag == 1 || r.clipflag == 3));
+                    const bool mapped = (r.flag & 0x4) == 0, mate_mapped = (r.flag & 0x8) == 0;
+                    if (mapped && mate_mapped && (int)r.mapq >= P.anchor_mapq) {
+                        if (r.mate_ref != r.ref) pair = true;
+                        else {
+                            const int64_t t = r.tlen < 0 ? -(int64_t)r.tlen : (int64_t)r.tlen;
+                            pair = t >= P.dist2 || (P.short_is && t <= P.dist1);
+                        }
+                    } else if (mapped && !mate_mapped) {
+                        unmap = true;
+                    }
+                }
+            }
+            gf_taghit hit;
+            hit.rec = rec; hit.gap = g;
+            hit.kind = GF_KIND_CLIP; hit.to_mate = 0;
+            emit_hit(clip, hit, hb, P.out, P.cap, P.n_out);
+            hit.kind = pair ? GF_KIND_DISCORDANT : GF_KIND_UNMAP; hit.to_mate = 1;
+            emit_hit(pair || unmap, hit, hb, P.out, P.cap, P.n_out);
+            if (more) ++g;
+        }
+        tag_wave_sync();
+        live_n = base;
     };
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -130,7 +197,6 @@ __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
             nb.y = __shfl_down(v[u].y, 1);
             bool live = !(lane & 1) && h < n_half;
             gf_alnrec r = {};
-            uint32_t g = 0, g_end = 0;
             if (live) {
                 r.pos = v[u].x; r.mate_pos = v[u].y; r.tlen = (int32_t)v[u].z; r.ref = v[u].w;
                 live = r.ref < P.n_scaffolds;
@@ -149,57 +215,21 @@ __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
                 const uint32_t b0 = P.bin_off[r.ref], nbin = P.bin_off[r.ref + 1] - b0, bi = r.pos >> P.bin_shift;
                 live = bi < nbin && ((bins[(b0 + bi) >> 5] >> ((b0 + bi) & 31)) & 1u);
             }
-            if (!__any(live)) continue;
+            // survivors (a few per mille) are queued; the window search below runs on 64 of them at a time instead of
+            // once per 1-KiB load with one or two busy lanes
+            const unsigned long long lb = __ballot(live);
+            if (!lb) continue;
             if (live) {
-                r.mate_ref = nb.x; r.flag = (uint16_t)(nb.y & 0xFFFF); r.mapq = (uint8_t)((nb.y >> 16) & 0xFF);
-                r.clipflag = (uint8_t)(nb.y >> 24);
-                g = P.scaf_off[r.ref];
-                g_end = P.scaf_off[r.ref + 1];
-                // first gap whose right window can still reach POS: end + dist2 > pos  (ends ascend)
-                uint32_t lo = g, hi = g_end;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if ((int64_t)P.gaps[mid].end + P.dist2 > (int64_t)r.pos) hi = mid; else lo = mid + 1;
-                }
-                g = lo;
+                LiveRec q;
+                q.pos = r.pos; q.ref = r.ref; q.tlen = r.tlen; q.mate_ref = nb.x; q.meta = nb.y; q.rec = (uint32_t)(h >> 1);
+                wlive[live_n + __popcll(lb & ((1ull << lane) - 1))] = q;
             }
-            const int64_t pos = r.pos;
-            const uint32_t rec = (uint32_t)(h >> 1);
-            // walk the (few) gaps whose windows can contain POS; lanes without work idle through the ballots
-            while (true) {
-                bool more = live && g < g_end && (int64_t)P.gaps[g].start - P.dist2 < pos;
-                if (!__any(more)) break;
-                bool clip = false, pair = false, unmap = false;
-                if (more) {
-                    const gf_gap gp = P.gaps[g];
-                    const int64_t il = (int64_t)gp.start - pos, ir = pos - (int64_t)gp.end;
-                    int tag = -1;  // 0: 0c, 1: 0d, 2: 1c, 3: 1d
-                    if (il >= 0 && il < P.dist2) tag = il <= P.clip_dist ? 0 : 1;
-                    else if (ir >= 0 && ir < P.dist2) tag = ir <= P.clip_dist ? 2 : 3;
-                    if (tag >= 0) {
-                        clip = (tag == 0 && r.clipflag >= 2) || (tag == 2 && (r.clipflag == 1 || r.clipflag == 3));
-                        const bool mapped = (r.flag & 0x4) == 0, mate_mapped = (r.flag & 0x8) == 0;
-                        if (mapped && mate_mapped && (int)r.mapq >= P.anchor_mapq) {
-                            if (r.mate_ref != r.ref) pair = true;
-                            else {
-                                const int64_t t = r.tlen < 0 ? -(int64_t)r.tlen : (int64_t)r.tlen;
-                                pair = t >= P.dist2 || (P.short_is && t <= P.dist1);
-                            }
-                        } else if (mapped && !mate_mapped) {
-                            unmap = true;
-                        }
-                    }
-                }
-                gf_taghit hit;
-                hit.rec = rec; hit.gap = g;
-                hit.kind = GF_KIND_CLIP; hit.to_mate = 0;
-                emit_hit(clip, hit, hb, P.out, P.cap, P.n_out);
-                hit.kind = pair ? GF_KIND_DISCORDANT : GF_KIND_UNMAP; hit.to_mate = 1;
-                emit_hit(pair || unmap, hit, hb, P.out, P.cap, P.n_out);
-                if (more) ++g;
-            }
+            live_n += (uint32_t)__popcll(lb);   // < 64 + 32 <= LIVEQ
+            tag_wave_sync();
+            if (live_n >= 64) drain();
         }
     }
+    while (live_n) drain();
     if (P.low && low_n) flush_low();
     flush_hits(hb, P.out, P.cap, P.n_out);
 }
