@@ -42,6 +42,7 @@ struct AsmParams {
     uint32_t* cnt_counts;
     uint32_t cnt_cap;
     uint32_t lds_words;        // dynamic LDS given to the staged pool
+    uint32_t* next_gap;        // work counter, zero at launch
     unsigned long long* dbg;   // diagnostic builds only: 8 wall-clock stamps per gap (100 MHz), or null
 };
 
@@ -91,6 +92,20 @@ __device__ __forceinline__ uint32_t pv_stream32(const PoolView& V, uint64_t bit)
 template <bool W>
 __device__ __forceinline__ K128 pv_kmer(const PoolView& V, uint32_t inst, int len) {
     const uint32_t r = inst / V.L, off = inst - r * V.L;
+    const uint64_t bit = (uint64_t)r * V.rb * 8 + 2ull * off;
+    K128 v;
+    v.hi = ((uint64_t)pv_stream32(V, bit) << 32) | pv_stream32(V, bit + 32);
+    v.lo = 0;
+    if (!W) {
+        v.hi &= ~0ull << (64 - 2 * len);
+        return v;
+    }
+    if (len > 32) v.lo = ((uint64_t)pv_stream32(V, bit + 64) << 32) | pv_stream32(V, bit + 96);
+    return mask_k(v, len);
+}
+// same for a (read, offset) pair: no division
+template <bool W>
+__device__ __forceinline__ K128 pv_kmer_at(const PoolView& V, uint32_t r, uint32_t off, int len) {
     const uint64_t bit = (uint64_t)r * V.rb * 8 + 2ull * off;
     K128 v;
     v.hi = ((uint64_t)pv_stream32(V, bit) << 32) | pv_stream32(V, bit + 32);
@@ -250,7 +265,14 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
     const int k = (int)P.k, kv = (int)P.kv;
     const uint32_t per = P.k - P.kv + 1;
 
-    for (uint32_t g = blockIdx.x; g < P.n_pools; g += gridDim.x) {
+    // gaps are handed out through one counter: pool sizes differ, a static stride left CUs idle behind the largest gaps
+    __shared__ uint32_t s_gap;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_gap = atomicAdd(P.next_gap, 1u);
+        __syncthreads();
+        const uint32_t g = s_gap;
+        if (g >= P.n_pools) break;
         const uint64_t r0 = P.pool_off[g], r1 = P.pool_off[g + 1];
         const uint32_t n_r = (uint32_t)(r1 - r0);
         if (n_r == 0) continue;
@@ -305,6 +327,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         // ---- P1: count canonical k-mers; remember each distinct k-mer's slot.  Optimistic LDS table first.
         Tab tab;
         tab.g = gtab;
+        bool keyslot = false;
+        uint32_t* dist_inst = P.nodes + 3 * inst_off;   // key-slot mode: instance id of the q-th distinct k-mer
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool use_lds = attempt == 0 && r_words / 2 >= 1024;
             if (attempt == 0 && !use_lds) continue;
@@ -312,10 +336,65 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             tab.off = R;
             tab.cap = use_lds ? r_words / 2 : gcap;
             const uint32_t limit = use_lds ? tab.cap - tab.cap / 4 : 0xFFFFFFFFu;
+            // Key-slot mode (LDS table, k <= 31, min_count <= 3, assembly): a slot holds the 62-bit canonical key itself plus a
+            // 2-bit saturating count in the spare low bits, so a repeat occurrence — most instances at sequencing depth —
+            // costs one 8-byte LDS read and a compare: no key re-derivation from the reads, and no atomic once the count
+            // has saturated.  The instance id of each distinct k-mer goes to a side list (the node arrays are idle here).
+            keyslot = use_lds && !W && k <= 31 && P.min_count <= 3 && !P.cnt_keys;
             if (use_lds) {
-                for (uint32_t i = tid; i < tab.cap; i += ASM_THREADS) tab.store(i, EMPTY64);
+                const unsigned long long e = keyslot ? ~0ull : EMPTY64;
+                for (uint32_t i = tid; i < tab.cap; i += ASM_THREADS) tab.store(i, e);
                 __syncthreads();
             }
+            if (keyslot) {
+                // positions are strided over the threads; (read, offset) advance incrementally (no division per k-mer).
+                // (Measured and dropped: rolling the k-mers along per-thread runs — fewer instructions per k-mer but longer
+                // runs per thread; 59 vs 48 us per gap, the phase is bound by the dependent LDS table accesses.)
+                const uint32_t dr = ASM_THREADS / npos, dp = ASM_THREADS - dr * npos;
+                uint32_t r = tid / npos, p = tid - r * npos;
+                for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS, r += dr, p += dp) {
+                    if (s_cnt[6]) break;
+                    if (p >= npos) { p -= npos; ++r; }
+                    const uint32_t inst = r * P.read_len + p;
+                    const unsigned long long fw = pv_kmer_at<false>(V, r, p, k).hi;
+                    const unsigned long long rc = revcomp_w<false>(K128{fw, 0}, k).hi;
+                    if (P.nmask) {
+                        bool bad = false;
+                        for (uint32_t q = p; q < p + P.k; ++q)
+                            if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
+                        if (bad) continue;
+                    }
+                    K128 key;
+                    key.hi = fw < rc ? fw : rc;
+                    key.lo = 0;
+                    uint32_t sl = slot_of(key, tab.cap);
+                    bool placed = false;
+                    for (uint32_t probes = 0; probes < tab.cap; ++probes) {
+                        unsigned long long v = tab.load(sl);
+                        if (v == ~0ull) {
+                            v = tab.cas(sl, ~0ull, key.hi | 1ull);
+                            if (v == ~0ull) {   // first occurrence
+                                const uint32_t q = atomicAdd(&s_cnt[4], 1u);
+                                if (q >= limit) s_cnt[6] = 1;
+                                if (q < n_unit) { list_a[q] = sl; dist_inst[q] = inst; }
+                                placed = true;
+                                break;
+                            }
+                        }
+                        if ((v & ~3ull) == key.hi) {
+                            while ((v & 3ull) != 3ull) {   // saturating increment
+                                const unsigned long long o = tab.cas(sl, v, v + 1);
+                                if (o == v) break;
+                                v = o;
+                            }
+                            placed = true;
+                            break;
+                        }
+                        sl = sl + 1 == tab.cap ? 0 : sl + 1;
+                    }
+                    if (!placed) s_cnt[6] = 1;
+                }
+            } else
             for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
                 if (use_lds && s_cnt[6]) break;
                 const uint32_t r = inst_i / npos, p = inst_i - r * npos;
@@ -355,8 +434,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             if (i < n_dist) {
                 const uint32_t sl = list_a[i];
                 const unsigned long long v = tab.load(sl);
-                id = (uint32_t)v;
-                c = (uint32_t)(v >> 32);
+                id = keyslot ? dist_inst[i] : (uint32_t)v;
+                c = keyslot ? (uint32_t)(v & 3ull) : (uint32_t)(v >> 32);
                 keep = c >= P.min_count;
                 if (tab_global) tab.store(sl, EMPTY64);
             }
@@ -754,7 +833,11 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     GF_HIP(ctx, hipMemsetAsync(d_seq_len, 0, 8, ctx->stream));
     if (n_pools) GF_HIP(ctx, hipMemsetAsync(d_gap_error, 0, n_pools * 4, ctx->stream));
     if (n_pools == 0) return GF_OK;
+    if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
+    uint32_t* d_next = (uint32_t*)ctx->counters.p + 8;
+    GF_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
     AsmParams P;
+    P.next_gap = d_next;
     const uint32_t rb = (uint32_t)((read_len + 3) / 4);
     P.reads32 = (const uint32_t*)d_pool;
     P.n_words = ((uint64_t)total_reads * rb) / 4;
