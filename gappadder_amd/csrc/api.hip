@@ -161,6 +161,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     }
     if (!strcmp(name, "screen_variant")) { ctx->screen_variant = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_dbg_ptr")) { ctx->asm_dbg = (void*)(uintptr_t)value; return GF_OK; }
+    if (!strcmp(name, "asm_keyslot")) { ctx->asm_keyslot = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_lds_pool_kb")) { ctx->asm_lds_pool_kb = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_lds_log2_max")) {
         ctx->screen_lds_log2_max = std::max(15, std::min(20, (int)value));
@@ -380,7 +381,11 @@ int gf_assemble(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, const 
         GF_HIP(ctx, hipMemcpyAsync(&sl, d_cnt + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
         if (n_pools) GF_HIP(ctx, hipMemcpyAsync(errs.data(), d_err, n_pools * 4, hipMemcpyDeviceToHost, ctx->stream));
         GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t e : errs) if (e) return GF_E_UNSUPPORTED;  // a pool overflowed its tables (ids/slots are 32-bit)
+        for (size_t gi = 0; gi < errs.size(); ++gi)
+            if (errs[gi]) {   // a pool overflowed a table or list (see the ASM_ERR_* bits in assemble.hip)
+                ctx->last_error = "assembly workspace overflow in pool " + std::to_string(gi) + " (code " + std::to_string(errs[gi]) + ")";
+                return GF_E_UNSUPPORTED;
+            }
         if (nc > contig_cap || sl > seq_cap || nc_total + nc > contig_cap || seq_total + sl > seq_cap) {
             nospace = true;
             nc_total += nc;

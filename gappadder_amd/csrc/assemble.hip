@@ -43,8 +43,12 @@ struct AsmParams {
     uint32_t cnt_cap;
     uint32_t lds_words;        // dynamic LDS given to the staged pool
     uint32_t* next_gap;        // work counter, zero at launch
+    uint32_t keyslot;          // allow the key-in-slot count phase
     unsigned long long* dbg;   // diagnostic builds only: 8 wall-clock stamps per gap (100 MHz), or null
 };
+
+// gap_error bits
+constexpr uint32_t ASM_ERR_IDS = 1, ASM_ERR_KTABLE = 2, ASM_ERR_NTABLE = 4, ASM_ERR_NLIST = 8, ASM_ERR_WALKS_PAR = 16, ASM_ERR_WALKS = 32;
 
 // node meta bits (high word of a table slot in the graph phases)
 constexpr uint32_t M_OUT = 0xFu, M_IN = 0xF0u, M_START0 = 1u << 8, M_START1 = 1u << 9, M_MULT_SHIFT = 12;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         const uint64_t n_unit64 = (uint64_t)n_r * unit;
         const uint64_t inst_off = r0 * unit;
         if (n_unit64 >= (1ull << 30) || (uint64_t)n_r * P.read_len >= 0xFFFFFFF0ull) {  // ids are 32-bit
-            if (tid == 0) P.gap_error[g] = 1;
+            if (tid == 0) P.gap_error[g] = ASM_ERR_IDS;
             continue;
         }
         const uint32_t n_inst = (uint32_t)((uint64_t)n_r * npos);   // k-mer positions
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             // 2-bit saturating count in the spare low bits, so a repeat occurrence — most instances at sequencing depth —
             // costs one 8-byte LDS read and a compare: no key re-derivation from the reads, and no atomic once the count
             // has saturated.  The instance id of each distinct k-mer goes to a side list (the node arrays are idle here).
-            keyslot = use_lds && !W && k <= 31 && P.min_count <= 3 && !P.cnt_keys;
+            keyslot = P.keyslot && use_lds && !W && k <= 31 && P.min_count <= 3 && !P.cnt_keys;
             if (use_lds) {
                 const unsigned long long e = keyslot ? ~0ull : EMPTY64;
                 for (uint32_t i = tid; i < tab.cap; i += ASM_THREADS) tab.store(i, e);
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const K128 key = canonical_w<W>(pv_kmer<W>(V, inst, k), k);
                 bool fresh;
                 const uint32_t s = table_upsert<W>(tab, V, key, inst, k, 1u, &fresh);
-                if (s == EMPTY32) { if (use_lds) s_cnt[6] = 1; else s_cnt[3] = 1; continue; }
+                if (s == EMPTY32) { if (use_lds) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_KTABLE); continue; }
                 if (fresh) {
                     const uint32_t q = atomicAdd(&s_cnt[4], 1u);
                     if (q >= limit) s_cnt[6] = 1;
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
         wg_phase_sync();
         if (P.cnt_keys) {
-            if (tid == 0) { *P.n_contigs = s_cnt[0]; if (s_cnt[3]) P.gap_error[g] = 1; }
+            if (tid == 0) { *P.n_contigs = s_cnt[0]; if (s_cnt[3]) P.gap_error[g] = s_cnt[3]; }
             __syncthreads();
             continue;
         }
@@ -512,11 +516,11 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     const uint32_t ninst = fwd ? inst + o : inst + (per - 1 - o);  // same read, shifted offset
                     bool fresh;
                     const uint32_t sl = table_upsert<W>(ntab, V, A, ninst, kv, 1u << M_MULT_SHIFT, &fresh);
-                    if (sl == EMPTY32) { if (graph_lds) s_cnt[6] = 1; else s_cnt[3] = 1; break; }
+                    if (sl == EMPTY32) { if (graph_lds) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_NTABLE); break; }
                     if (fresh) {
                         const uint32_t q = atomicAdd(&s_cnt[5], 1u);
                         if (graph_lds && q >= nb) { s_cnt[6] = 1; break; }
-                        if (q < n_unit) list_a[q] = sl; else s_cnt[3] = 1;
+                        if (q < n_unit) list_a[q] = sl; else atomicOr(&s_cnt[3], ASM_ERR_NLIST);
                     }
                     if (ps != EMPTY32) {  // edge prev -> this
                         const uint32_t c_out = kbase(t, (int)(o - 1) + kv), c_in = kbase(t, (int)o - 1);
@@ -649,11 +653,12 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     const K128 opp = (tail & 1) ? e : revcomp_w<W>(e, kv);
                     if (!(opp < first)) {
                         q = atomicAdd(&s_cnt[1], 1u);
-                        if (q >= rec_cap / 2 || q >= cacc_cap) { s_cnt[3] = 1; q = EMPTY32; }
+                        if (q >= rec_cap / 2) { atomicOr(&s_cnt[3], ASM_ERR_WALKS_PAR); q = EMPTY32; }
                         else {
                             rec[4 * q] = o;
                             rec[4 * q + 1] = len;
-                            cacc[q] = 0;
+                            rec[4 * q + 3] = 0;              // coverage sum when the LDS accumulators do not reach this far
+                            if (q < cacc_cap) cacc[q] = 0;
                             atomicAdd(&s_seq[0], (unsigned long long)(len + P.kv - 1));
                         }
                     }
@@ -662,11 +667,12 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             }
             wg_phase_sync();
             const uint32_t n_emit = s_cnt[1] < rec_cap / 2 ? s_cnt[1] : rec_cap / 2;
+            const bool cacc_lds = n_emit <= cacc_cap;   // else (LDS nearly full of nodes): sums accumulate in the global records
             if (tid == 0) {
                 s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
                 s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
                 s_seq[0] = 0;
-                if (s_cnt[3]) P.gap_error[g] = 1;
+                if (s_cnt[3]) P.gap_error[g] = s_cnt[3];
             }
             __syncthreads();
             ASM_STAMP(5);
@@ -686,7 +692,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 if (q == EMPTY32 || q >= n_emit) continue;
                 const unsigned long long off = s_seq[1] + rec[4 * q + 2];
                 const uint32_t len = rec[4 * q + 1] + P.kv - 1;
-                atomicAdd(&cacc[q], nmeta.get(o >> 1) >> M_MULT_SHIFT);
+                if (cacc_lds) atomicAdd(&cacc[q], nmeta.get(o >> 1) >> M_MULT_SHIFT);
+                else atomicAdd(&rec[4 * q + 3], nmeta.get(o >> 1) >> M_MULT_SHIFT);
                 if (off + len > P.seq_cap) continue;
                 const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(o >> 1), kv), kv);
                 const K128 ok = (o & 1) ? revcomp_w<W>(x, kv) : x;
@@ -702,7 +709,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 if (ci < P.contig_cap) {
                     gf_contig ct;
                     ct.gap = g; ct.k = (uint16_t)P.k; ct.kv = (uint16_t)P.kv; ct.n_nodes = rec[4 * q + 1];
-                    ct.length = rec[4 * q + 1] + P.kv - 1; ct.cov_sum = cacc[q]; ct.reserved = 0;
+                    ct.length = rec[4 * q + 1] + P.kv - 1; ct.cov_sum = cacc_lds ? cacc[q] : __hip_atomic_load(&rec[4 * q + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // from L2, where the atomics landed
+                    ct.reserved = 0;
                     ct.seq_off = s_seq[1] + rec[4 * q + 2];
                     P.contigs[ci] = ct;
                 }
@@ -728,7 +736,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     const K128 opp = (cur & 1) ? e : revcomp_w<W>(e, kv);  // first kv-mer of the opposite walk = revcomp_w<W>(last kv-mer)
                     if (opp < first) continue;
                     const uint32_t q = atomicAdd(&s_cnt[1], 1u);
-                    if (q >= rec_cap) { s_cnt[3] = 1; continue; }
+                    if (q >= rec_cap) { atomicOr(&s_cnt[3], ASM_ERR_WALKS); continue; }
                     rec[2 * q] = (ni << 1) | d;
                     rec[2 * q + 1] = nodes;
                     atomicAdd(&s_seq[0], (unsigned long long)(nodes + P.kv - 1));
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
                 s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
                 s_seq[0] = 0;
-                if (s_cnt[3]) P.gap_error[g] = 1;
+                if (s_cnt[3]) P.gap_error[g] = s_cnt[3];
             }
             __syncthreads();
             ASM_STAMP(5);
@@ -838,6 +846,7 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     GF_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
     AsmParams P;
     P.next_gap = d_next;
+    P.keyslot = (uint32_t)ctx->asm_keyslot;
     const uint32_t rb = (uint32_t)((read_len + 3) / 4);
     P.reads32 = (const uint32_t*)d_pool;
     P.n_words = ((uint64_t)total_reads * rb) / 4;

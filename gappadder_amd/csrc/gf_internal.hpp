@@ -76,6 +76,7 @@ struct gf_ctx {
     int screen_np_override = -1;
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)
     int asm_lds_pool_kb = 152;
+    int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
     void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)
     // tagger coarse bin map (rebuilt when dist2 changes)
     std::vector<uint32_t> bin_host;

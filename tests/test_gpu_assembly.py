@@ -101,6 +101,26 @@ def test_pool_larger_than_the_lds_stage_uses_global_reads(gf):
         assert got2 == got
 
 
+@pytest.mark.parametrize("n_reads", [1034, 2100])
+def test_deep_noisy_pool(gf, n_reads):
+    """150-400x depth with 1 % errors: tens of thousands of error k-mers pass min_count 2, the node arrays fill the LDS and
+    the per-contig coverage sums fall back to the global walk records (once an ASM_ERR_WALKS_PAR overflow)."""
+    rng = np.random.RandomState(n_reads)
+    g = LUT[rng.randint(0, 4, 2600)].tobytes()
+    L = 150
+    reads = tiled_reads(g, L, n_reads, rng)
+    for i in range(len(reads)):
+        b = bytearray(reads[i])
+        for pos in np.flatnonzero(rng.rand(L) < 0.01):
+            b[pos] = LUT[(list(b"ACGT").index(b[pos]) + 1 + rng.randint(3)) % 4]
+        reads[i] = bytes(b)
+    pool = b"".join(reads)
+    got, _ = _gpu_assemble(gf, [pool], L, [(31, 29)])
+    exp = CO.assemble_pool(pool, L, 31, 29)
+    assert len(exp) > 50
+    assert got[(0, 31, 29)] == exp
+
+
 def test_count_kmers_matches_oracle(gf):
     from gappadder_amd.hip_api import GapFill
     c = S.small_case(seed=9, n_pairs=6000, n_frac=0.1)
