@@ -11,6 +11,8 @@
 //   P3 graph      each survivor contributes k-kv+1 kv-mer nodes and k-kv edges (4+4 adjacency bits per node)
 //   P4 starts     oriented nodes whose in-degree != 1, or whose predecessor branches, start a unitig
 //   P5 walk       each start walks its unitig; the walk whose first kv-mer <= the opposite walk's is emitted
+#include <type_traits>
+
 #include "gf_internal.hpp"
 
 namespace gf {
@@ -340,24 +342,39 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             tab.off = R;
             tab.cap = use_lds ? r_words / 2 : gcap;
             const uint32_t limit = use_lds ? tab.cap - tab.cap / 4 : 0xFFFFFFFFu;
-            // Key-slot mode (LDS table, k <= 31, min_count <= 3, assembly): a slot holds the 62-bit canonical key itself plus a
-            // 2-bit saturating count in the spare low bits, so a repeat occurrence — most instances at sequencing depth —
-            // costs one 8-byte LDS read and a compare: no key re-derivation from the reads, and no atomic once the count
-            // has saturated.  The instance id of each distinct k-mer goes to a side list (the node arrays are idle here).
-            keyslot = P.keyslot && use_lds && !W && k <= 31 && P.min_count <= 3 && !P.cnt_keys;
+            // Key-slot mode (k <= 31, min_count <= 3, assembly): a slot holds the 62-bit canonical key itself plus a 2-bit
+            // saturating count in the spare low bits.  A repeat occurrence — most instances at
+            // sequencing depth — costs one 8-byte read and a compare: no key re-derivation from the reads, and no atomic
+            // once the count has saturated.  The instance id of each distinct k-mer goes to a side list (the node arrays
+            // are idle here).
+            keyslot = P.keyslot && !W && k <= 31 && P.min_count <= 3 && !P.cnt_keys;
+            // an LDS attempt that is bound to overflow is skipped: at ~1 % errors nearly half of all windows are distinct
+            if (use_lds && keyslot && n_inst / 4 > limit) continue;
+#ifndef GF_KS_COMPLEMENT_LDS
+#define GF_KS_COMPLEMENT_LDS 0
+#endif
+            // the global slice must keep its EMPTY64 pattern, so key|count is stored complemented there; an LDS table is
+            // private to the gap and stores it plain with an all-ones EMPTY
+            const unsigned long long xm = (!use_lds || GF_KS_COMPLEMENT_LDS) ? ~0ull : 0ull;
+            const unsigned long long kempty = xm ? EMPTY64 : ~0ull;
             if (use_lds) {
-                const unsigned long long e = keyslot ? ~0ull : EMPTY64;
+                const unsigned long long e = keyslot ? kempty : EMPTY64;
                 for (uint32_t i = tid; i < tab.cap; i += ASM_THREADS) tab.store(i, e);
                 __syncthreads();
             }
             if (keyslot) {
+                // one instantiation per home of the table, so that every access compiles to ds_* or global_* without a branch
+                auto count_keyslot = [&](auto lds_c) {
+                constexpr bool LDS = decltype(lds_c)::value;
+                Tab t = tab;
+                t.lds = LDS;
                 // positions are strided over the threads; (read, offset) advance incrementally (no division per k-mer).
                 // (Measured and dropped: rolling the k-mers along per-thread runs — fewer instructions per k-mer but longer
                 // runs per thread; 59 vs 48 us per gap, the phase is bound by the dependent LDS table accesses.)
                 const uint32_t dr = ASM_THREADS / npos, dp = ASM_THREADS - dr * npos;
                 uint32_t r = tid / npos, p = tid - r * npos;
                 for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS, r += dr, p += dp) {
-                    if (s_cnt[6]) break;
+                    if (LDS && s_cnt[6]) break;
                     if (p >= npos) { p -= npos; ++r; }
                     const uint32_t inst = r * P.read_len + p;
                     const unsigned long long fw = pv_kmer_at<false>(V, r, p, k).hi;
@@ -371,13 +388,13 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     K128 key;
                     key.hi = fw < rc ? fw : rc;
                     key.lo = 0;
-                    uint32_t sl = slot_of(key, tab.cap);
+                    uint32_t sl = slot_of(key, t.cap);
                     bool placed = false;
-                    for (uint32_t probes = 0; probes < tab.cap; ++probes) {
-                        unsigned long long v = tab.load(sl);
-                        if (v == ~0ull) {
-                            v = tab.cas(sl, ~0ull, key.hi | 1ull);
-                            if (v == ~0ull) {   // first occurrence
+                    for (uint32_t probes = 0; probes < t.cap; ++probes) {
+                        unsigned long long v = t.load(sl);
+                        if (v == kempty) {
+                            v = t.cas(sl, kempty, (key.hi | 1ull) ^ xm);
+                            if (v == kempty) {   // first occurrence
                                 const uint32_t q = atomicAdd(&s_cnt[4], 1u);
                                 if (q >= limit) s_cnt[6] = 1;
                                 if (q < n_unit) { list_a[q] = sl; dist_inst[q] = inst; }
@@ -385,19 +402,21 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                                 break;
                             }
                         }
-                        if ((v & ~3ull) == key.hi) {
-                            while ((v & 3ull) != 3ull) {   // saturating increment
-                                const unsigned long long o = tab.cas(sl, v, v + 1);
+                        if (((v ^ xm) & ~3ull) == key.hi) {
+                            while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment
+                                const unsigned long long o = t.cas(sl, v, ((v ^ xm) + 1) ^ xm);
                                 if (o == v) break;
                                 v = o;
                             }
                             placed = true;
                             break;
                         }
-                        sl = sl + 1 == tab.cap ? 0 : sl + 1;
+                        sl = sl + 1 == t.cap ? 0 : sl + 1;
                     }
-                    if (!placed) s_cnt[6] = 1;
+                    if (!placed) { if (LDS) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_KTABLE); }
                 }
+                };
+                if (use_lds) count_keyslot(std::true_type{}); else count_keyslot(std::false_type{});
             } else
             for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
                 if (use_lds && s_cnt[6]) break;
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const uint32_t sl = list_a[i];
                 const unsigned long long v = tab.load(sl);
                 id = keyslot ? dist_inst[i] : (uint32_t)v;
-                c = keyslot ? (uint32_t)(v & 3ull) : (uint32_t)(v >> 32);
+                c = keyslot ? (uint32_t)((tab_global ? ~v : (GF_KS_COMPLEMENT_LDS ? ~v : v)) & 3ull) : (uint32_t)(v >> 32);
                 keep = c >= P.min_count;
                 if (tab_global) tab.store(sl, EMPTY64);
             }
