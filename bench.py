@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--exchange", action="store_true",
+                    help="N > 1: all-to-all-v of the per-gap pools to one owner rank per gap before the assembly (off: every rank "
+                         "assembles the gaps from its own shard of the reads; the only collective is the final gather)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -65,6 +68,7 @@ def main():
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from gappadder_amd import _lib as B
+    from gappadder_amd import sharding as SH
     from gappadder_amd.hip_api import GapFill
 
     presets = {   # (seed, scaffold_len, n_scaffolds, gaps_per_scaffold, gap_len, reads per GPU, k)
@@ -143,6 +147,8 @@ def main():
     rows["src_scaffold"], rows["src_gap"] = gaps["scaffold"][disc["gap"]], gaps["idx_in_scaffold"][disc["gap"]]
     rows = np.sort(rows, order=["mate_scaffold", "mate_pos", "src_scaffold", "src_gap"])
 
+    exch_rows = [0]
+
     def step():
         recruit()
         rc = lib.gf_tag_low_mapq_compact_dev(h2, d_low.data_ptr(), cp + 112, low_cap, B._p(rows), len(rows), d_lhits.data_ptr(),
@@ -157,7 +163,18 @@ def main():
                                               d_keys.data_ptr(), key_cap, cp + 48) == 0
         assert lib.gf_build_pools_dev(h, d_reads.data_ptr(), n_reads, L, d_keys.data_ptr(), cp + 48, key_cap, d_pool.data_ptr(),
                                       pool_cap, d_pool_off.data_ptr(), d_pool_ids.data_ptr(), cp + 96) == 0
-        rc = lib.gf_assemble_dev(h, d_pool.data_ptr(), None, d_pool_off.data_ptr(), len(gaps), pool_cap, L, k, kv, 2, 40,
+        pool_ptr, off_ptr, pool_rows = d_pool.data_ptr(), d_pool_off.data_ptr(), pool_cap
+        if args.exchange and world > 1:
+            # optional exchange step: every gap gets ONE owner that holds the recruits of all ranks, so the
+            # assembled gaps equal a single-process run over all reads; costs a host sync (row counts) + one all-to-all-v
+            gf.sync()
+            n_rows = int(d_pool_off[-1])
+            merged, moff = SH.exchange_pools(d_pool[:n_rows * rb].view(n_rows, rb), d_pool_off, coll_device=coll_dev)
+            torch.cuda.synchronize()
+            step.keep = (merged, moff)     # alive until the assembly kernel has run
+            exch_rows[0] = int(merged.shape[0])
+            pool_ptr, off_ptr, pool_rows = merged.data_ptr(), moff.data_ptr(), max(1, int(merged.shape[0]))
+        rc = lib.gf_assemble_dev(h, pool_ptr, None, off_ptr, len(gaps), pool_rows, L, k, kv, 2, 40,
                                  d_ctg.data_ptr(), contig_cap, cp + 64, d_seq.data_ptr(), seq_cap, cp + 80, d_gap_err.data_ptr())
         assert rc == 0, rc
 
@@ -198,7 +215,6 @@ def main():
     ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
     if world > 1:
         # the only collective of the path: gather the assembled sequences of every rank's shard on rank 0 (RCCL)
-        from gappadder_amd import sharding as SH
         seq_local = d_seq[:n_seq].cpu().numpy().tobytes()
         payload = SH.encode_contigs([(int(c["gap"]), int(c["k"]), int(c["kv"]), int(c["n_nodes"]), int(c["cov_sum"]),
                                       seq_local[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode()) for c in ctg])
@@ -231,7 +247,9 @@ def main():
                                    "records) per GPU, k=%d kv=%d, IS 300/30; step = k-mer screen + alignment tagger + second hop + "
                                    "per-gap pools + per-gap assembly" % (args.config, len(gaps), glen, nscf, slen / 1e6, n_reads, L, k, kv),
                        "reads_per_gpu": n_reads, "gaps": int(len(gaps)), "k": k, "kv": kv,
-                       "sharding": "reads sharded over ranks, gaps replicated; RCCL only gathers the assembled sequences"},
+                       "sharding": ("reads sharded over ranks, gaps replicated; per-gap pools exchanged to one owner rank per gap (all-to-all-v), "
+                                    "then the assembled sequences gathered" if (args.exchange and world > 1) else
+                                    "reads sharded over ranks, gaps replicated; RCCL only gathers the assembled sequences")},
             "gaps_per_s": world * len(gaps) / (dt / args.steps),
             "gaps_closed_per_s": world * gaps_closed / (dt / args.steps),
             "roofline": {"bound": "hbm", "kernel": "screen_filter (software-pipelined wave kernel with LDS pre-filter when the key set allows it)", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -64,3 +64,63 @@ def test_two_rank_sharding_and_gather_equal_single_rank():
     assert len(parts) == 2 and multi == single and len(single) > 100
     # rank order is preserved inside the gathered list: shard 0's reads precede shard 1's
     assert max(r[3] for r in parts[0]) < min(r[3] for r in parts[1])
+
+
+def _exchange_worker(rank, world, port, n_pairs, batch, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from gappadder_amd import sharding as SH
+    from oracle import c_oracle as CO
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = CO.synth_cfg(scaffold_len=200000, n_scaffolds=4, gaps_per_scaffold=3)
+    gaps, flanks = CO.synth_layout(cfg)
+    a, b = SH.shard_range(n_pairs, rank, world)
+    packed, _ = CO.synth_pairs(cfg, a, b - a)
+    hits = CO.screen_reads(CO.unpack_reads(packed, 150), 150, flanks, 31, threads=2)
+    pools = [sorted(set(int(h["read"]) for h in hits if int(h["gap"]) == g)) for g in range(len(gaps))]
+    rows = np.concatenate([packed[np.array(p, dtype=np.int64)] for p in pools if p] or [np.zeros((0, 38), np.uint8)])
+    off = np.cumsum([0] + [len(p) for p in pools]).astype(np.int64)
+    merged, moff = SH.exchange_pools(torch.from_numpy(rows), torch.from_numpy(off), batch=batch)
+    q.put((rank, merged.numpy().tobytes(), moff.numpy().tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pool_exchange_gives_every_gap_one_owner_with_the_single_rank_pool():
+    """All-to-all-v of the per-gap pools: the owner's merged pool == the pool built from all reads."""
+    sys.path.insert(0, ROOT)
+    from gappadder_amd import sharding as SH
+    from oracle import c_oracle as CO
+    n_pairs, world, batch = 20001, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n_pairs, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        r, blob, moff = q.get(timeout=300)
+        got[r] = (blob, moff)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = CO.synth_cfg(scaffold_len=200000, n_scaffolds=4, gaps_per_scaffold=3)
+    gaps, flanks = CO.synth_layout(cfg)
+    packed, _ = CO.synth_pairs(cfg, 0, n_pairs)
+    hits = CO.screen_reads(CO.unpack_reads(packed, 150), 150, flanks, 31, threads=2)
+    owner = SH.gap_owner(len(gaps), world, batch).tolist()
+    assert sorted(set(owner)) == [0, 1, 2]
+    total = 0
+    for g in range(len(gaps)):
+        ids = sorted(set(int(h["read"]) for h in hits if int(h["gap"]) == g))
+        expect = packed[np.array(ids, dtype=np.int64)].tobytes() if ids else b""
+        for r in range(world):
+            blob, moff = got[r]
+            seg = blob[moff[g] * 38:moff[g + 1] * 38]
+            assert seg == (expect if r == owner[g] else b""), (g, r)
+        total += len(ids)
+    assert total > 100
