@@ -3,8 +3,9 @@
 (Velvet's role); write contigs_{k}_{kv}.fa and the merged contigs.fa with '>{k}_{kv}_' headers.  All gaps of a batch go
 through ONE gf_assemble call per pair instead of >= 5 process launches per (gap, k, kv).
 
-The later rounds of the reference's assemble_pipeline (contig merging with TERefiner/ContigsMerger, bwa-based picking,
-both-unmapped recruitment) are outside this build's scope."""
+assemble_pipeline follows the reference's round structure (assemble_gaps.py:328-366) without its contig-merging steps
+(TERefiner / ContigsMerger): first-round assembly -> pick -> both-unmapped recruitment for the gaps still
+open (collect_both_unmapped_reads.py) -> second-round assembly of those gaps -> pick at anchor 30, then 15."""
 import os
 
 from . import fastq_io
@@ -74,8 +75,10 @@ def run_assembly(id):
 
 
 class GapAssembler:
-    def __init__(self, sf_fai, sf_pos, n_jobs, working_space, kmer_list=None, gf=None):
+    def __init__(self, sf_fai, sf_pos, n_jobs, working_space, kmer_list=None, gf=None, bam_list=None, samtools_path=None):
         global kmer_len_list, working_folder, _gf
+        self.bam_list = list(bam_list or [])
+        self.samtools_path = samtools_path
         if kmer_list is not None:
             kmer_len_list = list(kmer_list)
         self.sf_fai = sf_fai
@@ -102,15 +105,25 @@ class GapAssembler:
         return [k for k in fa_list if k not in picked]
 
     def assemble_pipeline(self):
-        """First round of the reference's pipeline (assemble_gaps.py:328-339): assemble, then pick the gaps whose contigs are
-        anchored by both flanks (anchor length 30 = the reference's first bwa_min_score), then a second pick at 15 (:365-366).
-        The rounds in between (contig merging, both-unmapped recruitment) are outside this build."""
+        """The reference's rounds (assemble_gaps.py:328-366) minus contig merging: assemble; pick the gaps whose contigs are
+        anchored by both flanks (anchor length 30 = the reference's first bwa_min_score); for the gaps still open recruit the
+        both-unmapped pairs that share k-mers with their contigs and assemble again (:344-351); pick at 30, then at 15 (:365)."""
         from .pick_contigs import ContigsSelection
         fa_list = self.prepare_list()
         self.assembly(fa_list)
         sf_picked = working_folder + "../picked_seqs.fa"
         cs = ContigsSelection(working_folder)
-        n30 = cs.pick_full_constructed_contigs(30, fa_list, sf_picked)
+        closed = cs.pick_full_constructed_contigs(30, fa_list, sf_picked)
         remain = self.pick_already_constructed(cs, fa_list, sf_picked)
-        n15 = cs.pick_full_constructed_contigs(15, remain, sf_picked)
-        return {"gaps": len(fa_list), "closed": n30 + n15}
+        recruited = 0
+        if self.bam_list and self.samtools_path and remain:
+            from .collect_both_unmapped_reads import BothUnmappedReadsCollector
+            ks = [int(k) for k, _ in kmer_len_list if 16 <= int(k) <= 64]
+            burc = BothUnmappedReadsCollector(working_folder, self.samtools_path, _ctx(), min(ks) if ks else 31)
+            burc.collect_both_unmapped_reads(self.bam_list, remain)
+            recruited = sum(1 for key in remain if os.path.exists("%sunmapped_reads/%s.fastq" % (working_folder, key)))
+            self.assembly_given_list(remain)
+            closed += cs.pick_full_constructed_contigs(30, remain, sf_picked)
+            remain = self.pick_already_constructed(cs, remain, sf_picked)
+        closed += cs.pick_full_constructed_contigs(15, remain, sf_picked)
+        return {"gaps": len(fa_list), "closed": closed, "second_round_gaps": recruited}

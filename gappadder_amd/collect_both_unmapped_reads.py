@@ -1,0 +1,131 @@
+"""Second-round recruitment of pairs with BOTH mates unmapped (mirrors collect_both_unmapped_reads.py).
+
+File side — identical to the reference and pinned by the reference-generated fixture tests/golden/twolib/round2.json.gz:
+  run_collect_both_unmapped            `samtools view -f 12 BAM` -> BAM.both_unmapped.sam and BAM.both_unmapped.fq with names
+                                       `@{QNAME}_2` when FLAG > 128 (sic: a comparison, not a bit test, :26) else `_1`
+                                       (collect_both_unmapped_reads.py:14-34)
+  collect_both_unmapped_reads          cat of the per-BAM files -> both_unmapped.fq; both_unmapped_1.fq / _2.fq list, in order
+                                       of the `_1` records, `@{QNAME}` + the mate-1 resp. mate-2 record (:187-236)
+  align_unmapped_to_contigs            gap_contigs_all.fa = every contig of every listed gap as `>{gapKey}-{contigId}` + one
+                                       sequence line (:136-153); recruited records are APPENDED to gap_reads/{gapKey}.fastq
+                                       and written to unmapped_reads/{gapKey}.fastq as `@{name}_{1|2}` + seq/+/qual (:113-124)
+
+Recruitment side — where the reference runs `bwa mem -a` of the pairs against the contigs and keeps every read with an
+alignment record on a contig of the gap, plus its mate when the mate is unmapped or lies in another gap's contigs (:56-103) —
+this build has no aligner: a read is recruited for a gap when it shares at least one canonical k-mer with that gap's contigs
+(the same exact GPU screen that recruits against the flanks, gf_screen_reads), and its mate always comes along.  That is a
+definition of this build (bwa is an unpinned third-party tool, absent here: parity unpinned for this step), checked against
+the oracle's k-mer predicate."""
+import os
+import subprocess
+
+from . import fastq_io
+from .gnrt_pos_true_seqs import read_fasta
+from .hip_api import GapFill
+
+
+def run_collect_both_unmapped(sf_bam, samtools_path):
+    sf_both_unmap = sf_bam + ".both_unmapped.sam"
+    with open(sf_both_unmap, "w") as f:
+        subprocess.run([samtools_path, "view", "-f", "12", sf_bam], check=True, stdout=f)
+    with open(sf_both_unmap) as fin, open(sf_bam + ".both_unmapped.fq", "w") as fout:
+        for line in fin:
+            fields = line.split()
+            fout.write("@" + fields[0] + ("_2\n" if int(fields[1]) > 128 else "_1\n"))      # :26-29
+            fout.write(fields[9] + "\n+\n" + fields[10] + "\n")
+
+
+def kmer_recruit_unmapped(gf, gap_contigs, names, seqs, k, min_hits=1):
+    """gap_contigs: [[contig sequence, ...] per gap]; names/seqs: the both-unmapped records (`{q}_1` / `{q}_2`).
+    -> per gap, the list of record indices recruited (a hit recruits the record and its mate), in record order."""
+    import numpy as np
+    from . import _lib as B
+    n_gaps = len(gap_contigs)
+    out = [[] for _ in range(n_gaps)]
+    if not n_gaps or not any(len(s) >= k for s in seqs):      # e.g. SEQ '*' in the SAM text: nothing to screen
+        return out
+    gaps = np.zeros(n_gaps, dtype=B.GAP)          # coordinates are irrelevant to the screen
+    gaps["idx_in_scaffold"] = np.arange(n_gaps) + 1
+    # the contigs of a gap, joined by N (k-mers touching a non-ACGT byte are not indexed), play the role of a flank
+    gf.set_gaps(gaps, 1, [("N".join(c), "") for c in gap_contigs])
+    mate = {}
+    for i, nm in enumerate(names):
+        mate[nm] = i
+    by_len = {}
+    for i, s in enumerate(seqs):
+        by_len.setdefault(len(s), []).append(i)
+    got = [set() for _ in range(n_gaps)]
+    for L, idx in by_len.items():
+        if L < k:
+            continue
+        packed, nm, _, _ = fastq_io.pack_pools([[seqs[i] for i in idx]])
+        for h in gf.screen_reads(packed, L, k, min_hits, n_mask=nm):
+            i = idx[int(h["read"])]
+            g = int(h["gap"])
+            got[g].add(i)
+            other = names[i][:-1] + ("2" if names[i].endswith("1") else "1")
+            if other in mate:
+                got[g].add(mate[other])
+    return [sorted(s) for s in got]
+
+
+class BothUnmappedReadsCollector:
+    def __init__(self, working_space, samtools_path="samtools", gf=None, k=31):
+        self.wf = working_space
+        self.samtools_path = samtools_path
+        self.gf = gf
+        self.k = int(k)
+
+    def collect_both_unmapped_reads(self, bam_list, id_list):
+        wf = self.wf
+        for sf_bam in bam_list:
+            run_collect_both_unmapped(sf_bam, self.samtools_path)
+        with open(wf + "both_unmapped.fq", "w") as fout:                                   # `cat` of the per-BAM files (:197-202)
+            for sf_bam in bam_list:
+                with open(sf_bam + ".both_unmapped.fq") as f:
+                    fout.write(f.read())
+        self.reads = {}                                                                    # head -> "seq\n+\nqual\n" (:205-220)
+        with open(wf + "both_unmapped.fq") as fin:
+            lines = fin.read().split("\n")
+        for i in range(0, len(lines) - 3, 4):
+            self.reads[lines[i].rstrip()[1:]] = "".join(l.rstrip() + "\n" for l in lines[i + 1:i + 4])
+        with open(wf + "both_unmapped_1.fq", "w") as f_left, open(wf + "both_unmapped_2.fq", "w") as f_right:
+            for key in self.reads:                                                         # insertion order
+                if key[-1] == "1":
+                    read_id = key[:-2]
+                    f_left.write("@" + read_id + "\n" + self.reads[key])
+                    f_right.write("@" + read_id + "\n" + self.reads[read_id + "_2"])       # KeyError if absent, as in the reference
+        self.align_unmapped_to_contigs(id_list)
+
+    def align_unmapped_to_contigs(self, fa_list):
+        wf = self.wf
+        keys, contigs = [], []
+        with open(wf + "gap_contigs_all.fa", "w") as fout:
+            for key in fa_list:
+                sf_ctg = wf + "velvet_temp/%s/contigs.fa" % key
+                if not os.path.exists(sf_ctg):
+                    continue
+                recs = list(read_fasta(sf_ctg))
+                for name, seq in recs:
+                    fout.write(">" + key + "-" + name + "\n" + seq + "\n")
+                if recs:
+                    keys.append(key)
+                    contigs.append([s for _, s in recs])
+        if not keys or not self.reads:
+            return {}
+        gf = self.gf or GapFill(int(os.environ.get("GF_DEVICE", "0")))
+        names = list(self.reads)
+        seqs = [self.reads[n].split("\n", 1)[0] for n in names]
+        picked = kmer_recruit_unmapped(gf, contigs, names, seqs, self.k)
+        os.makedirs(wf + "unmapped_reads", exist_ok=True)
+        out = {}
+        for key, idx in zip(keys, picked):
+            if not idx:
+                continue
+            text = "".join("@" + names[i] + "\n" + self.reads[names[i]] for i in idx)
+            with open(wf + "gap_reads/%s.fastq" % key, "a") as f:                          # :113-117
+                f.write(text)
+            with open(wf + "unmapped_reads/%s.fastq" % key, "w") as f:                     # :119-123
+                f.write(text)
+            out[key] = [names[i] for i in idx]
+        return out

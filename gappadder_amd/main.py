@@ -98,10 +98,12 @@ def main_func(command, sf_config):
     if command in ("Assembly", "All"):
         for s in SUB_MERGED:
             os.makedirs(wf + MERGE_FOLDER + s, exist_ok=True)
-        ga = assemble_gaps.GapAssembler(sf_fai, sf_gap_pos, cfg["nthreads"], wf + MERGE_FOLDER, cfg["kmers"], gf)
+        ga = assemble_gaps.GapAssembler(sf_fai, sf_gap_pos, cfg["nthreads"], wf + MERGE_FOLDER, cfg["kmers"], gf,
+                                        bam_list=[bam for bam, _, _ in cfg["alignments"]], samtools_path=cfg["samtools"])
         res = ga.assemble_pipeline()
-        print("assembled %d gaps, %d closed (picked_seqs.fa); contigs in %svelvet_temp/*/contigs.fa; the reference's later rounds "
-              "(contig merging, both-unmapped recruitment) are not part of this build" % (res["gaps"], res["closed"], wf + MERGE_FOLDER))
+        print("assembled %d gaps, %d closed (picked_seqs.fa), %d gaps got both-unmapped pairs in the second round; contigs in "
+              "%svelvet_temp/*/contigs.fa; the reference's contig-merging steps (TERefiner / ContigsMerger) are not part of this "
+              "build" % (res["gaps"], res["closed"], res["second_round_gaps"], wf + MERGE_FOLDER))
 
 
 def main(argv=None):

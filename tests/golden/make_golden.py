@@ -70,15 +70,54 @@ def parse(path, fmt):
 SAMTOOLS_SHIM = '''#!/usr/bin/env python3
 # stand-in for `samtools view <bam> "<scaffold>"` / `samtools faidx <fa>`: serves <bam>.sam text
 import sys
-if sys.argv[1] == "view":
+if sys.argv[1] == "view" and sys.argv[2] == "-f":      # view -f <mask> <bam>
+    mask, bam = int(sys.argv[3]), sys.argv[4]
+    with open(bam + ".sam") as f:
+        for line in f:
+            if int(line.split("\\t")[1]) & mask == mask:
+                sys.stdout.write(line)
+elif sys.argv[1] == "view" and sys.argv[2].startswith("-"):
+    pass  # -H / -h -S -b on files this stand-in does not have
+elif sys.argv[1] == "view":
     bam, scf = sys.argv[2], sys.argv[3]
     with open(bam + ".sam") as f:
         for line in f:
             if line.split("\\t")[2] == scf:
                 sys.stdout.write(line)
-elif sys.argv[1] == "faidx":
-    pass  # the generator writes the .fai itself
+else:
+    pass  # faidx (the generator writes the .fai itself), index, sort
 '''
+
+
+ROUND2_DRIVER = '''
+import sys
+from Utility import set_software_paths, set_parameters
+import collect_both_unmapped_reads as M
+samtools, draft, wf, ids, bams = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4].split(","), sys.argv[5].split(",")
+set_software_paths("/nonexistent/bwa", samtools, "x", "x", "/nonexistent/kmc/", "/nonexistent/velvet/")
+set_parameters(draft, 2, wf, 0, 100, 300)
+M.BothUnmappedReadsCollector(wf).collect_both_unmapped_reads(bams, ids)
+'''
+
+
+def round2_contigs(case, coords, seed):
+    """Made-up first-round contigs for two gaps (inputs of the both-unmapped round): pieces of the true gap interior, so that
+    both-unmapped pairs (which come from gap interiors) share k-mers with them; 60-column FASTA, Velvet-style names.
+    coords: {gapKey: (scaffold name, start, end)}."""
+    import random
+    rng = random.Random(seed)
+    out = {}
+    for key in sorted(coords):
+        sname, st, en = coords[key]
+        inner = case["true_seqs"][sname][st:en]
+        recs = []
+        for n in range(2):
+            a = rng.randrange(0, max(1, len(inner) - 200))
+            piece = inner[a:a + rng.randrange(120, 200)]
+            recs.append(">31_29_NODE_%d_length_%d_cov_12.500000\n" % (n + 1, len(piece) - 28) +
+                        "".join(piece[i:i + 60] + "\n" for i in range(0, len(piece), 60)))
+        out[key] = "".join(recs)
+    return out
 
 
 def convert_reference(dst):
@@ -150,6 +189,34 @@ def run_reference(case, out_tar, in_dir):
         for stage in ("Preprocess", "Collect"):
             subprocess.check_call([sys.executable, "main.py", "-c", stage, "-g", cfgp], cwd=code, env=env,
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # ---- both-unmapped round (collect_both_unmapped_reads.py) on made-up first-round contigs, twolib only ----
+        round2 = None
+        if case["name"] == "twolib":
+            coords = {"0_3": ("scf0", 15000, 17000), "2_2": ("scf2", 9000, 10000)}
+            contigs = round2_contigs(case, coords, 77)
+            mwf = os.path.join(wf, "merged") + "/"
+            for key, fa in contigs.items():
+                os.makedirs(os.path.join(mwf, "velvet_temp", key), exist_ok=True)
+                with open(os.path.join(mwf, "velvet_temp", key, "contigs.fa"), "w") as f:
+                    f.write(fa)
+            for sub in ("unmapped_reads",):
+                os.makedirs(os.path.join(mwf, sub), exist_ok=True)
+            before = {fn: open(os.path.join(mwf, "gap_reads", fn)).read() for fn in os.listdir(os.path.join(mwf, "gap_reads"))}
+            with open(os.path.join(code, "run_second_round.py"), "w") as f:
+                f.write(ROUND2_DRIVER)
+            subprocess.check_call([sys.executable, "run_second_round.py", samtools, os.path.join(data, "draft.fa"), mwf,
+                                   ",".join(sorted(coords) + ["0_1"]), ",".join(b for (b, _, _, _, _) in libs)],
+                                  cwd=code, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            after = {fn: open(os.path.join(mwf, "gap_reads", fn)).read() for fn in os.listdir(os.path.join(mwf, "gap_reads"))}
+            assert after == before    # no bwa here: the reference's alignment step recruits nothing
+            round2 = {"contigs": contigs, "ids": sorted(coords) + ["0_1"], "files": {}}
+            for i, (bam, _, _, _, _) in enumerate(libs):
+                round2["files"]["lib%d.both_unmapped.fq" % i] = open(bam + ".both_unmapped.fq").read()
+            for fn in ("both_unmapped.fq", "both_unmapped_1.fq", "both_unmapped_2.fq", "gap_contigs_all.fa"):
+                round2["files"][fn] = open(os.path.join(mwf, fn)).read()
+                os.remove(os.path.join(mwf, fn))
+            shutil.rmtree(os.path.join(mwf, "velvet_temp"))
+            shutil.rmtree(os.path.join(mwf, "unmapped_reads"))
         # ---- capture inputs (data only) ----
         os.makedirs(in_dir, exist_ok=True)
         def gz(name, text):
@@ -186,6 +253,9 @@ def run_reference(case, out_tar, in_dir):
                     tf.addfile(ti, fh)
         with gzip.GzipFile(out_tar, "wb", mtime=0) as g:
             g.write(buf.getvalue())
+        if round2 is not None:
+            with gzip.GzipFile(os.path.join(os.path.dirname(out_tar), "round2.json.gz"), "wb", mtime=0) as g:
+                g.write(json.dumps(round2, indent=0, sort_keys=True).encode())
         return keep
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -6,7 +6,12 @@ import stat
 SAMTOOLS_STANDIN = '''#!/usr/bin/env python3
 # test stand-in for `samtools view <bam> "<scaffold>"`: serves <bam>.sam text
 import sys
-if sys.argv[1] == "view":
+if sys.argv[1] == "view" and sys.argv[2] == "-f":       # view -f <mask> <bam>
+    with open(sys.argv[4] + ".sam") as f:
+        for line in f:
+            if int(line.split("\\t")[1]) & int(sys.argv[3]) == int(sys.argv[3]):
+                sys.stdout.write(line)
+elif sys.argv[1] == "view":
     with open(sys.argv[2] + ".sam") as f:
         for line in f:
             if line.split("\\t")[2] == sys.argv[3]:

@@ -38,7 +38,9 @@ def test_collect_reproduces_the_reference_tree(run):
             assert sorted(got[rel].splitlines()) == sorted(txt.splitlines()), rel
         checked += 1
     assert checked == len(case.expected) and checked > 40
-    extra = [k for k in got if k not in case.expected and not k.startswith("merged/velvet_temp/") and not k.startswith("picked_seqs.fa")]
+    later = ("merged/velvet_temp/", "picked_seqs.fa",                                  # Assembly stage, first round
+             "merged/both_unmapped", "merged/gap_contigs_all.fa", "merged/unmapped_reads/")   # ... second round
+    extra = [k for k in got if k not in case.expected and not k.startswith(later)]
     assert not extra, extra
 
 
@@ -157,3 +159,78 @@ def test_kmer_screen_mode_adds_the_flank_matching_pairs(tmp_path):
         assert len(mine_ids) == len(set(mine_ids))
         n_new += len(set(mine_ids) - ref_ids)
     assert n_new > 50
+
+
+def test_both_unmapped_round_recruits_by_contig_kmers(tmp_path):
+    """collect_both_unmapped_reads.py with the aligner replaced by the exact k-mer screen: a both-unmapped record is recruited
+    for a gap iff it shares a canonical 31-mer with one of the gap's first-round contigs (oracle predicate), its mate comes
+    along; the records are appended to gap_reads/{key}.fastq and written to unmapped_reads/{key}.fastq."""
+    import numpy as np
+    import stat
+    from gappadder_amd.collect_both_unmapped_reads import BothUnmappedReadsCollector
+    from gappadder_amd.hip_api import GapFill
+    rng = np.random.RandomState(5)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    L, k = 100, 31
+    rnd = lambda n: lut[rng.randint(0, 4, n)].tobytes().decode()
+    keys = ["0_1", "0_2", "3_1"]
+    contigs = {key: [rnd(rng.randint(150, 400)) for _ in range(2)] for key in keys}
+    wf = str(tmp_path) + "/merged/"
+    os.makedirs(wf + "gap_reads")
+    for key in keys:
+        os.makedirs(wf + "velvet_temp/" + key)
+        with open(wf + "velvet_temp/%s/contigs.fa" % key, "w") as f:
+            for n, c in enumerate(contigs[key], 1):
+                f.write(">31_29_NODE_%d_length_%d_cov_9.000000\n" % (n, len(c) - 28))
+                f.write("".join(c[i:i + 60] + "\n" for i in range(0, len(c), 60)))
+    open(wf + "gap_reads/0_1.fastq", "w").write("@old_1\nACGT\n+\nIIII\n")
+    sam, recs = [], []
+    for p in range(240):
+        mates = []
+        for m in range(2):
+            if m == 0 and p % 5 < 3:     # mate 1 of 60 % of the pairs comes from a contig (one substitution, either strand)
+                c = contigs[keys[p % 3]][p % 2]
+                a = rng.randint(0, len(c) - L + 1)
+                s = bytearray(c[a:a + L].encode())
+                e = rng.randint(L)
+                s[e] = lut[(list(b"ACGT").index(s[e]) + 1) % 4]
+                s = bytes(s)
+                if p % 2:
+                    s = s.translate(comp)[::-1]
+                mates.append(s.decode())
+            else:
+                mates.append(rnd(L))
+        for m, flag in ((0, 77), (1, 141)):
+            sam.append("q%d\t%d\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (p, flag, mates[m], "I" * L))
+            recs.append(("q%d_%d" % (p, m + 1), mates[m]))
+    data = str(tmp_path) + "/data"
+    os.makedirs(data)
+    bam = data + "/lib0.bam"
+    open(bam, "w").close()
+    open(bam + ".sam", "w").write("".join(sam))
+    st = data + "/samtools_standin.py"
+    open(st, "w").write(PU.SAMTOOLS_STANDIN)
+    os.chmod(st, os.stat(st).st_mode | stat.S_IEXEC)
+    gf = GapFill(0)
+    try:
+        got = BothUnmappedReadsCollector(wf, samtools_path=st, gf=gf, k=k)
+        got.collect_both_unmapped_reads([bam], keys + ["9_9"])
+    finally:
+        gf.close()
+    # oracle: the k-mer predicate on the same records, contigs of a gap joined by N
+    blob = "".join(s for _, s in recs).encode()
+    hits = CO.screen_reads(blob, L, [("N".join(contigs[key]), "") for key in keys], k)
+    total = 0
+    for g, key in enumerate(keys):
+        idx = set()
+        for h in hits:
+            if int(h["gap"]) == g:
+                i = int(h["read"])
+                idx.update((i, i ^ 1))
+        exp = "".join("@%s\n%s\n+\n%s\n" % (recs[i][0], recs[i][1], "I" * L) for i in sorted(idx))
+        assert open(wf + "unmapped_reads/%s.fastq" % key).read() == exp
+        before = "@old_1\nACGT\n+\nIIII\n" if key == "0_1" else ""
+        assert open(wf + "gap_reads/%s.fastq" % key).read() == before + exp
+        total += len(idx)
+    assert total >= 2 * 140 and not os.path.exists(wf + "unmapped_reads/9_9.fastq")

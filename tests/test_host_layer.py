@@ -90,3 +90,33 @@ def test_pick_gap_sequence_anchors_and_quirks():
     assert pick_gap_sequence([("a", contig)], left[:20], right, 30) is None        # flank shorter than the anchor
     two = [("a", g[300:700]), ("b", g[300:395] + "ACGT" * 70 + g[605:700])]        # longest span wins (pick_contigs.py:300-321)
     assert pick_gap_sequence(two, left, right, 30)[0] == "b"
+
+
+def test_both_unmapped_round_files_match_reference(tmp_path):
+    """collect_both_unmapped_reads.py, file side: the per-BAM / merged / split both-unmapped FASTQ files and
+    gap_contigs_all.fa equal what the reference wrote for the same SAM text and the same first-round contigs
+    (tests/golden/twolib/round2.json.gz; record order compared as written: py3 dicts keep insertion order on both sides)."""
+    import gzip
+    import json
+    from gappadder_amd.collect_both_unmapped_reads import BothUnmappedReadsCollector
+    case = Case("twolib")
+    r2 = json.loads(gzip.open(os.path.join(case.dir, "round2.json.gz")).read())
+    cfgp, wf, st = PU.materialise(case, str(tmp_path))
+    data = os.path.join(str(tmp_path), "data")
+    mwf = wf + "merged/"
+    for key, fa in r2["contigs"].items():
+        os.makedirs(mwf + "velvet_temp/" + key)
+        open(mwf + "velvet_temp/%s/contigs.fa" % key, "w").write(fa)
+    os.makedirs(mwf + "gap_reads")
+
+    class NoGpu:     # the SAM text of the fixture carries '*' sequences: nothing to screen, the GPU must not be needed
+        def __getattr__(self, name):
+            raise AssertionError("GPU touched")
+    bams = [os.path.join(data, "lib%d.bam" % i) for i in range(len(case.libs))]
+    b = BothUnmappedReadsCollector(mwf, samtools_path=st, gf=NoGpu(), k=31)
+    b.collect_both_unmapped_reads(bams, r2["ids"])
+    for i in range(len(case.libs)):
+        assert open(bams[i] + ".both_unmapped.fq").read() == r2["files"]["lib%d.both_unmapped.fq" % i]
+    for fn in ("both_unmapped.fq", "both_unmapped_1.fq", "both_unmapped_2.fq", "gap_contigs_all.fa"):
+        assert open(mwf + fn).read() == r2["files"][fn], fn
+    assert len(r2["files"]["both_unmapped_1.fq"]) > 500 and r2["files"]["gap_contigs_all.fa"].count(">") == 4
