@@ -29,7 +29,7 @@ REF = "/root/reference"
 sys.path.insert(0, HERE)
 from synth_text import make_case  # noqa: E402  (text-level synthetic generator, this repo's own)
 
-REF_PY = ["main.py", "Utility.py", "gnrt_pos_true_seqs.py", "run_multi_threads_collect_reads.py",
+REF_PY = ["put_gap_seq_back_to_scaffold.py", "main.py", "Utility.py", "gnrt_pos_true_seqs.py", "run_multi_threads_collect_reads.py",
           "collect_reads_for_gaps.py", "run_multi_threads_discordant.py",
           "collect_discordant_low_mapq_reads.py", "merge_reads.py", "assemble_gaps.py",
           "MergeContigs.py", "pick_contigs.py", "collect_both_unmapped_reads.py"]
@@ -38,9 +38,23 @@ SEQIO_SHIM = '''
 class _Seq(str):
     pass
 class _Rec(object):
-    def __init__(self, id, seq):
+    def __init__(self, id, seq, description=None):
         self.id = id
         self.seq = _Seq(seq)
+        self.description = id if description is None else description
+def write(record, handle, fmt):
+    # Biopython's FastaWriter convention (Bio/SeqIO/FastaIO.py; Biopython itself is absent here): title = description when it
+    # starts with the id, "id description" when there is another description, else the id; sequence wrapped at 60 columns
+    assert fmt == "fasta"
+    d = record.description
+    if d and d.split(None, 1)[0] == record.id:
+        title = d
+    elif d:
+        title = "%s %s" % (record.id, d)
+    else:
+        title = record.id
+    s = str(record.seq)
+    handle.write(">" + title + "\\n" + "".join(s[i:i + 60] + "\\n" for i in range(0, len(s), 60)))
 def parse(path, fmt):
     if fmt == "fasta":
         name, chunks = None, []
@@ -49,12 +63,12 @@ def parse(path, fmt):
                 line = line.rstrip("\\n")
                 if line.startswith(">"):
                     if name is not None:
-                        yield _Rec(name, "".join(chunks))
-                    name, chunks = line[1:].split()[0], []
+                        yield _Rec(name, "".join(chunks), desc)
+                    name, chunks, desc = line[1:].split()[0], [], line[1:]
                 else:
                     chunks.append(line)
         if name is not None:
-            yield _Rec(name, "".join(chunks))
+            yield _Rec(name, "".join(chunks), desc)
     elif fmt == "fastq":
         with open(path) as f:
             while True:
@@ -131,6 +145,11 @@ def convert_reference(dst):
     open(os.path.join(dst, "Bio", "__init__.py"), "w").close()
     with open(os.path.join(dst, "Bio", "SeqIO.py"), "w") as f:
         f.write(SEQIO_SHIM)
+    with open(os.path.join(dst, "Bio", "Seq.py"), "w") as f:
+        f.write("class Seq(str):\n    pass\n")
+    with open(os.path.join(dst, "Bio", "SeqRecord.py"), "w") as f:
+        f.write("class SeqRecord(object):\n    def __init__(self, seq, id='', description=''):\n"
+                "        self.seq, self.id, self.description = seq, id, description\n")
     st = os.path.join(dst, "samtools_shim.py")
     with open(st, "w") as f:
         f.write(SAMTOOLS_SHIM)
@@ -217,6 +236,22 @@ def run_reference(case, out_tar, in_dir):
                 os.remove(os.path.join(mwf, fn))
             shutil.rmtree(os.path.join(mwf, "velvet_temp"))
             shutil.rmtree(os.path.join(mwf, "unmapped_reads"))
+        # ---- write-back of closed sequences into the scaffolds (put_gap_seq_back_to_scaffold.py), twolib only ----
+        writeback = None
+        if case["name"] == "twolib":
+            import random
+            rng = random.Random(5)
+            picked = ""
+            for gid in ("0_1", "0_3", "2_2"):     # 0_2 and 2_1 stay open; scf1 has no gap
+                seq = "".join(rng.choice("ACGT") for _ in range(rng.randrange(70, 200)))
+                picked += ">%s_31_29_NODE_1_length_99_cov_7.000000\n%s\n" % (gid, seq)
+            pf = os.path.join(tmp, "picked_seqs.fa")
+            open(pf, "w").write(picked)
+            newf = os.path.join(tmp, "new_scaffolds.fa")
+            subprocess.check_call([sys.executable, "put_gap_seq_back_to_scaffold.py", os.path.join(data, "draft.fa"),
+                                   os.path.join(wf, "gap_positions.txt"), pf, newf], cwd=code, env=env,
+                                  stdout=subprocess.DEVNULL)
+            writeback = {"picked_fa": picked, "new_scaffolds_fa": open(newf).read()}
         # ---- capture inputs (data only) ----
         os.makedirs(in_dir, exist_ok=True)
         def gz(name, text):
@@ -253,6 +288,9 @@ def run_reference(case, out_tar, in_dir):
                     tf.addfile(ti, fh)
         with gzip.GzipFile(out_tar, "wb", mtime=0) as g:
             g.write(buf.getvalue())
+        if writeback is not None:
+            with gzip.GzipFile(os.path.join(os.path.dirname(out_tar), "writeback.json.gz"), "wb", mtime=0) as g:
+                g.write(json.dumps(writeback, indent=0, sort_keys=True).encode())
         if round2 is not None:
             with gzip.GzipFile(os.path.join(os.path.dirname(out_tar), "round2.json.gz"), "wb", mtime=0) as g:
                 g.write(json.dumps(round2, indent=0, sort_keys=True).encode())

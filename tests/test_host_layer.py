@@ -120,3 +120,22 @@ def test_both_unmapped_round_files_match_reference(tmp_path):
     for fn in ("both_unmapped.fq", "both_unmapped_1.fq", "both_unmapped_2.fq", "gap_contigs_all.fa"):
         assert open(mwf + fn).read() == r2["files"][fn], fn
     assert len(r2["files"]["both_unmapped_1.fq"]) > 500 and r2["files"]["gap_contigs_all.fa"].count(">") == 4
+
+
+def test_write_back_matches_reference(tmp_path):
+    """put_gap_seq_back_to_scaffold.py: same new scaffold FASTA as the reference for the same draft, gap table and picked
+    sequences (two gaps of scf0 and one of scf2 filled, one gap each left open, scf1 without gaps)."""
+    import gzip
+    import json
+    from gappadder_amd.put_gap_seq_back_to_scaffold import put_gap_seq_back_to_scaffold
+    case = Case("twolib")
+    wb = json.loads(gzip.open(os.path.join(case.dir, "writeback.json.gz")).read())
+    d = str(tmp_path)
+    open(d + "/draft.fa", "w").write(case.draft_fa)
+    open(d + "/draft.fa.fai", "w").write(case.fai)
+    open(d + "/gap_positions.txt", "w").write(case.expected["gap_positions.txt"])
+    open(d + "/picked.fa", "w").write(wb["picked_fa"])
+    put_gap_seq_back_to_scaffold(d + "/draft.fa", d + "/gap_positions.txt", d + "/picked.fa", d + "/new.fa")
+    got = open(d + "/new.fa").read()
+    assert got == wb["new_scaffolds_fa"]
+    assert got.count(">") == 3 and got.count("N") == 600    # the two open gaps + the 50-N run below min_gap_size
