@@ -24,7 +24,7 @@ assert CONTIG.itemsize == 32 and GAP.itemsize == 16 and ALNREC.itemsize == 32 an
 GF_OK, GF_E_INVAL, GF_E_NODEV, GF_E_NOMEM, GF_E_NOSPACE, GF_E_STATE, GF_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 KIND_CLIP, KIND_DISCORDANT, KIND_UNMAP, KIND_LOWMAPQ = 0, 1, 2, 3
 KIND_NAMES = {KIND_CLIP: "clip", KIND_DISCORDANT: "discordant", KIND_UNMAP: "unmap"}
-KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_SYNTH, KERNEL_COUNT, KERNEL_VERIFY = range(8)
+KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_SYNTH, KERNEL_COUNT, KERNEL_VERIFY, KERNEL_INGEST = range(9)
 
 _lib = None
 
@@ -63,6 +63,8 @@ def lib():
         "gf_set_gaps": (i32, [vp, vp, sz, u32, C.c_char_p, vp]),
         "gf_pack_reads": (i32, [C.c_char_p, sz, i32, vp, vp]),
         "gf_packed_read_bytes": (sz, [i32]),
+        "gf_fastq_pack": (i32, [vp, C.c_char_p, sz, i32, vp, sz, vp, vp, szp, C.POINTER(C.c_uint32)]),
+        "gf_fastq_pack_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp, vp, vp]),
         "gf_screen_reads": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, szp]),
         "gf_screen_reads_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, vp]),
         "gf_tag_alignments": (i32, [vp, vp, sz, i32, i32, i32, i32, vp, sz, szp]),

@@ -68,6 +68,20 @@ class GapFill:
             raise B.GapFillError(rc, "gf_pack_reads")
         return packed, nm
 
+    def fastq_pack(self, text, read_len, with_mask=True):
+        """FASTQ text (bytes: a whole file or a chunk starting at a record boundary) -> (packed uint8 [n, rb], n_mask or None,
+        hdr_begin uint64 [n] = byte offset of every record's '@' line, status bits) — parsed and packed on the GPU."""
+        text = bytes(text)
+        rb = self._L.gf_packed_read_bytes(read_len)
+        cap = max(1, text.count(b"\n") // 4 + 1)
+        packed = np.zeros((cap, rb), dtype=np.uint8)
+        nm = np.zeros((cap, (read_len + 31) // 32), dtype=np.uint32) if with_mask else None
+        hdr = np.zeros(cap + 1, dtype=np.uint64)
+        n, st = C.c_size_t(0), C.c_uint32(0)
+        self._chk(self._L.gf_fastq_pack(self._h, text, len(text), read_len, B._p(packed), cap, B._p(nm), B._p(hdr), C.byref(n),
+                                        C.byref(st)), "gf_fastq_pack")
+        return packed[:n.value], (nm[:n.value] if with_mask else None), hdr[:n.value], int(st.value)
+
     def _grow(self, call, dtype, cap):
         while True:
             out = np.zeros(max(cap, 1), dtype=dtype)

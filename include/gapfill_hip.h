@@ -110,6 +110,20 @@ int gf_set_gaps(gf_ctx* ctx, const gf_gap* gaps, size_t n_gaps, uint32_t n_scaff
 int gf_pack_reads(const char* ascii, size_t n_reads, int read_len, uint8_t* packed, uint32_t* n_mask);
 size_t gf_packed_read_bytes(int read_len);
 
+/* ---- ingest: FASTQ TEXT -> the packed layout above, on the device.  `text` is the content of a FASTQ file
+ * (or a chunk that starts at a record boundary): strict 4-line records as the reference's line machine assumes
+ * (run_multi_threads_discordant.py:205-232); the last line may lack its newline; CRLF tolerated.  Read r = sequence line of
+ * record r, padded with masked A (N) up to read_len.  hdr_begin[r] = byte offset of record r's '@' line (ids are cut from the
+ * host's copy of the text: first whitespace token, up to '/', :212-214); needs cap_reads + 1 entries.
+ * *n_reads = records found (may exceed cap_reads: GF_E_NOSPACE from the host variant, status bit 4 from the device variant).
+ * status bits: 1 = a sequence line longer than read_len was truncated, 2 = trailing partial record ignored, 4 = capacity. */
+int gf_fastq_pack(gf_ctx* ctx, const char* text, size_t n_bytes, int read_len, uint8_t* packed, size_t cap_reads,
+                  uint32_t* n_mask_or_null, uint64_t* hdr_begin_or_null, size_t* n_reads, uint32_t* status);
+/* device variant: d_n_reads = u64, d_status = u32 (both written by the call; it synchronises the stream once to size the
+ * second pass). */
+int gf_fastq_pack_dev(gf_ctx* ctx, const void* d_text, size_t n_bytes, int read_len, void* d_packed, size_t cap_reads,
+                      void* d_n_mask_or_null, void* d_hdr_begin_or_null, void* d_n_reads, void* d_status);
+
 /* ---- north-star flank-k-mer screen ("flank-k-mer lookup to tag reads") ------------------------------
  * Emits (gap, read) for every read that has >= min_hits k-mer positions whose canonical k-mer occurs in the
  * gap's flank k-mer set (predicate shape of IsReadContainingFreqKmers, KmerUtils.cpp:215-241, on canonical
@@ -222,6 +236,7 @@ int gf_memset_dev(gf_ctx* ctx, void* d_ptr, int value, size_t bytes);
 #define GF_KERNEL_SYNTH 5
 #define GF_KERNEL_COUNT 6
 #define GF_KERNEL_VERIFY 7  /* second kernel of the screen: exact per-candidate verification */
+#define GF_KERNEL_INGEST 8  /* FASTQ text -> packed reads */
 int gf_timing_enable(gf_ctx* ctx, int on);
 int gf_timing_read(gf_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 int gf_timing_reset(gf_ctx* ctx);
