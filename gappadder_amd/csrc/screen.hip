@@ -580,7 +580,7 @@ struct PipeS {   // stage B -> C: the (up to two) exact-set lookups of one tile
 };
 constexpr uint32_t PIPE_NONE = 0xFFFFFFFFu;
 
-template <int NCH, int NP>
+template <int NCH, int NP, bool EXACT>   // EXACT: the launch has exactly NP probes per read (no per-probe np test)
 __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P, uint32_t slice_words) {
     static_assert(NCH >= 1, "whole 16-byte chunks per lane");
     extern __shared__ uint32_t sm[];  // [coarse bitmap][per wave: 64 reads + pad | WOBUF candidate ids]
@@ -673,20 +673,31 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
         wave_lds_sync();
         {
             const uint32_t en = (have && (uint64_t)t * 64 + lane < P.n_reads) ? 0xFFFFFFFFu : 0u;
-            uint32_t bw[NP];
+            uint32_t bw[NP], w32[NP];
+            // the uniform byte-aligned / bit-aligned choice is made ONCE around the unrolled loop, so that all NP tile reads
+            // are issued back to back (a branch per probe put an s_waitcnt lgkmcnt(0) behind every single ds_read2)
+            if (bytes_ok) {
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const uint32_t jj = (uint32_t)j < P.np ? (uint32_t)j : 0u;
-                const uint32_t w32 = bytes_ok ? stream32_bytes(tile, rbase + ((jj * P.stride2) >> 3)) : stream32(tile, rbase * 8 + jj * P.stride2);
-                WA.p[j] = canon16(w32) * S16_MUL;
+                for (int j = 0; j < NP; ++j) {
+                    const uint32_t jj = EXACT || (uint32_t)j < P.np ? (uint32_t)j : 0u;
+                    w32[j] = stream32_bytes(tile, rbase + ((jj * P.stride2) >> 3));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const uint32_t jj = EXACT || (uint32_t)j < P.np ? (uint32_t)j : 0u;
+                    w32[j] = stream32(tile, rbase * 8 + jj * P.stride2);
+                }
             }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) WA.p[j] = canon16(w32[j]) * S16_MUL;
 #pragma unroll
             for (int j = 0; j < NP; ++j) bw[j] = sm[WA.p[j] >> (sh_lds + 5)];
             uint32_t pm = 0;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 uint32_t pass = (uint32_t)__builtin_amdgcn_sbfe((int)bw[j], WA.p[j] >> sh_lds, 1);   // 0 or all ones
-                pass &= (uint32_t)j < P.np ? en : 0u;
+                pass &= EXACT || (uint32_t)j < P.np ? en : 0u;
                 pm |= pass & (1u << j);
                 vm_load32(WA.w[j], (WA.p[j] >> (sh_bm + 3)) & (pass & l2mask), P.bitmap);   // offset 0 when idle
             }
@@ -1106,9 +1117,12 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         const int nch = (rb + 15) / 16 <= 4 ? (int)((rb + 15) / 16) : 0;
         const int npt = std::max(5, (int)F.np);   // probes per read, unrolled
         void (*wk)(FilterParams, uint32_t) = nullptr;
-#define GF_PK(N, Q) if (nch == N && npt == Q) wk = screen_filter_pipe_kernel<N, Q>;
-#define GF_PKN(Q) GF_PK(1, Q) GF_PK(2, Q) GF_PK(3, Q) GF_PK(4, Q)
-        GF_PKN(5) GF_PKN(6) GF_PKN(7) GF_PKN(8) GF_PKN(9) GF_PKN(10)
+#define GF_PK(N, Q) if (nch == N && npt == Q) wk = (int)F.np == Q ? screen_filter_pipe_kernel<N, Q, true> : screen_filter_pipe_kernel<N, Q, false>;
+#define GF_PKX(N, Q) if (nch == N && npt == Q) wk = screen_filter_pipe_kernel<N, Q, true>;
+#define GF_PKN(Q) GF_PKX(1, Q) GF_PKX(2, Q) GF_PKX(3, Q) GF_PKX(4, Q)
+        GF_PK(1, 5) GF_PK(2, 5) GF_PK(3, 5) GF_PK(4, 5)
+        GF_PKN(6) GF_PKN(7) GF_PKN(8) GF_PKN(9) GF_PKN(10)
+#undef GF_PKX
 #undef GF_PKN
 #undef GF_PK
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
