@@ -333,7 +333,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         // ---- P1: count canonical k-mers; remember each distinct k-mer's slot.  Optimistic LDS table first.
         Tab tab;
         tab.g = gtab;
-        bool keyslot = false;
+        bool keyslot = false, keyslot_w = false;
         uint32_t* dist_inst = P.nodes + 3 * inst_off;   // key-slot mode: instance id of the q-th distinct k-mer
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool use_lds = attempt == 0 && r_words / 2 >= 1024;
@@ -348,8 +348,14 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             // once the count has saturated.  The instance id of each distinct k-mer goes to a side list (the node arrays
             // are idle here).
             keyslot = P.keyslot && !W && k <= 31 && P.min_count <= 3 && !P.cnt_keys;
+            // wide variant (32 < k <= 63): a 16-byte slot = {hi, ~(lo | count)}, see count_keyslot_wide below.  Only for the
+            // global table: in LDS the doubled slot size overflows pools that the 8-byte instance-id slots still hold
+            // (measured at k=41, 214-read pools: 161 us against 105 us per gap).
+            const bool wide_ok = P.keyslot && W && k > 32 && k <= 63 && P.min_count <= 3 && !P.cnt_keys;
+            keyslot_w = wide_ok && !use_lds;
+            const uint32_t limit_k = limit;
             // an LDS attempt that is bound to overflow is skipped: at ~1 % errors nearly half of all windows are distinct
-            if (use_lds && keyslot && n_inst / 4 > limit) continue;
+            if (use_lds && (keyslot || wide_ok) && n_inst / 4 > limit) continue;
 #ifndef GF_KS_COMPLEMENT_LDS
 #define GF_KS_COMPLEMENT_LDS 0
 #endif
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             const unsigned long long xm = (!use_lds || GF_KS_COMPLEMENT_LDS) ? ~0ull : 0ull;
             const unsigned long long kempty = xm ? EMPTY64 : ~0ull;
             if (use_lds) {
-                const unsigned long long e = keyslot ? kempty : EMPTY64;
+                const unsigned long long e = keyslot ? kempty : EMPTY64;   // (the wide variant keeps the EMPTY64 words)
                 for (uint32_t i = tid; i < tab.cap; i += ASM_THREADS) tab.store(i, e);
                 __syncthreads();
             }
@@ -417,6 +423,79 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 }
                 };
                 if (use_lds) count_keyslot(std::true_type{}); else count_keyslot(std::false_type{});
+            } else if (keyslot_w) {
+                // Wide key-slot: word 0 = key.hi, word 1 = ~(key.lo | count) (count in the >= 2 spare low bits of lo; the
+                // complement keeps data words apart from EMPTY64 and from the LOCK word, whose low two bits are 11).  A slot is
+                // claimed by CAS(word 1: EMPTY64 -> LOCK), then hi is written, then word 1 is published.
+                auto count_keyslot_wide = [&](auto lds_c) {
+                constexpr bool LDS = decltype(lds_c)::value;
+                constexpr unsigned long long LOCK = 0x80000000FFFFFFFFull;
+                Tab t = tab;
+                t.lds = LDS;
+                const uint32_t wcap = t.cap / 2;
+                auto put = [&](uint32_t word, unsigned long long v) {
+                    if (LDS) __hip_atomic_store(t.l() + word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store(t.g + word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                const uint32_t dr = ASM_THREADS / npos, dp = ASM_THREADS - dr * npos;
+                uint32_t r = tid / npos, p = tid - r * npos, inst_i = tid;
+                // A thread that meets a LOCKed slot does NOT spin: the owner's publishing stores sit on the exit path of the
+                // probe loop, which the SIMT control flow runs only after every lane of the wave has left that loop — a lane
+                // spinning inside it would wait for an owner in its own wave forever.  It leaves the probe loop and takes the
+                // same k-mer again in the next round of the outer loop, by which time an owner in its wave has published.
+                while (inst_i < n_inst) {
+                    if (LDS && s_cnt[6]) break;
+                    if (p >= npos) { p -= npos; ++r; }
+                    const uint32_t inst = r * P.read_len + p;
+                    bool bad = false;
+                    if (P.nmask) {
+                        for (uint32_t q = p; q < p + P.k; ++q)
+                            if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
+                    }
+                    bool placed = bad, retry = false;
+                    if (!bad) {
+                        const K128 key = canonical_w<true>(pv_kmer_at<true>(V, r, p, k), k);
+                        uint32_t sl = slot_of(key, wcap);
+                        for (uint32_t probes = 0; probes < wcap; ++probes) {
+                            unsigned long long b = t.load(2 * sl + 1);
+                            if (b == EMPTY64) {
+                                b = t.cas(2 * sl + 1, EMPTY64, LOCK);
+                                if (b == EMPTY64) {   // first occurrence: this thread owns the slot
+                                    put(2 * sl, key.hi);
+                                    // word 0 must be in place before word 1 says so.  LDS executes a wave's operations in order; a
+                                    // global store is acknowledged (vmcnt) once it is in L2, where every access of this table
+                                    // goes — a full agent-scope release (L2 write-back) here cost 5x the whole phase
+                                    if (LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    put(2 * sl + 1, ~(key.lo | 1ull));
+                                    const uint32_t q = atomicAdd(&s_cnt[4], 1u);
+                                    if (q >= limit_k) s_cnt[6] = 1;
+                                    if (q < n_unit) { list_a[q] = sl; dist_inst[q] = inst; }
+                                    placed = true;
+                                    break;
+                                }
+                            }
+                            if (b == LOCK) { retry = true; break; }
+                            asm volatile("" ::: "memory");          // word 0 is read after word 1 was seen published
+                            const unsigned long long a = t.load(2 * sl);
+                            if (a == key.hi && (~b & ~3ull) == key.lo) {
+                                while ((~b & 3ull) != 3ull) {   // saturating increment of the complemented count
+                                    const unsigned long long o = t.cas(2 * sl + 1, b, b - 1);
+                                    if (o == b) break;
+                                    b = o;
+                                }
+                                placed = true;
+                                break;
+                            }
+                            sl = sl + 1 == wcap ? 0 : sl + 1;
+                        }
+                    }
+                    if (retry) continue;
+                    if (!placed) { if (LDS) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_KTABLE); }
+                    inst_i += ASM_THREADS; r += dr; p += dp;
+                }
+                };
+                if (use_lds) count_keyslot_wide(std::true_type{}); else count_keyslot_wide(std::false_type{});
             } else
             for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
                 if (use_lds && s_cnt[6]) break;
@@ -456,11 +535,15 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             uint32_t id = 0, c = 0;
             if (i < n_dist) {
                 const uint32_t sl = list_a[i];
-                const unsigned long long v = tab.load(sl);
-                id = keyslot ? dist_inst[i] : (uint32_t)v;
-                c = keyslot ? (uint32_t)((tab_global ? ~v : (GF_KS_COMPLEMENT_LDS ? ~v : v)) & 3ull) : (uint32_t)(v >> 32);
+                const unsigned long long v = tab.load(keyslot_w ? 2 * sl + 1 : sl);
+                id = (keyslot || keyslot_w) ? dist_inst[i] : (uint32_t)v;
+                c = keyslot_w ? (uint32_t)(~v & 3ull)
+                    : keyslot ? (uint32_t)((tab_global ? ~v : (GF_KS_COMPLEMENT_LDS ? ~v : v)) & 3ull) : (uint32_t)(v >> 32);
                 keep = c >= P.min_count;
-                if (tab_global) tab.store(sl, EMPTY64);
+                if (tab_global) {
+                    if (keyslot_w) { tab.store(2 * sl, EMPTY64); tab.store(2 * sl + 1, EMPTY64); }
+                    else tab.store(sl, EMPTY64);
+                }
             }
             const unsigned long long bal = __ballot(keep);
             if (bal) {

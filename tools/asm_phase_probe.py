@@ -26,7 +26,7 @@ dbg = torch.zeros(len(gaps) * 8, dtype=torch.int64, device=dev)
 gf.set_option("asm_dbg_ptr", dbg.data_ptr())
 gf.timing(True)
 for _ in range(3):
-    ctg, seq = gf.assemble(pool, off, 150, [(31, 29)])
+    K = int(os.environ.get("K", "31")); ctg, seq = gf.assemble(pool, off, 150, [(K, K - 2)])
 ms, n = gf.kernel_time(B.KERNEL_ASSEMBLE)
 print("assemble kernel %.3f ms avg, contigs %d" % (ms / n, len(ctg)))
 d = dbg.cpu().numpy().reshape(-1, 8)
