@@ -101,8 +101,8 @@ def test_pool_larger_than_the_lds_stage_uses_global_reads(gf):
         assert got2 == got
 
 
-@pytest.mark.parametrize("n_reads", [1034, 2100])
-def test_deep_noisy_pool(gf, n_reads):
+@pytest.mark.parametrize("n_reads,kk", [(1034, [(31, 29)]), (2100, [(31, 29)]), (1034, [(41, 39), (51, 49)]), (700, [(63, 61), (64, 61)])])
+def test_deep_noisy_pool(gf, n_reads, kk):
     """150-400x depth with 1 % errors: tens of thousands of error k-mers pass min_count 2, the node arrays fill the LDS and
     the per-contig coverage sums fall back to the global walk records (once an ASM_ERR_WALKS_PAR overflow)."""
     rng = np.random.RandomState(n_reads)
@@ -115,10 +115,11 @@ def test_deep_noisy_pool(gf, n_reads):
             b[pos] = LUT[(list(b"ACGT").index(b[pos]) + 1 + rng.randint(3)) % 4]
         reads[i] = bytes(b)
     pool = b"".join(reads)
-    got, _ = _gpu_assemble(gf, [pool], L, [(31, 29)])
-    exp = CO.assemble_pool(pool, L, 31, 29)
-    assert len(exp) > 50
-    assert got[(0, 31, 29)] == exp
+    got, _ = _gpu_assemble(gf, [pool], L, kk)     # k <= 31 / 32 < k <= 63: key-slot count phase in the global table; 64: instance ids
+    for (k, kv) in kk:
+        exp = CO.assemble_pool(pool, L, k, kv)
+        assert len(exp) > 20, (k, kv)
+        assert got[(0, k, kv)] == exp, (k, kv)
 
 
 def test_count_kmers_matches_oracle(gf):
