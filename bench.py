@@ -88,8 +88,13 @@ def main():
     gf.set_gaps(gaps, int(cfg["n_scaffolds"][0]), flanks)
     # second context = second HIP stream on the same device: the alignment tagger + second hop are independent of the k-mer
     # screen until the pools are built, so they run beside the screen's verify pass
-    gf2 = GapFill(local)
-    gf2.set_gaps(gaps, int(cfg["n_scaffolds"][0]), None)
+    if os.environ.get("GF_VERIFY_BATCH"):
+        gf.set_option("screen_verify_batch", int(os.environ["GF_VERIFY_BATCH"]))
+    if os.environ.get("GF_BENCH_SERIAL"):     # diagnostic: tagger on the same stream, so every phase time is stand-alone
+        gf2 = gf
+    else:
+        gf2 = GapFill(local)
+        gf2.set_gaps(gaps, int(cfg["n_scaffolds"][0]), None)
     lib = B.lib()
     rb = lib.gf_packed_read_bytes(L)
 

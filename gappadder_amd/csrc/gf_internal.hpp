@@ -35,6 +35,14 @@ struct FlankIndex {
     // slot = one uint4 {hi.lo32, hi.hi32, gap, 0} for k <= 32, two uint4 {hi, lo}, {gap, 0, 0, 0} for k > 32;
     // gap == EMPTY32 marks a free slot
     void* d_table = nullptr;
+    // seed-and-extend verification (min_hits == 1, no repeat mask): per exact-set slot the first occurrence of its 16-mer,
+    // the occurrences {flank id, pos | strand<<16 | last<<17 | left room<<18 | right room<<24}, the flanks 2-bit packed
+    // (each padded by 4 words on both sides) and the word offset of every flank's first base
+    uint32_t* d_sval = nullptr;
+    uint32_t* d_occ = nullptr;
+    uint32_t* d_fpk = nullptr;
+    uint32_t* d_foff = nullptr;
+    bool ext_ok = false;     // every flank shorter than 65536 bases (16-bit positions in the occurrence words)
     size_t n_kmers = 0, n_s16 = 0;
     uint32_t max_gaps_per_kmer = 0;
 };
@@ -70,6 +78,8 @@ struct gf_ctx {
     int screen_variant = 0;     // tuning: load mode / unroll of the filter kernel
     int screen_wg_per_cu = 0;
     int screen_lds_direct = 0;
+    int screen_verify_batch = 64;  // verify kernel: candidates per wave and pass
+    int screen_verify_ext = 1;   // min_hits == 1 without repeat mask: seed-and-extend verification instead of the k-mer table
     int screen_verify_gate = 1;  // verify kernel: consult the k-mer table only around exact 16-mer hits
     int screen_stream_policy = 1;  // pipelined filter: read stream loaded non-temporal (nt): keeps the L2 for the bitmap, -8 % fabric fetches
     int screen_fuse = 0;         // wave kernel: 0 = two-loop form, 3/5/10 = fused L2 probes with that many in flight per lane

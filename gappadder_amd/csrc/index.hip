@@ -16,6 +16,12 @@ struct Entry {
     uint32_t gap;
 };
 
+struct Occ {        // one occurrence of a canonical 16-mer in a flank
+    uint32_t key;
+    uint32_t fid;   // 2 * gap + side
+    uint32_t info;  // pos | strand << 16 | (last << 17, set later) | left room << 18 | right room << 24
+};
+
 inline bool is_acgt(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
 int ceil_log2(size_t v) {
@@ -25,7 +31,8 @@ int ceil_log2(size_t v) {
 }
 
 // canonical k-mers (and canonical 16-mers inside them) of one flank; k-mers touching a non-ACGT byte are skipped
-void extract(const std::string& s, int k, uint32_t gap, std::vector<Entry>& kmers, std::vector<uint32_t>& s16) {
+void extract(const std::string& s, int k, uint32_t gap, std::vector<Entry>& kmers, std::vector<uint32_t>& s16,
+             uint32_t fid, std::vector<Occ>& occ) {
     const int n = (int)s.size();
     int run = 0;  // length of the current ACGT run ending at i
     for (int i = 0; i < n; ++i) {
@@ -51,7 +58,13 @@ void extract(const std::string& s, int k, uint32_t gap, std::vector<Entry>& kmer
             uint32_t w = 0;
             for (int q = i; q < j; ++q) {
                 w = (w << 2) | base_code(s[q]);
-                if (q - i + 1 >= 16) s16.push_back(canon16(w));
+                if (q - i + 1 >= 16) {
+                    const uint32_t key = canon16(w);
+                    s16.push_back(key);
+                    const int pos = q - 15;                       // the 16-mer occupies [pos, pos + 16) of the run [i, j)
+                    const uint32_t lroom = (uint32_t)std::min(63, pos - i), rroom = (uint32_t)std::min(63, j - (pos + 16));
+                    occ.push_back({key, fid, (uint32_t)pos | (key != w ? 1u << 16 : 0u) | lroom << 18 | rroom << 24});
+                }
             }
         }
         i = j;
@@ -65,6 +78,10 @@ void free_flank_index(gf_ctx*, FlankIndex& ix) {
     if (ix.d_bitmap_lds) (void)hipFree(ix.d_bitmap_lds);
     if (ix.d_sset) (void)hipFree(ix.d_sset);
     if (ix.d_table) (void)hipFree(ix.d_table);
+    if (ix.d_sval) (void)hipFree(ix.d_sval);
+    if (ix.d_occ) (void)hipFree(ix.d_occ);
+    if (ix.d_fpk) (void)hipFree(ix.d_fpk);
+    if (ix.d_foff) (void)hipFree(ix.d_foff);
     ix = FlankIndex();
 }
 
@@ -82,11 +99,13 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
 
     std::vector<Entry> ent;
     std::vector<uint32_t> s16;
+    std::vector<Occ> occ;
     const size_t ng = ctx->gaps.size();
     ent.reserve(ng * 600);
+    occ.reserve(ng * 600);
     for (size_t g = 0; g < ng; ++g) {
-        extract(ctx->flank_left[g], k, (uint32_t)g, ent, s16);
-        extract(ctx->flank_right[g], k, (uint32_t)g, ent, s16);
+        extract(ctx->flank_left[g], k, (uint32_t)g, ent, s16, (uint32_t)(2 * g), occ);
+        extract(ctx->flank_right[g], k, (uint32_t)g, ent, s16, (uint32_t)(2 * g + 1), occ);
     }
     std::sort(ent.begin(), ent.end(), [](const Entry& a, const Entry& b) {
         return a.key < b.key || (a.key == b.key && a.gap < b.gap);
@@ -140,6 +159,38 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
         sset[s] = key;
     }
     for (int i = 0; i < 4; ++i) sset[scap + i] = sset[i];   // wrap-around copy: a 4-slot read never needs the modulo
+    // occurrence lists for the seed-and-extend verification: sorted by key, the last of a key flagged, sval[slot] = first
+    std::sort(occ.begin(), occ.end(), [](const Occ& a, const Occ& b) {
+        return a.key < b.key || (a.key == b.key && (a.fid < b.fid || (a.fid == b.fid && a.info < b.info)));
+    });
+    std::vector<uint32_t> sval(scap + 4, 0), occw(2 * occ.size() + 2, 0);
+    for (size_t i = 0; i < occ.size(); ++i) {
+        const bool first = i == 0 || occ[i - 1].key != occ[i].key, last = i + 1 == occ.size() || occ[i + 1].key != occ[i].key;
+        if (first) {
+            uint32_t s = hash_s16_set(occ[i].key, ix.s_log2);
+            while (sset[s] != occ[i].key) s = (s + 1) & (scap - 1);
+            sval[s] = (uint32_t)i;
+        }
+        occw[2 * i] = occ[i].fid;
+        occw[2 * i + 1] = occ[i].info | (last ? 1u << 17 : 0u);
+    }
+    for (int i = 0; i < 4; ++i) sval[scap + i] = sval[i];
+    // flanks, 2 bits per base (non-ACGT -> A; the room fields keep extensions inside ACGT runs), 4 zero words around each
+    std::vector<uint32_t> foff(2 * ng + 1, 0), fpk;
+    for (size_t f = 0; f < 2 * ng; ++f) {
+        const std::string& fs = (f & 1) ? ctx->flank_right[f >> 1] : ctx->flank_left[f >> 1];
+        fpk.insert(fpk.end(), 4, 0u);
+        foff[f] = (uint32_t)fpk.size();
+        const size_t nw = (fs.size() + 15) / 16;
+        const size_t base = fpk.size();
+        fpk.insert(fpk.end(), nw, 0u);
+        for (size_t i = 0; i < fs.size(); ++i) fpk[base + i / 16] |= base_code(fs[i]) << (30 - 2 * (i % 16));
+        fpk.insert(fpk.end(), 4, 0u);
+    }
+    foff[2 * ng] = (uint32_t)fpk.size();
+    ix.ext_ok = true;
+    for (size_t g = 0; g < ng; ++g) ix.ext_ok = ix.ext_ok && ctx->flank_left[g].size() < 65536 && ctx->flank_right[g].size() < 65536;
+    if (fpk.empty()) fpk.push_back(0);
     // level 1 bitmap: at least 16 bits per key (<= 6 % false positives per probe, resolved by level 2) and never
     // fewer than 2^24 bits: the filter kernels test a 2^20-bit coarse copy in LDS first, and a level-1 bitmap only a few
     // times finer than that copy stops too little of what the copy lets through (measured on MI355X, 50 M reads:
@@ -177,6 +228,14 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
     GF_HIP(ctx, hipMalloc(&ix.d_table, tab.size() * 4));
     GF_HIP(ctx, hipMemcpy(ix.d_bitmap, bm.data(), bwords * 4, hipMemcpyHostToDevice));
     GF_HIP(ctx, hipMemcpy(ix.d_sset, sset.data(), (scap + 4) * 4, hipMemcpyHostToDevice));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_sval, sval.size() * 4));
+    GF_HIP(ctx, hipMemcpy(ix.d_sval, sval.data(), sval.size() * 4, hipMemcpyHostToDevice));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_occ, occw.size() * 4));
+    GF_HIP(ctx, hipMemcpy(ix.d_occ, occw.data(), occw.size() * 4, hipMemcpyHostToDevice));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_fpk, fpk.size() * 4));
+    GF_HIP(ctx, hipMemcpy(ix.d_fpk, fpk.data(), fpk.size() * 4, hipMemcpyHostToDevice));
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_foff, foff.size() * 4));
+    GF_HIP(ctx, hipMemcpy(ix.d_foff, foff.data(), foff.size() * 4, hipMemcpyHostToDevice));
     GF_HIP(ctx, hipMemcpy(ix.d_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     auto ins = ctx->index.emplace(k, ix);
     *out = &ins.first->second;

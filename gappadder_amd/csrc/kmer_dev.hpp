@@ -146,4 +146,15 @@ GF_HD K128 stream_kmer(P words, uint32_t bitoff, int k) {
     return mask_k(v, k);
 }
 
+// k <= 32: the same arithmetic on the one 64-bit word that carries the k-mer (the low word is zero)
+template <typename P>
+GF_HD uint64_t stream_kmer64(P words, uint32_t bitoff, int k) {
+    const uint64_t v = ((uint64_t)stream32(words, bitoff) << 32) | stream32(words, bitoff + 32);
+    return v & (~0ull << (64 - 2 * k));
+}
+GF_HD uint64_t canonical64(uint64_t f, int k) {
+    const uint64_t r = revpairs64(~f) << (64 - 2 * k);
+    return r < f ? r : f;
+}
+
 }  // namespace gf

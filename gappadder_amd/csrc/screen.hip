@@ -812,6 +812,12 @@ struct VerifyParams {
     // window gate: the exact canonical-16-mer set and the filter's probe geometry (sset null = gate off)
     const uint32_t* sset;
     uint32_t s_log2, stride, np;
+    uint32_t batch;          // candidates per wave and pass (<= 64)
+    // seed-and-extend kernel: occurrence lists and packed flanks (index.hip)
+    const uint32_t* sval;
+    const uint32_t* occ;
+    const uint32_t* fpk;
+    const uint32_t* foff;
     uint32_t* overflow;      // counter: candidates whose (position, gap) list exceeded list_cap
     uint32_t* overflow_list; // their read ids (re-verified by a second launch with a large list), or null
 };
@@ -846,7 +852,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
 
     // 64 candidates per wave and pass.  (Measured: smaller batches on more concurrent waves are SLOWER — the pass is bound by
     // random 16-B table loads served from the Infinity Cache, not by wave count.)
-    const uint32_t bsz = 64;
+    const uint32_t bsz = P.batch;
     for (uint32_t c0 = blockIdx.x * bsz; c0 < n_cand; c0 += gridDim.x * bsz) {
         const uint32_t nb = n_cand - c0 < bsz ? n_cand - c0 : bsz;
         const uint32_t my_r = lane < nb ? P.cand[c0 + lane] : 0;
@@ -925,39 +931,50 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
                     cn[u] = K128{0, 0};
                     slot[u] = 0;
                     if (act[u]) {
-                        cn[u] = canonical(stream_kmer(rwp, 2 * p, (int)P.k), (int)P.k);
+                        if (WIDE) cn[u] = canonical(stream_kmer(rwp, 2 * p, (int)P.k), (int)P.k);
+                        else cn[u] = K128{canonical64(stream_kmer64(rwp, 2 * p, (int)P.k), (int)P.k), 0};   // k <= 32: one word
                         slot[u] = hash_kmer(cn[u], (int)P.t_log2);
                     }
                 }
-                while (__any(act[0] || act[1])) {  // wave-uniform probe steps; finished lanes idle
-                    uint4 a[2], b[2];
+                // wave-uniform probe steps; finished lanes idle.  Two consecutive slots per step and position: the common chain
+                // (one matching entry, then the EMPTY terminator) ends in ONE round trip — the kernel walks its 64 candidates
+                // one after the other, so round trips per candidate set its pace
+                while (__any(act[0] || act[1])) {
+                    uint4 a[2][2], b[2][2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        a[u] = make_uint4(0, 0, EMPTY32, 0);
-                        b[u] = make_uint4(EMPTY32, 0, 0, 0);
-                        if (act[u]) {
-                            if (WIDE) { a[u] = P.table[2 * (uint64_t)slot[u]]; b[u] = P.table[2 * (uint64_t)slot[u] + 1]; }
-                            else a[u] = P.table[slot[u]];
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            a[u][d] = make_uint4(0, 0, EMPTY32, 0);
+                            b[u][d] = make_uint4(EMPTY32, 0, 0, 0);
+                            if (act[u]) {
+                                const uint64_t sl = (slot[u] + d) & tmask;
+                                if (WIDE) { a[u][d] = P.table[2 * sl]; b[u][d] = P.table[2 * sl + 1]; }
+                                else a[u][d] = P.table[sl];
+                            }
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const uint32_t g = WIDE ? b[u].x : a[u].z;
-                        bool eq = false;
-                        if (act[u]) {
-                            if (g == EMPTY32) act[u] = false;
-                            else {
-                                eq = (((uint64_t)a[u].y << 32) | a[u].x) == cn[u].hi;
-                                if (WIDE) eq = eq && (((uint64_t)a[u].w << 32) | a[u].z) == cn[u].lo;
-                                slot[u] = (slot[u] + 1) & tmask;
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            const uint32_t g = WIDE ? b[u][d].x : a[u][d].z;
+                            bool eq = false;
+                            if (act[u]) {
+                                if (g == EMPTY32) act[u] = false;
+                                else {
+                                    eq = (((uint64_t)a[u][d].y << 32) | a[u][d].x) == cn[u].hi;
+                                    if (WIDE) eq = eq && (((uint64_t)a[u][d].w << 32) | a[u][d].z) == cn[u].lo;
+                                }
+                            }
+                            const unsigned long long bal = __ballot(eq);
+                            if (bal) {
+                                const uint32_t o = n + __popcll(bal & ((1ull << lane) - 1));
+                                if (eq && o < P.list_cap) list[o] = g;
+                                n += (uint32_t)__popcll(bal);
                             }
                         }
-                        const unsigned long long bal = __ballot(eq);
-                        if (bal) {
-                            const uint32_t o = n + __popcll(bal & ((1ull << lane) - 1));
-                            if (eq && o < P.list_cap) list[o] = g;
-                            n += (uint32_t)__popcll(bal);
-                        }
+                        slot[u] = (slot[u] + 2) & tmask;
                     }
                 }
             }
@@ -1052,6 +1069,248 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
                 }
             }
             __syncthreads();
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (obuf_n) {
+        const uint32_t nn = obuf_n;
+        uint32_t gb = 0;
+        if (lane == 0) gb = atomicAdd(P.n_out, nn);
+        gb = __shfl(gb, 0);
+        for (uint32_t q = lane; q < nn; q += 64)
+            if (gb + q < P.cap) P.out[gb + q] = obuf[q];
+    }
+}
+
+// ---- seed-and-extend verification (min_hits == 1, no repeat mask) -----------------------------------------------------
+// A read k-mer at offset p equals a flank k-mer (either strand) iff the ONE stride-aligned 16-mer inside it (read offset
+// q = ceil(p / stride) * stride) equals the 16-mer at the corresponding flank position AND the exact match extends from that
+// seed far enough to cover [p, p + k) inside the read, the flank's ACGT run and no read N.  So instead of hashing every
+// k-mer of a candidate into the 16-B/slot k-mer table (tens of MB: every lookup a fabric request), each aligned 16-mer that
+// is a flank 16-mer (exact set, 4 slots per request) is looked up in its occurrence list and the match is extended along
+// the diagonal by XOR of 16-base words against the 2-bit packed flanks (0.15 MB at C2: L2/L1 resident):
+//   hit(gap)  <=>  some seed/occurrence of that gap has  left_ext + 16 + right_ext >= k,
+// extensions capped by k - 16, the read ends, the nearest read N, and the flank's room inside its ACGT run.
+// Palindromic 16-mers are tried on both strands.  Candidates that collect more than VEXT_LIST gap entries go to the table
+// kernel through the overflow list.
+constexpr uint32_t VEXT_LIST = 16;
+
+__device__ __forceinline__ uint32_t fl32(const uint32_t* words, uint32_t base) {   // 16 bases from base offset `base`, MSB-first words
+    const uint32_t d = base >> 4, sh = 2 * (base & 15);
+    const uint64_t v = ((uint64_t)words[d] << 32) | words[d + 1];
+    return (uint32_t)((v << sh) >> 32);
+}
+
+// 64 mask bits starting at bit `start` (may be negative or run past the row: those bits read 0)
+__device__ __forceinline__ uint64_t nbits64(const uint32_t* m, int nmw, int start) {
+    const int w0 = start >> 5;     // arithmetic shift: floor
+    const uint32_t sh = (uint32_t)start & 31;
+    uint32_t x[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int idx = w0 + t;
+        x[t] = (idx >= 0 && idx < nmw) ? m[idx] : 0u;
+    }
+    const uint64_t lo = ((uint64_t)x[1] << 32) | x[0];
+    return sh ? (lo >> sh) | ((uint64_t)x[2] << (64 - sh)) : lo;
+}
+
+__device__ __forceinline__ bool ext_hit(const uint32_t* row, uint32_t qs, const uint32_t* fw, uint32_t f, bool same, uint32_t capL,
+                                        uint32_t capR, uint32_t k) {
+    // row / fw point at base 0 of the read / flank; both have >= 4 readable words in front and zero padding behind
+    uint32_t lext = 0, rext = 0;
+    for (uint32_t c = 0; 16 * c < capL; ++c) {
+        const uint32_t R = stream32(row - 4, 128 + 2 * (qs - 16 * (c + 1)));
+        const uint32_t F = same ? fl32(fw - 4, 64 + f - 16 * (c + 1)) : revpairs32(~fl32(fw - 4, 64 + f + 16 + 16 * c));
+        const uint32_t X = R ^ F;
+        if (X == 0) { lext += 16; continue; }
+        lext += (uint32_t)__builtin_ctz(X) >> 1;
+        break;
+    }
+    lext = lext < capL ? lext : capL;
+    for (uint32_t c = 0; 16 * c < capR; ++c) {
+        const uint32_t R = stream32(row - 4, 128 + 2 * (qs + 16 + 16 * c));
+        const uint32_t F = same ? fl32(fw - 4, 64 + f + 16 + 16 * c) : revpairs32(~fl32(fw - 4, 64 + f - 16 * (c + 1)));
+        const uint32_t X = R ^ F;
+        if (X == 0) { rext += 16; continue; }
+        rext += (uint32_t)__builtin_clz(X) >> 1;
+        break;
+    }
+    rext = rext < capR ? rext : capR;
+    return lext + rext + 16 >= k;
+}
+
+__global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
+    extern __shared__ uint32_t sm[];   // rows [64][rwp] | nmask [64][nmw] | slots [64][np] | lists [64][VEXT_LIST] | cnt [64]
+    constexpr uint32_t OBUF = 128;
+    __shared__ gf_hit obuf[OBUF];
+    __shared__ uint32_t obuf_n;
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) obuf_n = 0;
+    const uint32_t rw = (P.rb + 24) / 4 + 1, rwp = rw + 4;
+    const uint32_t nmw = P.nmask ? P.nmw : 0;
+    uint32_t* rows = sm;
+    uint32_t* nmr = rows + 64 * rwp;
+    uint32_t* slots = nmr + 64 * nmw;
+    uint32_t* lists = slots + 64 * P.np;
+    uint32_t* cnt = lists + 64 * VEXT_LIST;
+    const uint32_t n_cand = *P.n_cand;
+    const uint32_t W = P.k - 16;
+    const uint32_t bsz = P.batch;
+    __syncthreads();
+    for (uint32_t c0 = blockIdx.x * bsz; c0 < n_cand; c0 += gridDim.x * bsz) {
+        const uint32_t nb = n_cand - c0 < bsz ? n_cand - c0 : bsz;
+        const uint32_t my_r = lane < nb ? P.cand[c0 + lane] : 0;
+        {   // stage my candidate's read, re-aligned to a word boundary, behind 4 zero words
+            const uint64_t o = (uint64_t)my_r * P.rb;
+            const uint64_t w0 = o >> 2;
+            const uint32_t sh = (uint32_t)(o & 3) * 8;
+            const uint32_t nw = (P.rb + 3) / 4;
+            uint32_t* row = rows + lane * rwp;
+            row[0] = row[1] = row[2] = row[3] = 0;
+            uint32_t prev = lane < nb ? packed_word(P, w0) : 0;
+            for (uint32_t i = 0; i < rw; ++i) {
+                uint32_t next = 0;
+                if (lane < nb && i < nw) next = packed_word(P, w0 + i + 1);
+                uint32_t v = sh ? (prev >> sh) | (next << (32 - sh)) : prev;
+                if (i >= nw) v = 0;
+                else if (i == nw - 1 && (P.rb & 3)) v &= (1u << ((P.rb & 3) * 8)) - 1;
+                row[4 + i] = v;
+                prev = next;
+            }
+            for (uint32_t i = 0; i < nmw; ++i) nmr[lane * nmw + i] = lane < nb ? P.nmask[(uint64_t)my_r * P.nmw + i] : 0;
+            cnt[lane] = 0;
+        }
+        __syncthreads();
+        // exact-set lookup of every aligned 16-mer of my candidate: slot of the match, or EMPTY32
+        if (lane < nb) {
+            const uint32_t* row = rows + lane * rwp + 4;
+            for (uint32_t q0 = 0; q0 < P.np; q0 += 3) {
+                uint32_t key[3], h[3];
+                Slots4 v[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const uint32_t q = q0 + u < P.np ? q0 + u : P.np - 1;
+                    key[u] = canon16(stream32(row, 2 * q * P.stride));
+                    h[u] = hash_s16_set(key[u], (int)P.s_log2);
+                    v[u] = *reinterpret_cast<const Slots4*>(P.sset + h[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    if (q0 + u >= P.np) continue;
+                    uint32_t sl = EMPTY32;
+                    if (v[u].x == key[u]) sl = h[u];
+                    else if (v[u].y == key[u]) sl = h[u] + 1;
+                    else if (v[u].z == key[u]) sl = h[u] + 2;
+                    else if (v[u].w == key[u]) sl = h[u] + 3;
+                    else if (v[u].x != EMPTY32 && v[u].y != EMPTY32 && v[u].z != EMPTY32 && v[u].w != EMPTY32) {
+                        uint32_t s2 = h[u] + 4;   // rare: four foreign keys in a row
+                        for (;;) {
+                            const uint32_t x = P.sset[s2 & ((1u << P.s_log2) - 1)];
+                            if (x == key[u]) { sl = s2; break; }
+                            if (x == EMPTY32) break;
+                            ++s2;
+                        }
+                    }
+                    slots[lane * P.np + q0 + u] = sl == EMPTY32 ? EMPTY32 : (sl & ((1u << P.s_log2) - 1));
+                }
+            }
+        }
+        __syncthreads();
+        // one work item per (candidate, aligned 16-mer); 64 items at a time
+        const uint32_t n_items = nb * P.np;
+        for (uint32_t i = lane; i < n_items; i += 64) {
+            const uint32_t j = i / P.np, q = i - j * P.np;
+            const uint32_t slot = slots[i];
+            if (slot == EMPTY32) continue;
+            const uint32_t* row = rows + j * rwp + 4;
+            const uint32_t qs = q * P.stride;
+            const uint32_t w16 = stream32(row, 2 * qs);
+            const uint32_t key = canon16(w16);
+            const bool ro = key != w16, pal = revpairs32(~key) == key;
+            uint32_t nl = 64, nr = 64;
+            if (nmw) {
+                const uint32_t* m = nmr + j * nmw;
+                if (nbits64(m, (int)nmw, (int)qs) & 0xFFFFull) continue;      // an N inside the seed: no k-mer through it counts
+                const uint64_t lb = nbits64(m, (int)nmw, (int)qs - 64), rbits = nbits64(m, (int)nmw, (int)qs + 16);
+                nl = lb ? (uint32_t)__builtin_clzll(lb) : 64;
+                nr = rbits ? (uint32_t)__builtin_ctzll(rbits) : 64;
+            }
+            uint32_t baseL = W < qs ? W : qs, baseR = P.read_len - (qs + 16);
+            baseL = baseL < nl ? baseL : nl;
+            baseR = baseR < W ? baseR : W;
+            baseR = baseR < nr ? baseR : nr;
+            uint32_t oi = P.sval[slot];
+            for (;;) {
+                const uint32_t fid = P.occ[2 * oi], info = P.occ[2 * oi + 1];
+                const uint32_t f = info & 0xFFFFu, lroom = (info >> 18) & 63u, rroom = (info >> 24) & 63u;
+                const bool fo = (info >> 16) & 1u;
+                const uint32_t* fw = P.fpk + P.foff[fid];
+                bool hit = false;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bool same = t == 0 ? (ro == fo) : (ro != fo);
+                    if (t == 1 && !pal) break;
+                    const uint32_t capL = baseL < (same ? lroom : rroom) ? baseL : (same ? lroom : rroom);
+                    const uint32_t capR = baseR < (same ? rroom : lroom) ? baseR : (same ? rroom : lroom);
+                    if (capL + capR + 16 < P.k) continue;
+                    hit = hit || ext_hit(row, qs, fw, f, same, capL, capR, P.k);
+                }
+                if (hit) {
+                    const uint32_t g = fid >> 1;
+                    uint32_t* lj = lists + j * VEXT_LIST;
+                    const uint32_t have = cnt[j] < VEXT_LIST ? cnt[j] : VEXT_LIST;
+                    bool dup = false;
+                    for (uint32_t e = 0; e < have; ++e) dup = dup || lj[e] == g;
+                    if (!dup) {
+                        const uint32_t e = atomicAdd(&cnt[j], 1u);
+                        if (e < VEXT_LIST) lj[e] = g;
+                    }
+                }
+                if ((info >> 17) & 1u) break;
+                ++oi;
+            }
+        }
+        __syncthreads();
+        // per candidate: distinct gaps -> hits (a list that ran over goes to the table kernel)
+        {
+            const uint32_t n = lane < nb ? cnt[lane] : 0;
+            const bool over = n > VEXT_LIST;
+            const unsigned long long ob = __ballot(over);
+            if (ob) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.overflow, (uint32_t)__popcll(ob));
+                base = __shfl(base, 0);
+                if (over && P.overflow_list) P.overflow_list[base + __popcll(ob & ((1ull << lane) - 1))] = my_r;
+            }
+            const uint32_t* lj = lists + lane * VEXT_LIST;
+            for (uint32_t d = 0; d < VEXT_LIST; ++d) {
+                bool emit = !over && d < n;
+                uint32_t g = 0;
+                if (emit) {
+                    g = lj[d];
+                    for (uint32_t e = 0; e < d; ++e) emit = emit && lj[e] != g;
+                }
+                const unsigned long long bal = __ballot(emit);
+                if (!bal) { if (!__any(d + 1 < n && !over)) break; else continue; }
+                const uint32_t base = obuf_n;
+                if (emit) obuf[base + __popcll(bal & ((1ull << lane) - 1))] = gf_hit{g, my_r};
+                __syncthreads();
+                if (lane == 0) obuf_n = base + (uint32_t)__popcll(bal);
+                __syncthreads();
+                if (obuf_n >= OBUF - 64) {
+                    const uint32_t nn = obuf_n;
+                    uint32_t gb = 0;
+                    if (lane == 0) gb = atomicAdd(P.n_out, nn);
+                    gb = __shfl(gb, 0);
+                    for (uint32_t q = lane; q < nn; q += 64)
+                        if (gb + q < P.cap) P.out[gb + q] = obuf[q];
+                    __syncthreads();
+                    if (lane == 0) obuf_n = 0;
+                    __syncthreads();
+                }
+            }
         }
         __syncthreads();
     }
@@ -1196,10 +1455,11 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.table = (const uint4*)ix.d_table;
     V.t_log2 = ix.t_log2;
     V.min_hits = min_hits < 1 ? 1 : min_hits;
-    V.sset = ctx->screen_verify_gate ? ix.d_sset : nullptr;
+    V.sset = (ctx->screen_verify_gate || ctx->screen_verify_ext) ? ix.d_sset : nullptr;
     V.s_log2 = ix.s_log2;
     V.stride = ix.stride;
     V.np = (uint32_t)((read_len - 16) / ix.stride + 1);
+    V.batch = (uint32_t)std::min(64, std::max(1, ctx->screen_verify_batch));
     const uint32_t npos = read_len - ix.k + 1;
     V.out = (gf_hit*)d_out;
     V.cap = (uint32_t)cap;
@@ -1218,7 +1478,16 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.list_cap = std::max<uint32_t>(256, 2 * npos);
     V.overflow = d_cnt + 2;
     V.overflow_list = (uint32_t*)ctx->cand2.p;
-    launch_verify(V);
+    V.sval = ix.d_sval; V.occ = ix.d_occ; V.fpk = ix.d_fpk; V.foff = ix.d_foff;
+    if (ctx->screen_verify_ext && V.min_hits == 1 && ix.max_gaps_per_kmer == 0 && ix.ext_ok && V.np >= 1 && V.np <= 32) {
+        // seed-and-extend kernel instead of the k-mer table (same hits; see screen_verify_ext_kernel)
+        const size_t rwp = (rb + 24) / 4 + 1 + 4, nmw = d_nmask ? V.nmw : 0;
+        const size_t lds2 = 64 * (rwp + nmw + V.np + VEXT_LIST + 1) * 4;
+        LaunchTimer tm(ctx, GF_KERNEL_VERIFY);
+        hipLaunchKernelGGL(screen_verify_ext_kernel, dim3(grid2), dim3(64), lds2, ctx->stream, V);
+    } else {
+        launch_verify(V);
+    }
     GF_HIP(ctx, hipGetLastError());
     // pass 2: the queued reads with a list as large as LDS allows; overflowing that is an error (d_cnt[1])
     size_t want = ix.max_gaps_per_kmer ? (size_t)npos * ix.max_gaps_per_kmer : 15000;
