@@ -263,7 +263,7 @@ def main():
                          "frac_of_measured_copy_6290": achieved / 6290.0},
             "phases_ms": phases,
             "phases_note": "HIP-event spans per kernel group; tagger + second hop run on a second stream beside the screen, so "
-                           "their spans include queueing behind the filter kernel (stand-alone: tagger 0.42 ms, verify 0.50 ms)",
+                           "their spans include queueing behind the filter kernel (stand-alone: tagger 0.41 ms, verify 0.16 ms; GF_BENCH_SERIAL=1 runs everything on one stream)",
             "tagger_gbs": n_reads * 32 / (phases["tag_alignments"] * 1e-3) / 1e9,
             "counts": {"screen_hits": n_hits, "tagger_hits": n_thits, "second_hop_hits": n_lhits, "pool_keys": n_keys,
                        "pooled_reads": int(pool_off[-1]), "contigs": n_ctg, "contig_bases": n_seq,

@@ -388,3 +388,62 @@ def test_reads_matching_many_gaps_take_the_large_list_pass(gf):
     full = CO.screen_reads(c["reads_blob"], c["L"], flanks, 31, 1)
     per_read = np.bincount(full["read"])
     assert per_read.max() >= 6          # some read is recruited by all six gaps (>= 6 x 100 matches in the verify list)
+
+
+@pytest.mark.parametrize("k,L", [(16, 60), (17, 80), (31, 100), (33, 100), (48, 150), (64, 150)])
+def test_seed_and_extend_verification_edge_cases(gf, k, L):
+    """The seed-and-extend verify kernel against the oracle on reads built to sit on its edges: matches of exactly k-1, k and
+    k+1 bases on either strand, at the ends of the read and of the flank, next to a read N and next to a non-ACGT flank base,
+    through palindromic 16-mers, and in flanks that repeat a segment (several occurrences per seed, also in other gaps);
+    the same inputs through the k-mer table kernel must agree too."""
+    from gappadder_amd.hip_api import GapFill
+    from gappadder_amd import _lib as B
+    rng = np.random.RandomState(1000 + k)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rnd = lambda n: lut[rng.randint(0, 4, n)].tobytes().decode()
+    pal = lambda: (lambda h: h + h.encode().translate(comp)[::-1].decode())(rnd(8))          # 16-mer == its reverse complement
+    n_gaps = 6
+    flanks = []
+    for g in range(n_gaps):
+        left = rnd(120) + pal() + rnd(60) + "N" + rnd(90) + "acgt" + rnd(70)       # palindrome, N, lower case (= not ACGT)
+        rep = rnd(70)
+        right = rnd(40) + rep + rnd(30) + rep + pal() + rnd(50)                     # a repeated 70-mer
+        flanks.append((left, right))
+    flanks[3] = (flanks[0][0][:200] + rnd(80), flanks[3][1])                        # gap 3 shares 200 bases with gap 0
+    gaps = np.zeros(n_gaps, dtype=B.GAP)
+    gaps["scaffold"] = 0
+    gaps["start"] = (np.arange(n_gaps) + 1) * 10000
+    gaps["end"] = gaps["start"] + 500
+    gaps["idx_in_scaffold"] = np.arange(n_gaps) + 1
+    reads = []
+    for i in range(6000):
+        g = rng.randint(n_gaps)
+        src = flanks[g][rng.randint(2)].upper().replace("N", "A")
+        m = int(rng.choice([k - 1, k, k + 1, k + 5, min(L, k + 40)]))                # length of the copied stretch
+        m = min(m, L, len(src))
+        a = rng.randint(0, len(src) - m + 1)
+        if rng.rand() < 0.2:
+            a = 0 if rng.rand() < 0.5 else len(src) - m                              # at a flank end
+        piece = src[a:a + m]
+        if rng.rand() < 0.5:
+            piece = piece.encode().translate(comp)[::-1].decode()
+        off = rng.randint(0, L - m + 1)
+        if rng.rand() < 0.3:
+            off = 0 if rng.rand() < 0.5 else L - m                                   # at a read end
+        r = list(rnd(L))
+        r[off:off + m] = piece
+        if rng.rand() < 0.3:
+            r[rng.randint(L)] = "N"                                                  # an N somewhere, often inside the stretch
+        reads.append("".join(r))
+    blob = "".join(reads).encode()
+    packed, nm = GapFill.pack_reads(blob, L, with_mask=True)
+    gf.set_gaps(gaps, 1, flanks)
+    exp = CO.screen_reads(blob, L, flanks, k)
+    got = gf.screen_reads(packed, L, k, 1, n_mask=nm)
+    assert _same(got, exp) and len(exp) > 500
+    gf.set_option("screen_verify_ext", 0)
+    try:
+        assert _same(gf.screen_reads(packed, L, k, 1, n_mask=nm), exp)
+    finally:
+        gf.set_option("screen_verify_ext", 1)
