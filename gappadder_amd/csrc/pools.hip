@@ -134,6 +134,47 @@ __global__ void pool_scatter_kernel(const unsigned long long* keys, const uint32
     }
 }
 
+// LDS-privatised forms of the two kernels above (used while one counter per gap fits in LDS): keys of one batch come in
+// random gap order, so the per-wave grouping loops run ~64 rounds; here every block counts its slice of the keys into an LDS
+// histogram with LDS atomics and touches the global counters once per non-empty bin
+__global__ __launch_bounds__(256) void pool_hist_lds_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap,
+                                                            uint32_t n_gaps, uint32_t* cnt) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t n = *n_keys < key_cap ? *n_keys : key_cap;
+    for (uint32_t i = threadIdx.x; i < n_gaps; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x, a = blockIdx.x * per, b = a + per < n ? a + per : n;
+    for (uint32_t i = a + threadIdx.x; i < b; i += blockDim.x) {
+        const uint32_t g = (uint32_t)(keys[i] >> 32);
+        if (g < n_gaps) atomicAdd(&hist[g], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_gaps; i += blockDim.x)
+        if (hist[i]) atomicAdd(&cnt[i], hist[i]);
+}
+
+__global__ __launch_bounds__(256) void pool_scatter_lds_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap,
+                                                               uint32_t n_gaps, const uint32_t* seg_off, uint32_t* cursor, uint32_t* seg) {
+    extern __shared__ uint32_t hist[];   // pass 1: this block's count per gap; pass 2: its next free position per gap
+    const uint32_t n = *n_keys < key_cap ? *n_keys : key_cap;
+    for (uint32_t i = threadIdx.x; i < n_gaps; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x, a = blockIdx.x * per, b = a + per < n ? a + per : n;   // same slices as the histogram
+    for (uint32_t i = a + threadIdx.x; i < b; i += blockDim.x) {
+        const uint32_t g = (uint32_t)(keys[i] >> 32);
+        if (g < n_gaps) atomicAdd(&hist[g], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_gaps; i += blockDim.x)
+        if (hist[i]) hist[i] = seg_off[i] + atomicAdd(&cursor[i], hist[i]);     // reserve this block's range of the gap's segment
+    __syncthreads();
+    for (uint32_t i = a + threadIdx.x; i < b; i += blockDim.x) {
+        const unsigned long long k = keys[i];
+        const uint32_t g = (uint32_t)(k >> 32), read = (uint32_t)k;
+        if (g < n_gaps) seg[atomicAdd(&hist[g], 1u)] = ((read & 1u) << 31) | (read >> 1);   // (mate, pair); order inside a gap is set by the sort
+    }
+}
+
 // one workgroup per gap: bitonic sort of the gap's keys in LDS, duplicates dropped, written back in place
 __global__ __launch_bounds__(256) void pool_sort_unique_kernel(uint32_t n_gaps, const uint32_t* seg_off, uint32_t* seg,
                                                               uint32_t* ucnt, uint32_t* error) {
@@ -284,14 +325,23 @@ int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, 
     GF_HIP(ctx, hipMemsetAsync(d_error, 0, 4, ctx->stream));
     LaunchTimer tm(ctx, GF_KERNEL_POOL);
     const unsigned blocks = ctx->n_cu * 4;
-    if (ng) {
+    const bool lds_bins = ng && (size_t)ng * 4 <= 128 * 1024;     // one LDS counter per gap
+    const unsigned lblocks = std::min<unsigned>(ctx->n_cu, 64);   // few, large slices: global atomics ~ blocks x non-empty bins
+    if (lds_bins) {
+        hipLaunchKernelGGL(pool_hist_lds_kernel, dim3(lblocks), dim3(256), (size_t)ng * 4, ctx->stream, (const unsigned long long*)d_keys,
+                           (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, cnt);
+    } else if (ng) {
         hipLaunchKernelGGL(pool_hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_keys,
                            (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, cnt);
     }
     hipLaunchKernelGGL(pool_scan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, cnt, ng, (void*)seg_off, cursor);
     if (ng) {
-        hipLaunchKernelGGL(pool_scatter_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_keys,
-                           (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, seg_off, cursor, seg);
+        if (lds_bins)
+            hipLaunchKernelGGL(pool_scatter_lds_kernel, dim3(lblocks), dim3(256), (size_t)ng * 4, ctx->stream, (const unsigned long long*)d_keys,
+                               (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, seg_off, cursor, seg);
+        else
+            hipLaunchKernelGGL(pool_scatter_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_keys,
+                               (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, seg_off, cursor, seg);
         hipLaunchKernelGGL(pool_sort_unique_kernel, dim3(std::min<unsigned>(ng, ctx->n_cu * 2)), dim3(256), POOL_SORT_MAX * 4,
                            ctx->stream, ng, seg_off, seg, ucnt, (uint32_t*)d_error);
     }
