@@ -170,13 +170,10 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         return GF_OK;
     }
     if (!strcmp(name, "screen_np_override")) { ctx->screen_np_override = (int)value; return GF_OK; }
-    if (!strcmp(name, "screen_lds_direct")) { ctx->screen_lds_direct = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_verify_batch")) { ctx->screen_verify_batch = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_verify_ext")) { ctx->screen_verify_ext = value != 0; return GF_OK; }
     if (!strcmp(name, "screen_verify_gate")) { ctx->screen_verify_gate = value != 0; return GF_OK; }
     if (!strcmp(name, "screen_stream_policy")) { ctx->screen_stream_policy = (int)value; return GF_OK; }
-    if (!strcmp(name, "screen_fuse")) { if (value != 0 && value != 3 && value != 5 && value != 10) return GF_E_INVAL; ctx->screen_fuse = (int)value; return GF_OK; }
-    if (!strcmp(name, "screen_wg_per_cu")) { ctx->screen_wg_per_cu = (int)value; return GF_OK; }
     return GF_E_INVAL;
 }
 

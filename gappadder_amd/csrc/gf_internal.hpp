@@ -75,14 +75,11 @@ struct gf_ctx {
     std::map<int, gf::FlankIndex> index;  // by k
     uint32_t max_gaps_per_kmer = 0;     // 0 = unlimited
     int bitmap_log2_override = 0;
-    int screen_variant = 0;     // tuning: load mode / unroll of the filter kernel
-    int screen_wg_per_cu = 0;
-    int screen_lds_direct = 0;
+    int screen_variant = 0;     // filter kernel: 0 automatic, 9 plain, 12 wave, 13 pipelined (ablation)
     int screen_verify_batch = 64;  // verify kernel: candidates per wave and pass
     int screen_verify_ext = 1;   // min_hits == 1 without repeat mask: seed-and-extend verification instead of the k-mer table
     int screen_verify_gate = 1;  // verify kernel: consult the k-mer table only around exact 16-mer hits
     int screen_stream_policy = 1;  // pipelined filter: read stream loaded non-temporal (nt): keeps the L2 for the bitmap, -8 % fabric fetches
-    int screen_fuse = 0;         // wave kernel: 0 = two-loop form, 3/5/10 = fused L2 probes with that many in flight per lane
     int screen_np_override = -1;
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)
     int asm_lds_pool_kb = 152;

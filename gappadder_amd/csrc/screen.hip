@@ -2,14 +2,14 @@
 // reads, flank-k-mer lookup to tag reads").  Predicate shape of IsReadContainingFreqKmers
 // (ContigsCompactor-v0.2.0/ContigsMerger/KmerUtils.cpp:215-241) applied per gap on canonical k-mers.
 //
-// Two kernels:
-//   screen_filter_kernel  streams every read once (coalesced 16-B loads of the packed bytes into LDS), probes
-//                         only ceil((L-15)/(k-15)) 16-mers per read against an L2-resident bitmap (any k-mer
-//                         shared with a flank contains one of those 16-mers), confirms bitmap hits
-//                         in an exact 16-mer set, and compacts the surviving read ids with a wave ballot +
-//                         prefix count into a candidate list.  This is the HBM-streaming kernel.
-//   screen_verify_kernel  one wavefront per candidate read: every k-mer position, canonical form, exact table
-//                         lookup, per-gap position count >= min_hits, hit emit.
+// Filter (streams every read once; probes only ceil((L-15)/(k-15)) 16-mers per read, because any k-mer shared with a flank
+// contains one of them; emits candidate read ids):
+//   screen_filter_pipe_kernel  default: coarse bitmap in LDS -> level-1 bitmap in L2 -> exact 16-mer set, software-pipelined
+//   screen_filter_wave_kernel  the same three levels without the pipeline (more than 10 probes per read; ablation)
+//   screen_filter_kernel       no LDS level (key sets that fill the coarse bitmap)
+// Verification of the candidates (exact):
+//   screen_verify_ext_kernel   seed and extend against the packed flanks (min_hits == 1, no repeat mask)
+//   screen_verify_kernel       every k-mer position through the k-mer -> gap table, per-gap position count >= min_hits
 #include "gf_internal.hpp"
 
 namespace gf {
@@ -28,26 +28,11 @@ struct FilterParams {
     // LDS pre-filter variant: a coarser copy of the bitmap (bit i = OR of the 2^(bm_log2-lds_log2) bits it covers)
     const uint32_t* bitmap_lds;
     uint32_t lds_log2;
-    uint32_t lds_direct;   // 1: probes that pass the LDS bitmap go straight to the exact set (no L2 bitmap hop)
     uint32_t stream_policy; // pipelined kernel: cache policy of the read stream (0 default, 1 nt, 2 sc1, 3 sc0 sc1 nt)
 };
 
-// how the filter's bitmap words are fetched: every probe is a 4-byte read of a random 128-B line of an
-// L2-resident table, so the L2->CU transfer per probe is what bounds the kernel
-enum { LOAD_PLAIN = 0, LOAD_NT = 1, LOAD_SC1 = 2, LOAD_SC01 = 3,
-       LOAD_ABL_STREAM = 10,   // ablation builds (timing only, wrong results): tile staging + one LDS word per probe
-       LOAD_ABL_COMPUTE = 11 };  // ... + key/hash arithmetic, no bitmap load
-
-template <int MODE>
-__device__ __forceinline__ uint32_t probe_load(const uint32_t* p) {
-    if (MODE == LOAD_NT) return __builtin_nontemporal_load(p);
-    if (MODE == LOAD_SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (MODE == LOAD_SC01) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return *p;
-}
-
 // PU = probes issued back-to-back before their results are consumed
-template <int MODE, int PU>
+template <int PU>
 __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
     extern __shared__ uint32_t tile[];  // TILE_READS * rb bytes + 16 B pad
     // candidates are buffered per workgroup and appended to the global list with ONE atomic per ~768 of them:
@@ -91,19 +76,15 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
                         word[u] = 0;
                         hb[u] = 0;
                         if (j < g1) {
-                            if (MODE == LOAD_ABL_STREAM) {
-                                word[u] = tile[(bit0 + j * P.stride2) >> 5] == 0x12345678u;
-                            } else {
-                                const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
-                                const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
-                                hb[u] = (h & 31) | (hash_s16_bit2(key) << 8);   // both bits of the key in its word
-                                word[u] = MODE == LOAD_ABL_COMPUTE ? (uint32_t)(h == 0x12345u) : probe_load<MODE>(P.bitmap + (h >> 5));
-                            }
+                            const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
+                            const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
+                            hb[u] = (h & 31) | (hash_s16_bit2(key) << 8);   // both bits of the key in its word
+                            word[u] = P.bitmap[h >> 5];
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < PU; ++u) {
-                        const uint32_t both = MODE >= LOAD_ABL_STREAM ? (word[u] >> (hb[u] & 31)) : (word[u] >> (hb[u] & 31)) & (word[u] >> (hb[u] >> 8));
+                        const uint32_t both = (word[u] >> (hb[u] & 31)) & (word[u] >> (hb[u] >> 8));
                         mask |= (both & 1u) << (j0 - g0 + u);
                     }
                 }
@@ -151,150 +132,6 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
     }
 }
 
-// Variant with an LDS-resident pre-filter.  The L2-resident bitmap is what bounds the plain kernel (one random L2 request
-// per probe); here every workgroup first copies a coarse version of that bitmap (<= 2^20 bits = 128 KiB) into LDS and
-// only probes that pass it go on to L2.  One workgroup per CU (the coarse bitmap fills most of the LDS); tile = one read
-// per thread.  Worth it while the coarse bitmap stays sparse (host decides, see launch_screen).
-constexpr uint32_t LDSF_CBUF = 512;
-
-// NCH = 16-byte chunks of a tile each thread fetches (ceil(rb/16)); the NEXT tile is fetched into registers while the
-// current one is processed (one workgroup per CU: nothing else would overlap the global->LDS latency).  NCH = 0: no prefetch.
-template <int NCH>
-__global__ __launch_bounds__(1024) void screen_filter_lds_kernel(FilterParams P) {
-    extern __shared__ uint32_t sm[];  // [coarse bitmap: 2^lds_log2 bits][tile: blockDim.x reads + 16 B]
-    __shared__ uint32_t cbuf[LDSF_CBUF];
-    __shared__ uint32_t cbuf_n, cbuf_base;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
-    const uint32_t bm_words = 1u << (P.lds_log2 - 5);
-    uint32_t* tile = sm + bm_words;
-    uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
-    for (uint32_t i = tid * 4; i < bm_words; i += nthr * 4)
-        *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap_lds + i);
-    if (tid == 0) cbuf_n = 0;
-    const uint32_t tile_bytes = nthr * P.rb;
-    const uint64_t total_bytes = P.n_reads * P.rb;
-    const uint64_t n_tiles = (P.n_reads + nthr - 1) / nthr;
-    const uint32_t smask = (1u << P.s_log2) - 1;
-    const uint32_t coarse_shift = P.bm_log2 - P.lds_log2;
-    const bool same = coarse_shift == 0;   // the LDS bitmap IS the level-1 bitmap
-    constexpr int NPF = NCH > 0 ? NCH : 1;
-    uint4 pf[NPF];
-    auto prefetch = [&](uint64_t t) {   // 16-B chunks tid, tid+nthr, ... of tile t (whole chunks only)
-        if (NCH == 0 || t >= n_tiles) return;
-        const uint64_t byte0 = t * tile_bytes;
-        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
-        const uint32_t n16 = nbytes >> 4;
-#pragma unroll
-        for (int c = 0; c < NPF; ++c) {
-            const uint32_t i = tid + c * nthr;
-            pf[c] = i < n16 ? *reinterpret_cast<const uint4*>(P.reads + byte0 + (uint64_t)i * 16) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    prefetch(blockIdx.x);
-    __syncthreads();
-
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t byte0 = t * tile_bytes;
-        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
-        const uint32_t n16 = nbytes & ~15u;
-        const uint8_t* src = P.reads + byte0;
-        if (NCH > 0) {
-#pragma unroll
-            for (int c = 0; c < NPF; ++c) {
-                const uint32_t i = tid + c * nthr;
-                if (i < (n16 >> 4)) *reinterpret_cast<uint4*>(tb + (uint64_t)i * 16) = pf[c];
-            }
-        } else {
-            for (uint32_t i = tid * 16; i < n16; i += nthr * 16)
-                *reinterpret_cast<uint4*>(tb + i) = *reinterpret_cast<const uint4*>(src + i);
-        }
-        for (uint32_t i = n16 + tid; i < nbytes; i += nthr) tb[i] = src[i];
-        if (tid < 16) tb[nbytes + tid] = 0;
-        __syncthreads();
-        prefetch(t + gridDim.x);
-
-        const uint64_t r = t * nthr + tid;
-        bool cand = false;
-        if (r < P.n_reads) {
-            const uint32_t bit0 = tid * P.rb * 8;
-            for (uint32_t g0 = 0; g0 < P.np && !cand; g0 += 32) {
-                const uint32_t g1 = g0 + 32 < P.np ? g0 + 32 : P.np;
-                uint32_t m1 = 0;   // probes that pass the LDS bitmap
-                for (uint32_t j = g0; j < g1; ++j) {
-                    const uint32_t h = hash_s16_bitmap(canon16(stream32(tile, bit0 + j * P.stride2)), P.bm_log2);
-                    const uint32_t c = h >> coarse_shift;
-                    m1 |= ((sm[c >> 5] >> (c & 31)) & 1u) << (j - g0);
-                }
-                // level 1 in L2 for the survivors (skipped when the LDS bitmap is the level-1 bitmap itself)
-                uint32_t mask = m1;
-                if (!same && m1) {
-                    mask = 0;
-                    uint32_t m = m1;
-                    while (m) {   // up to 5 L2 probes in flight
-                        uint32_t jj[5], word[5], hb[5];
-#pragma unroll
-                        for (int u = 0; u < 5; ++u) {
-                            word[u] = 0; hb[u] = 0; jj[u] = 0;
-                            if (m) {
-                                jj[u] = __ffs(m) - 1;
-                                m &= m - 1;
-                                const uint32_t key = canon16(stream32(tile, bit0 + (g0 + jj[u]) * P.stride2));
-                                const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
-                                hb[u] = (h & 31) | (hash_s16_bit2(key) << 8);   // both bits of the key in its word
-                                word[u] = P.bitmap[h >> 5];
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 5; ++u) mask |= ((word[u] >> (hb[u] & 31)) & (word[u] >> (hb[u] >> 8)) & 1u) << jj[u];
-                    }
-                }
-                // level 2: confirm in the exact canonical-16-mer set
-                while (mask && !cand) {
-                    const uint32_t j = g0 + __ffs(mask) - 1;
-                    mask &= mask - 1;
-                    const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
-                    uint32_t s = hash_s16_set(key, P.s_log2);
-                    uint32_t v;
-                    while ((v = P.sset[s]) != EMPTY32) {
-                        if (v == key) { cand = true; break; }
-                        s = (s + 1) & smask;
-                    }
-                }
-            }
-        }
-        const unsigned long long bal = __ballot(cand);
-        if (bal) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&cbuf_n, (uint32_t)__popcll(bal));
-            base = __shfl(base, 0);
-            const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
-            if (cand) {
-                if (o < LDSF_CBUF) cbuf[o] = (uint32_t)r;
-                else P.cand[atomicAdd(P.n_cand, 1u)] = (uint32_t)r;   // buffer full (candidate-dense tile): direct append
-            }
-        }
-        __syncthreads();
-        if (cbuf_n > LDSF_CBUF / 2) {
-            const uint32_t n = cbuf_n < LDSF_CBUF ? cbuf_n : LDSF_CBUF;
-            if (tid == 0) cbuf_base = atomicAdd(P.n_cand, n);
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += nthr) P.cand[cbuf_base + i] = cbuf[i];
-            __syncthreads();
-            if (tid == 0) cbuf_n = 0;
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    {
-        const uint32_t n = cbuf_n < LDSF_CBUF ? cbuf_n : LDSF_CBUF;
-        if (n) {
-            if (tid == 0) cbuf_base = atomicAdd(P.n_cand, n);
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += nthr) P.cand[cbuf_base + i] = cbuf[i];
-        }
-    }
-}
-
 // Wave-autonomous variant of the LDS pre-filter kernel: every wavefront streams its own 64-read mini-tiles through a
 // private LDS slice (no workgroup barrier in the loop, so one wave waiting on an L2 chain never stalls the other eleven),
 // prefetches its next mini-tile into registers, and appends candidates through a private LDS buffer.
@@ -305,7 +142,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int NCH, int FU>
+template <int NCH>
 __global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P, uint32_t slice_words) {
     extern __shared__ uint32_t sm[];  // [coarse bitmap][per wave: 64 reads + pad | WOBUF candidate ids]
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthr = blockDim.x, nw = nthr >> 6;
@@ -321,7 +158,7 @@ __global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P
     const uint64_t n_tiles = (P.n_reads + 63) / 64;
     const uint32_t smask = (1u << P.s_log2) - 1;
     const uint32_t coarse_shift = P.bm_log2 - P.lds_log2;
-    const bool same = coarse_shift == 0 || P.lds_direct;
+    const bool same = coarse_shift == 0;
     const bool bytes_ok = (P.stride2 & 7) == 0;   // probes start on byte boundaries (k = 31, 35, 39, ...)
     constexpr int NPF = NCH > 0 ? NCH : 1;
     // three mini-tiles in flight per wave: with ~11 waves per CU a single outstanding 2.4-KB fetch per wave leaves the
@@ -371,30 +208,6 @@ __global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P
             for (uint32_t g0 = 0; g0 < P.np && !cand; g0 += 32) {
                 const uint32_t g1 = g0 + 32 < P.np ? g0 + 32 : P.np;
                 uint32_t m1 = 0;   // probes that pass the LDS bitmap; three probes' LDS reads in flight at a time
-                if (FU > 0) {
-                    // fused: a probe that passes the coarse LDS bitmap issues its L2 bitmap load at once, while its hash is
-                    // live, instead of being re-derived in a second (divergent) loop; FU probes in flight per lane
-                    constexpr int U = FU > 0 ? FU : 1;
-                    for (uint32_t j0 = g0; j0 < g1; j0 += U) {
-                        uint32_t h[U], bw[U], word[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const uint32_t j = j0 + u < g1 ? j0 + u : g1 - 1;
-                            const uint32_t w32 = bytes_ok ? stream32_bytes(tile, (bit0 + j * P.stride2) >> 3) : stream32(tile, bit0 + j * P.stride2);
-                            h[u] = hash_s16_bitmap(canon16(w32), P.bm_log2);
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; ++u) bw[u] = sm[h[u] >> (coarse_shift + 5)];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const bool pass = ((bw[u] >> ((h[u] >> coarse_shift) & 31)) & 1u) && j0 + u < g1;
-                            word[u] = pass ? 0xFFFFFFFFu : 0u;
-                            if (pass && !same) word[u] = P.bitmap[h[u] >> 5];
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; ++u) m1 |= ((word[u] >> (h[u] & 31)) & 1u) << (j0 + u - g0);
-                    }
-                } else
                 for (uint32_t j0 = g0; j0 < g1; j0 += 3) {
                     uint32_t w32[3], c[3], bw[3];
 #pragma unroll
@@ -412,7 +225,7 @@ __global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P
                         if (j0 + u < g1) m1 |= ((bw[u] >> (c[u] & 31)) & 1u) << (j0 + u - g0);
                 }
                 uint32_t mask = m1;
-                if (FU == 0 && !same && m1) {
+                if (!same && m1) {
                     mask = 0;
                     uint32_t m = m1;
                     while (m) {   // up to 5 L2 probes in flight
@@ -1354,27 +1167,23 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     F.n_cand = d_cnt;
     F.bitmap_lds = ix.d_bitmap_lds;
     F.lds_log2 = ix.lds_log2;
-    F.lds_direct = ctx->screen_lds_direct;
     F.stream_policy = (uint32_t)ctx->screen_stream_policy;
-    const size_t n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
-    const size_t lds = TILE_READS * rb + 16;
-    const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * (ctx->screen_wg_per_cu > 0 ? ctx->screen_wg_per_cu : 8));
-    // LDS pre-filter variant: pays while the coarse bitmap is sparse enough to stop most probes before L2
-    // (screen_variant 8 forces it, 9 forbids it)
+    // Kernel choice (screen_variant: 0 = automatic; 9 / 12 / 13 force the plain / wave / pipelined kernel, for ablation):
+    // the LDS pre-filter pays while the coarse bitmap is sparse enough to stop most probes before L2 and a handful of waves
+    // fit next to it (long reads leave too few); the pipelined form covers up to 10 probes and 64 packed bytes per read
     const size_t w_bm_bytes = ix.d_bitmap_lds ? ((size_t)1 << ix.lds_log2) / 8 : 0;
     const size_t w_slice_words = ((size_t)64 * rb + 16 + 15) / 16 * 4;
     const size_t w_per_wave = (w_slice_words + WOBUF) * 4;
     const size_t w_nw = std::min<size_t>(16, (160 * 1024 - 512 - w_bm_bytes) / w_per_wave);
-    // the wave kernel needs a handful of waves per CU next to the coarse bitmap (long reads leave too few: plain kernel then)
-    const bool lds_ok = ix.d_bitmap_lds && ix.lds_fill <= 0.6 && ctx->screen_variant != 9 && w_nw >= 6;
-    const bool pipe_ok = F.np >= 1 && F.np <= 10 && ix.lds_log2 >= 7 && (rb + 15) / 16 <= 4;
-    if (((lds_ok && ctx->screen_variant == 0) || (ctx->screen_variant == 13 && ix.d_bitmap_lds && w_nw >= 2)) && pipe_ok) {
+    const size_t tiles64 = (n_reads + 63) / 64;
+    const int nch = (rb + 15) / 16 <= 4 ? (int)((rb + 15) / 16) : 0;
+    const bool lds_auto = ix.d_bitmap_lds && ix.lds_fill <= 0.6 && ctx->screen_variant == 0 && w_nw >= 6;
+    const bool lds_forced = (ctx->screen_variant == 12 || ctx->screen_variant == 13) && ix.d_bitmap_lds && w_nw >= 2;
+    const bool pipe_ok = F.np >= 1 && F.np <= 10 && ix.lds_log2 >= 7 && nch >= 1 && ctx->screen_variant != 12;
+    if ((lds_auto || lds_forced) && pipe_ok) {
         // software-pipelined wave kernel (three tiles in flight per wave)
-        size_t nw = std::min<size_t>(w_nw, 8);   // measured: 8 waves x 256 VGPRs beat 11 x 168
-        if (ctx->screen_wg_per_cu > 0) nw = std::min<size_t>(nw, (size_t)ctx->screen_wg_per_cu);   // diagnostic: fewer waves per CU
-        const size_t tiles2 = (n_reads + 63) / 64;
-        const int nch = (rb + 15) / 16 <= 4 ? (int)((rb + 15) / 16) : 0;
-        const int npt = std::max(5, (int)F.np);   // probes per read, unrolled
+        const size_t nw = std::min<size_t>(w_nw, 8);   // measured: 8 waves x 256 VGPRs beat 11 x 168
+        const int npt = std::max(5, (int)F.np);        // probes per read, unrolled
         void (*wk)(FilterParams, uint32_t) = nullptr;
 #define GF_PK(N, Q) if (nch == N && npt == Q) wk = (int)F.np == Q ? screen_filter_pipe_kernel<N, Q, true> : screen_filter_pipe_kernel<N, Q, false>;
 #define GF_PKX(N, Q) if (nch == N && npt == Q) wk = screen_filter_pipe_kernel<N, Q, true>;
@@ -1385,59 +1194,26 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
 #undef GF_PKN
 #undef GF_PK
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles2 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
+        hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
                            w_bm_bytes + nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
-    } else if ((lds_ok && ctx->screen_variant == 0) || (ctx->screen_variant == 12 && ix.d_bitmap_lds && w_nw >= 2)) {
+    } else if (lds_auto || lds_forced) {
         // wave-autonomous LDS pre-filter kernel: as many waves per CU as fit next to the coarse bitmap
-        const size_t bm_bytes = w_bm_bytes, slice_words = w_slice_words, per_wave = w_per_wave, nw = w_nw;
-        const size_t tiles2 = (n_reads + 63) / 64;
-        void (*wk)(FilterParams, uint32_t) = screen_filter_wave_kernel<0, 0>;
-        const int nch = (rb + 15) / 16 <= 4 ? (int)((rb + 15) / 16) : 0;
-        const int fu = ctx->screen_fuse;
-#define GF_WK(N, F) if (nch == N && fu == F) wk = screen_filter_wave_kernel<N, F>;
-#define GF_WKN(N) GF_WK(N, 0) GF_WK(N, 3) GF_WK(N, 5) GF_WK(N, 10)
-        GF_WKN(0) GF_WKN(1) GF_WKN(2) GF_WKN(3) GF_WKN(4)
-#undef GF_WKN
-#undef GF_WK
-        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles2 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
-                           bm_bytes + nw * per_wave, ctx->stream, F, (uint32_t)slice_words);
-    } else if (ctx->screen_variant == 8 && ix.d_bitmap_lds) {
-        const size_t bm_bytes = ((size_t)1 << ix.lds_log2) / 8;
-        size_t thr = (160 * 1024 - 2600 - bm_bytes - 16) / rb;
-        thr = std::min<size_t>(1024, thr / 64 * 64);
-        if (thr >= 256) {
-            const size_t tiles2 = (n_reads + thr - 1) / thr;
-            LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-            void (*lk)(FilterParams) = screen_filter_lds_kernel<0>;
-            switch ((rb + 15) / 16) {
-                case 1: lk = screen_filter_lds_kernel<1>; break;
-                case 2: lk = screen_filter_lds_kernel<2>; break;
-                case 3: lk = screen_filter_lds_kernel<3>; break;
-                case 4: lk = screen_filter_lds_kernel<4>; break;
-                default: break;
-            }
-            hipLaunchKernelGGL(lk, dim3((unsigned)std::min<size_t>(tiles2, ctx->n_cu)), dim3((unsigned)thr),
-                               bm_bytes + thr * rb + 16, ctx->stream, F);
-        } else {
-            return GF_E_UNSUPPORTED;
-        }
-    } else {
-        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        void (*kern)(FilterParams) = screen_filter_kernel<LOAD_PLAIN, 9>;
-        switch (ctx->screen_variant) {
-            case 1: kern = screen_filter_kernel<LOAD_NT, 3>; break;
-            case 2: kern = screen_filter_kernel<LOAD_SC1, 3>; break;
-            case 3: kern = screen_filter_kernel<LOAD_SC01, 3>; break;
-            case 4: kern = screen_filter_kernel<LOAD_PLAIN, 3>; break;
-            case 5: kern = screen_filter_kernel<LOAD_NT, 9>; break;
-            case 6: kern = screen_filter_kernel<LOAD_SC1, 9>; break;
-            case 7: kern = screen_filter_kernel<LOAD_PLAIN, 1>; break;
-            case 10: kern = screen_filter_kernel<LOAD_ABL_STREAM, 9>; break;
-            case 11: kern = screen_filter_kernel<LOAD_ABL_COMPUTE, 9>; break;
+        void (*wk)(FilterParams, uint32_t) = screen_filter_wave_kernel<0>;
+        switch (nch) {
+            case 1: wk = screen_filter_wave_kernel<1>; break;
+            case 2: wk = screen_filter_wave_kernel<2>; break;
+            case 3: wk = screen_filter_wave_kernel<3>; break;
+            case 4: wk = screen_filter_wave_kernel<4>; break;
             default: break;
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, F);
+        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
+        hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + w_nw - 1) / w_nw, ctx->n_cu)), dim3((unsigned)(w_nw * 64)),
+                           w_bm_bytes + w_nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
+    } else {
+        const size_t n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
+        const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * 8);
+        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
+        hipLaunchKernelGGL(screen_filter_kernel<9>, dim3(grid), dim3(256), TILE_READS * rb + 16, ctx->stream, F);
     }
     GF_HIP(ctx, hipGetLastError());
 

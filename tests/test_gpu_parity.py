@@ -298,9 +298,9 @@ def test_device_pools_follow_the_reference_fastq_join_order(gf):
         assert gseqs == [x[0] for x in e]
 
 
-@pytest.mark.parametrize("variant", [12, 8, 9, 2, 4])
+@pytest.mark.parametrize("variant", [12, 13, 9])
 def test_screen_filter_variants_agree(gf, variant):
-    """Both filter kernels (LDS pre-filter = 8, plain L2 bitmap = 9, plus load-mode/unroll builds) give the oracle's hits."""
+    """Every filter kernel (wave = 12, pipelined = 13, plain L2 bitmap = 9) gives the oracle's hits."""
     from gappadder_amd.hip_api import GapFill
     c = S.small_case(seed=41, n_pairs=25000)
     gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])

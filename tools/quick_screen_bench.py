@@ -23,15 +23,12 @@ flanks = [(lut[rng.randint(0, 4, 295)].tobytes().decode(), lut[rng.randint(0, 4,
 gf = GapFill(0)
 variants = [0] if len(sys.argv) <= 5 else [int(x) for x in sys.argv[5].split(",")]
 import itertools
-fuses = [int(x) for x in os.environ.get("FUSE", "0").split(",")]
-for bl, var, fuse in itertools.product(([0] if len(sys.argv) <= 4 else [int(x) for x in sys.argv[4].split(",")]), variants, fuses):
-    gf.set_option("screen_fuse", fuse)
-    gf.set_option("screen_wg_per_cu", int(os.environ.get("WG", "0")))
-    gf.set_option("screen_stream_policy", int(os.environ.get("POL", "0")))
+for bl, var in itertools.product(([0] if len(sys.argv) <= 4 else [int(x) for x in sys.argv[4].split(",")]), variants):
+    fuse = 0
+    gf.set_option("screen_stream_policy", int(os.environ.get("POL", "1")))
     gf.set_option("bitmap_log2", bl)
     gf.set_option("screen_lds_log2_max", int(os.environ.get("LDSMAX", "20")))
     gf.set_option("screen_variant", var % 100)
-    gf.set_option("screen_lds_direct", (var // 100) % 10)
     gf.set_option("screen_np_override", (var // 1000) - 1 if var >= 1000 else -1)
     t = time.time()
     gf.set_gaps(gaps, int(gaps["scaffold"].max()) + 1, flanks)
