@@ -457,8 +457,20 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         const K128 key = canonical_w<true>(pv_kmer_at<true>(V, r, p, k), k);
                         uint32_t sl = slot_of(key, wcap);
                         for (uint32_t probes = 0; probes < wcap; ++probes) {
-                            unsigned long long b = t.load(2 * sl + 1);
+                            // global table: both words of the slot in ONE 16-byte request (word 0 is in L2 before word 1 is
+                            // published, so a load that sees word 1 published sees word 0 too)
+                            unsigned long long b, a_pre = 0;
+                            bool a_valid = false;
+                            if (LDS) b = t.load(2 * sl + 1);
+                            else {   // sc0 sc1: from L2, like the atomics (the CU's L1 may hold the line as it was before a CAS)
+                                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                                u64x2 q;
+                                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(t.g + 2 * sl) : "memory");
+                                a_pre = q.x; b = q.y;
+                                a_valid = true;
+                            }
                             if (b == EMPTY64) {
+                                a_valid = false;   // b will come from the CAS: word 0 must be read again
                                 b = t.cas(2 * sl + 1, EMPTY64, LOCK);
                                 if (b == EMPTY64) {   // first occurrence: this thread owns the slot
                                     put(2 * sl, key.hi);
@@ -477,7 +489,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                             }
                             if (b == LOCK) { retry = true; break; }
                             asm volatile("" ::: "memory");          // word 0 is read after word 1 was seen published
-                            const unsigned long long a = t.load(2 * sl);
+                            const unsigned long long a = a_valid ? a_pre : t.load(2 * sl);
                             if (a == key.hi && (~b & ~3ull) == key.lo) {
                                 while ((~b & 3ull) != 3ull) {   // saturating increment of the complemented count
                                     const unsigned long long o = t.cas(2 * sl + 1, b, b - 1);
@@ -528,36 +540,50 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         const uint32_t n_dist = s_cnt[4] < n_unit ? s_cnt[4] : n_unit;
         ASM_STAMP(1);
 
-        // ---- P2: survivors (count >= min_count) -> list_b; a global table gets its used slots reset
-        for (uint32_t i0 = 0; i0 < n_dist; i0 += ASM_THREADS) {
-            const uint32_t i = i0 + tid;
-            bool keep = false;
-            uint32_t id = 0, c = 0;
-            if (i < n_dist) {
-                const uint32_t sl = list_a[i];
-                const unsigned long long v = tab.load(keyslot_w ? 2 * sl + 1 : sl);
-                id = (keyslot || keyslot_w) ? dist_inst[i] : (uint32_t)v;
-                c = keyslot_w ? (uint32_t)(~v & 3ull)
-                    : keyslot ? (uint32_t)((tab_global ? ~v : (GF_KS_COMPLEMENT_LDS ? ~v : v)) & 3ull) : (uint32_t)(v >> 32);
-                keep = c >= P.min_count;
-                if (tab_global) {
-                    if (keyslot_w) { tab.store(2 * sl, EMPTY64); tab.store(2 * sl + 1, EMPTY64); }
-                    else tab.store(sl, EMPTY64);
-                }
+        // ---- P2: survivors (count >= min_count) -> list_b; a global table gets its used slots reset.  Four items per thread
+        //      and round with their (dependent: list -> slot) loads issued together: in the global table this phase is a
+        //      chain of L2/fabric round trips
+        for (uint32_t i0 = 0; i0 < n_dist; i0 += 4 * ASM_THREADS) {
+            uint32_t sl[4], idv[4];
+            unsigned long long v[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * ASM_THREADS + tid;
+                in[u] = i < n_dist;
+                sl[u] = in[u] ? list_a[i] : 0;
+                idv[u] = (in[u] && (keyslot || keyslot_w)) ? dist_inst[i] : 0;
             }
-            const unsigned long long bal = __ballot(keep);
-            if (bal) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&s_cnt[0], (uint32_t)__popcll(bal));
-                base = __shfl(base, 0);
-                if (keep) {
-                    const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
-                    list_b[o] = id;
-                    if (P.cnt_keys && o < P.cnt_cap) {
-                        const K128 key = canonical_w<W>(pv_kmer<W>(V, id, k), k);
-                        P.cnt_keys[2 * (uint64_t)o] = key.hi;
-                        P.cnt_keys[2 * (uint64_t)o + 1] = key.lo;
-                        P.cnt_counts[o] = c > 10000000u ? 10000000u : c;  // kmc -cs10000000 (assemble_gaps.py:96)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = in[u] ? tab.load(keyslot_w ? 2 * sl[u] + 1 : sl[u]) : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bool keep = false;
+                uint32_t id = 0, c = 0;
+                if (in[u]) {
+                    id = (keyslot || keyslot_w) ? idv[u] : (uint32_t)v[u];
+                    c = keyslot_w ? (uint32_t)(~v[u] & 3ull)
+                        : keyslot ? (uint32_t)((tab_global ? ~v[u] : (GF_KS_COMPLEMENT_LDS ? ~v[u] : v[u])) & 3ull) : (uint32_t)(v[u] >> 32);
+                    keep = c >= P.min_count;
+                    if (tab_global) {
+                        if (keyslot_w) { tab.store(2 * sl[u], EMPTY64); tab.store(2 * sl[u] + 1, EMPTY64); }
+                        else tab.store(sl[u], EMPTY64);
+                    }
+                }
+                const unsigned long long bal = __ballot(keep);
+                if (bal) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_cnt[0], (uint32_t)__popcll(bal));
+                    base = __shfl(base, 0);
+                    if (keep) {
+                        const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
+                        list_b[o] = id;
+                        if (P.cnt_keys && o < P.cnt_cap) {
+                            const K128 key = canonical_w<W>(pv_kmer<W>(V, id, k), k);
+                            P.cnt_keys[2 * (uint64_t)o] = key.hi;
+                            P.cnt_keys[2 * (uint64_t)o + 1] = key.lo;
+                            P.cnt_counts[o] = c > 10000000u ? 10000000u : c;  // kmc -cs10000000 (assemble_gaps.py:96)
+                        }
                     }
                 }
             }
