@@ -64,6 +64,7 @@ def lib():
         "gf_pack_reads": (i32, [C.c_char_p, sz, i32, vp, vp]),
         "gf_packed_read_bytes": (sz, [i32]),
         "gf_fastq_pack": (i32, [vp, C.c_char_p, sz, i32, vp, sz, vp, vp, szp, C.POINTER(C.c_uint32)]),
+        "gf_sam_pack": (i32, [vp, C.c_char_p, sz, C.c_char_p, vp, sz, vp, sz, vp, szp]),
         "gf_fastq_pack_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp, vp, vp]),
         "gf_screen_reads": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, szp]),
         "gf_screen_reads_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, vp]),

@@ -26,10 +26,16 @@ def read_rows(path):
 
 def low_mapq_lines(gf, sam_lines, scaffold, rows, n_scaffolds):
     """-> {'left': [...], 'right': [...]} or None when no MAPQ-0 record was seen (the reference then writes no file)."""
-    sidx = {scaffold: int(rows["mate_scaffold"][0])} if len(rows) else {scaffold: 0}
-    recs, cols = sam_io.decode(sam_lines, sidx)
-    if not any(int(f[4]) == 0 for f in cols):
-        return None
+    idx = int(rows["mate_scaffold"][0]) if len(rows) else 0
+    if hasattr(gf, "sam_pack"):      # SAM text parsed on the GPU; only this scaffold's name has an index, as below
+        names = ["\x00%d" % i for i in range(idx)] + [scaffold]
+        recs, cols = sam_io.decode_on_device(gf, sam_lines, names)
+        if not (recs["mapq"] == 0).any():
+            return None
+    else:
+        recs, cols = sam_io.decode(sam_lines, {scaffold: idx})
+        if not any(int(f[4]) == 0 for f in cols):
+            return None
     out = {"left": [], "right": []}
     if len(rows):
         for h in gf.tag_low_mapq(recs, rows):

@@ -29,13 +29,24 @@ class GapReadsCollector:
         gaps, _ = sam_io.read_gap_positions(sf_gap_pos, sidx)
         gf = self._gf or GapFill(int(os.environ.get("GF_DEVICE", "0")))
         gf.set_gaps(gaps, len(names))
-        recs, cols = sam_io.decode(sam_lines, sidx)
+        on_device = hasattr(gf, "sam_pack")     # SAM text parsed on the GPU (gf_sam_pack); columns are cut lazily for the hits
+        recs, cols = sam_io.decode_on_device(gf, sam_lines, names) if on_device else sam_io.decode(sam_lines, sidx)
         hits = gf.tag_alignments(recs, self.insert_size, self.derivation, self.dist_clip, anchor_mapq)
         with_gaps = set(int(g) for g in gaps["scaffold"])
         out = {}
-        for f in cols:   # the reference opens the pair of files at the first record of a scaffold (:93-102)
-            if sidx.get(f[2], -1) in with_gaps and f[2] not in out:
-                out[f[2]] = {"left": [], "right": []}
+        # the reference opens the pair of files at the first record of a scaffold (:93-102)
+        seen = []
+        if on_device:
+            import numpy as np
+            _, first = np.unique(recs["ref"], return_index=True)
+            seen = [names[int(recs["ref"][i])] for i in sorted(first) if int(recs["ref"][i]) < len(names)]
+        else:
+            for f in cols:
+                if f[2] not in seen:
+                    seen.append(f[2])
+        for name in seen:
+            if sidx.get(name, -1) in with_gaps and name not in out:
+                out[name] = {"left": [], "right": []}
         for h in hits:
             f = cols[h["rec"]]
             g = gaps[h["gap"]]

@@ -5,6 +5,8 @@
 // that starts at a record boundary) is copied to HBM as it is and three small kernels turn it into the packed layout of
 // gf_pack_reads: count the newlines per tile, scan, record where every header and sequence line starts/ends, pack.  The host
 // keeps the text for the ids; the device returns the byte offset of every record's header so that ids can be cut lazily.
+#include <vector>
+
 #include "gf_internal.hpp"
 
 namespace gf {
@@ -164,6 +166,160 @@ __global__ __launch_bounds__(256) void fastq_pack_kernel(const uint8_t* text, ui
     }
 }
 
+// ---- SAM text -> 32-byte alignment records --------------------------------------------------------------------------
+// One thread per line.  Columns as the reference reads them (collect_reads_for_gaps.py:76-91: whitespace-split, fields 0-8):
+// FLAG, RNAME, POS, MAPQ, CIGAR, RNEXT, PNEXT, TLEN.  RNAME / RNEXT are looked up in the scaffold-name table ('=' -> RNAME's
+// index; unknown -> 0xFFFFFFFF); clipflag per GapReadsCollector.is_clipped (:13-26).  Header lines ('@') and lines with fewer
+// than nine fields yield no record; the others are numbered in line order.
+
+__device__ __forceinline__ bool is_ws(uint8_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+struct SamNames {
+    const uint8_t* blob;        // names back to back
+    const uint32_t* off;        // n + 1 offsets
+    const uint32_t* table;      // open addressing over FNV-1a of the name -> name index, EMPTY32 free
+    uint32_t t_log2, n;
+};
+
+__device__ __forceinline__ uint32_t fnv1a(const uint8_t* p, uint32_t n) {
+    uint32_t h = 2166136261u;
+    for (uint32_t i = 0; i < n; ++i) h = (h ^ p[i]) * 16777619u;
+    return h;
+}
+
+__device__ __forceinline__ uint32_t sam_name_index(const SamNames& N, const uint8_t* s, uint32_t len) {
+    if (N.n == 0) return 0xFFFFFFFFu;
+    uint32_t sl = fnv1a(s, len) >> (32 - N.t_log2);
+    for (;;) {
+        const uint32_t idx = N.table[sl];
+        if (idx == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+        const uint32_t a = N.off[idx], b = N.off[idx + 1];
+        if (b - a == len) {
+            bool eq = true;
+            for (uint32_t i = 0; i < len && eq; ++i) eq = N.blob[a + i] == s[i];
+            if (eq) return idx;
+        }
+        sl = (sl + 1) & ((1u << N.t_log2) - 1);
+    }
+}
+
+__device__ __forceinline__ long long sam_int(const uint8_t* s, uint32_t len) {
+    bool neg = false;
+    uint32_t i = 0;
+    if (len && (s[0] == '-' || s[0] == '+')) { neg = s[0] == '-'; i = 1; }
+    long long v = 0;
+    for (; i < len; ++i) {
+        const uint32_t d = (uint32_t)s[i] - '0';
+        if (d > 9) break;
+        v = v * 10 + d;
+    }
+    return neg ? -v : v;
+}
+
+// every newline position (line L ends at newline number L)
+__global__ __launch_bounds__(ING_THREADS) void nl_all_kernel(const uint8_t* text, uint64_t n, const unsigned long long* tile_off,
+                                                             uint64_t cap, unsigned long long* nl_pos) {
+    __shared__ uint32_t wsum[ING_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t a = (uint64_t)blockIdx.x * ING_TILE + (uint64_t)tid * ING_PER_THREAD;
+    const uint32_t c = a < n ? count_nl_segment(text, n, a) : 0;
+    uint32_t incl = c;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += v;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t before = incl - c;
+    for (uint32_t i = 0; i < w; ++i) before += wsum[i];
+    if (!c) return;
+    unsigned long long idx = tile_off[blockIdx.x] + before;
+    for (uint64_t i = a; i < a + ING_PER_THREAD && i < n; ++i)
+        if (text[i] == '\n') { if (idx < cap) nl_pos[idx] = i; ++idx; }
+}
+
+// pass 1: one flag per line (1 = yields a record); pass 2 (after a scan of the flags' block sums): parse and store
+__device__ __forceinline__ bool sam_fields(const uint8_t* text, uint64_t a, uint64_t b, uint32_t (&fs)[9], uint32_t (&fl)[9]) {
+    // [a, b) = the line without its newline; fs/fl = start (relative to a) and length of the first nine fields
+    uint64_t i = a;
+    if (i < b && text[i] == '@') return false;
+    int nf = 0;
+    while (i < b && nf < 9) {
+        while (i < b && is_ws(text[i])) ++i;
+        if (i >= b) break;
+        const uint64_t s = i;
+        while (i < b && !is_ws(text[i])) ++i;
+        fs[nf] = (uint32_t)(s - a);
+        fl[nf] = (uint32_t)(i - s);
+        ++nf;
+    }
+    return nf == 9;
+}
+
+__global__ __launch_bounds__(256) void sam_flag_kernel(const uint8_t* text, uint64_t n, const unsigned long long* nl_pos, uint64_t n_lines,
+                                                       uint64_t n_nl, uint32_t* block_cnt) {
+    __shared__ uint32_t part[4];
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ok = 0;
+    if (l < n_lines) {
+        const uint64_t a = l ? nl_pos[l - 1] + 1 : 0, b = l < n_nl ? nl_pos[l] : n;
+        uint32_t fs[9], fl[9];
+        ok = sam_fields(text, a, b, fs, fl) ? 1u : 0u;
+    }
+    uint32_t c = ok;
+    for (int d = 32; d; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void sam_parse_kernel(const uint8_t* text, uint64_t n, const unsigned long long* nl_pos, uint64_t n_lines,
+                                                        uint64_t n_nl, const unsigned long long* block_off, SamNames N, gf_alnrec* recs,
+                                                        unsigned long long* line_begin, uint64_t cap) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + tid;
+    uint32_t fs[9], fl[9];
+    uint64_t a = 0;
+    bool ok = false;
+    if (l < n_lines) {
+        a = l ? nl_pos[l - 1] + 1 : 0;
+        const uint64_t b = l < n_nl ? nl_pos[l] : n;
+        ok = sam_fields(text, a, b, fs, fl);
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) wsum[w] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint64_t idx = block_off[blockIdx.x] + __popcll(bal & ((1ull << lane) - 1));
+    for (uint32_t i = 0; i < w; ++i) idx += wsum[i];
+    if (!ok || idx >= cap) return;
+    const uint8_t* s = text + a;
+    gf_alnrec r;
+    r.flag = (uint16_t)(sam_int(s + fs[1], fl[1]) & 0xFFFF);
+    r.ref = sam_name_index(N, s + fs[2], fl[2]);
+    r.pos = (uint32_t)sam_int(s + fs[3], fl[3]);
+    const long long mq = sam_int(s + fs[4], fl[4]);
+    r.mapq = (uint8_t)(mq > 255 ? 255 : mq);
+    uint32_t cf = 0;
+    {   // CIGAR: +2 when it ends in S/H, +1 when its first operation is S/H
+        const uint8_t* c = s + fs[5];
+        const uint32_t cl = fl[5];
+        if (c[cl - 1] == 'S' || c[cl - 1] == 'H') cf = 2;
+        for (uint32_t i = 0; i < cl; ++i) {
+            if (c[i] >= '0' && c[i] <= '9') continue;
+            if (c[i] == 'S' || c[i] == 'H') cf += 1;
+            break;
+        }
+    }
+    r.clipflag = (uint8_t)cf;
+    r.mate_ref = (fl[6] == 1 && s[fs[6]] == '=') ? r.ref : sam_name_index(N, s + fs[6], fl[6]);
+    r.mate_pos = (uint32_t)sam_int(s + fs[7], fl[7]);
+    r.tlen = (int32_t)sam_int(s + fs[8], fl[8]);
+    r.read = idx;
+    recs[idx] = r;
+    if (line_begin) line_begin[idx] = a;
+}
+
 }  // namespace gf
 
 using namespace gf;
@@ -259,6 +415,87 @@ int gf_fastq_pack(gf_ctx* ctx, const char* text, size_t n_bytes, int read_len, u
         if (hdr_begin_or_null) GF_HIP(ctx, hipMemcpyAsync(hdr_begin_or_null, d_hdr, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return GF_OK;
+}
+
+int gf_sam_pack(gf_ctx* ctx, const char* text, size_t n_bytes, const char* names_blob, const uint32_t* name_off, size_t n_names,
+                gf_alnrec* recs, size_t cap_recs, uint64_t* line_begin_or_null, size_t* n_recs) {
+    if (!ctx || !n_recs || (n_bytes && !text) || (cap_recs && !recs) || (n_names && (!names_blob || !name_off))) return GF_E_INVAL;
+    *n_recs = 0;
+    if (n_bytes == 0) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    // name table on the host: FNV-1a (the device function's twin) -> index
+    int t_log2 = 4;
+    while (((size_t)1 << t_log2) < 2 * n_names + 2) ++t_log2;
+    std::vector<uint32_t> table((size_t)1 << t_log2, 0xFFFFFFFFu);
+    for (size_t i = 0; i < n_names; ++i) {
+        uint32_t h = 2166136261u;
+        for (uint32_t q = name_off[i]; q < name_off[i + 1]; ++q) h = (h ^ (uint8_t)names_blob[q]) * 16777619u;
+        uint32_t sl = h >> (32 - t_log2);
+        while (table[sl] != 0xFFFFFFFFu) sl = (sl + 1) & (((uint32_t)1 << t_log2) - 1);
+        table[sl] = (uint32_t)i;
+    }
+    const size_t blob_bytes = n_names ? name_off[n_names] : 0;
+    const size_t n_tiles = (n_bytes + ING_TILE - 1) / ING_TILE;
+    if (n_tiles >= 0xFFFFFFFFull) return GF_E_UNSUPPORTED;
+    int rc;
+    // stage: text | names blob | name offsets | table
+    const size_t b_text = (n_bytes + 127) & ~(size_t)63, b_blob = (blob_bytes + 63) & ~(size_t)63,
+                 b_noff = ((n_names + 1) * 4 + 63) & ~(size_t)63, b_tab = (table.size() * 4 + 63) & ~(size_t)63;
+    if ((rc = ensure(ctx, ctx->stage_in, b_text + b_blob + b_noff + b_tab))) return rc;
+    uint8_t* d_text = (uint8_t*)ctx->stage_in.p;
+    uint8_t* d_blob = d_text + b_text;
+    uint32_t* d_noff = (uint32_t*)(d_blob + b_blob);
+    uint32_t* d_tab = (uint32_t*)((uint8_t*)d_noff + b_noff);
+    GF_HIP(ctx, hipMemcpyAsync(d_text, text, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (blob_bytes) GF_HIP(ctx, hipMemcpyAsync(d_blob, names_blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (n_names) GF_HIP(ctx, hipMemcpyAsync(d_noff, name_off, (n_names + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(d_tab, table.data(), table.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    // newlines
+    const size_t b_cnt = (n_tiles * 4 + 63) & ~(size_t)63, b_off = ((n_tiles + 1) * 8 + 63) & ~(size_t)63;
+    if ((rc = ensure(ctx, ctx->pool_ws, b_cnt + b_off + 64))) return rc;
+    uint32_t* cnt = (uint32_t*)ctx->pool_ws.p;
+    unsigned long long* off = (unsigned long long*)((uint8_t*)ctx->pool_ws.p + b_cnt);
+    LaunchTimer tm(ctx, GF_KERNEL_INGEST);
+    hipLaunchKernelGGL(nl_count_kernel, dim3((unsigned)n_tiles), dim3(ING_THREADS), 0, ctx->stream, d_text, (uint64_t)n_bytes, cnt);
+    hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, (uint32_t)n_tiles, off);
+    unsigned long long n_nl = 0;
+    GF_HIP(ctx, hipMemcpyAsync(&n_nl, off + n_tiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long n_lines = n_nl + (text[n_bytes - 1] != '\n' ? 1 : 0);
+    const size_t lblocks = (size_t)((n_lines + 255) / 256);
+    // per-line workspace: newline positions, flag block sums + their scan, records, line offsets
+    const size_t b_nl = ((n_nl + 1) * 8 + 63) & ~(size_t)63, b_bc = (lblocks * 4 + 63) & ~(size_t)63, b_bo = ((lblocks + 1) * 8 + 63) & ~(size_t)63;
+    const size_t b_rec = (cap_recs * sizeof(gf_alnrec) + 63) & ~(size_t)63, b_lb = line_begin_or_null ? (cap_recs * 8 + 63) & ~(size_t)63 : 0;
+    if ((rc = ensure(ctx, ctx->stage_out, b_nl + b_bc + b_bo + b_rec + b_lb + 64))) return rc;
+    uint8_t* o = (uint8_t*)ctx->stage_out.p;
+    unsigned long long* d_nl = (unsigned long long*)o;
+    uint32_t* d_bc = (uint32_t*)(o + b_nl);
+    unsigned long long* d_bo = (unsigned long long*)(o + b_nl + b_bc);
+    gf_alnrec* d_recs = (gf_alnrec*)(o + b_nl + b_bc + b_bo);
+    unsigned long long* d_lb = line_begin_or_null ? (unsigned long long*)(o + b_nl + b_bc + b_bo + b_rec) : nullptr;
+    hipLaunchKernelGGL(nl_all_kernel, dim3((unsigned)n_tiles), dim3(ING_THREADS), 0, ctx->stream, d_text, (uint64_t)n_bytes, off,
+                       (uint64_t)(n_nl + 1), d_nl);
+    if (lblocks) {
+        if (lblocks >= 0xFFFFFFFFull) return GF_E_UNSUPPORTED;
+        hipLaunchKernelGGL(sam_flag_kernel, dim3((unsigned)lblocks), dim3(256), 0, ctx->stream, d_text, (uint64_t)n_bytes, d_nl,
+                           (uint64_t)n_lines, (uint64_t)n_nl, d_bc);
+        hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_bc, (uint32_t)lblocks, d_bo);
+        SamNames N{d_blob, d_noff, d_tab, (uint32_t)t_log2, (uint32_t)n_names};
+        hipLaunchKernelGGL(sam_parse_kernel, dim3((unsigned)lblocks), dim3(256), 0, ctx->stream, d_text, (uint64_t)n_bytes, d_nl,
+                           (uint64_t)n_lines, (uint64_t)n_nl, d_bo, N, d_recs, d_lb, (uint64_t)cap_recs);
+    }
+    unsigned long long total = 0;
+    if (lblocks) GF_HIP(ctx, hipMemcpyAsync(&total, d_bo + lblocks, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_recs = (size_t)total;
+    if (total > cap_recs) return GF_E_NOSPACE;
+    if (total) {
+        GF_HIP(ctx, hipMemcpyAsync(recs, d_recs, total * sizeof(gf_alnrec), hipMemcpyDeviceToHost, ctx->stream));
+        if (line_begin_or_null) GF_HIP(ctx, hipMemcpyAsync(line_begin_or_null, d_lb, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    GF_HIP(ctx, hipGetLastError());
     return GF_OK;
 }
 

@@ -82,6 +82,21 @@ class GapFill:
                                         C.byref(st)), "gf_fastq_pack")
         return packed[:n.value], (nm[:n.value] if with_mask else None), hdr[:n.value], int(st.value)
 
+    def sam_pack(self, text, names):
+        """SAM text (bytes; alignment lines) -> (records B.ALNREC [n], line_begin uint64 [n]) parsed on the GPU; names = the
+        scaffold names of the .fai in order.  Same records as sam_io.decode on the same lines."""
+        text = bytes(text)
+        blob = "".join(names).encode()
+        off = np.zeros(len(names) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(n.encode()) for n in names])
+        cap = max(1, text.count(b"\n") + 1)
+        recs = np.zeros(cap, dtype=B.ALNREC)
+        lb = np.zeros(cap, dtype=np.uint64)
+        n = C.c_size_t(0)
+        self._chk(self._L.gf_sam_pack(self._h, text, len(text), blob, B._p(off), len(names), B._p(recs), cap, B._p(lb), C.byref(n)),
+                  "gf_sam_pack")
+        return recs[:n.value], lb[:n.value]
+
     def _grow(self, call, dtype, cap):
         while True:
             out = np.zeros(max(cap, 1), dtype=dtype)

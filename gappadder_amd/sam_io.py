@@ -39,6 +39,29 @@ def decode(lines, scaffold_index):
     return recs, cols
 
 
+class LazyCols:
+    """The first nine columns of record i, cut from the SAM text on demand (only the records that produce a hit need them)."""
+
+    def __init__(self, text, line_begin):
+        self.text, self.lb = text, line_begin
+
+    def __len__(self):
+        return len(self.lb)
+
+    def __getitem__(self, i):
+        a = int(self.lb[i])
+        b = self.text.find(b"\n", a)
+        return self.text[a:b if b >= 0 else len(self.text)].decode().split(None, 9)[:9]
+
+
+def decode_on_device(gf, sam_lines, names):
+    """Same records as decode(sam_lines, {name: index}), parsed by gf_sam_pack on the GPU; columns come back lazily.
+    names: list indexed like the scaffold index (the .fai order)."""
+    text = sam_lines if isinstance(sam_lines, (bytes, bytearray)) else "\n".join(l.rstrip("\n") for l in sam_lines).encode()
+    recs, lb = gf.sam_pack(text, names)
+    return recs, LazyCols(bytes(text), lb)
+
+
 def read_fai(path):
     names = []
     with open(path) as f:

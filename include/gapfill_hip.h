@@ -128,6 +128,15 @@ int gf_fastq_pack(gf_ctx* ctx, const char* text, size_t n_bytes, int read_len, u
 int gf_fastq_pack_dev(gf_ctx* ctx, const void* d_text, size_t n_bytes, int read_len, void* d_packed, size_t cap_reads,
                       void* d_n_mask_or_null, void* d_hdr_begin_or_null, void* d_n_reads, void* d_status);
 
+/* SAM TEXT (alignment lines as `samtools view` prints them) -> gf_alnrec, parsed on the device exactly as the reference reads
+ * a line (collect_reads_for_gaps.py:76-91: whitespace-split, columns 0-8; clipflag per is_clipped :13-26): '@' lines and
+ * lines with fewer than nine fields yield no record; the others are numbered in line order (rec.read = record index).
+ * names_blob/name_off: the scaffold names of the .fai in order (n_names + 1 offsets); RNAME/RNEXT decode to the name's index,
+ * '=' to RNAME's index, an unknown name to 0xFFFFFFFF.  line_begin[r] = byte offset of record r's line (QNAME and the other
+ * text columns are cut from the host's copy for the few records that produce a hit).  GF_E_NOSPACE: *n_recs = needed. */
+int gf_sam_pack(gf_ctx* ctx, const char* text, size_t n_bytes, const char* names_blob, const uint32_t* name_off, size_t n_names,
+                gf_alnrec* recs, size_t cap_recs, uint64_t* line_begin_or_null, size_t* n_recs);
+
 /* ---- north-star flank-k-mer screen ("flank-k-mer lookup to tag reads") ------------------------------
  * Emits (gap, read) for every read that has >= min_hits k-mer positions whose canonical k-mer occurs in the
  * gap's flank k-mer set (predicate shape of IsReadContainingFreqKmers, KmerUtils.cpp:215-241, on canonical

@@ -99,3 +99,29 @@ def test_fastq_pack_feeds_the_screen(gf):
     a = gf.screen_reads(packed, L, 31, 1, n_mask=nm)
     b = gf.screen_reads(p2, L, 31, 1, n_mask=nm2)
     assert len(a) > 20 and np.array_equal(a, b)
+
+
+def test_sam_pack_matches_host_decoder_on_golden_sam(gf):
+    """gf_sam_pack (SAM text parsed on the GPU) == sam_io.decode (the host restatement of collect_reads_for_gaps.py:76-91) on
+    every SAM fixture, plus header lines, short lines, CRLF-free odd spacing, unknown reference names and '=' / named RNEXT."""
+    from golden_util import CASES, Case
+    from gappadder_amd import sam_io
+    total = 0
+    for name in CASES:
+        case = Case(name)
+        sidx = {n: i for i, n in enumerate(case.fai_names)}
+        for lib in case.libs:
+            text = lib["sam"]
+            extra = ("@HD\tVN:1.6\n@SQ\tSN:x\tLN:5\n" + text +
+                     "short\t4\t*\n" +
+                     "q1  99 %s   17  255 5S90M5H  nosuch 250   -321  ACGT IIII\n" % case.fai_names[0] +
+                     "q2\t147\tnosuch\t5\t300\t*\t%s\t9\t0\t*\t*" % case.fai_names[0])          # no trailing newline
+            exp, cols = sam_io.decode(extra.splitlines(), sidx)
+            recs, lb = gf.sam_pack(extra.encode(), case.fai_names)
+            assert len(recs) == len(exp)
+            assert recs.tobytes() == exp.tobytes()
+            b = extra.encode()
+            for i in (0, len(recs) // 2, len(recs) - 1):
+                assert b[int(lb[i]):].split(None, 1)[0].decode() == cols[i][0]
+            total += len(recs)
+    assert total > 5000
