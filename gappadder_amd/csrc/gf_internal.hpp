@@ -27,6 +27,10 @@ struct FlankIndex {
     uint32_t* d_bitmap_lds = nullptr;
     int lds_log2 = 0;
     double lds_fill = 1.0;
+    // L2-resident 2^24-bit OR-reduction of a level-1 bitmap that is larger than that (0 = none)
+    uint32_t* d_bitmap_mid = nullptr;
+    int mid_log2 = 0;
+    double mid_fill = 1.0;
     // level 2: exact set of canonical 16-mers (open addressing, EMPTY32)
     int s_log2 = 0;
     uint32_t* d_sset = nullptr;

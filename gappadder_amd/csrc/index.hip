@@ -76,6 +76,7 @@ void extract(const std::string& s, int k, uint32_t gap, std::vector<Entry>& kmer
 void free_flank_index(gf_ctx*, FlankIndex& ix) {
     if (ix.d_bitmap) (void)hipFree(ix.d_bitmap);
     if (ix.d_bitmap_lds) (void)hipFree(ix.d_bitmap_lds);
+    if (ix.d_bitmap_mid) (void)hipFree(ix.d_bitmap_mid);
     if (ix.d_sset) (void)hipFree(ix.d_sset);
     if (ix.d_table) (void)hipFree(ix.d_table);
     if (ix.d_sval) (void)hipFree(ix.d_sval);
@@ -223,6 +224,23 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
     GF_HIP(ctx, hipSetDevice(ctx->device));
     GF_HIP(ctx, hipMalloc((void**)&ix.d_bitmap_lds, cwords * 4));
     GF_HIP(ctx, hipMemcpy(ix.d_bitmap_lds, cbm.data(), cwords * 4, hipMemcpyHostToDevice));
+    // key sets whose level-1 bitmap outgrows the L2 (> 2^24 bits) get a 2^24-bit OR-reduction of it that does stay there:
+    // the plain filter kernel asks it first and sends only what it lets through to the big bitmap
+    ix.mid_log2 = 0;
+    if (bl > 24) {
+        ix.mid_log2 = 24;
+        const size_t mwords = ((size_t)1 << 24) / 32;
+        std::vector<uint32_t> mbm(mwords, 0);
+        size_t mset = 0;
+        for (uint32_t key : s16) {
+            const uint32_t c = hash_s16_bitmap(key, bl) >> (bl - 24);
+            if (!((mbm[c >> 5] >> (c & 31)) & 1u)) ++mset;
+            mbm[c >> 5] |= 1u << (c & 31);
+        }
+        ix.mid_fill = (double)mset / (double)((size_t)1 << 24);
+        GF_HIP(ctx, hipMalloc((void**)&ix.d_bitmap_mid, mwords * 4));
+        GF_HIP(ctx, hipMemcpy(ix.d_bitmap_mid, mbm.data(), mwords * 4, hipMemcpyHostToDevice));
+    }
     GF_HIP(ctx, hipMalloc((void**)&ix.d_bitmap, bwords * 4));
     GF_HIP(ctx, hipMalloc((void**)&ix.d_sset, (scap + 4) * 4));
     GF_HIP(ctx, hipMalloc(&ix.d_table, tab.size() * 4));

@@ -28,6 +28,8 @@ struct FilterParams {
     // LDS pre-filter variant: a coarser copy of the bitmap (bit i = OR of the 2^(bm_log2-lds_log2) bits it covers)
     const uint32_t* bitmap_lds;
     uint32_t lds_log2;
+    const uint32_t* bitmap_mid;   // plain kernel: L2-resident OR-reduction of a level-1 bitmap larger than the L2 (or null)
+    uint32_t mid_log2;
     uint32_t stream_policy; // pipelined kernel: cache policy of the read stream (0 default, 1 nt, 2 sc1, 3 sc0 sc1 nt)
 };
 
@@ -79,8 +81,22 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
                             const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
                             const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
                             hb[u] = (h & 31) | (hash_s16_bit2(key) << 8);   // both bits of the key in its word
-                            word[u] = P.bitmap[h >> 5];
+                            word[u] = h;                                    // (the level-1 word replaces it below)
                         }
+                    }
+                    if (P.bitmap_mid) {   // big key sets: an L2-resident reduced bitmap first, the fabric only for what passes
+                        uint32_t mw[PU];
+#pragma unroll
+                        for (int u = 0; u < PU; ++u) mw[u] = (j0 + u < g1) ? P.bitmap_mid[word[u] >> (P.bm_log2 - P.mid_log2 + 5)] : 0;
+#pragma unroll
+                        for (int u = 0; u < PU; ++u) {
+                            const uint32_t c = word[u] >> (P.bm_log2 - P.mid_log2);
+                            const bool pass = (j0 + u < g1) && ((mw[u] >> (c & 31)) & 1u);
+                            word[u] = pass ? P.bitmap[word[u] >> 5] : 0u;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < PU; ++u) word[u] = (j0 + u < g1) ? P.bitmap[word[u] >> 5] : 0u;
                     }
 #pragma unroll
                     for (int u = 0; u < PU; ++u) {
@@ -1168,6 +1184,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     F.bitmap_lds = ix.d_bitmap_lds;
     F.lds_log2 = ix.lds_log2;
     F.stream_policy = (uint32_t)ctx->screen_stream_policy;
+    F.bitmap_mid = ix.mid_log2 ? ix.d_bitmap_mid : nullptr;
+    F.mid_log2 = (uint32_t)ix.mid_log2;
     // Kernel choice (screen_variant: 0 = automatic; 9 / 12 / 13 force the plain / wave / pipelined kernel, for ablation):
     // the LDS pre-filter pays while the coarse bitmap is sparse enough to stop most probes before L2 and a handful of waves
     // fit next to it (long reads leave too few); the pipelined form covers up to 10 probes and 64 packed bytes per read
