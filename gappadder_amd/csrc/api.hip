@@ -27,6 +27,18 @@ int ensure(gf_ctx* ctx, DevBuf& b, size_t bytes) {
     return GF_OK;
 }
 
+__global__ void zero_regions_kernel(ZeroList z) {
+    for (int r = 0; r < 4; ++r)
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < z.n[r]; i += gridDim.x * blockDim.x) z.p[r][i] = 0;
+}
+
+void zero_regions(gf_ctx* ctx, const ZeroList& z) {
+    uint32_t most = 0;
+    for (int r = 0; r < 4; ++r) most = std::max(most, z.n[r]);
+    if (!most) return;
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(std::min<uint32_t>((most + 255) / 256, 1024)), dim3(256), 0, ctx->stream, z);
+}
+
 static void drain_timing(gf_ctx* ctx) {
     for (auto& l : ctx->launches) {
         float ms = 0;

@@ -965,13 +965,14 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     }
     if ((rc = ensure(ctx, ctx->asm_surv, std::max<uint64_t>(n_inst, 1) * 2 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->asm_nodes, std::max<uint64_t>(n_inst, 1) * 3 * 4))) return rc;
-    GF_HIP(ctx, hipMemsetAsync(d_n_contigs, 0, 4, ctx->stream));
-    GF_HIP(ctx, hipMemsetAsync(d_seq_len, 0, 8, ctx->stream));
-    if (n_pools) GF_HIP(ctx, hipMemsetAsync(d_gap_error, 0, n_pools * 4, ctx->stream));
+    if (n_pools == 0) {
+        GF_HIP(ctx, hipMemsetAsync(d_n_contigs, 0, 4, ctx->stream));
+        GF_HIP(ctx, hipMemsetAsync(d_seq_len, 0, 8, ctx->stream));
+    }
     if (n_pools == 0) return GF_OK;
     if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
     uint32_t* d_next = (uint32_t*)ctx->counters.p + 8;
-    GF_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
+    zero_regions(ctx, ZeroList{{(uint32_t*)d_n_contigs, (uint32_t*)d_seq_len, (uint32_t*)d_gap_error, d_next}, {1, 2, (uint32_t)n_pools, 1}});
     AsmParams P;
     P.next_gap = d_next;
     P.keyslot = (uint32_t)ctx->asm_keyslot;

@@ -136,6 +136,14 @@ struct LaunchTimer {
     }
 };
 
+// api.hip: zero up to four small device regions with ONE launch (every hipMemsetAsync is a launch of its own, and the step is
+// a chain of ~30 dependent launches)
+struct ZeroList {
+    uint32_t* p[4];
+    uint32_t n[4];   // 32-bit words
+};
+void zero_regions(gf_ctx* ctx, const ZeroList& z);
+
 // index.cpp
 int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out);
 void free_flank_index(gf_ctx* ctx, FlankIndex& ix);

@@ -321,8 +321,7 @@ int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, 
     uint32_t* ucnt = cursor + ng;
     uint32_t* seg_off = ucnt + ng;
     uint32_t* seg = (uint32_t*)((uint8_t*)ctx->pool_ws.p + w_small);
-    GF_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)ng * 4 + 4, ctx->stream));
-    GF_HIP(ctx, hipMemsetAsync(d_error, 0, 4, ctx->stream));
+    zero_regions(ctx, ZeroList{{cnt, (uint32_t*)d_error, nullptr, nullptr}, {ng + 1, 1, 0, 0}});
     LaunchTimer tm(ctx, GF_KERNEL_POOL);
     const unsigned blocks = ctx->n_cu * 4;
     const bool lds_bins = ng && (size_t)ng * 4 <= 128 * 1024;     // one LDS counter per gap

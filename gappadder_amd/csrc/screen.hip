@@ -1164,8 +1164,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     if ((rc = ensure(ctx, ctx->cand, std::max<size_t>(n_reads, 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
     uint32_t* d_cnt = (uint32_t*)ctx->counters.p;  // [0] n_cand, [1] overflow
-    GF_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));  // [0] n_cand [1] error overflow [2] n_cand2
-    GF_HIP(ctx, hipMemsetAsync(d_n_out, 0, 4, ctx->stream));
+    zero_regions(ctx, ZeroList{{d_cnt, (uint32_t*)d_n_out, nullptr, nullptr}, {4, 1, 0, 0}});  // [0] n_cand [1] error overflow [2] n_cand2
     if (n_reads == 0) return GF_OK;
 
     FilterParams F;

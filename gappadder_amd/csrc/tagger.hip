@@ -390,8 +390,7 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
                void* d_out, size_t cap, void* d_n_out, void* d_low, size_t low_cap, void* d_n_low) {
     if (!ctx->d_gaps) return GF_E_STATE;
     if (n >= 0xFFFFFFFFull || cap > 0xFFFFFFFFull) return GF_E_INVAL;
-    GF_HIP(ctx, hipMemsetAsync(d_n_out, 0, 4, ctx->stream));
-    if (d_n_low) GF_HIP(ctx, hipMemsetAsync(d_n_low, 0, 4, ctx->stream));
+    zero_regions(ctx, ZeroList{{(uint32_t*)d_n_out, (uint32_t*)d_n_low, nullptr, nullptr}, {1, d_n_low ? 1u : 0u, 0, 0}});
     if (n == 0) return GF_OK;
     TagParams P;
     P.low = (gf_lowrec*)d_low;
