@@ -92,13 +92,13 @@ struct gf_ctx {
     // tagger coarse bin map (rebuilt when dist2 changes)
     std::vector<uint32_t> bin_host;
     int bin_dist2 = -1, bin_shift = 0;
-    uint32_t bin_words = 0;
+    uint32_t bin_words = 0, fine_words = 0, fine_shift = 0;
     // second-hop table cache
     std::vector<uint32_t> low_rows, rowgap_rows;
     size_t low_b1 = 0, low_b2 = 0;
 
     // scratch
-    gf::DevBuf cand, cand2, binmap, asm_table, asm_surv, asm_nodes, rowgap, pool_ws, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, binmap, binmap_fine, asm_table, asm_surv, asm_nodes, rowgap, pool_ws, counters, stage_in, stage_out, stage_aux, table;
     // timing
     bool timing = false;
     std::vector<gf::TimedLaunch> launches;

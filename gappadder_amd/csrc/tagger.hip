@@ -25,6 +25,11 @@ struct TagParams {
     const uint32_t* bin_bits;
     const uint32_t* bin_off;  // n_scaffolds + 1
     uint32_t bin_shift, bin_words;
+    // fine bin map (global, L2-resident, <= 4 MiB): same test on narrower bins for the records the LDS map lets through.
+    // Only built when the LDS map's bins are wide (large genomes, many gaps); null otherwise.
+    const uint32_t* fine_bits;
+    const uint32_t* fine_off;
+    uint32_t fine_shift;
     gf_taghit* out;
     uint32_t cap;
     uint32_t* n_out;
@@ -215,6 +220,10 @@ __global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
                 const uint32_t b0 = P.bin_off[r.ref], nbin = P.bin_off[r.ref + 1] - b0, bi = r.pos >> P.bin_shift;
                 live = bi < nbin && ((bins[(b0 + bi) >> 5] >> ((b0 + bi) & 31)) & 1u);
             }
+            if (live && P.fine_bits) {
+                const uint32_t f0 = P.fine_off[r.ref], fi = r.pos >> P.fine_shift, fb = f0 + fi;
+                live = fi < P.fine_off[r.ref + 1] - f0 && ((P.fine_bits[fb >> 5] >> (fb & 31)) & 1u);
+            }
             // survivors (a few per mille) are queued; the window search below runs on 64 of them at a time instead of
             // once per 1-KiB load with one or two busy lanes
             const unsigned long long lb = __ballot(live);
@@ -358,27 +367,52 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
     for (const gf_gap& g : ctx->gaps) span[g.scaffold] = std::max<uint64_t>(span[g.scaffold], (uint64_t)g.end + d2);
     uint64_t total = 0;
     for (uint64_t v : span) total += v;
-    int shift = 6;
     auto nbits = [&](int sh) { uint64_t t = 0; for (uint64_t v : span) t += (v >> sh) + (v ? 1 : 0); return t; };
-    while (nbits(shift) > (1u << 17)) ++shift;  // <= 16 KiB of LDS (measured: an 8 KiB map sends more records down the slow path and loses)
-    std::vector<uint32_t> off(ctx->n_scaffolds + 1, 0);
-    for (uint32_t s = 0; s < ctx->n_scaffolds; ++s) off[s + 1] = off[s] + (uint32_t)((span[s] >> shift) + (span[s] ? 1 : 0));
-    const uint32_t words = (off[ctx->n_scaffolds] + 31) / 32 + 1;
-    std::vector<uint32_t>& h = ctx->bin_host;
-    h.assign(words + off.size(), 0);
-    for (const gf_gap& g : ctx->gaps) {
-        if (d2 == 0) break;
-        const int64_t lo = std::max<int64_t>(0, (int64_t)g.start - d2 + 1), hi = (int64_t)g.end + d2 - 1;
-        for (int64_t b = lo >> shift; b <= (hi >> shift); ++b) {
-            const uint32_t bit = off[g.scaffold] + (uint32_t)b;
-            h[bit >> 5] |= 1u << (bit & 31);
+    // one map = bit words followed by the n_scaffolds+1 bit offsets
+    auto build = [&](int shift, std::vector<uint32_t>& h, uint32_t& words) {
+        std::vector<uint32_t> off(ctx->n_scaffolds + 1, 0);
+        for (uint32_t s = 0; s < ctx->n_scaffolds; ++s) off[s + 1] = off[s] + (uint32_t)((span[s] >> shift) + (span[s] ? 1 : 0));
+        words = (off[ctx->n_scaffolds] + 31) / 32 + 1;
+        h.assign(words + off.size(), 0);
+        for (const gf_gap& g : ctx->gaps) {
+            if (d2 == 0) break;
+            const int64_t lo = std::max<int64_t>(0, (int64_t)g.start - d2 + 1), hi = (int64_t)g.end + d2 - 1;
+            for (int64_t b = lo >> shift; b <= (hi >> shift); ++b) {
+                const uint32_t bit = off[g.scaffold] + (uint32_t)b;
+                h[bit >> 5] |= 1u << (bit & 31);
+            }
         }
-    }
-    for (size_t i = 0; i < off.size(); ++i) h[words + i] = off[i];
+        for (size_t i = 0; i < off.size(); ++i) h[words + i] = off[i];
+    };
+    int shift = 6;
+    while (nbits(shift) > (1u << 17)) ++shift;  // <= 16 KiB of LDS (measured: an 8 KiB map sends more records down the slow path and loses)
+    uint32_t words = 0;
+    std::vector<uint32_t>& h = ctx->bin_host;
+    build(shift, h, words);
     int rc = ensure(ctx, ctx->binmap, h.size() * 4);
     if (rc) return rc;
     GF_HIP(ctx, hipMemcpyAsync(ctx->binmap.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // Human-scale genomes leave the LDS map with ~24 kb bins, a third of them set by 20 000 gaps: a second, finer map in
+    // global memory (<= 2^25 bits, stays in L2) restores the per-mille pass rate before the window search.
+    ctx->fine_words = 0;
+    uint64_t set_bits = 0;
+    for (uint32_t i = 0; i < words; ++i) set_bits += (uint64_t)__builtin_popcount(h[i]);
+    if (shift > 9 && set_bits * 20 > nbits(shift)) {   // worth a second look-up only when the LDS map passes > 5 %
+        int fs = 7;
+        while (nbits(fs) > (1u << 25)) ++fs;
+        if (fs + 2 <= shift) {
+            std::vector<uint32_t> hf;
+            uint32_t fw = 0;
+            build(fs, hf, fw);
+            rc = ensure(ctx, ctx->binmap_fine, hf.size() * 4);
+            if (rc) return rc;
+            GF_HIP(ctx, hipMemcpyAsync(ctx->binmap_fine.p, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->fine_words = fw;
+            ctx->fine_shift = fs;
+        }
+    }
     ctx->bin_dist2 = dist2;
     ctx->bin_shift = shift;
     ctx->bin_words = words;
@@ -416,6 +450,9 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
     P.bin_off = P.bin_bits + ctx->bin_words;
     P.bin_shift = ctx->bin_shift;
     P.bin_words = ctx->bin_words;
+    P.fine_bits = ctx->fine_words ? (const uint32_t*)ctx->binmap_fine.p : nullptr;
+    P.fine_off = P.fine_bits ? P.fine_bits + ctx->fine_words : nullptr;
+    P.fine_shift = ctx->fine_shift;
     {
         LaunchTimer tm(ctx, GF_KERNEL_TAG);
         hipLaunchKernelGGL(tag_kernel, dim3(stream_grid(ctx, n)), dim3(256), (size_t)ctx->bin_words * 4, ctx->stream, P);

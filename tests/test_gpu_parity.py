@@ -447,3 +447,17 @@ def test_seed_and_extend_verification_edge_cases(gf, k, L):
         assert _same(gf.screen_reads(packed, L, k, 1, n_mask=nm), exp)
     finally:
         gf.set_option("screen_verify_ext", 1)
+
+
+def test_tagger_on_human_scale_layout_uses_the_fine_bin_map(gf):
+    """24 scaffolds x 130 Mb with 20 000 gaps (BASELINE.json configs[3]'s layout): the LDS bin map has ~24 kb bins, so the
+    tagger's second, finer map in global memory decides which records reach the window search; hits must stay the oracle's."""
+    from gappadder_amd.hip_api import GapFill
+    cfg = GapFill.synth_cfg(seed=20260004, scaffold_len=130_000_000, n_scaffolds=24, gaps_per_scaffold=834, gap_len=1000)
+    gaps, flanks = GapFill.synth_layout(cfg)
+    gf.set_gaps(gaps, 24, flanks)
+    ocfg = np.frombuffer(cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
+    _, recs = CO.synth_pairs(ocfg, 0, 1_000_000)
+    for d2, cd in ((300, 30), (2500, 100)):
+        th = gf.tag_alignments(recs, d2, cd, cap=1 << 21)
+        assert _same(th, CO.tag_alignments(recs, gaps, d2, cd)) and len(th) > 1000
