@@ -21,7 +21,7 @@ SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", 
                       ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4")])
 assert CONTIG.itemsize == 32 and GAP.itemsize == 16 and ALNREC.itemsize == 32 and TAGHIT.itemsize == 12 and DPOS.itemsize == 16 and HIT.itemsize == 8
 
-GF_OK, GF_E_INVAL, GF_E_NODEV, GF_E_NOMEM, GF_E_NOSPACE, GF_E_STATE, GF_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+GF_OK, GF_E_INVAL, GF_E_NODEV, GF_E_NOMEM, GF_E_NOSPACE, GF_E_STATE, GF_E_UNSUPPORTED, GF_E_FORMAT = 0, -1, -2, -3, -4, -5, -6, -7
 KIND_CLIP, KIND_DISCORDANT, KIND_UNMAP, KIND_LOWMAPQ = 0, 1, 2, 3
 KIND_NAMES = {KIND_CLIP: "clip", KIND_DISCORDANT: "discordant", KIND_UNMAP: "unmap"}
 KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_SYNTH, KERNEL_COUNT, KERNEL_VERIFY, KERNEL_INGEST = range(9)
@@ -65,6 +65,8 @@ def lib():
         "gf_packed_read_bytes": (sz, [i32]),
         "gf_fastq_pack": (i32, [vp, C.c_char_p, sz, i32, vp, sz, vp, vp, szp, C.POINTER(C.c_uint32)]),
         "gf_sam_pack": (i32, [vp, C.c_char_p, sz, C.c_char_p, vp, sz, vp, sz, vp, szp]),
+        "gf_bgzf_inflate": (i32, [vp, C.c_char_p, sz, C.c_char_p, sz, vp, sz, szp, szp]),
+        "gf_bam_pack": (i32, [vp, vp, sz, sz, vp, sz, vp, sz, vp, szp, szp]),
         "gf_fastq_pack_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp, vp, vp]),
         "gf_screen_reads": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, szp]),
         "gf_screen_reads_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, vp]),

@@ -1,0 +1,99 @@
+"""BAM file -> decoded 32-byte alignment records (gf_alnrec) without samtools: the BGZF blocks are inflated and the records
+decoded on the GPU (gf_bgzf_inflate + gf_bam_pack, csrc/bam.hip); the host only reads the header and cuts the text columns of
+the few records that produce a hit.  The records and columns equal what sam_io.decode gives for the `samtools view` lines of
+the same file (the reference's input, collect_reads_for_gaps.py:76-91), in file order — one pass over the whole BAM instead
+of one `samtools view <bam> <scaffold>` pipe per scaffold (run_multi_threads_collect_reads.py:30-32)."""
+import struct
+
+import numpy as np
+
+NO_REF = 0xFFFFFFFF
+CIGAR_OPS = "MIDNSHP=X"
+
+
+def parse_header(stream):
+    """Inflated bytes from the start of the file -> (reference names, offset of the first alignment record), or None when
+    the header is not complete yet (SAMv1 §4.2: magic, l_text, text, n_ref, then l_name/name/l_ref per reference)."""
+    b = bytes(stream[:12]) if len(stream) >= 12 else b""
+    if len(b) < 12:
+        return None
+    if b[:4] != b"BAM\x01":
+        raise ValueError("not a BAM stream (magic %r)" % b[:4])
+    l_text = struct.unpack_from("<i", b, 4)[0]
+    o = 8 + l_text
+    if len(stream) < o + 4:
+        return None
+    n_ref = struct.unpack_from("<i", bytes(stream[o:o + 4]))[0]
+    o += 4
+    names = []
+    for _ in range(n_ref):
+        if len(stream) < o + 4:
+            return None
+        l_name = struct.unpack_from("<i", bytes(stream[o:o + 4]))[0]
+        if len(stream) < o + 4 + l_name + 4:
+            return None
+        names.append(bytes(stream[o + 4:o + 4 + l_name - 1]).decode())
+        o += 4 + l_name + 4
+    return names, o
+
+
+class BamCols:
+    """The nine SAM columns of record i as `samtools view` prints them, cut on demand from the inflated bytes."""
+
+    def __init__(self, stream, rec_begin, ref_names):
+        self.s, self.rb, self.names = stream, rec_begin, ref_names
+
+    def __len__(self):
+        return len(self.rb)
+
+    def __getitem__(self, i):
+        o = int(self.rb[i])
+        ref, pos, l_name, mapq, _bin, n_cig, flag, _l_seq, mref, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", bytes(self.s[o + 4:o + 36]))
+        p = o + 36
+        qname = bytes(self.s[p:p + l_name - 1]).decode()
+        ops = np.frombuffer(bytes(self.s[p + l_name:p + l_name + 4 * n_cig]), dtype="<u4")
+        cigar = "".join("%d%s" % (v >> 4, CIGAR_OPS[v & 15]) for v in ops) or "*"
+        rname = self.names[ref] if ref >= 0 else "*"
+        rnext = "*" if mref < 0 else ("=" if mref == ref else self.names[mref])
+        return [qname, str(flag), rname, str(pos + 1), str(mapq), cigar, rnext, str(mpos + 1), str(tlen)]
+
+
+def decode_chunks(gf, chunks, fai_names):
+    """chunks: iterable of consecutive pieces of a BAM file (any sizes).  Yields (records, BamCols) per piece that completed
+    at least one record; record indices (rec.read) restart at 0 in every yield, like one sam_io.decode call per piece."""
+    index = {n: i for i, n in enumerate(fai_names)}
+    ref_names, ref_map = None, None
+    file_carry, rec_carry = b"", b""
+    for piece in chunks:
+        data = file_carry + bytes(piece)
+        stream, used = gf.bgzf_inflate(data, rec_carry)
+        file_carry = data[used:]
+        first = 0
+        if ref_names is None:
+            hdr = parse_header(stream)
+            if hdr is None:          # header longer than this piece: keep everything inflated so far and go on
+                rec_carry = bytes(stream)
+                continue
+            ref_names, first = hdr
+            ref_map = np.array([index.get(n, NO_REF) for n in ref_names], dtype=np.uint32)
+        recs, rb, consumed = gf.bam_pack(None, first, ref_map, n_bytes=len(stream))
+        rec_carry = bytes(stream[consumed:])
+        if len(recs):
+            yield recs, BamCols(stream, rb, ref_names)
+    if file_carry:
+        raise ValueError("BAM file ends inside a BGZF block (%d stray bytes)" % len(file_carry))
+    if rec_carry and ref_names is not None:
+        raise ValueError("BAM file ends inside an alignment record (%d stray bytes)" % len(rec_carry))
+
+
+def read_file_chunks(path, chunk_bytes=256 << 20):
+    with open(path, "rb") as f:
+        while True:
+            b = f.read(chunk_bytes)
+            if not b:
+                return
+            yield b
+
+
+def decode_file(gf, path, fai_names, chunk_bytes=256 << 20):
+    return decode_chunks(gf, read_file_chunks(path, chunk_bytes), fai_names)

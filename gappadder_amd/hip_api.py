@@ -97,6 +97,40 @@ class GapFill:
                   "gf_sam_pack")
         return recs[:n.value], lb[:n.value]
 
+    def bgzf_inflate(self, bgzf, carry=b""):
+        """BGZF file bytes (from a block boundary) -> (inflated bytes = carry + whole blocks' contents, n_consumed); inflated
+        and CRC-checked on the GPU, where the stream also stays for bam_pack(None, ...)."""
+        bgzf, carry = bytes(bgzf), bytes(carry)
+        n, used = C.c_size_t(0), C.c_size_t(0)
+        out = np.zeros(1, dtype=np.uint8)
+        rc = self._L.gf_bgzf_inflate(self._h, bgzf, len(bgzf), carry, len(carry), B._p(out), 0, C.byref(n), C.byref(used))
+        if rc == B.GF_E_NOSPACE:
+            out = np.zeros(n.value, dtype=np.uint8)
+            rc = self._L.gf_bgzf_inflate(self._h, bgzf, len(bgzf), carry, len(carry), B._p(out), len(out), C.byref(n), C.byref(used))
+        self._chk(rc, "gf_bgzf_inflate")
+        return out[:n.value], int(used.value)
+
+    def bam_pack(self, stream, first, ref_map, n_bytes=None):
+        """Inflated BAM bytes (None: the n_bytes left on the GPU by bgzf_inflate) -> (records B.ALNREC [n], rec_begin uint64 [n],
+        n_consumed); first = offset of the first alignment record, ref_map[refID] = .fai index or 0xFFFFFFFF."""
+        if stream is not None:
+            stream = np.ascontiguousarray(np.frombuffer(bytes(stream), dtype=np.uint8))
+            n_bytes = len(stream)
+        ref_map = np.ascontiguousarray(ref_map, dtype=np.uint32)
+        cap = (n_bytes - first) // 128 + 16
+        n, used = C.c_size_t(0), C.c_size_t(0)
+        while True:
+            recs = np.zeros(cap, dtype=B.ALNREC)
+            rb = np.zeros(cap, dtype=np.uint64)
+            rc = self._L.gf_bam_pack(self._h, B._p(stream) if stream is not None else None, n_bytes, first, B._p(ref_map), len(ref_map),
+                                     B._p(recs), cap, B._p(rb), C.byref(n), C.byref(used))
+            if rc != B.GF_E_NOSPACE:
+                break
+            cap = n.value   # the stream stays on the device: the retry does not upload it again
+            stream = None
+        self._chk(rc, "gf_bam_pack")
+        return recs[:n.value], rb[:n.value], int(used.value)
+
     def _grow(self, call, dtype, cap):
         while True:
             out = np.zeros(max(cap, 1), dtype=dtype)

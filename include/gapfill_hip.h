@@ -29,6 +29,7 @@ extern "C" {
 #define GF_E_NOSPACE (-4)  /* output capacity too small; *n_out = required count */
 #define GF_E_STATE (-5)    /* call order violated (e.g. screen before gf_set_gaps) */
 #define GF_E_UNSUPPORTED (-6)
+#define GF_E_FORMAT (-7)   /* malformed input file bytes (BGZF / BAM); see gf_last_error */
 
 typedef struct gf_ctx gf_ctx;
 
@@ -136,6 +137,24 @@ int gf_fastq_pack_dev(gf_ctx* ctx, const void* d_text, size_t n_bytes, int read_
  * text columns are cut from the host's copy for the few records that produce a hit).  GF_E_NOSPACE: *n_recs = needed. */
 int gf_sam_pack(gf_ctx* ctx, const char* text, size_t n_bytes, const char* names_blob, const uint32_t* name_off, size_t n_names,
                 gf_alnrec* recs, size_t cap_recs, uint64_t* line_begin_or_null, size_t* n_recs);
+
+/* BGZF (the blocked gzip container of BAM, SAMv1 §4.1) inflated on the device, one wavefront per block, every block's CRC-32
+ * and ISIZE checked (GF_E_FORMAT + gf_last_error on a mismatch).  `bgzf` = file bytes starting at a block boundary; only whole
+ * blocks are taken: *n_consumed = bytes used (bring the rest back in front of the next chunk).  The inflated stream is
+ * `carry` (bytes the previous gf_bam_pack call left unconsumed: a partial record) followed by the blocks' contents; it STAYS ON
+ * THE DEVICE for gf_bam_pack and is also copied to out_or_null (capacity `cap`; GF_E_NOSPACE with *n_out = needed) — the
+ * host cuts QNAMEs for the few records that produce a hit from that copy, and reads the BAM header from the first chunk.
+ * Replaces the `samtools view` pipe of run_multi_threads_collect_reads.py:30-32 / run_multi_threads_discordant.py:131-133. */
+int gf_bgzf_inflate(gf_ctx* ctx, const uint8_t* bgzf, size_t n_bytes, const uint8_t* carry, size_t n_carry, uint8_t* out_or_null,
+                    size_t cap, size_t* n_out, size_t* n_consumed);
+/* BAM alignment records (SAMv1 §4.2) -> gf_alnrec, the same values gf_sam_pack gives for the `samtools view` line of the
+ * record (POS/PNEXT 1-based, clipflag from the first/last CIGAR operation, rec.read = record index in stream order).
+ * stream_or_null: the inflated bytes (NULL: the n_bytes left on the device by the last gf_bgzf_inflate); `first` = offset of
+ * the first alignment record (after the header in the first chunk, 0 afterwards); ref_map[refID] = .fai index of that BAM
+ * reference or 0xFFFFFFFF.  Only complete records are taken: *n_consumed = offset of the first incomplete one (== n_bytes when
+ * none).  rec_begin[r] = offset of record r's block_size field.  GF_E_NOSPACE: *n_recs = needed. */
+int gf_bam_pack(gf_ctx* ctx, const uint8_t* stream_or_null, size_t n_bytes, size_t first, const uint32_t* ref_map, size_t n_ref,
+                gf_alnrec* recs, size_t cap_recs, uint64_t* rec_begin_or_null, size_t* n_recs, size_t* n_consumed);
 
 /* ---- north-star flank-k-mer screen ("flank-k-mer lookup to tag reads") ------------------------------
  * Emits (gap, read) for every read that has >= min_hits k-mer positions whose canonical k-mer occurs in the
