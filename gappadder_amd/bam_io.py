@@ -9,6 +9,13 @@ import numpy as np
 
 NO_REF = 0xFFFFFFFF
 CIGAR_OPS = "MIDNSHP=X"
+SEQ_CODES = "=ACMGRSVTWYHKDBN"
+BUILTIN = "builtin"
+
+
+def is_builtin(samtools_path):
+    """software_path.samtools = "builtin" in the configuration JSON selects this module instead of a samtools executable."""
+    return samtools_path is not None and str(samtools_path).rstrip("/") == BUILTIN
 
 
 def parse_header(stream):
@@ -57,6 +64,21 @@ class BamCols:
         rnext = "*" if mref < 0 else ("=" if mref == ref else self.names[mref])
         return [qname, str(flag), rname, str(pos + 1), str(mapq), cigar, rnext, str(mpos + 1), str(tlen)]
 
+    def seq_qual(self, i):
+        """SEQ and QUAL columns of record i ('*' for an absent one), as `samtools view` prints them."""
+        o = int(self.rb[i])
+        l_name, n_cig, l_seq = self.s[o + 12], int(self.s[o + 16]) | (int(self.s[o + 17]) << 8), struct.unpack_from("<i", bytes(self.s[o + 20:o + 24]))[0]
+        p = o + 36 + int(l_name) + 4 * n_cig
+        if l_seq == 0:
+            return "*", "*"
+        nib = np.frombuffer(bytes(self.s[p:p + (l_seq + 1) // 2]), dtype=np.uint8)
+        codes = np.empty(2 * len(nib), dtype=np.uint8)
+        codes[0::2], codes[1::2] = nib >> 4, nib & 15
+        seq = "".join(SEQ_CODES[c] for c in codes[:l_seq])
+        q = np.frombuffer(bytes(self.s[p + (l_seq + 1) // 2:p + (l_seq + 1) // 2 + l_seq]), dtype=np.uint8)
+        qual = "*" if len(q) and q[0] == 0xFF else bytes(q + 33).decode()
+        return seq, qual
+
 
 def decode_chunks(gf, chunks, fai_names):
     """chunks: iterable of consecutive pieces of a BAM file (any sizes).  Yields (records, BamCols) per piece that completed
@@ -97,3 +119,24 @@ def read_file_chunks(path, chunk_bytes=256 << 20):
 
 def decode_file(gf, path, fai_names, chunk_bytes=256 << 20):
     return decode_chunks(gf, read_file_chunks(path, chunk_bytes), fai_names)
+
+
+def write_fai(sf_fasta):
+    """`samtools faidx` stand-in for the builtin mode: NAME LENGTH OFFSET LINEBASES LINEWIDTH per sequence."""
+    rows, cur = [], None
+    with open(sf_fasta, "rb") as f:
+        off = 0
+        for line in f:
+            if line.startswith(b">"):
+                if cur:
+                    rows.append(cur)
+                cur = [line[1:].split()[0].decode(), 0, off + len(line), 0, 0]
+            elif cur is not None and line.strip():
+                if cur[3] == 0:
+                    cur[3], cur[4] = len(line.rstrip(b"\r\n")), len(line)
+                cur[1] += len(line.rstrip(b"\r\n"))
+            off += len(line)
+    if cur:
+        rows.append(cur)
+    with open(sf_fasta + ".fai", "w") as f:
+        f.write("".join("%s\t%d\t%d\t%d\t%d\n" % tuple(r) for r in rows))

@@ -19,15 +19,21 @@ the oracle's k-mer predicate."""
 import os
 import subprocess
 
+from . import bam_io
 from . import fastq_io
 from .gnrt_pos_true_seqs import read_fasta
 from .hip_api import GapFill
 
 
-def run_collect_both_unmapped(sf_bam, samtools_path):
+def run_collect_both_unmapped(sf_bam, samtools_path, gf=None):
     sf_both_unmap = sf_bam + ".both_unmapped.sam"
     with open(sf_both_unmap, "w") as f:
-        subprocess.run([samtools_path, "view", "-f", "12", sf_bam], check=True, stdout=f)
+        if bam_io.is_builtin(samtools_path):      # `samtools view -f 12`: both FLAG bits 4 and 8 set; the 11 mandatory columns
+            for recs, cols in bam_io.decode_file(gf or GapFill(0), sf_bam, []):
+                for i in ((recs["flag"] & 12) == 12).nonzero()[0]:
+                    f.write("\t".join(cols[int(i)] + list(cols.seq_qual(int(i)))) + "\n")
+        else:
+            subprocess.run([samtools_path, "view", "-f", "12", sf_bam], check=True, stdout=f)
     with open(sf_both_unmap) as fin, open(sf_bam + ".both_unmapped.fq", "w") as fout:
         for line in fin:
             fields = line.split()
@@ -79,7 +85,7 @@ class BothUnmappedReadsCollector:
     def collect_both_unmapped_reads(self, bam_list, id_list):
         wf = self.wf
         for sf_bam in bam_list:
-            run_collect_both_unmapped(sf_bam, self.samtools_path)
+            run_collect_both_unmapped(sf_bam, self.samtools_path, self.gf)
         with open(wf + "both_unmapped.fq", "w") as fout:                                   # `cat` of the per-BAM files (:197-202)
             for sf_bam in bam_list:
                 with open(sf_bam + ".both_unmapped.fq") as f:

@@ -31,22 +31,20 @@ class GapReadsCollector:
         gf.set_gaps(gaps, len(names))
         on_device = hasattr(gf, "sam_pack")     # SAM text parsed on the GPU (gf_sam_pack); columns are cut lazily for the hits
         recs, cols = sam_io.decode_on_device(gf, sam_lines, names) if on_device else sam_io.decode(sam_lines, sidx)
+        return self.tag_decoded(gf, recs, cols, gaps, names, anchor_mapq, {})
+
+    def tag_decoded(self, gf, recs, cols, gaps, names, anchor_mapq, out):
+        """Tag one batch of decoded records (gf.set_gaps done); lines are appended to `out` in record order, so successive
+        batches of one coordinate-sorted file (bam_io.decode_file) give the lists of one pass over it."""
+        import numpy as np
         hits = gf.tag_alignments(recs, self.insert_size, self.derivation, self.dist_clip, anchor_mapq)
         with_gaps = set(int(g) for g in gaps["scaffold"])
-        out = {}
         # the reference opens the pair of files at the first record of a scaffold (:93-102)
-        seen = []
-        if on_device:
-            import numpy as np
-            _, first = np.unique(recs["ref"], return_index=True)
-            seen = [names[int(recs["ref"][i])] for i in sorted(first) if int(recs["ref"][i]) < len(names)]
-        else:
-            for f in cols:
-                if f[2] not in seen:
-                    seen.append(f[2])
-        for name in seen:
-            if sidx.get(name, -1) in with_gaps and name not in out:
-                out[name] = {"left": [], "right": []}
+        _, first = np.unique(recs["ref"], return_index=True)
+        for i in sorted(first):
+            r = int(recs["ref"][i])
+            if r < len(names) and r in with_gaps and names[r] not in out:
+                out[names[r]] = {"left": [], "right": []}
         for h in hits:
             f = cols[h["rec"]]
             g = gaps[h["gap"]]

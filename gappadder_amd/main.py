@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 from . import assemble_gaps
+from . import bam_io
 from .gnrt_pos_true_seqs import DGProcessor
 from .hip_api import GapFill
 from .merge_reads import ReadsMerger
@@ -64,7 +65,10 @@ def main_func(command, sf_config):
     wf = cfg["wf"]
     sf_fai = cfg["draft"] + ".fai"
     if not os.path.exists(sf_fai):
-        subprocess.call([cfg["samtools"], "faidx", cfg["draft"]])
+        if bam_io.is_builtin(cfg["samtools"]):
+            bam_io.write_fai(cfg["draft"])
+        else:
+            subprocess.call([cfg["samtools"], "faidx", cfg["draft"]])
     sf_gap_pos = wf + "gap_positions.txt"
     anchor_mapq, clip_dist = 30, 250      # main.py:215-216
     if command in ("Clean", "All"):

@@ -5,6 +5,7 @@ import os
 import numpy as np
 
 from . import _lib as B
+from . import bam_io
 from . import sam_io
 from .collect_discordant_low_mapq_reads import low_mapq_lines, read_rows
 from .hip_api import GapFill
@@ -55,6 +56,14 @@ class DiscordantReadsCollector:
         gf = self._gf or GapFill(0)
         open(self.working_folder + "cluster_by_discordant_reads_left.list", "w").close()
         open(self.working_folder + "cluster_by_discordant_reads_right.list", "w").close()
+        def write(scf, res):
+            for side in ("left", "right"):
+                with open(self.working_folder + "discordant_reads_list/%s_cluster_by_discordant_reads_%s.list" % (scf, side), "w") as f:
+                    f.write("".join(l + "\n" for l in res[side]))
+
+        if bam_io.is_builtin(self.samtools_path):
+            self._collect_from_bam(gf, names, write)
+            return
         for scf in names:
             sf = self.working_folder + "discordant_temp/" + scf + ".list"
             if not os.path.exists(sf):
@@ -63,11 +72,32 @@ class DiscordantReadsCollector:
             gf.set_gaps(np.zeros(0, dtype=B.GAP), len(names))
             lines = sam_of_scaffold(self.samtools_path, self.sf_bam, scf).splitlines()
             res = low_mapq_lines(gf, lines, scf, rows, len(names))
-            if res is None:
+            if res is not None:
+                write(scf, res)
+
+    def _collect_from_bam(self, gf, names, write):
+        """The per-scaffold loop above in one pass over the BAM (bam_io): the rows of every discordant_temp list form one
+        table (rows carry their mate scaffold), a MAPQ-0 record is looked up in the rows of its own scaffold."""
+        have = [i for i, n in enumerate(names) if os.path.exists(self.working_folder + "discordant_temp/" + n + ".list")]
+        tables = [read_rows(self.working_folder + "discordant_temp/" + names[i] + ".list") for i in have]
+        rows = np.concatenate(tables) if tables else np.zeros(0, dtype=B.DPOS)
+        listed = set(have)
+        gf.set_gaps(np.zeros(0, dtype=B.GAP), len(names))
+        res = {}
+        for recs, cols in bam_io.decode_file(gf, self.sf_bam, names):
+            low = recs["mapq"] == 0
+            for r in np.unique(recs["ref"][low]):          # the reference writes a scaffold's files once it saw a MAPQ-0 record
+                if int(r) in listed:
+                    res.setdefault(int(r), {"left": [], "right": []})
+            if not len(rows):
                 continue
-            for side in ("left", "right"):
-                with open(self.working_folder + "discordant_reads_list/%s_cluster_by_discordant_reads_%s.list" % (scf, side), "w") as f:
-                    f.write("".join(l + "\n" for l in res[side]))
+            for h in gf.tag_low_mapq(recs, rows):
+                f = cols[h["rec"]]
+                row = rows[h["gap"]]
+                res[int(row["mate_scaffold"])]["left" if int(f[1]) & 0x40 else "right"].append(
+                    "%s %d_%d %d" % (f[0], row["src_scaffold"], row["src_gap"], int(f[4])))
+        for i in sorted(res):
+            write(names[i], res[i])
 
     # ---- FASTQ join (run_multi_threads_discordant.py:141-317 / 452-594)
     def _read_gap_map(self, names, side, high_quality):

@@ -19,7 +19,7 @@ elif sys.argv[1] == "view":
 '''
 
 
-def materialise(case, root, kmers=((31, 29),), kmer_screen=0):
+def materialise(case, root, kmers=((31, 29),), kmer_screen=0, builtin_bam=False):
     data, wf = os.path.join(root, "data"), os.path.join(root, "wf")
     os.makedirs(data)
     os.makedirs(wf)
@@ -32,8 +32,15 @@ def materialise(case, root, kmers=((31, 29),), kmer_screen=0):
     libs = []
     for i, lib in enumerate(case.libs):
         bam = os.path.join(data, "lib%d.bam" % i)
-        open(bam, "w").close()
-        open(bam + ".sam", "w").write(lib["sam"])
+        if builtin_bam:      # a real BAM (test-side writer) for software_path.samtools = "builtin"; no stand-in text beside it
+            import bam_util
+            names = [l.split()[0] for l in case.fai.splitlines() if l.strip()]
+            lens = [int(l.split()[1]) for l in case.fai.splitlines() if l.strip()]
+            stream = bam_util.sam_to_bam_stream(lib["sam"].splitlines(), names[::-1], lens[::-1])   # header order != .fai order
+            open(bam, "wb").write(bam_util.bgzf_compress(stream, block=20000, seed=i + 1, levels=(6, 1, "fixed")))
+        else:
+            open(bam, "w").close()
+            open(bam + ".sam", "w").write(lib["sam"])
         l, r = os.path.join(data, "lib%d_1.fq" % i), os.path.join(data, "lib%d_2.fq" % i)
         open(l, "w").write(lib["fq1"])
         open(r, "w").write(lib["fq2"])
@@ -44,7 +51,7 @@ def materialise(case, root, kmers=((31, 29),), kmer_screen=0):
     cfg = {"draft_genome": {"fa": draft},
            "raw_reads": [{"left": l, "right": r} for (_, l, r, _, _) in libs],
            "alignments": [{"bam": b, "is": str(i), "std": str(s)} for (b, _, _, i, s) in libs],
-           "software_path": {"bwa": "bwa", "samtools": st, "velvet": "/x/", "kmc": "/x/", "TERefiner": "x", "ContigsMerger": "x"},
+           "software_path": {"bwa": "bwa", "samtools": "builtin" if builtin_bam else st, "velvet": "/x/", "kmc": "/x/", "TERefiner": "x", "ContigsMerger": "x"},
            "parameters": {"working_folder": wf, "min_gap_size": str(case.meta["min_gap"]), "flank_length": str(case.meta["flank"]),
                           "nthreads": "2", "verbose": "0", "kmer_screen": kmer_screen},
            "kmer_length": [{"k": k, "k_velvet": [{"k": kv} for kv in kvs]} for k, kvs in by_k.items()]}

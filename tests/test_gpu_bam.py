@@ -95,7 +95,7 @@ def _check_bam(gf, sam_text, fai_names, ref_names, pieces, **bgzf):
     for recs, bc in bam_io.decode_chunks(gf, (bam[a:b] for a, b in zip(cuts, cuts[1:])), fai_names):
         assert np.array_equal(recs["read"], np.arange(len(recs)))
         got.append(recs)
-        gcols += [(base + i, bc[i]) for i in range(0, len(recs), max(1, len(recs) // 50))]
+        gcols += [(base + i, bc[i] + list(bc.seq_qual(i))) for i in list(range(0, len(recs), max(1, len(recs) // 50))) + [len(recs) - 1]]
         base += len(recs)
     got = np.concatenate(got) if got else np.zeros(0, dtype=exp.dtype)
     assert len(got) == len(exp)
@@ -103,8 +103,8 @@ def _check_bam(gf, sam_text, fai_names, ref_names, pieces, **bgzf):
     a["read"] = 0
     b["read"] = 0
     assert a.tobytes() == b.tobytes()
-    for i, c in gcols:
-        assert c == cols[i], (i, c, cols[i])
+    for i, c in gcols:      # the 11 mandatory columns as `samtools view` would print them
+        assert c[:9] == cols[i] and c[9:] == lines[i].split("\t")[9:11], (i, c, lines[i][:200])
     return len(got)
 
 

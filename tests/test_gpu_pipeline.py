@@ -234,3 +234,22 @@ def test_both_unmapped_round_recruits_by_contig_kmers(tmp_path):
         assert open(wf + "gap_reads/%s.fastq" % key).read() == before + exp
         total += len(idx)
     assert total >= 2 * 140 and not os.path.exists(wf + "unmapped_reads/9_9.fastq")
+
+
+def test_builtin_bam_mode_writes_the_same_tree_as_the_samtools_pipes(run, tmp_path):
+    """software_path.samtools = "builtin": the BAM is inflated and decoded on the GPU in one pass (gappadder_amd/bam_io.py)
+    instead of one `samtools view` pipe per scaffold and stage; every file of the working folder must come out identical."""
+    from gappadder_amd import main as M
+    case, _, ref_tree = run
+    cfgp, wf, _ = PU.materialise(case, str(tmp_path), kmers=((31, 29), (41, 39), (41, 38)), builtin_bam=True)
+    os.remove(os.path.join(str(tmp_path), "data", "draft.fa.fai"))      # `samtools faidx` is part of the builtin mode too
+    for stage in ("Preprocess", "Collect", "Assembly"):
+        M.main(["-c", stage, "-g", cfgp])
+    assert open(os.path.join(str(tmp_path), "data", "draft.fa.fai")).read() == case.fai
+    got = PU.tree(wf)
+    assert sorted(got) == sorted(ref_tree)
+    for rel in ref_tree:
+        if "/scaffold_reads_list_all/" in rel or "/discordant_reads_list/" in rel or rel.endswith(".fastq") or rel.endswith(".fa"):
+            assert got[rel] == ref_tree[rel], rel
+        else:
+            assert sorted(got[rel].splitlines()) == sorted(ref_tree[rel].splitlines()), rel
