@@ -45,20 +45,48 @@ def parse_header(stream):
 
 
 class BamCols:
-    """The nine SAM columns of record i as `samtools view` prints them, cut on demand from the inflated bytes."""
+    """The SAM columns of record i as `samtools view` prints them, cut on demand from the record's bytes.  Host-backed
+    (`stream` = inflated bytes) or device-backed (`stream` = None, `gf` given): the records asked for are gathered from the
+    stream the GPU still holds (gf_bam_fetch) — valid until the next gf.bgzf_inflate / gf.bam_pack call; prefetch(indices)
+    gets many in one gather."""
 
-    def __init__(self, stream, rec_begin, ref_names):
-        self.s, self.rb, self.names = stream, rec_begin, ref_names
+    def __init__(self, stream, rec_begin, ref_names, gf=None, stream_end=None):
+        self.s, self.rb, self.names, self.gf = stream, np.asarray(rec_begin, dtype=np.uint64), ref_names, gf
+        self.end = int(stream_end if stream_end is not None else (len(stream) if stream is not None else 0))
+        self.cache = {}
 
     def __len__(self):
         return len(self.rb)
 
+    def prefetch(self, indices):
+        if self.s is not None:
+            return
+        idx = np.array(sorted(set(int(i) for i in indices) - set(self.cache)), dtype=np.int64)
+        if not len(idx):
+            return
+        begin = self.rb[idx]
+        nxt = np.append(self.rb[1:], np.uint64(self.end))
+        end = nxt[idx]
+        blob = self.gf.bam_fetch(begin, end).tobytes()
+        o = 0
+        for i, ln in zip(idx, (end - begin)):
+            self.cache[int(i)] = blob[o:o + int(ln)]
+            o += int(ln)
+
+    def _rec(self, i):
+        i = int(i)
+        if self.s is not None:
+            o = int(self.rb[i])
+            return bytes(self.s[o:o + 4 + struct.unpack_from("<i", bytes(self.s[o:o + 4]))[0]])
+        if i not in self.cache:
+            self.prefetch([i])
+        return self.cache[i]
+
     def __getitem__(self, i):
-        o = int(self.rb[i])
-        ref, pos, l_name, mapq, _bin, n_cig, flag, _l_seq, mref, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", bytes(self.s[o + 4:o + 36]))
-        p = o + 36
-        qname = bytes(self.s[p:p + l_name - 1]).decode()
-        ops = np.frombuffer(bytes(self.s[p + l_name:p + l_name + 4 * n_cig]), dtype="<u4")
+        r = self._rec(i)
+        ref, pos, l_name, mapq, _bin, n_cig, flag, _l_seq, mref, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", r, 4)
+        qname = r[36:36 + l_name - 1].decode()
+        ops = np.frombuffer(r[36 + l_name:36 + l_name + 4 * n_cig], dtype="<u4")
         cigar = "".join("%d%s" % (v >> 4, CIGAR_OPS[v & 15]) for v in ops) or "*"
         rname = self.names[ref] if ref >= 0 else "*"
         rnext = "*" if mref < 0 else ("=" if mref == ref else self.names[mref])
@@ -66,42 +94,50 @@ class BamCols:
 
     def seq_qual(self, i):
         """SEQ and QUAL columns of record i ('*' for an absent one), as `samtools view` prints them."""
-        o = int(self.rb[i])
-        l_name, n_cig, l_seq = self.s[o + 12], int(self.s[o + 16]) | (int(self.s[o + 17]) << 8), struct.unpack_from("<i", bytes(self.s[o + 20:o + 24]))[0]
-        p = o + 36 + int(l_name) + 4 * n_cig
+        r = self._rec(i)
+        l_name, n_cig, l_seq = r[12], r[16] | (r[17] << 8), struct.unpack_from("<i", r, 20)[0]
+        p = 36 + l_name + 4 * n_cig
         if l_seq == 0:
             return "*", "*"
-        nib = np.frombuffer(bytes(self.s[p:p + (l_seq + 1) // 2]), dtype=np.uint8)
+        nib = np.frombuffer(r[p:p + (l_seq + 1) // 2], dtype=np.uint8)
         codes = np.empty(2 * len(nib), dtype=np.uint8)
         codes[0::2], codes[1::2] = nib >> 4, nib & 15
         seq = "".join(SEQ_CODES[c] for c in codes[:l_seq])
-        q = np.frombuffer(bytes(self.s[p + (l_seq + 1) // 2:p + (l_seq + 1) // 2 + l_seq]), dtype=np.uint8)
+        q = np.frombuffer(r[p + (l_seq + 1) // 2:p + (l_seq + 1) // 2 + l_seq], dtype=np.uint8)
         qual = "*" if len(q) and q[0] == 0xFF else bytes(q + 33).decode()
         return seq, qual
 
 
 def decode_chunks(gf, chunks, fai_names):
     """chunks: iterable of consecutive pieces of a BAM file (any sizes).  Yields (records, BamCols) per piece that completed
-    at least one record; record indices (rec.read) restart at 0 in every yield, like one sam_io.decode call per piece."""
+    at least one record; record indices (rec.read) restart at 0 in every yield, like one sam_io.decode call per piece.
+    Only file bytes go to the GPU and only records (32 B each), the header and the records later asked of BamCols come back:
+    the inflated stream never crosses PCIe.  A BamCols is valid until the next piece is requested."""
     index = {n: i for i, n in enumerate(fai_names)}
     ref_names, ref_map = None, None
     file_carry, rec_carry = b"", b""
     for piece in chunks:
         data = file_carry + bytes(piece)
-        stream, used = gf.bgzf_inflate(data, rec_carry)
+        n_stream, used = gf.bgzf_inflate(data, rec_carry, want_host=False)
         file_carry = data[used:]
         first = 0
         if ref_names is None:
-            hdr = parse_header(stream)
-            if hdr is None:          # header longer than this piece: keep everything inflated so far and go on
-                rec_carry = bytes(stream)
+            hdr, want = None, 1 << 16
+            while hdr is None and n_stream:
+                got = min(want, n_stream)
+                hdr = parse_header(gf.bam_fetch([0], [got]).tobytes())
+                if got == n_stream:
+                    break
+                want *= 4
+            if hdr is None:          # header longer than the pieces so far: keep everything inflated and go on
+                rec_carry = gf.bam_fetch([0], [n_stream]).tobytes() if n_stream else b""
                 continue
             ref_names, first = hdr
             ref_map = np.array([index.get(n, NO_REF) for n in ref_names], dtype=np.uint32)
-        recs, rb, consumed = gf.bam_pack(None, first, ref_map, n_bytes=len(stream))
-        rec_carry = bytes(stream[consumed:])
+        recs, rb, consumed = gf.bam_pack(None, first, ref_map, n_bytes=n_stream)
+        rec_carry = gf.bam_fetch([consumed], [n_stream]).tobytes() if consumed < n_stream else b""
         if len(recs):
-            yield recs, BamCols(stream, rb, ref_names)
+            yield recs, BamCols(None, rb, ref_names, gf=gf, stream_end=consumed)
     if file_carry:
         raise ValueError("BAM file ends inside a BGZF block (%d stray bytes)" % len(file_carry))
     if rec_carry and ref_names is not None:

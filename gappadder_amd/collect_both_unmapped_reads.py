@@ -30,7 +30,9 @@ def run_collect_both_unmapped(sf_bam, samtools_path, gf=None):
     with open(sf_both_unmap, "w") as f:
         if bam_io.is_builtin(samtools_path):      # `samtools view -f 12`: both FLAG bits 4 and 8 set; the 11 mandatory columns
             for recs, cols in bam_io.decode_file(gf or GapFill(0), sf_bam, []):
-                for i in ((recs["flag"] & 12) == 12).nonzero()[0]:
+                both = ((recs["flag"] & 12) == 12).nonzero()[0]
+                cols.prefetch(both)
+                for i in both:
                     f.write("\t".join(cols[int(i)] + list(cols.seq_qual(int(i)))) + "\n")
         else:
             subprocess.run([samtools_path, "view", "-f", "12", sf_bam], check=True, stdout=f)

@@ -45,6 +45,8 @@ class GapReadsCollector:
             r = int(recs["ref"][i])
             if r < len(names) and r in with_gaps and names[r] not in out:
                 out[names[r]] = {"left": [], "right": []}
+        if hasattr(cols, "prefetch"):
+            cols.prefetch(hits["rec"])
         for h in hits:
             f = cols[h["rec"]]
             g = gaps[h["gap"]]

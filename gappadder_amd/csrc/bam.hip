@@ -474,6 +474,18 @@ __global__ __launch_bounds__(256) void bam_emit_kernel(BamStream B, uint64_t n_s
     bam_walk<true>(B, guess[s], bam_seg_end(B, s), c, ref_map, recs, rec_begin, off[s], cap);
 }
 
+// slice i of the device-resident stream -> dst[dst_off[i] ...), one wavefront per slice
+__global__ __launch_bounds__(256) void bam_fetch_kernel(const uint8_t* stream, const unsigned long long* begin, const unsigned long long* end,
+                                                        const unsigned long long* dst_off, uint64_t n, uint8_t* dst) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint8_t* s = stream + begin[i];
+    uint8_t* d = dst + dst_off[i];
+    const uint64_t len = end[i] - begin[i];
+    for (uint64_t k = lane; k < len; k += 64) d[k] = s[k];
+}
+
 }  // namespace gf
 
 using namespace gf;
@@ -626,6 +638,39 @@ int gf_bam_pack(gf_ctx* ctx, const uint8_t* stream_or_null, size_t n_bytes, size
         if (rec_begin_or_null) GF_HIP(ctx, hipMemcpyAsync(rec_begin_or_null, d_rb, total * 8, hipMemcpyDeviceToHost, ctx->stream));
         GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_bam_fetch(gf_ctx* ctx, const uint64_t* begin, const uint64_t* end, size_t n, uint8_t* dst, size_t cap, size_t* n_bytes) {
+    if (!ctx || !n_bytes || (n && (!begin || !end))) return GF_E_INVAL;
+    *n_bytes = 0;
+    if (n == 0) return GF_OK;
+    if (!ctx->bam_stream.p) return GF_E_STATE;
+    std::vector<unsigned long long> h(3 * n);   // begin | end | dst offsets
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (begin[i] > end[i] || end[i] > ctx->bam_stream_len) return GF_E_INVAL;
+        h[i] = begin[i];
+        h[n + i] = end[i];
+        h[2 * n + i] = total;
+        total += (size_t)(end[i] - begin[i]);
+    }
+    *n_bytes = total;
+    if (total > cap || (total && !dst)) return GF_E_NOSPACE;
+    if (total == 0) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t b_idx = (3 * n * 8 + 63) & ~(size_t)63;
+    if ((rc = ensure(ctx, ctx->stage_out, b_idx + total + 64))) return rc;
+    unsigned long long* d_idx = (unsigned long long*)ctx->stage_out.p;
+    uint8_t* d_dst = (uint8_t*)ctx->stage_out.p + b_idx;
+    GF_HIP(ctx, hipMemcpyAsync(d_idx, h.data(), 3 * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((n + 3) / 4 >= 0xFFFFFFFFull) return GF_E_UNSUPPORTED;
+    hipLaunchKernelGGL(bam_fetch_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->bam_stream.p, d_idx, d_idx + n,
+                       d_idx + 2 * n, (uint64_t)n, d_dst);
+    GF_HIP(ctx, hipMemcpyAsync(dst, d_dst, total, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
 }

@@ -97,11 +97,15 @@ class GapFill:
                   "gf_sam_pack")
         return recs[:n.value], lb[:n.value]
 
-    def bgzf_inflate(self, bgzf, carry=b""):
+    def bgzf_inflate(self, bgzf, carry=b"", want_host=True):
         """BGZF file bytes (from a block boundary) -> (inflated bytes = carry + whole blocks' contents, n_consumed); inflated
-        and CRC-checked on the GPU, where the stream also stays for bam_pack(None, ...)."""
+        and CRC-checked on the GPU, where the stream also stays for bam_pack(None, ...) / bam_fetch.  want_host=False returns
+        the stream length instead of a host copy of it."""
         bgzf, carry = bytes(bgzf), bytes(carry)
         n, used = C.c_size_t(0), C.c_size_t(0)
+        if not want_host:
+            self._chk(self._L.gf_bgzf_inflate(self._h, bgzf, len(bgzf), carry, len(carry), None, 0, C.byref(n), C.byref(used)), "gf_bgzf_inflate")
+            return int(n.value), int(used.value)
         out = np.zeros(1, dtype=np.uint8)
         rc = self._L.gf_bgzf_inflate(self._h, bgzf, len(bgzf), carry, len(carry), B._p(out), 0, C.byref(n), C.byref(used))
         if rc == B.GF_E_NOSPACE:
@@ -109,6 +113,16 @@ class GapFill:
             rc = self._L.gf_bgzf_inflate(self._h, bgzf, len(bgzf), carry, len(carry), B._p(out), len(out), C.byref(n), C.byref(used))
         self._chk(rc, "gf_bgzf_inflate")
         return out[:n.value], int(used.value)
+
+    def bam_fetch(self, begin, end):
+        """Slices [begin[i], end[i]) of the inflated stream on the GPU -> one uint8 array, back to back."""
+        begin = np.ascontiguousarray(begin, dtype=np.uint64)
+        end = np.ascontiguousarray(end, dtype=np.uint64)
+        total = int((end - begin).sum()) if len(begin) else 0
+        dst = np.zeros(max(1, total), dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self._L.gf_bam_fetch(self._h, B._p(begin), B._p(end), len(begin), B._p(dst), total, C.byref(n)), "gf_bam_fetch")
+        return dst[:n.value]
 
     def bam_pack(self, stream, first, ref_map, n_bytes=None):
         """Inflated BAM bytes (None: the n_bytes left on the GPU by bgzf_inflate) -> (records B.ALNREC [n], rec_begin uint64 [n],

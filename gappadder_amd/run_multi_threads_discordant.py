@@ -91,7 +91,9 @@ class DiscordantReadsCollector:
                     res.setdefault(int(r), {"left": [], "right": []})
             if not len(rows):
                 continue
-            for h in gf.tag_low_mapq(recs, rows):
+            hits = gf.tag_low_mapq(recs, rows)
+            cols.prefetch(hits["rec"])
+            for h in hits:
                 f = cols[h["rec"]]
                 row = rows[h["gap"]]
                 res[int(row["mate_scaffold"])]["left" if int(f[1]) & 0x40 else "right"].append(

@@ -142,8 +142,8 @@ int gf_sam_pack(gf_ctx* ctx, const char* text, size_t n_bytes, const char* names
  * and ISIZE checked (GF_E_FORMAT + gf_last_error on a mismatch).  `bgzf` = file bytes starting at a block boundary; only whole
  * blocks are taken: *n_consumed = bytes used (bring the rest back in front of the next chunk).  The inflated stream is
  * `carry` (bytes the previous gf_bam_pack call left unconsumed: a partial record) followed by the blocks' contents; it STAYS ON
- * THE DEVICE for gf_bam_pack and is also copied to out_or_null (capacity `cap`; GF_E_NOSPACE with *n_out = needed) — the
- * host cuts QNAMEs for the few records that produce a hit from that copy, and reads the BAM header from the first chunk.
+ * THE DEVICE for gf_bam_pack / gf_bam_fetch; out_or_null (capacity `cap`; GF_E_NOSPACE with *n_out = needed) additionally
+ * receives a host copy of all of it (NULL: none — the usual case, see gf_bam_fetch).
  * Replaces the `samtools view` pipe of run_multi_threads_collect_reads.py:30-32 / run_multi_threads_discordant.py:131-133. */
 int gf_bgzf_inflate(gf_ctx* ctx, const uint8_t* bgzf, size_t n_bytes, const uint8_t* carry, size_t n_carry, uint8_t* out_or_null,
                     size_t cap, size_t* n_out, size_t* n_consumed);
@@ -155,6 +155,11 @@ int gf_bgzf_inflate(gf_ctx* ctx, const uint8_t* bgzf, size_t n_bytes, const uint
  * none).  rec_begin[r] = offset of record r's block_size field.  GF_E_NOSPACE: *n_recs = needed. */
 int gf_bam_pack(gf_ctx* ctx, const uint8_t* stream_or_null, size_t n_bytes, size_t first, const uint32_t* ref_map, size_t n_ref,
                 gf_alnrec* recs, size_t cap_recs, uint64_t* rec_begin_or_null, size_t* n_recs, size_t* n_consumed);
+
+/* Slices [begin[i], end[i]) of the inflated stream that gf_bgzf_inflate / gf_bam_pack left on the device, packed back to back
+ * into dst (one small gather + one copy): the host asks for the header and for the few records that produced a hit instead of
+ * copying every inflated byte back.  *n_bytes = total size; GF_E_NOSPACE when cap is smaller. */
+int gf_bam_fetch(gf_ctx* ctx, const uint64_t* begin, const uint64_t* end, size_t n, uint8_t* dst, size_t cap, size_t* n_bytes);
 
 /* ---- north-star flank-k-mer screen ("flank-k-mer lookup to tag reads") ------------------------------
  * Emits (gap, read) for every read that has >= min_hits k-mer positions whose canonical k-mer occurs in the

@@ -156,3 +156,10 @@ def test_bam_pack_from_host_bytes_and_argument_errors(gf):
     with pytest.raises(B.GapFillError) as e:
         gf.bam_pack(bytes(bad), first, rmap)
     assert e.value.code == B.GF_E_FORMAT
+    # slices of the stream the GPU holds
+    gf.bam_pack(stream, first, rmap)
+    got = gf.bam_fetch([0, int(rb[3]), len(stream)], [4, int(rb[4]), len(stream)]).tobytes()
+    assert got == stream[:4] + stream[int(rb[3]):int(rb[4])]
+    with pytest.raises(B.GapFillError) as e:
+        gf.bam_fetch([0], [len(stream) + 1])
+    assert e.value.code == B.GF_E_INVAL
