@@ -128,7 +128,7 @@ void gf_destroy(gf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
-    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->binmap, &ctx->binmap_fine, &ctx->bam_stream, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->rowgap, &ctx->pool_ws, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->binmap, &ctx->binmap_fine, &ctx->bam_stream, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->rowgap, &ctx->pool_ws, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
         if (b->p) (void)hipFree(b->p);
     if (ctx->d_gaps) (void)hipFree(ctx->d_gaps);
     if (ctx->d_scaf_off) (void)hipFree(ctx->d_scaf_off);

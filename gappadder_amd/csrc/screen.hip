@@ -362,6 +362,221 @@ __device__ __forceinline__ bool sset_walk(const FilterParams& P, uint32_t key, u
     }
 }
 
+// ---- partitioned filter: key sets whose level-1 bitmap is larger than an XCD's L2 (human scale: 1.1e7 16-mers, 2^28 bits) -----
+// Every level-1 probe of the plain kernel then misses the L2 and pulls a 128-byte line over the fabric for two bits of it
+// (C4 shard, PMC: 3.1e8 fabric reads = 39 GB per launch for 4.3 GB of reads — the kernel runs at the fabric's bandwidth, not
+// the algorithm's).  Here the probes are radix-partitioned first so that each slice of the bitmap is probed from ONE L2:
+//   pass A  every wave streams its 64-read tiles, scrambles the aligned 16-mers and appends (scrambled key, read) pairs to one
+//           of NB = 8/16 buckets by the top bits of the key: NB ballots per probe place the pairs in per-wave LDS rows, a full
+//           row leaves as one 512-byte store into the wave's OWN part of the bucket (no atomics, no barrier);
+//   pass B  bucket b is read back by the workgroups that the dispatcher places on XCD b mod 8 (blockIdx mod 8), so its
+//           2^(bm_log2 - log2 NB)-bit slice (2 MiB at 2^28) stays in that XCD's L2: both bits of the key in one word, then the
+//           exact set, then one candidate entry per read (a `seen` bit per read).
+// All fabric traffic is streamed: reads once, pairs written and read once.  A part that runs full (degenerate inputs: millions
+// of identical reads) is not an error — its pairs are probed on the spot, the way the plain kernel does.
+struct PartParams {
+    FilterParams F;
+    uint32_t nb_log2;           // log2 buckets
+    uint32_t n_writers;         // writer waves of pass A
+    uint32_t cap;               // pairs per (bucket, writer)
+    unsigned long long* pairs;  // [bucket][writer][cap]: {read (high 32), scrambled key (low 32)}
+    uint32_t* count;            // [bucket][writer]
+    uint32_t* seen;             // one bit per read
+};
+constexpr uint32_t PF_ROW = 128;   // pairs per LDS row: a row is flushed at 64, one probe adds at most 64
+
+// level-1 + exact-set test of one pair; true for the first hit of a read
+__device__ __forceinline__ bool pf_test_pair(const PartParams& Q, uint32_t pk, uint32_t read, bool active) {
+    const FilterParams& P = Q.F;
+    bool cand = false;
+    if (active) {
+        const uint32_t h = pk >> (32 - P.bm_log2);
+        const uint32_t wd = P.bitmap[h >> 5];
+        if ((wd >> (h & 31)) & (wd >> (pk & 31)) & 1u) {   // both bits of the key in its word (hash_s16_bit2 = low bits of pk)
+            const uint32_t key = pk * S16_MUL_INV;
+            if (sset_walk(P, key, hash_s16_set(key, P.s_log2))) {
+                const uint32_t bit = 1u << (read & 31);
+                cand = !(atomicOr(&Q.seen[read >> 5], bit) & bit);
+            }
+        }
+    }
+    return cand;
+}
+
+template <int NB_LOG2>
+__global__ __launch_bounds__(512) void pf_scatter_kernel(PartParams Q, uint32_t slice_words) {
+    extern __shared__ uint32_t sm[];   // per wave: [tile: 64 reads + 16 B][NB row fills][NB rows of PF_ROW pairs]
+    constexpr uint32_t NB = 1u << NB_LOG2;
+    const FilterParams& P = Q.F;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    const uint32_t per_wave = slice_words + NB + NB * PF_ROW * 2;
+    uint32_t* tile = sm + wv * per_wave;
+    uint32_t* fill = tile + slice_words;   // pairs waiting in each row (LDS atomics place the pairs of one probe)
+    unsigned long long* rows = reinterpret_cast<unsigned long long*>(fill + NB);
+    uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
+    const uint32_t writer = blockIdx.x * nw + wv;
+    if (writer >= Q.n_writers) return;
+    const uint32_t tile_bytes = 64 * P.rb;
+    const uint64_t total_bytes = P.n_reads * P.rb;
+    const uint64_t n_tiles = (P.n_reads + 63) / 64;
+    const unsigned long long lt = (1ull << lane) - 1;
+    uint32_t written = 0;   // lane b < NB: pairs stored in this wave's part of bucket b
+    if (lane < NB) fill[lane] = 0;
+    auto part = [&](uint32_t b) { return Q.pairs + ((size_t)b * Q.n_writers + writer) * Q.cap; };
+    auto spill = [&](unsigned long long pair, bool active) {   // the part is full: probe now
+        const bool c = pf_test_pair(Q, (uint32_t)pair, (uint32_t)(pair >> 32), active);
+        const unsigned long long bal = __ballot(c);
+        if (bal) {
+            uint32_t gb = 0;
+            if (lane == 0) gb = atomicAdd(P.n_cand, (uint32_t)__popcll(bal));
+            gb = __shfl(gb, 0);
+            if (c) P.cand[gb + __popcll(bal & lt)] = (uint32_t)(pair >> 32);
+        }
+    };
+    // rows holding >= `level` pairs send their first min(fill, 64) pairs to this wave's part of the bucket (one 512-byte run)
+    auto drain = [&](uint32_t level) {
+        unsigned long long full = __ballot(lane < NB && fill[lane] >= level);
+        while (full) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(full);
+            full &= full - 1;
+            const uint32_t have = fill[b], n = have < 64 ? have : 64;
+            const uint32_t at = __builtin_amdgcn_readlane(written, b);
+            const unsigned long long head = rows[b * PF_ROW + lane], rest = rows[b * PF_ROW + 64 + lane];
+            if (at + n <= Q.cap) {
+                if (lane < n) part(b)[at + lane] = head;
+                if (lane == b) written += n;
+            } else {
+                spill(head, lane < n);
+            }
+            wave_lds_sync();
+            rows[b * PF_ROW + lane] = rest;
+            if (lane == 0) fill[b] = have - n;
+        }
+        wave_lds_sync();
+    };
+    constexpr int NPF = 4;   // 64 reads x <= 64 B
+    uint4 pf[NPF];
+    auto prefetch = [&](uint64_t t) {
+        if (t >= n_tiles) return;
+        const uint64_t byte0 = t * tile_bytes;
+        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+#pragma unroll
+        for (int c = 0; c < NPF; ++c) {
+            const uint32_t i = lane + c * 64;
+            pf[c] = i < (nbytes >> 4) ? *reinterpret_cast<const uint4*>(P.reads + byte0 + (uint64_t)i * 16) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    prefetch(writer);
+    for (uint64_t t = writer; t < n_tiles; t += Q.n_writers) {
+        const uint64_t byte0 = t * tile_bytes;
+        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+        const uint32_t n16 = nbytes & ~15u;
+#pragma unroll
+        for (int c = 0; c < NPF; ++c) {
+            const uint32_t i = lane + c * 64;
+            if (i < (n16 >> 4)) *reinterpret_cast<uint4*>(tb + (uint64_t)i * 16) = pf[c];
+        }
+        for (uint32_t i = n16 + lane; i < nbytes; i += 64) tb[i] = P.reads[byte0 + i];
+        if (lane < 16) tb[nbytes + lane] = 0;
+        wave_lds_sync();
+        prefetch(t + Q.n_writers);
+        const uint64_t r = t * 64 + lane;
+        const bool live = r < P.n_reads;
+        const uint32_t bit0 = lane * P.rb * 8;
+        for (uint32_t j = 0; j < P.np; ++j) {
+            const uint32_t pk = canon16(stream32(tile, bit0 + j * P.stride2)) * S16_MUL;
+            const uint32_t bk = pk >> (32 - NB_LOG2);
+            if (live) {   // a row has room: it held < 64 pairs and one probe adds at most 64
+                const uint32_t at = atomicAdd(&fill[bk], 1u);
+                rows[bk * PF_ROW + at] = ((unsigned long long)(uint32_t)r << 32) | pk;
+            }
+            wave_lds_sync();
+            drain(64);
+        }
+    }
+    drain(1);
+    if (lane < NB) Q.count[(size_t)lane * Q.n_writers + writer] = written;
+}
+
+__global__ __launch_bounds__(1024) void pf_probe_kernel(PartParams Q) {
+    extern __shared__ uint32_t sm[];   // [the bucket's slice of the 2^mid_log2-bit reduction (when there is one)][per wave: WOBUF candidates]
+    const FilterParams& P = Q.F;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t n_buckets = 1u << Q.nb_log2;
+    const uint32_t xcd = blockIdx.x & 7, li = blockIdx.x >> 3, n_local = (gridDim.x + 7 - xcd) >> 3;   // workgroups of this XCD
+    const bool mid = P.bitmap_mid != nullptr && P.mid_log2 >= Q.nb_log2 + 5;
+    const uint32_t mid_words = mid ? 1u << (P.mid_log2 - Q.nb_log2 - 5) : 0;
+    const uint32_t sh_mid = 32 - P.mid_log2, sh_bm = 32 - P.bm_log2;
+    uint32_t* obuf = sm + mid_words + wv * WOBUF;
+    uint32_t obuf_n = 0;   // wave-uniform
+    auto flush = [&]() {
+        uint32_t gb = 0;
+        if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
+        gb = __shfl(gb, 0);
+        for (uint32_t q = lane; q < obuf_n; q += 64) P.cand[gb + q] = obuf[q];
+        obuf_n = 0;
+        wave_lds_sync();
+    };
+    for (uint32_t b = xcd; b < n_buckets; b += 8) {
+        // the slice of the reduced bitmap that covers this bucket's keys: half of the pairs stop here without leaving the CU
+        __syncthreads();
+        for (uint32_t i = tid * 4; i < mid_words; i += 1024 * 4)
+            *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap_mid + (size_t)b * mid_words + i);
+        __syncthreads();
+        // every wave takes whole writer parts on its own
+        for (uint32_t w = li * 16 + wv; w < Q.n_writers; w += n_local * 16) {
+            const uint32_t n = Q.count[(size_t)b * Q.n_writers + w];
+            const unsigned long long* src = Q.pairs + ((size_t)b * Q.n_writers + w) * Q.cap;
+            // software pipeline: the next PB x 64 pairs are in flight while this batch asks the bitmap
+            constexpr int PB = 8;
+            unsigned long long nx[PB];
+            auto fetch = [&](uint32_t i0) {
+#pragma unroll
+                for (int u = 0; u < PB; ++u) nx[u] = i0 + u * 64 + lane < n ? src[i0 + u * 64 + lane] : 0ull;
+            };
+            fetch(0);
+            for (uint32_t i0 = 0; i0 < n; i0 += PB * 64) {
+                unsigned long long pr[PB];
+                uint32_t wd[PB];
+                bool live[PB];
+#pragma unroll
+                for (int u = 0; u < PB; ++u) pr[u] = nx[u];
+                if (i0 + PB * 64 < n) fetch(i0 + PB * 64);
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const uint32_t pk = (uint32_t)pr[u];
+                    live[u] = i0 + u * 64 + lane < n;
+                    if (mid && live[u]) {
+                        const uint32_t c = (pk >> sh_mid) & ((mid_words << 5) - 1);
+                        live[u] = (sm[c >> 5] >> (c & 31)) & 1u;
+                    }
+                    wd[u] = live[u] ? P.bitmap[(pk >> sh_bm) >> 5] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const uint32_t pk = (uint32_t)pr[u], read = (uint32_t)(pr[u] >> 32);
+                    bool cand = false;
+                    if (live[u] && ((wd[u] >> ((pk >> sh_bm) & 31)) & (wd[u] >> (pk & 31)) & 1u)) {
+                        const uint32_t key = pk * S16_MUL_INV;
+                        if (sset_walk(P, key, hash_s16_set(key, P.s_log2))) {
+                            const uint32_t bit = 1u << (read & 31);
+                            cand = !(atomicOr(&Q.seen[read >> 5], bit) & bit);
+                        }
+                    }
+                    const unsigned long long bal = __ballot(cand);
+                    if (bal) {
+                        if (cand) obuf[obuf_n + __popcll(bal & ((1ull << lane) - 1))] = read;
+                        obuf_n += (uint32_t)__popcll(bal);   // <= 31 + 64 <= WOBUF
+                        wave_lds_sync();
+                        if (obuf_n >= 32) flush();
+                    }
+                }
+            }
+        }
+    }
+    if (obuf_n) flush();
+}
+
 // Loads of the pipelined kernel are issued through inline asm and awaited with explicit s_waitcnt: the compiler's own
 // counter bookkeeping falls back to vmcnt(0) for loop-carried loads, which would drain the pipeline every step.  vmcnt
 // counts vector-memory operations in issue order, so "wait until at most N are outstanding" is safe whenever at least N
@@ -1226,6 +1441,35 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + w_nw - 1) / w_nw, ctx->n_cu)), dim3((unsigned)(w_nw * 64)),
                            w_bm_bytes + w_nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
+    } else if (ctx->screen_variant == 14 || (ctx->screen_variant == 0 && ix.bm_log2 >= 27 && n_reads >= (1u << 20) && rb <= 64)) {
+        // partitioned filter: the level-1 bitmap is far larger than an L2 (see pf_scatter_kernel)
+        PartParams Q;
+        Q.F = F;
+        Q.nb_log2 = 4;   // 16 buckets: two per XCD; a bucket's slice of the 2^24-bit reduction is 128 KiB of LDS in pass B
+        const uint32_t nb = 1u << Q.nb_log2;
+        const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;
+        const size_t per_wave = (slice_words + nb + (size_t)nb * PF_ROW * 2) * 4;
+        const unsigned nw = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / per_wave));
+        const size_t tiles64 = (n_reads + 63) / 64;
+        Q.n_writers = (uint32_t)std::min<size_t>(tiles64, (size_t)ctx->n_cu * nw);
+        // a writer's part of a bucket: expectation + 6 sigma + slack for the 64-pair granularity (keys hash uniformly; parts that
+        // still run full are probed in place)
+        const double tiles_w = (double)((tiles64 + Q.n_writers - 1) / Q.n_writers);
+        const double expect = tiles_w * 64.0 * F.np / nb;
+        Q.cap = ((uint32_t)(expect * 1.05 + 6.0 * std::sqrt(expect + 1.0) + 128.0) + 63u) & ~63u;
+        const size_t b_pairs = (size_t)nb * Q.n_writers * Q.cap * 8, b_cnt = ((size_t)nb * Q.n_writers * 4 + 255) & ~(size_t)255,
+                     b_seen = (((size_t)n_reads + 31) / 32 * 4 + 255) & ~(size_t)255;
+        if ((rc = ensure(ctx, ctx->part_ws, b_cnt + b_seen + b_pairs + 256))) return rc;
+        uint8_t* ws = (uint8_t*)ctx->part_ws.p;
+        Q.count = (uint32_t*)ws;
+        Q.seen = (uint32_t*)(ws + b_cnt);
+        Q.pairs = (unsigned long long*)(ws + b_cnt + b_seen);
+        GF_HIP(ctx, hipMemsetAsync(Q.seen, 0, b_seen, ctx->stream));
+        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
+        const unsigned grid_a = (unsigned)((Q.n_writers + nw - 1) / nw);
+        hipLaunchKernelGGL(pf_scatter_kernel<4>, dim3(grid_a), dim3(nw * 64), nw * per_wave, ctx->stream, Q, (uint32_t)slice_words);
+        const size_t mid_bytes = (F.bitmap_mid && F.mid_log2 >= Q.nb_log2 + 5) ? ((size_t)1 << (F.mid_log2 - Q.nb_log2)) / 8 : 0;
+        hipLaunchKernelGGL(pf_probe_kernel, dim3((unsigned)ctx->n_cu), dim3(1024), mid_bytes + 16 * WOBUF * 4, ctx->stream, Q);
     } else {
         const size_t n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
         const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * 8);

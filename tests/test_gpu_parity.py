@@ -298,9 +298,9 @@ def test_device_pools_follow_the_reference_fastq_join_order(gf):
         assert gseqs == [x[0] for x in e]
 
 
-@pytest.mark.parametrize("variant", [12, 13, 9])
+@pytest.mark.parametrize("variant", [12, 13, 9, 14])
 def test_screen_filter_variants_agree(gf, variant):
-    """Every filter kernel (wave = 12, pipelined = 13, plain L2 bitmap = 9) gives the oracle's hits."""
+    """Every filter kernel (wave = 12, pipelined = 13, plain L2 bitmap = 9, partitioned = 14) gives the oracle's hits."""
     from gappadder_amd.hip_api import GapFill
     c = S.small_case(seed=41, n_pairs=25000)
     gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
@@ -312,8 +312,8 @@ def test_screen_filter_variants_agree(gf, variant):
         for n in (len(packed), 1000, 769, 1):
             assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (variant, n)
         assert _same(gf.screen_reads(packed, c["L"], 51), exp51)
-        for bl in (16, 19, 22, 26):      # 26: level-1 bitmap beyond the L2 -> the plain kernel also asks the 2^24-bit reduction
-            gf.set_option("bitmap_log2", bl)
+        for bl in (16, 19, 22, 26, 28):  # 26: level-1 bitmap beyond the L2 -> the plain kernel also asks the 2^24-bit reduction;
+            gf.set_option("bitmap_log2", bl)   # 28: the partitioned filter uses 16 buckets instead of 8
             assert _same(gf.screen_reads(packed, c["L"], 31), exp31), (variant, bl)
     finally:
         gf.set_option("screen_variant", 0)
@@ -461,3 +461,25 @@ def test_tagger_on_human_scale_layout_uses_the_fine_bin_map(gf):
     for d2, cd in ((300, 30), (2500, 100)):
         th = gf.tag_alignments(recs, d2, cd, cap=1 << 21)
         assert _same(th, CO.tag_alignments(recs, gaps, d2, cd)) and len(th) > 1000
+
+
+def test_partitioned_filter_probes_in_place_when_a_bucket_part_runs_full(gf):
+    """Degenerate input for the partitioned filter (screen_variant 14): 60 000 poly-A reads put every probe into ONE bucket, eight
+    times what a writer's part of it holds, so most pairs take the in-place path; the hits must still be the oracle's (the flank
+    of gap 0 ends in a poly-A run, so those reads are real hits)."""
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=43, n_pairs=3000)
+    flanks = [list(f) for f in c["flanks"]]
+    flanks[0][0] = flanks[0][0][:-60] + "A" * 60
+    flanks = [tuple(f) for f in flanks]
+    L = c["L"]
+    blob = c["reads_blob"][:2000 * L] + b"A" * (60000 * L) + c["reads_blob"][2000 * L:]
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], flanks)
+    packed, _ = GapFill.pack_reads(blob, L)
+    exp = CO.screen_reads(blob, L, flanks, 31)
+    assert len(exp) > 60000
+    gf.set_option("screen_variant", 14)
+    try:
+        assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
+    finally:
+        gf.set_option("screen_variant", 0)
