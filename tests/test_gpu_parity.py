@@ -483,3 +483,34 @@ def test_partitioned_filter_probes_in_place_when_a_bucket_part_runs_full(gf):
         assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
     finally:
         gf.set_option("screen_variant", 0)
+
+
+def test_human_scale_key_set_all_filter_kernels_agree_on_20M_reads(gf):
+    """BASELINE.json configs[3]'s key set (19 840 gaps, 1.1e7 flank 16-mers, k=51: the level-1 bitmap gets 2^28 bits and the
+    partitioned filter is chosen) on 20 M synthetic reads: the automatic choice, the forced partitioned filter and the plain
+    kernel return the same hits, and every hit of the first 400 000 reads is the oracle's."""
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    cfg = GapFill.synth_cfg(seed=20260004, scaffold_len=5_000_000, n_scaffolds=620, gaps_per_scaffold=32, gap_len=2000)
+    gaps, flanks = GapFill.synth_layout(cfg)
+    gf.set_gaps(gaps, 620, flanks)
+    n_pairs, L, k = 10_000_000, 150, 51
+    dev = torch.device("cuda:0")
+    rb = B.lib().gf_packed_read_bytes(L)
+    d_reads = torch.empty(2 * n_pairs * rb + 64, dtype=torch.uint8, device=dev)
+    gf.synth_pairs_dev(cfg, 0, n_pairs, d_reads.data_ptr())
+    gf.sync()
+    packed = d_reads[:2 * n_pairs * rb].cpu().numpy().reshape(-1, rb)
+    res = {}
+    try:
+        for variant in (0, 14, 9):
+            gf.set_option("screen_variant", variant)
+            res[variant] = gf.screen_reads(packed, L, k, cap=1 << 20)
+    finally:
+        gf.set_option("screen_variant", 0)
+    assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[9])
+    m = 400_000
+    exp = CO.screen_reads(CO.unpack_reads(packed[:m], L), L, flanks, k)
+    head = res[0][res[0]["read"] < m]
+    assert _same(head, exp) and len(exp) > 500
