@@ -34,11 +34,11 @@ enum : uint32_t {
     INF_SHORT = 7, INF_TRAILING = 8, INF_CRC = 9,
 };
 
-__device__ const uint16_t INF_LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ const uint8_t INF_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ const uint16_t INF_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ const uint8_t INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__device__ const uint8_t INF_CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+__device__ const uint32_t INF_LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const uint32_t INF_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const uint32_t INF_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__device__ const uint32_t INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ const uint32_t INF_CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __device__ __forceinline__ void wave_lds_sync() {   // LDS hand-off between lanes of one wave
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -80,7 +80,9 @@ __global__ __launch_bounds__(64 * INF_WAVES) void bgzf_inflate_kernel(const uint
     __shared__ uint32_t crc_tab[256];
     __shared__ uint16_t s_ll[INF_WAVES][288], s_d[INF_WAVES][32], s_cl[INF_WAVES][20];
     __shared__ uint8_t s_len[INF_WAVES][320 + 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // everything below is per WAVE: the wave index goes through readfirstlane so that the compiler keeps the decoder state in
+    // scalar registers and branches on it with scalar branches (derived from threadIdx it would count as divergent)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
         uint32_t c = tid;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
@@ -97,22 +99,33 @@ __global__ __launch_bounds__(64 * INF_WAVES) void bgzf_inflate_kernel(const uint
     uint8_t* dst = out + blk.out_off;
     const uint32_t isize = blk.isize;
 
-    // ---- shared bit reader (everything here is wave-uniform except cur/nxt)
+    // ---- shared bit reader (everything here is wave-uniform except cur)
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(in + blk.in_off);
-    const uint32_t* wp = reinterpret_cast<const uint32_t*>(a0 & ~(uintptr_t)3);
+    const uint32_t* wp;
+    {   // scalar base for the window loads (readfirstlane returns int: rebuild the pointer from unsigned halves)
+        const uint64_t v = a0 & ~(uint64_t)3;
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        wp = reinterpret_cast<const uint32_t*>(((uint64_t)hi << 32) | lo);
+    }
     uint32_t widx = 0, cnt = 0, used = 0;   // next dword to take; bits in buf; bits consumed since wp
     uint64_t buf = 0;
-    uint32_t cur = wp[lane], nxt = wp[64 + lane];
+    uint32_t cur;                            // lane i: dword (widx & ~63) + i of the stream
+    // the window load carries its own wait: left to the compiler, the pending load is tracked across the decode loop and every
+    // refill gets an s_waitcnt vmcnt(0) that also waits for all literal stores in flight (measured: 2x slower)
+    auto load_window = [&](uint32_t first_dword) {
+        const uint32_t off = (first_dword + lane) * 4;
+        // s_nop: the scalar base may have just been written by a v_readlane (SGPR spill reload), and the compiler does not
+        // insert the VALU-writes-SGPR -> VMEM wait states in front of inline asm
+        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(cur) : "v"(off), "s"(wp) : "memory");
+    };
+    load_window(0);
     auto refill = [&]() {
         while (cnt <= 32) {
             const uint32_t v = __builtin_amdgcn_readlane(cur, widx & 63);
             buf |= (uint64_t)v << cnt;
             cnt += 32;
             ++widx;
-            if ((widx & 63) == 0) {
-                cur = nxt;
-                nxt = wp[widx + 64 + lane];
-            }
+            if ((widx & 63) == 0) load_window(widx);
         }
     };
     auto drop = [&](uint32_t n) { buf >>= n; cnt -= n; used += n; };
@@ -123,9 +136,7 @@ __global__ __launch_bounds__(64 * INF_WAVES) void bgzf_inflate_kernel(const uint
     };
     auto seek_bit = [&](uint32_t bit) {   // reposition at absolute bit offset from wp
         widx = bit >> 5;
-        const uint32_t base = widx & ~63u;
-        cur = wp[base + lane];
-        nxt = wp[base + 64 + lane];
+        load_window(widx & ~63u);
         buf = 0; cnt = 0; used = bit & ~31u;
         refill();
         drop(bit & 31u);
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(64 * INF_WAVES) void bgzf_inflate_kernel(const uint
         const uint32_t len = (uint32_t)__builtin_ctzll(m);
         const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane(bas, len) + (code15 >> (15 - len));
         drop(len);
-        return S[idx];
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)S[idx]);
     };
 
     refill();
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(64 * INF_WAVES) void bgzf_inflate_kernel(const uint
             }
             if (err) break;
             wave_lds_sync();
-            if (LL[256] == 0) { err = INF_BAD_LENGTHS; break; }   // no end-of-block code
+            if (__builtin_amdgcn_readfirstlane((int)LL[256]) == 0) { err = INF_BAD_LENGTHS; break; }   // no end-of-block code
             if (!build(LL, hlit, SLL, ll_lim, ll_bas) || !build(LL + hlit, hdist, SD, d_lim, d_bas)) { err = INF_BAD_LENGTHS; break; }
         }
         // ---- symbols of this block
