@@ -123,7 +123,7 @@ def main():
     d_seq = torch.empty(seq_cap, dtype=torch.uint8, device=dev)
     d_gap_err = torch.zeros(len(gaps), dtype=torch.int32, device=dev)
     # counters (device u32 unless noted): 0 screen hits, 4 tagger hits, 8 second-hop hits, 12 keys, 16 contigs,
-    # 20 (u64) contig bases, 24 pool-sort overflow, 28 MAPQ==0 records
+    # 20 (u64) contig bases, 24 pool-sort overflow, 28 MAPQ==0 records, 29 second-hop table rows
     d_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
     cp = d_cnt.data_ptr()
     gf.sync()
@@ -140,35 +140,34 @@ def main():
                                            d_low.data_ptr(), low_cap, cp + 112)
         assert rc == 0, rc
 
-    # second-hop table (run_multi_threads_discordant.py:19-122 inverts the discordant lines and runs sort(1) on the host;
-    # the table depends only on the batch, so it is built once here and re-used by every step)
+    # second-hop table (run_multi_threads_discordant.py:19-122 inverts the discordant lines and runs sort(1) on the host): built
+    # on the device from the tagger's hits INSIDE every step (gf_second_hop_table_dev); this untimed pass only sizes its buffers
     recruit()
     gf.sync()
     gf2.sync()
     n_th = int(d_cnt[4])
     th = np.frombuffer(d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
-    disc = th[th["kind"] == B.KIND_DISCORDANT]
-    recs_d = np.frombuffer(d_recs.view(torch.int64).view(-1, 4)[torch.from_numpy(disc["rec"].astype(np.int64)).to(dev)]
-                           .cpu().numpy().tobytes(), dtype=B.ALNREC)
-    rows = np.zeros(len(disc), dtype=B.DPOS)
-    rows["mate_scaffold"], rows["mate_pos"] = recs_d["mate_ref"], recs_d["mate_pos"]
-    rows["src_scaffold"], rows["src_gap"] = gaps["scaffold"][disc["gap"]], gaps["idx_in_scaffold"][disc["gap"]]
-    rows = np.sort(rows, order=["mate_scaffold", "mate_pos", "src_scaffold", "src_gap"])
+    row_cap = 2 * int((th["kind"] == B.KIND_DISCORDANT).sum()) + 4096
+    d_rows = torch.empty(row_cap * 16, dtype=torch.uint8, device=dev)
+    d_row_gap = torch.empty(row_cap, dtype=torch.int32, device=dev)
 
     exch_rows = [0]
 
     def step():
         recruit()
-        rc = lib.gf_tag_low_mapq_compact_dev(h2, d_low.data_ptr(), cp + 112, low_cap, B._p(rows), len(rows), d_lhits.data_ptr(),
-                                             hit_cap, cp + 32)
+        rc = lib.gf_second_hop_table_dev(h2, d_recs.data_ptr(), d_thits.data_ptr(), cp + 16, hit_cap, d_rows.data_ptr(), d_row_gap.data_ptr(),
+                                         row_cap, cp + 116)
+        assert rc == 0, rc
+        rc = lib.gf_tag_low_mapq_table_dev(h2, d_low.data_ptr(), cp + 112, low_cap, d_rows.data_ptr(), cp + 116, row_cap, d_lhits.data_ptr(),
+                                           hit_cap, cp + 32)
         assert rc == 0, rc
         assert lib.gf_stream_wait(h, h2) == 0          # pools need the tagger's and the second hop's hits
         assert lib.gf_pool_keys_reset(h, cp + 48) == 0
         assert lib.gf_pool_keys_from_screen_dev(h, d_hits.data_ptr(), cp, hit_cap, 1, d_keys.data_ptr(), key_cap, cp + 48) == 0
         assert lib.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_thits.data_ptr(), cp + 16, hit_cap, None, 0,
                                               d_keys.data_ptr(), key_cap, cp + 48) == 0
-        assert lib.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_lhits.data_ptr(), cp + 32, hit_cap, B._p(rows), len(rows),
-                                              d_keys.data_ptr(), key_cap, cp + 48) == 0
+        assert lib.gf_pool_keys_from_second_hop_dev(h, d_recs.data_ptr(), d_lhits.data_ptr(), cp + 32, hit_cap, d_row_gap.data_ptr(),
+                                                    d_keys.data_ptr(), key_cap, cp + 48) == 0
         assert lib.gf_build_pools_dev(h, d_reads.data_ptr(), n_reads, L, d_keys.data_ptr(), cp + 48, key_cap, d_pool.data_ptr(),
                                       pool_cap, d_pool_off.data_ptr(), d_pool_ids.data_ptr(), cp + 96) == 0
         pool_ptr, off_ptr, pool_rows = d_pool.data_ptr(), d_pool_off.data_ptr(), pool_cap
@@ -218,7 +217,7 @@ def main():
     n_hits, n_thits, n_lhits, n_keys, n_ctg = int(cnt[0]), int(cnt[4]), int(cnt[8]), int(cnt[12]), int(cnt[16])
     n_seq = int(cnt[20:22].view(np.uint64)[0])
     pool_off = d_pool_off.cpu().numpy()
-    assert int(cnt[28]) <= low_cap
+    assert int(cnt[28]) <= low_cap and int(cnt[29]) <= row_cap
     assert int(cnt[24]) == 0 and int(d_gap_err.sum()) == 0 and pool_off[-1] <= pool_cap and n_ctg <= contig_cap and n_seq <= seq_cap
     ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
     if world > 1:

@@ -303,6 +303,19 @@ int gf_pool_keys_from_tags_dev(gf_ctx* ctx, const void* d_recs, const void* d_ta
     return GF_OK;
 }
 
+int gf_pool_keys_from_second_hop_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits, size_t hit_cap,
+                                     const void* d_row_gap, void* d_keys, size_t key_cap, void* d_n_keys) {
+    if (!ctx || !d_recs || !d_taghits || !d_n_taghits || !d_row_gap || !d_keys || !d_n_keys || hit_cap > 0xFFFFFFFFull || key_cap > 0xFFFFFFFFull)
+        return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    LaunchTimer tm(ctx, GF_KERNEL_POOL);
+    hipLaunchKernelGGL(keys_from_tags_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_alnrec*)d_recs,
+                       (const gf_taghit*)d_taghits, (const uint32_t*)d_n_taghits, (uint32_t)hit_cap, (const uint32_t*)d_row_gap,
+                       (unsigned long long*)d_keys, (uint32_t)key_cap, (uint32_t*)d_n_keys);
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
 int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, int read_len, const void* d_keys,
                        const void* d_n_keys, size_t key_cap, void* d_pool_packed, size_t pool_cap_reads, void* d_pool_off,
                        void* d_pool_read_ids, void* d_error) {

@@ -527,4 +527,29 @@ int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* ta
     return GF_OK;
 }
 
+// second hop over the compacted MAPQ-0 list with look-up arrays that already live on the device (hop.hip builds them)
+int launch_low_mapq_devtable(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const uint32_t* upos, const uint32_t* urow,
+                             const uint32_t* soff, void* d_out, size_t cap, void* d_n_out) {
+    GF_HIP(ctx, hipMemsetAsync(d_n_out, 0, 4, ctx->stream));
+    LowParams P;
+    P.recs = nullptr;
+    P.n = 0;
+    P.low = (const gf_lowrec*)d_low;
+    P.n_low = (const uint32_t*)d_n_low;
+    P.low_cap = (uint32_t)low_cap;
+    P.upos = upos;
+    P.urow = urow;
+    P.scaf_off = soff;
+    P.n_scaffolds = ctx->n_scaffolds;
+    P.out = (gf_taghit*)d_out;
+    P.cap = (uint32_t)cap;
+    P.n_out = (uint32_t*)d_n_out;
+    {
+        LaunchTimer tm(ctx, GF_KERNEL_LOWMAPQ);
+        hipLaunchKernelGGL(low_mapq_compact_kernel, dim3(stream_grid(ctx, std::max<size_t>(low_cap, 1))), dim3(256), 0, ctx->stream, P);
+    }
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
 }  // namespace gf

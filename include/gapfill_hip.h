@@ -235,6 +235,19 @@ int gf_tag_alignments_low_dev(gf_ctx* ctx, const void* d_recs, size_t n, int ins
                               size_t low_cap, void* d_n_low /* u32 */);
 int gf_tag_low_mapq_compact_dev(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const gf_dpos* table,
                                 size_t n_rows, void* d_out, size_t cap, void* d_n_out);
+/* The second-hop table itself on the device (replaces collect_discordant_regions_v2 + sort(1) + the per-scaffold split,
+ * run_multi_threads_discordant.py:19-122): one row per DISCORDANT tagger hit whose mate lies on a known scaffold,
+ * {mate_ref, mate_pos of the hit's record; scaffold, idx_in_scaffold of the hit's gap}, sorted by (mate scaffold, mate
+ * position) with one radix sort.  d_rows (gf_dpos[row_cap]) and d_row_gap (u32[row_cap]: index of each row's gap, for
+ * gf_pool_keys_from_second_hop_dev) are the caller's device buffers; *d_n_rows (device u32) = rows found — more than row_cap
+ * means the table is truncated (size row_cap from the number of tagger hits).  Rows with equal (scaffold, position) keep no
+ * particular order (the reference's -k3n -k4n): they produce the same hits. */
+int gf_second_hop_table_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits, size_t hit_cap,
+                            void* d_rows, void* d_row_gap, size_t row_cap, void* d_n_rows);
+/* second hop over the compacted MAPQ-0 list against a DEVICE table (d_rows / d_n_rows as written by gf_second_hop_table_dev,
+ * or any sorted gf_dpos array in HBM); hit.gap = row index, as with gf_tag_low_mapq */
+int gf_tag_low_mapq_table_dev(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const void* d_rows,
+                              const void* d_n_rows, size_t row_cap, void* d_out, size_t cap, void* d_n_out);
 
 /* ---- a-4 / a-5 on the device: per-gap read pools.  The reference joins read IDs against whole FASTQ files
  * ({readId -> set(gapKey)}, run_multi_threads_discordant.py:153-185; stream + append, :209-241, 283-316; `cat` across
@@ -251,6 +264,9 @@ int gf_pool_keys_from_screen_dev(gf_ctx* ctx, const void* d_hits, const void* d_
 int gf_pool_keys_from_tags_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits,
                                size_t hit_cap, const gf_dpos* lowmapq_table_or_null, size_t n_rows, void* d_keys,
                                size_t key_cap, void* d_n_keys);
+/* second-hop hits against a device table: hit.gap (a row) resolves through d_row_gap (gf_second_hop_table_dev) */
+int gf_pool_keys_from_second_hop_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits,
+                                     size_t hit_cap, const void* d_row_gap, void* d_keys, size_t key_cap, void* d_n_keys);
 /* keys -> d_pool_off (n_gaps+1 x u64), d_pool_packed (pool_cap_reads reads), d_pool_read_ids (u32 per pooled read, or
  * null); *d_error (u32) counts gaps whose key list exceeded the LDS sort (16384 keys).  d_pool_off[n_gaps] > pool_cap_reads
  * means the pool buffer was too small (reads beyond it are not written). */

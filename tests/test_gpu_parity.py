@@ -514,3 +514,61 @@ def test_human_scale_key_set_all_filter_kernels_agree_on_20M_reads(gf):
     exp = CO.screen_reads(CO.unpack_reads(packed[:m], L), L, flanks, k)
     head = res[0][res[0]["read"] < m]
     assert _same(head, exp) and len(exp) > 500
+
+
+def test_device_second_hop_table_equals_the_host_sort(gf):
+    """gf_second_hop_table_dev (rows cut from the tagger's hits and radix-sorted in HBM) == the reference's inversion + sort(1)
+    (run_multi_threads_discordant.py:19-122) done with numpy on the same hits; the second hop and the pool keys through the
+    device table give what the host-table variants give."""
+    import torch
+    from gappadder_amd import _lib as B
+    c = S.small_case(seed=53, n_pairs=40000)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    recs = c["recs"]
+    dev = torch.device("cuda:0")
+    d_recs = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy()).to(dev)
+    n, cap, row_cap = len(recs), 1 << 16, 1 << 12
+    d_t = torch.zeros(cap * 12, dtype=torch.uint8, device=dev)
+    d_l = torch.zeros(cap * 12, dtype=torch.uint8, device=dev)
+    d_low = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+    d_rows = torch.zeros(row_cap * 16, dtype=torch.uint8, device=dev)
+    d_rg = torch.zeros(row_cap, dtype=torch.int32, device=dev)
+    d_keys = torch.zeros(2, cap, dtype=torch.int64, device=dev)
+    d_cnt = torch.zeros(16, dtype=torch.int32, device=dev)
+    L, h, cp = B.lib(), gf.handle, d_cnt.data_ptr()
+    assert L.gf_tag_alignments_low_dev(h, d_recs.data_ptr(), n, 300, 30, 250, 30, d_t.data_ptr(), cap, cp, d_low.data_ptr(), n, cp + 4) == 0
+    assert L.gf_second_hop_table_dev(h, d_recs.data_ptr(), d_t.data_ptr(), cp, cap, d_rows.data_ptr(), d_rg.data_ptr(), row_cap, cp + 8) == 0
+    assert L.gf_tag_low_mapq_table_dev(h, d_low.data_ptr(), cp + 4, n, d_rows.data_ptr(), cp + 8, row_cap, d_l.data_ptr(), cap, cp + 12) == 0
+    gf.sync()
+    cnt = d_cnt.cpu().numpy()
+    n_t, n_rows, n_l = int(cnt[0]), int(cnt[2]), int(cnt[3])
+    th = np.frombuffer(d_t[:n_t * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
+    disc = th[th["kind"] == B.KIND_DISCORDANT]
+    exp = np.zeros(len(disc), dtype=B.DPOS)
+    exp["mate_scaffold"], exp["mate_pos"] = recs["mate_ref"][disc["rec"]], recs["mate_pos"][disc["rec"]]
+    exp["src_scaffold"], exp["src_gap"] = c["gaps"]["scaffold"][disc["gap"]], c["gaps"]["idx_in_scaffold"][disc["gap"]]
+    order = ["mate_scaffold", "mate_pos", "src_scaffold", "src_gap"]
+    exp = np.sort(exp, order=order)
+    rows = np.frombuffer(d_rows[:n_rows * 16].cpu().numpy().tobytes(), dtype=B.DPOS)
+    assert n_rows == len(exp) > 50
+    key = rows["mate_scaffold"].astype(np.uint64) << np.uint64(32) | rows["mate_pos"].astype(np.uint64)
+    assert np.all(key[1:] >= key[:-1])                                     # sorted by (scaffold, position) ...
+    assert np.sort(rows, order=order).tobytes() == exp.tobytes()           # ... and the same rows as the host sort
+    rg = d_rg[:n_rows].cpu().numpy()
+    first = np.searchsorted(c["gaps"]["scaffold"], rows["src_scaffold"])   # gaps are grouped by scaffold
+    assert np.array_equal(rg, first + rows["src_gap"] - 1)
+    got_l = np.sort(np.frombuffer(d_l[:n_l * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT), order=["rec", "gap", "kind"])
+    assert _same(got_l, gf.tag_low_mapq(recs, rows.copy())) and n_l > 0
+    # pool keys of the second-hop hits: through the device row->gap array == through the host table
+    assert L.gf_pool_keys_reset(h, cp + 16) == 0 and L.gf_pool_keys_reset(h, cp + 20) == 0
+    assert L.gf_pool_keys_from_second_hop_dev(h, d_recs.data_ptr(), d_l.data_ptr(), cp + 12, cap, d_rg.data_ptr(), d_keys[0].data_ptr(), cap, cp + 16) == 0
+    rows_c = rows.copy()
+    assert L.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_l.data_ptr(), cp + 12, cap, B._p(rows_c), len(rows_c), d_keys[1].data_ptr(), cap, cp + 20) == 0
+    gf.sync()
+    cnt = d_cnt.cpu().numpy()
+    assert int(cnt[4]) == int(cnt[5]) == n_l
+    assert np.array_equal(np.sort(d_keys[0][:n_l].cpu().numpy()), np.sort(d_keys[1][:n_l].cpu().numpy()))
+    # a table that does not fit: the count says so
+    assert L.gf_second_hop_table_dev(h, d_recs.data_ptr(), d_t.data_ptr(), cp, cap, d_rows.data_ptr(), d_rg.data_ptr(), 16, cp + 8) == 0
+    gf.sync()
+    assert int(d_cnt[2]) == n_rows > 16
