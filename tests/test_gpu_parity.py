@@ -572,3 +572,31 @@ def test_device_second_hop_table_equals_the_host_sort(gf):
     assert L.gf_second_hop_table_dev(h, d_recs.data_ptr(), d_t.data_ptr(), cp, cap, d_rows.data_ptr(), d_rg.data_ptr(), 16, cp + 8) == 0
     gf.sync()
     assert int(d_cnt[2]) == n_rows > 16
+
+
+def test_device_second_hop_table_without_discordant_hits(gf):
+    """No DISCORDANT hit at all: the table is empty and the second hop finds nothing (and does not fault)."""
+    import torch
+    from gappadder_amd import _lib as B
+    c = S.small_case(seed=54, n_pairs=2000)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    recs = c["recs"].copy()
+    recs["mate_ref"] = recs["ref"]
+    recs["tlen"] = 300                       # every pair concordant
+    dev = torch.device("cuda:0")
+    d_recs = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy()).to(dev)
+    n, cap, row_cap = len(recs), 1 << 14, 256
+    bufs = [torch.zeros(cap * 12, dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_low = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+    d_rows = torch.zeros(row_cap * 16, dtype=torch.uint8, device=dev)
+    d_rg = torch.zeros(row_cap, dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(8, dtype=torch.int32, device=dev)
+    L, h, cp = B.lib(), gf.handle, d_cnt.data_ptr()
+    assert L.gf_tag_alignments_low_dev(h, d_recs.data_ptr(), n, 300, 30, 250, 30, bufs[0].data_ptr(), cap, cp, d_low.data_ptr(), n, cp + 4) == 0
+    assert L.gf_second_hop_table_dev(h, d_recs.data_ptr(), bufs[0].data_ptr(), cp, cap, d_rows.data_ptr(), d_rg.data_ptr(), row_cap, cp + 8) == 0
+    assert L.gf_tag_low_mapq_table_dev(h, d_low.data_ptr(), cp + 4, n, d_rows.data_ptr(), cp + 8, row_cap, bufs[1].data_ptr(), cap, cp + 12) == 0
+    gf.sync()
+    cnt = d_cnt.cpu().numpy()
+    th = np.frombuffer(bufs[0][:int(cnt[0]) * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
+    assert not (th["kind"] == B.KIND_DISCORDANT).any() and int(cnt[1]) > 0
+    assert int(cnt[2]) == 0 and int(cnt[3]) == 0
