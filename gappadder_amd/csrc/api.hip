@@ -182,7 +182,11 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         ctx->index.clear();
         return GF_OK;
     }
-    if (!strcmp(name, "screen_np_override")) { ctx->screen_np_override = (int)value; return GF_OK; }
+    if (!strcmp(name, "screen_np_override")) {   // timing experiments only (fewer probes = wrong hits): refused unless asked for
+        if (!getenv("GF_DIAGNOSTICS")) return GF_E_UNSUPPORTED;
+        ctx->screen_np_override = (int)value;
+        return GF_OK;
+    }
     if (!strcmp(name, "screen_verify_batch")) { ctx->screen_verify_batch = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_verify_ext")) { ctx->screen_verify_ext = value != 0; return GF_OK; }
     if (!strcmp(name, "screen_verify_gate")) { ctx->screen_verify_gate = value != 0; return GF_OK; }

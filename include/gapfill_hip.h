@@ -98,7 +98,7 @@ int gf_stream_wait(gf_ctx* waiter, gf_ctx* producer);
  * "bitmap_log2" (size of the screen's level-1 16-mer bitmap, 0 = automatic).
  * Ablation / diagnostic switches (results never change): "screen_variant" (0 automatic, 9 plain, 12 wave, 13 pipelined, 14 partitioned
  * filter kernel), "screen_verify_ext" (1: seed-and-extend verification when min_hits == 1), "screen_verify_gate",
- * "screen_verify_batch", "screen_stream_policy", "screen_lds_log2_max", "screen_np_override" (timing only: WRONG results),
+ * "screen_verify_batch", "screen_stream_policy", "screen_lds_log2_max", "screen_np_override" (timing experiments: fewer probes, WRONG hits; refused unless the environment has GF_DIAGNOSTICS set),
  * "asm_keyslot", "asm_lds_pool_kb", "asm_dbg_ptr". */
 int gf_set_option(gf_ctx* ctx, const char* name, long value);
 

@@ -2,6 +2,7 @@
  (a) torch copy of 1.9 GB (reads 1.9 GB), (b) the screen filter with probes disabled (np override 0: the same 16-B/lane
  tile stream as the real kernel, reads exactly n_reads * 38 B), (c) the real filter."""
 import os, sys
+os.environ.setdefault("GF_DIAGNOSTICS", "1")   # allows the screen_np_override timing knob
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gappadder_amd import _lib as B

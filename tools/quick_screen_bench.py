@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("GF_DIAGNOSTICS", "1")
 """Scratch measurement: screen filter kernel on uniform-random packed reads resident in HBM (not the bench)."""
 import ctypes as C
 import sys, os, time
