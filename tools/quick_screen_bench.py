@@ -1,8 +1,7 @@
-import os
-os.environ.setdefault("GF_DIAGNOSTICS", "1")
 """Scratch measurement: screen filter kernel on uniform-random packed reads resident in HBM (not the bench)."""
 import ctypes as C
 import sys, os, time
+os.environ.setdefault("GF_DIAGNOSTICS", "1")   # allows the screen_np_override timing knob
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
