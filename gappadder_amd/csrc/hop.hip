@@ -11,7 +11,8 @@
 
 namespace gf {
 
-__global__ __launch_bounds__(256) void hop_fill_kernel(unsigned long long* keys, uint32_t n, unsigned long long v) {
+__global__ __launch_bounds__(256) void hop_fill_kernel(unsigned long long* keys, uint32_t n, unsigned long long v, uint32_t* n_rows) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_rows = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[i] = v;
 }
 
@@ -62,8 +63,9 @@ __global__ __launch_bounds__(256) void hop_rows_kernel(const unsigned long long*
 // sorted rows -> upos (unique (scaffold, position) in order), urow (first row of each, + n at the end), soff (offsets of the
 // scaffolds into upos).  One workgroup: the table has 1e3..1e5 rows.
 __global__ __launch_bounds__(1024) void hop_table_kernel(const gf_dpos* rows, const uint32_t* n_rows, uint32_t row_cap, uint32_t n_scaffolds,
-                                                         uint32_t* upos, uint32_t* urow, uint32_t* soff) {
+                                                         uint32_t* upos, uint32_t* urow, uint32_t* soff, uint32_t* n_out) {
     __shared__ uint32_t part[1024];
+    if (threadIdx.x == 0) *n_out = 0;   // the hit counter of the look-up that follows
     __shared__ uint32_t s_total;
     const uint32_t tid = threadIdx.x;
     const uint32_t n = *n_rows < row_cap ? *n_rows : row_cap;
@@ -98,8 +100,9 @@ __global__ __launch_bounds__(1024) void hop_table_kernel(const gf_dpos* rows, co
     }
 }
 
+// tagger.hip; *d_n_out must be zero already
 int launch_low_mapq_devtable(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const uint32_t* upos, const uint32_t* urow,
-                             const uint32_t* soff, void* d_out, size_t cap, void* d_n_out);   // tagger.hip
+                             const uint32_t* soff, void* d_out, size_t cap, void* d_n_out);
 
 }  // namespace gf
 
@@ -130,9 +133,9 @@ int gf_second_hop_table_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghi
     uint32_t* v_out = (uint32_t*)(w + 2 * b_k + b_v);
     void* temp = w + 2 * b_k + 2 * b_v;
     LaunchTimer tm(ctx, GF_KERNEL_LOWMAPQ);
-    GF_HIP(ctx, hipMemsetAsync(d_n_rows, 0, 4, ctx->stream));
     const unsigned grid = (unsigned)std::min<size_t>((row_cap + 255) / 256, (size_t)ctx->n_cu * 4);
-    hipLaunchKernelGGL(hop_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, k_in, (uint32_t)row_cap, (unsigned long long)ctx->n_scaffolds << 32);
+    hipLaunchKernelGGL(hop_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, k_in, (uint32_t)row_cap, (unsigned long long)ctx->n_scaffolds << 32,
+                       (uint32_t*)d_n_rows);
     hipLaunchKernelGGL(hop_extract_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_alnrec*)d_recs, (const gf_taghit*)d_taghits,
                        (const uint32_t*)d_n_taghits, (uint32_t)hit_cap, ctx->n_scaffolds, k_in, v_in, (uint32_t)row_cap, (uint32_t*)d_n_rows);
     if (rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, row_cap, 0, end_bit, ctx->stream) != hipSuccess) return GF_E_NODEV;
@@ -160,7 +163,7 @@ int gf_tag_low_mapq_table_dev(gf_ctx* ctx, const void* d_low, const void* d_n_lo
     {
         LaunchTimer tm(ctx, GF_KERNEL_LOWMAPQ);
         hipLaunchKernelGGL(hop_table_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const gf_dpos*)d_rows, (const uint32_t*)d_n_rows, (uint32_t)row_cap,
-                           ctx->n_scaffolds, upos, urow, soff);
+                           ctx->n_scaffolds, upos, urow, soff, (uint32_t*)d_n_out);
     }
     return launch_low_mapq_devtable(ctx, d_low, d_n_low, low_cap, upos, urow, soff, d_out, cap, d_n_out);
 }

@@ -530,8 +530,7 @@ int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* ta
 // second hop over the compacted MAPQ-0 list with look-up arrays that already live on the device (hop.hip builds them)
 int launch_low_mapq_devtable(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const uint32_t* upos, const uint32_t* urow,
                              const uint32_t* soff, void* d_out, size_t cap, void* d_n_out) {
-    GF_HIP(ctx, hipMemsetAsync(d_n_out, 0, 4, ctx->stream));
-    LowParams P;
+    LowParams P;   // *d_n_out was zeroed by the kernel that built the look-up arrays
     P.recs = nullptr;
     P.n = 0;
     P.low = (const gf_lowrec*)d_low;
