@@ -172,6 +172,12 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         ctx->index.clear();
         return GF_OK;
     }
+    if (!strcmp(name, "index_host")) {   // takes effect for indexes built afterwards
+        ctx->index_host = value != 0;
+        for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
+        ctx->index.clear();
+        return GF_OK;
+    }
     if (!strcmp(name, "screen_variant")) { ctx->screen_variant = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_dbg_ptr")) { ctx->asm_dbg = (void*)(uintptr_t)value; return GF_OK; }
     if (!strcmp(name, "asm_keyslot")) { ctx->asm_keyslot = value != 0; return GF_OK; }

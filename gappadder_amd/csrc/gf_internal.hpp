@@ -79,6 +79,7 @@ struct gf_ctx {
     std::map<int, gf::FlankIndex> index;  // by k
     uint32_t max_gaps_per_kmer = 0;     // 0 = unlimited
     int bitmap_log2_override = 0;
+    int index_host = 0;         // 1: build the flank index on the host (comparator of the device builder)
     int screen_variant = 0;     // filter kernel: 0 automatic, 9 plain, 12 wave, 13 pipelined (ablation)
     int screen_verify_batch = 64;  // verify kernel: candidates per wave and pass
     int screen_verify_ext = 1;   // min_hits == 1 without repeat mask: seed-and-extend verification instead of the k-mer table
@@ -150,6 +151,7 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out);
 void free_flank_index(gf_ctx* ctx, FlankIndex& ix);
 
 // screen.hip
+int build_flank_index_dev(gf_ctx* ctx, int k, FlankIndex& ix);   // index_dev.hip
 int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const void* d_nmask, size_t n_reads,
                   int read_len, int min_hits, void* d_out, size_t cap, void* d_n_out);
 // tagger.hip

@@ -1,6 +1,6 @@
-// index.hip — host-side construction of the flank k-mer index (canonical k-mer extract/hash of the flanking
-// contigs, north_star) and its upload.  Flank sequences are tiny (2 x 295 bp per gap: gnrt_pos_true_seqs.py:94-99),
-// so this runs on the host once per k; the read side is what the GPU streams.
+// index.hip — the flank k-mer index: cache per k, and the HOST construction of it (std::sort + upload).  The product builds the
+// index on the device (index_dev.hip); this host builder is kept as its comparator (option "index_host" = 1,
+// tests/test_gpu_parity.py::test_device_built_flank_index_equals_the_host_built_one) — 4.6 s for the human-scale layout.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -97,6 +97,17 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
         ctx->index.erase(it);
     }
     if (k < 16 || k > 64) return GF_E_UNSUPPORTED;
+    if (!ctx->index_host) {   // the product path: built on the device (index_dev.hip); what follows is the host comparator
+        FlankIndex dev;
+        const int rc = build_flank_index_dev(ctx, k, dev);
+        if (rc) {
+            free_flank_index(ctx, dev);
+            return rc;
+        }
+        auto ins = ctx->index.emplace(k, dev);
+        *out = &ins.first->second;
+        return GF_OK;
+    }
 
     std::vector<Entry> ent;
     std::vector<uint32_t> s16;

@@ -600,3 +600,40 @@ def test_device_second_hop_table_without_discordant_hits(gf):
     th = np.frombuffer(bufs[0][:int(cnt[0]) * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
     assert not (th["kind"] == B.KIND_DISCORDANT).any() and int(cnt[1]) > 0
     assert int(cnt[2]) == 0 and int(cnt[3]) == 0
+
+
+def test_device_built_flank_index_equals_the_host_built_one(gf):
+    """The flank index is built on the device (csrc/index_dev.hip: extraction kernel, rocPRIM sorts, CAS-claimed tables); the host
+    builder (option index_host = 1: std::sort + upload) is its comparator.  Same hits in every regime the index serves: k from 16
+    to 64, min_hits > 1 (k-mer table) and == 1 (occurrence lists), the repeat mask, flanks with N, shorter than k, or empty,
+    duplicated flanks — and both equal the oracle."""
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=61, n_pairs=6000)
+    L = c["L"]
+    flanks = [list(f) for f in c["flanks"]]
+    flanks[1][0] = flanks[0][0]                                        # two gaps share a flank (k-mers with two gaps)
+    flanks[2][1] = flanks[2][1][:100] + "N" + flanks[2][1][101:200] + "nnn" + flanks[2][1][203:]   # non-ACGT bytes split the runs
+    flanks[3][0] = flanks[3][0][:20]                                   # shorter than every k > 20
+    flanks[4][1] = ""                                                  # empty flank
+    flanks[5][0] = "ACGT" * 80                                         # low complexity: the same k-mer many times in one flank
+    flanks = [tuple(f) for f in flanks]
+    packed, _ = GapFill.pack_reads(c["reads_blob"], L)
+    plan = [(16, 1, 0), (31, 1, 0), (32, 1, 0), (33, 1, 0), (51, 1, 0), (64, 1, 0), (31, 3, 0), (41, 2, 0), (31, 1, 1), (31, 2, 2)]
+    got = {}
+    try:
+        for host in (1, 0):
+            gf.set_option("index_host", host)
+            for k, mh, mg in plan:
+                gf.set_option("max_gaps_per_kmer", mg)
+                gf.set_gaps(c["gaps"], c["n_scaffolds"], flanks)
+                got[(host, k, mh, mg)] = gf.screen_reads(packed, L, k, mh)
+    finally:
+        gf.set_option("index_host", 0)
+        gf.set_option("max_gaps_per_kmer", 0)
+    total = 0
+    for k, mh, mg in plan:
+        a, b = got[(1, k, mh, mg)], got[(0, k, mh, mg)]
+        assert _same(a, b), (k, mh, mg)
+        assert _same(b, CO.screen_reads(c["reads_blob"], L, flanks, k, mh, mg)), (k, mh, mg)
+        total += len(b)
+    assert total > 2000
