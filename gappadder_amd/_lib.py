@@ -66,6 +66,8 @@ def lib():
         "gf_fastq_pack": (i32, [vp, C.c_char_p, sz, i32, vp, sz, vp, vp, szp, C.POINTER(C.c_uint32)]),
         "gf_sam_pack": (i32, [vp, C.c_char_p, sz, C.c_char_p, vp, sz, vp, sz, vp, szp]),
         "gf_bgzf_inflate": (i32, [vp, C.c_char_p, sz, C.c_char_p, sz, vp, sz, szp, szp]),
+        "gf_tag_alignments_bam": (i32, [vp, i32, i32, i32, i32, vp, sz, szp]),
+        "gf_tag_low_mapq_bam": (i32, [vp, vp, sz, vp, sz, szp]),
         "gf_bam_fetch": (i32, [vp, vp, vp, sz, vp, sz, szp]),
         "gf_bam_pack": (i32, [vp, vp, sz, sz, vp, sz, vp, sz, vp, szp, szp]),
         "gf_fastq_pack_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp, vp, vp]),

@@ -54,6 +54,7 @@ class BamCols:
         self.s, self.rb, self.names, self.gf = stream, np.asarray(rec_begin, dtype=np.uint64), ref_names, gf
         self.end = int(stream_end if stream_end is not None else (len(stream) if stream is not None else 0))
         self.cache = {}
+        self.on_device = stream is None   # the decoded records are still on the GPU too (gf.tag_alignments_bam)
 
     def __len__(self):
         return len(self.rb)

@@ -37,7 +37,10 @@ class GapReadsCollector:
         """Tag one batch of decoded records (gf.set_gaps done); lines are appended to `out` in record order, so successive
         batches of one coordinate-sorted file (bam_io.decode_file) give the lists of one pass over it."""
         import numpy as np
-        hits = gf.tag_alignments(recs, self.insert_size, self.derivation, self.dist_clip, anchor_mapq)
+        if getattr(cols, "on_device", False):   # builtin BAM mode: the records are on the GPU already
+            hits = gf.tag_alignments_bam(len(recs), self.insert_size, self.derivation, self.dist_clip, anchor_mapq)
+        else:
+            hits = gf.tag_alignments(recs, self.insert_size, self.derivation, self.dist_clip, anchor_mapq)
         with_gaps = set(int(g) for g in gaps["scaffold"])
         # the reference opens the pair of files at the first record of a scaffold (:93-102)
         _, first = np.unique(recs["ref"], return_index=True)

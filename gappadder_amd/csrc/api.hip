@@ -62,18 +62,20 @@ static bool taghit_less(const gf_taghit& a, const gf_taghit& b) {
     return a.kind < b.kind;
 }
 
+// recs on the host (staged to HBM here) or, with d_src, already on the device (the records gf_bam_pack left there)
 template <typename F>
-static int tag_host(gf_ctx* ctx, const gf_alnrec* recs, size_t n, gf_taghit* out, size_t cap, size_t* n_out, F launch) {
-    if (!ctx || !n_out || (n && !recs) || (cap && !out)) return GF_E_INVAL;
+static int tag_host(gf_ctx* ctx, const gf_alnrec* recs, size_t n, gf_taghit* out, size_t cap, size_t* n_out, F launch,
+                    const void* d_src = nullptr) {
+    if (!ctx || !n_out || (n && !recs && !d_src) || (cap && !out)) return GF_E_INVAL;
     *n_out = 0;
     GF_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ensure(ctx, ctx->stage_in, n * sizeof(gf_alnrec) + 64))) return rc;
+    if (!d_src && (rc = ensure(ctx, ctx->stage_in, n * sizeof(gf_alnrec) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->stage_out, cap * sizeof(gf_taghit) + 64))) return rc;
     uint32_t* d_n = (uint32_t*)((uint8_t*)ctx->stage_out.p + cap * sizeof(gf_taghit));
     d_n = (uint32_t*)(((uintptr_t)d_n + 15) & ~(uintptr_t)15);
-    if (n) GF_HIP(ctx, hipMemcpyAsync(ctx->stage_in.p, recs, n * sizeof(gf_alnrec), hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = launch(ctx->stage_in.p, ctx->stage_out.p, d_n))) return rc;
+    if (n && !d_src) GF_HIP(ctx, hipMemcpyAsync(ctx->stage_in.p, recs, n * sizeof(gf_alnrec), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch(d_src ? const_cast<void*>(d_src) : ctx->stage_in.p, ctx->stage_out.p, d_n))) return rc;
     uint32_t cnt = 0;
     GF_HIP(ctx, hipMemcpyAsync(&cnt, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -128,7 +130,7 @@ void gf_destroy(gf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
-    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->binmap, &ctx->binmap_fine, &ctx->bam_stream, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->rowgap, &ctx->pool_ws, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->binmap, &ctx->binmap_fine, &ctx->bam_stream, &ctx->bam_recs, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->rowgap, &ctx->pool_ws, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
         if (b->p) (void)hipFree(b->p);
     if (ctx->d_gaps) (void)hipFree(ctx->d_gaps);
     if (ctx->d_scaf_off) (void)hipFree(ctx->d_scaf_off);
@@ -328,6 +330,23 @@ int gf_tag_alignments(gf_ctx* ctx, const gf_alnrec* recs, size_t n, int insert_s
     return tag_host(ctx, recs, n, out, cap, n_out, [&](void* d_in, void* d_out, void* d_n) {
         return launch_tag(ctx, d_in, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n, nullptr, 0, nullptr);
     });
+}
+
+int gf_tag_alignments_bam(gf_ctx* ctx, int insert_size, int sd, int clip_dist, int anchor_mapq, gf_taghit* out, size_t cap, size_t* n_out) {
+    if (!ctx || !ctx->bam_recs.p) return ctx ? GF_E_STATE : GF_E_INVAL;
+    const size_t n = ctx->bam_n_recs;
+    return tag_host(ctx, nullptr, n, out, cap, n_out, [&](void* d_in, void* d_out, void* d_n) {
+        return launch_tag(ctx, d_in, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n, nullptr, 0, nullptr);
+    }, ctx->bam_recs.p);
+}
+
+int gf_tag_low_mapq_bam(gf_ctx* ctx, const gf_dpos* table, size_t n_rows, gf_taghit* out, size_t cap, size_t* n_out) {
+    if (!ctx || !ctx->bam_recs.p) return ctx ? GF_E_STATE : GF_E_INVAL;
+    if (n_rows && !table) return GF_E_INVAL;
+    const size_t n = ctx->bam_n_recs;
+    return tag_host(ctx, nullptr, n, out, cap, n_out, [&](void* d_in, void* d_out, void* d_n) {
+        return launch_low_mapq(ctx, d_in, n, table, n_rows, d_out, cap, d_n, nullptr, nullptr, 0);
+    }, ctx->bam_recs.p);
 }
 
 int gf_tag_low_mapq_dev(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* table, size_t n_rows, void* d_out,

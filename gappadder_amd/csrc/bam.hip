@@ -638,16 +638,19 @@ int gf_bam_pack(gf_ctx* ctx, const uint8_t* stream_or_null, size_t n_bytes, size
     }
     *n_recs = (size_t)total;
     *n_consumed = (size_t)(last_exit & ~BAM_TAIL);
+    ctx->bam_n_recs = 0;
     if (total > cap_recs) return GF_E_NOSPACE;
     if (total) {
+        // the records also stay on the device (bam_recs) for gf_tag_alignments_bam / gf_tag_low_mapq_bam
         const size_t b_rec = (total * sizeof(gf_alnrec) + 63) & ~(size_t)63, b_rb = rec_begin_or_null ? (total * 8 + 63) & ~(size_t)63 : 0;
-        if ((rc = ensure(ctx, ctx->stage_out, b_rec + b_rb))) return rc;
-        gf_alnrec* d_recs = (gf_alnrec*)ctx->stage_out.p;
-        unsigned long long* d_rb = rec_begin_or_null ? (unsigned long long*)((uint8_t*)ctx->stage_out.p + b_rec) : nullptr;
+        if ((rc = ensure(ctx, ctx->bam_recs, b_rec + b_rb))) return rc;
+        gf_alnrec* d_recs = (gf_alnrec*)ctx->bam_recs.p;
+        unsigned long long* d_rb = rec_begin_or_null ? (unsigned long long*)((uint8_t*)ctx->bam_recs.p + b_rec) : nullptr;
         hipLaunchKernelGGL(bam_emit_kernel, dim3(grid), dim3(256), 0, ctx->stream, B, n_seg, d_guess, d_off, d_map, d_recs, d_rb, (uint64_t)total);
         GF_HIP(ctx, hipMemcpyAsync(recs, d_recs, total * sizeof(gf_alnrec), hipMemcpyDeviceToHost, ctx->stream));
         if (rec_begin_or_null) GF_HIP(ctx, hipMemcpyAsync(rec_begin_or_null, d_rb, total * 8, hipMemcpyDeviceToHost, ctx->stream));
         GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->bam_n_recs = (size_t)total;
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;

@@ -174,6 +174,21 @@ class GapFill:
         self._chk(rc, "gf_tag_alignments")
         return out
 
+    def tag_alignments_bam(self, n_recs, insert_size, sd, clip_dist=250, anchor_mapq=30, cap=None):
+        """tag_alignments on the records the last bam_pack left on the GPU (n_recs of them: sizes the first output buffer)."""
+        rc, out = self._grow(lambda o, c, cnt: self._L.gf_tag_alignments_bam(self._h, insert_size, sd, clip_dist, anchor_mapq,
+                                                                              B._p(o), c, C.byref(cnt)),
+                             B.TAGHIT, cap if cap is not None else max(1024, n_recs // 8))
+        self._chk(rc, "gf_tag_alignments_bam")
+        return out
+
+    def tag_low_mapq_bam(self, n_recs, table, cap=None):
+        table = np.ascontiguousarray(table, dtype=B.DPOS)
+        rc, out = self._grow(lambda o, c, cnt: self._L.gf_tag_low_mapq_bam(self._h, B._p(table), len(table), B._p(o), c, C.byref(cnt)),
+                             B.TAGHIT, cap if cap is not None else max(1024, n_recs // 8))
+        self._chk(rc, "gf_tag_low_mapq_bam")
+        return out
+
     def tag_low_mapq(self, recs, table, cap=None):
         recs = np.ascontiguousarray(recs, dtype=B.ALNREC)
         table = np.ascontiguousarray(table, dtype=B.DPOS)

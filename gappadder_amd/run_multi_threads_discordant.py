@@ -91,7 +91,7 @@ class DiscordantReadsCollector:
                     res.setdefault(int(r), {"left": [], "right": []})
             if not len(rows):
                 continue
-            hits = gf.tag_low_mapq(recs, rows)
+            hits = gf.tag_low_mapq_bam(len(recs), rows) if cols.on_device else gf.tag_low_mapq(recs, rows)
             cols.prefetch(hits["rec"])
             for h in hits:
                 f = cols[h["rec"]]

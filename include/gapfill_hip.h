@@ -157,6 +157,11 @@ int gf_bgzf_inflate(gf_ctx* ctx, const uint8_t* bgzf, size_t n_bytes, const uint
 int gf_bam_pack(gf_ctx* ctx, const uint8_t* stream_or_null, size_t n_bytes, size_t first, const uint32_t* ref_map, size_t n_ref,
                 gf_alnrec* recs, size_t cap_recs, uint64_t* rec_begin_or_null, size_t* n_recs, size_t* n_consumed);
 
+/* gf_tag_alignments / gf_tag_low_mapq on the records the last gf_bam_pack left on the device (no second trip of the 32-byte
+ * records over PCIe); GF_E_STATE when there are none. */
+int gf_tag_alignments_bam(gf_ctx* ctx, int insert_size, int sd, int clip_dist, int anchor_mapq, gf_taghit* out, size_t cap,
+                          size_t* n_out);
+int gf_tag_low_mapq_bam(gf_ctx* ctx, const gf_dpos* table, size_t n_rows, gf_taghit* out, size_t cap, size_t* n_out);
 /* Slices [begin[i], end[i]) of the inflated stream that gf_bgzf_inflate / gf_bam_pack left on the device, packed back to back
  * into dst (one small gather + one copy): the host asks for the header and for the few records that produced a hit instead of
  * copying every inflated byte back.  *n_bytes = total size; GF_E_NOSPACE when cap is smaller. */

@@ -163,3 +163,27 @@ def test_bam_pack_from_host_bytes_and_argument_errors(gf):
     with pytest.raises(B.GapFillError) as e:
         gf.bam_fetch([0], [len(stream) + 1])
     assert e.value.code == B.GF_E_INVAL
+
+
+def test_tagging_the_records_left_on_the_gpu_equals_tagging_a_host_copy(gf):
+    """gf_tag_alignments_bam / gf_tag_low_mapq_bam (records stay in HBM after gf_bam_pack) == the host-array variants."""
+    from gappadder_amd import _lib as B, bam_io, sam_io
+    from golden_util import CASES, Case
+    import records_util as RU
+    case = Case(CASES[0])
+    lib = case.libs[0]
+    lines = [l for l in lib["sam"].splitlines() if l and l[0] != "@"]
+    from oracle import gp_oracle as O
+    names = list(case.fai_names)
+    gaps = RU.gaps_array(names, O.gap_positions(case.fasta_records(), case.meta["min_gap"]))
+    stream = U.sam_to_bam_stream(lines, names, [10 ** 6] * len(names))
+    _, first = bam_io.parse_header(stream)
+    gf.set_gaps(gaps, len(names))
+    recs, _, _ = gf.bam_pack(stream, first, np.arange(len(names), dtype=np.uint32))
+    a = gf.tag_alignments(recs, int(lib["is"]), int(lib["sd"]))
+    b = gf.tag_alignments_bam(len(recs), int(lib["is"]), int(lib["sd"]))
+    assert len(a) > 50 and a.tobytes() == b.tobytes()
+    rows = sorted((int(recs[h["rec"]]["mate_ref"]), int(recs[h["rec"]]["mate_pos"]), int(gaps[h["gap"]]["scaffold"]),
+                   int(gaps[h["gap"]]["idx_in_scaffold"])) for h in a if h["kind"] == B.KIND_DISCORDANT)
+    table = RU.dpos_array(rows).astype(B.DPOS)
+    assert gf.tag_low_mapq(recs, table).tobytes() == gf.tag_low_mapq_bam(len(recs), table).tobytes()
