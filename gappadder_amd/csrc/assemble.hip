@@ -379,27 +379,25 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 // runs per thread; 59 vs 48 us per gap, the phase is bound by the dependent LDS table accesses.)
                 const uint32_t dr = ASM_THREADS / npos, dp = ASM_THREADS - dr * npos;
                 uint32_t r = tid / npos, p = tid - r * npos;
-                for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS, r += dr, p += dp) {
-                    if (LDS && s_cnt[6]) break;
-                    if (p >= npos) { p -= npos; ++r; }
-                    const uint32_t inst = r * P.read_len + p;
-                    const unsigned long long fw = pv_kmer_at<false>(V, r, p, k).hi;
+                // the k-mer at (read rr, offset pp), or valid = false when the N mask covers it
+                auto kmer_of = [&](uint32_t rr, uint32_t pp, bool& valid) -> unsigned long long {
+                    const unsigned long long fw = pv_kmer_at<false>(V, rr, pp, k).hi;
                     const unsigned long long rc = revcomp_w<false>(K128{fw, 0}, k).hi;
+                    valid = true;
                     if (P.nmask) {
-                        bool bad = false;
-                        for (uint32_t q = p; q < p + P.k; ++q)
-                            if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
-                        if (bad) continue;
+                        for (uint32_t q = pp; q < pp + P.k; ++q)
+                            if ((P.nmask[(r0 + rr) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { valid = false; break; }
                     }
-                    K128 key;
-                    key.hi = fw < rc ? fw : rc;
-                    key.lo = 0;
-                    uint32_t sl = slot_of(key, t.cap);
+                    return fw < rc ? fw : rc;
+                };
+                // insert / count one k-mer; v = the slot's content as loaded by the caller (may be stale: every decision below is
+                // confirmed by a CAS, whose result replaces it)
+                auto upsert = [&](unsigned long long keyhi, uint32_t sl, unsigned long long v, uint32_t inst) {
                     bool placed = false;
                     for (uint32_t probes = 0; probes < t.cap; ++probes) {
-                        unsigned long long v = t.load(sl);
+                        if (probes) v = t.load(sl);
                         if (v == kempty) {
-                            v = t.cas(sl, kempty, (key.hi | 1ull) ^ xm);
+                            v = t.cas(sl, kempty, (keyhi | 1ull) ^ xm);
                             if (v == kempty) {   // first occurrence
                                 const uint32_t q = atomicAdd(&s_cnt[4], 1u);
                                 if (q >= limit) s_cnt[6] = 1;
@@ -408,7 +406,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                                 break;
                             }
                         }
-                        if (((v ^ xm) & ~3ull) == key.hi) {
+                        if (((v ^ xm) & ~3ull) == keyhi) {
                             while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment
                                 const unsigned long long o = t.cas(sl, v, ((v ^ xm) + 1) ^ xm);
                                 if (o == v) break;
@@ -420,6 +418,30 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         sl = sl + 1 == t.cap ? 0 : sl + 1;
                     }
                     if (!placed) { if (LDS) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_KTABLE); }
+                };
+                // KU k-mers per thread and round: their first probes are in flight together (the phase is bound by the latency of
+                // its dependent table accesses, not by their number)
+                constexpr int KU = 2;   // four measured 36.0 vs 37.3 us per gap but spills registers
+                for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += KU * ASM_THREADS) {
+                    if (LDS && s_cnt[6]) break;
+                    unsigned long long kk[KU], vv[KU];
+                    uint32_t ss[KU], ii[KU];
+                    bool ok[KU];
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) {
+                        if (p >= npos) { p -= npos; ++r; }
+                        ok[u] = false;
+                        kk[u] = 0;
+                        if (inst_i + u * ASM_THREADS < n_inst) kk[u] = kmer_of(r, p, ok[u]);
+                        ii[u] = r * P.read_len + p;
+                        ss[u] = slot_of(K128{kk[u], 0}, t.cap);
+                        r += dr; p += dp;
+                    }
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) vv[u] = t.load(ss[u]);
+#pragma unroll
+                    for (int u = 0; u < KU; ++u)
+                        if (ok[u]) upsert(kk[u], ss[u], vv[u], ii[u]);
                 }
                 };
                 if (use_lds) count_keyslot(std::true_type{}); else count_keyslot(std::false_type{});
