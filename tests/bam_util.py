@@ -23,7 +23,8 @@ BGZF_EOF = bgzf_block(b"")
 
 def bgzf_compress(data, block=0xFF00, seed=None, levels=(6,), eof=True):
     """block: bytes of input per BGZF block (seed given: random sizes in [1, block]); levels are cycled per block: 0 = stored
-    DEFLATE blocks, 'fixed' = fixed Huffman code, 1..9 = zlib levels (dynamic codes)."""
+    DEFLATE blocks, 'fixed' = fixed Huffman code, 'huffman' / 'rle' = zlib's Z_HUFFMAN_ONLY / Z_RLE strategies, 1..9 = zlib
+    levels (dynamic codes)."""
     rng = random.Random(seed)
     out, p, i = [], 0, 0
     while p < len(data):
@@ -32,6 +33,11 @@ def bgzf_compress(data, block=0xFF00, seed=None, levels=(6,), eof=True):
         chunk = data[p:p + n]
         if lv == "fixed":
             out.append(bgzf_block(chunk, 6, zlib.Z_FIXED))
+        elif lv == "huffman":      # Huffman coding only: no matches, long literal codes
+            out.append(bgzf_block(chunk[:40000], 6, zlib.Z_HUFFMAN_ONLY))
+            chunk = chunk[:40000]
+        elif lv == "rle":          # matches of distance 1 only
+            out.append(bgzf_block(chunk, 6, zlib.Z_RLE))
         else:
             if lv == 0 and len(chunk) > 65000:   # stored blocks add 5 bytes per 64 KiB - keep the BGZF block under 64 KiB
                 chunk = chunk[:65000]

@@ -19,6 +19,7 @@ def gf():
 
 def _payloads():
     rng = np.random.RandomState(7)
+    skew = bytes(np.minimum(255, rng.geometric(0.03, 150_000)).astype(np.uint8))   # skewed byte histogram: code lengths up to 15
     dna = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.randint(0, 4, 300_000)])
     text = b"".join(b"read%d\t%d\tchr%d\t%d\t60\t150M\t=\n" % (i, 99 + (i & 64), i % 23, i * 37) for i in range(20000))
     return {
@@ -29,10 +30,11 @@ def _payloads():
         "text": text,
         "runs": b"A" * 70000 + b"ab" * 40000 + b"xyz" * 30000 + bytes(1000),    # matches with distance 1, 2, 3 (< length)
         "far": dna[:32768] + dna[:32768] + dna[100:20000],                      # matches at the maximum distance
+        "skew": skew,
     }
 
 
-@pytest.mark.parametrize("levels", [(6,), (1,), (9,), (0,), ("fixed",), (0, 6, "fixed", 9, 1)])
+@pytest.mark.parametrize("levels", [(6,), (1,), (9,), (0,), ("fixed",), ("huffman",), ("rle",), (0, 6, "fixed", 9, 1, "huffman", "rle")])
 def test_bgzf_inflate_equals_zlib(gf, levels):
     for name, data in _payloads().items():
         for block, seed in ((0xFF00, None), (20000, 11), (700, 5)):
