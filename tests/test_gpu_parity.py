@@ -92,6 +92,14 @@ def test_screen_and_tagger_synthetic(gf, seed, n_pairs, L, k):
     hits = gf.screen_reads(packed, L, k)
     exp = CO.screen_reads(c["reads_blob"], L, c["flanks"], k)
     assert _same(hits, exp) and len(exp) > 100
+    if L <= 250:      # the partitioned filter (packed reads up to 64 bytes) on the same reads, with a 2^27-bit bitmap
+        gf.set_option("screen_variant", 14)
+        gf.set_option("bitmap_log2", 27)
+        try:
+            assert _same(gf.screen_reads(packed, L, k), exp)
+        finally:
+            gf.set_option("screen_variant", 0)
+            gf.set_option("bitmap_log2", 0)
     for (IS, sd) in ((max(300, L + 100), 30), (5000, 500)):
         th = gf.tag_alignments(c["recs"], IS, sd)
         assert _same(th, CO.tag_alignments(c["recs"], c["gaps"], IS, sd))
