@@ -645,3 +645,23 @@ def test_device_built_flank_index_equals_the_host_built_one(gf):
         assert _same(b, CO.screen_reads(c["reads_blob"], L, flanks, k, mh, mg)), (k, mh, mg)
         total += len(b)
     assert total > 2000
+
+
+def test_flank_index_degenerate_inputs(gf):
+    """No gaps, flanks without a single k-mer (all N, empty, lower case only), and homopolymer flanks: the device-built index
+    must not fault and must agree with the oracle."""
+    from gappadder_amd import _lib as B
+    packed = np.zeros((1000, 38), dtype=np.uint8)            # 1000 poly-A reads
+    blob = b"A" * (1000 * 150)
+    gf.set_gaps(np.zeros(0, dtype=B.GAP), 1, [])
+    assert len(gf.screen_reads(packed, 150, 31)) == 0
+    g = np.zeros(3, dtype=B.GAP)
+    g["start"], g["end"], g["idx_in_scaffold"] = [100, 1000, 5000], [200, 1100, 5100], [1, 2, 3]
+    flanks = [("N" * 300, "ACGT"), ("", ""), ("acgt" * 10, "NNNN")]
+    gf.set_gaps(g, 1, flanks)
+    assert len(gf.screen_reads(packed, 150, 31)) == 0 and len(gf.screen_reads(packed, 150, 64, 2)) == 0
+    flanks = [("A" * 300, "C" * 300), ("G" * 100, "T" * 100), ("ACGT" * 50, "A" * 40)]
+    gf.set_gaps(g, 1, flanks)
+    for k, mh in ((31, 1), (40, 1), (31, 5)):
+        assert _same(gf.screen_reads(packed, 150, k, mh, cap=4096), CO.screen_reads(blob, 150, flanks, k, mh))
+    assert len(gf.screen_reads(packed, 150, 31, cap=4096)) == 3000
