@@ -174,7 +174,8 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         ctx->index.clear();
         return GF_OK;
     }
-    if (!strcmp(name, "index_host")) {   // takes effect for indexes built afterwards
+    if (!strcmp(name, "index_host")) {   // test comparator (host-built index), never chosen automatically; takes effect for
+        if (value && !getenv("GF_DIAGNOSTICS")) return GF_E_UNSUPPORTED;   // indexes built afterwards
         ctx->index_host = value != 0;
         for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
         ctx->index.clear();

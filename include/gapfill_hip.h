@@ -96,7 +96,8 @@ int gf_sync(gf_ctx* ctx);
 int gf_stream_wait(gf_ctx* waiter, gf_ctx* producer);
 /* options: "max_gaps_per_kmer" (0 = unlimited; flank k-mers shared by more gaps are dropped from the index),
  * "bitmap_log2" (size of the screen's level-1 16-mer bitmap, 0 = automatic), "index_host" (1: build the flank k-mer index with
- * the host comparator instead of the device kernels; same index up to slot order).
+ * the host comparator instead of the device kernels — same index up to slot order; a test aid, refused unless the environment
+ * has GF_DIAGNOSTICS set).
  * Ablation / diagnostic switches (results never change): "screen_variant" (0 automatic, 9 plain, 12 wave, 13 pipelined, 14 partitioned
  * filter kernel), "screen_verify_ext" (1: seed-and-extend verification when min_hits == 1), "screen_verify_gate",
  * "screen_verify_batch", "screen_stream_policy", "screen_lds_log2_max", "screen_np_override" (timing experiments: fewer probes, WRONG hits; refused unless the environment has GF_DIAGNOSTICS set),

@@ -1,5 +1,7 @@
 """GPU parity tests proper: the HIP path, called through the C ABI, against the oracle and the reference-generated
 golden fixtures.  Bit-exact (integer / index work)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -626,6 +628,7 @@ def test_device_built_flank_index_equals_the_host_built_one(gf):
     flanks[5][0] = "ACGT" * 80                                         # low complexity: the same k-mer many times in one flank
     flanks = [tuple(f) for f in flanks]
     packed, _ = GapFill.pack_reads(c["reads_blob"], L)
+    os.environ["GF_DIAGNOSTICS"] = "1"                                 # the host builder is a test aid behind this switch
     plan = [(16, 1, 0), (31, 1, 0), (32, 1, 0), (33, 1, 0), (51, 1, 0), (64, 1, 0), (31, 3, 0), (41, 2, 0), (31, 1, 1), (31, 2, 2)]
     got = {}
     try:
@@ -638,6 +641,7 @@ def test_device_built_flank_index_equals_the_host_built_one(gf):
     finally:
         gf.set_option("index_host", 0)
         gf.set_option("max_gaps_per_kmer", 0)
+        del os.environ["GF_DIAGNOSTICS"]
     total = 0
     for k, mh, mg in plan:
         a, b = got[(1, k, mh, mg)], got[(0, k, mh, mg)]
