@@ -189,3 +189,33 @@ def test_tagging_the_records_left_on_the_gpu_equals_tagging_a_host_copy(gf):
                    int(gaps[h["gap"]]["idx_in_scaffold"])) for h in a if h["kind"] == B.KIND_DISCORDANT)
     table = RU.dpos_array(rows).astype(B.DPOS)
     assert gf.tag_low_mapq(recs, table).tobytes() == gf.tag_low_mapq_bam(len(recs), table).tobytes()
+
+
+def test_bgzf_inflate_fuzz(gf):
+    """40 seeded random payloads (mixtures of noise, runs, periodic text, sparse bytes) x random block sizes and DEFLATE
+    flavours: inflated on the GPU == zlib."""
+    kinds = [6, 1, 9, 0, "fixed", "huffman", "rle"]
+    for seed in range(40):
+        rng = np.random.RandomState(1000 + seed)
+        parts = []
+        for _ in range(rng.randint(1, 12)):
+            n = int(rng.randint(1, 60000))
+            t = rng.randint(5)
+            if t == 0:
+                parts.append(bytes(rng.randint(0, 256, n, dtype=np.uint8)))
+            elif t == 1:
+                parts.append(bytes([int(rng.randint(256))]) * n)
+            elif t == 2:
+                w = bytes(rng.randint(65, 91, int(rng.randint(1, 300)), dtype=np.uint8))
+                parts.append((w * (n // len(w) + 1))[:n])
+            elif t == 3:
+                a = np.zeros(n, dtype=np.uint8)
+                a[rng.randint(0, n, max(1, n // 50))] = rng.randint(1, 256)
+                parts.append(bytes(a))
+            else:
+                parts.append(bytes(np.frombuffer(b"ACGTN", np.uint8)[rng.randint(0, 5, n)]))
+        data = b"".join(parts)
+        levels = tuple(kinds[i] for i in rng.randint(0, len(kinds), 5))
+        z = U.bgzf_compress(data, block=int(rng.randint(100, 0xFF00)), seed=seed, levels=levels, eof=bool(seed & 1))
+        out, used = gf.bgzf_inflate(z)
+        assert used == len(z) and out.tobytes() == data, (seed, levels)
