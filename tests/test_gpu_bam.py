@@ -219,3 +219,32 @@ def test_bgzf_inflate_fuzz(gf):
         z = U.bgzf_compress(data, block=int(rng.randint(100, 0xFF00)), seed=seed, levels=levels, eof=bool(seed & 1))
         out, used = gf.bgzf_inflate(z)
         assert used == len(z) and out.tobytes() == data, (seed, levels)
+
+
+def test_bam_chain_survives_records_that_contain_plausible_records(gf):
+    """The first record of a 64-KiB segment is GUESSED and then verified against the chain from the previous segment.  Here a
+    record's quality bytes are themselves 300 KB of well-formed BAM records (so every guess inside it locks onto fake records) —
+    the decoded chain must still be the true one."""
+    import struct
+    from gappadder_amd import bam_io
+    case, sam = next(_golden_sams())
+    lines = [l for l in sam.splitlines() if l and l[0] != "@"][:2500]
+    names = list(case.fai_names)
+    idx = {n: i for i, n in enumerate(names)}
+    real = [U.sam_record(l, idx) for l in lines]
+    decoy = b"".join(real[:1500])[:300_000]                  # valid records back to back, used as payload bytes
+    l_seq = len(decoy)
+    body = struct.pack("<iiBBHHHiiii", 0, 99, 6, 60, 4681, 1, 0, l_seq, -1, -1, 0) + b"decoy\0" + struct.pack("<I", (l_seq << 4) | 0)
+    body += bytes((l_seq + 1) // 2) + decoy                  # SEQ (all '='), then QUAL = the decoy records
+    big = struct.pack("<i", len(body)) + body
+    header = U.sam_to_bam_stream([], names, [10 ** 6] * len(names))
+    stream = header + b"".join(real[:700]) + big + b"".join(real[700:1900]) + big + b"".join(real[1900:])
+    _, first = bam_io.parse_header(stream)
+    true_rb, o = [], first
+    while o < len(stream):
+        true_rb.append(o)
+        o += 4 + struct.unpack_from("<i", stream, o)[0]
+    assert o == len(stream) and len(true_rb) == len(real) + 2
+    recs, rb, used = gf.bam_pack(stream, first, np.arange(len(names), dtype=np.uint32))
+    assert used == len(stream) and np.array_equal(rb, np.array(true_rb, dtype=np.uint64))
+    assert int(recs[700]["pos"]) == 100 and int(recs[700]["mapq"]) == 60 and int(recs[1901]["pos"]) == 100
