@@ -230,13 +230,19 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(uint32_t n_gaps, const
         const unsigned long long p0 = pool_off[g], p1 = pool_off[g + 1];
         const uint32_t n = (uint32_t)(p1 - p0);
         const uint32_t s0 = seg_off[g];
-        const uint64_t nbytes = (uint64_t)n * rb;
-        for (uint64_t i = threadIdx.x; i < nbytes; i += blockDim.x) {
-            const uint32_t j = (uint32_t)(i / rb), b = (uint32_t)(i - (uint64_t)j * rb);
+        // a read starts at read * rb in both arrays: 2-byte units when rb is even (L = 150: 19 units), bytes otherwise;
+        // (unit index) / (units per read) in 32 bits — a gap's pool is far below 4 GB
+        const uint32_t ur = (rb & 1) ? rb : rb / 2;
+        const uint64_t units64 = (uint64_t)n * ur;
+        const uint32_t units = units64 < 0xFFFFFFFFull ? (uint32_t)units64 : 0xFFFFFFFFu;
+        for (uint32_t i = threadIdx.x; i < units; i += blockDim.x) {
+            const uint32_t j = i / ur, b = i - j * ur;
             if (p0 + j >= pool_cap_reads) break;
             const uint32_t key = seg[s0 + j];
             const uint32_t read = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
-            if (read < n_reads) pool[(p0 + j) * rb + b] = reads[(uint64_t)read * rb + b];
+            if (read >= n_reads) continue;
+            if (rb & 1) pool[(p0 + j) * rb + b] = reads[(uint64_t)read * rb + b];
+            else reinterpret_cast<uint16_t*>(pool)[(p0 + j) * ur + b] = reinterpret_cast<const uint16_t*>(reads)[(uint64_t)read * ur + b];
         }
         if (pool_ids)
             for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
