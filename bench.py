@@ -162,12 +162,8 @@ def main():
                                            hit_cap, cp + 32)
         assert rc == 0, rc
         assert lib.gf_stream_wait(h, h2) == 0          # pools need the tagger's and the second hop's hits
-        assert lib.gf_pool_keys_reset(h, cp + 48) == 0
-        assert lib.gf_pool_keys_from_screen_dev(h, d_hits.data_ptr(), cp, hit_cap, 1, d_keys.data_ptr(), key_cap, cp + 48) == 0
-        assert lib.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_thits.data_ptr(), cp + 16, hit_cap, None, 0,
-                                              d_keys.data_ptr(), key_cap, cp + 48) == 0
-        assert lib.gf_pool_keys_from_second_hop_dev(h, d_recs.data_ptr(), d_lhits.data_ptr(), cp + 32, hit_cap, d_row_gap.data_ptr(),
-                                                    d_keys.data_ptr(), key_cap, cp + 48) == 0
+        assert lib.gf_pool_keys_all_dev(h, d_hits.data_ptr(), cp, hit_cap, 1, d_recs.data_ptr(), d_thits.data_ptr(), cp + 16, hit_cap,
+                                        d_lhits.data_ptr(), cp + 32, hit_cap, d_row_gap.data_ptr(), d_keys.data_ptr(), key_cap, cp + 48) == 0
         assert lib.gf_build_pools_dev(h, d_reads.data_ptr(), n_reads, L, d_keys.data_ptr(), cp + 48, key_cap, d_pool.data_ptr(),
                                       pool_cap, d_pool_off.data_ptr(), d_pool_ids.data_ptr(), cp + 96) == 0
         pool_ptr, off_ptr, pool_rows = d_pool.data_ptr(), d_pool_off.data_ptr(), pool_cap

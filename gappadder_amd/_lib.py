@@ -79,6 +79,7 @@ def lib():
         "gf_tag_low_mapq_dev": (i32, [vp, vp, sz, vp, sz, vp, sz, vp]),
         "gf_second_hop_table_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, sz, vp]),
         "gf_tag_low_mapq_table_dev": (i32, [vp, vp, vp, sz, vp, vp, sz, vp, sz, vp]),
+        "gf_pool_keys_all_dev": (i32, [vp, vp, vp, sz, i32, vp, vp, vp, sz, vp, vp, sz, vp, vp, sz, vp]),
         "gf_pool_keys_from_second_hop_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, sz, vp]),
         "gf_tag_alignments_low_dev": (i32, [vp, vp, sz, i32, i32, i32, i32, vp, sz, vp, vp, sz, vp]),
         "gf_tag_low_mapq_compact_dev": (i32, [vp, vp, vp, sz, vp, sz, vp, sz, vp]),

@@ -59,6 +59,34 @@ __global__ void keys_from_tags_kernel(const gf_alnrec* recs, const gf_taghit* hi
     }
 }
 
+// all three hit lists of one batch in one launch and without atomics: the counts are on the device, so every key has a fixed
+// place — screen hits (with their mates) first, then the tagger's, then the second hop's
+__global__ __launch_bounds__(256) void keys_all_kernel(const gf_hit* hits, const uint32_t* n_hits, uint32_t hit_cap, int pairs,
+                                                       const gf_alnrec* recs, const gf_taghit* thits, const uint32_t* n_thits, uint32_t thit_cap,
+                                                       const gf_taghit* lhits, const uint32_t* n_lhits, uint32_t lhit_cap, const uint32_t* row_gap,
+                                                       unsigned long long* keys, uint32_t key_cap, uint32_t* n_keys) {
+    const uint32_t per = pairs ? 2 : 1;
+    const uint32_t n1 = (*n_hits < hit_cap ? *n_hits : hit_cap), n2 = thits ? (*n_thits < thit_cap ? *n_thits : thit_cap) : 0,
+                   n3 = lhits ? (*n_lhits < lhit_cap ? *n_lhits : lhit_cap) : 0;
+    const uint64_t total = (uint64_t)n1 * per + n2 + n3;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_keys = total < 0xFFFFFFFFull ? (uint32_t)total : 0xFFFFFFFFu;   // > key_cap: truncated
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + (uint64_t)n2 + n3; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (i < n1) {
+            const gf_hit h = hits[i];
+            const uint64_t o = i * per;
+            if (o < key_cap) keys[o] = ((unsigned long long)h.gap << 32) | h.read;
+            if (pairs && o + 1 < key_cap) keys[o + 1] = ((unsigned long long)h.gap << 32) | (h.read ^ 1u);
+        } else {
+            const bool second = i >= (uint64_t)n1 + n2;
+            const gf_taghit h = second ? lhits[i - n1 - n2] : thits[i - n1];
+            const uint32_t read = (uint32_t)recs[h.rec].read ^ (h.to_mate ? 1u : 0u);
+            const uint32_t gap = second ? row_gap[h.gap] : h.gap;
+            const uint64_t o = (uint64_t)n1 * per + (i - n1);
+            if (o < key_cap) keys[o] = ((unsigned long long)gap << 32) | read;
+        }
+    }
+}
+
 // keys arrive in runs of equal gap (hits of neighbouring reads), so a plain atomicAdd per key hammers one address;
 // each wave first groups its lanes by gap: one atomic per distinct gap per wave
 __global__ void pool_hist_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap, uint32_t n_gaps,
@@ -318,6 +346,23 @@ int gf_pool_keys_from_second_hop_dev(gf_ctx* ctx, const void* d_recs, const void
     hipLaunchKernelGGL(keys_from_tags_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_alnrec*)d_recs,
                        (const gf_taghit*)d_taghits, (const uint32_t*)d_n_taghits, (uint32_t)hit_cap, (const uint32_t*)d_row_gap,
                        (unsigned long long*)d_keys, (uint32_t)key_cap, (uint32_t*)d_n_keys);
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_pool_keys_all_dev(gf_ctx* ctx, const void* d_hits, const void* d_n_hits, size_t hit_cap, int pairs, const void* d_recs,
+                         const void* d_taghits, const void* d_n_taghits, size_t taghit_cap, const void* d_hophits, const void* d_n_hophits,
+                         size_t hophit_cap, const void* d_row_gap, void* d_keys, size_t key_cap, void* d_n_keys) {
+    if (!ctx || !d_hits || !d_n_hits || !d_keys || !d_n_keys || hit_cap > 0xFFFFFFFFull || taghit_cap > 0xFFFFFFFFull ||
+        hophit_cap > 0xFFFFFFFFull || key_cap > 0xFFFFFFFFull || (d_taghits && (!d_n_taghits || !d_recs)) ||
+        (d_hophits && (!d_n_hophits || !d_recs || !d_row_gap)))
+        return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    LaunchTimer tm(ctx, GF_KERNEL_POOL);
+    hipLaunchKernelGGL(keys_all_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_hit*)d_hits, (const uint32_t*)d_n_hits,
+                       (uint32_t)hit_cap, pairs, (const gf_alnrec*)d_recs, (const gf_taghit*)d_taghits, (const uint32_t*)d_n_taghits,
+                       (uint32_t)taghit_cap, (const gf_taghit*)d_hophits, (const uint32_t*)d_n_hophits, (uint32_t)hophit_cap,
+                       (const uint32_t*)d_row_gap, (unsigned long long*)d_keys, (uint32_t)key_cap, (uint32_t*)d_n_keys);
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
 }

@@ -271,6 +271,13 @@ int gf_pool_keys_from_screen_dev(gf_ctx* ctx, const void* d_hits, const void* d_
 int gf_pool_keys_from_tags_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits,
                                size_t hit_cap, const gf_dpos* lowmapq_table_or_null, size_t n_rows, void* d_keys,
                                size_t key_cap, void* d_n_keys);
+/* the three producers above in ONE launch without atomics (the counts are device words, so every key has a fixed place: screen
+ * hits and their mates, then tagger hits, then second-hop hits); writes *d_n_keys = number of keys (no reset needed).
+ * d_taghits / d_hophits may be NULL. */
+int gf_pool_keys_all_dev(gf_ctx* ctx, const void* d_hits, const void* d_n_hits, size_t hit_cap, int pairs, const void* d_recs,
+                         const void* d_taghits, const void* d_n_taghits, size_t taghit_cap, const void* d_hophits,
+                         const void* d_n_hophits, size_t hophit_cap, const void* d_row_gap, void* d_keys, size_t key_cap,
+                         void* d_n_keys);
 /* second-hop hits against a device table: hit.gap (a row) resolves through d_row_gap (gf_second_hop_table_dev) */
 int gf_pool_keys_from_second_hop_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits,
                                      size_t hit_cap, const void* d_row_gap, void* d_keys, size_t key_cap, void* d_n_keys);

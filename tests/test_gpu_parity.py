@@ -578,6 +578,23 @@ def test_device_second_hop_table_equals_the_host_sort(gf):
     cnt = d_cnt.cpu().numpy()
     assert int(cnt[4]) == int(cnt[5]) == n_l
     assert np.array_equal(np.sort(d_keys[0][:n_l].cpu().numpy()), np.sort(d_keys[1][:n_l].cpu().numpy()))
+    # the three key producers in one launch (gf_pool_keys_all_dev): the same key multiset as the separate calls
+    d_hits = torch.zeros(cap * 8, dtype=torch.uint8, device=dev)
+    from gappadder_amd.hip_api import GapFill
+    packed, _ = GapFill.pack_reads(c["reads_blob"], c["L"])
+    d_reads = torch.from_numpy(np.ascontiguousarray(packed)).to(dev)
+    assert L.gf_screen_reads_dev(h, d_reads.data_ptr(), None, len(packed), c["L"], 31, 1, d_hits.data_ptr(), cap, cp + 24) == 0
+    d_k = torch.zeros(2, 4 * cap, dtype=torch.int64, device=dev)
+    assert L.gf_pool_keys_reset(h, cp + 28) == 0
+    assert L.gf_pool_keys_from_screen_dev(h, d_hits.data_ptr(), cp + 24, cap, 1, d_k[0].data_ptr(), 4 * cap, cp + 28) == 0
+    assert L.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_t.data_ptr(), cp, cap, None, 0, d_k[0].data_ptr(), 4 * cap, cp + 28) == 0
+    assert L.gf_pool_keys_from_second_hop_dev(h, d_recs.data_ptr(), d_l.data_ptr(), cp + 12, cap, d_rg.data_ptr(), d_k[0].data_ptr(), 4 * cap, cp + 28) == 0
+    assert L.gf_pool_keys_all_dev(h, d_hits.data_ptr(), cp + 24, cap, 1, d_recs.data_ptr(), d_t.data_ptr(), cp, cap, d_l.data_ptr(), cp + 12, cap,
+                                  d_rg.data_ptr(), d_k[1].data_ptr(), 4 * cap, cp + 32) == 0
+    gf.sync()
+    cnt = d_cnt.cpu().numpy()
+    assert int(cnt[7]) == int(cnt[8]) == 2 * int(cnt[6]) + n_t + n_l and int(cnt[6]) > 100
+    assert np.array_equal(np.sort(d_k[0][:int(cnt[7])].cpu().numpy()), np.sort(d_k[1][:int(cnt[8])].cpu().numpy()))
     # a table that does not fit: the count says so
     assert L.gf_second_hop_table_dev(h, d_recs.data_ptr(), d_t.data_ptr(), cp, cap, d_rows.data_ptr(), d_rg.data_ptr(), 16, cp + 8) == 0
     gf.sync()
