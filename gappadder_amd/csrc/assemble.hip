@@ -305,7 +305,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         V.g32 = P.reads32; V.g_words = P.n_words; V.g_tail = P.tail_bytes;
         V.first_byte = r0 * P.rb;
         const uint64_t pool_bytes = (uint64_t)n_r * P.rb;
-        V.lds = pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / 3;  // at most a third of the LDS
+        V.lds = pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / (W ? 2 : 3);  // at most a third of the LDS (half when the count table is global anyway)
         uint32_t pool_words = 0;
         if (V.lds) {
             const uint64_t w0 = V.first_byte >> 2;
