@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — reads screened/s (+ gaps/s) of the recruit + local-assembly hot path on MI355X.
+"""bench.py — reads screened/s + gaps closed/s of the recruit + local-assembly hot path on MI355X.
 
-A step = one pass of the hot path over one batch of the seeded synthetic workload (include/gf_synth.h),
-inputs already resident in HBM when the timed region starts.  Workload at every N: BASELINE.json configs[1]
-("C2": 1 000 gaps x 2 kb, 50 M 2x150-bp read records, k=31) PER GPU — gaps are replicated, reads sharded
-(rank r owns pairs [r*P, (r+1)*P)), no data-path collective; scaling = weak.
+A step = one pass of the hot path over the seeded synthetic workload (include/gf_synth.h), inputs resident in HBM when the
+timed region starts:   k-mer screen + alignment tagger + second hop  ->  per-gap pools (per library, merged in library order)
+                       ->  [N > 1: pools to the gap's owner rank, RCCL all-to-all]  ->  per-gap assembly, every (k, kv)
+                       ->  flank anchoring (which gaps are closed).
+Default workload = the configuration BASELINE.json quotes its metric on, configs[3] ("C4"): human-scale draft,
+19 840 gaps x 2 kb in 620 x 5 Mb scaffolds, 900 M 150-bp read records (+ 900 M alignment records), k=51 — all of it on ONE
+GPU at N=1 (63 GB resident).  At N > 1 the SAME reads are split over the ranks (rank r owns a contiguous range of pairs;
+scaling = strong), gaps and the flank index are replicated, and every gap is assembled exactly once, by its owner rank, from
+the recruits of all ranks (the reference maps each gap to one Pool task, assemble_gaps.py:296-299).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the screen
-filter; algorithmic bytes = ceil(2L/8) per read) and `cpu_baseline` (the oracle's C restatement —
-kind "port" — timed on the host cores on a bounded sample of the same workload; that sample is also checked
-bit-for-bit against the GPU's hits).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the screen filter; algorithmic bytes = ceil(2L/8) per read,
+SURVEY.md §8d) and `cpu_baseline` (the oracle's C restatement — kind "port" — on the host cores on a bounded sample of the
+same workload, also checked bit-for-bit against the GPU's results on that sample).  At N=1 the default run appends `extras`:
+the same step on C2 (configs[1]) and on C5 (configs[4]: + mate-pair library IS 5000, k in {31,41,51}), each in a child process.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,32 +35,44 @@ import torch
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
+# seed, scaffold_len, n_scaffolds, gaps_per_scaffold, gap_len, read records (whole job), [(k, kv)]
+PRESETS = {
+    "C2": (20260002, 5_000_000, 50, 20, 2000, 50_000_000, [(31, 29)]),
+    "C3": (20260003, 4_600_000, 1, 200, 1000, 5_000_000, [(41, 39)]),
+    "C4": (20260004, 5_000_000, 620, 32, 2000, 900_000_000, [(51, 49)]),
+    # C4's draft and short library + a mate-pair library (IS 5000 / sd 500 -> the tagger's long-IS branch,
+    # collect_reads_for_gaps.py:275-278) + the multi-k sweep; per-gap pools = both libraries in library order (merge_reads.py:43-51)
+    "C5": (20260004, 5_000_000, 620, 32, 2000, 900_000_000, [(31, 29), (41, 39), (51, 49)]),
+}
+MP_READS_DEFAULT = 100_000_000   # "extra 100 M records"
+
+
+class Lib:
+    """One read library (an `alignments[]` / `raw_reads[]` entry of the reference's JSON) resident on this rank."""
+    pass
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4"],
-                    help="BASELINE.json workload: C2 (default, the metric's configuration), C3 (E. coli scale, k=41), "
-                         "C4 (human scale, k=51; --reads is the PER-GPU shard of the 900 M reads)")
-    ap.add_argument("--reads", type=int, default=0, help="read records per GPU (default: C2 50 M, C3 5 M, C4 112.5 M)")
-    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--config", default="C4", choices=sorted(PRESETS),
+                    help="BASELINE.json workload: C4 (default: the metric's configuration, 900 M reads), C2, C3, C5 (C4 + mate pairs + multi-k)")
+    ap.add_argument("--reads", type=int, default=0, help="read records of the first library, WHOLE JOB (default: the config's)")
+    ap.add_argument("--mp-reads", type=int, default=-1, help="C5: read records of the mate-pair library, whole job (default 100 M)")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-human-scale", action="store_true",
-                    help="skip the extra C4-shard measurement that the default (N=1, C2) run appends as `human_scale_shard`")
-    ap.add_argument("--exchange", action="store_true",
-                    help="N > 1: all-to-all-v of the per-gap pools to one owner rank per gap before the assembly (off: every rank "
-                         "assembles the gaps from its own shard of the reads; the only collective is the final gather)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C5 child runs that the default N=1 run appends as `extras`")
+    ap.add_argument("--dump-contigs", default="", help="rank 0 writes the gathered contigs (sorted) of the last step to this JSON file")
     args = ap.parse_args()
-    args.reads_given = bool(args.reads)
+    default_workload = not args.reads and args.mp_reads < 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # GF_BENCH_BACKEND=gloo + GF_BENCH_ONE_GPU=1: smoke-test of the multi-rank code path with every rank on cuda:0
-    # (single-GPU boxes); the real runs use nccl (= RCCL) with one GPU per rank
+    # GF_BENCH_BACKEND=gloo + GF_BENCH_ONE_GPU=1: the multi-rank code path with every rank on cuda:0 (single-GPU boxes, the
+    # 2-rank GPU test); the real runs use nccl (= RCCL) with one GPU per rank
     backend = os.environ.get("GF_BENCH_BACKEND", "nccl")
     if os.environ.get("GF_BENCH_ONE_GPU"):
         local = 0
@@ -74,246 +92,381 @@ def main():
     from gappadder_amd import sharding as SH
     from gappadder_amd.hip_api import GapFill
 
-    presets = {   # (seed, scaffold_len, n_scaffolds, gaps_per_scaffold, gap_len, reads per GPU, k)
-        "C2": (20260002, 5_000_000, 50, 20, 2000, 50_000_000, 31),
-        "C3": (20260003, 4_600_000, 1, 200, 1000, 5_000_000, 41),
-        "C4": (20260004, 5_000_000, 620, 32, 2000, 112_500_000, 51),
-    }
-    seed, slen, nscf, gps, glen, dreads, dk = presets[args.config]
-    args.reads = args.reads or dreads
-    L, k = 150, (args.k or dk)
-    n_pairs = args.reads // 2
-    n_reads = 2 * n_pairs
-    cfg = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen,
-                            read_len=L, insert_mean=300, insert_sd=30)
-    gaps, flanks = GapFill.synth_layout(cfg)
-    gf = GapFill(local)
-    gf.set_gaps(gaps, int(cfg["n_scaffolds"][0]), flanks)
-    # second context = second HIP stream on the same device: the alignment tagger + second hop are independent of the k-mer
-    # screen until the pools are built, so they run beside the screen's verify pass
-    if os.environ.get("GF_VERIFY_BATCH"):
-        gf.set_option("screen_verify_batch", int(os.environ["GF_VERIFY_BATCH"]))
-    if os.environ.get("GF_BENCH_SERIAL"):     # diagnostic: tagger on the same stream, so every phase time is stand-alone
-        gf2 = gf
-    else:
-        gf2 = GapFill(local)
-        gf2.set_gaps(gaps, int(cfg["n_scaffolds"][0]), None)
+    seed, slen, nscf, gps, glen, dreads, kk = PRESETS[args.config]
+    total_reads = (args.reads or dreads) // 2 * 2
+    L = 150
+    lib_defs = [("short-insert", 300, 30, 0, total_reads)]
+    if args.config == "C5":
+        mp = MP_READS_DEFAULT if args.mp_reads < 0 else args.mp_reads
+        lib_defs.append(("mate-pair", 5000, 500, 1, mp // 2 * 2))
+    n_lib = len(lib_defs)
+
     lib = B.lib()
     rb = lib.gf_packed_read_bytes(L)
-
-    # ---- inputs resident in HBM (torch = device-memory plumbing) ----
-    d_reads = torch.empty(n_reads * rb + 64, dtype=torch.uint8, device=dev)
-    d_recs = torch.empty(n_reads * 32, dtype=torch.uint8, device=dev)
-    first_pair = rank * n_pairs
-    gf.synth_pairs_dev(cfg, first_pair, n_pairs, d_reads.data_ptr(), d_recs.data_ptr())
-    hit_cap = max(1 << 20, n_reads // 8)
-    d_hits = torch.empty(hit_cap * 8, dtype=torch.uint8, device=dev)
-    d_thits = torch.empty(hit_cap * 12, dtype=torch.uint8, device=dev)
-    d_lhits = torch.empty(hit_cap * 12, dtype=torch.uint8, device=dev)
-    low_cap = max(1 << 20, n_reads // 8)          # MAPQ==0 records compacted by the tagger pass (2 % of the records here)
-    d_low = torch.empty(low_cap * 12, dtype=torch.uint8, device=dev)
-    key_cap = 4 * hit_cap
-    d_keys = torch.empty(key_cap, dtype=torch.int64, device=dev)
-    pool_cap = max(1 << 20, n_reads // 32)    # pooled reads (also sizes the assembly workspace: ~6.5 KB per pooled read)
-    d_pool = torch.empty(pool_cap * rb + 64, dtype=torch.uint8, device=dev)
-    d_pool_off = torch.zeros(len(gaps) + 1, dtype=torch.int64, device=dev)
-    d_pool_ids = torch.empty(pool_cap, dtype=torch.int32, device=dev)
-    contig_cap, seq_cap = 256 * len(gaps) + 1024, 32768 * len(gaps) + (1 << 20)
-    d_ctg = torch.empty(contig_cap * 32, dtype=torch.uint8, device=dev)
-    d_seq = torch.empty(seq_cap, dtype=torch.uint8, device=dev)
-    d_gap_err = torch.zeros(len(gaps), dtype=torch.int32, device=dev)
-    # counters (device u32 unless noted): 0 screen hits, 4 tagger hits, 8 second-hop hits, 12 keys, 16 contigs,
-    # 20 (u64) contig bases, 24 pool-sort overflow, 28 MAPQ==0 records, 29 second-hop table rows
-    d_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
-    cp = d_cnt.data_ptr()
-    gf.sync()
-    kv = k - 2
+    gf = GapFill(local)
+    # second context = second HIP stream on the same device: the alignment tagger + second hop are independent of the k-mer
+    # screen until the pools are built
+    serial = bool(os.environ.get("GF_BENCH_SERIAL"))     # diagnostic: one stream, so every phase time is stand-alone
+    # (one per library: the tagger caches its coarse bin map per insert-size window)
+    gf2s = [gf if serial else GapFill(local) for _ in lib_defs]
+    stream = None
+    if world > 1:
+        # the collectives are ordered against the kernels by running everything on ONE torch side stream (not the legacy
+        # default stream): the library adopts it
+        stream = torch.cuda.Stream(device=dev)
+        assert lib.gf_set_stream(gf.handle, C.c_void_p(stream.cuda_stream)) == 0
     h = gf.handle
 
-    h2 = gf2.handle
+    cfg0 = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L,
+                             insert_mean=300, insert_sd=30)
+    gaps, flanks = GapFill.synth_layout(cfg0)
+    n_gaps = len(gaps)
+    gf.set_gaps(gaps, int(cfg0["n_scaffolds"][0]), flanks)
+    for g2 in gf2s:
+        if g2 is not gf:
+            g2.set_gaps(gaps, int(cfg0["n_scaffolds"][0]), None)
+    batch = SH.owner_batch(n_gaps, world)
 
-    def recruit():
-        assert lib.gf_stream_wait(h2, h) == 0          # the previous step's consumers of the tagger buffers are done
-        rc = lib.gf_screen_reads_dev(h, d_reads.data_ptr(), None, n_reads, L, k, 1, d_hits.data_ptr(), hit_cap, cp)
-        assert rc == 0, rc
-        rc = lib.gf_tag_alignments_low_dev(h2, d_recs.data_ptr(), n_reads, 300, 30, 250, 30, d_thits.data_ptr(), hit_cap, cp + 16,
-                                           d_low.data_ptr(), low_cap, cp + 112)
-        assert rc == 0, rc
-
-    # second-hop table (run_multi_threads_discordant.py:19-122 inverts the discordant lines and runs sort(1) on the host): built
-    # on the device from the tagger's hits INSIDE every step (gf_second_hop_table_dev); this untimed pass only sizes its buffers
-    recruit()
+    # ---- inputs resident in HBM (torch = device-memory plumbing) ----
+    libs = []
+    for name, is_mean, is_sd, lib_no, n_total in lib_defs:
+        lb = Lib()
+        lb.name, lb.is_mean, lb.is_sd = name, is_mean, is_sd
+        lb.h2 = gf2s[len(libs)].handle
+        lb.cfg = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L,
+                                   insert_mean=is_mean, insert_sd=is_sd, library=lib_no)
+        p0, p1 = SH.shard_range(n_total // 2, rank, world)          # strong scaling: the same pairs, split
+        lb.first_pair, lb.n_pairs, lb.n_reads, lb.n_total = p0, p1 - p0, 2 * (p1 - p0), n_total
+        lb.d_reads = torch.empty(lb.n_reads * rb + 64, dtype=torch.uint8, device=dev)
+        lb.d_recs = torch.empty(max(1, lb.n_reads) * 32, dtype=torch.uint8, device=dev)
+        gf.synth_pairs_dev(lb.cfg, lb.first_pair, lb.n_pairs, lb.d_reads.data_ptr(), lb.d_recs.data_ptr())
+        lb.hit_cap = max(1 << 20, lb.n_reads // 8)
+        lb.d_hits = torch.empty(lb.hit_cap * 8, dtype=torch.uint8, device=dev)
+        lb.d_thits = torch.empty(lb.hit_cap * 12, dtype=torch.uint8, device=dev)
+        lb.d_lhits = torch.empty(lb.hit_cap * 12, dtype=torch.uint8, device=dev)
+        lb.d_low = torch.empty(lb.hit_cap * 12, dtype=torch.uint8, device=dev)   # MAPQ==0 records compacted by the tagger (2 %)
+        lb.key_cap = 4 * lb.hit_cap
+        lb.d_keys = torch.empty(lb.key_cap, dtype=torch.int64, device=dev)
+        lb.d_pool_off = torch.zeros(n_gaps + 1, dtype=torch.int64, device=dev)
+        # counters (device u32): 0 screen hits, 4 tagger hits, 8 second-hop hits, 12 keys, 24 pool error, 28 MAPQ==0 records,
+        # 29 second-hop table rows
+        lb.d_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
+        lb.cp = lb.d_cnt.data_ptr()
+        libs.append(lb)
     gf.sync()
-    gf2.sync()
-    n_th = int(d_cnt[4])
-    th = np.frombuffer(d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
-    row_cap = 2 * int((th["kind"] == B.KIND_DISCORDANT).sum()) + 4096
-    d_rows = torch.empty(row_cap * 16, dtype=torch.uint8, device=dev)
-    d_row_gap = torch.empty(row_cap, dtype=torch.int32, device=dev)
+    gaps_n = n_gaps
 
-    exch_rows = [0]
+    # the reference recruits once, then assembles at every k (assemble_gaps.py:87-122): the screen runs at the SMALLEST k of the
+    # sweep — a read that shares a 51-mer with a flank shares its 31-mers too, so this is the superset every assembly k needs
+    k_screen = min(a for a, _ in kk)
+
+    def sync_all():
+        gf.sync()
+        for g2 in gf2s:
+            g2.sync()
+
+    def recruit(lb):
+        assert lib.gf_stream_wait(lb.h2, h) == 0          # the previous consumers of the tagger buffers are done
+        rc = lib.gf_screen_reads_dev(h, lb.d_reads.data_ptr(), None, lb.n_reads, L, k_screen, 1, lb.d_hits.data_ptr(), lb.hit_cap, lb.cp)
+        assert rc == 0, rc
+        rc = lib.gf_tag_alignments_low_dev(lb.h2, lb.d_recs.data_ptr(), lb.n_reads, lb.is_mean, lb.is_sd, 250, 30, lb.d_thits.data_ptr(),
+                                           lb.hit_cap, lb.cp + 16, lb.d_low.data_ptr(), lb.hit_cap, lb.cp + 112)
+        assert rc == 0, rc
+
+    # ---- sizing pass (untimed): second-hop table rows, pooled reads, exchange slots ----
+    for lb in libs:
+        recruit(lb)
+    sync_all()
+    for lb in libs:
+        n_th = int(lb.d_cnt[4])
+        assert n_th <= lb.hit_cap
+        th = np.frombuffer(lb.d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
+        lb.row_cap = 2 * int((th["kind"] == B.KIND_DISCORDANT).sum()) + 4096
+        lb.d_rows = torch.empty(lb.row_cap * 16, dtype=torch.uint8, device=dev)
+        lb.d_row_gap = torch.empty(lb.row_cap, dtype=torch.int32, device=dev)
+
+    def hop_and_keys(lb):
+        rc = lib.gf_second_hop_table_dev(lb.h2, lb.d_recs.data_ptr(), lb.d_thits.data_ptr(), lb.cp + 16, lb.hit_cap, lb.d_rows.data_ptr(),
+                                         lb.d_row_gap.data_ptr(), lb.row_cap, lb.cp + 116)
+        assert rc == 0, rc
+        rc = lib.gf_tag_low_mapq_table_dev(lb.h2, lb.d_low.data_ptr(), lb.cp + 112, lb.hit_cap, lb.d_rows.data_ptr(), lb.cp + 116, lb.row_cap,
+                                           lb.d_lhits.data_ptr(), lb.hit_cap, lb.cp + 32)
+        assert rc == 0, rc
+        assert lib.gf_stream_wait(h, lb.h2) == 0          # pools need the tagger's and the second hop's hits
+        assert lib.gf_pool_keys_all_dev(h, lb.d_hits.data_ptr(), lb.cp, lb.hit_cap, 1, lb.d_recs.data_ptr(), lb.d_thits.data_ptr(), lb.cp + 16,
+                                        lb.hit_cap, lb.d_lhits.data_ptr(), lb.cp + 32, lb.hit_cap, lb.d_row_gap.data_ptr(),
+                                        lb.d_keys.data_ptr(), lb.key_cap, lb.cp + 48) == 0
+
+    def build_pools(lb, pool_ptr, pool_cap):
+        assert lib.gf_build_pools_dev(h, lb.d_reads.data_ptr(), lb.n_reads, L, lb.d_keys.data_ptr(), lb.cp + 48, lb.key_cap, pool_ptr,
+                                      pool_cap, lb.d_pool_off.data_ptr(), None, lb.cp + 96) == 0
+
+    for lb in libs:
+        hop_and_keys(lb)
+        build_pools(lb, None, 0)        # offsets only
+    sync_all()
+    rows_lib = [int(lb.d_pool_off[-1]) for lb in libs]
+    lib_cap = max(4096, int(1.25 * max(rows_lib)) + 1024)            # rows of one library's pool array
+    # local pool arrays: [n_lib][lib_cap] rows (slot l = library l: the source layout of gf_pools_merge_dev)
+    d_pools = torch.empty(n_lib * lib_cap * rb + 64, dtype=torch.uint8, device=dev)
+    pool_ptr = [d_pools.data_ptr() + l * lib_cap * rb for l in range(n_lib)]
+    d_xerr = torch.zeros(4, dtype=torch.int32, device=dev)
+    d_libcnt = torch.zeros(n_lib * n_gaps, dtype=torch.int32, device=dev)         # [n_lib][n_gaps]
+    if world > 1:
+        owner = SH.gap_owner(n_gaps, world).to(dev)
+        per_dst = torch.zeros(n_lib, world, dtype=torch.int64, device=dev)
+        for l, lb in enumerate(libs):
+            cnt = (lb.d_pool_off[1:] - lb.d_pool_off[:-1])
+            per_dst[l].index_add_(0, owner, cnt)
+        mx = per_dst.max().to(coll_dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        slot_cap = max(1024, int(1.25 * int(mx)) + 256)
+        mine = per_dst[:, rank].sum().to(coll_dev)
+        recv_rows = mine.clone()
+        dist.all_reduce(recv_rows, op=dist.ReduceOp.SUM)    # upper bound of what any owner receives: every rank's rows for it
+        tot = torch.stack([per_dst[:, r].sum() for r in range(world)]).to(coll_dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        merged_cap = max(4096, int(1.25 * int(tot.max())) + 1024)
+        d_send = torch.empty(world * n_lib * slot_cap * rb, dtype=torch.uint8, device=dev)
+        d_recv = torch.empty(world * n_lib * slot_cap * rb, dtype=torch.uint8, device=dev)
+        d_allcnt = torch.zeros(world * n_lib * n_gaps, dtype=torch.int32, device=dev)
+    else:
+        slot_cap = lib_cap
+        merged_cap = max(4096, int(1.25 * sum(rows_lib)) + 1024)
+    need_merge = world > 1 or n_lib > 1
+    d_merged = torch.empty(merged_cap * rb + 64, dtype=torch.uint8, device=dev) if need_merge else None
+    d_moff = torch.zeros(n_gaps + 1, dtype=torch.int64, device=dev)
+    contig_cap, seq_cap = (64 * n_gaps + 4096) * len(kk), (24576 * n_gaps + (1 << 20)) * len(kk)
+    d_ctg = torch.empty(contig_cap * 32, dtype=torch.uint8, device=dev)
+    d_seq = torch.empty(seq_cap, dtype=torch.uint8, device=dev)
+    d_gap_err = torch.zeros(n_gaps, dtype=torch.int32, device=dev)
+    d_best = torch.zeros(n_gaps, dtype=torch.int64, device=dev)
+    # assembly counters: 0 contigs (u32), 2-3 contig bases (u64), 4 gaps closed (u32)
+    d_acnt = torch.zeros(8, dtype=torch.int32, device=dev)
+    ap_ = d_acnt.data_ptr()
+    k_arr = (C.c_int * len(kk))(*[a for a, _ in kk])
+    kv_arr = (C.c_int * len(kk))(*[b for _, b in kk])
 
     def step():
-        recruit()
-        rc = lib.gf_second_hop_table_dev(h2, d_recs.data_ptr(), d_thits.data_ptr(), cp + 16, hit_cap, d_rows.data_ptr(), d_row_gap.data_ptr(),
-                                         row_cap, cp + 116)
+        for lb in libs:
+            recruit(lb)
+        for l, lb in enumerate(libs):
+            hop_and_keys(lb)
+            build_pools(lb, pool_ptr[l], lib_cap)
+        # (zeroed through the library = on its stream; a torch op here would run on torch's stream)
+        assert lib.gf_memset_dev(h, d_xerr.data_ptr(), 0, 16) == 0 and lib.gf_memset_dev(h, d_best.data_ptr(), 0, 8 * n_gaps) == 0
+        assert lib.gf_memset_dev(h, ap_ + 16, 0, 16) == 0
+        if not need_merge:
+            asm_ptr, asm_off, asm_rows = pool_ptr[0], libs[0].d_pool_off.data_ptr(), lib_cap
+        elif world == 1:
+            for l, lb in enumerate(libs):
+                assert lib.gf_pool_counts_dev(h, lb.d_pool_off.data_ptr(), n_gaps, d_libcnt.data_ptr() + 4 * l * n_gaps) == 0
+            assert lib.gf_pools_merge_dev(h, d_pools.data_ptr(), lib_cap, d_libcnt.data_ptr(), n_lib, 1, n_gaps, L, 0, 1, batch,
+                                          d_merged.data_ptr(), merged_cap, d_moff.data_ptr(), d_xerr.data_ptr()) == 0
+            asm_ptr, asm_off, asm_rows = d_merged.data_ptr(), d_moff.data_ptr(), merged_cap
+        else:
+            # the one exchange step: rows regrouped by owner rank, counts all-gathered, slots all-to-all'ed
+            # (equal-sized slots: no host sizes, no host sync), owners merge in (library, source rank) order
+            for l, lb in enumerate(libs):
+                assert lib.gf_pools_pack_for_owners_dev(h, pool_ptr[l], lb.d_pool_off.data_ptr(), n_gaps, L, world, batch, l, n_lib,
+                                                        d_send.data_ptr(), slot_cap, d_libcnt.data_ptr() + 4 * l * n_gaps,
+                                                        d_xerr.data_ptr()) == 0
+            if backend == "nccl":
+                dist.all_gather_into_tensor(d_allcnt, d_libcnt)
+                dist.all_to_all_single(d_recv, d_send)
+            else:       # gloo smoke path: through host memory
+                a, s_ = d_allcnt.cpu(), d_send.cpu()
+                r_ = torch.empty_like(s_)
+                dist.all_gather_into_tensor(a, d_libcnt.cpu())
+                dist.all_to_all_single(r_, s_)
+                d_allcnt.copy_(a); d_recv.copy_(r_)
+            assert lib.gf_pools_merge_dev(h, d_recv.data_ptr(), slot_cap, d_allcnt.data_ptr(), n_lib, world, n_gaps, L, rank, world, batch,
+                                          d_merged.data_ptr(), merged_cap, d_moff.data_ptr(), d_xerr.data_ptr()) == 0
+            asm_ptr, asm_off, asm_rows = d_merged.data_ptr(), d_moff.data_ptr(), merged_cap
+        rc = lib.gf_assemble_multi_dev(h, asm_ptr, None, asm_off, n_gaps, asm_rows, L, k_arr, kv_arr, len(kk), 2, 40,
+                                       d_ctg.data_ptr(), contig_cap, ap_, d_seq.data_ptr(), seq_cap, ap_ + 8, d_gap_err.data_ptr())
         assert rc == 0, rc
-        rc = lib.gf_tag_low_mapq_table_dev(h2, d_low.data_ptr(), cp + 112, low_cap, d_rows.data_ptr(), cp + 116, row_cap, d_lhits.data_ptr(),
-                                           hit_cap, cp + 32)
-        assert rc == 0, rc
-        assert lib.gf_stream_wait(h, h2) == 0          # pools need the tagger's and the second hop's hits
-        assert lib.gf_pool_keys_all_dev(h, d_hits.data_ptr(), cp, hit_cap, 1, d_recs.data_ptr(), d_thits.data_ptr(), cp + 16, hit_cap,
-                                        d_lhits.data_ptr(), cp + 32, hit_cap, d_row_gap.data_ptr(), d_keys.data_ptr(), key_cap, cp + 48) == 0
-        assert lib.gf_build_pools_dev(h, d_reads.data_ptr(), n_reads, L, d_keys.data_ptr(), cp + 48, key_cap, d_pool.data_ptr(),
-                                      pool_cap, d_pool_off.data_ptr(), d_pool_ids.data_ptr(), cp + 96) == 0
-        pool_ptr, off_ptr, pool_rows = d_pool.data_ptr(), d_pool_off.data_ptr(), pool_cap
-        if args.exchange and world > 1:
-            # optional exchange step: every gap gets ONE owner that holds the recruits of all ranks, so the
-            # assembled gaps equal a single-process run over all reads; costs a host sync (row counts) + one all-to-all-v
-            gf.sync()
-            n_rows = int(d_pool_off[-1])
-            merged, moff = SH.exchange_pools(d_pool[:n_rows * rb].view(n_rows, rb), d_pool_off, coll_device=coll_dev)
-            torch.cuda.synchronize()
-            step.keep = (merged, moff)     # alive until the assembly kernel has run
-            exch_rows[0] = int(merged.shape[0])
-            pool_ptr, off_ptr, pool_rows = merged.data_ptr(), moff.data_ptr(), max(1, int(merged.shape[0]))
-        rc = lib.gf_assemble_dev(h, pool_ptr, None, off_ptr, len(gaps), pool_rows, L, k, kv, 2, 40,
-                                 d_ctg.data_ptr(), contig_cap, cp + 64, d_seq.data_ptr(), seq_cap, cp + 80, d_gap_err.data_ptr())
-        assert rc == 0, rc
+        # which gaps are closed: both flanks anchored on one contig (pick_contigs.py:64-358; scores 30 then 15, assemble_gaps.py:336, 365)
+        for a_len in (30, 15):
+            assert lib.gf_pick_anchored_dev(h, d_ctg.data_ptr(), ap_, contig_cap, d_seq.data_ptr(), a_len, d_best.data_ptr(), ap_ + 16) == 0
+
+    def run_steps(n):
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                for _ in range(n):
+                    step()
+        else:
+            for _ in range(n):
+                step()
 
     def barrier():
-        gf.sync()
-        gf2.sync()
+        sync_all()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
-    gf.timing(True)
-    gf2.timing(True)
+    [g_.timing(True) for g_ in {id(x): x for x in [gf] + gf2s}.values()]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    kt = {name: g_.kernel_time(idx) for name, idx, g_ in (("screen_filter", B.KERNEL_SCREEN, gf), ("screen_verify", B.KERNEL_VERIFY, gf),
-                                                          ("tag_alignments", B.KERNEL_TAG, gf2), ("tag_low_mapq", B.KERNEL_LOWMAPQ, gf2),
-                                                          ("pools", B.KERNEL_POOL, gf), ("assemble", B.KERNEL_ASSEMBLE, gf))}
-    t_filter, n_filter = kt["screen_filter"]
-    gf.timing(False)
-    gf2.timing(False)
+    ctxs = list({id(x): x for x in [gf] + gf2s}.values())
+
+    def ktime(idx):     # (total ms, launches) of one kernel group over all contexts
+        tt = [g_.kernel_time(idx) for g_ in ctxs]
+        return sum(t for t, _ in tt), sum(n for _, n in tt)
+    kt = {name: ktime(idx) for name, idx in (("screen_filter", B.KERNEL_SCREEN), ("screen_verify", B.KERNEL_VERIFY),
+                                             ("tag_alignments", B.KERNEL_TAG), ("tag_low_mapq", B.KERNEL_LOWMAPQ),
+                                             ("pools", B.KERNEL_POOL), ("assemble", B.KERNEL_ASSEMBLE), ("pick_anchored", B.KERNEL_PICK))}
+    [g_.timing(False) for g_ in {id(x): x for x in [gf] + gf2s}.values()]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    cnt = d_cnt.cpu().numpy()
-    n_hits, n_thits, n_lhits, n_keys, n_ctg = int(cnt[0]), int(cnt[4]), int(cnt[8]), int(cnt[12]), int(cnt[16])
-    n_seq = int(cnt[20:22].view(np.uint64)[0])
-    pool_off = d_pool_off.cpu().numpy()
-    assert int(cnt[28]) <= low_cap and int(cnt[29]) <= row_cap
-    assert int(cnt[24]) == 0 and int(d_gap_err.sum()) == 0 and pool_off[-1] <= pool_cap and n_ctg <= contig_cap and n_seq <= seq_cap
-    ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
-    if world > 1:
-        # the only collective of the path: gather the assembled sequences of every rank's shard on rank 0 (RCCL)
-        seq_local = d_seq[:n_seq].cpu().numpy().tobytes()
-        payload = SH.encode_contigs([(int(c["gap"]), int(c["k"]), int(c["kv"]), int(c["n_nodes"]), int(c["cov_sum"]),
-                                      seq_local[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode()) for c in ctg])
-        gathered = SH.gather_bytes(payload, dst=0, device=coll_dev)
-        if rank == 0:
-            assert len(gathered) == world and all(len(g) > 0 for g in gathered)
+    step_s = dt / args.steps
 
-    out = None
+    # ---- results of the last step ----
+    acnt = d_acnt.cpu().numpy()
+    n_ctg, n_seq, n_closed_local = int(acnt[0]), int(acnt[2:4].view(np.uint64)[0]), int(acnt[4])
+    xerr = int(d_xerr[0])
+    for lb in libs:
+        c = lb.d_cnt.cpu().numpy()
+        lb.counts = {"screen_hits": int(c[0]), "tagger_hits": int(c[4]), "second_hop_hits": int(c[8]), "pool_keys": int(c[12]),
+                     "pooled_reads": int(lb.d_pool_off[-1])}
+        assert int(c[0]) <= lb.hit_cap and int(c[4]) <= lb.hit_cap and int(c[8]) <= lb.hit_cap and int(c[12]) <= lb.key_cap
+        assert int(c[28]) <= lb.hit_cap and int(c[29]) <= lb.row_cap and int(c[24]) == 0, (int(c[24]), int(c[28]), int(c[29]))
+    assert xerr == 0 and int(d_gap_err.sum()) == 0 and n_ctg <= contig_cap and n_seq <= seq_cap, (xerr, int(d_gap_err.sum()), n_ctg, n_seq)
+    asm_off_t = d_moff if need_merge else libs[0].d_pool_off
+    asm_pool_t = d_merged if need_merge else d_pools
+    asm_rows_total = int(asm_off_t[-1])
+    ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
+    n_closed, n_ctg_all, gaps_with_contig = n_closed_local, n_ctg, int(len(np.unique(ctg["gap"])))
+    gather_ms = None
+    if world > 1:
+        red = torch.tensor([n_closed_local, n_ctg, gaps_with_contig, asm_rows_total], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        n_closed, n_ctg_all, gaps_with_contig, asm_rows_total = (int(x) for x in red)
+        # final gather on rank 0 (north_star: "RCCL over xGMI only for the final gather of closed sequences"): the picked contig
+        # of every closed gap — or every contig when --dump-contigs asks for the full comparison
+        tg = time.perf_counter()
+        seq_local = d_seq[:n_seq].cpu().numpy().tobytes()
+        best = d_best.cpu().numpy().view(np.uint64)
+        if args.dump_contigs:
+            sel = range(n_ctg)
+        else:
+            sel = [0x7FFFFFFF - int((int(b) >> 1) & 0x7FFFFFFF) for b in best if b]
+        payload = SH.encode_contigs([(int(ctg[i]["gap"]), int(ctg[i]["k"]), int(ctg[i]["kv"]), int(ctg[i]["n_nodes"]), int(ctg[i]["cov_sum"]),
+                                      seq_local[int(ctg[i]["seq_off"]):int(ctg[i]["seq_off"]) + int(ctg[i]["length"])].decode()) for i in sel])
+        gathered = SH.gather_bytes(payload, dst=0, device=coll_dev)
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        all_records = [r for part in (gathered or []) for r in SH.decode_contigs(part)]
+    else:
+        all_records = None
+    if args.dump_contigs and rank == 0:
+        if all_records is None:
+            seq_local = d_seq[:n_seq].cpu().numpy().tobytes()
+            all_records = [(int(c["gap"]), int(c["k"]), int(c["kv"]), int(c["n_nodes"]), int(c["cov_sum"]),
+                            seq_local[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode()) for c in ctg]
+        with open(args.dump_contigs, "w") as f:
+            json.dump({"contigs": sorted(all_records), "gaps_closed": n_closed}, f)
+
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        filt_ms = t_filter / max(1, n_filter)
-        achieved = n_reads * rb / (filt_ms * 1e-3) / 1e9
-        phases = {name: t / max(1, n_filter) for name, (t, _) in kt.items()}
-        gaps_with_contig = int(len(np.unique(ctg["gap"])))
-        # "closed" = a contig anchored by both flanks (gappadder_amd/pick_contigs.py, anchor 30 then 15 like the reference's two
-        # bwa scores); host-side, outside the timed region.  With one 300-bp library the recruited reads reach ~450 bp into a
-        # 2-kb gap from each side, so the reference's first round cannot close these gaps either.
-        from gappadder_amd.pick_contigs import pick_gap_sequence
-        seq_all = d_seq[:n_seq].cpu().numpy().tobytes().decode()
-        by_gap = {}
-        for c in ctg:
-            by_gap.setdefault(int(c["gap"]), []).append(("c", seq_all[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])]))
-        gaps_closed = sum(1 for g, cs in by_gap.items()
-                          if pick_gap_sequence(cs, flanks[g][0], flanks[g][1], 30) or pick_gap_sequence(cs, flanks[g][0], flanks[g][1], 15))
+        n_screened = sum(lb.n_total for lb in libs)
+        t_filter, n_filter = kt["screen_filter"]
+        filt_ms = t_filter / max(1, n_filter)                          # average launch of the filter (one launch per library and step)
+        reads_per_launch = sum(lb.n_reads for lb in libs) / len(libs)
+        achieved = reads_per_launch * rb / (filt_ms * 1e-3) / 1e9
+        phases = {name: t / args.steps for name, (t, _) in kt.items()}
+        k_s = k_screen
+        wl = ("%s: %d gaps x %d bp in %d x %.1f Mb scaffolds; %s; k/kv %s; step = k-mer screen (k=%d) + alignment tagger + second hop + per-gap "
+              "pools%s + per-gap assembly + flank anchoring" %
+              (args.config, n_gaps, glen, nscf, slen / 1e6,
+               " + ".join("%s library IS %d/%d: %d x %d-bp read records (+ as many 32-B alignment records)" % (lb.name, lb.is_mean, lb.is_sd, lb.n_total, L)
+                          for lb in libs),
+               ",".join("%d/%d" % p for p in kk), k_s,
+               " (libraries merged in library order)" if n_lib > 1 else ""))
         out = {
-            "metric": "reads_screened_per_s", "value": world * n_reads / (dt / args.steps), "unit": "reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: %d gaps x %d bp in %d x %.1f Mb scaffolds, %d x %d-bp read records (+ as many 32-B alignment "
-                                   "records) per GPU, k=%d kv=%d, IS 300/30; step = k-mer screen + alignment tagger + second hop + "
-                                   "per-gap pools + per-gap assembly" % (args.config, len(gaps), glen, nscf, slen / 1e6, n_reads, L, k, kv),
-                       "reads_per_gpu": n_reads, "gaps": int(len(gaps)), "k": k, "kv": kv,
-                       "sharding": ("reads sharded over ranks, gaps replicated; per-gap pools exchanged to one owner rank per gap (all-to-all-v), "
-                                    "then the assembled sequences gathered" if (args.exchange and world > 1) else
-                                    "reads sharded over ranks, gaps replicated; RCCL only gathers the assembled sequences")},
-            "gaps_per_s": world * len(gaps) / (dt / args.steps),
-            "gaps_closed_per_s": world * gaps_closed / (dt / args.steps),
-            "roofline": {"bound": "hbm", "kernel": "screen_filter (software-pipelined wave kernel with LDS pre-filter; the plain kernel when the key set is too large for it, as at C4)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n_reads, L, k),
-                         "algorithmic_bytes_per_launch": n_reads * rb, "avg_launch_ms": filt_ms,
+            "metric": "reads_screened_per_s", "value": n_screened / step_s, "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": wl, "reads_total": n_screened, "reads_per_gpu": sum(lb.n_reads for lb in libs), "gaps": n_gaps,
+                       "k_pairs": [list(p) for p in kk],
+                       "sharding": ("single GPU: all reads and all gaps on one device" if world == 1 else
+                                    "the same reads split over the ranks (contiguous pair ranges), gaps + flank index replicated; per-gap pools "
+                                    "sent to one owner rank per gap (batches of %d gaps round-robin; device pack + all-gather of counts + "
+                                    "equal-slot all-to-all + device merge, no host sync), every gap assembled once by its owner from all "
+                                    "ranks' recruits; final gather of the closed gaps' contigs on rank 0" % batch)},
+            "gaps_per_s": n_gaps / step_s,
+            "gaps_closed_per_s": n_closed / step_s,
+            "roofline": {"bound": "hbm",
+                         "kernel": "screen_filter (one launch group per library and step: the partitioned pf_scatter + pf_probe pair on key sets "
+                                   "beyond the LDS pre-filter as at C4/C5, the software-pipelined wave kernel otherwise)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.config, int(reads_per_launch), L, k_s),
+                         "algorithmic_bytes_per_launch": int(reads_per_launch * rb), "avg_launch_ms": filt_ms,
                          "frac_of_measured_copy_6290": achieved / 6290.0},
             "phases_ms": phases,
-            "phases_note": "HIP-event spans per kernel group; tagger + second hop run on a second stream beside the screen, so "
-                           "their spans include queueing behind the filter kernel (stand-alone: tagger 0.41 ms, verify 0.16 ms; GF_BENCH_SERIAL=1 runs everything on one stream)",
-            "tagger_gbs": n_reads * 32 / (phases["tag_alignments"] * 1e-3) / 1e9,
-            "counts": {"screen_hits": n_hits, "tagger_hits": n_thits, "second_hop_hits": n_lhits, "pool_keys": n_keys,
-                       "pooled_reads": int(pool_off[-1]), "contigs": n_ctg, "contig_bases": n_seq,
-                       "gaps_with_contig": gaps_with_contig, "gaps_closed": gaps_closed},
+            "phases_note": "HIP-event spans per kernel group, summed over the libraries, per step; tagger + second hop run on a second "
+                           "stream beside the screen, so their spans include queueing behind the filter (GF_BENCH_SERIAL=1: one stream)",
+            "counts": {"libraries": {lb.name: lb.counts for lb in libs}, "assembled_pool_reads": asm_rows_total, "contigs": n_ctg_all,
+                       "gaps_with_contig": gaps_with_contig, "gaps_closed": n_closed},
         }
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, d_pool, pool_off,
-                                               ctg, d_seq, n_seq, dt / args.steps, n_reads, B)
-        if world == 1 and args.config == "C2" and not args.no_cpu and not args.no_human_scale and not (args.reads_given or args.k):
-            out["human_scale_shard"] = human_scale_shard()
+        if gather_ms is not None:
+            out["final_gather_ms"] = gather_ms
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, libs, flanks, gaps, L, kk, asm_pool_t, asm_off_t, ctg, d_seq, n_seq, d_best, step_s,
+                                               n_screened, B, rb)
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_cpu and default_workload and args.config == "C4":
+        torch.cuda.empty_cache()
+        out["extras"] = {"C2": child_run(["--config", "C2", "--steps", "20", "--warmup", "2"]),
+                         "C5_mate_pair_multi_k": child_run(["--config", "C5", "--steps", "3", "--warmup", "1"])}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def human_scale_shard():
-    """BASELINE.json's metric names the 30x human-scale synthetic (configs[3], 8 GPUs).  The bench line is quoted on the largest
-    single-GPU configuration (C2); this adds one GPU's shard of the human-scale run (C4: 19 840 gaps, k=51, 112.5 M of the 900 M
-    read records — what every rank of the 8-GPU job processes) measured by the same code in a child process."""
-    import subprocess
+def child_run(argv):
+    """The same step on another BASELINE.json configuration, measured by the same code in a child process (never an exec of a
+    process that has touched the GPU)."""
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "C4", "--steps", "5", "--warmup", "2", "--no-cpu"],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu"] + argv, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
-        return {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "reads_per_s": d["value"], "gaps_per_s": d["gaps_per_s"],
-                "steps": d["steps"], "warmup": d["warmup"], "roofline_frac": d["roofline"]["frac"], "filter_ms": d["roofline"]["avg_launch_ms"],
-                "phases_ms": d["phases_ms"], "counts": d["counts"]}
-    except Exception as e:      # the headline line must not depend on this extra
-        return {"error": repr(e)[:200]}
+        return {key: d[key] for key in ("value", "ms_per_step", "steps", "warmup", "gaps_per_s", "gaps_closed_per_s", "phases_ms", "counts")} | \
+               {"workload": d["config"]["workload"], "roofline_frac": d["roofline"]["frac"], "filter_ms": d["roofline"]["avg_launch_ms"]}
+    except Exception as e:      # the headline line must not depend on an extra
+        return {"error": repr(e)[:300]}
 
 
-def pmc_traffic(n_reads, L, k):
-    """Bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json: rocprofv3 --pmc
+def pmc_traffic(config, reads_per_launch, L, k):
+    """Bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_traffic_<config>.json: rocprofv3 --pmc
     FETCH_SIZE and WRITE_SIZE in separate runs of this same command, gfx950 x2 correction applied to FETCH_SIZE).  Counters
-    cannot be collected from inside the timed run; null when no profile matches this configuration."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if t["reads_per_launch"] == n_reads and t["read_len"] == L and t["k"] == k:
-            return t["traffic_bytes_per_launch"]
-    except Exception:
-        pass
+    cannot be collected from inside the timed run; null when no committed profile matches this configuration."""
+    for name in ("r02_traffic_%s.json" % config.lower(), "r01_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if t["reads_per_launch"] == reads_per_launch and t["read_len"] == L and t["k"] == k:
+                return t["traffic_bytes_per_launch"]
+        except Exception:
+            pass
     return None
 
 
-def cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, d_pool, pool_off, ctg, d_seq, n_seq, gpu_step_s,
-                 n_reads, B):
+def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_seq, d_best, gpu_step_s, n_screened, B, rb):
     """The oracle (oracle/gp_oracle.c, OpenMP over all host cores; kind "port") on a bounded sample of the same step:
-    k-mer screen + alignment tagger on the first --cpu-sample-reads reads of rank 0's shard, and the assembly of the first
-    gaps' pools.  Also the checker: the GPU's hits on that prefix and its contigs for those gaps must equal the oracle's."""
+    k-mer screen + alignment tagger on the first --cpu-sample-reads reads of the first library, and the assembly of the first
+    gaps' pools at every (k, kv).  Also the checker: the GPU's hits on that prefix, its contigs for those gaps and its closed
+    flags must equal the oracle's / the host picker's."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle as CO
-    n_s = min(args.cpu_sample_reads, args.reads) // 2 * 2
+    from gappadder_amd.pick_contigs import pick_gap_sequence
+    lb = libs[0]
+    n_s = min(args.cpu_sample_reads, lb.n_reads) // 2 * 2
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # a cgroup CPU quota (cpu.max "quota period") caps the usable cores below the visible ones
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -321,43 +474,54 @@ def cpu_baseline(args, cfg, flanks, gaps, first_pair, L, k, kv, d_hits, n_hits, 
             cores = max(1, min(cores, int(q) // int(per)))
     except Exception:
         pass
-    ocfg = np.frombuffer(cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
+    ocfg = np.frombuffer(lb.cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
     CO.set_threads(cores)
-    packed, recs = CO.synth_pairs(ocfg, first_pair, n_s // 2)
+    packed, recs = CO.synth_pairs(ocfg, lb.first_pair, n_s // 2)
     blob = CO.unpack_reads(packed, L)
+    k_s = min(a for a, _ in kk)
     t0 = time.perf_counter()
-    ohits = CO.screen_reads(blob, L, flanks, k, 1, 0, cores)
+    ohits = CO.screen_reads(blob, L, flanks, k_s, 1, 0, cores)
     t1 = time.perf_counter()
-    CO.tag_alignments(recs, gaps, 300, 30)
+    CO.tag_alignments(recs, gaps, lb.is_mean, lb.is_sd)
     t2 = time.perf_counter()
-    hits = np.frombuffer(d_hits[:n_hits * 8].cpu().numpy().tobytes(), dtype=B.HIT)
+    n_hits = int(lb.d_cnt[0])
+    hits = np.frombuffer(lb.d_hits[:n_hits * 8].cpu().numpy().tobytes(), dtype=B.HIT)
     sub = np.sort(hits[hits["read"] < n_s], order=["gap", "read"])
     ok = len(sub) == len(ohits) and sub.tobytes() == ohits.astype(B.HIT).tobytes()
-    # assembly sample: the first gaps' pools exactly as the GPU built them
+    # assembly sample: the first gaps' pools exactly as the GPU assembled them (all libraries merged)
     n_g = min(len(gaps), 256)
-    rb = (L + 3) // 4
-    pool = d_pool[:int(pool_off[n_g]) * rb].cpu().numpy().reshape(-1, rb)
+    pool_off = off_t.cpu().numpy()
+    pool = pool_t[:int(pool_off[n_g]) * rb].cpu().numpy().reshape(-1, rb)
     pblob = CO.unpack_reads(pool, L)
     seq = d_seq[:n_seq].cpu().numpy().tobytes()
-    from concurrent.futures import ThreadPoolExecutor
     t3 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:   # gaps are independent (assemble_gaps.py:296-299 uses a process pool)
-        exp = list(ex.map(lambda g: CO.assemble_pool(pblob[int(pool_off[g]) * L:int(pool_off[g + 1]) * L], L, k, kv), range(n_g)))
+        exp = list(ex.map(lambda g: [CO.assemble_pool(pblob[int(pool_off[g]) * L:int(pool_off[g + 1]) * L], L, k, kv) for k, kv in kk], range(n_g)))
     t4 = time.perf_counter()
-    ok_asm = True
+    ok_asm, ok_pick = True, True
+    best = d_best.cpu().numpy().view(np.uint64)
     for g in range(n_g):
-        mine = sorted((seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode(), int(c["n_nodes"]), int(c["cov_sum"]))
-                      for c in ctg[ctg["gap"] == g])
-        ok_asm = ok_asm and mine == sorted(exp[g])
+        want = []
+        for (k, kv), e in zip(kk, exp[g]):
+            mine = sorted((seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode(), int(c["n_nodes"]), int(c["cov_sum"]))
+                          for c in ctg[(ctg["gap"] == g) & (ctg["k"] == k)])
+            ok_asm = ok_asm and mine == sorted(e)
+            want += [("c", s) for s, _, _ in e]
+        span = 0
+        for a_len in (30, 15):
+            r = pick_gap_sequence(want, flanks[g][0], flanks[g][1], a_len)
+            if r is not None:
+                span = max(span, len(r[1]))       # picked slice = span + 1 bases
+        ok_pick = ok_pick and span == (int(best[g]) >> 32)
     # whole-step CPU time extrapolated from the two samples (recruit scales with reads, assembly with gaps)
-    cpu_step = (t2 - t0) * (n_reads / n_s) + (t4 - t3) * (len(gaps) / n_g)
-    return {"value": n_reads / cpu_step, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "recruit: first %d reads of rank 0's shard (k-mer screen %.2f s + alignment tagger %.2f s, OpenMP %d threads); "
-                      "assembly: pools of the first %d gaps (%.2f s, same thread count); value = reads / (sample times scaled to the whole "
-                      "step); oracle/gp_oracle.c" % (n_s, t1 - t0, t2 - t1, cores, n_g, t4 - t3),
+    cpu_step = (t2 - t0) * (n_screened / n_s) + (t4 - t3) * (len(gaps) / n_g)
+    return {"value": n_screened / cpu_step, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "recruit: first %d reads of the first library (k-mer screen %.2f s + alignment tagger %.2f s, OpenMP %d threads); "
+                      "assembly: pools of the first %d gaps at %s (%.2f s, same thread count); value = reads / (sample times scaled to the "
+                      "whole step); oracle/gp_oracle.c" % (n_s, t1 - t0, t2 - t1, cores, n_g, ",".join("%d/%d" % p for p in kk), t4 - t3),
             "recruit_reads_per_s": n_s / (t2 - t0), "assembly_gaps_per_s": n_g / (t4 - t3),
-            "parity_on_sample": bool(ok and ok_asm), "parity_recruit": bool(ok), "parity_assembly": bool(ok_asm),
-            "sample_hits": int(len(ohits)), "sample_contigs": int(sum(len(e) for e in exp))}
+            "parity_on_sample": bool(ok and ok_asm and ok_pick), "parity_recruit": bool(ok), "parity_assembly": bool(ok_asm),
+            "parity_pick": bool(ok_pick), "sample_hits": int(len(ohits)), "sample_contigs": int(sum(len(e) for ee in exp for e in ee))}
 
 
 if __name__ == "__main__":

@@ -18,13 +18,14 @@ CONTIG = np.dtype([("gap", "<u4"), ("k", "<u2"), ("kv", "<u2"), ("n_nodes", "<u4
                    ("reserved", "<u4"), ("seq_off", "<u8")])
 SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", "<u4"), ("gaps_per_scaffold", "<u4"),
                       ("gap_len", "<u4"), ("read_len", "<u4"), ("insert_mean", "<u4"), ("insert_sd", "<u4"),
-                      ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4")])
+                      ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4"),
+                      ("library", "<u4"), ("reserved", "<u4")])
 assert CONTIG.itemsize == 32 and GAP.itemsize == 16 and ALNREC.itemsize == 32 and TAGHIT.itemsize == 12 and DPOS.itemsize == 16 and HIT.itemsize == 8
 
 GF_OK, GF_E_INVAL, GF_E_NODEV, GF_E_NOMEM, GF_E_NOSPACE, GF_E_STATE, GF_E_UNSUPPORTED, GF_E_FORMAT = 0, -1, -2, -3, -4, -5, -6, -7
 KIND_CLIP, KIND_DISCORDANT, KIND_UNMAP, KIND_LOWMAPQ = 0, 1, 2, 3
 KIND_NAMES = {KIND_CLIP: "clip", KIND_DISCORDANT: "discordant", KIND_UNMAP: "unmap"}
-KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_SYNTH, KERNEL_COUNT, KERNEL_VERIFY, KERNEL_INGEST = range(9)
+KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_SYNTH, KERNEL_COUNT, KERNEL_VERIFY, KERNEL_INGEST, KERNEL_PICK = range(10)
 
 _lib = None
 
@@ -85,6 +86,11 @@ def lib():
         "gf_tag_low_mapq_compact_dev": (i32, [vp, vp, vp, sz, vp, sz, vp, sz, vp]),
         "gf_assemble": (i32, [vp, vp, vp, vp, sz, i32, vp, vp, i32, i32, i32, vp, sz, szp, vp, sz, szp]),
         "gf_assemble_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, i32, i32, i32, i32, vp, sz, vp, vp, sz, vp, vp]),
+        "gf_assemble_multi_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, vp, vp, i32, i32, i32, vp, sz, vp, vp, sz, vp, vp]),
+        "gf_pool_counts_dev": (i32, [vp, vp, sz, vp]),
+        "gf_pools_pack_for_owners_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
+        "gf_pools_merge_dev": (i32, [vp, vp, sz, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz, vp, vp]),
+        "gf_pick_anchored_dev": (i32, [vp, vp, vp, sz, vp, i32, vp, vp]),
         "gf_count_kmers": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp, sz, szp]),
         "gf_pool_keys_reset": (i32, [vp, vp]),
         "gf_pool_keys_from_screen_dev": (i32, [vp, vp, vp, sz, i32, vp, sz, vp]),

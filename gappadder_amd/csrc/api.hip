@@ -130,8 +130,9 @@ void gf_destroy(gf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
-    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->binmap, &ctx->binmap_fine, &ctx->bam_stream, &ctx->bam_recs, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->rowgap, &ctx->pool_ws, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->binmap, &ctx->binmap_fine, &ctx->bam_stream, &ctx->bam_recs, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->rowgap, &ctx->pool_ws, &ctx->xchg_ws, &ctx->xchg_ws2, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
         if (b->p) (void)hipFree(b->p);
+    for (auto& kv : ctx->anchor_tabs) if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->d_gaps) (void)hipFree(ctx->d_gaps);
     if (ctx->d_scaf_off) (void)hipFree(ctx->d_scaf_off);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -232,6 +233,8 @@ int gf_set_gaps(gf_ctx* ctx, const gf_gap* gaps, size_t n_gaps, uint32_t n_scaff
     }
     if (ctx->d_gaps) { (void)hipFree(ctx->d_gaps); ctx->d_gaps = nullptr; }
     if (ctx->d_scaf_off) { (void)hipFree(ctx->d_scaf_off); ctx->d_scaf_off = nullptr; }
+    for (auto& kv : ctx->anchor_tabs) if (kv.second.p) (void)hipFree(kv.second.p);
+    ctx->anchor_tabs.clear();
     std::vector<uint32_t> off(n_scaffolds + 1, 0);
     for (size_t g = 0; g < n_gaps; ++g) off[gaps[g].scaffold + 1]++;
     for (uint32_t s = 0; s < n_scaffolds; ++s) off[s + 1] += off[s];
@@ -375,7 +378,24 @@ int gf_assemble_dev(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
         return GF_E_INVAL;
     GF_HIP(ctx, hipSetDevice(ctx->device));
     return launch_assemble(ctx, d_pool, d_nmask, d_pool_off, n_pools, total_reads, read_len, k, kv, min_count, min_contig,
-                           d_contigs, contig_cap, d_n_contigs, d_seq, seq_cap, d_seq_len, d_gap_error, nullptr, nullptr, 0);
+                           d_contigs, contig_cap, d_n_contigs, d_seq, seq_cap, d_seq_len, d_gap_error, nullptr, nullptr, 0, false);
+}
+
+int gf_assemble_multi_dev(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
+                          size_t total_reads, int read_len, const int* k_list, const int* kv_list, int n_k, int min_count,
+                          int min_contig, void* d_contigs, size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap,
+                          void* d_seq_len, void* d_gap_error) {
+    if (!ctx || !d_n_contigs || !d_seq_len || (n_pools && (!d_pool_off || !d_gap_error)) || (total_reads && !d_pool) ||
+        (contig_cap && !d_contigs) || (seq_cap && !d_seq) || n_k < 1 || !k_list || !kv_list)
+        return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n_k; ++i) {   // the (k, k_velvet) loop of run_assembly (assemble_gaps.py:87-122); one contig list
+        const int rc = launch_assemble(ctx, d_pool, d_nmask, d_pool_off, n_pools, total_reads, read_len, k_list[i], kv_list[i], min_count,
+                                       min_contig, d_contigs, contig_cap, d_n_contigs, d_seq, seq_cap, d_seq_len, d_gap_error, nullptr,
+                                       nullptr, 0, i > 0);
+        if (rc) return rc;
+    }
+    return GF_OK;
 }
 
 int gf_assemble(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, const uint64_t* pool_off, size_t n_pools,
@@ -415,7 +435,7 @@ int gf_assemble(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, const 
     for (int i = 0; i < n_k; ++i) {
         rc = launch_assemble(ctx, d_pool, n_mask ? ctx->stage_aux.p : nullptr, d_off, n_pools, total, read_len, k_list[i],
                              kv_list[i], min_count, min_contig, d_ctg, contig_cap, d_cnt, d_seq, seq_cap, d_cnt + 8, d_err,
-                             nullptr, nullptr, 0);
+                             nullptr, nullptr, 0, false);
         if (rc) return rc;
         uint32_t nc = 0;
         unsigned long long sl = 0;
@@ -482,7 +502,7 @@ int gf_count_kmers(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, siz
     GF_HIP(ctx, hipMemcpyAsync(d_off, off, 16, hipMemcpyHostToDevice, ctx->stream));
     if (n_mask && n_reads) GF_HIP(ctx, hipMemcpyAsync(ctx->stage_aux.p, n_mask, n_reads * nmw * 4, hipMemcpyHostToDevice, ctx->stream));
     rc = launch_assemble(ctx, d_pool, n_mask ? ctx->stage_aux.p : nullptr, d_off, 1, n_reads, read_len, k, 0, min_count, 0,
-                         nullptr, 0, d_cnt, nullptr, 0, d_cnt + 8, d_err, d_keys, d_counts, cap);
+                         nullptr, 0, d_cnt, nullptr, 0, d_cnt + 8, d_err, d_keys, d_counts, cap, false);
     if (rc) return rc;
     uint32_t n = 0, err = 0;
     GF_HIP(ctx, hipMemcpyAsync(&n, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));

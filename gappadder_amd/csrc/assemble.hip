@@ -27,6 +27,7 @@ struct AsmParams {
     const uint32_t* nmask;     // may be null
     const uint64_t* pool_off;  // n_pools + 1, in reads
     uint32_t n_pools;
+    uint64_t total_reads;      // rows of the pool array = what the workspace slices are sized for
     uint32_t rb, read_len, k, kv, nmw;
     uint32_t min_count, min_contig;
     unsigned long long* table; // 4 slots per k-mer instance: low 32 = instance id, high 32 = count / node meta
@@ -280,6 +281,10 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         const uint32_t g = s_gap;
         if (g >= P.n_pools) break;
         const uint64_t r0 = P.pool_off[g], r1 = P.pool_off[g + 1];
+        if (r1 < r0 || r1 > P.total_reads) {   // pool_off beyond the pool array (an overflowed gf_build_pools_dev): refuse the gap
+            if (tid == 0) P.gap_error[g] = ASM_ERR_IDS;
+            continue;
+        }
         const uint32_t n_r = (uint32_t)(r1 - r0);
         if (n_r == 0) continue;
         // workspace unit: every k-mer AND every kv-mer of the gap is a window of one of its reads, so
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
         wg_phase_sync();
         if (P.cnt_keys) {
-            if (tid == 0) { *P.n_contigs = s_cnt[0]; if (s_cnt[3]) P.gap_error[g] = s_cnt[3]; }
+            if (tid == 0) { *P.n_contigs = s_cnt[0]; if (s_cnt[3]) P.gap_error[g] |= s_cnt[3]; }
             __syncthreads();
             continue;
         }
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
                 s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
                 s_seq[0] = 0;
-                if (s_cnt[3]) P.gap_error[g] = s_cnt[3];
+                if (s_cnt[3]) P.gap_error[g] |= s_cnt[3];
             }
             __syncthreads();
             ASM_STAMP(5);
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
                 s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
                 s_seq[0] = 0;
-                if (s_cnt[3]) P.gap_error[g] = s_cnt[3];
+                if (s_cnt[3]) P.gap_error[g] |= s_cnt[3];
             }
             __syncthreads();
             ASM_STAMP(5);
@@ -969,7 +974,7 @@ __global__ void fill_empty_kernel(unsigned long long* t, uint64_t n) {
 int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
                     size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig, void* d_contigs,
                     size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len, void* d_gap_error,
-                    void* d_cnt_keys, void* d_cnt_counts, size_t cnt_cap) {
+                    void* d_cnt_keys, void* d_cnt_counts, size_t cnt_cap, bool append) {
     if (k < 16 || k > 64 || read_len < k || read_len > 1000) return GF_E_UNSUPPORTED;
     if (!d_cnt_keys && (kv < 15 || kv >= k || !(kv & 1))) return GF_E_UNSUPPORTED;
     if (n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull) return GF_E_INVAL;
@@ -987,14 +992,16 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     }
     if ((rc = ensure(ctx, ctx->asm_surv, std::max<uint64_t>(n_inst, 1) * 2 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->asm_nodes, std::max<uint64_t>(n_inst, 1) * 3 * 4))) return rc;
-    if (n_pools == 0) {
+    if (n_pools == 0 && !append) {
         GF_HIP(ctx, hipMemsetAsync(d_n_contigs, 0, 4, ctx->stream));
         GF_HIP(ctx, hipMemsetAsync(d_seq_len, 0, 8, ctx->stream));
     }
     if (n_pools == 0) return GF_OK;
     if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
     uint32_t* d_next = (uint32_t*)ctx->counters.p + 8;
-    zero_regions(ctx, ZeroList{{(uint32_t*)d_n_contigs, (uint32_t*)d_seq_len, (uint32_t*)d_gap_error, d_next}, {1, 2, (uint32_t)n_pools, 1}});
+    // append: a further (k, kv) pair of the same call adds to the contig list and keeps the error flags of the earlier pairs
+    if (append) zero_regions(ctx, ZeroList{{d_next, nullptr, nullptr, nullptr}, {1, 0, 0, 0}});
+    else zero_regions(ctx, ZeroList{{(uint32_t*)d_n_contigs, (uint32_t*)d_seq_len, (uint32_t*)d_gap_error, d_next}, {1, 2, (uint32_t)n_pools, 1}});
     AsmParams P;
     P.next_gap = d_next;
     P.keyslot = (uint32_t)ctx->asm_keyslot;
@@ -1005,6 +1012,7 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.nmask = (const uint32_t*)d_nmask;
     P.pool_off = (const uint64_t*)d_pool_off;
     P.n_pools = (uint32_t)n_pools;
+    P.total_reads = total_reads;
     P.rb = rb; P.read_len = read_len; P.k = k; P.kv = kv; P.nmw = (read_len + 31) / 32;
     P.min_count = min_count < 1 ? 1 : min_count;
     P.min_contig = min_contig < 0 ? 0 : min_contig;

@@ -204,6 +204,8 @@ __global__ __launch_bounds__(64 * INF_WAVES) void bgzf_inflate_kernel(const uint
             const uint32_t nlen = take(16);
             if ((len ^ nlen) != 0xFFFFu) { err = INF_BAD_STORED; break; }
             if (pos + len > isize) { err = INF_OVERRUN; break; }
+            // the stored bytes must lie inside this block's compressed data (a corrupt LEN would read past the staged chunk)
+            if ((used >> 3) + len > blk.clen + (uint32_t)(a0 & 3)) { err = INF_OVERRUN; break; }
             const uint8_t* src = reinterpret_cast<const uint8_t*>(wp) + (used >> 3);
             for (uint32_t i = lane; i < len; i += 64) dst[pos + i] = src[i];
             pos += len;
@@ -265,6 +267,9 @@ __global__ __launch_bounds__(64 * INF_WAVES) void bgzf_inflate_kernel(const uint
         // ---- symbols of this block
         while (!err) {
             refill();
+            // a corrupt block must not decode on into the next blocks: stop once the bit position is past this block's data
+            // (+4 bytes of slack for the bits held in the buffer); the exact end is checked below (INF_TRAILING)
+            if (used > 8 * (blk.clen + 4 + (uint32_t)(a0 & 3))) { err = INF_OVERRUN; break; }
             uint32_t sym = decode(SLL, ll_lim, ll_bas);
             if (err) break;
             if (sym < 256) {

@@ -14,7 +14,7 @@ namespace gf {
 
 constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
 constexpr int TILE_READS = 256;  // reads staged per workgroup pass of the screen filter
-constexpr int N_KERNEL_SLOTS = 9;
+constexpr int N_KERNEL_SLOTS = 10;
 
 // flank k-mer index for one k: three levels, all read-only on the device
 struct FlankIndex {
@@ -96,10 +96,11 @@ struct gf_ctx {
     uint32_t bin_words = 0, fine_words = 0, fine_shift = 0;
     // second-hop table cache
     std::vector<uint32_t> low_rows, rowgap_rows;
+    std::map<int, gf::DevBuf> anchor_tabs;   // by anchor length: the flank anchors of gf_pick_anchored_dev (dropped by gf_set_gaps)
     size_t low_b1 = 0, low_b2 = 0;
 
     // scratch
-    gf::DevBuf cand, cand2, part_ws, binmap, binmap_fine, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, rowgap, pool_ws, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, part_ws, binmap, binmap_fine, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, rowgap, pool_ws, xchg_ws, xchg_ws2, counters, stage_in, stage_out, stage_aux, table;
     size_t bam_n_recs = 0;       // alignment records gf_bam_pack left in bam_recs (for gf_tag_*_bam)
     size_t bam_stream_len = 0;   // inflated BAM bytes gf_bgzf_inflate left in bam_stream
     // timing
@@ -165,6 +166,6 @@ int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* ta
 int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
                     size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig, void* d_contigs,
                     size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len, void* d_gap_error,
-                    void* d_cnt_keys, void* d_cnt_counts, size_t cnt_cap);
+                    void* d_cnt_keys, void* d_cnt_counts, size_t cnt_cap, bool append);
 
 }  // namespace gf

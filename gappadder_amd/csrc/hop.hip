@@ -126,6 +126,7 @@ int gf_second_hop_table_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghi
     const size_t b_k = (row_cap * 8 + 255) & ~(size_t)255, b_v = (row_cap * 4 + 255) & ~(size_t)255;
     int rc;
     if ((rc = ensure(ctx, ctx->rowgap, 2 * b_k + 2 * b_v + temp_bytes + 256))) return rc;
+    ctx->rowgap_rows.clear();   // the buffer is sort scratch now: gf_pool_keys_from_tags_dev's cached row -> gap map is gone
     uint8_t* w = (uint8_t*)ctx->rowgap.p;
     unsigned long long* k_in = (unsigned long long*)w;
     unsigned long long* k_out = (unsigned long long*)(w + b_k);

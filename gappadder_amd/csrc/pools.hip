@@ -253,7 +253,9 @@ __global__ __launch_bounds__(256) void pool_sort_unique_kernel(uint32_t n_gaps, 
 __global__ __launch_bounds__(256) void pool_gather_kernel(uint32_t n_gaps, const uint32_t* seg_off, const uint32_t* seg,
                                                          const unsigned long long* pool_off, const uint8_t* reads, uint32_t rb,
                                                          uint64_t n_reads, uint8_t* pool, uint64_t pool_cap_reads,
-                                                         uint32_t* pool_ids) {
+                                                         uint32_t* pool_ids, uint32_t* error) {
+    // the pool buffer is too small for the recruits: say so (the gather stops at the capacity, pool_off stays exact)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && pool_off[n_gaps] > pool_cap_reads) atomicOr(error, 0x80000000u);
     for (uint32_t g = blockIdx.x; g < n_gaps; g += gridDim.x) {
         const unsigned long long p0 = pool_off[g], p1 = pool_off[g + 1];
         const uint32_t n = (uint32_t)(p1 - p0);
@@ -277,6 +279,128 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(uint32_t n_gaps, const
                 if (p0 + j >= pool_cap_reads) break;
                 const uint32_t key = seg[s0 + j];
                 pool_ids[p0 + j] = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
+            }
+    }
+}
+
+// ---- §8e exchange step / a-5 library concatenation: pools regrouped by owner rank, and pools of several sources merged ----
+// owner of gap g: batches of `batch` consecutive gaps dealt round-robin over the ranks
+__device__ __forceinline__ uint32_t owner_of(uint32_t g, uint32_t batch, uint32_t world) { return (g / batch) % world; }
+
+// exclusive scan of one value per thread over a 1024-thread block; *total = sum (same in every thread)
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_w /* >= 17 words */, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if ((int)lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) s_w[w] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t q = 0; q < (blockDim.x >> 6); ++q) { const uint32_t t = s_w[q]; if (q < w) base += t; tot += t; }
+    *total = tot;
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(1024) void pool_counts_kernel(const unsigned long long* pool_off, uint32_t n_gaps, uint32_t* cnt) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_gaps; g += gridDim.x * blockDim.x)
+        cnt[g] = (uint32_t)(pool_off[g + 1] - pool_off[g]);
+}
+
+// block d: rows of the gaps owned by rank d, in gap order -> their row offset inside d's slot; cnt[g] for every gap
+__global__ __launch_bounds__(1024) void xchg_send_offsets_kernel(const unsigned long long* pool_off, uint32_t n_gaps, uint32_t world,
+                                                                 uint32_t batch, uint32_t* cnt, uint32_t* dst_off) {
+    __shared__ uint32_t s_w[20];
+    const uint32_t d = blockIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < n_gaps; g0 += blockDim.x) {
+        const uint32_t g = g0 + threadIdx.x;
+        const bool mine = g < n_gaps && owner_of(g, batch, world) == d;
+        const uint32_t n = mine ? (uint32_t)(pool_off[g + 1] - pool_off[g]) : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan_excl(n, s_w, &tot);
+        if (mine) { cnt[g] = n; dst_off[g] = carry + ex; }
+        carry += tot;
+        __syncthreads();
+    }
+}
+
+// one workgroup per gap: its rows go to slot (owner * n_lib + lib) of the send buffer
+__global__ __launch_bounds__(256) void xchg_pack_kernel(const uint8_t* pool, const unsigned long long* pool_off, uint32_t n_gaps, uint32_t rb,
+                                                        uint32_t world, uint32_t batch, uint32_t lib, uint32_t n_lib, const uint32_t* dst_off,
+                                                        uint8_t* send, uint64_t cap_rows, uint32_t* error) {
+    const uint32_t ur = (rb & 1) ? rb : rb / 2;
+    for (uint32_t g = blockIdx.x; g < n_gaps; g += gridDim.x) {
+        const unsigned long long p0 = pool_off[g];
+        uint32_t n = (uint32_t)(pool_off[g + 1] - p0);
+        if (!n) continue;
+        const uint32_t o = dst_off[g];
+        if ((uint64_t)o + n > cap_rows) {   // slot too small: say so, send what fits
+            if (threadIdx.x == 0) atomicOr(error, 0x40000000u);
+            n = o < cap_rows ? (uint32_t)(cap_rows - o) : 0u;
+        }
+        const uint64_t slot = (uint64_t)owner_of(g, batch, world) * n_lib + lib;
+        const uint64_t src0 = p0 * ur, dst0 = (slot * cap_rows + o) * ur;
+        const uint64_t units = (uint64_t)n * ur;
+        if (rb & 1) for (uint64_t i = threadIdx.x; i < units; i += blockDim.x) send[dst0 + i] = pool[src0 + i];
+        else for (uint64_t i = threadIdx.x; i < units; i += blockDim.x)
+            reinterpret_cast<uint16_t*>(send)[dst0 + i] = reinterpret_cast<const uint16_t*>(pool)[src0 + i];
+    }
+}
+
+// blocks 0 .. n_slots-1: row offsets of my gaps inside slot i (a slot holds MY gaps' rows of one source, in gap order);
+// block n_slots: merged pool_off (u64, n_gaps + 1) = scan over my gaps of the rows of all sources
+__global__ __launch_bounds__(1024) void merge_offsets_kernel(const uint32_t* cnt /* [n_slots][n_gaps] */, uint32_t n_slots, uint32_t n_gaps,
+                                                             uint32_t rank, uint32_t world, uint32_t batch, uint32_t* src_off /* [n_slots][n_gaps] */,
+                                                             unsigned long long* moff) {
+    __shared__ uint32_t s_w[20];
+    const uint32_t i = blockIdx.x;
+    unsigned long long carry = 0;
+    for (uint32_t g0 = 0; g0 < n_gaps; g0 += blockDim.x) {
+        const uint32_t g = g0 + threadIdx.x;
+        const bool mine = g < n_gaps && owner_of(g, batch, world) == rank;
+        uint32_t n = 0;
+        if (mine) {
+            if (i < n_slots) n = cnt[(uint64_t)i * n_gaps + g];
+            else for (uint32_t q = 0; q < n_slots; ++q) n += cnt[(uint64_t)q * n_gaps + g];
+        }
+        uint32_t tot;
+        const uint32_t ex = block_scan_excl(n, s_w, &tot);
+        if (g < n_gaps) {
+            if (i < n_slots) src_off[(uint64_t)i * n_gaps + g] = (uint32_t)carry + ex;
+            else moff[g] = carry + ex;
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (i == n_slots && threadIdx.x == 0) moff[n_gaps] = carry;
+}
+
+// one workgroup per gap I own: the sources' rows one after the other — libraries in order (merge_reads.py:43-51: `cat` of the
+// per-library files), inside a library the source ranks in order (contiguous read shards: global read order)
+__global__ __launch_bounds__(256) void merge_copy_kernel(const uint8_t* src, uint64_t cap_rows, const uint32_t* cnt, const uint32_t* src_off,
+                                                         uint32_t n_lib, uint32_t n_ranks_src, uint32_t n_gaps, uint32_t rb, uint32_t rank,
+                                                         uint32_t world, uint32_t batch, const unsigned long long* moff, uint8_t* merged,
+                                                         uint64_t merged_cap_rows, uint32_t* error) {
+    const uint32_t ur = (rb & 1) ? rb : rb / 2;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && moff[n_gaps] > merged_cap_rows) atomicOr(error, 0x80000000u);
+    for (uint32_t g = blockIdx.x; g < n_gaps; g += gridDim.x) {
+        if (owner_of(g, batch, world) != rank) continue;
+        unsigned long long at = moff[g];
+        for (uint32_t l = 0; l < n_lib; ++l)
+            for (uint32_t r = 0; r < n_ranks_src; ++r) {
+                const uint64_t slot = (uint64_t)r * n_lib + l;
+                uint32_t n = cnt[slot * n_gaps + g];
+                if (!n) continue;
+                if (at + n > merged_cap_rows) n = at < merged_cap_rows ? (uint32_t)(merged_cap_rows - at) : 0u;
+                const uint64_t src0 = (slot * cap_rows + src_off[slot * n_gaps + g]) * ur, dst0 = at * ur;
+                const uint64_t units = (uint64_t)n * ur;
+                if (rb & 1) for (uint64_t i = threadIdx.x; i < units; i += blockDim.x) merged[dst0 + i] = src[src0 + i];
+                else for (uint64_t i = threadIdx.x; i < units; i += blockDim.x)
+                    reinterpret_cast<uint16_t*>(merged)[dst0 + i] = reinterpret_cast<const uint16_t*>(src)[src0 + i];
+                at += cnt[slot * n_gaps + g];
             }
     }
 }
@@ -412,8 +536,64 @@ int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, 
     if (ng && pool_cap_reads) {
         hipLaunchKernelGGL(pool_gather_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ng, seg_off, seg,
                            (const unsigned long long*)d_pool_off, (const uint8_t*)d_packed_reads, rb, (uint64_t)n_reads,
-                           (uint8_t*)d_pool_packed, (uint64_t)pool_cap_reads, (uint32_t*)d_pool_read_ids);
+                           (uint8_t*)d_pool_packed, (uint64_t)pool_cap_reads, (uint32_t*)d_pool_read_ids, (uint32_t*)d_error);
     }
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_pool_counts_dev(gf_ctx* ctx, const void* d_pool_off, size_t n_gaps, void* d_cnt) {
+    if (!ctx || !d_pool_off || !d_cnt || n_gaps > 0xFFFFFFF0ull) return GF_E_INVAL;
+    if (!n_gaps) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    LaunchTimer tm(ctx, GF_KERNEL_POOL);
+    hipLaunchKernelGGL(pool_counts_kernel, dim3((unsigned)std::min<size_t>((n_gaps + 1023) / 1024, 256)), dim3(1024), 0, ctx->stream,
+                       (const unsigned long long*)d_pool_off, (uint32_t)n_gaps, (uint32_t*)d_cnt);
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_pools_pack_for_owners_dev(gf_ctx* ctx, const void* d_pool, const void* d_pool_off, size_t n_gaps, int read_len, int world,
+                                 int batch, int lib, int n_lib, void* d_send, size_t cap_rows, void* d_cnt, void* d_error) {
+    if (!ctx || !d_pool_off || !d_send || !d_cnt || !d_error || world < 1 || batch < 1 || n_lib < 1 || lib < 0 || lib >= n_lib ||
+        read_len <= 0 || n_gaps > 0xFFFFFFF0ull || cap_rows > 0xFFFFFFFFull)
+        return GF_E_INVAL;
+    if (!n_gaps) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->xchg_ws, n_gaps * 4 + 256))) return rc;
+    uint32_t* dst_off = (uint32_t*)ctx->xchg_ws.p;
+    const uint32_t rb = (uint32_t)gf_packed_read_bytes(read_len);
+    LaunchTimer tm(ctx, GF_KERNEL_POOL);
+    hipLaunchKernelGGL(xchg_send_offsets_kernel, dim3((unsigned)world), dim3(1024), 0, ctx->stream, (const unsigned long long*)d_pool_off,
+                       (uint32_t)n_gaps, (uint32_t)world, (uint32_t)batch, (uint32_t*)d_cnt, dst_off);
+    hipLaunchKernelGGL(xchg_pack_kernel, dim3((unsigned)std::min<size_t>(n_gaps, (size_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                       (const uint8_t*)d_pool, (const unsigned long long*)d_pool_off, (uint32_t)n_gaps, rb, (uint32_t)world, (uint32_t)batch,
+                       (uint32_t)lib, (uint32_t)n_lib, dst_off, (uint8_t*)d_send, (uint64_t)cap_rows, (uint32_t*)d_error);
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const void* d_cnt, int n_lib, int n_src_ranks, size_t n_gaps,
+                       int read_len, int rank, int world, int batch, void* d_merged, size_t merged_cap_rows, void* d_merged_off,
+                       void* d_error) {
+    if (!ctx || !d_src || !d_cnt || !d_merged_off || !d_error || (merged_cap_rows && !d_merged) || n_lib < 1 || n_src_ranks < 1 ||
+        world < 1 || rank < 0 || rank >= world || batch < 1 || read_len <= 0 || n_gaps > 0xFFFFFFF0ull || cap_rows > 0xFFFFFFFFull)
+        return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    if (!n_gaps) { GF_HIP(ctx, hipMemsetAsync(d_merged_off, 0, 8, ctx->stream)); return GF_OK; }
+    const uint32_t n_slots = (uint32_t)n_lib * (uint32_t)n_src_ranks;
+    int rc;
+    if ((rc = ensure(ctx, ctx->xchg_ws2, (size_t)n_slots * n_gaps * 4 + 256))) return rc;
+    uint32_t* src_off = (uint32_t*)ctx->xchg_ws2.p;
+    const uint32_t rb = (uint32_t)gf_packed_read_bytes(read_len);
+    LaunchTimer tm(ctx, GF_KERNEL_POOL);
+    hipLaunchKernelGGL(merge_offsets_kernel, dim3(n_slots + 1), dim3(1024), 0, ctx->stream, (const uint32_t*)d_cnt, n_slots, (uint32_t)n_gaps,
+                       (uint32_t)rank, (uint32_t)world, (uint32_t)batch, src_off, (unsigned long long*)d_merged_off);
+    hipLaunchKernelGGL(merge_copy_kernel, dim3((unsigned)std::min<size_t>(n_gaps, (size_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                       (const uint8_t*)d_src, (uint64_t)cap_rows, (const uint32_t*)d_cnt, src_off, (uint32_t)n_lib, (uint32_t)n_src_ranks,
+                       (uint32_t)n_gaps, rb, (uint32_t)rank, (uint32_t)world, (uint32_t)batch, (const unsigned long long*)d_merged_off,
+                       (uint8_t*)d_merged, (uint64_t)merged_cap_rows, (uint32_t*)d_error);
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
 }

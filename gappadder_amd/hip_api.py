@@ -256,10 +256,10 @@ class GapFill:
     # ---- synthetic workload (include/gf_synth.h) ----------------------------------------------------
     @staticmethod
     def synth_cfg(seed=20260002, scaffold_len=5_000_000, n_scaffolds=50, gaps_per_scaffold=20, gap_len=2000,
-                  read_len=150, insert_mean=300, insert_sd=30, err=0.005, mapq0=0.02, chimeric=0.01, flank_len=300):
+                  read_len=150, insert_mean=300, insert_sd=30, err=0.005, mapq0=0.02, chimeric=0.01, flank_len=300, library=0):
         c = np.zeros(1, dtype=B.SYNTH_CFG)
         c[0] = (seed, scaffold_len, n_scaffolds, gaps_per_scaffold, gap_len, read_len, insert_mean, insert_sd,
-                int(round(err * 65536)), int(round(mapq0 * 65536)), int(round(chimeric * 65536)), flank_len)
+                int(round(err * 65536)), int(round(mapq0 * 65536)), int(round(chimeric * 65536)), flank_len, library, 0)
         return c
 
     @staticmethod

@@ -2,7 +2,8 @@
 542-581).  The reference aligns the two flanks to the gap's contigs with `bwa mem -T {score} -a` and keeps the contig both
 flanks hit on the same strand; bwa is out of scope here, so the anchors are EXACT matches: the last `score` bases of the left
 flank and the first `score` bases of the right flank (score = the reference's bwa_min_score: 30, later 15).  Among the
-qualifying contigs the longest span wins (pick_contigs.py:300-321); the picked slice is contig[left_end : right_start + 1]
+qualifying contigs — every occurrence of the anchors, both orientations — the longest span wins (pick_contigs.py:300-321);
+the same rule runs on the device as gf_pick_anchored_dev (csrc/pick.hip); the picked slice is contig[left_end : right_start + 1]
 in flank orientation — the +1 reproduces the reference's 1-based/0-based slice (:341-349); header '>{gapId}_{contigName}'
 (:352).  A gap with a picked sequence is what this build reports as "closed"."""
 import os
@@ -30,8 +31,26 @@ def read_fasta(path):
     return out
 
 
+def anchor_spans(seq, la, ra):
+    """Both orientations of one contig: [(span, left_end, right_start, oriented)] for every orientation in which the left anchor
+    occurs and the right anchor occurs at or behind its end — leftmost left anchor, rightmost right anchor, i.e. the longest
+    span the anchors allow (the reference keeps the longest span among its bwa hits, pick_contigs.py:300-321)."""
+    out = []
+    a = len(la)
+    for oriented in (seq, revcomp(seq)):
+        i = oriented.find(la)
+        if i < 0:
+            continue
+        j = oriented.rfind(ra)
+        if j < i + a:
+            continue
+        out.append((j - (i + a), i + a, j, oriented))
+    return out
+
+
 def pick_gap_sequence(contigs, left_flank, right_flank, anchor_len):
-    """contigs: [(name, seq)].  Returns (name, gap_seq, oriented_contig) or None."""
+    """contigs: [(name, seq)].  Returns (name, gap_seq, oriented_contig) or None.  Longest span over all contigs and both
+    orientations; ties go to the first contig of the list, forward orientation first."""
     if len(left_flank) < anchor_len or len(right_flank) < anchor_len:
         return None
     la, ra = left_flank[-anchor_len:], right_flank[:anchor_len]
@@ -39,18 +58,9 @@ def pick_gap_sequence(contigs, left_flank, right_flank, anchor_len):
         return None
     best = None
     for name, seq in contigs:
-        for oriented in (seq, revcomp(seq)):
-            i = oriented.find(la)
-            if i < 0:
-                continue
-            left_end = i + anchor_len
-            j = oriented.find(ra, left_end)
-            if j < 0:
-                continue
-            span = j - left_end
+        for span, left_end, j, oriented in anchor_spans(seq, la, ra):
             if best is None or span > best[0]:
                 best = (span, name, oriented[left_end:j + 1], oriented)
-            break
     return None if best is None else best[1:]
 
 

@@ -35,9 +35,14 @@ def gather_bytes(payload, dst=0, device=None):
     return [bytes(p[:s].cpu().numpy().tobytes()) for p, s in zip(parts, sizes)]
 
 
+def owner_batch(n_gaps, world, batch=256):
+    """Batch size of the round-robin deal: 256 consecutive gaps, fewer when that would leave ranks without gaps."""
+    return max(1, min(batch, -(-n_gaps // max(1, world))))
+
+
 def gap_owner(n_gaps, world, batch=256):
-    """Owner rank of every gap: batches of `batch` consecutive gaps dealt round-robin."""
-    return (torch.arange(n_gaps, dtype=torch.int64) // batch) % world
+    """Owner rank of every gap: batches of consecutive gaps dealt round-robin."""
+    return (torch.arange(n_gaps, dtype=torch.int64) // owner_batch(n_gaps, world, batch)) % world
 
 
 def exchange_pools(pool, pool_off, coll_device=None, batch=256):

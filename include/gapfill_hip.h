@@ -224,6 +224,12 @@ int gf_assemble_dev(gf_ctx* ctx, const void* d_pool_packed, const void* d_pool_n
                     size_t n_pools, size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig,
                     void* d_contigs, size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len,
                     void* d_gap_error);
+/* every (k_list[i], kv_list[i]) pair of run_assembly's loop (assemble_gaps.py:87-122) in one call: one launch per pair, all
+ * appending to the same contig list (gf_contig.k / .kv tell the pairs apart); counters and error flags as gf_assemble_dev. */
+int gf_assemble_multi_dev(gf_ctx* ctx, const void* d_pool_packed, const void* d_pool_n_mask_or_null, const void* d_pool_off,
+                          size_t n_pools, size_t total_reads, int read_len, const int* k_list, const int* kv_list, int n_k,
+                          int min_count, int min_contig, void* d_contigs, size_t contig_cap, void* d_n_contigs, void* d_seq,
+                          size_t seq_cap, void* d_seq_len, void* d_gap_error);
 /* counted canonical k-mers of ONE pool, ascending (what `kmc_dump -ci0` lists after `kmc -k{k}`, assemble_gaps.py:96-102).
  * kmers: 2 x uint64 per k-mer (hi, lo), left-aligned KmerUtils layout; counts capped at 10^7 (-cs10000000). */
 int gf_count_kmers(gf_ctx* ctx, const uint8_t* pool_packed, const uint32_t* pool_n_mask_or_null, size_t n_reads,
@@ -288,6 +294,38 @@ int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, 
                        const void* d_n_keys, size_t key_cap, void* d_pool_packed, size_t pool_cap_reads, void* d_pool_off,
                        void* d_pool_read_ids, void* d_error);
 
+/* ---- pools of several sources -> one pool per gap.  Two uses, one primitive:
+ *  (a-5) library merge, merge_reads.py:43-51 (`cat` of the per-library gap_reads/{id}.fastq in library order): build one pool
+ *        array per library (gf_build_pools_dev into slot l of a [n_lib][cap_rows] buffer), gf_pool_counts_dev per library, then
+ *        gf_pools_merge_dev(n_lib, n_src_ranks = 1, rank 0 of world 1);
+ *  (§8e) the one exchange step of a multi-GPU run: every rank regroups its pools by OWNER rank (gf_pools_pack_for_owners_dev:
+ *        owner(g) = (g / batch) % world; slot (owner * n_lib + lib) of the send buffer holds that owner's gaps' rows in gap
+ *        order), the ranks all-gather the per-gap counts and all-to-all the slots (RCCL: equal-sized slots, no host sizes), and
+ *        every owner merges its gaps' rows (gf_pools_merge_dev: libraries in order, inside a library the source ranks in order
+ *        — with contiguous read shards that is the order of a single-process run over all reads; the reference assembles each gap
+ *        exactly once from all of its reads, assemble_gaps.py:296-299).
+ * Row = one packed read (gf_packed_read_bytes(read_len) bytes).  d_cnt = u32 per gap.  *d_error (u32, not reset by these calls)
+ * gets bit 30 when a send slot, bit 31 when the merged buffer is too small (rows beyond the capacity are dropped). */
+int gf_pool_counts_dev(gf_ctx* ctx, const void* d_pool_off /* u64[n_gaps+1] */, size_t n_gaps, void* d_cnt);
+int gf_pools_pack_for_owners_dev(gf_ctx* ctx, const void* d_pool_packed, const void* d_pool_off, size_t n_gaps, int read_len,
+                                 int world, int batch, int lib, int n_lib, void* d_send /* [world][n_lib][cap_rows] rows */,
+                                 size_t cap_rows, void* d_cnt /* u32[n_gaps]: this library's rows per gap */, void* d_error);
+/* d_src: [n_src_ranks][n_lib][cap_rows] rows (slot (r, l) = rows of MY gaps from source rank r, library l, in gap order);
+ * d_cnt: u32 [n_src_ranks][n_lib][n_gaps] (the all-gathered pack counts; for a local library merge the per-library counts).
+ * Writes d_merged_off (u64[n_gaps+1]; gaps this rank does not own are empty) and the rows. */
+int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const void* d_cnt, int n_lib, int n_src_ranks,
+                       size_t n_gaps, int read_len, int rank, int world, int batch, void* d_merged, size_t merged_cap_rows,
+                       void* d_merged_off, void* d_error);
+
+/* ---- §8f-1 on the device: flank anchoring (ContigsSelection, pick_contigs.py:64-358, with exact anchors instead of
+ * `bwa mem -T {score}`: the last / first anchor_len bases of the left / right flank given to gf_set_gaps; 8 <= anchor_len <= 32;
+ * the reference's scores are 30, then 15: assemble_gaps.py:336, 365).  For every contig and both orientations: leftmost left
+ * anchor, rightmost right anchor behind it; d_gap_best[gap] (u64, caller zeroes; atomicMax, so several calls — other anchor
+ * lengths, other contig lists — accumulate) = (span + 1) << 32 | (0x7FFFFFFF - contig index) << 1 | orientation, 0 = no
+ * contig of the gap is anchored = gap not closed; *d_n_closed (u32, caller zeroes) counts the gaps that became non-zero. */
+int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
+                         int anchor_len, void* d_gap_best, void* d_n_closed);
+
 /* ---- device memory + timing helpers (so a ctypes host needs no other HIP binding) ---------------------- */
 int gf_dev_alloc(gf_ctx* ctx, size_t bytes, void** d_ptr);
 int gf_dev_free(gf_ctx* ctx, void* d_ptr);
@@ -304,6 +342,7 @@ int gf_memset_dev(gf_ctx* ctx, void* d_ptr, int value, size_t bytes);
 #define GF_KERNEL_COUNT 6
 #define GF_KERNEL_VERIFY 7  /* second kernel of the screen: exact per-candidate verification */
 #define GF_KERNEL_INGEST 8  /* FASTQ text -> packed reads */
+#define GF_KERNEL_PICK 9    /* flank anchoring */
 int gf_timing_enable(gf_ctx* ctx, int on);
 int gf_timing_read(gf_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 int gf_timing_reset(gf_ctx* ctx);

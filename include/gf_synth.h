@@ -28,6 +28,10 @@ typedef struct {
     uint32_t mapq0_q16;         /* fraction of mapped reads reported with MAPQ 0, * 65536 (2 % = 1311) */
     uint32_t chimeric_q16;      /* fraction of pairs whose reverse read comes from a random other place (1 % = 655) */
     uint32_t flank_len;         /* 300 (configuration.json:38) */
+    uint32_t library;           /* read library drawn from the SAME genome: 0 = first (reproduces the single-library data), 1, 2 ...
+                                 * select independent pair streams (a second `alignments[]` entry of the reference's JSON, e.g. the
+                                 * IS 5000 mate-pair library of BASELINE.json configs[4]) */
+    uint32_t reserved;          /* 0 */
 } gf_synth_cfg;
 
 typedef struct {
@@ -58,7 +62,7 @@ GFS_HD uint64_t gfs_gap_start(const gf_synth_cfg* c, uint32_t j) { /* j-th gap (
 }
 
 GFS_HD void gfs_make_pair(const gf_synth_cfg* c, uint64_t pair, gfs_pair* o) {
-    const uint64_t base = gfs_mix(c->seed * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull);
+    const uint64_t base = gfs_mix(c->seed * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull + (uint64_t)c->library * 0xA0761D6478BD642Full);
     const uint64_t r0 = gfs_mix(base + 4 * pair), r1 = gfs_mix(base + 4 * pair + 1), r2 = gfs_mix(base + 4 * pair + 2),
                    r3 = gfs_mix(base + 4 * pair + 3);
     const int64_t L = c->read_len;

@@ -41,15 +41,20 @@ static int put(or_taghit* out, size_t cap, size_t* n, uint32_t rec, uint32_t gap
     return 0;
 }
 
-static size_t tag_range(const or_alnrec* recs, size_t i0, size_t i1, const or_gap* gaps, size_t n_gaps, int insert_size,
-                        int sd, int clip_dist, int anchor_mapq, or_taghit* out, size_t cap) {
+/* gaps of one scaffold: `by_scaf` lists gap indices grouped by scaffold (each group in the caller's gap order — the order
+ * the reference reads gap_positions.txt in, :36-63), scaf_off[s] .. scaf_off[s+1] is scaffold s's group.  Same lines as a scan
+ * over all gaps that skips the other scaffolds, without the O(records x gaps) cost at 20 000 gaps. */
+static size_t tag_range(const or_alnrec* recs, size_t i0, size_t i1, const or_gap* gaps, const uint32_t* by_scaf,
+                        const size_t* scaf_off, size_t n_scaf, int insert_size, int sd, int clip_dist, int anchor_mapq,
+                        or_taghit* out, size_t cap) {
     const long dist1 = insert_size - 3L * sd, dist2 = insert_size + 3L * sd; /* collect_reads_for_gaps.py:5-6 */
     const int short_is = insert_size < 750;                                  /* :275 */
     size_t cnt = 0;
     for (size_t i = i0; i < i1; ++i) {
         const or_alnrec* r = &recs[i];
-        for (size_t g = 0; g < n_gaps; ++g) { /* every gap of the record's scaffold (:36-63) */
-            if (gaps[g].scaffold != r->ref) continue;
+        if (r->ref >= n_scaf) continue;
+        for (size_t q = scaf_off[r->ref]; q < scaf_off[r->ref + 1]; ++q) { /* every gap of the record's scaffold (:36-63) */
+            const size_t g = by_scaf[q];
             const long start = gaps[g].start, end = gaps[g].end, pos = r->pos;
             int tag = -1; /* 0:0c 1:0d 2:1c 3:1d */
             /* focal_region keys start-i, i in range(dist2), start-i >= 0 (:47-55); end+i (:57-62) */
@@ -85,17 +90,30 @@ size_t or_tag_alignments(const or_alnrec* recs, size_t n, const or_gap* gaps, si
     size_t cnts[64];
     or_taghit* bufs[64];
     size_t caps[64];
+    /* gap indices grouped by scaffold (counting sort, stable: the caller's order inside a scaffold) */
+    size_t n_scaf = 0;
+    for (size_t g = 0; g < n_gaps; ++g) if ((size_t)gaps[g].scaffold + 1 > n_scaf) n_scaf = (size_t)gaps[g].scaffold + 1;
+    size_t* scaf_off = calloc(n_scaf + 2, sizeof(size_t));
+    uint32_t* by_scaf = malloc((n_gaps + 1) * sizeof(uint32_t));
+    for (size_t g = 0; g < n_gaps; ++g) scaf_off[gaps[g].scaffold + 1]++;
+    for (size_t sc = 0; sc < n_scaf; ++sc) scaf_off[sc + 1] += scaf_off[sc];
+    {
+        size_t* cur = malloc((n_scaf + 1) * sizeof(size_t));
+        memcpy(cur, scaf_off, (n_scaf + 1) * sizeof(size_t));
+        for (size_t g = 0; g < n_gaps; ++g) by_scaf[cur[gaps[g].scaffold]++] = (uint32_t)g;
+        free(cur);
+    }
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
     for (int t = 0; t < nt; ++t) {
         size_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
         caps[t] = 4 * (i1 - i0) + 64;
         bufs[t] = malloc(caps[t] * sizeof(or_taghit));
-        cnts[t] = tag_range(recs, i0, i1, gaps, n_gaps, insert_size, sd, clip_dist, anchor_mapq, bufs[t], caps[t]);
+        cnts[t] = tag_range(recs, i0, i1, gaps, by_scaf, scaf_off, n_scaf, insert_size, sd, clip_dist, anchor_mapq, bufs[t], caps[t]);
         if (cnts[t] > caps[t]) { /* dense overlap of windows: redo with exact room */
             free(bufs[t]);
             caps[t] = cnts[t];
             bufs[t] = malloc(caps[t] * sizeof(or_taghit));
-            cnts[t] = tag_range(recs, i0, i1, gaps, n_gaps, insert_size, sd, clip_dist, anchor_mapq, bufs[t], caps[t]);
+            cnts[t] = tag_range(recs, i0, i1, gaps, by_scaf, scaf_off, n_scaf, insert_size, sd, clip_dist, anchor_mapq, bufs[t], caps[t]);
         }
     }
     size_t cnt = 0;
@@ -103,6 +121,7 @@ size_t or_tag_alignments(const or_alnrec* recs, size_t n, const or_gap* gaps, si
         for (size_t i = 0; i < cnts[t]; ++i) { if (cnt < cap) out[cnt] = bufs[t][i]; ++cnt; }
         free(bufs[t]);
     }
+    free(scaf_off); free(by_scaf);
     return cnt;
 }
 

@@ -70,6 +70,12 @@ CASES = {
         "libs": [(300, 30, 2800)],
         "min_gap": 100, "flank": 300, "L": 150, "no_err": True,
     },
+    # BASELINE.json configs[0] / SURVEY.md §8d "C1": 100 kb, one 2-kb gap at [49 000, 51 000), 10 000 pairs of 2x150 (30x), IS 300/30
+    "c1": {
+        "scaffolds": [("chr1", 100000, [(49000, 2000)])],
+        "libs": [(300, 30, 10000)],
+        "min_gap": 100, "flank": 300, "L": 150,
+    },
     "edge": {
         "scaffolds": [
             ("ctgA", 6000, [(3, 120), (2000, 100), (2250, 99), (2500, 300), (5890, 110)]),  # start<5; ==min; <min; trailing N-run
