@@ -160,6 +160,15 @@ def main():
     # sweep — a read that shares a 51-mer with a flank shares its 31-mers too, so this is the superset every assembly k needs
     k_screen = min(a for a, _ in kk)
 
+    def all_gather(dst, src):
+        # fixed-size slots: no host sizes, no host sync (RCCL); the gloo smoke path goes through host memory
+        if backend == "nccl":
+            dist.all_gather_into_tensor(dst, src)
+        else:
+            parts = list(torch.empty_like(dst, device="cpu").chunk(world))
+            dist.all_gather(parts, src.cpu())
+            dst.copy_(torch.cat(parts))
+
     def sync_all():
         gf.sync()
         for g2 in gf2s:
@@ -182,6 +191,16 @@ def main():
         assert n_th <= lb.hit_cap
         th = np.frombuffer(lb.d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
         lb.row_cap = 2 * int((th["kind"] == B.KIND_DISCORDANT).sum()) + 4096
+        if world > 1:
+            rc_t = torch.tensor([lb.row_cap], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(rc_t, op=dist.ReduceOp.MAX)
+            lb.row_cap = int(rc_t)
+            lb.d_rows_all = torch.empty(world * lb.row_cap * 16, dtype=torch.uint8, device=dev)
+            lb.d_rowgap_all = torch.empty(world * lb.row_cap, dtype=torch.int32, device=dev)
+            lb.d_nrows_all = torch.zeros(world, dtype=torch.int32, device=dev)
+            lb.d_rows_u = torch.empty(world * lb.row_cap * 16, dtype=torch.uint8, device=dev)
+            lb.d_rowgap_u = torch.empty(world * lb.row_cap, dtype=torch.int32, device=dev)
+            lb.d_nrows_u = torch.zeros(4, dtype=torch.int32, device=dev)
         lb.d_rows = torch.empty(lb.row_cap * 16, dtype=torch.uint8, device=dev)
         lb.d_row_gap = torch.empty(lb.row_cap, dtype=torch.int32, device=dev)
 
@@ -189,22 +208,44 @@ def main():
         rc = lib.gf_second_hop_table_dev(lb.h2, lb.d_recs.data_ptr(), lb.d_thits.data_ptr(), lb.cp + 16, lb.hit_cap, lb.d_rows.data_ptr(),
                                          lb.d_row_gap.data_ptr(), lb.row_cap, lb.cp + 116)
         assert rc == 0, rc
-        rc = lib.gf_tag_low_mapq_table_dev(lb.h2, lb.d_low.data_ptr(), lb.cp + 112, lb.hit_cap, lb.d_rows.data_ptr(), lb.cp + 116, lb.row_cap,
-                                           lb.d_lhits.data_ptr(), lb.hit_cap, lb.cp + 32)
+        if world == 1:
+            rows_p, rowgap_p, nrows_p, rcap, hh = lb.d_rows.data_ptr(), lb.d_row_gap.data_ptr(), lb.cp + 116, lb.row_cap, lb.h2
+        else:
+            # the reads are sharded, the second hop is not: a MAPQ-0 record is linked to discordant mates of ANY rank's reads
+            # (collect_discordant_low_mapq_reads.py reads the whole discordant_reads_pos file), so the ranks all-gather their
+            # rows (fixed-size slots) and every rank sorts the union
+            assert lib.gf_stream_wait(h, lb.h2) == 0
+            all_gather(lb.d_rows_all, lb.d_rows)
+            all_gather(lb.d_rowgap_all, lb.d_row_gap)
+            all_gather(lb.d_nrows_all, lb.d_cnt[29:30])
+            assert lib.gf_second_hop_table_merge_dev(h, lb.d_rows_all.data_ptr(), lb.d_rowgap_all.data_ptr(), lb.d_nrows_all.data_ptr(), world,
+                                                     lb.row_cap, lb.d_rows_u.data_ptr(), lb.d_rowgap_u.data_ptr(), world * lb.row_cap,
+                                                     lb.d_nrows_u.data_ptr()) == 0
+            rows_p, rowgap_p, nrows_p, rcap, hh = lb.d_rows_u.data_ptr(), lb.d_rowgap_u.data_ptr(), lb.d_nrows_u.data_ptr(), world * lb.row_cap, h
+        rc = lib.gf_tag_low_mapq_table_dev(hh, lb.d_low.data_ptr(), lb.cp + 112, lb.hit_cap, rows_p, nrows_p, rcap, lb.d_lhits.data_ptr(),
+                                           lb.hit_cap, lb.cp + 32)
         assert rc == 0, rc
-        assert lib.gf_stream_wait(h, lb.h2) == 0          # pools need the tagger's and the second hop's hits
+        if hh is not h:
+            assert lib.gf_stream_wait(h, lb.h2) == 0          # pools need the tagger's and the second hop's hits
         assert lib.gf_pool_keys_all_dev(h, lb.d_hits.data_ptr(), lb.cp, lb.hit_cap, 1, lb.d_recs.data_ptr(), lb.d_thits.data_ptr(), lb.cp + 16,
-                                        lb.hit_cap, lb.d_lhits.data_ptr(), lb.cp + 32, lb.hit_cap, lb.d_row_gap.data_ptr(),
+                                        lb.hit_cap, lb.d_lhits.data_ptr(), lb.cp + 32, lb.hit_cap, rowgap_p,
                                         lb.d_keys.data_ptr(), lb.key_cap, lb.cp + 48) == 0
 
     def build_pools(lb, pool_ptr, pool_cap):
         assert lib.gf_build_pools_dev(h, lb.d_reads.data_ptr(), lb.n_reads, L, lb.d_keys.data_ptr(), lb.cp + 48, lb.key_cap, pool_ptr,
                                       pool_cap, lb.d_pool_off.data_ptr(), None, lb.cp + 96) == 0
 
-    for lb in libs:
-        hop_and_keys(lb)
-        build_pools(lb, None, 0)        # offsets only
+    def sizing_pools():
+        for lb in libs:
+            hop_and_keys(lb)
+            build_pools(lb, None, 0)        # offsets only
+    if stream is not None:
+        with torch.cuda.stream(stream):
+            sizing_pools()
+    else:
+        sizing_pools()
     sync_all()
+    torch.cuda.synchronize()
     rows_lib = [int(lb.d_pool_off[-1]) for lb in libs]
     lib_cap = max(4096, int(1.25 * max(rows_lib)) + 1024)            # rows of one library's pool array
     # local pool arrays: [n_lib][lib_cap] rows (slot l = library l: the source layout of gf_pools_merge_dev)
@@ -271,15 +312,13 @@ def main():
                 assert lib.gf_pools_pack_for_owners_dev(h, pool_ptr[l], lb.d_pool_off.data_ptr(), n_gaps, L, world, batch, l, n_lib,
                                                         d_send.data_ptr(), slot_cap, d_libcnt.data_ptr() + 4 * l * n_gaps,
                                                         d_xerr.data_ptr()) == 0
+            all_gather(d_allcnt, d_libcnt)
             if backend == "nccl":
-                dist.all_gather_into_tensor(d_allcnt, d_libcnt)
                 dist.all_to_all_single(d_recv, d_send)
-            else:       # gloo smoke path: through host memory
-                a, s_ = d_allcnt.cpu(), d_send.cpu()
-                r_ = torch.empty_like(s_)
-                dist.all_gather_into_tensor(a, d_libcnt.cpu())
-                dist.all_to_all_single(r_, s_)
-                d_allcnt.copy_(a); d_recv.copy_(r_)
+            else:
+                r_ = torch.empty_like(d_send, device="cpu")
+                dist.all_to_all_single(r_, d_send.cpu())
+                d_recv.copy_(r_)
             assert lib.gf_pools_merge_dev(h, d_recv.data_ptr(), slot_cap, d_allcnt.data_ptr(), n_lib, world, n_gaps, L, rank, world, batch,
                                           d_merged.data_ptr(), merged_cap, d_moff.data_ptr(), d_xerr.data_ptr()) == 0
             asm_ptr, asm_off, asm_rows = d_merged.data_ptr(), d_moff.data_ptr(), merged_cap
@@ -465,8 +504,6 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
     from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle as CO
     from gappadder_amd.pick_contigs import pick_gap_sequence
-    lb = libs[0]
-    n_s = min(args.cpu_sample_reads, lb.n_reads) // 2 * 2
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # a cgroup CPU quota (cpu.max "quota period") caps the usable cores below the visible ones
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -474,20 +511,34 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
             cores = max(1, min(cores, int(q) // int(per)))
     except Exception:
         pass
-    ocfg = np.frombuffer(lb.cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
     CO.set_threads(cores)
-    packed, recs = CO.synth_pairs(ocfg, lb.first_pair, n_s // 2)
-    blob = CO.unpack_reads(packed, L)
     k_s = min(a for a, _ in kk)
-    t0 = time.perf_counter()
-    ohits = CO.screen_reads(blob, L, flanks, k_s, 1, 0, cores)
-    t1 = time.perf_counter()
-    CO.tag_alignments(recs, gaps, lb.is_mean, lb.is_sd)
-    t2 = time.perf_counter()
-    n_hits = int(lb.d_cnt[0])
-    hits = np.frombuffer(lb.d_hits[:n_hits * 8].cpu().numpy().tobytes(), dtype=B.HIT)
-    sub = np.sort(hits[hits["read"] < n_s], order=["gap", "read"])
-    ok = len(sub) == len(ohits) and sub.tobytes() == ohits.astype(B.HIT).tobytes()
+    ok, ok_tag, t_rec, n_rec, n_ohits, notes = True, True, 0.0, 0, 0, []
+    tb = time.perf_counter()
+    CO.screen_reads(b"", L, flanks, k_s, 1, 0, cores)       # the oracle's flank k-mer table alone (built once per run, not per read)
+    t_build = time.perf_counter() - tb
+    for li, lb in enumerate(libs):      # first library: --cpu-sample-reads; further libraries: a quarter of that
+        n_s = min(args.cpu_sample_reads if li == 0 else args.cpu_sample_reads // 4, lb.n_reads) // 2 * 2
+        ocfg = np.frombuffer(lb.cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
+        packed, recs = CO.synth_pairs(ocfg, lb.first_pair, n_s // 2)
+        blob = CO.unpack_reads(packed, L)
+        t0 = time.perf_counter()
+        ohits = CO.screen_reads(blob, L, flanks, k_s, 1, 0, cores)
+        t1 = time.perf_counter()
+        otags = CO.tag_alignments(recs, gaps, lb.is_mean, lb.is_sd)
+        t2 = time.perf_counter()
+        n_hits, n_th = int(lb.d_cnt[0]), int(lb.d_cnt[4])
+        hits = np.frombuffer(lb.d_hits[:n_hits * 8].cpu().numpy().tobytes(), dtype=B.HIT)
+        sub = np.sort(hits[hits["read"] < n_s], order=["gap", "read"])
+        ok = ok and len(sub) == len(ohits) and sub.tobytes() == ohits.astype(B.HIT).tobytes()
+        th = np.frombuffer(lb.d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
+        tsub = np.sort(th[th["rec"] < n_s], order=["rec", "gap", "kind", "to_mate"])
+        ok_tag = ok_tag and len(tsub) == len(otags) and tsub.tobytes() == np.sort(otags.astype(B.TAGHIT), order=["rec", "gap", "kind", "to_mate"]).tobytes()
+        t_rec += max(1e-3, (t1 - t0) - t_build) + (t2 - t1)
+        n_rec += n_s
+        n_ohits += len(ohits)
+        notes.append("%s: first %d reads (k-mer screen %.2f s + alignment tagger %.2f s; %d + %d hits)" % (lb.name, n_s, t1 - t0, t2 - t1, len(ohits), len(otags)))
+    ok = ok and ok_tag
     # assembly sample: the first gaps' pools exactly as the GPU assembled them (all libraries merged)
     n_g = min(len(gaps), 256)
     pool_off = off_t.cpu().numpy()
@@ -514,14 +565,13 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
                 span = max(span, len(r[1]))       # picked slice = span + 1 bases
         ok_pick = ok_pick and span == (int(best[g]) >> 32)
     # whole-step CPU time extrapolated from the two samples (recruit scales with reads, assembly with gaps)
-    cpu_step = (t2 - t0) * (n_screened / n_s) + (t4 - t3) * (len(gaps) / n_g)
+    cpu_step = t_build + t_rec * (n_screened / n_rec) + (t4 - t3) * (len(gaps) / n_g)
     return {"value": n_screened / cpu_step, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "recruit: first %d reads of the first library (k-mer screen %.2f s + alignment tagger %.2f s, OpenMP %d threads); "
-                      "assembly: pools of the first %d gaps at %s (%.2f s, same thread count); value = reads / (sample times scaled to the "
-                      "whole step); oracle/gp_oracle.c" % (n_s, t1 - t0, t2 - t1, cores, n_g, ",".join("%d/%d" % p for p in kk), t4 - t3),
-            "recruit_reads_per_s": n_s / (t2 - t0), "assembly_gaps_per_s": n_g / (t4 - t3),
+            "sample": "flank k-mer table %.2f s (once); recruit, OpenMP %d threads — %s; assembly: pools of the first %d gaps at %s (%.2f s, same thread count); value = reads / "
+                      "(table + sample times scaled to the whole step); oracle/gp_oracle.c" % (t_build, cores, "; ".join(notes), n_g, ",".join("%d/%d" % p for p in kk), t4 - t3),
+            "recruit_reads_per_s": n_rec / t_rec, "table_build_s": t_build, "assembly_gaps_per_s": n_g / (t4 - t3),
             "parity_on_sample": bool(ok and ok_asm and ok_pick), "parity_recruit": bool(ok), "parity_assembly": bool(ok_asm),
-            "parity_pick": bool(ok_pick), "sample_hits": int(len(ohits)), "sample_contigs": int(sum(len(e) for ee in exp for e in ee))}
+            "parity_pick": bool(ok_pick), "sample_hits": int(n_ohits), "sample_contigs": int(sum(len(e) for ee in exp for e in ee))}
 
 
 if __name__ == "__main__":

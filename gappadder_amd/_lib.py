@@ -79,6 +79,7 @@ def lib():
         "gf_tag_low_mapq": (i32, [vp, vp, sz, vp, sz, vp, sz, szp]),
         "gf_tag_low_mapq_dev": (i32, [vp, vp, sz, vp, sz, vp, sz, vp]),
         "gf_second_hop_table_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, sz, vp]),
+        "gf_second_hop_table_merge_dev": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, sz, vp]),
         "gf_tag_low_mapq_table_dev": (i32, [vp, vp, vp, sz, vp, vp, sz, vp, sz, vp]),
         "gf_pool_keys_all_dev": (i32, [vp, vp, vp, sz, i32, vp, vp, vp, sz, vp, vp, sz, vp, vp, sz, vp]),
         "gf_pool_keys_from_second_hop_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, sz, vp]),

@@ -60,6 +60,26 @@ __global__ __launch_bounds__(256) void hop_rows_kernel(const unsigned long long*
     }
 }
 
+// rows of several tables (one per source rank), back to back: key/value arrays for the sort
+__global__ __launch_bounds__(256) void hop_concat_kernel(const gf_dpos* rows_all, const uint32_t* row_gap_all, const uint32_t* n_rows_all,
+                                                         uint32_t n_parts, uint32_t part_cap, unsigned long long* keys, uint32_t* vals,
+                                                         uint32_t row_cap, uint32_t* n_rows) {
+    uint32_t total = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) total += n_rows_all[p] < part_cap ? n_rows_all[p] : part_cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_rows = total;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total && i < row_cap; i += gridDim.x * blockDim.x) {
+        uint32_t p = 0, base = 0;
+        for (;; ++p) {
+            const uint32_t n = n_rows_all[p] < part_cap ? n_rows_all[p] : part_cap;
+            if (i < base + n) break;
+            base += n;
+        }
+        const gf_dpos d = rows_all[(uint64_t)p * part_cap + (i - base)];
+        keys[i] = ((unsigned long long)d.mate_scaffold << 32) | d.mate_pos;
+        vals[i] = row_gap_all[(uint64_t)p * part_cap + (i - base)];
+    }
+}
+
 // sorted rows -> upos (unique (scaffold, position) in order), urow (first row of each, + n at the end), soff (offsets of the
 // scaffolds into upos).  One workgroup: the table has 1e3..1e5 rows.
 __global__ __launch_bounds__(1024) void hop_table_kernel(const gf_dpos* rows, const uint32_t* n_rows, uint32_t row_cap, uint32_t n_scaffolds,
@@ -139,6 +159,42 @@ int gf_second_hop_table_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghi
                        (uint32_t*)d_n_rows);
     hipLaunchKernelGGL(hop_extract_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_alnrec*)d_recs, (const gf_taghit*)d_taghits,
                        (const uint32_t*)d_n_taghits, (uint32_t)hit_cap, ctx->n_scaffolds, k_in, v_in, (uint32_t)row_cap, (uint32_t*)d_n_rows);
+    if (rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, row_cap, 0, end_bit, ctx->stream) != hipSuccess) return GF_E_NODEV;
+    hipLaunchKernelGGL(hop_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, k_out, v_out, (const uint32_t*)d_n_rows, (uint32_t)row_cap,
+                       (const gf_gap*)ctx->d_gaps, (gf_dpos*)d_rows, (uint32_t*)d_row_gap);
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_second_hop_table_merge_dev(gf_ctx* ctx, const void* d_rows_all, const void* d_row_gap_all, const void* d_n_rows_all, int n_parts,
+                                  size_t part_cap, void* d_rows, void* d_row_gap, size_t row_cap, void* d_n_rows) {
+    if (!ctx || !d_rows_all || !d_row_gap_all || !d_n_rows_all || !d_rows || !d_row_gap || !d_n_rows || n_parts < 1 || n_parts > 1024 ||
+        part_cap == 0 || row_cap == 0 || row_cap >= 0x7FFFFFFFull || part_cap >= 0x7FFFFFFFull)
+        return GF_E_INVAL;
+    if (ctx->n_scaffolds == 0 || !ctx->d_gaps) return GF_E_STATE;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned end_bit = 33;
+    while (end_bit < 64 && (ctx->n_scaffolds >> (end_bit - 32)) != 0) ++end_bit;
+    size_t temp_bytes = 0;
+    unsigned long long* nullk = nullptr;
+    uint32_t* nullv = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, nullk, nullk, nullv, nullv, row_cap, 0, end_bit, ctx->stream) != hipSuccess) return GF_E_NODEV;
+    const size_t b_k = (row_cap * 8 + 255) & ~(size_t)255, b_v = (row_cap * 4 + 255) & ~(size_t)255;
+    int rc;
+    if ((rc = ensure(ctx, ctx->rowgap, 2 * b_k + 2 * b_v + temp_bytes + 256))) return rc;
+    ctx->rowgap_rows.clear();
+    uint8_t* w = (uint8_t*)ctx->rowgap.p;
+    unsigned long long* k_in = (unsigned long long*)w;
+    unsigned long long* k_out = (unsigned long long*)(w + b_k);
+    uint32_t* v_in = (uint32_t*)(w + 2 * b_k);
+    uint32_t* v_out = (uint32_t*)(w + 2 * b_k + b_v);
+    void* temp = w + 2 * b_k + 2 * b_v;
+    LaunchTimer tm(ctx, GF_KERNEL_LOWMAPQ);
+    const unsigned grid = (unsigned)std::min<size_t>((row_cap + 255) / 256, (size_t)ctx->n_cu * 4);
+    hipLaunchKernelGGL(hop_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, k_in, (uint32_t)row_cap, (unsigned long long)ctx->n_scaffolds << 32,
+                       (uint32_t*)d_n_rows);
+    hipLaunchKernelGGL(hop_concat_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const gf_dpos*)d_rows_all, (const uint32_t*)d_row_gap_all,
+                       (const uint32_t*)d_n_rows_all, (uint32_t)n_parts, (uint32_t)part_cap, k_in, v_in, (uint32_t)row_cap, (uint32_t*)d_n_rows);
     if (rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, row_cap, 0, end_bit, ctx->stream) != hipSuccess) return GF_E_NODEV;
     hipLaunchKernelGGL(hop_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, k_out, v_out, (const uint32_t*)d_n_rows, (uint32_t)row_cap,
                        (const gf_gap*)ctx->d_gaps, (gf_dpos*)d_rows, (uint32_t*)d_row_gap);

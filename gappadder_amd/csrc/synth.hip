@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void synth_kernel(gf_synth_cfg c, uint64_t fir
     if (c.read_len & 3) o[rb - 1] = (uint8_t)(acc << (2 * (4 - (c.read_len & 3))));
     if (recs) {
         uint32_t r[2][8];
-        gfs_make_records(&c, first_pair + lp, &p, r);
+        gfs_make_records(&c, lp, &p, r);   // read id = index in THIS batch (what the pool builder gathers by)
         uint4* dst = reinterpret_cast<uint4*>(recs + (2 * lp + end) * 8);
         dst[0] = make_uint4(r[end][0], r[end][1], r[end][2], r[end][3]);
         dst[1] = make_uint4(r[end][4], r[end][5], r[end][6], r[end][7]);

@@ -257,6 +257,12 @@ int gf_tag_low_mapq_compact_dev(gf_ctx* ctx, const void* d_low, const void* d_n_
  * particular order (the reference's -k3n -k4n): they produce the same hits. */
 int gf_second_hop_table_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits, size_t hit_cap,
                             void* d_rows, void* d_row_gap, size_t row_cap, void* d_n_rows);
+/* Multi-GPU runs shard the reads, but the second hop links a MAPQ-0 record to discordant mates of ANY read: every rank builds the
+ * rows of its records (gf_second_hop_table_dev), the ranks all-gather rows / row gaps / counts (fixed part_cap slots), and this
+ * call concatenates the n_parts slots and sorts them again — the table of a single-process run up to the order of equal keys.
+ * d_rows_all: gf_dpos [n_parts][part_cap]; d_row_gap_all: u32 [n_parts][part_cap]; d_n_rows_all: u32 [n_parts]. */
+int gf_second_hop_table_merge_dev(gf_ctx* ctx, const void* d_rows_all, const void* d_row_gap_all, const void* d_n_rows_all, int n_parts,
+                                  size_t part_cap, void* d_rows, void* d_row_gap, size_t row_cap, void* d_n_rows);
 /* second hop over the compacted MAPQ-0 list against a DEVICE table (d_rows / d_n_rows as written by gf_second_hop_table_dev,
  * or any sorted gf_dpos array in HBM); hit.gap = row index, as with gf_tag_low_mapq */
 int gf_tag_low_mapq_table_dev(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const void* d_rows,
@@ -349,7 +355,8 @@ int gf_timing_reset(gf_ctx* ctx);
 
 /* ---- synthetic workload (bench/test utility, not part of the reference's path; definition: include/gf_synth.h,
  * shared bit-for-bit with oracle/gp_oracle.c).  gf_synth_pairs_dev fills 2*n_pairs packed reads (read 2p+m =
- * mate m+1 of pair first_pair+p) and, optionally, 2*n_pairs gf_alnrec (record 2p+e = forward/reverse end).
+ * mate m+1 of pair first_pair+p) and, optionally, 2*n_pairs gf_alnrec (record 2p+e = forward/reverse end; record.read = 2p+m,
+ * the read's index in THIS batch).
  * gf_synth_layout writes the n_scaffolds*gaps_per_scaffold gaps and their flanks (2*(flank_len-5) bases per gap). */
 int gf_synth_pairs_dev(gf_ctx* ctx, const void* cfg /* gf_synth_cfg */, uint64_t first_pair, size_t n_pairs,
                        void* d_packed_reads, void* d_alnrecs_or_null);

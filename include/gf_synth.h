@@ -128,7 +128,8 @@ GFS_HD void gfs_align(const gf_synth_cfg* c, uint64_t lo, gfs_aln* o) {
     }
 }
 
-/* the two 32-byte alignment records of a pair, as 8 x uint32 each (layout of gf_alnrec) */
+/* the two 32-byte alignment records of a pair, as 8 x uint32 each (layout of gf_alnrec); `pair` only numbers the read ids
+ * (2 * pair + mate): the generators pass the pair's index inside the generated batch, so that record.read indexes the batch's reads */
 GFS_HD void gfs_make_records(const gf_synth_cfg* c, uint64_t pair, const gfs_pair* p, uint32_t out[2][8]) {
     gfs_aln al[2];
     gfs_align(c, p->p[0], &al[0]);

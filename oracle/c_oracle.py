@@ -46,6 +46,8 @@ def lib():
         L.or_count_kmers.argtypes = [C.c_char_p, sz, i32, i32, i32, vp, vp, vp, sz]
         L.or_assemble_pool.restype = sz
         L.or_assemble_pool.argtypes = [C.c_char_p, sz, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
+        L.or_assemble_pool2.restype = sz
+        L.or_assemble_pool2.argtypes = [C.c_char_p, sz, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
         L.or_synth_pairs.restype = None
         L.or_synth_pairs.argtypes = [vp, C.c_uint64, sz, vp, vp]
         L.or_synth_layout.restype = None
@@ -149,16 +151,17 @@ def count_kmers(reads_blob, read_len, k, min_count=2):
     return hi[:m], lo[:m], cnt[:m]
 
 
-def assemble_pool(reads_blob, read_len, k, kv, min_count=2, min_contig=40):
-    """[(sequence, n_nodes, cov_sum)] sorted by (-length, sequence)."""
+def assemble_pool(reads_blob, read_len, k, kv, min_count=2, min_contig=40, simplify=0):
+    """[(sequence, n_nodes, cov_sum)] sorted by (-length, sequence).  simplify = rounds of tip clipping + bubble popping
+    (0: raw unitigs)."""
     n = len(reads_blob) // read_len
     cap = max(16, n * (read_len - k + 1))
     nn = np.zeros(cap, np.uint32); ln = np.zeros(cap, np.uint32); cv = np.zeros(cap, np.uint32)
     scap = max(1024, 8 * n * read_len)
     seq = np.zeros(scap, np.uint8)
     need = C.c_size_t(0)
-    m = lib().or_assemble_pool(bytes(reads_blob), n, read_len, k, kv, min_count, min_contig, _p(nn), _p(ln), _p(cv), cap,
-                               _p(seq), scap, C.byref(need))
+    m = lib().or_assemble_pool2(bytes(reads_blob), n, read_len, k, kv, min_count, min_contig, simplify, _p(nn), _p(ln), _p(cv), cap,
+                                _p(seq), scap, C.byref(need))
     assert m <= cap and need.value <= scap
     out, off = [], 0
     b = seq.tobytes()

@@ -304,7 +304,7 @@ void or_synth_pairs(const void* c_, uint64_t first_pair, size_t n_pairs, uint8_t
         }
         if (recs) {
             uint32_t r[2][8];
-            gfs_make_records(c, first_pair + lp, &p, r);
+            gfs_make_records(c, (uint64_t)lp, &p, r);   /* read id = index in this batch */
             memcpy(&recs[2 * lp], r[0], 32);
             memcpy(&recs[2 * lp + 1], r[1], 32);
         }
@@ -392,24 +392,15 @@ size_t or_count_kmers(const char* reads, size_t n_reads, int L, int k, int min_c
     return w;
 }
 
-typedef struct { k128 key; uint32_t mult; uint8_t out, in; } or_node;
+typedef struct { k128 key; uint32_t mult; uint8_t out, in, dead; } or_node;
 static long node_find(const or_node* nd, size_t n, k128 key) {
     size_t a = 0, b = n;
     while (a < b) { size_t m = (a + b) / 2; if (k128_lt(nd[m].key, key)) a = m + 1; else b = m; }
     return (a < n && k128_eq(nd[a].key, key)) ? (long)a : -1;
 }
-static inline unsigned bits_out(const or_node* nd, long i, int d) { /* oriented out-edges, bit c = next base c */
-    if (!d) return nd[i].out;
-    unsigned r = 0;
-    for (int c = 0; c < 4; ++c) if (nd[i].in & (1u << (3 - c))) r |= 1u << c;
-    return r;
-}
-static inline unsigned bits_in(const or_node* nd, long i, int d) {
-    if (!d) return nd[i].in;
-    unsigned r = 0;
-    for (int c = 0; c < 4; ++c) if (nd[i].out & (1u << (3 - c))) r |= 1u << c;
-    return r;
-}
+static inline unsigned rev4(unsigned b) { return ((b & 1) << 3) | ((b & 2) << 1) | ((b & 4) >> 1) | ((b & 8) >> 3); }
+static inline unsigned bits_out(const or_node* nd, long i, int d) { return d ? rev4(nd[i].in) : nd[i].out; } /* bit c = next base c */
+static inline unsigned bits_in(const or_node* nd, long i, int d) { return d ? rev4(nd[i].out) : nd[i].in; }  /* bit c = previous base c */
 static inline int popc4(unsigned b) { return (b & 1) + ((b >> 1) & 1) + ((b >> 2) & 1) + ((b >> 3) & 1); }
 static inline int ctz4(unsigned b) { return (b & 1) ? 0 : (b & 2) ? 1 : (b & 4) ? 2 : 3; }
 
@@ -420,11 +411,168 @@ static int ctg_cmp(const void* a, const void* b) {
     return strcmp(x->seq, y->seq);
 }
 
+/* ---- the kv-mer graph of one pool.  Oriented node o = 2 * index + d (d = 1: the reverse complement of the stored key). */
+typedef struct {
+    or_node* nd; size_t nn; int kv;
+    /* unitig decomposition of the live graph (graph_unitigs): per ORIENTED node */
+    uint32_t* head;   /* head of the oriented unitig the oriented node lies on (NONE on an isolated cycle) */
+    uint32_t* tail;   /* [head]: last oriented node */
+    uint32_t* len;    /* [head]: nodes */
+    uint32_t* cov;    /* [head]: sum of the nodes' multiplicities */
+    uint32_t* next;   /* unitig-internal successor, or NONE */
+    k128* ukey;       /* [head]: min(first kv-mer of the unitig, first kv-mer of its reverse) — orientation-free order */
+    uint8_t* kill;    /* [node index]: marked for removal in this round */
+} or_graph;
+#define OR_NONE 0xFFFFFFFFu
+
+static k128 g_oseq(const or_graph* G, uint32_t o) { return (o & 1) ? k128_rc(G->nd[o >> 1].key, G->kv) : G->nd[o >> 1].key; }
+static unsigned g_out(const or_graph* G, uint32_t o) { return bits_out(G->nd, (long)(o >> 1), (int)(o & 1)); }
+static unsigned g_in(const or_graph* G, uint32_t o) { return bits_in(G->nd, (long)(o >> 1), (int)(o & 1)); }
+/* oriented successor of o along base c / oriented predecessor that has base c in front */
+static uint32_t g_succ(const or_graph* G, uint32_t o, unsigned c) {
+    k128 cur = g_oseq(G, o), y = {0, 0};
+    for (int q = 0; q + 1 < G->kv; ++q) k128_set(&y, q, k128_base(cur, q + 1));
+    k128_set(&y, G->kv - 1, c);
+    int dy;
+    k128 Y = k128_canon(y, G->kv, &dy);
+    long iy = node_find(G->nd, G->nn, Y);
+    return iy < 0 ? OR_NONE : (uint32_t)(2 * iy + dy);
+}
+static uint32_t g_pred(const or_graph* G, uint32_t o, unsigned c) {
+    k128 cur = g_oseq(G, o), p = {0, 0};
+    k128_set(&p, 0, c);
+    for (int q = 1; q < G->kv; ++q) k128_set(&p, q, k128_base(cur, q - 1));
+    int dp;
+    k128 P = k128_canon(p, G->kv, &dp);
+    long ip = node_find(G->nd, G->nn, P);
+    return ip < 0 ? OR_NONE : (uint32_t)(2 * ip + dp);
+}
+
+/* unitigs of the live graph: an oriented node STARTS a unitig iff its in-degree != 1 or its unique predecessor's out-degree
+ * != 1; a walk extends while out-degree == 1 and the successor's in-degree == 1 */
+static void graph_unitigs(or_graph* G) {
+    const size_t no = 2 * G->nn;
+    for (size_t o = 0; o < no; ++o) { G->head[o] = OR_NONE; G->next[o] = OR_NONE; }
+    for (size_t o = 0; o < no; ++o) {
+        if (G->nd[o >> 1].dead) continue;
+        unsigned ib = g_in(G, (uint32_t)o);
+        int start = popc4(ib) != 1;
+        if (!start) start = popc4(g_out(G, g_pred(G, (uint32_t)o, (unsigned)ctz4(ib)))) != 1;
+        if (!start) continue;
+        uint32_t cur = (uint32_t)o, n = 1, cov = G->nd[o >> 1].mult;
+        G->head[o] = (uint32_t)o;
+        for (;;) {
+            unsigned ob = g_out(G, cur);
+            if (popc4(ob) != 1) break;
+            uint32_t y = g_succ(G, cur, (unsigned)ctz4(ob));
+            if (popc4(g_in(G, y)) != 1) break;
+            G->next[cur] = y;
+            G->head[y] = (uint32_t)o;
+            cur = y; ++n; cov += G->nd[y >> 1].mult;
+        }
+        G->tail[o] = cur; G->len[o] = n; G->cov[o] = cov;
+        k128 a = g_oseq(G, (uint32_t)o), b = k128_rc(g_oseq(G, cur), G->kv);
+        G->ukey[o] = k128_lt(b, a) ? b : a;
+    }
+}
+
+/* Velvet's default error removal (velvetg without -cov_cutoff: tip clipping + Tour Bus bubble popping), DEFINED
+ * here on the unitig graph — Velvet itself is absent, and its coverage-based choices are coin flips on this input where every
+ * surviving k-mer is one read (assemble_gaps.py:104-118), so ties are broken by an orientation-free sequence order:
+ *   X beats Y  :=  (cov X, then the SMALLER ukey) wins, preceded by (nodes) where lengths can differ.
+ * One round decides on ONE snapshot of the graph, for every oriented unitig X (head h, tail t, n nodes):
+ *  TIP     out-degree(t) == 0, in-degree(h) == 1 with predecessor p of out-degree >= 2, n <= kv (i.e. n + kv - 1 < 2 kv bases:
+ *          Velvet's tip length), and some OTHER branch Y leaving p beats X: Y is not tip-shaped itself (tip-shaped = dead end,
+ *          n <= kv, in-degree(head) == 1), or (n, cov, smaller ukey) of Y > that of X.  So of several tips on one junction the
+ *          best one stays when nothing longer leaves the junction.
+ *  BUBBLE  in-degree(h) == 1 with predecessor p of out-degree >= 2, out-degree(t) == 1 with successor s of in-degree >= 2,
+ *          n <= 2 kv, and there is an alternative path p -> A1 .. Am -> s of whole unitigs (m <= 4, none of them X or its reverse)
+ *          with exactly n nodes in total (substitution bubbles), and (m >= 2, or A1 beats X by (cov, smaller ukey)).
+ * Removed unitigs lose all their nodes and the arcs p -> h and t -> s.  Rounds repeat (at most `rounds`) while something was
+ * removed; every round re-derives the unitigs. */
+#define OR_ALT_DEPTH 4
+static int tip_shaped(const or_graph* G, uint32_t h) {
+    return popc4(g_out(G, G->tail[h])) == 0 && G->len[h] <= (uint32_t)G->kv && popc4(g_in(G, h)) == 1;
+}
+/* does Y (head y) beat X (head x)?  with_len: compare node counts first */
+static int beats(const or_graph* G, uint32_t y, uint32_t x, int with_len) {
+    if (with_len && G->len[y] != G->len[x]) return G->len[y] > G->len[x];
+    if (G->cov[y] != G->cov[x]) return G->cov[y] > G->cov[x];
+    return k128_lt(G->ukey[y], G->ukey[x]);
+}
+/* alternative paths from tail q (q = p at depth 0) to s with exactly `remain` nodes; returns 1 when X must go */
+static int alt_search(const or_graph* G, uint32_t q, uint32_t s, uint32_t remain, int depth, uint32_t x) {
+    const uint32_t xr = G->tail[x] ^ 1u;   /* head of X reversed */
+    unsigned ob = g_out(G, q);
+    for (unsigned c = 0; c < 4; ++c) {
+        if (!(ob & (1u << c))) continue;
+        uint32_t y = g_succ(G, q, c);
+        if (y == OR_NONE || G->head[y] != y) continue;   /* (always a head; guards a corrupt graph) */
+        if (y == x || y == xr) continue;
+        if (G->len[y] > remain) continue;
+        if (G->len[y] == remain) {
+            unsigned tb = g_out(G, G->tail[y]);
+            int reaches = 0;
+            for (unsigned c2 = 0; c2 < 4; ++c2) if ((tb & (1u << c2)) && g_succ(G, G->tail[y], c2) == s) reaches = 1;
+            if (!reaches) continue;
+            if (depth >= 1 || beats(G, y, x, 0)) return 1;
+        } else if (depth + 1 < OR_ALT_DEPTH) {
+            if (alt_search(G, G->tail[y], s, remain - G->len[y], depth + 1, x)) return 1;
+        }
+    }
+    return 0;
+}
+static size_t simplify_round(or_graph* G) {
+    const size_t no = 2 * G->nn;
+    memset(G->kill, 0, G->nn);
+    size_t removed = 0;
+    for (size_t o = 0; o < no; ++o) {
+        if (G->nd[o >> 1].dead || G->head[o] != o) continue;
+        const uint32_t h = (uint32_t)o, t = G->tail[h], n = G->len[h];
+        unsigned ib = g_in(G, h);
+        if (popc4(ib) != 1) continue;
+        const uint32_t p = g_pred(G, h, (unsigned)ctz4(ib));
+        const unsigned pb = g_out(G, p);
+        if (popc4(pb) < 2) continue;
+        int go = 0;
+        const unsigned tb = g_out(G, t);
+        if (popc4(tb) == 0 && n <= (uint32_t)G->kv) {                       /* TIP */
+            for (unsigned c = 0; c < 4 && !go; ++c) {
+                if (!(pb & (1u << c))) continue;
+                uint32_t y = g_succ(G, p, c);
+                if (y == OR_NONE || y == h || G->head[y] != y || y == (t ^ 1u)) continue;
+                if (!tip_shaped(G, y) || beats(G, y, h, 1)) go = 1;
+            }
+        } else if (popc4(tb) == 1 && n <= 2u * (uint32_t)G->kv) {           /* BUBBLE */
+            const uint32_t s = g_succ(G, t, (unsigned)ctz4(tb));
+            if (s != OR_NONE && popc4(g_in(G, s)) >= 2) go = alt_search(G, p, s, n, 0, h);
+        }
+        if (!go) continue;
+        for (uint32_t cur = h;; cur = G->next[cur]) { G->kill[cur >> 1] = 1; if (cur == t) break; }
+        ++removed;
+    }
+    if (!removed) return 0;
+    for (size_t i = 0; i < G->nn; ++i) if (G->kill[i]) G->nd[i].dead = 1;
+    /* arcs into removed nodes disappear (by the rules these are exactly p -> h and t -> s of every removed unitig) */
+    for (size_t o = 0; o < no; ++o) {
+        if (G->nd[o >> 1].dead) continue;
+        unsigned ob = g_out(G, (uint32_t)o);
+        for (unsigned c = 0; c < 4; ++c) {
+            if (!(ob & (1u << c))) continue;
+            uint32_t y = g_succ(G, (uint32_t)o, c);
+            if (y != OR_NONE && !G->nd[y >> 1].dead) continue;
+            if (!(o & 1)) G->nd[o >> 1].out &= (uint8_t)~(1u << c); else G->nd[o >> 1].in &= (uint8_t)~(1u << (3 - c));
+        }
+    }
+    return removed;
+}
+
 /* contigs of one pool.  seq_out receives the sequences back to back (no terminators); per contig n_nodes[], length[],
- * cov_sum[].  Returns the number of contigs (may exceed cap; *seq_need = bytes needed). */
-size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig,
-                        uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
-                        size_t* seq_need) {
+ * cov_sum[].  simplify = rounds of tip clipping + bubble popping (0: raw unitigs; 2: the default of the product).
+ * Returns the number of contigs (may exceed cap; *seq_need = bytes needed). */
+size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig, int simplify,
+                         uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
+                         size_t* seq_need) {
     *seq_need = 0;
     if (kv >= k || !(kv & 1) || k > 64 || L < k) return 0;
     size_t tot = n_reads * (size_t)(L - k + 1);
@@ -443,7 +591,7 @@ size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv,
     for (size_t i = 0; i < nk;) {
         size_t j = i;
         while (j < nk && k128_eq(keys[j], keys[i])) ++j;
-        nd[nn].key = keys[i]; nd[nn].mult = (uint32_t)(j - i); nd[nn].out = nd[nn].in = 0; ++nn;
+        nd[nn].key = keys[i]; nd[nn].mult = (uint32_t)(j - i); nd[nn].out = nd[nn].in = nd[nn].dead = 0; ++nn;
         i = j;
     }
     for (size_t s = 0; s < ns; ++s) { /* edges */
@@ -457,53 +605,32 @@ size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv,
             if (!db) nd[ib].in |= 1u << c_in; else nd[ib].out |= 1u << (3 - c_in);
         }
     }
+    or_graph G;
+    G.nd = nd; G.nn = nn; G.kv = kv;
+    G.head = malloc((2 * nn + 1) * 4); G.tail = malloc((2 * nn + 1) * 4); G.len = malloc((2 * nn + 1) * 4);
+    G.cov = malloc((2 * nn + 1) * 4); G.next = malloc((2 * nn + 1) * 4); G.ukey = malloc((2 * nn + 1) * sizeof(k128));
+    G.kill = malloc(nn + 1);
+    graph_unitigs(&G);
+    for (int round = 0; round < simplify; ++round) {
+        if (!simplify_round(&G)) break;
+        graph_unitigs(&G);
+    }
     or_ctg* ctg = malloc((2 * nn + 1) * sizeof(or_ctg));
     size_t nc = 0;
-    for (size_t i = 0; i < nn; ++i)
-        for (int d = 0; d < 2; ++d) {
-            /* start? */
-            unsigned ib = bits_in(nd, (long)i, d);
-            int start = popc4(ib) != 1;
-            k128 cur = d ? k128_rc(nd[i].key, kv) : nd[i].key;
-            if (!start) {
-                k128 p = {0, 0};
-                k128_set(&p, 0, (unsigned)ctz4(ib));
-                for (int q = 1; q < kv; ++q) k128_set(&p, q, k128_base(cur, q - 1));
-                int dp;
-                k128 P = k128_canon(p, kv, &dp);
-                long ip = node_find(nd, nn, P);
-                start = popc4(bits_out(nd, ip, dp)) != 1;
-            }
-            if (!start) continue;
-            /* walk */
-            size_t capb = 64;
-            char* seq = malloc(capb + kv + 2);
-            size_t len = 0;
-            for (int q = 0; q < kv; ++q) seq[len++] = "ACGT"[k128_base(cur, q)];
-            uint32_t nodes = 1, cov = nd[i].mult;
-            long ci = (long)i; int cd = d;
-            for (;;) {
-                unsigned ob = bits_out(nd, ci, cd);
-                if (popc4(ob) != 1) break;
-                unsigned c = (unsigned)ctz4(ob);
-                k128 y = {0, 0};
-                for (int q = 0; q + 1 < kv; ++q) k128_set(&y, q, k128_base(cur, q + 1));
-                k128_set(&y, kv - 1, c);
-                int dy;
-                k128 Y = k128_canon(y, kv, &dy);
-                long iy = node_find(nd, nn, Y);
-                if (popc4(bits_in(nd, iy, dy)) != 1) break;
-                if (len + 2 > capb + kv) { capb *= 2; seq = realloc(seq, capb + kv + 2); }
-                seq[len++] = "ACGT"[c];
-                ++nodes; cov += nd[iy].mult;
-                ci = iy; cd = dy; cur = y;
-            }
-            seq[len] = 0;
-            /* emit rule: first kv-mer of this walk <= first kv-mer of the opposite walk (= revcomp of the last kv-mer) */
-            k128 opp = k128_rc(cur, kv), first = d ? k128_rc(nd[i].key, kv) : nd[i].key;
-            if (k128_lt(opp, first) || (int)len < min_contig) { free(seq); continue; }
-            ctg[nc].n_nodes = nodes; ctg[nc].length = (uint32_t)len; ctg[nc].cov_sum = cov; ctg[nc].seq = seq; ++nc;
-        }
+    for (size_t o = 0; o < 2 * nn; ++o) {
+        if (nd[o >> 1].dead || G.head[o] != o) continue;
+        const uint32_t t = G.tail[o], nodes = G.len[o];
+        const size_t len = (size_t)nodes + kv - 1;
+        /* emit rule: first kv-mer of this walk <= first kv-mer of the opposite walk (= revcomp of the last kv-mer) */
+        k128 first = g_oseq(&G, (uint32_t)o), opp = k128_rc(g_oseq(&G, t), kv);
+        if (k128_lt(opp, first) || (int)len < min_contig) continue;
+        char* seq = malloc(len + 1);
+        size_t w = 0;
+        for (int q = 0; q < kv; ++q) seq[w++] = "ACGT"[k128_base(first, q)];
+        for (uint32_t cur = G.next[o]; cur != OR_NONE; cur = G.next[cur]) seq[w++] = "ACGT"[k128_base(g_oseq(&G, cur), kv - 1)];
+        seq[w] = 0;
+        ctg[nc].n_nodes = nodes; ctg[nc].length = (uint32_t)len; ctg[nc].cov_sum = G.cov[o]; ctg[nc].seq = seq; ++nc;
+    }
     qsort(ctg, nc, sizeof(or_ctg), ctg_cmp);
     size_t off = 0;
     for (size_t c = 0; c < nc; ++c) {
@@ -513,6 +640,13 @@ size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv,
         free(ctg[c].seq);
     }
     *seq_need = off;
-    free(ctg); free(nd); free(keys); free(hi); free(lo); free(cn);
+    free(ctg); free(G.head); free(G.tail); free(G.len); free(G.cov); free(G.next); free(G.ukey); free(G.kill);
+    free(nd); free(keys); free(hi); free(lo); free(cn);
     return nc;
+}
+
+size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig,
+                        uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
+                        size_t* seq_need) {   /* raw unitigs (no error removal) */
+    return or_assemble_pool2(reads, n_reads, L, k, kv, min_count, min_contig, 0, n_nodes, length, cov_sum, cap, seq_out, seq_cap, seq_need);
 }

@@ -33,6 +33,10 @@ size_t or_count_kmers(const char* reads, size_t n_reads, int L, int k, int min_c
 size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig,
                         uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
                         size_t* seq_need);
+/* same with `simplify` rounds of tip clipping + bubble popping (Velvet's defaults, as defined in gp_oracle.c); 0 = raw unitigs */
+size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig, int simplify,
+                         uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
+                         size_t* seq_need);
 /* synthetic workload, definition in include/gf_synth.h (cfg = gf_synth_cfg) */
 void or_synth_pairs(const void* cfg, uint64_t first_pair, size_t n_pairs, uint8_t* packed, or_alnrec* recs_or_null);
 void or_synth_layout(const void* cfg, or_gap* gaps, char* flank_ascii, uint64_t* flank_off);

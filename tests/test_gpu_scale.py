@@ -1,0 +1,325 @@
+"""GPU tests of the multi-library / multi-GPU plumbing and of the BASELINE.json configurations at their full sizes
+(§8e): owner-rank exchange kernels, library merge order, multi-k assembly call, device flank
+anchoring vs the host picker, the 2-rank owner assembly vs the single-process run, and bench.py's sample parity at full size."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _dev(t):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(t)).cuda()
+
+
+def _random_pools(rng, n_gaps, rb, max_rows):
+    cnt = rng.integers(0, max_rows + 1, size=n_gaps)
+    cnt[rng.integers(0, n_gaps, size=max(1, n_gaps // 5))] = 0          # empty pools
+    off = np.zeros(n_gaps + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(cnt)
+    rows = rng.integers(0, 256, size=(int(off[-1]), rb), dtype=np.uint8)
+    return rows, off
+
+
+@pytest.mark.parametrize("world,n_lib,n_gaps,batch,L", [(3, 1, 37, 4, 150), (4, 2, 1030, 256, 150), (2, 2, 19, 3, 101), (1, 3, 50, 256, 150)])
+def test_owner_exchange_and_library_merge_kernels(world, n_lib, n_gaps, batch, L):
+    """gf_pools_pack_for_owners_dev + (the all-to-all, done here by slicing) + gf_pools_merge_dev == the definition: every gap's
+    rows at its owner, libraries in order, inside a library the source ranks in order (merge_reads.py:43-51)."""
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    lib = B.lib()
+    rb = lib.gf_packed_read_bytes(L)
+    rng = np.random.default_rng(world * 100 + n_lib)
+    gf = GapFill(0)
+    h = gf.handle
+    pools = [[_random_pools(rng, n_gaps, rb, 40) for _ in range(n_lib)] for _ in range(world)]     # [rank][lib] -> (rows, off)
+    owner = (np.arange(n_gaps) // batch) % world
+    cap = 1 + max(int(sum(int(off[g + 1] - off[g]) for g in range(n_gaps) if owner[g] == d))
+                  for r in range(world) for (_, off) in pools[r] for d in range(world))
+    sends, cnts = [], []
+    for r in range(world):
+        d_send = torch.zeros(world * n_lib * cap * rb, dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros(n_lib * n_gaps, dtype=torch.int32, device="cuda")
+        d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for l, (rows, off) in enumerate(pools[r]):
+            d_rows, d_off = _dev(rows.reshape(-1) if len(rows) else np.zeros(1, np.uint8)), _dev(off.view(np.int64))
+            assert lib.gf_pools_pack_for_owners_dev(h, d_rows.data_ptr(), d_off.data_ptr(), n_gaps, L, world, batch, l, n_lib,
+                                                    d_send.data_ptr(), cap, d_cnt.data_ptr() + 4 * l * n_gaps, d_err.data_ptr()) == 0
+        gf.sync()
+        assert int(d_err[0]) == 0
+        sends.append(d_send.cpu().numpy().reshape(world, n_lib * cap * rb))
+        cnts.append(d_cnt.cpu().numpy())
+        for l, (rows, off) in enumerate(pools[r]):
+            assert (cnts[-1][l * n_gaps:(l + 1) * n_gaps] == np.diff(off.astype(np.int64))).all()
+    all_cnt = np.concatenate(cnts)                                          # [rank][lib][gap] = all_gather_into_tensor
+    total = 0
+    for me in range(world):
+        recv = np.concatenate([sends[src][me] for src in range(world)])    # all_to_all_single with equal slots
+        want_rows, want_off = [], [0]
+        for g in range(n_gaps):
+            if owner[g] == me:
+                for l in range(n_lib):
+                    for r in range(world):
+                        rows, off = pools[r][l]
+                        want_rows.append(rows[int(off[g]):int(off[g + 1])])
+            want_off.append(sum(len(x) for x in want_rows))
+        want = np.concatenate(want_rows) if want_rows else np.zeros((0, rb), np.uint8)
+        mcap = len(want) + 3
+        d_merged = torch.zeros(mcap * rb + 8, dtype=torch.uint8, device="cuda")
+        d_moff = torch.zeros(n_gaps + 1, dtype=torch.int64, device="cuda")
+        d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        assert lib.gf_pools_merge_dev(h, _dev(recv).data_ptr(), cap, _dev(all_cnt).data_ptr(), n_lib, world, n_gaps, L, me, world, batch,
+                                      d_merged.data_ptr(), mcap, d_moff.data_ptr(), d_err.data_ptr()) == 0
+        gf.sync()
+        assert int(d_err[0]) == 0
+        assert d_moff.cpu().numpy().tolist() == want_off
+        assert d_merged.cpu().numpy()[:len(want) * rb].tobytes() == want.tobytes()
+        total += len(want)
+        # a merged buffer that is too small is flagged, never overrun
+        if len(want) > 4:
+            small = torch.full(((len(want) - 2) * rb + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+            assert lib.gf_pools_merge_dev(h, _dev(recv).data_ptr(), cap, _dev(all_cnt).data_ptr(), n_lib, world, n_gaps, L, me, world, batch,
+                                          small.data_ptr(), len(want) - 2, d_moff.data_ptr(), d_err.data_ptr()) == 0
+            gf.sync()
+            assert int(d_err[0]) & 0x80000000 and (small.cpu().numpy()[(len(want) - 2) * rb:] == 0xEE).all()
+    assert total == sum(len(rows) for r in range(world) for rows, _ in pools[r])
+
+
+def test_pack_flags_a_send_slot_that_is_too_small():
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    lib = B.lib()
+    gf = GapFill(0)
+    rng = np.random.default_rng(5)
+    rows, off = _random_pools(rng, 64, 38, 30)
+    d_send = torch.full((2 * 8 * 38 + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(64, dtype=torch.int32, device="cuda")
+    d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert lib.gf_pools_pack_for_owners_dev(gf.handle, _dev(rows.reshape(-1)).data_ptr(), _dev(off.view(np.int64)).data_ptr(), 64, 150, 2, 4, 0, 1,
+                                            d_send.data_ptr(), 8, d_cnt.data_ptr(), d_err.data_ptr()) == 0
+    gf.sync()
+    assert int(d_err[0]) & 0x40000000 and (d_send.cpu().numpy()[2 * 8 * 38:] == 0xEE).all()
+
+
+def _rand_seq(rng, n):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+
+
+def test_device_flank_anchoring_equals_the_host_picker():
+    """gf_pick_anchored_dev vs pick_contigs.pick_gap_sequence (the definition of "closed", pick_contigs.py:64-358 with exact
+    anchors): both orientations, repeated anchors (longest span), anchors in the wrong order, overlapping anchors, a contig
+    shorter than the anchors, a gap without flanks."""
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    from gappadder_amd.pick_contigs import pick_gap_sequence, revcomp
+    rng = np.random.default_rng(11)
+    n_gaps = 40
+    flanks = [(_rand_seq(rng, 120), _rand_seq(rng, 120)) for _ in range(n_gaps)]
+    flanks[7] = ("ACGT" * 5, "TTGA" * 5)              # shorter than anchor 30
+    flanks[8] = (flanks[8][0][:-3] + "NNN", flanks[8][1])
+    gaps = np.zeros(n_gaps, dtype=B.GAP)
+    for g in range(n_gaps):
+        gaps[g] = (0, 1000 * (g + 1), 1000 * (g + 1) + 100, g + 1)
+    contigs = []                                          # (gap, seq)
+    for g in range(n_gaps):
+        l, r = flanks[g]
+        for a in (30, 15):
+            la, ra = l[-a:], r[:a]
+            mid = _rand_seq(rng, int(rng.integers(0, 300)))
+            kind = (g + a) % 8
+            if kind == 0:
+                s = _rand_seq(rng, 50) + la + mid + ra + _rand_seq(rng, 40)
+            elif kind == 1:
+                s = revcomp(_rand_seq(rng, 20) + la + mid + ra + _rand_seq(rng, 5))
+            elif kind == 2:                               # repeated anchors: leftmost left / rightmost right
+                s = la + _rand_seq(rng, 30) + la + mid + ra + _rand_seq(rng, 17) + ra
+            elif kind == 3:                               # wrong order
+                s = ra + mid + la
+            elif kind == 4:                               # anchors back to back (span 0)
+                s = _rand_seq(rng, 9) + la + ra
+            elif kind == 5:                               # only one anchor
+                s = _rand_seq(rng, 60) + la + mid
+            elif kind == 6:                               # right anchor overlapping the left anchor's end: no pair
+                s = la[:-5] + ra
+            else:
+                s = _rand_seq(rng, int(rng.integers(10, 25)))
+            contigs.append((g, s))
+        contigs.append((g, _rand_seq(rng, 200)))
+    order = rng.permutation(len(contigs))
+    contigs = [contigs[i] for i in order]
+    ctg = np.zeros(len(contigs), dtype=B.CONTIG)
+    seq = "".join(s for _, s in contigs)
+    o = 0
+    for i, (g, s) in enumerate(contigs):
+        ctg[i] = (g, 31, 29, max(1, len(s) - 28), len(s), 0, 0, o)
+        o += len(s)
+    gf = GapFill(0)
+    gf.set_gaps(gaps, 1, flanks)
+    lib = B.lib()
+    d_ctg, d_seq = _dev(ctg.view(np.uint8)), _dev(np.frombuffer(seq.encode(), dtype=np.uint8))
+    d_n = torch.tensor([len(contigs)], dtype=torch.int32, device="cuda")
+    d_best = torch.zeros(n_gaps, dtype=torch.int64, device="cuda")
+    d_closed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    closed_host = 0
+    for a in (30, 15):
+        assert lib.gf_pick_anchored_dev(gf.handle, d_ctg.data_ptr(), d_n.data_ptr(), len(contigs), d_seq.data_ptr(), a, d_best.data_ptr(),
+                                        d_closed.data_ptr()) == 0
+    gf.sync()
+    best = d_best.cpu().numpy().view(np.uint64)
+    n_some = 0
+    for g in range(n_gaps):
+        mine = [("c%d" % i, s) for i, (gg, s) in enumerate(contigs) if gg == g]
+        want = 0
+        for a in (30, 15):
+            r = pick_gap_sequence(mine, flanks[g][0], flanks[g][1], a)
+            if r is not None:
+                want = max(want, len(r[1]))
+        assert int(best[g]) >> 32 == want, (g, int(best[g]) >> 32, want)
+        if want:
+            closed_host += 1
+            ci = 0x7FFFFFFF - ((int(best[g]) >> 1) & 0x7FFFFFFF)
+            assert contigs[ci][0] == g                    # the winning contig belongs to the gap
+            n_some += 1
+    assert int(d_closed[0]) == closed_host and 10 < n_some < n_gaps
+
+
+def test_multi_k_call_equals_one_call_per_pair():
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    import synth_small as S
+    case = S.small_case(seed=3, n_pairs=6000)
+    L = case["L"]
+    gf = GapFill(0)
+    lib = B.lib()
+    packed, _ = GapFill.pack_reads(case["reads_blob"], L)
+    n = packed.shape[0]
+    off = np.array([0, n // 3, n // 3, n], dtype=np.uint64)       # three pools, the middle one empty
+    kk = [(31, 29), (41, 39), (51, 49)]
+    single = []
+    for k, kv in kk:
+        c, s = gf.assemble(packed, off, L, [(k, kv)])
+        single += sorted((int(x["gap"]), k, kv, s[int(x["seq_off"]):int(x["seq_off"]) + int(x["length"])].decode(), int(x["n_nodes"]), int(x["cov_sum"])) for x in c)
+    d_pool, d_off = _dev(packed.reshape(-1)), _dev(off.view(np.int64))
+    ccap, scap = 1 << 16, 1 << 24
+    d_ctg = torch.zeros(ccap * 32, dtype=torch.uint8, device="cuda")
+    d_seq = torch.zeros(scap, dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(8, dtype=torch.int32, device="cuda")
+    d_err = torch.zeros(3, dtype=torch.int32, device="cuda")
+    ks, kvs = (C.c_int * 3)(*[a for a, _ in kk]), (C.c_int * 3)(*[b for _, b in kk])
+    assert lib.gf_assemble_multi_dev(gf.handle, d_pool.data_ptr(), None, d_off.data_ptr(), 3, n, L, ks, kvs, 3, 2, 40, d_ctg.data_ptr(), ccap,
+                                     d_cnt.data_ptr(), d_seq.data_ptr(), scap, d_cnt.data_ptr() + 8, d_err.data_ptr()) == 0
+    gf.sync()
+    cnt = d_cnt.cpu().numpy()
+    nc, ns = int(cnt[0]), int(cnt[2:4].view(np.uint64)[0])
+    assert int(d_err.sum()) == 0 and nc <= ccap and ns <= scap
+    c = np.frombuffer(d_ctg[:nc * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
+    s = d_seq[:ns].cpu().numpy().tobytes()
+    multi = sorted((int(x["gap"]), int(x["k"]), int(x["kv"]), s[int(x["seq_off"]):int(x["seq_off"]) + int(x["length"])].decode(), int(x["n_nodes"]),
+                    int(x["cov_sum"])) for x in c)
+    assert multi == sorted(single) and len(single) > 10 and {x[1] for x in multi} == {31, 41, 51}
+
+
+def test_assembly_refuses_pool_offsets_beyond_the_pool_array():
+    """an overflowed pool_off must not make the kernel touch memory outside its workspace."""
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    import synth_small as S
+    case = S.small_case(seed=4, n_pairs=2000)
+    L = case["L"]
+    gf = GapFill(0)
+    lib = B.lib()
+    packed, _ = GapFill.pack_reads(case["reads_blob"], L)
+    n = 600
+    off = np.array([0, 300, 600, 5000], dtype=np.uint64)          # third pool claims rows beyond total_reads = 600
+    d_pool, d_off = _dev(packed[:n].reshape(-1)), _dev(off.view(np.int64))
+    d_ctg = torch.zeros(4096 * 32, dtype=torch.uint8, device="cuda")
+    d_seq = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(8, dtype=torch.int32, device="cuda")
+    d_err = torch.zeros(3, dtype=torch.int32, device="cuda")
+    assert lib.gf_assemble_dev(gf.handle, d_pool.data_ptr(), None, d_off.data_ptr(), 3, n, L, 31, 29, 2, 40, d_ctg.data_ptr(), 4096, d_cnt.data_ptr(),
+                               d_seq.data_ptr(), 1 << 20, d_cnt.data_ptr() + 8, d_err.data_ptr()) == 0
+    gf.sync()
+    e = d_err.cpu().numpy()
+    assert e[0] == 0 and e[1] == 0 and e[2] != 0
+
+
+def test_pool_builder_flags_a_pool_buffer_that_is_too_small():
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    import synth_small as S
+    case = S.small_case(seed=9, n_pairs=3000)
+    L = case["L"]
+    gf = GapFill(0)
+    gf.set_gaps(case["gaps"], case["n_scaffolds"], case["flanks"])
+    lib = B.lib()
+    packed, _ = GapFill.pack_reads(case["reads_blob"], L)
+    hits = gf.screen_reads(packed, L, 31)
+    keys = (hits["gap"].astype(np.uint64) << np.uint64(32)) | hits["read"].astype(np.uint64)
+    d_reads, d_keys = _dev(packed.reshape(-1)), _dev(keys.view(np.int64))
+    d_nk = torch.tensor([len(keys)], dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(len(case["gaps"]) + 1, dtype=torch.int64, device="cuda")
+    d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for cap, flagged in ((len(keys) + 8, False), (max(1, len(keys) // 2), True)):
+        d_pool = torch.full((cap * 38 + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        assert lib.gf_build_pools_dev(gf.handle, d_reads.data_ptr(), packed.shape[0], L, d_keys.data_ptr(), d_nk.data_ptr(), len(keys),
+                                      d_pool.data_ptr(), cap, d_off.data_ptr(), None, d_err.data_ptr()) == 0
+        gf.sync()
+        assert bool(int(d_err[0]) & 0x80000000) == flagged and int(d_off[-1]) == len(set(keys.tolist()))
+        assert (d_pool.cpu().numpy()[cap * 38:] == 0xEE).all()
+
+
+def _bench(argv, env_extra=None, timeout=1500, nproc=1):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    if nproc == 1:
+        env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + argv
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + argv
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("config,extra", [("C2", ["--reads", "6000000"]), ("C5", ["--reads", "4000000", "--mp-reads", "2000000"])])
+def test_two_rank_owner_assembly_equals_the_single_process_run(tmp_path, config, extra):
+    """SURVEY.md §8e / north_star: the HIP kernels on two ranks (sharing this box's one GPU, gloo for the collectives), reads split,
+    pools exchanged to the gap owners — the gathered contigs and the closed count equal the single-process run over all reads."""
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    a = _bench(["--config", config, "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extras", "--dump-contigs", one] + extra)
+    b = _bench(["--config", config, "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extras", "--dump-contigs", two] + extra,
+               env_extra={"GF_BENCH_BACKEND": "gloo", "GF_BENCH_ONE_GPU": "1"}, nproc=2)
+    ja, jb = json.load(open(one)), json.load(open(two))
+    assert ja["contigs"] == jb["contigs"] and len(ja["contigs"]) > 100
+    assert ja["gaps_closed"] == jb["gaps_closed"]
+    assert a["counts"]["assembled_pool_reads"] == b["counts"]["assembled_pool_reads"] and b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert abs(a["gaps_per_s"] * a["ms_per_step"] - b["gaps_per_s"] * b["ms_per_step"]) < 1e-3 * a["gaps_per_s"] * a["ms_per_step"]   # same gaps, counted once
+
+
+@pytest.mark.parametrize("config", ["C2", "C4", "C5"])
+def test_full_size_config_sample_parity(config):
+    """BASELINE.json configs[1], [3], [4] at FULL size on this GPU (reads generated on the device): all screen and tagger hits of
+    the oracle's read prefix (every library), the merged pools' assembly of 256 gaps at every (k, kv) and the closed flags equal
+    the oracle / the host picker; every gap recruits reads and yields contigs."""
+    d = _bench(["--config", config, "--steps", "1", "--warmup", "0", "--no-extras"])
+    cb = d["cpu_baseline"]
+    assert cb["parity_recruit"] and cb["parity_assembly"] and cb["parity_pick"] and cb["parity_on_sample"], cb
+    assert cb["sample_hits"] > 1000 and cb["sample_contigs"] > 100
+    n_gaps = d["config"]["gaps"]
+    assert d["counts"]["gaps_with_contig"] == n_gaps
+    want_reads = {"C2": 50_000_000, "C4": 900_000_000, "C5": 1_000_000_000}[config]
+    assert d["config"]["reads_total"] == want_reads and d["n_gpus"] == 1
