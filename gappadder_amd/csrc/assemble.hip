@@ -33,6 +33,8 @@ struct AsmParams {
     unsigned long long* table; // 4 slots per k-mer instance: low 32 = instance id, high 32 = count / node meta
     uint32_t* surv;            // 2 words per instance: slot lists, survivor list, node instance ids, emitted-walk records
     uint32_t* nodes;           // 3 words per instance: per-node meta + succ[2] when they do not fit in LDS
+    uint32_t* jump;            // 4 words per instance: the unitig-ranking pairs of the oriented nodes when they do not fit in LDS
+    uint32_t simplify;         // rounds of tip clipping + bubble popping (0: raw unitigs)
     gf_contig* contigs;
     uint32_t contig_cap;
     uint32_t* n_contigs;
@@ -51,10 +53,12 @@ struct AsmParams {
 };
 
 // gap_error bits
-constexpr uint32_t ASM_ERR_IDS = 1, ASM_ERR_KTABLE = 2, ASM_ERR_NTABLE = 4, ASM_ERR_NLIST = 8, ASM_ERR_WALKS_PAR = 16, ASM_ERR_WALKS = 32;
+constexpr uint32_t ASM_ERR_IDS = 1, ASM_ERR_KTABLE = 2, ASM_ERR_NTABLE = 4, ASM_ERR_NLIST = 8, ASM_ERR_WALKS_PAR = 16;
 
 // node meta bits (high word of a table slot in the graph phases)
-constexpr uint32_t M_OUT = 0xFu, M_IN = 0xF0u, M_START0 = 1u << 8, M_START1 = 1u << 9, M_MULT_SHIFT = 12;
+constexpr uint32_t M_OUT = 0xFu, M_IN = 0xF0u, M_START0 = 1u << 8, M_START1 = 1u << 9, M_MULT_SHIFT = 13;
+// error removal: KILL = the unitig this node heads is removed in this round; DEADMARK -> DEAD = the node is gone
+constexpr uint32_t M_KILL = 1u << 10, M_DEADMARK = 1u << 11, M_DEAD = 1u << 12;
 
 // the kernel's dynamic LDS, at file scope so that every helper addresses it as LDS (ds_* instructions) instead of through
 // a generic pointer (flat_* instructions, several times the latency)
@@ -191,6 +195,23 @@ struct Arr {
     __device__ __forceinline__ uint32_t get(uint32_t i) const { return lds ? g_lds[off + i] : __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { if (lds) g_lds[off + i] = v; else g[i] = v; }
     __device__ __forceinline__ void or_(uint32_t i, uint32_t v) const { if (lds) atomicOr(&g_lds[off + i], v); else atomicOr(g + i, v); }
+    __device__ __forceinline__ void and_(uint32_t i, uint32_t v) const { if (lds) atomicAnd(&g_lds[off + i], v); else atomicAnd(g + i, v); }
+};
+
+// 8-byte pairs in LDS (word offset, 8-byte aligned) or global memory, read and written whole
+struct Pairs {
+    bool lds;
+    uint32_t off;
+    unsigned long long* g;
+    __device__ __forceinline__ unsigned long long* l() const { return reinterpret_cast<unsigned long long*>(&g_lds[off]); }
+    __device__ __forceinline__ unsigned long long load(uint32_t i) const {
+        return lds ? __hip_atomic_load(l() + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                   : __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void store(uint32_t i, unsigned long long v) const {
+        if (lds) __hip_atomic_store(l() + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(g + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 };
 
 // Find-or-insert the canonical `len`-mer `key` (instance `inst`) and add `inc` to the slot's high word, with ONE 64-bit
@@ -624,8 +645,10 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         const uint32_t n_surv = s_cnt[0];
         ASM_STAMP(2);
 
-        // ---- graph-phase memory: node table + 4 arrays.  Optimistic LDS plan first: room for `nb` nodes (7 words each:
-        //      4/3 table slots + inst_of/meta/succ0/succ1); if the gap has more nodes the phase is redone in global memory.
+        // ---- graph-phase memory: node table + 4 arrays + the unitig-ranking pairs.  Optimistic LDS plan first: room for `nb`
+        //      nodes (11 words each: 4/3 table slots + inst_of/meta/succ0/succ1 + one 8-byte {ancestor, distance} pair per
+        //      oriented node); if the gap has more nodes the phase is redone in global memory.  The node table stays alive to the
+        //      end: error removal looks neighbours up again after every round.
         const uint64_t node_bound = (uint64_t)per * n_surv < n_unit ? (uint64_t)per * n_surv : n_unit;
         bool graph_lds = false;
         uint32_t nb = 0, n_nodes = 0;
@@ -634,13 +657,13 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         for (int attempt = 0; attempt < 2; ++attempt) {
             graph_lds = false;
             if (attempt == 0) {
-                nb = (uint32_t)(node_bound < r_words / 7 ? node_bound : r_words / 7);
+                nb = (uint32_t)(node_bound < r_words / 11 ? node_bound : r_words / 11);
                 if (nb < n_surv || nb < 64) continue;       // cannot even hold one node per survivor: go global
                 graph_lds = true;
             }
             ntab.lds = graph_lds;
             ntab.off = R + 4 * nb;
-            ntab.cap = graph_lds ? (r_words - 4 * nb) / 2 : gcap;
+            ntab.cap = graph_lds ? ((r_words - 8 * nb) / 2) : gcap;
             if (graph_lds) {
                 for (uint32_t i = tid; i < ntab.cap; i += ASM_THREADS) ntab.store(i, EMPTY64);
                 __syncthreads();
@@ -697,12 +720,15 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         ASM_STAMP(3);
 
         // ---- P3.5: dense node indices.  slot.id <- node index; inst_of / meta / succ arrays
-        // LDS: [inst_of | meta | succ0 | succ1] at R;  global: inst_of = list_b, [meta | succ0 | succ1] in the node workspace
+        // LDS: [inst_of | meta | succ0 | succ1] at R, pairs behind the table;  global: inst_of = list_b, [meta | succ0 | succ1] in
+        // the node workspace, pairs in the jump workspace
         const Arr inst_of{graph_lds, R, list_b};
         const Arr nmeta{graph_lds, R + astride, garr};
         const Arr succ0{graph_lds, R + 2 * astride, garr + astride};
         const Arr succ1{graph_lds, R + 3 * astride, garr + 2 * astride};
-        uint32_t* rec = list_b + (graph_lds ? 0 : n_nodes);           // emitted-walk records, 2 words each
+        const uint32_t Joff = graph_lds ? ntab.off + 2 * ntab.cap : 0;
+        const Pairs J{graph_lds, Joff, reinterpret_cast<unsigned long long*>(P.jump + 4 * inst_off)};
+        uint32_t* rec = list_b + (graph_lds ? 0 : n_nodes);           // emitted-walk records, 4 words each
         const uint32_t rec_cap = (n_unit - (graph_lds ? 0 : n_nodes)) / 2;
         for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
             const uint32_t sl = list_a[ni];
@@ -715,97 +741,251 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
         wg_phase_sync();
 
-        // ---- P4: unitig-internal edges.  (x,d) -> (y,dy) is internal iff out-degree(x,d) == 1 and in-degree(y,dy) == 1;
-        //      an oriented node that no internal edge enters is a unitig START.
-        for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
-            const uint32_t meta = nmeta.get(ni) & 0xFFu;   // adjacency bits are final after P3
-            const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(ni), kv), kv);
-            for (uint32_t d = 0; d < 2; ++d) {
-                const uint32_t ob = out_bits(meta, d);
-                if (__popc(ob) != 1) continue;
-                const K128 cur = d ? revcomp_w<W>(x, kv) : x;
-                const K128 y = shift_in(cur, __ffs(ob) - 1, kv);
-                const K128 yr = revcomp_w<W>(y, kv);
-                const uint32_t dy = yr < y ? 1u : 0u;
-                const K128 Y = dy ? yr : y;
-                uint32_t sl = slot_of(Y, ntab.cap), yi = EMPTY32;   // slot.id is a node index now
-                for (uint32_t probes = 0; probes < ntab.cap; ++probes) {
-                    const uint32_t cand = ntab.id(sl);
-                    if (cand == EMPTY32) break;
-                    if (cand < n_nodes && canonical_w<W>(pv_kmer<W>(V, inst_of.get(cand), kv), kv) == Y) { yi = cand; break; }
-                    sl = sl + 1 == ntab.cap ? 0 : sl + 1;
-                }
-                if (yi == EMPTY32) continue;
-                if (__popc(in_bits(nmeta.get(yi) & 0xFFu, dy)) != 1) continue;
-                (d ? succ1 : succ0).set(ni, (yi << 1) | dy);
-                nmeta.or_(yi, dy ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
+        // ---- neighbourhood helpers (all of them read the adjacency bits, the node table and the staged reads only)
+        const uint32_t n_or = 2 * n_nodes;
+        auto node_seq = [&](uint32_t o) -> K128 {   // oriented kv-mer of oriented node o
+            const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(o >> 1), kv), kv);
+            return (o & 1) ? revcomp_w<W>(x, kv) : x;
+        };
+        auto find_oriented = [&](K128 y) -> uint32_t {   // oriented node with oriented sequence y, or EMPTY32
+            const K128 yr = revcomp_w<W>(y, kv);
+            const uint32_t dy = yr < y ? 1u : 0u;
+            const K128 Y = dy ? yr : y;
+            uint32_t sl = slot_of(Y, ntab.cap);
+            for (uint32_t probes = 0; probes < ntab.cap; ++probes) {
+                const uint32_t cand = ntab.id(sl);
+                if (cand == EMPTY32) break;
+                if (cand < n_nodes && canonical_w<W>(pv_kmer<W>(V, inst_of.get(cand), kv), kv) == Y) return (cand << 1) | dy;
+                sl = sl + 1 == ntab.cap ? 0 : sl + 1;
             }
-        }
-        wg_phase_sync();
-        ASM_STAMP(4);
+            return EMPTY32;
+        };
+        auto adj = [&](uint32_t o) -> uint32_t { return nmeta.get(o >> 1) & 0xFFu; };
+        auto outb = [&](uint32_t o) -> uint32_t { return out_bits(adj(o), o & 1); };
+        auto inb = [&](uint32_t o) -> uint32_t { return in_bits(adj(o), o & 1); };
+        auto has_pred = [&](uint32_t o) { return (nmeta.get(o >> 1) & ((o & 1) ? M_START1 : M_START0)) != 0; };   // internal predecessor
+        auto is_dead = [&](uint32_t o) { return (nmeta.get(o >> 1) & M_DEAD) != 0; };
+        auto succ_get = [&](uint32_t o) -> uint32_t { return ((o & 1) ? succ1 : succ0).get(o >> 1); };
 
-        // ---- P5 (parallel form): when the graph lives in LDS and the dead node-table region can hold one 8-byte
-        //      {ancestor, distance} pair per oriented node, unitigs are ranked by pointer jumping instead of being walked:
-        //      every oriented node learns its unitig's head and its rank in ~log2(longest unitig) rounds; tails tell heads
-        //      the length; heads decide emission; then every node writes its own base.  Pairs are read and written as single
-        //      64-bit LDS accesses, so the asynchronous in-place update keeps the invariant "ancestor at that distance".
-        const uint32_t Toff = R + 4 * nb, Twords = graph_lds ? r_words - 4 * nb : 0;
-        const bool par_ok = graph_lds && (uint64_t)4 * n_nodes + 64 <= Twords;
-        if (par_ok) {
-            unsigned long long* J = reinterpret_cast<unsigned long long*>(&g_lds[Toff]);
-            uint32_t* cacc = &g_lds[Toff + 4 * n_nodes];                       // per-contig coverage sums
-            const uint32_t cacc_cap = Twords - 4 * n_nodes;
-            const uint32_t n_or = 2 * n_nodes;
-            auto has_pred = [&](uint32_t o) { return (nmeta.get(o >> 1) & ((o & 1) ? M_START1 : M_START0)) != 0; };
+        uint32_t n_emit = 0;
+        bool cacc_lds = false;
+        uint32_t* cacc = nullptr;
+        uint32_t cacc_cap = 0;
+        for (uint32_t round = 0;; ++round) {
+            // ---- P4: unitig-internal edges.  (x,d) -> (y,dy) is internal iff out-degree(x,d) == 1 and in-degree(y,dy) == 1;
+            //      an oriented node that no internal edge enters is a unitig START.
+            if (round) {
+                for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
+                    nmeta.and_(ni, ~(M_START0 | M_START1 | M_KILL));
+                    succ0.set(ni, EMPTY32);
+                    succ1.set(ni, EMPTY32);
+                }
+                wg_phase_sync();
+            }
+            for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
+                const uint32_t meta = nmeta.get(ni);
+                if (meta & M_DEAD) continue;
+                const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(ni), kv), kv);
+                for (uint32_t d = 0; d < 2; ++d) {
+                    const uint32_t ob = out_bits(meta & 0xFFu, d);
+                    if (__popc(ob) != 1) continue;
+                    const K128 cur = d ? revcomp_w<W>(x, kv) : x;
+                    const uint32_t y = find_oriented(shift_in(cur, __ffs(ob) - 1, kv));
+                    if (y == EMPTY32) continue;
+                    if (__popc(inb(y)) != 1) continue;
+                    (d ? succ1 : succ0).set(ni, y);
+                    nmeta.or_(y >> 1, (y & 1) ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
+                }
+            }
+            wg_phase_sync();
+            if (round == 0) ASM_STAMP(4);
+
+            // ---- P5: unitigs ranked by pointer jumping: every oriented node learns its unitig's head and its rank in
+            //      ~log2(longest unitig) rounds.  Pairs are read and written as single 64-bit accesses, so the asynchronous
+            //      in-place update keeps the invariant "ancestor at that distance".
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                unsigned long long pr = o;                                      // heads: {self, 0}
+                unsigned long long pr = o;                                      // heads (and dead nodes): {self, 0}
                 if (has_pred(o)) {
-                    const uint32_t back = ((o & 1) ? succ0 : succ1).get(o >> 1);  // walking the other way from this node
+                    const uint32_t back = succ_get(o ^ 1u);                     // walking the other way from this node
                     pr = (1ull << 32) | (back ^ 1u);                            // its internal predecessor, one step away
                 }
-                J[o] = pr;
+                J.store(o, pr);
             }
-            __syncthreads();
-            for (int round = 0; round < 18; ++round) {
+            wg_phase_sync();
+            for (int jr = 0; jr < 24; ++jr) {
                 if (tid == 0) s_cnt[7] = 0;
                 __syncthreads();
                 bool changed = false;
                 for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                    const unsigned long long a0 = J[o];
+                    const unsigned long long a0 = J.load(o);
                     const uint32_t pa = (uint32_t)a0;
                     if (pa == o) continue;
-                    const unsigned long long a1 = J[pa];
+                    const unsigned long long a1 = J.load(pa);
                     const uint32_t pb = (uint32_t)a1;
                     if (pb == pa) continue;                                     // parent is a head (or this is a finished cycle hop)
-                    J[o] = ((unsigned long long)((uint32_t)(a0 >> 32) + (uint32_t)(a1 >> 32)) << 32) | pb;
+                    J.store(o, ((unsigned long long)((uint32_t)(a0 >> 32) + (uint32_t)(a1 >> 32)) << 32) | pb);
                     changed = true;
                 }
                 if (changed) s_cnt[7] = 1;
                 __syncthreads();
                 if (!s_cnt[7]) break;
+                __syncthreads();
             }
-            __syncthreads();
-            // S1: tails publish {tail, length} in their head's pair (heads are not read as ancestors any more)
+            wg_phase_sync();
+            // tails publish {tail, length} in their head's pair (heads are not read as ancestors any more)
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                if (((o & 1) ? succ1 : succ0).get(o >> 1) != EMPTY32) continue;
-                const unsigned long long a0 = J[o];
-                const uint32_t h = has_pred(o) ? (uint32_t)a0 : o;
+                if (is_dead(o) || succ_get(o) != EMPTY32) continue;
+                const bool hp = has_pred(o);
+                const unsigned long long a0 = hp ? J.load(o) : 0ull;
+                const uint32_t h = hp ? (uint32_t)a0 : o;
                 if (has_pred(h)) continue;                                      // part of an isolated cycle: never reported
-                const uint32_t rank = has_pred(o) ? (uint32_t)(a0 >> 32) : 0;
-                g_lds[Toff + 2 * h] = o;                                        // written as two words: no reader until the barrier
-                g_lds[Toff + 2 * h + 1] = rank + 1;
+                const uint32_t rank = hp ? (uint32_t)(a0 >> 32) : 0;
+                J.store(h, ((unsigned long long)(rank + 1) << 32) | o);
             }
+            wg_phase_sync();
+            if (round >= P.simplify) break;
+
+            // ---- error removal, one round on this snapshot (semantics: oracle/gp_oracle.c simplify_round): every
+            //      head decides for its unitig X — TIP (dead end, <= kv nodes, hangs on a junction where another branch beats it)
+            //      or BUBBLE (<= 2 kv nodes between two junctions that an alternative path of the same length also joins).
+            //      Decisions only set the KILL bit of the head's node; the graph changes after the barrier.
+            if (tid == 0) s_cnt[7] = 0;
             __syncthreads();
-            // S2: heads decide
+            auto uni_cov = [&](uint32_t h, uint32_t n) -> uint32_t {
+                uint32_t cur = h, c = 0;
+                for (uint32_t i = 0; i < n && cur != EMPTY32; ++i) { c += nmeta.get(cur >> 1) >> M_MULT_SHIFT; cur = succ_get(cur); }
+                return c;
+            };
+            auto uni_key = [&](uint32_t h, uint32_t t) -> K128 {
+                const K128 a = node_seq(h), b = node_seq(t ^ 1u);
+                return b < a ? b : a;
+            };
+            // does the unitig headed by y (tail ty, ny nodes) beat the one headed by x?
+            auto beats = [&](uint32_t y, uint32_t ty, uint32_t ny, uint32_t x, uint32_t tx, uint32_t nx, bool with_len) -> bool {
+                if (with_len && ny != nx) return ny > nx;
+                const uint32_t cy = uni_cov(y, ny), cx = uni_cov(x, nx);
+                if (cy != cx) return cy > cx;
+                return uni_key(y, ty) < uni_key(x, tx);
+            };
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                if (has_pred(o)) continue;
-                const uint32_t tail = g_lds[Toff + 2 * o], len = g_lds[Toff + 2 * o + 1];
+                if (is_dead(o) || has_pred(o)) continue;
+                const unsigned long long jo = J.load(o);
+                const uint32_t t = (uint32_t)jo, n = (uint32_t)(jo >> 32);
+                if (n == 0) continue;                                           // (a pair no tail wrote: cannot happen for a live head)
+                const uint32_t ib = inb(o);
+                if (__popc(ib) != 1) continue;
+                const K128 hs = node_seq(o);
+                const uint32_t p = find_oriented(shift_in_front(hs, __ffs(ib) - 1, kv));
+                if (p == EMPTY32) continue;
+                const uint32_t pb = outb(p);
+                if (__popc(pb) < 2) continue;
+                const uint32_t tb = outb(t);
+                bool go = false;
+                if (tb == 0 && n <= P.kv) {                                     // TIP
+                    const K128 ps = node_seq(p);
+                    for (uint32_t c = 0; c < 4 && !go; ++c) {
+                        if (!((pb >> c) & 1u)) continue;
+                        const uint32_t y = find_oriented(shift_in(ps, c, kv));
+                        if (y == EMPTY32 || y == o || has_pred(y) || y == (t ^ 1u)) continue;
+                        const unsigned long long jy = J.load(y);
+                        const uint32_t ty = (uint32_t)jy, ny = (uint32_t)(jy >> 32);
+                        const bool tip_shaped = outb(ty) == 0 && ny <= P.kv && __popc(inb(y)) == 1;
+                        if (!tip_shaped || beats(y, ty, ny, o, t, n, true)) go = true;
+                    }
+                } else if (__popc(tb) == 1 && n <= 2 * P.kv) {                  // BUBBLE
+                    const uint32_t s = find_oriented(shift_in(node_seq(t), __ffs(tb) - 1, kv));
+                    if (s != EMPTY32 && __popc(inb(s)) >= 2) {
+                        // alternative paths p -> A1 .. Am -> s of whole unitigs, m <= 4, exactly n nodes, none of them X or its reverse
+                        uint32_t st_q[4], st_rem[4], st_c[4];
+                        int sp = 0;
+                        st_q[0] = p; st_rem[0] = n; st_c[0] = 0;
+                        while (sp >= 0 && !go) {
+                            if (st_c[sp] == 4) { --sp; continue; }
+                            const uint32_t c = st_c[sp]++;
+                            const uint32_t q = st_q[sp], rem = st_rem[sp];
+                            if (!((outb(q) >> c) & 1u)) continue;
+                            const uint32_t y = find_oriented(shift_in(node_seq(q), c, kv));
+                            if (y == EMPTY32 || has_pred(y) || y == o || y == (t ^ 1u)) continue;
+                            const unsigned long long jy = J.load(y);
+                            const uint32_t ty = (uint32_t)jy, ny = (uint32_t)(jy >> 32);
+                            if (ny > rem) continue;
+                            if (ny == rem) {
+                                const uint32_t yb = outb(ty);
+                                bool reaches = false;
+                                const K128 tys = node_seq(ty);
+                                for (uint32_t c2 = 0; c2 < 4; ++c2)
+                                    if (((yb >> c2) & 1u) && find_oriented(shift_in(tys, c2, kv)) == s) reaches = true;
+                                if (!reaches) continue;
+                                if (sp >= 1 || beats(y, ty, ny, o, t, n, false)) go = true;
+                            } else if (sp + 1 < 4) {
+                                ++sp;
+                                st_q[sp] = ty; st_rem[sp] = rem - ny; st_c[sp] = 0;
+                            }
+                        }
+                    }
+                }
+                if (go) {   // both end nodes: the reverse orientation of a tip does not qualify by itself (its head has no predecessor)
+                    nmeta.or_(o >> 1, M_KILL);
+                    nmeta.or_(t >> 1, M_KILL);
+                    s_cnt[7] = 1;
+                }
+            }
+            wg_phase_sync();
+            if (!s_cnt[7]) break;                                               // nothing to remove: the ranking above is final
+            // the killed heads remember the arc that enters them (their pair is free: only {tail, length} of a removed unitig)
+            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                if (is_dead(o) || has_pred(o) || !(nmeta.get(o >> 1) & M_KILL)) continue;
+                const uint32_t ib = inb(o);
+                unsigned long long arc = ~0ull;
+                if (__popc(ib) == 1) {
+                    const K128 hs = node_seq(o);
+                    const uint32_t p = find_oriented(shift_in_front(hs, __ffs(ib) - 1, kv));
+                    if (p != EMPTY32) arc = ((unsigned long long)kbase(hs, kv - 1) << 32) | p;
+                }
+                J.store(o, arc);
+            }
+            wg_phase_sync();
+            // nodes of removed unitigs die; the arcs into the removed unitigs are cleared at their sources
+            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                if (is_dead(o)) continue;
+                const bool hp = has_pred(o);
+                if (!hp && (nmeta.get(o >> 1) & M_KILL)) {
+                    const unsigned long long arc = J.load(o);
+                    if (arc != ~0ull) {
+                        const uint32_t p = (uint32_t)arc, c = (uint32_t)(arc >> 32);
+                        nmeta.and_(p >> 1, ~((p & 1) ? (1u << (4 + (3 - c))) : (1u << c)));
+                    }
+                }
+                if (o & 1) continue;                                            // one orientation marks the node
+                uint32_t h = o;
+                if (hp) {
+                    h = (uint32_t)J.load(o);
+                    if (has_pred(h)) continue;                                  // isolated cycle
+                }
+                if (nmeta.get(h >> 1) & M_KILL) nmeta.or_(o >> 1, M_DEADMARK);
+            }
+            wg_phase_sync();
+            for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS)
+                if (nmeta.get(ni) & M_DEADMARK) nmeta.or_(ni, M_DEAD);
+            wg_phase_sync();
+        }
+
+        // ---- emission: heads decide, then every node of an emitted unitig writes its own base
+        {
+            // per-contig coverage sums: in the LDS behind the pairs when the graph lives there, else in the global records
+            if (graph_lds) {
+                const uint32_t used = Joff + 4 * n_nodes;
+                cacc = &g_lds[used];
+                cacc_cap = P.lds_words > used ? P.lds_words - used : 0;
+            }
+            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                if (is_dead(o) || has_pred(o)) continue;
+                const unsigned long long jo = J.load(o);
+                const uint32_t tail = (uint32_t)jo, len = (uint32_t)(jo >> 32);
                 uint32_t q = EMPTY32;
-                if (len + P.kv - 1 >= P.min_contig) {
-                    const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(o >> 1), kv), kv);
-                    const K128 first = (o & 1) ? revcomp_w<W>(x, kv) : x;
-                    const K128 e = canonical_w<W>(pv_kmer<W>(V, inst_of.get(tail >> 1), kv), kv);
-                    const K128 opp = (tail & 1) ? e : revcomp_w<W>(e, kv);
+                if (len && len + P.kv - 1 >= P.min_contig) {
+                    const K128 first = node_seq(o);
+                    const K128 opp = node_seq(tail ^ 1u);
                     if (!(opp < first)) {
                         q = atomicAdd(&s_cnt[1], 1u);
                         if (q >= rec_cap / 2) { atomicOr(&s_cnt[3], ASM_ERR_WALKS_PAR); q = EMPTY32; }
@@ -818,11 +998,11 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         }
                     }
                 }
-                g_lds[Toff + 2 * o] = q;
+                J.store(o, q);                               // heads now carry their contig number (EMPTY32: not emitted)
             }
             wg_phase_sync();
-            const uint32_t n_emit = s_cnt[1] < rec_cap / 2 ? s_cnt[1] : rec_cap / 2;
-            const bool cacc_lds = n_emit <= cacc_cap;   // else (LDS nearly full of nodes): sums accumulate in the global records
+            n_emit = s_cnt[1] < rec_cap / 2 ? s_cnt[1] : rec_cap / 2;
+            cacc_lds = n_emit <= cacc_cap;   // else (LDS nearly full of nodes): sums accumulate in the global records
             if (tid == 0) {
                 s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
                 s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
@@ -834,31 +1014,30 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             for (uint32_t q = tid; q < n_emit; q += ASM_THREADS)                // relative offsets of the contigs
                 rec[4 * q + 2] = (uint32_t)atomicAdd(&s_seq[0], (unsigned long long)(rec[4 * q + 1] + P.kv - 1));
             wg_phase_sync();
-            // S4: every oriented node of an emitted unitig writes its own base
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                if (is_dead(o)) continue;
                 uint32_t h = o, rank = 0;
                 if (has_pred(o)) {
-                    const unsigned long long a0 = J[o];
+                    const unsigned long long a0 = J.load(o);
                     h = (uint32_t)a0;
                     rank = (uint32_t)(a0 >> 32);
                     if (has_pred(h)) continue;
                 }
-                const uint32_t q = g_lds[Toff + 2 * h];
+                const uint32_t q = (uint32_t)J.load(h);
                 if (q == EMPTY32 || q >= n_emit) continue;
                 const unsigned long long off = s_seq[1] + rec[4 * q + 2];
                 const uint32_t len = rec[4 * q + 1] + P.kv - 1;
                 if (cacc_lds) atomicAdd(&cacc[q], nmeta.get(o >> 1) >> M_MULT_SHIFT);
                 else atomicAdd(&rec[4 * q + 3], nmeta.get(o >> 1) >> M_MULT_SHIFT);
                 if (off + len > P.seq_cap) continue;
-                const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(o >> 1), kv), kv);
-                const K128 ok = (o & 1) ? revcomp_w<W>(x, kv) : x;
+                const K128 ok = node_seq(o);
                 if (rank == 0) {
                     for (int bq = 0; bq < kv; ++bq) P.seq[off + bq] = "ACGT"[kbase(ok, bq)];
                 } else {
                     P.seq[off + kv - 1 + rank] = "ACGT"[kbase(ok, kv - 1)];
                 }
             }
-            __syncthreads();
+            wg_phase_sync();
             for (uint32_t q = tid; q < n_emit; q += ASM_THREADS) {
                 const uint32_t ci = s_cnt[2] + q;
                 if (ci < P.contig_cap) {
@@ -867,89 +1046,6 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     ct.length = rec[4 * q + 1] + P.kv - 1; ct.cov_sum = cacc_lds ? cacc[q] : __hip_atomic_load(&rec[4 * q + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // from L2, where the atomics landed
                     ct.reserved = 0;
                     ct.seq_off = s_seq[1] + rec[4 * q + 2];
-                    P.contigs[ci] = ct;
-                }
-            }
-            __syncthreads();
-        } else {
-            // ---- P5a: walk every start along the succ pointers; keep the walks that are emitted
-            for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
-                const uint32_t meta0 = nmeta.get(ni);
-                for (uint32_t d = 0; d < 2; ++d) {
-                    if (meta0 & (d ? M_START1 : M_START0)) continue;  // has an internal predecessor: not a start
-                    uint32_t cur = (ni << 1) | d, nodes = 1;
-                    for (;;) {
-                        const uint32_t nx = ((cur & 1) ? succ1 : succ0).get(cur >> 1);
-                        if (nx == EMPTY32) break;
-                        cur = nx;
-                        ++nodes;
-                    }
-                    if (nodes + P.kv - 1 < P.min_contig) continue;
-                    const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(ni), kv), kv);
-                    const K128 first = d ? revcomp_w<W>(x, kv) : x;
-                    const K128 e = canonical_w<W>(pv_kmer<W>(V, inst_of.get(cur >> 1), kv), kv);
-                    const K128 opp = (cur & 1) ? e : revcomp_w<W>(e, kv);  // first kv-mer of the opposite walk = revcomp_w<W>(last kv-mer)
-                    if (opp < first) continue;
-                    const uint32_t q = atomicAdd(&s_cnt[1], 1u);
-                    if (q >= rec_cap) { atomicOr(&s_cnt[3], ASM_ERR_WALKS); continue; }
-                    rec[2 * q] = (ni << 1) | d;
-                    rec[2 * q + 1] = nodes;
-                    atomicAdd(&s_seq[0], (unsigned long long)(nodes + P.kv - 1));
-                }
-            }
-            wg_phase_sync();
-            const uint32_t n_emit = s_cnt[1] < rec_cap ? s_cnt[1] : rec_cap;
-            if (tid == 0) {
-                s_cnt[2] = n_emit ? atomicAdd(P.n_contigs, n_emit) : 0;
-                s_seq[1] = s_seq[0] ? atomicAdd(P.seq_len, s_seq[0]) : 0;
-                s_seq[0] = 0;
-                if (s_cnt[3]) P.gap_error[g] |= s_cnt[3];
-            }
-            __syncthreads();
-            ASM_STAMP(5);
-
-            // ---- P5b: re-walk the kept starts and write sequences
-            for (uint32_t q = tid; q < n_emit; q += ASM_THREADS) {
-                const uint32_t st = rec[2 * q], nodes = rec[2 * q + 1];
-                const uint32_t len = nodes + P.kv - 1;
-                const unsigned long long off = s_seq[1] + atomicAdd(&s_seq[0], (unsigned long long)len);
-                const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(st >> 1), kv), kv);
-                const K128 firstk = (st & 1) ? revcomp_w<W>(x, kv) : x;
-                const bool room = off + len <= P.seq_cap;
-                if (room)
-                    for (int b = 0; b < kv; ++b) P.seq[off + b] = "ACGT"[kbase(firstk, b)];
-                uint32_t cur = st, cov = nmeta.get(st >> 1) >> M_MULT_SHIFT;
-                uint32_t acc = 0;   // up to 4 bases gathered for one aligned 32-bit store
-                for (uint32_t n = 1; n < nodes; ++n) {
-                    const uint32_t c = __ffs(out_bits(nmeta.get(cur >> 1) & 0xFFu, cur & 1)) - 1;
-                    cur = ((cur & 1) ? succ1 : succ0).get(cur >> 1);
-                    cov += nmeta.get(cur >> 1) >> M_MULT_SHIFT;
-                    if (!room) continue;
-                    const unsigned long long pos = off + kv - 1 + n;
-                    const uint32_t ch = (0x54474341u >> (8 * c)) & 0xFFu;   // "ACGT"[c]
-                    const uint32_t b = (uint32_t)(reinterpret_cast<uintptr_t>(P.seq) + pos) & 3;   // byte lane of the ADDRESS
-                    acc |= ch << (8 * b);
-                    if (b == 3) {
-                        if (acc >> 24 && (acc & 0xFF) && ((acc >> 8) & 0xFF) && ((acc >> 16) & 0xFF)) {
-                            *reinterpret_cast<uint32_t*>(P.seq + pos - 3) = acc;     // all four bytes are this contig's
-                        } else {
-                            for (uint32_t q = 0; q < 4; ++q)
-                                if ((acc >> (8 * q)) & 0xFF) P.seq[pos - 3 + q] = (char)((acc >> (8 * q)) & 0xFF);
-                        }
-                        acc = 0;
-                    }
-                }
-                if (room && acc) {   // trailing partial word
-                    const unsigned long long last = off + kv - 1 + nodes - 1;
-                    const uint32_t bl = (uint32_t)(reinterpret_cast<uintptr_t>(P.seq) + last) & 3;
-                    for (uint32_t q = 0; q <= bl; ++q)
-                        if ((acc >> (8 * q)) & 0xFF) P.seq[last - bl + q] = (char)((acc >> (8 * q)) & 0xFF);
-                }
-                const uint32_t ci = s_cnt[2] + q;
-                if (ci < P.contig_cap) {
-                    gf_contig ct;
-                    ct.gap = g; ct.k = (uint16_t)P.k; ct.kv = (uint16_t)P.kv; ct.n_nodes = nodes; ct.length = len;
-                    ct.cov_sum = cov; ct.reserved = 0; ct.seq_off = off;
                     P.contigs[ci] = ct;
                 }
             }
@@ -992,6 +1088,7 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     }
     if ((rc = ensure(ctx, ctx->asm_surv, std::max<uint64_t>(n_inst, 1) * 2 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->asm_nodes, std::max<uint64_t>(n_inst, 1) * 3 * 4))) return rc;
+    if (!d_cnt_keys && (rc = ensure(ctx, ctx->asm_jump, std::max<uint64_t>(n_inst, 1) * 4 * 4))) return rc;
     if (n_pools == 0 && !append) {
         GF_HIP(ctx, hipMemsetAsync(d_n_contigs, 0, 4, ctx->stream));
         GF_HIP(ctx, hipMemsetAsync(d_seq_len, 0, 8, ctx->stream));
@@ -1019,6 +1116,8 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.table = (unsigned long long*)ctx->asm_table.p;
     P.surv = (uint32_t*)ctx->asm_surv.p;
     P.nodes = (uint32_t*)ctx->asm_nodes.p;
+    P.jump = (uint32_t*)ctx->asm_jump.p;
+    P.simplify = (uint32_t)std::max(0, ctx->asm_simplify);
     P.contigs = (gf_contig*)d_contigs;
     P.contig_cap = (uint32_t)contig_cap;
     P.n_contigs = (uint32_t*)d_n_contigs;

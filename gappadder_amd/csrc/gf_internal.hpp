@@ -88,6 +88,7 @@ struct gf_ctx {
     int screen_np_override = -1;
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)
     int asm_lds_pool_kb = 152;
+    int asm_simplify = 2;        // rounds of tip clipping + bubble popping in the assembly (Velvet's defaults are on; 0: raw unitigs)
     int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
     void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)
     // tagger coarse bin map (rebuilt when dist2 changes)
@@ -100,7 +101,7 @@ struct gf_ctx {
     size_t low_b1 = 0, low_b2 = 0;
 
     // scratch
-    gf::DevBuf cand, cand2, part_ws, binmap, binmap_fine, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, rowgap, pool_ws, xchg_ws, xchg_ws2, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, part_ws, binmap, binmap_fine, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, asm_jump, rowgap, pool_ws, xchg_ws, xchg_ws2, counters, stage_in, stage_out, stage_aux, table;
     size_t bam_n_recs = 0;       // alignment records gf_bam_pack left in bam_recs (for gf_tag_*_bam)
     size_t bam_stream_len = 0;   // inflated BAM bytes gf_bgzf_inflate left in bam_stream
     // timing

@@ -26,8 +26,9 @@ def test_error_free_reads_give_one_contig_equal_to_the_segment():
     g = LUT[rng.randint(0, 4, 3000)].tobytes()
     L = 150
     reads = tiled_reads(g, L, 700, rng) + [g[:L], g[-L:], g[:L], g[-L:]]
-    ctg = CO.assemble_pool(b"".join(reads), L, 31, 29)
+    ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=0)
     assert len(ctg) == 1
+    assert ctg == CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=2)      # nothing to remove
     seq = ctg[0][0].encode()
     assert seq in (g, rc(g)) and seq == min(g, rc(g))
     assert ctg[0][1] == len(g) - 29 + 1          # nodes = kv-mers
@@ -40,13 +41,13 @@ def test_single_error_read_is_removed_by_min_count_2():
     g = LUT[rng.randint(0, 4, 1200)].tobytes()
     L = 100
     reads = tiled_reads(g, L, 400, rng) + [g[:L], g[-L:], g[:L], g[-L:]]
-    clean = CO.assemble_pool(b"".join(reads), L, 31, 29)
+    clean = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=0)
     bad = bytearray(reads[0])
     bad[50] = ord("A") if bad[50] != ord("A") else ord("C")
-    dirty = CO.assemble_pool(b"".join([bytes(bad)] + reads[1:] + [reads[0]]), L, 31, 29)
+    dirty = CO.assemble_pool(b"".join([bytes(bad)] + reads[1:] + [reads[0]]), L, 31, 29, simplify=0)
     assert clean == dirty and len(clean) == 1
     # with min_count 1 the error k-mers survive and open a bubble -> more unitigs
-    assert len(CO.assemble_pool(b"".join([bytes(bad)] + reads[1:] + [reads[0]]), L, 31, 29, min_count=1, min_contig=29)) > 1
+    assert len(CO.assemble_pool(b"".join([bytes(bad)] + reads[1:] + [reads[0]]), L, 31, 29, min_count=1, min_contig=29, simplify=0)) > 1
 
 
 def test_snp_bubble_gives_four_unitigs():
@@ -57,7 +58,7 @@ def test_snp_bubble_gives_four_unitigs():
     h = bytes(h)
     L = 100
     reads = tiled_reads(g, L, 300, rng) + tiled_reads(h, L, 300, rng) + [g[:L], g[-L:], h[:L], h[-L:]] * 2
-    ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29)
+    ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=0)
     # left arm, right arm, two bubble branches of kv nodes each
     lens = sorted(len(c[0]) for c in ctg)
     assert len(ctg) == 4 and lens[0] == lens[1] == 29 + 29 - 1
@@ -71,7 +72,7 @@ def test_two_copy_repeat_longer_than_kv_gives_three_unitigs():
     g = a + rep + b + rep + c
     L = 100
     reads = tiled_reads(g, L, 500, rng) + [g[:L], g[-L:]] * 2
-    ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29)
+    ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=0)
     # a+, rep, b (between the copies), c: the repeat collapses into one node path entered twice
     assert len(ctg) == 4
     assert any(x[0].encode() in (rep, rc(rep)) or rep in x[0].encode() or rc(rep) in x[0].encode() for x in ctg)
@@ -116,7 +117,7 @@ def test_snp_bubble_is_popped_into_one_contig():
     h = _mut(g, 500)
     L = 100
     reads = _cover(g, L) + _cover(h[430:590], L, step=3)
-    raw = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29)
+    raw = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=0)
     assert len(raw) == 4
     ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=2)
     assert len(ctg) == 1 and len(ctg[0][0]) == 1000
@@ -134,7 +135,7 @@ def test_short_tip_is_clipped_and_the_true_path_joined():
     # two reads that follow the genome up to position 420 and then run 20 bases into random sequence: a dead-end branch
     tip = g[340:420] + LUT[rng.randint(0, 4, 20)].tobytes()
     reads = _cover(g, L) + [tip, tip]
-    raw = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29)
+    raw = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=0)
     assert len(raw) == 3                                   # left part, right part, the tip (>= 29 bases)
     ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=2)
     assert len(ctg) == 1 and ctg[0][0].encode() in (g, rc(g))
@@ -157,7 +158,7 @@ def test_true_fork_of_a_two_copy_repeat_is_kept():
     g = a + rep + b + rep + c
     L = 100
     reads = tiled_reads(g, L, 500, rng) + [g[:L], g[-L:]] * 2
-    assert CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=2) == CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29)
+    assert CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=2) == CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=0)
 
 
 def test_two_overlapping_snp_bubbles_are_both_popped():
@@ -168,7 +169,7 @@ def test_two_overlapping_snp_bubbles_are_both_popped():
     L = 100
     h1, h2 = _mut(g, 500), _mut(g, 512, 2)
     reads = _cover(g, L) + _cover(h1[430:580], L, step=3) + _cover(h2[440:600], L, step=3)
-    raw = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29)
+    raw = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=0)
     assert len(raw) >= 6
     ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=2)
     assert len(ctg) == 1 and ctg[0][0].encode() in (g, rc(g))
@@ -191,7 +192,7 @@ def test_tip_and_bubble_at_k51_wide_keys():
     reads = _cover(g, L) + _cover(_mut(g, 300)[200:420], L, step=3) + [tip, tip, rc(tip)]
     ctg = CO.assemble_pool(b"".join(reads), L, 51, 49, simplify=2)
     assert len(ctg) == 1 and len(ctg[0][0]) == 1200
-    assert len(CO.assemble_pool(b"".join(reads), L, 51, 49)) > 1
+    assert len(CO.assemble_pool(b"".join(reads), L, 51, 49, simplify=0)) > 1
 
 
 def test_sequencing_errors_seen_twice_no_longer_split_the_gap_contig():
@@ -207,7 +208,7 @@ def test_sequencing_errors_seen_twice_no_longer_split_the_gap_contig():
             r[p] = b"ACGT"[(b"ACGT".index(bytes([r[p]])) + 1 + rng.randint(3)) % 4]
         r = bytes(r)
         reads.append(rc(r) if rng.randint(2) else r)
-    raw = CO.assemble_pool(b"".join(reads), L, 31, 29)
+    raw = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=0)
     ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=2)
     assert len(raw) > 3 and len(ctg) < len(raw)
     # one contig now spans the whole interior (a popped bubble may keep the error allele — equal coverage, the tie-break is

@@ -118,8 +118,16 @@ def test_deep_noisy_pool(gf, n_reads, kk):
     got, _ = _gpu_assemble(gf, [pool], L, kk)     # k <= 31 / 32 < k <= 63: key-slot count phase in the global table; 64: instance ids
     for (k, kv) in kk:
         exp = CO.assemble_pool(pool, L, k, kv)
-        assert len(exp) > 20, (k, kv)
         assert got[(0, k, kv)] == exp, (k, kv)
+    gf.set_option("asm_simplify", 0)          # raw unitigs: the errors seen twice split the graph into dozens of pieces
+    try:
+        raw, _ = _gpu_assemble(gf, [pool], L, kk)
+    finally:
+        gf.set_option("asm_simplify", 2)
+    for (k, kv) in kk:
+        exp = CO.assemble_pool(pool, L, k, kv, simplify=0)
+        assert len(exp) > 20, (k, kv)
+        assert raw[(0, k, kv)] == exp, (k, kv)
 
 
 def test_count_kmers_matches_oracle(gf):
@@ -141,3 +149,104 @@ def test_even_kv_is_rejected(gf):
     with pytest.raises(B.GapFillError) as e:
         gf.assemble(packed, np.array([0, 4], np.uint64), 100, [(31, 28)])
     assert e.value.code == B.GF_E_UNSUPPORTED
+
+
+def _kat_pools():
+    """The hand-built error-removal cases of tests/test_assembly_oracle.py as pools: SNP bubble, short tip, long dead end,
+    two-copy repeat, overlapping bubbles, three alleles, noisy 40x pool; (k, kv) per pool."""
+    from test_assembly_oracle import _cover, _mut
+    pools = []
+    rng = np.random.RandomState(17)
+    g = LUT[rng.randint(0, 4, 1000)].tobytes()
+    pools.append((100, (31, 29), _cover(g, 100) + _cover(_mut(g, 500)[430:590], 100, step=3)))
+    rng = np.random.RandomState(18)
+    g = LUT[rng.randint(0, 4, 900)].tobytes()
+    tip = g[340:420] + LUT[rng.randint(0, 4, 20)].tobytes()
+    pools.append((100, (31, 29), _cover(g, 100) + [tip, tip]))
+    rng = np.random.RandomState(19)
+    g = LUT[rng.randint(0, 4, 900)].tobytes()
+    pools.append((100, (31, 29), _cover(g, 100) + _cover(g[300:420] + LUT[rng.randint(0, 4, 80)].tobytes(), 100, step=5)))
+    rng = np.random.RandomState(8)
+    rep = LUT[rng.randint(0, 4, 60)].tobytes()
+    a, b, c = (LUT[rng.randint(0, 4, 300)].tobytes() for _ in range(3))
+    g = a + rep + b + rep + c
+    pools.append((100, (31, 29), tiled_reads(g, 100, 500, rng) + [g[:100], g[-100:]] * 2))
+    rng = np.random.RandomState(21)
+    g = LUT[rng.randint(0, 4, 1000)].tobytes()
+    pools.append((100, (31, 29), _cover(g, 100) + _cover(_mut(g, 500)[430:580], 100, step=3) + _cover(_mut(g, 512, 2)[440:600], 100, step=3)))
+    rng = np.random.RandomState(22)
+    g = LUT[rng.randint(0, 4, 800)].tobytes()
+    pools.append((100, (31, 29), _cover(g, 100) + _cover(_mut(g, 400, 1)[330:490], 100, step=3) + _cover(_mut(g, 400, 2)[330:490], 100, step=3)))
+    rng = np.random.RandomState(23)
+    g = LUT[rng.randint(0, 4, 1200)].tobytes()
+    tip = g[500:630] + LUT[rng.randint(0, 4, 20)].tobytes()
+    pools.append((150, (51, 49), _cover(g, 150) + _cover(_mut(g, 300)[200:420], 150, step=3) + [tip, tip, rc(tip)]))
+    rng = np.random.RandomState(24)
+    g = LUT[rng.randint(0, 4, 2600)].tobytes()
+    reads = []
+    for _ in range(int(40 * len(g) / 150)):
+        s = rng.randint(0, len(g) - 150 + 1)
+        r = bytearray(g[s:s + 150])
+        for p in np.nonzero(rng.rand(150) < 0.005)[0]:
+            r[p] = b"ACGT"[(b"ACGT".index(bytes([r[p]])) + 1 + rng.randint(3)) % 4]
+        reads.append(rc(bytes(r)) if rng.randint(2) else bytes(r))
+    pools.append((150, (31, 29), reads))
+    pools.append((150, (41, 39), reads))
+    return pools
+
+
+@pytest.mark.parametrize("simplify", [0, 1, 2, 4])
+def test_error_removal_known_answers_on_gpu(gf, simplify):
+    """Tip clipping + bubble popping (Velvet's defaults as oracle/gp_oracle.c defines them) in the assembly kernel: every
+    hand-built case, every number of rounds, bit-exact vs the oracle; the LDS plan and the all-global plan agree."""
+    gf.set_option("asm_simplify", simplify)
+    try:
+        for L in (100, 150):
+            for kk in ((31, 29), (51, 49), (41, 39)):
+                group = [b"".join(r) for (l, k2, r) in _kat_pools() if l == L and k2 == kk]
+                if not group:
+                    continue
+                got, _ = _gpu_assemble(gf, group, L, [kk])
+                for i, p in enumerate(group):
+                    exp = CO.assemble_pool(p, L, kk[0], kk[1], simplify=simplify)
+                    assert got.get((i, kk[0], kk[1]), []) == exp, (L, kk, i, simplify)
+                gf.set_option("asm_lds_pool_kb", 8)        # nothing fits in LDS: graph, pairs and table in global memory
+                try:
+                    got2, _ = _gpu_assemble(gf, group, L, [kk])
+                finally:
+                    gf.set_option("asm_lds_pool_kb", 152)
+                assert got2 == got, (L, kk, simplify)
+        if simplify >= 1:
+            snp = [b"".join(r) for (l, k2, r) in _kat_pools() if l == 100][0]
+            assert len(_gpu_assemble(gf, [snp], 100, [(31, 29)])[0][(0, 31, 29)]) == 1     # the SNP bubble is one contig now
+    finally:
+        gf.set_option("asm_simplify", 2)
+
+
+def test_random_error_graphs_match_oracle(gf):
+    """Many small pools with planted substitutions seen twice at random places (bubbles, tips at read ends, clusters closer than
+    kv): GPU == oracle at the default two rounds, pool by pool."""
+    rng = np.random.RandomState(99)
+    L = 100
+    pools = []
+    for _ in range(60):
+        g = LUT[rng.randint(0, 4, rng.randint(300, 900))].tobytes()
+        reads = []
+        for s in range(0, len(g) - L + 1, 5):
+            reads += [g[s:s + L], rc(g[s:s + L])]
+        for _e in range(rng.randint(1, 6)):
+            s = rng.randint(0, len(g) - L + 1)
+            r = bytearray(g[s:s + L])
+            for _m in range(rng.randint(1, 3)):
+                p = rng.randint(0, L)
+                r[p] = b"ACGT"[(b"ACGT".index(bytes([r[p]])) + 1 + rng.randint(3)) % 4]
+            reads += [bytes(r)] * 2
+        pools.append(b"".join(reads))
+    got, _ = _gpu_assemble(gf, pools, L, [(31, 29), (41, 39)])
+    n_diff_raw = 0
+    for i, p in enumerate(pools):
+        for k, kv in ((31, 29), (41, 39)):
+            exp = CO.assemble_pool(p, L, k, kv)
+            assert got.get((i, k, kv), []) == exp, (i, k, kv)
+            n_diff_raw += exp != CO.assemble_pool(p, L, k, kv, simplify=0)
+    assert n_diff_raw > 30      # the removal did something in most pools
