@@ -247,6 +247,12 @@ def main():
     sync_all()
     torch.cuda.synchronize()
     rows_lib = [int(lb.d_pool_off[-1]) for lb in libs]
+    # largest merged pool (all libraries, all ranks): bounds the assembly's per-workgroup workspace slices
+    per_gap = sum((lb.d_pool_off[1:] - lb.d_pool_off[:-1]) for lb in libs).to(coll_dev)
+    if world > 1:
+        dist.all_reduce(per_gap, op=dist.ReduceOp.SUM)
+    max_pool_rows = int(per_gap.max())
+    gf.set_option("asm_max_pool_reads", int(1.5 * max_pool_rows) + 64)
     lib_cap = max(4096, int(1.25 * max(rows_lib)) + 1024)            # rows of one library's pool array
     # local pool arrays: [n_lib][lib_cap] rows (slot l = library l: the source layout of gf_pools_merge_dev)
     d_pools = torch.empty(n_lib * lib_cap * rb + 64, dtype=torch.uint8, device=dev)
@@ -451,7 +457,7 @@ def main():
             "phases_note": "HIP-event spans per kernel group, summed over the libraries, per step; tagger + second hop run on a second "
                            "stream beside the screen, so their spans include queueing behind the filter (GF_BENCH_SERIAL=1: one stream)",
             "counts": {"libraries": {lb.name: lb.counts for lb in libs}, "assembled_pool_reads": asm_rows_total, "contigs": n_ctg_all,
-                       "gaps_with_contig": gaps_with_contig, "gaps_closed": n_closed},
+                       "gaps_with_contig": gaps_with_contig, "gaps_closed": n_closed, "largest_pool_reads": max_pool_rows},
         }
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms

@@ -185,6 +185,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "screen_variant")) { ctx->screen_variant = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_dbg_ptr")) { ctx->asm_dbg = (void*)(uintptr_t)value; return GF_OK; }
     if (!strcmp(name, "asm_keyslot")) { ctx->asm_keyslot = value != 0; return GF_OK; }
+    if (!strcmp(name, "asm_max_pool_reads")) { if (value < 0 || value > 0x3FFFFFFF) return GF_E_INVAL; ctx->asm_max_pool_reads = value; return GF_OK; }
     if (!strcmp(name, "asm_simplify")) { if (value < 0 || value > 8) return GF_E_INVAL; ctx->asm_simplify = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_lds_pool_kb")) { ctx->asm_lds_pool_kb = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_lds_log2_max")) {
@@ -413,6 +414,15 @@ int gf_assemble(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, const 
     for (size_t g = 0; g < n_pools; ++g) if (pool_off[g] > pool_off[g + 1]) return GF_E_INVAL;
     const size_t rb = gf_packed_read_bytes(read_len), nmw = (size_t)(read_len + 31) / 32;
     int rc;
+    // the host knows its pools: bound the per-workgroup workspace slices by the largest one
+    struct MaxRows {
+        gf_ctx* c; long saved;
+        MaxRows(gf_ctx* c_, long v) : c(c_), saved(c_->asm_max_pool_reads) { c->asm_max_pool_reads = v; }
+        ~MaxRows() { c->asm_max_pool_reads = saved; }
+    };
+    size_t max_rows = 1;
+    for (size_t g = 0; g < n_pools; ++g) max_rows = std::max<size_t>(max_rows, (size_t)(pool_off[g + 1] - pool_off[g]));
+    MaxRows bound(ctx, (long)std::min<size_t>(max_rows, 0x3FFFFFFF));
     // device staging: [pool | pool_off | gap_error | counters | contigs | seq]
     const size_t b_pool = (total * rb + 63) & ~(size_t)63, b_off = ((n_pools + 1) * 8 + 63) & ~(size_t)63,
                  b_err = (n_pools * 4 + 63) & ~(size_t)63, b_ctg = (contig_cap * sizeof(gf_contig) + 63) & ~(size_t)63;

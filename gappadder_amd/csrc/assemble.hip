@@ -35,6 +35,7 @@ struct AsmParams {
     uint32_t* nodes;           // 3 words per instance: per-node meta + succ[2] when they do not fit in LDS
     uint32_t* jump;            // 4 words per instance: the unitig-ranking pairs of the oriented nodes when they do not fit in LDS
     uint32_t simplify;         // rounds of tip clipping + bubble popping (0: raw unitigs)
+    uint32_t slice_rows;       // > 0: the workspace holds one slice of this many pool rows per workgroup
     gf_contig* contigs;
     uint32_t contig_cap;
     uint32_t* n_contigs;
@@ -312,7 +313,13 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         // n_r * (L - kv + 1) bounds the distinct k-mers, the nodes and every list below
         const uint32_t unit = P.cnt_keys ? npos : P.read_len - P.kv + 1;
         const uint64_t n_unit64 = (uint64_t)n_r * unit;
-        const uint64_t inst_off = r0 * unit;
+        // workspace slice: per pool row (slice_rows == 0), or one private slice per workgroup that every gap it takes re-uses
+        // (kernels leave their slice EMPTY) — sized by the caller's bound on the rows of one pool
+        if (P.slice_rows && n_r > P.slice_rows) {
+            if (tid == 0) P.gap_error[g] |= ASM_ERR_IDS;
+            continue;
+        }
+        const uint64_t inst_off = P.slice_rows ? (uint64_t)blockIdx.x * P.slice_rows * unit : r0 * unit;
         if (n_unit64 >= (1ull << 30) || (uint64_t)n_r * P.read_len >= 0xFFFFFFF0ull) {  // ids are 32-bit
             if (tid == 0) P.gap_error[g] = ASM_ERR_IDS;
             continue;
@@ -1075,7 +1082,11 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     if (!d_cnt_keys && (kv < 15 || kv >= k || !(kv & 1))) return GF_E_UNSUPPORTED;
     if (n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull) return GF_E_INVAL;
     const uint32_t unit = d_cnt_keys ? read_len - k + 1 : read_len - kv + 1;
-    const uint64_t n_inst = (uint64_t)total_reads * unit;  // workspace units (see the kernel)
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(n_pools, (size_t)ctx->n_cu));
+    // workspace units (see the kernel): one slice per pool row, or — when the caller bounds the rows of one pool (option
+    // asm_max_pool_reads; the host entry points know their pools) — one slice of that many rows per workgroup
+    const uint64_t slice_rows = ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * grid < total_reads ? (uint64_t)ctx->asm_max_pool_reads : 0;
+    const uint64_t n_inst = (slice_rows ? slice_rows * grid : (uint64_t)total_reads) * unit;
     int rc;
     {   // the table must be all-EMPTY (id 0xFFFFFFFF, meta 0) on entry; kernels leave it so, a fresh buffer is filled once
         void* before = ctx->asm_table.p;
@@ -1118,6 +1129,7 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.nodes = (uint32_t*)ctx->asm_nodes.p;
     P.jump = (uint32_t*)ctx->asm_jump.p;
     P.simplify = (uint32_t)std::max(0, ctx->asm_simplify);
+    P.slice_rows = (uint32_t)slice_rows;
     P.contigs = (gf_contig*)d_contigs;
     P.contig_cap = (uint32_t)contig_cap;
     P.n_contigs = (uint32_t*)d_n_contigs;
@@ -1132,7 +1144,6 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     // dynamic LDS (option asm_lds_kb, default all 152 KiB): the gap's packed reads, then meta + succ[2] of its nodes;
     // whatever does not fit is read from / kept in global memory
     P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
-    const unsigned grid = (unsigned)std::min<size_t>(n_pools, (size_t)ctx->n_cu);
     {
         LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
         hipLaunchKernelGGL(k <= 32 ? assemble_kernel<false> : assemble_kernel<true>, dim3(grid), dim3(ASM_THREADS), (size_t)P.lds_words * 4, ctx->stream, P);

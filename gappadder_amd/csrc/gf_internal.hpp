@@ -89,6 +89,7 @@ struct gf_ctx {
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)
     int asm_lds_pool_kb = 152;
     int asm_simplify = 2;        // rounds of tip clipping + bubble popping in the assembly (Velvet's defaults are on; 0: raw unitigs)
+    long asm_max_pool_reads = 0; // > 0: no pool has more rows than this (the assembly workspace is then one slice per workgroup, not per row)
     int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
     void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)
     // tagger coarse bin map (rebuilt when dist2 changes)

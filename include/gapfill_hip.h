@@ -101,7 +101,11 @@ int gf_stream_wait(gf_ctx* waiter, gf_ctx* producer);
  * Ablation / diagnostic switches (results never change): "screen_variant" (0 automatic, 9 plain, 12 wave, 13 pipelined, 14 partitioned
  * filter kernel), "screen_verify_ext" (1: seed-and-extend verification when min_hits == 1), "screen_verify_gate",
  * "screen_verify_batch", "screen_stream_policy", "screen_lds_log2_max", "screen_np_override" (timing experiments: fewer probes, WRONG hits; refused unless the environment has GF_DIAGNOSTICS set),
- * "asm_keyslot", "asm_lds_pool_kb", "asm_dbg_ptr". */
+ * "asm_keyslot", "asm_lds_pool_kb", "asm_dbg_ptr".
+ * Assembly: "asm_simplify" (rounds of tip clipping + bubble popping — Velvet's defaults, which the reference runs with
+ * (assemble_gaps.py:117); default 2, 0 = raw unitigs), "asm_max_pool_reads" (device variants: upper bound on the rows of one
+ * pool; the assembly workspace is then one slice of that size per workgroup instead of one per pool row — a pool beyond the bound
+ * sets its gap_error; 0 = no bound). */
 int gf_set_option(gf_ctx* ctx, const char* name, long value);
 
 /* ---- gaps + flanks (gnrt_pos_true_seqs.py:12-100 defines them; host-side there and here) ----------- */

@@ -37,7 +37,7 @@ def test_collect_reproduces_the_reference_tree(run):
         else:   # list files whose line order is dict-defined in the reference: same lines
             assert sorted(got[rel].splitlines()) == sorted(txt.splitlines()), rel
         checked += 1
-    assert checked == len(case.expected) and checked > 40
+    assert checked == len(case.expected) and checked > 15
     later = ("merged/velvet_temp/", "picked_seqs.fa",                                  # Assembly stage, first round
              "merged/both_unmapped", "merged/gap_contigs_all.fa", "merged/unmapped_reads/")   # ... second round
     extra = [k for k in got if k not in case.expected and not k.startswith(later)]
