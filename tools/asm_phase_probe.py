@@ -17,6 +17,8 @@ hits = gf.screen_reads(packed, 150, 31)
 ids = {}
 for h in hits:
     ids.setdefault(int(h["gap"]), set()).update((int(h["read"]), int(h["read"]) ^ 1))
+for h in gf.tag_alignments(recs, 300, 30):
+    ids.setdefault(int(h["gap"]), set()).add(int(recs[h["rec"]]["read"]) ^ int(h["to_mate"]))
 order = [sorted(ids.get(g, [])) for g in range(len(gaps))]
 off = np.cumsum([0] + [len(o) for o in order]).astype(np.uint64)
 pool = packed[np.concatenate([np.array(o, dtype=np.int64) for o in order if o])]
@@ -25,13 +27,15 @@ dev = torch.device("cuda:0")
 dbg = torch.zeros(len(gaps) * 8, dtype=torch.int64, device=dev)
 gf.set_option("asm_dbg_ptr", dbg.data_ptr())
 gf.timing(True)
+if os.environ.get("SIMPLIFY"):
+    gf.set_option("asm_simplify", int(os.environ["SIMPLIFY"]))
 for _ in range(3):
     K = int(os.environ.get("K", "31")); ctg, seq = gf.assemble(pool, off, 150, [(K, K - 2)])
 ms, n = gf.kernel_time(B.KERNEL_ASSEMBLE)
 print("assemble kernel %.3f ms avg, contigs %d" % (ms / n, len(ctg)))
 d = dbg.cpu().numpy().reshape(-1, 8)
 ph = np.diff(d[:, :7], axis=1) / 100.0  # us
-names = ["P1 count", "P2 survivors", "P3 graph", "P4 starts", "P5a walk", "P5b write"]
+names = ["P1 count", "P2 survivors", "P3 graph+index", "P4 links", "rank+error removal", "emission"]
 for i, nm in enumerate(names):
     print("%-14s mean %8.1f us   max %8.1f us" % (nm, ph[:, i].mean(), ph[:, i].max()))
 print("total/gap mean %.1f us max %.1f us; kernel span %.1f us" % (ph.sum(1).mean(), ph.sum(1).max(), (d[:, 6].max() - d[:, 0].min()) / 100.0))
