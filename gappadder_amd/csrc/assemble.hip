@@ -99,11 +99,40 @@ __device__ __forceinline__ uint32_t pv_stream32(const PoolView& V, uint64_t bit)
     return (uint32_t)((v << sh) >> 32);
 }
 
-// left-aligned `len`-mer at instance id (read * L + off)
-// W = false: the launch has k <= 32, so every key is one 64-bit word (lo == 0) and the 128-bit halves compile away
+// instance id of a read window: read-in-pool << 10 | offset (read_len <= 1000; a pool has fewer than 2^22 reads): no division
+// when a key is re-derived from an id, and `id + o` is the window o bases further on in the same read
+constexpr uint32_t INST_OFF_BITS = 10, INST_OFF_MASK = (1u << INST_OFF_BITS) - 1;
+__device__ __forceinline__ uint32_t make_inst(uint32_t r, uint32_t off) { return (r << INST_OFF_BITS) | off; }
+
+// left-aligned `len`-mer at (read r, offset off) of the pool staged at the start of the dynamic LDS: six dwords, five byte
+// permutes (unaligned fetch + byte swap in one v_perm each) and a funnel shift by the 0/2/4/6 bits the offset leaves
 template <bool W>
-__device__ __forceinline__ K128 pv_kmer(const PoolView& V, uint32_t inst, int len) {
-    const uint32_t r = inst / V.L, off = inst - r * V.L;
+__device__ __forceinline__ K128 lds_window(uint32_t rb, uint32_t r, uint32_t off, int len) {
+    const uint32_t byte = r * rb + (off >> 2);
+    const uint32_t w = byte >> 2;
+    const uint32_t sel = 0x00010203u + (byte & 3u) * 0x01010101u;
+    const uint32_t sh = 2u * (off & 3u);
+    const uint32_t a0 = g_lds[w], a1 = g_lds[w + 1], a2 = g_lds[w + 2], a3 = g_lds[w + 3];
+    const uint32_t b0 = __builtin_amdgcn_perm(a1, a0, sel), b1 = __builtin_amdgcn_perm(a2, a1, sel), b2 = __builtin_amdgcn_perm(a3, a2, sel);
+    const uint64_t x0 = ((uint64_t)b0 << 32) | b1;
+    K128 v;
+    if (!W) {
+        v.hi = ((x0 << sh) | (((uint64_t)b2 >> 1) >> (31 - sh))) & (~0ull << (64 - 2 * len));
+        v.lo = 0;
+        return v;
+    }
+    const uint32_t a4 = g_lds[w + 4], a5 = g_lds[w + 5];
+    const uint32_t b3 = __builtin_amdgcn_perm(a4, a3, sel), b4 = __builtin_amdgcn_perm(a5, a4, sel);
+    const uint64_t x1 = ((uint64_t)b2 << 32) | b3, x2 = (uint64_t)b4 << 32;
+    v.hi = (x0 << sh) | ((x1 >> 1) >> (63 - sh));
+    v.lo = (x1 << sh) | ((x2 >> 1) >> (63 - sh));
+    return mask_k(v, len);
+}
+
+// same for a (read, offset) pair of any pool view
+template <bool W>
+__device__ __forceinline__ K128 pv_kmer_at(const PoolView& V, uint32_t r, uint32_t off, int len) {
+    if (V.lds) return lds_window<W>(V.rb, r, off, len);
     const uint64_t bit = (uint64_t)r * V.rb * 8 + 2ull * off;
     K128 v;
     v.hi = ((uint64_t)pv_stream32(V, bit) << 32) | pv_stream32(V, bit + 32);
@@ -115,19 +144,11 @@ __device__ __forceinline__ K128 pv_kmer(const PoolView& V, uint32_t inst, int le
     if (len > 32) v.lo = ((uint64_t)pv_stream32(V, bit + 64) << 32) | pv_stream32(V, bit + 96);
     return mask_k(v, len);
 }
-// same for a (read, offset) pair: no division
+// left-aligned `len`-mer at an instance id
+// W = false: the launch has k <= 32, so every key is one 64-bit word (lo == 0) and the 128-bit halves compile away
 template <bool W>
-__device__ __forceinline__ K128 pv_kmer_at(const PoolView& V, uint32_t r, uint32_t off, int len) {
-    const uint64_t bit = (uint64_t)r * V.rb * 8 + 2ull * off;
-    K128 v;
-    v.hi = ((uint64_t)pv_stream32(V, bit) << 32) | pv_stream32(V, bit + 32);
-    v.lo = 0;
-    if (!W) {
-        v.hi &= ~0ull << (64 - 2 * len);
-        return v;
-    }
-    if (len > 32) v.lo = ((uint64_t)pv_stream32(V, bit + 64) << 32) | pv_stream32(V, bit + 96);
-    return mask_k(v, len);
+__device__ __forceinline__ K128 pv_kmer(const PoolView& V, uint32_t inst, int len) {
+    return pv_kmer_at<W>(V, inst >> INST_OFF_BITS, inst & INST_OFF_MASK, len);
 }
 template <bool W>
 __device__ __forceinline__ K128 revcomp_w(K128 v, int len) {
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             continue;
         }
         const uint64_t inst_off = P.slice_rows ? (uint64_t)blockIdx.x * P.slice_rows * unit : r0 * unit;
-        if (n_unit64 >= (1ull << 30) || (uint64_t)n_r * P.read_len >= 0xFFFFFFF0ull) {  // ids are 32-bit
+        if (n_unit64 >= (1ull << 30) || n_r >= (1u << (32 - INST_OFF_BITS)) - 1) {  // ids are 32-bit: read << 10 | offset
             if (tid == 0) P.gap_error[g] = ASM_ERR_IDS;
             continue;
         }
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         // ---- P1: count canonical k-mers; remember each distinct k-mer's slot.  Optimistic LDS table first.
         Tab tab;
         tab.g = gtab;
-        bool keyslot = false, keyslot_w = false;
+        bool keyslot = false, keyslot_w = false, fpslot_used = false;
         uint32_t* dist_inst = P.nodes + 3 * inst_off;   // key-slot mode: instance id of the q-th distinct k-mer
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool use_lds = attempt == 0 && r_words / 2 >= 1024;
@@ -386,6 +407,14 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             // (measured at k=41, 214-read pools: 161 us against 105 us per gap).
             const bool wide_ok = P.keyslot && W && k > 32 && k <= 63 && P.min_count <= 3 && !P.cnt_keys;
             keyslot_w = wide_ok && !use_lds;
+            // fingerprint slots (32 < k <= 63 in an LDS table over an LDS-staged pool): slot = instance id | 30-bit key fingerprint
+            // << 32 | 2-bit saturating count << 62.  A probe that meets another key sees it in the fingerprint (no re-derivation of
+            // the occupant's key: at 1 % errors 60 % of the slots fill up and every collision cost a 128-bit fetch + reverse
+            // complement); an equal fingerprint is verified EXACTLY by comparing the occupant's raw window with this window and
+            // its reverse complement; once the count is saturated a repeat costs no atomic.  (PMC: 900 wave instructions per k-mer
+            // with instance-id slots at k = 51.)
+            const bool fpslot = wide_ok && use_lds && V.lds;
+            fpslot_used = fpslot;
             const uint32_t limit_k = limit;
             // an LDS attempt that is bound to overflow is skipped: at ~1 % errors nearly half of all windows are distinct
             if (use_lds && (keyslot || wide_ok) && n_inst / 4 > limit) continue;
@@ -466,7 +495,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         ok[u] = false;
                         kk[u] = 0;
                         if (inst_i + u * ASM_THREADS < n_inst) kk[u] = kmer_of(r, p, ok[u]);
-                        ii[u] = r * P.read_len + p;
+                        ii[u] = make_inst(r, p);
                         ss[u] = slot_of(K128{kk[u], 0}, t.cap);
                         r += dr; p += dp;
                     }
@@ -501,7 +530,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 while (inst_i < n_inst) {
                     if (LDS && s_cnt[6]) break;
                     if (p >= npos) { p -= npos; ++r; }
-                    const uint32_t inst = r * P.read_len + p;
+                    const uint32_t inst = make_inst(r, p);
                     bool bad = false;
                     if (P.nmask) {
                         for (uint32_t q = p; q < p + P.k; ++q)
@@ -563,6 +592,58 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 }
                 };
                 if (use_lds) count_keyslot_wide(std::true_type{}); else count_keyslot_wide(std::false_type{});
+            } else if (fpslot) {
+                const uint32_t dr = ASM_THREADS / npos, dp = ASM_THREADS - dr * npos;
+                uint32_t r = tid / npos, p = tid - r * npos;
+                for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS, r += dr, p += dp) {
+                    if (s_cnt[6]) break;
+                    if (p >= npos) { p -= npos; ++r; }
+                    if (P.nmask) {
+                        bool bad = false;
+                        for (uint32_t q = p; q < p + P.k; ++q)
+                            if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
+                        if (bad) continue;
+                    }
+                    const K128 fw = lds_window<true>(V.rb, r, p, k);
+                    const K128 rc = revcomp(fw, k);
+                    const K128 key = rc < fw ? rc : fw;
+                    uint64_t x = key.hi ^ (key.lo * 0x9E3779B97F4A7C15ull) ^ (key.lo >> 29);
+                    x ^= x >> 31;
+                    x *= 0xD6E8FEB86659FD93ull;
+                    x ^= x >> 32;
+                    uint32_t sl = (uint32_t)(((x & 0xFFFFFFFFull) * tab.cap) >> 32);
+                    const unsigned long long fp = (x >> 34) << 32;                    // 30 bits, in place
+                    const unsigned long long mine = (1ull << 62) | fp | make_inst(r, p);
+                    bool placed = false;
+                    for (uint32_t probes = 0; probes < tab.cap; ++probes) {
+                        unsigned long long v = tab.load(sl);
+                        if ((uint32_t)v == EMPTY32) {
+                            v = tab.cas(sl, EMPTY64, mine);
+                            if (v == EMPTY64) {   // first occurrence
+                                const uint32_t q = atomicAdd(&s_cnt[4], 1u);
+                                if (q >= limit) s_cnt[6] = 1;
+                                if (q < n_unit) list_a[q] = sl;
+                                placed = true;
+                                break;
+                            }
+                        }
+                        if ((v & 0x3FFFFFFF00000000ull) == fp) {
+                            const uint32_t oi = (uint32_t)v;
+                            const K128 ow = lds_window<true>(V.rb, oi >> INST_OFF_BITS, oi & INST_OFF_MASK, k);
+                            if (ow == fw || ow == rc) {   // the same canonical k-mer
+                                while ((v >> 62) != 3ull) {   // saturating increment
+                                    const unsigned long long o = tab.cas(sl, v, v + (1ull << 62));
+                                    if (o == v) break;
+                                    v = o;
+                                }
+                                placed = true;
+                                break;
+                            }
+                        }
+                        sl = sl + 1 == tab.cap ? 0 : sl + 1;
+                    }
+                    if (!placed) s_cnt[6] = 1;
+                }
             } else
             for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
                 if (use_lds && s_cnt[6]) break;
@@ -573,7 +654,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
                     if (bad) continue;
                 }
-                const uint32_t inst = r * P.read_len + p;
+                const uint32_t inst = make_inst(r, p);
                 const K128 key = canonical_w<W>(pv_kmer<W>(V, inst, k), k);
                 bool fresh;
                 const uint32_t s = table_upsert<W>(tab, V, key, inst, k, 1u, &fresh);
@@ -617,7 +698,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 uint32_t id = 0, c = 0;
                 if (in[u]) {
                     id = (keyslot || keyslot_w) ? idv[u] : (uint32_t)v[u];
-                    c = keyslot_w ? (uint32_t)(~v[u] & 3ull)
+                    c = fpslot_used ? (uint32_t)(v[u] >> 62)
+                        : keyslot_w ? (uint32_t)(~v[u] & 3ull)
                         : keyslot ? (uint32_t)((tab_global ? ~v[u] : (GF_KS_COMPLEMENT_LDS ? ~v[u] : v[u])) & 3ull) : (uint32_t)(v[u] >> 32);
                     keep = c >= P.min_count;
                     if (tab_global) {
@@ -778,109 +860,69 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         bool cacc_lds = false;
         uint32_t* cacc = nullptr;
         uint32_t cacc_cap = 0;
-        for (uint32_t round = 0;; ++round) {
-            // ---- P4: unitig-internal edges.  (x,d) -> (y,dy) is internal iff out-degree(x,d) == 1 and in-degree(y,dy) == 1;
-            //      an oriented node that no internal edge enters is a unitig START.
-            if (round) {
-                for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
-                    nmeta.and_(ni, ~(M_START0 | M_START1 | M_KILL));
-                    succ0.set(ni, EMPTY32);
-                    succ1.set(ni, EMPTY32);
-                }
-                wg_phase_sync();
+        // ---- P4: unitig-internal edges.  (x,d) -> (y,dy) is internal iff out-degree(x,d) == 1 and in-degree(y,dy) == 1;
+        //      an oriented node that no internal edge enters is a unitig START.
+        for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
+            const uint32_t meta = nmeta.get(ni);
+            const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(ni), kv), kv);
+            for (uint32_t d = 0; d < 2; ++d) {
+                const uint32_t ob = out_bits(meta & 0xFFu, d);
+                if (__popc(ob) != 1) continue;
+                const K128 cur = d ? revcomp_w<W>(x, kv) : x;
+                const uint32_t y = find_oriented(shift_in(cur, __ffs(ob) - 1, kv));
+                if (y == EMPTY32) continue;
+                if (__popc(inb(y)) != 1) continue;
+                (d ? succ1 : succ0).set(ni, y);
+                nmeta.or_(y >> 1, (y & 1) ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
             }
-            for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
-                const uint32_t meta = nmeta.get(ni);
-                if (meta & M_DEAD) continue;
-                const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(ni), kv), kv);
-                for (uint32_t d = 0; d < 2; ++d) {
-                    const uint32_t ob = out_bits(meta & 0xFFu, d);
-                    if (__popc(ob) != 1) continue;
-                    const K128 cur = d ? revcomp_w<W>(x, kv) : x;
-                    const uint32_t y = find_oriented(shift_in(cur, __ffs(ob) - 1, kv));
-                    if (y == EMPTY32) continue;
-                    if (__popc(inb(y)) != 1) continue;
-                    (d ? succ1 : succ0).set(ni, y);
-                    nmeta.or_(y >> 1, (y & 1) ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
-                }
-            }
-            wg_phase_sync();
-            if (round == 0) ASM_STAMP(4);
+        }
+        wg_phase_sync();
+        ASM_STAMP(4);
 
-            // ---- P5: unitigs ranked by pointer jumping: every oriented node learns its unitig's head and its rank in
-            //      ~log2(longest unitig) rounds.  Pairs are read and written as single 64-bit accesses, so the asynchronous
-            //      in-place update keeps the invariant "ancestor at that distance".
-            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                unsigned long long pr = o;                                      // heads (and dead nodes): {self, 0}
-                if (has_pred(o)) {
-                    const uint32_t back = succ_get(o ^ 1u);                     // walking the other way from this node
-                    pr = (1ull << 32) | (back ^ 1u);                            // its internal predecessor, one step away
-                }
-                J.store(o, pr);
+        // ---- error removal (semantics: oracle/gp_oracle.c simplify_round): rounds on snapshots of the graph.  Every
+        //      head decides for its unitig X — TIP (dead end, <= kv nodes, hangs on a junction where another branch beats it) or
+        //      BUBBLE (<= 2 kv nodes between two junctions that an alternative path of the same length also joins).  Candidates are
+        //      short, so heads WALK the links (no ranking needed yet): a decision only sets the KILL bit of X's end nodes; after the
+        //      barrier the arcs into X are cleared at their sources, X's nodes die, and the junctions that lost a branch re-link.
+        // unitig headed by h: tail and node count, false when it has more than `limit` nodes
+        auto walk = [&](uint32_t h, uint32_t limit, uint32_t& tail, uint32_t& n) -> bool {
+            uint32_t cur = h;
+            n = 1;
+            for (;;) {
+                const uint32_t nx = succ_get(cur);
+                if (nx == EMPTY32) break;
+                if (n == limit) return false;
+                cur = nx;
+                ++n;
             }
-            wg_phase_sync();
-            for (int jr = 0; jr < 24; ++jr) {
-                if (tid == 0) s_cnt[7] = 0;
-                __syncthreads();
-                bool changed = false;
-                for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                    const unsigned long long a0 = J.load(o);
-                    const uint32_t pa = (uint32_t)a0;
-                    if (pa == o) continue;
-                    const unsigned long long a1 = J.load(pa);
-                    const uint32_t pb = (uint32_t)a1;
-                    if (pb == pa) continue;                                     // parent is a head (or this is a finished cycle hop)
-                    J.store(o, ((unsigned long long)((uint32_t)(a0 >> 32) + (uint32_t)(a1 >> 32)) << 32) | pb);
-                    changed = true;
-                }
-                if (changed) s_cnt[7] = 1;
-                __syncthreads();
-                if (!s_cnt[7]) break;
-                __syncthreads();
-            }
-            wg_phase_sync();
-            // tails publish {tail, length} in their head's pair (heads are not read as ancestors any more)
-            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                if (is_dead(o) || succ_get(o) != EMPTY32) continue;
-                const bool hp = has_pred(o);
-                const unsigned long long a0 = hp ? J.load(o) : 0ull;
-                const uint32_t h = hp ? (uint32_t)a0 : o;
-                if (has_pred(h)) continue;                                      // part of an isolated cycle: never reported
-                const uint32_t rank = hp ? (uint32_t)(a0 >> 32) : 0;
-                J.store(h, ((unsigned long long)(rank + 1) << 32) | o);
-            }
-            wg_phase_sync();
-            if (round >= P.simplify) break;
-
-            // ---- error removal, one round on this snapshot (semantics: oracle/gp_oracle.c simplify_round): every
-            //      head decides for its unitig X — TIP (dead end, <= kv nodes, hangs on a junction where another branch beats it)
-            //      or BUBBLE (<= 2 kv nodes between two junctions that an alternative path of the same length also joins).
-            //      Decisions only set the KILL bit of the head's node; the graph changes after the barrier.
+            tail = cur;
+            return true;
+        };
+        auto uni_cov = [&](uint32_t h, uint32_t n) -> uint32_t {
+            uint32_t cur = h, c = 0;
+            for (uint32_t i = 0; i < n && cur != EMPTY32; ++i) { c += nmeta.get(cur >> 1) >> M_MULT_SHIFT; cur = succ_get(cur); }
+            return c;
+        };
+        auto uni_key = [&](uint32_t h, uint32_t t) -> K128 {
+            const K128 a = node_seq(h), b = node_seq(t ^ 1u);
+            return b < a ? b : a;
+        };
+        // does the unitig headed by y (tail ty, ny nodes) beat the one headed by x?
+        auto beats = [&](uint32_t y, uint32_t ty, uint32_t ny, uint32_t x, uint32_t tx, uint32_t nx, bool with_len) -> bool {
+            if (with_len && ny != nx) return ny > nx;
+            const uint32_t cy = uni_cov(y, ny), cx = uni_cov(x, nx);
+            if (cy != cx) return cy > cx;
+            return uni_key(y, ty) < uni_key(x, tx);
+        };
+        for (uint32_t round = 0; round < P.simplify; ++round) {
             if (tid == 0) s_cnt[7] = 0;
             __syncthreads();
-            auto uni_cov = [&](uint32_t h, uint32_t n) -> uint32_t {
-                uint32_t cur = h, c = 0;
-                for (uint32_t i = 0; i < n && cur != EMPTY32; ++i) { c += nmeta.get(cur >> 1) >> M_MULT_SHIFT; cur = succ_get(cur); }
-                return c;
-            };
-            auto uni_key = [&](uint32_t h, uint32_t t) -> K128 {
-                const K128 a = node_seq(h), b = node_seq(t ^ 1u);
-                return b < a ? b : a;
-            };
-            // does the unitig headed by y (tail ty, ny nodes) beat the one headed by x?
-            auto beats = [&](uint32_t y, uint32_t ty, uint32_t ny, uint32_t x, uint32_t tx, uint32_t nx, bool with_len) -> bool {
-                if (with_len && ny != nx) return ny > nx;
-                const uint32_t cy = uni_cov(y, ny), cx = uni_cov(x, nx);
-                if (cy != cx) return cy > cx;
-                return uni_key(y, ty) < uni_key(x, tx);
-            };
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
                 if (is_dead(o) || has_pred(o)) continue;
-                const unsigned long long jo = J.load(o);
-                const uint32_t t = (uint32_t)jo, n = (uint32_t)(jo >> 32);
-                if (n == 0) continue;                                           // (a pair no tail wrote: cannot happen for a live head)
                 const uint32_t ib = inb(o);
                 if (__popc(ib) != 1) continue;
+                uint32_t t, n;
+                if (!walk(o, 2 * P.kv, t, n)) continue;
                 const K128 hs = node_seq(o);
                 const uint32_t p = find_oriented(shift_in_front(hs, __ffs(ib) - 1, kv));
                 if (p == EMPTY32) continue;
@@ -894,12 +936,11 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         if (!((pb >> c) & 1u)) continue;
                         const uint32_t y = find_oriented(shift_in(ps, c, kv));
                         if (y == EMPTY32 || y == o || has_pred(y) || y == (t ^ 1u)) continue;
-                        const unsigned long long jy = J.load(y);
-                        const uint32_t ty = (uint32_t)jy, ny = (uint32_t)(jy >> 32);
-                        const bool tip_shaped = outb(ty) == 0 && ny <= P.kv && __popc(inb(y)) == 1;
+                        uint32_t ty, ny;
+                        const bool tip_shaped = walk(y, P.kv, ty, ny) && outb(ty) == 0 && __popc(inb(y)) == 1;
                         if (!tip_shaped || beats(y, ty, ny, o, t, n, true)) go = true;
                     }
-                } else if (__popc(tb) == 1 && n <= 2 * P.kv) {                  // BUBBLE
+                } else if (__popc(tb) == 1) {                                   // BUBBLE (n <= 2 kv by the walk)
                     const uint32_t s = find_oriented(shift_in(node_seq(t), __ffs(tb) - 1, kv));
                     if (s != EMPTY32 && __popc(inb(s)) >= 2) {
                         // alternative paths p -> A1 .. Am -> s of whole unitigs, m <= 4, exactly n nodes, none of them X or its reverse
@@ -913,9 +954,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                             if (!((outb(q) >> c) & 1u)) continue;
                             const uint32_t y = find_oriented(shift_in(node_seq(q), c, kv));
                             if (y == EMPTY32 || has_pred(y) || y == o || y == (t ^ 1u)) continue;
-                            const unsigned long long jy = J.load(y);
-                            const uint32_t ty = (uint32_t)jy, ny = (uint32_t)(jy >> 32);
-                            if (ny > rem) continue;
+                            uint32_t ty, ny;
+                            if (!walk(y, rem, ty, ny)) continue;                 // more nodes than remain
                             if (ny == rem) {
                                 const uint32_t yb = outb(ty);
                                 bool reaches = false;
@@ -938,8 +978,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 }
             }
             wg_phase_sync();
-            if (!s_cnt[7]) break;                                               // nothing to remove: the ranking above is final
-            // the killed heads remember the arc that enters them (their pair is free: only {tail, length} of a removed unitig)
+            if (!s_cnt[7]) break;                                               // nothing to remove
+            // the killed heads remember the arc that enters them (the pairs are not in use before the ranking)
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
                 if (is_dead(o) || has_pred(o) || !(nmeta.get(o >> 1) & M_KILL)) continue;
                 const uint32_t ib = inb(o);
@@ -952,30 +992,88 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 J.store(o, arc);
             }
             wg_phase_sync();
-            // nodes of removed unitigs die; the arcs into the removed unitigs are cleared at their sources
+            // arcs into the removed unitigs are cleared at their sources; the heads walk their unitigs and mark the nodes dead
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                if (is_dead(o)) continue;
-                const bool hp = has_pred(o);
-                if (!hp && (nmeta.get(o >> 1) & M_KILL)) {
-                    const unsigned long long arc = J.load(o);
-                    if (arc != ~0ull) {
-                        const uint32_t p = (uint32_t)arc, c = (uint32_t)(arc >> 32);
-                        nmeta.and_(p >> 1, ~((p & 1) ? (1u << (4 + (3 - c))) : (1u << c)));
-                    }
+                if (has_pred(o) || !(nmeta.get(o >> 1) & M_KILL) || (nmeta.get(o >> 1) & M_DEAD)) continue;
+                const unsigned long long arc = J.load(o);
+                if (arc != ~0ull) {
+                    const uint32_t p = (uint32_t)arc, c = (uint32_t)(arc >> 32);
+                    nmeta.and_(p >> 1, ~((p & 1) ? (1u << (4 + (3 - c))) : (1u << c)));
                 }
-                if (o & 1) continue;                                            // one orientation marks the node
-                uint32_t h = o;
-                if (hp) {
-                    h = (uint32_t)J.load(o);
-                    if (has_pred(h)) continue;                                  // isolated cycle
-                }
-                if (nmeta.get(h >> 1) & M_KILL) nmeta.or_(o >> 1, M_DEADMARK);
+                for (uint32_t cur = o; cur != EMPTY32; cur = succ_get(cur)) nmeta.or_(cur >> 1, M_DEADMARK);
             }
             wg_phase_sync();
-            for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS)
-                if (nmeta.get(ni) & M_DEADMARK) nmeta.or_(ni, M_DEAD);
+            // junctions that lost a branch: with one successor left, the edge to it may have become unitig-internal (both directions)
+            auto is_gone = [&](uint32_t o) { return (nmeta.get(o >> 1) & (M_DEAD | M_DEADMARK)) != 0; };
+            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                const uint32_t m = nmeta.get(o >> 1);
+                if (has_pred(o) || !(m & M_KILL) || (m & M_DEAD)) continue;      // the heads removed in this round hold their arc
+                const unsigned long long arc = J.load(o);
+                if (arc == ~0ull) continue;
+                const uint32_t p = (uint32_t)arc;
+                if (is_gone(p)) continue;
+                const uint32_t pb = outb(p);
+                if (__popc(pb) != 1) continue;
+                const uint32_t y = find_oriented(shift_in(node_seq(p), __ffs(pb) - 1, kv));
+                if (y == EMPTY32 || is_gone(y) || __popc(inb(y)) != 1) continue;
+                ((p & 1) ? succ1 : succ0).set(p >> 1, y);
+                nmeta.or_(y >> 1, (y & 1) ? M_START1 : M_START0);
+                ((y & 1) ? succ0 : succ1).set(y >> 1, p ^ 1u);                   // the reverse link y' -> p'
+                nmeta.or_(p >> 1, (p & 1) ? M_START0 : M_START1);
+            }
+            wg_phase_sync();
+            for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
+                const uint32_t m = nmeta.get(ni);
+                if ((m & M_DEADMARK) && !(m & M_DEAD)) nmeta.or_(ni, M_DEAD);
+                if (m & M_KILL) nmeta.and_(ni, ~M_KILL);
+            }
             wg_phase_sync();
         }
+
+        ASM_STAMP(7);
+        // ---- P5: unitigs ranked by pointer jumping: every oriented node learns its unitig's head and its rank in
+        //      ~log2(longest unitig) rounds.  Pairs are read and written as single 64-bit accesses, so the asynchronous
+        //      in-place update keeps the invariant "ancestor at that distance".
+        for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+            unsigned long long pr = o;                                      // heads (and dead nodes): {self, 0}
+            if (!is_dead(o) && has_pred(o)) {
+                const uint32_t back = succ_get(o ^ 1u);                     // walking the other way from this node
+                pr = (1ull << 32) | (back ^ 1u);                            // its internal predecessor, one step away
+            }
+            J.store(o, pr);
+        }
+        wg_phase_sync();
+        for (int jr = 0; jr < 24; ++jr) {
+            if (tid == 0) s_cnt[7] = 0;
+            __syncthreads();
+            bool changed = false;
+            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+                const unsigned long long a0 = J.load(o);
+                const uint32_t pa = (uint32_t)a0;
+                if (pa == o) continue;
+                const unsigned long long a1 = J.load(pa);
+                const uint32_t pb = (uint32_t)a1;
+                if (pb == pa) continue;                                     // parent is a head (or this is a finished cycle hop)
+                J.store(o, ((unsigned long long)((uint32_t)(a0 >> 32) + (uint32_t)(a1 >> 32)) << 32) | pb);
+                changed = true;
+            }
+            if (changed) s_cnt[7] = 1;
+            __syncthreads();
+            if (!s_cnt[7]) break;
+            __syncthreads();
+        }
+        wg_phase_sync();
+        // tails publish {tail, length} in their head's pair (heads are not read as ancestors any more)
+        for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
+            if (is_dead(o) || succ_get(o) != EMPTY32) continue;
+            const bool hp = has_pred(o);
+            const unsigned long long a0 = hp ? J.load(o) : 0ull;
+            const uint32_t h = hp ? (uint32_t)a0 : o;
+            if (has_pred(h)) continue;                                      // part of an isolated cycle: never reported
+            const uint32_t rank = hp ? (uint32_t)(a0 >> 32) : 0;
+            J.store(h, ((unsigned long long)(rank + 1) << 32) | o);
+        }
+        wg_phase_sync();
 
         // ---- emission: heads decide, then every node of an emitted unitig writes its own base
         {

@@ -34,8 +34,9 @@ for _ in range(3):
 ms, n = gf.kernel_time(B.KERNEL_ASSEMBLE)
 print("assemble kernel %.3f ms avg, contigs %d" % (ms / n, len(ctg)))
 d = dbg.cpu().numpy().reshape(-1, 8)
-ph = np.diff(d[:, :7], axis=1) / 100.0  # us
-names = ["P1 count", "P2 survivors", "P3 graph+index", "P4 links", "rank+error removal", "emission"]
+order = [0, 1, 2, 3, 4, 7, 5, 6]        # stamp 7 sits between 4 (links) and 5 (emission start)
+ph = np.diff(d[:, order], axis=1) / 100.0  # us
+names = ["P1 count", "P2 survivors", "P3 graph+index", "P4 links", "error removal", "ranking", "emission"]
 for i, nm in enumerate(names):
     print("%-14s mean %8.1f us   max %8.1f us" % (nm, ph[:, i].mean(), ph[:, i].max()))
 print("total/gap mean %.1f us max %.1f us; kernel span %.1f us" % (ph.sum(1).mean(), ph.sum(1).max(), (d[:, 6].max() - d[:, 0].min()) / 100.0))
