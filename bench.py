@@ -44,7 +44,11 @@ PRESETS = {
     # collect_reads_for_gaps.py:275-278) + the multi-k sweep; per-gap pools = both libraries in library order (merge_reads.py:43-51)
     "C5": (20260004, 5_000_000, 620, 32, 2000, 900_000_000, [(31, 29), (41, 39), (51, 49)]),
 }
-MP_READS_DEFAULT = 100_000_000   # "extra 100 M records"
+# Mate-pair library of C5.  SURVEY.md §8d says "extra 100 M records" = 4.8x: at KMC's min-count 2 a k-mer of the gap interior (covered by
+# this library only) is then missing with P = e^-3.9 (1 + 3.9) = 10 % per position, so no 2-kb gap can close (measured on the GPU:
+# 0 of 19 840; tools/closure_experiment.py: 0/6 at 4.8x, 1/6 at 10x, 28/30 at 15x, 30/30 at 19x).  The bench therefore draws
+# 400 M records (19.4x); --mp-reads 100000000 reproduces the survey's figure.
+MP_READS_DEFAULT = 400_000_000
 
 
 class Lib:
@@ -52,7 +56,7 @@ class Lib:
     pass
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -60,13 +64,33 @@ def main():
     ap.add_argument("--config", default="C4", choices=sorted(PRESETS),
                     help="BASELINE.json workload: C4 (default: the metric's configuration, 900 M reads), C2, C3, C5 (C4 + mate pairs + multi-k)")
     ap.add_argument("--reads", type=int, default=0, help="read records of the first library, WHOLE JOB (default: the config's)")
-    ap.add_argument("--mp-reads", type=int, default=-1, help="C5: read records of the mate-pair library, whole job (default 100 M)")
+    ap.add_argument("--mp-reads", type=int, default=-1, help="C5: read records of the mate-pair library, whole job (default 400 M = 19.4x; SURVEY.md §8d names 100 M)")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C5 child runs that the default N=1 run appends as `extras`")
     ap.add_argument("--dump-contigs", default="", help="rank 0 writes the gathered contigs (sorted) of the last step to this JSON file")
-    args = ap.parse_args()
-    default_workload = not args.reads and args.mp_reads < 0
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    out, rank, world = run(args)
+    # the extras run in child processes AFTER this process has released its device memory (run()'s tensors and contexts are gone)
+    if rank == 0 and world == 1 and args.config == "C4" and not args.no_extras and not args.no_cpu and not args.reads and args.mp_reads < 0:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["extras"] = {"C2": child_run(["--config", "C2", "--steps", "20", "--warmup", "2"]),
+                         "C5_mate_pair_multi_k": child_run(["--config", "C5", "--steps", "3", "--warmup", "1"])}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run(args):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -464,20 +488,15 @@ def main():
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, libs, flanks, gaps, L, kk, asm_pool_t, asm_off_t, ctg, d_seq, n_seq, d_best, step_s,
                                                n_screened, B, rb)
-    if rank == 0 and world == 1 and not args.no_extras and not args.no_cpu and default_workload and args.config == "C4":
-        torch.cuda.empty_cache()
-        out["extras"] = {"C2": child_run(["--config", "C2", "--steps", "20", "--warmup", "2"]),
-                         "C5_mate_pair_multi_k": child_run(["--config", "C5", "--steps", "3", "--warmup", "1"])}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    for g_ in ctxs:
+        g_.close()
+    return (out if rank == 0 else None), rank, world
 
 
 def child_run(argv):
     """The same step on another BASELINE.json configuration, measured by the same code in a child process (never an exec of a
     process that has touched the GPU)."""
+    r = None
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu"] + argv, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
@@ -485,7 +504,7 @@ def child_run(argv):
         return {key: d[key] for key in ("value", "ms_per_step", "steps", "warmup", "gaps_per_s", "gaps_closed_per_s", "phases_ms", "counts")} | \
                {"workload": d["config"]["workload"], "roofline_frac": d["roofline"]["frac"], "filter_ms": d["roofline"]["avg_launch_ms"]}
     except Exception as e:      # the headline line must not depend on an extra
-        return {"error": repr(e)[:300]}
+        return {"error": repr(e)[:300], "stderr_tail": (r.stderr.decode()[-400:] if r is not None else "")}
 
 
 def pmc_traffic(config, reads_per_launch, L, k):
