@@ -149,6 +149,9 @@ def run(args):
     for g2 in gf2s:
         if g2 is not gf:
             g2.set_gaps(gaps, int(cfg0["n_scaffolds"][0]), None)
+            # (GF_BENCH_TAG_LIGHT=1: the one-wave tagger variant that fits on the CUs whose LDS the filter owns — measured: no gain, the two
+            # kernels contend for the memory system, C4 78.6 vs 77.4 ms)
+            g2.set_option("tag_light", int(os.environ.get("GF_BENCH_TAG_LIGHT", "0")))
     batch = SH.owner_batch(n_gaps, world)
 
     # ---- inputs resident in HBM (torch = device-memory plumbing) ----
@@ -375,6 +378,10 @@ def run(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    d_dbg = None
+    if os.environ.get("GF_BENCH_ASM_PROBE"):      # diagnostic (needs GF_DIAGNOSTICS=1): per-gap phase stamps of the LAST assembly launch
+        d_dbg = torch.zeros(n_gaps * 8, dtype=torch.int64, device=dev)
+        gf.set_option("asm_dbg_ptr", d_dbg.data_ptr())
     run_steps(args.warmup)
     barrier()
     [g_.timing(True) for g_ in {id(x): x for x in [gf] + gf2s}.values()]
@@ -397,6 +404,14 @@ def run(args):
         dt = float(tt.item())
     step_s = dt / args.steps
 
+    if d_dbg is not None:
+        d = d_dbg.cpu().numpy().reshape(-1, 8)
+        d = d[d[:, 6] > 0]
+        ph = np.diff(d[:, [0, 1, 2, 3, 4, 7, 5, 6]], axis=1) / 100.0
+        names = ["P1 count", "P2 survivors", "P3 graph+index", "P4 links", "error removal", "ranking", "emission"]
+        sys.stderr.write("assembly phases of the last (k, kv) launch, us per gap (%d gaps with reads): " % len(d) +
+                         ", ".join("%s %.1f (max %.1f)" % (nm, ph[:, i].mean(), ph[:, i].max()) for i, nm in enumerate(names)) +
+                         "; total %.1f\n" % ph.sum(1).mean())
     # ---- results of the last step ----
     acnt = d_acnt.cpu().numpy()
     n_ctg, n_seq, n_closed_local = int(acnt[0]), int(acnt[2:4].view(np.uint64)[0]), int(acnt[4])

@@ -107,7 +107,7 @@ class GapAssembler:
     def assemble_pipeline(self):
         """The reference's rounds (assemble_gaps.py:328-366) minus contig merging: assemble; pick the gaps whose contigs are
         anchored by both flanks (anchor length 30 = the reference's first bwa_min_score); for the gaps still open recruit the
-        both-unmapped pairs that share k-mers with their contigs and assemble again (:344-351); pick at 30, then at 15 (:365)."""
+        both-unmapped pairs that share k-mers with their contigs and assemble again (:344-351); pick at 30, then at 15 (:365); what is still open gets the extended (partial, 'NN'-joined) fill (:367-368)."""
         from .pick_contigs import ContigsSelection
         fa_list = self.prepare_list()
         self.assembly(fa_list)
@@ -126,4 +126,6 @@ class GapAssembler:
             closed += cs.pick_full_constructed_contigs(30, remain, sf_picked)
             remain = self.pick_already_constructed(cs, remain, sf_picked)
         closed += cs.pick_full_constructed_contigs(15, remain, sf_picked)
-        return {"gaps": len(fa_list), "closed": closed, "second_round_gaps": recruited}
+        remain = self.pick_already_constructed(cs, remain, sf_picked)
+        extended = cs.pick_extended_contigs(15, remain, sf_picked)        # partial fills, left + 'NN' + right (:367-368)
+        return {"gaps": len(fa_list), "closed": closed, "extended": extended, "second_round_gaps": recruited}

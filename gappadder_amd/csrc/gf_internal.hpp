@@ -86,7 +86,9 @@ struct gf_ctx {
     int screen_verify_gate = 1;  // verify kernel: consult the k-mer table only around exact 16-mer hits
     int screen_stream_policy = 1;  // pipelined filter: read stream loaded non-temporal (nt): keeps the L2 for the bitmap, -8 % fabric fetches
     int screen_np_override = -1;
+    int screen_pf_diag = 0;      // partitioned filter timing experiments (wrong results; refused unless GF_DIAGNOSTICS)
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)
+    int tag_light = 0;           // alignment tagger: one-wave workgroups, bin map through L1/L2 (runs beside the k-mer filter)
     int asm_lds_pool_kb = 152;
     int asm_simplify = 2;        // rounds of tip clipping + bubble popping in the assembly (Velvet's defaults are on; 0: raw unitigs)
     long asm_max_pool_reads = 0; // > 0: no pool has more rows than this (the assembly workspace is then one slice per workgroup, not per row)

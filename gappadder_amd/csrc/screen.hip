@@ -382,6 +382,7 @@ struct PartParams {
     unsigned long long* pairs;  // [bucket][writer][cap]: {read (high 32), scrambled key (low 32)}
     uint32_t* count;            // [bucket][writer]
     uint32_t* seen;             // one bit per read
+    uint32_t diag;              // timing experiments (GF_DIAGNOSTICS builds of a run only; results WRONG): 1 = no level-1 probe, 2 = no LDS pre-test, 4 = no pair loads
 };
 constexpr uint32_t PF_ROW = 128;   // pairs per LDS row: a row is flushed at 64, one probe adds at most 64
 
@@ -546,11 +547,13 @@ __global__ __launch_bounds__(1024) void pf_probe_kernel(PartParams Q) {
                 for (int u = 0; u < PB; ++u) {
                     const uint32_t pk = (uint32_t)pr[u];
                     live[u] = i0 + u * 64 + lane < n;
-                    if (mid && live[u]) {
+                    if (mid && live[u] && !(Q.diag & 2)) {
                         const uint32_t c = (pk >> sh_mid) & ((mid_words << 5) - 1);
                         live[u] = (sm[c >> 5] >> (c & 31)) & 1u;
                     }
-                    wd[u] = live[u] ? P.bitmap[(pk >> sh_bm) >> 5] : 0u;
+                    if (Q.diag & 8) wd[u] = live[u] ? __hip_atomic_fetch_or(const_cast<uint32_t*>(P.bitmap) + ((pk >> sh_bm) >> 5), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    else
+                    wd[u] = (live[u] && !(Q.diag & 1)) ? P.bitmap[(pk >> sh_bm) >> 5] : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < PB; ++u) {
@@ -1445,6 +1448,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         // partitioned filter: the level-1 bitmap is far larger than an L2 (see pf_scatter_kernel)
         PartParams Q;
         Q.F = F;
+        Q.diag = (uint32_t)ctx->screen_pf_diag;
         Q.nb_log2 = 4;   // 16 buckets: two per XCD; a bucket's slice of the 2^24-bit reduction is 128 KiB of LDS in pass B
         const uint32_t nb = 1u << Q.nb_log2;
         const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;

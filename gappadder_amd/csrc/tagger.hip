@@ -43,15 +43,17 @@ struct TagParams {
 // "dequeue"/"fanin" rows), so they are first collected in a per-workgroup LDS buffer: wave ballot + prefix count,
 // one LDS atomic per wave, and ONE global atomic per workgroup when the kernel ends.  A full buffer falls back to
 // direct global appends (correct, just slower).
-constexpr uint32_t HITBUF = 512;
-
-struct HitBuf {
-    gf_taghit h[HITBUF];
-    uint32_t n;       // slots handed out (may run past HITBUF)
+template <uint32_t CAP>
+struct HitBufT {
+    static constexpr uint32_t cap_ = CAP;
+    gf_taghit h[CAP];
+    uint32_t n;       // slots handed out (may run past CAP)
     uint32_t stored;  // end of the contiguous prefix actually written
 };
+using HitBuf = HitBufT<512>;
 
-__device__ __forceinline__ void emit_hit(bool want, const gf_taghit& h, HitBuf& hb, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
+template <typename HB>
+__device__ __forceinline__ void emit_hit(bool want, const gf_taghit& h, HB& hb, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
     const unsigned long long bal = __ballot(want);
     if (!bal) return;
     const uint32_t lane = threadIdx.x & 63;
@@ -61,7 +63,7 @@ __device__ __forceinline__ void emit_hit(bool want, const gf_taghit& h, HitBuf& 
     if (lane == leader) base = atomicAdd(&hb.n, cnt);
     base = __shfl(base, leader);
     const uint32_t off = __popcll(bal & ((1ull << lane) - 1));
-    if (base + cnt <= HITBUF) {
+    if (base + cnt <= HB::cap_) {
         if (want) hb.h[base + off] = h;
         if (lane == leader) atomicMax(&hb.stored, base + cnt);
     } else {  // buffer full: this wave's hits go straight to the global list
@@ -72,7 +74,8 @@ __device__ __forceinline__ void emit_hit(bool want, const gf_taghit& h, HitBuf& 
     }
 }
 
-__device__ __forceinline__ void flush_hits(HitBuf& hb, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
+template <typename HB>
+__device__ __forceinline__ void flush_hits(HB& hb, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
     __shared__ uint32_t s_base;
     __syncthreads();
     const uint32_t n = hb.stored;  // slots are handed out in order, so the stored entries are the prefix [0, stored)
@@ -93,15 +96,21 @@ __device__ __forceinline__ void tag_wave_sync() {   // LDS hand-off between lane
 }
 constexpr int TAG_UNROLL = 8;  // 8 KiB (256 records) per wave and stage, two stages in flight
 
-__global__ __launch_bounds__(256) void tag_kernel(TagParams P) {
-    extern __shared__ uint32_t bins[];  // the whole bin map (<= 16 KiB), staged once per workgroup
-    __shared__ HitBuf hb;
+// NW waves per workgroup.  BINS_LDS: the coarse bin map is staged in LDS (the stand-alone form: 33 KiB of LDS per workgroup at
+// human scale); BINS_LDS = false reads it through L1/L2 instead and runs one-wave workgroups with ~6 KiB of LDS, so that the
+// tagger's workgroups fit on the CUs NEXT TO the k-mer filter's (which own 137-151 KiB of every CU's LDS but leave most of its
+// issue slots idle: PMC SQ_WAIT_ANY 53-77 %) — the "light" variant a pipeline launches on its second stream.
+template <int NW, bool BINS_LDS>
+__global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
+    extern __shared__ uint32_t bins_lds[];  // the whole bin map (<= 16 KiB), staged once per workgroup
+    __shared__ HitBufT<128 * NW> hb;
     constexpr uint32_t LOWBUF = 128;    // MAPQ==0 records buffered per wave (one global atomic per ~64-128 of them)
-    __shared__ gf_lowrec lowbuf[4][LOWBUF];
-    __shared__ LiveRec liveq[4][LIVEQ];
+    __shared__ gf_lowrec lowbuf[NW][LOWBUF];
+    __shared__ LiveRec liveq[NW][LIVEQ];
     uint32_t low_n = 0;                 // wave-uniform
     if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
-    for (uint32_t i = threadIdx.x; i < P.bin_words; i += blockDim.x) bins[i] = P.bin_bits[i];
+    if (BINS_LDS) for (uint32_t i = threadIdx.x; i < P.bin_words; i += blockDim.x) bins_lds[i] = P.bin_bits[i];
+    const uint32_t* bins = BINS_LDS ? bins_lds : P.bin_bits;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     gf_lowrec* wlow = lowbuf[threadIdx.x >> 6];
@@ -455,7 +464,10 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
     P.fine_shift = ctx->fine_shift;
     {
         LaunchTimer tm(ctx, GF_KERNEL_TAG);
-        hipLaunchKernelGGL(tag_kernel, dim3(stream_grid(ctx, n)), dim3(256), (size_t)ctx->bin_words * 4, ctx->stream, P);
+        if (ctx->tag_light)   // one-wave workgroups without the LDS bin map: co-resident with the k-mer filter's workgroups
+            hipLaunchKernelGGL((tag_kernel<1, false>), dim3(4 * stream_grid(ctx, n)), dim3(64), 0, ctx->stream, P);
+        else
+            hipLaunchKernelGGL((tag_kernel<4, true>), dim3(stream_grid(ctx, n)), dim3(256), (size_t)ctx->bin_words * 4, ctx->stream, P);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;

@@ -64,6 +64,49 @@ def pick_gap_sequence(contigs, left_flank, right_flank, anchor_len):
     return None if best is None else best[1:]
 
 
+def pick_extended_sequence(contigs, left_flank, right_flank, anchor_len):
+    """The fallback of the last round (run_pick_extended_contig, pick_contigs.py:361-539): no contig carries both anchors in
+    order, so the gap is filled from each side as far as a contig reaches — left part = what follows the left anchor in the
+    contig that reaches furthest into the gap, right part = what precedes the right anchor — joined by 'NN' (:513-520).
+    The reference takes, per side, the bwa hit with the longest match and breaks ties by a comparison that is constant in
+    Python 2 (int > str, :444, :457), i.e. by dict order; with exact anchors every match has the same length, so this build
+    DEFINES the tie: the longest extension wins, then the first contig of the list, forward orientation first.  When both sides
+    pick the same contig the reference keeps only the side with the longer match, the right side on a tie (:468-486): here always
+    the right side.  Returns (left_name, right_name, sequence, contig_text) or None when neither anchor occurs."""
+    if len(left_flank) < anchor_len or len(right_flank) < anchor_len:
+        return None
+    la, ra = left_flank[-anchor_len:], right_flank[:anchor_len]
+    if any(c not in "ACGT" for c in la + ra):
+        return None
+    best_l = best_r = None        # (extension length, name, extension, contig as written)
+    for name, seq in contigs:
+        for oriented in (seq, revcomp(seq)):
+            i = oriented.find(la)
+            if i >= 0:
+                ext = oriented[i + anchor_len:]
+                if best_l is None or len(ext) > best_l[0]:
+                    best_l = (len(ext), name, ext, seq)
+            j = oriented.rfind(ra)
+            if j >= 0:
+                ext = oriented[:j]
+                if best_r is None or len(ext) > best_r[0]:
+                    best_r = (len(ext), name, ext, seq)
+    if best_l is None and best_r is None:
+        return None
+    if best_l is not None and best_r is not None and best_l[1] == best_r[1]:
+        best_l = None
+    left_name, left_seq = (best_l[1], best_l[2]) if best_l else ("", "")
+    right_name, right_seq = (best_r[1], best_r[2]) if best_r else ("", "")
+    seq = left_seq + "NN" + right_seq
+    if best_l and best_r:
+        contig_text = best_l[3] + "NN" + best_r[3]
+    else:
+        contig_text = (best_l or best_r)[3]
+    if seq == "NN":
+        return None
+    return left_name, right_name, seq, contig_text
+
+
 class ContigsSelection:
     def __init__(self, working_space):
         self.working_folder = working_space
@@ -99,6 +142,30 @@ class ContigsSelection:
                 if os.path.exists(p):
                     with open(dst, "a") as out, open(p) as f:   # the reference appends with `cat >>` (:564-572)
                         out.write(f.read())
+        return n
+
+    def pick_extended_contigs(self, bwa_score, fa_list, sf_picked):
+        """pick_contigs.py:583-603: per gap velvet_temp/{id}/picked_seqs.fa + picked_contigs.fa with header
+        '>{id}_{left contig}_{right contig}_extended', appended to the ledger like the full picks."""
+        n = 0
+        for gid in fa_list:
+            wf = self.working_folder
+            sf_flank = wf + "../flank_regions/%s.fa" % gid
+            sf_contig = wf + "velvet_temp/%s/contigs.fa" % gid
+            if not (os.path.exists(sf_flank) and os.path.exists(sf_contig)):
+                continue
+            fl = dict(read_fasta(sf_flank))
+            res = pick_extended_sequence(read_fasta(sf_contig), fl.get(gid + "_left", ""), fl.get(gid + "_right", ""), int(bwa_score))
+            if res is None:
+                continue
+            left_name, right_name, seq, contig_text = res
+            hdr = ">%s_%s_%s_extended\n" % (gid, left_name, right_name)
+            for fn, body, dst in (("picked_seqs.fa", seq, sf_picked), ("picked_contigs.fa", contig_text, sf_picked + "_ori.txt")):
+                with open(wf + "velvet_temp/%s/%s" % (gid, fn), "w") as f:
+                    f.write(hdr + body + "\n")
+                with open(dst, "a") as out:
+                    out.write(hdr + body + "\n")
+            n += 1
         return n
 
     def get_already_picked(self, sf_picked):

@@ -102,6 +102,8 @@ int gf_stream_wait(gf_ctx* waiter, gf_ctx* producer);
  * filter kernel), "screen_verify_ext" (1: seed-and-extend verification when min_hits == 1), "screen_verify_gate",
  * "screen_verify_batch", "screen_stream_policy", "screen_lds_log2_max", "screen_np_override" (timing experiments: fewer probes, WRONG hits; refused unless the environment has GF_DIAGNOSTICS set),
  * "asm_keyslot", "asm_lds_pool_kb", "asm_dbg_ptr".
+ * Tagger: "tag_light" (1: one-wave workgroups that read the coarse bin map through L1/L2 instead of staging it in LDS — same hits;
+ * for a pipeline that runs the tagger on a second context beside the k-mer filter, whose workgroups own most of every CU's LDS).
  * Assembly: "asm_simplify" (rounds of tip clipping + bubble popping — Velvet's defaults, which the reference runs with
  * (assemble_gaps.py:117); default 2, 0 = raw unitigs), "asm_max_pool_reads" (device variants: upper bound on the rows of one
  * pool; the assembly workspace is then one slice of that size per workgroup instead of one per pool row — a pool beyond the bound

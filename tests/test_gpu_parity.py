@@ -40,6 +40,11 @@ def test_tagger_equals_reference_lists(gf, case):
         recs, fields = RU.sam_to_records(lib["sam"], case.fai_names)
         hits = gf.tag_alignments(recs, lib["is"], lib["sd"], case.meta["clip_dist"], case.meta["anchor_mapq"])
         assert _same(hits, CO.tag_alignments(recs, garr, lib["is"], lib["sd"], case.meta["clip_dist"], case.meta["anchor_mapq"]))
+        gf.set_option("tag_light", 1)      # the one-wave variant that reads the bin map through L1/L2 (runs beside the k-mer filter)
+        try:
+            assert _same(gf.tag_alignments(recs, lib["is"], lib["sd"], case.meta["clip_dist"], case.meta["anchor_mapq"]), hits)
+        finally:
+            gf.set_option("tag_light", 0)
         got = RU.hits_to_lines(hits, recs, fields, garr, case.fai_names)
         exp = case.exp_dir(lib["folder"] + "/scaffold_reads_list_all/")
         for scf in set(g[3] for g in gaps):

@@ -139,3 +139,82 @@ def test_write_back_matches_reference(tmp_path):
     got = open(d + "/new.fa").read()
     assert got == wb["new_scaffolds_fa"]
     assert got.count(">") == 3 and got.count("N") == 600    # the two open gaps + the 50-N run below min_gap_size
+
+
+# ---- flank anchoring (pick_contigs.py:64-358, 361-539 with exact anchors) ----
+
+def _rnd(rng, n):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+
+
+def test_pick_takes_the_longest_span_over_all_anchor_occurrences_and_both_orientations():
+    import numpy as np
+    from gappadder_amd.pick_contigs import pick_gap_sequence, revcomp
+    rng = np.random.default_rng(3)
+    left, right = _rnd(rng, 100), _rnd(rng, 100)
+    la, ra = left[-30:], right[:30]
+    gap = _rnd(rng, 200)
+    # one contig with the left anchor twice and the right anchor twice: leftmost left, rightmost right (pick_contigs.py:300-321)
+    c1 = _rnd(rng, 10) + la + _rnd(rng, 20) + la + gap + ra + _rnd(rng, 15) + ra + _rnd(rng, 5)
+    name, seq, oriented = pick_gap_sequence([("a", c1)], left, right, 30)
+    i, j = c1.find(la) + 30, c1.rfind(ra)
+    assert seq == c1[i:j + 1] and oriented == c1            # the +1: the reference's 1-based / 0-based slice (:341-349)
+    # the reverse-complemented contig gives the same gap sequence, reported in flank orientation
+    assert pick_gap_sequence([("a", revcomp(c1))], left, right, 30)[1] == seq
+    # among contigs the longest span wins, ties go to the first
+    c2 = la + gap[:50] + ra
+    assert pick_gap_sequence([("short", c2), ("long", c1)], left, right, 30)[0] == "long"
+    assert pick_gap_sequence([("x", c2), ("y", c2)], left, right, 30)[0] == "x"
+    # anchors in the wrong order, overlapping, or missing: not closed
+    assert pick_gap_sequence([("w", ra + gap + la)], left, right, 30) is None
+    assert pick_gap_sequence([("o", la[:-5] + ra)], left, right, 30) is None
+    assert pick_gap_sequence([("m", la + gap)], left, right, 30) is None
+    # a shorter anchor (the reference's second score, 15) finds what 30 misses when a base of the anchor differs
+    c3 = left[-15:] + gap + right[:15]
+    assert pick_gap_sequence([("c", c3)], left, right, 30) is None and pick_gap_sequence([("c", c3)], left, right, 15)[1] == gap + right[0]
+
+
+def test_extended_pick_joins_partial_fills_with_NN():
+    import numpy as np
+    from gappadder_amd.pick_contigs import pick_extended_sequence, revcomp
+    rng = np.random.default_rng(4)
+    left, right = _rnd(rng, 80), _rnd(rng, 80)
+    la, ra = left[-15:], right[:15]
+    into_gap, out_of_gap = _rnd(rng, 120), _rnd(rng, 90)
+    cl = left[-40:] + into_gap                      # reaches 120 bases into the gap from the left
+    cr = revcomp(out_of_gap + right[:50])           # reaches 90 bases into the gap from the right, written reverse-complemented
+    ln, rn, seq, txt = pick_extended_sequence([("L", cl), ("R", cr), ("junk", _rnd(rng, 200))], left, right, 15)
+    assert (ln, rn) == ("L", "R") and seq == into_gap + "NN" + out_of_gap and txt == cl + "NN" + cr
+    # only one side reachable
+    assert pick_extended_sequence([("L", cl)], left, right, 15)[:3] == ("L", "", into_gap + "NN")
+    assert pick_extended_sequence([("R", cr)], left, right, 15)[:3] == ("", "R", "NN" + out_of_gap)
+    # the longer extension wins per side
+    cl2 = la + into_gap[:30]
+    assert pick_extended_sequence([("s", cl2), ("L", cl)], left, right, 15)[0] == "L"
+    # one contig hit by both anchors (but not in order): the right side only (pick_contigs.py:468-486, equal match lengths)
+    pre = _rnd(rng, 25)
+    both = pre + ra + _rnd(rng, 30) + la + into_gap[:10]
+    assert pick_extended_sequence([("b", both)], left, right, 15)[:3] == ("", "b", "NN" + pre)
+    assert pick_extended_sequence([("b", ra + _rnd(rng, 30) + la)], left, right, 15) is None      # nothing but 'NN' to report
+    assert pick_extended_sequence([("n", _rnd(rng, 300))], left, right, 15) is None
+
+
+def test_extended_pick_writes_the_reference_files(tmp_path):
+    from gappadder_amd.pick_contigs import ContigsSelection
+    wf = str(tmp_path / "wf" / "merged") + "/"
+    os.makedirs(wf + "velvet_temp/0_1")
+    os.makedirs(str(tmp_path / "wf" / "flank_regions"))
+    import numpy as np
+    rng = np.random.default_rng(5)
+    left, right, fill = _rnd(rng, 60), _rnd(rng, 60), _rnd(rng, 70)
+    with open(str(tmp_path / "wf" / "flank_regions" / "0_1.fa"), "w") as f:
+        f.write(">0_1_left\n%s\n>0_1_right\n%s\n" % (left, right))
+    with open(wf + "velvet_temp/0_1/contigs.fa", "w") as f:
+        f.write(">31_29_NODE_1_length_60_cov_3.000000\n%s\n" % (left[-20:] + fill))
+    cs = ContigsSelection(wf)
+    sf = wf + "../picked_seqs.fa"
+    assert cs.pick_full_constructed_contigs(15, ["0_1"], sf) == 0
+    assert cs.pick_extended_contigs(15, ["0_1"], sf) == 1
+    txt = open(sf).read()
+    assert txt == ">0_1_31_29_NODE_1_length_60_cov_3.000000__extended\n%sNN\n" % fill
+    assert "0_1" in cs.get_already_picked(sf)
