@@ -20,12 +20,13 @@ SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", 
                       ("gap_len", "<u4"), ("read_len", "<u4"), ("insert_mean", "<u4"), ("insert_sd", "<u4"),
                       ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4"),
                       ("library", "<u4"), ("reserved", "<u4")])
+QCPAIR = np.dtype([("set", "<u4"), ("i", "<u4"), ("j", "<u4")])
 assert CONTIG.itemsize == 32 and GAP.itemsize == 16 and ALNREC.itemsize == 32 and TAGHIT.itemsize == 12 and DPOS.itemsize == 16 and HIT.itemsize == 8
 
 GF_OK, GF_E_INVAL, GF_E_NODEV, GF_E_NOMEM, GF_E_NOSPACE, GF_E_STATE, GF_E_UNSUPPORTED, GF_E_FORMAT = 0, -1, -2, -3, -4, -5, -6, -7
 KIND_CLIP, KIND_DISCORDANT, KIND_UNMAP, KIND_LOWMAPQ = 0, 1, 2, 3
 KIND_NAMES = {KIND_CLIP: "clip", KIND_DISCORDANT: "discordant", KIND_UNMAP: "unmap"}
-KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_SYNTH, KERNEL_COUNT, KERNEL_VERIFY, KERNEL_INGEST, KERNEL_PICK = range(10)
+KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_SYNTH, KERNEL_COUNT, KERNEL_VERIFY, KERNEL_INGEST, KERNEL_PICK, KERNEL_MERGE = range(11)
 
 _lib = None
 
@@ -91,6 +92,8 @@ def lib():
         "gf_pool_counts_dev": (i32, [vp, vp, sz, vp]),
         "gf_pools_pack_for_owners_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
         "gf_pools_merge_dev": (i32, [vp, vp, sz, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz, vp, vp]),
+        "gf_quick_check": (i32, [vp, C.c_char_p, vp, vp, sz, i32, vp, sz, szp]),
+        "gf_quick_check_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, vp, sz, vp]),
         "gf_pick_anchored_dev": (i32, [vp, vp, vp, sz, vp, i32, vp, vp]),
         "gf_count_kmers": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp, sz, szp]),
         "gf_pool_keys_reset": (i32, [vp, vp]),

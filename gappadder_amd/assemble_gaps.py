@@ -100,6 +100,12 @@ class GapAssembler:
 
     assembly_given_list = assembly
 
+    def run_contigs_merge(self, fa_list):
+        """assemble_gaps.py:301-306 / run_merge :138-145.  Of the reference's merge step only the first stage is built: the
+        candidate pairs of ContigsMerger's 10-mer prefilter, on the GPU (MergeContigs.merge_candidates); contigs.fa stays as is."""
+        from .MergeContigs import merge_candidates
+        return merge_candidates(_ctx(), working_folder, fa_list)
+
     def pick_already_constructed(self, contigs_select, fa_list, sf_picked):
         picked = contigs_select.get_already_picked(sf_picked)
         return [k for k in fa_list if k not in picked]
@@ -125,6 +131,7 @@ class GapAssembler:
             self.assembly_given_list(remain)
             closed += cs.pick_full_constructed_contigs(30, remain, sf_picked)
             remain = self.pick_already_constructed(cs, remain, sf_picked)
+        self.run_contigs_merge(remain)      # (the reference merges the open gaps' contigs here, :353-361; built: candidate pairs only)
         closed += cs.pick_full_constructed_contigs(15, remain, sf_picked)
         remain = self.pick_already_constructed(cs, remain, sf_picked)
         extended = cs.pick_extended_contigs(15, remain, sf_picked)        # partial fills, left + 'NN' + right (:367-368)

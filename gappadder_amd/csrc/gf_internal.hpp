@@ -14,7 +14,7 @@ namespace gf {
 
 constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
 constexpr int TILE_READS = 256;  // reads staged per workgroup pass of the screen filter
-constexpr int N_KERNEL_SLOTS = 10;
+constexpr int N_KERNEL_SLOTS = 11;
 
 // flank k-mer index for one k: three levels, all read-only on the device
 struct FlankIndex {

@@ -1,0 +1,246 @@
+// merge.hip — first GPU piece of the contig dedup/merge step: the all-pairs k-mer prefilter of the reference's
+// ContigsMerger.  CompactVer3 (ContigsCompactor.cpp:773-983) makes a node of every contig and of its reverse complement
+// (:782-800), builds one QuickCheckerContigsMatch per node (the set of ALL 10-mers of the node, :2041-2056) and asks for every
+// pair i <= j whether some 10-mer of the first or last 30 bases of node j is in node i's set (IsMatchFeasibleV2 :2020-2039,
+// threadQuickCheck :1073-1098); only the surviving pairs get the O(n m) overlap DP (:1572-1976, not built).  The reference
+// does this with std::map probes from a pthread pool; a per-gap contig set has tens to hundreds of contigs, and a run has one
+// set per gap.
+//
+// Here: one workgroup per contig set.  The END k-mers of a chunk of nodes go into an LDS hash table keyed by the k-mer (entries
+// (k-mer, j), 2 x (30 - k + 1) per node); then every position of every node i is probed against it — a hit on (k-mer, j) with
+// j >= i sets bit (i, j) of the set's pair matrix; the matrix is compacted into (set, i, j) triples.  k-mers use KmerUtils'
+// code (anything but C/G/T is A, KmerUtils.cpp:25-41; nothing is canonical); the reverse-complement node keeps non-ACGT symbols
+// as they are (FastaSequence::RevsereComplement), i.e. as A.
+#include <algorithm>
+#include <cstring>
+
+#include "gf_internal.hpp"
+
+namespace gf {
+
+constexpr uint32_t QC_SLOTS = 16384;            // 8-byte slots: 128 KiB of LDS
+constexpr uint32_t QC_END = 30;                 // lenContigLen (ContigsCompactor.cpp:2024)
+constexpr unsigned long long QC_EMPTY = ~0ull;
+
+struct QcParams {
+    const char* seq;
+    const unsigned long long* contig_off;   // n_contigs + 1
+    const unsigned long long* set_off;      // n_sets + 1 (contig indices)
+    uint32_t n_sets;
+    uint32_t k;
+    uint32_t max_nodes;                     // nodes of the largest set (matrix slice = max_nodes^2 bits per workgroup)
+    uint32_t* matrix;                       // [gridDim.x][words]
+    uint32_t words;                         // words per slice
+    gf_qcpair* out;
+    uint32_t cap;
+    uint32_t* n_out;
+    uint32_t* next_set;
+    uint32_t* error;                        // bit 0: a contig shorter than 30 bases (its set is skipped)
+};
+
+// base code at position p of node `node` (node = 2 * contig + strand) of a set whose first contig is c0
+__device__ __forceinline__ uint32_t qc_code(const QcParams& P, unsigned long long c0, uint32_t node, uint32_t p, uint32_t len) {
+    const unsigned long long o = P.contig_off[c0 + (node >> 1)];
+    char ch = P.seq[o + ((node & 1) ? len - 1 - p : p)];
+    if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+    const uint32_t f = ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0u;
+    if (!(node & 1)) return f;
+    return (ch == 'A' || f) ? 3u - f : 0u;    // complement of A/C/G/T; any other symbol stays itself = A
+}
+
+__device__ __forceinline__ uint32_t qc_kmer(const QcParams& P, unsigned long long c0, uint32_t node, uint32_t p, uint32_t len) {
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < P.k; ++i) v = (v << 2) | qc_code(P, c0, node, p + i, len);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t qc_slot(uint32_t kmer) { return ((kmer * 0x9E3779B1u) >> 7) & (QC_SLOTS - 1); }
+
+__global__ __launch_bounds__(1024) void quick_check_kernel(QcParams P) {
+    extern __shared__ unsigned long long qtab[];   // QC_SLOTS entries: k-mer << 32 | node j
+    __shared__ uint32_t s_set, s_bad;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    uint32_t* mat = P.matrix + (size_t)blockIdx.x * P.words;
+    const uint32_t per_node = 2 * (QC_END - P.k + 1);
+    const uint32_t chunk = (QC_SLOTS / 2) / per_node;      // nodes whose end k-mers fill the table to at most one half
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) { s_set = atomicAdd(P.next_set, 1u); s_bad = 0; }
+        __syncthreads();
+        const uint32_t st = s_set;
+        if (st >= P.n_sets) break;
+        const unsigned long long c0 = P.set_off[st], c1 = P.set_off[st + 1];
+        const uint32_t n = (uint32_t)(c1 - c0), M = 2 * n;
+        if (n == 0) continue;
+        if (M > P.max_nodes) { if (tid == 0) atomicOr(P.error, 2u); continue; }
+        for (uint32_t c = tid; c < n; c += blockDim.x)
+            if (P.contig_off[c0 + c + 1] - P.contig_off[c0 + c] < QC_END) s_bad = 1;
+        const uint32_t mwords = (M * M + 31) / 32;
+        for (uint32_t i = tid; i < mwords; i += blockDim.x) mat[i] = 0;
+        __syncthreads();
+        if (s_bad) { if (tid == 0) atomicOr(P.error, 1u); continue; }
+        for (uint32_t j0 = 0; j0 < M; j0 += chunk) {
+            const uint32_t j1 = j0 + chunk < M ? j0 + chunk : M;
+            for (uint32_t i = tid; i < QC_SLOTS; i += blockDim.x) qtab[i] = QC_EMPTY;
+            __syncthreads();
+            // end k-mers of nodes j0 .. j1-1
+            for (uint32_t w = tid; w < (j1 - j0) * per_node; w += blockDim.x) {
+                const uint32_t j = j0 + w / per_node, e = w % per_node, half = per_node / 2;
+                const uint32_t len = (uint32_t)(P.contig_off[c0 + (j >> 1) + 1] - P.contig_off[c0 + (j >> 1)]);
+                const uint32_t p = e < half ? e : len - QC_END + (e - half);
+                const uint32_t km = qc_kmer(P, c0, j, p, len);
+                const unsigned long long mine = ((unsigned long long)km << 32) | j;
+                uint32_t s = qc_slot(km);
+                for (;;) {
+                    unsigned long long v = qtab[s];
+                    if (v == QC_EMPTY) {
+                        v = atomicCAS(&qtab[s], QC_EMPTY, mine);
+                        if (v == QC_EMPTY) break;
+                    }
+                    if (v == mine) break;       // the same k-mer twice in this node's ends
+                    s = (s + 1) & (QC_SLOTS - 1);
+                }
+            }
+            __syncthreads();
+            // every position of every node i <= j1-1 asks for its k-mer; entries with j >= i make the pair feasible
+            // work item = (node i, position): nodes are walked by the waves, positions by the lanes
+            for (uint32_t i = tid >> 6; i < j1; i += blockDim.x >> 6) {
+                const uint32_t len = (uint32_t)(P.contig_off[c0 + (i >> 1) + 1] - P.contig_off[c0 + (i >> 1)]);
+                const uint32_t npos = len - P.k + 1;
+                for (uint32_t p = lane; p < npos; p += 64) {
+                    const uint32_t km = qc_kmer(P, c0, i, p, len);
+                    uint32_t s = qc_slot(km);
+                    for (;;) {
+                        const unsigned long long v = qtab[s];
+                        if (v == QC_EMPTY) break;
+                        if ((uint32_t)(v >> 32) == km) {
+                            const uint32_t j = (uint32_t)v;
+                            if (j >= i) {
+                                const uint32_t bit = i * M + j;
+                                // (checked through L2, where the atomics land: this CU's L1 may still hold the slice of the previous set)
+                                if (!((__hip_atomic_load(&mat[bit >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31)) & 1u))
+                                    atomicOr(&mat[bit >> 5], 1u << (bit & 31));
+                            }
+                        }
+                        s = (s + 1) & (QC_SLOTS - 1);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // the matrix slice went through L2 atomics and plain loads of this CU: make the loads below see the atomics
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        for (uint32_t w0 = 0; w0 < mwords; w0 += blockDim.x) {
+            const uint32_t w = w0 + tid;
+            uint32_t bits = w < mwords ? __hip_atomic_load(&mat[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const uint32_t cnt = (uint32_t)__popc(bits);
+            // wave-level reservation: prefix over the lanes' counts
+            uint32_t pre = cnt;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(pre, d);
+                if ((int)lane >= d) pre += y;
+            }
+            const uint32_t total = __shfl(pre, 63);
+            if (!total) continue;
+            uint32_t base = 0;
+            if (lane == 63) base = atomicAdd(P.n_out, total);
+            base = __shfl(base, 63) + pre - cnt;
+            while (bits) {
+                const uint32_t b = (uint32_t)__ffs(bits) - 1;
+                bits &= bits - 1;
+                const uint32_t bit = w * 32 + b;
+                if (base < P.cap) { gf_qcpair q; q.set = st; q.i = bit / M; q.j = bit % M; P.out[base] = q; }
+                ++base;
+            }
+        }
+    }
+}
+
+}  // namespace gf
+
+using namespace gf;
+
+extern "C" {
+
+int gf_quick_check_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off, const void* d_set_off, size_t n_sets, size_t max_set_contigs,
+                       int k, void* d_out, size_t cap, void* d_n_out) {
+    if (!ctx || !d_contig_off || !d_set_off || !d_n_out || (cap && !d_out) || k < 4 || k > 16 || n_sets >= 0xFFFFFFFFull || cap > 0xFFFFFFFFull ||
+        max_set_contigs > 16384)
+        return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
+    uint32_t* d_next = (uint32_t*)ctx->counters.p + 9;
+    uint32_t* d_err = (uint32_t*)ctx->counters.p + 10;
+    zero_regions(ctx, ZeroList{{(uint32_t*)d_n_out, d_next, nullptr, nullptr}, {1, 2, 0, 0}});
+    if (!n_sets) return GF_OK;
+    QcParams P;
+    P.seq = (const char*)d_seq;
+    P.contig_off = (const unsigned long long*)d_contig_off;
+    P.set_off = (const unsigned long long*)d_set_off;
+    P.n_sets = (uint32_t)n_sets;
+    P.k = (uint32_t)k;
+    P.max_nodes = (uint32_t)(2 * std::max<size_t>(1, max_set_contigs));
+    P.words = (uint32_t)(((uint64_t)P.max_nodes * P.max_nodes + 31) / 32 + 1);
+    const unsigned grid = (unsigned)std::min<size_t>(n_sets, (size_t)ctx->n_cu);
+    if ((rc = ensure(ctx, ctx->xchg_ws2, (size_t)grid * P.words * 4 + 256))) return rc;
+    P.matrix = (uint32_t*)ctx->xchg_ws2.p;
+    P.out = (gf_qcpair*)d_out;
+    P.cap = (uint32_t)cap;
+    P.n_out = (uint32_t*)d_n_out;
+    P.next_set = d_next;
+    P.error = d_err;
+    {
+        LaunchTimer tm(ctx, GF_KERNEL_MERGE);
+        hipLaunchKernelGGL(quick_check_kernel, dim3(grid), dim3(1024), (size_t)QC_SLOTS * 8, ctx->stream, P);
+    }
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_quick_check(gf_ctx* ctx, const char* seq, const uint64_t* contig_off, const uint64_t* set_off, size_t n_sets, int k, gf_qcpair* out,
+                   size_t cap, size_t* n_out) {
+    if (!ctx || !n_out || (n_sets && (!contig_off || !set_off)) || (cap && !out)) return GF_E_INVAL;
+    *n_out = 0;
+    if (!n_sets) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n_contigs = (size_t)set_off[n_sets];
+    size_t max_set = 0;
+    for (size_t s = 0; s < n_sets; ++s) {
+        if (set_off[s] > set_off[s + 1]) return GF_E_INVAL;
+        max_set = std::max<size_t>(max_set, (size_t)(set_off[s + 1] - set_off[s]));
+    }
+    const size_t n_bytes = (size_t)contig_off[n_contigs];
+    for (size_t c = 0; c < n_contigs; ++c)
+        if (contig_off[c] > contig_off[c + 1] || contig_off[c + 1] - contig_off[c] < QC_END) {
+            ctx->last_error = "gf_quick_check: contig " + std::to_string(c) + " has fewer than 30 bases";
+            return GF_E_INVAL;
+        }
+    int rc;
+    const size_t b_seq = (n_bytes + 63) & ~(size_t)63, b_co = ((n_contigs + 1) * 8 + 63) & ~(size_t)63, b_so = ((n_sets + 1) * 8 + 63) & ~(size_t)63;
+    if ((rc = ensure(ctx, ctx->stage_in, b_seq + b_co + b_so + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, std::max<size_t>(cap, 1) * sizeof(gf_qcpair) + 64))) return rc;
+    uint8_t* d_seq = (uint8_t*)ctx->stage_in.p;
+    uint8_t* d_co = d_seq + b_seq;
+    uint8_t* d_so = d_co + b_co;
+    uint8_t* d_cnt = d_so + b_so;
+    if (n_bytes) GF_HIP(ctx, hipMemcpyAsync(d_seq, seq, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(d_co, contig_off, (n_contigs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(d_so, set_off, (n_sets + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = gf_quick_check_dev(ctx, d_seq, d_co, d_so, n_sets, max_set, k, ctx->stage_out.p, cap, d_cnt))) return rc;
+    uint32_t n = 0;
+    GF_HIP(ctx, hipMemcpyAsync(&n, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = n;
+    if (n > cap) return GF_E_NOSPACE;
+    if (n) GF_HIP(ctx, hipMemcpy(out, ctx->stage_out.p, n * sizeof(gf_qcpair), hipMemcpyDeviceToHost));
+    std::sort(out, out + n, [](const gf_qcpair& a, const gf_qcpair& b) {
+        if (a.set != b.set) return a.set < b.set;
+        if (a.i != b.i) return a.i < b.i;
+        return a.j < b.j;
+    });
+    return GF_OK;
+}
+
+}  // extern "C"

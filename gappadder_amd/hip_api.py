@@ -240,6 +240,26 @@ class GapFill:
             self._chk(rc, "gf_count_kmers")
             return km[:m.value], cn[:m.value]
 
+    def quick_check(self, contig_sets, k=10):
+        """The contig merger's all-pairs k-mer prefilter (ContigsCompactor.cpp:1982-2095) for a batch of contig sets (one per
+        gap): contig_sets = [[seq, ...], ...].  Returns B.QCPAIR triples (set, i, j) sorted, nodes = 2 * contig + strand."""
+        flat = [c for cs in contig_sets for c in cs]
+        blob = "".join(flat).encode()
+        coff = np.zeros(len(flat) + 1, dtype=np.uint64)
+        coff[1:] = np.cumsum([len(c) for c in flat])
+        soff = np.zeros(len(contig_sets) + 1, dtype=np.uint64)
+        soff[1:] = np.cumsum([len(cs) for cs in contig_sets])
+        cap = 4096
+        while True:
+            out = np.zeros(cap, dtype=B.QCPAIR)
+            n = C.c_size_t(0)
+            rc = self._L.gf_quick_check(self._h, blob, B._p(coff), B._p(soff), len(contig_sets), k, B._p(out), cap, C.byref(n))
+            if rc == B.GF_E_NOSPACE:
+                cap = n.value
+                continue
+            self._chk(rc, "gf_quick_check")
+            return out[:n.value]
+
     # ---- timing -------------------------------------------------------------------------------------
     def timing(self, on=True):
         self._chk(self._L.gf_timing_enable(self._h, 1 if on else 0), "gf_timing_enable")

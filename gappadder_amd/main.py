@@ -105,9 +105,10 @@ def main_func(command, sf_config):
         ga = assemble_gaps.GapAssembler(sf_fai, sf_gap_pos, cfg["nthreads"], wf + MERGE_FOLDER, cfg["kmers"], gf,
                                         bam_list=[bam for bam, _, _ in cfg["alignments"]], samtools_path=cfg["samtools"])
         res = ga.assemble_pipeline()
-        print("assembled %d gaps, %d closed (picked_seqs.fa), %d gaps got both-unmapped pairs in the second round; contigs in "
-              "%svelvet_temp/*/contigs.fa; the reference's contig-merging steps (TERefiner / ContigsMerger) are not part of this "
-              "build" % (res["gaps"], res["closed"], res["second_round_gaps"], wf + MERGE_FOLDER))
+        print("assembled %d gaps, %d closed (picked_seqs.fa), %d with an extended (partial) fill, %d gaps got both-unmapped pairs in the "
+              "second round; contigs in %svelvet_temp/*/contigs.fa; of the reference's contig-merging step (TERefiner / ContigsMerger) only "
+              "the candidate-pair prefilter is built (velvet_temp/*/merge_candidates.txt)"
+              % (res["gaps"], res["closed"], res.get("extended", 0), res["second_round_gaps"], wf + MERGE_FOLDER))
 
 
 def main(argv=None):

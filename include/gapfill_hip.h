@@ -338,6 +338,25 @@ int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const vo
 int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
                          int anchor_len, void* d_gap_best, void* d_n_closed);
 
+/* ---- §8f-3, first piece: the all-pairs k-mer prefilter of the reference's ContigsMerger (QuickCheckerContigsMatch,
+ * ContigsCompactor.cpp:1982-2095, applied by CompactVer3 :836-853 / threadQuickCheck :1073-1098).  A contig SET (one per gap: its
+ * contigs.fa) becomes the node list [c0, revcomp(c0), c1, revcomp(c1), ...]; pair (i, j), i <= j, is feasible iff some k-mer of
+ * the first or last 30 bases of node j occurs anywhere in node i (KmerUtils' 2-bit k-mers: any symbol but C/G/T counts as A).
+ * Only feasible pairs go on to the overlap alignment (:1572-1976, not part of this build).  Contigs need >= 30 bases
+ * (GF_E_INVAL; the reference reads out of bounds).  4 <= k <= 16 (the reference's default is 10).
+ * seq: the contigs' ASCII bases back to back; contig_off[n_contigs+1]; set_off[n_sets+1] = contig index ranges of the sets.
+ * Host variant: triples sorted by (set, i, j). */
+typedef struct {
+    uint32_t set; /* index of the contig set */
+    uint32_t i, j; /* nodes: 2 * contig-in-set + strand (1 = reverse complement), i <= j */
+} gf_qcpair;
+int gf_quick_check(gf_ctx* ctx, const char* seq, const uint64_t* contig_off, const uint64_t* set_off, size_t n_sets, int k,
+                   gf_qcpair* out, size_t cap, size_t* n_out);
+/* device variant: max_set_contigs = contigs of the largest set (sizes the pair matrices); *d_n_out (u32) = triples found (more
+ * than cap: truncated); order unspecified */
+int gf_quick_check_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off, const void* d_set_off, size_t n_sets,
+                       size_t max_set_contigs, int k, void* d_out, size_t cap, void* d_n_out);
+
 /* ---- device memory + timing helpers (so a ctypes host needs no other HIP binding) ---------------------- */
 int gf_dev_alloc(gf_ctx* ctx, size_t bytes, void** d_ptr);
 int gf_dev_free(gf_ctx* ctx, void* d_ptr);
@@ -355,6 +374,7 @@ int gf_memset_dev(gf_ctx* ctx, void* d_ptr, int value, size_t bytes);
 #define GF_KERNEL_VERIFY 7  /* second kernel of the screen: exact per-candidate verification */
 #define GF_KERNEL_INGEST 8  /* FASTQ text -> packed reads */
 #define GF_KERNEL_PICK 9    /* flank anchoring */
+#define GF_KERNEL_MERGE 10  /* contig-merge prefilter */
 int gf_timing_enable(gf_ctx* ctx, int on);
 int gf_timing_read(gf_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 int gf_timing_reset(gf_ctx* ctx);

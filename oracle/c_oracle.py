@@ -48,6 +48,8 @@ def lib():
         L.or_assemble_pool.argtypes = [C.c_char_p, sz, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
         L.or_assemble_pool2.restype = sz
         L.or_assemble_pool2.argtypes = [C.c_char_p, sz, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
+        L.or_quick_check.restype = sz
+        L.or_quick_check.argtypes = [C.c_char_p, vp, sz, i32, vp, vp, sz]
         L.or_synth_pairs.restype = None
         L.or_synth_pairs.argtypes = [vp, C.c_uint64, sz, vp, vp]
         L.or_synth_layout.restype = None
@@ -169,3 +171,16 @@ def assemble_pool(reads_blob, read_len, k, kv, min_count=2, min_contig=40, simpl
         out.append((b[off:off + int(ln[i])].decode(), int(nn[i]), int(cv[i])))
         off += int(ln[i])
     return out
+
+
+def quick_check(contigs, k=10):
+    """[(i, j)] feasible pairs of the node list [c0, revcomp(c0), c1, ...] (the contig merger's prefilter), in (i, j) order."""
+    blob = "".join(contigs).encode()
+    off = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(c) for c in contigs])
+    nn = 2 * len(contigs)
+    cap = nn * (nn + 1) // 2 + 1
+    oi = np.zeros(cap, np.uint32); oj = np.zeros(cap, np.uint32)
+    m = lib().or_quick_check(blob, _p(off), len(contigs), k, _p(oi), _p(oj), cap)
+    assert m <= cap
+    return list(zip(oi[:m].tolist(), oj[:m].tolist()))

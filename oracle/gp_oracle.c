@@ -125,6 +125,69 @@ size_t or_tag_alignments(const or_alnrec* recs, size_t n, const or_gap* gaps, si
     return cnt;
 }
 
+/* ------------------------------------------------------------------ f-3: the contig merger's all-pairs k-mer prefilter
+ * QuickCheckerContigsMatch (ContigsCompactor.cpp:1982-2095) as CompactVer3 applies it (:836-853, threadQuickCheck :1073-1098):
+ * node list = [c0, revcomp(c0), c1, revcomp(c1), ...] (:782-800); pair (i, j), i <= j (the pair (i, i) included), is FEASIBLE iff
+ * some k-mer of the first 30 or of the last 30 bases of node j (IsMatchFeasibleV2 :2020-2039, lenContigLen = 30) occurs
+ * anywhere in node i (Init :2041-2056); k-mers are KmerUtils' 2-bit strings, so any symbol other than C/G/T counts as A
+ * (KmerUtils.cpp:25-41) and nothing is canonical.  Contigs must have >= 30 bases (the reference reads out of bounds below).
+ * seqs: contigs back to back, off[n+1]; out: pairs (i, j) in (i, j) order; returns the number of pairs (may exceed cap). */
+static uint64_t qc_kmer(const char* s, int k) {
+    uint64_t v = 0;
+    for (int i = 0; i < k; ++i) v = (v << 2) | code_of(s[i]);
+    return v;
+}
+static int qc_cmp(const void* a, const void* b) {
+    const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : x > y;
+}
+size_t or_quick_check(const char* seqs, const uint64_t* off, size_t n, int k, uint32_t* out_i, uint32_t* out_j, size_t cap) {
+    const size_t nn = 2 * n;
+    char** node = malloc((nn + 1) * sizeof(char*));
+    size_t* len = malloc((nn + 1) * sizeof(size_t));
+    for (size_t c = 0; c < n; ++c) {
+        const size_t l = (size_t)(off[c + 1] - off[c]);
+        len[2 * c] = len[2 * c + 1] = l;
+        node[2 * c] = malloc(l + 1);
+        node[2 * c + 1] = malloc(l + 1);
+        for (size_t i = 0; i < l; ++i) {
+            char ch = seqs[off[c] + i];
+            if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);          /* the FASTA reader upper-cases */
+            node[2 * c][i] = ch;
+        }
+        for (size_t i = 0; i < l; ++i) {                               /* FastaSequence::RevsereComplement: A<->T, C<->G, rest kept */
+            const char ch = node[2 * c][l - 1 - i];
+            node[2 * c + 1][i] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
+        }
+    }
+    size_t cnt = 0;
+    for (size_t i = 0; i < nn; ++i) {
+        const size_t li = len[i];
+        if (li < (size_t)k) continue;
+        const size_t m = li - k + 1;
+        uint64_t* set = malloc((m + 1) * 8);                           /* mapKmerFreqInRepeat of node i, as a sorted array */
+        for (size_t p = 0; p < m; ++p) set[p] = qc_kmer(node[i] + p, k);
+        qsort(set, m, 8, qc_cmp);
+        for (size_t j = i; j < nn; ++j) {
+            int hit = 0;
+            for (int side = 0; side < 2 && !hit; ++side) {
+                const char* e = side ? node[j] + len[j] - 30 : node[j];
+                for (int p = 0; p + k <= 30 && !hit; ++p) {
+                    const uint64_t x = qc_kmer(e + p, k);
+                    size_t a = 0, b = m;
+                    while (a < b) { size_t mid = (a + b) / 2; if (set[mid] < x) a = mid + 1; else b = mid; }
+                    hit = a < m && set[a] == x;
+                }
+            }
+            if (hit) { if (cnt < cap) { out_i[cnt] = (uint32_t)i; out_j[cnt] = (uint32_t)j; } ++cnt; }
+        }
+        free(set);
+    }
+    for (size_t i = 0; i < nn; ++i) free(node[i]);
+    free(node); free(len);
+    return cnt;
+}
+
 /* ------------------------------------------------------------------ a-3: second hop */
 size_t or_tag_low_mapq(const or_alnrec* recs, size_t n, const or_dpos* table, size_t n_rows, or_taghit* out, size_t cap) {
     size_t cnt = 0;

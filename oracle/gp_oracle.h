@@ -37,6 +37,9 @@ size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv,
 size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig, int simplify,
                          uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
                          size_t* seq_need);
+/* f-3: the contig merger's all-pairs k-mer prefilter (QuickCheckerContigsMatch, ContigsCompactor.cpp:1982-2095) over the node list
+ * [c0, revcomp(c0), c1, ...]; pairs (i <= j) in order; returns their number (may exceed cap).  Contigs of >= 30 bases. */
+size_t or_quick_check(const char* seqs, const uint64_t* off, size_t n, int k, uint32_t* out_i, uint32_t* out_j, size_t cap);
 /* synthetic workload, definition in include/gf_synth.h (cfg = gf_synth_cfg) */
 void or_synth_pairs(const void* cfg, uint64_t first_pair, size_t n_pairs, uint8_t* packed, or_alnrec* recs_or_null);
 void or_synth_layout(const void* cfg, or_gap* gaps, char* flank_ascii, uint64_t* flank_off);

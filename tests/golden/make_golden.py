@@ -332,10 +332,51 @@ def kmerutils_kat():
         json.dump(out, f, indent=1)
 
 
+def quickcheck_kat():
+    """Known answers from the reference's own all-pairs 10-mer prefilter of the contig merger (QuickCheckerContigsMatch,
+    ContigsCompactor.cpp:1982-2095), built into oracle/_ref/quickcheck_kat: contig sets -> feasible node pairs."""
+    import random
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "ref"])
+    exe = os.path.join(REPO, "oracle", "_ref", "quickcheck_kat")
+    rng = random.Random(20260301)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+    sets = []
+    a = rnd(200)
+    sets.append([a, a[150:] + rnd(150), rnd(120)])                                   # a suffix-prefix overlap, an unrelated contig
+    g = rnd(1500)
+    sets.append([g[i:i + rng.randrange(80, 400)] for i in range(0, 1300, 90)])       # a tiling: many overlaps
+    sets.append([rc(x) if i % 2 else x for i, x in enumerate(sets[-1])])             # the same, every other contig reverse-complemented
+    sets.append([rnd(30), rnd(31), rnd(40), "ACGT" * 10, "A" * 45, "AC" * 30])       # shortest legal contigs, low complexity
+    n = rnd(300)
+    sets.append([n[:100] + "NNNNN" + n[105:200], n[150:300], "N" * 12 + n[20:80]])   # N counts as A (KmerUtils.cpp:25-41)
+    sets.append([rnd(rng.randrange(40, 300)) for _ in range(60)])                     # 60 unrelated contigs: hits by chance only
+    rep = rnd(60)
+    sets.append([rnd(100) + rep + rnd(100), rep + rnd(80), rnd(90) + rep, rc(rep) + rnd(70)])   # a shared repeat at contig ends
+    out = []
+    tmp = tempfile.mkdtemp(prefix="gp_qc_")
+    try:
+        for ci, contigs in enumerate(sets):
+            fa = os.path.join(tmp, "c%d.fa" % ci)
+            with open(fa, "w") as f:
+                f.write("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(contigs)))
+            for k in ((10,) if ci else (10, 8, 12)):
+                r = subprocess.check_output([exe, fa, str(k)]).decode().split()
+                pairs = [[int(r[i]), int(r[i + 1])] for i in range(0, len(r), 2)]
+                out.append({"contigs": contigs, "k": k, "pairs": pairs})
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with gzip.GzipFile(os.path.join(HERE, "quickcheck_kat.json.gz"), "wb", mtime=0) as gzf:
+        gzf.write(json.dumps(out, sort_keys=True).encode())
+    print("quickcheck_kat:", len(out), "cases,", sum(len(o["pairs"]) for o in out), "feasible pairs")
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
     kmerutils_kat()
+    quickcheck_kat()
     for name, seed in (("twolib", 20260001), ("edge", 20260011), ("bounds", 20260031), ("c1", 20260001)):
         case = make_case(name, seed)
         d = os.path.join(HERE, name)

@@ -1,0 +1,93 @@
+"""GPU parity of the contig-merge prefilter (SURVEY.md §8f-3 first piece: QuickCheckerContigsMatch, ContigsCompactor.cpp:1982-2095)
+through the C ABI: the reference's own answers (tests/golden/quickcheck_kat.json.gz, printed by oracle/_ref/quickcheck_kat) and the
+oracle on contig sets as the assembly produces them."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN
+from oracle import c_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gf():
+    from gappadder_amd.hip_api import GapFill
+    g = GapFill(0)
+    yield g
+    g.close()
+
+
+def _triples(out):
+    return [(int(x["set"]), int(x["i"]), int(x["j"])) for x in out]
+
+
+def test_quick_check_equals_the_reference_vectors(gf):
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "quickcheck_kat.json.gz"), "rt").read())
+    for k in sorted({c["k"] for c in cases}):
+        batch = [c for c in cases if c["k"] == k]
+        got = _triples(gf.quick_check([c["contigs"] for c in batch], k))
+        want = [(s, i, j) for s, c in enumerate(batch) for i, j in c["pairs"]]
+        assert got == want, k
+    assert sum(len(c["pairs"]) for c in cases) > 300
+
+
+def test_quick_check_on_many_sets_matches_oracle(gf):
+    """Hundreds of sets in one call (one workgroup per set, dynamic hand-out), sets larger than one table chunk (> 195 nodes),
+    an empty set, lower case and N."""
+    rng = np.random.default_rng(7)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.integers(0, 4, n)].tobytes().decode()
+    sets = []
+    for s in range(150):
+        g = rnd(int(rng.integers(400, 3000)))
+        n = int(rng.integers(1, 40))
+        cs = []
+        for _ in range(n):
+            a = int(rng.integers(0, len(g) - 60))
+            c = g[a:a + int(rng.integers(30, 400))]
+            if rng.integers(0, 2):
+                c = c[::-1].translate(str.maketrans("ACGT", "TGCA"))
+            if rng.integers(0, 10) == 0:
+                c = c[:10] + "N" + c[11:]
+            if rng.integers(0, 10) == 0:
+                c = c.lower()
+            cs.append(c)
+        sets.append(cs)
+    sets.append([])
+    g = rnd(20000)
+    sets.append([g[a:a + 150] for a in range(0, 19000, 60)])          # 317 contigs = 634 nodes: four table chunks
+    got = _triples(gf.quick_check(sets, 10))
+    want = [(s, i, j) for s, cs in enumerate(sets) for i, j in (CO.quick_check(cs, 10) if cs else [])]
+    assert got == want and len(want) > 5000
+
+
+def test_quick_check_rejects_short_contigs(gf):
+    from gappadder_amd import _lib as B
+    with pytest.raises(B.GapFillError) as e:
+        gf.quick_check([["ACGT" * 10, "ACGTACGT"]], 10)
+    assert e.value.code == B.GF_E_INVAL
+
+
+def test_quick_check_on_assembled_contigs(gf):
+    """The use the reference makes of it: the contigs.fa of a gap (all (k, kv) pairs) -> candidate pairs for the overlap merge."""
+    import synth_small as S
+    from gappadder_amd.hip_api import GapFill
+    c = S.small_case(seed=21, n_pairs=12000)
+    L = c["L"]
+    hits = CO.screen_reads(c["reads_blob"], L, c["flanks"], 31)
+    sets = []
+    for g in range(len(c["gaps"])):
+        ids = sorted(set(int(h["read"]) for h in hits if h["gap"] == g) | set(int(h["read"]) ^ 1 for h in hits if h["gap"] == g))
+        pool = b"".join(c["reads_blob"][i * L:(i + 1) * L] for i in ids)
+        cs = [s for k, kv in ((31, 29), (41, 39)) for s, _, _ in CO.assemble_pool(pool, L, k, kv)]
+        sets.append(cs)
+    got = _triples(gf.quick_check(sets, 10))
+    want = [(s, i, j) for s, cs in enumerate(sets) for i, j in CO.quick_check(cs, 10)]
+    assert got == want and len(want) > len(sets)
+    # the same genome assembled at two k's overlaps itself: more than the diagonal is feasible
+    assert any(i // 2 != j // 2 for _, i, j in want)

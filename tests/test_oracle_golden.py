@@ -106,3 +106,18 @@ def test_wide_kmer_layout_extends_kmerutils():
         assert O.pack_kmer128(s, 3, k) >> 64 == O.pack_kmer64(s, 3, k)
     f = O.pack_kmer128(s, 0, 41)
     assert O.kmer128_to_string(O.revcomp_kmer128(f, 41), 41) == O._rc(s[:41])
+
+
+def test_quick_check_equals_the_reference_prefilter():
+    """oracle or_quick_check vs the feasible pairs the reference's own QuickCheckerContigsMatch printed (oracle/_ref/quickcheck_kat,
+    ContigsCompactor.cpp:1982-2095): every committed contig set, k = 8, 10, 12."""
+    import gzip
+    from oracle import c_oracle as CO
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "quickcheck_kat.json.gz"), "rt").read())
+    assert len(cases) >= 9
+    total = 0
+    for c in cases:
+        got = CO.quick_check(c["contigs"], c["k"])
+        assert got == [tuple(p) for p in c["pairs"]], (c["k"], len(c["contigs"]))
+        total += len(got)
+    assert total > 300
