@@ -316,7 +316,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
     const uint32_t per = P.k - P.kv + 1;
 
     // gaps are handed out through one counter: pool sizes differ, a static stride left CUs idle behind the largest gaps
-    __shared__ uint32_t s_gap;
+    __shared__ uint32_t s_gap, s_cand;
     for (;;) {
         __syncthreads();
         if (tid == 0) s_gap = atomicAdd(P.next_gap, 1u);
@@ -885,44 +885,50 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         //      short, so heads WALK the links (no ranking needed yet): a decision only sets the KILL bit of X's end nodes; after the
         //      barrier the arcs into X are cleared at their sources, X's nodes die, and the junctions that lost a branch re-link.
         // unitig headed by h: tail and node count, false when it has more than `limit` nodes
-        auto walk = [&](uint32_t h, uint32_t limit, uint32_t& tail, uint32_t& n) -> bool {
+        auto walk = [&](uint32_t h, uint32_t limit, uint32_t& tail, uint32_t& n, uint32_t& cov) -> bool {
             uint32_t cur = h;
             n = 1;
+            cov = nmeta.get(h >> 1) >> M_MULT_SHIFT;     // the coverage sum rides along: no second walk when two unitigs are compared
             for (;;) {
                 const uint32_t nx = succ_get(cur);
                 if (nx == EMPTY32) break;
                 if (n == limit) return false;
                 cur = nx;
+                cov += nmeta.get(cur >> 1) >> M_MULT_SHIFT;
                 ++n;
             }
             tail = cur;
             return true;
         };
-        auto uni_cov = [&](uint32_t h, uint32_t n) -> uint32_t {
-            uint32_t cur = h, c = 0;
-            for (uint32_t i = 0; i < n && cur != EMPTY32; ++i) { c += nmeta.get(cur >> 1) >> M_MULT_SHIFT; cur = succ_get(cur); }
-            return c;
-        };
         auto uni_key = [&](uint32_t h, uint32_t t) -> K128 {
             const K128 a = node_seq(h), b = node_seq(t ^ 1u);
             return b < a ? b : a;
         };
-        // does the unitig headed by y (tail ty, ny nodes) beat the one headed by x?
-        auto beats = [&](uint32_t y, uint32_t ty, uint32_t ny, uint32_t x, uint32_t tx, uint32_t nx, bool with_len) -> bool {
+        // does the unitig headed by y (tail ty, ny nodes, coverage cy) beat the one headed by x?
+        auto beats = [&](uint32_t y, uint32_t ty, uint32_t ny, uint32_t cy, uint32_t x, uint32_t tx, uint32_t nx, uint32_t cx, bool with_len) -> bool {
             if (with_len && ny != nx) return ny > nx;
-            const uint32_t cy = uni_cov(y, ny), cx = uni_cov(x, nx);
             if (cy != cx) return cy > cx;
             return uni_key(y, ty) < uni_key(x, tx);
         };
         for (uint32_t round = 0; round < P.simplify; ++round) {
-            if (tid == 0) s_cnt[7] = 0;
+            if (tid == 0) { s_cnt[7] = 0; s_cand = 0; }
             __syncthreads();
+            // candidate heads first (live, no internal predecessor, exactly one arc in) into a queue — the pairs are idle before the
+            // ranking —, then one candidate per thread: the evaluation is a serial chain of walks and look-ups (3-40 us each), and
+            // a thread that found three candidates in its own stride set the pace of the whole phase
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                if (is_dead(o) || has_pred(o)) continue;
+                if (is_dead(o) || has_pred(o) || __popc(inb(o)) != 1) continue;
+                J.store(atomicAdd(&s_cand, 1u), o);
+            }
+            wg_phase_sync();
+            const uint32_t n_cand = s_cand;
+            // dealt round-robin over the WAVES (candidate q -> wave q mod 16): every wave gets as few divergent lanes as possible and
+            // all waves' latency chains overlap (packing them into the first waves measured slower than no queue at all)
+            for (uint32_t qi = (tid & 63) * (ASM_THREADS / 64) + (tid >> 6); qi < n_cand; qi += ASM_THREADS) {
+                const uint32_t o = (uint32_t)J.load(qi);
                 const uint32_t ib = inb(o);
-                if (__popc(ib) != 1) continue;
-                uint32_t t, n;
-                if (!walk(o, 2 * P.kv, t, n)) continue;
+                uint32_t t, n, cx;
+                if (!walk(o, 2 * P.kv, t, n, cx)) continue;
                 const K128 hs = node_seq(o);
                 const uint32_t p = find_oriented(shift_in_front(hs, __ffs(ib) - 1, kv));
                 if (p == EMPTY32) continue;
@@ -936,9 +942,9 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         if (!((pb >> c) & 1u)) continue;
                         const uint32_t y = find_oriented(shift_in(ps, c, kv));
                         if (y == EMPTY32 || y == o || has_pred(y) || y == (t ^ 1u)) continue;
-                        uint32_t ty, ny;
-                        const bool tip_shaped = walk(y, P.kv, ty, ny) && outb(ty) == 0 && __popc(inb(y)) == 1;
-                        if (!tip_shaped || beats(y, ty, ny, o, t, n, true)) go = true;
+                        uint32_t ty, ny, cy;
+                        const bool tip_shaped = walk(y, P.kv, ty, ny, cy) && outb(ty) == 0 && __popc(inb(y)) == 1;
+                        if (!tip_shaped || beats(y, ty, ny, cy, o, t, n, cx, true)) go = true;
                     }
                 } else if (__popc(tb) == 1) {                                   // BUBBLE (n <= 2 kv by the walk)
                     const uint32_t s = find_oriented(shift_in(node_seq(t), __ffs(tb) - 1, kv));
@@ -954,8 +960,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                             if (!((outb(q) >> c) & 1u)) continue;
                             const uint32_t y = find_oriented(shift_in(node_seq(q), c, kv));
                             if (y == EMPTY32 || has_pred(y) || y == o || y == (t ^ 1u)) continue;
-                            uint32_t ty, ny;
-                            if (!walk(y, rem, ty, ny)) continue;                 // more nodes than remain
+                            uint32_t ty, ny, cy;
+                            if (!walk(y, rem, ty, ny, cy)) continue;             // more nodes than remain
                             if (ny == rem) {
                                 const uint32_t yb = outb(ty);
                                 bool reaches = false;
@@ -963,7 +969,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                                 for (uint32_t c2 = 0; c2 < 4; ++c2)
                                     if (((yb >> c2) & 1u) && find_oriented(shift_in(tys, c2, kv)) == s) reaches = true;
                                 if (!reaches) continue;
-                                if (sp >= 1 || beats(y, ty, ny, o, t, n, false)) go = true;
+                                if (sp >= 1 || beats(y, ty, ny, cy, o, t, n, cx, false)) go = true;
                             } else if (sp + 1 < 4) {
                                 ++sp;
                                 st_q[sp] = ty; st_rem[sp] = rem - ny; st_c[sp] = 0;
