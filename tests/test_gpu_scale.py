@@ -310,9 +310,9 @@ def test_two_rank_owner_assembly_equals_the_single_process_run(tmp_path, config,
     assert abs(a["gaps_per_s"] * a["ms_per_step"] - b["gaps_per_s"] * b["ms_per_step"]) < 1e-3 * a["gaps_per_s"] * a["ms_per_step"]   # same gaps, counted once
 
 
-@pytest.mark.parametrize("config", ["C2", "C4", "C5"])
+@pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5"])
 def test_full_size_config_sample_parity(config):
-    """BASELINE.json configs[1], [3], [4] at FULL size on this GPU (reads generated on the device): all screen and tagger hits of
+    """BASELINE.json configs[1], [2], [3], [4] at FULL size on this GPU (reads generated on the device): all screen and tagger hits of
     the oracle's read prefix (every library), the merged pools' assembly of 256 gaps at every (k, kv) and the closed flags equal
     the oracle / the host picker; every gap recruits reads and yields contigs."""
     d = _bench(["--config", config, "--steps", "1", "--warmup", "0", "--no-extras"])
@@ -321,7 +321,7 @@ def test_full_size_config_sample_parity(config):
     assert cb["sample_hits"] > 1000 and cb["sample_contigs"] > 100
     n_gaps = d["config"]["gaps"]
     assert d["counts"]["gaps_with_contig"] == n_gaps
-    want_reads = {"C2": 50_000_000, "C4": 900_000_000, "C5": 1_300_000_000}[config]     # C5: 900 M + the 400 M mate-pair records that make 2-kb gaps closable (bench.py)
+    want_reads = {"C2": 50_000_000, "C3": 5_000_000, "C4": 900_000_000, "C5": 1_300_000_000}[config]     # C5: 900 M + the 400 M mate-pair records that make 2-kb gaps closable (bench.py)
     assert d["config"]["reads_total"] == want_reads and d["n_gpus"] == 1
     if config == "C5":      # the mate-pair geometry closes the gaps in one pass (tip clipping + bubble popping on)
         assert d["counts"]["gaps_closed"] > 0.9 * n_gaps and d["gaps_closed_per_s"] > 0
