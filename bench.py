@@ -119,10 +119,15 @@ def run(args):
     seed, slen, nscf, gps, glen, dreads, kk = PRESETS[args.config]
     total_reads = (args.reads or dreads) // 2 * 2
     L = 150
-    lib_defs = [("short-insert", 300, 30, 0, total_reads)]
+    # (name, IS, sd, library number, records, pull the mates of k-mer-screen hits?)  A read that shares a k-mer with a flank lies AT
+    # the gap; its mate lies one insert away: inside or next to the gap for the 300-bp library (pulled: north_star's "candidate read
+    # pairs"), 5 kb away for the mate-pair library (not pulled: those mates are recruited by the tagger's rules when they belong to the
+    # gap — mate unmapped / discordant / clipped inside the focal window — and are distant sequence otherwise; GF_BENCH_MP_PAIRS=1 pulls
+    # them anyway: 819 instead of 620 reads per pool, the same gaps closed)
+    lib_defs = [("short-insert", 300, 30, 0, total_reads, 1)]
     if args.config == "C5":
         mp = MP_READS_DEFAULT if args.mp_reads < 0 else args.mp_reads
-        lib_defs.append(("mate-pair", 5000, 500, 1, mp // 2 * 2))
+        lib_defs.append(("mate-pair", 5000, 500, 1, mp // 2 * 2, int(os.environ.get("GF_BENCH_MP_PAIRS", "0"))))
     n_lib = len(lib_defs)
 
     lib = B.lib()
@@ -156,9 +161,9 @@ def run(args):
 
     # ---- inputs resident in HBM (torch = device-memory plumbing) ----
     libs = []
-    for name, is_mean, is_sd, lib_no, n_total in lib_defs:
+    for name, is_mean, is_sd, lib_no, n_total, pull_mates in lib_defs:
         lb = Lib()
-        lb.name, lb.is_mean, lb.is_sd = name, is_mean, is_sd
+        lb.name, lb.is_mean, lb.is_sd, lb.pull_mates = name, is_mean, is_sd, pull_mates
         lb.h2 = gf2s[len(libs)].handle
         lb.cfg = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L,
                                    insert_mean=is_mean, insert_sd=is_sd, library=lib_no)
@@ -254,7 +259,7 @@ def run(args):
         assert rc == 0, rc
         if hh is not h:
             assert lib.gf_stream_wait(h, lb.h2) == 0          # pools need the tagger's and the second hop's hits
-        assert lib.gf_pool_keys_all_dev(h, lb.d_hits.data_ptr(), lb.cp, lb.hit_cap, 1, lb.d_recs.data_ptr(), lb.d_thits.data_ptr(), lb.cp + 16,
+        assert lib.gf_pool_keys_all_dev(h, lb.d_hits.data_ptr(), lb.cp, lb.hit_cap, lb.pull_mates, lb.d_recs.data_ptr(), lb.d_thits.data_ptr(), lb.cp + 16,
                                         lb.hit_cap, lb.d_lhits.data_ptr(), lb.cp + 32, lb.hit_cap, rowgap_p,
                                         lb.d_keys.data_ptr(), lb.key_cap, lb.cp + 48) == 0
 
@@ -468,7 +473,7 @@ def run(args):
         wl = ("%s: %d gaps x %d bp in %d x %.1f Mb scaffolds; %s; k/kv %s; step = k-mer screen (k=%d) + alignment tagger + second hop + per-gap "
               "pools%s + per-gap assembly + flank anchoring" %
               (args.config, n_gaps, glen, nscf, slen / 1e6,
-               " + ".join("%s library IS %d/%d: %d x %d-bp read records (+ as many 32-B alignment records)" % (lb.name, lb.is_mean, lb.is_sd, lb.n_total, L)
+               " + ".join("%s library IS %d/%d: %d x %d-bp read records (+ as many 32-B alignment records)%s" % (lb.name, lb.is_mean, lb.is_sd, lb.n_total, L, "" if lb.pull_mates else ", screen hits without their mates")
                           for lb in libs),
                ",".join("%d/%d" % p for p in kk), k_s,
                " (libraries merged in library order)" if n_lib > 1 else ""))

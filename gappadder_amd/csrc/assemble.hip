@@ -860,6 +860,9 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         bool cacc_lds = false;
         uint32_t* cacc = nullptr;
         uint32_t cacc_cap = 0;
+        // between phases that hand data over through the graph arrays only: a plain barrier when those live in LDS (the L1
+        // invalidate of wg_phase_sync is for hand-overs through global memory)
+        auto graph_sync = [&]() { if (graph_lds) __syncthreads(); else wg_phase_sync(); };
         // ---- P4: unitig-internal edges.  (x,d) -> (y,dy) is internal iff out-degree(x,d) == 1 and in-degree(y,dy) == 1;
         //      an oriented node that no internal edge enters is a unitig START.
         for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 nmeta.or_(y >> 1, (y & 1) ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
             }
         }
-        wg_phase_sync();
+        graph_sync();
         ASM_STAMP(4);
 
         // ---- error removal (semantics: oracle/gp_oracle.c simplify_round): rounds on snapshots of the graph.  Every
@@ -920,7 +923,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 if (is_dead(o) || has_pred(o) || __popc(inb(o)) != 1) continue;
                 J.store(atomicAdd(&s_cand, 1u), o);
             }
-            wg_phase_sync();
+            graph_sync();
             const uint32_t n_cand = s_cand;
             // dealt round-robin over the WAVES (candidate q -> wave q mod 16): every wave gets as few divergent lanes as possible and
             // all waves' latency chains overlap (packing them into the first waves measured slower than no queue at all)
@@ -983,7 +986,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     s_cnt[7] = 1;
                 }
             }
-            wg_phase_sync();
+            graph_sync();
             if (!s_cnt[7]) break;                                               // nothing to remove
             // the killed heads remember the arc that enters them (the pairs are not in use before the ranking)
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 }
                 J.store(o, arc);
             }
-            wg_phase_sync();
+            graph_sync();
             // arcs into the removed unitigs are cleared at their sources; the heads walk their unitigs and mark the nodes dead
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
                 if (has_pred(o) || !(nmeta.get(o >> 1) & M_KILL) || (nmeta.get(o >> 1) & M_DEAD)) continue;
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 }
                 for (uint32_t cur = o; cur != EMPTY32; cur = succ_get(cur)) nmeta.or_(cur >> 1, M_DEADMARK);
             }
-            wg_phase_sync();
+            graph_sync();
             // junctions that lost a branch: with one successor left, the edge to it may have become unitig-internal (both directions)
             auto is_gone = [&](uint32_t o) { return (nmeta.get(o >> 1) & (M_DEAD | M_DEADMARK)) != 0; };
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
@@ -1027,13 +1030,13 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 ((y & 1) ? succ0 : succ1).set(y >> 1, p ^ 1u);                   // the reverse link y' -> p'
                 nmeta.or_(p >> 1, (p & 1) ? M_START0 : M_START1);
             }
-            wg_phase_sync();
+            graph_sync();
             for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
                 const uint32_t m = nmeta.get(ni);
                 if ((m & M_DEADMARK) && !(m & M_DEAD)) nmeta.or_(ni, M_DEAD);
                 if (m & M_KILL) nmeta.and_(ni, ~M_KILL);
             }
-            wg_phase_sync();
+            graph_sync();
         }
 
         ASM_STAMP(7);
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             }
             J.store(o, pr);
         }
-        wg_phase_sync();
+        graph_sync();
         for (int jr = 0; jr < 24; ++jr) {
             if (tid == 0) s_cnt[7] = 0;
             __syncthreads();
@@ -1068,7 +1071,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             if (!s_cnt[7]) break;
             __syncthreads();
         }
-        wg_phase_sync();
+        graph_sync();
         // tails publish {tail, length} in their head's pair (heads are not read as ancestors any more)
         for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
             if (is_dead(o) || succ_get(o) != EMPTY32) continue;
@@ -1079,7 +1082,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             const uint32_t rank = hp ? (uint32_t)(a0 >> 32) : 0;
             J.store(h, ((unsigned long long)(rank + 1) << 32) | o);
         }
-        wg_phase_sync();
+        graph_sync();
 
         // ---- emission: heads decide, then every node of an emitted unitig writes its own base
         {
