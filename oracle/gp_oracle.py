@@ -403,70 +403,5 @@ def _rc(s):
     return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
 
 
-def assemble_kmers(kmer_strings, kv, min_contig=40):
-    """Stage 2 of the reference's 'two stage local assembly' (assemble_gaps.py:104-118: every surviving k-mer
-    becomes one Velvet read at hash length kv).  PARITY UNPINNED; this build DEFINES:
-      nodes  = distinct canonical kv-mers of the k-mer strings;
-      edges  = distinct (kv+1)-mers of the k-mer strings (both orientations);
-      unitig = maximal path whose inner junctions have exactly one out-edge and one in-edge;
-      each unitig is reported once, in the orientation min(seq, revcomp(seq)); unitigs shorter than
-      min_contig bp are dropped; output sorted by (-length, sequence).
-    Returns [sequence]."""
-    succ, pred = {}, {}
-    nodes = set()
-    for s in kmer_strings:
-        for t in (s, _rc(s)):
-            for i in range(len(t) - kv + 1):
-                nodes.add(t[i:i + kv])
-            for i in range(len(t) - kv):
-                a, b = t[i:i + kv], t[i + 1:i + 1 + kv]
-                succ.setdefault(a, set()).add(b)
-                pred.setdefault(b, set()).add(a)
-
-    def out1(a):
-        s = succ.get(a, ())
-        return next(iter(s)) if len(s) == 1 else None
-
-    def in1(a):
-        return len(pred.get(a, ())) == 1
-
-    seen, contigs = set(), []
-    for start in sorted(nodes):
-        if start in seen:
-            continue
-        # is `start` a unitig head?  (no unique predecessor whose only successor is start)
-        p = pred.get(start, ())
-        is_head = not (len(p) == 1 and len(succ.get(next(iter(p)), ())) == 1)
-        if not is_head:
-            continue
-        path, cur = [start], start
-        while True:
-            nx = out1(cur)
-            if nx is None or not in1(nx) or nx == start or nx == _rc(cur):
-                break
-            if nx in path:
-                break
-            path.append(nx)
-            cur = nx
-        seq = path[0] + "".join(n[-1] for n in path[1:])
-        for n in path:
-            seen.add(n)
-            seen.add(_rc(n))
-        contigs.append(min(seq, _rc(seq)))
-    # isolated cycles (no head): walk from the smallest unseen node
-    for start in sorted(nodes):
-        if start in seen:
-            continue
-        path, cur = [start], start
-        seen.add(start); seen.add(_rc(start))
-        while True:
-            nx = out1(cur)
-            if nx is None or nx in seen:
-                break
-            path.append(nx)
-            seen.add(nx); seen.add(_rc(nx))
-            cur = nx
-        seq = path[0] + "".join(n[-1] for n in path[1:])
-        contigs.append(min(seq, _rc(seq)))
-    contigs = sorted(set(c for c in contigs if len(c) >= min_contig), key=lambda c: (-len(c), c))
-    return contigs
+# Stage 2 (the kv-mer graph, unitigs, Velvet's default tip clipping + bubble popping) is restated in C only:
+# oracle/gp_oracle.c `or_assemble_pool2` (bound as oracle.c_oracle.assemble_pool) — the definition the GPU kernel is checked against.
