@@ -1,10 +1,11 @@
 """rocprofv3 results (rocpd SQLite: <src>/trace, <src>/pmc_<COUNTER>) -> profiles/r02_kernel_stats_<cfg>.csv,
 r02_pmc_summary_<cfg>.csv, r02_traffic_<cfg>.json (the file bench.py's roofline.traffic reads).
-usage: summarise_profiles_r02.py SRC CFG READS_PER_LAUNCH K "CMD" """
+usage: summarise_profiles_r02.py SRC CFG READS_PER_LAUNCH K "CMD" [DST=profiles] """
 import collections, csv, glob, json, os, sqlite3, sys
 
 src, cfg, reads, k, cmd = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-dst = "profiles"
+dst = sys.argv[6] if len(sys.argv) > 6 else "profiles"
+os.makedirs(dst, exist_ok=True)
 
 
 def newest_db(d):
