@@ -135,7 +135,11 @@ def run(args):
     gf = GapFill(local)
     # second context = second HIP stream on the same device: the alignment tagger + second hop are independent of the k-mer
     # screen until the pools are built
-    serial = bool(os.environ.get("GF_BENCH_SERIAL"))     # diagnostic: one stream, so every phase time is stand-alone
+    # One stream by default: every placement of the tagger beside the screen was measured (beside the filter, beside the verification
+    # pass, as one-wave workgroups next to the filter's) and gave the SUM of the stand-alone times within 1-3 % (C4: 68.0 / 70.3 / 69.0
+    # vs 68.3 ms in a row) — the kernels take turns on the memory system; in a row every kernel's HIP-event span is its own duration.
+    # GF_BENCH_TWO_STREAMS=1: tagger + second hop on a second context / stream beside the filter.
+    serial = os.environ.get("GF_BENCH_TWO_STREAMS", "0") != "1"
     # (one per library: the tagger caches its coarse bin map per insert-size window)
     gf2s = [gf if serial else GapFill(local) for _ in lib_defs]
     stream = None
@@ -206,8 +210,14 @@ def run(args):
         for g2 in gf2s:
             g2.sync()
 
+    tag_after_filter = not serial and os.environ.get("GF_BENCH_TAG_AFTER_FILTER", "0") == "1"
+
     def recruit(lb):
         assert lib.gf_stream_wait(lb.h2, h) == 0          # the previous consumers of the tagger buffers are done
+        if tag_after_filter:
+            # the tagger (a pure 32-B-record stream) starts when the k-mer FILTER has finished and runs beside the latency-bound
+            # verification pass: beside the filter the two only took turns on the memory system (C4: 36.5 ms together, 26.6 + 10.5 alone)
+            assert lib.gf_stream_wait_after_filter(lb.h2, h) == 0
         rc = lib.gf_screen_reads_dev(h, lb.d_reads.data_ptr(), None, lb.n_reads, L, k_screen, 1, lb.d_hits.data_ptr(), lb.hit_cap, lb.cp)
         assert rc == 0, rc
         rc = lib.gf_tag_alignments_low_dev(lb.h2, lb.d_recs.data_ptr(), lb.n_reads, lb.is_mean, lb.is_sd, 250, 30, lb.d_thits.data_ptr(),
@@ -498,8 +508,8 @@ def run(args):
                          "algorithmic_bytes_per_launch": int(reads_per_launch * rb), "avg_launch_ms": filt_ms,
                          "frac_of_measured_copy_6290": achieved / 6290.0},
             "phases_ms": phases,
-            "phases_note": "HIP-event spans per kernel group, summed over the libraries, per step; tagger + second hop run on a second "
-                           "stream beside the screen, so their spans include queueing behind the filter (GF_BENCH_SERIAL=1: one stream)",
+            "phases_note": "HIP-event spans per kernel group, summed over the libraries, per step; one stream: the step is their sum "
+                           "(GF_BENCH_TWO_STREAMS=1 runs tagger + second hop on a second stream beside the filter: same step time within 1-3 %)",
             "counts": {"libraries": {lb.name: lb.counts for lb in libs}, "assembled_pool_reads": asm_rows_total, "contigs": n_ctg_all,
                        "gaps_with_contig": gaps_with_contig, "gaps_closed": n_closed, "largest_pool_reads": max_pool_rows},
         }

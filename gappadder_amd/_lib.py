@@ -61,6 +61,7 @@ def lib():
         "gf_set_stream": (i32, [vp, vp]),
         "gf_sync": (i32, [vp]),
         "gf_stream_wait": (i32, [vp, vp]),
+        "gf_stream_wait_after_filter": (i32, [vp, vp]),
         "gf_set_option": (i32, [vp, C.c_char_p, C.c_long]),
         "gf_set_gaps": (i32, [vp, vp, sz, u32, C.c_char_p, vp]),
         "gf_pack_reads": (i32, [C.c_char_p, sz, i32, vp, vp]),

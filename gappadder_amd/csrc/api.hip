@@ -166,6 +166,12 @@ int gf_stream_wait(gf_ctx* waiter, gf_ctx* producer) {
     return GF_OK;
 }
 
+int gf_stream_wait_after_filter(gf_ctx* waiter, gf_ctx* producer) {
+    if (!waiter || !producer || waiter == producer || waiter->device != producer->device) return GF_E_INVAL;
+    producer->after_filter = waiter;
+    return GF_OK;
+}
+
 int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!ctx || !name) return GF_E_INVAL;
     if (!strcmp(name, "max_gaps_per_kmer")) { ctx->max_gaps_per_kmer = value < 0 ? 0 : (uint32_t)value; return GF_OK; }

@@ -68,6 +68,7 @@ struct gf_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string last_error;
+    gf_ctx* after_filter = nullptr;   // one-shot: this context's stream waits for the end of the next filter pass of the owner (gf_stream_wait_after_filter)
     int n_cu = 256;
 
     // gaps

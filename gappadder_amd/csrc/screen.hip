@@ -580,6 +580,243 @@ __global__ __launch_bounds__(1024) void pf_probe_kernel(PartParams Q) {
     if (obuf_n) flush();
 }
 
+// ---- partitioned filter, second form: 256 buckets, so that a bucket's slice of the LEVEL-1 bitmap itself (2^bm_log2 / 256 bits:
+// 128 KiB at 2^28) is what pass B holds in LDS — both bits of a key are tested without leaving the CU, and only the ~1 % that pass
+// go on to the exact set.  The 16-bucket form above stops 52 % of the pairs in LDS and sends the rest to the L2 at its random-request
+// rate (1.4e11/s chip-wide: 1.5 of pass B's 2.2 ms, PMC in DESIGN.md §7).  256 rows per WAVE were tried in round 1 (flush
+// bookkeeping: 18 ms); here the unit is the WORKGROUP: sixteen waves scramble one 64-read tile each, every pair takes its rank inside
+// its bucket with ONE LDS atomic on a 256-bin histogram, a scan turns the histogram into offsets, the pairs are placed in bucket
+// order in LDS and leave as runs (about 16 pairs = 128 B per bucket and iteration) into the workgroup's own part of each bucket.
+constexpr uint32_t PF2_NB_LOG2 = 8, PF2_NB = 1u << PF2_NB_LOG2;
+constexpr uint32_t PF2_WAVES = 16, PF2_GROUP = 4;                       // waves per workgroup; probes sorted per iteration and read
+constexpr uint32_t PF2_TILES = 2;                                      // 64-read tiles per wave and iteration
+constexpr uint32_t PF2_BATCH = PF2_WAVES * PF2_TILES * 64 * PF2_GROUP; // 8192 pairs = 64 KiB
+// Measured on 112.5 M reads, k=51 (2^28-bit bitmap): 16 waves x 1 tile 2.47 ms, 16 x 2 tiles + alternating histograms 2.22 ms (longer
+// runs per bucket: 32 pairs = 256 B); 8 waves x 2 tiles with the sort buffer overlaid on the tiles, three workgroups per CU: 2.68 ms
+// (128-B runs, three times the parts); 16 x 3 tiles overlaid: 5.6 ms (36 scrambled keys per lane in registers spill).
+
+__global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams Q, uint32_t slice_words) {
+    extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][sorted pairs: PF2_BATCH x 8 B][hist 2 x 256][offs 257][written 256]
+    const FilterParams& P = Q.F;
+    constexpr uint32_t NT = 64 * PF2_WAVES;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* tiles = sm + wv * PF2_TILES * slice_words;
+    unsigned long long* sorted = reinterpret_cast<unsigned long long*>(sm + PF2_WAVES * PF2_TILES * slice_words);
+    uint32_t* hist2 = reinterpret_cast<uint32_t*>(sorted + PF2_BATCH);   // two histograms, used alternately: the idle one is zeroed
+    uint32_t* offs = hist2 + 2 * PF2_NB;                                 // during the copy-out (one barrier less per group)
+    uint32_t* written = offs + PF2_NB + 1;
+    const uint32_t writer = blockIdx.x;
+    const uint32_t tile_bytes = 64 * P.rb;
+    const uint64_t total_bytes = P.n_reads * P.rb;
+    const uint64_t n_tiles = (P.n_reads + 63) / 64;
+    const unsigned long long lt = (1ull << lane) - 1;
+    auto part = [&](uint32_t b) { return Q.pairs + ((size_t)b * Q.n_writers + writer) * Q.cap; };
+    for (uint32_t i = tid; i < PF2_NB; i += NT) { written[i] = 0; hist2[i] = 0; hist2[PF2_NB + i] = 0; }
+    constexpr int NPF = 4;   // 64 reads x <= 64 B
+    uint4 pf[PF2_TILES][NPF];
+    auto prefetch = [&](uint64_t t0) {
+#pragma unroll
+        for (uint32_t q = 0; q < PF2_TILES; ++q) {
+            const uint64_t t = t0 + q;
+            if (t >= n_tiles) continue;
+            const uint64_t byte0 = t * tile_bytes;
+            const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) {
+                const uint32_t i = lane + c * 64;
+                pf[q][c] = i < (nbytes >> 4) ? *reinterpret_cast<const uint4*>(P.reads + byte0 + (uint64_t)i * 16) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    const uint64_t t_step = (uint64_t)gridDim.x * PF2_WAVES * PF2_TILES;
+    const uint64_t n_iter = (n_tiles + t_step - 1) / t_step;
+    prefetch(((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES);
+    uint32_t flip = 0;
+    __syncthreads();
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        const uint64_t t0 = it * t_step + ((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES;
+#pragma unroll
+        for (uint32_t q = 0; q < PF2_TILES; ++q) {
+            const uint64_t t = t0 + q;
+            if (t >= n_tiles) continue;
+            uint8_t* tb = reinterpret_cast<uint8_t*>(tiles + q * slice_words);
+            const uint64_t byte0 = t * tile_bytes;
+            const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+            const uint32_t n16 = nbytes & ~15u;
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) {
+                const uint32_t i = lane + c * 64;
+                if (i < (n16 >> 4)) *reinterpret_cast<uint4*>(tb + (uint64_t)i * 16) = pf[q][c];
+            }
+            for (uint32_t i = n16 + lane; i < nbytes; i += 64) tb[i] = P.reads[byte0 + i];
+            if (lane < 16) tb[nbytes + lane] = 0;
+        }
+        wave_lds_sync();
+        prefetch(t0 + t_step);
+        const uint32_t bit0 = lane * P.rb * 8;
+        for (uint32_t j0 = 0; j0 < P.np; j0 += PF2_GROUP) {
+            uint32_t* hist = hist2 + flip * PF2_NB;        // all zero (start / zeroed during the previous copy-out)
+            uint32_t pk[PF2_TILES][PF2_GROUP], rank[PF2_TILES][PF2_GROUP];
+#pragma unroll
+            for (uint32_t q = 0; q < PF2_TILES; ++q) {
+                const bool live = t0 + q < n_tiles && (t0 + q) * 64 + lane < P.n_reads;
+#pragma unroll
+                for (uint32_t u = 0; u < PF2_GROUP; ++u) {
+                    const bool on = live && j0 + u < P.np;
+                    pk[q][u] = on ? canon16(stream32(tiles + q * slice_words, bit0 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
+                    rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
+                }
+            }
+            __syncthreads();
+            if (wv == 0) {   // exclusive scan of the 256 bins: four per lane
+                uint32_t v[4], sum = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] = hist[lane * 4 + q]; sum += v[q]; }
+                uint32_t inc = sum;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(inc, d);
+                    if ((int)lane >= d) inc += y;
+                }
+                uint32_t run = inc - sum;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { offs[lane * 4 + q] = run; run += v[q]; }
+                if (lane == 63) offs[PF2_NB] = inc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t q = 0; q < PF2_TILES; ++q)
+#pragma unroll
+                for (uint32_t u = 0; u < PF2_GROUP; ++u)
+                    if (rank[q][u] != EMPTY32)
+                        sorted[offs[pk[q][u] >> (32 - PF2_NB_LOG2)] + rank[q][u]] = ((unsigned long long)(uint32_t)((t0 + q) * 64 + lane) << 32) | pk[q][u];
+            __syncthreads();
+            const uint32_t n_pairs = offs[PF2_NB];
+            for (uint32_t i = tid; i < PF2_NB; i += NT) hist2[(flip ^ 1u) * PF2_NB + i] = 0;          // the next group's histogram
+            for (uint32_t i0 = 0; i0 < n_pairs; i0 += NT) {         // (whole waves stay in the loop: ballots and shuffles below)
+                const uint32_t i = i0 + tid;
+                const bool valid = i < n_pairs;
+                const unsigned long long pr = valid ? sorted[i] : 0ull;
+                const uint32_t b = (uint32_t)pr >> (32 - PF2_NB_LOG2);
+                const uint32_t at = valid ? written[b] + (i - offs[b]) : 0u;
+                const bool spill = valid && at >= Q.cap;
+                if (valid && !spill) part(b)[at] = pr;
+                // a part that is full (degenerate inputs): probe on the spot
+                const unsigned long long sb = __ballot(spill);
+                if (sb) {
+                    const bool c = pf_test_pair(Q, (uint32_t)pr, (uint32_t)(pr >> 32), spill);
+                    const unsigned long long bal = __ballot(c);
+                    if (bal) {
+                        uint32_t gb = 0;
+                        if (lane == 0) gb = atomicAdd(P.n_cand, (uint32_t)__popcll(bal));
+                        gb = __shfl(gb, 0);
+                        if (c) P.cand[gb + __popcll(bal & lt)] = (uint32_t)(pr >> 32);
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < PF2_NB; i += NT) {
+                const uint32_t w = written[i] + hist[i];
+                written[i] = w < Q.cap ? w : Q.cap;
+            }
+            flip ^= 1u;
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < PF2_NB; i += NT) Q.count[(size_t)i * Q.n_writers + writer] = written[i];
+}
+
+// pass B of the 256-bucket form: one workgroup per bucket at a time; the bucket's slice of the level-1 bitmap lives in LDS.
+// Pairs that pass both bits (~1 %: false positives of the two-bit test + the true hits) are queued per wave and their exact-set
+// look-ups run 64 at a time — done on the spot, one or two busy lanes made the whole wave wait for a global round trip in 40 % of
+// the 64-pair steps (1.67 ms per 112.5 M reads; queued: see DESIGN.md).
+constexpr uint32_t PF2_PEND = 128;   // per wave: < 64 waiting + <= 64 from one step
+__global__ __launch_bounds__(1024) void pf2_probe_kernel(PartParams Q) {
+    extern __shared__ uint32_t sm[];   // [slice of the level-1 bitmap: 2^(bm_log2 - 8) bits][per wave: WOBUF candidates | PF2_PEND pairs]
+    const FilterParams& P = Q.F;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t slice_words = 1u << (P.bm_log2 - PF2_NB_LOG2 - 5);
+    const uint32_t sh_bm = 32 - P.bm_log2;
+    uint32_t* obuf = sm + slice_words + wv * (WOBUF + 2 * PF2_PEND);
+    unsigned long long* pend = reinterpret_cast<unsigned long long*>(obuf + WOBUF);
+    uint32_t obuf_n = 0, pend_n = 0;   // wave-uniform
+    const unsigned long long lt = (1ull << lane) - 1;
+    auto flush = [&]() {
+        uint32_t gb = 0;
+        if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
+        gb = __shfl(gb, 0);
+        for (uint32_t q = lane; q < obuf_n; q += 64) P.cand[gb + q] = obuf[q];
+        obuf_n = 0;
+        wave_lds_sync();
+    };
+    // exact-set look-up of the last min(64, pend_n) queued pairs, one per lane; first hit of a read becomes a candidate
+    auto settle = [&]() {
+        const uint32_t base = pend_n > 64 ? pend_n - 64 : 0;
+        bool cand = false;
+        uint32_t read = 0;
+        if (base + lane < pend_n) {
+            const unsigned long long pr = pend[base + lane];
+            const uint32_t key = (uint32_t)pr * S16_MUL_INV;
+            read = (uint32_t)(pr >> 32);
+            if (sset_walk(P, key, hash_s16_set(key, P.s_log2))) {
+                const uint32_t bit = 1u << (read & 31);
+                cand = !(atomicOr(&Q.seen[read >> 5], bit) & bit);
+            }
+        }
+        pend_n = base;
+        const unsigned long long bal = __ballot(cand);
+        if (bal) {
+            if (obuf_n + (uint32_t)__popcll(bal) > WOBUF) flush();
+            if (cand) obuf[obuf_n + __popcll(bal & lt)] = read;
+            obuf_n += (uint32_t)__popcll(bal);
+            wave_lds_sync();
+            if (obuf_n >= 32) flush();
+        }
+        wave_lds_sync();
+    };
+    for (uint32_t b = blockIdx.x; b < PF2_NB; b += gridDim.x) {
+        __syncthreads();
+        for (uint32_t i = tid * 4; i < slice_words; i += 1024 * 4)
+            *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap + (size_t)b * slice_words + i);
+        __syncthreads();
+        for (uint32_t w = wv; w < Q.n_writers; w += 16) {
+            const uint32_t n = Q.count[(size_t)b * Q.n_writers + w];
+            const unsigned long long* src = Q.pairs + ((size_t)b * Q.n_writers + w) * Q.cap;
+            constexpr int PB = 8;
+            unsigned long long nx[PB];
+            auto fetch = [&](uint32_t i0) {
+#pragma unroll
+                for (int u = 0; u < PB; ++u) nx[u] = i0 + u * 64 + lane < n ? src[i0 + u * 64 + lane] : 0ull;
+            };
+            fetch(0);
+            for (uint32_t i0 = 0; i0 < n; i0 += PB * 64) {
+                unsigned long long pr[PB];
+#pragma unroll
+                for (int u = 0; u < PB; ++u) pr[u] = nx[u];
+                if (i0 + PB * 64 < n) fetch(i0 + PB * 64);
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const uint32_t pk = (uint32_t)pr[u];
+                    bool pass = false;
+                    if (i0 + u * 64 + lane < n) {
+                        const uint32_t h = pk >> sh_bm;                       // bit index in the whole bitmap; its top 8 bits = b
+                        const uint32_t wd = sm[(h >> 5) & (slice_words - 1)];
+                        pass = (wd >> (h & 31)) & (wd >> (pk & 31)) & 1u;      // both bits of the key in its word
+                    }
+                    const unsigned long long bal = __ballot(pass);
+                    if (bal) {
+                        if (pass) pend[pend_n + __popcll(bal & lt)] = pr[u];
+                        pend_n += (uint32_t)__popcll(bal);                    // < 64 + 64 <= PF2_PEND
+                        wave_lds_sync();
+                        if (pend_n >= 64) settle();
+                    }
+                }
+            }
+        }
+    }
+    while (pend_n) settle();
+    if (obuf_n) flush();
+}
+
 // Loads of the pipelined kernel are issued through inline asm and awaited with explicit s_waitcnt: the compiler's own
 // counter bookkeeping falls back to vmcnt(0) for loop-carried loads, which would drain the pipeline every step.  vmcnt
 // counts vector-memory operations in issue order, so "wait until at most N are outstanding" is safe whenever at least N
@@ -1444,7 +1681,35 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + w_nw - 1) / w_nw, ctx->n_cu)), dim3((unsigned)(w_nw * 64)),
                            w_bm_bytes + w_nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
-    } else if (ctx->screen_variant == 14 || (ctx->screen_variant == 0 && ix.bm_log2 >= 27 && n_reads >= (1u << 20) && rb <= 64)) {
+    } else if ((ctx->screen_variant == 15 || (ctx->screen_variant == 0 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
+               ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) + (size_t)PF2_BATCH * 2 + 4 * PF2_NB + 8) * 4 <= 156 * 1024) {   // (reads up to ~180 bases)
+        // partitioned filter, 256 buckets: a bucket's slice of the level-1 bitmap itself fits the LDS of pass B (see pf2_scatter_kernel)
+        PartParams Q;
+        Q.F = F;
+        Q.diag = 0;
+        Q.nb_log2 = PF2_NB_LOG2;
+        const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;
+        const size_t tiles64 = (n_reads + 63) / 64;
+        const size_t tiles_wg = (size_t)PF2_WAVES * PF2_TILES;      // tiles per workgroup and iteration
+        const size_t lds_a = (tiles_wg * slice_words + (size_t)PF2_BATCH * 2 + 4 * PF2_NB + 8) * 4;
+        const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>(16 / PF2_WAVES, (160 * 1024 - 2048) / lds_a));
+        Q.n_writers = (uint32_t)std::min<size_t>((tiles64 + tiles_wg - 1) / tiles_wg, (size_t)ctx->n_cu * wg_per_cu);
+        const double pairs_w = (double)((tiles64 + (size_t)Q.n_writers * tiles_wg - 1) / ((size_t)Q.n_writers * tiles_wg)) * tiles_wg * 64.0 * F.np;
+        const double expect = pairs_w / PF2_NB;
+        Q.cap = ((uint32_t)(expect * 1.05 + 6.0 * std::sqrt(expect + 1.0) + 128.0) + 63u) & ~63u;
+        const size_t b_pairs = (size_t)PF2_NB * Q.n_writers * Q.cap * 8, b_cnt = ((size_t)PF2_NB * Q.n_writers * 4 + 255) & ~(size_t)255,
+                     b_seen = (((size_t)n_reads + 31) / 32 * 4 + 255) & ~(size_t)255;
+        if ((rc = ensure(ctx, ctx->part_ws, b_cnt + b_seen + b_pairs + 256))) return rc;
+        uint8_t* ws = (uint8_t*)ctx->part_ws.p;
+        Q.count = (uint32_t*)ws;
+        Q.seen = (uint32_t*)(ws + b_cnt);
+        Q.pairs = (unsigned long long*)(ws + b_cnt + b_seen);
+        GF_HIP(ctx, hipMemsetAsync(Q.seen, 0, b_seen, ctx->stream));
+        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
+        hipLaunchKernelGGL(pf2_scatter_kernel, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
+        const size_t lds_b = (((size_t)1 << (ix.bm_log2 - PF2_NB_LOG2 - 5)) + 16 * (WOBUF + 2 * PF2_PEND)) * 4;
+        hipLaunchKernelGGL(pf2_probe_kernel, dim3((unsigned)std::min<size_t>(PF2_NB, (size_t)ctx->n_cu)), dim3(1024), lds_b, ctx->stream, Q);
+    } else if (ctx->screen_variant == 14 || ctx->screen_variant == 15 || (ctx->screen_variant == 0 && ix.bm_log2 >= 27 && n_reads >= (1u << 20) && rb <= 64)) {
         // partitioned filter: the level-1 bitmap is far larger than an L2 (see pf_scatter_kernel)
         PartParams Q;
         Q.F = F;
@@ -1481,6 +1746,15 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         hipLaunchKernelGGL(screen_filter_kernel<9>, dim3(grid), dim3(256), TILE_READS * rb + 16, ctx->stream, F);
     }
     GF_HIP(ctx, hipGetLastError());
+    if (ctx->after_filter) {   // gf_stream_wait_after_filter: the peer's stream goes on once the filter pass above has finished
+        hipEvent_t ev;
+        GF_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->after_filter->stream, ev, 0);
+        (void)hipEventDestroy(ev);
+        ctx->after_filter = nullptr;
+        if (e != hipSuccess) return set_hip_error(ctx, e, "gf_stream_wait_after_filter");
+    }
 
     VerifyParams V;
     V.reads32 = (const uint32_t*)d_reads;

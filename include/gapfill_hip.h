@@ -94,6 +94,10 @@ int gf_sync(gf_ctx* ctx);
  * other: they are independent until the pools are built).  gf_stream_wait makes everything enqueued on `waiter` after
  * this call wait for everything enqueued on `producer` before it — no host synchronisation. */
 int gf_stream_wait(gf_ctx* waiter, gf_ctx* producer);
+/* One-shot: everything enqueued on `waiter` after the NEXT gf_screen_reads_dev call on `producer` waits until that call's FILTER pass
+ * has finished — not for its verification pass.  The filter owns every CU's LDS and most of the memory system, the verification pass
+ * is a latency-bound look-up kernel: a bandwidth-bound stream (the alignment tagger) overlaps the second, not the first. */
+int gf_stream_wait_after_filter(gf_ctx* waiter, gf_ctx* producer);
 /* options: "max_gaps_per_kmer" (0 = unlimited; flank k-mers shared by more gaps are dropped from the index),
  * "bitmap_log2" (size of the screen's level-1 16-mer bitmap, 0 = automatic), "index_host" (1: build the flank k-mer index with
  * the host comparator instead of the device kernels — same index up to slot order; a test aid, refused unless the environment

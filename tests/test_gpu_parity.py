@@ -99,14 +99,15 @@ def test_screen_and_tagger_synthetic(gf, seed, n_pairs, L, k):
     hits = gf.screen_reads(packed, L, k)
     exp = CO.screen_reads(c["reads_blob"], L, c["flanks"], k)
     assert _same(hits, exp) and len(exp) > 100
-    if L <= 250:      # the partitioned filter (packed reads up to 64 bytes) on the same reads, with a 2^27-bit bitmap
-        gf.set_option("screen_variant", 14)
-        gf.set_option("bitmap_log2", 27)
-        try:
-            assert _same(gf.screen_reads(packed, L, k), exp)
-        finally:
-            gf.set_option("screen_variant", 0)
-            gf.set_option("bitmap_log2", 0)
+    if L <= 250:      # the partitioned filters (packed reads up to 64 bytes) on the same reads, with a 2^27-bit bitmap:
+        for variant in (14, 15):      # 16 buckets with per-wave rows / 256 buckets with the workgroup sort
+            gf.set_option("screen_variant", variant)
+            gf.set_option("bitmap_log2", 27)
+            try:
+                assert _same(gf.screen_reads(packed, L, k), exp), variant
+            finally:
+                gf.set_option("screen_variant", 0)
+                gf.set_option("bitmap_log2", 0)
     for (IS, sd) in ((max(300, L + 100), 30), (5000, 500)):
         th = gf.tag_alignments(c["recs"], IS, sd)
         assert _same(th, CO.tag_alignments(c["recs"], c["gaps"], IS, sd))
@@ -330,6 +331,13 @@ def test_screen_filter_variants_agree(gf, variant):
         for bl in (16, 19, 22, 26, 28):  # 26: level-1 bitmap beyond the L2 -> the plain kernel also asks the 2^24-bit reduction;
             gf.set_option("bitmap_log2", bl)   # 28: the partitioned filter uses 16 buckets instead of 8
             assert _same(gf.screen_reads(packed, c["L"], 31), exp31), (variant, bl)
+        if variant == 14:      # the 256-bucket partitioned filter (variant 15) exists for 2^27- and 2^28-bit bitmaps
+            gf.set_option("screen_variant", 15)
+            for bl in (27, 28):
+                gf.set_option("bitmap_log2", bl)
+                for n in (len(packed), 1000, 769, 1):
+                    assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (15, bl, n)
+                assert _same(gf.screen_reads(packed, c["L"], 51), exp51), (15, bl)
     finally:
         gf.set_option("screen_variant", 0)
         gf.set_option("bitmap_log2", 0)
@@ -493,11 +501,15 @@ def test_partitioned_filter_probes_in_place_when_a_bucket_part_runs_full(gf):
     packed, _ = GapFill.pack_reads(blob, L)
     exp = CO.screen_reads(blob, L, flanks, 31)
     assert len(exp) > 60000
-    gf.set_option("screen_variant", 14)
     try:
+        gf.set_option("screen_variant", 14)
+        assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
+        gf.set_option("screen_variant", 15)        # 256 buckets: the same degenerate reads overflow a workgroup's part
+        gf.set_option("bitmap_log2", 27)
         assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
     finally:
         gf.set_option("screen_variant", 0)
+        gf.set_option("bitmap_log2", 0)
 
 
 def test_human_scale_key_set_all_filter_kernels_agree_on_20M_reads(gf):
@@ -519,12 +531,12 @@ def test_human_scale_key_set_all_filter_kernels_agree_on_20M_reads(gf):
     packed = d_reads[:2 * n_pairs * rb].cpu().numpy().reshape(-1, rb)
     res = {}
     try:
-        for variant in (0, 14, 9):
+        for variant in (0, 14, 15, 9):
             gf.set_option("screen_variant", variant)
             res[variant] = gf.screen_reads(packed, L, k, cap=1 << 20)
     finally:
         gf.set_option("screen_variant", 0)
-    assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[9])
+    assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[15]) and _same(res[0], res[9])
     m = 400_000
     exp = CO.screen_reads(CO.unpack_reads(packed[:m], L), L, flanks, k)
     head = res[0][res[0]["read"] < m]
