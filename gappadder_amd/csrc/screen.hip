@@ -580,6 +580,43 @@ __global__ __launch_bounds__(1024) void pf_probe_kernel(PartParams Q) {
     if (obuf_n) flush();
 }
 
+// Loads of the pipelined kernel are issued through inline asm and awaited with explicit s_waitcnt: the compiler's own
+// counter bookkeeping falls back to vmcnt(0) for loop-carried loads, which would drain the pipeline every step.  vmcnt
+// counts vector-memory operations in issue order, so "wait until at most N are outstanding" is safe whenever at least N
+// operations were issued after the awaited one; every step therefore issues the same number of loads (idle slots read a
+// dummy address), and anything the compiler issues on its own only makes a wait longer, never shorter.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// global loads with a scalar base and a 32-bit per-lane byte offset
+__device__ __forceinline__ void vm_load128(u32x4& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void vm_load128_nt(u32x4& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(d) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void vm_load128_sc1(u32x4& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(d) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void vm_load128_sc01nt(u32x4& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1 nt" : "=v"(d) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void vm_load32(uint32_t& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase));
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// after a wait: uses of x are ordered behind it
+__device__ __forceinline__ void vm_ready(uint32_t& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void vm_ready(u32x4& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));   // the builtin returns int
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    // VALU write of an SGPR -> VMEM read of it needs 5 wait states; the hazard recogniser does not look into inline asm
+    uint32_t hi2 = hi;
+    asm volatile("s_nop 4" : "+s"(hi2), "+s"(lo));
+    return (const void*)(((uint64_t)hi2 << 32) | lo);
+}
+
 // ---- partitioned filter, second form: 256 buckets, so that a bucket's slice of the LEVEL-1 bitmap itself (2^bm_log2 / 256 bits:
 // 128 KiB at 2^28) is what pass B holds in LDS — both bits of a key are tested without leaving the CU, and only the ~1 % that pass
 // go on to the exact set.  The 16-bucket form above stops 52 % of the pairs in LDS and sends the rest to the L2 at its random-request
@@ -591,50 +628,73 @@ constexpr uint32_t PF2_NB_LOG2 = 8, PF2_NB = 1u << PF2_NB_LOG2;
 constexpr uint32_t PF2_WAVES = 16, PF2_GROUP = 4;                       // waves per workgroup; probes sorted per iteration and read
 constexpr uint32_t PF2_TILES = 2;                                      // 64-read tiles per wave and iteration
 constexpr uint32_t PF2_BATCH = PF2_WAVES * PF2_TILES * 64 * PF2_GROUP; // 8192 pairs = 64 KiB
+static_assert(PF2_WAVES > PF2_NB / 64, "waves 1..4 keep the parts' fill while wave 0 scans");
 // Measured on 112.5 M reads, k=51 (2^28-bit bitmap): 16 waves x 1 tile 2.47 ms, 16 x 2 tiles + alternating histograms 2.22 ms (longer
 // runs per bucket: 32 pairs = 256 B); 8 waves x 2 tiles with the sort buffer overlaid on the tiles, three workgroups per CU: 2.68 ms
 // (128-B runs, three times the parts); 16 x 3 tiles overlaid: 5.6 ms (36 scrambled keys per lane in registers spill).
 
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams Q, uint32_t slice_words) {
-    extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][sorted pairs: PF2_BATCH x 8 B][hist 2 x 256][offs 257][written 256]
+    extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][sorted pairs: PF2_BATCH x 8 B][hist 3 x 256][offs 257 (+1)][written 2 x 256]
     const FilterParams& P = Q.F;
     constexpr uint32_t NT = 64 * PF2_WAVES;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t* tiles = sm + wv * PF2_TILES * slice_words;
     unsigned long long* sorted = reinterpret_cast<unsigned long long*>(sm + PF2_WAVES * PF2_TILES * slice_words);
-    uint32_t* hist2 = reinterpret_cast<uint32_t*>(sorted + PF2_BATCH);   // two histograms, used alternately: the idle one is zeroed
-    uint32_t* offs = hist2 + 2 * PF2_NB;                                 // during the copy-out (one barrier less per group)
-    uint32_t* written = offs + PF2_NB + 1;
+    // three histograms in rotation (the one of the group after next is zeroed during a copy-out) and two `written` arrays used
+    // alternately: a group costs three barriers (count | scan | place), the copy-out runs into the next group's counting
+    uint32_t* hist3 = reinterpret_cast<uint32_t*>(sorted + PF2_BATCH);
+    uint32_t* offs = hist3 + 3 * PF2_NB;
+    uint32_t* written2 = offs + PF2_NB + 2;
     const uint32_t writer = blockIdx.x;
     const uint32_t tile_bytes = 64 * P.rb;
     const uint64_t total_bytes = P.n_reads * P.rb;
     const uint64_t n_tiles = (P.n_reads + 63) / 64;
     const unsigned long long lt = (1ull << lane) - 1;
     auto part = [&](uint32_t b) { return Q.pairs + ((size_t)b * Q.n_writers + writer) * Q.cap; };
-    for (uint32_t i = tid; i < PF2_NB; i += NT) { written[i] = 0; hist2[i] = 0; hist2[PF2_NB + i] = 0; }
+    unsigned long long* dummy = Q.pairs + (size_t)PF2_NB * Q.n_writers * Q.cap;   // 64 x 8 bytes behind the parts
+    for (uint32_t i = tid; i < PF2_NB; i += NT) { written2[i] = 0; hist3[i] = 0; hist3[PF2_NB + i] = 0; hist3[2 * PF2_NB + i] = 0; }
+    // The tile loads and the copy-out stores go through inline asm with counted waits: stores share vmcnt with loads on gfx9, and
+    // the compiler, unable to count the stores of a loop, drains them all (vmcnt(0)) before it touches the prefetched tile — the
+    // stores of a group then never overlap the next group's counting (measured: 2.35 ms with, 1.34 ms without the stores).
+    // Every wave issues exactly NPF * PF2_TILES loads per prefetch and one store per copy-out trip (idle lanes and idle
+    // tiles use a dummy address), so "the loads are done" = "at most <stores issued since> operations outstanding".
     constexpr int NPF = 4;   // 64 reads x <= 64 B
-    uint4 pf[PF2_TILES][NPF];
+    u32x4 pf[PF2_TILES][NPF];
     auto prefetch = [&](uint64_t t0) {
 #pragma unroll
         for (uint32_t q = 0; q < PF2_TILES; ++q) {
             const uint64_t t = t0 + q;
-            if (t >= n_tiles) continue;
-            const uint64_t byte0 = t * tile_bytes;
-            const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+            const bool on = t < n_tiles;
+            const uint64_t byte0 = on ? t * tile_bytes : 0;
+            const uint32_t nbytes = on ? (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes) : 0u;
+            const void* base = uniform_ptr(nbytes >= 16 ? (const void*)(P.reads + byte0) : (const void*)Q.count);   // (idle: 16 bytes of the workspace)
 #pragma unroll
             for (int c = 0; c < NPF; ++c) {
                 const uint32_t i = lane + c * 64;
-                pf[q][c] = i < (nbytes >> 4) ? *reinterpret_cast<const uint4*>(P.reads + byte0 + (uint64_t)i * 16) : make_uint4(0, 0, 0, 0);
+                vm_load128(pf[q][c], i < (nbytes >> 4) ? i * 16 : 0u, base);   // (nt: 2.32 against 2.25 ms)
             }
         }
     };
     const uint64_t t_step = (uint64_t)gridDim.x * PF2_WAVES * PF2_TILES;
     const uint64_t n_iter = (n_tiles + t_step - 1) / t_step;
     prefetch(((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES);
-    uint32_t flip = 0;
+    uint32_t hsel = 0, wsel = 0;
+    uint32_t stores_since = 0;   // copy-out stores this wave has issued since its last prefetch (wave-uniform)
     __syncthreads();
     for (uint64_t it = 0; it < n_iter; ++it) {
         const uint64_t t0 = it * t_step + ((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES;
+        // this tile's loads were issued before the previous iteration's copy-out stores: those may stay in flight
+        switch (stores_since < 12u ? stores_since : 12u) {
+            case 0: vm_wait<0>(); break;   case 1: vm_wait<1>(); break;   case 2: vm_wait<2>(); break;   case 3: vm_wait<3>(); break;
+            case 4: vm_wait<4>(); break;   case 5: vm_wait<5>(); break;   case 6: vm_wait<6>(); break;   case 7: vm_wait<7>(); break;
+            case 8: vm_wait<8>(); break;   case 9: vm_wait<9>(); break;   case 10: vm_wait<10>(); break; case 11: vm_wait<11>(); break;
+            default: vm_wait<12>(); break;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < PF2_TILES; ++q)
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) vm_ready(pf[q][c]);
+        stores_since = 0;
 #pragma unroll
         for (uint32_t q = 0; q < PF2_TILES; ++q) {
             const uint64_t t = t0 + q;
@@ -646,7 +706,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams 
 #pragma unroll
             for (int c = 0; c < NPF; ++c) {
                 const uint32_t i = lane + c * 64;
-                if (i < (n16 >> 4)) *reinterpret_cast<uint4*>(tb + (uint64_t)i * 16) = pf[q][c];
+                if (i < (n16 >> 4)) *reinterpret_cast<u32x4*>(tb + (uint64_t)i * 16) = pf[q][c];
             }
             for (uint32_t i = n16 + lane; i < nbytes; i += 64) tb[i] = P.reads[byte0 + i];
             if (lane < 16) tb[nbytes + lane] = 0;
@@ -655,7 +715,8 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams 
         prefetch(t0 + t_step);
         const uint32_t bit0 = lane * P.rb * 8;
         for (uint32_t j0 = 0; j0 < P.np; j0 += PF2_GROUP) {
-            uint32_t* hist = hist2 + flip * PF2_NB;        // all zero (start / zeroed during the previous copy-out)
+            uint32_t* hist = hist3 + hsel * PF2_NB;        // all zero (start / zeroed during the copy-out before last)
+            const uint32_t* written = written2 + wsel * PF2_NB;
             uint32_t pk[PF2_TILES][PF2_GROUP], rank[PF2_TILES][PF2_GROUP];
 #pragma unroll
             for (uint32_t q = 0; q < PF2_TILES; ++q) {
@@ -681,6 +742,10 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { offs[lane * 4 + q] = run; run += v[q]; }
                 if (lane == 63) offs[PF2_NB] = inc;
+            } else if (wv <= PF2_NB / 64) {   // the parts' fill after this group
+                const uint32_t i = tid - 64;
+                const uint32_t w = written[i] + hist[i];
+                written2[(wsel ^ 1u) * PF2_NB + i] = w < Q.cap ? w : Q.cap;
             }
             __syncthreads();
 #pragma unroll
@@ -691,7 +756,8 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams 
                         sorted[offs[pk[q][u] >> (32 - PF2_NB_LOG2)] + rank[q][u]] = ((unsigned long long)(uint32_t)((t0 + q) * 64 + lane) << 32) | pk[q][u];
             __syncthreads();
             const uint32_t n_pairs = offs[PF2_NB];
-            for (uint32_t i = tid; i < PF2_NB; i += NT) hist2[(flip ^ 1u) * PF2_NB + i] = 0;          // the next group's histogram
+            const uint32_t hz = hsel == 0 ? 2 : hsel - 1;
+            for (uint32_t i = tid; i < PF2_NB; i += NT) hist3[hz * PF2_NB + i] = 0;                  // the histogram of the group after next
             for (uint32_t i0 = 0; i0 < n_pairs; i0 += NT) {         // (whole waves stay in the loop: ballots and shuffles below)
                 const uint32_t i = i0 + tid;
                 const bool valid = i < n_pairs;
@@ -699,7 +765,11 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams 
                 const uint32_t b = (uint32_t)pr >> (32 - PF2_NB_LOG2);
                 const uint32_t at = valid ? written[b] + (i - offs[b]) : 0u;
                 const bool spill = valid && at >= Q.cap;
-                if (valid && !spill) part(b)[at] = pr;
+                {   // one store per wave and trip, whatever the lanes hold (idle lanes: their own 8 bytes of the dummy line)
+                    unsigned long long* dst = (valid && !spill && !(Q.diag & 16)) ? part(b) + at : dummy + lane;
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(pr) : "memory");
+                    ++stores_since;
+                }
                 // a part that is full (degenerate inputs): probe on the spot
                 const unsigned long long sb = __ballot(spill);
                 if (sb) {
@@ -713,16 +783,12 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams 
                     }
                 }
             }
-            __syncthreads();
-            for (uint32_t i = tid; i < PF2_NB; i += NT) {
-                const uint32_t w = written[i] + hist[i];
-                written[i] = w < Q.cap ? w : Q.cap;
-            }
-            flip ^= 1u;
-            __syncthreads();
+            hsel = hsel == 2 ? 0 : hsel + 1;
+            wsel ^= 1u;
         }
     }
-    for (uint32_t i = tid; i < PF2_NB; i += NT) Q.count[(size_t)i * Q.n_writers + writer] = written[i];
+    vm_wait<0>();   // the last prefetch (idle tiles) still targets this wave's registers
+    for (uint32_t i = tid; i < PF2_NB; i += NT) Q.count[(size_t)i * Q.n_writers + writer] = written2[wsel * PF2_NB + i];
 }
 
 // pass B of the 256-bucket form: one workgroup per bucket at a time; the bucket's slice of the level-1 bitmap lives in LDS.
@@ -815,40 +881,6 @@ __global__ __launch_bounds__(1024) void pf2_probe_kernel(PartParams Q) {
     }
     while (pend_n) settle();
     if (obuf_n) flush();
-}
-
-// Loads of the pipelined kernel are issued through inline asm and awaited with explicit s_waitcnt: the compiler's own
-// counter bookkeeping falls back to vmcnt(0) for loop-carried loads, which would drain the pipeline every step.  vmcnt
-// counts vector-memory operations in issue order, so "wait until at most N are outstanding" is safe whenever at least N
-// operations were issued after the awaited one; every step therefore issues the same number of loads (idle slots read a
-// dummy address), and anything the compiler issues on its own only makes a wait longer, never shorter.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// global loads with a scalar base and a 32-bit per-lane byte offset
-__device__ __forceinline__ void vm_load128(u32x4& d, uint32_t voff, const void* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase));
-}
-__device__ __forceinline__ void vm_load128_nt(u32x4& d, uint32_t voff, const void* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(d) : "v"(voff), "s"(sbase));
-}
-__device__ __forceinline__ void vm_load128_sc1(u32x4& d, uint32_t voff, const void* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(d) : "v"(voff), "s"(sbase));
-}
-__device__ __forceinline__ void vm_load128_sc01nt(u32x4& d, uint32_t voff, const void* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1 nt" : "=v"(d) : "v"(voff), "s"(sbase));
-}
-__device__ __forceinline__ void vm_load32(uint32_t& d, uint32_t voff, const void* sbase) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase));
-}
-template <int N>
-__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// after a wait: uses of x are ordered behind it
-__device__ __forceinline__ void vm_ready(uint32_t& x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void vm_ready(u32x4& x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ const void* uniform_ptr(const void* p) {
-    const uint64_t v = (uint64_t)p;
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));   // the builtin returns int
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
-    return (const void*)(((uint64_t)hi << 32) | lo);
 }
 
 template <int NP>
@@ -1682,16 +1714,16 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + w_nw - 1) / w_nw, ctx->n_cu)), dim3((unsigned)(w_nw * 64)),
                            w_bm_bytes + w_nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
     } else if ((ctx->screen_variant == 15 || (ctx->screen_variant == 0 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
-               ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) + (size_t)PF2_BATCH * 2 + 4 * PF2_NB + 8) * 4 <= 156 * 1024) {   // (reads up to ~180 bases)
+               ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) + (size_t)PF2_BATCH * 2 + 6 * PF2_NB + 8) * 4 <= 156 * 1024) {   // (reads up to ~180 bases)
         // partitioned filter, 256 buckets: a bucket's slice of the level-1 bitmap itself fits the LDS of pass B (see pf2_scatter_kernel)
         PartParams Q;
         Q.F = F;
-        Q.diag = 0;
+        Q.diag = (uint32_t)ctx->screen_pf_diag;
         Q.nb_log2 = PF2_NB_LOG2;
         const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;
         const size_t tiles64 = (n_reads + 63) / 64;
         const size_t tiles_wg = (size_t)PF2_WAVES * PF2_TILES;      // tiles per workgroup and iteration
-        const size_t lds_a = (tiles_wg * slice_words + (size_t)PF2_BATCH * 2 + 4 * PF2_NB + 8) * 4;
+        const size_t lds_a = (tiles_wg * slice_words + (size_t)PF2_BATCH * 2 + 6 * PF2_NB + 8) * 4;
         const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>(16 / PF2_WAVES, (160 * 1024 - 2048) / lds_a));
         Q.n_writers = (uint32_t)std::min<size_t>((tiles64 + tiles_wg - 1) / tiles_wg, (size_t)ctx->n_cu * wg_per_cu);
         const double pairs_w = (double)((tiles64 + (size_t)Q.n_writers * tiles_wg - 1) / ((size_t)Q.n_writers * tiles_wg)) * tiles_wg * 64.0 * F.np;
@@ -1699,7 +1731,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.cap = ((uint32_t)(expect * 1.05 + 6.0 * std::sqrt(expect + 1.0) + 128.0) + 63u) & ~63u;
         const size_t b_pairs = (size_t)PF2_NB * Q.n_writers * Q.cap * 8, b_cnt = ((size_t)PF2_NB * Q.n_writers * 4 + 255) & ~(size_t)255,
                      b_seen = (((size_t)n_reads + 31) / 32 * 4 + 255) & ~(size_t)255;
-        if ((rc = ensure(ctx, ctx->part_ws, b_cnt + b_seen + b_pairs + 256))) return rc;
+        if ((rc = ensure(ctx, ctx->part_ws, b_cnt + b_seen + b_pairs + 1024))) return rc;
         uint8_t* ws = (uint8_t*)ctx->part_ws.p;
         Q.count = (uint32_t*)ws;
         Q.seen = (uint32_t*)(ws + b_cnt);
