@@ -395,7 +395,7 @@ def run(args):
 
     d_dbg = None
     if os.environ.get("GF_BENCH_ASM_PROBE"):      # diagnostic (needs GF_DIAGNOSTICS=1): per-gap phase stamps of the LAST assembly launch
-        d_dbg = torch.zeros(n_gaps * 8, dtype=torch.int64, device=dev)
+        d_dbg = torch.zeros(n_gaps * 16, dtype=torch.int64, device=dev)
         gf.set_option("asm_dbg_ptr", d_dbg.data_ptr())
     run_steps(args.warmup)
     barrier()
@@ -420,7 +420,7 @@ def run(args):
     step_s = dt / args.steps
 
     if d_dbg is not None:
-        d = d_dbg.cpu().numpy().reshape(-1, 8)
+        d = d_dbg.cpu().numpy().reshape(-1, 16)
         d = d[d[:, 6] > 0]
         ph = np.diff(d[:, [0, 1, 2, 3, 4, 7, 5, 6]], axis=1) / 100.0
         names = ["P1 count", "P2 survivors", "P3 graph+index", "P4 links", "error removal", "ranking", "emission"]

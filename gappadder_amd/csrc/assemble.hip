@@ -50,7 +50,9 @@ struct AsmParams {
     uint32_t lds_words;        // dynamic LDS given to the staged pool
     uint32_t* next_gap;        // work counter, zero at launch
     uint32_t keyslot;          // allow the key-in-slot count phase
-    unsigned long long* dbg;   // diagnostic builds only: 8 wall-clock stamps per gap (100 MHz), or null
+    uint32_t diag;             // timing experiments (wrong results)
+    uint32_t precount;         // allow the bit-array pre-count (k-mers seen fewer than min_count times never enter the table)
+    unsigned long long* dbg;   // diagnostic runs only: 16 wall-clock stamps per gap (100 MHz), or null
 };
 
 // gap_error bits
@@ -166,12 +168,30 @@ __device__ __forceinline__ K128 canonical_w(K128 f, int len) {
     return r;
 }
 
-__device__ __forceinline__ uint32_t slot_of(K128 key, uint32_t cap) {
+__device__ __forceinline__ uint64_t hash_of(K128 key) {
     uint64_t x = key.hi ^ (key.lo * 0x9E3779B97F4A7C15ull) ^ (key.lo >> 29);
     x ^= x >> 31;
     x *= 0xD6E8FEB86659FD93ull;
     x ^= x >> 32;
-    return (uint32_t)(((x & 0xFFFFFFFFull) * cap) >> 32);
+    return x;
+}
+__device__ __forceinline__ uint32_t slot_of_hash(uint64_t x, uint32_t cap) { return (uint32_t)(((x & 0xFFFFFFFFull) * cap) >> 32); }
+__device__ __forceinline__ uint32_t slot_of(K128 key, uint32_t cap) { return slot_of_hash(hash_of(key), cap); }
+// bit of a k-mer in the pre-count bit arrays (2^bits_log2 bits): the hash's high word mixed once more, so that k-mers which share
+// a bit do not also share their table neighbourhood (slot = low word) or their fingerprint (bits 34..63)
+// hash of the count phase (internal to it: slot from the low word, fingerprint and pre-count bit from the high word): six 32-bit
+// multiplies where hash_of spends three 64-bit ones (twelve quarter-rate instructions) — the phase is issue-bound
+template <bool W>
+__device__ __forceinline__ uint64_t hash_p1(K128 key) {
+    const uint32_t a = (uint32_t)(key.hi >> 32), b = (uint32_t)key.hi;
+    const uint32_t c = W ? (uint32_t)(key.lo >> 32) : a, d = W ? (uint32_t)key.lo : b;
+    const uint32_t u = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u);
+    const uint32_t v = (c * 0xC2B2AE3Du) ^ (d * 0x27D4EB2Fu);
+    uint32_t h1 = u ^ ((v << 15) | (v >> 17));
+    h1 ^= h1 >> 15; h1 *= 0x2C1B3C6Du; h1 ^= h1 >> 12;
+    uint32_t h2 = v ^ ((u << 13) | (u >> 19));
+    h2 ^= h2 >> 16; h2 *= 0x297A2D39u; h2 ^= h2 >> 15;
+    return ((uint64_t)h2 << 32) | h1;
 }
 
 __device__ __forceinline__ uint32_t* slot_id(unsigned long long* t, uint32_t s) { return reinterpret_cast<uint32_t*>(t + s); }
@@ -299,7 +319,7 @@ __device__ __forceinline__ void wg_phase_sync() {
     __syncthreads();
 }
 
-#define ASM_STAMP(n) do { if (P.dbg && tid == 0) P.dbg[(uint64_t)g * 8 + (n)] = wall_clock64(); } while (0)
+#define ASM_STAMP(n) do { if (P.dbg && tid == 0) P.dbg[(uint64_t)g * 16 + (n)] = wall_clock64(); } while (0)
 
 // LDS plan of one gap (dynamic LDS = P.lds_words words):  [ staged pool | region R ]
 //   count phase   R = k-mer table (8-B slots) when the distinct k-mers keep it under 3/4 full, else the global slice
@@ -389,13 +409,19 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         tab.g = gtab;
         bool keyslot = false, keyslot_w = false, fpslot_used = false;
         uint32_t* dist_inst = P.nodes + 3 * inst_off;   // key-slot mode: instance id of the q-th distinct k-mer
+        // Pre-count (min_count 2 or 3): one bit array per occurrence level in LDS; a k-mer's bit climbs one level per occurrence
+        // and only k-mers whose bit reached the last level are counted exactly afterwards.  At ~1 % read errors half of all
+        // windows are k-mers seen once — they never enter the table, which then fits the LDS at a low load (a shared bit only
+        // lets a k-mer through to the exact count: no k-mer is lost).  The last level sits at R, the table behind it; the lower
+        // levels are dead once the bits are up and lie under the table.
+        bool pre_built = false;
+        uint32_t pre_log2 = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool use_lds = attempt == 0 && r_words / 2 >= 1024;
             if (attempt == 0 && !use_lds) continue;
             tab.lds = use_lds;
             tab.off = R;
             tab.cap = use_lds ? r_words / 2 : gcap;
-            const uint32_t limit = use_lds ? tab.cap - tab.cap / 4 : 0xFFFFFFFFu;
             // Key-slot mode (k <= 31, min_count <= 3, assembly): a slot holds the 62-bit canonical key itself plus a 2-bit
             // saturating count in the spare low bits.  A repeat occurrence — most instances at
             // sequencing depth — costs one 8-byte read and a compare: no key re-derivation from the reads, and no atomic
@@ -415,9 +441,106 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             // with instance-id slots at k = 51.)
             const bool fpslot = wide_ok && use_lds && V.lds;
             fpslot_used = fpslot;
-            const uint32_t limit_k = limit;
             // an LDS attempt that is bound to overflow is skipped: at ~1 % errors nearly half of all windows are distinct
-            if (use_lds && (keyslot || wide_ok) && n_inst / 4 > limit) continue;
+            const uint32_t levels = P.min_count;
+            bool pre = P.precount && (keyslot || keyslot_w || fpslot) && levels >= 2 && levels <= 3;
+            // (an LDS table that holds every key of a k <= 31 pool is filled faster without: see count_keyslot_strided)
+            if (keyslot && use_lds && n_inst / 4 <= (r_words / 2) - (r_words / 2) / 4) pre = false;
+            if (pre && !pre_built) {   // 8 bits per window when they fit: half of the LDS region under an LDS table, all of it otherwise
+                uint32_t lg = 11;
+                while ((1u << lg) < 8 * n_inst && lg < 22) ++lg;
+                const uint32_t maxw = (use_lds ? r_words / 2 : r_words) / levels;
+                while (lg > 11 && (1u << (lg - 5)) > maxw) --lg;
+                pre = (1u << (lg - 5)) <= maxw;
+                pre_log2 = lg;
+            }
+            const uint32_t pre_words = pre ? 1u << (pre_log2 - 5) : 0u;
+            if (pre && use_lds) {
+                tab.off = R + pre_words;
+                tab.cap = (r_words - pre_words) / 2;
+            }
+            const uint32_t limit = use_lds ? tab.cap - tab.cap / 4 : 0xFFFFFFFFu;
+            const uint32_t limit_k = limit;
+            // (pre-counted: true k-mers + the few that share a bit; measured 3 000 of 66 000 windows at 30x, 1 % errors)
+            if (use_lds && (keyslot || wide_ok) && n_inst / (pre ? 12 : 4) > limit) continue;
+            auto pre_pass = [&](uint64_t x) -> bool {
+                const uint32_t b = (uint32_t)(x >> 32) >> (32 - pre_log2);
+                return (g_lds[R + (b >> 5)] >> (b & 31)) & 1u;
+            };
+            // ---- window generator of the three table modes below: a thread takes S consecutive windows of one read, derives the
+            //      first from the staged bytes (two unaligned fetches, byte swaps, a 128-bit reverse complement) and ROLLS the others:
+            //      one base shifted into the forward strand and its complement into the reverse strand.  (PMC before: 580 vector
+            //      instructions per window over the whole kernel, most of them this derivation — the count phase was issue-bound,
+            //      not table-bound.)  S is picked per gap so that the items fill whole rounds of the 1024 threads.
+            const bool rolled = keyslot || keyslot_w || fpslot;
+            uint32_t S = 8;
+            if (rolled) {
+                uint32_t best = 0xFFFFFFFFu;
+                for (uint32_t c = 6; c <= 16; ++c) {
+                    const uint32_t rounds = (n_r * ((npos + c - 1) / c) + ASM_THREADS - 1) / ASM_THREADS;
+                    const uint32_t cost = rounds * (c + 3);   // the first window of an item costs about three rolled ones
+                    if (cost < best) { best = cost; S = c; }
+                }
+            }
+            const uint32_t chunks = (npos + S - 1) / S, n_items = n_r * chunks;
+            // body(read, offset, canonical key, forward, reverse complement) -> true = call me again with the same window
+            auto for_windows = [&](auto&& body) {
+                const uint32_t dr = ASM_THREADS / chunks, dc = ASM_THREADS - dr * chunks;
+                uint32_t r = tid / chunks, c = tid - r * chunks;
+                for (uint32_t item = tid; item < n_items; item += ASM_THREADS, r += dr, c += dc) {
+                    if (c >= chunks) { c -= chunks; ++r; }
+                    if (use_lds && s_cnt[6]) break;
+                    uint32_t p = c * S;
+                    const uint32_t pe = p + S < npos ? p + S : npos;
+                    K128 fw = pv_kmer_at<W>(V, r, p, k);
+                    K128 rc = revcomp_w<W>(fw, k);
+                    uint32_t nxt = pv_stream32(V, (uint64_t)r * V.rb * 8 + 2ull * (p + P.k));   // the bases behind the window
+                    for (;;) {
+                        bool ok = true;
+                        if (P.nmask) {
+                            for (uint32_t q = p; q < p + P.k; ++q)
+                                if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { ok = false; break; }
+                        }
+                        if (ok) {
+                            const K128 key = rc < fw ? rc : fw;
+                            while (body(r, p, key, fw, rc)) {}
+                        }
+                        if (++p >= pe) break;
+                        const uint64_t b = nxt >> 30;
+                        nxt <<= 2;
+                        if (W) {   // k > 32: the new base lands in the low word
+                            const int sh = 128 - 2 * k;
+                            fw.hi = (fw.hi << 2) | (fw.lo >> 62);
+                            fw.lo = (fw.lo << 2) | (b << sh);
+                            rc.lo = ((rc.lo >> 2) | (rc.hi << 62)) & (~0ull << sh);
+                            rc.hi = (rc.hi >> 2) | ((3ull - b) << 62);
+                        } else {
+                            const int sh = 64 - 2 * k;
+                            fw.hi = (fw.hi << 2) | (b << sh);
+                            rc.hi = ((rc.hi >> 2) | ((3ull - b) << 62)) & (~0ull << sh);
+                        }
+                    }
+                }
+            };
+            if (pre && !pre_built) {
+                for (uint32_t i = tid; i < levels * pre_words; i += ASM_THREADS) g_lds[R + i] = 0;
+                __syncthreads();
+                uint32_t* fin = &g_lds[R];
+                uint32_t* up1 = fin + pre_words;
+                uint32_t* up2 = up1 + pre_words;
+                for_windows([&](uint32_t, uint32_t, const K128& key, const K128&, const K128&) -> bool {
+                    const uint32_t b = (uint32_t)(hash_p1<W>(key) >> 32) >> (32 - pre_log2);
+                    const uint32_t w = b >> 5, m = 1u << (b & 31);
+                    if (fin[w] & m) return false;                       // already up: most windows at sequencing depth
+                    if (!(atomicOr(&up1[w], m) & m)) return false;      // first occurrence
+                    if (levels == 3 && !(atomicOr(&up2[w], m) & m)) return false;
+                    atomicOr(&fin[w], m);
+                    return false;
+                });
+                __syncthreads();
+                ASM_STAMP(8);
+                pre_built = true;
+            }
 #ifndef GF_KS_COMPLEMENT_LDS
 #define GF_KS_COMPLEMENT_LDS 0
 #endif
@@ -429,10 +552,49 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const unsigned long long e = keyslot ? kempty : EMPTY64;   // (the wide variant keeps the EMPTY64 words)
                 for (uint32_t i = tid; i < tab.cap; i += ASM_THREADS) tab.store(i, e);
                 __syncthreads();
+                ASM_STAMP(9);
             }
             if (keyslot) {
                 // one instantiation per home of the table, so that every access compiles to ds_* or global_* without a branch
                 auto count_keyslot = [&](auto lds_c) {
+                constexpr bool LDS = decltype(lds_c)::value;
+                Tab t = tab;
+                t.lds = LDS;
+                for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128&, const K128&) -> bool {
+                    const unsigned long long keyhi = key.hi;
+                    const uint64_t x = hash_p1<W>(key);
+                    if (pre && !pre_pass(x)) return false;
+                    uint32_t sl = slot_of_hash(x, t.cap);
+                    // insert / count: every decision is confirmed by a CAS, whose result replaces the loaded value
+                    bool placed = false;
+                    for (uint32_t probes = 0; probes < t.cap; ++probes) {
+                        unsigned long long v = t.load(sl);
+                        if (v == kempty) {
+                            v = t.cas(sl, kempty, (keyhi | 1ull) ^ xm);
+                            if (v == kempty) {   // first occurrence
+                                const uint32_t q = atomicAdd(&s_cnt[4], 1u);
+                                if (q >= limit) s_cnt[6] = 1;
+                                if (q < n_unit) { list_a[q] = sl; dist_inst[q] = make_inst(r, p); }
+                                placed = true;
+                                break;
+                            }
+                        }
+                        if (((v ^ xm) & ~3ull) == keyhi) {
+                            while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment
+                                const unsigned long long o = t.cas(sl, v, ((v ^ xm) + 1) ^ xm);
+                                if (o == v) break;
+                                v = o;
+                            }
+                            placed = true;
+                            break;
+                        }
+                        sl = sl + 1 == t.cap ? 0 : sl + 1;
+                    }
+                    if (!placed) { if (LDS) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_KTABLE); }
+                    return false;
+                });
+                };
+                auto count_keyslot_strided = [&](auto lds_c) {
                 constexpr bool LDS = decltype(lds_c)::value;
                 Tab t = tab;
                 t.lds = LDS;
@@ -506,7 +668,11 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         if (ok[u]) upsert(kk[u], ss[u], vv[u], ii[u]);
                 }
                 };
-                if (use_lds) count_keyslot(std::true_type{}); else count_keyslot(std::false_type{});
+                // an LDS table holds every key of a k <= 31 pool that gets here: strided windows with two table probes in flight beat
+                // the rolled generator there (58 against 80 us per 320-read pool at k = 31); the global table is the other way round
+                if (use_lds && !pre) count_keyslot_strided(std::true_type{});
+                else if (use_lds) count_keyslot(std::true_type{});
+                else count_keyslot(std::false_type{});
             } else if (keyslot_w) {
                 // Wide key-slot: word 0 = key.hi, word 1 = ~(key.lo | count) (count in the >= 2 spare low bits of lo; the
                 // complement keeps data words apart from EMPTY64 and from the LOCK word, whose low two bits are 11).  A slot is
@@ -521,102 +687,79 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     if (LDS) __hip_atomic_store(t.l() + word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else __hip_atomic_store(t.g + word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 };
-                const uint32_t dr = ASM_THREADS / npos, dp = ASM_THREADS - dr * npos;
-                uint32_t r = tid / npos, p = tid - r * npos, inst_i = tid;
                 // A thread that meets a LOCKed slot does NOT spin: the owner's publishing stores sit on the exit path of the
                 // probe loop, which the SIMT control flow runs only after every lane of the wave has left that loop — a lane
-                // spinning inside it would wait for an owner in its own wave forever.  It leaves the probe loop and takes the
-                // same k-mer again in the next round of the outer loop, by which time an owner in its wave has published.
-                while (inst_i < n_inst) {
-                    if (LDS && s_cnt[6]) break;
-                    if (p >= npos) { p -= npos; ++r; }
+                // spinning inside it would wait for an owner in its own wave forever.  It leaves the probe loop and is called
+                // again with the same window, by which time an owner in its wave has published.
+                for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128&, const K128&) -> bool {
+                    const uint64_t x = hash_p1<W>(key);
+                    if (pre && !pre_pass(x)) return false;
                     const uint32_t inst = make_inst(r, p);
-                    bool bad = false;
-                    if (P.nmask) {
-                        for (uint32_t q = p; q < p + P.k; ++q)
-                            if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
-                    }
-                    bool placed = bad, retry = false;
-                    if (!bad) {
-                        const K128 key = canonical_w<true>(pv_kmer_at<true>(V, r, p, k), k);
-                        uint32_t sl = slot_of(key, wcap);
-                        for (uint32_t probes = 0; probes < wcap; ++probes) {
-                            // global table: both words of the slot in ONE 16-byte request (word 0 is in L2 before word 1 is
-                            // published, so a load that sees word 1 published sees word 0 too)
-                            unsigned long long b, a_pre = 0;
-                            bool a_valid = false;
-                            if (LDS) b = t.load(2 * sl + 1);
-                            else {   // sc0 sc1: from L2, like the atomics (the CU's L1 may hold the line as it was before a CAS)
-                                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-                                u64x2 q;
-                                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(t.g + 2 * sl) : "memory");
-                                a_pre = q.x; b = q.y;
-                                a_valid = true;
-                            }
-                            if (b == EMPTY64) {
-                                a_valid = false;   // b will come from the CAS: word 0 must be read again
-                                b = t.cas(2 * sl + 1, EMPTY64, LOCK);
-                                if (b == EMPTY64) {   // first occurrence: this thread owns the slot
-                                    put(2 * sl, key.hi);
-                                    // word 0 must be in place before word 1 says so.  LDS executes a wave's operations in order; a
-                                    // global store is acknowledged (vmcnt) once it is in L2, where every access of this table
-                                    // goes — a full agent-scope release (L2 write-back) here cost 5x the whole phase
-                                    if (LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                    put(2 * sl + 1, ~(key.lo | 1ull));
-                                    const uint32_t q = atomicAdd(&s_cnt[4], 1u);
-                                    if (q >= limit_k) s_cnt[6] = 1;
-                                    if (q < n_unit) { list_a[q] = sl; dist_inst[q] = inst; }
-                                    placed = true;
-                                    break;
-                                }
-                            }
-                            if (b == LOCK) { retry = true; break; }
-                            asm volatile("" ::: "memory");          // word 0 is read after word 1 was seen published
-                            const unsigned long long a = a_valid ? a_pre : t.load(2 * sl);
-                            if (a == key.hi && (~b & ~3ull) == key.lo) {
-                                while ((~b & 3ull) != 3ull) {   // saturating increment of the complemented count
-                                    const unsigned long long o = t.cas(2 * sl + 1, b, b - 1);
-                                    if (o == b) break;
-                                    b = o;
-                                }
+                    bool placed = false, retry = false;
+                    uint32_t sl = slot_of_hash(x, wcap);
+                    for (uint32_t probes = 0; probes < wcap; ++probes) {
+                        // global table: both words of the slot in ONE 16-byte request (word 0 is in L2 before word 1 is
+                        // published, so a load that sees word 1 published sees word 0 too)
+                        unsigned long long b, a_pre = 0;
+                        bool a_valid = false;
+                        if (LDS) b = t.load(2 * sl + 1);
+                        else {   // sc0 sc1: from L2, like the atomics (the CU's L1 may hold the line as it was before a CAS)
+                            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                            u64x2 q;
+                            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(t.g + 2 * sl) : "memory");
+                            a_pre = q.x; b = q.y;
+                            a_valid = true;
+                        }
+                        if (b == EMPTY64) {
+                            a_valid = false;   // b will come from the CAS: word 0 must be read again
+                            b = t.cas(2 * sl + 1, EMPTY64, LOCK);
+                            if (b == EMPTY64) {   // first occurrence: this thread owns the slot
+                                put(2 * sl, key.hi);
+                                // word 0 must be in place before word 1 says so.  LDS executes a wave's operations in order; a
+                                // global store is acknowledged (vmcnt) once it is in L2, where every access of this table
+                                // goes — a full agent-scope release (L2 write-back) here cost 5x the whole phase
+                                if (LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                put(2 * sl + 1, ~(key.lo | 1ull));
+                                const uint32_t q = atomicAdd(&s_cnt[4], 1u);
+                                if (q >= limit_k) s_cnt[6] = 1;
+                                if (q < n_unit) { list_a[q] = sl; dist_inst[q] = inst; }
                                 placed = true;
                                 break;
                             }
-                            sl = sl + 1 == wcap ? 0 : sl + 1;
                         }
+                        if (b == LOCK) { retry = true; break; }
+                        asm volatile("" ::: "memory");          // word 0 is read after word 1 was seen published
+                        const unsigned long long a = a_valid ? a_pre : t.load(2 * sl);
+                        if (a == key.hi && (~b & ~3ull) == key.lo) {
+                            while ((~b & 3ull) != 3ull) {   // saturating increment of the complemented count
+                                const unsigned long long o = t.cas(2 * sl + 1, b, b - 1);
+                                if (o == b) break;
+                                b = o;
+                            }
+                            placed = true;
+                            break;
+                        }
+                        sl = sl + 1 == wcap ? 0 : sl + 1;
                     }
-                    if (retry) continue;
+                    if (retry) return true;
                     if (!placed) { if (LDS) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_KTABLE); }
-                    inst_i += ASM_THREADS; r += dr; p += dp;
-                }
+                    return false;
+                });
                 };
                 if (use_lds) count_keyslot_wide(std::true_type{}); else count_keyslot_wide(std::false_type{});
             } else if (fpslot) {
-                const uint32_t dr = ASM_THREADS / npos, dp = ASM_THREADS - dr * npos;
-                uint32_t r = tid / npos, p = tid - r * npos;
-                for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS, r += dr, p += dp) {
-                    if (s_cnt[6]) break;
-                    if (p >= npos) { p -= npos; ++r; }
-                    if (P.nmask) {
-                        bool bad = false;
-                        for (uint32_t q = p; q < p + P.k; ++q)
-                            if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
-                        if (bad) continue;
-                    }
-                    const K128 fw = lds_window<true>(V.rb, r, p, k);
-                    const K128 rc = revcomp(fw, k);
-                    const K128 key = rc < fw ? rc : fw;
-                    uint64_t x = key.hi ^ (key.lo * 0x9E3779B97F4A7C15ull) ^ (key.lo >> 29);
-                    x ^= x >> 31;
-                    x *= 0xD6E8FEB86659FD93ull;
-                    x ^= x >> 32;
-                    uint32_t sl = (uint32_t)(((x & 0xFFFFFFFFull) * tab.cap) >> 32);
+                for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128& fw, const K128& rc) -> bool {
+                    const uint64_t x = hash_p1<W>(key);
+                    if (pre && !pre_pass(x)) return false;
+                    if (P.diag & 1) return false;
+                    uint32_t sl = slot_of_hash(x, tab.cap);
                     const unsigned long long fp = (x >> 34) << 32;                    // 30 bits, in place
                     const unsigned long long mine = (1ull << 62) | fp | make_inst(r, p);
                     bool placed = false;
                     for (uint32_t probes = 0; probes < tab.cap; ++probes) {
                         unsigned long long v = tab.load(sl);
+                        if ((P.diag & 4) && (uint32_t)v != EMPTY32) { placed = true; break; }
                         if ((uint32_t)v == EMPTY32) {
                             v = tab.cas(sl, EMPTY64, mine);
                             if (v == EMPTY64) {   // first occurrence
@@ -629,9 +772,9 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         }
                         if ((v & 0x3FFFFFFF00000000ull) == fp) {
                             const uint32_t oi = (uint32_t)v;
-                            const K128 ow = lds_window<true>(V.rb, oi >> INST_OFF_BITS, oi & INST_OFF_MASK, k);
+                            const K128 ow = (P.diag & 2) ? fw : lds_window<true>(V.rb, oi >> INST_OFF_BITS, oi & INST_OFF_MASK, k);
                             if (ow == fw || ow == rc) {   // the same canonical k-mer
-                                while ((v >> 62) != 3ull) {   // saturating increment
+                                while ((v >> 62) != 3ull && !(P.diag & 8)) {   // saturating increment
                                     const unsigned long long o = tab.cas(sl, v, v + (1ull << 62));
                                     if (o == v) break;
                                     v = o;
@@ -643,7 +786,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         sl = sl + 1 == tab.cap ? 0 : sl + 1;
                     }
                     if (!placed) s_cnt[6] = 1;
-                }
+                    return false;
+                });
             } else
             for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
                 if (use_lds && s_cnt[6]) break;
@@ -733,6 +877,9 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
         const uint32_t n_surv = s_cnt[0];
         ASM_STAMP(2);
+        if (P.dbg && tid == 0) {   // diagnostics: distinct k-mers counted exactly, table home, survivors, windows
+            P.dbg[(uint64_t)g * 16 + 10] = n_dist; P.dbg[(uint64_t)g * 16 + 11] = tab_global; P.dbg[(uint64_t)g * 16 + 12] = n_surv; P.dbg[(uint64_t)g * 16 + 13] = n_inst; P.dbg[(uint64_t)g * 16 + 14] = s_cnt[7]; P.dbg[(uint64_t)g * 16 + 15] = tab.cap;
+        }
 
         // ---- graph-phase memory: node table + 4 arrays + the unitig-ranking pairs.  Optimistic LDS plan first: room for `nb`
         //      nodes (11 words each: 4/3 table slots + inst_of/meta/succ0/succ1 + one 8-byte {ancestor, distance} pair per
@@ -1220,6 +1367,8 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     AsmParams P;
     P.next_gap = d_next;
     P.keyslot = (uint32_t)ctx->asm_keyslot;
+    P.precount = (uint32_t)ctx->asm_precount;
+    P.diag = (uint32_t)ctx->asm_diag;
     const uint32_t rb = (uint32_t)((read_len + 3) / 4);
     P.reads32 = (const uint32_t*)d_pool;
     P.n_words = ((uint64_t)total_reads * rb) / 4;

@@ -24,19 +24,27 @@ off = np.cumsum([0] + [len(o) for o in order]).astype(np.uint64)
 pool = packed[np.concatenate([np.array(o, dtype=np.int64) for o in order if o])]
 print("gaps", len(gaps), "pooled reads", len(pool), "mean/gap", len(pool) / len(gaps))
 dev = torch.device("cuda:0")
-dbg = torch.zeros(len(gaps) * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(len(gaps) * 16, dtype=torch.int64, device=dev)
 gf.set_option("asm_dbg_ptr", dbg.data_ptr())
 gf.timing(True)
+if os.environ.get("PRECOUNT"):
+    gf.set_option("asm_precount", int(os.environ["PRECOUNT"]))
+if os.environ.get("ASMDIAG"):
+    os.environ["GF_DIAGNOSTICS"] = "1"; gf.set_option("asm_diag", int(os.environ["ASMDIAG"]))
 if os.environ.get("SIMPLIFY"):
     gf.set_option("asm_simplify", int(os.environ["SIMPLIFY"]))
 for _ in range(3):
     K = int(os.environ.get("K", "31")); ctg, seq = gf.assemble(pool, off, 150, [(K, K - 2)])
 ms, n = gf.kernel_time(B.KERNEL_ASSEMBLE)
 print("assemble kernel %.3f ms avg, contigs %d" % (ms / n, len(ctg)))
-d = dbg.cpu().numpy().reshape(-1, 8)
+d = dbg.cpu().numpy().reshape(-1, 16)
 order = [0, 1, 2, 3, 4, 7, 5, 6]        # stamp 7 sits between 4 (links) and 5 (emission start)
 ph = np.diff(d[:, order], axis=1) / 100.0  # us
 names = ["P1 count", "P2 survivors", "P3 graph+index", "P4 links", "error removal", "ranking", "emission"]
 for i, nm in enumerate(names):
     print("%-14s mean %8.1f us   max %8.1f us" % (nm, ph[:, i].mean(), ph[:, i].max()))
+if d[:, 8].any():
+    print("P1 split: pre-count %.1f us, table init %.1f us, exact count %.1f us" % (((d[:, 8] - d[:, 0]) / 100.0).mean(), ((d[:, 9] - d[:, 8]) / 100.0).mean(), ((d[:, 1] - d[:, 9]) / 100.0).mean()))
+print("windows %.0f, distinct counted %.0f, survivors %.0f, global table in %.0f %% of the gaps" % (d[:, 13].mean(), d[:, 10].mean(), d[:, 12].mean(), 100.0 * d[:, 11].mean()))
+print("table probes %.0f, table slots %.0f" % (d[:, 14].mean(), d[:, 15].mean()))
 print("total/gap mean %.1f us max %.1f us; kernel span %.1f us" % (ph.sum(1).mean(), ph.sum(1).max(), (d[:, 6].max() - d[:, 0].min()) / 100.0))
