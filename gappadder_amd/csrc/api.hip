@@ -202,6 +202,9 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         ctx->index.clear();
         return GF_OK;
     }
+    if (!strcmp(name, "tag_bins_log2")) { ctx->tag_bins_log2 = std::max(13, std::min(19, (int)value)); ctx->bin_dist2 = -1; return GF_OK; }
+    if (!strcmp(name, "tag_fine_log2")) { ctx->tag_fine_log2 = std::max(20, std::min(28, (int)value)); ctx->bin_dist2 = -1; return GF_OK; }
+    if (!strcmp(name, "tag_nt")) { ctx->tag_nt = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_diag")) {
         if (!getenv("GF_DIAGNOSTICS")) return GF_E_UNSUPPORTED;
         ctx->asm_diag = (int)value;

@@ -99,6 +99,10 @@ struct gf_ctx {
     void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)
     // tagger coarse bin map (rebuilt when dist2 changes)
     std::vector<uint32_t> bin_host;
+    // tagger: bits of the LDS bin map and of the global one behind it; non-temporal record loads.  Measured on the C4 layout (200 M
+    // records, rocprof): 2^25-bit global map 2.24 ms; + nt loads (the record stream no longer evicts the map from the L2s) 1.90 ms;
+    // 2^23 bits + nt 1.82 ms; 32 / 64 KiB LDS maps 2.85 / 3.13 ms (fewer workgroups per CU)
+    int tag_bins_log2 = 17, tag_fine_log2 = 23, tag_nt = 1;
     int bin_dist2 = -1, bin_shift = 0;
     uint32_t bin_words = 0, fine_words = 0, fine_shift = 0;
     // second-hop table cache

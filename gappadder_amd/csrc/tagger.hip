@@ -100,7 +100,7 @@ constexpr int TAG_UNROLL = 8;  // 8 KiB (256 records) per wave and stage, two st
 // human scale); BINS_LDS = false reads it through L1/L2 instead and runs one-wave workgroups with ~6 KiB of LDS, so that the
 // tagger's workgroups fit on the CUs NEXT TO the k-mer filter's (which own 137-151 KiB of every CU's LDS but leave most of its
 // issue slots idle: PMC SQ_WAIT_ANY 53-77 %) — the "light" variant a pipeline launches on its second stream.
-template <int NW, bool BINS_LDS>
+template <int NW, bool BINS_LDS, bool NT = false>
 __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
     extern __shared__ uint32_t bins_lds[];  // the whole bin map (<= 16 KiB), staged once per workgroup
     __shared__ HitBufT<128 * NW> hb;
@@ -193,6 +193,11 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
 #pragma unroll
         for (int u = 0; u < TAG_UNROLL; ++u) {
             const uint64_t h = h0 + 64ull * u + lane;
+            if (NT) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 t = h < n_half ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + h) : u32x4{0, 0, 0, 0xFFFFFFFFu};
+                vn[u] = make_uint4(t.x, t.y, t.z, t.w);
+            } else
             vn[u] = h < n_half ? src[h] : make_uint4(0, 0, 0, 0xFFFFFFFFu);
         }
     };
@@ -394,7 +399,7 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
         for (size_t i = 0; i < off.size(); ++i) h[words + i] = off[i];
     };
     int shift = 6;
-    while (nbits(shift) > (1u << 17)) ++shift;  // <= 16 KiB of LDS (measured: an 8 KiB map sends more records down the slow path and loses)
+    while (nbits(shift) > (1u << ctx->tag_bins_log2)) ++shift;  // <= 16 KiB of LDS by default (measured: an 8 KiB map sends more records down the slow path and loses)
     uint32_t words = 0;
     std::vector<uint32_t>& h = ctx->bin_host;
     build(shift, h, words);
@@ -409,7 +414,7 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
     for (uint32_t i = 0; i < words; ++i) set_bits += (uint64_t)__builtin_popcount(h[i]);
     if (shift > 9 && set_bits * 20 > nbits(shift)) {   // worth a second look-up only when the LDS map passes > 5 %
         int fs = 7;
-        while (nbits(fs) > (1u << 25)) ++fs;
+        while (nbits(fs) > (1u << ctx->tag_fine_log2)) ++fs;
         if (fs + 2 <= shift) {
             std::vector<uint32_t> hf;
             uint32_t fw = 0;
@@ -466,6 +471,8 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
         LaunchTimer tm(ctx, GF_KERNEL_TAG);
         if (ctx->tag_light)   // one-wave workgroups without the LDS bin map: co-resident with the k-mer filter's workgroups
             hipLaunchKernelGGL((tag_kernel<1, false>), dim3(4 * stream_grid(ctx, n)), dim3(64), 0, ctx->stream, P);
+        else if (ctx->tag_nt)
+            hipLaunchKernelGGL((tag_kernel<4, true, true>), dim3(stream_grid(ctx, n)), dim3(256), (size_t)ctx->bin_words * 4, ctx->stream, P);
         else
             hipLaunchKernelGGL((tag_kernel<4, true>), dim3(stream_grid(ctx, n)), dim3(256), (size_t)ctx->bin_words * 4, ctx->stream, P);
     }

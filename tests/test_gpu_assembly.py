@@ -130,6 +130,35 @@ def test_deep_noisy_pool(gf, n_reads, kk):
         assert raw[(0, k, kv)] == exp, (k, kv)
 
 
+@pytest.mark.parametrize("n_reads,kk,min_count", [(320, [(31, 29), (51, 49)], 2), (660, [(31, 29), (41, 39), (51, 49)], 2),
+                                                   (320, [(31, 29), (51, 49)], 3), (1500, [(51, 49)], 3), (90, [(63, 61)], 2)])
+def test_pre_count_leaves_the_counts_unchanged(gf, n_reads, kk, min_count):
+    """The bit-array pre-count of the count phase (k-mers seen fewer than min_count times never reach the table) against the
+    oracle and against the same launch without it, at the depths of C4 / C5 pools, with N bases in the reads."""
+    rng = np.random.RandomState(n_reads + min_count)
+    g = LUT[rng.randint(0, 4, 2600)].tobytes()
+    L = 150
+    reads = tiled_reads(g, L, n_reads, rng)
+    for i in range(len(reads)):
+        b = bytearray(reads[i])
+        for pos in np.flatnonzero(rng.rand(L) < 0.01):
+            b[pos] = LUT[(list(b"ACGT").index(b[pos]) + 1 + rng.randint(3)) % 4]
+        if i % 37 == 0:
+            b[rng.randint(L)] = ord("N")
+        reads[i] = bytes(b)
+    pool = b"".join(reads)
+    got, _ = _gpu_assemble(gf, [pool, pool[:40 * L]], L, kk, min_count=min_count)
+    gf.set_option("asm_precount", 0)
+    try:
+        plain, _ = _gpu_assemble(gf, [pool, pool[:40 * L]], L, kk, min_count=min_count)
+    finally:
+        gf.set_option("asm_precount", 1)
+    assert got == plain
+    for (k, kv) in kk:
+        assert got.get((0, k, kv), []) == CO.assemble_pool(pool, L, k, kv, min_count=min_count), (k, kv)
+        assert len(got.get((0, k, kv), [])) >= 1
+
+
 def test_count_kmers_matches_oracle(gf):
     from gappadder_amd.hip_api import GapFill
     c = S.small_case(seed=9, n_pairs=6000, n_frac=0.1)
