@@ -632,6 +632,10 @@ static_assert(PF2_WAVES > PF2_NB / 64, "waves 1..4 keep the parts' fill while wa
 // Measured on 112.5 M reads, k=51 (2^28-bit bitmap): 16 waves x 1 tile 2.47 ms, 16 x 2 tiles + alternating histograms 2.22 ms (longer
 // runs per bucket: 32 pairs = 256 B); 8 waves x 2 tiles with the sort buffer overlaid on the tiles, three workgroups per CU: 2.68 ms
 // (128-B runs, three times the parts); 16 x 3 tiles overlaid: 5.6 ms (36 scrambled keys per lane in registers spill).
+// What bounds it (same launch, parts of the kernel switched off): loads without stores 1.34 ms, stores without loads 1.57 ms, both
+// 2.25-2.37 ms = 8.2 GB at 3.5 TB/s.  Twelve producer waves sorting into one of two 6-byte-entry LDS buffers while four copier waves
+// write the other buffer out (stores off every producer's path) took the same 2.377 ms, `nt` stores 2.82 ms, `sc1` stores 2.26 ms:
+// the mix of a 4.3-GB read stream and 65 536 scattered 256-B write runs is what the memory system delivers at this rate.
 
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams Q, uint32_t slice_words) {
     extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][sorted pairs: PF2_BATCH x 8 B][hist 3 x 256][offs 257 (+1)][written 2 x 256]
@@ -671,6 +675,10 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams 
 #pragma unroll
             for (int c = 0; c < NPF; ++c) {
                 const uint32_t i = lane + c * 64;
+                if (Q.diag & 32) {   // timing experiment: no tile loads, pseudo-random bases instead
+                    const uint32_t z = ((uint32_t)t * 0x9E3779B1u) ^ (i * 0x85EBCA77u);
+                    pf[q][c] = u32x4{z * 0xC2B2AE3Du, z * 0x27D4EB2Fu, z * 0x165667B1u, (z >> 7) * 0x9E3779B1u};
+                } else
                 vm_load128(pf[q][c], i < (nbytes >> 4) ? i * 16 : 0u, base);   // (nt: 2.32 against 2.25 ms)
             }
         }
