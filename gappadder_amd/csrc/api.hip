@@ -210,6 +210,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         ctx->asm_diag = (int)value;
         return GF_OK;
     }
+    if (!strcmp(name, "screen_pf4")) { ctx->screen_pf4 = value != 0; return GF_OK; }
     if (!strcmp(name, "screen_pf_diag")) {
         if (!getenv("GF_DIAGNOSTICS")) return GF_E_UNSUPPORTED;
         ctx->screen_pf_diag = (int)value;

@@ -529,7 +529,10 @@ __global__ __launch_bounds__(1024) void pf_probe_kernel(PartParams Q) {
             const uint32_t n = Q.count[(size_t)b * Q.n_writers + w];
             const unsigned long long* src = Q.pairs + ((size_t)b * Q.n_writers + w) * Q.cap;
             // software pipeline: the next PB x 64 pairs are in flight while this batch asks the bitmap
-            constexpr int PB = 8;
+#ifndef GF_PF2_PB
+#define GF_PF2_PB 8
+#endif
+            constexpr int PB = GF_PF2_PB;
             unsigned long long nx[PB];
             auto fetch = [&](uint32_t i0) {
 #pragma unroll
@@ -855,7 +858,10 @@ __global__ __launch_bounds__(1024) void pf2_probe_kernel(PartParams Q) {
         for (uint32_t w = wv; w < Q.n_writers; w += 16) {
             const uint32_t n = Q.count[(size_t)b * Q.n_writers + w];
             const unsigned long long* src = Q.pairs + ((size_t)b * Q.n_writers + w) * Q.cap;
-            constexpr int PB = 8;
+#ifndef GF_PF2_PB
+#define GF_PF2_PB 8
+#endif
+            constexpr int PB = GF_PF2_PB;
             unsigned long long nx[PB];
             auto fetch = [&](uint32_t i0) {
 #pragma unroll
@@ -889,6 +895,445 @@ __global__ __launch_bounds__(1024) void pf2_probe_kernel(PartParams Q) {
     }
     while (pend_n) settle();
     if (obuf_n) flush();
+}
+
+// ---- 256-bucket filter with 4-BYTE pairs.  The 8-byte (key, read) pairs of pf2_* triple the stream (38 B of read -> + 32 B written
+// + 32 B read back: 3.06 x the algorithmic bytes at C4) and both passes run at the rate the memory system moves those bytes.  What
+// pass B needs of a pair: the 24 key bits below the bucket (both bitmap bits and the exact-set key derive from them) — and the read
+// only for the ~0.6 % of the pairs that are in the exact set.  So an entry is  key bits << 8 | OCTET of the read inside the
+// workgroup's batch (2048 reads = 256 octets of 8 consecutive reads), and the rest of the read id is recovered, exactly:
+//   * which BATCH (tile iteration) a pair belongs to follows from its POSITION in the part: pass A records the part's fill before
+//     every group (`fills`, staged in LDS and written as 64-byte rows: 3 % of the pair bytes), pass B searches it for the few
+//     pairs that need it;
+//   * which of the octet's 8 reads: pf4_resolve_kernel fetches the octet (304 contiguous bytes) and keeps the read(s) that have
+//     an aligned 16-mer with this scrambled key — those are exactly the reads the pair can have come from, and each of them IS a
+//     candidate (it has a seed in the exact set); the `seen` bit per read keeps one entry per read, as before.
+struct Part4Params {
+    FilterParams F;
+    uint32_t n_writers, cap;      // parts: [bucket][writer][cap] entries
+    uint32_t* pairs;              // entry = low 24 bits of the scrambled key << 8 | octet in the batch
+    uint32_t* count;              // [bucket][writer]
+    uint32_t* fills;              // [bucket][writer][gs]: fill of the part before group g, g = 0 .. n_groups
+    uint32_t gs, n_groups, n_grp; // row stride; groups in all; groups per tile iteration
+    uint32_t tiles_wg;            // tiles per workgroup and tile iteration
+    uint32_t* seen;               // one bit per read
+    unsigned long long* cand8;    // pairs found in the exact set: {writer << 56 | position in the part << 32 | batch octet << 24 | key bits}; ~0 = unused
+    uint8_t* chunk_b;             // bucket of every PF4_CHUNK entries of that list
+    uint32_t* n_cand8;
+    uint32_t cap8;
+    uint32_t diag;
+};
+constexpr uint32_t PF4_CHUNK = 256;   // entries of the pair list a wave of pass B reserves at a time
+constexpr uint32_t PF4_STAGE = 16;   // groups of fill history staged in LDS (one 64-byte row per bucket and flush)
+
+// does read r have an aligned 16-mer with scrambled key pk?  (slow path: bytes from global memory)
+__device__ __forceinline__ bool pf4_read_has_key(const FilterParams& P, uint64_t r, uint32_t pk) {
+    const uint8_t* rd = P.reads + r * P.rb;
+    for (uint32_t j = 0; j < P.np; ++j) {
+        const uint32_t bit = j * P.stride2, by = bit >> 3, sh = bit & 7;
+        uint64_t v = 0;
+        for (uint32_t q = 0; q < 5; ++q) v = (v << 8) | ((by + q < P.rb) ? rd[by + q] : 0);
+        const uint32_t w16 = (uint32_t)((v << sh) >> 8);
+        if (canon16(w16) * S16_MUL == pk) return true;
+    }
+    return false;
+}
+// octet (read >> 3) of the pair at position `pos` of part (b, w) with batch octet `oc`: the batch is the group g with
+// fills[g] <= pos < fills[g + 1] — searched from the proportional guess (the fills grow almost linearly)
+__device__ __forceinline__ uint32_t pf4_octet(const Part4Params& Q, uint32_t b, uint32_t w, uint32_t pos, uint32_t oc) {
+    const uint32_t* F = Q.fills + ((size_t)b * Q.n_writers + w) * Q.gs;
+    const uint32_t G = Q.n_groups, n = F[G];
+    uint32_t lo = (uint32_t)((uint64_t)pos * G / (n ? n : 1u)), hi;
+    if (lo >= G) lo = G - 1;
+    if (F[lo] <= pos) {
+        uint32_t st = 1;
+        hi = lo + 1;
+        while (hi < G && F[hi] <= pos) { lo = hi; st <<= 1; hi = lo + st < G ? lo + st : G; }
+    } else {
+        uint32_t st = 1;
+        hi = lo;
+        lo = hi > st ? hi - st : 0;
+        while (lo > 0 && F[lo] > pos) { hi = lo; st <<= 1; lo = hi > st ? hi - st : 0; }
+    }
+    while (hi - lo > 1) {   // F[lo] <= pos < F[hi]
+        const uint32_t mid = (lo + hi) >> 1;
+        if (F[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return (uint32_t)(((uint64_t)(lo / Q.n_grp) * Q.n_writers * Q.tiles_wg + (uint64_t)w * Q.tiles_wg) * 8) + oc;
+}
+// every read of an octet that can have produced the pair is marked a candidate — by one lane on its own (pair list full, or a
+// part that ran full in pass A)
+__device__ __forceinline__ void pf4_resolve_octet_serial(const Part4Params& Q, uint32_t octet, uint32_t pk) {
+    const FilterParams& P = Q.F;
+    for (uint32_t sub = 0; sub < 8; ++sub) {
+        const uint64_t r = (uint64_t)octet * 8 + sub;
+        if (r < P.n_reads && pf4_read_has_key(P, r, pk)) atomicOr(&Q.seen[r >> 5], 1u << (r & 31));
+    }
+}
+__global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params Q, uint32_t slice_words) {
+    extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][keys: BATCH x 4 B][octets: BATCH x 1 B][fill stage 256 x 17][hist 3 x 256][offs 258][written 2 x 256]
+    const FilterParams& P = Q.F;
+    constexpr uint32_t NT = 64 * PF2_WAVES;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* tiles = sm + wv * PF2_TILES * slice_words;
+    uint32_t* skey = sm + PF2_WAVES * PF2_TILES * slice_words;
+    uint8_t* sidx = reinterpret_cast<uint8_t*>(skey + PF2_BATCH);
+    uint32_t* stage = reinterpret_cast<uint32_t*>(sidx + PF2_BATCH);
+    uint32_t* hist3 = stage + PF2_NB * (PF4_STAGE + 1);
+    uint32_t* offs = hist3 + 3 * PF2_NB;
+    uint32_t* written2 = offs + PF2_NB + 2;
+    const uint32_t writer = blockIdx.x;
+    const uint32_t tile_bytes = 64 * P.rb;
+    const uint64_t total_bytes = P.n_reads * P.rb;
+    const uint64_t n_tiles = (P.n_reads + 63) / 64;
+    auto part = [&](uint32_t b) { return Q.pairs + ((size_t)b * Q.n_writers + writer) * Q.cap; };
+    auto fill_row = [&](uint32_t b) { return Q.fills + ((size_t)b * Q.n_writers + writer) * Q.gs; };
+    uint32_t* dummy = Q.pairs + (size_t)PF2_NB * Q.n_writers * Q.cap;   // 64 x 4 bytes behind the parts
+    for (uint32_t i = tid; i < PF2_NB; i += NT) { written2[i] = 0; hist3[i] = 0; hist3[PF2_NB + i] = 0; hist3[2 * PF2_NB + i] = 0; }
+    constexpr int NPF = 4;   // 64 reads x <= 64 B
+    u32x4 pf[PF2_TILES][NPF];
+    auto prefetch = [&](uint64_t t0) {
+#pragma unroll
+        for (uint32_t q = 0; q < PF2_TILES; ++q) {
+            const uint64_t t = t0 + q;
+            const bool on = t < n_tiles;
+            const uint64_t byte0 = on ? t * tile_bytes : 0;
+            const uint32_t nbytes = on ? (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes) : 0u;
+            const void* base = uniform_ptr(nbytes >= 16 ? (const void*)(P.reads + byte0) : (const void*)Q.count);   // (idle: 16 bytes of the workspace)
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) {
+                const uint32_t i = lane + c * 64;
+                vm_load128(pf[q][c], i < (nbytes >> 4) ? i * 16 : 0u, base);
+            }
+        }
+    };
+    const uint64_t t_step = (uint64_t)gridDim.x * PF2_WAVES * PF2_TILES;
+    const uint64_t n_iter = (n_tiles + t_step - 1) / t_step;
+    prefetch(((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES);
+    uint32_t hsel = 0, wsel = 0, g = 0;
+    uint32_t stores_since = 0;   // copy-out stores this wave has issued since its last prefetch (wave-uniform)
+    __syncthreads();
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        const uint64_t t0 = it * t_step + ((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES;
+        const uint32_t octet0 = (uint32_t)((it * t_step + (uint64_t)blockIdx.x * PF2_WAVES * PF2_TILES) * 8);   // octet of batch index 0
+        // this tile's loads were issued before the previous iteration's copy-out stores: those may stay in flight
+        switch (stores_since < 12u ? stores_since : 12u) {
+            case 0: vm_wait<0>(); break;   case 1: vm_wait<1>(); break;   case 2: vm_wait<2>(); break;   case 3: vm_wait<3>(); break;
+            case 4: vm_wait<4>(); break;   case 5: vm_wait<5>(); break;   case 6: vm_wait<6>(); break;   case 7: vm_wait<7>(); break;
+            case 8: vm_wait<8>(); break;   case 9: vm_wait<9>(); break;   case 10: vm_wait<10>(); break; case 11: vm_wait<11>(); break;
+            default: vm_wait<12>(); break;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < PF2_TILES; ++q)
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) vm_ready(pf[q][c]);
+        stores_since = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PF2_TILES; ++q) {
+            const uint64_t t = t0 + q;
+            if (t >= n_tiles) continue;
+            uint8_t* tb = reinterpret_cast<uint8_t*>(tiles + q * slice_words);
+            const uint64_t byte0 = t * tile_bytes;
+            const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+            const uint32_t n16 = nbytes & ~15u;
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) {
+                const uint32_t i = lane + c * 64;
+                if (i < (n16 >> 4)) *reinterpret_cast<u32x4*>(tb + (uint64_t)i * 16) = pf[q][c];
+            }
+            for (uint32_t i = n16 + lane; i < nbytes; i += 64) tb[i] = P.reads[byte0 + i];
+            if (lane < 16) tb[nbytes + lane] = 0;
+        }
+        wave_lds_sync();
+        prefetch(t0 + t_step);
+        const uint32_t bit0 = lane * P.rb * 8;
+        for (uint32_t j0 = 0; j0 < P.np; j0 += PF2_GROUP, ++g) {
+            uint32_t* hist = hist3 + hsel * PF2_NB;        // all zero (start / zeroed during the copy-out before last)
+            const uint32_t* written = written2 + wsel * PF2_NB;
+            uint32_t pk[PF2_TILES][PF2_GROUP], rank[PF2_TILES][PF2_GROUP];
+#pragma unroll
+            for (uint32_t q = 0; q < PF2_TILES; ++q) {
+                const bool live = t0 + q < n_tiles && (t0 + q) * 64 + lane < P.n_reads;
+#pragma unroll
+                for (uint32_t u = 0; u < PF2_GROUP; ++u) {
+                    const bool on = live && j0 + u < P.np;
+                    pk[q][u] = on ? canon16(stream32(tiles + q * slice_words, bit0 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
+                    rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
+                }
+            }
+            __syncthreads();
+            if (wv == 0) {   // exclusive scan of the 256 bins: four per lane
+                uint32_t v[4], sum = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] = hist[lane * 4 + q]; sum += v[q]; }
+                uint32_t inc = sum;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(inc, d);
+                    if ((int)lane >= d) inc += y;
+                }
+                uint32_t run = inc - sum;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { offs[lane * 4 + q] = run; run += v[q]; }
+                if (lane == 63) offs[PF2_NB] = inc;
+            } else if (wv <= PF2_NB / 64) {   // the parts' fill before (history) and after this group
+                const uint32_t i = tid - 64;
+                const uint32_t w0 = written[i], w = w0 + hist[i];
+                stage[i * (PF4_STAGE + 1) + (g % PF4_STAGE)] = w0;
+                written2[(wsel ^ 1u) * PF2_NB + i] = w < Q.cap ? w : Q.cap;
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t q = 0; q < PF2_TILES; ++q)
+#pragma unroll
+                for (uint32_t u = 0; u < PF2_GROUP; ++u)
+                    if (rank[q][u] != EMPTY32) {
+                        const uint32_t at = offs[pk[q][u] >> (32 - PF2_NB_LOG2)] + rank[q][u];
+                        skey[at] = pk[q][u];
+                        sidx[at] = (uint8_t)((wv * PF2_TILES + q) * 8 + (lane >> 3));
+                    }
+            __syncthreads();
+            const uint32_t n_pairs = offs[PF2_NB];
+            const uint32_t hz = hsel == 0 ? 2 : hsel - 1;
+            for (uint32_t i = tid; i < PF2_NB; i += NT) hist3[hz * PF2_NB + i] = 0;                  // the histogram of the group after next
+            for (uint32_t i0 = 0; i0 < n_pairs; i0 += NT) {         // (whole waves stay in the loop: one store per wave and trip)
+                const uint32_t i = i0 + tid;
+                const bool valid = i < n_pairs;
+                const uint32_t key = valid ? skey[i] : 0u;
+                const uint32_t oc = valid ? (uint32_t)sidx[i] : 0u;
+                const uint32_t b = key >> (32 - PF2_NB_LOG2);
+                const uint32_t at = valid ? written[b] + (i - offs[b]) : 0u;
+                const bool spill = valid && at >= Q.cap;
+                {
+                    uint32_t* dst = (valid && !spill && !(Q.diag & 16)) ? part(b) + at : dummy + lane;
+                    const uint32_t e = (key << 8) | oc;
+                    asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
+                    ++stores_since;
+                }
+                if (spill) {   // a part that is full (degenerate inputs): tested on the spot
+                    const uint32_t h = key >> (32 - P.bm_log2);
+                    const uint32_t wd = P.bitmap[h >> 5];
+                    if ((wd >> (h & 31)) & (wd >> (key & 31)) & 1u) {
+                        const uint32_t k16 = key * S16_MUL_INV;
+                        if (sset_walk(P, k16, hash_s16_set(k16, P.s_log2))) pf4_resolve_octet_serial(Q, octet0 + oc, key);
+                    }
+                }
+            }
+            if ((g % PF4_STAGE) == PF4_STAGE - 1 || g + 1 == Q.n_groups) {   // the staged fill rows leave as 64-byte pieces
+                const uint32_t g_lo = g - g % PF4_STAGE;
+                for (uint32_t i = tid; i < PF2_NB * PF4_STAGE; i += NT) {
+                    const uint32_t b = i / PF4_STAGE, j = i % PF4_STAGE;
+                    if (g_lo + j <= g) fill_row(b)[g_lo + j] = stage[b * (PF4_STAGE + 1) + j];
+                }
+            }
+            hsel = hsel == 2 ? 0 : hsel + 1;
+            wsel ^= 1u;
+        }
+    }
+    vm_wait<0>();   // the last prefetch (idle tiles) still targets this wave's registers
+    __syncthreads();
+    for (uint32_t i = tid; i < PF2_NB; i += NT) {
+        const uint32_t w = written2[wsel * PF2_NB + i];
+        Q.count[(size_t)i * Q.n_writers + writer] = w;
+        fill_row(i)[Q.n_groups] = w;
+    }
+}
+
+__global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
+    extern __shared__ uint32_t sm[];   // [slice of the level-1 bitmap: 2^(bm_log2 - 8) bits][per wave: 2 x WOBUF words of candidates | 2 x PF2_PEND words of pairs]
+    const FilterParams& P = Q.F;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t slice_words = 1u << (P.bm_log2 - PF2_NB_LOG2 - 5);
+    const uint32_t sh_bm = 32 - P.bm_log2;
+    unsigned long long* obuf = reinterpret_cast<unsigned long long*>(sm + slice_words + wv * (2 * WOBUF + 2 * PF2_PEND));
+    unsigned long long* pend = obuf + WOBUF;
+    uint32_t obuf_n = 0, pend_n = 0;   // wave-uniform
+    const unsigned long long lt = (1ull << lane) - 1;
+    for (uint32_t b = blockIdx.x; b < PF2_NB; b += gridDim.x) {
+        // The pair list is reserved in CHUNKS of PF4_CHUNK entries per wave and bucket (a single global counter serialises returning
+        // atomics at ~11 ns each: one atomic per 32-64 entries was 0.8 ms per 112.5 M reads, the whole pass); a chunk belongs to ONE
+        // bucket (chunk_b), so an entry needs no bucket bits; what is left of a wave's last chunk is filled with the invalid entry ~0.
+        uint32_t ch_at = 0, ch_end = 0;   // wave-uniform: this wave's chunk
+        auto flush = [&]() {
+            uint32_t done = 0;
+            while (done < obuf_n) {
+                if (ch_at == ch_end) {
+                    uint32_t gb = 0;
+                    if (lane == 0) {
+                        gb = atomicAdd(Q.n_cand8, PF4_CHUNK);
+                        if (gb < Q.cap8) Q.chunk_b[gb / PF4_CHUNK] = (uint8_t)b;
+                    }
+                    ch_at = __shfl(gb, 0);
+                    ch_end = ch_at + PF4_CHUNK;
+                }
+                const uint32_t room = ch_end - ch_at, m = obuf_n - done < room ? obuf_n - done : room;
+                for (uint32_t q = lane; q < m; q += 64) {
+                    const unsigned long long cp = obuf[done + q];
+                    if (ch_at + q < Q.cap8) Q.cand8[ch_at + q] = cp;
+                    else pf4_resolve_octet_serial(Q, pf4_octet(Q, b, (uint32_t)(cp >> 56), (uint32_t)(cp >> 32) & 0xFFFFFFu, (uint32_t)(cp >> 24) & 255u),
+                                                  (b << 24) | ((uint32_t)cp & 0xFFFFFFu));
+                }
+                ch_at += m;
+                done += m;
+            }
+            obuf_n = 0;
+            wave_lds_sync();
+        };
+        // exact-set look-up of the last min(64, pend_n) queued pairs {writer | position | batch octet | key bits}, one per lane
+        auto settle = [&]() {
+            const uint32_t base = pend_n > 64 ? pend_n - 64 : 0;
+            bool cand = false;
+            unsigned long long pr = 0;
+            if (base + lane < pend_n) {
+                pr = pend[base + lane];
+                const uint32_t key = ((b << 24) | ((uint32_t)pr & 0xFFFFFFu)) * S16_MUL_INV;
+                cand = sset_walk(P, key, hash_s16_set(key, P.s_log2));
+            }
+            pend_n = base;
+            const unsigned long long bal = __ballot(cand);
+            if (bal) {
+                if (obuf_n + (uint32_t)__popcll(bal) > WOBUF) flush();
+                if (cand) obuf[obuf_n + __popcll(bal & lt)] = pr;
+                obuf_n += (uint32_t)__popcll(bal);
+                wave_lds_sync();
+                if (obuf_n >= 32) flush();
+            }
+            wave_lds_sync();
+        };
+        __syncthreads();
+        for (uint32_t i = tid * 4; i < slice_words; i += 1024 * 4)
+            *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap + (size_t)b * slice_words + i);
+        __syncthreads();
+        for (uint32_t w = wv; w < Q.n_writers; w += 16) {
+            const uint32_t n = Q.count[(size_t)b * Q.n_writers + w];
+            const uint32_t* src = Q.pairs + ((size_t)b * Q.n_writers + w) * Q.cap;
+            constexpr int PB = 16;
+            uint32_t nx[PB];
+            auto fetch = [&](uint32_t i0) {
+#pragma unroll
+                for (int u = 0; u < PB; ++u) nx[u] = i0 + u * 64 + lane < n ? src[i0 + u * 64 + lane] : 0u;
+            };
+            fetch(0);
+            for (uint32_t i0 = 0; i0 < n; i0 += PB * 64) {
+                uint32_t pr[PB];
+#pragma unroll
+                for (int u = 0; u < PB; ++u) pr[u] = nx[u];
+                if (i0 + PB * 64 < n) fetch(i0 + PB * 64);
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const uint32_t pos = i0 + u * 64 + lane;
+                    const uint32_t pk = (b << (32 - PF2_NB_LOG2)) | (pr[u] >> 8);
+                    bool pass = false;
+                    if (pos < n) {
+                        const uint32_t h = pk >> sh_bm;                       // bit index in the whole bitmap; its top 8 bits = b
+                        const uint32_t wd = sm[(h >> 5) & (slice_words - 1)];
+                        pass = (wd >> (h & 31)) & (wd >> (pk & 31)) & 1u;      // both bits of the key in its word
+                    }
+                    const unsigned long long bal = __ballot(pass);
+                    if (bal) {
+                        if (pass) pend[pend_n + __popcll(bal & lt)] = ((unsigned long long)w << 56) | ((unsigned long long)pos << 32) | ((pr[u] & 255u) << 24) | (pr[u] >> 8);
+                        pend_n += (uint32_t)__popcll(bal);                    // < 64 + 64 <= PF2_PEND
+                        wave_lds_sync();
+                        if (pend_n >= 64) settle();
+                    }
+                }
+            }
+        }
+        while (pend_n) settle();
+        if (obuf_n) flush();
+        for (uint32_t q = ch_at + lane; q < ch_end; q += 64)
+            if (q < Q.cap8) Q.cand8[q] = ~0ull;
+    }
+}
+
+// A pair that is in the exact set -> the reads it can have come from.  Its batch follows from its position in the part (the
+// part's fill history), its octet from the entry; every read of the octet that has an aligned 16-mer with the pair's scrambled key
+// IS a candidate: its bit in `seen` is set.  Eight lanes per pair (lane = read of the octet), eight pairs per lane group in flight;
+// a read's aligned 16-mers are fetched with one unaligned 8-byte load each.
+__global__ __launch_bounds__(256) void pf4_resolve_kernel(Part4Params Q) {
+    extern __shared__ uint32_t sm[];   // per wave: 8 octets x (octet words rounded up to 4, + 4)
+    const FilterParams& P = Q.F;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 7, slot = lane >> 3;
+    const uint32_t ow = 2 * P.rb;                         // words per octet (8 reads x rb bytes; the octet starts 16-byte aligned)
+    const uint32_t ow4 = (ow + 3) / 4;                    // 16-byte pieces
+    const uint32_t row = ow4 * 4 + 4;
+    uint32_t* stg = sm + (wv * 8 + slot) * row;
+    const uint32_t n = *Q.n_cand8 < Q.cap8 ? *Q.n_cand8 : Q.cap8;
+    const uint64_t total_bytes = P.n_reads * P.rb;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t e0 = wave * 64; e0 < n; e0 += n_waves * 64) {
+        // lane = pair: its octet (one dependent chain of look-ups per lane, 64 in flight per wave) ...
+        uint32_t my_octet = 0xFFFFFFFFu, my_pk = 0;
+        {
+            const uint64_t e = e0 + lane;
+            const unsigned long long cp = e < n ? Q.cand8[e] : ~0ull;
+            if (cp != ~0ull) {   // (~0: unused tail of a wave's chunk)
+                const uint32_t b = Q.chunk_b[e / PF4_CHUNK];
+                my_pk = (b << 24) | ((uint32_t)cp & 0xFFFFFFu);
+                my_octet = pf4_octet(Q, b, (uint32_t)(cp >> 56), (uint32_t)(cp >> 32) & 0xFFFFFFu, (uint32_t)(cp >> 24) & 255u);
+            }
+        }
+        // ... then eight lanes per pair, eight pairs per round: the lanes stage the octet (8 reads, contiguous) in LDS with aligned
+        // 16-byte loads, lane = read scrambles its own aligned 16-mers
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t octet = __shfl(my_octet, u * 8 + slot), pk = __shfl(my_pk, u * 8 + slot);
+            const bool valid = octet != 0xFFFFFFFFu;
+            if (!__any(valid)) continue;
+            const uint64_t byte0 = (uint64_t)octet * 8 * P.rb;
+            for (uint32_t c = sub; c < ow4; c += 8) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const uint64_t at = byte0 + (uint64_t)c * 16;
+                if (valid) {
+                    if (at + 16 <= total_bytes) v = *reinterpret_cast<const uint4*>(P.reads + at);
+                    else {
+                        uint32_t t[4] = {0, 0, 0, 0};
+                        for (uint32_t q = 0; q < 16; ++q) if (at + q < total_bytes) t[q >> 2] |= (uint32_t)P.reads[at + q] << (8 * (q & 3));
+                        v = make_uint4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+                *reinterpret_cast<uint4*>(stg + c * 4) = v;
+            }
+            wave_lds_sync();
+            const uint64_t r = (uint64_t)octet * 8 + sub;
+            bool hit = false;
+            if (valid && r < P.n_reads)
+                for (uint32_t j = 0; j < P.np && !hit; ++j) hit = canon16(stream32(stg, sub * P.rb * 8 + j * P.stride2)) * S16_MUL == pk;
+            if (hit) atomicOr(&Q.seen[r >> 5], 1u << (r & 31));
+            wave_lds_sync();
+        }
+    }
+}
+
+// the candidate list = the reads whose `seen` bit is set: every workgroup compacts one contiguous slice of the bitmap (count, one
+// global atomic for the slice, then write)
+__global__ __launch_bounds__(256) void pf4_list_kernel(Part4Params Q) {
+    __shared__ uint32_t s_part[256], s_base;
+    const FilterParams& P = Q.F;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_words = (P.n_reads + 31) / 32;
+    const uint64_t per = (n_words + gridDim.x - 1) / gridDim.x;
+    const uint64_t w0 = (uint64_t)blockIdx.x * per, w1 = w0 + per < n_words ? w0 + per : n_words;
+    // thread t owns the contiguous words [w0 + t * pt, w0 + (t + 1) * pt)
+    const uint64_t pt = (per + 255) / 256;
+    const uint64_t a = w0 + (uint64_t)tid * pt < w1 ? w0 + (uint64_t)tid * pt : w1, bnd = a + pt < w1 ? a + pt : w1;
+    uint32_t c = 0;
+    for (uint64_t i = a; i < bnd; ++i) c += (uint32_t)__popc(Q.seen[i]);
+    s_part[tid] = c;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < 256; ++i) { const uint32_t v = s_part[i]; s_part[i] = run; run += v; }
+        s_base = run ? atomicAdd(P.n_cand, run) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = s_base + s_part[tid];
+    for (uint64_t i = a; i < bnd; ++i) {
+        uint32_t v = Q.seen[i];
+        while (v) {
+            const uint32_t bit = (uint32_t)__ffs(v) - 1;
+            v &= v - 1;
+            P.cand[at++] = (uint32_t)(i * 32 + bit);
+        }
+    }
 }
 
 template <int NP>
@@ -1721,6 +2166,48 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + w_nw - 1) / w_nw, ctx->n_cu)), dim3((unsigned)(w_nw * 64)),
                            w_bm_bytes + w_nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
+    } else if (ctx->screen_variant == 0 && ctx->screen_pf4 && n_reads >= (1u << 20) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
+               ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) * 4 + (size_t)PF2_BATCH * 5 + (size_t)PF2_NB * (PF4_STAGE + 1) * 4 +
+                (6 * PF2_NB + 8) * 4) <= 156 * 1024) {
+        // partitioned filter, 256 buckets, 4-byte pairs (see Part4Params)
+        Part4Params Q;
+        Q.F = F;
+        Q.diag = (uint32_t)ctx->screen_pf_diag;
+        const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;
+        const size_t tiles64 = (n_reads + 63) / 64;
+        const size_t tiles_wg = (size_t)PF2_WAVES * PF2_TILES;      // tiles per workgroup and iteration
+        const size_t lds_a = tiles_wg * slice_words * 4 + (size_t)PF2_BATCH * 5 + (size_t)PF2_NB * (PF4_STAGE + 1) * 4 + (6 * PF2_NB + 8) * 4;
+        Q.n_writers = (uint32_t)std::min<size_t>((tiles64 + tiles_wg - 1) / tiles_wg, (size_t)ctx->n_cu);
+        Q.tiles_wg = (uint32_t)tiles_wg;
+        const size_t n_iter = (tiles64 + (size_t)Q.n_writers * tiles_wg - 1) / ((size_t)Q.n_writers * tiles_wg);
+        Q.n_grp = (F.np + PF2_GROUP - 1) / PF2_GROUP;
+        Q.n_groups = (uint32_t)(n_iter * Q.n_grp);
+        Q.gs = (Q.n_groups + 1 + 15) & ~15u;
+        const double pairs_w = (double)n_iter * tiles_wg * 64.0 * F.np;
+        const double expect = pairs_w / PF2_NB;
+        Q.cap = ((uint32_t)(expect * 1.05 + 6.0 * std::sqrt(expect + 1.0) + 128.0) + 63u) & ~63u;
+        Q.cap8 = (uint32_t)(std::min<size_t>(std::max<size_t>((size_t)1 << 22, n_reads / 2), 0x7FFFFFFFu) / PF4_CHUNK * PF4_CHUNK);
+        const size_t b_pairs = (size_t)PF2_NB * Q.n_writers * Q.cap * 4, b_cnt = ((size_t)PF2_NB * Q.n_writers * 4 + 255 + 256) & ~(size_t)255,
+                     b_seen = (((size_t)n_reads + 31) / 32 * 4 + 255) & ~(size_t)255, b_fill = (size_t)PF2_NB * Q.n_writers * Q.gs * 4,
+                     b_c8 = ((size_t)Q.cap8 * 8 + Q.cap8 / PF4_CHUNK + 1 + 255) & ~(size_t)255;
+        if (Q.cap >= (1u << 24)) return GF_E_INVAL;   // a position must fit 24 bits (2^32 reads stay far below)
+        if ((rc = ensure(ctx, ctx->part_ws, b_cnt + b_seen + b_fill + b_c8 + b_pairs + 1024))) return rc;
+        uint8_t* ws = (uint8_t*)ctx->part_ws.p;
+        Q.count = (uint32_t*)ws;
+        Q.n_cand8 = (uint32_t*)(ws + b_cnt - 256);
+        Q.seen = (uint32_t*)(ws + b_cnt);
+        Q.fills = (uint32_t*)(ws + b_cnt + b_seen);
+        Q.cand8 = (unsigned long long*)(ws + b_cnt + b_seen + b_fill);
+        Q.chunk_b = (uint8_t*)(ws + b_cnt + b_seen + b_fill + (size_t)Q.cap8 * 8);
+        Q.pairs = (uint32_t*)(ws + b_cnt + b_seen + b_fill + b_c8);
+        GF_HIP(ctx, hipMemsetAsync(ws + b_cnt - 256, 0, 256 + b_seen, ctx->stream));
+        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
+        hipLaunchKernelGGL(pf4_scatter_kernel, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
+        const size_t lds_b = (((size_t)1 << (ix.bm_log2 - PF2_NB_LOG2 - 5)) + 16 * (2 * WOBUF + 2 * PF2_PEND)) * 4;
+        hipLaunchKernelGGL(pf4_probe_kernel, dim3((unsigned)std::min<size_t>(PF2_NB, (size_t)ctx->n_cu)), dim3(1024), lds_b, ctx->stream, Q);
+        const size_t lds_r = (size_t)4 * 8 * (((2 * (size_t)rb + 3) / 4) * 4 + 4) * 4;
+        hipLaunchKernelGGL(pf4_resolve_kernel, dim3((unsigned)ctx->n_cu * 8), dim3(256), lds_r, ctx->stream, Q);
+        hipLaunchKernelGGL(pf4_list_kernel, dim3((unsigned)std::min<size_t>((size_t)ctx->n_cu * 4, (n_reads + 32 * 256 - 1) / (32 * 256))), dim3(256), 0, ctx->stream, Q);
     } else if ((ctx->screen_variant == 15 || (ctx->screen_variant == 0 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
                ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) + (size_t)PF2_BATCH * 2 + 6 * PF2_NB + 8) * 4 <= 156 * 1024) {   // (reads up to ~180 bases)
         // partitioned filter, 256 buckets: a bucket's slice of the level-1 bitmap itself fits the LDS of pass B (see pf2_scatter_kernel)
