@@ -211,6 +211,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         return GF_OK;
     }
     if (!strcmp(name, "screen_pf4")) { ctx->screen_pf4 = value != 0; return GF_OK; }
+    if (!strcmp(name, "screen_pf4_cap8")) { ctx->screen_pf4_cap8 = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_pf_diag")) {
         if (!getenv("GF_DIAGNOSTICS")) return GF_E_UNSUPPORTED;
         ctx->screen_pf_diag = (int)value;

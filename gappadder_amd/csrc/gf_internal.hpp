@@ -87,6 +87,7 @@ struct gf_ctx {
     int screen_verify_gate = 1;  // verify kernel: consult the k-mer table only around exact 16-mer hits
     int screen_stream_policy = 1;  // pipelined filter: read stream loaded non-temporal (nt): keeps the L2 for the bitmap, -8 % fabric fetches
     int screen_np_override = -1;
+    int screen_pf4_cap8 = 0;     // tests: capacity of the 4-byte filter's pair list (0: sized from the reads)
     int screen_pf4 = 1;          // 256-bucket filter: 4-byte pairs (0: the 8-byte form, pf2_*)
     int screen_pf_diag = 0;      // partitioned filter timing experiments (wrong results; refused unless GF_DIAGNOSTICS)
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)

@@ -2166,7 +2166,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + w_nw - 1) / w_nw, ctx->n_cu)), dim3((unsigned)(w_nw * 64)),
                            w_bm_bytes + w_nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
-    } else if (ctx->screen_variant == 0 && ctx->screen_pf4 && n_reads >= (1u << 20) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
+    } else if ((ctx->screen_variant == 16 || (ctx->screen_variant == 0 && ctx->screen_pf4 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
                ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) * 4 + (size_t)PF2_BATCH * 5 + (size_t)PF2_NB * (PF4_STAGE + 1) * 4 +
                 (6 * PF2_NB + 8) * 4) <= 156 * 1024) {
         // partitioned filter, 256 buckets, 4-byte pairs (see Part4Params)
@@ -2187,6 +2187,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         const double expect = pairs_w / PF2_NB;
         Q.cap = ((uint32_t)(expect * 1.05 + 6.0 * std::sqrt(expect + 1.0) + 128.0) + 63u) & ~63u;
         Q.cap8 = (uint32_t)(std::min<size_t>(std::max<size_t>((size_t)1 << 22, n_reads / 2), 0x7FFFFFFFu) / PF4_CHUNK * PF4_CHUNK);
+        if (ctx->screen_pf4_cap8 > 0) Q.cap8 = (uint32_t)std::max(1, ctx->screen_pf4_cap8 / (int)PF4_CHUNK) * PF4_CHUNK;   // tests: a short pair list (the serial path)
         const size_t b_pairs = (size_t)PF2_NB * Q.n_writers * Q.cap * 4, b_cnt = ((size_t)PF2_NB * Q.n_writers * 4 + 255 + 256) & ~(size_t)255,
                      b_seen = (((size_t)n_reads + 31) / 32 * 4 + 255) & ~(size_t)255, b_fill = (size_t)PF2_NB * Q.n_writers * Q.gs * 4,
                      b_c8 = ((size_t)Q.cap8 * 8 + Q.cap8 / PF4_CHUNK + 1 + 255) & ~(size_t)255;

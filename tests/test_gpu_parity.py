@@ -100,7 +100,7 @@ def test_screen_and_tagger_synthetic(gf, seed, n_pairs, L, k):
     exp = CO.screen_reads(c["reads_blob"], L, c["flanks"], k)
     assert _same(hits, exp) and len(exp) > 100
     if L <= 250:      # the partitioned filters (packed reads up to 64 bytes) on the same reads, with a 2^27-bit bitmap:
-        for variant in (14, 15):      # 16 buckets with per-wave rows / 256 buckets with the workgroup sort
+        for variant in (14, 15, 16):  # 16 buckets with per-wave rows / 256 buckets with the workgroup sort, 8-byte pairs / 4-byte pairs
             gf.set_option("screen_variant", variant)
             gf.set_option("bitmap_log2", 27)
             try:
@@ -507,9 +507,18 @@ def test_partitioned_filter_probes_in_place_when_a_bucket_part_runs_full(gf):
         gf.set_option("screen_variant", 15)        # 256 buckets: the same degenerate reads overflow a workgroup's part
         gf.set_option("bitmap_log2", 27)
         assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
+        gf.set_option("screen_variant", 16)        # 4-byte pairs: a full part is tested on the spot and resolved by the lane itself
+        assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
+        gf.set_option("screen_pf4_cap8", 256)      # ... and so is every pair beyond a (here: tiny) pair list
+        assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
+        for cut in (1, 5, 67):                     # read counts that end inside an octet / a tile
+            blob2 = blob[:len(blob) - cut * L]
+            packed2, _ = GapFill.pack_reads(blob2, L)
+            assert _same(gf.screen_reads(packed2, L, 31, cap=1 << 18), CO.screen_reads(blob2, L, flanks, 31)), cut
     finally:
         gf.set_option("screen_variant", 0)
         gf.set_option("bitmap_log2", 0)
+        gf.set_option("screen_pf4_cap8", 0)
 
 
 def test_human_scale_key_set_all_filter_kernels_agree_on_20M_reads(gf):
@@ -536,7 +545,12 @@ def test_human_scale_key_set_all_filter_kernels_agree_on_20M_reads(gf):
             res[variant] = gf.screen_reads(packed, L, k, cap=1 << 20)
     finally:
         gf.set_option("screen_variant", 0)
-    assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[15]) and _same(res[0], res[9])
+    assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[15]) and _same(res[0], res[9])   # (0 = the 4-byte-pair filter)
+    try:   # a short pair list: most pairs that are in the exact set take the serial path
+        gf.set_option("screen_pf4_cap8", 1 << 16)
+        assert _same(res[0], gf.screen_reads(packed, L, k, cap=1 << 20))
+    finally:
+        gf.set_option("screen_pf4_cap8", 0)
     m = 400_000
     exp = CO.screen_reads(CO.unpack_reads(packed[:m], L), L, flanks, k)
     head = res[0][res[0]["read"] < m]
