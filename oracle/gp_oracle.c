@@ -188,6 +188,100 @@ size_t or_quick_check(const char* seqs, const uint64_t* off, size_t n, int k, ui
     return cnt;
 }
 
+/* ------------------------------------------------------------------ f-3, second stage: the overlap evaluation of one node pair
+   ContigsCompactor::Evaluate + IsScoreSignificant + ContigsCompactorAction::SetMergedStringConcat / IsContainment
+   (ContigsCompactor-v0.2.0/ContigsMerger/ContigsCompactor.cpp:1572-1976, :108-159).  Overlap alignment: first row and column 0,
+   match +1, mismatch (int)mismatch (the reference assigns the double to an int, :1640), indel as given; predecessor order
+   diagonal, then (i-1, j), then (i, j-1), each replacing only on a strictly larger score (:1651-1666).  The end cell is the
+   maximum over the last column / last row shifted in by c = 0 .. max_clip (:1679-1708; strict >, so the first cell in that scan
+   order wins; the reference keeps the maximum in an int, :1674).  The trace back ends on row 0 or column 0 (:1763-1808); whether
+   it is row 0 / column 0 is all the caller uses of it (the contained flag, :1830-1833), so that is carried forward with the scores
+   instead of a trace-back table. */
+void or_overlap_evaluate(const char* s1, int n1, const char* s2, int n2, const or_ovl_params* pr, or_ovl_result* out) {
+    const int mis = (int)pr->mismatch;
+    const int W = n2 + 1;
+    const int clip = (int)pr->max_clip;                      /* `c <= maxOverlapClipLen` with a double bound */
+    double* prev = malloc((size_t)W * sizeof(double));
+    double* cur = malloc((size_t)W * sizeof(double));
+    unsigned char* fprev = malloc((size_t)W);               /* bit 0: the path starts on row 0, bit 1: on column 0 */
+    unsigned char* fcur = malloc((size_t)W);
+    /* scores and start flags of the last clip + 1 columns (every row) and of the last clip + 1 rows (every column) */
+    const int CW = clip + 1;
+    double* colS = malloc((size_t)(n1 + 1) * CW * sizeof(double));
+    unsigned char* colF = malloc((size_t)(n1 + 1) * CW);
+    double* rowS = malloc((size_t)CW * W * sizeof(double));
+    unsigned char* rowF = malloc((size_t)CW * W);
+    for (int i = 0; i <= n1; ++i) {
+        if (i == 0) {
+            for (int j = 0; j <= n2; ++j) { cur[j] = 0.0; fcur[j] = (unsigned char)(1 | (j == 0 ? 2 : 0)); }
+        } else {
+            cur[0] = 0.0; fcur[0] = 2;
+            for (int j = 1; j <= n2; ++j) {
+                double sc = prev[j - 1] + (s1[i - 1] == s2[j - 1] ? 1 : mis);
+                unsigned char f = fprev[j - 1];
+                if (sc < prev[j] + pr->indel) { sc = prev[j] + pr->indel; f = fprev[j]; }
+                if (sc < cur[j - 1] + pr->indel) { sc = cur[j - 1] + pr->indel; f = fcur[j - 1]; }
+                cur[j] = sc; fcur[j] = f;
+            }
+        }
+        for (int c = 0; c < CW; ++c) {
+            const int col = n2 - c;
+            if (col >= 0) { colS[(size_t)i * CW + c] = cur[col]; colF[(size_t)i * CW + c] = fcur[col]; }
+        }
+        if (n1 - i < CW) {
+            const int c = n1 - i;
+            for (int j = 0; j <= n2; ++j) { rowS[(size_t)c * W + j] = cur[j]; rowF[(size_t)c * W + j] = fcur[j]; }
+        }
+        { double* t = prev; prev = cur; cur = t; }
+        { unsigned char* t = fprev; fprev = fcur; fcur = t; }
+    }
+    int score_max = -1000000000, row_end = -1, col_end = -1, nclip = -1;
+    unsigned char fend = 0;
+    for (int c = 0; c <= clip; ++c) {
+        for (int i = 0; i <= n1; ++i) {
+            const int icol = n2 - c;
+            if (icol < 0) break;
+            if (colS[(size_t)i * CW + c] > score_max) { score_max = (int)colS[(size_t)i * CW + c]; col_end = icol; row_end = i; nclip = c; fend = colF[(size_t)i * CW + c]; }
+        }
+        for (int j = 0; j <= n2; ++j) {
+            const int irow = n1 - c;
+            if (irow < 0) break;
+            if (rowS[(size_t)c * W + j] > score_max) { score_max = (int)rowS[(size_t)c * W + j]; col_end = j; row_end = irow; nclip = c; fend = rowF[(size_t)c * W + j]; }
+        }
+    }
+    free(prev); free(cur); free(fprev); free(fcur); free(colS); free(colF); free(rowS); free(rowF);
+    /* IsScoreSignificant, :1875-1976 */
+    int res;
+    {
+        int ov0 = n1 < n2 ? n1 : n2, ov1 = ov0, ov2 = ov0;
+        if (row_end + nclip == n1) ov1 = col_end;
+        if (col_end + nclip == n2) ov2 = row_end;
+        int ov = ov1 < ov2 ? ov1 : ov2;
+        if (ov0 < ov) ov = ov0;
+        res = 2;
+        if (ov < n1 * pr->frac_min_overlap && ov < n2 * pr->frac_min_overlap) res = 0;
+        else if (row_end + nclip == n1 && col_end + 5 - 1 >= n2) res = 0;
+        else if (col_end + nclip == n2 && row_end + 5 - 1 >= n1) res = 0;
+        else if (score_max < ov * (1 - pr->frac_loss)) res = 0;
+        else if (ov < pr->min_overlap_scaffold) res = 0;
+        else if (ov < pr->min_overlap) res = 1;
+    }
+    memset(out, 0, sizeof *out);
+    out->res = res; out->row_end = row_end; out->col_end = col_end; out->nclip = nclip; out->score = score_max;
+    if (res == 0) return;                                    /* the reference returns before it fills the action */
+    const int contained = (row_end + nclip == n1 && (fend & 1)) || (col_end + nclip == n2 && (fend & 2));
+    int merged;                                              /* SetMergedStringConcat, :108-153 */
+    if (contained && row_end + nclip == n1 && n1 < n2) merged = n2;
+    else if (contained && col_end + nclip == n2 && n2 < n1) merged = n1;
+    else if (row_end + nclip == n1) merged = (n1 - nclip) + (n2 - col_end);
+    else merged = (n2 - nclip) + (n1 - row_end);
+    out->contained = contained;
+    out->merged_len = merged;
+    out->overlap = n1 + n2 - nclip - merged;                 /* GetOverlapSize */
+    out->containment = contained && ((row_end + nclip == n1 && n1 < col_end) || (col_end + nclip == n2 && n2 < row_end));   /* IsContainment */
+    out->first_goes_first = (row_end + nclip) == n1;         /* threadMergeContigV2, :656-670: MODE_1_2, else MODE_2_1 */
+}
+
 /* ------------------------------------------------------------------ a-3: second hop */
 size_t or_tag_low_mapq(const or_alnrec* recs, size_t n, const or_dpos* table, size_t n_rows, or_taghit* out, size_t cap) {
     size_t cnt = 0;

@@ -43,10 +43,10 @@ with open("%s/r02_pmc_summary_%s.csv" % (dst, cfg), "w") as f:
         for cn in sorted(acc[kn]):
             v = acc[kn][cn]
             w.writerow([short(kn), cn, len(v), "%.6g" % (sum(v) / len(v))])
-# the dominant kernel group = the screen filter: pf2_scatter + pf2_probe (256-bucket partitioned), pf_scatter + pf_probe (16-bucket) or screen_filter_* (one kernel)
+# the dominant kernel group = the screen filter: pf4_scatter + pf4_probe + pf4_resolve + pf4_list (256 buckets, 4-byte pairs), pf2_* (8-byte pairs), pf_* (16 buckets) or screen_filter_* (one kernel)
 kern, tot_traffic, tot_ns = {}, 0.0, 0.0
 for n in acc:
-    if not any(t in n for t in ("pf_scatter", "pf_probe", "pf2_scatter", "pf2_probe", "screen_filter")) or "FETCH_SIZE" not in acc[n] or "WRITE_SIZE" not in acc[n]:
+    if not any(t in n for t in ("pf_scatter", "pf_probe", "pf2_scatter", "pf2_probe", "pf4_scatter", "pf4_probe", "pf4_resolve", "pf4_list", "screen_filter")) or "FETCH_SIZE" not in acc[n] or "WRITE_SIZE" not in acc[n]:
         continue
     fch, wr = (sum(acc[n][c]) / len(acc[n][c]) for c in ("FETCH_SIZE", "WRITE_SIZE"))
     kern[n] = {"FETCH_SIZE_kb": fch, "WRITE_SIZE_kb": wr, "traffic_bytes_per_launch": (2 * fch + wr) * 1024.0, "rocprof_avg_launch_ns": avg.get(n)}
