@@ -21,6 +21,10 @@ SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", 
                       ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4"),
                       ("library", "<u4"), ("reserved", "<u4")])
 QCPAIR = np.dtype([("set", "<u4"), ("i", "<u4"), ("j", "<u4")])
+OVL_PARAMS = np.dtype([("mismatch", "<f8"), ("indel", "<f8"), ("max_clip", "<f8"), ("frac_min_overlap", "<f8"), ("frac_loss", "<f8"),
+                       ("min_overlap", "<f8"), ("min_overlap_scaffold", "<f8")])
+OVL_RESULT = np.dtype([(n, "<i4") for n in ("res", "row_end", "col_end", "nclip", "score", "contained", "merged_len", "overlap",
+                                            "containment", "first_goes_first")])
 assert CONTIG.itemsize == 32 and GAP.itemsize == 16 and ALNREC.itemsize == 32 and TAGHIT.itemsize == 12 and DPOS.itemsize == 16 and HIT.itemsize == 8
 
 GF_OK, GF_E_INVAL, GF_E_NODEV, GF_E_NOMEM, GF_E_NOSPACE, GF_E_STATE, GF_E_UNSUPPORTED, GF_E_FORMAT = 0, -1, -2, -3, -4, -5, -6, -7
@@ -95,6 +99,8 @@ def lib():
         "gf_pools_merge_dev": (i32, [vp, vp, sz, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz, vp, vp]),
         "gf_quick_check": (i32, [vp, C.c_char_p, vp, vp, sz, i32, vp, sz, szp]),
         "gf_quick_check_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, vp, sz, vp]),
+        "gf_overlap_evaluate": (i32, [vp, C.c_char_p, vp, vp, sz, vp, sz, vp, vp]),
+        "gf_overlap_evaluate_dev": (i32, [vp, vp, vp, vp, vp, sz, vp, vp]),
         "gf_pick_anchored_dev": (i32, [vp, vp, vp, sz, vp, i32, vp, vp]),
         "gf_count_kmers": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp, sz, szp]),
         "gf_pool_keys_reset": (i32, [vp, vp]),

@@ -101,10 +101,13 @@ class GapAssembler:
     assembly_given_list = assembly
 
     def run_contigs_merge(self, fa_list):
-        """assemble_gaps.py:301-306 / run_merge :138-145.  Of the reference's merge step only the first stage is built: the
-        candidate pairs of ContigsMerger's 10-mer prefilter, on the GPU (MergeContigs.merge_candidates); contigs.fa stays as is."""
-        from .MergeContigs import merge_candidates
-        return merge_candidates(_ctx(), working_folder, fa_list)
+        """assemble_gaps.py:301-306 / run_merge :138-145.  Of the reference's merge step the first two stages of ContigsMerger are
+        built, on the GPU: the candidate pairs of its 10-mer prefilter and their overlap evaluation = the edges of its overlap graph
+        (MergeContigs.merge_candidates / merge_edges); the path search and the TERefiner dedup are not: contigs.fa stays as is."""
+        from .MergeContigs import merge_candidates, merge_edges
+        cand = merge_candidates(_ctx(), working_folder, fa_list)
+        merge_edges(_ctx(), working_folder, fa_list)
+        return cand
 
     def pick_already_constructed(self, contigs_select, fa_list, sf_picked):
         picked = contigs_select.get_already_picked(sf_picked)

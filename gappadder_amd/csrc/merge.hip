@@ -157,6 +157,145 @@ __global__ __launch_bounds__(1024) void quick_check_kernel(QcParams P) {
     }
 }
 
+// ---- f-3, second stage: the overlap evaluation of a node pair (ContigsCompactor::Evaluate + IsScoreSignificant +
+// ContigsCompactorAction::SetMergedStringConcat / IsContainment, ContigsCompactor-v0.2.0/ContigsMerger/ContigsCompactor.cpp:1572-1976,
+// :108-159; semantics restated in oracle/gp_oracle.c::or_overlap_evaluate, pinned on the reference's own answers).  An overlap
+// alignment (first row / column 0, match +1, mismatch, indel; predecessor order diagonal, up, left, each only on a strictly larger
+// score); the end cell is the maximum over the last column / row shifted in by c = 0 .. max_clip in the reference's scan order.
+// One workgroup per pair sweeps the anti-diagonals (three rolling diagonals of integer scores in LDS — the scores are integers
+// whenever the indel score is, which the entry point requires); the reference's trace-back table is not needed: all its caller
+// uses of the trace back is whether the path starts on row 0 or on column 0, two bits that travel with the scores; the end cell is
+// kept per thread as (score, rank in the reference's scan order) and reduced at the end.
+constexpr uint32_t OV_MAXLEN = 8190;
+struct OvParams {
+    const char* seq;
+    const unsigned long long* contig_off;
+    const unsigned long long* set_off;
+    const gf_qcpair* pairs;
+    uint32_t n_pairs;
+    gf_ovl_params pr;
+    gf_ovl_result* out;
+    uint32_t* next;
+};
+
+__global__ __launch_bounds__(256) void overlap_eval_kernel(OvParams P) {
+    extern __shared__ uint32_t sm[];   // [3 x (OV_MAXLEN + 2) scores][3 x (OV_MAXLEN + 2) start flags (bytes)][node 1][node 2]
+    __shared__ uint32_t s_pair;
+    __shared__ long long s_best_sc[256];
+    __shared__ unsigned long long s_best_rk[256];
+    constexpr uint32_t ROW = OV_MAXLEN + 2;
+    int32_t* sc = reinterpret_cast<int32_t*>(sm);
+    uint8_t* fl = reinterpret_cast<uint8_t*>(sm + 3 * ROW);
+    char* a = reinterpret_cast<char*>(fl + 3 * ROW);
+    char* b = a + ROW;
+    const uint32_t tid = threadIdx.x;
+    const int mis = (int)P.pr.mismatch, ind = (int)P.pr.indel, clip = (int)P.pr.max_clip;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_pair = atomicAdd(P.next, 1u);
+        __syncthreads();
+        const uint32_t pi = s_pair;
+        if (pi >= P.n_pairs) break;
+        const gf_qcpair q = P.pairs[pi];
+        const unsigned long long c0 = P.set_off[q.set];
+        const unsigned long long o1 = P.contig_off[c0 + q.i / 2], e1 = P.contig_off[c0 + q.i / 2 + 1];
+        const unsigned long long o2 = P.contig_off[c0 + q.j / 2], e2 = P.contig_off[c0 + q.j / 2 + 1];
+        const int n1 = (int)(e1 - o1), n2 = (int)(e2 - o2);
+        gf_ovl_result r;
+        memset(&r, 0, sizeof r);
+        if (n1 > (int)OV_MAXLEN || n2 > (int)OV_MAXLEN || n1 < 1 || n2 < 1) {
+            if (tid == 0) { r.res = -1; P.out[pi] = r; }
+            continue;
+        }
+        auto load_node = [&](char* dst, unsigned long long o, int n, bool rc) {
+            for (int i = (int)tid; i < n; i += 256) {
+                char ch = P.seq[o + (rc ? n - 1 - i : i)];
+                if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+                if (rc) ch = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
+                dst[i] = ch;
+            }
+        };
+        load_node(a, o1, n1, q.i & 1);
+        load_node(b, o2, n2, q.j & 1);
+        long long best_sc = -1000000000ll;
+        unsigned long long best_rk = ~0ull;   // c << 40 | (row candidate) << 39 | index << 2 | start flags
+        __syncthreads();
+        for (int d = 0; d <= n1 + n2; ++d) {
+            int32_t* cur = sc + (d % 3) * ROW;
+            const int32_t* p1 = sc + ((d + 2) % 3) * ROW;   // diagonal d - 1
+            const int32_t* p2 = sc + ((d + 1) % 3) * ROW;   // diagonal d - 2
+            uint8_t* fcur = fl + (d % 3) * ROW;
+            const uint8_t* f1 = fl + ((d + 2) % 3) * ROW;
+            const uint8_t* f2 = fl + ((d + 1) % 3) * ROW;
+            const int ilo = d > n2 ? d - n2 : 0, ihi = d < n1 ? d : n1;
+            for (int i = ilo + (int)tid; i <= ihi; i += 256) {
+                const int j = d - i;
+                int s;
+                uint32_t f;
+                if (i == 0) { s = 0; f = 1u | (j == 0 ? 2u : 0u); }
+                else if (j == 0) { s = 0; f = 2u; }
+                else {
+                    s = p2[i - 1] + (a[i - 1] == b[j - 1] ? 1 : mis);
+                    f = f2[i - 1];
+                    const int up = p1[i - 1] + ind, lf = p1[i] + ind;
+                    if (s < up) { s = up; f = f1[i - 1]; }
+                    if (s < lf) { s = lf; f = f1[i]; }
+                }
+                cur[i] = s;
+                fcur[i] = (uint8_t)f;
+                // end-cell candidates: column n2 - c (scanned over i) before row n1 - c (scanned over j), c ascending
+                unsigned long long rk = ~0ull;
+                if (n2 - j <= clip) rk = ((unsigned long long)(n2 - j) << 40) | ((unsigned long long)i << 2);
+                if (n1 - i <= clip) {
+                    const unsigned long long rr = ((unsigned long long)(n1 - i) << 40) | (1ull << 39) | ((unsigned long long)j << 2);
+                    if (rr < rk) rk = rr;
+                }
+                if (rk != ~0ull && (s > best_sc || (s == best_sc && rk < (best_rk & ~3ull)))) { best_sc = s; best_rk = rk | f; }
+            }
+            __syncthreads();
+        }
+        s_best_sc[tid] = best_sc;
+        s_best_rk[tid] = best_rk;
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t t = 1; t < 256; ++t)
+                if (s_best_sc[t] > best_sc || (s_best_sc[t] == best_sc && (s_best_rk[t] & ~3ull) < (best_rk & ~3ull))) { best_sc = s_best_sc[t]; best_rk = s_best_rk[t]; }
+            const int nclip = (int)(best_rk >> 40);
+            const bool rowc = (best_rk >> 39) & 1u;
+            const int idx = (int)((best_rk >> 2) & 0x1FFFFFFFFull), fend = (int)(best_rk & 3u);
+            const int row_end = rowc ? n1 - nclip : idx, col_end = rowc ? idx : n2 - nclip;
+            const int score = (int)best_sc;
+            int ov0 = n1 < n2 ? n1 : n2, ov1 = ov0, ov2 = ov0;
+            if (row_end + nclip == n1) ov1 = col_end;
+            if (col_end + nclip == n2) ov2 = row_end;
+            int ov = ov1 < ov2 ? ov1 : ov2;
+            if (ov0 < ov) ov = ov0;
+            int res = 2;
+            if (ov < n1 * P.pr.frac_min_overlap && ov < n2 * P.pr.frac_min_overlap) res = 0;
+            else if (row_end + nclip == n1 && col_end + 5 - 1 >= n2) res = 0;
+            else if (col_end + nclip == n2 && row_end + 5 - 1 >= n1) res = 0;
+            else if (score < ov * (1 - P.pr.frac_loss)) res = 0;
+            else if (ov < P.pr.min_overlap_scaffold) res = 0;
+            else if (ov < P.pr.min_overlap) res = 1;
+            r.res = res; r.row_end = row_end; r.col_end = col_end; r.nclip = nclip; r.score = score;
+            if (res) {
+                const int contained = (row_end + nclip == n1 && (fend & 1)) || (col_end + nclip == n2 && (fend & 2));
+                int merged;
+                if (contained && row_end + nclip == n1 && n1 < n2) merged = n2;
+                else if (contained && col_end + nclip == n2 && n2 < n1) merged = n1;
+                else if (row_end + nclip == n1) merged = (n1 - nclip) + (n2 - col_end);
+                else merged = (n2 - nclip) + (n1 - row_end);
+                r.contained = contained;
+                r.merged_len = merged;
+                r.overlap = n1 + n2 - nclip - merged;
+                r.containment = contained && ((row_end + nclip == n1 && n1 < col_end) || (col_end + nclip == n2 && n2 < row_end));
+                r.first_goes_first = (row_end + nclip) == n1;
+            }
+            P.out[pi] = r;
+        }
+    }
+}
+
 }  // namespace gf
 
 using namespace gf;
@@ -240,6 +379,78 @@ int gf_quick_check(gf_ctx* ctx, const char* seq, const uint64_t* contig_off, con
         if (a.i != b.i) return a.i < b.i;
         return a.j < b.j;
     });
+    return GF_OK;
+}
+
+int gf_overlap_evaluate_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off, const void* d_set_off, const void* d_pairs, size_t n_pairs,
+                            const gf_ovl_params* params, void* d_out) {
+    if (!ctx || !params || (n_pairs && (!d_seq || !d_contig_off || !d_set_off || !d_pairs || !d_out)) || n_pairs >= 0xFFFFFFFFull) return GF_E_INVAL;
+    // integer scores: the reference assigns the mismatch score to an int (ContigsCompactor.cpp:1640); with an integral indel score
+    // every cell is an integer and the kernel's int32 sweep is the reference's double table exactly
+    if (params->indel != (double)(int)params->indel || params->max_clip < 0 || params->max_clip > 1e6) {
+        ctx->last_error = "gf_overlap_evaluate: the indel score must be integral";
+        return GF_E_UNSUPPORTED;
+    }
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
+    uint32_t* d_next = (uint32_t*)ctx->counters.p + 11;
+    zero_regions(ctx, ZeroList{{d_next, nullptr, nullptr, nullptr}, {1, 0, 0, 0}});
+    if (!n_pairs) return GF_OK;
+    OvParams P;
+    P.seq = (const char*)d_seq;
+    P.contig_off = (const unsigned long long*)d_contig_off;
+    P.set_off = (const unsigned long long*)d_set_off;
+    P.pairs = (const gf_qcpair*)d_pairs;
+    P.n_pairs = (uint32_t)n_pairs;
+    P.pr = *params;
+    P.out = (gf_ovl_result*)d_out;
+    P.next = d_next;
+    const size_t lds = (size_t)3 * (OV_MAXLEN + 2) * 4 + (size_t)3 * (OV_MAXLEN + 2) + (size_t)2 * (OV_MAXLEN + 2) + 16;
+    {
+        LaunchTimer tm(ctx, GF_KERNEL_MERGE);
+        hipLaunchKernelGGL(overlap_eval_kernel, dim3((unsigned)std::min<size_t>(n_pairs, (size_t)ctx->n_cu)), dim3(256), lds, ctx->stream, P);
+    }
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+int gf_overlap_evaluate(gf_ctx* ctx, const char* seq, const uint64_t* contig_off, const uint64_t* set_off, size_t n_sets, const gf_qcpair* pairs,
+                        size_t n_pairs, const gf_ovl_params* params, gf_ovl_result* out) {
+    if (!ctx || !params || (n_pairs && (!seq || !contig_off || !set_off || !pairs || !out || !n_sets))) return GF_E_INVAL;
+    if (!n_pairs) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n_contigs = (size_t)set_off[n_sets];
+    const size_t n_bytes = (size_t)contig_off[n_contigs];
+    for (size_t p = 0; p < n_pairs; ++p) {
+        if (pairs[p].set >= n_sets) return GF_E_INVAL;
+        const size_t nc = (size_t)(set_off[pairs[p].set + 1] - set_off[pairs[p].set]);
+        if (pairs[p].i >= 2 * nc || pairs[p].j >= 2 * nc) return GF_E_INVAL;
+        for (uint32_t nd : {pairs[p].i, pairs[p].j}) {
+            const size_t c = (size_t)set_off[pairs[p].set] + nd / 2;
+            const uint64_t len = contig_off[c + 1] - contig_off[c];
+            if (contig_off[c] > contig_off[c + 1] || len < 1 || len > OV_MAXLEN) {
+                ctx->last_error = "gf_overlap_evaluate: contig " + std::to_string(c) + " is empty or longer than " + std::to_string(OV_MAXLEN) + " bases";
+                return GF_E_INVAL;
+            }
+        }
+    }
+    int rc;
+    const size_t b_seq = (n_bytes + 63) & ~(size_t)63, b_co = ((n_contigs + 1) * 8 + 63) & ~(size_t)63, b_so = ((n_sets + 1) * 8 + 63) & ~(size_t)63,
+                 b_pr = (n_pairs * sizeof(gf_qcpair) + 63) & ~(size_t)63;
+    if ((rc = ensure(ctx, ctx->stage_in, b_seq + b_co + b_so + b_pr + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, n_pairs * sizeof(gf_ovl_result) + 64))) return rc;
+    uint8_t* d_seq = (uint8_t*)ctx->stage_in.p;
+    uint8_t* d_co = d_seq + b_seq;
+    uint8_t* d_so = d_co + b_co;
+    uint8_t* d_pr = d_so + b_so;
+    GF_HIP(ctx, hipMemcpyAsync(d_seq, seq, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(d_co, contig_off, (n_contigs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(d_so, set_off, (n_sets + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(d_pr, pairs, n_pairs * sizeof(gf_qcpair), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = gf_overlap_evaluate_dev(ctx, d_seq, d_co, d_so, d_pr, n_pairs, params, ctx->stage_out.p))) return rc;
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GF_HIP(ctx, hipMemcpy(out, ctx->stage_out.p, n_pairs * sizeof(gf_ovl_result), hipMemcpyDeviceToHost));
     return GF_OK;
 }
 

@@ -260,6 +260,28 @@ class GapFill:
             self._chk(rc, "gf_quick_check")
             return out[:n.value]
 
+    # ContigsMerger's options as GAPPadder sets them (MergeContigs.py:75: -s 0.4 -i1 -2.0 -i2 -2.0 -x 12 -y 50) + its defaults (main.cpp:24-27)
+    MERGER_PARAMS = (-2.0, -2.0, 50.0, 0.005, 0.4, 12.0, 6.0)
+
+    def overlap_evaluate(self, contig_sets, pairs, params=None):
+        """The contig merger's pairwise overlap evaluation (ContigsCompactor::Evaluate, ContigsCompactor.cpp:1572-1976) of the
+        ordered node pairs `pairs` (B.QCPAIR triples: set, i, j; nodes = 2 * contig + strand) -> B.OVL_RESULT array, same order."""
+        pairs = np.ascontiguousarray(pairs, dtype=B.QCPAIR)
+        out = np.zeros(len(pairs), dtype=B.OVL_RESULT)
+        if not len(pairs):
+            return out
+        flat = [c for cs in contig_sets for c in cs]
+        blob = "".join(flat).encode()
+        coff = np.zeros(len(flat) + 1, dtype=np.uint64)
+        coff[1:] = np.cumsum([len(c) for c in flat])
+        soff = np.zeros(len(contig_sets) + 1, dtype=np.uint64)
+        soff[1:] = np.cumsum([len(cs) for cs in contig_sets])
+        pr = np.zeros(1, dtype=B.OVL_PARAMS)
+        pr[0] = tuple(self.MERGER_PARAMS if params is None else params)
+        self._chk(self._L.gf_overlap_evaluate(self._h, blob, B._p(coff), B._p(soff), len(contig_sets), B._p(pairs), len(pairs), B._p(pr), B._p(out)),
+                  "gf_overlap_evaluate")
+        return out
+
     # ---- timing -------------------------------------------------------------------------------------
     def timing(self, on=True):
         self._chk(self._L.gf_timing_enable(self._h, 1 if on else 0), "gf_timing_enable")

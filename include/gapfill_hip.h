@@ -361,6 +361,32 @@ int gf_quick_check(gf_ctx* ctx, const char* seq, const uint64_t* contig_off, con
 int gf_quick_check_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off, const void* d_set_off, size_t n_sets,
                        size_t max_set_contigs, int k, void* d_out, size_t cap, void* d_n_out);
 
+/* ---- §8f-3, second stage: the contig merger's pairwise overlap evaluation (ContigsCompactor::Evaluate + IsScoreSignificant +
+ * ContigsCompactorAction, ContigsCompactor-v0.2.0/ContigsMerger/ContigsCompactor.cpp:1572-1976, :108-159): an overlap alignment of
+ * node i against node j (match +1, `mismatch` truncated to an int as the reference does, `indel`; ends may be clipped by up to
+ * `max_clip` bases) classified like IsScoreSignificant.  Parameters = ContigsMerger's options (main.cpp:60-200): -i1 mismatch,
+ * -i2 indel, -y max_clip, -c frac_min_overlap, -s frac_loss, -x min_overlap, -z min_overlap_scaffold; GAPPadder runs it with
+ * -s 0.4 -i1 -2.0 -i2 -2.0 -x 12 -y 50 (MergeContigs.py:75).  The indel score must be integral (GF_E_UNSUPPORTED otherwise); contigs
+ * up to 8190 bases.  Pairs are gf_qcpair {set, i, j} (ANY ordered node pair: i is the reference's pSeq1, j its pSeq2). */
+typedef struct {
+    double mismatch, indel, max_clip, frac_min_overlap, frac_loss, min_overlap, min_overlap_scaffold;
+} gf_ovl_params;
+typedef struct {
+    int32_t res;              /* 0 no usable overlap, 1 overlap in [min_overlap_scaffold, min_overlap), 2 overlap >= min_overlap; -1: contig too long */
+    int32_t row_end, col_end; /* end cell of the alignment (posRowEnd, posColEnd) */
+    int32_t nclip;            /* bases clipped at one end */
+    int32_t score;
+    int32_t contained;        /* res != 0 only from here on: the action's contained flag */
+    int32_t merged_len;       /* length of SetMergedStringConcat's string */
+    int32_t overlap;          /* GetOverlapSize */
+    int32_t containment;      /* IsContainment: such pairs form no edge (ContigsCompactor.cpp:672-674) */
+    int32_t first_goes_first; /* 1: MODE_1_2 (node i then node j), 0: MODE_2_1 (:656-670) */
+} gf_ovl_result;
+int gf_overlap_evaluate(gf_ctx* ctx, const char* seq, const uint64_t* contig_off, const uint64_t* set_off, size_t n_sets, const gf_qcpair* pairs,
+                        size_t n_pairs, const gf_ovl_params* params, gf_ovl_result* out);
+int gf_overlap_evaluate_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off, const void* d_set_off, const void* d_pairs, size_t n_pairs,
+                            const gf_ovl_params* params, void* d_out);
+
 /* ---- device memory + timing helpers (so a ctypes host needs no other HIP binding) ---------------------- */
 int gf_dev_alloc(gf_ctx* ctx, size_t bytes, void** d_ptr);
 int gf_dev_free(gf_ctx* ctx, void* d_ptr);

@@ -50,6 +50,8 @@ def lib():
         L.or_assemble_pool2.argtypes = [C.c_char_p, sz, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
         L.or_quick_check.restype = sz
         L.or_quick_check.argtypes = [C.c_char_p, vp, sz, i32, vp, vp, sz]
+        L.or_overlap_evaluate.restype = None
+        L.or_overlap_evaluate.argtypes = [C.c_char_p, i32, C.c_char_p, i32, vp, vp]
         L.or_synth_pairs.restype = None
         L.or_synth_pairs.argtypes = [vp, C.c_uint64, sz, vp, vp]
         L.or_synth_layout.restype = None
@@ -184,3 +186,28 @@ def quick_check(contigs, k=10):
     m = lib().or_quick_check(blob, _p(off), len(contigs), k, _p(oi), _p(oj), cap)
     assert m <= cap
     return list(zip(oi[:m].tolist(), oj[:m].tolist()))
+
+
+OVL_PARAMS = np.dtype([("mismatch", "<f8"), ("indel", "<f8"), ("max_clip", "<f8"), ("frac_min_overlap", "<f8"), ("frac_loss", "<f8"),
+                       ("min_overlap", "<f8"), ("min_overlap_scaffold", "<f8")])
+OVL_RESULT = np.dtype([(n, "<i4") for n in ("res", "row_end", "col_end", "nclip", "score", "contained", "merged_len", "overlap",
+                                            "containment", "first_goes_first")])
+GAPPADDER_OVL = (-2.0, -2.0, 50.0, 0.005, 0.4, 12.0, 6.0)   # MergeContigs.py:75 (-i1 -i2 -y -s -x) + ContigsMerger's defaults (main.cpp:24-27)
+
+
+def merger_nodes(contigs):
+    """The contig merger's node list [c0, revcomp(c0), c1, ...] (CompactVer3, ContigsCompactor.cpp:782-800; upper-cased)."""
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    out = []
+    for c in contigs:
+        c = c.upper()
+        out += [c, "".join(comp.get(ch, ch) for ch in reversed(c))]
+    return out
+
+
+def overlap_evaluate(s1, s2, params=GAPPADDER_OVL):
+    """ContigsCompactor::Evaluate on one ordered pair of node strings -> dict of OVL_RESULT fields."""
+    pr = np.zeros(1, OVL_PARAMS); pr[0] = tuple(params)
+    out = np.zeros(1, OVL_RESULT)
+    lib().or_overlap_evaluate(s1.encode(), len(s1), s2.encode(), len(s2), _p(pr), _p(out))
+    return {n: int(out[0][n]) for n in OVL_RESULT.names}

@@ -372,11 +372,60 @@ def quickcheck_kat():
     print("quickcheck_kat:", len(out), "cases,", sum(len(o["pairs"]) for o in out), "feasible pairs")
 
 
+def evaluate_kat():
+    """Known answers from the reference's own pairwise overlap evaluation of the contig merger (ContigsCompactor::Evaluate,
+    ContigsCompactor.cpp:1572-1976), built into oracle/_ref/evaluate_kat: contig sets + parameters -> the result of every ordered node
+    pair (class; for classes 1/2: end row, clip, overlap size, merged length, containment)."""
+    import random
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "ref"])
+    exe = os.path.join(REPO, "oracle", "_ref", "evaluate_kat")
+    rng = random.Random(20260302)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+    def noisy(s, subs, indels):
+        s = list(s)
+        for _ in range(subs):
+            i = rng.randrange(len(s)); s[i] = rng.choice([c for c in "ACGT" if c != s[i]])
+        for _ in range(indels):
+            i = rng.randrange(1, len(s) - 1)
+            if rng.random() < 0.5: del s[i]
+            else: s.insert(i, rng.choice("ACGT"))
+        return "".join(s)
+    gappadder = (-2.0, -2.0, 50, 0.005, 0.4, 12, 6)          # MergeContigs.py:75: -i1 -2.0 -i2 -2.0 -y 50 -s 0.4 -x 12; main.cpp:24-27 defaults
+    sets = []
+    g = rnd(900)
+    sets.append(([g[0:300], g[220:560], g[500:900]], gappadder))                                   # clean suffix-prefix overlaps
+    sets.append(([g[0:300], rc(g[220:560]), g[500:900], rnd(200)], gappadder))                     # one contig reverse-complemented, one unrelated
+    sets.append(([g[0:400], g[100:250], noisy(g[300:700], 6, 2), g[650:900] + rnd(40)], gappadder))  # containment; mismatches + indels; a dirty end (clip)
+    sets.append(([noisy(g[0:350], 10, 3), noisy(g[250:600], 10, 3), noisy(g[560:900], 4, 0)], gappadder))
+    sets.append(([g[0:300], g[220:560], g[500:900]], (-1.0, -1.0, 0, 0.005, 0.01, 100000, 6)))     # the tool's own defaults: class 1 only
+    sets.append(([g[0:120], g[100:230], g[225:300], rnd(30), g[0:120]], (-2.0, -2.0, 10, 0.3, 0.2, 25, 15)))   # short overlaps around the thresholds, a duplicate
+    sets.append(([rnd(rng.randrange(40, 160)) for _ in range(12)], gappadder))                     # unrelated contigs: chance overlaps at the ends
+    sets.append((["ACGT" * 20, "CGTA" * 15 + rnd(30), "A" * 50, "A" * 30 + rnd(20)], gappadder))   # repeats: many equal scores (tie-breaking)
+    out = []
+    tmp = tempfile.mkdtemp(prefix="gp_ev_")
+    try:
+        for ci, (contigs, pr) in enumerate(sets):
+            fa = os.path.join(tmp, "c%d.fa" % ci)
+            with open(fa, "w") as f:
+                f.write("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(contigs)))
+            lines = subprocess.check_output([exe, fa] + [repr(float(x)) for x in pr]).decode().strip().split("\n")
+            out.append({"contigs": contigs, "params": list(pr), "results": [[int(x) for x in l.split()] for l in lines]})
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with gzip.GzipFile(os.path.join(HERE, "evaluate_kat.json.gz"), "wb", mtime=0) as gzf:
+        gzf.write(json.dumps(out, sort_keys=True).encode())
+    print("evaluate_kat:", len(out), "cases,", sum(len(o["results"]) for o in out), "node pairs,",
+          sum(1 for o in out for r in o["results"] if r[2]), "with an overlap")
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
     kmerutils_kat()
     quickcheck_kat()
+    evaluate_kat()
     for name, seed in (("twolib", 20260001), ("edge", 20260011), ("bounds", 20260031), ("c1", 20260001)):
         case = make_case(name, seed)
         d = os.path.join(HERE, name)

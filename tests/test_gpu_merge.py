@@ -1,5 +1,5 @@
 """GPU parity of the contig-merge prefilter (SURVEY.md §8f-3 first piece: QuickCheckerContigsMatch, ContigsCompactor.cpp:1982-2095)
-through the C ABI: the reference's own answers (tests/golden/quickcheck_kat.json.gz, printed by oracle/_ref/quickcheck_kat) and the
+and of the pairwise overlap evaluation (second piece: ContigsCompactor::Evaluate, :1572-1976) through the C ABI: the reference's own answers (tests/golden/quickcheck_kat.json.gz, printed by oracle/_ref/quickcheck_kat) and the
 oracle on contig sets as the assembly produces them."""
 import gzip
 import json
@@ -91,3 +91,72 @@ def test_quick_check_on_assembled_contigs(gf):
     assert got == want and len(want) > len(sets)
     # the same genome assembled at two k's overlaps itself: more than the diagonal is feasible
     assert any(i // 2 != j // 2 for _, i, j in want)
+
+
+OVL_FIELDS = ("res", "row_end", "col_end", "nclip", "score", "contained", "merged_len", "overlap", "containment", "first_goes_first")
+
+
+def _all_ordered_pairs(sets):
+    from gappadder_amd import _lib as B
+    tr = [(s, i, j) for s, cs in enumerate(sets) for i in range(2 * len(cs)) for j in range(2 * len(cs)) if i != j]
+    out = np.zeros(len(tr), dtype=B.QCPAIR)
+    out["set"], out["i"], out["j"] = [t[0] for t in tr], [t[1] for t in tr], [t[2] for t in tr]
+    return out
+
+
+def test_overlap_evaluate_equals_the_reference_vectors(gf):
+    """Every ordered node pair of every committed contig set against what the reference's own Evaluate printed
+    (tests/golden/evaluate_kat.json.gz), one GPU call per parameter set."""
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "evaluate_kat.json.gz"), "rt").read())
+    n_ovl = 0
+    for c in cases:
+        pairs = _all_ordered_pairs([c["contigs"]])
+        got = gf.overlap_evaluate([c["contigs"]], pairs, c["params"])
+        assert [(int(p["i"]), int(p["j"])) for p in pairs] == [(r[0], r[1]) for r in c["results"]]
+        for g, r in zip(got, c["results"]):
+            assert int(g["res"]) == r[2], (r, g)
+            if r[2]:
+                assert [int(g[f]) for f in ("row_end", "nclip", "overlap", "merged_len", "containment")] == r[3:], (r, g)
+                n_ovl += 1
+    assert n_ovl >= 100
+
+
+def test_overlap_evaluate_matches_oracle_on_assembly_like_sets(gf):
+    """Tilings of random genomes with substitutions and indels, both strands, lower case and N, contigs up to 3 kb, several sets in
+    one call; every field of every ordered pair against the oracle; and the edges merge_edges would write."""
+    rng = np.random.default_rng(11)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.integers(0, 4, n)].tobytes().decode()
+    sets = []
+    for s in range(6):
+        g = rnd(int(rng.integers(1500, 6000)))
+        cs = []
+        for _ in range(int(rng.integers(2, 7))):
+            a = int(rng.integers(0, len(g) - 200))
+            c = list(g[a:a + int(rng.integers(60, 3000 if s == 0 else 900))])
+            for _ in range(int(rng.integers(0, 6))):
+                i = int(rng.integers(1, len(c) - 1))
+                op = int(rng.integers(0, 3))
+                if op == 0: c[i] = "ACGT"[int(rng.integers(0, 4))]
+                elif op == 1: del c[i]
+                else: c.insert(i, "ACGT"[int(rng.integers(0, 4))])
+            c = "".join(c)
+            if rng.integers(0, 2):
+                c = c[::-1].translate(str.maketrans("ACGT", "TGCA"))
+            if rng.integers(0, 8) == 0:
+                c = c[:20] + "N" + c[21:]
+            if rng.integers(0, 8) == 0:
+                c = c.lower()
+            cs.append(c)
+        sets.append(cs)
+    pairs = _all_ordered_pairs(sets)
+    got = gf.overlap_evaluate(sets, pairs)
+    n_edge = 0
+    for p, g in zip(pairs, got):
+        nodes = CO.merger_nodes(sets[int(p["set"])])
+        exp = CO.overlap_evaluate(nodes[int(p["i"])], nodes[int(p["j"])])
+        assert {f: int(g[f]) for f in OVL_FIELDS} == exp, (int(p["set"]), int(p["i"]), int(p["j"]))
+        n_edge += exp["res"] == 2 and not exp["containment"]
+    assert n_edge > 10
+    with pytest.raises(Exception):
+        gf.overlap_evaluate(sets, pairs[:4], (-2.0, -1.5, 50.0, 0.005, 0.4, 12.0, 6.0))   # a fractional indel score is refused

@@ -121,3 +121,24 @@ def test_quick_check_equals_the_reference_prefilter():
         assert got == [tuple(p) for p in c["pairs"]], (c["k"], len(c["contigs"]))
         total += len(got)
     assert total > 300
+
+
+def test_overlap_evaluation_equals_the_reference():
+    """oracle or_overlap_evaluate vs the reference's own ContigsCompactor::Evaluate (oracle/_ref/evaluate_kat, ContigsCompactor.cpp:
+    1572-1976) on every ordered node pair of every committed contig set: class, and for classes 1/2 the end row, the clip, the
+    overlap size, the merged length and the containment flag."""
+    import gzip
+    from oracle import c_oracle as CO
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "evaluate_kat.json.gz"), "rt").read())
+    assert len(cases) >= 8
+    n_pairs = n_ovl = 0
+    for c in cases:
+        nodes = CO.merger_nodes(c["contigs"])
+        for r in c["results"]:
+            got = CO.overlap_evaluate(nodes[r[0]], nodes[r[1]], c["params"])
+            assert got["res"] == r[2], (r, got)
+            if r[2]:
+                assert [got["row_end"], got["nclip"], got["overlap"], got["merged_len"], got["containment"]] == r[3:], (r, got)
+                n_ovl += 1
+            n_pairs += 1
+    assert n_pairs >= 900 and n_ovl >= 100
