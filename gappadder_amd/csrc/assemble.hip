@@ -51,6 +51,7 @@ struct AsmParams {
     uint32_t* next_gap;        // work counter, zero at launch
     uint32_t keyslot;          // allow the key-in-slot count phase
     uint32_t diag;             // timing experiments (wrong results)
+    uint32_t ranked;           // allow the ranked table behind the pre-count
     uint32_t precount;         // allow the bit-array pre-count (k-mers seen fewer than min_count times never enter the table)
     unsigned long long* dbg;   // diagnostic runs only: 16 wall-clock stamps per gap (100 MHz), or null
 };
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
 
     // gaps are handed out through one counter: pool sizes differ, a static stride left CUs idle behind the largest gaps
     __shared__ uint32_t s_gap, s_cand;
+    __shared__ uint32_t s_scan[ASM_THREADS / 64];
     for (;;) {
         __syncthreads();
         if (tid == 0) s_gap = atomicAdd(P.next_gap, 1u);
@@ -541,6 +543,43 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 ASM_STAMP(8);
                 pre_built = true;
             }
+            // Ranked table (fingerprint slots behind a pre-count): the set bits of the last level ARE a perfect hash of the k-mers that
+            // get counted, up to the few that share a bit — a k-mer's slot is the rank of its bit (prefix of set bits per word + a
+            // popcount), so a look-up is ONE slot, no probe sequence (with linear probing a second probe happened in 7 % of the
+            // look-ups but in 99 % of the 64-lane steps, and every extra round costs the whole wave an LDS round trip).  A k-mer that
+            // finds another one on its bit goes to a small hashed overflow region behind the ranked slots.
+            bool ranked = false;
+            uint32_t n_set = 0, ovf_cap = 0;
+            if ((fpslot || keyslot) && pre && use_lds && P.ranked) {
+                uint32_t* fin = &g_lds[R];
+                uint32_t* pfx = fin + pre_words;                      // over the lower levels (dead now)
+                const uint32_t cw = (pre_words + ASM_THREADS - 1) / ASM_THREADS;
+                const uint32_t w0 = tid * cw < pre_words ? tid * cw : pre_words, w1 = w0 + cw < pre_words ? w0 + cw : pre_words;
+                uint32_t local = 0;
+                for (uint32_t w = w0; w < w1; ++w) local += (uint32_t)__popc(fin[w]);
+                uint32_t inc = local;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(inc, d);
+                    if ((int)lane >= d) inc += y;
+                }
+                if (lane == 63) s_scan[tid >> 6] = inc;
+                __syncthreads();
+                uint32_t wave_off = 0, total = 0;
+                for (uint32_t v = 0; v < ASM_THREADS / 64; ++v) { const uint32_t t = s_scan[v]; if (v < (tid >> 6)) wave_off += t; total += t; }
+                uint32_t run = wave_off + inc - local;
+                for (uint32_t w = w0; w < w1; ++w) { const uint32_t c = (uint32_t)__popc(fin[w]); pfx[w] = run; run += c; }
+                n_set = total;
+                // overflow region: as many slots as ranked ones when they fit (deep pools leave ~4 bits per window: a quarter of the
+                // counted k-mers share a bit), at least half as many
+                ovf_cap = n_set > 256 ? n_set : 256;
+                if (2 * (uint64_t)pre_words + 2 * ((uint64_t)n_set + ovf_cap) > r_words) ovf_cap = n_set / 2 > 256 ? n_set / 2 : 256;
+                ranked = 2 * (uint64_t)pre_words + 2 * ((uint64_t)n_set + ovf_cap) <= r_words;
+                if (ranked) {
+                    tab.off = R + 2 * pre_words;
+                    tab.cap = n_set + ovf_cap;
+                }
+                __syncthreads();
+            }
 #ifndef GF_KS_COMPLEMENT_LDS
 #define GF_KS_COMPLEMENT_LDS 0
 #endif
@@ -563,17 +602,43 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128&, const K128&) -> bool {
                     const unsigned long long keyhi = key.hi;
                     const uint64_t x = hash_p1<W>(key);
-                    if (pre && !pre_pass(x)) return false;
-                    uint32_t sl = slot_of_hash(x, t.cap);
+                    uint32_t lo_sl = 0, n_sl = t.cap;                                  // probe region [lo_sl, lo_sl + n_sl)
+                    if (LDS && ranked) {   // the slot of the k-mer's pre-count bit first (see `ranked`), the hashed overflow region behind it
+                        const uint32_t* fin = &g_lds[R];
+                        const uint32_t b = (uint32_t)(x >> 32) >> (32 - pre_log2);
+                        const uint32_t word = fin[b >> 5];
+                        if (!((word >> (b & 31)) & 1u)) return false;
+                        const uint32_t rnk = fin[pre_words + (b >> 5)] + (uint32_t)__popc(word & ((1u << (b & 31)) - 1u));
+                        unsigned long long v = t.load(rnk);
+                        if (v == kempty) {
+                            v = t.cas(rnk, kempty, (keyhi | 1ull) ^ xm);
+                            if (v == kempty) {   // first occurrence
+                                const uint32_t q = atomicAdd(&s_cnt[4], 1u);
+                                if (q < n_unit) { list_a[q] = rnk; dist_inst[q] = make_inst(r, p); }
+                                return false;
+                            }
+                        }
+                        if (((v ^ xm) & ~3ull) == keyhi) {
+                            while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment
+                                const unsigned long long o = t.cas(rnk, v, ((v ^ xm) + 1) ^ xm);
+                                if (o == v) break;
+                                v = o;
+                            }
+                            return false;
+                        }
+                        lo_sl = n_set; n_sl = ovf_cap;
+                    } else if (pre && !pre_pass(x)) return false;
+                    uint32_t sl = lo_sl + slot_of_hash(x, n_sl);
                     // insert / count: every decision is confirmed by a CAS, whose result replaces the loaded value
                     bool placed = false;
-                    for (uint32_t probes = 0; probes < t.cap; ++probes) {
+                    for (uint32_t probes = 0; probes < n_sl; ++probes) {
                         unsigned long long v = t.load(sl);
                         if (v == kempty) {
                             v = t.cas(sl, kempty, (keyhi | 1ull) ^ xm);
                             if (v == kempty) {   // first occurrence
                                 const uint32_t q = atomicAdd(&s_cnt[4], 1u);
-                                if (q >= limit) s_cnt[6] = 1;
+                                if (LDS && ranked) { if (atomicAdd(&s_cnt[7], 1u) >= ovf_cap - ovf_cap / 4) s_cnt[6] = 1; }
+                                else if (q >= limit) s_cnt[6] = 1;
                                 if (q < n_unit) { list_a[q] = sl; dist_inst[q] = make_inst(r, p); }
                                 placed = true;
                                 break;
@@ -588,7 +653,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                             placed = true;
                             break;
                         }
-                        sl = sl + 1 == t.cap ? 0 : sl + 1;
+                        sl = sl + 1 == lo_sl + n_sl ? lo_sl : sl + 1;
                     }
                     if (!placed) { if (LDS) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_KTABLE); }
                     return false;
@@ -749,22 +814,55 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 };
                 if (use_lds) count_keyslot_wide(std::true_type{}); else count_keyslot_wide(std::false_type{});
             } else if (fpslot) {
+                const uint32_t* fin = &g_lds[R];
+                const uint32_t* pfx = fin + pre_words;
                 for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128& fw, const K128& rc) -> bool {
                     const uint64_t x = hash_p1<W>(key);
-                    if (pre && !pre_pass(x)) return false;
-                    if (P.diag & 1) return false;
-                    uint32_t sl = slot_of_hash(x, tab.cap);
                     const unsigned long long fp = (x >> 34) << 32;                    // 30 bits, in place
                     const unsigned long long mine = (1ull << 62) | fp | make_inst(r, p);
+                    uint32_t sl, lo_sl = 0, n_sl = tab.cap;                            // probe region [lo_sl, lo_sl + n_sl)
+                    if (ranked) {
+                        const uint32_t b = (uint32_t)(x >> 32) >> (32 - pre_log2);
+                        const uint32_t word = fin[b >> 5];
+                        if (!((word >> (b & 31)) & 1u)) return false;
+                        const uint32_t rnk = pfx[b >> 5] + (uint32_t)__popc(word & ((1u << (b & 31)) - 1u));
+                        unsigned long long v = tab.load(rnk);
+                        if ((uint32_t)v == EMPTY32) {
+                            v = tab.cas(rnk, EMPTY64, mine);
+                            if (v == EMPTY64) {   // first occurrence
+                                const uint32_t q = atomicAdd(&s_cnt[4], 1u);
+                                if (q < n_unit) list_a[q] = rnk;
+                                return false;
+                            }
+                        }
+                        if ((v & 0x3FFFFFFF00000000ull) == fp) {
+                            const uint32_t oi = (uint32_t)v;
+                            const K128 ow = lds_window<true>(V.rb, oi >> INST_OFF_BITS, oi & INST_OFF_MASK, k);
+                            if (ow == fw || ow == rc) {   // the same canonical k-mer
+                                while ((v >> 62) != 3ull) {   // saturating increment
+                                    const unsigned long long o = tab.cas(rnk, v, v + (1ull << 62));
+                                    if (o == v) break;
+                                    v = o;
+                                }
+                                return false;
+                            }
+                        }
+                        lo_sl = n_set; n_sl = ovf_cap;   // another k-mer owns the bit's slot: hashed overflow region
+                    } else {
+                        if (pre && !pre_pass(x)) return false;
+                    }
+                    if (P.diag & 1) return false;
+                    sl = lo_sl + slot_of_hash(x, n_sl);
                     bool placed = false;
-                    for (uint32_t probes = 0; probes < tab.cap; ++probes) {
+                    for (uint32_t probes = 0; probes < n_sl; ++probes) {
                         unsigned long long v = tab.load(sl);
                         if ((P.diag & 4) && (uint32_t)v != EMPTY32) { placed = true; break; }
                         if ((uint32_t)v == EMPTY32) {
                             v = tab.cas(sl, EMPTY64, mine);
                             if (v == EMPTY64) {   // first occurrence
                                 const uint32_t q = atomicAdd(&s_cnt[4], 1u);
-                                if (q >= limit) s_cnt[6] = 1;
+                                if (ranked) { if (atomicAdd(&s_cnt[7], 1u) >= ovf_cap - ovf_cap / 4) s_cnt[6] = 1; }
+                                else if (q >= limit) s_cnt[6] = 1;
                                 if (q < n_unit) list_a[q] = sl;
                                 placed = true;
                                 break;
@@ -783,7 +881,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                                 break;
                             }
                         }
-                        sl = sl + 1 == tab.cap ? 0 : sl + 1;
+                        sl = sl + 1 == lo_sl + n_sl ? lo_sl : sl + 1;
                     }
                     if (!placed) s_cnt[6] = 1;
                     return false;
@@ -1368,6 +1466,7 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.next_gap = d_next;
     P.keyslot = (uint32_t)ctx->asm_keyslot;
     P.precount = (uint32_t)ctx->asm_precount;
+    P.ranked = (uint32_t)ctx->asm_ranked;
     P.diag = (uint32_t)ctx->asm_diag;
     const uint32_t rb = (uint32_t)((read_len + 3) / 4);
     P.reads32 = (const uint32_t*)d_pool;
