@@ -1153,17 +1153,20 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
         // atomics at ~11 ns each: one atomic per 32-64 entries was 0.8 ms per 112.5 M reads, the whole pass); a chunk belongs to ONE
         // bucket (chunk_b), so an entry needs no bucket bits; what is left of a wave's last chunk is filled with the invalid entry ~0.
         uint32_t ch_at = 0, ch_end = 0;   // wave-uniform: this wave's chunk
+        bool list_full = false;           // wave-uniform: a reservation came back beyond the list — no more reservations (the counter
+                                          // then stops at most one chunk per wave beyond the capacity: it cannot wrap)
         auto flush = [&]() {
             uint32_t done = 0;
             while (done < obuf_n) {
                 if (ch_at == ch_end) {
-                    uint32_t gb = 0;
-                    if (lane == 0) {
+                    uint32_t gb = Q.cap8;
+                    if (lane == 0 && !list_full) {
                         gb = atomicAdd(Q.n_cand8, PF4_CHUNK);
                         if (gb < Q.cap8) Q.chunk_b[gb / PF4_CHUNK] = (uint8_t)b;
                     }
                     ch_at = __shfl(gb, 0);
                     ch_end = ch_at + PF4_CHUNK;
+                    list_full = ch_at >= Q.cap8;
                 }
                 const uint32_t room = ch_end - ch_at, m = obuf_n - done < room ? obuf_n - done : room;
                 for (uint32_t q = lane; q < m; q += 64) {
