@@ -917,7 +917,6 @@ struct Part4Params {
     uint32_t gs, n_groups, n_grp; // row stride; groups in all; groups per tile iteration
     uint32_t tiles_wg;            // tiles per workgroup and tile iteration
     uint32_t* seen;               // one bit per read
-    uint8_t* seedm;               // per read: which aligned 16-mers are in the exact set (bit min(j, 7)); cleared by the verify kernel
     unsigned long long* cand8;    // pairs found in the exact set: {writer << 56 | position in the part << 32 | batch octet << 24 | key bits}; ~0 = unused
     uint8_t* chunk_b;             // bucket of every PF4_CHUNK entries of that list
     uint32_t* n_cand8;
@@ -928,22 +927,16 @@ constexpr uint32_t PF4_CHUNK = 256;   // entries of the pair list a wave of pass
 constexpr uint32_t PF4_STAGE = 16;   // groups of fill history staged in LDS (one 64-byte row per bucket and flush)
 
 // does read r have an aligned 16-mer with scrambled key pk?  (slow path: bytes from global memory)
-__device__ __forceinline__ uint32_t pf4_read_has_key(const FilterParams& P, uint64_t r, uint32_t pk) {
+__device__ __forceinline__ bool pf4_read_has_key(const FilterParams& P, uint64_t r, uint32_t pk) {
     const uint8_t* rd = P.reads + r * P.rb;
-    uint32_t m = 0;   // bit min(j, 7) per matching aligned 16-mer j
     for (uint32_t j = 0; j < P.np; ++j) {
         const uint32_t bit = j * P.stride2, by = bit >> 3, sh = bit & 7;
         uint64_t v = 0;
         for (uint32_t q = 0; q < 5; ++q) v = (v << 8) | ((by + q < P.rb) ? rd[by + q] : 0);
         const uint32_t w16 = (uint32_t)((v << sh) >> 8);
-        if (canon16(w16) * S16_MUL == pk) m |= 1u << (j < 7 ? j : 7);
+        if (canon16(w16) * S16_MUL == pk) return true;
     }
-    return m;
-}
-// read r is a candidate, its aligned 16-mers `m` are in the exact set (byte-wide atomic through the enclosing word)
-__device__ __forceinline__ void pf4_mark(const Part4Params& Q, uint64_t r, uint32_t m) {
-    atomicOr(&Q.seen[r >> 5], 1u << (r & 31));
-    atomicOr(reinterpret_cast<uint32_t*>(Q.seedm) + (r >> 2), m << ((r & 3) * 8));
+    return false;
 }
 // octet (read >> 3) of the pair at position `pos` of part (b, w) with batch octet `oc`: the batch is the group g with
 // fills[g] <= pos < fills[g + 1] — searched from the proportional guess (the fills grow almost linearly)
@@ -974,9 +967,7 @@ __device__ __forceinline__ void pf4_resolve_octet_serial(const Part4Params& Q, u
     const FilterParams& P = Q.F;
     for (uint32_t sub = 0; sub < 8; ++sub) {
         const uint64_t r = (uint64_t)octet * 8 + sub;
-        if (r >= P.n_reads) continue;
-        const uint32_t m = pf4_read_has_key(P, r, pk);
-        if (m) pf4_mark(Q, r, m);
+        if (r < P.n_reads && pf4_read_has_key(P, r, pk)) atomicOr(&Q.seen[r >> 5], 1u << (r & 31));
     }
 }
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params Q, uint32_t slice_words) {
@@ -1306,11 +1297,10 @@ __global__ __launch_bounds__(256) void pf4_resolve_kernel(Part4Params Q) {
             }
             wave_lds_sync();
             const uint64_t r = (uint64_t)octet * 8 + sub;
-            uint32_t m = 0;   // every aligned 16-mer of the read with this key (the same 16-mer may sit at two of them)
+            bool hit = false;
             if (valid && r < P.n_reads)
-                for (uint32_t j = 0; j < P.np; ++j)
-                    if (canon16(stream32(stg, sub * P.rb * 8 + j * P.stride2)) * S16_MUL == pk) m |= 1u << (j < 7 ? j : 7);
-            if (m) pf4_mark(Q, r, m);
+                for (uint32_t j = 0; j < P.np && !hit; ++j) hit = canon16(stream32(stg, sub * P.rb * 8 + j * P.stride2)) * S16_MUL == pk;
+            if (hit) atomicOr(&Q.seen[r >> 5], 1u << (r & 31));
             wave_lds_sync();
         }
     }
@@ -1600,8 +1590,6 @@ struct VerifyParams {
     const uint32_t* occ;
     const uint32_t* fpk;
     const uint32_t* foff;
-    uint8_t* seedm;          // seed-and-extend kernel: per read, which aligned 16-mers are in the exact set (bit min(j, 7)), or null;
-                             // read AND cleared here (a stale bit only costs a look-up: any superset is exact)
     uint32_t* overflow;      // counter: candidates whose (position, gap) list exceeded list_cap
     uint32_t* overflow_list; // their read ids (re-verified by a second launch with a large list), or null
 };
@@ -1970,25 +1958,20 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
         // exact-set lookup of every aligned 16-mer of my candidate: slot of the match, or EMPTY32
         if (lane < nb) {
             const uint32_t* row = rows + lane * rwp + 4;
-            uint32_t sm8 = 0xFFu;   // aligned 16-mers that can be in the set (the 4-byte-pair filter knows; bit 7 = "j >= 7")
-            if (P.seedm) { sm8 = P.seedm[my_r]; P.seedm[my_r] = 0; }
             for (uint32_t q0 = 0; q0 < P.np; q0 += 3) {
                 uint32_t key[3], h[3];
                 Slots4 v[3];
-                bool want[3];
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
                     const uint32_t q = q0 + u < P.np ? q0 + u : P.np - 1;
-                    want[u] = q0 + u < P.np && ((sm8 >> (q < 7 ? q : 7)) & 1u);
                     key[u] = canon16(stream32(row, 2 * q * P.stride));
                     h[u] = hash_s16_set(key[u], (int)P.s_log2);
-                    v[u] = want[u] ? *reinterpret_cast<const Slots4*>(P.sset + h[u]) : Slots4{EMPTY32, EMPTY32, EMPTY32, EMPTY32};
+                    v[u] = *reinterpret_cast<const Slots4*>(P.sset + h[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
                     if (q0 + u >= P.np) continue;
                     uint32_t sl = EMPTY32;
-                    if (!want[u]) { slots[lane * P.np + q0 + u] = EMPTY32; continue; }
                     if (v[u].x == key[u]) sl = h[u];
                     else if (v[u].y == key[u]) sl = h[u] + 1;
                     else if (v[u].z == key[u]) sl = h[u] + 2;
@@ -2139,7 +2122,6 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     F.bm_log2 = ix.bm_log2;
     F.s_log2 = ix.s_log2;
     F.cand = (uint32_t*)ctx->cand.p;
-    uint8_t* seedm_for_verify = nullptr;   // set by the 4-byte-pair filter: per-read masks of the aligned 16-mers that are in the exact set
     F.n_cand = d_cnt;
     F.bitmap_lds = ix.d_bitmap_lds;
     F.lds_log2 = ix.lds_log2;
@@ -2221,15 +2203,6 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.fills = (uint32_t*)(ws + b_cnt + b_seen);
         Q.cand8 = (unsigned long long*)(ws + b_cnt + b_seen + b_fill);
         Q.chunk_b = (uint8_t*)(ws + b_cnt + b_seen + b_fill + (size_t)Q.cap8 * 8);
-        {   // the per-read seed masks: zero when allocated, returned to zero by the verify kernel
-            const size_t b_sm = (((size_t)n_reads + 3) & ~(size_t)3) + 256;
-            if (ctx->seedm.bytes < b_sm) {
-                if ((rc = ensure(ctx, ctx->seedm, b_sm))) return rc;
-                GF_HIP(ctx, hipMemsetAsync(ctx->seedm.p, 0, ctx->seedm.bytes, ctx->stream));
-            }
-            Q.seedm = (uint8_t*)ctx->seedm.p;
-            seedm_for_verify = Q.seedm;
-        }
         Q.pairs = (uint32_t*)(ws + b_cnt + b_seen + b_fill + b_c8);
         GF_HIP(ctx, hipMemsetAsync(ws + b_cnt - 256, 0, 256 + b_seen, ctx->stream));
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
@@ -2352,7 +2325,6 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.overflow = d_cnt + 2;
     V.overflow_list = (uint32_t*)ctx->cand2.p;
     V.sval = ix.d_sval; V.occ = ix.d_occ; V.fpk = ix.d_fpk; V.foff = ix.d_foff;
-    V.seedm = seedm_for_verify;
     if (ctx->screen_verify_ext && V.min_hits == 1 && ix.max_gaps_per_kmer == 0 && ix.ext_ok && V.np >= 1 && V.np <= 32) {
         // seed-and-extend kernel instead of the k-mer table (same hits; see screen_verify_ext_kernel)
         const size_t rwp = (rb + 24) / 4 + 1 + 4, nmw = d_nmask ? V.nmw : 0;
