@@ -1309,33 +1309,44 @@ __global__ __launch_bounds__(256) void pf4_resolve_kernel(Part4Params Q) {
 // the candidate list = the reads whose `seen` bit is set: every workgroup compacts one contiguous slice of the bitmap (count, one
 // global atomic for the slice, then write)
 __global__ __launch_bounds__(256) void pf4_list_kernel(Part4Params Q) {
-    __shared__ uint32_t s_part[256], s_base;
+    __shared__ uint32_t s_w[4], s_base;
     const FilterParams& P = Q.F;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t n_words = (P.n_reads + 31) / 32;
-    const uint64_t per = (n_words + gridDim.x - 1) / gridDim.x;
+    const uint64_t per = ((n_words + gridDim.x - 1) / gridDim.x + 255) & ~(uint64_t)255;   // whole 256-word rows per workgroup
     const uint64_t w0 = (uint64_t)blockIdx.x * per, w1 = w0 + per < n_words ? w0 + per : n_words;
-    // thread t owns the contiguous words [w0 + t * pt, w0 + (t + 1) * pt)
-    const uint64_t pt = (per + 255) / 256;
-    const uint64_t a = w0 + (uint64_t)tid * pt < w1 ? w0 + (uint64_t)tid * pt : w1, bnd = a + pt < w1 ? a + pt : w1;
+    // pass 1: the slice's candidates (coalesced: thread t takes word t of every 256-word row)
     uint32_t c = 0;
-    for (uint64_t i = a; i < bnd; ++i) c += (uint32_t)__popc(Q.seen[i]);
-    s_part[tid] = c;
+    for (uint64_t i = w0 + tid; i < w1; i += 256) c += (uint32_t)__popc(Q.seen[i]);
+    for (int d = 32; d; d >>= 1) c += __shfl_down(c, d);
+    if (lane == 0) s_w[wv] = c;
     __syncthreads();
     if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < 256; ++i) { const uint32_t v = s_part[i]; s_part[i] = run; run += v; }
-        s_base = run ? atomicAdd(P.n_cand, run) : 0u;
+        const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        s_base = tot ? atomicAdd(P.n_cand, tot) : 0u;
     }
     __syncthreads();
-    uint32_t at = s_base + s_part[tid];
-    for (uint64_t i = a; i < bnd; ++i) {
-        uint32_t v = Q.seen[i];
+    uint32_t base = s_base;
+    // pass 2 (the slice is in L2 now): row by row, a block scan of the words' popcounts places every read in read order
+    for (uint64_t r0 = w0; r0 < w1; r0 += 256) {
+        uint32_t v = r0 + tid < w1 ? Q.seen[r0 + tid] : 0u;
+        const uint32_t n = (uint32_t)__popc(v);
+        uint32_t inc = n;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(inc, d);
+            if ((int)lane >= d) inc += y;
+        }
+        __syncthreads();                       // (the previous row's wave totals have been read)
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        uint32_t off = base + inc - n;
+        for (uint32_t q = 0; q < wv; ++q) off += s_w[q];
         while (v) {
             const uint32_t bit = (uint32_t)__ffs(v) - 1;
             v &= v - 1;
-            P.cand[at++] = (uint32_t)(i * 32 + bit);
+            P.cand[off++] = (uint32_t)((r0 + tid) * 32 + bit);
         }
+        base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
     }
 }
 
