@@ -507,9 +507,10 @@ def run(args):
             "gaps_per_s": n_gaps / step_s,
             "gaps_closed_per_s": n_closed / step_s,
             "roofline": {"bound": "hbm",
-                         "kernel": "screen_filter (one launch group per library and step: pf2_scatter_kernel + pf2_probe_kernel — probes sorted "
-                                   "into 256 slices of the level-1 bitmap, each tested from LDS — on key sets beyond an L2 as at C4/C5; the "
-                                   "software-pipelined screen_filter_pipe_kernel otherwise, as at C2)",
+                         "kernel": "screen_filter (one launch group per library and step: pf4_scatter_kernel + pf4_probe_kernel + pf4_resolve_kernel + "
+                                   "pf4_list_kernel — probes sorted into 256 slices of the level-1 bitmap as 4-byte pairs, each slice tested from LDS, "
+                                   "read ids recovered from positions — on key sets beyond an L2 as at C4/C5; the software-pipelined "
+                                   "screen_filter_pipe_kernel otherwise, as at C2)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.config, int(reads_per_launch), L, k_s),
                          "algorithmic_bytes_per_launch": int(reads_per_launch * rb), "avg_launch_ms": filt_ms,
