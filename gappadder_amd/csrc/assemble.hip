@@ -281,6 +281,35 @@ __device__ __forceinline__ uint32_t table_upsert(const Tab& t, const PoolView& V
     return EMPTY32;
 }
 
+// The same for the NODE table (kv-mers), with an 8-bit key fingerprint in the top byte of the slot's high word when `fp_on`: a probe
+// that meets another node sees it in the fingerprint and does not re-derive the occupant's kv-mer from the reads (a window fetch + a
+// reverse complement per foreign slot on the way).  The multiplicity lives in bits 13..23 then, which bounds it by 2047: the caller
+// switches the fingerprint on only when k - kv <= 4 (a kv-mer lies in at most (k - kv + 1) * 4^(k - kv) <= 1280 distinct k-mers).
+constexpr uint32_t NODE_FP_SHIFT = 24;
+__device__ __forceinline__ uint32_t node_fp(uint64_t x) { return (uint32_t)(x >> 56); }
+template <bool W>
+__device__ __forceinline__ uint32_t node_upsert(const Tab& t, const PoolView& V, K128 key, uint32_t inst, int len, uint32_t inc, bool fp_on,
+                                                bool* fresh) {
+    const uint64_t x = hash_of(key);
+    const uint32_t fp = fp_on ? node_fp(x) : 0u;
+    uint32_t s = slot_of_hash(x, t.cap);
+    *fresh = false;
+    for (uint32_t probes = 0; probes < t.cap; ++probes) {
+        unsigned long long v = t.load(s);
+        if ((uint32_t)v == EMPTY32) {
+            v = t.cas(s, EMPTY64, ((unsigned long long)(inc | (fp << NODE_FP_SHIFT)) << 32) | inst);
+            if (v == EMPTY64) { *fresh = true; return s; }
+        }
+        const uint32_t cur = (uint32_t)v;
+        if ((!fp_on || (uint32_t)(v >> (32 + NODE_FP_SHIFT)) == fp) && (cur == inst || canonical_w<W>(pv_kmer<W>(V, cur, len), len) == key)) {
+            t.add(s, (unsigned long long)inc << 32);
+            return s;
+        }
+        s = s + 1 == t.cap ? 0 : s + 1;
+    }
+    return EMPTY32;
+}
+
 __device__ __forceinline__ uint32_t rev4(uint32_t b) {  // bit c -> bit 3-c
     return ((b & 1) << 3) | ((b & 2) << 1) | ((b & 4) >> 1) | ((b & 8) >> 3);
 }
@@ -985,6 +1014,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         //      end: error removal looks neighbours up again after every round.
         const uint64_t node_bound = (uint64_t)per * n_surv < n_unit ? (uint64_t)per * n_surv : n_unit;
         bool graph_lds = false;
+        const bool node_fp_on = P.k - P.kv <= 4;   // see node_upsert
         uint32_t nb = 0, n_nodes = 0;
         Tab ntab;
         ntab.g = gtab;
@@ -1027,7 +1057,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     const K128 A = d ? rc : a;
                     const uint32_t ninst = fwd ? inst + o : inst + (per - 1 - o);  // same read, shifted offset
                     bool fresh;
-                    const uint32_t sl = table_upsert<W>(ntab, V, A, ninst, kv, 1u << M_MULT_SHIFT, &fresh);
+                    const uint32_t sl = node_upsert<W>(ntab, V, A, ninst, kv, 1u << M_MULT_SHIFT, node_fp_on, &fresh);
                     if (sl == EMPTY32) { if (graph_lds) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_NTABLE); break; }
                     if (fresh) {
                         const uint32_t q = atomicAdd(&s_cnt[5], 1u);
@@ -1068,7 +1098,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             const uint32_t sl = list_a[ni];
             const unsigned long long v = ntab.load(sl);
             inst_of.set(ni, (uint32_t)v);
-            nmeta.set(ni, (uint32_t)(v >> 32));
+            nmeta.set(ni, (uint32_t)(v >> 32) & (node_fp_on ? (1u << NODE_FP_SHIFT) - 1u : 0xFFFFFFFFu));   // (without the fingerprint)
             succ0.set(ni, EMPTY32);
             succ1.set(ni, EMPTY32);
             ntab.set_id(sl, ni);
@@ -1085,11 +1115,16 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             const K128 yr = revcomp_w<W>(y, kv);
             const uint32_t dy = yr < y ? 1u : 0u;
             const K128 Y = dy ? yr : y;
-            uint32_t sl = slot_of(Y, ntab.cap);
+            const uint64_t x = hash_of(Y);
+            const uint32_t fp = node_fp(x);
+            uint32_t sl = slot_of_hash(x, ntab.cap);
             for (uint32_t probes = 0; probes < ntab.cap; ++probes) {
-                const uint32_t cand = ntab.id(sl);
+                const unsigned long long v = ntab.load(sl);
+                const uint32_t cand = (uint32_t)v;
                 if (cand == EMPTY32) break;
-                if (cand < n_nodes && canonical_w<W>(pv_kmer<W>(V, inst_of.get(cand), kv), kv) == Y) return (cand << 1) | dy;
+                if ((!node_fp_on || (uint32_t)(v >> (32 + NODE_FP_SHIFT)) == fp) && cand < n_nodes &&
+                    canonical_w<W>(pv_kmer<W>(V, inst_of.get(cand), kv), kv) == Y)
+                    return (cand << 1) | dy;
                 sl = sl + 1 == ntab.cap ? 0 : sl + 1;
             }
             return EMPTY32;
