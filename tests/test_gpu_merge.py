@@ -160,3 +160,40 @@ def test_overlap_evaluate_matches_oracle_on_assembly_like_sets(gf):
     assert n_edge > 10
     with pytest.raises(Exception):
         gf.overlap_evaluate(sets, pairs[:4], (-2.0, -1.5, 50.0, 0.005, 0.4, 12.0, 6.0))   # a fractional indel score is refused
+
+
+def test_merge_edges_file_lists_the_graph_edges(gf, tmp_path):
+    """MergeContigs.merge_edges on a working folder with two gaps: merge_edges.txt holds, per gap, exactly the edges the reference's
+    threadMergeContigV2 would form from the feasible pairs (class 2, no containment; mode 12 / 21; overlap size) — here derived
+    with the oracle from the oracle's own prefilter."""
+    from gappadder_amd.MergeContigs import merge_edges
+    rng = np.random.default_rng(5)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.integers(0, 4, n)].tobytes().decode()
+    rc = lambda x: x[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    g = rnd(1200)
+    sets = {"7_1": [g[0:400], g[330:800], rc(g[720:1200]), rnd(150)], "7_2": [g[100:500], g[100:300]], "9_1": [rnd(20)]}
+    wf = str(tmp_path) + "/"
+    for gid, cs in sets.items():
+        os.makedirs(wf + "velvet_temp/" + gid)
+        with open(wf + "velvet_temp/%s/contigs.fa" % gid, "w") as f:
+            f.write("".join(">NODE_%d_length_%d_cov_9.0\n%s\n" % (i + 1, len(c), c) for i, c in enumerate(cs)))
+    got = merge_edges(gf, wf, ["7_1", "7_2", "9_1", "missing"])
+    assert set(got) == {"7_1", "7_2"}                       # 9_1 has no contig of 30 bases, `missing` no file
+    n_edges = 0
+    for gid in ("7_1", "7_2"):
+        nodes = CO.merger_nodes(sets[gid])
+        exp = []
+        for (i, j) in CO.quick_check(sets[gid], 10):
+            r = CO.overlap_evaluate(nodes[i], nodes[j])
+            if r["res"] == 2 and not r["containment"]:
+                exp.append((i, j, "12" if r["first_goes_first"] else "21", r["overlap"]))
+        assert got[gid] == exp, gid
+        lines = open(wf + "velvet_temp/%s/merge_edges.txt" % gid).read().split("\n")[:-1]
+        assert len(lines) == len(exp)
+        for line, (i, j, mode, ov) in zip(lines, exp):
+            a, sa, b, sb, m, o = line.split()
+            assert (a, sa, b, sb, m, int(o)) == ("NODE_%d_length_%d_cov_9.0" % (i // 2 + 1, len(sets[gid][i // 2])), "-" if i & 1 else "+",
+                                                 "NODE_%d_length_%d_cov_9.0" % (j // 2 + 1, len(sets[gid][j // 2])), "-" if j & 1 else "+", mode, ov)
+        n_edges += len(exp)
+    assert n_edges >= 4                                     # the tiling's overlaps in both orientations
