@@ -433,6 +433,9 @@ def run(args):
         sys.stderr.write("assembly phases of the last (k, kv) launch, us per gap (%d gaps with reads): " % len(d) +
                          ", ".join("%s %.1f (max %.1f)" % (nm, ph[:, i].mean(), ph[:, i].max()) for i, nm in enumerate(names)) +
                          "; total %.1f\n" % ph.sum(1).mean())
+        sys.stderr.write("  windows %.0f, counted %.0f, survivors %.0f, nodes %.0f (max %d); count table global in %.0f %% of the gaps; graph plan LDS / LDS + global pairs / global: %s\n"
+                         % (d[:, 13].mean(), d[:, 10].mean(), d[:, 12].mean(), d[:, 14].mean(), d[:, 14].max(), 100.0 * d[:, 11].mean(),
+                            " / ".join("%.0f %%" % (100.0 * (d[:, 15] == v).mean()) for v in (0, 1, 2))))
     # ---- results of the last step ----
     acnt = d_acnt.cpu().numpy()
     n_ctg, n_seq, n_closed_local = int(acnt[0]), int(acnt[2:4].view(np.uint64)[0]), int(acnt[4])

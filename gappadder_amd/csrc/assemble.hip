@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         const uint32_t n_surv = s_cnt[0];
         ASM_STAMP(2);
         if (P.dbg && tid == 0) {   // diagnostics: distinct k-mers counted exactly, table home, survivors, windows
-            P.dbg[(uint64_t)g * 16 + 10] = n_dist; P.dbg[(uint64_t)g * 16 + 11] = tab_global; P.dbg[(uint64_t)g * 16 + 12] = n_surv; P.dbg[(uint64_t)g * 16 + 13] = n_inst; P.dbg[(uint64_t)g * 16 + 14] = s_cnt[7]; P.dbg[(uint64_t)g * 16 + 15] = tab.cap;
+            P.dbg[(uint64_t)g * 16 + 10] = n_dist; P.dbg[(uint64_t)g * 16 + 11] = tab_global; P.dbg[(uint64_t)g * 16 + 12] = n_surv; P.dbg[(uint64_t)g * 16 + 13] = n_inst;
         }
 
         // ---- graph-phase memory: node table + 4 arrays + the unitig-ranking pairs.  Optimistic LDS plan first: room for `nb`
@@ -1013,21 +1013,29 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         //      oriented node); if the gap has more nodes the phase is redone in global memory.  The node table stays alive to the
         //      end: error removal looks neighbours up again after every round.
         const uint64_t node_bound = (uint64_t)per * n_surv < n_unit ? (uint64_t)per * n_surv : n_unit;
-        bool graph_lds = false;
+        // Three plans: 0 = everything in LDS (11 words per node); 1 = node table + arrays in LDS, the ranking pairs in the global
+        // slice (7 words per node: gaps with up to 4 900 nodes instead of 3 100 beside a 720-read pool — C5's pools, whose graph
+        // phases all ran in the global slice before: 910 us per gap at k = 51); 2 = everything in the global slice.  The survivors
+        // say where to start (a gap has about as many nodes as surviving k-mers); a plan that overflows falls through to the next.
+        bool graph_lds = false, j_lds = false;
         const bool node_fp_on = P.k - P.kv <= 4;   // see node_upsert
         uint32_t nb = 0, n_nodes = 0;
         Tab ntab;
         ntab.g = gtab;
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint32_t want = n_surv + n_surv / 8;
+        for (int attempt = want <= r_words / 11 ? 0 : want <= r_words / 7 ? 1 : 2; attempt < 3; ++attempt) {
             graph_lds = false;
-            if (attempt == 0) {
-                nb = (uint32_t)(node_bound < r_words / 11 ? node_bound : r_words / 11);
-                if (nb < n_surv || nb < 64) continue;       // cannot even hold one node per survivor: go global
+            j_lds = false;
+            if (attempt < 2) {
+                const uint32_t per_node = attempt == 0 ? 11 : 7;
+                nb = (uint32_t)(node_bound < r_words / per_node ? node_bound : r_words / per_node);
+                if (nb < n_surv || nb < 64) continue;       // cannot even hold one node per survivor
                 graph_lds = true;
+                j_lds = attempt == 0;
             }
             ntab.lds = graph_lds;
             ntab.off = R + 4 * nb;
-            ntab.cap = graph_lds ? ((r_words - 8 * nb) / 2) : gcap;
+            ntab.cap = graph_lds ? ((r_words - (j_lds ? 8 : 4) * nb) / 2) : gcap;
             if (graph_lds) {
                 for (uint32_t i = tid; i < ntab.cap; i += ASM_THREADS) ntab.store(i, EMPTY64);
                 __syncthreads();
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             wg_phase_sync();
             if (!(graph_lds && s_cnt[6])) break;
             __syncthreads();
-            if (tid == 0) { s_cnt[5] = 0; s_cnt[6] = 0; }   // too many nodes for the LDS plan: redo in the global slice
+            if (tid == 0) { s_cnt[5] = 0; s_cnt[6] = 0; }   // too many nodes for this plan: redo with the next one
             __syncthreads();
         }
         n_nodes = s_cnt[5] < n_unit ? s_cnt[5] : n_unit;
@@ -1090,8 +1098,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         const Arr nmeta{graph_lds, R + astride, garr};
         const Arr succ0{graph_lds, R + 2 * astride, garr + astride};
         const Arr succ1{graph_lds, R + 3 * astride, garr + 2 * astride};
-        const uint32_t Joff = graph_lds ? ntab.off + 2 * ntab.cap : 0;
-        const Pairs J{graph_lds, Joff, reinterpret_cast<unsigned long long*>(P.jump + 4 * inst_off)};
+        uint32_t Joff = j_lds ? ntab.off + 2 * ntab.cap : 0;
+        Pairs J{j_lds, Joff, reinterpret_cast<unsigned long long*>(P.jump + 4 * inst_off)};
         uint32_t* rec = list_b + (graph_lds ? 0 : n_nodes);           // emitted-walk records, 4 words each
         const uint32_t rec_cap = (n_unit - (graph_lds ? 0 : n_nodes)) / 2;
         for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
@@ -1142,7 +1150,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         uint32_t cacc_cap = 0;
         // between phases that hand data over through the graph arrays only: a plain barrier when those live in LDS (the L1
         // invalidate of wg_phase_sync is for hand-overs through global memory)
-        auto graph_sync = [&]() { if (graph_lds) __syncthreads(); else wg_phase_sync(); };
+        auto graph_sync = [&]() { if (j_lds) __syncthreads(); else wg_phase_sync(); };   // (j_lds implies graph_lds)
         // ---- P4: unitig-internal edges.  (x,d) -> (y,dy) is internal iff out-degree(x,d) == 1 and in-degree(y,dy) == 1;
         //      an oriented node that no internal edge enters is a unitig START.
         for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
@@ -1320,6 +1328,14 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         }
 
         ASM_STAMP(7);
+        // plan 1: nothing looks a node up any more — the ranking pairs move over the node table when they fit there
+        if (P.dbg && tid == 0) { P.dbg[(uint64_t)g * 16 + 14] = n_nodes; P.dbg[(uint64_t)g * 16 + 15] = graph_lds ? (j_lds ? 0 : 1) : 2; }   // diagnostics: nodes, plan
+        if (graph_lds && !j_lds && 4 * (uint64_t)n_nodes + 8 <= 2 * (uint64_t)ntab.cap) {
+            wg_phase_sync();
+            Joff = ntab.off;
+            J = Pairs{true, Joff, J.g};
+            j_lds = true;
+        }
         // ---- P5: unitigs ranked by pointer jumping: every oriented node learns its unitig's head and its rank in
         //      ~log2(longest unitig) rounds.  Pairs are read and written as single 64-bit accesses, so the asynchronous
         //      in-place update keeps the invariant "ancestor at that distance".
@@ -1367,7 +1383,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         // ---- emission: heads decide, then every node of an emitted unitig writes its own base
         {
             // per-contig coverage sums: in the LDS behind the pairs when the graph lives there, else in the global records
-            if (graph_lds) {
+            if (j_lds) {
                 const uint32_t used = Joff + 4 * n_nodes;
                 cacc = &g_lds[used];
                 cacc_cap = P.lds_words > used ? P.lds_words - used : 0;

@@ -46,5 +46,5 @@ for i, nm in enumerate(names):
 if d[:, 8].any():
     print("P1 split: pre-count %.1f us, table init %.1f us, exact count %.1f us" % (((d[:, 8] - d[:, 0]) / 100.0).mean(), ((d[:, 9] - d[:, 8]) / 100.0).mean(), ((d[:, 1] - d[:, 9]) / 100.0).mean()))
 print("windows %.0f, distinct counted %.0f, survivors %.0f, global table in %.0f %% of the gaps" % (d[:, 13].mean(), d[:, 10].mean(), d[:, 12].mean(), 100.0 * d[:, 11].mean()))
-print("table probes %.0f, table slots %.0f" % (d[:, 14].mean(), d[:, 15].mean()))
+print("nodes %.0f, graph plan (0 LDS, 1 LDS + global pairs, 2 global) mean %.2f" % (d[:, 14].mean(), d[:, 15].mean()))
 print("total/gap mean %.1f us max %.1f us; kernel span %.1f us" % (ph.sum(1).mean(), ph.sum(1).max(), (d[:, 6].max() - d[:, 0].min()) / 100.0))
