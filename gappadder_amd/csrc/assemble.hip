@@ -581,7 +581,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             uint32_t n_set = 0, ovf_cap = 0;
             if ((fpslot || keyslot) && pre && use_lds && P.ranked) {
                 uint32_t* fin = &g_lds[R];
-                uint32_t* pfx = fin + pre_words;                      // over the lower levels (dead now)
+                uint16_t* pfx = reinterpret_cast<uint16_t*>(fin + pre_words);   // over the lower levels (dead now); 16 bits: < 65 536 counted k-mers
                 const uint32_t cw = (pre_words + ASM_THREADS - 1) / ASM_THREADS;
                 const uint32_t w0 = tid * cw < pre_words ? tid * cw : pre_words, w1 = w0 + cw < pre_words ? w0 + cw : pre_words;
                 uint32_t local = 0;
@@ -596,15 +596,16 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 uint32_t wave_off = 0, total = 0;
                 for (uint32_t v = 0; v < ASM_THREADS / 64; ++v) { const uint32_t t = s_scan[v]; if (v < (tid >> 6)) wave_off += t; total += t; }
                 uint32_t run = wave_off + inc - local;
-                for (uint32_t w = w0; w < w1; ++w) { const uint32_t c = (uint32_t)__popc(fin[w]); pfx[w] = run; run += c; }
+                for (uint32_t w = w0; w < w1; ++w) { const uint32_t c = (uint32_t)__popc(fin[w]); pfx[w] = (uint16_t)run; run += c; }
                 n_set = total;
                 // overflow region: as many slots as ranked ones when they fit (deep pools leave ~4 bits per window: a quarter of the
                 // counted k-mers share a bit), at least half as many
+                const uint64_t head = (uint64_t)pre_words + pre_words / 2;   // last level + prefixes
                 ovf_cap = n_set > 256 ? n_set : 256;
-                if (2 * (uint64_t)pre_words + 2 * ((uint64_t)n_set + ovf_cap) > r_words) ovf_cap = n_set / 2 > 256 ? n_set / 2 : 256;
-                ranked = 2 * (uint64_t)pre_words + 2 * ((uint64_t)n_set + ovf_cap) <= r_words;
+                if (head + 2 * ((uint64_t)n_set + ovf_cap) > r_words) ovf_cap = n_set / 2 > 256 ? n_set / 2 : 256;
+                ranked = n_set < 65536 && head + 2 * ((uint64_t)n_set + ovf_cap) <= r_words;
                 if (ranked) {
-                    tab.off = R + 2 * pre_words;
+                    tab.off = R + pre_words + pre_words / 2;
                     tab.cap = n_set + ovf_cap;
                 }
                 __syncthreads();
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         const uint32_t b = (uint32_t)(x >> 32) >> (32 - pre_log2);
                         const uint32_t word = fin[b >> 5];
                         if (!((word >> (b & 31)) & 1u)) return false;
-                        const uint32_t rnk = fin[pre_words + (b >> 5)] + (uint32_t)__popc(word & ((1u << (b & 31)) - 1u));
+                        const uint32_t rnk = reinterpret_cast<const uint16_t*>(fin + pre_words)[b >> 5] + (uint32_t)__popc(word & ((1u << (b & 31)) - 1u));
                         unsigned long long v = t.load(rnk);
                         if (v == kempty) {
                             v = t.cas(rnk, kempty, (keyhi | 1ull) ^ xm);
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 if (use_lds) count_keyslot_wide(std::true_type{}); else count_keyslot_wide(std::false_type{});
             } else if (fpslot) {
                 const uint32_t* fin = &g_lds[R];
-                const uint32_t* pfx = fin + pre_words;
+                const uint16_t* pfx = reinterpret_cast<const uint16_t*>(fin + pre_words);
                 for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128& fw, const K128& rc) -> bool {
                     const uint64_t x = hash_p1<W>(key);
                     const unsigned long long fp = (x >> 34) << 32;                    // 30 bits, in place
