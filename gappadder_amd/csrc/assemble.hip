@@ -242,17 +242,19 @@ struct Arr {
 };
 
 // 8-byte pairs in LDS (word offset, 8-byte aligned) or global memory, read and written whole
+// In LDS a pair is ONE 32-bit word {high half << 16 | low half}: both halves of every pair the graph phase keeps there (an oriented
+// node and a distance / a rank / a base code) stay below 65 535 because an LDS plan holds fewer than 32 767 nodes; ~0 stays ~0.
 struct Pairs {
     bool lds;
     uint32_t off;
     unsigned long long* g;
-    __device__ __forceinline__ unsigned long long* l() const { return reinterpret_cast<unsigned long long*>(&g_lds[off]); }
     __device__ __forceinline__ unsigned long long load(uint32_t i) const {
-        return lds ? __hip_atomic_load(l() + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                   : __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!lds) return __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t w = __hip_atomic_load(&g_lds[off + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return w == 0xFFFFFFFFu ? ~0ull : ((unsigned long long)(w >> 16) << 32) | (w & 0xFFFFu);
     }
     __device__ __forceinline__ void store(uint32_t i, unsigned long long v) const {
-        if (lds) __hip_atomic_store(l() + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lds) __hip_atomic_store(&g_lds[off + i], v == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(v >> 32) << 16) | ((uint32_t)v & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_store(g + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
@@ -1014,29 +1016,31 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         //      oriented node); if the gap has more nodes the phase is redone in global memory.  The node table stays alive to the
         //      end: error removal looks neighbours up again after every round.
         const uint64_t node_bound = (uint64_t)per * n_surv < n_unit ? (uint64_t)per * n_surv : n_unit;
-        // Three plans: 0 = everything in LDS (11 words per node); 1 = node table + arrays in LDS, the ranking pairs in the global
-        // slice (7 words per node: gaps with up to 4 900 nodes instead of 3 100 beside a 720-read pool — C5's pools, whose graph
-        // phases all ran in the global slice before: 910 us per gap at k = 51); 2 = everything in the global slice.  The survivors
+        // Three plans: 0 = everything in LDS (9 words per node: 4 array words, 3/2 table slots, one 32-bit pair per oriented node);
+        // 1 = node table + arrays in LDS, the pairs in the global slice until error removal is over, then over the node table
+        // (7 words per node: gaps with up to 4 900 nodes beside a 720-read pool — C5's pools, whose graph phases all ran in the
+        // global slice before: 910 us per gap at k = 51); 2 = everything in the global slice.  The survivors
         // say where to start (a gap has about as many nodes as surviving k-mers); a plan that overflows falls through to the next.
         bool graph_lds = false, j_lds = false;
         const bool node_fp_on = P.k - P.kv <= 4;   // see node_upsert
         uint32_t nb = 0, n_nodes = 0;
         Tab ntab;
         ntab.g = gtab;
-        const uint32_t want = n_surv + n_surv / 8;
-        for (int attempt = want <= r_words / 11 ? 0 : want <= r_words / 7 ? 1 : 2; attempt < 3; ++attempt) {
+        const uint32_t want = n_surv + n_surv / 32 + 64;   // (measured: 4 129 nodes for 4 089 survivors)
+        // (plan 2 = plan 1 with 5/4 instead of 3/2 table slots per node: 6.5 words)
+        for (int attempt = want <= r_words / 9 ? 0 : want <= r_words / 7 ? 1 : want <= 2 * r_words / 13 ? 2 : 3; attempt < 4; ++attempt) {
             graph_lds = false;
             j_lds = false;
-            if (attempt < 2) {
-                const uint32_t per_node = attempt == 0 ? 11 : 7;
-                nb = (uint32_t)(node_bound < r_words / per_node ? node_bound : r_words / per_node);
+            if (attempt < 3) {
+                const uint32_t room = attempt == 0 ? r_words / 9 : attempt == 1 ? r_words / 7 : 2 * r_words / 13;
+                nb = (uint32_t)(node_bound < room ? node_bound : room);
                 if (nb < n_surv || nb < 64) continue;       // cannot even hold one node per survivor
                 graph_lds = true;
                 j_lds = attempt == 0;
             }
             ntab.lds = graph_lds;
             ntab.off = R + 4 * nb;
-            ntab.cap = graph_lds ? ((r_words - (j_lds ? 8 : 4) * nb) / 2) : gcap;
+            ntab.cap = graph_lds ? ((r_words - (j_lds ? 6 : 4) * nb) / 2) : gcap;
             if (graph_lds) {
                 for (uint32_t i = tid; i < ntab.cap; i += ASM_THREADS) ntab.store(i, EMPTY64);
                 __syncthreads();
@@ -1330,8 +1334,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
 
         ASM_STAMP(7);
         // plan 1: nothing looks a node up any more — the ranking pairs move over the node table when they fit there
-        if (P.dbg && tid == 0) { P.dbg[(uint64_t)g * 16 + 14] = n_nodes; P.dbg[(uint64_t)g * 16 + 15] = graph_lds ? (j_lds ? 0 : 1) : 2; }   // diagnostics: nodes, plan
-        if (graph_lds && !j_lds && 4 * (uint64_t)n_nodes + 8 <= 2 * (uint64_t)ntab.cap) {
+        if (P.dbg && tid == 0) { P.dbg[(uint64_t)g * 16 + 14] = n_nodes; P.dbg[(uint64_t)g * 16 + 15] = graph_lds ? (j_lds ? 0 : 1) : 2; }   // diagnostics: nodes, plan (0 LDS, 1 LDS + global pairs, 2 global)
+        if (graph_lds && !j_lds && 2 * (uint64_t)n_nodes + 8 <= 2 * (uint64_t)ntab.cap) {
             wg_phase_sync();
             Joff = ntab.off;
             J = Pairs{true, Joff, J.g};
@@ -1385,7 +1389,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         {
             // per-contig coverage sums: in the LDS behind the pairs when the graph lives there, else in the global records
             if (j_lds) {
-                const uint32_t used = Joff + 4 * n_nodes;
+                const uint32_t used = Joff + 2 * n_nodes;
                 cacc = &g_lds[used];
                 cacc_cap = P.lds_words > used ? P.lds_words - used : 0;
             }
