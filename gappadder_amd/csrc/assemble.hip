@@ -844,7 +844,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     return false;
                 });
                 };
-                if (use_lds) count_keyslot_wide(std::true_type{}); else count_keyslot_wide(std::false_type{});
+                count_keyslot_wide(std::false_type{});   // (keyslot_w implies the global table: no LDS instantiation — the kernel is at the edge of its registers and every unused path costs the used ones)
             } else if (fpslot) {
                 const uint32_t* fin = &g_lds[R];
                 const uint16_t* pfx = reinterpret_cast<const uint16_t*>(fin + pre_words);
