@@ -243,7 +243,9 @@ struct Arr {
 
 // 8-byte pairs in LDS (word offset, 8-byte aligned) or global memory, read and written whole
 // In LDS a pair is ONE 32-bit word {high half << 16 | low half}: both halves of every pair the graph phase keeps there (an oriented
-// node and a distance / a rank / a base code) stay below 65 535 because an LDS plan holds fewer than 32 767 nodes; ~0 stays ~0.
+// node and a distance / a rank / a base code) stay below 65 535 because an LDS plan holds fewer than 32 767 nodes.  "No arc" is a value
+// that survives the packing.
+constexpr unsigned long long NO_ARC = 0x0000FFFF0000FFFFull;
 struct Pairs {
     bool lds;
     uint32_t off;
@@ -251,10 +253,10 @@ struct Pairs {
     __device__ __forceinline__ unsigned long long load(uint32_t i) const {
         if (!lds) return __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t w = __hip_atomic_load(&g_lds[off + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return w == 0xFFFFFFFFu ? ~0ull : ((unsigned long long)(w >> 16) << 32) | (w & 0xFFFFu);
+        return ((unsigned long long)(w >> 16) << 32) | (w & 0xFFFFu);
     }
     __device__ __forceinline__ void store(uint32_t i, unsigned long long v) const {
-        if (lds) __hip_atomic_store(&g_lds[off + i], v == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(v >> 32) << 16) | ((uint32_t)v & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lds) __hip_atomic_store(&g_lds[off + i], ((uint32_t)(v >> 32) << 16) | ((uint32_t)v & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_store(g + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
@@ -1285,7 +1287,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
                 if (is_dead(o) || has_pred(o) || !(nmeta.get(o >> 1) & M_KILL)) continue;
                 const uint32_t ib = inb(o);
-                unsigned long long arc = ~0ull;
+                unsigned long long arc = NO_ARC;
                 if (__popc(ib) == 1) {
                     const K128 hs = node_seq(o);
                     const uint32_t p = find_oriented(shift_in_front(hs, __ffs(ib) - 1, kv));
@@ -1298,7 +1300,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
                 if (has_pred(o) || !(nmeta.get(o >> 1) & M_KILL) || (nmeta.get(o >> 1) & M_DEAD)) continue;
                 const unsigned long long arc = J.load(o);
-                if (arc != ~0ull) {
+                if (arc != NO_ARC) {
                     const uint32_t p = (uint32_t)arc, c = (uint32_t)(arc >> 32);
                     nmeta.and_(p >> 1, ~((p & 1) ? (1u << (4 + (3 - c))) : (1u << c)));
                 }
@@ -1311,7 +1313,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                 const uint32_t m = nmeta.get(o >> 1);
                 if (has_pred(o) || !(m & M_KILL) || (m & M_DEAD)) continue;      // the heads removed in this round hold their arc
                 const unsigned long long arc = J.load(o);
-                if (arc == ~0ull) continue;
+                if (arc == NO_ARC) continue;
                 const uint32_t p = (uint32_t)arc;
                 if (is_gone(p)) continue;
                 const uint32_t pb = outb(p);
