@@ -87,7 +87,9 @@ def main():
         c5 = out["extras"]["C5_mate_pair_multi_k"]
         if "gaps_closed_per_s" in c5:
             out["gaps_closed_per_s_with_mate_pairs"] = {"value": c5["gaps_closed_per_s"], "config": "C5 (extras.C5_mate_pair_multi_k)",
-                                                        "gaps_closed": c5.get("counts", {}).get("gaps_closed"), "ms_per_step": c5["ms_per_step"]}
+                                                        "gaps_closed": c5.get("counts", {}).get("gaps_closed"),
+                                                        "gaps_closed_correct": c5.get("counts", {}).get("gaps_closed_correct"),
+                                                        "correct_per_s": c5.get("gaps_closed_correct_per_s"), "ms_per_step": c5["ms_per_step"]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -453,14 +455,19 @@ def run(args):
     ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
     n_closed, n_ctg_all, gaps_with_contig = n_closed_local, n_ctg, int(len(np.unique(ctg["gap"])))
     gather_ms = None
+    # ground truth (untimed): the sequence picked for every closed gap of this rank against the true bases behind the planted gap
+    seq_host = d_seq[:n_seq].cpu().numpy().tobytes()
+    truth = truth_check(cfg0, gaps, flanks, ctg, seq_host, d_best.cpu().numpy().view(np.uint64), GapFill)
+    assert truth["closed"] == n_closed_local, (truth["closed"], n_closed_local)
+    n_correct = truth["correct"]
     if world > 1:
-        red = torch.tensor([n_closed_local, n_ctg, gaps_with_contig, asm_rows_total], dtype=torch.int64, device=coll_dev)
+        red = torch.tensor([n_closed_local, n_ctg, gaps_with_contig, asm_rows_total, n_correct], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
-        n_closed, n_ctg_all, gaps_with_contig, asm_rows_total = (int(x) for x in red)
+        n_closed, n_ctg_all, gaps_with_contig, asm_rows_total, n_correct = (int(x) for x in red)
         # final gather on rank 0 (north_star: "RCCL over xGMI only for the final gather of closed sequences"): the picked contig
         # of every closed gap — or every contig when --dump-contigs asks for the full comparison
         tg = time.perf_counter()
-        seq_local = d_seq[:n_seq].cpu().numpy().tobytes()
+        seq_local = seq_host
         best = d_best.cpu().numpy().view(np.uint64)
         if args.dump_contigs:
             sel = range(n_ctg)
@@ -475,7 +482,7 @@ def run(args):
         all_records = None
     if args.dump_contigs and rank == 0:
         if all_records is None:
-            seq_local = d_seq[:n_seq].cpu().numpy().tobytes()
+            seq_local = seq_host
             all_records = [(int(c["gap"]), int(c["k"]), int(c["kv"]), int(c["n_nodes"]), int(c["cov_sum"]),
                             seq_local[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode()) for c in ctg]
         with open(args.dump_contigs, "w") as f:
@@ -509,6 +516,7 @@ def run(args):
                                     "ranks' recruits; final gather of the closed gaps' contigs on rank 0" % batch)},
             "gaps_per_s": n_gaps / step_s,
             "gaps_closed_per_s": n_closed / step_s,
+            "gaps_closed_correct_per_s": n_correct / step_s,
             "roofline": {"bound": "hbm",
                          "kernel": "screen_filter (one launch group per library and step: pf4_scatter_kernel + pf4_probe_kernel + pf4_resolve_kernel + "
                                    "pf4_list_kernel — probes sorted into 256 slices of the level-1 bitmap as 4-byte pairs, each slice tested from LDS, "
@@ -522,7 +530,12 @@ def run(args):
             "phases_note": "HIP-event spans per kernel group, summed over the libraries, per step; one stream: the step is their sum "
                            "(GF_BENCH_TWO_STREAMS=1 runs tagger + second hop on a second stream beside the filter: same step time within 1-3 %)",
             "counts": {"libraries": {lb.name: lb.counts for lb in libs}, "assembled_pool_reads": asm_rows_total, "contigs": n_ctg_all,
-                       "gaps_with_contig": gaps_with_contig, "gaps_closed": n_closed, "largest_pool_reads": max_pool_rows},
+                       "gaps_with_contig": gaps_with_contig, "gaps_closed": n_closed, "gaps_closed_correct": n_correct,
+                       "largest_pool_reads": max_pool_rows},
+            "closed_truth_check": {"what": "the picked sequence of EVERY closed gap (pick_contigs.py:341-349 slice of the winning contig) compared with the "
+                                           "true bases behind the planted N-run, regenerated from include/gf_synth.h: genome[start-5 : end+6] on the forward "
+                                           "strand, genome[start-6 : end+5] when the contig is reverse-complemented (the reference's slice keeps one anchor base)",
+                                   "closed": n_closed, "correct": n_correct, "wrong_on_rank0": truth["wrong"][:8], "wrong_causes_rank0": truth["causes"]},
         }
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
@@ -534,6 +547,36 @@ def run(args):
     return (out if rank == 0 else None), rank, world
 
 
+def truth_check(cfg, gaps, flanks, ctg, seq, best, GapFill):
+    """Every closed gap of this rank: the sequence the picker writes for the winning contig (gappadder_amd/pick_contigs.py on that one
+    contig: same contig, strand and span as the device word, asserted) against the TRUE bases behind the planted gap
+    (gf_synth_truth; the reference evaluates its fills against the true sequences too, validate_gap_seqs.py:5-75)."""
+    from gappadder_amd.pick_contigs import pick_gap_sequence
+    closed = correct = 0
+    wrong, causes = [], {}
+    for g in np.nonzero(best)[0]:
+        b = int(best[g])
+        a_len, span1, ci, rev = b >> 56, (b >> 32) & 0xFFFFFF, 0x7FFFFFFF - ((b >> 1) & 0x7FFFFFFF), b & 1
+        c = ctg[ci]
+        assert int(c["gap"]) == g
+        contig = seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode()
+        r = pick_gap_sequence([("c", contig)], flanks[g][0], flanks[g][1], a_len)
+        assert r is not None and len(r[1]) == span1 and (r[2] != contig) == bool(rev), (g, b)
+        st, en, sc = int(gaps[g]["start"]), int(gaps[g]["end"]), int(gaps[g]["scaffold"])
+        lo, hi = (st - 6, en + 5) if rev else (st - 5, en + 6)
+        true = GapFill.synth_truth(cfg, sc, lo, hi - lo)
+        closed += 1
+        if r[1] == true:
+            correct += 1
+        else:
+            cause = ("length %+d" % (len(r[1]) - len(true))) if len(r[1]) != len(true) else "substitutions"
+            causes[cause] = causes.get(cause, 0) + 1
+            if len(wrong) < 64:
+                nd = sum(1 for x, y in zip(r[1], true) if x != y) if len(r[1]) == len(true) else None
+                wrong.append({"gap": int(g), "anchor": a_len, "k": int(c["k"]), "picked_len": len(r[1]), "true_len": len(true), "mismatches": nd})
+    return {"closed": closed, "correct": correct, "wrong": wrong, "causes": causes}
+
+
 def child_run(argv):
     """The same step on another BASELINE.json configuration, measured by the same code in a child process (never an exec of a
     process that has touched the GPU)."""
@@ -542,7 +585,8 @@ def child_run(argv):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu"] + argv, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
-        return {key: d[key] for key in ("value", "ms_per_step", "steps", "warmup", "gaps_per_s", "gaps_closed_per_s", "phases_ms", "counts")} | \
+        return {key: d[key] for key in ("value", "ms_per_step", "steps", "warmup", "gaps_per_s", "gaps_closed_per_s", "gaps_closed_correct_per_s",
+                                        "phases_ms", "counts", "closed_truth_check")} | \
                {"workload": d["config"]["workload"], "roofline_frac": d["roofline"]["frac"], "filter_ms": d["roofline"]["avg_launch_ms"]}
     except Exception as e:      # the headline line must not depend on an extra
         return {"error": repr(e)[:300], "stderr_tail": (r.stderr.decode()[-400:] if r is not None else "")}
@@ -569,7 +613,6 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
     flags must equal the oracle's / the host picker's."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle as CO
-    from gappadder_amd.pick_contigs import pick_gap_sequence
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # a cgroup CPU quota (cpu.max "quota period") caps the usable cores below the visible ones
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -617,19 +660,32 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
     t4 = time.perf_counter()
     ok_asm, ok_pick = True, True
     best = d_best.cpu().numpy().view(np.uint64)
+    from oracle import gp_oracle as PO
     for g in range(n_g):
-        want = []
+        want, idx = [], []
         for (k, kv), e in zip(kk, exp[g]):
+            rows = np.nonzero((ctg["gap"] == g) & (ctg["k"] == k))[0]
             mine = sorted((seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode(), int(c["n_nodes"]), int(c["cov_sum"]))
-                          for c in ctg[(ctg["gap"] == g) & (ctg["k"] == k)])
+                          for c in ctg[rows])
             ok_asm = ok_asm and mine == sorted(e)
-            want += [("c", s) for s, _, _ in e]
-        span = 0
+            # the picker sees the gap's contigs in the order the device listed them (ties between equal spans go to the earlier contig)
+            for i in rows:
+                want.append(("c%d" % i, seq[int(ctg[i]["seq_off"]):int(ctg[i]["seq_off"]) + int(ctg[i]["length"])].decode()))
+                idx.append(int(i))
+        # oracle/gp_oracle.py::pick_gap = the reference's selection (pick_contigs.py:97-358, pinned on its own answers) on the exact-anchor
+        # stand-in's hits; scores 30 then 15 (assemble_gaps.py:336, 365)
+        order = sorted(range(len(idx)), key=lambda i: idx[i])
+        want, idx = [want[i] for i in order], [idx[i] for i in order]
+        exp_word = 0
         for a_len in (30, 15):
-            r = pick_gap_sequence(want, flanks[g][0], flanks[g][1], a_len)
-            if r is not None:
-                span = max(span, len(r[1]))       # picked slice = span + 1 bases
-        ok_pick = ok_pick and span == (int(best[g]) >> 32)
+            seqs, ctgs_txt = PO.pick_gap("0_1", want, flanks[g][0], flanks[g][1], a_len)
+            if seqs:
+                hdr, body = seqs.split("\n")[:2]
+                ci = idx[[n for n, _ in want].index(hdr[len(">0_1_"):])]
+                rev = int(ctgs_txt.split("\n")[1] != dict(want)["c%d" % ci])
+                exp_word = (a_len << 56) | (len(body) << 32) | ((0x7FFFFFFF - ci) << 1) | rev
+                break
+        ok_pick = ok_pick and exp_word == int(best[g])
     # whole-step CPU time extrapolated from the two samples (recruit scales with reads, assembly with gaps)
     cpu_step = t_build + t_rec * (n_screened / n_rec) + (t4 - t3) * (len(gaps) / n_g)
     return {"value": n_screened / cpu_step, "unit": "reads/s", "cores": cores, "kind": "port",

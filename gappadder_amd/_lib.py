@@ -117,6 +117,7 @@ def lib():
         "gf_timing_reset": (i32, [vp]),
         "gf_synth_pairs_dev": (i32, [vp, vp, C.c_uint64, sz, vp, vp]),
         "gf_synth_layout": (i32, [vp, vp, vp, vp]),
+        "gf_synth_truth": (i32, [vp, C.c_uint32, C.c_uint64, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = header/library mismatch: fail loudly

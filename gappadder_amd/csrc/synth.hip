@@ -88,4 +88,15 @@ int gf_synth_layout(const void* c_, gf_gap* gaps, char* flank_ascii, uint64_t* f
     return GF_OK;
 }
 
+// host: the TRUE bases (what lies behind the planted N-runs too) of [start, start + n) of one scaffold — ground truth for the
+// closed-gap check (the reference evaluates filled gaps against the true sequences the same way, validate_gap_seqs.py:5-75)
+int gf_synth_truth(const void* c_, uint32_t scaffold, uint64_t start, size_t n, char* out_ascii) {
+    const gf_synth_cfg* c = (const gf_synth_cfg*)c_;
+    int rc = synth_check(c);
+    if (rc) return rc;
+    if (!out_ascii || scaffold >= c->n_scaffolds || start + n > c->scaffold_len) return GF_E_INVAL;
+    for (size_t i = 0; i < n; ++i) out_ascii[i] = "ACGT"[gfs_base(c, scaffold, start + i)];
+    return GF_OK;
+}
+
 }  // extern "C"

@@ -318,6 +318,15 @@ class GapFill:
         flanks = [(b[int(off[2 * g]):int(off[2 * g + 1])], b[int(off[2 * g + 1]):int(off[2 * g + 2])]) for g in range(n)]
         return gaps, flanks
 
+    @staticmethod
+    def synth_truth(cfg, scaffold, start, n):
+        """The true bases of [start, start + n) of a scaffold of the synthetic draft (the planted gaps' interiors included)."""
+        out = np.zeros(int(n), dtype=np.uint8)
+        rc = B.lib().gf_synth_truth(B._p(cfg), int(scaffold), int(start), int(n), B._p(out))
+        if rc:
+            raise B.GapFillError(rc, "gf_synth_truth")
+        return out.tobytes().decode()
+
     def synth_pairs_dev(self, cfg, first_pair, n_pairs, d_packed, d_recs=None):
         self._chk(self._L.gf_synth_pairs_dev(self._h, B._p(cfg), int(first_pair), int(n_pairs), d_packed, d_recs),
                   "gf_synth_pairs_dev")

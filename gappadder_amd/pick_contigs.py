@@ -1,14 +1,17 @@
 """Flank anchoring -> gap sequence selection (SURVEY.md §8f "next" rank 1; mirrors ContigsSelection, pick_contigs.py:64-358,
-542-581).  The reference aligns the two flanks to the gap's contigs with `bwa mem -T {score} -a` and keeps the contig both
-flanks hit on the same strand; bwa is out of scope here, so the anchors are EXACT matches: the last `score` bases of the left
-flank and the first `score` bases of the right flank (score = the reference's bwa_min_score: 30, later 15).  Among the
-qualifying contigs — every occurrence of the anchors, both orientations — the longest span wins (pick_contigs.py:300-321);
-the same rule runs on the device as gf_pick_anchored_dev (csrc/pick.hip); the picked slice is contig[left_end : right_start + 1]
-in flank orientation — the +1 reproduces the reference's 1-based/0-based slice (:341-349); header '>{gapId}_{contigName}'
-(:352).  A gap with a picked sequence is what this build reports as "closed"."""
+361-539, 542-603).  The reference aligns the two flanks to the gap's contigs with `bwa mem -T {score} -a`, and everything after
+that is its own code: per contig and side the longest hit of each clip type (:97-146), the best same-strand pair of a left and a
+right hit (:149-297), over the contigs the longest span (:300-321), the slice (:341-349) and the header (:352).  bwa is out of scope
+here; its place is taken by EXACT anchors (`anchor_hits`): the last `score` bases of the left flank and the first `score` bases of
+the right flank (score = the reference's bwa_min_score: 30, later 15).  The selection itself follows the reference hit for hit —
+including what its coordinates do on the reverse strand (the slice then keeps the last base of the LEFT anchor instead of the
+first base of the right one) — and is pinned on the reference's own answers (tests/golden/pick_kat.json.gz through
+oracle/gp_oracle.py).  The same rule runs on the device as gf_pick_anchored_dev (csrc/pick.hip).  A gap with a picked sequence
+is what this build reports as "closed"."""
 import os
 
-_COMP = str.maketrans("ACGTacgt", "TGCAtgca")
+_COMP = str.maketrans("ACGTacgt", "TGCATGCA")            # gnrt_reverse_complementary, pick_contigs.py:19-33: upper-case output
+_BOTH, _LEFT, _RIGHT, _NONE = 1, 2, 3, 4                 # clip types (pick_contigs.py:9-12)
 
 
 def revcomp(s):
@@ -31,80 +34,110 @@ def read_fasta(path):
     return out
 
 
-def anchor_spans(seq, la, ra):
-    """Both orientations of one contig: [(span, left_end, right_start, oriented)] for every orientation in which the left anchor
-    occurs and the right anchor occurs at or behind its end — leftmost left anchor, rightmost right anchor, i.e. the longest
-    span the anchors allow (the reference keeps the longest span among its bwa hits, pick_contigs.py:300-321)."""
+def anchor_hits(contigs, left_flank, right_flank, score):
+    """The stand-in for `bwa mem -T {score} -a` (pick_contigs.py:79-86): [(side, reverse?, contig index, 1-based position in the
+    contig, clip type, matched bases)], per contig forward left / forward right / reverse left / reverse right.  Forward: the
+    LEFTMOST occurrence of the left anchor, the RIGHTMOST of the right anchor; reverse: the same in the reverse-complemented
+    contig, reported in the contig's own coordinates with the clip on the other end, as SAM does."""
+    a = int(score)
+    if len(left_flank) < a or len(right_flank) < a:
+        return []
+    la, ra = left_flank[len(left_flank) - a:], right_flank[:a]
+    if any(c not in "ACGT" for c in la + ra):
+        return []
+    l_clipped, r_clipped = len(left_flank) > a, len(right_flank) > a
     out = []
-    a = len(la)
-    for oriented in (seq, revcomp(seq)):
-        i = oriented.find(la)
-        if i < 0:
-            continue
-        j = oriented.rfind(ra)
-        if j < i + a:
-            continue
-        out.append((j - (i + a), i + a, j, oriented))
+    for ci, (_, seq) in enumerate(contigs):
+        n = len(seq)
+        for rev, s in ((False, seq), (True, revcomp(seq))):
+            i, j = s.find(la), s.rfind(ra)
+            if i >= 0:       # left flank = [clipped part][anchor]: clip in front on the forward strand, behind on the reverse strand
+                out.append(("left", rev, ci, n - i - a + 1 if rev else i + 1, _NONE if not l_clipped else _RIGHT if rev else _LEFT, a))
+            if j >= 0:
+                out.append(("right", rev, ci, n - j - a + 1 if rev else j + 1, _NONE if not r_clipped else _LEFT if rev else _RIGHT, a))
     return out
 
 
-def pick_gap_sequence(contigs, left_flank, right_flank, anchor_len):
-    """contigs: [(name, seq)].  Returns (name, gap_seq, oriented_contig) or None.  Longest span over all contigs and both
-    orientations; ties go to the first contig of the list, forward orientation first."""
-    if len(left_flank) < anchor_len or len(right_flank) < anchor_len:
-        return None
-    la, ra = left_flank[-anchor_len:], right_flank[:anchor_len]
-    if any(c not in "ACGT" for c in la + ra):
-        return None
+_PAIRS = ((_NONE, _NONE), (_NONE, _LEFT), (_NONE, _RIGHT), (_LEFT, _NONE), (_LEFT, _RIGHT), (_RIGHT, _NONE), (_RIGHT, _LEFT))
+
+
+def select_full(hits):
+    """pick_contigs.py:97-321 on hit tuples: (contig index, left pos, right pos, left match, right match, reverse?) or None."""
+    table = {}                                           # contig -> side -> clip type -> (reverse?, match, pos)
+    for side, rev, ci, pos, ct, m in hits:
+        if ct == _BOTH:
+            continue
+        slot = table.setdefault(ci, {}).setdefault(side, {})
+        if ct not in slot or m > slot[ct][1]:
+            slot[ct] = (rev, m, pos)
     best = None
-    for name, seq in contigs:
-        for span, left_end, j, oriented in anchor_spans(seq, la, ra):
-            if best is None or span > best[0]:
-                best = (span, name, oriented[left_end:j + 1], oriented)
+    for ci, sides in table.items():
+        if len(sides) != 2:
+            continue
+        top, sel, rc = -1, None, False
+        for lt, rt in _PAIRS:                            # the reference's seven pairs in its order (:173-291)
+            l, r = sides["left"].get(lt), sides["right"].get(rt)
+            if l is None or r is None or l[0] != r[0] or not top < l[1] + r[1]:
+                continue
+            top, sel = l[1] + r[1], (l[2], r[2], l[1], r[1])
+            rc = rc or l[0]                              # (:176-177: set by any winning reverse pair, never cleared)
+        if sel is None:
+            continue
+        lp, rp, lm, rm = sel
+        span = (lp - (rp + rm)) if rc else (rp - (lp + lm))
+        if span > (-1 if best is None else best[0]):     # longest span, the earlier contig on ties (:313-321)
+            best = (span, ci, lp, rp, lm, rm, rc)
     return None if best is None else best[1:]
+
+
+def pick_gap_sequence(contigs, left_flank, right_flank, anchor_len):
+    """contigs: [(name, seq)].  Returns (name, gap_seq, contig as written to picked_contigs.fa) or None (pick_contigs.py:331-358)."""
+    sel = select_full(anchor_hits(contigs, left_flank, right_flank, anchor_len))
+    if sel is None:
+        return None
+    ci, lp, rp, lm, rm, rc = sel
+    name, seq = contigs[ci]
+    if rc:
+        return name, revcomp(seq[rp + rm - 1:lp]), revcomp(seq)
+    return name, seq[lp + lm - 1:rp], seq
 
 
 def pick_extended_sequence(contigs, left_flank, right_flank, anchor_len):
     """The fallback of the last round (run_pick_extended_contig, pick_contigs.py:361-539): no contig carries both anchors in
-    order, so the gap is filled from each side as far as a contig reaches — left part = what follows the left anchor in the
-    contig that reaches furthest into the gap, right part = what precedes the right anchor — joined by 'NN' (:513-520).
-    The reference takes, per side, the bwa hit with the longest match and breaks ties by a comparison that is constant in
-    Python 2 (int > str, :444, :457), i.e. by dict order; with exact anchors every match has the same length, so this build
-    DEFINES the tie: the longest extension wins, then the first contig of the list, forward orientation first.  When both sides
-    pick the same contig the reference keeps only the side with the longer match, the right side on a tie (:468-486): here always
-    the right side.  Returns (left_name, right_name, sequence, contig_text) or None when neither anchor occurs."""
-    if len(left_flank) < anchor_len or len(right_flank) < anchor_len:
+    order, so the gap is filled from each side as far as a contig reaches and the parts are joined by 'NN' (:517-525).  Hit for
+    hit the reference's rule on the stand-in's hits: clipped hits only (:388-389), per side the contig with the longest match —
+    the anchors all match `anchor_len` bases and the reference's tie test is constant (int > str, :444, :457), so the FIRST contig
+    with a hit; when both sides pick the same contig only the right side is used, and its slice then keeps the first anchor base
+    (:480-486 vs :509-512); reverse-strand slices keep one anchor base as well (:496, :474).  Returns (left_name, right_name,
+    sequence or None, picked_contigs text or None)."""
+    first = {"left": None, "right": None}
+    for side, rev, ci, pos, ct, m in anchor_hits(contigs, left_flank, right_flank, anchor_len):
+        want = (_RIGHT if rev else _LEFT) if side == "left" else (_LEFT if rev else _RIGHT)
+        if ct == want and first[side] is None:
+            first[side] = (ci, pos, m, rev)
+    l, r = first["left"], first["right"]
+    if l is None and r is None:
         return None
-    la, ra = left_flank[-anchor_len:], right_flank[:anchor_len]
-    if any(c not in "ACGT" for c in la + ra):
-        return None
-    best_l = best_r = None        # (extension length, name, extension, contig as written)
-    for name, seq in contigs:
-        for oriented in (seq, revcomp(seq)):
-            i = oriented.find(la)
-            if i >= 0:
-                ext = oriented[i + anchor_len:]
-                if best_l is None or len(ext) > best_l[0]:
-                    best_l = (len(ext), name, ext, seq)
-            j = oriented.rfind(ra)
-            if j >= 0:
-                ext = oriented[:j]
-                if best_r is None or len(ext) > best_r[0]:
-                    best_r = (len(ext), name, ext, seq)
-    if best_l is None and best_r is None:
-        return None
-    if best_l is not None and best_r is not None and best_l[1] == best_r[1]:
-        best_l = None
-    left_name, left_seq = (best_l[1], best_l[2]) if best_l else ("", "")
-    right_name, right_seq = (best_r[1], best_r[2]) if best_r else ("", "")
-    seq = left_seq + "NN" + right_seq
-    if best_l and best_r:
-        contig_text = best_l[3] + "NN" + best_r[3]
+    l_seq = r_seq = text = ""
+    rc_l = rc_r = True
+    if l is not None and r is not None and l[0] == r[0]:
+        l = None
+        ci, pos, m, rc_r = r
+        seq = contigs[ci][1]
+        r_seq, text = (seq[pos + m - 1:] if rc_r else seq[:pos]), seq
+        rc_l = first["left"][3]
     else:
-        contig_text = (best_l or best_r)[3]
-    if seq == "NN":
-        return None
-    return left_name, right_name, seq, contig_text
+        if l is not None:
+            ci, pos, m, rc_l = l
+            seq = contigs[ci][1]
+            l_seq, text = (seq[:pos] if rc_l else seq[pos + m - 1:]), seq
+        if r is not None:
+            ci, pos, m, rc_r = r
+            seq = contigs[ci][1]
+            r_seq, text = (seq[pos + m - 1:] if rc_r else seq[:pos - 1]), text + "NN" + seq
+    out = (revcomp(l_seq) if rc_l else l_seq) + "NN" + (revcomp(r_seq) if rc_r else r_seq)
+    names = tuple(contigs[x[0]][0] if x is not None else "" for x in (first["left"], first["right"]))
+    return names[0], names[1], (out if out != "NN" else None), (text if text not in ("", "NN") else None)
 
 
 class ContigsSelection:
@@ -161,11 +194,13 @@ class ContigsSelection:
             left_name, right_name, seq, contig_text = res
             hdr = ">%s_%s_%s_extended\n" % (gid, left_name, right_name)
             for fn, body, dst in (("picked_seqs.fa", seq, sf_picked), ("picked_contigs.fa", contig_text, sf_picked + "_ori.txt")):
+                if body is None:                          # nothing but 'NN' to report: the file is not written (:527-537)
+                    continue
                 with open(wf + "velvet_temp/%s/%s" % (gid, fn), "w") as f:
                     f.write(hdr + body + "\n")
                 with open(dst, "a") as out:
                     out.write(hdr + body + "\n")
-            n += 1
+            n += seq is not None
         return n
 
     def get_already_picked(self, sf_picked):

@@ -335,10 +335,14 @@ int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const vo
 
 /* ---- §8f-1 on the device: flank anchoring (ContigsSelection, pick_contigs.py:64-358, with exact anchors instead of
  * `bwa mem -T {score}`: the last / first anchor_len bases of the left / right flank given to gf_set_gaps; 8 <= anchor_len <= 32;
- * the reference's scores are 30, then 15: assemble_gaps.py:336, 365).  For every contig and both orientations: leftmost left
- * anchor, rightmost right anchor behind it; d_gap_best[gap] (u64, caller zeroes; atomicMax, so several calls — other anchor
- * lengths, other contig lists — accumulate) = (span + 1) << 32 | (0x7FFFFFFF - contig index) << 1 | orientation, 0 = no
- * contig of the gap is anchored = gap not closed; *d_n_closed (u32, caller zeroes) counts the gaps that became non-zero. */
+ * the reference's scores are 30, then 15: assemble_gaps.py:336, 365).  Per contig the reference's pair choice (:149-297) on the
+ * exact-anchor hits: the forward pair (leftmost left anchor, rightmost right anchor) when both forward hits exist, else the
+ * reverse-strand pair; a pair counts when the right anchor starts at or behind the left anchor's end (:313-321).
+ * d_gap_best[gap] (u64, caller zeroes; atomicMax, so several calls — other anchor lengths, other contig lists — accumulate) =
+ * anchor_len << 56 | (span + 1) << 32 | (0x7FFFFFFF - contig index) << 1 | reverse strand: the longest span wins, the earlier
+ * contig on ties (:313-321), and a pick at a longer anchor outranks every pick at a shorter one (the pipeline tries 15 only on
+ * what 30 left open); 0 = no contig of the gap is anchored = gap not closed; *d_n_closed (u32, caller zeroes) counts the gaps
+ * that became non-zero. */
 int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
                          int anchor_len, void* d_gap_best, void* d_n_closed);
 
@@ -417,6 +421,9 @@ int gf_timing_reset(gf_ctx* ctx);
 int gf_synth_pairs_dev(gf_ctx* ctx, const void* cfg /* gf_synth_cfg */, uint64_t first_pair, size_t n_pairs,
                        void* d_packed_reads, void* d_alnrecs_or_null);
 int gf_synth_layout(const void* cfg /* gf_synth_cfg */, gf_gap* gaps, char* flank_ascii, uint64_t* flank_off);
+/* the true bases of [start, start + n) of a scaffold, the planted gaps' interiors included: ground truth for checking filled gaps
+ * (the reference's own evaluation compares picked sequences with the true ones: validate_gap_seqs.py:5-75) */
+int gf_synth_truth(const void* cfg /* gf_synth_cfg */, uint32_t scaffold, uint64_t start, size_t n, char* out_ascii);
 
 #ifdef __cplusplus
 }

@@ -405,3 +405,211 @@ def _rc(s):
 
 # Stage 2 (the kv-mer graph, unitigs, Velvet's default tip clipping + bubble popping) is restated in C only:
 # oracle/gp_oracle.c `or_assemble_pool2` (bound as oracle.c_oracle.assemble_pool) — the definition the GPU kernel is checked against.
+
+
+# ----------------------------------------------------------------------------- f-1: flank anchoring -> picked_seqs.fa
+# PINNED: tests/golden/pick_kat.json.gz holds flanks.sam texts + contigs and the files the reference's own pick_contigs.py wrote for
+# them (make_golden.py::pick_kat runs the 2to3-converted reference with a `bwa` stand-in that serves the prepared SAM text).  What is
+# NOT pinnable is which hits bwa itself would report (bwa is absent): `exact_anchor_sam` below DEFINES the stand-in.
+
+BOTH_CLIP, LEFT_CLIP, RIGHT_CLIP, UNCLIP = 1, 2, 3, 4
+
+
+def clip_type_length(cigar):
+    """pick_contigs.py:35-62: (clip type, total length of the M operations)."""
+    ops, temp, total_m = [], "", 0
+    for ch in cigar:
+        if "0" <= ch <= "9":
+            temp += ch
+        else:
+            if ch == "M":
+                total_m += int(temp)
+            ops.append(ch)
+            temp = ""
+    first, last = ops[0] in "SH", ops[-1] in "SH"
+    if first and last:
+        return BOTH_CLIP, total_m
+    if first:
+        return LEFT_CLIP, total_m
+    if last:
+        return RIGHT_CLIP, total_m
+    return UNCLIP, total_m
+
+
+def pick_revcomp(s):
+    """pick_contigs.py:19-33: complements ACGT of either case to UPPER case, keeps every other symbol."""
+    m = {"A": "T", "a": "T", "T": "A", "t": "A", "C": "G", "c": "G", "G": "C", "g": "C"}
+    return "".join(m.get(ch, ch) for ch in reversed(s))
+
+
+def pick_full_from_sam(gid, sam_text, contigs):
+    """run_pick_full_constructed_contig, pick_contigs.py:97-358, from the point where flanks.sam exists.  contigs = [(id, seq)]
+    in file order.  Returns (picked_seqs.fa text or None, picked_contigs.fa text or None): None = the file is not written.
+    Dicts iterate in insertion order (what the 2to3-converted reference does under Python 3; Python 2 iterates in hash order, so
+    among contigs of EQUAL span the reference's choice is arbitrary)."""
+    hits = {}                                            # rname -> side -> clip type -> (flag, map_length, map_pos)   :97-146
+    for line in sam_text.splitlines():
+        f = line.split()
+        if len(f) < 6:
+            continue
+        cigar, flag = f[5], int(f[1])
+        if cigar == "*":
+            continue
+        ct, ml = clip_type_length(cigar)
+        if ct == BOTH_CLIP:
+            continue
+        side = f[0].split("_")[-1]
+        if side not in ("left", "right"):
+            continue
+        slot = hits.setdefault(f[2], {}).setdefault(side, {})
+        if ct not in slot or ml > slot[ct][1]:           # first hit of a type stays on equal match length (:125-129)
+            slot[ct] = (flag, ml, int(f[3]))
+    picked = {}
+    for rname, h in hits.items():                        # :149-297
+        if len(h) != 2:
+            continue
+        best, sel, b_rc = -1, None, False
+        for lt, rt in ((UNCLIP, UNCLIP), (UNCLIP, LEFT_CLIP), (UNCLIP, RIGHT_CLIP), (LEFT_CLIP, UNCLIP), (LEFT_CLIP, RIGHT_CLIP),
+                       (RIGHT_CLIP, UNCLIP), (RIGHT_CLIP, LEFT_CLIP)):
+            if lt in h["left"] and rt in h["right"]:
+                lf, ll, lp = h["left"][lt]
+                rf, rl, rp = h["right"][rt]
+                if best < ll + rl and (lf & 16) == (rf & 16):
+                    best, sel = ll + rl, (lp, rp, ll, rl)
+                    if lf & 16:
+                        b_rc = True                      # never reset when a later forward pair wins (:176-177 ...)
+        if sel is not None:
+            picked[rname] = sel + (b_rc,)
+    s_picked, min_len = "", -1
+    for key, (lp, rp, ll, rl, rc) in picked.items():     # longest span, the first one on ties (:300-321)
+        start, end = (rp + rl, lp) if rc else (lp + ll, rp)
+        if end - start > min_len:
+            s_picked, min_len = key, end - start
+    if s_picked == "":
+        return None, None
+    lp, rp, ll, rl, rc = picked[s_picked]
+    seqs, ctgs = "", ""
+    for cid, s_ori in contigs:                           # :331-358
+        if cid != s_picked:
+            continue
+        if rc:
+            s_gap = pick_revcomp(s_ori[rp + rl - 1:lp])
+            s_contig = pick_revcomp(s_ori)
+        else:
+            s_gap = s_ori[lp + ll - 1:rp]
+            s_contig = s_ori
+        if s_gap != "":
+            seqs += ">" + gid + "_" + cid + "\n" + s_gap + "\n"
+        if s_contig != "":
+            ctgs += ">" + gid + "_" + cid + "\n" + s_contig + "\n"
+    return seqs, ctgs
+
+
+def pick_extended_from_sam(gid, sam_text, contigs):
+    """run_pick_extended_contig, pick_contigs.py:361-539 (reads the flanks.sam the last full pick left behind).  Returns
+    (picked_seqs.fa text or None, picked_contigs.fa text or None).  Quirks kept: strand = `flag*16 != 0` (:383-384: ANY non-zero
+    flag counts as reverse); on equal match lengths the tie test compares an int with a str (:444, :457) — constant False in
+    Python 2 (a TypeError in Python 3: the fixtures avoid such ties), so the first contig stays."""
+    m_contigs = dict(contigs)
+    hits = {}                                            # qname -> side -> rname -> (map_pos, map_length, b_rc)
+    for line in sam_text.splitlines():
+        f = line.split()
+        if len(f) < 6:
+            continue
+        cigar, flag = f[5], int(f[1])
+        if cigar == "*":
+            continue
+        b_rc = flag * 16 != 0
+        ct, ml = clip_type_length(cigar)
+        if ct in (UNCLIP, BOTH_CLIP):
+            continue
+        qname, rname, side = f[0], f[2], f[0].split("_")[-1]
+        if side == "left":
+            if (b_rc and ct == LEFT_CLIP) or (not b_rc and ct == RIGHT_CLIP):
+                continue
+        elif side == "right":
+            if (b_rc and ct == RIGHT_CLIP) or (not b_rc and ct == LEFT_CLIP):
+                continue
+        else:
+            continue
+        if qname not in hits:
+            hits[qname] = {side: {rname: (int(f[3]), ml, b_rc)}}
+        else:                                            # (a qname's other side would raise KeyError in the reference: not reachable,
+            slot = hits[qname][side]                     #  '{id}_left' only ever carries side 'left')
+            if rname not in slot or ml > slot[rname][1]:
+                slot[rname] = (int(f[3]), ml, b_rc)
+    s_left, s_right = "", ""
+    for qname, h in hits.items():                        # :430-459
+        for side in ("left", "right"):
+            best = 0
+            for rname, (_, ml, _) in h.get(side, {}).items():
+                if ml > best:
+                    best = ml
+                    if side == "left":
+                        s_left = rname
+                    else:
+                        s_right = rname
+    l_seq = r_seq = s_contig = ""
+    rc_l = rc_r = True
+    if s_left != "" and s_left == s_right:               # :468-491
+        lp, ll, rc_l = hits[gid + "_left"]["left"][s_left]
+        rp, rl, rc_r = hits[gid + "_right"]["right"][s_right]
+        if ll > rl:
+            l_seq = m_contigs[s_left][0:lp] if rc_l else m_contigs[s_left][lp + ll - 1:]
+            s_contig = m_contigs[s_left]
+        else:
+            r_seq = m_contigs[s_right][0:rp] if not rc_r else m_contigs[s_right][rp + rl - 1:]
+            s_contig = m_contigs[s_right]
+    else:                                                # :492-515
+        if s_left != "":
+            lp, ll, rc_l = hits[gid + "_left"]["left"][s_left]
+            l_seq = m_contigs[s_left][0:lp] if rc_l else m_contigs[s_left][lp + ll - 1:]
+            s_contig = m_contigs[s_left]
+        if s_right != "":
+            rp, rl, rc_r = hits[gid + "_right"]["right"][s_right]
+            r_seq = m_contigs[s_right][0:rp - 1] if not rc_r else m_contigs[s_right][rp + rl - 1:]
+            s_contig = s_contig + "NN" + m_contigs[s_right]
+    s_seq = (pick_revcomp(l_seq) if rc_l else l_seq) + "NN" + (pick_revcomp(r_seq) if rc_r else r_seq)   # :517-525
+    hdr = ">" + gid + "_" + s_left + "_" + s_right + "_extended\n"
+    return (hdr + s_seq + "\n" if s_seq not in ("", "NN") else None,
+            hdr + s_contig + "\n" if s_contig not in ("", "NN") else None)
+
+
+def exact_anchor_sam(gid, contigs, left_flank, right_flank, score):
+    """DEFINITION (bwa is absent: parity of this step unpinned) of the stand-in for `bwa mem -T {score} -a contigs.fa flanks.fa`
+    (pick_contigs.py:79-86): the only alignments reported are EXACT matches of the `score` flank bases next to the gap — the last
+    `score` bases of the left flank, the first `score` of the right flank, upper-case ACGT only — never extended.  Per contig, in
+    file order: forward strand left (its LEFTMOST occurrence), forward right (RIGHTMOST), reverse strand left (the occurrence that
+    is leftmost in the reverse-complemented contig), reverse right (rightmost there); flag 0 / 16 (no secondary flags), the rest of
+    the flank soft-clipped, reverse-strand lines in the contig's coordinates with the CIGAR reversed, as SAM has them."""
+    a = int(score)
+    if len(left_flank) < a or len(right_flank) < a:
+        return ""
+    la, ra = left_flank[len(left_flank) - a:], right_flank[:a]
+    if any(c not in "ACGT" for c in la + ra):
+        return ""
+    lclip, rclip = len(left_flank) - a, len(right_flank) - a
+    out = []
+    for name, seq in contigs:
+        n = len(seq)
+        rcs = _rc(seq) if all(c in "ACGT" for c in seq) else pick_revcomp(seq)
+        for flag, s in ((0, seq), (16, rcs)):
+            i, j = s.find(la), s.rfind(ra)
+            for qn, p, clip, clip_first in (("left", i, lclip, True), ("right", j, rclip, False)):
+                if p < 0:
+                    continue
+                pos = p + 1 if flag == 0 else n - p - a + 1
+                parts = ["%dM" % a]
+                if clip:
+                    parts = ["%dS" % clip] + parts if clip_first == (flag == 0) else parts + ["%dS" % clip]
+                out.append("%s_%s\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t*\t*" % (gid, qn, flag, name, pos, "".join(parts)))
+    return "".join(l + "\n" for l in out)
+
+
+def pick_gap(gid, contigs, left_flank, right_flank, score):
+    """The picker as this build runs it: the reference's selection on the stand-in's hits.  Returns (seqs text, contigs text)."""
+    return pick_full_from_sam(gid, exact_anchor_sam(gid, contigs, left_flank, right_flank, score), contigs)
+
+
+def pick_gap_extended(gid, contigs, left_flank, right_flank, score):
+    return pick_extended_from_sam(gid, exact_anchor_sam(gid, contigs, left_flank, right_flank, score), contigs)

@@ -419,6 +419,184 @@ def evaluate_kat():
     print("evaluate_kat:", len(out), "cases,", sum(len(o["results"]) for o in out), "node pairs,",
           sum(1 for o in out for r in o["results"] if r[2]), "with an overlap")
 
+BWA_SHIM = '''#!/usr/bin/env python3
+# stand-in for `bwa index <fa>` / `bwa mem -T <score> -a <contigs.fa> <flanks.fa>`: serves the prepared SAM text <contigs.fa>.sam
+import os, sys
+if sys.argv[1] == "mem":
+    p = sys.argv[-2] + ".sam"
+    if os.path.exists(p):
+        sys.stdout.write(open(p).read())
+'''
+
+SAMVIEW_SHIM = '''#!/usr/bin/env python3
+# stand-in for `samtools view -S -`: SAM text through, header lines dropped
+import sys
+for line in sys.stdin:
+    if not line.startswith("@"):
+        sys.stdout.write(line)
+'''
+
+PICK_DRIVER = '''
+import os, sys, json
+from Utility import set_software_paths, set_parameters
+bwa, samtools, wf, score, mode = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
+ids = sys.argv[6].split(",")
+set_software_paths(bwa, samtools, "x", "x", "/nonexistent/kmc/", "/nonexistent/velvet/")
+set_parameters("x", 1, wf, 0, 100, 300)
+import pick_contigs as M
+cs = M.ContigsSelection(wf)
+if mode == "full":
+    cs.pick_full_constructed_contigs(score, ids, wf + "../picked_seqs.fa")
+else:
+    for i in ids:                      # one gap at a time: an int-vs-str tie test (a TypeError under Python 3) must not take the others down
+        try:
+            M.run_pick_extended_contig(i)
+        except TypeError:
+            open(wf + "velvet_temp/%s/TIE" % i, "w").close()
+'''
+
+
+def pick_kat():
+    """Known answers of the reference's own contig picker (pick_contigs.py:64-358 full pick, 361-539 extended pick) for prepared
+    flanks.sam texts: hand-built cases (every clip-type pair, both strands, several hits of one type, equal spans, hits that must be
+    ignored) and random hit sets.  bwa is absent, so a stand-in serves the prepared SAM text; everything downstream of flanks.sam is
+    the reference's code.  Output: tests/golden/pick_kat.json.gz = [{id, contigs, sam, score, full: [seqs, contigs, ledger], ext: [seqs, contigs] | "TIE"}]."""
+    import random
+    rng = random.Random(20260310)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+
+    def sam(gid, side, flag, rname, pos, cigar):
+        return "%s_%s\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t*\t*\n" % (gid, side, flag, rname, pos, cigar)
+    cases = []
+
+    def add(contigs, lines, score=30):
+        gid = "%d_%d" % (len(cases) // 7, len(cases) % 7 + 1)
+        cases.append({"id": gid, "contigs": contigs, "sam": "".join(sam(gid, *l) for l in lines), "score": score})
+    c = [("NODE_1_length_372_cov_9.000000", rnd(400)), ("NODE_2_length_172_cov_4.500000", rnd(200)), ("NODE_3_length_72_cov_2.000000", rnd(100))]
+    n1, n2, n3 = (x[0] for x in c)
+    add(c, [("left", 0, n1, 21, "265S30M"), ("right", 0, n1, 301, "30M265S")])                       # the plain forward case
+    add(c, [("left", 16, n1, 301, "30M265S"), ("right", 16, n1, 21, "265S30M")])                     # both on the reverse strand
+    add(c, [("left", 0, n1, 21, "265S30M"), ("right", 16, n1, 301, "30M265S")])                      # strands differ: nothing
+    add(c, [("left", 0, n1, 21, "265S30M"), ("right", 0, n1, 301, "265S30M")])                       # (left clip, left clip): no such pair
+    add(c, [("left", 0, n1, 1, "295M"), ("right", 0, n1, 330, "60M235S")])                           # unclipped + right clip
+    add(c, [("left", 0, n1, 1, "295M"), ("right", 0, n1, 330, "71M")])                               # unclipped + unclipped
+    add(c, [("left", 0, n1, 300, "30M265S"), ("right", 0, n1, 5, "265S30M")])                        # (right clip, left clip) forward: negative span
+    add(c, [("left", 0, n1, 21, "100S30M165S"), ("right", 0, n1, 301, "30M265S")])                   # both-clipped hit ignored
+    add(c, [("left", 0, n1, 21, "265S30M"), ("left", 0, n1, 51, "255S40M"), ("right", 0, n1, 301, "30M265S")])      # longer match of one type replaces
+    add(c, [("left", 0, n1, 21, "265S30M"), ("left", 0, n1, 51, "265S30M"), ("right", 0, n1, 301, "30M265S")])      # equal match: the first stays
+    add(c, [("left", 0, n1, 21, "265S30M"), ("right", 0, n1, 301, "30M265S"), ("left", 0, n2, 11, "265S30M"), ("right", 0, n2, 151, "30M265S")])   # two contigs: longest span
+    add(c, [("left", 0, n2, 11, "265S30M"), ("right", 0, n2, 151, "30M265S"), ("left", 0, n1, 21, "265S30M"), ("right", 0, n1, 301, "30M265S")])
+    add(c, [("left", 0, n2, 11, "265S30M"), ("right", 0, n2, 151, "30M265S"), ("left", 0, n3, 1, "265S30M"), ("right", 0, n3, 141, "30M265S")])    # hmm: equal spans (110): the first
+    add(c, [("left", 0, n1, 21, "265S30M"), ("right", 0, n2, 151, "30M265S")])                       # flanks on different contigs: extended only
+    add(c, [("left", 16, n1, 301, "30M265S"), ("right", 0, n2, 151, "30M265S")])
+    add(c, [("left", 0, n1, 21, "265S30M")])                                                         # one side only
+    add(c, [("right", 16, n2, 21, "265S30M")])
+    add(c, [("left", 0, n1, 21, "*"), ("right", 0, n1, 301, "30M265S")])                             # unaligned line
+    add(c, [("left", 0, n1, 21, "265S30M"), ("right", 0, n1, 51, "30M265S")])                        # span 0: one base written (the slice's +1)
+    add(c, [("left", 0, n1, 21, "265S30M"), ("right", 0, n1, 50, "30M265S")])                        # span -1: picked_seqs.fa written EMPTY
+    add(c, [("left", 16, n1, 301, "30M265S"), ("right", 16, n1, 21, "265S30M"), ("left", 0, n1, 40, "265S25M"), ("right", 0, n1, 200, "45M250S")])  # a longer forward pair after a reverse one: b_rc sticks
+    add(c, [("left", 256, n1, 21, "265S30M"), ("right", 256, n1, 301, "30M265S")])                   # secondary lines (-a): extended treats them as reverse
+    add(c, [("left", 0, n1, 21, "265S20M3I7M"), ("right", 0, n1, 301, "12M2D18M265S")], 15)          # indels: only M counts
+    add([("a", rnd(80).lower()), ("b", "ACGTNNRYacgt" * 10)], [("left", 16, "b", 60, "20M5S"), ("right", 16, "b", 11, "5S20M"),
+                                                                 ("left", 0, "a", 5, "5S20M"), ("right", 0, "a", 50, "20M5S")], 15)   # lower case, IUPAC: revcomp's table
+    types_l = ["%dS%dM", "%dM%dS", "%dM"]
+    for _ in range(240):                                 # random hit sets over 1-4 contigs
+        ctg = [("c%d" % i, rnd(rng.randrange(60, 400))) for i in range(rng.randrange(1, 5))]
+        lines = []
+        for _h in range(rng.randrange(1, 9)):
+            name, s = rng.choice(ctg)
+            m = rng.randrange(15, 60)
+            t = rng.choice(types_l)
+            cigar = t % ((295 - m, m) if t.startswith("%dS") else (m, 295 - m) if t.endswith("S") else (m,))
+            lines.append((rng.choice(["left", "right"]), rng.choice([0, 0, 16, 16, 256]), name, rng.randrange(1, max(2, len(s) - m)), cigar))
+        add(ctg, lines, rng.choice([30, 15]))
+    for _ in range(240):                                 # random PAIRS (one left + one right hit per contig, mostly compatible) + noise lines
+        ctg = [("c%d" % i, rnd(rng.randrange(120, 500))) for i in range(rng.randrange(1, 5))]
+        lines = []
+        for name, s in ctg:
+            if rng.random() < 0.25:
+                continue
+            rcs = rng.random() < 0.4
+            ml, mr = rng.randrange(15, 50), rng.randrange(15, 50)
+            a, b = sorted((rng.randrange(1, len(s) - 60), rng.randrange(1, len(s) - 60)))
+            if rng.random() < 0.15:
+                a, b = b, a
+            kind = rng.random()
+            lc = "%dM" % ml if kind < 0.15 else ("%dM%dS" % (ml, 295 - ml) if rcs else "%dS%dM" % (295 - ml, ml))
+            rcg = "%dM" % mr if 0.1 < kind < 0.25 else ("%dS%dM" % (295 - mr, mr) if rcs else "%dM%dS" % (mr, 295 - mr))
+            fl = 16 if rcs else 0
+            pair = [("left", fl, name, b if rcs else a, lc), ("right", fl if rng.random() < 0.9 else 16 - fl, name, a if rcs else b, rcg)]
+            rng.shuffle(pair)
+            lines += pair
+        for _h in range(rng.randrange(0, 3)):
+            name, s = rng.choice(ctg)
+            m = rng.randrange(15, 60)
+            lines.insert(rng.randrange(0, len(lines) + 1), (rng.choice(["left", "right"]), rng.choice([0, 16]), name, rng.randrange(1, len(s) - m),
+                                                             rng.choice(["%dS%dM" % (295 - m, m), "%dM%dS" % (m, 295 - m), "*", "10S%dM10S" % m])))
+        add(ctg, lines, rng.choice([30, 15]))
+    tmp = tempfile.mkdtemp(prefix="gp_pick_")
+    try:
+        code = os.path.join(tmp, "code")
+        os.mkdir(code)
+        _, bindir = convert_reference(code)
+        for name, text in (("bwa_shim.py", BWA_SHIM), ("samview_shim.py", SAMVIEW_SHIM), ("run_pick.py", PICK_DRIVER)):
+            with open(os.path.join(code, name), "w") as f:
+                f.write(text)
+            os.chmod(os.path.join(code, name), 0o755)
+        env = dict(os.environ)
+        env["PATH"] = bindir + ":" + env["PATH"]
+        wf = os.path.join(tmp, "wf", "merged") + "/"
+        os.makedirs(os.path.join(tmp, "wf", "flank_regions"))
+        for cs in cases:
+            d = wf + "velvet_temp/%s/" % cs["id"]
+            os.makedirs(d)
+            with open(d + "contigs.fa", "w") as f:
+                f.write("".join(">%s\n%s\n" % (n, "\n".join(s[i:i + 60] for i in range(0, len(s), 60))) for n, s in cs["contigs"]))
+            with open(d + "contigs.fa.sam", "w") as f:
+                f.write("@SQ\tSN:x\tLN:1\n" + cs["sam"])
+            with open(os.path.join(tmp, "wf", "flank_regions", cs["id"] + ".fa"), "w") as f:
+                f.write(">%s_left\nACGT\n>%s_right\nACGT\n" % (cs["id"], cs["id"]))
+        rd = lambda p: open(p).read() if os.path.exists(p) else None
+        for score in (30, 15):
+            ids = [cs["id"] for cs in cases if cs["score"] == score]
+            ledger = os.path.join(tmp, "wf", "picked_seqs.fa")
+            for p in (ledger, ledger + "_ori.txt"):
+                if os.path.exists(p):
+                    os.remove(p)
+            subprocess.check_call([sys.executable, "run_pick.py", os.path.join(code, "bwa_shim.py"), os.path.join(code, "samview_shim.py"), wf,
+                                   str(score), "full", ",".join(ids)], cwd=code, env=env, stdout=subprocess.DEVNULL)
+            for cs in cases:
+                if cs["score"] == score:
+                    d = wf + "velvet_temp/%s/" % cs["id"]
+                    assert rd(d + "flanks.sam") == cs["sam"]
+                    cs["full"] = [rd(d + "picked_seqs.fa"), rd(d + "picked_contigs.fa")]
+            ledgers = [rd(ledger), rd(ledger + "_ori.txt")]
+            for cs in cases:
+                if cs["score"] == score:
+                    cs["ledgers_of_score"] = ledgers if cs["id"] == ids[0] else None
+            # the extended pick re-reads the flanks.sam of the full pick (it never runs bwa itself); start from a clean folder like the
+            # reference's last round does for gaps the full pick left open
+            for cs in cases:
+                if cs["score"] == score:
+                    d = wf + "velvet_temp/%s/" % cs["id"]
+                    for fn in ("picked_seqs.fa", "picked_contigs.fa"):
+                        if os.path.exists(d + fn):
+                            os.remove(d + fn)
+            subprocess.check_call([sys.executable, "run_pick.py", os.path.join(code, "bwa_shim.py"), os.path.join(code, "samview_shim.py"), wf,
+                                   str(score), "ext", ",".join(ids)], cwd=code, env=env, stdout=subprocess.DEVNULL)
+            for cs in cases:
+                if cs["score"] == score:
+                    d = wf + "velvet_temp/%s/" % cs["id"]
+                    cs["ext"] = "TIE" if os.path.exists(d + "TIE") else [rd(d + "picked_seqs.fa"), rd(d + "picked_contigs.fa")]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with gzip.GzipFile(os.path.join(HERE, "pick_kat.json.gz"), "wb", mtime=0) as gzf:
+        gzf.write(json.dumps(cases, sort_keys=True).encode())
+    print("pick_kat:", len(cases), "cases,", sum(1 for c in cases if c["full"][0]), "full picks,",
+          sum(1 for c in cases if c["ext"] != "TIE" and c["ext"][0]), "extended picks,", sum(1 for c in cases if c["ext"] == "TIE"), "int-vs-str ties")
+
 
 def main():
     if not os.path.isdir(REF):
@@ -426,6 +604,7 @@ def main():
     kmerutils_kat()
     quickcheck_kat()
     evaluate_kat()
+    pick_kat()
     for name, seed in (("twolib", 20260001), ("edge", 20260011), ("bounds", 20260031), ("c1", 20260001)):
         case = make_case(name, seed)
         d = os.path.join(HERE, name)

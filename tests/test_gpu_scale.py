@@ -114,47 +114,46 @@ def _rand_seq(rng, n):
     return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
 
 
-def test_device_flank_anchoring_equals_the_host_picker():
-    """gf_pick_anchored_dev vs pick_contigs.pick_gap_sequence (the definition of "closed", pick_contigs.py:64-358 with exact
-    anchors): both orientations, repeated anchors (longest span), anchors in the wrong order, overlapping anchors, a contig
-    shorter than the anchors, a gap without flanks."""
+def decode_best(b):
+    """gap_best word -> (anchor length, span + 1, contig index, reverse?)."""
+    b = int(b)
+    return b >> 56, (b >> 32) & 0xFFFFFF, 0x7FFFFFFF - ((b >> 1) & 0x7FFFFFFF), b & 1
+
+
+def oracle_pick(gid, contigs, left, right, scores=(30, 15)):
+    """The pipeline's pick of one gap — the first score that picks something (assemble_gaps.py:336-366) — by the oracle:
+    (score, contig index, gap sequence, reverse?) or None.  contigs = [(name, seq)] with unique names."""
+    from oracle import gp_oracle as O
+    for a in scores:
+        seqs, ctgs = O.pick_gap(gid, contigs, left, right, a)
+        if seqs:
+            hdr, body = seqs.split("\n")[:2]
+            name = hdr[len(">" + gid + "_"):]
+            ci = [n for n, _ in contigs].index(name)
+            written = ctgs.split("\n")[1]
+            rev = written != contigs[ci][1]
+            assert rev or written == contigs[ci][1]
+            return a, ci, body, rev
+    return None
+
+
+def test_device_flank_anchoring_equals_the_oracle_picker():
+    """gf_pick_anchored_dev vs oracle/gp_oracle.py::pick_gap (the reference's selection, pick_contigs.py:97-358, pinned on its own
+    answers, on the exact-anchor stand-in's hits): contig, strand and span of every gap — both orientations, repeated anchors,
+    anchors in the wrong order / overlapping / back to back, forward and reverse pair in one contig, flanks shorter than or exactly
+    as long as the anchor, non-ACGT in an anchor; the pick at 30 outranks any pick at 15."""
     import torch
     from gappadder_amd import _lib as B
     from gappadder_amd.hip_api import GapFill
-    from gappadder_amd.pick_contigs import pick_gap_sequence, revcomp
-    rng = np.random.default_rng(11)
-    n_gaps = 40
-    flanks = [(_rand_seq(rng, 120), _rand_seq(rng, 120)) for _ in range(n_gaps)]
-    flanks[7] = ("ACGT" * 5, "TTGA" * 5)              # shorter than anchor 30
-    flanks[8] = (flanks[8][0][:-3] + "NNN", flanks[8][1])
+    import pick_util as PK
+    cases = PK.picker_cases(11, 300)
+    n_gaps = len(cases)
+    flanks = [(l, r) for l, r, _ in cases]
     gaps = np.zeros(n_gaps, dtype=B.GAP)
     for g in range(n_gaps):
         gaps[g] = (0, 1000 * (g + 1), 1000 * (g + 1) + 100, g + 1)
-    contigs = []                                          # (gap, seq)
-    for g in range(n_gaps):
-        l, r = flanks[g]
-        for a in (30, 15):
-            la, ra = l[-a:], r[:a]
-            mid = _rand_seq(rng, int(rng.integers(0, 300)))
-            kind = (g + a) % 8
-            if kind == 0:
-                s = _rand_seq(rng, 50) + la + mid + ra + _rand_seq(rng, 40)
-            elif kind == 1:
-                s = revcomp(_rand_seq(rng, 20) + la + mid + ra + _rand_seq(rng, 5))
-            elif kind == 2:                               # repeated anchors: leftmost left / rightmost right
-                s = la + _rand_seq(rng, 30) + la + mid + ra + _rand_seq(rng, 17) + ra
-            elif kind == 3:                               # wrong order
-                s = ra + mid + la
-            elif kind == 4:                               # anchors back to back (span 0)
-                s = _rand_seq(rng, 9) + la + ra
-            elif kind == 5:                               # only one anchor
-                s = _rand_seq(rng, 60) + la + mid
-            elif kind == 6:                               # right anchor overlapping the left anchor's end: no pair
-                s = la[:-5] + ra
-            else:
-                s = _rand_seq(rng, int(rng.integers(10, 25)))
-            contigs.append((g, s))
-        contigs.append((g, _rand_seq(rng, 200)))
+    rng = np.random.default_rng(12)
+    contigs = [(g, s) for g, (_, _, seqs) in enumerate(cases) for s in seqs]
     order = rng.permutation(len(contigs))
     contigs = [contigs[i] for i in order]
     ctg = np.zeros(len(contigs), dtype=B.CONTIG)
@@ -168,29 +167,28 @@ def test_device_flank_anchoring_equals_the_host_picker():
     lib = B.lib()
     d_ctg, d_seq = _dev(ctg.view(np.uint8)), _dev(np.frombuffer(seq.encode(), dtype=np.uint8))
     d_n = torch.tensor([len(contigs)], dtype=torch.int32, device="cuda")
-    d_best = torch.zeros(n_gaps, dtype=torch.int64, device="cuda")
-    d_closed = torch.zeros(1, dtype=torch.int32, device="cuda")
-    closed_host = 0
-    for a in (30, 15):
-        assert lib.gf_pick_anchored_dev(gf.handle, d_ctg.data_ptr(), d_n.data_ptr(), len(contigs), d_seq.data_ptr(), a, d_best.data_ptr(),
-                                        d_closed.data_ptr()) == 0
-    gf.sync()
-    best = d_best.cpu().numpy().view(np.uint64)
-    n_some = 0
-    for g in range(n_gaps):
-        mine = [("c%d" % i, s) for i, (gg, s) in enumerate(contigs) if gg == g]
-        want = 0
-        for a in (30, 15):
-            r = pick_gap_sequence(mine, flanks[g][0], flanks[g][1], a)
-            if r is not None:
-                want = max(want, len(r[1]))
-        assert int(best[g]) >> 32 == want, (g, int(best[g]) >> 32, want)
-        if want:
-            closed_host += 1
-            ci = 0x7FFFFFFF - ((int(best[g]) >> 1) & 0x7FFFFFFF)
-            assert contigs[ci][0] == g                    # the winning contig belongs to the gap
-            n_some += 1
-    assert int(d_closed[0]) == closed_host and 10 < n_some < n_gaps
+    for scores in ((30, 15), (15, 30)):                     # the order of the calls does not matter: the longer anchor outranks
+        d_best = torch.zeros(n_gaps, dtype=torch.int64, device="cuda")
+        d_closed = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for a in scores:
+            assert lib.gf_pick_anchored_dev(gf.handle, d_ctg.data_ptr(), d_n.data_ptr(), len(contigs), d_seq.data_ptr(), a, d_best.data_ptr(),
+                                            d_closed.data_ptr()) == 0
+        gf.sync()
+        best = d_best.cpu().numpy().view(np.uint64)
+        n_closed = n_rev = n_15 = 0
+        for g in range(n_gaps):
+            mine = [("c%d" % i, s) for i, (gg, s) in enumerate(contigs) if gg == g]
+            idx = [i for i, (gg, _) in enumerate(contigs) if gg == g]
+            want = oracle_pick("0_%d" % (g + 1), mine, flanks[g][0], flanks[g][1])
+            if want is None:
+                assert int(best[g]) == 0, g
+                continue
+            a, ci, body, rev = want
+            assert decode_best(best[g]) == (a, len(body), idx[ci], int(rev)), (g, decode_best(best[g]), want)
+            n_closed += 1
+            n_rev += rev
+            n_15 += a == 15
+        assert int(d_closed[0]) == n_closed and n_closed > 100 and n_rev > 20 and n_15 > 20 and n_closed < n_gaps - 20
 
 
 def test_multi_k_call_equals_one_call_per_pair():

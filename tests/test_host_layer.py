@@ -75,23 +75,6 @@ def test_gap_scan_quirks():
         assert flanks(s, start, start + 50, 300) == O.flank_seqs(s, start, start + 50, 300)
 
 
-def test_pick_gap_sequence_anchors_and_quirks():
-    from gappadder_amd.pick_contigs import pick_gap_sequence, revcomp
-    import numpy as np
-    rng = np.random.RandomState(3)
-    g = "".join("ACGT"[i] for i in rng.randint(0, 4, 1200))
-    left, gap, right = g[100:395], g[395:605], g[605:900]      # flanks exclude 5 bp next to the gap (gnrt_pos_true_seqs.py:94-99)
-    contig = g[50:950]
-    for c in (contig, revcomp(contig)):
-        name, seq, oriented = pick_gap_sequence([("short", g[380:500]), ("NODE_1", c)], left, right, 30)
-        assert name == "NODE_1" and oriented == contig
-        assert seq == gap + right[0]                             # the reference's slice keeps one base of the right flank
-    assert pick_gap_sequence([("a", g[50:600])], left, right, 30) is None          # right anchor missing
-    assert pick_gap_sequence([("a", contig)], left[:20], right, 30) is None        # flank shorter than the anchor
-    two = [("a", g[300:700]), ("b", g[300:395] + "ACGT" * 70 + g[605:700])]        # longest span wins (pick_contigs.py:300-321)
-    assert pick_gap_sequence(two, left, right, 30)[0] == "b"
-
-
 def test_both_unmapped_round_files_match_reference(tmp_path):
     """collect_both_unmapped_reads.py, file side: the per-BAM / merged / split both-unmapped FASTQ files and
     gap_contigs_all.fa equal what the reference wrote for the same SAM text and the same first-round contigs
@@ -147,55 +130,65 @@ def _rnd(rng, n):
     return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
 
 
-def test_pick_takes_the_longest_span_over_all_anchor_occurrences_and_both_orientations():
+def test_host_picker_equals_the_oracle_on_exact_anchor_hits():
+    """gappadder_amd.pick_contigs (hit tuples) against oracle/gp_oracle.py::pick_gap / pick_gap_extended — the reference's selection,
+    pinned on its own answers, applied to the SAM text of the exact-anchor stand-in — full and extended pick, anchors 30 and 15."""
+    from gappadder_amd.pick_contigs import pick_extended_sequence, pick_gap_sequence
+    from oracle import gp_oracle as O
+    import pick_util as PK
+    n_full = n_ext = 0
+    for g, (l, r, seqs) in enumerate(PK.picker_cases(21, 400)):
+        contigs = [("c%d" % i, s) for i, s in enumerate(seqs)]
+        gid = "0_%d" % (g + 1)
+        for a in (30, 15):
+            res = pick_gap_sequence(contigs, l, r, a)
+            mine = (None, None) if res is None else (">%s_%s\n%s\n" % (gid, res[0], res[1]), ">%s_%s\n%s\n" % (gid, res[0], res[2]))
+            assert mine == O.pick_gap(gid, contigs, l, r, a), (g, a)
+            n_full += res is not None
+            res = pick_extended_sequence(contigs, l, r, a)
+            if res is None:
+                mine = (None, None)
+            else:
+                hdr = ">%s_%s_%s_extended\n" % (gid, res[0], res[1])
+                mine = tuple(hdr + x + "\n" if x is not None else None for x in res[2:])
+            assert mine == O.pick_gap_extended(gid, contigs, l, r, a), (g, a)
+            n_ext += res is not None and res[2] is not None
+    assert n_full > 200 and n_ext > 300
+
+
+def test_pick_quirks_of_the_reference_slices():
     import numpy as np
-    from gappadder_amd.pick_contigs import pick_gap_sequence, revcomp
+    from gappadder_amd.pick_contigs import pick_extended_sequence, pick_gap_sequence, revcomp
     rng = np.random.default_rng(3)
     left, right = _rnd(rng, 100), _rnd(rng, 100)
     la, ra = left[-30:], right[:30]
     gap = _rnd(rng, 200)
-    # one contig with the left anchor twice and the right anchor twice: leftmost left, rightmost right (pick_contigs.py:300-321)
     c1 = _rnd(rng, 10) + la + _rnd(rng, 20) + la + gap + ra + _rnd(rng, 15) + ra + _rnd(rng, 5)
     name, seq, oriented = pick_gap_sequence([("a", c1)], left, right, 30)
     i, j = c1.find(la) + 30, c1.rfind(ra)
-    assert seq == c1[i:j + 1] and oriented == c1            # the +1: the reference's 1-based / 0-based slice (:341-349)
-    # the reverse-complemented contig gives the same gap sequence, reported in flank orientation
-    assert pick_gap_sequence([("a", revcomp(c1))], left, right, 30)[1] == seq
-    # among contigs the longest span wins, ties go to the first
+    assert seq == c1[i:j + 1] and oriented == c1            # forward: the slice keeps the first base of the right anchor (:341-349)
+    name, seq_rc, oriented = pick_gap_sequence([("a", revcomp(c1))], left, right, 30)
+    assert seq_rc == c1[i - 1:j] and oriented == c1         # reverse: it keeps the last base of the LEFT anchor instead (:343-345)
     c2 = la + gap[:50] + ra
-    assert pick_gap_sequence([("short", c2), ("long", c1)], left, right, 30)[0] == "long"
-    assert pick_gap_sequence([("x", c2), ("y", c2)], left, right, 30)[0] == "x"
-    # anchors in the wrong order, overlapping, or missing: not closed
-    assert pick_gap_sequence([("w", ra + gap + la)], left, right, 30) is None
-    assert pick_gap_sequence([("o", la[:-5] + ra)], left, right, 30) is None
-    assert pick_gap_sequence([("m", la + gap)], left, right, 30) is None
-    # a shorter anchor (the reference's second score, 15) finds what 30 misses when a base of the anchor differs
+    assert pick_gap_sequence([("short", c2), ("long", c1)], left, right, 30)[0] == "long"      # longest span (:313-321)
+    assert pick_gap_sequence([("x", c2), ("y", c2)], left, right, 30)[0] == "x"                # ties: the first
+    assert pick_gap_sequence([("w", ra + gap + la)], left, right, 30) is None                  # wrong order
+    assert pick_gap_sequence([("o", la[:-5] + ra)], left, right, 30) is None                   # overlapping
+    assert pick_gap_sequence([("m", la + gap)], left, right, 30) is None                       # one anchor
+    assert pick_gap_sequence([("z", la + ra)], left, right, 30)[1] == ra[0]                    # span 0: one base
     c3 = left[-15:] + gap + right[:15]
     assert pick_gap_sequence([("c", c3)], left, right, 30) is None and pick_gap_sequence([("c", c3)], left, right, 15)[1] == gap + right[0]
-
-
-def test_extended_pick_joins_partial_fills_with_NN():
-    import numpy as np
-    from gappadder_amd.pick_contigs import pick_extended_sequence, revcomp
-    rng = np.random.default_rng(4)
-    left, right = _rnd(rng, 80), _rnd(rng, 80)
-    la, ra = left[-15:], right[:15]
+    # extended (:361-539): left part + 'NN' + right part; the FIRST contig with a hit per side; right-only picked_contigs = 'NN' + contig
     into_gap, out_of_gap = _rnd(rng, 120), _rnd(rng, 90)
-    cl = left[-40:] + into_gap                      # reaches 120 bases into the gap from the left
-    cr = revcomp(out_of_gap + right[:50])           # reaches 90 bases into the gap from the right, written reverse-complemented
-    ln, rn, seq, txt = pick_extended_sequence([("L", cl), ("R", cr), ("junk", _rnd(rng, 200))], left, right, 15)
-    assert (ln, rn) == ("L", "R") and seq == into_gap + "NN" + out_of_gap and txt == cl + "NN" + cr
-    # only one side reachable
-    assert pick_extended_sequence([("L", cl)], left, right, 15)[:3] == ("L", "", into_gap + "NN")
-    assert pick_extended_sequence([("R", cr)], left, right, 15)[:3] == ("", "R", "NN" + out_of_gap)
-    # the longer extension wins per side
-    cl2 = la + into_gap[:30]
-    assert pick_extended_sequence([("s", cl2), ("L", cl)], left, right, 15)[0] == "L"
-    # one contig hit by both anchors (but not in order): the right side only (pick_contigs.py:468-486, equal match lengths)
-    pre = _rnd(rng, 25)
-    both = pre + ra + _rnd(rng, 30) + la + into_gap[:10]
-    assert pick_extended_sequence([("b", both)], left, right, 15)[:3] == ("", "b", "NN" + pre)
-    assert pick_extended_sequence([("b", ra + _rnd(rng, 30) + la)], left, right, 15) is None      # nothing but 'NN' to report
+    cl, cr = left[-40:] + into_gap, out_of_gap + right[:50]
+    assert pick_extended_sequence([("L", cl), ("R", cr)], left, right, 15) == ("L", "R", into_gap + "NN" + out_of_gap, cl + "NN" + cr)
+    assert pick_extended_sequence([("L", cl)], left, right, 15) == ("L", "", into_gap + "NN", cl)
+    assert pick_extended_sequence([("R", cr)], left, right, 15) == ("", "R", "NN" + out_of_gap, "NN" + cr)
+    assert pick_extended_sequence([("s", left[-15:] + "ACGTA"), ("L", cl)], left, right, 15)[0] == "s"
+    assert pick_extended_sequence([("R", revcomp(cr))], left, right, 15)[2] == "NN" + out_of_gap
+    assert pick_extended_sequence([("L", revcomp(cl))], left, right, 15)[2] == left[-1] + into_gap + "NN"   # reverse left: one anchor base rides along (:496)
+    both = out_of_gap[:25] + right[:15] + _rnd(rng, 30) + left[-15:] + into_gap[:10]          # one contig, anchors out of order
+    assert pick_extended_sequence([("b", both)], left, right, 15)[:3] == ("b", "b", "NN" + out_of_gap[:25] + right[0])
     assert pick_extended_sequence([("n", _rnd(rng, 300))], left, right, 15) is None
 
 
@@ -218,3 +211,38 @@ def test_extended_pick_writes_the_reference_files(tmp_path):
     txt = open(sf).read()
     assert txt == ">0_1_31_29_NODE_1_length_60_cov_3.000000__extended\n%sNN\n" % fill
     assert "0_1" in cs.get_already_picked(sf)
+
+
+def test_truth_check_of_closed_gaps_catches_wrong_fills():
+    """bench.py::truth_check (the `gaps_closed_correct` count): a picked sequence equal to the true bases behind the planted gap counts
+    as correct on either strand; one substituted or one missing base inside the gap does not."""
+    import numpy as np
+    import bench
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    from gappadder_amd.pick_contigs import revcomp
+    cfg = GapFill.synth_cfg(seed=77, scaffold_len=200_000, n_scaffolds=2, gaps_per_scaffold=3, gap_len=500)
+    gaps, flanks = GapFill.synth_layout(cfg)
+    contigs, words = [], []
+    for g in range(len(gaps)):
+        st, en, sc = int(gaps[g]["start"]), int(gaps[g]["end"]), int(gaps[g]["scaffold"])
+        t = GapFill.synth_truth(cfg, sc, st - 100, en - st + 200)
+        assert t[100 - 5 - 30:100 - 5] == flanks[g][0][-30:] and t[en - st + 105:en - st + 135] == flanks[g][1][:30]
+        if g == 1:
+            t = t[:300] + ("A" if t[300] != "A" else "C") + t[301:]           # a substitution inside the gap
+        if g == 2:
+            t = t[:350] + t[351:]                                             # a missing base
+        rev = g in (3, 4)
+        if g == 4:
+            t = t[:222] + ("G" if t[222] != "G" else "T") + t[223:]
+        contigs.append(revcomp(t) if rev else t)
+        words.append((30 << 56) | ((len(t) - 200 + 11) << 32) | ((0x7FFFFFFF - g) << 1) | int(rev))
+    words[5] = 0                                                              # an open gap is not looked at
+    ctg = np.zeros(len(contigs), dtype=B.CONTIG)
+    off = 0
+    for i, s in enumerate(contigs):
+        ctg[i] = (i, 31, 29, len(s) - 28, len(s), 0, 0, off)
+        off += len(s)
+    r = bench.truth_check(cfg, gaps, flanks, ctg, "".join(contigs).encode(), np.array(words, dtype=np.uint64), GapFill)
+    assert r["closed"] == 5 and r["correct"] == 2 and sorted(w["gap"] for w in r["wrong"]) == [1, 2, 4]
+    assert r["causes"] == {"substitutions": 2, "length -1": 1}

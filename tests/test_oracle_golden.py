@@ -142,3 +142,32 @@ def test_overlap_evaluation_equals_the_reference():
                 n_ovl += 1
             n_pairs += 1
     assert n_pairs >= 900 and n_ovl >= 100
+
+
+# ---- f-1: the contig picker (pick_contigs.py:64-358, 361-539), from flanks.sam on ----
+
+def test_picker_restatement_equals_the_reference_on_prepared_sam_files():
+    """tests/golden/pick_kat.json.gz: 504 prepared flanks.sam texts (hand-built: every clip-type pair, both strands, several hits of
+    a type, equal spans, span 0 and -1, secondary lines, indel CIGARs, lower case / IUPAC; random hit sets and random pairs) and the
+    picked_seqs.fa / picked_contigs.fa the reference's own pick_contigs.py wrote for each, full pick and extended pick."""
+    import gzip
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "pick_kat.json.gz")).read())
+    n_full = n_ext = 0
+    for c in cases:
+        contigs = [tuple(x) for x in c["contigs"]]
+        assert list(O.pick_full_from_sam(c["id"], c["sam"], contigs)) == c["full"], c["id"]
+        n_full += c["full"][0] is not None
+        if c["ext"] != "TIE":                              # (the reference's int-vs-str tie test raises under Python 3)
+            assert list(O.pick_extended_from_sam(c["id"], c["sam"], contigs)) == c["ext"], c["id"]
+            n_ext += c["ext"][0] is not None
+    assert len(cases) >= 500 and n_full > 150 and n_ext > 300
+
+
+def test_picker_ledger_is_the_concatenation_of_the_per_gap_files():
+    """pick_full_constructed_contigs appends every gap's picked_seqs.fa / picked_contigs.fa to the ledger in list order (:564-572)."""
+    import gzip
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "pick_kat.json.gz")).read())
+    for score in (30, 15):
+        mine = [c for c in cases if c["score"] == score]
+        led = [c["ledgers_of_score"] for c in mine if c["ledgers_of_score"]][0]
+        assert led[0] == "".join(c["full"][0] or "" for c in mine) and led[1] == "".join(c["full"][1] or "" for c in mine)
