@@ -72,8 +72,33 @@ def parse_args():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a bare shell (N > 1, no torch.distributed.run around it): start the N ranks as a CHILD
+    `python -m torch.distributed.run` before this process has touched the GPU (never an exec, never after a HIP call), relay rank 0's
+    JSON line and exit with the child's code.  On a box with fewer than N GPUs the ranks share GPU 0 and the collectives go through
+    gloo (functional mode: the same kernels and the same exchange, no RCCL); the line then says so."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < args.gpus and "GF_BENCH_BACKEND" not in env:     # (device_count does not initialise the GPU)
+        env.update(GF_BENCH_BACKEND="gloo", GF_BENCH_ONE_GPU="1")
+        sys.stderr.write("bench.py: %d rank(s) on %d GPU(s): ranks share cuda:0, collectives over gloo\n" % (args.gpus, torch.cuda.device_count()))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    sys.stdout.write(r.stdout.decode())
+    sys.stdout.flush()
+    sys.exit(r.returncode)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     out, rank, world = run(args)
     # the extras run in child processes AFTER this process has released its device memory (run()'s tensors and contexts are gone)
     if rank == 0 and world == 1 and args.config == "C4" and not args.no_extras and not args.no_cpu and not args.reads and args.mp_reads < 0:
@@ -205,13 +230,7 @@ def run(args):
     k_screen = min(a for a, _ in kk)
 
     def all_gather(dst, src):
-        # fixed-size slots: no host sizes, no host sync (RCCL); the gloo smoke path goes through host memory
-        if backend == "nccl":
-            dist.all_gather_into_tensor(dst, src)
-        else:
-            parts = list(torch.empty_like(dst, device="cpu").chunk(world))
-            dist.all_gather(parts, src.cpu())
-            dst.copy_(torch.cat(parts))
+        SH.all_gather_slots(dst, src, backend)
 
     def sync_all():
         gf.sync()
@@ -324,9 +343,7 @@ def run(args):
         tot = torch.stack([per_dst[:, r].sum() for r in range(world)]).to(coll_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         merged_cap = max(4096, int(1.25 * int(tot.max())) + 1024)
-        d_send = torch.empty(world * n_lib * slot_cap * rb, dtype=torch.uint8, device=dev)
-        d_recv = torch.empty(world * n_lib * slot_cap * rb, dtype=torch.uint8, device=dev)
-        d_allcnt = torch.zeros(world * n_lib * n_gaps, dtype=torch.int32, device=dev)
+        xchg = SH.OwnerExchange(world, n_lib, n_gaps, slot_cap, rb, dev, backend)
     else:
         slot_cap = lib_cap
         merged_cap = max(4096, int(1.25 * sum(rows_lib)) + 1024)
@@ -364,19 +381,14 @@ def run(args):
         else:
             # the one exchange step: rows regrouped by owner rank, counts all-gathered, slots all-to-all'ed
             # (equal-sized slots: no host sizes, no host sync), owners merge in (library, source rank) order
-            for l, lb in enumerate(libs):
-                assert lib.gf_pools_pack_for_owners_dev(h, pool_ptr[l], lb.d_pool_off.data_ptr(), n_gaps, L, world, batch, l, n_lib,
-                                                        d_send.data_ptr(), slot_cap, d_libcnt.data_ptr() + 4 * l * n_gaps,
-                                                        d_xerr.data_ptr()) == 0
-            all_gather(d_allcnt, d_libcnt)
-            if backend == "nccl":
-                dist.all_to_all_single(d_recv, d_send)
-            else:
-                r_ = torch.empty_like(d_send, device="cpu")
-                dist.all_to_all_single(r_, d_send.cpu())
-                d_recv.copy_(r_)
-            assert lib.gf_pools_merge_dev(h, d_recv.data_ptr(), slot_cap, d_allcnt.data_ptr(), n_lib, world, n_gaps, L, rank, world, batch,
-                                          d_merged.data_ptr(), merged_cap, d_moff.data_ptr(), d_xerr.data_ptr()) == 0
+            def pack(l, send, cap, cnt):
+                assert lib.gf_pools_pack_for_owners_dev(h, pool_ptr[l], libs[l].d_pool_off.data_ptr(), n_gaps, L, world, batch, l, n_lib,
+                                                        send.data_ptr(), cap, cnt.data_ptr(), d_xerr.data_ptr()) == 0
+
+            def merge(recv, cap, all_cnt):
+                assert lib.gf_pools_merge_dev(h, recv.data_ptr(), cap, all_cnt.data_ptr(), n_lib, world, n_gaps, L, rank, world, batch,
+                                              d_merged.data_ptr(), merged_cap, d_moff.data_ptr(), d_xerr.data_ptr()) == 0
+            xchg.run(pack, merge)
             asm_ptr, asm_off, asm_rows = d_merged.data_ptr(), d_moff.data_ptr(), merged_cap
         rc = lib.gf_assemble_multi_dev(h, asm_ptr, None, asm_off, n_gaps, asm_rows, L, k_arr, kv_arr, len(kk), 2, 40,
                                        d_ctg.data_ptr(), contig_cap, ap_, d_seq.data_ptr(), seq_cap, ap_ + 8, d_gap_err.data_ptr())
@@ -509,6 +521,8 @@ def run(args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": wl, "reads_total": n_screened, "reads_per_gpu": sum(lb.n_reads for lb in libs), "gaps": n_gaps,
                        "k_pairs": [list(p) for p in kk],
+                       "collectives": ("none (one rank)" if world == 1 else "RCCL (nccl backend), one GPU per rank" if backend == "nccl" else
+                                       "%s through host memory%s" % (backend, ", all ranks on cuda:0 (functional mode)" if os.environ.get("GF_BENCH_ONE_GPU") else "")),
                        "sharding": ("single GPU: all reads and all gaps on one device" if world == 1 else
                                     "the same reads split over the ranks (contiguous pair ranges), gaps + flank index replicated; per-gap pools "
                                     "sent to one owner rank per gap (batches of %d gaps round-robin; device pack + all-gather of counts + "

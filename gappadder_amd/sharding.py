@@ -1,8 +1,9 @@
-"""Multi-GPU layout of the hot path: one process per GPU, READS sharded (rank r owns a contiguous range
-of read pairs), gaps/flanks replicated; by default no collective on the data path and the only exchange is the final gather
-of the assembled sequences on rank 0 (north_star: "RCCL over xGMI only for the final gather of closed sequences").
-`exchange_pools` is the optional all-to-all-v that gives every gap ONE owner holding the recruits of all ranks.
-Backend-agnostic: `nccl` (= RCCL) on GPUs, `gloo` in the CPU tests."""
+"""Multi-GPU layout of the hot path: one process per GPU, READS sharded (rank r owns a contiguous range of
+read pairs), gaps / flanks replicated, every gap ASSEMBLED ONCE by its owner rank from the recruits of all ranks (the reference
+maps each gap to one Pool task, assemble_gaps.py:296-299).  `OwnerExchange` is the one exchange step on the data path — device
+pack by owner, all-gather of the per-gap counts, equal-slot all-to-all, device merge — and `gather_bytes` the final gather of
+the closed sequences on rank 0 (north_star).  Backend-agnostic: `nccl` (= RCCL) on GPUs, `gloo` in the CPU tests and in the
+one-GPU multi-rank mode of bench.py."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -45,46 +46,48 @@ def gap_owner(n_gaps, world, batch=256):
     return (torch.arange(n_gaps, dtype=torch.int64) // owner_batch(n_gaps, world, batch)) % world
 
 
-def exchange_pools(pool, pool_off, coll_device=None, batch=256):
-    """The one exchange step of a multi-GPU run that wants whole-data pools per gap: every rank has built
-    per-gap pools from ITS shard of the reads; each gap's pool is sent to the rank that owns the gap (all-to-all-v) and the
-    owner concatenates the contributions in source-rank order — with contiguous read shards that is global read order, so
-    the merged pool of a gap is byte-identical to the pool a single process builds from all reads.
+def all_gather_slots(dst, src, backend):
+    """Fixed-size slots: no host sizes, no host sync with RCCL; gloo goes through host memory (CPU tensors pass straight through)."""
+    if backend == "nccl":
+        dist.all_gather_into_tensor(dst, src)
+        return
+    world = dist.get_world_size()
+    parts = list(torch.empty_like(dst, device="cpu").chunk(world))
+    dist.all_gather(parts, src.cpu())
+    dst.copy_(torch.cat(parts))
 
-    pool:     uint8 tensor [n_rows, row_bytes] — packed reads of all gaps, gap after gap
-    pool_off: int64/uint64 tensor [n_gaps + 1] — row offsets per gap
-    coll_device: device the collectives run on (the pool's device with nccl/RCCL, cpu with gloo)
-    Returns (merged_pool [m_rows, row_bytes] on pool.device, merged_off int64 [n_gaps + 1] on pool.device);
-    gaps this rank does not own come back empty."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    dev = pool.device
-    cdev = coll_device or dev
-    n_gaps = pool_off.numel() - 1
-    rb = pool.shape[1] if pool.dim() == 2 else 1
-    off = pool_off.to(torch.int64)
-    counts = (off[1:] - off[:-1]).to(cdev)
-    all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts)
-    all_counts = torch.stack(all_counts)                      # [world, n_gaps]
-    owner = gap_owner(n_gaps, world, batch).to(cdev)
-    # send side: rows regrouped by destination (stable: gap order, then read order, survives inside each group)
-    gid = torch.repeat_interleave(torch.arange(n_gaps, device=cdev), counts)
-    perm = torch.argsort(owner[gid], stable=True)
-    send = pool.reshape(-1, rb)[perm.to(dev)].to(cdev).reshape(-1)
-    send_rows = torch.zeros(world, dtype=torch.int64, device=cdev).index_add_(0, owner, counts)
-    mine = owner == rank
-    recv_rows = (all_counts * mine).sum(dim=1)                # rows coming from every source
-    recv = torch.empty(int(recv_rows.sum()) * rb, dtype=torch.uint8, device=cdev)
-    dist.all_to_all_single(recv, send, [int(x) * rb for x in recv_rows], [int(x) * rb for x in send_rows])
-    # receive side: rows arrive as [source 0: my gaps in order | source 1: ...]; regroup by gap, sources in rank order
-    my_gaps = torch.nonzero(mine).reshape(-1)
-    gid_r = torch.cat([torch.repeat_interleave(my_gaps, all_counts[s][my_gaps]) for s in range(world)]) if world else gid
-    perm2 = torch.argsort(gid_r, stable=True)                 # stable: keeps source order inside a gap
-    merged = recv.reshape(-1, rb)[perm2].to(dev)
-    mcounts = (all_counts.sum(dim=0) * mine).to(torch.int64)
-    moff = torch.zeros(n_gaps + 1, dtype=torch.int64, device=cdev)
-    moff[1:] = torch.cumsum(mcounts, 0)
-    return merged, moff.to(dev)
+
+def all_to_all_slots(dst, src, backend):
+    if backend == "nccl":
+        dist.all_to_all_single(dst, src)
+        return
+    r_ = torch.empty_like(src, device="cpu")
+    dist.all_to_all_single(r_, src.cpu())
+    dst.copy_(r_)
+
+
+class OwnerExchange:
+    """The one exchange step of a multi-GPU run: every rank has built per-gap pools (one array per library) from ITS
+    shard of the reads; each gap's rows go to the rank that owns the gap, and the owner concatenates them in (library, source
+    rank) order — with contiguous read shards that is the order of a single-process run over all reads, so pools, contigs and
+    closed flags are bit-identical to the 1-GPU run.  Buffers are equal-sized slots `[owner][library][slot_cap]` (no host sizes, no
+    host sync); the two kernels are injected: bench.py passes gf_pools_pack_for_owners_dev / gf_pools_merge_dev, the CPU test
+    (tests/test_distributed_cpu.py) their definitions in numpy — the collectives and the buffer layout are the same code."""
+
+    def __init__(self, world, n_lib, n_gaps, slot_cap, row_bytes, device, backend):
+        self.world, self.n_lib, self.n_gaps, self.slot_cap, self.rb, self.backend = world, n_lib, n_gaps, slot_cap, row_bytes, backend
+        self.send = torch.empty(world * n_lib * slot_cap * row_bytes, dtype=torch.uint8, device=device)
+        self.recv = torch.empty(world * n_lib * slot_cap * row_bytes, dtype=torch.uint8, device=device)
+        self.lib_cnt = torch.zeros(n_lib * n_gaps, dtype=torch.int32, device=device)            # [n_lib][n_gaps], this rank's rows
+        self.all_cnt = torch.zeros(world * n_lib * n_gaps, dtype=torch.int32, device=device)    # [world][n_lib][n_gaps]
+
+    def run(self, pack, merge):
+        """pack(lib, send, slot_cap, lib_cnt_of_that_library) per library; merge(recv, slot_cap, all_cnt)."""
+        for l in range(self.n_lib):
+            pack(l, self.send, self.slot_cap, self.lib_cnt[l * self.n_gaps:(l + 1) * self.n_gaps])
+        all_gather_slots(self.all_cnt, self.lib_cnt, self.backend)
+        all_to_all_slots(self.recv, self.send, self.backend)
+        merge(self.recv, self.slot_cap, self.all_cnt)
 
 
 def encode_contigs(records):

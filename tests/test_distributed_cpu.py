@@ -1,5 +1,5 @@
-"""N > 1 path on CPU: two `gloo` ranks shard the read pairs, screen their shard (oracle stands in for the GPU kernels
-here — this test is about the sharding and the final gather), and rank 0 gathers; the union must equal the 1-rank result."""
+"""N > 1 path on CPU (gloo): read sharding + final gather on two ranks, and the owner exchange that bench.py's step() runs
+(sharding.OwnerExchange) on three ranks; the oracle / numpy definitions stand in for the GPU kernels."""
 import os
 import socket
 import sys
@@ -66,6 +66,39 @@ def test_two_rank_sharding_and_gather_equal_single_rank():
     assert max(r[3] for r in parts[0]) < min(r[3] for r in parts[1])
 
 
+def _np_pack_for_owners(rows, off, world, batch, lib, n_lib, send, slot_cap, cnt, rb):
+    """Definition of gf_pools_pack_for_owners_dev (include/gapfill_hip.h): slot (owner * n_lib + lib) of the send buffer holds that
+    owner's gaps' rows in gap order; cnt[g] = this library's rows of gap g."""
+    n_gaps = len(off) - 1
+    fill = [0] * world
+    sv = send.numpy().reshape(world, n_lib, slot_cap, rb)
+    for g in range(n_gaps):
+        o = (g // batch) % world
+        n = int(off[g + 1] - off[g])
+        sv[o, lib, fill[o]:fill[o] + n] = rows[int(off[g]):int(off[g + 1])]
+        fill[o] += n
+        cnt[g] = n
+
+
+def _np_merge(recv, slot_cap, all_cnt, n_lib, world, n_gaps, rank, batch, rb):
+    """Definition of gf_pools_merge_dev: for each of MY gaps, libraries in order, inside a library the source ranks in order."""
+    rv = recv.numpy().reshape(world, n_lib, slot_cap, rb)
+    cnt = all_cnt.numpy().reshape(world, n_lib, n_gaps)
+    pos = np.zeros((world, n_lib), dtype=np.int64)
+    out, moff = [], [0]
+    for g in range(n_gaps):
+        n = 0
+        if (g // batch) % world == rank:
+            for l in range(n_lib):
+                for r in range(world):
+                    c = int(cnt[r, l, g])
+                    out.append(rv[r, l, pos[r, l]:pos[r, l] + c].copy())
+                    pos[r, l] += c
+                    n += c
+        moff.append(moff[-1] + n)
+    return (np.concatenate(out) if out else np.zeros((0, rb), np.uint8)), moff
+
+
 def _exchange_worker(rank, world, port, n_pairs, batch, q):
     sys.path.insert(0, ROOT)
     import torch
@@ -75,22 +108,41 @@ def _exchange_worker(rank, world, port, n_pairs, batch, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = CO.synth_cfg(scaffold_len=200000, n_scaffolds=4, gaps_per_scaffold=3)
-    gaps, flanks = CO.synth_layout(cfg)
-    a, b = SH.shard_range(n_pairs, rank, world)
-    packed, _ = CO.synth_pairs(cfg, a, b - a)
-    hits = CO.screen_reads(CO.unpack_reads(packed, 150), 150, flanks, 31, threads=2)
-    pools = [sorted(set(int(h["read"]) for h in hits if int(h["gap"]) == g)) for g in range(len(gaps))]
-    rows = np.concatenate([packed[np.array(p, dtype=np.int64)] for p in pools if p] or [np.zeros((0, 38), np.uint8)])
-    off = np.cumsum([0] + [len(p) for p in pools]).astype(np.int64)
-    merged, moff = SH.exchange_pools(torch.from_numpy(rows), torch.from_numpy(off), batch=batch)
-    q.put((rank, merged.numpy().tobytes(), moff.numpy().tolist()))
+    n_lib, rb = 2, 38
+    gaps = flanks = None
+    libs = []
+    for l in range(n_lib):                                   # two libraries drawn from the same draft (bench.py's C5 shape)
+        cfg = CO.synth_cfg(scaffold_len=200000, n_scaffolds=4, gaps_per_scaffold=3, library=l, insert_mean=300 if l == 0 else 900, insert_sd=30)
+        gaps, flanks = CO.synth_layout(cfg)
+        a, b = SH.shard_range(n_pairs, rank, world)
+        packed, _ = CO.synth_pairs(cfg, a, b - a)
+        hits = CO.screen_reads(CO.unpack_reads(packed, 150), 150, flanks, 31, threads=2)    # the oracle stands in for the recruit kernels
+        pools = [sorted(set(int(h["read"]) for h in hits if int(h["gap"]) == g)) for g in range(len(gaps))]
+        rows = np.concatenate([packed[np.array(p, dtype=np.int64)] for p in pools if p] or [np.zeros((0, rb), np.uint8)])
+        libs.append((rows, np.cumsum([0] + [len(p) for p in pools]).astype(np.int64)))
+    n_gaps = len(gaps)
+    assert batch == SH.owner_batch(n_gaps, world, batch)
+    x = SH.OwnerExchange(world, n_lib, n_gaps, 512, rb, torch.device("cpu"), "gloo")     # the class bench.py's step() drives
+    res = {}
+
+    def pack(l, send, cap, cnt):
+        _np_pack_for_owners(libs[l][0], libs[l][1], world, batch, l, n_lib, send, cap, cnt.numpy(), rb)
+
+    def merge(recv, cap, all_cnt):
+        res["m"] = _np_merge(recv, cap, all_cnt, n_lib, world, n_gaps, rank, batch, rb)
+    x.run(pack, merge)
+    x.run(pack, merge)                                       # a second step reuses the buffers
+    merged, moff = res["m"]
+    q.put((rank, merged.tobytes(), moff))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_pool_exchange_gives_every_gap_one_owner_with_the_single_rank_pool():
-    """All-to-all-v of the per-gap pools: the owner's merged pool == the pool built from all reads."""
+def test_owner_exchange_gives_every_gap_one_owner_with_the_single_rank_pool():
+    """sharding.OwnerExchange — the exchange bench.py's step() runs at N > 1 (pack by owner, all-gather of the counts, equal-slot
+    all-to-all, merge) — on three gloo ranks with the kernels' definitions in numpy: every gap's merged pool sits at
+    exactly one rank (assemble_gaps.py:296-299: one owner per gap) and equals the pool a single process builds from all reads of both
+    libraries, libraries in order."""
     sys.path.insert(0, ROOT)
     from gappadder_amd import sharding as SH
     from oracle import c_oracle as CO
@@ -108,19 +160,22 @@ def test_pool_exchange_gives_every_gap_one_owner_with_the_single_rank_pool():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    cfg = CO.synth_cfg(scaffold_len=200000, n_scaffolds=4, gaps_per_scaffold=3)
-    gaps, flanks = CO.synth_layout(cfg)
-    packed, _ = CO.synth_pairs(cfg, 0, n_pairs)
-    hits = CO.screen_reads(CO.unpack_reads(packed, 150), 150, flanks, 31, threads=2)
+    expect = None
+    for l in range(2):
+        cfg = CO.synth_cfg(scaffold_len=200000, n_scaffolds=4, gaps_per_scaffold=3, library=l, insert_mean=300 if l == 0 else 900, insert_sd=30)
+        gaps, flanks = CO.synth_layout(cfg)
+        packed, _ = CO.synth_pairs(cfg, 0, n_pairs)
+        hits = CO.screen_reads(CO.unpack_reads(packed, 150), 150, flanks, 31, threads=2)
+        if expect is None:
+            expect = [b""] * len(gaps)
+        for g in range(len(gaps)):
+            ids = sorted(set(int(h["read"]) for h in hits if int(h["gap"]) == g))
+            expect[g] += packed[np.array(ids, dtype=np.int64)].tobytes() if ids else b""
     owner = SH.gap_owner(len(gaps), world, batch).tolist()
     assert sorted(set(owner)) == [0, 1, 2]
-    total = 0
     for g in range(len(gaps)):
-        ids = sorted(set(int(h["read"]) for h in hits if int(h["gap"]) == g))
-        expect = packed[np.array(ids, dtype=np.int64)].tobytes() if ids else b""
         for r in range(world):
             blob, moff = got[r]
             seg = blob[moff[g] * 38:moff[g + 1] * 38]
-            assert seg == (expect if r == owner[g] else b""), (g, r)
-        total += len(ids)
-    assert total > 100
+            assert seg == (expect[g] if r == owner[g] else b""), (g, r)
+    assert sum(len(e) for e in expect) > 200 * 38
