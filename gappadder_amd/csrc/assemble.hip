@@ -1,16 +1,19 @@
 // assemble.hip — per-gap local assembly: what `run_assembly` (assemble_gaps.py:82-136) obtains from
 // `kmc -k{k}` | `kmc_dump` | `velveth {kv}` | `velvetg -min_contig_lgth 40`, for one (k, kv) pair per launch.
-// Semantics (PARITY UNPINNED, defined by this build): oracle/gp_oracle.c `or_assemble_pool`, DESIGN.md.
+// Semantics (PARITY UNPINNED, defined by this build): oracle/gp_oracle.c `or_assemble_pool2`, DESIGN.md §2.
 //
-// One workgroup per gap.  The gap's packed read pool is staged in LDS when it fits; the two open-addressing tables
-// (canonical k-mer -> count, canonical kv-mer -> adjacency/multiplicity) live in a per-gap slice of a global
-// workspace and store 32-bit INSTANCE ids (read-in-pool * L + offset) instead of keys, so one 32-bit CAS claims a
-// slot for any k <= 64 and a key is re-derived from the staged reads when slots are compared.
-//   P1 count      every k-mer position of every read -> canonical -> table (CAS id, add count)
-//   P2 survivors  slots with count >= min_count -> compacted instance list; table cleared
-//   P3 graph      each survivor contributes k-kv+1 kv-mer nodes and k-kv edges (4+4 adjacency bits per node)
-//   P4 starts     oriented nodes whose in-degree != 1, or whose predecessor branches, start a unitig
-//   P5 walk       each start walks its unitig; the walk whose first kv-mer <= the opposite walk's is emitted
+// One workgroup per gap.  The gap's packed read pool is staged in LDS when it fits; the open-addressing tables (canonical k-mer ->
+// count, canonical kv-mer -> adjacency/multiplicity) live in LDS when the gap fits an LDS plan, else in a per-workgroup slice of a
+// global workspace, and store 32-bit INSTANCE ids (read-in-pool << 10 | offset) instead of keys, so one 64-bit CAS claims a slot
+// for any k <= 64 and a key is re-derived from the staged reads when slots are compared.
+//   P1 count      bit-array pre-count (k-mers seen fewer than min_count times never enter the table), then every remaining k-mer
+//                 window -> canonical -> table (key / fingerprint / instance-id slots, ranked behind the pre-count)
+//   P2 survivors  slots with count >= min_count -> compacted instance list (bit 31: the k-mer is WEAK, count <= min_count)
+//   P3 graph      each survivor contributes k-kv+1 kv-mer nodes and k-kv edges (4+4 adjacency bits per node); dense node indices
+//   P4 links      unitig-internal edges; oriented nodes that no internal edge enters start a unitig
+//   ER            error removal rounds: tip clipping + bubble popping on snapshots of the graph (heads walk their unitigs)
+//   P5 ranking    every oriented node learns its unitig's head and its rank by pointer jumping
+//   P6 emission   the walk whose first kv-mer <= the opposite walk's is emitted; every node writes its own base
 #include <type_traits>
 
 #include "gf_internal.hpp"
@@ -60,7 +63,9 @@ struct AsmParams {
 constexpr uint32_t ASM_ERR_IDS = 1, ASM_ERR_KTABLE = 2, ASM_ERR_NTABLE = 4, ASM_ERR_NLIST = 8, ASM_ERR_WALKS_PAR = 16;
 
 // node meta bits (high word of a table slot in the graph phases)
-constexpr uint32_t M_OUT = 0xFu, M_IN = 0xF0u, M_START0 = 1u << 8, M_START1 = 1u << 9, M_MULT_SHIFT = 13;
+constexpr uint32_t M_OUT = 0xFu, M_IN = 0xF0u, M_START0 = 1u << 8, M_START1 = 1u << 9, M_MULT_SHIFT = 14;
+// WEAK = one of the surviving k-mers the node came from was seen no more often than min_count (the tie-break of the error removal)
+constexpr uint32_t M_WEAK = 1u << 13, INST_WEAK = 1u << 31;
 // error removal: KILL = the unitig this node heads is removed in this round; DEADMARK -> DEAD = the node is gone
 constexpr uint32_t M_KILL = 1u << 10, M_DEADMARK = 1u << 11, M_DEAD = 1u << 12;
 
@@ -287,8 +292,8 @@ __device__ __forceinline__ uint32_t table_upsert(const Tab& t, const PoolView& V
 
 // The same for the NODE table (kv-mers), with an 8-bit key fingerprint in the top byte of the slot's high word when `fp_on`: a probe
 // that meets another node sees it in the fingerprint and does not re-derive the occupant's kv-mer from the reads (a window fetch + a
-// reverse complement per foreign slot on the way).  The multiplicity lives in bits 13..23 then, which bounds it by 2047: the caller
-// switches the fingerprint on only when k - kv <= 4 (a kv-mer lies in at most (k - kv + 1) * 4^(k - kv) <= 1280 distinct k-mers).
+// reverse complement per foreign slot on the way).  The multiplicity lives in bits 14..23 then, which bounds it by 1023: the caller
+// switches the fingerprint on only when k - kv <= 3 (a kv-mer lies in at most (k - kv + 1) * 4^(k - kv) <= 256 distinct k-mers).
 constexpr uint32_t NODE_FP_SHIFT = 24;
 __device__ __forceinline__ uint32_t node_fp(uint64_t x) { return (uint32_t)(x >> 56); }
 template <bool W>
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             continue;
         }
         const uint64_t inst_off = P.slice_rows ? (uint64_t)blockIdx.x * P.slice_rows * unit : r0 * unit;
-        if (n_unit64 >= (1ull << 30) || n_r >= (1u << (32 - INST_OFF_BITS)) - 1) {  // ids are 32-bit: read << 10 | offset
+        if (n_unit64 >= (1ull << 30) || n_r >= (1u << (31 - INST_OFF_BITS)) - 1) {  // ids are 31-bit: read << 10 | offset (bit 31: INST_WEAK)
             if (tid == 0) P.gap_error[g] = ASM_ERR_IDS;
             continue;
         }
@@ -978,6 +983,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         : keyslot_w ? (uint32_t)(~v[u] & 3ull)
                         : keyslot ? (uint32_t)((tab_global ? ~v[u] : (GF_KS_COMPLEMENT_LDS ? ~v[u] : v[u])) & 3ull) : (uint32_t)(v[u] >> 32);
                     keep = c >= P.min_count;
+                    if (!P.cnt_keys && (c < 3u ? c : 3u) <= P.min_count) id |= INST_WEAK;   // (counts saturate at 3: the 2-bit counters)
                     if (tab_global) {
                         if (keyslot_w) { tab.store(2 * sl[u], EMPTY64); tab.store(2 * sl[u] + 1, EMPTY64); }
                         else tab.store(sl[u], EMPTY64);
@@ -1024,7 +1030,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         // global slice before: 910 us per gap at k = 51); 2 = everything in the global slice.  The survivors
         // say where to start (a gap has about as many nodes as surviving k-mers); a plan that overflows falls through to the next.
         bool graph_lds = false, j_lds = false;
-        const bool node_fp_on = P.k - P.kv <= 4;   // see node_upsert
+        const bool node_fp_on = P.k - P.kv <= 3;   // see node_upsert
         uint32_t nb = 0, n_nodes = 0;
         Tab ntab;
         ntab.g = gtab;
@@ -1050,7 +1056,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             // ---- P3: nodes + edges; remember each node's slot
             for (uint32_t j = tid; j < n_surv; j += ASM_THREADS) {
                 if (graph_lds && s_cnt[6]) break;
-                const uint32_t inst = list_b[j];
+                const uint32_t inst_w = list_b[j];
+                const uint32_t inst = inst_w & ~INST_WEAK;
                 const K128 tf = pv_kmer<W>(V, inst, k);
                 K128 t = tf;
                 {   // use the canonical k-mer string (what kmc_dump lists); either strand yields the same graph
@@ -1074,6 +1081,7 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                     bool fresh;
                     const uint32_t sl = node_upsert<W>(ntab, V, A, ninst, kv, 1u << M_MULT_SHIFT, node_fp_on, &fresh);
                     if (sl == EMPTY32) { if (graph_lds) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_NTABLE); break; }
+                    if (inst_w & INST_WEAK) ntab.or_meta(sl, M_WEAK);   // (a few per cent of the survivors)
                     if (fresh) {
                         const uint32_t q = atomicAdd(&s_cnt[5], 1u);
                         if (graph_lds && q >= nb) { s_cnt[6] = 1; break; }
@@ -1183,16 +1191,21 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
         //      short, so heads WALK the links (no ranking needed yet): a decision only sets the KILL bit of X's end nodes; after the
         //      barrier the arcs into X are cleared at their sources, X's nodes die, and the junctions that lost a branch re-link.
         // unitig headed by h: tail and node count, false when it has more than `limit` nodes
-        auto walk = [&](uint32_t h, uint32_t limit, uint32_t& tail, uint32_t& n, uint32_t& cov) -> bool {
+        // (cov = coverage sum << 32 | nodes that are not weak: "more coverage, then fewer weak nodes" is one 64-bit comparison
+        //  between unitigs of the same node count — the only ones whose coverage is ever compared)
+        auto cov_of = [&](uint32_t m) -> unsigned long long {
+            return ((unsigned long long)(m >> M_MULT_SHIFT) << 32) | ((m & M_WEAK) ? 0u : 1u);   // (nmeta carries no fingerprint)
+        };
+        auto walk = [&](uint32_t h, uint32_t limit, uint32_t& tail, uint32_t& n, unsigned long long& cov) -> bool {
             uint32_t cur = h;
             n = 1;
-            cov = nmeta.get(h >> 1) >> M_MULT_SHIFT;     // the coverage sum rides along: no second walk when two unitigs are compared
+            cov = cov_of(nmeta.get(h >> 1));     // the coverage sum rides along: no second walk when two unitigs are compared
             for (;;) {
                 const uint32_t nx = succ_get(cur);
                 if (nx == EMPTY32) break;
                 if (n == limit) return false;
                 cur = nx;
-                cov += nmeta.get(cur >> 1) >> M_MULT_SHIFT;
+                cov += cov_of(nmeta.get(cur >> 1));
                 ++n;
             }
             tail = cur;
@@ -1203,9 +1216,9 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             return b < a ? b : a;
         };
         // does the unitig headed by y (tail ty, ny nodes, coverage cy) beat the one headed by x?
-        auto beats = [&](uint32_t y, uint32_t ty, uint32_t ny, uint32_t cy, uint32_t x, uint32_t tx, uint32_t nx, uint32_t cx, bool with_len) -> bool {
+        auto beats = [&](uint32_t y, uint32_t ty, uint32_t ny, unsigned long long cy, uint32_t x, uint32_t tx, uint32_t nx, unsigned long long cx, bool with_len) -> bool {
             if (with_len && ny != nx) return ny > nx;
-            if (cy != cx) return cy > cx;
+            if (cy != cx) return cy > cx;     // equal node counts here: more coverage, then fewer weak nodes
             return uni_key(y, ty) < uni_key(x, tx);
         };
         for (uint32_t round = 0; round < P.simplify; ++round) {
@@ -1225,7 +1238,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
             for (uint32_t qi = (tid & 63) * (ASM_THREADS / 64) + (tid >> 6); qi < n_cand; qi += ASM_THREADS) {
                 const uint32_t o = (uint32_t)J.load(qi);
                 const uint32_t ib = inb(o);
-                uint32_t t, n, cx;
+                uint32_t t, n;
+                unsigned long long cx;
                 if (!walk(o, 2 * P.kv, t, n, cx)) continue;
                 const K128 hs = node_seq(o);
                 const uint32_t p = find_oriented(shift_in_front(hs, __ffs(ib) - 1, kv));
@@ -1240,7 +1254,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                         if (!((pb >> c) & 1u)) continue;
                         const uint32_t y = find_oriented(shift_in(ps, c, kv));
                         if (y == EMPTY32 || y == o || has_pred(y) || y == (t ^ 1u)) continue;
-                        uint32_t ty, ny, cy;
+                        uint32_t ty, ny;
+                        unsigned long long cy;
                         const bool tip_shaped = walk(y, P.kv, ty, ny, cy) && outb(ty) == 0 && __popc(inb(y)) == 1;
                         if (!tip_shaped || beats(y, ty, ny, cy, o, t, n, cx, true)) go = true;
                     }
@@ -1258,7 +1273,8 @@ __global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
                             if (!((outb(q) >> c) & 1u)) continue;
                             const uint32_t y = find_oriented(shift_in(node_seq(q), c, kv));
                             if (y == EMPTY32 || has_pred(y) || y == o || y == (t ^ 1u)) continue;
-                            uint32_t ty, ny, cy;
+                            uint32_t ty, ny;
+                            unsigned long long cy;
                             if (!walk(y, rem, ty, ny, cy)) continue;             // more nodes than remain
                             if (ny == rem) {
                                 const uint32_t yb = outb(ty);

@@ -495,8 +495,9 @@ void or_synth_layout(const void* c_, or_gap* gaps, char* flank_ascii, uint64_t* 
  *            unique predecessor has out-degree != 1; a walk extends while out-degree == 1 and the successor's in-degree == 1;
  *   each unitig is found from both ends; the walk whose first kv-mer is <= the first kv-mer of the opposite walk is
  *   emitted (so the contig is min(seq, revcomp(seq)) whenever the two first kv-mers differ);
- *   contigs shorter than min_contig bases are dropped; isolated cycles (no start) are not reported; no tip clipping,
- *   no bubble popping (v1).  Output order: length descending, then sequence ascending.
+ *   contigs shorter than min_contig bases are dropped; isolated cycles (no start) are not reported.  Velvet's default error
+ *   removal (tip clipping + bubble popping) runs on the unitig graph before the emission: simplify_round below.
+ *   Output order: length descending, then sequence ascending.
  */
 typedef struct { uint64_t hi, lo; } k128;
 static inline int k128_lt(k128 a, k128 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
@@ -549,7 +550,9 @@ size_t or_count_kmers(const char* reads, size_t n_reads, int L, int k, int min_c
     return w;
 }
 
-typedef struct { k128 key; uint32_t mult; uint8_t out, in, dead; } or_node;
+/* weak: one of the surviving k-mers the node came from was seen no more often than min_count (counts saturate at 3, like the
+ * kernel's 2-bit counters: with min_count >= 3 every node is weak and the rule below is void) */
+typedef struct { k128 key; uint32_t mult; uint8_t out, in, dead, weak; } or_node;
 static long node_find(const or_node* nd, size_t n, k128 key) {
     size_t a = 0, b = n;
     while (a < b) { size_t m = (a + b) / 2; if (k128_lt(nd[m].key, key)) a = m + 1; else b = m; }
@@ -576,6 +579,7 @@ typedef struct {
     uint32_t* tail;   /* [head]: last oriented node */
     uint32_t* len;    /* [head]: nodes */
     uint32_t* cov;    /* [head]: sum of the nodes' multiplicities */
+    uint32_t* wk;     /* [head]: number of weak nodes */
     uint32_t* next;   /* unitig-internal successor, or NONE */
     k128* ukey;       /* [head]: min(first kv-mer of the unitig, first kv-mer of its reverse) — orientation-free order */
     uint8_t* kill;    /* [node index]: marked for removal in this round */
@@ -616,7 +620,7 @@ static void graph_unitigs(or_graph* G) {
         int start = popc4(ib) != 1;
         if (!start) start = popc4(g_out(G, g_pred(G, (uint32_t)o, (unsigned)ctz4(ib)))) != 1;
         if (!start) continue;
-        uint32_t cur = (uint32_t)o, n = 1, cov = G->nd[o >> 1].mult;
+        uint32_t cur = (uint32_t)o, n = 1, cov = G->nd[o >> 1].mult, wk = G->nd[o >> 1].weak;
         G->head[o] = (uint32_t)o;
         for (;;) {
             unsigned ob = g_out(G, cur);
@@ -625,9 +629,9 @@ static void graph_unitigs(or_graph* G) {
             if (popc4(g_in(G, y)) != 1) break;
             G->next[cur] = y;
             G->head[y] = (uint32_t)o;
-            cur = y; ++n; cov += G->nd[y >> 1].mult;
+            cur = y; ++n; cov += G->nd[y >> 1].mult; wk += G->nd[y >> 1].weak;
         }
-        G->tail[o] = cur; G->len[o] = n; G->cov[o] = cov;
+        G->tail[o] = cur; G->len[o] = n; G->cov[o] = cov; G->wk[o] = wk;
         k128 a = g_oseq(G, (uint32_t)o), b = k128_rc(g_oseq(G, cur), G->kv);
         G->ukey[o] = k128_lt(b, a) ? b : a;
     }
@@ -635,8 +639,10 @@ static void graph_unitigs(or_graph* G) {
 
 /* Velvet's default error removal (velvetg without -cov_cutoff: tip clipping + Tour Bus bubble popping), DEFINED
  * here on the unitig graph — Velvet itself is absent, and its coverage-based choices are coin flips on this input where every
- * surviving k-mer is one read (assemble_gaps.py:104-118), so ties are broken by an orientation-free sequence order:
- *   X beats Y  :=  (cov X, then the SMALLER ukey) wins, preceded by (nodes) where lengths can differ.
+ * surviving k-mer is one read (assemble_gaps.py:104-118), so ties are broken — north_star: "for fixed tie-breaking" — first by the
+ * evidence the k-mer counts still hold (a sequencing error that made it past min_count was seen exactly min_count times, the true
+ * sequence many more: the side with FEWER WEAK nodes stays), then by an orientation-free sequence order:
+ *   X beats Y  :=  (cov X, then fewer weak nodes, then the SMALLER ukey) wins, preceded by (nodes) where lengths can differ.
  * One round decides on ONE snapshot of the graph, for every oriented unitig X (head h, tail t, n nodes):
  *  TIP     out-degree(t) == 0, in-degree(h) == 1 with predecessor p of out-degree >= 2, n <= kv (i.e. n + kv - 1 < 2 kv bases:
  *          Velvet's tip length), and some OTHER branch Y leaving p beats X: Y is not tip-shaped itself (tip-shaped = dead end,
@@ -655,6 +661,7 @@ static int tip_shaped(const or_graph* G, uint32_t h) {
 static int beats(const or_graph* G, uint32_t y, uint32_t x, int with_len) {
     if (with_len && G->len[y] != G->len[x]) return G->len[y] > G->len[x];
     if (G->cov[y] != G->cov[x]) return G->cov[y] > G->cov[x];
+    if (G->wk[y] != G->wk[x]) return G->wk[y] < G->wk[x];
     return k128_lt(G->ukey[y], G->ukey[x]);
 }
 /* alternative paths from tail q (q = p at depth 0) to s with exactly `remain` nodes; returns 1 when X must go */
@@ -748,8 +755,13 @@ size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv
     for (size_t i = 0; i < nk;) {
         size_t j = i;
         while (j < nk && k128_eq(keys[j], keys[i])) ++j;
-        nd[nn].key = keys[i]; nd[nn].mult = (uint32_t)(j - i); nd[nn].out = nd[nn].in = nd[nn].dead = 0; ++nn;
+        nd[nn].key = keys[i]; nd[nn].mult = (uint32_t)(j - i); nd[nn].out = nd[nn].in = nd[nn].dead = nd[nn].weak = 0; ++nn;
         i = j;
+    }
+    for (size_t s = 0; s < ns; ++s) { /* weak k-mers mark their nodes */
+        if ((cn[s] < 3 ? cn[s] : 3u) > (uint32_t)(min_count < 1 ? 1 : min_count)) continue;
+        k128 t = {hi[s], lo[s]};
+        for (int o = 0; o < per; ++o) nd[node_find(nd, nn, k128_canon(k128_sub(t, o, kv), kv, NULL))].weak = 1;
     }
     for (size_t s = 0; s < ns; ++s) { /* edges */
         k128 t = {hi[s], lo[s]};
@@ -765,7 +777,7 @@ size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv
     or_graph G;
     G.nd = nd; G.nn = nn; G.kv = kv;
     G.head = malloc((2 * nn + 1) * 4); G.tail = malloc((2 * nn + 1) * 4); G.len = malloc((2 * nn + 1) * 4);
-    G.cov = malloc((2 * nn + 1) * 4); G.next = malloc((2 * nn + 1) * 4); G.ukey = malloc((2 * nn + 1) * sizeof(k128));
+    G.cov = malloc((2 * nn + 1) * 4); G.wk = malloc((2 * nn + 1) * 4); G.next = malloc((2 * nn + 1) * 4); G.ukey = malloc((2 * nn + 1) * sizeof(k128));
     G.kill = malloc(nn + 1);
     graph_unitigs(&G);
     for (int round = 0; round < simplify; ++round) {
@@ -797,7 +809,7 @@ size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv
         free(ctg[c].seq);
     }
     *seq_need = off;
-    free(ctg); free(G.head); free(G.tail); free(G.len); free(G.cov); free(G.next); free(G.ukey); free(G.kill);
+    free(ctg); free(G.head); free(G.tail); free(G.len); free(G.cov); free(G.wk); free(G.next); free(G.ukey); free(G.kill);
     free(nd); free(keys); free(hi); free(lo); free(cn);
     return nc;
 }

@@ -279,3 +279,32 @@ def test_random_error_graphs_match_oracle(gf):
             assert got.get((i, k, kv), []) == exp, (i, k, kv)
             n_diff_raw += exp != CO.assemble_pool(p, L, k, kv, simplify=0)
     assert n_diff_raw > 30      # the removal did something in most pools
+
+
+@pytest.mark.parametrize("kk,L", [((31, 29), 100), ((51, 49), 150), ((41, 37), 150)])
+def test_weak_kmers_lose_the_ties_of_the_error_removal(gf, kk, L):
+    """An error seen exactly min_count times against the true allele (oracle: test_an_error_seen_exactly_min_count_times_...): the
+    kernel keeps the true allele like the oracle — key-slot, fingerprint and instance-id count tables (k 31 / 51, kv = k - 4 runs
+    without node fingerprints), LDS and global plans, min_count 2 and 3 (void rule) and 1."""
+    from test_assembly_oracle import _cover, _mut
+    rng = np.random.RandomState(41)
+    pools, truth = [], []
+    for trial in range(16):
+        g = LUT[rng.randint(0, 4, 900)].tobytes()
+        h = _mut(g, 450, 1 + trial % 3)
+        err = h[450 - L // 2:450 + L // 2]
+        reads = _cover(g, L) + [err, rc(err)] + ([err] if trial >= 12 else [])
+        pools.append(b"".join(reads))
+        truth.append(g)
+    for mc in (2, 3, 1):
+        for lds_kb in (152, 8):
+            gf.set_option("asm_lds_pool_kb", lds_kb)
+            try:
+                got, _ = _gpu_assemble(gf, pools, L, [kk], min_count=mc)
+            finally:
+                gf.set_option("asm_lds_pool_kb", 152)
+            for i, p in enumerate(pools):
+                exp = CO.assemble_pool(p, L, kk[0], kk[1], min_count=mc)
+                assert got.get((i, kk[0], kk[1]), []) == exp, (i, mc, lds_kb)
+                if mc == 2 and i < 12:
+                    assert len(exp) == 1 and exp[0][0].encode() in (truth[i], rc(truth[i]))
