@@ -322,6 +322,8 @@ def run(args):
         dist.all_reduce(per_gap, op=dist.ReduceOp.SUM)
     max_pool_rows = int(per_gap.max())
     gf.set_option("asm_max_pool_reads", int(1.5 * max_pool_rows) + 64)
+    if os.environ.get("GF_BENCH_ASM_THREADS"):       # threads per gap in the assembly kernel (1024 / 512 / 256; default: by the pool bound)
+        gf.set_option("asm_threads", int(os.environ["GF_BENCH_ASM_THREADS"]))
     lib_cap = max(4096, int(1.25 * max(rows_lib)) + 1024)            # rows of one library's pool array
     # local pool arrays: [n_lib][lib_cap] rows (slot l = library l: the source layout of gf_pools_merge_dev)
     d_pools = torch.empty(n_lib * lib_cap * rb + 64, dtype=torch.uint8, device=dev)

@@ -197,6 +197,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "asm_max_pool_reads")) { if (value < 0 || value > 0x3FFFFFFF) return GF_E_INVAL; ctx->asm_max_pool_reads = value; return GF_OK; }
     if (!strcmp(name, "asm_simplify")) { if (value < 0 || value > 8) return GF_E_INVAL; ctx->asm_simplify = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_lds_pool_kb")) { ctx->asm_lds_pool_kb = (int)value; return GF_OK; }
+    if (!strcmp(name, "asm_threads")) { if (value != 0 && value != 1024 && value != 512 && value != 256) return GF_E_INVAL; ctx->asm_threads = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_lds_log2_max")) {
         ctx->screen_lds_log2_max = std::max(15, std::min(20, (int)value));
         for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);

@@ -20,8 +20,12 @@
 
 namespace gf {
 
-constexpr uint32_t ASM_THREADS = 1024;  // one workgroup per CU: the phases are latency-bound loops over the gap's items
-constexpr uint32_t ASM_LDS_MAX_WORDS = 38 * 1024;  // 152 KiB of dynamic LDS: staged reads, then per-node arrays
+// Threads per workgroup = per gap: 1024 (one workgroup per CU with all 152 KiB of LDS: deep pools), 512 (two per CU, 76 KiB each)
+// or 256 (four per CU, 38 KiB each).  The CU runs 16 waves either way; with several gaps per CU one gap's barriers and its
+// poorly parallel phases (graph construction over a few thousand survivors, error-removal walks, ranking rounds) overlap another
+// gap's work instead of leaving waves idle.
+constexpr uint32_t ASM_THREADS_MAX = 1024;
+constexpr uint32_t ASM_LDS_MAX_WORDS = 38 * 1024;  // 152 KiB of dynamic LDS per CU: staged reads, then tables and per-node arrays
 
 struct AsmParams {
     const uint32_t* reads32;   // packed pool reads as little-endian words
@@ -364,8 +368,9 @@ __device__ __forceinline__ void wg_phase_sync() {
 //   count phase   R = k-mer table (8-B slots) when the distinct k-mers keep it under 3/4 full, else the global slice
 //   graph phase   R = node table (2 slots per possible node) + inst_of/meta/succ0/succ1 arrays, else global
 // Every pointer below is generic (LDS or global); the code path is the same.
-template <bool W>
-__global__ __launch_bounds__(ASM_THREADS) void assemble_kernel(AsmParams P) {
+template <bool W, int NT>
+__global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 waves per SIMD = 16 per CU for every NT: <= 128 VGPRs)
+    constexpr uint32_t ASM_THREADS = NT;
     __shared__ uint32_t s_cnt[8];  // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes [6] LDS table overflow
     __shared__ unsigned long long s_seq[2];  // [0] bases to emit  [1] global base offset
     const uint32_t tid = threadIdx.x;
@@ -1508,7 +1513,13 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     if (!d_cnt_keys && (kv < 15 || kv >= k || !(kv & 1))) return GF_E_UNSUPPORTED;
     if (n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull) return GF_E_INVAL;
     const uint32_t unit = d_cnt_keys ? read_len - k + 1 : read_len - kv + 1;
-    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(n_pools, (size_t)ctx->n_cu));
+    // threads per gap: option asm_threads (1024 / 512 / 256), or by the caller's bound on the largest pool (asm_max_pool_reads):
+    // pools that leave room for their tables in half of a CU's LDS run two gaps per CU
+    int nt = ctx->asm_threads;
+    if (nt != 1024 && nt != 512 && nt != 256)
+        nt = (ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * ((read_len + 3) / 4) <= 28 * 1024) ? 512 : 1024;
+    const unsigned per_cu = 1024u / (unsigned)nt;
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(n_pools, (size_t)ctx->n_cu * per_cu));
     // workspace units (see the kernel): one slice per pool row, or — when the caller bounds the rows of one pool (option
     // asm_max_pool_reads; the host entry points know their pools) — one slice of that many rows per workgroup
     const uint64_t slice_rows = ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * grid < total_reads ? (uint64_t)ctx->asm_max_pool_reads : 0;
@@ -1572,10 +1583,13 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.dbg = (unsigned long long*)ctx->asm_dbg;
     // dynamic LDS (option asm_lds_kb, default all 152 KiB): the gap's packed reads, then meta + succ[2] of its nodes;
     // whatever does not fit is read from / kept in global memory
-    P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
+    P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS / per_cu, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
     {
         LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
-        hipLaunchKernelGGL(k <= 32 ? assemble_kernel<false> : assemble_kernel<true>, dim3(grid), dim3(ASM_THREADS), (size_t)P.lds_words * 4, ctx->stream, P);
+        void (*kern)(AsmParams) = nt == 1024 ? (k <= 32 ? assemble_kernel<false, 1024> : assemble_kernel<true, 1024>)
+                                  : nt == 512 ? (k <= 32 ? assemble_kernel<false, 512> : assemble_kernel<true, 512>)
+                                              : (k <= 32 ? assemble_kernel<false, 256> : assemble_kernel<true, 256>);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), (size_t)P.lds_words * 4, ctx->stream, P);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
