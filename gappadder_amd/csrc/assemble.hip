@@ -24,7 +24,6 @@ namespace gf {
 // or 256 (four per CU, 38 KiB each).  The CU runs 16 waves either way; with several gaps per CU one gap's barriers and its
 // poorly parallel phases (graph construction over a few thousand survivors, error-removal walks, ranking rounds) overlap another
 // gap's work instead of leaving waves idle.
-constexpr uint32_t ASM_THREADS_MAX = 1024;
 constexpr uint32_t ASM_LDS_MAX_WORDS = 38 * 1024;  // 152 KiB of dynamic LDS per CU: staged reads, then tables and per-node arrays
 
 struct AsmParams {
@@ -1513,11 +1512,17 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     if (!d_cnt_keys && (kv < 15 || kv >= k || !(kv & 1))) return GF_E_UNSUPPORTED;
     if (n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull) return GF_E_INVAL;
     const uint32_t unit = d_cnt_keys ? read_len - k + 1 : read_len - kv + 1;
-    // threads per gap: option asm_threads (1024 / 512 / 256), or by the caller's bound on the largest pool (asm_max_pool_reads):
-    // pools that leave room for their tables in half of a CU's LDS run two gaps per CU
+    // threads per gap: option asm_threads (1024 / 512 / 256), or automatic: two gaps per CU (512) when the caller's bound on the
+    // largest pool (asm_max_pool_reads) leaves room for the tables in half of a CU's LDS and there are gaps enough to keep every CU
+    // busy with pairs of them.  Measured on MI355X (us per gap and CU at 1024 / 512 threads): C4's 313-read pools at k = 51: 221 /
+    // 386 -> 18.0 / 15.6 ms per 19 840 gaps; every phase takes about twice as long with half the threads — the CU is throughput-bound
+    // on its LDS pipeline, not short of ready waves —, the gain is what the barriers and the serial error-removal walks left idle.
+    // C2 (1 000 gaps = 4 per CU: latency per gap counts) 0.59 / 0.82 ms; C5's 722-read pools fall out of the LDS plans at 76 KiB (142
+    // / 268 ms); four gaps per CU (256 threads, 38 KiB) push C4's graph phases into the global slice: 37 ms.
     int nt = ctx->asm_threads;
     if (nt != 1024 && nt != 512 && nt != 256)
-        nt = (ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * ((read_len + 3) / 4) <= 28 * 1024) ? 512 : 1024;
+        nt = (ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * ((read_len + 3) / 4) <= 28 * 1024 &&
+              n_pools >= 8 * (size_t)ctx->n_cu) ? 512 : 1024;
     const unsigned per_cu = 1024u / (unsigned)nt;
     const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(n_pools, (size_t)ctx->n_cu * per_cu));
     // workspace units (see the kernel): one slice per pool row, or — when the caller bounds the rows of one pool (option

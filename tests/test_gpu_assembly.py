@@ -308,3 +308,28 @@ def test_weak_kmers_lose_the_ties_of_the_error_removal(gf, kk, L):
                 assert got.get((i, kk[0], kk[1]), []) == exp, (i, mc, lds_kb)
                 if mc == 2 and i < 12:
                     assert len(exp) == 1 and exp[0][0].encode() in (truth[i], rc(truth[i]))
+
+
+@pytest.mark.parametrize("threads", [512, 256])
+def test_two_and_four_gaps_per_cu_give_the_same_contigs(gf, threads):
+    """option asm_threads: 512 / 256 threads per gap (two / four gaps per CU, 76 / 38 KiB of LDS each) against the oracle — small pools
+    in LDS, the noisy deep pools that fall back to the global slice at those budgets, k <= 32 and k > 32."""
+    c = S.small_case(seed=5, n_pairs=12000, L=150, insert=300)
+    pools = _pools_from_case(c)
+    deep = [b"".join(r) for (l, k2, r) in _kat_pools() if l == 150]
+    gf.set_option("asm_threads", threads)
+    try:
+        got, _ = _gpu_assemble(gf, pools, 150, [(31, 29), (51, 49)])
+        got2, _ = _gpu_assemble(gf, deep, 150, [(31, 29), (41, 39)])
+    finally:
+        gf.set_option("asm_threads", 0)
+    n = 0
+    for g, p in enumerate(pools):
+        for k, kv in ((31, 29), (51, 49)):
+            exp = CO.assemble_pool(p, 150, k, kv)
+            assert got.get((g, k, kv), []) == exp, (g, k, kv)
+            n += len(exp)
+    for g, p in enumerate(deep):
+        for k, kv in ((31, 29), (41, 39)):
+            assert got2.get((g, k, kv), []) == CO.assemble_pool(p, 150, k, kv), (g, k, kv)
+    assert n > 20
