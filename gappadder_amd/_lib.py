@@ -22,7 +22,7 @@ SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", 
                       ("library", "<u4"), ("reserved", "<u4")])
 QCPAIR = np.dtype([("set", "<u4"), ("i", "<u4"), ("j", "<u4")])
 OVL_PARAMS = np.dtype([("mismatch", "<f8"), ("indel", "<f8"), ("max_clip", "<f8"), ("frac_min_overlap", "<f8"), ("frac_loss", "<f8"),
-                       ("min_overlap", "<f8"), ("min_overlap_scaffold", "<f8")])
+                       ("min_overlap", "<f8"), ("min_overlap_scaffold", "<f8"), ("relax", "<f8")])
 OVL_RESULT = np.dtype([(n, "<i4") for n in ("res", "row_end", "col_end", "nclip", "score", "contained", "merged_len", "overlap",
                                             "containment", "first_goes_first")])
 assert CONTIG.itemsize == 32 and GAP.itemsize == 16 and ALNREC.itemsize == 32 and TAGHIT.itemsize == 12 and DPOS.itemsize == 16 and HIT.itemsize == 8

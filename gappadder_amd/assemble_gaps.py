@@ -3,9 +3,9 @@
 (Velvet's role); write contigs_{k}_{kv}.fa and the merged contigs.fa with '>{k}_{kv}_' headers.  All gaps of a batch go
 through ONE gf_assemble call per pair instead of >= 5 process launches per (gap, k, kv).
 
-assemble_pipeline follows the reference's round structure (assemble_gaps.py:328-366) without its contig-merging steps
-(TERefiner / ContigsMerger): first-round assembly -> pick -> both-unmapped recruitment for the gaps still
-open (collect_both_unmapped_reads.py) -> second-round assembly of those gaps -> pick at anchor 30, then 15."""
+assemble_pipeline follows the reference's round structure (assemble_gaps.py:328-368): first-round assembly + contig merging
+(MergeContigs.py) -> pick -> both-unmapped recruitment for the gaps still open (collect_both_unmapped_reads.py) -> second-round
+assembly of those gaps -> pick -> merge -> pick -> high-quality bridging reads + merge -> pick at anchor 15 -> extended fills."""
 import os
 
 from . import fastq_io
@@ -101,25 +101,80 @@ class GapAssembler:
     assembly_given_list = assembly
 
     def run_contigs_merge(self, fa_list):
-        """assemble_gaps.py:301-306 / run_merge :138-145.  Of the reference's merge step the first two stages of ContigsMerger are
-        built, on the GPU: the candidate pairs of its 10-mer prefilter and their overlap evaluation = the edges of its overlap graph
-        (MergeContigs.merge_candidates / merge_edges); the path search and the TERefiner dedup are not: contigs.fa stays as is."""
-        from .MergeContigs import merge_candidates, merge_edges
-        cand = merge_candidates(_ctx(), working_folder, fa_list)
-        merge_edges(_ctx(), working_folder, fa_list)
-        return cand
+        """assemble_gaps.py:301-306 / run_merge :138-145: dedup + ContigsMerger + dedup per gap (MergeContigs.merge_contigs: contigs.fa
+        becomes the merged set, the assembly's own contigs move to original_contigs_before_merging.fa).  The reference's merge is
+        a best-effort step — each gap is its own Pool task and a failed one leaves its contigs.fa alone —, so a failure here is
+        reported and the pipeline goes on with the contigs as they are."""
+        from .MergeContigs import merge_contigs
+        try:
+            return merge_contigs(_ctx(), working_folder, fa_list)
+        except Exception as e:          # noqa: BLE001 — any failure of this optional step must not take the picking down
+            import sys
+            sys.stderr.write("contig merging skipped for %d gaps: %r\n" % (len(fa_list), e))
+            return {}
+
+    def collect_high_quality_unmap_to_contigs_reads(self, id_list, seed_len=30):
+        """run_collect_high_quality_unmap_to_contig_reads (assemble_gaps.py:166-217): the gap's high-quality reads
+        (gap_reads_high_quality/{id}.fastq, MAPQ 60 only) that align CLIPPED to at least two of its merged contigs are bridges
+        between them; the merged contigs.fa is dropped, the assembly's own contigs come back (original_contigs_before_merging.fa)
+        and the bridging reads are appended as FASTA records, so that the next merge can chain through them.  `bwa mem` is replaced
+        by exact matching: a read aligns clipped to a contig when they share an exact stretch of seed_len bases (bwa's default
+        output threshold -T 30) on either strand and the read does not lie inside the contig as a whole.  Returns the number of
+        reads appended."""
+        from .pick_contigs import read_fasta, revcomp
+        n_added = 0
+        for gid in id_list:
+            d = "%svelvet_temp/%s/" % (working_folder, gid)
+            sf_reads = "%sgap_reads_high_quality/%s.fastq" % (working_folder, gid)
+            if not os.path.exists(d + "contigs.fa") or not os.path.exists(sf_reads):      # (:170-179)
+                continue
+            contigs = [(n, s.upper()) for n, s in read_fasta(d + "contigs.fa")]
+            reads = {}                                                                    # first record of an id counts (:188-191)
+            with open(sf_reads) as f:
+                while True:
+                    h = f.readline()
+                    if not h:
+                        break
+                    seq = f.readline().strip()
+                    f.readline()
+                    f.readline()
+                    reads.setdefault(h[1:].split()[0], seq)
+            seeds = {}                                                                    # seed -> contigs that hold it
+            for ci, (_, s) in enumerate(contigs):
+                for strand in (s, revcomp(s)):
+                    for i in range(len(strand) - seed_len + 1):
+                        seeds.setdefault(strand[i:i + seed_len], set()).add(ci)
+            bridges = []
+            for rid, seq in reads.items():
+                su = seq.upper()
+                hit = set()
+                for i in range(len(su) - seed_len + 1):
+                    hit |= seeds.get(su[i:i + seed_len], set())
+                clipped = [ci for ci in hit if su not in contigs[ci][1] and revcomp(su) not in contigs[ci][1]]
+                if len(clipped) >= 2:                                                     # clipped at two contigs at least (:213)
+                    bridges.append((rid, seq))
+            if os.path.exists(d + "original_contigs_before_merging.fa"):                  # (:206-210)
+                os.replace(d + "original_contigs_before_merging.fa", d + "contigs.fa")
+            with open(d + "contigs.fa", "a") as f:
+                for rid, seq in bridges:
+                    f.write(">%s\n%s\n" % (rid, seq))
+            n_added += len(bridges)
+        return n_added
 
     def pick_already_constructed(self, contigs_select, fa_list, sf_picked):
         picked = contigs_select.get_already_picked(sf_picked)
         return [k for k in fa_list if k not in picked]
 
     def assemble_pipeline(self):
-        """The reference's rounds (assemble_gaps.py:328-366) minus contig merging: assemble; pick the gaps whose contigs are
-        anchored by both flanks (anchor length 30 = the reference's first bwa_min_score); for the gaps still open recruit the
-        both-unmapped pairs that share k-mers with their contigs and assemble again (:344-351); pick at 30, then at 15 (:365); what is still open gets the extended (partial, 'NN'-joined) fill (:367-368)."""
+        """The reference's rounds (assemble_gaps.py:328-368): assemble + merge; pick the gaps whose contigs are anchored by both
+        flanks (anchor length 30 = the reference's first bwa_min_score); for the gaps still open recruit the both-unmapped pairs that
+        share k-mers with their contigs and assemble again (:344-351), pick; merge those that are still open, pick (:353-356); bring
+        in the high-quality reads that bridge two contigs and merge once more (:358-361); pick at 15 (:364-366); what is still open
+        gets the extended (partial, 'NN'-joined) fill (:367-368)."""
         from .pick_contigs import ContigsSelection
         fa_list = self.prepare_list()
         self.assembly(fa_list)
+        merged = sum(1 for v in self.run_contigs_merge(fa_list).values() if v)
         sf_picked = working_folder + "../picked_seqs.fa"
         cs = ContigsSelection(working_folder)
         closed = cs.pick_full_constructed_contigs(30, fa_list, sf_picked)
@@ -131,11 +186,16 @@ class GapAssembler:
             burc = BothUnmappedReadsCollector(working_folder, self.samtools_path, _ctx(), min(ks) if ks else 31)
             burc.collect_both_unmapped_reads(self.bam_list, remain)
             recruited = sum(1 for key in remain if os.path.exists("%sunmapped_reads/%s.fastq" % (working_folder, key)))
-            self.assembly_given_list(remain)
-            closed += cs.pick_full_constructed_contigs(30, remain, sf_picked)
-            remain = self.pick_already_constructed(cs, remain, sf_picked)
-        self.run_contigs_merge(remain)      # (the reference merges the open gaps' contigs here, :353-361; built: candidate pairs only)
-        closed += cs.pick_full_constructed_contigs(15, remain, sf_picked)
+        self.assembly_given_list(remain)                                     # second-round assembly (:349-351)
+        closed += cs.pick_full_constructed_contigs(30, remain, sf_picked)
         remain = self.pick_already_constructed(cs, remain, sf_picked)
-        extended = cs.pick_extended_contigs(15, remain, sf_picked)        # partial fills, left + 'NN' + right (:367-368)
-        return {"gaps": len(fa_list), "closed": closed, "extended": extended, "second_round_gaps": recruited}
+        merged += sum(1 for v in self.run_contigs_merge(remain).values() if v)             # second-round merging (:353-356)
+        closed += cs.pick_full_constructed_contigs(30, remain, sf_picked)
+        remain = self.pick_already_constructed(cs, remain, sf_picked)
+        bridges = self.collect_high_quality_unmap_to_contigs_reads(remain)   # (:358-361)
+        merged += sum(1 for v in self.run_contigs_merge(remain).values() if v)
+        closed += cs.pick_full_constructed_contigs(15, remain, sf_picked)    # (:364-366)
+        remain = self.pick_already_constructed(cs, remain, sf_picked)
+        extended = cs.pick_extended_contigs(15, remain, sf_picked)           # partial fills, left + 'NN' + right (:367-368)
+        return {"gaps": len(fa_list), "closed": closed, "extended": extended, "second_round_gaps": recruited,
+                "gaps_with_merged_contigs": merged, "bridging_reads": bridges}

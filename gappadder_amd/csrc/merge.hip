@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void overlap_eval_kernel(OvParams P) {
             else if (score < ov * (1 - P.pr.frac_loss)) res = 0;
             else if (ov < P.pr.min_overlap_scaffold) res = 0;
             else if (ov < P.pr.min_overlap) res = 1;
+            if (P.pr.relax != 0.0) res = 2;   // Evaluate's fRelax mode (ContigsCompactor.cpp:1712-1725): no significance test
             r.res = res; r.row_end = row_end; r.col_end = col_end; r.nclip = nclip; r.score = score;
             if (res) {
                 const int contained = (row_end + nclip == n1 && (fend & 1)) || (col_end + nclip == n2 && (fend & 2));

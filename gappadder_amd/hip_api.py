@@ -263,7 +263,7 @@ class GapFill:
     # ContigsMerger's options as GAPPadder sets them (MergeContigs.py:75: -s 0.4 -i1 -2.0 -i2 -2.0 -x 12 -y 50) + its defaults (main.cpp:24-27)
     MERGER_PARAMS = (-2.0, -2.0, 50.0, 0.005, 0.4, 12.0, 6.0)
 
-    def overlap_evaluate(self, contig_sets, pairs, params=None):
+    def overlap_evaluate(self, contig_sets, pairs, params=None, relax=False):
         """The contig merger's pairwise overlap evaluation (ContigsCompactor::Evaluate, ContigsCompactor.cpp:1572-1976) of the
         ordered node pairs `pairs` (B.QCPAIR triples: set, i, j; nodes = 2 * contig + strand) -> B.OVL_RESULT array, same order."""
         pairs = np.ascontiguousarray(pairs, dtype=B.QCPAIR)
@@ -277,7 +277,8 @@ class GapFill:
         soff = np.zeros(len(contig_sets) + 1, dtype=np.uint64)
         soff[1:] = np.cumsum([len(cs) for cs in contig_sets])
         pr = np.zeros(1, dtype=B.OVL_PARAMS)
-        pr[0] = tuple(self.MERGER_PARAMS if params is None else params)
+        p7 = tuple(self.MERGER_PARAMS if params is None else params)
+        pr[0] = p7[:7] + (float(p7[7]) if len(p7) > 7 else (1.0 if relax else 0.0),)
         self._chk(self._L.gf_overlap_evaluate(self._h, blob, B._p(coff), B._p(soff), len(contig_sets), B._p(pairs), len(pairs), B._p(pr), B._p(out)),
                   "gf_overlap_evaluate")
         return out

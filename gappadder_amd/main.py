@@ -106,9 +106,9 @@ def main_func(command, sf_config):
                                         bam_list=[bam for bam, _, _ in cfg["alignments"]], samtools_path=cfg["samtools"])
         res = ga.assemble_pipeline()
         print("assembled %d gaps, %d closed (picked_seqs.fa), %d with an extended (partial) fill, %d gaps got both-unmapped pairs in the "
-              "second round; contigs in %svelvet_temp/*/contigs.fa; of the reference's contig-merging step (TERefiner / ContigsMerger) the "
-              "candidate-pair prefilter and the pairwise overlap evaluation are built (velvet_temp/*/merge_candidates.txt, merge_edges.txt)"
-              % (res["gaps"], res["closed"], res.get("extended", 0), res["second_round_gaps"], wf + MERGE_FOLDER))
+              "second round, contigs merged in %d gap rounds (%d bridging high-quality reads); contigs in %svelvet_temp/*/contigs.fa"
+              % (res["gaps"], res["closed"], res.get("extended", 0), res["second_round_gaps"], res["gaps_with_merged_contigs"],
+                 res["bridging_reads"], wf + MERGE_FOLDER))
 
 
 def main(argv=None):

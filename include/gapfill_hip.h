@@ -374,6 +374,7 @@ int gf_quick_check_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off,
  * up to 8190 bases.  Pairs are gf_qcpair {set, i, j} (ANY ordered node pair: i is the reference's pSeq1, j its pSeq2). */
 typedef struct {
     double mismatch, indel, max_clip, frac_min_overlap, frac_loss, min_overlap, min_overlap_scaffold;
+    double relax;             /* != 0: Evaluate's fRelax mode (FormMergedSeqFromPath, ContigsCompactor.cpp:1489): no significance test, res = 2 */
 } gf_ovl_params;
 typedef struct {
     int32_t res;              /* 0 no usable overlap, 1 overlap in [min_overlap_scaffold, min_overlap), 2 overlap >= min_overlap; -1: contig too long */

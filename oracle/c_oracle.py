@@ -189,7 +189,7 @@ def quick_check(contigs, k=10):
 
 
 OVL_PARAMS = np.dtype([("mismatch", "<f8"), ("indel", "<f8"), ("max_clip", "<f8"), ("frac_min_overlap", "<f8"), ("frac_loss", "<f8"),
-                       ("min_overlap", "<f8"), ("min_overlap_scaffold", "<f8")])
+                       ("min_overlap", "<f8"), ("min_overlap_scaffold", "<f8"), ("relax", "<f8")])
 OVL_RESULT = np.dtype([(n, "<i4") for n in ("res", "row_end", "col_end", "nclip", "score", "contained", "merged_len", "overlap",
                                             "containment", "first_goes_first")])
 GAPPADDER_OVL = (-2.0, -2.0, 50.0, 0.005, 0.4, 12.0, 6.0)   # MergeContigs.py:75 (-i1 -i2 -y -s -x) + ContigsMerger's defaults (main.cpp:24-27)
@@ -205,9 +205,10 @@ def merger_nodes(contigs):
     return out
 
 
-def overlap_evaluate(s1, s2, params=GAPPADDER_OVL):
-    """ContigsCompactor::Evaluate on one ordered pair of node strings -> dict of OVL_RESULT fields."""
-    pr = np.zeros(1, OVL_PARAMS); pr[0] = tuple(params)
+def overlap_evaluate(s1, s2, params=GAPPADDER_OVL, relax=False):
+    """ContigsCompactor::Evaluate on one ordered pair of node strings -> dict of OVL_RESULT fields.  relax: its fRelax mode
+    (no significance test; FormMergedSeqFromPath, ContigsCompactor.cpp:1489)."""
+    pr = np.zeros(1, OVL_PARAMS); pr[0] = tuple(params)[:7] + (1.0 if relax else 0.0,)
     out = np.zeros(1, OVL_RESULT)
     lib().or_overlap_evaluate(s1.encode(), len(s1), s2.encode(), len(s2), _p(pr), _p(out))
     return {n: int(out[0][n]) for n in OVL_RESULT.names}

@@ -265,6 +265,7 @@ void or_overlap_evaluate(const char* s1, int n1, const char* s2, int n2, const o
         else if (score_max < ov * (1 - pr->frac_loss)) res = 0;
         else if (ov < pr->min_overlap_scaffold) res = 0;
         else if (ov < pr->min_overlap) res = 1;
+        if (pr->relax != 0.0) res = 2;                       /* fRelax (:1712-1725): the significance test is skipped */
     }
     memset(out, 0, sizeof *out);
     out->res = res; out->row_end = row_end; out->col_end = col_end; out->nclip = nclip; out->score = score_max;

@@ -39,7 +39,7 @@ size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv
                          size_t* seq_need);
 /* f-3: the contig merger's all-pairs k-mer prefilter (QuickCheckerContigsMatch, ContigsCompactor.cpp:1982-2095) over the node list
  * [c0, revcomp(c0), c1, ...]; pairs (i <= j) in order; returns their number (may exceed cap).  Contigs of >= 30 bases. */
-typedef struct { double mismatch, indel, max_clip, frac_min_overlap, frac_loss, min_overlap, min_overlap_scaffold; } or_ovl_params;
+typedef struct { double mismatch, indel, max_clip, frac_min_overlap, frac_loss, min_overlap, min_overlap_scaffold, relax; } or_ovl_params;
 typedef struct { int32_t res, row_end, col_end, nclip, score, contained, merged_len, overlap, containment, first_goes_first; } or_ovl_result;
 void or_overlap_evaluate(const char* s1, int n1, const char* s2, int n2, const or_ovl_params* pr, or_ovl_result* out);
 size_t or_quick_check(const char* seqs, const uint64_t* off, size_t n, int k, uint32_t* out_i, uint32_t* out_j, size_t cap);

@@ -598,6 +598,78 @@ def pick_kat():
           sum(1 for c in cases if c["ext"] != "TIE" and c["ext"][0]), "extended picks,", sum(1 for c in cases if c["ext"] == "TIE"), "int-vs-str ties")
 
 
+def merger_kat():
+    """Known answers of the reference's own ContigsMerger (its main.cpp + sources built into oracle/_ref/contigs_merger, options of
+    MergeContigs.py:75 with -t 1): contig sets -> the NEW_CONTIG_MERGE_n records it prints (sequence + the path of its .info file)."""
+    import random
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "ref"])
+    exe = os.path.join(REPO, "oracle", "_ref", "contigs_merger")
+    rng = random.Random(20260320)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+
+    def noisy(s, subs, indels):
+        s = list(s)
+        for _ in range(subs):
+            i = rng.randrange(len(s)); s[i] = rng.choice([c for c in "ACGT" if c != s[i]])
+        for _ in range(indels):
+            i = rng.randrange(1, len(s) - 1)
+            if rng.random() < 0.5: del s[i]
+            else: s.insert(i, rng.choice("ACGT"))
+        return "".join(s)
+    sets = []
+    g = rnd(1600)
+    sets.append([g[0:300], g[220:560], g[500:900]])                                             # a chain of three
+    sets.append([g[0:300], rc(g[220:560]), g[500:900], rnd(200)])                               # one link reverse-complemented, a stranger
+    sets.append([g[500:900], g[0:300], g[220:560]])                                             # the same chain listed out of order
+    sets.append([g[0:400], g[100:250], g[300:700], g[650:1000]])                                # a contained contig: no edge
+    sets.append([g[0:300], g[250:600], g[250:520] + rnd(150), g[550:900]])                      # a fork: two ways on from c0
+    sets.append([g[0:300], g[200:500], g[420:700], g[230:480], g[650:1000]])                    # alternative routes: the larger total overlap
+    sets.append([noisy(g[0:350], 3, 1), noisy(g[280:640], 3, 1), noisy(g[580:900], 2, 0)])      # dirty overlaps: clips and the relaxed re-evaluation
+    sets.append([g[0:300] + rnd(30), g[260:600]])                                               # a dirty end that must be clipped (-y 50)
+    sets.append([rnd(250), rnd(260), rnd(270)])                                                 # nothing overlaps: no new contig
+    a, b = rnd(200), rnd(200)
+    sets.append([a + b, b + a])                                                                 # a 2-cycle: one strongly connected component
+    sets.append([a + b[:100], b[:100] + rnd(80) + a[:90], a[:90] + rnd(50)])                    # a chain through a repeat-like overlap
+    for _ in range(30):                                                                         # random tilings of a random genome, random strands
+        gg = rnd(rng.randrange(600, 2500))
+        cs, pos = [], 0
+        while pos < len(gg) - 80:
+            ln = rng.randrange(120, 500)
+            piece = gg[pos:pos + ln]
+            if rng.random() < 0.3:
+                piece = noisy(piece, rng.randrange(0, 3), rng.randrange(0, 2))
+            cs.append(rc(piece) if rng.random() < 0.5 else piece)
+            pos += ln - rng.randrange(20, 110)
+        if rng.random() < 0.5:
+            cs.append(rnd(rng.randrange(60, 200)))
+        rng.shuffle(cs)
+        sets.append(cs)
+    out = []
+    tmp = tempfile.mkdtemp(prefix="gp_mg_")
+    try:
+        for ci, contigs in enumerate(sets):
+            fa = os.path.join(tmp, "c%d.fa" % ci)
+            with open(fa, "w") as f:
+                f.write("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(contigs)))
+            txt = subprocess.check_output([exe, "-s", "0.4", "-i1", "-2.0", "-i2", "-2.0", "-x", "12", "-y", "50", "-k", "10", "-t", "1", "-m", "1",
+                                           "-o", fa + ".info", fa], cwd=tmp).decode()
+            recs = []
+            for r in txt.split(">")[1:]:
+                h, *body = r.split("\n")
+                recs.append((h.split()[0], "".join(body)))
+            new = [(h, q) for h, q in recs if h.startswith("NEW_CONTIG_MERGE_")]
+            assert [q for h, q in recs if not h.startswith("NEW_CONTIG_MERGE_")] == contigs       # the originals follow, unchanged
+            info = {l.split()[0]: l.split()[1:] for l in open(fa + ".info").read().splitlines() if l.strip()}
+            out.append({"contigs": contigs, "new": [{"seq": q, "path": info[h]} for h, q in new]})
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with gzip.GzipFile(os.path.join(HERE, "merger_kat.json.gz"), "wb", mtime=0) as gzf:
+        gzf.write(json.dumps(out, sort_keys=True).encode())
+    print("merger_kat:", len(out), "contig sets,", sum(len(o["new"]) for o in out), "merged contigs,", sum(1 for o in out if not o["new"]), "sets without")
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
@@ -605,6 +677,7 @@ def main():
     quickcheck_kat()
     evaluate_kat()
     pick_kat()
+    merger_kat()
     for name, seed in (("twolib", 20260001), ("edge", 20260011), ("bounds", 20260031), ("c1", 20260001)):
         case = make_case(name, seed)
         d = os.path.join(HERE, name)

@@ -197,3 +197,104 @@ def test_merge_edges_file_lists_the_graph_edges(gf, tmp_path):
                                                  "NODE_%d_length_%d_cov_9.0" % (j // 2 + 1, len(sets[gid][j // 2])), "-" if j & 1 else "+", mode, ov)
         n_edges += len(exp)
     assert n_edges >= 4                                     # the tiling's overlaps in both orientations
+
+
+def test_merge_contigs_on_the_device_equals_the_reference_binary(gf, tmp_path):
+    """MergeContigs.merge_contigs with the GPU prefilter + overlap evaluation (strict and relaxed mode) on the contig sets the
+    reference's own ContigsMerger answered (tests/golden/merger_kat.json.gz): the NEW_CONTIG_MERGE sequences and merge.info paths of
+    every set without contained contigs equal the reference's; all sets equal the oracle on the de-duplicated set."""
+    import gzip
+    import json
+    from golden_util import GOLDEN
+    from gappadder_amd import MergeContigs as MC
+    from oracle import gp_oracle as O
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "merger_kat.json.gz")).read())
+    wf = str(tmp_path) + "/"
+    ids = []
+    for ci, c in enumerate(cases):
+        gid = "3_%d" % (ci + 1)
+        ids.append(gid)
+        os.makedirs(wf + "velvet_temp/" + gid)
+        with open(wf + "velvet_temp/%s/contigs.fa" % gid, "w") as f:
+            f.write("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(c["contigs"])))
+    done = MC.merge_contigs(gf, wf, ids)
+    n_direct = n_new = 0
+    for gid, c in zip(ids, cases):
+        d = wf + "velvet_temp/%s/" % gid
+        nodup = MC.drop_contained([("c%d" % i, s) for i, s in enumerate(c["contigs"])])
+        new = [s for n, s in MC.read_fasta(d + "contigs.fa_no_dup.fa.merged.fa") if n.startswith("NEW_CONTIG_MERGE_")]
+        assert new == [s for _, s in O.merger_new_contigs([s for _, s in nodup], CO.GAPPADDER_OVL)] and done[gid] == len(new), gid
+        if len(nodup) == len(c["contigs"]):
+            assert new == [x["seq"] for x in c["new"]], gid
+            assert [l.split()[1:] for l in open(d + "contigs.fa_no_dup.fa.merge.info").read().splitlines()] == [x["path"] for x in c["new"]], gid
+            n_direct += 1
+        n_new += len(new)
+    assert n_direct >= 30 and n_new >= 40
+
+
+def _one_gap_folder(root, left, right, reads, hq_reads=None):
+    """A working folder with one gap '0_1': flank FASTA, read pool (and high-quality pool), .fai + gap_positions for prepare_list."""
+    wf = root + "/wf/"
+    for sub in ("merged/gap_reads", "merged/gap_reads_high_quality", "merged/velvet_temp", "flank_regions"):
+        os.makedirs(wf + sub)
+    open(wf + "flank_regions/0_1.fa", "w").write(">0_1_left\n%s\n>0_1_right\n%s\n" % (left, right))
+    open(wf + "merged/gap_reads/0_1.fastq", "w").write("".join("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in enumerate(reads)))
+    if hq_reads is not None:
+        open(wf + "merged/gap_reads_high_quality/0_1.fastq", "w").write("".join("@h%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in enumerate(hq_reads)))
+    open(root + "/d.fai", "w").write("scf0\t100000\t6\t60\t61\n")
+    open(wf + "gap_positions.txt", "w").write("5000 5600 600 scf0\n")
+    return wf
+
+
+def _tile(g, L=100, step=5):
+    rc = lambda x: x[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    out = []
+    for s in list(range(0, len(g) - L + 1, step)) + [len(g) - L]:
+        out += [g[s:s + L], rc(g[s:s + L])]
+    return out
+
+
+def test_a_gap_that_only_the_contig_merging_closes(gf, tmp_path):
+    """assemble_pipeline (assemble_gaps.py:328-368): the reads hold a long dead-end branch inside the gap (80 bases seen by several
+    reads: not a tip), so the assembly stops at the junction — no contig carries both anchors; ContigsMerger's path search chains
+    the unitigs across it (they overlap by kv - 1 bases) and the merged contig closes the gap with the true sequence."""
+    from gappadder_amd import assemble_gaps as AG
+    rng = np.random.default_rng(77)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.integers(0, 4, n)].tobytes().decode()
+    g = rnd(1400)                                          # left flank 100..395, gap 400..1000, right flank 1005..1300
+    left, right = g[100:395], g[1005:1300]
+    branch = g[560:680] + rnd(80)                          # follows the genome to 680, then leaves it for 80 bases
+    reads = _tile(g[60:1340]) + _tile(branch, step=4)
+    wf = _one_gap_folder(str(tmp_path), left, right, reads)
+    ga = AG.GapAssembler(str(tmp_path) + "/d.fai", wf + "gap_positions.txt", 1, wf + "merged/", kmer_list=[(31, 29)], gf=gf)
+    # without merging: open
+    ga.assembly(["0_1"])
+    from gappadder_amd.pick_contigs import ContigsSelection, read_fasta
+    assert ContigsSelection(wf + "merged/").pick_full_constructed_contigs(30, ["0_1"], wf + "tmp_picked.fa") == 0
+    n_before = len(read_fasta(wf + "merged/velvet_temp/0_1/contigs.fa"))
+    res = ga.assemble_pipeline()
+    assert res["closed"] == 1 and res["gaps_with_merged_contigs"] >= 1 and n_before >= 3
+    picked = open(wf + "picked_seqs.fa").read().split("\n")
+    assert picked[0].startswith(">0_1_NEW_CONTIG_MERGE_") and picked[1] in (g[395:1006], g[394:1005])
+    assert os.path.exists(wf + "merged/velvet_temp/0_1/original_contigs_before_merging.fa")
+
+
+def test_a_gap_that_only_the_bridging_high_quality_reads_close(gf, tmp_path):
+    """The rescue round (assemble_gaps.py:357-361): the pool misses a stretch inside the gap, so two contigs end 40 bases apart with
+    nothing to overlap; a high-quality read that spans the hole aligns clipped to both, is appended to the contigs, and the next
+    merge chains left contig -> read -> right contig: the gap is closed at the last pick."""
+    from gappadder_amd import assemble_gaps as AG
+    rng = np.random.default_rng(78)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.integers(0, 4, n)].tobytes().decode()
+    g = rnd(1400)
+    left, right = g[100:395], g[1005:1300]
+    reads = _tile(g[60:700]) + _tile(g[740:1340])          # nothing covers 700..740 with a whole k-mer
+    hq = [g[640:790], g[200:350], rnd(150)]                # one read across the hole, one inside a contig, one stranger
+    wf = _one_gap_folder(str(tmp_path), left, right, reads, hq)
+    ga = AG.GapAssembler(str(tmp_path) + "/d.fai", wf + "gap_positions.txt", 1, wf + "merged/", kmer_list=[(31, 29)], gf=gf)
+    res = ga.assemble_pipeline()
+    assert res["bridging_reads"] == 1 and res["closed"] == 1, res
+    picked = open(wf + "picked_seqs.fa").read().split("\n")
+    assert picked[1] in (g[395:1006], g[394:1005])

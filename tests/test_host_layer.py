@@ -246,3 +246,118 @@ def test_truth_check_of_closed_gaps_catches_wrong_fills():
     r = bench.truth_check(cfg, gaps, flanks, ctg, "".join(contigs).encode(), np.array(words, dtype=np.uint64), GapFill)
     assert r["closed"] == 5 and r["correct"] == 2 and sorted(w["gap"] for w in r["wrong"]) == [1, 2, 4]
     assert r["causes"] == {"substitutions": 2, "length -1": 1}
+
+
+# ---- contig merging, host side (MergeContigs.py; GraphUtils.cpp:625-859, ContigsCompactor.cpp:1422-1520) ----
+
+class _OracleEvaluator:
+    """Stand-in for the two GPU calls of MergeContigs on a box without a GPU: the oracle's prefilter and overlap evaluation."""
+    def quick_check(self, sets, k=10):
+        from gappadder_amd import _lib as B
+        from oracle import c_oracle as CO
+        rows = [(s, i, j) for s, cs in enumerate(sets) for i, j in CO.quick_check(cs, k)]
+        out = np.zeros(len(rows), dtype=B.QCPAIR)
+        for x, r in enumerate(rows):
+            out[x] = r
+        return out
+
+    def overlap_evaluate(self, sets, pairs, params=None, relax=False):
+        from gappadder_amd import _lib as B
+        from oracle import c_oracle as CO
+        out = np.zeros(len(pairs), dtype=B.OVL_RESULT)
+        for x, p in enumerate(pairs):
+            nodes = CO.merger_nodes(sets[int(p["set"])])
+            r = CO.overlap_evaluate(nodes[int(p["i"])], nodes[int(p["j"])], params or CO.GAPPADDER_OVL, relax=relax)
+            out[x] = tuple(r[n] for n in B.OVL_RESULT.names)
+        return out
+
+
+import numpy as np  # noqa: E402
+
+
+def test_path_search_and_merged_strings_equal_the_reference(tmp_path):
+    """MergeContigs.find_paths / merged_strings / merge_contigs (host logic; the GPU calls replaced by the oracle's evaluation) on
+    the contig sets the reference's own ContigsMerger answered (tests/golden/merger_kat.json.gz): same paths, same merged contigs,
+    same merge.info, and the file protocol of MergeContigs.py:66-99."""
+    import gzip
+    import json
+    from golden_util import GOLDEN
+    from gappadder_amd import MergeContigs as MC
+    from oracle import c_oracle as CO, gp_oracle as O
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "merger_kat.json.gz")).read())
+    wf = str(tmp_path) + "/"
+    ids = []
+    for ci, c in enumerate(cases):
+        _, adj = O.merger_edges(c["contigs"], CO.GAPPADDER_OVL)
+        assert MC.find_paths(adj) == O.merger_paths(adj), ci
+        gid = "0_%d" % (ci + 1)
+        ids.append(gid)
+        os.makedirs(wf + "velvet_temp/" + gid)
+        with open(wf + "velvet_temp/%s/contigs.fa" % gid, "w") as f:
+            f.write("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(c["contigs"])))
+    done = MC.merge_contigs(_OracleEvaluator(), wf, ids + ["missing"])
+    assert set(done) == set(ids)
+    n_direct = n_shrunk = 0
+    for ci, (gid, c) in enumerate(zip(ids, cases)):
+        d = wf + "velvet_temp/%s/" % gid
+        nodup = MC.drop_contained([("c%d" % i, s) for i, s in enumerate(c["contigs"])])
+        exp = O.merger_new_contigs([s for _, s in nodup], CO.GAPPADDER_OVL)
+        merged = MC.read_fasta(d + "contigs.fa_no_dup.fa.merged.fa")
+        new = [s for n, s in merged if n.startswith("NEW_CONTIG_MERGE_")]
+        assert new == [s for _, s in exp] and done[gid] == len(exp), ci
+        assert [(n, s) for n, s in merged if not n.startswith("NEW_")] == nodup
+        if len(nodup) == len(c["contigs"]):          # nothing contained: the reference binary saw the same set
+            assert new == [x["seq"] for x in c["new"]], ci
+            info = [l.split()[1:] for l in open(d + "contigs.fa_no_dup.fa.merge.info").read().splitlines()]
+            assert info == [x["path"] for x in c["new"]], ci
+            n_direct += 1
+        assert MC.read_fasta(d + "original_contigs_before_merging.fa") == [("c%d" % i, s) for i, s in enumerate(c["contigs"])]
+        final = MC.read_fasta(d + "contigs.fa")
+        assert final == MC.drop_contained(merged)
+        n_shrunk += len(final) < len(merged)         # the exact pieces of a merged contig lie inside it: they are gone
+    assert n_direct >= 30 and n_shrunk >= 20
+
+
+def test_exact_dedup_and_the_merge_size_guard(tmp_path):
+    from gappadder_amd import MergeContigs as MC
+    from gappadder_amd.pick_contigs import revcomp
+    rng = np.random.default_rng(8)
+    a, b = _rnd(rng, 300), _rnd(rng, 200)
+    recs = [("a", a), ("inside", a[50:150]), ("b", b), ("a_again", a), ("b_rc", revcomp(b)), ("inside_rc", revcomp(a[100:260])), ("c", _rnd(rng, 90))]
+    assert [n for n, _ in MC.drop_contained(recs)] == ["a", "b", "c"]          # of identical contigs the first stays
+    # a de-duplicated file above 1 MB is not merged (MergeContigs.py:70-74): it becomes contigs.fa as it is
+    wf = str(tmp_path) + "/"
+    os.makedirs(wf + "velvet_temp/0_1")
+    big = [("n%d" % i, _rnd(rng, 8000)) for i in range(130)]
+    with open(wf + "velvet_temp/0_1/contigs.fa", "w") as f:
+        f.write("".join(">%s\n%s\n" % r for r in big + [("dup", big[0][1][:500])]))
+
+    class NoGpu:
+        def __getattr__(self, name):
+            raise AssertionError("GPU touched")
+    assert MC.merge_contigs(NoGpu(), wf, ["0_1"]) == {"0_1": 0}
+    assert MC.read_fasta(wf + "velvet_temp/0_1/contigs.fa") == big
+    assert len(MC.read_fasta(wf + "velvet_temp/0_1/original_contigs_before_merging.fa")) == 131
+
+
+def test_high_quality_reads_that_bridge_two_contigs_are_appended(tmp_path):
+    """collect_high_quality_unmap_to_contigs_reads (assemble_gaps.py:166-217 with exact matching for bwa): the assembly's own
+    contigs come back and the reads clipped at two contigs follow them as FASTA records."""
+    from gappadder_amd import assemble_gaps as AG
+    from gappadder_amd.pick_contigs import read_fasta, revcomp
+    rng = np.random.default_rng(9)
+    g = _rnd(rng, 1000)
+    c1, c2, c3 = g[0:400], g[440:800], _rnd(rng, 300)
+    wf = str(tmp_path) + "/"
+    os.makedirs(wf + "velvet_temp/0_1")
+    os.makedirs(wf + "gap_reads_high_quality")
+    open(wf + "velvet_temp/0_1/contigs.fa", "w").write(">merged_1\n%s\n>merged_2\n%s\n" % (c1, c2))
+    open(wf + "velvet_temp/0_1/original_contigs_before_merging.fa", "w").write(">o1\n%s\n>o2\n%s\n>o3\n%s\n" % (c1, c2, c3))
+    reads = [("bridge", g[350:500]), ("inside", g[100:250]), ("one_side", g[380:430] + _rnd(rng, 100)), ("bridge_rc", revcomp(g[360:510])),
+             ("bridge", g[0:150]), ("short_overlap", g[390:400] + _rnd(rng, 140))]
+    open(wf + "gap_reads_high_quality/0_1.fastq", "w").write("".join("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)) for n, s in reads))
+    ga = AG.GapAssembler("x.fai", "x.pos", 1, wf, kmer_list=[(31, 29)], gf=object())
+    assert ga.collect_high_quality_unmap_to_contigs_reads(["0_1", "0_2"]) == 2
+    got = read_fasta(wf + "velvet_temp/0_1/contigs.fa")
+    assert got == [("o1", c1), ("o2", c2), ("o3", c3), ("bridge", g[350:500]), ("bridge_rc", revcomp(g[360:510]))]
+    assert not os.path.exists(wf + "velvet_temp/0_1/original_contigs_before_merging.fa")

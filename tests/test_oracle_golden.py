@@ -171,3 +171,21 @@ def test_picker_ledger_is_the_concatenation_of_the_per_gap_files():
         mine = [c for c in cases if c["score"] == score]
         led = [c["ledgers_of_score"] for c in mine if c["ledgers_of_score"]][0]
         assert led[0] == "".join(c["full"][0] or "" for c in mine) and led[1] == "".join(c["full"][1] or "" for c in mine)
+
+
+# ---- f-3: ContigsMerger from the edges to the merged contigs (ContigsCompactor.cpp:773-983, GraphUtils.cpp:625-859) ----
+
+def test_merger_restatement_equals_the_reference_binary():
+    """tests/golden/merger_kat.json.gz: 41 contig sets (chains, reverse-complemented links, forks, alternative routes, containment,
+    dirty ends, a 2-cycle, random tilings with errors) and the NEW_CONTIG_MERGE records + paths the reference's own ContigsMerger
+    (built from its sources, -t 1) printed: same merged sequences, same paths, same order."""
+    import gzip
+    from oracle import c_oracle as CO
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "merger_kat.json.gz")).read())
+    n_new = 0
+    for c in cases:
+        got = O.merger_new_contigs(c["contigs"], CO.GAPPADDER_OVL)
+        mine = [{"seq": s, "path": ["c%d%s" % (v >> 1, "_R" if v & 1 else "") for v in p]} for p, s in got]
+        assert mine == c["new"]
+        n_new += len(mine)
+    assert len(cases) >= 40 and n_new >= 45
