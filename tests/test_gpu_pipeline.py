@@ -56,7 +56,7 @@ def test_assembly_stage_files(run):
     case, wf, got = run
     ids = [k[len("merged/gap_reads/"):-len(".fastq")] for k in got if k.startswith("merged/gap_reads/")]
     assert ids
-    n_ctg = 0
+    n_ctg = n_merged_sets = 0
     for gid in ids:
         seqs = [l for i, l in enumerate(got["merged/gap_reads/%s.fastq" % gid].splitlines()) if i % 4 == 1]
         L = max(len(s) for s in seqs)
@@ -67,8 +67,14 @@ def test_assembly_stage_files(run):
             assert got["merged/velvet_temp/%s/contigs_%d_%d.fa" % (gid, k, kv_cfg)] == exp, (gid, k, kv_cfg)
             merged += "".join((">%d_%d_%s" % (k, kv_cfg, l[1:]) if l.startswith(">") else l) for l in exp.splitlines(True))
             n_ctg += exp.count(">")
-        assert got["merged/velvet_temp/%s/contigs.fa" % gid] == merged
-    assert n_ctg > 0
+        # the assembly's contigs.fa is what the merge step set aside (MergeContigs.py:96-99), followed by the bridging high-quality
+        # reads of the rescue round, if any (assemble_gaps.py:211-216); contigs.fa itself is the merged set by now
+        orig = got.get("merged/velvet_temp/%s/original_contigs_before_merging.fa" % gid, got["merged/velvet_temp/%s/contigs.fa" % gid])
+        assert orig.startswith(merged), gid
+        tail = orig[len(merged):].splitlines()
+        assert len(tail) % 2 == 0 and all(l.startswith(">") for l in tail[0::2]), gid
+        n_merged_sets += "merged/velvet_temp/%s/contigs.fa_no_dup.fa.merged.fa" % gid in got
+    assert n_ctg > 0 and n_merged_sets > 0
 
 
 def test_kmc_velvet_executables_follow_the_reference_command_lines(run, tmp_path):
