@@ -2,7 +2,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "gf_internal.hpp"
 
@@ -103,6 +105,10 @@ const char* gf_strerror(int code) {
     }
 }
 
+// live contexts: gf_destroy disarms every gf_stream_wait_after_filter that still points at the context going away
+static std::mutex g_live_mu;
+static std::vector<gf_ctx*> g_live;
+
 int gf_init(int device_ordinal, gf_ctx** out) {
     if (!out) return GF_E_INVAL;
     *out = nullptr;
@@ -120,12 +126,22 @@ int gf_init(int device_ordinal, gf_ctx** out) {
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cu = prop.multiProcessorCount;
     if (const char* e = getenv("GF_BITMAP_LOG2")) ctx->bitmap_log2_override = atoi(e);
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.push_back(ctx);
+    }
     *out = ctx;
     return GF_OK;
 }
 
 void gf_destroy(gf_ctx* ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.erase(std::remove(g_live.begin(), g_live.end(), ctx), g_live.end());
+        for (gf_ctx* other : g_live)
+            if (other->after_filter == ctx) other->after_filter = nullptr;
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
@@ -207,18 +223,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "tag_bins_log2")) { ctx->tag_bins_log2 = std::max(13, std::min(19, (int)value)); ctx->bin_dist2 = -1; return GF_OK; }
     if (!strcmp(name, "tag_fine_log2")) { ctx->tag_fine_log2 = std::max(20, std::min(28, (int)value)); ctx->bin_dist2 = -1; return GF_OK; }
     if (!strcmp(name, "tag_nt")) { ctx->tag_nt = value != 0; return GF_OK; }
-    if (!strcmp(name, "asm_diag")) {
-        if (!getenv("GF_DIAGNOSTICS")) return GF_E_UNSUPPORTED;
-        ctx->asm_diag = (int)value;
-        return GF_OK;
-    }
-    if (!strcmp(name, "screen_pf4")) { ctx->screen_pf4 = value != 0; return GF_OK; }
     if (!strcmp(name, "screen_pf4_cap8")) { ctx->screen_pf4_cap8 = (int)value; return GF_OK; }
-    if (!strcmp(name, "screen_pf_diag")) {
-        if (!getenv("GF_DIAGNOSTICS")) return GF_E_UNSUPPORTED;
-        ctx->screen_pf_diag = (int)value;
-        return GF_OK;
-    }
     if (!strcmp(name, "screen_np_override")) {   // timing experiments only (fewer probes = wrong hits): refused unless asked for
         if (!getenv("GF_DIAGNOSTICS")) return GF_E_UNSUPPORTED;
         ctx->screen_np_override = (int)value;

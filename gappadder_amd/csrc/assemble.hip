@@ -56,7 +56,6 @@ struct AsmParams {
     uint32_t lds_words;        // dynamic LDS given to the staged pool
     uint32_t* next_gap;        // work counter, zero at launch
     uint32_t keyslot;          // allow the key-in-slot count phase
-    uint32_t diag;             // timing experiments (wrong results)
     uint32_t ranked;           // allow the ranked table behind the pre-count
     uint32_t precount;         // allow the bit-array pre-count (k-mers seen fewer than min_count times never enter the table)
     unsigned long long* dbg;   // diagnostic runs only: 16 wall-clock stamps per gap (100 MHz), or null
@@ -894,12 +893,10 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                     } else {
                         if (pre && !pre_pass(x)) return false;
                     }
-                    if (P.diag & 1) return false;
                     sl = lo_sl + slot_of_hash(x, n_sl);
                     bool placed = false;
                     for (uint32_t probes = 0; probes < n_sl; ++probes) {
                         unsigned long long v = tab.load(sl);
-                        if ((P.diag & 4) && (uint32_t)v != EMPTY32) { placed = true; break; }
                         if ((uint32_t)v == EMPTY32) {
                             v = tab.cas(sl, EMPTY64, mine);
                             if (v == EMPTY64) {   // first occurrence
@@ -913,9 +910,9 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                         }
                         if ((v & 0x3FFFFFFF00000000ull) == fp) {
                             const uint32_t oi = (uint32_t)v;
-                            const K128 ow = (P.diag & 2) ? fw : lds_window<true>(V.rb, oi >> INST_OFF_BITS, oi & INST_OFF_MASK, k);
+                            const K128 ow = lds_window<true>(V.rb, oi >> INST_OFF_BITS, oi & INST_OFF_MASK, k);
                             if (ow == fw || ow == rc) {   // the same canonical k-mer
-                                while ((v >> 62) != 3ull && !(P.diag & 8)) {   // saturating increment
+                                while ((v >> 62) != 3ull) {   // saturating increment
                                     const unsigned long long o = tab.cas(sl, v, v + (1ull << 62));
                                     if (o == v) break;
                                     v = o;
@@ -1557,7 +1554,6 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.keyslot = (uint32_t)ctx->asm_keyslot;
     P.precount = (uint32_t)ctx->asm_precount;
     P.ranked = (uint32_t)ctx->asm_ranked;
-    P.diag = (uint32_t)ctx->asm_diag;
     const uint32_t rb = (uint32_t)((read_len + 3) / 4);
     P.reads32 = (const uint32_t*)d_pool;
     P.n_words = ((uint64_t)total_reads * rb) / 4;

@@ -81,15 +81,13 @@ struct gf_ctx {
     uint32_t max_gaps_per_kmer = 0;     // 0 = unlimited
     int bitmap_log2_override = 0;
     int index_host = 0;         // 1: build the flank index on the host (comparator of the device builder)
-    int screen_variant = 0;     // filter kernel: 0 automatic, 9 plain, 12 wave, 13 pipelined (ablation)
+    int screen_variant = 0;     // filter kernel: 0 automatic; 9 plain, 13 pipelined, 14 16-bucket partitioned, 16 256-bucket partitioned (tests run each)
     int screen_verify_batch = 64;  // verify kernel: candidates per wave and pass
     int screen_verify_ext = 1;   // min_hits == 1 without repeat mask: seed-and-extend verification instead of the k-mer table
     int screen_verify_gate = 1;  // verify kernel: consult the k-mer table only around exact 16-mer hits
     int screen_stream_policy = 1;  // pipelined filter: read stream loaded non-temporal (nt): keeps the L2 for the bitmap, -8 % fabric fetches
     int screen_np_override = -1;
     int screen_pf4_cap8 = 0;     // tests: capacity of the 4-byte filter's pair list (0: sized from the reads)
-    int screen_pf4 = 1;          // 256-bucket filter: 4-byte pairs (0: the 8-byte form, pf2_*)
-    int screen_pf_diag = 0;      // partitioned filter timing experiments (wrong results; refused unless GF_DIAGNOSTICS)
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)
     int tag_light = 0;           // alignment tagger: one-wave workgroups, bin map through L1/L2 (runs beside the k-mer filter)
     int asm_lds_pool_kb = 152;
@@ -97,7 +95,6 @@ struct gf_ctx {
     int asm_simplify = 2;        // rounds of tip clipping + bubble popping in the assembly (Velvet's defaults are on; 0: raw unitigs)
     long asm_max_pool_reads = 0; // > 0: no pool has more rows than this (the assembly workspace is then one slice per workgroup, not per row)
     int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
-    int asm_diag = 0;            // assembly timing experiments (wrong results; refused unless GF_DIAGNOSTICS)
     int asm_ranked = 1;          // count phase: ranked (perfect-hash) table behind the pre-count (k > 32, LDS)
     int asm_precount = 1;        // count phase: bit-array pre-count in LDS when min_count is 2 or 3 (0: every window goes to the table)
     void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)

@@ -312,8 +312,8 @@ int gf_quick_check_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off,
     int rc;
     if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
     uint32_t* d_next = (uint32_t*)ctx->counters.p + 9;
-    uint32_t* d_err = (uint32_t*)ctx->counters.p + 10;
-    zero_regions(ctx, ZeroList{{(uint32_t*)d_n_out, d_next, nullptr, nullptr}, {1, 2, 0, 0}});
+    uint32_t* d_err = (uint32_t*)d_n_out + 1;   // the caller's second word: skipped sets (bit 0: a contig shorter than 30 bases, bit 1: more contigs than max_set_contigs)
+    zero_regions(ctx, ZeroList{{(uint32_t*)d_n_out, d_next, nullptr, nullptr}, {2, 1, 0, 0}});
     if (!n_sets) return GF_OK;
     QcParams P;
     P.seq = (const char*)d_seq;
@@ -369,9 +369,14 @@ int gf_quick_check(gf_ctx* ctx, const char* seq, const uint64_t* contig_off, con
     GF_HIP(ctx, hipMemcpyAsync(d_co, contig_off, (n_contigs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     GF_HIP(ctx, hipMemcpyAsync(d_so, set_off, (n_sets + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = gf_quick_check_dev(ctx, d_seq, d_co, d_so, n_sets, max_set, k, ctx->stage_out.p, cap, d_cnt))) return rc;
-    uint32_t n = 0;
-    GF_HIP(ctx, hipMemcpyAsync(&n, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t nn[2] = {0, 0};
+    GF_HIP(ctx, hipMemcpyAsync(nn, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t n = nn[0];
+    if (nn[1]) {   // (cannot happen after the checks above; a device-side caller reads the same word)
+        ctx->last_error = "gf_quick_check: contig sets were skipped (flags " + std::to_string(nn[1]) + ")";
+        return GF_E_INVAL;
+    }
     *n_out = n;
     if (n > cap) return GF_E_NOSPACE;
     if (n) GF_HIP(ctx, hipMemcpy(out, ctx->stage_out.p, n * sizeof(gf_qcpair), hipMemcpyDeviceToHost));

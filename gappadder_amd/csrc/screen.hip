@@ -148,190 +148,16 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
     }
 }
 
-// Wave-autonomous variant of the LDS pre-filter kernel: every wavefront streams its own 64-read mini-tiles through a
-// private LDS slice (no workgroup barrier in the loop, so one wave waiting on an L2 chain never stalls the other eleven),
-// prefetches its next mini-tile into registers, and appends candidates through a private LDS buffer.
-constexpr uint32_t WOBUF = 96;   // candidates buffered per wave; flushed with one global atomic when >= 32
+constexpr uint32_t WOBUF = 96;   // candidates buffered per wave (LDS); flushed with one global atomic when >= 32
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // LDS ops of one wave execute in order: only the compiler must not reorder
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int NCH>
-__global__ __launch_bounds__(1024) void screen_filter_wave_kernel(FilterParams P, uint32_t slice_words) {
-    extern __shared__ uint32_t sm[];  // [coarse bitmap][per wave: 64 reads + pad | WOBUF candidate ids]
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthr = blockDim.x, nw = nthr >> 6;
-    const uint32_t bm_words = 1u << (P.lds_log2 - 5);
-    for (uint32_t i = tid * 4; i < bm_words; i += nthr * 4)
-        *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap_lds + i);
-    uint32_t* tile = sm + bm_words + w * (slice_words + WOBUF);
-    uint32_t* obuf = tile + slice_words;
-    uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
-    uint32_t obuf_n = 0;   // wave-uniform
-    const uint32_t tile_bytes = 64 * P.rb;
-    const uint64_t total_bytes = P.n_reads * P.rb;
-    const uint64_t n_tiles = (P.n_reads + 63) / 64;
-    const uint32_t smask = (1u << P.s_log2) - 1;
-    const uint32_t coarse_shift = P.bm_log2 - P.lds_log2;
-    const bool same = coarse_shift == 0;
-    const bool bytes_ok = (P.stride2 & 7) == 0;   // probes start on byte boundaries (k = 31, 35, 39, ...)
-    constexpr int NPF = NCH > 0 ? NCH : 1;
-    // three mini-tiles in flight per wave: with ~11 waves per CU a single outstanding 2.4-KB fetch per wave leaves the
-    // kernel bound by memory latency x concurrency, not by bandwidth
-    uint4 pfA[NPF], pfB[NPF], pfC[NPF];
-    auto prefetch = [&](uint4 (&pf)[NPF], uint64_t t) {
-        if (NCH == 0 || t >= n_tiles) return;
-        const uint64_t byte0 = t * tile_bytes;
-        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
-        const uint32_t n16 = nbytes >> 4;
-#pragma unroll
-        for (int c = 0; c < NPF; ++c) {
-            const uint32_t i = lane + c * 64;
-            pf[c] = i < n16 ? *reinterpret_cast<const uint4*>(P.reads + byte0 + (uint64_t)i * 16) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    const uint64_t t0 = (uint64_t)blockIdx.x * nw + w, tstride = (uint64_t)gridDim.x * nw;
-    prefetch(pfA, t0);
-    prefetch(pfB, t0 + tstride);
-    prefetch(pfC, t0 + 2 * tstride);
-    __syncthreads();   // coarse bitmap staged
-
-    auto process = [&](uint4 (&pf)[NPF], uint64_t t) {
-        const uint64_t byte0 = t * tile_bytes;
-        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
-        const uint32_t n16 = nbytes & ~15u;
-        const uint8_t* src = P.reads + byte0;
-        if (NCH > 0) {
-#pragma unroll
-            for (int c = 0; c < NPF; ++c) {
-                const uint32_t i = lane + c * 64;
-                if (i < (n16 >> 4)) *reinterpret_cast<uint4*>(tb + (uint64_t)i * 16) = pf[c];
-            }
-        } else {
-            for (uint32_t i = lane * 16; i < n16; i += 64 * 16)
-                *reinterpret_cast<uint4*>(tb + i) = *reinterpret_cast<const uint4*>(src + i);
-        }
-        for (uint32_t i = n16 + lane; i < nbytes; i += 64) tb[i] = src[i];
-        if (lane < 16) tb[nbytes + lane] = 0;
-        wave_lds_sync();
-        prefetch(pf, t + 3 * tstride);
-
-        const uint64_t r = t * 64 + lane;
-        bool cand = false;
-        if (r < P.n_reads) {
-            const uint32_t bit0 = lane * P.rb * 8;
-            for (uint32_t g0 = 0; g0 < P.np && !cand; g0 += 32) {
-                const uint32_t g1 = g0 + 32 < P.np ? g0 + 32 : P.np;
-                uint32_t m1 = 0;   // probes that pass the LDS bitmap; three probes' LDS reads in flight at a time
-                for (uint32_t j0 = g0; j0 < g1; j0 += 3) {
-                    uint32_t w32[3], c[3], bw[3];
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        const uint32_t j = j0 + u < g1 ? j0 + u : g1 - 1;
-                        w32[u] = bytes_ok ? stream32_bytes(tile, (bit0 + j * P.stride2) >> 3) : stream32(tile, bit0 + j * P.stride2);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        c[u] = hash_s16_bitmap(canon16(w32[u]), P.bm_log2) >> coarse_shift;
-                        bw[u] = sm[c[u] >> 5];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 3; ++u)
-                        if (j0 + u < g1) m1 |= ((bw[u] >> (c[u] & 31)) & 1u) << (j0 + u - g0);
-                }
-                uint32_t mask = m1;
-                if (!same && m1) {
-                    mask = 0;
-                    uint32_t m = m1;
-                    while (m) {   // up to 5 L2 probes in flight
-                        uint32_t jj[5], word[5], hb[5];
-#pragma unroll
-                        for (int u = 0; u < 5; ++u) {
-                            word[u] = 0; hb[u] = 0; jj[u] = 0;
-                            if (m) {
-                                jj[u] = __ffs(m) - 1;
-                                m &= m - 1;
-                                const uint32_t key = canon16(stream32(tile, bit0 + (g0 + jj[u]) * P.stride2));
-                                const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
-                                hb[u] = (h & 31) | (hash_s16_bit2(key) << 8);   // both bits of the key in its word
-                                word[u] = P.bitmap[h >> 5];
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 5; ++u) mask |= ((word[u] >> (hb[u] & 31)) & (word[u] >> (hb[u] >> 8)) & 1u) << jj[u];
-                    }
-                }
-                while (mask && !cand) {   // level 2: exact canonical-16-mer set, up to 3 lookups in flight
-                    uint32_t key[3], sl[3], v[3];
-                    bool on[3];
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        on[u] = mask != 0;
-                        key[u] = 0; sl[u] = 0; v[u] = EMPTY32;
-                        if (on[u]) {
-                            const uint32_t j = g0 + __ffs(mask) - 1;
-                            mask &= mask - 1;
-                            key[u] = canon16(stream32(tile, bit0 + j * P.stride2));
-                            sl[u] = hash_s16_set(key[u], P.s_log2);
-                            v[u] = P.sset[sl[u]];
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        while (on[u] && v[u] != EMPTY32) {   // rare: walk the collision chain
-                            if (v[u] == key[u]) { cand = true; break; }
-                            sl[u] = (sl[u] + 1) & smask;
-                            v[u] = P.sset[sl[u]];
-                        }
-                    }
-                }
-            }
-        }
-        const unsigned long long bal = __ballot(cand);
-        if (bal) {
-            const uint32_t cnt = (uint32_t)__popcll(bal);
-            if (obuf_n + cnt > WOBUF) {   // cannot happen with the >= 32 flush below and cnt <= 64, kept for safety
-                uint32_t gb = 0;
-                if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
-                gb = __shfl(gb, 0);
-                for (uint32_t i = lane; i < obuf_n; i += 64) P.cand[gb + i] = obuf[i];
-                obuf_n = 0;
-                wave_lds_sync();
-            }
-            if (cand) obuf[obuf_n + __popcll(bal & ((1ull << lane) - 1))] = (uint32_t)r;
-            obuf_n += cnt;
-            wave_lds_sync();
-            if (obuf_n >= 32) {
-                uint32_t gb = 0;
-                if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
-                gb = __shfl(gb, 0);
-                for (uint32_t i = lane; i < obuf_n; i += 64) P.cand[gb + i] = obuf[i];
-                obuf_n = 0;
-            }
-        }
-        wave_lds_sync();   // all lanes are done with the slice before it is overwritten
-    };
-    for (uint64_t t = t0; t < n_tiles;) {
-        process(pfA, t);
-        t += tstride;
-        if (t >= n_tiles) break;
-        process(pfB, t);
-        t += tstride;
-        if (t >= n_tiles) break;
-        process(pfC, t);
-        t += tstride;
-    }
-    if (obuf_n) {
-        uint32_t gb = 0;
-        if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
-        gb = __shfl(gb, 0);
-        for (uint32_t i = lane; i < obuf_n; i += 64) P.cand[gb + i] = obuf[i];
-    }
-}
 
 // ---- software-pipelined wave kernel ---------------------------------------------------------------------------------
-// The two-loop wave kernel above pays two dependent L2 round trips per 64-read tile (level-1 bitmap word, then the exact
+// A wave that streams its tiles and probes them on the spot pays two dependent L2 round trips per 64-read tile (level-1 bitmap word, then the exact
 // set), ~2.5 us a tile and wave whatever the probe count; with 11 waves per CU that chain, not bandwidth, set its floor
 // (measured: 0.31 ms with no probes, 0.73 ms with one).  Here each wave keeps THREE tiles in flight in registers:
 //   stage A (tile t)    stage the tile in LDS, scramble its NP 16-mers, test the coarse LDS bitmap, ISSUE the level-1 loads
@@ -382,7 +208,6 @@ struct PartParams {
     unsigned long long* pairs;  // [bucket][writer][cap]: {read (high 32), scrambled key (low 32)}
     uint32_t* count;            // [bucket][writer]
     uint32_t* seen;             // one bit per read
-    uint32_t diag;              // timing experiments (GF_DIAGNOSTICS builds of a run only; results WRONG): 1 = no level-1 probe, 2 = no LDS pre-test, 4 = no pair loads
 };
 constexpr uint32_t PF_ROW = 128;   // pairs per LDS row: a row is flushed at 64, one probe adds at most 64
 
@@ -550,13 +375,11 @@ __global__ __launch_bounds__(1024) void pf_probe_kernel(PartParams Q) {
                 for (int u = 0; u < PB; ++u) {
                     const uint32_t pk = (uint32_t)pr[u];
                     live[u] = i0 + u * 64 + lane < n;
-                    if (mid && live[u] && !(Q.diag & 2)) {
+                    if (mid && live[u]) {
                         const uint32_t c = (pk >> sh_mid) & ((mid_words << 5) - 1);
                         live[u] = (sm[c >> 5] >> (c & 31)) & 1u;
                     }
-                    if (Q.diag & 8) wd[u] = live[u] ? __hip_atomic_fetch_or(const_cast<uint32_t*>(P.bitmap) + ((pk >> sh_bm) >> 5), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                    else
-                    wd[u] = (live[u] && !(Q.diag & 1)) ? P.bitmap[(pk >> sh_bm) >> 5] : 0u;
+                    wd[u] = live[u] ? P.bitmap[(pk >> sh_bm) >> 5] : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < PB; ++u) {
@@ -640,262 +463,9 @@ static_assert(PF2_WAVES > PF2_NB / 64, "waves 1..4 keep the parts' fill while wa
 // write the other buffer out (stores off every producer's path) took the same 2.377 ms, `nt` stores 2.82 ms, `sc1` stores 2.26 ms:
 // the mix of a 4.3-GB read stream and 65 536 scattered 256-B write runs is what the memory system delivers at this rate.
 
-__global__ __launch_bounds__(64 * PF2_WAVES) void pf2_scatter_kernel(PartParams Q, uint32_t slice_words) {
-    extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][sorted pairs: PF2_BATCH x 8 B][hist 3 x 256][offs 257 (+1)][written 2 x 256]
-    const FilterParams& P = Q.F;
-    constexpr uint32_t NT = 64 * PF2_WAVES;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint32_t* tiles = sm + wv * PF2_TILES * slice_words;
-    unsigned long long* sorted = reinterpret_cast<unsigned long long*>(sm + PF2_WAVES * PF2_TILES * slice_words);
-    // three histograms in rotation (the one of the group after next is zeroed during a copy-out) and two `written` arrays used
-    // alternately: a group costs three barriers (count | scan | place), the copy-out runs into the next group's counting
-    uint32_t* hist3 = reinterpret_cast<uint32_t*>(sorted + PF2_BATCH);
-    uint32_t* offs = hist3 + 3 * PF2_NB;
-    uint32_t* written2 = offs + PF2_NB + 2;
-    const uint32_t writer = blockIdx.x;
-    const uint32_t tile_bytes = 64 * P.rb;
-    const uint64_t total_bytes = P.n_reads * P.rb;
-    const uint64_t n_tiles = (P.n_reads + 63) / 64;
-    const unsigned long long lt = (1ull << lane) - 1;
-    auto part = [&](uint32_t b) { return Q.pairs + ((size_t)b * Q.n_writers + writer) * Q.cap; };
-    unsigned long long* dummy = Q.pairs + (size_t)PF2_NB * Q.n_writers * Q.cap;   // 64 x 8 bytes behind the parts
-    for (uint32_t i = tid; i < PF2_NB; i += NT) { written2[i] = 0; hist3[i] = 0; hist3[PF2_NB + i] = 0; hist3[2 * PF2_NB + i] = 0; }
-    // The tile loads and the copy-out stores go through inline asm with counted waits: stores share vmcnt with loads on gfx9, and
-    // the compiler, unable to count the stores of a loop, drains them all (vmcnt(0)) before it touches the prefetched tile — the
-    // stores of a group then never overlap the next group's counting (measured: 2.35 ms with, 1.34 ms without the stores).
-    // Every wave issues exactly NPF * PF2_TILES loads per prefetch and one store per copy-out trip (idle lanes and idle
-    // tiles use a dummy address), so "the loads are done" = "at most <stores issued since> operations outstanding".
-    constexpr int NPF = 4;   // 64 reads x <= 64 B
-    u32x4 pf[PF2_TILES][NPF];
-    auto prefetch = [&](uint64_t t0) {
-#pragma unroll
-        for (uint32_t q = 0; q < PF2_TILES; ++q) {
-            const uint64_t t = t0 + q;
-            const bool on = t < n_tiles;
-            const uint64_t byte0 = on ? t * tile_bytes : 0;
-            const uint32_t nbytes = on ? (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes) : 0u;
-            const void* base = uniform_ptr(nbytes >= 16 ? (const void*)(P.reads + byte0) : (const void*)Q.count);   // (idle: 16 bytes of the workspace)
-#pragma unroll
-            for (int c = 0; c < NPF; ++c) {
-                const uint32_t i = lane + c * 64;
-                if (Q.diag & 32) {   // timing experiment: no tile loads, pseudo-random bases instead
-                    const uint32_t z = ((uint32_t)t * 0x9E3779B1u) ^ (i * 0x85EBCA77u);
-                    pf[q][c] = u32x4{z * 0xC2B2AE3Du, z * 0x27D4EB2Fu, z * 0x165667B1u, (z >> 7) * 0x9E3779B1u};
-                } else
-                vm_load128(pf[q][c], i < (nbytes >> 4) ? i * 16 : 0u, base);   // (nt: 2.32 against 2.25 ms)
-            }
-        }
-    };
-    const uint64_t t_step = (uint64_t)gridDim.x * PF2_WAVES * PF2_TILES;
-    const uint64_t n_iter = (n_tiles + t_step - 1) / t_step;
-    prefetch(((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES);
-    uint32_t hsel = 0, wsel = 0;
-    uint32_t stores_since = 0;   // copy-out stores this wave has issued since its last prefetch (wave-uniform)
-    __syncthreads();
-    for (uint64_t it = 0; it < n_iter; ++it) {
-        const uint64_t t0 = it * t_step + ((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES;
-        // this tile's loads were issued before the previous iteration's copy-out stores: those may stay in flight
-        switch (stores_since < 12u ? stores_since : 12u) {
-            case 0: vm_wait<0>(); break;   case 1: vm_wait<1>(); break;   case 2: vm_wait<2>(); break;   case 3: vm_wait<3>(); break;
-            case 4: vm_wait<4>(); break;   case 5: vm_wait<5>(); break;   case 6: vm_wait<6>(); break;   case 7: vm_wait<7>(); break;
-            case 8: vm_wait<8>(); break;   case 9: vm_wait<9>(); break;   case 10: vm_wait<10>(); break; case 11: vm_wait<11>(); break;
-            default: vm_wait<12>(); break;
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < PF2_TILES; ++q)
-#pragma unroll
-            for (int c = 0; c < NPF; ++c) vm_ready(pf[q][c]);
-        stores_since = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < PF2_TILES; ++q) {
-            const uint64_t t = t0 + q;
-            if (t >= n_tiles) continue;
-            uint8_t* tb = reinterpret_cast<uint8_t*>(tiles + q * slice_words);
-            const uint64_t byte0 = t * tile_bytes;
-            const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
-            const uint32_t n16 = nbytes & ~15u;
-#pragma unroll
-            for (int c = 0; c < NPF; ++c) {
-                const uint32_t i = lane + c * 64;
-                if (i < (n16 >> 4)) *reinterpret_cast<u32x4*>(tb + (uint64_t)i * 16) = pf[q][c];
-            }
-            for (uint32_t i = n16 + lane; i < nbytes; i += 64) tb[i] = P.reads[byte0 + i];
-            if (lane < 16) tb[nbytes + lane] = 0;
-        }
-        wave_lds_sync();
-        prefetch(t0 + t_step);
-        const uint32_t bit0 = lane * P.rb * 8;
-        for (uint32_t j0 = 0; j0 < P.np; j0 += PF2_GROUP) {
-            uint32_t* hist = hist3 + hsel * PF2_NB;        // all zero (start / zeroed during the copy-out before last)
-            const uint32_t* written = written2 + wsel * PF2_NB;
-            uint32_t pk[PF2_TILES][PF2_GROUP], rank[PF2_TILES][PF2_GROUP];
-#pragma unroll
-            for (uint32_t q = 0; q < PF2_TILES; ++q) {
-                const bool live = t0 + q < n_tiles && (t0 + q) * 64 + lane < P.n_reads;
-#pragma unroll
-                for (uint32_t u = 0; u < PF2_GROUP; ++u) {
-                    const bool on = live && j0 + u < P.np;
-                    pk[q][u] = on ? canon16(stream32(tiles + q * slice_words, bit0 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
-                    rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
-                }
-            }
-            __syncthreads();
-            if (wv == 0) {   // exclusive scan of the 256 bins: four per lane
-                uint32_t v[4], sum = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] = hist[lane * 4 + q]; sum += v[q]; }
-                uint32_t inc = sum;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t y = __shfl_up(inc, d);
-                    if ((int)lane >= d) inc += y;
-                }
-                uint32_t run = inc - sum;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { offs[lane * 4 + q] = run; run += v[q]; }
-                if (lane == 63) offs[PF2_NB] = inc;
-            } else if (wv <= PF2_NB / 64) {   // the parts' fill after this group
-                const uint32_t i = tid - 64;
-                const uint32_t w = written[i] + hist[i];
-                written2[(wsel ^ 1u) * PF2_NB + i] = w < Q.cap ? w : Q.cap;
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t q = 0; q < PF2_TILES; ++q)
-#pragma unroll
-                for (uint32_t u = 0; u < PF2_GROUP; ++u)
-                    if (rank[q][u] != EMPTY32)
-                        sorted[offs[pk[q][u] >> (32 - PF2_NB_LOG2)] + rank[q][u]] = ((unsigned long long)(uint32_t)((t0 + q) * 64 + lane) << 32) | pk[q][u];
-            __syncthreads();
-            const uint32_t n_pairs = offs[PF2_NB];
-            const uint32_t hz = hsel == 0 ? 2 : hsel - 1;
-            for (uint32_t i = tid; i < PF2_NB; i += NT) hist3[hz * PF2_NB + i] = 0;                  // the histogram of the group after next
-            for (uint32_t i0 = 0; i0 < n_pairs; i0 += NT) {         // (whole waves stay in the loop: ballots and shuffles below)
-                const uint32_t i = i0 + tid;
-                const bool valid = i < n_pairs;
-                const unsigned long long pr = valid ? sorted[i] : 0ull;
-                const uint32_t b = (uint32_t)pr >> (32 - PF2_NB_LOG2);
-                const uint32_t at = valid ? written[b] + (i - offs[b]) : 0u;
-                const bool spill = valid && at >= Q.cap;
-                {   // one store per wave and trip, whatever the lanes hold (idle lanes: their own 8 bytes of the dummy line)
-                    unsigned long long* dst = (valid && !spill && !(Q.diag & 16)) ? part(b) + at : dummy + lane;
-                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(pr) : "memory");
-                    ++stores_since;
-                }
-                // a part that is full (degenerate inputs): probe on the spot
-                const unsigned long long sb = __ballot(spill);
-                if (sb) {
-                    const bool c = pf_test_pair(Q, (uint32_t)pr, (uint32_t)(pr >> 32), spill);
-                    const unsigned long long bal = __ballot(c);
-                    if (bal) {
-                        uint32_t gb = 0;
-                        if (lane == 0) gb = atomicAdd(P.n_cand, (uint32_t)__popcll(bal));
-                        gb = __shfl(gb, 0);
-                        if (c) P.cand[gb + __popcll(bal & lt)] = (uint32_t)(pr >> 32);
-                    }
-                }
-            }
-            hsel = hsel == 2 ? 0 : hsel + 1;
-            wsel ^= 1u;
-        }
-    }
-    vm_wait<0>();   // the last prefetch (idle tiles) still targets this wave's registers
-    for (uint32_t i = tid; i < PF2_NB; i += NT) Q.count[(size_t)i * Q.n_writers + writer] = written2[wsel * PF2_NB + i];
-}
 
-// pass B of the 256-bucket form: one workgroup per bucket at a time; the bucket's slice of the level-1 bitmap lives in LDS.
-// Pairs that pass both bits (~1 %: false positives of the two-bit test + the true hits) are queued per wave and their exact-set
-// look-ups run 64 at a time — done on the spot, one or two busy lanes made the whole wave wait for a global round trip in 40 % of
-// the 64-pair steps (1.67 ms per 112.5 M reads; queued: see DESIGN.md).
+// (pass B of the 256-bucket filter queues the pairs that pass the bitmap and looks them up in the exact set 64 at a time)
 constexpr uint32_t PF2_PEND = 128;   // per wave: < 64 waiting + <= 64 from one step
-__global__ __launch_bounds__(1024) void pf2_probe_kernel(PartParams Q) {
-    extern __shared__ uint32_t sm[];   // [slice of the level-1 bitmap: 2^(bm_log2 - 8) bits][per wave: WOBUF candidates | PF2_PEND pairs]
-    const FilterParams& P = Q.F;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t slice_words = 1u << (P.bm_log2 - PF2_NB_LOG2 - 5);
-    const uint32_t sh_bm = 32 - P.bm_log2;
-    uint32_t* obuf = sm + slice_words + wv * (WOBUF + 2 * PF2_PEND);
-    unsigned long long* pend = reinterpret_cast<unsigned long long*>(obuf + WOBUF);
-    uint32_t obuf_n = 0, pend_n = 0;   // wave-uniform
-    const unsigned long long lt = (1ull << lane) - 1;
-    auto flush = [&]() {
-        uint32_t gb = 0;
-        if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
-        gb = __shfl(gb, 0);
-        for (uint32_t q = lane; q < obuf_n; q += 64) P.cand[gb + q] = obuf[q];
-        obuf_n = 0;
-        wave_lds_sync();
-    };
-    // exact-set look-up of the last min(64, pend_n) queued pairs, one per lane; first hit of a read becomes a candidate
-    auto settle = [&]() {
-        const uint32_t base = pend_n > 64 ? pend_n - 64 : 0;
-        bool cand = false;
-        uint32_t read = 0;
-        if (base + lane < pend_n) {
-            const unsigned long long pr = pend[base + lane];
-            const uint32_t key = (uint32_t)pr * S16_MUL_INV;
-            read = (uint32_t)(pr >> 32);
-            if (sset_walk(P, key, hash_s16_set(key, P.s_log2))) {
-                const uint32_t bit = 1u << (read & 31);
-                cand = !(atomicOr(&Q.seen[read >> 5], bit) & bit);
-            }
-        }
-        pend_n = base;
-        const unsigned long long bal = __ballot(cand);
-        if (bal) {
-            if (obuf_n + (uint32_t)__popcll(bal) > WOBUF) flush();
-            if (cand) obuf[obuf_n + __popcll(bal & lt)] = read;
-            obuf_n += (uint32_t)__popcll(bal);
-            wave_lds_sync();
-            if (obuf_n >= 32) flush();
-        }
-        wave_lds_sync();
-    };
-    for (uint32_t b = blockIdx.x; b < PF2_NB; b += gridDim.x) {
-        __syncthreads();
-        for (uint32_t i = tid * 4; i < slice_words; i += 1024 * 4)
-            *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap + (size_t)b * slice_words + i);
-        __syncthreads();
-        for (uint32_t w = wv; w < Q.n_writers; w += 16) {
-            const uint32_t n = Q.count[(size_t)b * Q.n_writers + w];
-            const unsigned long long* src = Q.pairs + ((size_t)b * Q.n_writers + w) * Q.cap;
-#ifndef GF_PF2_PB
-#define GF_PF2_PB 8
-#endif
-            constexpr int PB = GF_PF2_PB;
-            unsigned long long nx[PB];
-            auto fetch = [&](uint32_t i0) {
-#pragma unroll
-                for (int u = 0; u < PB; ++u) nx[u] = i0 + u * 64 + lane < n ? src[i0 + u * 64 + lane] : 0ull;
-            };
-            fetch(0);
-            for (uint32_t i0 = 0; i0 < n; i0 += PB * 64) {
-                unsigned long long pr[PB];
-#pragma unroll
-                for (int u = 0; u < PB; ++u) pr[u] = nx[u];
-                if (i0 + PB * 64 < n) fetch(i0 + PB * 64);
-#pragma unroll
-                for (int u = 0; u < PB; ++u) {
-                    const uint32_t pk = (uint32_t)pr[u];
-                    bool pass = false;
-                    if (i0 + u * 64 + lane < n) {
-                        const uint32_t h = pk >> sh_bm;                       // bit index in the whole bitmap; its top 8 bits = b
-                        const uint32_t wd = sm[(h >> 5) & (slice_words - 1)];
-                        pass = (wd >> (h & 31)) & (wd >> (pk & 31)) & 1u;      // both bits of the key in its word
-                    }
-                    const unsigned long long bal = __ballot(pass);
-                    if (bal) {
-                        if (pass) pend[pend_n + __popcll(bal & lt)] = pr[u];
-                        pend_n += (uint32_t)__popcll(bal);                    // < 64 + 64 <= PF2_PEND
-                        wave_lds_sync();
-                        if (pend_n >= 64) settle();
-                    }
-                }
-            }
-        }
-    }
-    while (pend_n) settle();
-    if (obuf_n) flush();
-}
 
 // ---- 256-bucket filter with 4-BYTE pairs.  The 8-byte (key, read) pairs of pf2_* triple the stream (38 B of read -> + 32 B written
 // + 32 B read back: 3.06 x the algorithmic bytes at C4) and both passes run at the rate the memory system moves those bytes.  What
@@ -921,7 +491,6 @@ struct Part4Params {
     uint8_t* chunk_b;             // bucket of every PF4_CHUNK entries of that list
     uint32_t* n_cand8;
     uint32_t cap8;
-    uint32_t diag;
 };
 constexpr uint32_t PF4_CHUNK = 256;   // entries of the pair list a wave of pass B reserves at a time
 constexpr uint32_t PF4_STAGE = 16;   // groups of fill history staged in LDS (one 64-byte row per bucket and flush)
@@ -1104,7 +673,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
                 const uint32_t at = valid ? written[b] + (i - offs[b]) : 0u;
                 const bool spill = valid && at >= Q.cap;
                 {
-                    uint32_t* dst = (valid && !spill && !(Q.diag & 16)) ? part(b) + at : dummy + lane;
+                    uint32_t* dst = (valid && !spill) ? part(b) + at : dummy + lane;
                     const uint32_t e = (key << 8) | oc;
                     asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
                     ++stores_since;
@@ -2110,6 +1679,9 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
 
 int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const void* d_nmask, size_t n_reads,
                   int read_len, int min_hits, void* d_out, size_t cap, void* d_n_out) {
+    // one-shot (gf_stream_wait_after_filter): taken here, so that no exit below leaves it armed for a later, unrelated pass
+    gf_ctx* const waiter = ctx->after_filter;
+    ctx->after_filter = nullptr;
     if (read_len < ix.k || read_len > 1000) return GF_E_INVAL;
     if (n_reads >= 0xFFFFFFFFull || cap > 0xFFFFFFFFull) return GF_E_INVAL;
     const uint32_t rb = (uint32_t)((read_len + 3) / 4);
@@ -2139,7 +1711,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     F.stream_policy = (uint32_t)ctx->screen_stream_policy;
     F.bitmap_mid = ix.mid_log2 ? ix.d_bitmap_mid : nullptr;
     F.mid_log2 = (uint32_t)ix.mid_log2;
-    // Kernel choice (screen_variant: 0 = automatic; 9 / 12 / 13 force the plain / wave / pipelined kernel, for ablation):
+    // Kernel choice (screen_variant: 0 = automatic; 9 / 13 / 14 / 16 force the plain / pipelined / 16-bucket / 256-bucket form — the
+    // parity tests run every one of them on the same inputs):
     // the LDS pre-filter pays while the coarse bitmap is sparse enough to stop most probes before L2 and a handful of waves
     // fit next to it (long reads leave too few); the pipelined form covers up to 10 probes and 64 packed bytes per read
     const size_t w_bm_bytes = ix.d_bitmap_lds ? ((size_t)1 << ix.lds_log2) / 8 : 0;
@@ -2149,8 +1722,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     const size_t tiles64 = (n_reads + 63) / 64;
     const int nch = (rb + 15) / 16 <= 4 ? (int)((rb + 15) / 16) : 0;
     const bool lds_auto = ix.d_bitmap_lds && ix.lds_fill <= 0.6 && ctx->screen_variant == 0 && w_nw >= 6;
-    const bool lds_forced = (ctx->screen_variant == 12 || ctx->screen_variant == 13) && ix.d_bitmap_lds && w_nw >= 2;
-    const bool pipe_ok = F.np >= 1 && F.np <= 10 && ix.lds_log2 >= 7 && nch >= 1 && ctx->screen_variant != 12;
+    const bool lds_forced = ctx->screen_variant == 13 && ix.d_bitmap_lds && w_nw >= 2;
+    const bool pipe_ok = F.np >= 1 && F.np <= 10 && ix.lds_log2 >= 7 && nch >= 1;
     if ((lds_auto || lds_forced) && pipe_ok) {
         // software-pipelined wave kernel (three tiles in flight per wave)
         const size_t nw = std::min<size_t>(w_nw, 8);   // measured: 8 waves x 256 VGPRs beat 11 x 168
@@ -2167,31 +1740,17 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
                            w_bm_bytes + nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
-    } else if (lds_auto || lds_forced) {
-        // wave-autonomous LDS pre-filter kernel: as many waves per CU as fit next to the coarse bitmap
-        void (*wk)(FilterParams, uint32_t) = screen_filter_wave_kernel<0>;
-        switch (nch) {
-            case 1: wk = screen_filter_wave_kernel<1>; break;
-            case 2: wk = screen_filter_wave_kernel<2>; break;
-            case 3: wk = screen_filter_wave_kernel<3>; break;
-            case 4: wk = screen_filter_wave_kernel<4>; break;
-            default: break;
-        }
-        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + w_nw - 1) / w_nw, ctx->n_cu)), dim3((unsigned)(w_nw * 64)),
-                           w_bm_bytes + w_nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
-    } else if ((ctx->screen_variant == 16 || (ctx->screen_variant == 0 && ctx->screen_pf4 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
+    } else if ((ctx->screen_variant == 16 || (ctx->screen_variant == 0 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
                ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) * 4 + (size_t)PF2_BATCH * 5 + (size_t)PF2_NB * (PF4_STAGE + 1) * 4 +
                 (6 * PF2_NB + 8) * 4) <= 156 * 1024) {
         // partitioned filter, 256 buckets, 4-byte pairs (see Part4Params)
         Part4Params Q;
         Q.F = F;
-        Q.diag = (uint32_t)ctx->screen_pf_diag;
         const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;
         const size_t tiles64 = (n_reads + 63) / 64;
         const size_t tiles_wg = (size_t)PF2_WAVES * PF2_TILES;      // tiles per workgroup and iteration
         const size_t lds_a = tiles_wg * slice_words * 4 + (size_t)PF2_BATCH * 5 + (size_t)PF2_NB * (PF4_STAGE + 1) * 4 + (6 * PF2_NB + 8) * 4;
-        Q.n_writers = (uint32_t)std::min<size_t>((tiles64 + tiles_wg - 1) / tiles_wg, (size_t)ctx->n_cu);
+        Q.n_writers = (uint32_t)std::min<size_t>(std::min<size_t>((tiles64 + tiles_wg - 1) / tiles_wg, (size_t)ctx->n_cu), 256);   // the pair list carries the writer in 8 bits
         Q.tiles_wg = (uint32_t)tiles_wg;
         const size_t n_iter = (tiles64 + (size_t)Q.n_writers * tiles_wg - 1) / ((size_t)Q.n_writers * tiles_wg);
         Q.n_grp = (F.np + PF2_GROUP - 1) / PF2_GROUP;
@@ -2223,39 +1782,10 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         const size_t lds_r = (size_t)4 * 8 * (((2 * (size_t)rb + 3) / 4) * 4 + 4) * 4;
         hipLaunchKernelGGL(pf4_resolve_kernel, dim3((unsigned)ctx->n_cu * 8), dim3(256), lds_r, ctx->stream, Q);
         hipLaunchKernelGGL(pf4_list_kernel, dim3((unsigned)std::min<size_t>((size_t)ctx->n_cu * 4, (n_reads + 32 * 256 - 1) / (32 * 256))), dim3(256), 0, ctx->stream, Q);
-    } else if ((ctx->screen_variant == 15 || (ctx->screen_variant == 0 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
-               ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) + (size_t)PF2_BATCH * 2 + 6 * PF2_NB + 8) * 4 <= 156 * 1024) {   // (reads up to ~180 bases)
-        // partitioned filter, 256 buckets: a bucket's slice of the level-1 bitmap itself fits the LDS of pass B (see pf2_scatter_kernel)
-        PartParams Q;
-        Q.F = F;
-        Q.diag = (uint32_t)ctx->screen_pf_diag;
-        Q.nb_log2 = PF2_NB_LOG2;
-        const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;
-        const size_t tiles64 = (n_reads + 63) / 64;
-        const size_t tiles_wg = (size_t)PF2_WAVES * PF2_TILES;      // tiles per workgroup and iteration
-        const size_t lds_a = (tiles_wg * slice_words + (size_t)PF2_BATCH * 2 + 6 * PF2_NB + 8) * 4;
-        const size_t wg_per_cu = std::max<size_t>(1, std::min<size_t>(16 / PF2_WAVES, (160 * 1024 - 2048) / lds_a));
-        Q.n_writers = (uint32_t)std::min<size_t>((tiles64 + tiles_wg - 1) / tiles_wg, (size_t)ctx->n_cu * wg_per_cu);
-        const double pairs_w = (double)((tiles64 + (size_t)Q.n_writers * tiles_wg - 1) / ((size_t)Q.n_writers * tiles_wg)) * tiles_wg * 64.0 * F.np;
-        const double expect = pairs_w / PF2_NB;
-        Q.cap = ((uint32_t)(expect * 1.05 + 6.0 * std::sqrt(expect + 1.0) + 128.0) + 63u) & ~63u;
-        const size_t b_pairs = (size_t)PF2_NB * Q.n_writers * Q.cap * 8, b_cnt = ((size_t)PF2_NB * Q.n_writers * 4 + 255) & ~(size_t)255,
-                     b_seen = (((size_t)n_reads + 31) / 32 * 4 + 255) & ~(size_t)255;
-        if ((rc = ensure(ctx, ctx->part_ws, b_cnt + b_seen + b_pairs + 1024))) return rc;
-        uint8_t* ws = (uint8_t*)ctx->part_ws.p;
-        Q.count = (uint32_t*)ws;
-        Q.seen = (uint32_t*)(ws + b_cnt);
-        Q.pairs = (unsigned long long*)(ws + b_cnt + b_seen);
-        GF_HIP(ctx, hipMemsetAsync(Q.seen, 0, b_seen, ctx->stream));
-        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        hipLaunchKernelGGL(pf2_scatter_kernel, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
-        const size_t lds_b = (((size_t)1 << (ix.bm_log2 - PF2_NB_LOG2 - 5)) + 16 * (WOBUF + 2 * PF2_PEND)) * 4;
-        hipLaunchKernelGGL(pf2_probe_kernel, dim3((unsigned)std::min<size_t>(PF2_NB, (size_t)ctx->n_cu)), dim3(1024), lds_b, ctx->stream, Q);
-    } else if (ctx->screen_variant == 14 || ctx->screen_variant == 15 || (ctx->screen_variant == 0 && ix.bm_log2 >= 27 && n_reads >= (1u << 20) && rb <= 64)) {
+    } else if (ctx->screen_variant == 14 || (ctx->screen_variant == 0 && ix.bm_log2 >= 27 && n_reads >= (1u << 20) && rb <= 64)) {
         // partitioned filter: the level-1 bitmap is far larger than an L2 (see pf_scatter_kernel)
         PartParams Q;
         Q.F = F;
-        Q.diag = (uint32_t)ctx->screen_pf_diag;
         Q.nb_log2 = 4;   // 16 buckets: two per XCD; a bucket's slice of the 2^24-bit reduction is 128 KiB of LDS in pass B
         const uint32_t nb = 1u << Q.nb_log2;
         const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;
@@ -2288,13 +1818,12 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         hipLaunchKernelGGL(screen_filter_kernel<9>, dim3(grid), dim3(256), TILE_READS * rb + 16, ctx->stream, F);
     }
     GF_HIP(ctx, hipGetLastError());
-    if (ctx->after_filter) {   // gf_stream_wait_after_filter: the peer's stream goes on once the filter pass above has finished
+    if (waiter) {   // gf_stream_wait_after_filter: the peer's stream goes on once the filter pass above has finished
         hipEvent_t ev;
         GF_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         hipError_t e = hipEventRecord(ev, ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->after_filter->stream, ev, 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(waiter->stream, ev, 0);
         (void)hipEventDestroy(ev);
-        ctx->after_filter = nullptr;
         if (e != hipSuccess) return set_hip_error(ctx, e, "gf_stream_wait_after_filter");
     }
 

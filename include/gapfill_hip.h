@@ -350,7 +350,7 @@ int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_con
  * ContigsCompactor.cpp:1982-2095, applied by CompactVer3 :836-853 / threadQuickCheck :1073-1098).  A contig SET (one per gap: its
  * contigs.fa) becomes the node list [c0, revcomp(c0), c1, revcomp(c1), ...]; pair (i, j), i <= j, is feasible iff some k-mer of
  * the first or last 30 bases of node j occurs anywhere in node i (KmerUtils' 2-bit k-mers: any symbol but C/G/T counts as A).
- * Only feasible pairs go on to the overlap alignment (:1572-1976, not part of this build).  Contigs need >= 30 bases
+ * Only feasible pairs go on to the overlap alignment (gf_overlap_evaluate below).  Contigs need >= 30 bases
  * (GF_E_INVAL; the reference reads out of bounds).  4 <= k <= 16 (the reference's default is 10).
  * seq: the contigs' ASCII bases back to back; contig_off[n_contigs+1]; set_off[n_sets+1] = contig index ranges of the sets.
  * Host variant: triples sorted by (set, i, j). */
@@ -360,8 +360,9 @@ typedef struct {
 } gf_qcpair;
 int gf_quick_check(gf_ctx* ctx, const char* seq, const uint64_t* contig_off, const uint64_t* set_off, size_t n_sets, int k,
                    gf_qcpair* out, size_t cap, size_t* n_out);
-/* device variant: max_set_contigs = contigs of the largest set (sizes the pair matrices); *d_n_out (u32) = triples found (more
- * than cap: truncated); order unspecified */
+/* device variant: max_set_contigs = contigs of the largest set (sizes the pair matrices); d_n_out = u32[2]: [0] triples found (more
+ * than cap: truncated), [1] flags of SKIPPED sets (bit 0: a contig shorter than 30 bases, bit 1: more contigs than
+ * max_set_contigs) — the host variant turns a non-zero flag into GF_E_INVAL; order unspecified */
 int gf_quick_check_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off, const void* d_set_off, size_t n_sets,
                        size_t max_set_contigs, int k, void* d_out, size_t cap, void* d_n_out);
 

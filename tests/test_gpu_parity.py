@@ -100,7 +100,7 @@ def test_screen_and_tagger_synthetic(gf, seed, n_pairs, L, k):
     exp = CO.screen_reads(c["reads_blob"], L, c["flanks"], k)
     assert _same(hits, exp) and len(exp) > 100
     if L <= 250:      # the partitioned filters (packed reads up to 64 bytes) on the same reads, with a 2^27-bit bitmap:
-        for variant in (14, 15, 16):  # 16 buckets with per-wave rows / 256 buckets with the workgroup sort, 8-byte pairs / 4-byte pairs
+        for variant in (14, 16):  # 16 buckets with per-wave rows / 256 buckets with the workgroup sort and 4-byte pairs
             gf.set_option("screen_variant", variant)
             gf.set_option("bitmap_log2", 27)
             try:
@@ -314,9 +314,9 @@ def test_device_pools_follow_the_reference_fastq_join_order(gf):
         assert gseqs == [x[0] for x in e]
 
 
-@pytest.mark.parametrize("variant", [12, 13, 9, 14])
+@pytest.mark.parametrize("variant", [13, 9, 14])
 def test_screen_filter_variants_agree(gf, variant):
-    """Every filter kernel (wave = 12, pipelined = 13, plain L2 bitmap = 9, partitioned = 14) gives the oracle's hits."""
+    """Every filter kernel (pipelined = 13, plain L2 bitmap = 9, partitioned = 14 / 16) gives the oracle's hits."""
     from gappadder_amd.hip_api import GapFill
     c = S.small_case(seed=41, n_pairs=25000)
     gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
@@ -331,13 +331,13 @@ def test_screen_filter_variants_agree(gf, variant):
         for bl in (16, 19, 22, 26, 28):  # 26: level-1 bitmap beyond the L2 -> the plain kernel also asks the 2^24-bit reduction;
             gf.set_option("bitmap_log2", bl)   # 28: the partitioned filter uses 16 buckets instead of 8
             assert _same(gf.screen_reads(packed, c["L"], 31), exp31), (variant, bl)
-        if variant == 14:      # the 256-bucket partitioned filter (variant 15) exists for 2^27- and 2^28-bit bitmaps
-            gf.set_option("screen_variant", 15)
+        if variant == 14:      # the 256-bucket partitioned filter (variant 16) exists for 2^27- and 2^28-bit bitmaps
+            gf.set_option("screen_variant", 16)
             for bl in (27, 28):
                 gf.set_option("bitmap_log2", bl)
                 for n in (len(packed), 1000, 769, 1):
-                    assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (15, bl, n)
-                assert _same(gf.screen_reads(packed, c["L"], 51), exp51), (15, bl)
+                    assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (16, bl, n)
+                assert _same(gf.screen_reads(packed, c["L"], 51), exp51), (16, bl)
     finally:
         gf.set_option("screen_variant", 0)
         gf.set_option("bitmap_log2", 0)
@@ -504,10 +504,8 @@ def test_partitioned_filter_probes_in_place_when_a_bucket_part_runs_full(gf):
     try:
         gf.set_option("screen_variant", 14)
         assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
-        gf.set_option("screen_variant", 15)        # 256 buckets: the same degenerate reads overflow a workgroup's part
         gf.set_option("bitmap_log2", 27)
-        assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
-        gf.set_option("screen_variant", 16)        # 4-byte pairs: a full part is tested on the spot and resolved by the lane itself
+        gf.set_option("screen_variant", 16)        # 256 buckets, 4-byte pairs: the same degenerate reads overflow a workgroup's part — a full part is tested on the spot and resolved by the lane itself
         assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
         gf.set_option("screen_pf4_cap8", 256)      # ... and so is every pair beyond a (here: tiny) pair list
         assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
@@ -540,12 +538,12 @@ def test_human_scale_key_set_all_filter_kernels_agree_on_20M_reads(gf):
     packed = d_reads[:2 * n_pairs * rb].cpu().numpy().reshape(-1, rb)
     res = {}
     try:
-        for variant in (0, 14, 15, 9):
+        for variant in (0, 14, 9):
             gf.set_option("screen_variant", variant)
             res[variant] = gf.screen_reads(packed, L, k, cap=1 << 20)
     finally:
         gf.set_option("screen_variant", 0)
-    assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[15]) and _same(res[0], res[9])   # (0 = the 4-byte-pair filter)
+    assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[9])   # (0 = the 256-bucket 4-byte-pair filter)
     try:   # a short pair list: most pairs that are in the exact set take the serial path
         gf.set_option("screen_pf4_cap8", 1 << 16)
         assert _same(res[0], gf.screen_reads(packed, L, k, cap=1 << 20))

@@ -29,8 +29,6 @@ gf.set_option("asm_dbg_ptr", dbg.data_ptr())
 gf.timing(True)
 if os.environ.get("PRECOUNT"):
     gf.set_option("asm_precount", int(os.environ["PRECOUNT"]))
-if os.environ.get("ASMDIAG"):
-    os.environ["GF_DIAGNOSTICS"] = "1"; gf.set_option("asm_diag", int(os.environ["ASMDIAG"]))
 if os.environ.get("SIMPLIFY"):
     gf.set_option("asm_simplify", int(os.environ["SIMPLIFY"]))
 for _ in range(3):

@@ -30,8 +30,6 @@ for bl, var in itertools.product(([0] if len(sys.argv) <= 4 else [int(x) for x i
     gf.set_option("bitmap_log2", bl)
     gf.set_option("screen_lds_log2_max", int(os.environ.get("LDSMAX", "20")))
     gf.set_option("screen_variant", var % 100)
-    gf.set_option("screen_pf_diag", int(os.environ.get("PFDIAG", "0")))
-    gf.set_option("screen_pf4", int(os.environ.get("PF4", "1")))
     gf.set_option("screen_np_override", (var // 1000) - 1 if var >= 1000 else -1)
     t = time.time()
     gf.set_gaps(gaps, int(gaps["scaffold"].max()) + 1, flanks)
