@@ -106,7 +106,10 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         out["extras"] = {"C2": child_run(["--config", "C2", "--steps", "20", "--warmup", "2"]),
-                         "C5_mate_pair_multi_k": child_run(["--config", "C5", "--steps", "3", "--warmup", "1"])}
+                         "C5_mate_pair_multi_k": child_run(["--config", "C5", "--steps", "3", "--warmup", "1"]),
+                         # SURVEY.md §8d's own figure for the mate-pair library (100 M records = 4.8x): recorded as it is — at KMC's
+                         # min-count 2 that depth leaves holes in every 2-kb gap, so (nearly) nothing closes; see MP_READS_DEFAULT
+                         "C5_survey_sized_100M_mate_pairs": child_run(["--config", "C5", "--mp-reads", "100000000", "--steps", "2", "--warmup", "1"])}
         # the second half of BASELINE.json's metric: 2-kb gaps cannot close from a 300-bp library alone (C4: 0 by construction of the
         # workload); configs[4] adds the mate-pair library and the multi-k sweep, and its closed count is part of this line
         c5 = out["extras"]["C5_mate_pair_multi_k"]
@@ -396,8 +399,7 @@ def run(args):
                                        d_ctg.data_ptr(), contig_cap, ap_, d_seq.data_ptr(), seq_cap, ap_ + 8, d_gap_err.data_ptr())
         assert rc == 0, rc
         # which gaps are closed: both flanks anchored on one contig (pick_contigs.py:64-358; scores 30 then 15, assemble_gaps.py:336, 365)
-        for a_len in (30, 15):
-            assert lib.gf_pick_anchored_dev(h, d_ctg.data_ptr(), ap_, contig_cap, d_seq.data_ptr(), a_len, d_best.data_ptr(), ap_ + 16) == 0
+        assert lib.gf_pick_anchored2_dev(h, d_ctg.data_ptr(), ap_, contig_cap, d_seq.data_ptr(), 30, 15, d_best.data_ptr(), ap_ + 16) == 0
 
     def run_steps(n):
         if stream is not None:
@@ -415,12 +417,16 @@ def run(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    d_astat = torch.zeros(4, dtype=torch.int64, device=dev)      # windows, k-mers counted exactly, surviving k-mers, nodes (all steps, all k)
+    gf.set_option("asm_stats_ptr", d_astat.data_ptr())
     d_dbg = None
     if os.environ.get("GF_BENCH_ASM_PROBE"):      # diagnostic (needs GF_DIAGNOSTICS=1): per-gap phase stamps of the LAST assembly launch
         d_dbg = torch.zeros(n_gaps * 16, dtype=torch.int64, device=dev)
         gf.set_option("asm_dbg_ptr", d_dbg.data_ptr())
     run_steps(args.warmup)
     barrier()
+    d_astat.zero_()
+    torch.cuda.synchronize()
     [g_.timing(True) for g_ in {id(x): x for x in [gf] + gf2s}.values()]
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -453,6 +459,8 @@ def run(args):
                          % (d[:, 13].mean(), d[:, 10].mean(), d[:, 12].mean(), d[:, 14].mean(), d[:, 14].max(), 100.0 * d[:, 11].mean(),
                             " / ".join("%.0f %%" % (100.0 * (d[:, 15] == v).mean()) for v in (0, 1, 2))))
     # ---- results of the last step ----
+    astat = (d_astat.cpu().numpy().astype(np.float64) / max(1, args.steps))      # per step (this rank's gaps)
+    gf.set_option("asm_stats_ptr", 0)
     acnt = d_acnt.cpu().numpy()
     n_ctg, n_seq, n_closed_local = int(acnt[0]), int(acnt[2:4].view(np.uint64)[0]), int(acnt[4])
     xerr = int(d_xerr[0])
@@ -553,6 +561,17 @@ def run(args):
                                            "strand, genome[start-6 : end+5] when the contig is reverse-complemented (the reference's slice keeps one anchor base)",
                                    "closed": n_closed, "correct": n_correct, "wrong_on_rank0": truth["wrong"][:8], "wrong_causes_rank0": truth["causes"]},
         }
+        # the assembly's algorithmic bytes ("report bytes anyway"): 38 B x pool reads in + 2 x 20 B x distinct k-mers
+        # (16-B key + 4-B count, written once, read once) + contig bases out, per (k, kv) pass; LDS/latency-bound, so no roofline claim
+        asm_ms = phases["assemble"]
+        asm_bytes = len(kk) * asm_rows_total * rb + 2 * 20 * float(astat[1]) * (world if world > 1 else 1) + n_seq
+        out["assembly"] = {"algorithmic_bytes": int(asm_bytes), "gaps_per_s": n_gaps / (asm_ms * 1e-3) if asm_ms else None,
+                           "us_per_gap_and_k": 1e3 * asm_ms / max(1, n_gaps * len(kk)), "ms": asm_ms, "k_passes": len(kk),
+                           "pool_reads": asm_rows_total, "read_windows": int(astat[0]), "kmers_counted_exactly": int(astat[1]),
+                           "surviving_kmers": int(astat[2]), "graph_nodes": int(astat[3]), "contig_bases": n_seq,
+                           "achieved_GBps": asm_bytes / (asm_ms * 1e-3) / 1e9 if asm_ms else None,
+                           "note": "per step; k-mers seen fewer than min_count times are stopped by the bit-array pre-count and never counted exactly"
+                                   + ("; k-mer figures are rank 0's gaps x world" if world > 1 else "")}
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
         if not args.no_cpu and world == 1:
@@ -602,7 +621,7 @@ def child_run(argv):
                            stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
         return {key: d[key] for key in ("value", "ms_per_step", "steps", "warmup", "gaps_per_s", "gaps_closed_per_s", "gaps_closed_correct_per_s",
-                                        "phases_ms", "counts", "closed_truth_check")} | \
+                                        "phases_ms", "counts", "closed_truth_check", "assembly")} | \
                {"workload": d["config"]["workload"], "roofline_frac": d["roofline"]["frac"], "filter_ms": d["roofline"]["avg_launch_ms"]}
     except Exception as e:      # the headline line must not depend on an extra
         return {"error": repr(e)[:300], "stderr_tail": (r.stderr.decode()[-400:] if r is not None else "")}

@@ -102,6 +102,7 @@ def lib():
         "gf_overlap_evaluate": (i32, [vp, C.c_char_p, vp, vp, sz, vp, sz, vp, vp]),
         "gf_overlap_evaluate_dev": (i32, [vp, vp, vp, vp, vp, sz, vp, vp]),
         "gf_pick_anchored_dev": (i32, [vp, vp, vp, sz, vp, i32, vp, vp]),
+        "gf_pick_anchored2_dev": (i32, [vp, vp, vp, sz, vp, i32, i32, vp, vp]),
         "gf_count_kmers": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp, sz, szp]),
         "gf_pool_keys_reset": (i32, [vp, vp]),
         "gf_pool_keys_from_screen_dev": (i32, [vp, vp, vp, sz, i32, vp, sz, vp]),

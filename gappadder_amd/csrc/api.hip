@@ -206,6 +206,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     }
     if (!strcmp(name, "screen_variant")) { ctx->screen_variant = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_dbg_ptr")) { ctx->asm_dbg = (void*)(uintptr_t)value; return GF_OK; }
+    if (!strcmp(name, "asm_stats_ptr")) { ctx->asm_stats = (void*)(uintptr_t)value; return GF_OK; }
     if (!strcmp(name, "tag_light")) { ctx->tag_light = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_keyslot")) { ctx->asm_keyslot = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_precount")) { ctx->asm_precount = value != 0; return GF_OK; }

@@ -58,6 +58,8 @@ struct AsmParams {
     uint32_t keyslot;          // allow the key-in-slot count phase
     uint32_t ranked;           // allow the ranked table behind the pre-count
     uint32_t precount;         // allow the bit-array pre-count (k-mers seen fewer than min_count times never enter the table)
+    unsigned long long* stats; // or null: [0] += read windows, [1] += k-mers counted exactly, [2] += surviving k-mers, [3] += nodes (the
+                               // assembly's algorithmic bytes, SURVEY.md §8d: 38 B x pool reads + 2 x 20 B x distinct k-mers + contig bases)
     unsigned long long* dbg;   // diagnostic runs only: 16 wall-clock stamps per gap (100 MHz), or null
 };
 
@@ -1103,6 +1105,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
             __syncthreads();
         }
         n_nodes = s_cnt[5] < n_unit ? s_cnt[5] : n_unit;
+        if (P.stats && tid < 4) atomicAdd(P.stats + tid, (unsigned long long)(tid == 0 ? n_inst : tid == 1 ? n_dist : tid == 2 ? n_surv : n_nodes));
         const uint32_t astride = graph_lds ? nb : n_nodes;
         uint32_t* garr = P.nodes + 3 * inst_off;
         ASM_STAMP(3);
@@ -1582,6 +1585,7 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.cnt_counts = (uint32_t*)d_cnt_counts;
     P.cnt_cap = (uint32_t)std::min<size_t>(cnt_cap, 0xFFFFFFFFu);
     P.dbg = (unsigned long long*)ctx->asm_dbg;
+    P.stats = (unsigned long long*)ctx->asm_stats;
     // dynamic LDS (option asm_lds_kb, default all 152 KiB): the gap's packed reads, then meta + succ[2] of its nodes;
     // whatever does not fit is read from / kept in global memory
     P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS / per_cu, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);

@@ -97,6 +97,7 @@ struct gf_ctx {
     int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
     int asm_ranked = 1;          // count phase: ranked (perfect-hash) table behind the pre-count (k > 32, LDS)
     int asm_precount = 1;        // count phase: bit-array pre-count in LDS when min_count is 2 or 3 (0: every window goes to the table)
+    void* asm_stats = nullptr;  // device u64[4], added to by every assembled gap: windows, k-mers counted exactly, surviving k-mers, nodes (option asm_stats_ptr)
     void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)
     // tagger coarse bin map (rebuilt when dist2 changes)
     std::vector<uint32_t> bin_host;

@@ -28,40 +28,94 @@ constexpr int ANCHOR_MAX = 32;
 constexpr int ANCHOR_ROW = 5 * ANCHOR_MAX;
 
 // anchors: per gap 5 x 32 bytes: left, right, revcomp(left), revcomp(right), each `a` bases from byte 0 (byte 0 == 0: none), and a
-// flags row: byte 0 bit 0 = the left flank is exactly `a` bases long (unclipped hits), bit 1 = the right flank is
-__global__ __launch_bounds__(256) void pick_anchor_kernel(const gf_contig* contigs, const uint32_t* n_contigs, uint32_t contig_cap,
-                                                          const char* seq, const uint8_t* anchors, uint32_t n_gaps, uint32_t a,
-                                                          unsigned long long* gap_best, uint32_t* n_closed) {
-    const uint32_t n = *n_contigs < contig_cap ? *n_contigs : contig_cap;
+// flags row: byte 0 bit 0 = the left flank is exactly `a` bases long (unclipped hits), bit 1 = the right flank is.
+//
+// One wave per contig, ONE pass over it for up to two anchor lengths (a_long > a_short: the short anchors are the inner ends of the
+// long ones, so a long hit is a short hit that extends): a lane loads four bases at its position as one dword and compares them
+// with the heads of the four SHORT patterns held in registers (1.5 % of the positions go on to the byte loop); a short hit updates
+// the short pattern's leftmost / rightmost position and, when the long pattern's other a_long - a_short bases match as well, the
+// long one's.  (Before: one launch per anchor length, four pattern-byte loads per position.)
+struct PickParams {
+    const gf_contig* contigs;
+    const uint32_t* n_contigs;
+    uint32_t contig_cap;
+    const char* seq;
+    const uint8_t* anc_s;      // table of the short (or only) anchor length
+    const uint8_t* anc_l;      // table of the long anchor length, or null
+    uint32_t n_gaps, a_s, a_l;
+    unsigned long long* gap_best;
+    uint32_t* n_closed;
+};
+
+__device__ __forceinline__ uint32_t pick_span(const bool* any, const uint32_t* mn, const uint32_t* mx, uint32_t fl, uint32_t a, uint32_t* orient) {
+    // forward: left anchor at mn[0], right anchor at mx[1];  reverse: revcomp(right) at mn[3], revcomp(left) at mx[2] (the oriented
+    // contig is the reverse complement).  An unclipped flank's reverse hit is hidden by its forward hit.
+    const bool lf = any[0], rf = any[1], lr = any[2] && !((fl & 1) && any[0]), rr = any[3] && !((fl & 2) && any[1]);
+    *orient = 0;
+    if (lf && rf) return mx[1] >= mn[0] + a ? mx[1] - (mn[0] + a) + 1 : 0;
+    if (lr && rr) { *orient = 1; return mx[2] >= mn[3] + a ? mx[2] - (mn[3] + a) + 1 : 0; }
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void pick_anchor_kernel(PickParams P) {
+    const uint32_t n = *P.n_contigs < P.contig_cap ? *P.n_contigs : P.contig_cap;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t a = P.a_s, al = P.a_l, ext = P.anc_l ? al - a : 0;
     for (uint32_t ci = wave; ci < n; ci += n_waves) {
-        const gf_contig c = contigs[ci];
-        if (c.gap >= n_gaps || c.length < 2 * a) continue;
-        const uint8_t* an = anchors + (uint64_t)c.gap * ANCHOR_ROW;
-        if (an[0] == 0 || an[ANCHOR_MAX] == 0) continue;
-        const char* s = seq + c.seq_off;
-        // positions where each of the four patterns occurs: min and max per pattern
-        uint32_t mn[4] = {EMPTY32, EMPTY32, EMPTY32, EMPTY32}, mx[4] = {0, 0, 0, 0};
-        bool any[4] = {false, false, false, false};
+        const gf_contig c = P.contigs[ci];
+        if (c.gap >= P.n_gaps || c.length < 2 * a) continue;
+        const uint8_t* as = P.anc_s + (uint64_t)c.gap * ANCHOR_ROW;
+        if (as[0] == 0 || as[ANCHOR_MAX] == 0) continue;         // (no short anchors: no long ones either)
+        const uint8_t* alp = P.anc_l ? P.anc_l + (uint64_t)c.gap * ANCHOR_ROW : nullptr;
+        const bool has_long = alp && alp[0] != 0 && alp[ANCHOR_MAX] != 0 && c.length >= 2 * al;
+        const char* s = P.seq + c.seq_off;
+        uint32_t head[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint8_t* pat = as + q * ANCHOR_MAX;
+            head[q] = (uint32_t)pat[0] | ((uint32_t)pat[1] << 8) | ((uint32_t)pat[2] << 16) | ((uint32_t)pat[3] << 24);
+        }
+        // positions where each pattern occurs: min and max per pattern, short [0..3] and long [4..7]
+        uint32_t mn[8], mx[8];
+        bool any[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { mn[q] = EMPTY32; mx[q] = 0; any[q] = false; }
         const uint32_t last = c.length - a;
         for (uint32_t p = lane; p <= last; p += 64) {
-            const uint8_t b0 = (uint8_t)s[p];
+            uint32_t w = 0;                                       // four bases at p (a >= 8: they exist)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) w |= (uint32_t)(uint8_t)s[p + b] << (8 * b);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint8_t* pat = an + q * ANCHOR_MAX;
-                if (pat[0] != b0) continue;
-                uint32_t i = 1;
+                if (w != head[q]) continue;
+                const uint8_t* pat = as + q * ANCHOR_MAX;
+                uint32_t i = 4;
                 while (i < a && (uint8_t)s[p + i] == pat[i]) ++i;
-                if (i == a) {
-                    any[q] = true;
-                    mn[q] = p < mn[q] ? p : mn[q];
-                    mx[q] = p > mx[q] ? p : mx[q];
+                if (i != a) continue;
+                any[q] = true;
+                mn[q] = p < mn[q] ? p : mn[q];
+                mx[q] = p > mx[q] ? p : mx[q];
+                if (!has_long) continue;
+                // the long pattern around this short hit: the short one is its END for the left anchor and for revcomp(right), its
+                // START for the right anchor and for revcomp(left)
+                const uint8_t* lp = alp + q * ANCHOR_MAX;
+                const bool at_end = q == 0 || q == 3;
+                if (at_end ? p < ext : p + al > c.length) continue;
+                const uint32_t p0 = at_end ? p - ext : p;
+                bool ok = true;
+                for (uint32_t j = 0; j < ext && ok; ++j) {
+                    const uint32_t o = at_end ? j : a + j;
+                    ok = (uint8_t)s[p0 + o] == lp[o];
                 }
+                if (!ok) continue;
+                any[4 + q] = true;
+                mn[4 + q] = p0 < mn[4 + q] ? p0 : mn[4 + q];
+                mx[4 + q] = p0 > mx[4 + q] ? p0 : mx[4 + q];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {   // wave reductions
+        for (int q = 0; q < 8; ++q) {   // wave reductions
             for (int d = 32; d >= 1; d >>= 1) {
                 const uint32_t m2 = __shfl_xor(mn[q], d), x2 = __shfl_xor(mx[q], d);
                 mn[q] = m2 < mn[q] ? m2 : mn[q];
@@ -70,21 +124,14 @@ __global__ __launch_bounds__(256) void pick_anchor_kernel(const gf_contig* conti
             any[q] = __ballot(any[q]) != 0;
         }
         if (lane != 0) continue;
-        // forward: left anchor at mn[0], right anchor at mx[1];  reverse: revcomp(right) at mn[3], revcomp(left) at mx[2] (the oriented
-        // contig is the reverse complement).  An unclipped flank's reverse hit is hidden by its forward hit.
-        const uint32_t fl = an[4 * ANCHOR_MAX];
-        const bool lf = any[0], rf = any[1], lr = any[2] && !((fl & 1) && any[0]), rr = any[3] && !((fl & 2) && any[1]);
-        uint32_t best = 0, orient = 0;
-        if (lf && rf) {
-            if (mx[1] >= mn[0] + a) best = mx[1] - (mn[0] + a) + 1;
-        } else if (lr && rr) {
-            if (mx[2] >= mn[3] + a) { best = mx[2] - (mn[3] + a) + 1; orient = 1; }
-        }
+        uint32_t orient = 0, best = 0, alen = al;
+        if (has_long) best = pick_span(any + 4, mn + 4, mx + 4, alp[4 * ANCHOR_MAX], al, &orient);
+        if (!best) { best = pick_span(any, mn, mx, as[4 * ANCHOR_MAX], a, &orient); alen = a; }
         if (!best) continue;
-        const unsigned long long val = ((unsigned long long)a << 56) | ((unsigned long long)(best & 0xFFFFFFu) << 32) |
+        const unsigned long long val = ((unsigned long long)alen << 56) | ((unsigned long long)(best & 0xFFFFFFu) << 32) |
                                        ((unsigned long long)(0x7FFFFFFFu - ci) << 1) | orient;
-        const unsigned long long old = atomicMax(gap_best + c.gap, val);
-        if (old == 0) atomicAdd(n_closed, 1u);
+        const unsigned long long old = atomicMax(P.gap_best + c.gap, val);
+        if (old == 0) atomicAdd(P.n_closed, 1u);
     }
 }
 
@@ -94,15 +141,8 @@ using namespace gf;
 
 extern "C" {
 
-int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
-                         int anchor_len, void* d_gap_best, void* d_n_closed) {
-    if (!ctx || !d_contigs || !d_n_contigs || !d_seq || !d_gap_best || !d_n_closed || anchor_len < 8 || anchor_len > ANCHOR_MAX ||
-        contig_cap > 0xFFFFFFFFull)
-        return GF_E_INVAL;
+static int anchor_table(gf_ctx* ctx, int anchor_len, const uint8_t** out) {
     const size_t ng = ctx->gaps.size();
-    if (ctx->flank_left.size() != ng || ctx->flank_right.size() != ng) return GF_E_STATE;
-    if (!ng) return GF_OK;
-    GF_HIP(ctx, hipSetDevice(ctx->device));
     DevBuf& tab = ctx->anchor_tabs[anchor_len];
     if (!tab.p) {   // built once per anchor length (gf_set_gaps drops the tables)
         std::vector<uint8_t> h(ng * ANCHOR_ROW, 0);
@@ -129,12 +169,44 @@ int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_con
         if (rc) return rc;
         GF_HIP(ctx, hipMemcpy(tab.p, h.data(), h.size(), hipMemcpyHostToDevice));
     }
+    *out = (const uint8_t*)tab.p;
+    return GF_OK;
+}
+
+int gf_pick_anchored2_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
+                          int anchor_len, int anchor_len_short, void* d_gap_best, void* d_n_closed) {
+    if (!ctx || !d_contigs || !d_n_contigs || !d_seq || !d_gap_best || !d_n_closed || anchor_len < 8 || anchor_len > ANCHOR_MAX ||
+        contig_cap > 0xFFFFFFFFull || (anchor_len_short && (anchor_len_short < 8 || anchor_len_short >= anchor_len)))
+        return GF_E_INVAL;
+    const size_t ng = ctx->gaps.size();
+    if (ctx->flank_left.size() != ng || ctx->flank_right.size() != ng) return GF_E_STATE;
+    if (!ng) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    PickParams P;
+    int rc;
+    P.anc_l = nullptr;
+    if (anchor_len_short) {
+        if ((rc = anchor_table(ctx, anchor_len, &P.anc_l))) return rc;
+        if ((rc = anchor_table(ctx, anchor_len_short, &P.anc_s))) return rc;
+    } else if ((rc = anchor_table(ctx, anchor_len, &P.anc_s))) return rc;
+    P.a_s = (uint32_t)(anchor_len_short ? anchor_len_short : anchor_len);
+    P.a_l = (uint32_t)anchor_len;
+    P.contigs = (const gf_contig*)d_contigs;
+    P.n_contigs = (const uint32_t*)d_n_contigs;
+    P.contig_cap = (uint32_t)contig_cap;
+    P.seq = (const char*)d_seq;
+    P.n_gaps = (uint32_t)ng;
+    P.gap_best = (unsigned long long*)d_gap_best;
+    P.n_closed = (uint32_t*)d_n_closed;
     LaunchTimer tm(ctx, GF_KERNEL_PICK);
-    hipLaunchKernelGGL(pick_anchor_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_contig*)d_contigs,
-                       (const uint32_t*)d_n_contigs, (uint32_t)contig_cap, (const char*)d_seq, (const uint8_t*)tab.p,
-                       (uint32_t)ng, (uint32_t)anchor_len, (unsigned long long*)d_gap_best, (uint32_t*)d_n_closed);
+    hipLaunchKernelGGL(pick_anchor_kernel, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, P);
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
+}
+
+int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
+                         int anchor_len, void* d_gap_best, void* d_n_closed) {
+    return gf_pick_anchored2_dev(ctx, d_contigs, d_n_contigs, contig_cap, d_seq, anchor_len, 0, d_gap_best, d_n_closed);
 }
 
 }  // extern "C"

@@ -345,6 +345,10 @@ int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const vo
  * that became non-zero. */
 int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
                          int anchor_len, void* d_gap_best, void* d_n_closed);
+/* both scores of the pipeline in ONE pass over the contigs (anchor_len_short < anchor_len; 0: anchor_len only): the same words as
+ * gf_pick_anchored_dev(anchor_len) followed by gf_pick_anchored_dev(anchor_len_short) leave in d_gap_best */
+int gf_pick_anchored2_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
+                          int anchor_len, int anchor_len_short, void* d_gap_best, void* d_n_closed);
 
 /* ---- §8f-3, first piece: the all-pairs k-mer prefilter of the reference's ContigsMerger (QuickCheckerContigsMatch,
  * ContigsCompactor.cpp:1982-2095, applied by CompactVer3 :836-853 / threadQuickCheck :1073-1098).  A contig SET (one per gap: its

@@ -167,12 +167,16 @@ def test_device_flank_anchoring_equals_the_oracle_picker():
     lib = B.lib()
     d_ctg, d_seq = _dev(ctg.view(np.uint8)), _dev(np.frombuffer(seq.encode(), dtype=np.uint8))
     d_n = torch.tensor([len(contigs)], dtype=torch.int32, device="cuda")
-    for scores in ((30, 15), (15, 30)):                     # the order of the calls does not matter: the longer anchor outranks
+    for scores in ((30, 15), (15, 30), "one pass"):         # the order of the calls does not matter: the longer anchor outranks
         d_best = torch.zeros(n_gaps, dtype=torch.int64, device="cuda")
         d_closed = torch.zeros(1, dtype=torch.int32, device="cuda")
-        for a in scores:
-            assert lib.gf_pick_anchored_dev(gf.handle, d_ctg.data_ptr(), d_n.data_ptr(), len(contigs), d_seq.data_ptr(), a, d_best.data_ptr(),
-                                            d_closed.data_ptr()) == 0
+        if scores == "one pass":                            # both scores in one launch (what bench.py's step runs)
+            assert lib.gf_pick_anchored2_dev(gf.handle, d_ctg.data_ptr(), d_n.data_ptr(), len(contigs), d_seq.data_ptr(), 30, 15, d_best.data_ptr(),
+                                             d_closed.data_ptr()) == 0
+        else:
+            for a in scores:
+                assert lib.gf_pick_anchored_dev(gf.handle, d_ctg.data_ptr(), d_n.data_ptr(), len(contigs), d_seq.data_ptr(), a, d_best.data_ptr(),
+                                                d_closed.data_ptr()) == 0
         gf.sync()
         best = d_best.cpu().numpy().view(np.uint64)
         n_closed = n_rev = n_15 = 0
