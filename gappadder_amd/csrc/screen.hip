@@ -19,6 +19,7 @@ struct FilterParams {
     uint64_t n_reads;
     uint32_t rb;       // bytes per read
     uint32_t stride2;  // 2 * stride (bits between probed 16-mers)
+    uint32_t first2;   // 2 * first: bit offset of the first probed 16-mer in a read (probe j sits at first + j * stride)
     uint32_t np;       // probes per read
     const uint32_t* bitmap;
     const uint32_t* sset;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
                         word[u] = 0;
                         hb[u] = 0;
                         if (j < g1) {
-                            const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
+                            const uint32_t key = canon16(stream32(tile, bit0 + P.first2 + j * P.stride2));
                             const uint32_t h = hash_s16_bitmap(key, P.bm_log2);
                             hb[u] = (h & 31) | (hash_s16_bit2(key) << 8);   // both bits of the key in its word
                             word[u] = h;                                    // (the level-1 word replaces it below)
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void screen_filter_kernel(FilterParams P) {
                 while (mask && !cand) {
                     const uint32_t j = g0 + __ffs(mask) - 1;
                     mask &= mask - 1;
-                    const uint32_t key = canon16(stream32(tile, bit0 + j * P.stride2));
+                    const uint32_t key = canon16(stream32(tile, bit0 + P.first2 + j * P.stride2));
                     uint32_t s = hash_s16_set(key, P.s_log2);
                     uint32_t v;
                     while ((v = P.sset[s]) != EMPTY32) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(512) void pf_scatter_kernel(PartParams Q, uint32_t 
         const bool live = r < P.n_reads;
         const uint32_t bit0 = lane * P.rb * 8;
         for (uint32_t j = 0; j < P.np; ++j) {
-            const uint32_t pk = canon16(stream32(tile, bit0 + j * P.stride2)) * S16_MUL;
+            const uint32_t pk = canon16(stream32(tile, bit0 + P.first2 + j * P.stride2)) * S16_MUL;
             const uint32_t bk = pk >> (32 - NB_LOG2);
             if (live) {   // a row has room: it held < 64 pairs and one probe adds at most 64
                 const uint32_t at = atomicAdd(&fill[bk], 1u);
@@ -499,7 +500,7 @@ constexpr uint32_t PF4_STAGE = 16;   // groups of fill history staged in LDS (on
 __device__ __forceinline__ bool pf4_read_has_key(const FilterParams& P, uint64_t r, uint32_t pk) {
     const uint8_t* rd = P.reads + r * P.rb;
     for (uint32_t j = 0; j < P.np; ++j) {
-        const uint32_t bit = j * P.stride2, by = bit >> 3, sh = bit & 7;
+        const uint32_t bit = P.first2 + j * P.stride2, by = bit >> 3, sh = bit & 7;
         uint64_t v = 0;
         for (uint32_t q = 0; q < 5; ++q) v = (v << 8) | ((by + q < P.rb) ? rd[by + q] : 0);
         const uint32_t w16 = (uint32_t)((v << sh) >> 8);
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
 #pragma unroll
                 for (uint32_t u = 0; u < PF2_GROUP; ++u) {
                     const bool on = live && j0 + u < P.np;
-                    pk[q][u] = on ? canon16(stream32(tiles + q * slice_words, bit0 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
+                    pk[q][u] = on ? canon16(stream32(tiles + q * slice_words, bit0 + P.first2 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
                     rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
                 }
             }
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(256) void pf4_resolve_kernel(Part4Params Q) {
             const uint64_t r = (uint64_t)octet * 8 + sub;
             bool hit = false;
             if (valid && r < P.n_reads)
-                for (uint32_t j = 0; j < P.np && !hit; ++j) hit = canon16(stream32(stg, sub * P.rb * 8 + j * P.stride2)) * S16_MUL == pk;
+                for (uint32_t j = 0; j < P.np && !hit; ++j) hit = canon16(stream32(stg, sub * P.rb * 8 + P.first2 + j * P.stride2)) * S16_MUL == pk;
             if (hit) atomicOr(&Q.seen[r >> 5], 1u << (r & 31));
             wave_lds_sync();
         }
@@ -949,7 +950,7 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
     const uint64_t total_bytes = P.n_reads * P.rb;
     const uint32_t n_tiles = (uint32_t)((P.n_reads + 63) / 64);
     const bool same = P.bm_log2 == P.lds_log2;
-    const bool bytes_ok = (P.stride2 & 7) == 0;
+    const bool bytes_ok = ((P.stride2 | P.first2) & 7) == 0;
     const uint32_t sh_lds = 32 - P.lds_log2, sh_bm = 32 - P.bm_log2;
     const uint32_t l2mask = same ? 0u : ~3u;
     const void* dummy = P.bitmap_lds;   // >= 16 readable bytes
@@ -1032,13 +1033,13 @@ __global__ __launch_bounds__(512) void screen_filter_pipe_kernel(FilterParams P,
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     const uint32_t jj = EXACT || (uint32_t)j < P.np ? (uint32_t)j : 0u;
-                    w32[j] = stream32_bytes(tile, rbase + ((jj * P.stride2) >> 3));
+                    w32[j] = stream32_bytes(tile, rbase + ((P.first2 + jj * P.stride2) >> 3));
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     const uint32_t jj = EXACT || (uint32_t)j < P.np ? (uint32_t)j : 0u;
-                    w32[j] = stream32(tile, rbase * 8 + jj * P.stride2);
+                    w32[j] = stream32(tile, rbase * 8 + P.first2 + jj * P.stride2);
                 }
             }
 #pragma unroll
@@ -1163,7 +1164,7 @@ struct VerifyParams {
     uint32_t* n_out;
     // window gate: the exact canonical-16-mer set and the filter's probe geometry (sset null = gate off)
     const uint32_t* sset;
-    uint32_t s_log2, stride, np;
+    uint32_t s_log2, stride, np, first;   // probed 16-mers: read offsets first + j * stride, j < np
     uint32_t batch;          // candidates per wave and pass (<= 64)
     // seed-and-extend kernel: occurrence lists and packed flanks (index.hip)
     const uint32_t* sval;
@@ -1225,8 +1226,8 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
             }
         }
         __syncthreads();
-        // Window gate.  A k-mer of the read can only equal a flank k-mer if the ONE stride-aligned 16-mer it contains
-        // (offset q * stride, q = ceil(p / stride); stride = k - 15) is a flank 16-mer.  Every lane looks its own
+        // Window gate.  A k-mer of the read can only equal a flank k-mer if the ONE probed 16-mer it contains
+        // (offset first + q * stride, q = ceil((p - first) / stride) or 0; stride = k - 15) is a flank 16-mer.  Every lane looks its own
         // candidate's np aligned 16-mers up in the exact set (three lookups in flight, four slots per request), so the
         // table below is only consulted around real 16-mer hits: a chance candidate costs ~k-15 table reads, not L-k+1.
         uint32_t my_gate = 0xFFFFFFFFu;
@@ -1240,7 +1241,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
                         const uint32_t q = q0 + u < P.np ? q0 + u : P.np - 1;
-                        key[u] = canon16(stream32(row, 2 * q * P.stride));
+                        key[u] = canon16(stream32(row, 2 * (P.first + q * P.stride)));
                         v[u] = *reinterpret_cast<const Slots4*>(P.sset + hash_s16_set(key[u], (int)P.s_log2));
                     }
 #pragma unroll
@@ -1275,7 +1276,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
                 for (int u = 0; u < 2; ++u) {
                     const uint32_t p = pp + lane + 64 * u;
                     act[u] = p < npos;
-                    if (gate && act[u]) act[u] = (gate_j >> ((p + P.stride - 1) / P.stride)) & 1u;
+                    if (gate && act[u]) act[u] = (gate_j >> (p <= P.first ? 0u : (p - P.first + P.stride - 1) / P.stride)) & 1u;
                     if (act[u] && P.nmask) {  // any N inside [p, p+k) ?
                         for (uint32_t q = p; q < p + P.k; ++q)
                             if ((P.nmask[(uint64_t)r * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { act[u] = false; break; }
@@ -1436,8 +1437,8 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
 }
 
 // ---- seed-and-extend verification (min_hits == 1, no repeat mask) -----------------------------------------------------
-// A read k-mer at offset p equals a flank k-mer (either strand) iff the ONE stride-aligned 16-mer inside it (read offset
-// q = ceil(p / stride) * stride) equals the 16-mer at the corresponding flank position AND the exact match extends from that
+// A read k-mer at offset p equals a flank k-mer (either strand) iff the ONE probed 16-mer inside it (read offset
+// first + q * stride) equals the 16-mer at the corresponding flank position AND the exact match extends from that
 // seed far enough to cover [p, p + k) inside the read, the flank's ACGT run and no read N.  So instead of hashing every
 // k-mer of a candidate into the 16-B/slot k-mer table (tens of MB: every lookup a fabric request), each aligned 16-mer that
 // is a flank 16-mer (exact set, 4 slots per request) is looked up in its occurrence list and the match is extended along
@@ -1544,7 +1545,7 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
                     const uint32_t q = q0 + u < P.np ? q0 + u : P.np - 1;
-                    key[u] = canon16(stream32(row, 2 * q * P.stride));
+                    key[u] = canon16(stream32(row, 2 * (P.first + q * P.stride)));
                     h[u] = hash_s16_set(key[u], (int)P.s_log2);
                     v[u] = *reinterpret_cast<const Slots4*>(P.sset + h[u]);
                 }
@@ -1577,7 +1578,7 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
             const uint32_t slot = slots[i];
             if (slot == EMPTY32) continue;
             const uint32_t* row = rows + j * rwp + 4;
-            const uint32_t qs = q * P.stride;
+            const uint32_t qs = P.first + q * P.stride;
             const uint32_t w16 = stream32(row, 2 * qs);
             const uint32_t key = canon16(w16);
             const bool ro = key != w16, pal = revpairs32(~key) == key;
@@ -1697,8 +1698,21 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     F.reads = (const uint8_t*)d_reads;
     F.n_reads = n_reads;
     F.rb = rb;
+    // Probed 16-mers of a read: offsets first + j * stride, stride = k - 15.  A k-mer at offset p in [0, L - k] covers the 16-mer
+    // offsets [p, p + stride - 1], so the probes must start at first <= k - 16 and reach L - k: np = floor((L - k) / stride) + 1 of
+    // them do — one fewer than probing from offset 0 to the end of the read whenever (L - 16) mod stride < k - 16 (150-base reads:
+    // k = 51: 3 instead of 4, k = 41: 5 instead of 6, k = 31: 8 instead of 9).  first = the byte-aligned offset closest below k - 16
+    // that still reaches (the pipelined kernel fetches byte-aligned probes faster).
+    const uint32_t np_probe = (uint32_t)((read_len - ix.k) / ix.stride + 1);
+    uint32_t first_probe = (uint32_t)(ix.k - 16);
+    {
+        const int lo = (read_len - ix.k) - (int)(np_probe - 1) * ix.stride;
+        const uint32_t al = first_probe & ~3u;
+        if ((int)al >= lo) first_probe = al;
+    }
     F.stride2 = 2 * ix.stride;
-    F.np = (uint32_t)((read_len - 16) / ix.stride + 1);
+    F.first2 = 2 * first_probe;
+    F.np = np_probe;
     if (ctx->screen_np_override >= 0) F.np = (uint32_t)ctx->screen_np_override;  // diagnostic (timing only)
     F.bitmap = ix.d_bitmap;
     F.sset = ix.d_sset;
@@ -1844,7 +1858,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.sset = (ctx->screen_verify_gate || ctx->screen_verify_ext) ? ix.d_sset : nullptr;
     V.s_log2 = ix.s_log2;
     V.stride = ix.stride;
-    V.np = (uint32_t)((read_len - 16) / ix.stride + 1);
+    V.np = np_probe;
+    V.first = first_probe;
     V.batch = (uint32_t)std::min(64, std::max(1, ctx->screen_verify_batch));
     const uint32_t npos = read_len - ix.k + 1;
     V.out = (gf_hit*)d_out;
