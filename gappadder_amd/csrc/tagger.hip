@@ -403,6 +403,18 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
     uint32_t words = 0;
     std::vector<uint32_t>& h = ctx->bin_host;
     build(shift, h, words);
+    // Many gaps on a large genome (human scale: 19 840 windows over 3.1 Gb) leave a 16-KiB map with 24-kb bins, a fifth of them
+    // set: then a 64-KiB map (6-kb bins, a twentieth set) shared by ONE 16-wave workgroup per CU takes its place — the same 16 waves
+    // and 132 KiB of LDS per CU as four 4-wave workgroups with 16 KiB each (which is why a 64-KiB map per 4-wave workgroup lost:
+    // half the waves).  Only when the option was left at its default.
+    if (ctx->tag_bins_log2 == 17 && shift > 8) {
+        uint64_t set0 = 0;
+        for (uint32_t i = 0; i < words; ++i) set0 += (uint64_t)__builtin_popcount(h[i]);
+        if (set0 * 10 > nbits(shift)) {
+            while (shift > 6 && nbits(shift - 1) <= (1u << 19)) --shift;
+            build(shift, h, words);
+        }
+    }
     int rc = ensure(ctx, ctx->binmap, h.size() * 4);
     if (rc) return rc;
     GF_HIP(ctx, hipMemcpyAsync(ctx->binmap.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -471,6 +483,9 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
         LaunchTimer tm(ctx, GF_KERNEL_TAG);
         if (ctx->tag_light)   // one-wave workgroups without the LDS bin map: co-resident with the k-mer filter's workgroups
             hipLaunchKernelGGL((tag_kernel<1, false>), dim3(4 * stream_grid(ctx, n)), dim3(64), 0, ctx->stream, P);
+        else if ((size_t)ctx->bin_words * 4 > 32 * 1024)   // the 64-KiB map: one 16-wave workgroup per CU
+            hipLaunchKernelGGL((tag_kernel<16, true, true>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + 1023) / 1024, (size_t)ctx->n_cu))), dim3(1024),
+                               (size_t)ctx->bin_words * 4, ctx->stream, P);
         else if (ctx->tag_nt)
             hipLaunchKernelGGL((tag_kernel<4, true, true>), dim3(stream_grid(ctx, n)), dim3(256), (size_t)ctx->bin_words * 4, ctx->stream, P);
         else
