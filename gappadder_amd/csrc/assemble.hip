@@ -8,7 +8,7 @@
 // for any k <= 64 and a key is re-derived from the staged reads when slots are compared.
 //   P1 count      bit-array pre-count (k-mers seen fewer than min_count times never enter the table), then every remaining k-mer
 //                 window -> canonical -> table (key / fingerprint / instance-id slots, ranked behind the pre-count)
-//   P2 survivors  slots with count >= min_count -> compacted instance list (bit 31: the k-mer is WEAK, count <= min_count)
+//   P2 survivors  slots with count >= min_count -> compacted instance list (bit 31: the k-mer is WEAK, count <= min_count + 1)
 //   P3 graph      each survivor contributes k-kv+1 kv-mer nodes and k-kv edges (4+4 adjacency bits per node); dense node indices
 //   P4 links      unitig-internal edges; oriented nodes that no internal edge enters start a unitig
 //   ER            error removal rounds: tip clipping + bubble popping on snapshots of the graph (heads walk their unitigs)
@@ -68,7 +68,7 @@ constexpr uint32_t ASM_ERR_IDS = 1, ASM_ERR_KTABLE = 2, ASM_ERR_NTABLE = 4, ASM_
 
 // node meta bits (high word of a table slot in the graph phases)
 constexpr uint32_t M_OUT = 0xFu, M_IN = 0xF0u, M_START0 = 1u << 8, M_START1 = 1u << 9, M_MULT_SHIFT = 14;
-// WEAK = one of the surviving k-mers the node came from was seen no more often than min_count (the tie-break of the error removal)
+// WEAK = one of the surviving k-mers the node came from was seen at most min_count + 1 times (the tie-break of the error removal)
 constexpr uint32_t M_WEAK = 1u << 13, INST_WEAK = 1u << 31;
 // error removal: KILL = the unitig this node heads is removed in this round; DEADMARK -> DEAD = the node is gone
 constexpr uint32_t M_KILL = 1u << 10, M_DEADMARK = 1u << 11, M_DEAD = 1u << 12;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
             // wide variant (32 < k <= 63): a 16-byte slot = {hi, ~(lo | count)}, see count_keyslot_wide below.  Only for the
             // global table: in LDS the doubled slot size overflows pools that the 8-byte instance-id slots still hold
             // (measured at k=41, 214-read pools: 161 us against 105 us per gap).
-            const bool wide_ok = P.keyslot && W && k > 32 && k <= 63 && P.min_count <= 3 && !P.cnt_keys;
+            const bool wide_ok = P.keyslot && W && k > 32 && k <= 62 && P.min_count <= 3 && !P.cnt_keys;   // (k <= 62: three spare bits in the 16-byte slot)
             keyslot_w = wide_ok && !use_lds;
             // fingerprint slots (32 < k <= 63 in an LDS table over an LDS-staged pool): slot = instance id | 30-bit key fingerprint
             // << 32 | 2-bit saturating count << 62.  A probe that meets another key sees it in the fingerprint (no re-derivation of
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                         const uint32_t rnk = reinterpret_cast<const uint16_t*>(fin + pre_words)[b >> 5] + (uint32_t)__popc(word & ((1u << (b & 31)) - 1u));
                         unsigned long long v = t.load(rnk);
                         if (v == kempty) {
-                            v = t.cas(rnk, kempty, (keyhi | 1ull) ^ xm);
+                            v = t.cas(rnk, kempty, keyhi ^ xm);
                             if (v == kempty) {   // first occurrence
                                 const uint32_t q = atomicAdd(&s_cnt[4], 1u);
                                 if (q < n_unit) { list_a[q] = rnk; dist_inst[q] = make_inst(r, p); }
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                             }
                         }
                         if (((v ^ xm) & ~3ull) == keyhi) {
-                            while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment
+                            while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment (the field holds count - 1: saturates at 4 occurrences)
                                 const unsigned long long o = t.cas(rnk, v, ((v ^ xm) + 1) ^ xm);
                                 if (o == v) break;
                                 v = o;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                     for (uint32_t probes = 0; probes < n_sl; ++probes) {
                         unsigned long long v = t.load(sl);
                         if (v == kempty) {
-                            v = t.cas(sl, kempty, (keyhi | 1ull) ^ xm);
+                            v = t.cas(sl, kempty, keyhi ^ xm);
                             if (v == kempty) {   // first occurrence
                                 const uint32_t q = atomicAdd(&s_cnt[4], 1u);
                                 if (LDS && ranked) { if (atomicAdd(&s_cnt[7], 1u) >= ovf_cap - ovf_cap / 4) s_cnt[6] = 1; }
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                             }
                         }
                         if (((v ^ xm) & ~3ull) == keyhi) {
-                            while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment
+                            while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment (the field holds count - 1: saturates at 4 occurrences)
                                 const unsigned long long o = t.cas(sl, v, ((v ^ xm) + 1) ^ xm);
                                 if (o == v) break;
                                 v = o;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                     for (uint32_t probes = 0; probes < t.cap; ++probes) {
                         if (probes) v = t.load(sl);
                         if (v == kempty) {
-                            v = t.cas(sl, kempty, (keyhi | 1ull) ^ xm);
+                            v = t.cas(sl, kempty, keyhi ^ xm);
                             if (v == kempty) {   // first occurrence
                                 const uint32_t q = atomicAdd(&s_cnt[4], 1u);
                                 if (q >= limit) s_cnt[6] = 1;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                             }
                         }
                         if (((v ^ xm) & ~3ull) == keyhi) {
-                            while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment
+                            while (((v ^ xm) & 3ull) != 3ull) {   // saturating increment (the field holds count - 1: saturates at 4 occurrences)
                                 const unsigned long long o = t.cas(sl, v, ((v ^ xm) + 1) ^ xm);
                                 if (o == v) break;
                                 v = o;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                                 // goes — a full agent-scope release (L2 write-back) here cost 5x the whole phase
                                 if (LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                put(2 * sl + 1, ~(key.lo | 1ull));
+                                put(2 * sl + 1, ~(key.lo | 1ull));   // (3-bit count field, 1..4)
                                 const uint32_t q = atomicAdd(&s_cnt[4], 1u);
                                 if (q >= limit_k) s_cnt[6] = 1;
                                 if (q < n_unit) { list_a[q] = sl; dist_inst[q] = inst; }
@@ -840,8 +840,8 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                         if (b == LOCK) { retry = true; break; }
                         asm volatile("" ::: "memory");          // word 0 is read after word 1 was seen published
                         const unsigned long long a = a_valid ? a_pre : t.load(2 * sl);
-                        if (a == key.hi && (~b & ~3ull) == key.lo) {
-                            while ((~b & 3ull) != 3ull) {   // saturating increment of the complemented count
+                        if (a == key.hi && (~b & ~7ull) == key.lo) {
+                            while ((~b & 7ull) != 4ull) {   // saturating increment of the complemented count
                                 const unsigned long long o = t.cas(2 * sl + 1, b, b - 1);
                                 if (o == b) break;
                                 b = o;
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                 for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128& fw, const K128& rc) -> bool {
                     const uint64_t x = hash_p1<W>(key);
                     const unsigned long long fp = (x >> 34) << 32;                    // 30 bits, in place
-                    const unsigned long long mine = (1ull << 62) | fp | make_inst(r, p);
+                    const unsigned long long mine = fp | make_inst(r, p);   // (count - 1 = 0 in bits 62..63)
                     uint32_t sl, lo_sl = 0, n_sl = tab.cap;                            // probe region [lo_sl, lo_sl + n_sl)
                     if (ranked) {
                         const uint32_t b = (uint32_t)(x >> 32) >> (32 - pre_log2);
@@ -982,11 +982,12 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                 uint32_t id = 0, c = 0;
                 if (in[u]) {
                     id = (keyslot || keyslot_w) ? idv[u] : (uint32_t)v[u];
-                    c = fpslot_used ? (uint32_t)(v[u] >> 62)
-                        : keyslot_w ? (uint32_t)(~v[u] & 3ull)
-                        : keyslot ? (uint32_t)((tab_global ? ~v[u] : (GF_KS_COMPLEMENT_LDS ? ~v[u] : v[u])) & 3ull) : (uint32_t)(v[u] >> 32);
+                    // occurrences, saturating at 4 in the slot forms (their 2-bit fields hold count - 1, the wide slot 1..4)
+                    c = fpslot_used ? (uint32_t)(v[u] >> 62) + 1u
+                        : keyslot_w ? (uint32_t)(~v[u] & 7ull)
+                        : keyslot ? (uint32_t)((tab_global ? ~v[u] : (GF_KS_COMPLEMENT_LDS ? ~v[u] : v[u])) & 3ull) + 1u : (uint32_t)(v[u] >> 32);
                     keep = c >= P.min_count;
-                    if (!P.cnt_keys && (c < 3u ? c : 3u) <= P.min_count) id |= INST_WEAK;   // (counts saturate at 3: the 2-bit counters)
+                    if (!P.cnt_keys && (c < 4u ? c : 4u) <= P.min_count + 1) id |= INST_WEAK;   // (counts saturate at 4: the slots' 2-bit counters)
                     if (tab_global) {
                         if (keyslot_w) { tab.store(2 * sl[u], EMPTY64); tab.store(2 * sl[u] + 1, EMPTY64); }
                         else tab.store(sl[u], EMPTY64);

@@ -551,7 +551,7 @@ size_t or_count_kmers(const char* reads, size_t n_reads, int L, int k, int min_c
     return w;
 }
 
-/* weak: one of the surviving k-mers the node came from was seen no more often than min_count (counts saturate at 3, like the
+/* weak: one of the surviving k-mers the node came from was seen at most min_count + 1 times (counts saturate at 4, like the
  * kernel's 2-bit counters: with min_count >= 3 every node is weak and the rule below is void) */
 typedef struct { k128 key; uint32_t mult; uint8_t out, in, dead, weak; } or_node;
 static long node_find(const or_node* nd, size_t n, k128 key) {
@@ -641,8 +641,8 @@ static void graph_unitigs(or_graph* G) {
 /* Velvet's default error removal (velvetg without -cov_cutoff: tip clipping + Tour Bus bubble popping), DEFINED
  * here on the unitig graph — Velvet itself is absent, and its coverage-based choices are coin flips on this input where every
  * surviving k-mer is one read (assemble_gaps.py:104-118), so ties are broken — north_star: "for fixed tie-breaking" — first by the
- * evidence the k-mer counts still hold (a sequencing error that made it past min_count was seen exactly min_count times, the true
- * sequence many more: the side with FEWER WEAK nodes stays), then by an orientation-free sequence order:
+ * evidence the k-mer counts still hold (a sequencing error that made it past min_count was seen min_count times, rarely once more,
+ * the true sequence many more: the side with FEWER WEAK nodes stays), then by an orientation-free sequence order:
  *   X beats Y  :=  (cov X, then fewer weak nodes, then the SMALLER ukey) wins, preceded by (nodes) where lengths can differ.
  * One round decides on ONE snapshot of the graph, for every oriented unitig X (head h, tail t, n nodes):
  *  TIP     out-degree(t) == 0, in-degree(h) == 1 with predecessor p of out-degree >= 2, n <= kv (i.e. n + kv - 1 < 2 kv bases:
@@ -760,7 +760,7 @@ size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv
         i = j;
     }
     for (size_t s = 0; s < ns; ++s) { /* weak k-mers mark their nodes */
-        if ((cn[s] < 3 ? cn[s] : 3u) > (uint32_t)(min_count < 1 ? 1 : min_count)) continue;
+        if ((cn[s] < 4 ? cn[s] : 4u) > (uint32_t)(min_count < 1 ? 1 : min_count) + 1u) continue;
         k128 t = {hi[s], lo[s]};
         for (int o = 0; o < per; ++o) nd[node_find(nd, nn, k128_canon(k128_sub(t, o, kv), kv, NULL))].weak = 1;
     }

@@ -223,10 +223,10 @@ def test_sequencing_errors_seen_twice_no_longer_split_the_gap_contig():
     assert best is not None and best <= 10
 
 
-def test_an_error_seen_exactly_min_count_times_loses_the_bubble_to_the_true_allele():
-    """The tie-break of the error removal: every surviving k-mer is ONE read for the graph, so a substitution error that two reads
-    share (count 2 = min_count) opens a bubble whose sides tie on node count and coverage; the side with fewer WEAK nodes — k-mers
-    seen no more often than min_count — stays, whichever of the two sequences is the smaller one."""
+def test_an_error_seen_at_most_min_count_plus_one_times_loses_the_bubble_to_the_true_allele():
+    """The tie-break of the error removal: every surviving k-mer is ONE read for the graph, so a substitution error that two or three
+    reads share opens a bubble whose sides tie on node count and coverage; the side with fewer WEAK nodes — k-mers seen at most
+    min_count + 1 times — stays, whichever of the two sequences is the smaller one."""
     rng = np.random.RandomState(31)
     L = 100
     n_true = 0
@@ -234,17 +234,18 @@ def test_an_error_seen_exactly_min_count_times_loses_the_bubble_to_the_true_alle
         g = LUT[rng.randint(0, 4, 700)].tobytes()
         h = _mut(g, 350, 1 + trial % 3)
         err_read = h[300:400]
-        reads = _cover(g, L) + [err_read, rc(err_read)]                 # the error allele is seen exactly twice
-        raw = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=0)
-        assert len(raw) == 4
-        ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=2)
-        assert len(ctg) == 1 and ctg[0][0].encode() in (g, rc(g)), trial
-        # seen three times the error is no longer weak: the sequence order decides again (either allele, whole)
-        ctg3 = CO.assemble_pool(b"".join(reads + [err_read]), L, 31, 29, simplify=2)
-        assert len(ctg3) == 1 and ctg3[0][0].encode() in (g, rc(g), h, rc(h))
-        n_true += ctg3[0][0].encode() in (g, rc(g))
+        for copies in ([err_read, rc(err_read)], [err_read, rc(err_read), err_read]):       # the error allele seen twice / three times
+            reads = _cover(g, L) + copies
+            raw = CO.assemble_pool(b"".join(reads), L, 31, 29, min_contig=29, simplify=0)
+            assert len(raw) == 4
+            ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=2)
+            assert len(ctg) == 1 and ctg[0][0].encode() in (g, rc(g)), (trial, len(copies))
+        # seen four times the error is no longer weak (the counters saturate there): the sequence order decides again (either allele, whole)
+        ctg4 = CO.assemble_pool(b"".join(reads + [err_read]), L, 31, 29, simplify=2)
+        assert len(ctg4) == 1 and ctg4[0][0].encode() in (g, rc(g), h, rc(h))
+        n_true += ctg4[0][0].encode() in (g, rc(g))
     assert 0 < n_true < 12                                              # ... and that order is not the truth's
-    # min_count 3: the 2-bit counters saturate there, every k-mer is weak and the rule is void (defined, checked on the GPU too)
+    # min_count 3: the 2-bit counters saturate at min_count + 1, every k-mer is weak and the rule is void (defined, checked on the GPU too)
     reads3 = _cover(g, L) + [err_read, rc(err_read), err_read]
     c3 = max(CO.assemble_pool(b"".join(reads3), L, 31, 29, min_count=3, simplify=2), key=lambda c: len(c[0]))[0].encode()
     assert len(c3) > 600 and any(x[320:380] in c3 for x in (g, rc(g), h, rc(h)))

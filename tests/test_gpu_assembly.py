@@ -283,8 +283,8 @@ def test_random_error_graphs_match_oracle(gf):
 
 @pytest.mark.parametrize("kk,L", [((31, 29), 100), ((51, 49), 150), ((41, 37), 150)])
 def test_weak_kmers_lose_the_ties_of_the_error_removal(gf, kk, L):
-    """An error seen exactly min_count times against the true allele (oracle: test_an_error_seen_exactly_min_count_times_...): the
-    kernel keeps the true allele like the oracle — key-slot, fingerprint and instance-id count tables (k 31 / 51, kv = k - 4 runs
+    """An error seen two, three and four times against the true allele (oracle: test_an_error_seen_at_most_min_count_plus_one_...):
+    the kernel keeps the true allele like the oracle — key-slot, fingerprint and instance-id count tables (k 31 / 51, kv = k - 4 runs
     without node fingerprints), LDS and global plans, min_count 2 and 3 (void rule) and 1."""
     from test_assembly_oracle import _cover, _mut
     rng = np.random.RandomState(41)
@@ -293,7 +293,7 @@ def test_weak_kmers_lose_the_ties_of_the_error_removal(gf, kk, L):
         g = LUT[rng.randint(0, 4, 900)].tobytes()
         h = _mut(g, 450, 1 + trial % 3)
         err = h[450 - L // 2:450 + L // 2]
-        reads = _cover(g, L) + [err, rc(err)] + ([err] if trial >= 12 else [])
+        reads = _cover(g, L) + [err, rc(err)] + [err] * (0 if trial < 6 else 1 if trial < 12 else 2)    # seen 2 / 3 / 4 times
         pools.append(b"".join(reads))
         truth.append(g)
     for mc in (2, 3, 1):
