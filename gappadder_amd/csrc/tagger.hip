@@ -25,6 +25,7 @@ struct TagParams {
     const uint32_t* bin_bits;
     const uint32_t* bin_off;  // n_scaffolds + 1
     uint32_t bin_shift, bin_words;
+    uint32_t off_words;       // > 0: the n_scaffolds + 1 offsets follow the bits in the staged LDS copy as well
     // fine bin map (global, L2-resident, <= 4 MiB): same test on narrower bins for the records the LDS map lets through.
     // Only built when the LDS map's bins are wide (large genomes, many gaps); null otherwise.
     const uint32_t* fine_bits;
@@ -90,6 +91,12 @@ __device__ __forceinline__ void flush_hits(HB& hb, gf_taghit* out, uint32_t cap,
 // Even lanes run the coarse bin test; the rare survivors pull their second half from the neighbour lane.
 struct LiveRec { uint32_t pos, ref, mate_ref, meta; int32_t tlen; uint32_t rec; };   // a record that passed the bin map
 constexpr uint32_t LIVEQ = 96;   // per wave: < 64 waiting + <= 32 from one 1-KiB load
+// With a second, finer map in global memory (human scale) the records that pass the LDS map (a twentieth) are not looked up in it on
+// the spot — nearly every 1-KiB step has such a lane, and the whole wave then waits for two dependent global loads (PMC: waves wait
+// 79 % of their cycles in a kernel that only streams) — but queued with 12 bytes each and sifted 64 at a time; the few that pass
+// load their record again and join the queue of the window search.
+struct CandRec { uint32_t pos, ref, rec; };
+constexpr uint32_t CANDQ = 96;
 __device__ __forceinline__ void tag_wave_sync() {   // LDS hand-off between lanes of ONE wave (in-order LDS: compiler fence only)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -100,17 +107,19 @@ constexpr int TAG_UNROLL = 8;  // 8 KiB (256 records) per wave and stage, two st
 // human scale); BINS_LDS = false reads it through L1/L2 instead and runs one-wave workgroups with ~6 KiB of LDS, so that the
 // tagger's workgroups fit on the CUs NEXT TO the k-mer filter's (which own 137-151 KiB of every CU's LDS but leave most of its
 // issue slots idle: PMC SQ_WAIT_ANY 53-77 %) — the "light" variant a pipeline launches on its second stream.
-template <int NW, bool BINS_LDS, bool NT = false>
+template <int NW, bool BINS_LDS, bool NT = false, bool FINEQ = false>
 __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
-    extern __shared__ uint32_t bins_lds[];  // the whole bin map (<= 16 KiB), staged once per workgroup
-    __shared__ HitBufT<128 * NW> hb;
-    constexpr uint32_t LOWBUF = 128;    // MAPQ==0 records buffered per wave (one global atomic per ~64-128 of them)
+    extern __shared__ uint32_t bins_lds[];  // the whole bin map (16 or 64 KiB), staged once per workgroup
+    __shared__ HitBufT<(NW > 4 ? 64 : 128) * NW> hb;
+    constexpr uint32_t LOWBUF = NW > 4 ? 96 : 128;    // MAPQ==0 records buffered per wave (one global atomic per ~64-128 of them)
     __shared__ gf_lowrec lowbuf[NW][LOWBUF];
     __shared__ LiveRec liveq[NW][LIVEQ];
+    __shared__ CandRec candq[FINEQ ? NW : 1][FINEQ ? CANDQ : 1];
     uint32_t low_n = 0;                 // wave-uniform
     if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
-    if (BINS_LDS) for (uint32_t i = threadIdx.x; i < P.bin_words; i += blockDim.x) bins_lds[i] = P.bin_bits[i];
+    if (BINS_LDS) for (uint32_t i = threadIdx.x; i < P.bin_words + P.off_words; i += blockDim.x) bins_lds[i] = P.bin_bits[i];   // (bits, then offsets: one array)
     const uint32_t* bins = BINS_LDS ? bins_lds : P.bin_bits;
+    const uint32_t* boff = BINS_LDS && P.off_words ? bins_lds + P.bin_words : P.bin_off;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     gf_lowrec* wlow = lowbuf[threadIdx.x >> 6];
@@ -187,6 +196,35 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
     const uint64_t n_half = 2 * P.n;                       // 16-byte halves
     const uint64_t chunk = 64ull * TAG_UNROLL;             // halves per wave iteration
     const uint4* src = reinterpret_cast<const uint4*>(P.recs);
+    // ---- per-wave queue of records that passed the LDS map and wait for the fine map (FINEQ)
+    CandRec* wcand = candq[FINEQ ? threadIdx.x >> 6 : 0];
+    uint32_t cand_n = 0;   // wave-uniform
+    auto sift = [&]() {    // fine-map test of the last min(64, cand_n) queued records, one per lane
+        const uint32_t base = cand_n > 64 ? cand_n - 64 : 0;
+        bool live = base + lane < cand_n;
+        CandRec c = {};
+        if (live) {
+            c = wcand[base + lane];
+            const uint32_t f0 = P.fine_off[c.ref], fi = c.pos >> P.fine_shift, fb = f0 + fi;
+            live = fi < P.fine_off[c.ref + 1] - f0 && ((P.fine_bits[fb >> 5] >> (fb & 31)) & 1u);
+        }
+        tag_wave_sync();
+        cand_n = base;
+        const unsigned long long lb = __ballot(live);
+        if (lb) {
+            const uint32_t cnt = (uint32_t)__popcll(lb);
+            if (live_n + cnt > LIVEQ) drain();             // (live_n < 64 on entry: one drain makes room)
+            if (live) {
+                const uint4 a = src[2 * (uint64_t)c.rec], b = src[2 * (uint64_t)c.rec + 1];
+                LiveRec q;
+                q.pos = a.x; q.ref = a.w; q.tlen = (int32_t)a.z; q.mate_ref = b.x; q.meta = b.y; q.rec = c.rec;
+                wlive[live_n + __popcll(lb & ((1ull << lane) - 1))] = q;
+            }
+            live_n += cnt;
+            tag_wave_sync();
+            if (live_n >= 64) drain();
+        }
+    };
     // software pipeline: the next chunk's loads are issued before the current chunk is processed
     uint4 vn[TAG_UNROLL];
     auto fetch = [&](uint64_t h0) {
@@ -231,8 +269,17 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
                 }
             }
             if (live) {  // coarse test first: almost every record lies far from every gap
-                const uint32_t b0 = P.bin_off[r.ref], nbin = P.bin_off[r.ref + 1] - b0, bi = r.pos >> P.bin_shift;
+                const uint32_t b0 = boff[r.ref], nbin = boff[r.ref + 1] - b0, bi = r.pos >> P.bin_shift;
                 live = bi < nbin && ((bins[(b0 + bi) >> 5] >> ((b0 + bi) & 31)) & 1u);
+            }
+            if (FINEQ) {   // (launched with FINEQ only when the fine map exists)
+                const unsigned long long cb = __ballot(live);
+                if (!cb) continue;
+                if (live) wcand[cand_n + __popcll(cb & ((1ull << lane) - 1))] = CandRec{r.pos, r.ref, (uint32_t)(h >> 1)};
+                cand_n += (uint32_t)__popcll(cb);   // < 64 + 32 <= CANDQ
+                tag_wave_sync();
+                if (cand_n >= 64) sift();
+                continue;
             }
             if (live && P.fine_bits) {
                 const uint32_t f0 = P.fine_off[r.ref], fi = r.pos >> P.fine_shift, fb = f0 + fi;
@@ -252,6 +299,7 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
             if (live_n >= 64) drain();
         }
     }
+    if (FINEQ) while (cand_n) sift();
     while (live_n) drain();
     if (P.low && low_n) flush_low();
     flush_hits(hb, P.out, P.cap, P.n_out);
@@ -476,6 +524,8 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
     P.bin_off = P.bin_bits + ctx->bin_words;
     P.bin_shift = ctx->bin_shift;
     P.bin_words = ctx->bin_words;
+    P.off_words = ctx->n_scaffolds + 1 <= 2048 ? ctx->n_scaffolds + 1 : 0;   // the per-scaffold offsets ride along in LDS when they are few
+    const size_t lds_map = ((size_t)ctx->bin_words + P.off_words) * 4;
     P.fine_bits = ctx->fine_words ? (const uint32_t*)ctx->binmap_fine.p : nullptr;
     P.fine_off = P.fine_bits ? P.fine_bits + ctx->fine_words : nullptr;
     P.fine_shift = ctx->fine_shift;
@@ -483,13 +533,18 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
         LaunchTimer tm(ctx, GF_KERNEL_TAG);
         if (ctx->tag_light)   // one-wave workgroups without the LDS bin map: co-resident with the k-mer filter's workgroups
             hipLaunchKernelGGL((tag_kernel<1, false>), dim3(4 * stream_grid(ctx, n)), dim3(64), 0, ctx->stream, P);
-        else if ((size_t)ctx->bin_words * 4 > 32 * 1024)   // the 64-KiB map: one 16-wave workgroup per CU
-            hipLaunchKernelGGL((tag_kernel<16, true, true>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + 1023) / 1024, (size_t)ctx->n_cu))), dim3(1024),
-                               (size_t)ctx->bin_words * 4, ctx->stream, P);
+        else if ((size_t)ctx->bin_words * 4 > 32 * 1024 && P.fine_bits)   // the 64-KiB map: one 16-wave workgroup per CU
+            hipLaunchKernelGGL((tag_kernel<16, true, true, true>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + 1023) / 1024, (size_t)ctx->n_cu))), dim3(1024),
+                               lds_map, ctx->stream, P);
+        else if ((size_t)ctx->bin_words * 4 > 32 * 1024)
+            hipLaunchKernelGGL((tag_kernel<16, true, true, false>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + 1023) / 1024, (size_t)ctx->n_cu))), dim3(1024),
+                               lds_map, ctx->stream, P);
+        else if (ctx->tag_nt && P.fine_bits)
+            hipLaunchKernelGGL((tag_kernel<4, true, true, true>), dim3(stream_grid(ctx, n)), dim3(256), lds_map, ctx->stream, P);
         else if (ctx->tag_nt)
-            hipLaunchKernelGGL((tag_kernel<4, true, true>), dim3(stream_grid(ctx, n)), dim3(256), (size_t)ctx->bin_words * 4, ctx->stream, P);
+            hipLaunchKernelGGL((tag_kernel<4, true, true>), dim3(stream_grid(ctx, n)), dim3(256), lds_map, ctx->stream, P);
         else
-            hipLaunchKernelGGL((tag_kernel<4, true>), dim3(stream_grid(ctx, n)), dim3(256), (size_t)ctx->bin_words * 4, ctx->stream, P);
+            hipLaunchKernelGGL((tag_kernel<4, true>), dim3(stream_grid(ctx, n)), dim3(256), lds_map, ctx->stream, P);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
