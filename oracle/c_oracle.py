@@ -155,9 +155,9 @@ def count_kmers(reads_blob, read_len, k, min_count=2):
     return hi[:m], lo[:m], cnt[:m]
 
 
-def assemble_pool(reads_blob, read_len, k, kv, min_count=2, min_contig=40, simplify=2):
-    """[(sequence, n_nodes, cov_sum)] sorted by (-length, sequence).  simplify = rounds of tip clipping + bubble popping
-    (2: the product's default, Velvet's defaults on; 0: raw unitigs)."""
+def assemble_pool(reads_blob, read_len, k, kv, min_count=2, min_contig=40, simplify=8):
+    """[(sequence, n_nodes, cov_sum)] sorted by (-length, sequence).  simplify = rounds of tip clipping + bubble popping, stopping
+    when a round removes nothing (8: the product's default = to convergence in practice, Velvet's defaults on; 0: raw unitigs)."""
     n = len(reads_blob) // read_len
     cap = max(16, n * (read_len - k + 1))
     nn = np.zeros(cap, np.uint32); ln = np.zeros(cap, np.uint32); cv = np.zeros(cap, np.uint32)

@@ -123,7 +123,7 @@ def test_deep_noisy_pool(gf, n_reads, kk):
     try:
         raw, _ = _gpu_assemble(gf, [pool], L, kk)
     finally:
-        gf.set_option("asm_simplify", 2)
+        gf.set_option("asm_simplify", 8)
     for (k, kv) in kk:
         exp = CO.assemble_pool(pool, L, k, kv, simplify=0)
         assert len(exp) > 20, (k, kv)
@@ -249,7 +249,7 @@ def test_error_removal_known_answers_on_gpu(gf, simplify):
             snp = [b"".join(r) for (l, k2, r) in _kat_pools() if l == 100][0]
             assert len(_gpu_assemble(gf, [snp], 100, [(31, 29)])[0][(0, 31, 29)]) == 1     # the SNP bubble is one contig now
     finally:
-        gf.set_option("asm_simplify", 2)
+        gf.set_option("asm_simplify", 8)
 
 
 def test_random_error_graphs_match_oracle(gf):
