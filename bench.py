@@ -630,10 +630,10 @@ def child_run(argv):
 
 
 def pmc_traffic(config, reads_per_launch, L, k):
-    """Bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_traffic_<config>.json: rocprofv3 --pmc
+    """Bytes per launch of the dominant kernel from the committed PMC passes (profiles/r03_traffic_<config>.json: rocprofv3 --pmc
     FETCH_SIZE and WRITE_SIZE in separate runs of this same command, gfx950 x2 correction applied to FETCH_SIZE).  Counters
     cannot be collected from inside the timed run; null when no committed profile matches this configuration."""
-    for name in ("r02_traffic_%s.json" % config.lower(), "r01_traffic.json"):
+    for name in ("r03_traffic_%s.json" % config.lower(), "r02_traffic_%s.json" % config.lower()):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             if t["reads_per_launch"] == reads_per_launch and t["read_len"] == L and t["k"] == k:
