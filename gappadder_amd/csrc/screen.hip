@@ -540,6 +540,9 @@ __device__ __forceinline__ void pf4_resolve_octet_serial(const Part4Params& Q, u
         if (r < P.n_reads && pf4_read_has_key(P, r, pk)) atomicOr(&Q.seen[r >> 5], 1u << (r & 31));
     }
 }
+// G = probes sorted per group: PF2_GROUP, or the read's whole probe count when that is smaller (k = 51: three — a fourth, dead probe
+// slot costs every lane its instructions all the same)
+template <uint32_t G>
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params Q, uint32_t slice_words) {
     extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][keys: BATCH x 4 B][octets: BATCH x 1 B][fill stage 256 x 17][hist 3 x 256][offs 258][written 2 x 256]
     const FilterParams& P = Q.F;
@@ -617,15 +620,15 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
         wave_lds_sync();
         prefetch(t0 + t_step);
         const uint32_t bit0 = lane * P.rb * 8;
-        for (uint32_t j0 = 0; j0 < P.np; j0 += PF2_GROUP, ++g) {
+        for (uint32_t j0 = 0; j0 < P.np; j0 += G, ++g) {
             uint32_t* hist = hist3 + hsel * PF2_NB;        // all zero (start / zeroed during the copy-out before last)
             const uint32_t* written = written2 + wsel * PF2_NB;
-            uint32_t pk[PF2_TILES][PF2_GROUP], rank[PF2_TILES][PF2_GROUP];
+            uint32_t pk[PF2_TILES][G], rank[PF2_TILES][G];
 #pragma unroll
             for (uint32_t q = 0; q < PF2_TILES; ++q) {
                 const bool live = t0 + q < n_tiles && (t0 + q) * 64 + lane < P.n_reads;
 #pragma unroll
-                for (uint32_t u = 0; u < PF2_GROUP; ++u) {
+                for (uint32_t u = 0; u < G; ++u) {
                     const bool on = live && j0 + u < P.np;
                     pk[q][u] = on ? canon16(stream32(tiles + q * slice_words, bit0 + P.first2 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
                     rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
 #pragma unroll
             for (uint32_t q = 0; q < PF2_TILES; ++q)
 #pragma unroll
-                for (uint32_t u = 0; u < PF2_GROUP; ++u)
+                for (uint32_t u = 0; u < G; ++u)
                     if (rank[q][u] != EMPTY32) {
                         const uint32_t at = offs[pk[q][u] >> (32 - PF2_NB_LOG2)] + rank[q][u];
                         skey[at] = pk[q][u];
@@ -1767,7 +1770,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.n_writers = (uint32_t)std::min<size_t>(std::min<size_t>((tiles64 + tiles_wg - 1) / tiles_wg, (size_t)ctx->n_cu), 256);   // the pair list carries the writer in 8 bits
         Q.tiles_wg = (uint32_t)tiles_wg;
         const size_t n_iter = (tiles64 + (size_t)Q.n_writers * tiles_wg - 1) / ((size_t)Q.n_writers * tiles_wg);
-        Q.n_grp = (F.np + PF2_GROUP - 1) / PF2_GROUP;
+        const uint32_t grp = F.np < PF2_GROUP ? (F.np ? F.np : 1u) : PF2_GROUP;   // probes per sorted group
+        Q.n_grp = (F.np + grp - 1) / grp;
         Q.n_groups = (uint32_t)(n_iter * Q.n_grp);
         Q.gs = (Q.n_groups + 1 + 15) & ~15u;
         const double pairs_w = (double)n_iter * tiles_wg * 64.0 * F.np;
@@ -1790,7 +1794,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.pairs = (uint32_t*)(ws + b_cnt + b_seen + b_fill + b_c8);
         GF_HIP(ctx, hipMemsetAsync(ws + b_cnt - 256, 0, 256 + b_seen, ctx->stream));
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        hipLaunchKernelGGL(pf4_scatter_kernel, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
+        void (*scatter)(Part4Params, uint32_t) = grp == 1 ? pf4_scatter_kernel<1> : grp == 2 ? pf4_scatter_kernel<2> : grp == 3 ? pf4_scatter_kernel<3> : pf4_scatter_kernel<4>;
+        hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
         const size_t lds_b = (((size_t)1 << (ix.bm_log2 - PF2_NB_LOG2 - 5)) + 16 * (2 * WOBUF + 2 * PF2_PEND)) * 4;
         hipLaunchKernelGGL(pf4_probe_kernel, dim3((unsigned)std::min<size_t>(PF2_NB, (size_t)ctx->n_cu)), dim3(1024), lds_b, ctx->stream, Q);
         const size_t lds_r = (size_t)4 * 8 * (((2 * (size_t)rb + 3) / 4) * 4 + 4) * 4;
