@@ -313,6 +313,22 @@ def test_two_rank_owner_assembly_equals_the_single_process_run(tmp_path, config,
     assert abs(a["gaps_per_s"] * a["ms_per_step"] - b["gaps_per_s"] * b["ms_per_step"]) < 1e-3 * a["gaps_per_s"] * a["ms_per_step"]   # same gaps, counted once
 
 
+def test_bench_launches_its_own_ranks_from_a_bare_shell(tmp_path):
+    """`python bench.py --gpus 2` without torch.distributed.run around it (no WORLD_SIZE in the environment): bench.py starts the
+    ranks as a child process; on this one-GPU box they share cuda:0 and talk over gloo.  Same contigs as the single-process run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GF_BENCH_BACKEND", "GF_BENCH_ONE_GPU")}
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    argv = ["--config", "C2", "--reads", "4000000", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extras"]
+    a = _bench(argv + ["--dump-contigs", one])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + argv + ["--dump-contigs", two], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    b = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert b["n_gpus"] == 2 and "gloo" in b["config"]["collectives"] and "ranks share cuda:0" in r.stderr.decode()
+    assert json.load(open(one))["contigs"] == json.load(open(two))["contigs"]
+    assert a["counts"]["assembled_pool_reads"] == b["counts"]["assembled_pool_reads"]
+
+
 @pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5"])
 def test_full_size_config_sample_parity(config):
     """BASELINE.json configs[1], [2], [3], [4] at FULL size on this GPU (reads generated on the device): all screen and tagger hits of
