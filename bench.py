@@ -325,6 +325,8 @@ def run(args):
         dist.all_reduce(per_gap, op=dist.ReduceOp.SUM)
     max_pool_rows = int(per_gap.max())
     gf.set_option("asm_max_pool_reads", int(1.5 * max_pool_rows) + 64)
+    if os.environ.get("GF_BENCH_SCREEN_VARIANT"):    # filter kernel (experiments: 17 = pass A with unaligned runs)
+        gf.set_option("screen_variant", int(os.environ["GF_BENCH_SCREEN_VARIANT"]))
     if os.environ.get("GF_BENCH_ASM_SIMPLIFY"):      # rounds of tip clipping + bubble popping (experiments; the parity sample then disagrees unless it is 2)
         gf.set_option("asm_simplify", int(os.environ["GF_BENCH_ASM_SIMPLIFY"]))
     if os.environ.get("GF_BENCH_ASM_THREADS"):       # threads per gap in the assembly kernel (1024 / 512 / 256; default: by the pool bound)

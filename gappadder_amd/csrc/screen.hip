@@ -542,6 +542,9 @@ __device__ __forceinline__ void pf4_resolve_octet_serial(const Part4Params& Q, u
 }
 // G = probes sorted per group: PF2_GROUP, or the read's whole probe count when that is smaller (k = 51: three — a fourth, dead probe
 // slot costs every lane its instructions all the same)
+#ifndef GF_EXP
+#define GF_EXP 0
+#endif
 template <uint32_t G>
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params Q, uint32_t slice_words) {
     extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][keys: BATCH x 4 B][octets: BATCH x 1 B][fill stage 256 x 17][hist 3 x 256][offs 258][written 2 x 256]
@@ -620,6 +623,9 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
         wave_lds_sync();
         prefetch(t0 + t_step);
         const uint32_t bit0 = lane * P.rb * 8;
+#if GF_EXP == 3
+        if (P.np == 12345)
+#endif
         for (uint32_t j0 = 0; j0 < P.np; j0 += G, ++g) {
             uint32_t* hist = hist3 + hsel * PF2_NB;        // all zero (start / zeroed during the copy-out before last)
             const uint32_t* written = written2 + wsel * PF2_NB;
@@ -631,7 +637,12 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
                 for (uint32_t u = 0; u < G; ++u) {
                     const bool on = live && j0 + u < P.np;
                     pk[q][u] = on ? canon16(stream32(tiles + q * slice_words, bit0 + P.first2 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
+#if GF_EXP == 4
+                    rank[q][u] = on ? (pk[q][u] & 15u) : EMPTY32;
+                    if (on && (pk[q][u] & 0xFFFu) == 77u) atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 16u);
+#else
                     rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
+#endif
                 }
             }
             __syncthreads();
@@ -655,6 +666,9 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
                 written2[(wsel ^ 1u) * PF2_NB + i] = w < Q.cap ? w : Q.cap;
             }
             __syncthreads();
+#if GF_EXP == 2
+            if (P.np == 12345)
+#endif
 #pragma unroll
             for (uint32_t q = 0; q < PF2_TILES; ++q)
 #pragma unroll
@@ -665,7 +679,11 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
                         sidx[at] = (uint8_t)((wv * PF2_TILES + q) * 8 + (lane >> 3));
                     }
             __syncthreads();
+#if GF_EXP == 2
+            const uint32_t n_pairs = P.np == 12345 ? offs[PF2_NB] : 0u;
+#else
             const uint32_t n_pairs = offs[PF2_NB];
+#endif
             const uint32_t hz = hsel == 0 ? 2 : hsel - 1;
             for (uint32_t i = tid; i < PF2_NB; i += NT) hist3[hz * PF2_NB + i] = 0;                  // the histogram of the group after next
             for (uint32_t i0 = 0; i0 < n_pairs; i0 += NT) {         // (whole waves stay in the loop: one store per wave and trip)
@@ -679,8 +697,14 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
                 {
                     uint32_t* dst = (valid && !spill) ? part(b) + at : dummy + lane;
                     const uint32_t e = (key << 8) | oc;
-                    asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
-                    ++stores_since;
+#if GF_EXP == 1
+                    if (P.np == 12345)
+#endif
+                    { asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
+                    ++stores_since; }
+#if GF_EXP == 1
+                    if (e == 0x12345u && dst == nullptr) atomicAdd(Q.n_cand8, 1u);
+#endif
                 }
                 if (spill) {   // a part that is full (degenerate inputs): tested on the spot
                     const uint32_t h = key >> (32 - P.bm_log2);
@@ -706,6 +730,258 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
     __syncthreads();
     for (uint32_t i = tid; i < PF2_NB; i += NT) {
         const uint32_t w = written2[wsel * PF2_NB + i];
+        Q.count[(size_t)i * Q.n_writers + writer] = w;
+        fill_row(i)[Q.n_groups] = w;
+    }
+}
+
+// ---- pass A with WHOLE-LINE stores.  The kernel above writes a bucket's pairs of one group (about 24 at k = 51) where the part's fill
+// stands: 96-byte runs that start anywhere.  Measured with the same write pattern beside a read stream (tools/scratch/wbench.hip:
+// 65 536 parts filled front to back, 8.2 GB read): unaligned 96-byte runs 2.96 ms (WRITE_SIZE 1.25 x the bytes), aligned 64-byte
+// pieces 2.35 ms (1.33 x: the L2 line is 128 bytes), aligned 128-byte lines 2.21 ms with twice the bytes written — 0.2 ms over the
+// read stream alone (1.98 ms).  So a bucket's pairs leave only as whole, aligned 32-entry lines: what a group leaves over (< 32
+// entries per bucket) waits in an LDS line per bucket (`carry`, two per bucket: the line being filled, and the one that takes the
+// group's tail while the filled line is on its way out) and is the head of the bucket's next line.  A pair's position in its part is
+// still its generation order (T_old + rank), which is all pass B and the fill history need.
+//   placement of a new pair with position p_rel = (T_old & 31) + rank relative to the open line:
+//     p_rel < 32            -> the open line                          carry[sel][b][p_rel]
+//     p_rel < full          -> a whole line of this group             sent[offs[b] + p_rel - 32]  (full = (c + n) & ~31)
+//     otherwise             -> the tail: head of the next open line   carry[sel ^ 1][b][p_rel & 31]
+//   copy-out: the open lines that were completed (32 lanes per bucket: one 128-byte store), then `sent` (whole lines; a line's bucket
+//   and position in its part are in `ldesc`).
+// The 64 KiB of open lines fit because a wave stages ONE tile at a time (its second tile waits in the prefetch registers until the
+// first one's keys are taken): reads up to 160 bases, all probes of a read in one group (np <= 4).
+constexpr uint32_t PF4_LINE = 32;
+constexpr size_t pf4_lines_lds_bytes(size_t slice_words, uint32_t G) {
+    return ((size_t)PF2_WAVES * slice_words + (size_t)G * PF2_WAVES * PF2_TILES * 64 + 2 * PF2_NB * PF4_LINE + PF2_NB * (PF4_STAGE + 1) +
+            3 * PF2_NB + PF2_NB + 4 + 2 * PF2_NB + PF2_NB + PF2_NB + (size_t)G * PF2_WAVES * PF2_TILES * 64 / PF4_LINE) * 4;
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_upto(uint32_t n) {   // s_waitcnt vmcnt(min(n, N)): the count is an immediate
+    if constexpr (N == 0) vm_wait<0>();
+    else { if (n >= (uint32_t)N) vm_wait<N>(); else vm_wait_upto<N - 1>(n); }
+}
+template <uint32_t G>
+__global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4Params Q, uint32_t slice_words) {
+    extern __shared__ uint32_t sm[];   // [16 waves x 1 tile][sent][carry 2 x 256 x 32][fill stage 256 x 17][hist 3 x 256][offs 260][written 2 x 256][desc 256][fl 256][ldesc]
+    const FilterParams& P = Q.F;
+    constexpr uint32_t NT = 64 * PF2_WAVES;
+    constexpr uint32_t ST = PF4_STAGE, LN = PF4_LINE, LM = PF4_LINE - 1;
+    constexpr uint32_t NSENT = G * PF2_WAVES * PF2_TILES * 64;
+    constexpr uint32_t TMASK = 0x7FFFFFFFu;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* tile = sm + wv * slice_words;
+    uint32_t* sent = sm + PF2_WAVES * slice_words;
+    uint32_t* carry = sent + NSENT;
+    uint32_t* stage = carry + 2 * PF2_NB * LN;
+    uint32_t* hist3 = stage + PF2_NB * (ST + 1);
+    uint32_t* offs = hist3 + 3 * PF2_NB;
+    uint32_t* written2 = offs + PF2_NB + 4;   // generated so far (<= cap) | open line's carry buffer << 31
+    uint32_t* desc = written2 + 2 * PF2_NB;   // c | sel << 5 | line completed << 6 | part runs full << 7 | full << 8
+    uint32_t* fl = desc + PF2_NB;             // completed open line: its position in the part | sel << 31; ~0: none
+    uint32_t* ldesc = fl + PF2_NB;            // line of `sent`: bucket << 24 | position in the part
+    const uint32_t writer = blockIdx.x;
+    const uint32_t tile_bytes = 64 * P.rb;
+    const uint64_t total_bytes = P.n_reads * P.rb;
+    const uint64_t n_tiles = (P.n_reads + 63) / 64;
+    auto part = [&](uint32_t b) { return Q.pairs + ((size_t)b * Q.n_writers + writer) * Q.cap; };
+    auto fill_row = [&](uint32_t b) { return Q.fills + ((size_t)b * Q.n_writers + writer) * Q.gs; };
+    for (uint32_t i = tid; i < PF2_NB; i += NT) { written2[i] = 0; hist3[i] = 0; hist3[PF2_NB + i] = 0; hist3[2 * PF2_NB + i] = 0; }
+    constexpr int NPF = 4;   // 64 reads x <= 64 B
+    u32x4 pf[PF2_TILES][NPF];
+    auto prefetch = [&](uint64_t t, uint32_t q) {
+        const bool on = t < n_tiles;
+        const uint64_t byte0 = on ? t * tile_bytes : 0;
+        const uint32_t nbytes = on ? (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes) : 0u;
+        const void* base = uniform_ptr(nbytes >= 16 ? (const void*)(P.reads + byte0) : (const void*)Q.count);   // (idle: 16 bytes of the workspace)
+#pragma unroll
+        for (int c = 0; c < NPF; ++c) {
+            const uint32_t i = lane + c * 64;
+            vm_load128(pf[q][c], i < (nbytes >> 4) ? i * 16 : 0u, base);
+        }
+    };
+    const uint64_t t_step = (uint64_t)gridDim.x * PF2_WAVES * PF2_TILES;
+    const uint64_t n_iter = (n_tiles + t_step - 1) / t_step;
+#pragma unroll
+    for (uint32_t q = 0; q < PF2_TILES; ++q) prefetch(((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES + q, q);
+    uint32_t hsel = 0, wsel = 0;
+    uint32_t stores_since = 0;   // copy-out stores this wave has issued since its last prefetch (wave-uniform)
+    __syncthreads();
+    for (uint64_t it = 0; it < n_iter; ++it) {   // one group per iteration: g = it
+        const uint32_t g = (uint32_t)it;
+        const uint64_t t0 = it * t_step + ((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES;
+        const uint32_t octet0 = (uint32_t)((it * t_step + (uint64_t)blockIdx.x * PF2_WAVES * PF2_TILES) * 8);   // octet of batch index 0
+        uint32_t* hist = hist3 + hsel * PF2_NB;        // all zero (start / zeroed during the copy-out before last)
+        const uint32_t* written = written2 + wsel * PF2_NB;
+        uint32_t pk[PF2_TILES][G], rank[PF2_TILES][G];
+        const uint32_t bit0 = lane * P.rb * 8;
+#pragma unroll
+        for (uint32_t q = 0; q < PF2_TILES; ++q) {
+            // tile q's loads were issued before the loads of the tiles behind it and the previous copy-out's stores: those may stay in flight
+            vm_wait_upto<16>(stores_since + (PF2_TILES - 1) * NPF);
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) vm_ready(pf[q][c]);
+            const uint64_t t = t0 + q;
+            if (t < n_tiles) {
+                uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
+                const uint64_t byte0 = t * tile_bytes;
+                const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
+                const uint32_t n16 = nbytes & ~15u;
+#pragma unroll
+                for (int c = 0; c < NPF; ++c) {
+                    const uint32_t i = lane + c * 64;
+                    if (i < (n16 >> 4)) *reinterpret_cast<u32x4*>(tb + (uint64_t)i * 16) = pf[q][c];
+                }
+                for (uint32_t i = n16 + lane; i < nbytes; i += 64) tb[i] = P.reads[byte0 + i];
+                if (lane < 16) tb[nbytes + lane] = 0;
+            }
+            wave_lds_sync();
+            prefetch(t + t_step, q);
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u) pk[q][u] = stream32(tile, bit0 + P.first2 + u * P.stride2);
+            wave_lds_sync();   // the tile's probes are taken (LDS operations of a wave execute in order): the next tile may take its place
+        }
+        stores_since = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PF2_TILES; ++q) {
+            const bool live = t0 + q < n_tiles && (t0 + q) * 64 + lane < P.n_reads;
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u) {
+                const bool on = live && u < P.np;
+                pk[q][u] = on ? canon16(pk[q][u]) * S16_MUL : 0u;
+                rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
+            }
+        }
+        __syncthreads();
+        // per bucket: n new pairs (those beyond the part's capacity are not placed), c waiting in the open line
+        auto bucket = [&](uint32_t b, uint32_t& t_old, uint32_t& sel, uint32_t& n_new, uint32_t& ne, uint32_t& c, uint32_t& total) {
+            const uint32_t w = written[b];
+            t_old = w & TMASK;
+            sel = w >> 31;
+            n_new = hist[b];
+            const uint32_t room = Q.cap - t_old;
+            ne = n_new < room ? n_new : room;
+            c = t_old & LM;
+            total = c + ne;
+        };
+        if (wv == 0) {   // exclusive scan of the whole lines behind the open one, 256 buckets: four per lane
+            uint32_t v[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t t_old, sel, n_new, ne, c, total;
+                bucket(lane * 4 + q, t_old, sel, n_new, ne, c, total);
+                v[q] = total >= LN ? (total & ~LM) - LN : 0u;
+                sum += v[q];
+            }
+            uint32_t inc = sum;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(inc, d);
+                if ((int)lane >= d) inc += y;
+            }
+            uint32_t run = inc - sum;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { offs[lane * 4 + q] = run; run += v[q]; }
+            if (lane == 63) offs[PF2_NB] = inc;
+        } else if (wv <= PF2_NB / 64) {   // the parts' fill before (history) and after this group; what placement and copy-out need
+            const uint32_t i = tid - 64;
+            uint32_t t_old, sel, n_new, ne, c, total;
+            bucket(i, t_old, sel, n_new, ne, c, total);
+            const uint32_t done = total >= LN ? 1u : 0u;
+            stage[i * (ST + 1) + (g % ST)] = t_old;
+            desc[i] = c | (sel << 5) | (done << 6) | ((n_new > ne ? 1u : 0u) << 7) | ((total & ~LM) << 8);
+            fl[i] = done ? ((t_old & ~LM) | (sel << 31)) : EMPTY32;
+            written2[(wsel ^ 1u) * PF2_NB + i] = (t_old + ne) | ((sel ^ done) << 31);
+        }
+        __syncthreads();
+        uint32_t spilled = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PF2_TILES; ++q)
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u)
+                if (rank[q][u] != EMPTY32) {
+                    const uint32_t key = pk[q][u], b = key >> (32 - PF2_NB_LOG2);
+                    const uint32_t e = (key << 8) | ((wv * PF2_TILES + q) * 8 + (lane >> 3));
+                    const uint32_t d = desc[b], p_rel = (d & LM) + rank[q][u], sel = (d >> 5) & 1u;
+                    if ((d & 128u) && rank[q][u] >= Q.cap - (written[b] & TMASK)) {   // a part that is full (degenerate inputs): tested on the spot, below
+                        spilled |= 1u << (q * G + u);
+                    } else if (p_rel >= LN && p_rel < (d >> 8)) {
+                        const uint32_t at = offs[b] + p_rel - LN;
+                        sent[at] = e;
+                        if ((at & LM) == 0) ldesc[at >> 5] = (b << 24) | ((written[b] & TMASK & ~LM) + p_rel);
+                    } else {   // the open line, or (behind the last whole line) the next one
+                        carry[(p_rel < LN ? sel : sel ^ 1u) * (PF2_NB * LN) + b * LN + (p_rel & LM)] = e;
+                    }
+                }
+        if (spilled) {   // (static indices: a dynamically indexed pk[][] would live in scratch memory)
+#pragma unroll
+            for (uint32_t x = 0; x < PF2_TILES * G; ++x)
+                if ((spilled >> x) & 1u) {
+                    const uint32_t q = x / G, u = x % G, key = pk[q][u];
+                    const uint32_t h = key >> (32 - P.bm_log2);
+                    const uint32_t wd = P.bitmap[h >> 5];
+                    if ((wd >> (h & 31)) & (wd >> (key & 31)) & 1u) {
+                        const uint32_t k16 = key * S16_MUL_INV;
+                        if (sset_walk(P, k16, hash_s16_set(k16, P.s_log2))) pf4_resolve_octet_serial(Q, octet0 + (wv * PF2_TILES + q) * 8 + (lane >> 3), key);
+                    }
+                }
+        }
+        __syncthreads();
+        const uint32_t n_sent = offs[PF2_NB];
+        const uint32_t hz = hsel == 0 ? 2 : hsel - 1;
+        for (uint32_t i = tid; i < PF2_NB; i += NT) hist3[hz * PF2_NB + i] = 0;                  // the histogram of the group after next
+#pragma unroll 1
+        for (uint32_t v = 0; v < PF2_NB * LN / NT; ++v) {   // completed open lines: 32 lanes per bucket (whole waves store: one store per wave and trip)
+            const uint32_t t = tid + v * NT, b = t >> 5;
+            const uint32_t f = fl[b];
+            const bool valid = f != EMPTY32;
+            const uint32_t e = valid ? carry[(f >> 31) * (PF2_NB * LN) + t] : 0u;
+            uint32_t* dst = part(b) + (f & TMASK) + (t & LM);
+#if GF_EXP == 1
+            if (P.np == 12345)
+#endif
+            if (__ballot(valid)) {   // (a wave with no lane to store issues nothing: the count stays the number of stores issued)
+                if (valid) asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
+                ++stores_since;
+            }
+#if GF_EXP == 1
+            if (e == 0x12345u && dst == nullptr) atomicAdd(Q.n_cand8, 1u);
+#endif
+        }
+        for (uint32_t i0 = 0; i0 < n_sent; i0 += NT) {
+            const uint32_t i = i0 + tid;
+            const bool valid = i < n_sent;
+            const uint32_t e = valid ? sent[i] : 0u;
+            const uint32_t ld = valid ? ldesc[i >> 5] : 0u;
+            uint32_t* dst = part(ld >> 24) + (ld & 0xFFFFFFu) + (i & LM);
+#if GF_EXP == 1
+            if (P.np == 12345)
+#endif
+            if (__ballot(valid)) {   // (a wave with no lane to store issues nothing: the count stays the number of stores issued)
+                if (valid) asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
+                ++stores_since;
+            }
+#if GF_EXP == 1
+            if (e == 0x12345u && dst == nullptr) atomicAdd(Q.n_cand8, 1u);
+#endif
+        }
+        if ((g % ST) == ST - 1 || g + 1 == Q.n_groups) {   // the staged fill rows leave as 64-byte pieces
+            const uint32_t g_lo = g - g % ST;
+            for (uint32_t i = tid; i < PF2_NB * ST; i += NT) {
+                const uint32_t b = i / ST, j = i % ST;
+                if (g_lo + j <= g) fill_row(b)[g_lo + j] = stage[b * (ST + 1) + j];
+            }
+        }
+        hsel = hsel == 2 ? 0 : hsel + 1;
+        wsel ^= 1u;
+    }
+    vm_wait<0>();   // the last prefetch (idle tiles) still targets this wave's registers
+    __syncthreads();
+    for (uint32_t t = tid; t < PF2_NB * LN; t += NT) {   // the open lines
+        const uint32_t b = t >> 5, w = written2[wsel * PF2_NB + b], T = w & TMASK;
+        if ((t & LM) < (T & LM)) part(b)[(T & ~LM) + (t & LM)] = carry[(w >> 31) * (PF2_NB * LN) + t];
+    }
+    for (uint32_t i = tid; i < PF2_NB; i += NT) {
+        const uint32_t w = written2[wsel * PF2_NB + i] & TMASK;
         Q.count[(size_t)i * Q.n_writers + writer] = w;
         fill_row(i)[Q.n_groups] = w;
     }
@@ -1757,7 +2033,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
                            w_bm_bytes + nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
-    } else if ((ctx->screen_variant == 16 || (ctx->screen_variant == 0 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
+    } else if ((ctx->screen_variant == 16 || ctx->screen_variant == 17 || (ctx->screen_variant == 0 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
                ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) * 4 + (size_t)PF2_BATCH * 5 + (size_t)PF2_NB * (PF4_STAGE + 1) * 4 +
                 (6 * PF2_NB + 8) * 4) <= 156 * 1024) {
         // partitioned filter, 256 buckets, 4-byte pairs (see Part4Params)
@@ -1794,8 +2070,16 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.pairs = (uint32_t*)(ws + b_cnt + b_seen + b_fill + b_c8);
         GF_HIP(ctx, hipMemsetAsync(ws + b_cnt - 256, 0, 256 + b_seen, ctx->stream));
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        void (*scatter)(Part4Params, uint32_t) = grp == 1 ? pf4_scatter_kernel<1> : grp == 2 ? pf4_scatter_kernel<2> : grp == 3 ? pf4_scatter_kernel<3> : pf4_scatter_kernel<4>;
-        hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
+        // whole-line stores where the open lines fit beside the tiles (reads up to 160 bases) and a read's probes make one group
+        // (screen_variant 17: the unaligned form all the same)
+        const size_t lds_l = pf4_lines_lds_bytes(slice_words, grp);
+        if (lds_l <= 160 * 1024 && Q.n_grp == 1 && ctx->screen_variant != 17) {
+            void (*scatter)(Part4Params, uint32_t) = grp == 1 ? pf4_scatter_lines_kernel<1> : grp == 2 ? pf4_scatter_lines_kernel<2> : grp == 3 ? pf4_scatter_lines_kernel<3> : pf4_scatter_lines_kernel<4>;
+            hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_l, ctx->stream, Q, (uint32_t)slice_words);
+        } else {
+            void (*scatter)(Part4Params, uint32_t) = grp == 1 ? pf4_scatter_kernel<1> : grp == 2 ? pf4_scatter_kernel<2> : grp == 3 ? pf4_scatter_kernel<3> : pf4_scatter_kernel<4>;
+            hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
+        }
         const size_t lds_b = (((size_t)1 << (ix.bm_log2 - PF2_NB_LOG2 - 5)) + 16 * (2 * WOBUF + 2 * PF2_PEND)) * 4;
         hipLaunchKernelGGL(pf4_probe_kernel, dim3((unsigned)std::min<size_t>(PF2_NB, (size_t)ctx->n_cu)), dim3(1024), lds_b, ctx->stream, Q);
         const size_t lds_r = (size_t)4 * 8 * (((2 * (size_t)rb + 3) / 4) * 4 + 4) * 4;

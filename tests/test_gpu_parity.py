@@ -100,7 +100,7 @@ def test_screen_and_tagger_synthetic(gf, seed, n_pairs, L, k):
     exp = CO.screen_reads(c["reads_blob"], L, c["flanks"], k)
     assert _same(hits, exp) and len(exp) > 100
     if L <= 250:      # the partitioned filters (packed reads up to 64 bytes) on the same reads, with a 2^27-bit bitmap:
-        for variant in (14, 16):  # 16 buckets with per-wave rows / 256 buckets with the workgroup sort and 4-byte pairs
+        for variant in (14, 16, 17):  # 16 buckets with per-wave rows / 256 buckets with the workgroup sort and 4-byte pairs (whole-line stores where they fit; 17: unaligned runs)
             gf.set_option("screen_variant", variant)
             gf.set_option("bitmap_log2", 27)
             try:
@@ -332,12 +332,14 @@ def test_screen_filter_variants_agree(gf, variant):
             gf.set_option("bitmap_log2", bl)   # 28: the partitioned filter uses 16 buckets instead of 8
             assert _same(gf.screen_reads(packed, c["L"], 31), exp31), (variant, bl)
         if variant == 14:      # the 256-bucket partitioned filter (variant 16) exists for 2^27- and 2^28-bit bitmaps
-            gf.set_option("screen_variant", 16)
-            for bl in (27, 28):
-                gf.set_option("bitmap_log2", bl)
-                for n in (len(packed), 1000, 769, 1):
-                    assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (16, bl, n)
-                assert _same(gf.screen_reads(packed, c["L"], 51), exp51), (16, bl)
+            for v256 in (16, 17):   # pass A with whole-line stores / with unaligned runs
+                gf.set_option("screen_variant", v256)
+                for bl in (27, 28):
+                    gf.set_option("bitmap_log2", bl)
+                    for n in (len(packed), 1000, 769, 1):
+                        assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (v256, bl, n)
+                    assert _same(gf.screen_reads(packed, c["L"], 51), exp51), (v256, bl)
+                    assert _same(gf.screen_reads(packed, c["L"], 41), CO.screen_reads(c["reads_blob"], c["L"], c["flanks"], 41)), (v256, bl)
     finally:
         gf.set_option("screen_variant", 0)
         gf.set_option("bitmap_log2", 0)
@@ -505,14 +507,16 @@ def test_partitioned_filter_probes_in_place_when_a_bucket_part_runs_full(gf):
         gf.set_option("screen_variant", 14)
         assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
         gf.set_option("bitmap_log2", 27)
-        gf.set_option("screen_variant", 16)        # 256 buckets, 4-byte pairs: the same degenerate reads overflow a workgroup's part — a full part is tested on the spot and resolved by the lane itself
-        assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
-        gf.set_option("screen_pf4_cap8", 256)      # ... and so is every pair beyond a (here: tiny) pair list
-        assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
-        for cut in (1, 5, 67):                     # read counts that end inside an octet / a tile
-            blob2 = blob[:len(blob) - cut * L]
-            packed2, _ = GapFill.pack_reads(blob2, L)
-            assert _same(gf.screen_reads(packed2, L, 31, cap=1 << 18), CO.screen_reads(blob2, L, flanks, 31)), cut
+        for v256 in (16, 17):                      # 256 buckets, 4-byte pairs (whole-line stores / unaligned runs): the same degenerate reads overflow a workgroup's part — a full part is tested on the spot and resolved by the lane itself
+            gf.set_option("screen_pf4_cap8", 0)
+            gf.set_option("screen_variant", v256)
+            assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp), v256
+            gf.set_option("screen_pf4_cap8", 256)      # ... and so is every pair beyond a (here: tiny) pair list
+            assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp), v256
+            for cut in (1, 5, 67):                     # read counts that end inside an octet / a tile
+                blob2 = blob[:len(blob) - cut * L]
+                packed2, _ = GapFill.pack_reads(blob2, L)
+                assert _same(gf.screen_reads(packed2, L, 31, cap=1 << 18), CO.screen_reads(blob2, L, flanks, 31)), (v256, cut)
     finally:
         gf.set_option("screen_variant", 0)
         gf.set_option("bitmap_log2", 0)
@@ -538,12 +542,12 @@ def test_human_scale_key_set_all_filter_kernels_agree_on_20M_reads(gf):
     packed = d_reads[:2 * n_pairs * rb].cpu().numpy().reshape(-1, rb)
     res = {}
     try:
-        for variant in (0, 14, 9):
+        for variant in (0, 17, 14, 9):
             gf.set_option("screen_variant", variant)
             res[variant] = gf.screen_reads(packed, L, k, cap=1 << 20)
     finally:
         gf.set_option("screen_variant", 0)
-    assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[9])   # (0 = the 256-bucket 4-byte-pair filter)
+    assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[9]) and _same(res[0], res[17])   # (0 = the 256-bucket 4-byte-pair filter, whole-line stores; 17 = unaligned runs)
     try:   # a short pair list: most pairs that are in the exact set take the serial path
         gf.set_option("screen_pf4_cap8", 1 << 16)
         assert _same(res[0], gf.screen_reads(packed, L, k, cap=1 << 20))
