@@ -546,7 +546,7 @@ def run(args):
             "gaps_closed_per_s": n_closed / step_s,
             "gaps_closed_correct_per_s": n_correct / step_s,
             "roofline": {"bound": "hbm",
-                         "kernel": "screen_filter (one launch group per library and step: pf4_scatter_kernel + pf4_probe_kernel + pf4_resolve_kernel + "
+                         "kernel": "screen_filter (one launch group per library and step: pf4_scatter_lines_kernel (pf4_scatter_kernel where a read has more than four probes) + pf4_probe_kernel + pf4_resolve_kernel + "
                                    "pf4_list_kernel — probes sorted into 256 slices of the level-1 bitmap as 4-byte pairs, each slice tested from LDS, "
                                    "read ids recovered from positions — on key sets beyond an L2 as at C4/C5; the software-pipelined "
                                    "screen_filter_pipe_kernel otherwise, as at C2)",

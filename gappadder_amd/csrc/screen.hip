@@ -542,9 +542,6 @@ __device__ __forceinline__ void pf4_resolve_octet_serial(const Part4Params& Q, u
 }
 // G = probes sorted per group: PF2_GROUP, or the read's whole probe count when that is smaller (k = 51: three — a fourth, dead probe
 // slot costs every lane its instructions all the same)
-#ifndef GF_EXP
-#define GF_EXP 0
-#endif
 template <uint32_t G>
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params Q, uint32_t slice_words) {
     extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][keys: BATCH x 4 B][octets: BATCH x 1 B][fill stage 256 x 17][hist 3 x 256][offs 258][written 2 x 256]
@@ -623,9 +620,6 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
         wave_lds_sync();
         prefetch(t0 + t_step);
         const uint32_t bit0 = lane * P.rb * 8;
-#if GF_EXP == 3
-        if (P.np == 12345)
-#endif
         for (uint32_t j0 = 0; j0 < P.np; j0 += G, ++g) {
             uint32_t* hist = hist3 + hsel * PF2_NB;        // all zero (start / zeroed during the copy-out before last)
             const uint32_t* written = written2 + wsel * PF2_NB;
@@ -637,12 +631,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
                 for (uint32_t u = 0; u < G; ++u) {
                     const bool on = live && j0 + u < P.np;
                     pk[q][u] = on ? canon16(stream32(tiles + q * slice_words, bit0 + P.first2 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
-#if GF_EXP == 4
-                    rank[q][u] = on ? (pk[q][u] & 15u) : EMPTY32;
-                    if (on && (pk[q][u] & 0xFFFu) == 77u) atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 16u);
-#else
                     rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
-#endif
                 }
             }
             __syncthreads();
@@ -666,9 +655,6 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
                 written2[(wsel ^ 1u) * PF2_NB + i] = w < Q.cap ? w : Q.cap;
             }
             __syncthreads();
-#if GF_EXP == 2
-            if (P.np == 12345)
-#endif
 #pragma unroll
             for (uint32_t q = 0; q < PF2_TILES; ++q)
 #pragma unroll
@@ -679,11 +665,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
                         sidx[at] = (uint8_t)((wv * PF2_TILES + q) * 8 + (lane >> 3));
                     }
             __syncthreads();
-#if GF_EXP == 2
-            const uint32_t n_pairs = P.np == 12345 ? offs[PF2_NB] : 0u;
-#else
             const uint32_t n_pairs = offs[PF2_NB];
-#endif
             const uint32_t hz = hsel == 0 ? 2 : hsel - 1;
             for (uint32_t i = tid; i < PF2_NB; i += NT) hist3[hz * PF2_NB + i] = 0;                  // the histogram of the group after next
             for (uint32_t i0 = 0; i0 < n_pairs; i0 += NT) {         // (whole waves stay in the loop: one store per wave and trip)
@@ -697,14 +679,8 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
                 {
                     uint32_t* dst = (valid && !spill) ? part(b) + at : dummy + lane;
                     const uint32_t e = (key << 8) | oc;
-#if GF_EXP == 1
-                    if (P.np == 12345)
-#endif
-                    { asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
-                    ++stores_since; }
-#if GF_EXP == 1
-                    if (e == 0x12345u && dst == nullptr) atomicAdd(Q.n_cand8, 1u);
-#endif
+                    asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
+                    ++stores_since;
                 }
                 if (spill) {   // a part that is full (degenerate inputs): tested on the spot
                     const uint32_t h = key >> (32 - P.bm_log2);
@@ -739,54 +715,65 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
 // stands: 96-byte runs that start anywhere.  Measured with the same write pattern beside a read stream (tools/scratch/wbench.hip:
 // 65 536 parts filled front to back, 8.2 GB read): unaligned 96-byte runs 2.96 ms (WRITE_SIZE 1.25 x the bytes), aligned 64-byte
 // pieces 2.35 ms (1.33 x: the L2 line is 128 bytes), aligned 128-byte lines 2.21 ms with twice the bytes written — 0.2 ms over the
-// read stream alone (1.98 ms).  So a bucket's pairs leave only as whole, aligned 32-entry lines: what a group leaves over (< 32
-// entries per bucket) waits in an LDS line per bucket (`carry`, two per bucket: the line being filled, and the one that takes the
-// group's tail while the filled line is on its way out) and is the head of the bucket's next line.  A pair's position in its part is
-// still its generation order (T_old + rank), which is all pass B and the fill history need.
-//   placement of a new pair with position p_rel = (T_old & 31) + rank relative to the open line:
-//     p_rel < 32            -> the open line                          carry[sel][b][p_rel]
-//     p_rel < full          -> a whole line of this group             sent[offs[b] + p_rel - 32]  (full = (c + n) & ~31)
-//     otherwise             -> the tail: head of the next open line   carry[sel ^ 1][b][p_rel & 31]
-//   copy-out: the open lines that were completed (32 lanes per bucket: one 128-byte store), then `sent` (whole lines; a line's bucket
-//   and position in its part are in `ldesc`).
-// The 64 KiB of open lines fit because a wave stages ONE tile at a time (its second tile waits in the prefetch registers until the
-// first one's keys are taken): reads up to 160 bases, all probes of a read in one group (np <= 4).
+// read stream alone (1.98 ms).  So a bucket's pairs leave as whole, aligned 32-entry lines: what a group leaves over (< 32 entries
+// per bucket) waits in an LDS line per bucket (`carry`, two per bucket: the line being filled, and the one that takes the group's
+// tail while the filled line is on its way out) and is the head of the bucket's next line.  A pair's position in its part is still
+// its generation order (T_old + rank), which is all pass B and the fill history need.
+//   A new pair with position p_rel = c + rank relative to the open line (c = T_old & 31, total = c + the group's pairs):
+//     p_rel < 32               -> the open line                          carry[sel][b][p_rel]
+//     p_rel >= total & ~31     -> the tail: head of the next open line   carry[sel ^ 1][b][p_rel & 31]
+//     otherwise                -> a whole line between the two           sent[offs[b] + p_rel - 32]   (few: ~24 pairs per bucket and group)
+//   Between the ranks and the placement four waves prepare the buckets' words, one bucket per lane: c, sel, total (`desc`), the
+//   fill history, the list of completed open lines (`lga` = line index in `pairs`, `lsrc` = where
+//   the line stands in LDS), room in `sent` for the few buckets with whole lines between (an LDS counter: their order is free).
+//   Copy-out: the listed lines leave, 32 lanes per line.
+// A wave stages ONE tile at a time (its second tile waits in the prefetch registers until the first one's probes are taken): the
+// 64 KiB of open lines fit for reads up to 160 bases.  All probes of a read are in one group (np <= 4).
 constexpr uint32_t PF4_LINE = 32;
+constexpr uint32_t pf4_stage_of(uint32_t G) { return G >= 4 ? 8u : 16u; }   // groups of fill history staged in LDS (what fits beside the lines)
 constexpr size_t pf4_lines_lds_bytes(size_t slice_words, uint32_t G) {
-    return ((size_t)PF2_WAVES * slice_words + (size_t)G * PF2_WAVES * PF2_TILES * 64 + 2 * PF2_NB * PF4_LINE + PF2_NB * (PF4_STAGE + 1) +
-            3 * PF2_NB + PF2_NB + 4 + 2 * PF2_NB + PF2_NB + PF2_NB + (size_t)G * PF2_WAVES * PF2_TILES * 64 / PF4_LINE) * 4;
+    return ((size_t)PF2_WAVES * slice_words + (size_t)G * PF2_WAVES * PF2_TILES * 64 + 2 * PF2_NB * PF4_LINE + PF2_NB * (pf4_stage_of(G) + 1) +
+            3 * PF2_NB + 2 * PF2_NB + PF2_NB + PF2_NB + 2 * (PF2_NB + (size_t)G * PF2_WAVES * PF2_TILES * 64 / PF4_LINE) + 8) * 4;
 }
-template <int N>
-__device__ __forceinline__ void vm_wait_upto(uint32_t n) {   // s_waitcnt vmcnt(min(n, N)): the count is an immediate
-    if constexpr (N == 0) vm_wait<0>();
-    else { if (n >= (uint32_t)N) vm_wait<N>(); else vm_wait_upto<N - 1>(n); }
+template <int LO, int HI>
+__device__ __forceinline__ void vm_wait_range(uint32_t n) {   // s_waitcnt vmcnt(clamp(n, LO, HI)), n wave-uniform: the count is an immediate
+    if constexpr (LO == HI) vm_wait<LO>();
+    else {
+        constexpr int MID = (LO + HI + 1) / 2;
+        if (n >= (uint32_t)MID) vm_wait_range<MID, HI>(n); else vm_wait_range<LO, MID - 1>(n);
+    }
 }
 template <uint32_t G>
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4Params Q, uint32_t slice_words) {
-    extern __shared__ uint32_t sm[];   // [16 waves x 1 tile][sent][carry 2 x 256 x 32][fill stage 256 x 17][hist 3 x 256][offs 260][written 2 x 256][desc 256][fl 256][ldesc]
+    extern __shared__ uint32_t sm[];   // [16 waves x 1 tile][sent][carry 2 x 256 x 32][fill stage 256 x (ST + 1)][hist 3 x 256][written 2 x 256][desc 256][offs 256][lga, lsrc: 2 x (256 + sent lines)][cnt 8]
     const FilterParams& P = Q.F;
     constexpr uint32_t NT = 64 * PF2_WAVES;
-    constexpr uint32_t ST = PF4_STAGE, LN = PF4_LINE, LM = PF4_LINE - 1;
-    constexpr uint32_t NSENT = G * PF2_WAVES * PF2_TILES * 64;
+    constexpr uint32_t ST = pf4_stage_of(G), LN = PF4_LINE, LM = PF4_LINE - 1;
+    constexpr uint32_t NSENT = G * PF2_WAVES * PF2_TILES * 64, NLINE = PF2_NB + NSENT / LN;
     constexpr uint32_t TMASK = 0x7FFFFFFFu;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t tid0 = threadIdx.x, wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid0 >> 6);
+    uint32_t tid = tid0, lane = tid0 & 63;
     uint32_t* tile = sm + wv * slice_words;
     uint32_t* sent = sm + PF2_WAVES * slice_words;
-    uint32_t* carry = sent + NSENT;
+    uint32_t* carry = sent + NSENT;            // (behind `sent`: a pair's place is one index into both)
     uint32_t* stage = carry + 2 * PF2_NB * LN;
     uint32_t* hist3 = stage + PF2_NB * (ST + 1);
-    uint32_t* offs = hist3 + 3 * PF2_NB;
-    uint32_t* written2 = offs + PF2_NB + 4;   // generated so far (<= cap) | open line's carry buffer << 31
-    uint32_t* desc = written2 + 2 * PF2_NB;   // c | sel << 5 | line completed << 6 | part runs full << 7 | full << 8
-    uint32_t* fl = desc + PF2_NB;             // completed open line: its position in the part | sel << 31; ~0: none
-    uint32_t* ldesc = fl + PF2_NB;            // line of `sent`: bucket << 24 | position in the part
+    uint32_t* written2 = hist3 + 3 * PF2_NB;   // generated so far (<= cap) | open line's carry buffer << 31
+    uint32_t* desc = written2 + 2 * PF2_NB;    // c | sel << 5 | part runs full << 7 | (total & ~31) << 8
+    uint32_t* offs = desc + PF2_NB;            // the bucket's whole lines in `sent`
+    uint32_t* lga = offs + PF2_NB;             // lines that leave in this group: line index in `pairs` — [0, 256): completed open lines; behind: the lines of `sent`
+    uint32_t* lsrc = lga + NLINE;              // ... and where the line stands in LDS (word index from `sent`)
+    uint32_t* cnt = lsrc + NLINE;              // [g & 1] completed open lines, [2 + (g & 1)] words of `sent` taken
     const uint32_t writer = blockIdx.x;
     const uint32_t tile_bytes = 64 * P.rb;
     const uint64_t total_bytes = P.n_reads * P.rb;
     const uint64_t n_tiles = (P.n_reads + 63) / 64;
+    const uint32_t cap_lines = Q.cap >> 5;     // (the capacity is a multiple of 64 entries; the host checked that every line index fits 32 bits)
     auto part = [&](uint32_t b) { return Q.pairs + ((size_t)b * Q.n_writers + writer) * Q.cap; };
     auto fill_row = [&](uint32_t b) { return Q.fills + ((size_t)b * Q.n_writers + writer) * Q.gs; };
+    const uint32_t dummy_line = PF2_NB * Q.n_writers * cap_lines;   // 128 bytes behind the parts
     for (uint32_t i = tid; i < PF2_NB; i += NT) { written2[i] = 0; hist3[i] = 0; hist3[PF2_NB + i] = 0; hist3[2 * PF2_NB + i] = 0; }
+    if (tid < 8) cnt[tid] = 0;
     constexpr int NPF = 4;   // 64 reads x <= 64 B
     u32x4 pf[PF2_TILES][NPF];
     auto prefetch = [&](uint64_t t, uint32_t q) {
@@ -808,6 +795,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
     uint32_t stores_since = 0;   // copy-out stores this wave has issued since its last prefetch (wave-uniform)
     __syncthreads();
     for (uint64_t it = 0; it < n_iter; ++it) {   // one group per iteration: g = it
+        asm volatile("" : "+v"(tid), "+v"(lane));   // (opaque: what derives from them is computed where it is used, not kept in registers across the iteration)
         const uint32_t g = (uint32_t)it;
         const uint64_t t0 = it * t_step + ((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES;
         const uint32_t octet0 = (uint32_t)((it * t_step + (uint64_t)blockIdx.x * PF2_WAVES * PF2_TILES) * 8);   // octet of batch index 0
@@ -818,7 +806,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
 #pragma unroll
         for (uint32_t q = 0; q < PF2_TILES; ++q) {
             // tile q's loads were issued before the loads of the tiles behind it and the previous copy-out's stores: those may stay in flight
-            vm_wait_upto<16>(stores_since + (PF2_TILES - 1) * NPF);
+            vm_wait_range<(PF2_TILES - 1) * NPF, (PF2_TILES - 1) * NPF + 15>((uint32_t)__builtin_amdgcn_readfirstlane(stores_since) + (PF2_TILES - 1) * NPF);
 #pragma unroll
             for (int c = 0; c < NPF; ++c) vm_ready(pf[q][c]);
             const uint64_t t = t0 + q;
@@ -853,65 +841,56 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
             }
         }
         __syncthreads();
-        // per bucket: n new pairs (those beyond the part's capacity are not placed), c waiting in the open line
-        auto bucket = [&](uint32_t b, uint32_t& t_old, uint32_t& sel, uint32_t& n_new, uint32_t& ne, uint32_t& c, uint32_t& total) {
-            const uint32_t w = written[b];
-            t_old = w & TMASK;
-            sel = w >> 31;
-            n_new = hist[b];
-            const uint32_t room = Q.cap - t_old;
-            ne = n_new < room ? n_new : room;
-            c = t_old & LM;
-            total = c + ne;
-        };
-        if (wv == 0) {   // exclusive scan of the whole lines behind the open one, 256 buckets: four per lane
-            uint32_t v[4], sum = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t t_old, sel, n_new, ne, c, total;
-                bucket(lane * 4 + q, t_old, sel, n_new, ne, c, total);
-                v[q] = total >= LN ? (total & ~LM) - LN : 0u;
-                sum += v[q];
-            }
-            uint32_t inc = sum;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(inc, d);
-                if ((int)lane >= d) inc += y;
-            }
-            uint32_t run = inc - sum;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { offs[lane * 4 + q] = run; run += v[q]; }
-            if (lane == 63) offs[PF2_NB] = inc;
-        } else if (wv <= PF2_NB / 64) {   // the parts' fill before (history) and after this group; what placement and copy-out need
-            const uint32_t i = tid - 64;
-            uint32_t t_old, sel, n_new, ne, c, total;
-            bucket(i, t_old, sel, n_new, ne, c, total);
-            const uint32_t done = total >= LN ? 1u : 0u;
+        if (wv >= 1 && wv <= PF2_NB / 64) {   // the buckets' words, one bucket per lane
+            const uint32_t i = tid - 64, w = written[i], t_old = w & TMASK, sel = w >> 31, n_new = hist[i];
+            const uint32_t room = Q.cap - t_old, ne = n_new < room ? n_new : room;   // (pairs beyond the part's capacity are not placed)
+            const uint32_t c = t_old & LM, total = c + ne, full = total & ~LM;
+            const bool done = total >= LN;
             stage[i * (ST + 1) + (g % ST)] = t_old;
-            desc[i] = c | (sel << 5) | (done << 6) | ((n_new > ne ? 1u : 0u) << 7) | ((total & ~LM) << 8);
-            fl[i] = done ? ((t_old & ~LM) | (sel << 31)) : EMPTY32;
-            written2[(wsel ^ 1u) * PF2_NB + i] = (t_old + ne) | ((sel ^ done) << 31);
+            written2[(wsel ^ 1u) * PF2_NB + i] = (t_old + ne) | ((sel ^ (done ? 1u : 0u)) << 31);
+            desc[i] = c | (sel << 5) | ((n_new > ne ? 1u : 0u) << 7) | (full << 8);
+            if (full > LN) offs[i] = atomicAdd(&cnt[2 + (g & 1u)], full - LN);   // whole lines between the open line and the tail
+            const unsigned long long bal = __ballot(done);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&cnt[g & 1u], (uint32_t)__popcll(bal));   // (the four waves' lists follow each other in any order)
+            base = (uint32_t)__builtin_amdgcn_readfirstlane(base);
+            if (done) {   // the open line leaves: from carry[sel][b] to position t_old & ~31 of the part
+                const uint32_t at = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1));
+                lga[at] = (i * Q.n_writers + writer) * cap_lines + (t_old >> 5);
+                lsrc[at] = NSENT + sel * (PF2_NB * LN) + i * LN;
+            }
         }
         __syncthreads();
         uint32_t spilled = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < PF2_TILES; ++q)
+        for (uint32_t q = 0; q < PF2_TILES; ++q) {
+            uint32_t dsc[G], of[G];
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u) {   // the buckets' words first: independent LDS reads
+                const uint32_t b = pk[q][u] >> (32 - PF2_NB_LOG2);
+                dsc[u] = desc[b];
+                of[u] = offs[b];    // (stale unless the bucket has whole lines between: used only then)
+            }
 #pragma unroll
             for (uint32_t u = 0; u < G; ++u)
                 if (rank[q][u] != EMPTY32) {
                     const uint32_t key = pk[q][u], b = key >> (32 - PF2_NB_LOG2);
                     const uint32_t e = (key << 8) | ((wv * PF2_TILES + q) * 8 + (lane >> 3));
-                    const uint32_t d = desc[b], p_rel = (d & LM) + rank[q][u], sel = (d >> 5) & 1u;
+                    const uint32_t d = dsc[u], p_rel = (d & LM) + rank[q][u];
                     if ((d & 128u) && rank[q][u] >= Q.cap - (written[b] & TMASK)) {   // a part that is full (degenerate inputs): tested on the spot, below
                         spilled |= 1u << (q * G + u);
-                    } else if (p_rel >= LN && p_rel < (d >> 8)) {
-                        const uint32_t at = offs[b] + p_rel - LN;
-                        sent[at] = e;
-                        if ((at & LM) == 0) ldesc[at >> 5] = (b << 24) | ((written[b] & TMASK & ~LM) + p_rel);
-                    } else {   // the open line, or (behind the last whole line) the next one
-                        carry[(p_rel < LN ? sel : sel ^ 1u) * (PF2_NB * LN) + b * LN + (p_rel & LM)] = e;
+                        continue;
+                    }
+                    const bool mid = p_rel >= LN && p_rel < (d >> 8);
+                    const uint32_t at = of[u] + p_rel - LN;
+                    const uint32_t open_at = NSENT + ((((d >> 5) ^ (p_rel >> 5 ? 1u : 0u)) & 1u) * (PF2_NB * LN)) + b * LN + (p_rel & LM);
+                    sent[mid ? at : open_at] = e;
+                    if (mid && (at & LM) == 0) {   // the line's first pair lists it
+                        lga[PF2_NB + (at >> 5)] = (b * Q.n_writers + writer) * cap_lines + (((written[b] & TMASK & ~LM) + p_rel) >> 5);
+                        lsrc[PF2_NB + (at >> 5)] = at;
                     }
                 }
+        }
         if (spilled) {   // (static indices: a dynamically indexed pk[][] would live in scratch memory)
 #pragma unroll
             for (uint32_t x = 0; x < PF2_TILES * G; ++x)
@@ -926,45 +905,33 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
                 }
         }
         __syncthreads();
-        const uint32_t n_sent = offs[PF2_NB];
+        const uint32_t n_open = cnt[g & 1u], n_out = (n_open + (cnt[2 + (g & 1u)] >> 5)) * LN;
+        if (tid < 2) cnt[2 * tid + ((g + 1) & 1u)] = 0;   // (the next group's)
         const uint32_t hz = hsel == 0 ? 2 : hsel - 1;
         for (uint32_t i = tid; i < PF2_NB; i += NT) hist3[hz * PF2_NB + i] = 0;                  // the histogram of the group after next
-#pragma unroll 1
-        for (uint32_t v = 0; v < PF2_NB * LN / NT; ++v) {   // completed open lines: 32 lanes per bucket (whole waves store: one store per wave and trip)
-            const uint32_t t = tid + v * NT, b = t >> 5;
-            const uint32_t f = fl[b];
-            const bool valid = f != EMPTY32;
-            const uint32_t e = valid ? carry[(f >> 31) * (PF2_NB * LN) + t] : 0u;
-            uint32_t* dst = part(b) + (f & TMASK) + (t & LM);
-#if GF_EXP == 1
-            if (P.np == 12345)
-#endif
-            if (__ballot(valid)) {   // (a wave with no lane to store issues nothing: the count stays the number of stores issued)
-                if (valid) asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
-                ++stores_since;
+        // whole lines leave (32 lanes each), four trips' LDS reads in flight.  Whole waves stay in the loop — one store per wave and
+        // trip, lanes without a pair write behind the parts — so that the number of stores in flight is known.
+        for (uint32_t i0 = 0; i0 < n_out; i0 += 4 * NT) {
+            uint32_t ga[4], src[4], e[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t i = i0 + j * NT + tid, ln = i >> 5;
+                const bool valid = i < n_out;
+                const uint32_t at = ln < n_open ? ln : PF2_NB + ln - n_open;
+                ga[j] = valid ? lga[at] : dummy_line;
+                src[j] = valid ? lsrc[at] + (tid & LM) : 0u;
             }
-#if GF_EXP == 1
-            if (e == 0x12345u && dst == nullptr) atomicAdd(Q.n_cand8, 1u);
-#endif
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) e[j] = sent[src[j]];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if (i0 + j * NT < n_out) {
+                    const uint32_t* dst = Q.pairs + (((size_t)ga[j] << 5) | (tid & LM));
+                    asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e[j]) : "memory");
+                    ++stores_since;
+                }
         }
-        for (uint32_t i0 = 0; i0 < n_sent; i0 += NT) {
-            const uint32_t i = i0 + tid;
-            const bool valid = i < n_sent;
-            const uint32_t e = valid ? sent[i] : 0u;
-            const uint32_t ld = valid ? ldesc[i >> 5] : 0u;
-            uint32_t* dst = part(ld >> 24) + (ld & 0xFFFFFFu) + (i & LM);
-#if GF_EXP == 1
-            if (P.np == 12345)
-#endif
-            if (__ballot(valid)) {   // (a wave with no lane to store issues nothing: the count stays the number of stores issued)
-                if (valid) asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e) : "memory");
-                ++stores_since;
-            }
-#if GF_EXP == 1
-            if (e == 0x12345u && dst == nullptr) atomicAdd(Q.n_cand8, 1u);
-#endif
-        }
-        if ((g % ST) == ST - 1 || g + 1 == Q.n_groups) {   // the staged fill rows leave as 64-byte pieces
+        if ((g % ST) == ST - 1 || g + 1 == Q.n_groups) {   // the staged fill rows leave as 64- (32-) byte pieces
             const uint32_t g_lo = g - g % ST;
             for (uint32_t i = tid; i < PF2_NB * ST; i += NT) {
                 const uint32_t b = i / ST, j = i % ST;
@@ -2046,13 +2013,17 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.n_writers = (uint32_t)std::min<size_t>(std::min<size_t>((tiles64 + tiles_wg - 1) / tiles_wg, (size_t)ctx->n_cu), 256);   // the pair list carries the writer in 8 bits
         Q.tiles_wg = (uint32_t)tiles_wg;
         const size_t n_iter = (tiles64 + (size_t)Q.n_writers * tiles_wg - 1) / ((size_t)Q.n_writers * tiles_wg);
-        const uint32_t grp = F.np < PF2_GROUP ? (F.np ? F.np : 1u) : PF2_GROUP;   // probes per sorted group
-        Q.n_grp = (F.np + grp - 1) / grp;
-        Q.n_groups = (uint32_t)(n_iter * Q.n_grp);
-        Q.gs = (Q.n_groups + 1 + 15) & ~15u;
         const double pairs_w = (double)n_iter * tiles_wg * 64.0 * F.np;
         const double expect = pairs_w / PF2_NB;
         Q.cap = ((uint32_t)(expect * 1.05 + 6.0 * std::sqrt(expect + 1.0) + 128.0) + 63u) & ~63u;
+        // whole-line stores (pf4_scatter_lines_kernel) where all probes of a read make one group, the open lines fit beside the tiles
+        // and a line's index in `pairs` fits 32 bits (screen_variant 17: the unaligned form all the same)
+        const uint32_t grp = F.np < PF2_GROUP ? (F.np ? F.np : 1u) : PF2_GROUP;   // probes per sorted group
+        Q.n_grp = (F.np + grp - 1) / grp;
+        const bool lines = Q.n_grp == 1 && pf4_lines_lds_bytes(slice_words, grp) <= 160 * 1024 && ctx->screen_variant != 17 &&
+                           (uint64_t)PF2_NB * Q.n_writers * (Q.cap >> 5) + 1 < 0xFFFFFFFFull;
+        Q.n_groups = (uint32_t)(n_iter * Q.n_grp);
+        Q.gs = (Q.n_groups + 1 + 15) & ~15u;
         Q.cap8 = (uint32_t)(std::min<size_t>(std::max<size_t>((size_t)1 << 22, n_reads / 2), 0x7FFFFFFFu) / PF4_CHUNK * PF4_CHUNK);
         if (ctx->screen_pf4_cap8 > 0) Q.cap8 = (uint32_t)std::max(1, ctx->screen_pf4_cap8 / (int)PF4_CHUNK) * PF4_CHUNK;   // tests: a short pair list (the serial path)
         const size_t b_pairs = (size_t)PF2_NB * Q.n_writers * Q.cap * 4, b_cnt = ((size_t)PF2_NB * Q.n_writers * 4 + 255 + 256) & ~(size_t)255,
@@ -2070,12 +2041,9 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.pairs = (uint32_t*)(ws + b_cnt + b_seen + b_fill + b_c8);
         GF_HIP(ctx, hipMemsetAsync(ws + b_cnt - 256, 0, 256 + b_seen, ctx->stream));
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        // whole-line stores where the open lines fit beside the tiles (reads up to 160 bases) and a read's probes make one group
-        // (screen_variant 17: the unaligned form all the same)
-        const size_t lds_l = pf4_lines_lds_bytes(slice_words, grp);
-        if (lds_l <= 160 * 1024 && Q.n_grp == 1 && ctx->screen_variant != 17) {
+        if (lines) {
             void (*scatter)(Part4Params, uint32_t) = grp == 1 ? pf4_scatter_lines_kernel<1> : grp == 2 ? pf4_scatter_lines_kernel<2> : grp == 3 ? pf4_scatter_lines_kernel<3> : pf4_scatter_lines_kernel<4>;
-            hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_l, ctx->stream, Q, (uint32_t)slice_words);
+            hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), pf4_lines_lds_bytes(slice_words, grp), ctx->stream, Q, (uint32_t)slice_words);
         } else {
             void (*scatter)(Part4Params, uint32_t) = grp == 1 ? pf4_scatter_kernel<1> : grp == 2 ? pf4_scatter_kernel<2> : grp == 3 ? pf4_scatter_kernel<3> : pf4_scatter_kernel<4>;
             hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
