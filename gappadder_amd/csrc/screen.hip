@@ -1448,6 +1448,30 @@ __device__ __forceinline__ uint32_t packed_word(const VerifyParams& P, uint64_t 
     return v;
 }
 
+// read r of the packed array, re-aligned to a word boundary, into row[0 .. rw) (zero behind its rb bytes).  The words are fetched
+// sixteen at a time before any is used: a lane's fetches are independent, one round of global latency per sixteen words (fetched and
+// stored one by one, every word of a candidate cost the wave a round trip: 60 us per 64 candidates at C4)
+__device__ __forceinline__ void stage_read(const VerifyParams& P, uint32_t* row, uint32_t rw, uint32_t r, bool active) {
+    const uint64_t o = (uint64_t)r * P.rb;
+    const uint64_t w0 = o >> 2;
+    const uint32_t sh = (uint32_t)(o & 3) * 8;
+    const uint32_t nw = (P.rb + 3) / 4;
+    for (uint32_t i0 = 0; i0 < rw; i0 += 16) {
+        uint32_t x[17];
+#pragma unroll
+        for (uint32_t t = 0; t < 17; ++t) x[t] = (active && i0 + t <= nw) ? packed_word(P, w0 + i0 + t) : 0u;
+#pragma unroll
+        for (uint32_t t = 0; t < 16; ++t) {
+            const uint32_t i = i0 + t;
+            if (i >= rw) break;
+            uint32_t v = sh ? (x[t] >> sh) | (x[t + 1] << (32 - sh)) : x[t];
+            if (i >= nw) v = 0;
+            else if (i == nw - 1 && (P.rb & 3)) v &= (1u << ((P.rb & 3) * 8)) - 1;   // drop the next read's bytes
+            row[i] = v;
+        }
+    }
+}
+
 // One wavefront per workgroup.  A wave takes 64 candidates at a time: lane j fetches candidate j's packed read
 // into LDS (one round of global latency for 64 reads), then the whole wave verifies the candidates one by one —
 // lane = k-mer position, two positions per lane in flight, one 16-B (32-B for k > 32) slot load per probe step.
@@ -1472,22 +1496,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
     for (uint32_t c0 = blockIdx.x * bsz; c0 < n_cand; c0 += gridDim.x * bsz) {
         const uint32_t nb = n_cand - c0 < bsz ? n_cand - c0 : bsz;
         const uint32_t my_r = lane < nb ? P.cand[c0 + lane] : 0;
-        {   // stage my candidate's read, re-aligned to a word boundary
-            const uint64_t o = (uint64_t)my_r * P.rb;
-            const uint64_t w0 = o >> 2;
-            const uint32_t sh = (uint32_t)(o & 3) * 8;
-            const uint32_t nw = (P.rb + 3) / 4;
-            uint32_t prev = lane < nb ? packed_word(P, w0) : 0;
-            for (uint32_t i = 0; i < rw; ++i) {
-                uint32_t next = 0;
-                if (lane < nb && i < nw) next = packed_word(P, w0 + i + 1);
-                uint32_t v = sh ? (prev >> sh) | (next << (32 - sh)) : prev;
-                if (i >= nw) v = 0;
-                else if (i == nw - 1 && (P.rb & 3)) v &= (1u << ((P.rb & 3) * 8)) - 1;  // drop the next read's bytes
-                sm[lane * rw + i] = v;
-                prev = next;
-            }
-        }
+        stage_read(P, sm + lane * rw, rw, my_r, lane < nb);   // my candidate's read
         __syncthreads();
         // Window gate.  A k-mer of the read can only equal a flank k-mer if the ONE probed 16-mer it contains
         // (offset first + q * stride, q = ceil((p - first) / stride) or 0; stride = k - 15) is a flank 16-mer.  Every lane looks its own
@@ -1712,6 +1721,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
 // kernel through the overflow list.
 constexpr uint32_t VEXT_LIST = 16;
 
+
 __device__ __forceinline__ uint32_t fl32(const uint32_t* words, uint32_t base) {   // 16 bases from base offset `base`, MSB-first words
     const uint32_t d = base >> 4, sh = 2 * (base & 15);
     const uint64_t v = ((uint64_t)words[d] << 32) | words[d + 1];
@@ -1779,22 +1789,9 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
         const uint32_t nb = n_cand - c0 < bsz ? n_cand - c0 : bsz;
         const uint32_t my_r = lane < nb ? P.cand[c0 + lane] : 0;
         {   // stage my candidate's read, re-aligned to a word boundary, behind 4 zero words
-            const uint64_t o = (uint64_t)my_r * P.rb;
-            const uint64_t w0 = o >> 2;
-            const uint32_t sh = (uint32_t)(o & 3) * 8;
-            const uint32_t nw = (P.rb + 3) / 4;
             uint32_t* row = rows + lane * rwp;
             row[0] = row[1] = row[2] = row[3] = 0;
-            uint32_t prev = lane < nb ? packed_word(P, w0) : 0;
-            for (uint32_t i = 0; i < rw; ++i) {
-                uint32_t next = 0;
-                if (lane < nb && i < nw) next = packed_word(P, w0 + i + 1);
-                uint32_t v = sh ? (prev >> sh) | (next << (32 - sh)) : prev;
-                if (i >= nw) v = 0;
-                else if (i == nw - 1 && (P.rb & 3)) v &= (1u << ((P.rb & 3) * 8)) - 1;
-                row[4 + i] = v;
-                prev = next;
-            }
+            stage_read(P, row + 4, rw, my_r, lane < nb);
             for (uint32_t i = 0; i < nmw; ++i) nmr[lane * nmw + i] = lane < nb ? P.nmask[(uint64_t)my_r * P.nmw + i] : 0;
             cnt[lane] = 0;
         }
