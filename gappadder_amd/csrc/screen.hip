@@ -909,25 +909,27 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
         if (tid < 2) cnt[2 * tid + ((g + 1) & 1u)] = 0;   // (the next group's)
         const uint32_t hz = hsel == 0 ? 2 : hsel - 1;
         for (uint32_t i = tid; i < PF2_NB; i += NT) hist3[hz * PF2_NB + i] = 0;                  // the histogram of the group after next
-        // whole lines leave (32 lanes each), four trips' LDS reads in flight.  Whole waves stay in the loop — one store per wave and
-        // trip, lanes without a pair write behind the parts — so that the number of stores in flight is known.
-        for (uint32_t i0 = 0; i0 < n_out; i0 += 4 * NT) {
-            uint32_t ga[4], src[4], e[4];
+        // whole lines leave, eight lanes each (16 bytes per lane), two trips' LDS reads in flight.  Whole waves stay in the loop — one
+        // store per wave and trip, lanes without a piece write behind the parts — so that the number of stores in flight is known.
+        const uint32_t n_q = n_out >> 2;
+        for (uint32_t i0 = 0; i0 < n_q; i0 += 2 * NT) {
+            uint32_t ga[2], src[2];
+            u32x4 e[2];
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t i = i0 + j * NT + tid, ln = i >> 5;
-                const bool valid = i < n_out;
+            for (uint32_t j = 0; j < 2; ++j) {
+                const uint32_t i = i0 + j * NT + tid, ln = i >> 3;
+                const bool valid = i < n_q;
                 const uint32_t at = ln < n_open ? ln : PF2_NB + ln - n_open;
                 ga[j] = valid ? lga[at] : dummy_line;
-                src[j] = valid ? lsrc[at] + (tid & LM) : 0u;
+                src[j] = valid ? lsrc[at] + (tid & 7u) * 4 : 0u;
             }
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) e[j] = sent[src[j]];
+            for (uint32_t j = 0; j < 2; ++j) e[j] = *reinterpret_cast<const u32x4*>(sent + src[j]);
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j)
-                if (i0 + j * NT < n_out) {
-                    const uint32_t* dst = Q.pairs + (((size_t)ga[j] << 5) | (tid & LM));
-                    asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(e[j]) : "memory");
+            for (uint32_t j = 0; j < 2; ++j)
+                if (i0 + j * NT < n_q) {
+                    const uint32_t* dst = Q.pairs + (((size_t)ga[j] << 5) | ((tid & 7u) * 4));
+                    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(e[j]) : "memory");
                     ++stores_since;
                 }
         }
