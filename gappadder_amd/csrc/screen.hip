@@ -1043,21 +1043,24 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
         for (uint32_t w = wv; w < Q.n_writers; w += 16) {
             const uint32_t n = Q.count[(size_t)b * Q.n_writers + w];
             const uint32_t* src = Q.pairs + ((size_t)b * Q.n_writers + w) * Q.cap;
-            constexpr int PB = 16;
-            uint32_t nx[PB];
+            constexpr int PB = 16;   // entries per lane and trip: four 16-byte loads (eight: 0.86 vs 0.81 ms per 675 M pairs) (lane = four consecutive entries of each 1 024-byte row)
+            uint4 nx4[PB / 4];
             auto fetch = [&](uint32_t i0) {
 #pragma unroll
-                for (int u = 0; u < PB; ++u) nx[u] = i0 + u * 64 + lane < n ? src[i0 + u * 64 + lane] : 0u;
+                for (int c = 0; c < PB / 4; ++c) {
+                    const uint32_t at = i0 + (c * 64 + lane) * 4;
+                    nx4[c] = at < n ? *reinterpret_cast<const uint4*>(src + at) : make_uint4(0, 0, 0, 0);   // (a part's capacity is a multiple of 64 entries)
+                }
             };
             fetch(0);
             for (uint32_t i0 = 0; i0 < n; i0 += PB * 64) {
                 uint32_t pr[PB];
 #pragma unroll
-                for (int u = 0; u < PB; ++u) pr[u] = nx[u];
+                for (int c = 0; c < PB / 4; ++c) { pr[4 * c] = nx4[c].x; pr[4 * c + 1] = nx4[c].y; pr[4 * c + 2] = nx4[c].z; pr[4 * c + 3] = nx4[c].w; }
                 if (i0 + PB * 64 < n) fetch(i0 + PB * 64);
 #pragma unroll
                 for (int u = 0; u < PB; ++u) {
-                    const uint32_t pos = i0 + u * 64 + lane;
+                    const uint32_t pos = i0 + ((u >> 2) * 64 + lane) * 4 + (u & 3);
                     const uint32_t pk = (b << (32 - PF2_NB_LOG2)) | (pr[u] >> 8);
                     bool pass = false;
                     if (pos < n) {
