@@ -368,16 +368,22 @@ __device__ __forceinline__ void wg_phase_sync() {
 //   count phase   R = k-mer table (8-B slots) when the distinct k-mers keep it under 3/4 full, else the global slice
 //   graph phase   R = node table (2 slots per possible node) + inst_of/meta/succ0/succ1 arrays, else global
 // Every pointer below is generic (LDS or global); the code path is the same.
-template <bool W, int NT>
-__global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 waves per SIMD = 16 per CU for every NT: <= 128 VGPRs)
+// KC: k as a compile-time constant with kv = k - 2 (the pipeline's pairs 31/29, 41/39, 51/49), or 0: any k, kv of the call.  The
+// count and graph loops test a dozen k-dependent uniform conditions per window (which words a window spans, which masks apply); with k
+// known they fold away — as run-time values they cost scalar registers the kernel does not have (a quarter of the count loops'
+// vector instructions were v_readlane reloads of spilled scalars)
+template <bool W, int NT, int KC>
+__global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
+    static_assert(KC == 0 || (KC > 32) == W, "W = k > 32");   // (4 waves per SIMD = 16 per CU for every NT: <= 128 VGPRs)
     constexpr uint32_t ASM_THREADS = NT;
     __shared__ uint32_t s_cnt[8];  // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes [6] LDS table overflow
     __shared__ unsigned long long s_seq[2];  // [0] bases to emit  [1] global base offset
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
-    const uint32_t npos = P.read_len - P.k + 1;
-    const int k = (int)P.k, kv = (int)P.kv;
-    const uint32_t per = P.k - P.kv + 1;
+    const uint32_t PK = KC ? (uint32_t)KC : P.k, PKV = KC ? (uint32_t)(KC - 2) : P.kv;
+    const uint32_t npos = P.read_len - PK + 1;
+    const int k = (int)PK, kv = (int)PKV;
+    const uint32_t per = PK - PKV + 1;
 
     // gaps are handed out through one counter: pool sizes differ, a static stride left CUs idle behind the largest gaps
     __shared__ uint32_t s_gap, s_cand;
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
         if (n_r == 0) continue;
         // workspace unit: every k-mer AND every kv-mer of the gap is a window of one of its reads, so
         // n_r * (L - kv + 1) bounds the distinct k-mers, the nodes and every list below
-        const uint32_t unit = P.cnt_keys ? npos : P.read_len - P.kv + 1;
+        const uint32_t unit = P.cnt_keys ? npos : P.read_len - PKV + 1;
         const uint64_t n_unit64 = (uint64_t)n_r * unit;
         // workspace slice: per pool row (slice_rows == 0), or one private slice per workgroup that every gap it takes re-uses
         // (kernels leave their slice EMPTY) — sized by the caller's bound on the rows of one pool
@@ -539,11 +545,11 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                     const uint32_t pe = p + S < npos ? p + S : npos;
                     K128 fw = pv_kmer_at<W>(V, r, p, k);
                     K128 rc = revcomp_w<W>(fw, k);
-                    uint32_t nxt = pv_stream32(V, (uint64_t)r * V.rb * 8 + 2ull * (p + P.k));   // the bases behind the window
+                    uint32_t nxt = pv_stream32(V, (uint64_t)r * V.rb * 8 + 2ull * (p + PK));   // the bases behind the window
                     for (;;) {
                         bool ok = true;
                         if (P.nmask) {
-                            for (uint32_t q = p; q < p + P.k; ++q)
+                            for (uint32_t q = p; q < p + PK; ++q)
                                 if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { ok = false; break; }
                         }
                         if (ok) {
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                         if (++p >= pe) break;
                         const uint64_t b = nxt >> 30;
                         nxt <<= 2;
-                        if (W) {   // k > 32: the new base lands in the low word
+                        if constexpr (W) {   // k > 32: the new base lands in the low word
                             const int sh = 128 - 2 * k;
                             fw.hi = (fw.hi << 2) | (fw.lo >> 62);
                             fw.lo = (fw.lo << 2) | (b << sh);
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                     const unsigned long long rc = revcomp_w<false>(K128{fw, 0}, k).hi;
                     valid = true;
                     if (P.nmask) {
-                        for (uint32_t q = pp; q < pp + P.k; ++q)
+                        for (uint32_t q = pp; q < pp + PK; ++q)
                             if ((P.nmask[(r0 + rr) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { valid = false; break; }
                     }
                     return fw < rc ? fw : rc;
@@ -934,7 +940,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                 const uint32_t r = inst_i / npos, p = inst_i - r * npos;
                 if (P.nmask) {
                     bool bad = false;
-                    for (uint32_t q = p; q < p + P.k; ++q)
+                    for (uint32_t q = p; q < p + PK; ++q)
                         if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
                     if (bad) continue;
                 }
@@ -1034,7 +1040,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
         // global slice before: 910 us per gap at k = 51); 2 = everything in the global slice.  The survivors
         // say where to start (a gap has about as many nodes as surviving k-mers); a plan that overflows falls through to the next.
         bool graph_lds = false, j_lds = false;
-        const bool node_fp_on = P.k - P.kv <= 3;   // see node_upsert
+        const bool node_fp_on = PK - PKV <= 3;   // see node_upsert
         uint32_t nb = 0, n_nodes = 0;
         Tab ntab;
         ntab.g = gtab;
@@ -1216,12 +1222,14 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
             tail = cur;
             return true;
         };
-        auto uni_key = [&](uint32_t h, uint32_t t) -> K128 {
+        // (always_inline: left as calls, uni_key / beats keep the pool view, the node arrays and two closures in SCRATCH memory — every window of
+        // the count phase then reads the view from there)
+        auto uni_key = [&](uint32_t h, uint32_t t) __attribute__((always_inline)) -> K128 {
             const K128 a = node_seq(h), b = node_seq(t ^ 1u);
             return b < a ? b : a;
         };
         // does the unitig headed by y (tail ty, ny nodes, coverage cy) beat the one headed by x?
-        auto beats = [&](uint32_t y, uint32_t ty, uint32_t ny, unsigned long long cy, uint32_t x, uint32_t tx, uint32_t nx, unsigned long long cx, bool with_len) -> bool {
+        auto beats = [&](uint32_t y, uint32_t ty, uint32_t ny, unsigned long long cy, uint32_t x, uint32_t tx, uint32_t nx, unsigned long long cx, bool with_len) __attribute__((always_inline)) -> bool {
             if (with_len && ny != nx) return ny > nx;
             if (cy != cx) return cy > cx;     // equal node counts here: more coverage, then fewer weak nodes
             return uni_key(y, ty) < uni_key(x, tx);
@@ -1245,7 +1253,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                 const uint32_t ib = inb(o);
                 uint32_t t, n;
                 unsigned long long cx;
-                if (!walk(o, 2 * P.kv, t, n, cx)) continue;
+                if (!walk(o, 2 * PKV, t, n, cx)) continue;
                 const K128 hs = node_seq(o);
                 const uint32_t p = find_oriented(shift_in_front(hs, __ffs(ib) - 1, kv));
                 if (p == EMPTY32) continue;
@@ -1253,7 +1261,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                 if (__popc(pb) < 2) continue;
                 const uint32_t tb = outb(t);
                 bool go = false;
-                if (tb == 0 && n <= P.kv) {                                     // TIP
+                if (tb == 0 && n <= PKV) {                                     // TIP
                     const K128 ps = node_seq(p);
                     for (uint32_t c = 0; c < 4 && !go; ++c) {
                         if (!((pb >> c) & 1u)) continue;
@@ -1261,7 +1269,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                         if (y == EMPTY32 || y == o || has_pred(y) || y == (t ^ 1u)) continue;
                         uint32_t ty, ny;
                         unsigned long long cy;
-                        const bool tip_shaped = walk(y, P.kv, ty, ny, cy) && outb(ty) == 0 && __popc(inb(y)) == 1;
+                        const bool tip_shaped = walk(y, PKV, ty, ny, cy) && outb(ty) == 0 && __popc(inb(y)) == 1;
                         if (!tip_shaped || beats(y, ty, ny, cy, o, t, n, cx, true)) go = true;
                     }
                 } else if (__popc(tb) == 1) {                                   // BUBBLE (n <= 2 kv by the walk)
@@ -1421,7 +1429,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                 const unsigned long long jo = J.load(o);
                 const uint32_t tail = (uint32_t)jo, len = (uint32_t)(jo >> 32);
                 uint32_t q = EMPTY32;
-                if (len && len + P.kv - 1 >= P.min_contig) {
+                if (len && len + PKV - 1 >= P.min_contig) {
                     const K128 first = node_seq(o);
                     const K128 opp = node_seq(tail ^ 1u);
                     if (!(opp < first)) {
@@ -1432,7 +1440,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                             rec[4 * q + 1] = len;
                             rec[4 * q + 3] = 0;              // coverage sum when the LDS accumulators do not reach this far
                             if (q < cacc_cap) cacc[q] = 0;
-                            atomicAdd(&s_seq[0], (unsigned long long)(len + P.kv - 1));
+                            atomicAdd(&s_seq[0], (unsigned long long)(len + PKV - 1));
                         }
                     }
                 }
@@ -1450,7 +1458,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
             __syncthreads();
             ASM_STAMP(5);
             for (uint32_t q = tid; q < n_emit; q += ASM_THREADS)                // relative offsets of the contigs
-                rec[4 * q + 2] = (uint32_t)atomicAdd(&s_seq[0], (unsigned long long)(rec[4 * q + 1] + P.kv - 1));
+                rec[4 * q + 2] = (uint32_t)atomicAdd(&s_seq[0], (unsigned long long)(rec[4 * q + 1] + PKV - 1));
             wg_phase_sync();
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
                 if (is_dead(o)) continue;
@@ -1464,7 +1472,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                 const uint32_t q = (uint32_t)J.load(h);
                 if (q == EMPTY32 || q >= n_emit) continue;
                 const unsigned long long off = s_seq[1] + rec[4 * q + 2];
-                const uint32_t len = rec[4 * q + 1] + P.kv - 1;
+                const uint32_t len = rec[4 * q + 1] + PKV - 1;
                 if (cacc_lds) atomicAdd(&cacc[q], nmeta.get(o >> 1) >> M_MULT_SHIFT);
                 else atomicAdd(&rec[4 * q + 3], nmeta.get(o >> 1) >> M_MULT_SHIFT);
                 if (off + len > P.seq_cap) continue;
@@ -1480,8 +1488,8 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {   // (4 
                 const uint32_t ci = s_cnt[2] + q;
                 if (ci < P.contig_cap) {
                     gf_contig ct;
-                    ct.gap = g; ct.k = (uint16_t)P.k; ct.kv = (uint16_t)P.kv; ct.n_nodes = rec[4 * q + 1];
-                    ct.length = rec[4 * q + 1] + P.kv - 1; ct.cov_sum = cacc_lds ? cacc[q] : __hip_atomic_load(&rec[4 * q + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // from L2, where the atomics landed
+                    ct.gap = g; ct.k = (uint16_t)PK; ct.kv = (uint16_t)PKV; ct.n_nodes = rec[4 * q + 1];
+                    ct.length = rec[4 * q + 1] + PKV - 1; ct.cov_sum = cacc_lds ? cacc[q] : __hip_atomic_load(&rec[4 * q + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // from L2, where the atomics landed
                     ct.reserved = 0;
                     ct.seq_off = s_seq[1] + rec[4 * q + 2];
                     P.contigs[ci] = ct;
@@ -1592,9 +1600,14 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS / per_cu, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
     {
         LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
-        void (*kern)(AsmParams) = nt == 1024 ? (k <= 32 ? assemble_kernel<false, 1024> : assemble_kernel<true, 1024>)
-                                  : nt == 512 ? (k <= 32 ? assemble_kernel<false, 512> : assemble_kernel<true, 512>)
-                                              : (k <= 32 ? assemble_kernel<false, 256> : assemble_kernel<true, 256>);
+        void (*kern)(AsmParams) = nt == 1024 ? (k <= 32 ? assemble_kernel<false, 1024, 0> : assemble_kernel<true, 1024, 0>)
+                                  : nt == 512 ? (k <= 32 ? assemble_kernel<false, 512, 0> : assemble_kernel<true, 512, 0>)
+                                              : (k <= 32 ? assemble_kernel<false, 256, 0> : assemble_kernel<true, 256, 0>);
+        if (kv == k - 2 && nt >= 512) {   // the pipeline's k / kv pairs: k at compile time
+            if (k == 51) kern = nt == 1024 ? assemble_kernel<true, 1024, 51> : assemble_kernel<true, 512, 51>;
+            if (k == 41) kern = nt == 1024 ? assemble_kernel<true, 1024, 41> : assemble_kernel<true, 512, 41>;
+            if (k == 31) kern = nt == 1024 ? assemble_kernel<false, 1024, 31> : assemble_kernel<false, 512, 31>;
+        }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), (size_t)P.lds_words * 4, ctx->stream, P);
     }
     GF_HIP(ctx, hipGetLastError());

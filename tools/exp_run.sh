@@ -1,10 +1,12 @@
 #!/bin/bash
-cd /root/repo; mkdir -p gpurun_out/exp; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "variants or partitioned or synthetic or human_scale" < /dev/null 2>&1 | tail -3
-for k in 51 41 31; do
-for v in 0 17; do
-    timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/exp/r$k$v -o r -- python3 tools/exp_filter.py - 112500000 $k $v < /dev/null 2>&1 | grep "filter"
-    timeout 60 python3 tools/rocpd_top.py gpurun_out/exp/r$k$v pf4_scatter < /dev/null 2>&1 | head -2
-done
-done
-rm -rf gpurun_out/exp
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -m gpu -x -q < /dev/null 2>&1 | tail -3
+timeout 600 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu < /dev/null 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['phases_ms'])"
+timeout 900 python bench.py --steps 2 --warmup 1 --no-extras --no-cpu --config C5 < /dev/null 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['phases_ms'], d['counts']['gaps_closed'], d['closed_truth_check']['correct'])"
+timeout 900 python bench.py --steps 20 --warmup 2 --no-extras --no-cpu --config C2 < /dev/null 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['phases_ms'])"
