@@ -372,9 +372,13 @@ __device__ __forceinline__ void wg_phase_sync() {
 // count and graph loops test a dozen k-dependent uniform conditions per window (which words a window spans, which masks apply); with k
 // known they fold away — as run-time values they cost scalar registers the kernel does not have (a quarter of the count loops'
 // vector instructions were v_readlane reloads of spilled scalars)
-template <bool W, int NT, int KC>
+// PIPE: the launch is the pipeline's (no N masks, no count-only output, every pool fits its share of the LDS: the host checked) — the
+// per-window tests of those cases fold away with the rest
+template <bool W, int NT, int KC, bool PIPE>
 __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
-    static_assert(KC == 0 || (KC > 32) == W, "W = k > 32");   // (4 waves per SIMD = 16 per CU for every NT: <= 128 VGPRs)
+    static_assert(KC == 0 || (KC > 32) == W, "W = k > 32");
+    const uint32_t* const nmask = PIPE ? nullptr : P.nmask;
+    uint64_t* const cnt_keys = PIPE ? nullptr : P.cnt_keys;   // (4 waves per SIMD = 16 per CU for every NT: <= 128 VGPRs)
     constexpr uint32_t ASM_THREADS = NT;
     __shared__ uint32_t s_cnt[8];  // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes [6] LDS table overflow
     __shared__ unsigned long long s_seq[2];  // [0] bases to emit  [1] global base offset
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         if (n_r == 0) continue;
         // workspace unit: every k-mer AND every kv-mer of the gap is a window of one of its reads, so
         // n_r * (L - kv + 1) bounds the distinct k-mers, the nodes and every list below
-        const uint32_t unit = P.cnt_keys ? npos : P.read_len - PKV + 1;
+        const uint32_t unit = cnt_keys ? npos : P.read_len - PKV + 1;
         const uint64_t n_unit64 = (uint64_t)n_r * unit;
         // workspace slice: per pool row (slice_rows == 0), or one private slice per workgroup that every gap it takes re-uses
         // (kernels leave their slice EMPTY) — sized by the caller's bound on the rows of one pool
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         V.g32 = P.reads32; V.g_words = P.n_words; V.g_tail = P.tail_bytes;
         V.first_byte = r0 * P.rb;
         const uint64_t pool_bytes = (uint64_t)n_r * P.rb;
-        V.lds = pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / (W ? 2 : 3);  // at most a third of the LDS (half when the count table is global anyway)
+        V.lds = PIPE ? true : pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / (W ? 2 : 3);  // at most a third of the LDS (half when the count table is global anyway)
         uint32_t pool_words = 0;
         if (V.lds) {
             const uint64_t w0 = V.first_byte >> 2;
@@ -478,11 +482,11 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             // sequencing depth — costs one 8-byte read and a compare: no key re-derivation from the reads, and no atomic
             // once the count has saturated.  The instance id of each distinct k-mer goes to a side list (the node arrays
             // are idle here).
-            keyslot = P.keyslot && !W && k <= 31 && P.min_count <= 3 && !P.cnt_keys;
+            keyslot = P.keyslot && !W && k <= 31 && P.min_count <= 3 && !cnt_keys;
             // wide variant (32 < k <= 63): a 16-byte slot = {hi, ~(lo | count)}, see count_keyslot_wide below.  Only for the
             // global table: in LDS the doubled slot size overflows pools that the 8-byte instance-id slots still hold
             // (measured at k=41, 214-read pools: 161 us against 105 us per gap).
-            const bool wide_ok = P.keyslot && W && k > 32 && k <= 62 && P.min_count <= 3 && !P.cnt_keys;   // (k <= 62: three spare bits in the 16-byte slot)
+            const bool wide_ok = P.keyslot && W && k > 32 && k <= 62 && P.min_count <= 3 && !cnt_keys;   // (k <= 62: three spare bits in the 16-byte slot)
             keyslot_w = wide_ok && !use_lds;
             // fingerprint slots (32 < k <= 63 in an LDS table over an LDS-staged pool): slot = instance id | 30-bit key fingerprint
             // << 32 | 2-bit saturating count << 62.  A probe that meets another key sees it in the fingerprint (no re-derivation of
@@ -548,9 +552,9 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                     uint32_t nxt = pv_stream32(V, (uint64_t)r * V.rb * 8 + 2ull * (p + PK));   // the bases behind the window
                     for (;;) {
                         bool ok = true;
-                        if (P.nmask) {
+                        if (nmask) {
                             for (uint32_t q = p; q < p + PK; ++q)
-                                if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { ok = false; break; }
+                                if ((nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { ok = false; break; }
                         }
                         if (ok) {
                             const K128 key = rc < fw ? rc : fw;
@@ -723,9 +727,9 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                     const unsigned long long fw = pv_kmer_at<false>(V, rr, pp, k).hi;
                     const unsigned long long rc = revcomp_w<false>(K128{fw, 0}, k).hi;
                     valid = true;
-                    if (P.nmask) {
+                    if (nmask) {
                         for (uint32_t q = pp; q < pp + PK; ++q)
-                            if ((P.nmask[(r0 + rr) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { valid = false; break; }
+                            if ((nmask[(r0 + rr) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { valid = false; break; }
                     }
                     return fw < rc ? fw : rc;
                 };
@@ -938,10 +942,10 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
                 if (use_lds && s_cnt[6]) break;
                 const uint32_t r = inst_i / npos, p = inst_i - r * npos;
-                if (P.nmask) {
+                if (nmask) {
                     bool bad = false;
                     for (uint32_t q = p; q < p + PK; ++q)
-                        if ((P.nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
+                        if ((nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
                     if (bad) continue;
                 }
                 const uint32_t inst = make_inst(r, p);
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                         : keyslot_w ? (uint32_t)(~v[u] & 7ull)
                         : keyslot ? (uint32_t)((tab_global ? ~v[u] : (GF_KS_COMPLEMENT_LDS ? ~v[u] : v[u])) & 3ull) + 1u : (uint32_t)(v[u] >> 32);
                     keep = c >= P.min_count;
-                    if (!P.cnt_keys && (c < 4u ? c : 4u) <= P.min_count + 1) id |= INST_WEAK;   // (counts saturate at 4: the slots' 2-bit counters)
+                    if (!cnt_keys && (c < 4u ? c : 4u) <= P.min_count + 1) id |= INST_WEAK;   // (counts saturate at 4: the slots' 2-bit counters)
                     if (tab_global) {
                         if (keyslot_w) { tab.store(2 * sl[u], EMPTY64); tab.store(2 * sl[u] + 1, EMPTY64); }
                         else tab.store(sl[u], EMPTY64);
@@ -1007,10 +1011,10 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                     if (keep) {
                         const uint32_t o = base + __popcll(bal & ((1ull << lane) - 1));
                         list_b[o] = id;
-                        if (P.cnt_keys && o < P.cnt_cap) {
+                        if (cnt_keys && o < P.cnt_cap) {
                             const K128 key = canonical_w<W>(pv_kmer<W>(V, id, k), k);
-                            P.cnt_keys[2 * (uint64_t)o] = key.hi;
-                            P.cnt_keys[2 * (uint64_t)o + 1] = key.lo;
+                            cnt_keys[2 * (uint64_t)o] = key.hi;
+                            cnt_keys[2 * (uint64_t)o + 1] = key.lo;
                             P.cnt_counts[o] = c > 10000000u ? 10000000u : c;  // kmc -cs10000000 (assemble_gaps.py:96)
                         }
                     }
@@ -1018,7 +1022,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             }
         }
         wg_phase_sync();
-        if (P.cnt_keys) {
+        if (cnt_keys) {
             if (tid == 0) { *P.n_contigs = s_cnt[0]; if (s_cnt[3]) P.gap_error[g] |= s_cnt[3]; }
             __syncthreads();
             continue;
@@ -1600,13 +1604,15 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS / per_cu, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
     {
         LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
-        void (*kern)(AsmParams) = nt == 1024 ? (k <= 32 ? assemble_kernel<false, 1024, 0> : assemble_kernel<true, 1024, 0>)
-                                  : nt == 512 ? (k <= 32 ? assemble_kernel<false, 512, 0> : assemble_kernel<true, 512, 0>)
-                                              : (k <= 32 ? assemble_kernel<false, 256, 0> : assemble_kernel<true, 256, 0>);
-        if (kv == k - 2 && nt >= 512) {   // the pipeline's k / kv pairs: k at compile time
-            if (k == 51) kern = nt == 1024 ? assemble_kernel<true, 1024, 51> : assemble_kernel<true, 512, 51>;
-            if (k == 41) kern = nt == 1024 ? assemble_kernel<true, 1024, 41> : assemble_kernel<true, 512, 41>;
-            if (k == 31) kern = nt == 1024 ? assemble_kernel<false, 1024, 31> : assemble_kernel<false, 512, 31>;
+        void (*kern)(AsmParams) = nt == 1024 ? (k <= 32 ? assemble_kernel<false, 1024, 0, false> : assemble_kernel<true, 1024, 0, false>)
+                                  : nt == 512 ? (k <= 32 ? assemble_kernel<false, 512, 0, false> : assemble_kernel<true, 512, 0, false>)
+                                              : (k <= 32 ? assemble_kernel<false, 256, 0, false> : assemble_kernel<true, 256, 0, false>);
+        // the pipeline's launches: k / kv one of its pairs, no N masks, no count-only output, every pool within its share of the LDS
+        const bool pools_fit = slice_rows > 0 && (uint64_t)slice_rows * rb + 32 <= (uint64_t)P.lds_words * 4 / (k > 32 ? 2 : 3);
+        if (kv == k - 2 && nt >= 512 && !d_nmask && !d_cnt_keys && pools_fit) {
+            if (k == 51) kern = nt == 1024 ? assemble_kernel<true, 1024, 51, true> : assemble_kernel<true, 512, 51, true>;
+            if (k == 41) kern = nt == 1024 ? assemble_kernel<true, 1024, 41, true> : assemble_kernel<true, 512, 41, true>;
+            if (k == 31) kern = nt == 1024 ? assemble_kernel<false, 1024, 31, true> : assemble_kernel<false, 512, 31, true>;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), (size_t)P.lds_words * 4, ctx->stream, P);
     }
