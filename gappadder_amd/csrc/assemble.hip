@@ -372,9 +372,9 @@ __device__ __forceinline__ void wg_phase_sync() {
 // count and graph loops test a dozen k-dependent uniform conditions per window (which words a window spans, which masks apply); with k
 // known they fold away — as run-time values they cost scalar registers the kernel does not have (a quarter of the count loops'
 // vector instructions were v_readlane reloads of spilled scalars)
-// PIPE: the launch is the pipeline's (no N masks, no count-only output, every pool fits its share of the LDS: the host checked) — the
-// per-window tests of those cases fold away with the rest
-template <bool W, int NT, int KC, bool PIPE>
+// PIPE: the launch is the pipeline's (no N masks, no count-only output); FIT: every pool fits its share of the LDS (the host
+// checked) — the per-window tests of those cases fold away with the rest
+template <bool W, int NT, int KC, bool PIPE, bool FIT>   // FIT: every pool fits its share of the LDS
 __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
     static_assert(KC == 0 || (KC > 32) == W, "W = k > 32");
     const uint32_t* const nmask = PIPE ? nullptr : P.nmask;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         V.g32 = P.reads32; V.g_words = P.n_words; V.g_tail = P.tail_bytes;
         V.first_byte = r0 * P.rb;
         const uint64_t pool_bytes = (uint64_t)n_r * P.rb;
-        V.lds = PIPE ? true : pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / (W ? 2 : 3);  // at most a third of the LDS (half when the count table is global anyway)
+        V.lds = FIT ? true : pool_bytes + 32 <= (uint64_t)P.lds_words * 4 / (W ? 2 : 3);  // at most a third of the LDS (half when the count table is global anyway)
         uint32_t pool_words = 0;
         if (V.lds) {
             const uint64_t w0 = V.first_byte >> 2;
@@ -1604,15 +1604,16 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS / per_cu, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
     {
         LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
-        void (*kern)(AsmParams) = nt == 1024 ? (k <= 32 ? assemble_kernel<false, 1024, 0, false> : assemble_kernel<true, 1024, 0, false>)
-                                  : nt == 512 ? (k <= 32 ? assemble_kernel<false, 512, 0, false> : assemble_kernel<true, 512, 0, false>)
-                                              : (k <= 32 ? assemble_kernel<false, 256, 0, false> : assemble_kernel<true, 256, 0, false>);
-        // the pipeline's launches: k / kv one of its pairs, no N masks, no count-only output, every pool within its share of the LDS
+        void (*kern)(AsmParams) = nt == 1024 ? (k <= 32 ? assemble_kernel<false, 1024, 0, false, false> : assemble_kernel<true, 1024, 0, false, false>)
+                                  : nt == 512 ? (k <= 32 ? assemble_kernel<false, 512, 0, false, false> : assemble_kernel<true, 512, 0, false, false>)
+                                              : (k <= 32 ? assemble_kernel<false, 256, 0, false, false> : assemble_kernel<true, 256, 0, false, false>);
+        // the pipeline's launches: k / kv one of its pairs, no N masks, no count-only output; every pool within its share of the LDS
         const bool pools_fit = slice_rows > 0 && (uint64_t)slice_rows * rb + 32 <= (uint64_t)P.lds_words * 4 / (k > 32 ? 2 : 3);
-        if (kv == k - 2 && nt >= 512 && !d_nmask && !d_cnt_keys && pools_fit) {
-            if (k == 51) kern = nt == 1024 ? assemble_kernel<true, 1024, 51, true> : assemble_kernel<true, 512, 51, true>;
-            if (k == 41) kern = nt == 1024 ? assemble_kernel<true, 1024, 41, true> : assemble_kernel<true, 512, 41, true>;
-            if (k == 31) kern = nt == 1024 ? assemble_kernel<false, 1024, 31, true> : assemble_kernel<false, 512, 31, true>;
+        if (kv == k - 2 && nt >= 512 && !d_nmask && !d_cnt_keys) {
+            if (k == 51 && pools_fit) kern = nt == 1024 ? assemble_kernel<true, 1024, 51, true, true> : assemble_kernel<true, 512, 51, true, true>;
+            if (k == 41 && pools_fit) kern = nt == 1024 ? assemble_kernel<true, 1024, 41, true, true> : assemble_kernel<true, 512, 41, true, true>;
+            if (k == 31) kern = pools_fit ? (nt == 1024 ? assemble_kernel<false, 1024, 31, true, true> : assemble_kernel<false, 512, 31, true, true>)
+                                          : (nt == 1024 ? assemble_kernel<false, 1024, 31, true, false> : assemble_kernel<false, 512, 31, true, false>);
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), (size_t)P.lds_words * 4, ctx->stream, P);
     }
