@@ -1058,16 +1058,24 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
 #pragma unroll
                 for (int c = 0; c < PB / 4; ++c) { pr[4 * c] = nx4[c].x; pr[4 * c + 1] = nx4[c].y; pr[4 * c + 2] = nx4[c].z; pr[4 * c + 3] = nx4[c].w; }
                 if (i0 + PB * 64 < n) fetch(i0 + PB * 64);
+                // both bits of every key in its word of the slice: the trip's sixteen LDS reads first (independent), then the tests
+                uint32_t wd[PB], passm = 0;
 #pragma unroll
                 for (int u = 0; u < PB; ++u) {
                     const uint32_t pos = i0 + ((u >> 2) * 64 + lane) * 4 + (u & 3);
+                    const uint32_t h = ((b << (32 - PF2_NB_LOG2)) | (pr[u] >> 8)) >> sh_bm;   // bit index in the whole bitmap; its top 8 bits = b
+                    wd[u] = pos < n ? sm[(h >> 5) & (slice_words - 1)] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
                     const uint32_t pk = (b << (32 - PF2_NB_LOG2)) | (pr[u] >> 8);
-                    bool pass = false;
-                    if (pos < n) {
-                        const uint32_t h = pk >> sh_bm;                       // bit index in the whole bitmap; its top 8 bits = b
-                        const uint32_t wd = sm[(h >> 5) & (slice_words - 1)];
-                        pass = (wd >> (h & 31)) & (wd >> (pk & 31)) & 1u;      // both bits of the key in its word
-                    }
+                    passm |= ((wd[u] >> ((pk >> sh_bm) & 31)) & (wd[u] >> (pk & 31)) & 1u) << u;
+                }
+                if (!__any(passm != 0)) continue;
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const uint32_t pos = i0 + ((u >> 2) * 64 + lane) * 4 + (u & 3);
+                    const bool pass = (passm >> u) & 1u;
                     const unsigned long long bal = __ballot(pass);
                     if (bal) {
                         if (pass) pend[pend_n + __popcll(bal & lt)] = ((unsigned long long)w << 56) | ((unsigned long long)pos << 32) | ((pr[u] & 255u) << 24) | (pr[u] >> 8);
