@@ -303,7 +303,7 @@ __device__ __forceinline__ uint32_t node_fp(uint64_t x) { return (uint32_t)(x >>
 template <bool W>
 __device__ __forceinline__ uint32_t node_upsert(const Tab& t, const PoolView& V, K128 key, uint32_t inst, int len, uint32_t inc, bool fp_on,
                                                 bool* fresh) {
-    const uint64_t x = hash_of(key);
+    const uint64_t x = hash_p1<W>(key);   // (as in the count phase: six 32-bit multiplies instead of three 64-bit ones)
     const uint32_t fp = fp_on ? node_fp(x) : 0u;
     uint32_t s = slot_of_hash(x, t.cap);
     *fresh = false;
@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             const K128 yr = revcomp_w<W>(y, kv);
             const uint32_t dy = yr < y ? 1u : 0u;
             const K128 Y = dy ? yr : y;
-            const uint64_t x = hash_of(Y);
+            const uint64_t x = hash_p1<W>(Y);
             const uint32_t fp = node_fp(x);
             uint32_t sl = slot_of_hash(x, ntab.cap);
             for (uint32_t probes = 0; probes < ntab.cap; ++probes) {

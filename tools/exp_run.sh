@@ -1,8 +1,6 @@
 #!/bin/bash
-cd /root/repo; mkdir -p gpurun_out/exp; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "variants or partitioned or synthetic or human_scale" < /dev/null 2>&1 | tail -3
-for k in 51 31; do
-    timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/exp/r$k -o r -- python3 tools/exp_filter.py - 112500000 $k 0 < /dev/null 2>&1 | grep "filter"
-    timeout 60 python3 tools/rocpd_top.py gpurun_out/exp/r$k pf4 < /dev/null 2>&1 | head -4
-done
-rm -rf gpurun_out/exp
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_assembly.py tests/test_gpu_scale.py -x -q < /dev/null 2>&1 | tail -3
+GF_DIAGNOSTICS=1 GF_BENCH_ASM_PROBE=1 timeout 600 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu < /dev/null 2>/tmp/err.txt | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['phases_ms'])"; grep "assembly phases" /tmp/err.txt
