@@ -102,14 +102,14 @@ int gf_stream_wait_after_filter(gf_ctx* waiter, gf_ctx* producer);
  * "bitmap_log2" (size of the screen's level-1 16-mer bitmap, 0 = automatic), "index_host" (1: build the flank k-mer index with
  * the host comparator instead of the device kernels — same index up to slot order; a test aid, refused unless the environment
  * has GF_DIAGNOSTICS set).
- * Ablation / diagnostic switches (results never change): "screen_variant" (0 automatic, 9 plain, 12 wave, 13 pipelined, 14 partitioned
- * filter kernel), "screen_verify_ext" (1: seed-and-extend verification when min_hits == 1), "screen_verify_gate",
+ * Ablation / diagnostic switches (results never change): "screen_variant" (0 automatic, 9 plain, 13 pipelined, 14 partitioned with
+ * 16 buckets, 16 partitioned with 256 buckets and 4-byte pairs, 17 the same with unaligned pair runs in its first pass), "screen_verify_ext" (1: seed-and-extend verification when min_hits == 1), "screen_verify_gate",
  * "screen_verify_batch", "screen_stream_policy", "screen_lds_log2_max", "screen_np_override" (timing experiments: fewer probes, WRONG hits; refused unless the environment has GF_DIAGNOSTICS set),
  * "asm_keyslot", "asm_lds_pool_kb", "asm_dbg_ptr".
  * Tagger: "tag_light" (1: one-wave workgroups that read the coarse bin map through L1/L2 instead of staging it in LDS — same hits;
  * for a pipeline that runs the tagger on a second context beside the k-mer filter, whose workgroups own most of every CU's LDS).
  * Assembly: "asm_simplify" (rounds of tip clipping + bubble popping — Velvet's defaults, which the reference runs with
- * (assemble_gaps.py:117); default 2, 0 = raw unitigs), "asm_max_pool_reads" (device variants: upper bound on the rows of one
+ * (assemble_gaps.py:117); default 8 (where the rounds have converged), 0 = raw unitigs), "asm_max_pool_reads" (device variants: upper bound on the rows of one
  * pool; the assembly workspace is then one slice of that size per workgroup instead of one per pool row — a pool beyond the bound
  * sets its gap_error; 0 = no bound). */
 int gf_set_option(gf_ctx* ctx, const char* name, long value);
