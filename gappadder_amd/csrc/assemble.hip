@@ -1044,6 +1044,12 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         // global slice before: 910 us per gap at k = 51); 2 = everything in the global slice.  The survivors
         // say where to start (a gap has about as many nodes as surviving k-mers); a plan that overflows falls through to the next.
         bool graph_lds = false, j_lds = false;
+        // Successor slots: while the nodes are built every edge is at hand with BOTH its slots, so it leaves "a successor of (slot,
+        // orientation)" in the pair workspace (idle until the error removal) — for an oriented node with ONE arc out that is the
+        // successor, and the links phase reads it instead of finding the shifted kv-mer in the node table again (derive, reverse
+        // complement, hash, probe, verify: 34 of a C4 gap's 314 us).  Equal values race when the out-degree is 1; otherwise unused.
+        bool cand_on = false;
+        uint32_t* const scand = P.jump + 4 * inst_off;
         const bool node_fp_on = PK - PKV <= 3;   // see node_upsert
         uint32_t nb = 0, n_nodes = 0;
         Tab ntab;
@@ -1063,6 +1069,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             ntab.lds = graph_lds;
             ntab.off = R + 4 * nb;
             ntab.cap = graph_lds ? ((r_words - (j_lds ? 6 : 4) * nb) / 2) : gcap;
+            cand_on = graph_lds && 2ull * ntab.cap <= 4ull * n_unit;   // (the slice of the pair workspace holds two words per slot)
             if (graph_lds) {
                 for (uint32_t i = tid; i < ntab.cap; i += ASM_THREADS) ntab.store(i, EMPTY64);
                 __syncthreads();
@@ -1105,6 +1112,10 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                         const uint32_t c_out = kbase(t, (int)(o - 1) + kv), c_in = kbase(t, (int)o - 1);
                         ntab.or_meta(ps, pd ? (1u << (4 + (3 - c_out))) : (1u << c_out));
                         ntab.or_meta(sl, d ? (1u << (3 - c_in)) : (1u << (4 + c_in)));
+                        if (cand_on) {
+                            scand[2 * ps + pd] = (sl << 1) | d;                  // (prev, pd) -> (this, d)
+                            scand[2 * sl + (d ^ 1u)] = (ps << 1) | (pd ^ 1u);    // and the same edge read from the other strand
+                        }
                     }
                     ps = sl; pd = d;
                 }
@@ -1183,6 +1194,25 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         auto graph_sync = [&]() { if (j_lds) __syncthreads(); else wg_phase_sync(); };   // (j_lds implies graph_lds)
         // ---- P4: unitig-internal edges.  (x,d) -> (y,dy) is internal iff out-degree(x,d) == 1 and in-degree(y,dy) == 1;
         //      an oriented node that no internal edge enters is a unitig START.
+        if (cand_on) {
+            for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
+                const uint32_t meta = nmeta.get(ni);
+                const uint32_t o0 = out_bits(meta & 0xFFu, 0), o1 = out_bits(meta & 0xFFu, 1);
+                if (__popc(o0) != 1 && __popc(o1) != 1) continue;
+                const uint32_t sl = list_a[ni];
+                // (written by other waves two phase barriers ago; read from L2 like every hand-over through global memory)
+                const uint32_t c0 = __popc(o0) == 1 ? __hip_atomic_load(&scand[2 * sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                const uint32_t c1 = __popc(o1) == 1 ? __hip_atomic_load(&scand[2 * sl + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                for (uint32_t d = 0; d < 2; ++d) {
+                    if (__popc(d ? o1 : o0) != 1) continue;
+                    const uint32_t c = d ? c1 : c0;
+                    const uint32_t y = (ntab.id(c >> 1) << 1) | (c & 1u);
+                    if (__popc(inb(y)) != 1) continue;
+                    (d ? succ1 : succ0).set(ni, y);
+                    nmeta.or_(y >> 1, (y & 1) ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
+                }
+            }
+        } else
         for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
             const uint32_t meta = nmeta.get(ni);
             const K128 x = canonical_w<W>(pv_kmer<W>(V, inst_of.get(ni), kv), kv);
