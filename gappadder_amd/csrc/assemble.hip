@@ -300,6 +300,10 @@ __device__ __forceinline__ uint32_t table_upsert(const Tab& t, const PoolView& V
 // switches the fingerprint on only when k - kv <= 3 (a kv-mer lies in at most (k - kv + 1) * 4^(k - kv) <= 256 distinct k-mers).
 constexpr uint32_t NODE_FP_SHIFT = 24;
 __device__ __forceinline__ uint32_t node_fp(uint64_t x) { return (uint32_t)(x >> 56); }
+// The probe sequence is walked in TWO nested steps: a cheap scan to the next slot that is empty or carries this key's fingerprint, then —
+// outside that scan — the claim or the exact comparison with the occupant's kv-mer (re-derived from the staged reads: ~50 instructions
+// and 5 LDS reads).  With the comparison inside the one probe loop every iteration of a wave ran it as soon as any of its 64 lanes
+// stood at a matching fingerprint: ~760 instructions per upsert and wave at C4; almost every lane needs it exactly once.
 template <bool W>
 __device__ __forceinline__ uint32_t node_upsert(const Tab& t, const PoolView& V, K128 key, uint32_t inst, int len, uint32_t inc, bool fp_on,
                                                 bool* fresh) {
@@ -307,18 +311,30 @@ __device__ __forceinline__ uint32_t node_upsert(const Tab& t, const PoolView& V,
     const uint32_t fp = fp_on ? node_fp(x) : 0u;
     uint32_t s = slot_of_hash(x, t.cap);
     *fresh = false;
-    for (uint32_t probes = 0; probes < t.cap; ++probes) {
+    uint32_t probes = 0;
+    while (probes < t.cap) {
         unsigned long long v = t.load(s);
+        while ((uint32_t)v != EMPTY32 && fp_on && (uint32_t)(v >> (32 + NODE_FP_SHIFT)) != fp) {   // another key's slot: next
+            s = s + 1 == t.cap ? 0 : s + 1;
+            if (++probes >= t.cap) return EMPTY32;
+            v = t.load(s);
+        }
         if ((uint32_t)v == EMPTY32) {
             v = t.cas(s, EMPTY64, ((unsigned long long)(inc | (fp << NODE_FP_SHIFT)) << 32) | inst);
             if (v == EMPTY64) { *fresh = true; return s; }
+            if (fp_on && (uint32_t)(v >> (32 + NODE_FP_SHIFT)) != fp) {   // claimed meanwhile, by another key
+                s = s + 1 == t.cap ? 0 : s + 1;
+                ++probes;
+                continue;
+            }
         }
         const uint32_t cur = (uint32_t)v;
-        if ((!fp_on || (uint32_t)(v >> (32 + NODE_FP_SHIFT)) == fp) && (cur == inst || canonical_w<W>(pv_kmer<W>(V, cur, len), len) == key)) {
+        if (cur == inst || canonical_w<W>(pv_kmer<W>(V, cur, len), len) == key) {
             t.add(s, (unsigned long long)inc << 32);
             return s;
         }
         s = s + 1 == t.cap ? 0 : s + 1;
+        ++probes;
     }
     return EMPTY32;
 }
@@ -1167,14 +1183,19 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             const uint64_t x = hash_p1<W>(Y);
             const uint32_t fp = node_fp(x);
             uint32_t sl = slot_of_hash(x, ntab.cap);
-            for (uint32_t probes = 0; probes < ntab.cap; ++probes) {
-                const unsigned long long v = ntab.load(sl);
+            uint32_t probes = 0;
+            while (probes < ntab.cap) {   // (scan to the next slot with this fingerprint, compare outside the scan: see node_upsert)
+                unsigned long long v = ntab.load(sl);
+                while ((uint32_t)v != EMPTY32 && node_fp_on && (uint32_t)(v >> (32 + NODE_FP_SHIFT)) != fp) {
+                    sl = sl + 1 == ntab.cap ? 0 : sl + 1;
+                    if (++probes >= ntab.cap) return EMPTY32;
+                    v = ntab.load(sl);
+                }
                 const uint32_t cand = (uint32_t)v;
                 if (cand == EMPTY32) break;
-                if ((!node_fp_on || (uint32_t)(v >> (32 + NODE_FP_SHIFT)) == fp) && cand < n_nodes &&
-                    canonical_w<W>(pv_kmer<W>(V, inst_of.get(cand), kv), kv) == Y)
-                    return (cand << 1) | dy;
+                if (cand < n_nodes && canonical_w<W>(pv_kmer<W>(V, inst_of.get(cand), kv), kv) == Y) return (cand << 1) | dy;
                 sl = sl + 1 == ntab.cap ? 0 : sl + 1;
+                ++probes;
             }
             return EMPTY32;
         };
