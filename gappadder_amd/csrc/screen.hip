@@ -542,7 +542,7 @@ __device__ __forceinline__ void pf4_resolve_octet_serial(const Part4Params& Q, u
 }
 // G = probes sorted per group: PF2_GROUP, or the read's whole probe count when that is smaller (k = 51: three — a fourth, dead probe
 // slot costs every lane its instructions all the same)
-template <uint32_t G>
+template <uint32_t G, bool BYTES>   // BYTES: the probes start at byte boundaries: one byte permute fetches them
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params Q, uint32_t slice_words) {
     extern __shared__ uint32_t sm[];   // [16 waves x PF2_TILES tiles][keys: BATCH x 4 B][octets: BATCH x 1 B][fill stage 256 x 17][hist 3 x 256][offs 258][written 2 x 256]
     const FilterParams& P = Q.F;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_kernel(Part4Params
 #pragma unroll
                 for (uint32_t u = 0; u < G; ++u) {
                     const bool on = live && j0 + u < P.np;
-                    pk[q][u] = on ? canon16(stream32(tiles + q * slice_words, bit0 + P.first2 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
+                    pk[q][u] = on ? canon16(BYTES ? stream32_bytes(tiles + q * slice_words, (bit0 + P.first2 + (j0 + u) * P.stride2) >> 3) : stream32(tiles + q * slice_words, bit0 + P.first2 + (j0 + u) * P.stride2)) * S16_MUL : 0u;
                     rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
                 }
             }
@@ -743,7 +743,7 @@ __device__ __forceinline__ void vm_wait_range(uint32_t n) {   // s_waitcnt vmcnt
         if (n >= (uint32_t)MID) vm_wait_range<MID, HI>(n); else vm_wait_range<LO, MID - 1>(n);
     }
 }
-template <uint32_t G>
+template <uint32_t G, bool BYTES>   // BYTES: the probes start at byte boundaries (k = 51, 31, ... at 2 bits per base): one byte permute fetches them
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4Params Q, uint32_t slice_words) {
     extern __shared__ uint32_t sm[];   // [16 waves x 1 tile][sent][carry 2 x 256 x 32][fill stage 256 x (ST + 1)][hist 3 x 256][written 2 x 256][desc 256][offs 256][lga, lsrc: 2 x (256 + sent lines)][cnt 8]
     const FilterParams& P = Q.F;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
             wave_lds_sync();
             prefetch(t + t_step, q);
 #pragma unroll
-            for (uint32_t u = 0; u < G; ++u) pk[q][u] = stream32(tile, bit0 + P.first2 + u * P.stride2);
+            for (uint32_t u = 0; u < G; ++u) pk[q][u] = BYTES ? stream32_bytes(tile, (bit0 + P.first2 + u * P.stride2) >> 3) : stream32(tile, bit0 + P.first2 + u * P.stride2);
             wave_lds_sync();   // the tile's probes are taken (LDS operations of a wave execute in order): the next tile may take its place
         }
         stores_since = 0;
@@ -2069,10 +2069,16 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         GF_HIP(ctx, hipMemsetAsync(ws + b_cnt - 256, 0, 256 + b_seen, ctx->stream));
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         if (lines) {
-            void (*scatter)(Part4Params, uint32_t) = grp == 1 ? pf4_scatter_lines_kernel<1> : grp == 2 ? pf4_scatter_lines_kernel<2> : grp == 3 ? pf4_scatter_lines_kernel<3> : pf4_scatter_lines_kernel<4>;
+            const bool bytes = (F.first2 & 7u) == 0 && (F.stride2 & 7u) == 0;
+            void (*scatter)(Part4Params, uint32_t) =
+                bytes ? (grp == 1 ? pf4_scatter_lines_kernel<1, true> : grp == 2 ? pf4_scatter_lines_kernel<2, true> : grp == 3 ? pf4_scatter_lines_kernel<3, true> : pf4_scatter_lines_kernel<4, true>)
+                      : (grp == 1 ? pf4_scatter_lines_kernel<1, false> : grp == 2 ? pf4_scatter_lines_kernel<2, false> : grp == 3 ? pf4_scatter_lines_kernel<3, false> : pf4_scatter_lines_kernel<4, false>);
             hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), pf4_lines_lds_bytes(slice_words, grp), ctx->stream, Q, (uint32_t)slice_words);
         } else {
-            void (*scatter)(Part4Params, uint32_t) = grp == 1 ? pf4_scatter_kernel<1> : grp == 2 ? pf4_scatter_kernel<2> : grp == 3 ? pf4_scatter_kernel<3> : pf4_scatter_kernel<4>;
+            const bool bytes = (F.first2 & 7u) == 0 && (F.stride2 & 7u) == 0;
+            void (*scatter)(Part4Params, uint32_t) =
+                bytes ? (grp == 1 ? pf4_scatter_kernel<1, true> : grp == 2 ? pf4_scatter_kernel<2, true> : grp == 3 ? pf4_scatter_kernel<3, true> : pf4_scatter_kernel<4, true>)
+                      : (grp == 1 ? pf4_scatter_kernel<1, false> : grp == 2 ? pf4_scatter_kernel<2, false> : grp == 3 ? pf4_scatter_kernel<3, false> : pf4_scatter_kernel<4, false>);
             hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
         }
         const size_t lds_b = (((size_t)1 << (ix.bm_log2 - PF2_NB_LOG2 - 5)) + 16 * (2 * WOBUF + 2 * PF2_PEND)) * 4;
