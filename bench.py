@@ -43,7 +43,12 @@ PRESETS = {
     # C4's draft and short library + a mate-pair library (IS 5000 / sd 500 -> the tagger's long-IS branch,
     # collect_reads_for_gaps.py:275-278) + the multi-k sweep; per-gap pools = both libraries in library order (merge_reads.py:43-51)
     "C5": (20260004, 5_000_000, 620, 32, 2000, 900_000_000, [(31, 29), (41, 39), (51, 49)]),
+    # stress workload (not a BASELINE configuration): C2's draft with planted repeats — every eighth gap at a copy of a 50-copy repeat
+    # family (0.5-5 kb, either strand), two of every eight at the copies of a 2-copy repeat, one with a low-complexity run in its
+    # flank (include/gf_synth.h `repeats`).  Reads hit up to 50 gaps at once, pools of the repeat gaps hold thousands of reads.
+    "C2R": (20260002, 5_000_000, 50, 20, 2000, 50_000_000, [(31, 29)]),
 }
+REPEATS = {"C2R": (8, 50)}   # config -> (period, copies) of the planted repeats
 # Mate-pair library of C5.  SURVEY.md §8d says "extra 100 M records" = 4.8x: at KMC's min-count 2 a k-mer of the gap interior (covered by
 # this library only) is then missing with P = e^-3.9 (1 + 3.9) = 10 % per position, so no 2-kb gap can close (measured on the GPU:
 # 0 of 19 840; tools/closure_experiment.py: 0/6 at 4.8x, 1/6 at 10x, 28/30 at 15x, 30/30 at 19x).  The bench therefore draws
@@ -62,7 +67,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C4", choices=sorted(PRESETS),
-                    help="BASELINE.json workload: C4 (default: the metric's configuration, 900 M reads), C2, C3, C5 (C4 + mate pairs + multi-k)")
+                    help="BASELINE.json workload: C4 (default: the metric's configuration, 900 M reads), C2, C3, C5 (C4 + mate pairs + multi-k); "
+                         "C2R = C2's draft with planted repeats (stress workload)")
     ap.add_argument("--reads", type=int, default=0, help="read records of the first library, WHOLE JOB (default: the config's)")
     ap.add_argument("--mp-reads", type=int, default=-1, help="C5: read records of the mate-pair library, whole job (default 400 M = 19.4x; SURVEY.md §8d names 100 M)")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
@@ -106,6 +112,8 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         out["extras"] = {"C2": child_run(["--config", "C2", "--steps", "20", "--warmup", "2"]),
+                         # stress workload: C2's draft with planted repeats (reads that hit 50 gaps, pools of thousands of reads)
+                         "C2_with_planted_repeats": child_run(["--config", "C2R", "--steps", "5", "--warmup", "1"]),
                          "C5_mate_pair_multi_k": child_run(["--config", "C5", "--steps", "3", "--warmup", "1"]),
                          # SURVEY.md §8d's own figure for the mate-pair library (100 M records = 4.8x): recorded as it is — at KMC's
                          # min-count 2 that depth leaves holes in every 2-kb gap, so (nearly) nothing closes; see MP_READS_DEFAULT
@@ -186,8 +194,9 @@ def run(args):
         assert lib.gf_set_stream(gf.handle, C.c_void_p(stream.cuda_stream)) == 0
     h = gf.handle
 
+    rep_p, rep_c = REPEATS.get(args.config, (0, 50))
     cfg0 = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L,
-                             insert_mean=300, insert_sd=30)
+                             insert_mean=300, insert_sd=30, repeat_period=rep_p, repeat_copies=rep_c)
     gaps, flanks = GapFill.synth_layout(cfg0)
     n_gaps = len(gaps)
     gf.set_gaps(gaps, int(cfg0["n_scaffolds"][0]), flanks)
@@ -206,7 +215,7 @@ def run(args):
         lb.name, lb.is_mean, lb.is_sd, lb.pull_mates = name, is_mean, is_sd, pull_mates
         lb.h2 = gf2s[len(libs)].handle
         lb.cfg = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L,
-                                   insert_mean=is_mean, insert_sd=is_sd, library=lib_no)
+                                   insert_mean=is_mean, insert_sd=is_sd, library=lib_no, repeat_period=rep_p, repeat_copies=rep_c)
         p0, p1 = SH.shard_range(n_total // 2, rank, world)          # strong scaling: the same pairs, split
         lb.first_pair, lb.n_pairs, lb.n_reads, lb.n_total = p0, p1 - p0, 2 * (p1 - p0), n_total
         lb.d_reads = torch.empty(lb.n_reads * rb + 64, dtype=torch.uint8, device=dev)
@@ -324,7 +333,11 @@ def run(args):
     if world > 1:
         dist.all_reduce(per_gap, op=dist.ReduceOp.SUM)
     max_pool_rows = int(per_gap.max())
-    gf.set_option("asm_max_pool_reads", int(1.5 * max_pool_rows) + 64)
+    # bound on the rows of one pool = the workspace slice of the assembly's main launch.  Deeper pools are not an error (they take the
+    # assembly's second launch, option asm_big_pool_reads), so the bound needs no safety margin, and where a few repeat gaps hold many
+    # times the reads of the others (C2R) it follows the bulk of the pools, not the deepest one
+    asm_bound = max_pool_rows if max_pool_rows <= 4096 else max(4096, int(np.percentile(per_gap.cpu().numpy(), 99)))
+    gf.set_option("asm_max_pool_reads", asm_bound)
     if os.environ.get("GF_BENCH_SCREEN_VARIANT"):    # filter kernel (experiments: 17 = pass A with unaligned runs)
         gf.set_option("screen_variant", int(os.environ["GF_BENCH_SCREEN_VARIANT"]))
     if os.environ.get("GF_BENCH_ASM_SIMPLIFY"):      # rounds of tip clipping + bubble popping (experiments; the parity sample then disagrees unless it is 2)
@@ -559,7 +572,8 @@ def run(args):
                            "(GF_BENCH_TWO_STREAMS=1 runs tagger + second hop on a second stream beside the filter: same step time within 1-3 %)",
             "counts": {"libraries": {lb.name: lb.counts for lb in libs}, "assembled_pool_reads": asm_rows_total, "contigs": n_ctg_all,
                        "gaps_with_contig": gaps_with_contig, "gaps_closed": n_closed, "gaps_closed_correct": n_correct,
-                       "largest_pool_reads": max_pool_rows},
+                       "largest_pool_reads": max_pool_rows, "assembly_slice_rows": asm_bound,
+                       "pools_beyond_the_slice": int((per_gap > asm_bound).sum())},
             "closed_truth_check": {"what": "the picked sequence of EVERY closed gap (pick_contigs.py:341-349 slice of the winning contig) compared with the "
                                            "true bases behind the planted N-run, regenerated from include/gf_synth.h: genome[start-5 : end+6] on the forward "
                                            "strand, genome[start-6 : end+5] when the contig is reverse-complemented (the reference's slice keeps one anchor base)",

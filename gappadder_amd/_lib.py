@@ -19,7 +19,7 @@ CONTIG = np.dtype([("gap", "<u4"), ("k", "<u2"), ("kv", "<u2"), ("n_nodes", "<u4
 SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", "<u4"), ("gaps_per_scaffold", "<u4"),
                       ("gap_len", "<u4"), ("read_len", "<u4"), ("insert_mean", "<u4"), ("insert_sd", "<u4"),
                       ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4"),
-                      ("library", "<u4"), ("reserved", "<u4")])
+                      ("library", "<u4"), ("repeats", "<u4")])
 QCPAIR = np.dtype([("set", "<u4"), ("i", "<u4"), ("j", "<u4")])
 OVL_PARAMS = np.dtype([("mismatch", "<f8"), ("indel", "<f8"), ("max_clip", "<f8"), ("frac_min_overlap", "<f8"), ("frac_loss", "<f8"),
                        ("min_overlap", "<f8"), ("min_overlap_scaffold", "<f8"), ("relax", "<f8")])

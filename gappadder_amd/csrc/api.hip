@@ -146,7 +146,7 @@ void gf_destroy(gf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
-    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->binmap, &ctx->binmap_fine, &ctx->bam_stream, &ctx->bam_recs, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->asm_jump, &ctx->rowgap, &ctx->pool_ws, &ctx->xchg_ws, &ctx->xchg_ws2, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->binmap, &ctx->binmap_fine, &ctx->bam_stream, &ctx->bam_recs, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->asm_jump, &ctx->asm_big, &ctx->rowgap, &ctx->pool_ws, &ctx->xchg_ws, &ctx->xchg_ws2, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
         if (b->p) (void)hipFree(b->p);
     for (auto& kv : ctx->anchor_tabs) if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->d_gaps) (void)hipFree(ctx->d_gaps);
@@ -212,6 +212,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "asm_precount")) { ctx->asm_precount = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_ranked")) { ctx->asm_ranked = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_max_pool_reads")) { if (value < 0 || value > 0x3FFFFFFF) return GF_E_INVAL; ctx->asm_max_pool_reads = value; return GF_OK; }
+    if (!strcmp(name, "asm_big_pool_reads")) { if (value < 0 || value > 0x1FFFFF) return GF_E_INVAL; ctx->asm_big_pool_reads = value; return GF_OK; }
     if (!strcmp(name, "asm_simplify")) { if (value < 0 || value > 8) return GF_E_INVAL; ctx->asm_simplify = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_lds_pool_kb")) { ctx->asm_lds_pool_kb = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_threads")) { if (value != 0 && value != 1024 && value != 512 && value != 256) return GF_E_INVAL; ctx->asm_threads = (int)value; return GF_OK; }
@@ -225,11 +226,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "tag_fine_log2")) { ctx->tag_fine_log2 = std::max(20, std::min(28, (int)value)); ctx->bin_dist2 = -1; return GF_OK; }
     if (!strcmp(name, "tag_nt")) { ctx->tag_nt = value != 0; return GF_OK; }
     if (!strcmp(name, "screen_pf4_cap8")) { ctx->screen_pf4_cap8 = (int)value; return GF_OK; }
-    if (!strcmp(name, "screen_np_override")) {   // timing experiments only (fewer probes = wrong hits): refused unless asked for
-        if (!getenv("GF_DIAGNOSTICS")) return GF_E_UNSUPPORTED;
-        ctx->screen_np_override = (int)value;
-        return GF_OK;
-    }
+    if (!strcmp(name, "screen_ext")) { ctx->screen_ext = value != 0; return GF_OK; }
     if (!strcmp(name, "screen_verify_batch")) { ctx->screen_verify_batch = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_verify_ext")) { ctx->screen_verify_ext = value != 0; return GF_OK; }
     if (!strcmp(name, "screen_verify_gate")) { ctx->screen_verify_gate = value != 0; return GF_OK; }
@@ -453,6 +450,7 @@ int gf_assemble(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, const 
     };
     size_t max_rows = 1;
     for (size_t g = 0; g < n_pools; ++g) max_rows = std::max<size_t>(max_rows, (size_t)(pool_off[g + 1] - pool_off[g]));
+    if (ctx->asm_max_pool_reads > 0) max_rows = std::min<size_t>(max_rows, (size_t)ctx->asm_max_pool_reads);   // (a caller's own, lower bound stays: deeper pools take the second launch)
     MaxRows bound(ctx, (long)std::min<size_t>(max_rows, 0x3FFFFFFF));
     // device staging: [pool | pool_off | gap_error | counters | contigs | seq]
     const size_t b_pool = (total * rb + 63) & ~(size_t)63, b_off = ((n_pools + 1) * 8 + 63) & ~(size_t)63,

@@ -42,6 +42,13 @@ struct AsmParams {
     uint32_t* jump;            // 4 words per instance: the unitig-ranking pairs of the oriented nodes when they do not fit in LDS
     uint32_t simplify;         // rounds of tip clipping + bubble popping (0: raw unitigs)
     uint32_t slice_rows;       // > 0: the workspace holds one slice of this many pool rows per workgroup
+    uint64_t slice_base;       // ... the first of them starts at this instance offset
+    // pools beyond slice_rows are not refused: the launch lists them (big_list, *n_big) and a second, small launch takes them from
+    // that list (gap_list, *n_gap_list) with slices of its own, sized for deep pools (option asm_big_pool_reads)
+    uint32_t* big_list;
+    uint32_t* n_big;
+    const uint32_t* gap_list;
+    const uint32_t* n_gap_list;
     gf_contig* contigs;
     uint32_t contig_cap;
     uint32_t* n_contigs;
@@ -412,8 +419,11 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         __syncthreads();
         if (tid == 0) s_gap = atomicAdd(P.next_gap, 1u);
         __syncthreads();
-        const uint32_t g = s_gap;
-        if (g >= P.n_pools) break;
+        uint32_t g = s_gap;
+        if (P.gap_list) {
+            if (g >= *P.n_gap_list) break;
+            g = P.gap_list[g];
+        } else if (g >= P.n_pools) break;
         const uint64_t r0 = P.pool_off[g], r1 = P.pool_off[g + 1];
         if (r1 < r0 || r1 > P.total_reads) {   // pool_off beyond the pool array (an overflowed gf_build_pools_dev): refuse the gap
             if (tid == 0) P.gap_error[g] = ASM_ERR_IDS;
@@ -428,10 +438,13 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         // workspace slice: per pool row (slice_rows == 0), or one private slice per workgroup that every gap it takes re-uses
         // (kernels leave their slice EMPTY) — sized by the caller's bound on the rows of one pool
         if (P.slice_rows && n_r > P.slice_rows) {
-            if (tid == 0) P.gap_error[g] |= ASM_ERR_IDS;
+            if (tid == 0) {
+                if (P.big_list) P.big_list[atomicAdd(P.n_big, 1u)] = g;   // (at most n_pools entries)
+                else P.gap_error[g] |= ASM_ERR_IDS;
+            }
             continue;
         }
-        const uint64_t inst_off = P.slice_rows ? (uint64_t)blockIdx.x * P.slice_rows * unit : r0 * unit;
+        const uint64_t inst_off = P.slice_rows ? P.slice_base + (uint64_t)blockIdx.x * P.slice_rows * unit : r0 * unit;
         if (n_unit64 >= (1ull << 30) || n_r >= (1u << (31 - INST_OFF_BITS)) - 1) {  // ids are 31-bit: read << 10 | offset (bit 31: INST_WEAK)
             if (tid == 0) P.gap_error[g] = ASM_ERR_IDS;
             continue;
@@ -1568,6 +1581,8 @@ __global__ void fill_empty_kernel(unsigned long long* t, uint64_t n) {
         t[i] = 0x00000000FFFFFFFFull;
 }
 
+constexpr unsigned ASM_BIG_WGS = 8;   // workgroups (= workspace slices) of the launch that takes the pools beyond asm_max_pool_reads
+
 int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
                     size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig, void* d_contigs,
                     size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len, void* d_gap_error,
@@ -1592,7 +1607,12 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     // workspace units (see the kernel): one slice per pool row, or — when the caller bounds the rows of one pool (option
     // asm_max_pool_reads; the host entry points know their pools) — one slice of that many rows per workgroup
     const uint64_t slice_rows = ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * grid < total_reads ? (uint64_t)ctx->asm_max_pool_reads : 0;
-    const uint64_t n_inst = (slice_rows ? slice_rows * grid : (uint64_t)total_reads) * unit;
+    // pools beyond that bound (a flank inside a repeat recruits thousands of reads; the reference runs KMC and Velvet on whatever
+    // the pool holds) go to a second launch of ASM_BIG_WGS workgroups with slices of asm_big_pool_reads rows; only a pool beyond
+    // THAT sets its gap_error
+    const uint64_t big_rows = slice_rows ? std::min<uint64_t>(std::max<uint64_t>((uint64_t)std::max(0l, ctx->asm_big_pool_reads), slice_rows), total_reads) : 0;
+    const uint64_t big_base = slice_rows * grid * unit;
+    const uint64_t n_inst = slice_rows ? big_base + big_rows * ASM_BIG_WGS * unit : (uint64_t)total_reads * unit;
     int rc;
     {   // the table must be all-EMPTY (id 0xFFFFFFFF, meta 0) on entry; kernels leave it so, a fresh buffer is filled once
         void* before = ctx->asm_table.p;
@@ -1612,12 +1632,18 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     }
     if (n_pools == 0) return GF_OK;
     if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
-    uint32_t* d_next = (uint32_t*)ctx->counters.p + 8;
+    uint32_t* d_next = (uint32_t*)ctx->counters.p + 8;   // [8] work counter, [9] the second launch's, [10] pools listed for it
+    if (slice_rows && (rc = ensure(ctx, ctx->asm_big, n_pools * 4))) return rc;
     // append: a further (k, kv) pair of the same call adds to the contig list and keeps the error flags of the earlier pairs
-    if (append) zero_regions(ctx, ZeroList{{d_next, nullptr, nullptr, nullptr}, {1, 0, 0, 0}});
-    else zero_regions(ctx, ZeroList{{(uint32_t*)d_n_contigs, (uint32_t*)d_seq_len, (uint32_t*)d_gap_error, d_next}, {1, 2, (uint32_t)n_pools, 1}});
+    if (append) zero_regions(ctx, ZeroList{{d_next, nullptr, nullptr, nullptr}, {3, 0, 0, 0}});
+    else zero_regions(ctx, ZeroList{{(uint32_t*)d_n_contigs, (uint32_t*)d_seq_len, (uint32_t*)d_gap_error, d_next}, {1, 2, (uint32_t)n_pools, 3}});
     AsmParams P;
     P.next_gap = d_next;
+    P.slice_base = 0;
+    P.big_list = slice_rows ? (uint32_t*)ctx->asm_big.p : nullptr;
+    P.n_big = d_next + 2;
+    P.gap_list = nullptr;
+    P.n_gap_list = nullptr;
     P.keyslot = (uint32_t)ctx->asm_keyslot;
     P.precount = (uint32_t)ctx->asm_precount;
     P.ranked = (uint32_t)ctx->asm_ranked;
@@ -1667,6 +1693,18 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
                                           : (nt == 1024 ? assemble_kernel<false, 1024, 31, true, false> : assemble_kernel<false, 512, 31, true, false>);
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), (size_t)P.lds_words * 4, ctx->stream, P);
+        if (slice_rows) {   // the pools the launch above listed (none, as a rule: the workgroups leave at once)
+            AsmParams B = P;
+            B.next_gap = d_next + 1;
+            B.slice_rows = (uint32_t)big_rows;
+            B.slice_base = big_base;
+            B.big_list = nullptr;
+            B.gap_list = (const uint32_t*)ctx->asm_big.p;
+            B.n_gap_list = d_next + 2;
+            B.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
+            hipLaunchKernelGGL((k <= 32 ? assemble_kernel<false, 1024, 0, false, false> : assemble_kernel<true, 1024, 0, false, false>),
+                               dim3(ASM_BIG_WGS), dim3(1024), (size_t)B.lds_words * 4, ctx->stream, B);
+        }
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;

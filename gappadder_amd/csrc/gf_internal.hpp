@@ -47,6 +47,11 @@ struct FlankIndex {
     uint32_t* d_fpk = nullptr;
     uint32_t* d_foff = nullptr;
     bool ext_ok = false;     // every flank shorter than 65536 bases (16-bit positions in the occurrence words)
+    // the exact set once more for pass B of the partitioned filter, in aligned groups of four slots that carry what stands NEXT to
+    // the 16-mer in the flanks: 8 words {key x 4, ext x 4}, a key's home = group hash_s16_set(key) >> 2 (then the following groups);
+    // ext = mask over the 2-base codes (nearest base first) left of the canonical 16-mer | the same for the right side << 16,
+    // OR-ed over all occurrences (an occurrence with one neighbour sets the whole nibble of that base; no neighbour: nothing)
+    uint32_t* d_sgrp = nullptr;
     size_t n_kmers = 0, n_s16 = 0;
     uint32_t max_gaps_per_kmer = 0;
 };
@@ -81,12 +86,12 @@ struct gf_ctx {
     uint32_t max_gaps_per_kmer = 0;     // 0 = unlimited
     int bitmap_log2_override = 0;
     int index_host = 0;         // 1: build the flank index on the host (comparator of the device builder)
-    int screen_variant = 0;     // filter kernel: 0 automatic; 9 plain, 13 pipelined, 14 16-bucket partitioned, 16 256-bucket partitioned (tests run each)
+    int screen_variant = 0;     // filter kernel: 0 automatic; 9 plain, 13 pipelined, 16 / 17 256-bucket partitioned with whole-line / unaligned stores (tests run each)
     int screen_verify_batch = 64;  // verify kernel: candidates per wave and pass
     int screen_verify_ext = 1;   // min_hits == 1 without repeat mask: seed-and-extend verification instead of the k-mer table
     int screen_verify_gate = 1;  // verify kernel: consult the k-mer table only around exact 16-mer hits
     int screen_stream_policy = 1;  // pipelined filter: read stream loaded non-temporal (nt): keeps the L2 for the bitmap, -8 % fabric fetches
-    int screen_np_override = -1;
+    int screen_ext = 1;          // 256-bucket filter: check the bases next to a seed against the flanks' (0: 16-base seeds as they are)
     int screen_pf4_cap8 = 0;     // tests: capacity of the 4-byte filter's pair list (0: sized from the reads)
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)
     int tag_light = 0;           // alignment tagger: one-wave workgroups, bin map through L1/L2 (runs beside the k-mer filter)
@@ -95,6 +100,7 @@ struct gf_ctx {
     int asm_simplify = 8;        // rounds of tip clipping + bubble popping in the assembly: until a round removes nothing, at most this many
                                  // (Velvet's defaults are on; 0: raw unitigs; measured: every C4 / C5 gap converges within two rounds)
     long asm_max_pool_reads = 0; // > 0: no pool has more rows than this (the assembly workspace is then one slice per workgroup, not per row)
+    long asm_big_pool_reads = 131072;   // ... and pools beyond asm_max_pool_reads go to a second launch whose slices hold this many rows (a pool beyond this sets its gap_error)
     int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
     int asm_ranked = 1;          // count phase: ranked (perfect-hash) table behind the pre-count (k > 32, LDS)
     int asm_precount = 1;        // count phase: bit-array pre-count in LDS when min_count is 2 or 3 (0: every window goes to the table)
@@ -114,7 +120,7 @@ struct gf_ctx {
     size_t low_b1 = 0, low_b2 = 0;
 
     // scratch
-    gf::DevBuf cand, cand2, part_ws, binmap, binmap_fine, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, asm_jump, rowgap, pool_ws, xchg_ws, xchg_ws2, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, part_ws, binmap, binmap_fine, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, asm_jump, asm_big, rowgap, pool_ws, xchg_ws, xchg_ws2, counters, stage_in, stage_out, stage_aux, table;
     size_t bam_n_recs = 0;       // alignment records gf_bam_pack left in bam_recs (for gf_tag_*_bam)
     size_t bam_stream_len = 0;   // inflated BAM bytes gf_bgzf_inflate left in bam_stream
     // timing
@@ -168,6 +174,7 @@ void free_flank_index(gf_ctx* ctx, FlankIndex& ix);
 
 // screen.hip
 int build_flank_index_dev(gf_ctx* ctx, int k, FlankIndex& ix);   // index_dev.hip
+int build_sgrp_dev(gf_ctx* ctx, FlankIndex& ix);                 // index_dev.hip: d_sgrp from d_sset / d_sval / d_occ / d_fpk
 int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const void* d_nmask, size_t n_reads,
                   int read_len, int min_hits, void* d_out, size_t cap, void* d_n_out);
 // tagger.hip

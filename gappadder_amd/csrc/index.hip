@@ -83,6 +83,7 @@ void free_flank_index(gf_ctx*, FlankIndex& ix) {
     if (ix.d_occ) (void)hipFree(ix.d_occ);
     if (ix.d_fpk) (void)hipFree(ix.d_fpk);
     if (ix.d_foff) (void)hipFree(ix.d_foff);
+    if (ix.d_sgrp) (void)hipFree(ix.d_sgrp);
     ix = FlankIndex();
 }
 
@@ -209,7 +210,7 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
     // 100-400 gaps 1.5-1.6 ms with 16 bits per key, 0.9-1.1 ms with 2^24 bits).  A 2 MiB bitmap stays in every XCD's
     // L2; a sparser 4 MiB one measured slower.
     int bl = std::max(24, ceil_log2(16 * s16.size() + 1));
-    bl = std::min(30, bl);
+    bl = std::min(28, bl);
     if (ctx->bitmap_log2_override) bl = std::min(31, std::max(10, ctx->bitmap_log2_override));
     ix.bm_log2 = bl;
     const size_t bwords = ((size_t)1 << bl) / 32;
@@ -266,6 +267,10 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
     GF_HIP(ctx, hipMalloc((void**)&ix.d_foff, foff.size() * 4));
     GF_HIP(ctx, hipMemcpy(ix.d_foff, foff.data(), foff.size() * 4, hipMemcpyHostToDevice));
     GF_HIP(ctx, hipMemcpy(ix.d_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    {
+        const int rc = build_sgrp_dev(ctx, ix);
+        if (rc) { free_flank_index(ctx, ix); return rc; }
+    }
     auto ins = ctx->index.emplace(k, ix);
     *out = &ins.first->second;
     return GF_OK;

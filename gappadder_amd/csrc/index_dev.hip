@@ -191,6 +191,50 @@ __global__ __launch_bounds__(256) void idx_pack_flanks_kernel(const char* fa, co
     }
 }
 
+// The grouped copy of the exact set (FlankIndex::d_sgrp).  One thread per slot of the plain set: the neighbours of every occurrence
+// of its 16-mer, read from the packed flanks, in the orientation of the CANONICAL 16-mer (an occurrence whose text is the reverse
+// complement of the canonical form swaps sides and complements: code -> code ^ 15 = the mask bit-reversed; a 16-mer that is its
+// own reverse complement gets both readings).
+__device__ __forceinline__ uint32_t ext_mask2(const uint32_t* fw, uint32_t at1, uint32_t at2, uint32_t room) {
+    // mask over the codes (nearest << 2 | next) of the two bases at at1 (nearest) and at2; room = how many of them exist
+    if (room == 0) return 0u;
+    const uint32_t b1 = (fw[at1 >> 4] >> (30 - 2 * (at1 & 15))) & 3u;
+    if (room == 1) return 0xFu << (4 * b1);
+    const uint32_t b2 = (fw[at2 >> 4] >> (30 - 2 * (at2 & 15))) & 3u;
+    return 1u << (4 * b1 + b2);
+}
+__global__ __launch_bounds__(256) void idx_sgrp_build_kernel(const uint32_t* sset, const uint32_t* sval, const uint32_t* occ, const uint32_t* fpk,
+                                                             const uint32_t* foff, uint32_t scap, int s_log2, int ext_ok, uint32_t* sgrp) {
+    const uint32_t gmask = (scap >> 2) - 1;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < scap; i += gridDim.x * blockDim.x) {
+        const uint32_t key = sset[i];
+        if (key == EMPTY32) continue;
+        uint32_t L = 0, R = 0;
+        if (!ext_ok) L = R = 0xFFFFu;   // (positions do not fit the occurrence words: no statement about the neighbours)
+        else {
+            const bool pal = revpairs32(~key) == key;
+            uint32_t oi = sval[i];
+            for (;;) {
+                const uint32_t fid = occ[2 * (size_t)oi], info = occ[2 * (size_t)oi + 1];
+                const uint32_t pos = info & 0xFFFFu, lroom = (info >> 18) & 63u, rroom = (info >> 24) & 63u;
+                const bool fo = (info >> 16) & 1u;
+                const uint32_t* fw = fpk + foff[fid];
+                const uint32_t tr = ext_mask2(fw, pos + 16, pos + 17, rroom < 2 ? rroom : 2u);            // right of the text 16-mer
+                const uint32_t tl = ext_mask2(fw, pos - 1, pos - 2, lroom < 2 ? lroom : 2u);              // left of it (pos >= lroom)
+                const uint32_t trc = __brev(tr) >> 16, tlc = __brev(tl) >> 16;                            // complemented codes
+                if (!fo || pal) { R |= tr; L |= tl; }
+                if (fo || pal) { R |= tlc; L |= trc; }
+                if ((info >> 17) & 1u) break;
+                ++oi;
+            }
+        }
+        uint32_t g = hash_s16_set(key, s_log2) >> 2, j = 0;
+        while (atomicCAS(&sgrp[(size_t)g * 8 + j], EMPTY32, key) != EMPTY32)
+            if (++j == 4) { j = 0; g = (g + 1) & gmask; }
+        sgrp[(size_t)g * 8 + 4 + j] = L | (R << 16);
+    }
+}
+
 int ceil_log2_sz(size_t v) {
     int l = 0;
     while (((size_t)1 << l) < v) ++l;
@@ -204,6 +248,17 @@ int dev_alloc(gf_ctx* ctx, T** p, size_t n) {
 }
 
 }  // namespace
+
+int build_sgrp_dev(gf_ctx* ctx, FlankIndex& ix) {
+    const size_t scap = (size_t)1 << ix.s_log2;
+    GF_HIP(ctx, hipMalloc((void**)&ix.d_sgrp, scap * 2 * 4));
+    GF_HIP(ctx, hipMemsetAsync(ix.d_sgrp, 0xFF, scap * 2 * 4, ctx->stream));
+    hipLaunchKernelGGL(idx_sgrp_build_kernel, dim3((unsigned)ctx->n_cu * 8), dim3(256), 0, ctx->stream, ix.d_sset, ix.d_sval, ix.d_occ, ix.d_fpk, ix.d_foff,
+                       (uint32_t)scap, ix.s_log2, ix.ext_ok ? 1 : 0, ix.d_sgrp);
+    GF_HIP(ctx, hipGetLastError());
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GF_OK;
+}
 
 // Same FlankIndex as build_flank_index's host path (index.hip); table/set layouts differ only in which of several equal-hash
 // keys took which slot.
@@ -302,7 +357,7 @@ int build_flank_index_dev(gf_ctx* ctx, int k, FlankIndex& ix) {
     ix.s_log2 = std::max(8, ceil_log2_sz(2 * (size_t)cnt[3] + 2));
     const size_t scap = (size_t)1 << ix.s_log2;
     int bl = std::max(24, ceil_log2_sz(16 * (size_t)cnt[3] + 1));
-    bl = std::min(30, bl);
+    bl = std::min(28, bl);   // (the 256-bucket filter holds a 1/256 slice in LDS: beyond 2^28 bits fewer bits per key, not another kernel)
     if (ctx->bitmap_log2_override) bl = std::min(31, std::max(10, ctx->bitmap_log2_override));
     ix.bm_log2 = bl;
     ix.lds_log2 = std::min(ctx->screen_lds_log2_max, bl);
@@ -343,6 +398,7 @@ int build_flank_index_dev(gf_ctx* ctx, int k, FlankIndex& ix) {
     IDX_HIP(hipGetLastError());
     ix.lds_fill = (double)pop[0] / (double)((size_t)1 << ix.lds_log2);
     if (mwords) ix.mid_fill = (double)pop[1] / (double)((size_t)1 << 24);
+    IDX_TRY(build_sgrp_dev(ctx, ix));
     cleanup();
 #undef IDX_TRY
 #undef IDX_HIP

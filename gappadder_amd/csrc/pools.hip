@@ -15,7 +15,7 @@
 
 namespace gf {
 
-constexpr uint32_t POOL_SORT_MAX = 16384;  // keys of one gap sorted in LDS (64 KiB)
+constexpr uint32_t POOL_SORT_MAX = 16384;  // keys of one gap sorted in LDS at a time (64 KiB); longer key lists: chunks of this size + passes over the segment
 
 __global__ void keys_from_screen_kernel(const gf_hit* hits, const uint32_t* n_hits, uint32_t hit_cap, int pairs,
                                         unsigned long long* keys, uint32_t key_cap, uint32_t* n_keys) {
@@ -203,34 +203,92 @@ __global__ __launch_bounds__(256) void pool_scatter_lds_kernel(const unsigned lo
     }
 }
 
-// one workgroup per gap: bitonic sort of the gap's keys in LDS, duplicates dropped, written back in place
+// Ascending compare-exchange network in LDS: the classic bitonic sort with every merge's first step mirrored (i against
+// size - 1 - i), so that EVERY exchange moves the larger key to the higher index — keys padded with 0xFFFFFFFF at the top then
+// never move, and a list of any length sorts in the first n places.  [first_size, m]: merge sizes to run (2 = sort from scratch;
+// `first_size == 0`: only the half-cleaners of strides < m, the tail of a larger merge whose wide strides ran in global memory).
+__device__ __forceinline__ void lds_sort_network(uint32_t* sk, uint32_t m, uint32_t first_size) {
+    auto cleaners = [&](uint32_t from_stride) {
+        for (uint32_t stride = from_stride; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
+                const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const uint32_t x = sk[lo], y = sk[hi];
+                if (x > y) { sk[lo] = y; sk[hi] = x; }
+            }
+            __syncthreads();
+        }
+    };
+    if (first_size == 0) { cleaners(m >> 1); return; }
+    for (uint32_t size = first_size; size <= m; size <<= 1) {
+        for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {   // mirrored step
+            const uint32_t half = size >> 1, blk = t / half, j = t - blk * half;
+            const uint32_t lo = blk * size + j, hi = blk * size + size - 1 - j;
+            const uint32_t x = sk[lo], y = sk[hi];
+            if (x > y) { sk[lo] = y; sk[hi] = x; }
+        }
+        __syncthreads();
+        cleaners(size >> 2);
+    }
+}
+
+// one workgroup per gap: sort of the gap's keys, duplicates dropped, written back in place.  Up to POOL_SORT_MAX keys in LDS; a
+// gap with more (a flank inside a repeat, a collapsed region: the reference has no bound, run_multi_threads_discordant.py:209-241)
+// is sorted in place in global memory by the same network — chunks of POOL_SORT_MAX keys in LDS, the strides beyond a chunk as
+// passes over the segment (the workgroup's own stores are visible to it after a barrier) — slower, never dropped.
 __global__ __launch_bounds__(256) void pool_sort_unique_kernel(uint32_t n_gaps, const uint32_t* seg_off, uint32_t* seg,
                                                               uint32_t* ucnt, uint32_t* error) {
     extern __shared__ uint32_t sk[];
     __shared__ uint32_t s_n;
+    (void)error;
     for (uint32_t g = blockIdx.x; g < n_gaps; g += gridDim.x) {
         const uint32_t a = seg_off[g], n = seg_off[g + 1] - a;
         if (n == 0) { if (threadIdx.x == 0) ucnt[g] = 0; continue; }
-        if (n > POOL_SORT_MAX) { if (threadIdx.x == 0) { ucnt[g] = 0; atomicAdd(error, 1u); } continue; }
         uint32_t m = 1;
         while (m < n) m <<= 1;
-        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) sk[i] = i < n ? seg[a + i] : 0xFFFFFFFFu;
+        const bool big = n > POOL_SORT_MAX;
         if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-        for (uint32_t size = 2; size <= m; size <<= 1)
-            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
-                    const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                    const bool up = (lo & size) == 0;
-                    const uint32_t x = sk[lo], y = sk[hi];
-                    if ((x > y) == up) { sk[lo] = y; sk[hi] = x; }
+        if (!big) {
+            for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) sk[i] = i < n ? seg[a + i] : 0xFFFFFFFFu;
+            __syncthreads();
+            lds_sort_network(sk, m, 2);
+        } else {
+            constexpr uint32_t C = POOL_SORT_MAX;
+            uint32_t* S = seg + a;
+            auto chunks = [&](uint32_t first_size) {   // every chunk of C keys through LDS
+                for (uint32_t c0 = 0; c0 < n; c0 += C) {
+                    for (uint32_t i = threadIdx.x; i < C; i += blockDim.x) sk[i] = c0 + i < n ? S[c0 + i] : 0xFFFFFFFFu;
+                    __syncthreads();
+                    lds_sort_network(sk, C, first_size);
+                    for (uint32_t i = threadIdx.x; i < C; i += blockDim.x) if (c0 + i < n) S[c0 + i] = sk[i];
+                    __syncthreads();
+                }
+            };
+            __syncthreads();
+            chunks(2);                                  // sorted runs of C
+            for (uint32_t size = 2 * C; size <= m; size <<= 1) {
+                for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {   // mirrored step (hi >= n: a padding key, nothing moves)
+                    const uint32_t half = size >> 1, blk = t / half, j = t - blk * half;
+                    const uint32_t lo = blk * size + j, hi = blk * size + size - 1 - j;
+                    if (hi < n) { const uint32_t x = S[lo], y = S[hi]; if (x > y) { S[lo] = y; S[hi] = x; } }
                 }
                 __syncthreads();
+                for (uint32_t stride = size >> 2; stride >= C; stride >>= 1) {
+                    for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
+                        const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                        if (hi < n) { const uint32_t x = S[lo], y = S[hi]; if (x > y) { S[lo] = y; S[hi] = x; } }
+                    }
+                    __syncthreads();
+                }
+                chunks(0);                              // strides C/2 .. 1
             }
-        // unique (sorted): keep sk[i] if it differs from sk[i-1]; order-preserving compaction by prefix count
+        }
+        // unique (sorted): keep key i if it differs from key i-1; order-preserving compaction by prefix count.  (In place for the
+        // big gaps: a key moves to a lower or the same index, so nothing a later round reads has been overwritten.)
         for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
             const uint32_t i = i0 + threadIdx.x;
-            const bool keep = i < n && (i == 0 || sk[i] != sk[i - 1]);
+            uint32_t cur = 0, prev = 0;
+            if (i < n) { cur = big ? seg[a + i] : sk[i]; prev = i ? (big ? seg[a + i - 1] : sk[i - 1]) : ~cur; }
+            const bool keep = i < n && (i == 0 || cur != prev);
             // block-wide exclusive count of `keep` below this thread, in wave order
             const unsigned long long bal = __ballot(keep);
             __shared__ uint32_t wcnt[4];
@@ -239,7 +297,7 @@ __global__ __launch_bounds__(256) void pool_sort_unique_kernel(uint32_t n_gaps, 
             __syncthreads();
             uint32_t base = s_n;
             for (uint32_t q = 0; q < w; ++q) base += wcnt[q];
-            if (keep) seg[a + base + __popcll(bal & ((1ull << lane) - 1))] = sk[i];
+            if (keep) seg[a + base + __popcll(bal & ((1ull << lane) - 1))] = cur;
             __syncthreads();
             if (threadIdx.x == 0) s_n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
             __syncthreads();

@@ -189,224 +189,6 @@ __device__ __forceinline__ bool sset_walk(const FilterParams& P, uint32_t key, u
     }
 }
 
-// ---- partitioned filter: key sets whose level-1 bitmap is larger than an XCD's L2 (human scale: 1.1e7 16-mers, 2^28 bits) -----
-// Every level-1 probe of the plain kernel then misses the L2 and pulls a 128-byte line over the fabric for two bits of it
-// (C4 shard, PMC: 3.1e8 fabric reads = 39 GB per launch for 4.3 GB of reads — the kernel runs at the fabric's bandwidth, not
-// the algorithm's).  Here the probes are radix-partitioned first so that each slice of the bitmap is probed from ONE L2:
-//   pass A  every wave streams its 64-read tiles, scrambles the aligned 16-mers and appends (scrambled key, read) pairs to one
-//           of NB = 8/16 buckets by the top bits of the key: NB ballots per probe place the pairs in per-wave LDS rows, a full
-//           row leaves as one 512-byte store into the wave's OWN part of the bucket (no atomics, no barrier);
-//   pass B  bucket b is read back by the workgroups that the dispatcher places on XCD b mod 8 (blockIdx mod 8), so its
-//           2^(bm_log2 - log2 NB)-bit slice (2 MiB at 2^28) stays in that XCD's L2: both bits of the key in one word, then the
-//           exact set, then one candidate entry per read (a `seen` bit per read).
-// All fabric traffic is streamed: reads once, pairs written and read once.  A part that runs full (degenerate inputs: millions
-// of identical reads) is not an error — its pairs are probed on the spot, the way the plain kernel does.
-struct PartParams {
-    FilterParams F;
-    uint32_t nb_log2;           // log2 buckets
-    uint32_t n_writers;         // writer waves of pass A
-    uint32_t cap;               // pairs per (bucket, writer)
-    unsigned long long* pairs;  // [bucket][writer][cap]: {read (high 32), scrambled key (low 32)}
-    uint32_t* count;            // [bucket][writer]
-    uint32_t* seen;             // one bit per read
-};
-constexpr uint32_t PF_ROW = 128;   // pairs per LDS row: a row is flushed at 64, one probe adds at most 64
-
-// level-1 + exact-set test of one pair; true for the first hit of a read
-__device__ __forceinline__ bool pf_test_pair(const PartParams& Q, uint32_t pk, uint32_t read, bool active) {
-    const FilterParams& P = Q.F;
-    bool cand = false;
-    if (active) {
-        const uint32_t h = pk >> (32 - P.bm_log2);
-        const uint32_t wd = P.bitmap[h >> 5];
-        if ((wd >> (h & 31)) & (wd >> (pk & 31)) & 1u) {   // both bits of the key in its word (hash_s16_bit2 = low bits of pk)
-            const uint32_t key = pk * S16_MUL_INV;
-            if (sset_walk(P, key, hash_s16_set(key, P.s_log2))) {
-                const uint32_t bit = 1u << (read & 31);
-                cand = !(atomicOr(&Q.seen[read >> 5], bit) & bit);
-            }
-        }
-    }
-    return cand;
-}
-
-template <int NB_LOG2>
-__global__ __launch_bounds__(512) void pf_scatter_kernel(PartParams Q, uint32_t slice_words) {
-    extern __shared__ uint32_t sm[];   // per wave: [tile: 64 reads + 16 B][NB row fills][NB rows of PF_ROW pairs]
-    constexpr uint32_t NB = 1u << NB_LOG2;
-    const FilterParams& P = Q.F;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
-    const uint32_t per_wave = slice_words + NB + NB * PF_ROW * 2;
-    uint32_t* tile = sm + wv * per_wave;
-    uint32_t* fill = tile + slice_words;   // pairs waiting in each row (LDS atomics place the pairs of one probe)
-    unsigned long long* rows = reinterpret_cast<unsigned long long*>(fill + NB);
-    uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
-    const uint32_t writer = blockIdx.x * nw + wv;
-    if (writer >= Q.n_writers) return;
-    const uint32_t tile_bytes = 64 * P.rb;
-    const uint64_t total_bytes = P.n_reads * P.rb;
-    const uint64_t n_tiles = (P.n_reads + 63) / 64;
-    const unsigned long long lt = (1ull << lane) - 1;
-    uint32_t written = 0;   // lane b < NB: pairs stored in this wave's part of bucket b
-    if (lane < NB) fill[lane] = 0;
-    auto part = [&](uint32_t b) { return Q.pairs + ((size_t)b * Q.n_writers + writer) * Q.cap; };
-    auto spill = [&](unsigned long long pair, bool active) {   // the part is full: probe now
-        const bool c = pf_test_pair(Q, (uint32_t)pair, (uint32_t)(pair >> 32), active);
-        const unsigned long long bal = __ballot(c);
-        if (bal) {
-            uint32_t gb = 0;
-            if (lane == 0) gb = atomicAdd(P.n_cand, (uint32_t)__popcll(bal));
-            gb = __shfl(gb, 0);
-            if (c) P.cand[gb + __popcll(bal & lt)] = (uint32_t)(pair >> 32);
-        }
-    };
-    // rows holding >= `level` pairs send their first min(fill, 64) pairs to this wave's part of the bucket (one 512-byte run)
-    auto drain = [&](uint32_t level) {
-        unsigned long long full = __ballot(lane < NB && fill[lane] >= level);
-        while (full) {
-            const uint32_t b = (uint32_t)__builtin_ctzll(full);
-            full &= full - 1;
-            const uint32_t have = fill[b], n = have < 64 ? have : 64;
-            const uint32_t at = __builtin_amdgcn_readlane(written, b);
-            const unsigned long long head = rows[b * PF_ROW + lane], rest = rows[b * PF_ROW + 64 + lane];
-            if (at + n <= Q.cap) {
-                if (lane < n) part(b)[at + lane] = head;
-                if (lane == b) written += n;
-            } else {
-                spill(head, lane < n);
-            }
-            wave_lds_sync();
-            rows[b * PF_ROW + lane] = rest;
-            if (lane == 0) fill[b] = have - n;
-        }
-        wave_lds_sync();
-    };
-    constexpr int NPF = 4;   // 64 reads x <= 64 B
-    uint4 pf[NPF];
-    auto prefetch = [&](uint64_t t) {
-        if (t >= n_tiles) return;
-        const uint64_t byte0 = t * tile_bytes;
-        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
-#pragma unroll
-        for (int c = 0; c < NPF; ++c) {
-            const uint32_t i = lane + c * 64;
-            pf[c] = i < (nbytes >> 4) ? *reinterpret_cast<const uint4*>(P.reads + byte0 + (uint64_t)i * 16) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    prefetch(writer);
-    for (uint64_t t = writer; t < n_tiles; t += Q.n_writers) {
-        const uint64_t byte0 = t * tile_bytes;
-        const uint32_t nbytes = (uint32_t)((total_bytes - byte0) < tile_bytes ? (total_bytes - byte0) : tile_bytes);
-        const uint32_t n16 = nbytes & ~15u;
-#pragma unroll
-        for (int c = 0; c < NPF; ++c) {
-            const uint32_t i = lane + c * 64;
-            if (i < (n16 >> 4)) *reinterpret_cast<uint4*>(tb + (uint64_t)i * 16) = pf[c];
-        }
-        for (uint32_t i = n16 + lane; i < nbytes; i += 64) tb[i] = P.reads[byte0 + i];
-        if (lane < 16) tb[nbytes + lane] = 0;
-        wave_lds_sync();
-        prefetch(t + Q.n_writers);
-        const uint64_t r = t * 64 + lane;
-        const bool live = r < P.n_reads;
-        const uint32_t bit0 = lane * P.rb * 8;
-        for (uint32_t j = 0; j < P.np; ++j) {
-            const uint32_t pk = canon16(stream32(tile, bit0 + P.first2 + j * P.stride2)) * S16_MUL;
-            const uint32_t bk = pk >> (32 - NB_LOG2);
-            if (live) {   // a row has room: it held < 64 pairs and one probe adds at most 64
-                const uint32_t at = atomicAdd(&fill[bk], 1u);
-                rows[bk * PF_ROW + at] = ((unsigned long long)(uint32_t)r << 32) | pk;
-            }
-            wave_lds_sync();
-            drain(64);
-        }
-    }
-    drain(1);
-    if (lane < NB) Q.count[(size_t)lane * Q.n_writers + writer] = written;
-}
-
-__global__ __launch_bounds__(1024) void pf_probe_kernel(PartParams Q) {
-    extern __shared__ uint32_t sm[];   // [the bucket's slice of the 2^mid_log2-bit reduction (when there is one)][per wave: WOBUF candidates]
-    const FilterParams& P = Q.F;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t n_buckets = 1u << Q.nb_log2;
-    const uint32_t xcd = blockIdx.x & 7, li = blockIdx.x >> 3, n_local = (gridDim.x + 7 - xcd) >> 3;   // workgroups of this XCD
-    const bool mid = P.bitmap_mid != nullptr && P.mid_log2 >= Q.nb_log2 + 5;
-    const uint32_t mid_words = mid ? 1u << (P.mid_log2 - Q.nb_log2 - 5) : 0;
-    const uint32_t sh_mid = 32 - P.mid_log2, sh_bm = 32 - P.bm_log2;
-    uint32_t* obuf = sm + mid_words + wv * WOBUF;
-    uint32_t obuf_n = 0;   // wave-uniform
-    auto flush = [&]() {
-        uint32_t gb = 0;
-        if (lane == 0) gb = atomicAdd(P.n_cand, obuf_n);
-        gb = __shfl(gb, 0);
-        for (uint32_t q = lane; q < obuf_n; q += 64) P.cand[gb + q] = obuf[q];
-        obuf_n = 0;
-        wave_lds_sync();
-    };
-    for (uint32_t b = xcd; b < n_buckets; b += 8) {
-        // the slice of the reduced bitmap that covers this bucket's keys: half of the pairs stop here without leaving the CU
-        __syncthreads();
-        for (uint32_t i = tid * 4; i < mid_words; i += 1024 * 4)
-            *reinterpret_cast<uint4*>(sm + i) = *reinterpret_cast<const uint4*>(P.bitmap_mid + (size_t)b * mid_words + i);
-        __syncthreads();
-        // every wave takes whole writer parts on its own
-        for (uint32_t w = li * 16 + wv; w < Q.n_writers; w += n_local * 16) {
-            const uint32_t n = Q.count[(size_t)b * Q.n_writers + w];
-            const unsigned long long* src = Q.pairs + ((size_t)b * Q.n_writers + w) * Q.cap;
-            // software pipeline: the next PB x 64 pairs are in flight while this batch asks the bitmap
-#ifndef GF_PF2_PB
-#define GF_PF2_PB 8
-#endif
-            constexpr int PB = GF_PF2_PB;
-            unsigned long long nx[PB];
-            auto fetch = [&](uint32_t i0) {
-#pragma unroll
-                for (int u = 0; u < PB; ++u) nx[u] = i0 + u * 64 + lane < n ? src[i0 + u * 64 + lane] : 0ull;
-            };
-            fetch(0);
-            for (uint32_t i0 = 0; i0 < n; i0 += PB * 64) {
-                unsigned long long pr[PB];
-                uint32_t wd[PB];
-                bool live[PB];
-#pragma unroll
-                for (int u = 0; u < PB; ++u) pr[u] = nx[u];
-                if (i0 + PB * 64 < n) fetch(i0 + PB * 64);
-#pragma unroll
-                for (int u = 0; u < PB; ++u) {
-                    const uint32_t pk = (uint32_t)pr[u];
-                    live[u] = i0 + u * 64 + lane < n;
-                    if (mid && live[u]) {
-                        const uint32_t c = (pk >> sh_mid) & ((mid_words << 5) - 1);
-                        live[u] = (sm[c >> 5] >> (c & 31)) & 1u;
-                    }
-                    wd[u] = live[u] ? P.bitmap[(pk >> sh_bm) >> 5] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < PB; ++u) {
-                    const uint32_t pk = (uint32_t)pr[u], read = (uint32_t)(pr[u] >> 32);
-                    bool cand = false;
-                    if (live[u] && ((wd[u] >> ((pk >> sh_bm) & 31)) & (wd[u] >> (pk & 31)) & 1u)) {
-                        const uint32_t key = pk * S16_MUL_INV;
-                        if (sset_walk(P, key, hash_s16_set(key, P.s_log2))) {
-                            const uint32_t bit = 1u << (read & 31);
-                            cand = !(atomicOr(&Q.seen[read >> 5], bit) & bit);
-                        }
-                    }
-                    const unsigned long long bal = __ballot(cand);
-                    if (bal) {
-                        if (cand) obuf[obuf_n + __popcll(bal & ((1ull << lane) - 1))] = read;
-                        obuf_n += (uint32_t)__popcll(bal);   // <= 31 + 64 <= WOBUF
-                        wave_lds_sync();
-                        if (obuf_n >= 32) flush();
-                    }
-                }
-            }
-        }
-    }
-    if (obuf_n) flush();
-}
-
 // Loads of the pipelined kernel are issued through inline asm and awaited with explicit s_waitcnt: the compiler's own
 // counter bookkeeping falls back to vmcnt(0) for loop-carried loads, which would drain the pipeline every step.  vmcnt
 // counts vector-memory operations in issue order, so "wait until at most N are outstanding" is safe whenever at least N
@@ -492,7 +274,40 @@ struct Part4Params {
     uint8_t* chunk_b;             // bucket of every PF4_CHUNK entries of that list
     uint32_t* n_cand8;
     uint32_t cap8;
+    // Chance candidates: a 16-mer seed against 1.1e7 flank 16-mers lets 0.5 % of the probes through by chance.  The probes are
+    // therefore spaced for (16 + ext)-base seeds — ext <= 2 bases to the right of the 16-mer, as many as leave the probe count
+    // unchanged — and what stands next to the 16-mer in the flanks rides along with the exact set (FlankIndex::d_sgrp): pass B gets
+    // it in the request that answers the look-up and forwards it (`cand8x`), the resolve step — the read is in LDS there — drops
+    // the pair when the read's own neighbours are none of the flanks' (each base divides the chance rate by 4).
+    const uint32_t* sgrp;         // grouped exact set {key x 4, ext x 4}
+    uint32_t ext;                 // bases checked next to the seed (0: none)
+    uint32_t* cand8x;             // per list entry: the ext word of the pair's 16-mer
 };
+constexpr uint32_t PF4_OBUF = 80;     // list entries buffered per wave of pass B (8 + 4 bytes each)
+// the pair's key in the grouped exact set, from group g on: found -> its ext word
+__device__ __forceinline__ bool pf4_sgrp_walk(const Part4Params& Q, uint32_t key, uint32_t g, uint32_t& ext) {
+    const uint32_t gmask = (1u << (Q.F.s_log2 - 2)) - 1;
+    for (;;) {
+        const uint32_t* G = Q.sgrp + (size_t)(g & gmask) * 8;
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t v = G[j];
+            if (v == key) { ext = G[4 + j]; return true; }
+            if (v == EMPTY32) return false;
+        }
+        ++g;
+    }
+}
+// do the bases right of the probe at bit offset `bit` of the read staged at `words` (bit offsets from the start of `words`) agree
+// with what some flank has next to this 16-mer?  w16 = the read's 16-mer, key = its canonical form
+template <typename P>
+__device__ __forceinline__ bool pf4_ext_ok(P words, uint32_t bit, uint32_t w16, uint32_t key, uint32_t ext, uint32_t xw) {
+    if (ext == 0) return true;
+    const uint32_t nb = stream32(words, bit + 32) >> 28;          // the two bases behind the 16-mer: nearest << 2 | next
+    const bool ro = key != w16;                                    // the read shows the reverse complement of the canonical form:
+    const uint32_t code = ro ? nb ^ 15u : nb;                      // its right side is the canonical LEFT side, complemented
+    const uint32_t mask = ro ? (xw & 0xFFFFu) : (xw >> 16);
+    return ext >= 2 ? (mask >> code) & 1u : ((mask >> (code & 12u)) & 15u) != 0;
+}
 constexpr uint32_t PF4_CHUNK = 256;   // entries of the pair list a wave of pass B reserves at a time
 constexpr uint32_t PF4_STAGE = 16;   // groups of fill history staged in LDS (one 64-byte row per bucket and flush)
 
@@ -957,13 +772,14 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
 }
 
 __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
-    extern __shared__ uint32_t sm[];   // [slice of the level-1 bitmap: 2^(bm_log2 - 8) bits][per wave: 2 x WOBUF words of candidates | 2 x PF2_PEND words of pairs]
+    extern __shared__ uint32_t sm[];   // [slice of the level-1 bitmap: 2^(bm_log2 - 8) bits][per wave: 2 x PF4_OBUF words of list entries | 2 x PF2_PEND words of pairs | PF4_OBUF ext words]
     const FilterParams& P = Q.F;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t slice_words = 1u << (P.bm_log2 - PF2_NB_LOG2 - 5);
     const uint32_t sh_bm = 32 - P.bm_log2;
-    unsigned long long* obuf = reinterpret_cast<unsigned long long*>(sm + slice_words + wv * (2 * WOBUF + 2 * PF2_PEND));
-    unsigned long long* pend = obuf + WOBUF;
+    unsigned long long* obuf = reinterpret_cast<unsigned long long*>(sm + slice_words + wv * (3 * PF4_OBUF + 2 * PF2_PEND));
+    unsigned long long* pend = obuf + PF4_OBUF;
+    uint32_t* obx = reinterpret_cast<uint32_t*>(pend + PF2_PEND);
     uint32_t obuf_n = 0, pend_n = 0;   // wave-uniform
     const unsigned long long lt = (1ull << lane) - 1;
     for (uint32_t b = blockIdx.x; b < PF2_NB; b += gridDim.x) {
@@ -989,7 +805,7 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
                 const uint32_t room = ch_end - ch_at, m = obuf_n - done < room ? obuf_n - done : room;
                 for (uint32_t q = lane; q < m; q += 64) {
                     const unsigned long long cp = obuf[done + q];
-                    if (ch_at + q < Q.cap8) Q.cand8[ch_at + q] = cp;
+                    if (ch_at + q < Q.cap8) { Q.cand8[ch_at + q] = cp; Q.cand8x[ch_at + q] = obx[done + q]; }
                     else pf4_resolve_octet_serial(Q, pf4_octet(Q, b, (uint32_t)(cp >> 56), (uint32_t)(cp >> 32) & 0xFFFFFFu, (uint32_t)(cp >> 24) & 255u),
                                                   (b << 24) | ((uint32_t)cp & 0xFFFFFFu));
                 }
@@ -1003,22 +819,26 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
         // steps: `ask` sends for the four slots at the key's home (one request), `take` — called before the next `ask`, a batch of
         // pairs later — reads the answer, so the wave streams on while the set answers (asked and taken in one go, the look-ups were
         // 0.24 of pass B's 0.91 ms per 675 M pairs: every 6 400 pairs a wave stood still for a round trip to the set).
-        Slots4 asked_v = {EMPTY32, EMPTY32, EMPTY32, EMPTY32};
+        uint4 asked_v = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32), asked_x = make_uint4(0, 0, 0, 0);   // the key's home group: four keys, their ext words
         unsigned long long asked_pr = 0;
         bool asked = false;           // this lane has a look-up in flight
         auto take = [&]() {
             bool cand = false;
+            uint32_t xw = 0;
             if (asked) {
                 const uint32_t key = ((b << 24) | ((uint32_t)asked_pr & 0xFFFFFFu)) * S16_MUL_INV;
-                cand = asked_v.x == key || asked_v.y == key || asked_v.z == key || asked_v.w == key;
-                if (!cand && asked_v.x != EMPTY32 && asked_v.y != EMPTY32 && asked_v.z != EMPTY32 && asked_v.w != EMPTY32)   // rare: four foreign keys in a row
-                    cand = sset_walk(P, key, hash_s16_set(key, P.s_log2) + 4);
+                if (asked_v.x == key) { cand = true; xw = asked_x.x; }
+                else if (asked_v.y == key) { cand = true; xw = asked_x.y; }
+                else if (asked_v.z == key) { cand = true; xw = asked_x.z; }
+                else if (asked_v.w == key) { cand = true; xw = asked_x.w; }
+                else if (asked_v.x != EMPTY32 && asked_v.y != EMPTY32 && asked_v.z != EMPTY32 && asked_v.w != EMPTY32)   // rare: a full group of foreign keys
+                    cand = pf4_sgrp_walk(Q, key, (hash_s16_set(key, P.s_log2) >> 2) + 1, xw);
             }
             asked = false;
             const unsigned long long bal = __ballot(cand);
             if (bal) {
-                if (obuf_n + (uint32_t)__popcll(bal) > WOBUF) flush();
-                if (cand) obuf[obuf_n + __popcll(bal & lt)] = asked_pr;
+                if (obuf_n + (uint32_t)__popcll(bal) > PF4_OBUF) flush();
+                if (cand) { obuf[obuf_n + __popcll(bal & lt)] = asked_pr; obx[obuf_n + __popcll(bal & lt)] = xw; }
                 obuf_n += (uint32_t)__popcll(bal);
                 wave_lds_sync();
                 if (obuf_n >= 32) flush();
@@ -1030,7 +850,9 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
             if (base + lane < pend_n) {
                 asked_pr = pend[base + lane];
                 const uint32_t key = ((b << 24) | ((uint32_t)asked_pr & 0xFFFFFFu)) * S16_MUL_INV;
-                asked_v = *reinterpret_cast<const Slots4*>(P.sset + hash_s16_set(key, P.s_log2));   // (the set ends in a copy of its first four slots)
+                const uint4* G = reinterpret_cast<const uint4*>(Q.sgrp + (size_t)(hash_s16_set(key, P.s_log2) >> 2) * 8);   // 32 aligned bytes: one request
+                asked_v = G[0];
+                asked_x = G[1];
                 asked = true;
             }
             pend_n = base;
@@ -1111,12 +933,13 @@ __global__ __launch_bounds__(256) void pf4_resolve_kernel(Part4Params Q) {
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t e0 = wave * 64; e0 < n; e0 += n_waves * 64) {
         // lane = pair: its octet (one dependent chain of look-ups per lane, 64 in flight per wave) ...
-        uint32_t my_octet = 0xFFFFFFFFu, my_pk = 0;
+        uint32_t my_octet = 0xFFFFFFFFu, my_pk = 0, my_xw = 0;
         {
             const uint64_t e = e0 + lane;
             const unsigned long long cp = e < n ? Q.cand8[e] : ~0ull;
             if (cp != ~0ull) {   // (~0: unused tail of a wave's chunk)
                 const uint32_t b = Q.chunk_b[e / PF4_CHUNK];
+                my_xw = Q.cand8x[e];
                 my_pk = (b << 24) | ((uint32_t)cp & 0xFFFFFFu);
                 my_octet = pf4_octet(Q, b, (uint32_t)(cp >> 56), (uint32_t)(cp >> 32) & 0xFFFFFFu, (uint32_t)(cp >> 24) & 255u);
             }
@@ -1124,7 +947,7 @@ __global__ __launch_bounds__(256) void pf4_resolve_kernel(Part4Params Q) {
         // ... then eight lanes per pair, eight pairs per round: the lanes stage the octet (8 reads, contiguous) in LDS with aligned
         // 16-byte loads, lane = read scrambles its own aligned 16-mers
         for (int u = 0; u < 8; ++u) {
-            const uint32_t octet = __shfl(my_octet, u * 8 + slot), pk = __shfl(my_pk, u * 8 + slot);
+            const uint32_t octet = __shfl(my_octet, u * 8 + slot), pk = __shfl(my_pk, u * 8 + slot), xw = __shfl(my_xw, u * 8 + slot);
             const bool valid = octet != 0xFFFFFFFFu;
             if (!__any(valid)) continue;
             const uint64_t byte0 = (uint64_t)octet * 8 * P.rb;
@@ -1145,7 +968,10 @@ __global__ __launch_bounds__(256) void pf4_resolve_kernel(Part4Params Q) {
             const uint64_t r = (uint64_t)octet * 8 + sub;
             bool hit = false;
             if (valid && r < P.n_reads)
-                for (uint32_t j = 0; j < P.np && !hit; ++j) hit = canon16(stream32(stg, sub * P.rb * 8 + P.first2 + j * P.stride2)) * S16_MUL == pk;
+                for (uint32_t j = 0; j < P.np && !hit; ++j) {
+                    const uint32_t bit = sub * P.rb * 8 + P.first2 + j * P.stride2, w16 = stream32(stg, bit), key = canon16(w16);
+                    hit = key * S16_MUL == pk && pf4_ext_ok(stg, bit, w16, key, Q.ext, xw);
+                }
             if (hit) atomicOr(&Q.seen[r >> 5], 1u << (r & 31));
             wave_lds_sync();
         }
@@ -1976,17 +1802,28 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     // them do — one fewer than probing from offset 0 to the end of the read whenever (L - 16) mod stride < k - 16 (150-base reads:
     // k = 51: 3 instead of 4, k = 41: 5 instead of 6, k = 31: 8 instead of 9).  first = the byte-aligned offset closest below k - 16
     // that still reaches (the pipelined kernel fetches byte-aligned probes faster).
-    const uint32_t np_probe = (uint32_t)((read_len - ix.k) / ix.stride + 1);
-    uint32_t first_probe = (uint32_t)(ix.k - 16);
+    // The 256-bucket filter checks `ext` more bases behind every seed (Part4Params::ext): a k-mer must then contain the 16-mer AND
+    // those bases, so the stride is k - 15 - ext and first <= k - 16 - ext; ext = the most (<= 2) that leaves np as it is
+    // (150-base reads: k = 51: 2, stride 34; k = 41: 2; k = 31: 1).
+    const bool use_pf4 = (ctx->screen_variant == 16 || ctx->screen_variant == 17 || (ctx->screen_variant == 0 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 &&
+                         ix.bm_log2 <= 28 && rb <= 64 && ix.d_sgrp &&
+                         ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) * 4 + (size_t)PF2_BATCH * 5 + (size_t)PF2_NB * (PF4_STAGE + 1) * 4 +
+                          (6 * PF2_NB + 8) * 4) <= 156 * 1024;
+    int ext = 0;
+    if (use_pf4 && ctx->screen_ext)
+        for (int e = 2; e >= 1 && !ext; --e)
+            if (ix.stride - e >= 1 && (read_len - ix.k) / (ix.stride - e) == (read_len - ix.k) / ix.stride) ext = e;
+    const int stride_probe = ix.stride - ext;
+    const uint32_t np_probe = (uint32_t)((read_len - ix.k) / stride_probe + 1);
+    uint32_t first_probe = (uint32_t)(ix.k - 16 - ext);
     {
-        const int lo = (read_len - ix.k) - (int)(np_probe - 1) * ix.stride;
+        const int lo = (read_len - ix.k) - (int)(np_probe - 1) * stride_probe;
         const uint32_t al = first_probe & ~3u;
         if ((int)al >= lo) first_probe = al;
     }
-    F.stride2 = 2 * ix.stride;
+    F.stride2 = 2 * (uint32_t)stride_probe;
     F.first2 = 2 * first_probe;
     F.np = np_probe;
-    if (ctx->screen_np_override >= 0) F.np = (uint32_t)ctx->screen_np_override;  // diagnostic (timing only)
     F.bitmap = ix.d_bitmap;
     F.sset = ix.d_sset;
     F.bm_log2 = ix.bm_log2;
@@ -2027,12 +1864,12 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
                            w_bm_bytes + nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
-    } else if ((ctx->screen_variant == 16 || ctx->screen_variant == 17 || (ctx->screen_variant == 0 && n_reads >= (1u << 20))) && ix.bm_log2 >= 27 && ix.bm_log2 <= 28 && rb <= 64 &&
-               ((size_t)PF2_WAVES * PF2_TILES * (((size_t)64 * rb + 16 + 7) / 8 * 2) * 4 + (size_t)PF2_BATCH * 5 + (size_t)PF2_NB * (PF4_STAGE + 1) * 4 +
-                (6 * PF2_NB + 8) * 4) <= 156 * 1024) {
+    } else if (use_pf4) {
         // partitioned filter, 256 buckets, 4-byte pairs (see Part4Params)
         Part4Params Q;
         Q.F = F;
+        Q.sgrp = ix.d_sgrp;
+        Q.ext = (uint32_t)ext;
         const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;
         const size_t tiles64 = (n_reads + 63) / 64;
         const size_t tiles_wg = (size_t)PF2_WAVES * PF2_TILES;      // tiles per workgroup and iteration
@@ -2055,7 +1892,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         if (ctx->screen_pf4_cap8 > 0) Q.cap8 = (uint32_t)std::max(1, ctx->screen_pf4_cap8 / (int)PF4_CHUNK) * PF4_CHUNK;   // tests: a short pair list (the serial path)
         const size_t b_pairs = (size_t)PF2_NB * Q.n_writers * Q.cap * 4, b_cnt = ((size_t)PF2_NB * Q.n_writers * 4 + 255 + 256) & ~(size_t)255,
                      b_seen = (((size_t)n_reads + 31) / 32 * 4 + 255) & ~(size_t)255, b_fill = (size_t)PF2_NB * Q.n_writers * Q.gs * 4,
-                     b_c8 = ((size_t)Q.cap8 * 8 + Q.cap8 / PF4_CHUNK + 1 + 255) & ~(size_t)255;
+                     b_c8 = ((size_t)Q.cap8 * 12 + Q.cap8 / PF4_CHUNK + 1 + 255) & ~(size_t)255;
         if (Q.cap >= (1u << 24)) return GF_E_INVAL;   // a position must fit 24 bits (2^32 reads stay far below)
         if ((rc = ensure(ctx, ctx->part_ws, b_cnt + b_seen + b_fill + b_c8 + b_pairs + 1024))) return rc;
         uint8_t* ws = (uint8_t*)ctx->part_ws.p;
@@ -2064,7 +1901,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.seen = (uint32_t*)(ws + b_cnt);
         Q.fills = (uint32_t*)(ws + b_cnt + b_seen);
         Q.cand8 = (unsigned long long*)(ws + b_cnt + b_seen + b_fill);
-        Q.chunk_b = (uint8_t*)(ws + b_cnt + b_seen + b_fill + (size_t)Q.cap8 * 8);
+        Q.cand8x = (uint32_t*)(ws + b_cnt + b_seen + b_fill + (size_t)Q.cap8 * 8);
+        Q.chunk_b = (uint8_t*)(ws + b_cnt + b_seen + b_fill + (size_t)Q.cap8 * 12);
         Q.pairs = (uint32_t*)(ws + b_cnt + b_seen + b_fill + b_c8);
         GF_HIP(ctx, hipMemsetAsync(ws + b_cnt - 256, 0, 256 + b_seen, ctx->stream));
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
@@ -2081,40 +1919,11 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
                       : (grp == 1 ? pf4_scatter_kernel<1, false> : grp == 2 ? pf4_scatter_kernel<2, false> : grp == 3 ? pf4_scatter_kernel<3, false> : pf4_scatter_kernel<4, false>);
             hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), lds_a, ctx->stream, Q, (uint32_t)slice_words);
         }
-        const size_t lds_b = (((size_t)1 << (ix.bm_log2 - PF2_NB_LOG2 - 5)) + 16 * (2 * WOBUF + 2 * PF2_PEND)) * 4;
+        const size_t lds_b = (((size_t)1 << (ix.bm_log2 - PF2_NB_LOG2 - 5)) + 16 * (3 * PF4_OBUF + 2 * PF2_PEND)) * 4;
         hipLaunchKernelGGL(pf4_probe_kernel, dim3((unsigned)std::min<size_t>(PF2_NB, (size_t)ctx->n_cu)), dim3(1024), lds_b, ctx->stream, Q);
         const size_t lds_r = (size_t)4 * 8 * (((2 * (size_t)rb + 3) / 4) * 4 + 4) * 4;
         hipLaunchKernelGGL(pf4_resolve_kernel, dim3((unsigned)ctx->n_cu * 8), dim3(256), lds_r, ctx->stream, Q);
         hipLaunchKernelGGL(pf4_list_kernel, dim3((unsigned)std::min<size_t>((size_t)ctx->n_cu * 4, (n_reads + 32 * 256 - 1) / (32 * 256))), dim3(256), 0, ctx->stream, Q);
-    } else if (ctx->screen_variant == 14 || (ctx->screen_variant == 0 && ix.bm_log2 >= 27 && n_reads >= (1u << 20) && rb <= 64)) {
-        // partitioned filter: the level-1 bitmap is far larger than an L2 (see pf_scatter_kernel)
-        PartParams Q;
-        Q.F = F;
-        Q.nb_log2 = 4;   // 16 buckets: two per XCD; a bucket's slice of the 2^24-bit reduction is 128 KiB of LDS in pass B
-        const uint32_t nb = 1u << Q.nb_log2;
-        const size_t slice_words = ((size_t)64 * rb + 16 + 7) / 8 * 2;
-        const size_t per_wave = (slice_words + nb + (size_t)nb * PF_ROW * 2) * 4;
-        const unsigned nw = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / per_wave));
-        const size_t tiles64 = (n_reads + 63) / 64;
-        Q.n_writers = (uint32_t)std::min<size_t>(tiles64, (size_t)ctx->n_cu * nw);
-        // a writer's part of a bucket: expectation + 6 sigma + slack for the 64-pair granularity (keys hash uniformly; parts that
-        // still run full are probed in place)
-        const double tiles_w = (double)((tiles64 + Q.n_writers - 1) / Q.n_writers);
-        const double expect = tiles_w * 64.0 * F.np / nb;
-        Q.cap = ((uint32_t)(expect * 1.05 + 6.0 * std::sqrt(expect + 1.0) + 128.0) + 63u) & ~63u;
-        const size_t b_pairs = (size_t)nb * Q.n_writers * Q.cap * 8, b_cnt = ((size_t)nb * Q.n_writers * 4 + 255) & ~(size_t)255,
-                     b_seen = (((size_t)n_reads + 31) / 32 * 4 + 255) & ~(size_t)255;
-        if ((rc = ensure(ctx, ctx->part_ws, b_cnt + b_seen + b_pairs + 256))) return rc;
-        uint8_t* ws = (uint8_t*)ctx->part_ws.p;
-        Q.count = (uint32_t*)ws;
-        Q.seen = (uint32_t*)(ws + b_cnt);
-        Q.pairs = (unsigned long long*)(ws + b_cnt + b_seen);
-        GF_HIP(ctx, hipMemsetAsync(Q.seen, 0, b_seen, ctx->stream));
-        LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
-        const unsigned grid_a = (unsigned)((Q.n_writers + nw - 1) / nw);
-        hipLaunchKernelGGL(pf_scatter_kernel<4>, dim3(grid_a), dim3(nw * 64), nw * per_wave, ctx->stream, Q, (uint32_t)slice_words);
-        const size_t mid_bytes = (F.bitmap_mid && F.mid_log2 >= Q.nb_log2 + 5) ? ((size_t)1 << (F.mid_log2 - Q.nb_log2)) / 8 : 0;
-        hipLaunchKernelGGL(pf_probe_kernel, dim3((unsigned)ctx->n_cu), dim3(1024), mid_bytes + 16 * WOBUF * 4, ctx->stream, Q);
     } else {
         const size_t n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
         const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * 8);
@@ -2147,7 +1956,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.min_hits = min_hits < 1 ? 1 : min_hits;
     V.sset = (ctx->screen_verify_gate || ctx->screen_verify_ext) ? ix.d_sset : nullptr;
     V.s_log2 = ix.s_log2;
-    V.stride = ix.stride;
+    V.stride = (uint32_t)stride_probe;
     V.np = np_probe;
     V.first = first_probe;
     V.batch = (uint32_t)std::min(64, std::max(1, ctx->screen_verify_batch));

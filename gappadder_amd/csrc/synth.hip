@@ -46,6 +46,10 @@ static int synth_check(const gf_synth_cfg* c) {
     if (c->gaps_per_scaffold && (uint64_t)c->gap_len + 4ull * c->flank_len + 2ull * c->read_len >= c->scaffold_len / (c->gaps_per_scaffold + 1))
         return GF_E_INVAL;
     if ((uint64_t)c->insert_mean + 8ull * c->insert_sd + c->read_len >= c->scaffold_len) return GF_E_INVAL;
+    if (c->repeats) {   // planted repeats: period >= 4, a copy count, and gaps far enough apart that two gaps' planted intervals never meet
+        if ((c->repeats & 0xFFu) < 4 || ((c->repeats >> 8) & 0xFFu) < 1 || (c->repeats >> 16) || c->gaps_per_scaffold == 0) return GF_E_INVAL;
+        if ((uint64_t)c->gap_len + 2ull * (GFS_REP_MAXLEN + 400) + 2ull * c->read_len >= c->scaffold_len / (c->gaps_per_scaffold + 1)) return GF_E_INVAL;
+    }
     return GF_OK;
 }
 

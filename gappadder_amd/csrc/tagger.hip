@@ -40,50 +40,37 @@ struct TagParams {
     uint32_t* n_low;
 };
 
-// Hits are rare and a single global counter serialises returning atomics at ~11 ns each (MI355X_MICROARCH.md
-// "dequeue"/"fanin" rows), so they are first collected in a per-workgroup LDS buffer: wave ballot + prefix count,
-// one LDS atomic per wave, and ONE global atomic per workgroup when the kernel ends.  A full buffer falls back to
-// direct global appends (correct, just slower).
-template <uint32_t CAP>
-struct HitBufT {
-    static constexpr uint32_t cap_ = CAP;
-    gf_taghit h[CAP];
-    uint32_t n;       // slots handed out (may run past CAP)
-    uint32_t stored;  // end of the contiguous prefix actually written
+// A single global counter serialises returning atomics at ~11 ns each (MI355X_MICROARCH.md "dequeue"/"fanin" rows), so hits are
+// collected in an LDS buffer per WAVE (ballot + prefix count, no LDS atomic: the fill is wave-uniform) that leaves with one global
+// atomic per 33-96 hits.  (Rounds 1-3 kept one buffer per workgroup, flushed once when the kernel ended, with direct global appends
+// once it was full: at human scale a workgroup finds 10 000-25 000 hits, so nearly every hit took that fall-back — 600 000
+// returning atomics per launch of the long-insert library, 6 of its 12 ms.)
+constexpr uint32_t WHCAP = 96;   // < 33 waiting + <= 64 from one step
+struct WaveHits {
+    gf_taghit* h;     // this wave's WHCAP entries (LDS)
+    uint32_t n;       // wave-uniform
 };
-using HitBuf = HitBufT<512>;
-
-template <typename HB>
-__device__ __forceinline__ void emit_hit(bool want, const gf_taghit& h, HB& hb, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
+__device__ __forceinline__ void tag_wave_sync();
+__device__ __forceinline__ void flush_wave_hits(WaveHits& w, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t gb = 0;
+    if (lane == 0) gb = atomicAdd(n_out, w.n);
+    gb = __shfl(gb, 0);
+    for (uint32_t i = lane; i < w.n; i += 64)
+        if (gb + i < cap) out[gb + i] = w.h[i];
+    w.n = 0;
+    tag_wave_sync();
+}
+__device__ __forceinline__ void emit_hit(bool want, const gf_taghit& h, WaveHits& w, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
     const unsigned long long bal = __ballot(want);
     if (!bal) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t cnt = (uint32_t)__popcll(bal);
-    const uint32_t leader = __ffsll((long long)bal) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&hb.n, cnt);
-    base = __shfl(base, leader);
-    const uint32_t off = __popcll(bal & ((1ull << lane) - 1));
-    if (base + cnt <= HB::cap_) {
-        if (want) hb.h[base + off] = h;
-        if (lane == leader) atomicMax(&hb.stored, base + cnt);
-    } else {  // buffer full: this wave's hits go straight to the global list
-        uint32_t gb = 0;
-        if (lane == leader) gb = atomicAdd(n_out, cnt);
-        gb = __shfl(gb, leader);
-        if (want && gb + off < cap) out[gb + off] = h;
-    }
-}
-
-template <typename HB>
-__device__ __forceinline__ void flush_hits(HB& hb, gf_taghit* out, uint32_t cap, uint32_t* n_out) {
-    __shared__ uint32_t s_base;
-    __syncthreads();
-    const uint32_t n = hb.stored;  // slots are handed out in order, so the stored entries are the prefix [0, stored)
-    if (threadIdx.x == 0) s_base = n ? atomicAdd(n_out, n) : 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-        if (s_base + i < cap) out[s_base + i] = hb.h[i];
+    if (w.n + cnt > WHCAP) flush_wave_hits(w, out, cap, n_out);
+    if (want) w.h[w.n + __popcll(bal & ((1ull << lane) - 1))] = h;
+    w.n += cnt;
+    tag_wave_sync();
+    if (w.n > WHCAP - 64) flush_wave_hits(w, out, cap, n_out);
 }
 
 // Records are streamed as whole 1-KiB wave loads (16 B per lane, consecutive lanes = consecutive 16-B halves):
@@ -110,13 +97,13 @@ constexpr int TAG_UNROLL = 8;  // 8 KiB (256 records) per wave and stage, two st
 template <int NW, bool BINS_LDS, bool NT = false, bool FINEQ = false>
 __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
     extern __shared__ uint32_t bins_lds[];  // the whole bin map (16 or 64 KiB), staged once per workgroup
-    __shared__ HitBufT<(NW > 4 ? 64 : 128) * NW> hb;
-    constexpr uint32_t LOWBUF = NW > 4 ? 96 : 128;    // MAPQ==0 records buffered per wave (one global atomic per ~64-128 of them)
+    __shared__ gf_taghit whits[NW][WHCAP];
+    constexpr uint32_t LOWBUF = NW > 4 ? 64 : 128;    // MAPQ==0 records buffered per wave (one global atomic per ~32-128 of them)
     __shared__ gf_lowrec lowbuf[NW][LOWBUF];
     __shared__ LiveRec liveq[NW][LIVEQ];
     __shared__ CandRec candq[FINEQ ? NW : 1][FINEQ ? CANDQ : 1];
     uint32_t low_n = 0;                 // wave-uniform
-    if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
+    WaveHits hb{whits[threadIdx.x >> 6], 0};
     if (BINS_LDS) for (uint32_t i = threadIdx.x; i < P.bin_words + P.off_words; i += blockDim.x) bins_lds[i] = P.bin_bits[i];   // (bits, then offsets: one array)
     const uint32_t* bins = BINS_LDS ? bins_lds : P.bin_bits;
     const uint32_t* boff = BINS_LDS && P.off_words ? bins_lds + P.bin_words : P.bin_off;
@@ -302,7 +289,7 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
     if (FINEQ) while (cand_n) sift();
     while (live_n) drain();
     if (P.low && low_n) flush_low();
-    flush_hits(hb, P.out, P.cap, P.n_out);
+    if (hb.n) flush_wave_hits(hb, P.out, P.cap, P.n_out);
 }
 
 struct LowParams {
@@ -321,9 +308,8 @@ struct LowParams {
 };
 
 __global__ __launch_bounds__(256) void low_mapq_kernel(LowParams P) {
-    __shared__ HitBuf hb;
-    if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
-    __syncthreads();
+    __shared__ gf_taghit whits[4][WHCAP];
+    WaveHits hb{whits[threadIdx.x >> 6], 0};
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -371,14 +357,13 @@ __global__ __launch_bounds__(256) void low_mapq_kernel(LowParams P) {
             }
         }
     }
-    flush_hits(hb, P.out, P.cap, P.n_out);
+    if (hb.n) flush_wave_hits(hb, P.out, P.cap, P.n_out);
 }
 
 // second hop over the compacted list (2 % of the records, 12 B each) instead of a second pass over every record
 __global__ __launch_bounds__(256) void low_mapq_compact_kernel(LowParams P) {
-    __shared__ HitBuf hb;
-    if (threadIdx.x == 0) { hb.n = 0; hb.stored = 0; }
-    __syncthreads();
+    __shared__ gf_taghit whits[4][WHCAP];
+    WaveHits hb{whits[threadIdx.x >> 6], 0};
     const uint32_t n = *P.n_low < P.low_cap ? *P.n_low : P.low_cap;
     const uint32_t n_round = (n + 63) & ~63u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
@@ -412,8 +397,12 @@ __global__ __launch_bounds__(256) void low_mapq_compact_kernel(LowParams P) {
             if (more) ++row;
         }
     }
-    flush_hits(hb, P.out, P.cap, P.n_out);
+    if (hb.n) flush_wave_hits(hb, P.out, P.cap, P.n_out);
 }
+
+// static LDS of tag_kernel<16, ..., FINEQ = true>: hit buffers, MAPQ-0 buffers, the two queues (+ alignment slack)
+constexpr size_t TAG16_STATIC_LDS = 16 * (WHCAP * sizeof(gf_taghit) + 64 * sizeof(gf_lowrec) + LIVEQ * sizeof(LiveRec) + CANDQ * sizeof(CandRec)) + 64;
+static_assert(TAG16_STATIC_LDS + 64 * 1024 + 2049 * 4 <= 160 * 1024, "tag_kernel<16>: queues + a 64-KiB bin map + 2 049 scaffold offsets must fit a CU's LDS");
 
 static unsigned stream_grid(gf_ctx* ctx, size_t n) {
     size_t blocks = (n + 255) / 256;
@@ -479,12 +468,21 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
             std::vector<uint32_t> hf;
             uint32_t fw = 0;
             build(fs, hf, fw);
-            rc = ensure(ctx, ctx->binmap_fine, hf.size() * 4);
-            if (rc) return rc;
-            GF_HIP(ctx, hipMemcpyAsync(ctx->binmap_fine.p, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->fine_words = fw;
-            ctx->fine_shift = fs;
+            // ... and only when the finer bins stop a good part of what the LDS map lets through.  Long-insert libraries do not:
+            // their windows (2 x dist2 + the gap, 15 kb at IS 5 000) are wider than the LDS map's bins, 13 % of the records pass the
+            // LDS map and 10 % lie in a window — the second look-up and the re-load of the record it implies (13 % of the records a
+            // second time, at random) cost more than the window search of the 3 % it would stop.
+            uint64_t set_fine = 0;
+            for (uint32_t i = 0; i < fw; ++i) set_fine += (uint64_t)__builtin_popcount(hf[i]);
+            const double cover_lds = (double)set_bits * (double)(1ull << shift), cover_fine = (double)set_fine * (double)(1ull << fs);
+            if (cover_fine <= 0.6 * cover_lds) {
+                rc = ensure(ctx, ctx->binmap_fine, hf.size() * 4);
+                if (rc) return rc;
+                GF_HIP(ctx, hipMemcpyAsync(ctx->binmap_fine.p, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                ctx->fine_words = fw;
+                ctx->fine_shift = fs;
+            }
         }
     }
     ctx->bin_dist2 = dist2;
@@ -525,7 +523,14 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
     P.bin_shift = ctx->bin_shift;
     P.bin_words = ctx->bin_words;
     P.off_words = ctx->n_scaffolds + 1 <= 2048 ? ctx->n_scaffolds + 1 : 0;   // the per-scaffold offsets ride along in LDS when they are few
-    const size_t lds_map = ((size_t)ctx->bin_words + P.off_words) * 4;
+    size_t lds_map = ((size_t)ctx->bin_words + P.off_words) * 4;
+    // the 16-wave form keeps TAG16_STATIC_LDS bytes of queues and buffers beside the staged map: when the two do not fit a CU's LDS
+    // the per-scaffold offsets stay in global memory
+    if ((size_t)ctx->bin_words * 4 > 32 * 1024 && TAG16_STATIC_LDS + lds_map > 160 * 1024) {
+        P.off_words = 0;
+        lds_map = (size_t)ctx->bin_words * 4;
+        if (TAG16_STATIC_LDS + lds_map > 160 * 1024) return GF_E_UNSUPPORTED;   // (a 64-KiB map is the largest ensure_bin_map builds)
+    }
     P.fine_bits = ctx->fine_words ? (const uint32_t*)ctx->binmap_fine.p : nullptr;
     P.fine_off = P.fine_bits ? P.fine_bits + ctx->fine_words : nullptr;
     P.fine_shift = ctx->fine_shift;

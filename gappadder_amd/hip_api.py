@@ -299,10 +299,14 @@ class GapFill:
     # ---- synthetic workload (include/gf_synth.h) ----------------------------------------------------
     @staticmethod
     def synth_cfg(seed=20260002, scaffold_len=5_000_000, n_scaffolds=50, gaps_per_scaffold=20, gap_len=2000,
-                  read_len=150, insert_mean=300, insert_sd=30, err=0.005, mapq0=0.02, chimeric=0.01, flank_len=300, library=0):
+                  read_len=150, insert_mean=300, insert_sd=30, err=0.005, mapq0=0.02, chimeric=0.01, flank_len=300, library=0,
+                  repeat_period=0, repeat_copies=50):
+        """repeat_period P >= 4: the stress workload of include/gf_synth.h — every P-th gap sits at a copy of a repeat family shared
+        by repeat_copies gaps, two more of every P share a 2-copy repeat, one carries a low-complexity run in its flank."""
         c = np.zeros(1, dtype=B.SYNTH_CFG)
         c[0] = (seed, scaffold_len, n_scaffolds, gaps_per_scaffold, gap_len, read_len, insert_mean, insert_sd,
-                int(round(err * 65536)), int(round(mapq0 * 65536)), int(round(chimeric * 65536)), flank_len, library, 0)
+                int(round(err * 65536)), int(round(mapq0 * 65536)), int(round(chimeric * 65536)), flank_len, library,
+                (int(repeat_period) & 0xFF) | ((int(repeat_copies) & 0xFF) << 8) if repeat_period else 0)
         return c
 
     @staticmethod

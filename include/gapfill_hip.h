@@ -102,10 +102,13 @@ int gf_stream_wait_after_filter(gf_ctx* waiter, gf_ctx* producer);
  * "bitmap_log2" (size of the screen's level-1 16-mer bitmap, 0 = automatic), "index_host" (1: build the flank k-mer index with
  * the host comparator instead of the device kernels — same index up to slot order; a test aid, refused unless the environment
  * has GF_DIAGNOSTICS set).
- * Ablation / diagnostic switches (results never change): "screen_variant" (0 automatic, 9 plain, 13 pipelined, 14 partitioned with
- * 16 buckets, 16 partitioned with 256 buckets and 4-byte pairs, 17 the same with unaligned pair runs in its first pass), "screen_verify_ext" (1: seed-and-extend verification when min_hits == 1), "screen_verify_gate",
- * "screen_verify_batch", "screen_stream_policy", "screen_lds_log2_max", "screen_np_override" (timing experiments: fewer probes, WRONG hits; refused unless the environment has GF_DIAGNOSTICS set),
- * "asm_keyslot", "asm_lds_pool_kb", "asm_dbg_ptr".
+ * Ablation / diagnostic switches (results never change): "screen_variant" (0 automatic, 9 plain, 13 pipelined,
+ * 16 partitioned with 256 buckets and 4-byte pairs, 17 the same with unaligned pair runs in its first pass), "screen_ext" (1: the
+ * partitioned filter drops seeds whose neighbouring bases are none of the flanks'; 0: 16-base seeds as they are),
+ * "screen_verify_ext" (1: seed-and-extend verification when min_hits == 1), "screen_verify_gate",
+ * "screen_verify_batch", "screen_stream_policy", "screen_lds_log2_max", "screen_pf4_cap8",
+ * "asm_keyslot", "asm_precount", "asm_ranked", "asm_lds_pool_kb", "asm_threads" (threads per gap: 1024 / 512 / 256, 0 = by the pool
+ * bound), "asm_stats_ptr" (device u64[4] the assembly adds its window / k-mer / survivor / node counts to), "asm_dbg_ptr".
  * Tagger: "tag_light" (1: one-wave workgroups that read the coarse bin map through L1/L2 instead of staging it in LDS — same hits;
  * for a pipeline that runs the tagger on a second context beside the k-mer filter, whose workgroups own most of every CU's LDS).
  * Assembly: "asm_simplify" (rounds of tip clipping + bubble popping — Velvet's defaults, which the reference runs with
@@ -304,8 +307,9 @@ int gf_pool_keys_all_dev(gf_ctx* ctx, const void* d_hits, const void* d_n_hits, 
 int gf_pool_keys_from_second_hop_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits,
                                      size_t hit_cap, const void* d_row_gap, void* d_keys, size_t key_cap, void* d_n_keys);
 /* keys -> d_pool_off (n_gaps+1 x u64), d_pool_packed (pool_cap_reads reads), d_pool_read_ids (u32 per pooled read, or
- * null); *d_error (u32) counts gaps whose key list exceeded the LDS sort (16384 keys).  d_pool_off[n_gaps] > pool_cap_reads
- * means the pool buffer was too small (reads beyond it are not written). */
+ * null).  A gap may have any number of keys (up to 16 384 are sorted in LDS, longer lists in place in global memory: slower, never
+ * dropped — the reference has no bound either, run_multi_threads_discordant.py:209-241).  *d_error (u32): bit 31 set =
+ * d_pool_off[n_gaps] > pool_cap_reads, the pool buffer was too small (reads beyond it are not written; d_pool_off stays exact). */
 int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, int read_len, const void* d_keys,
                        const void* d_n_keys, size_t key_cap, void* d_pool_packed, size_t pool_cap_reads, void* d_pool_off,
                        void* d_pool_read_ids, void* d_error);

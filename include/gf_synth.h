@@ -31,7 +31,13 @@ typedef struct {
     uint32_t library;           /* read library drawn from the SAME genome: 0 = first (reproduces the single-library data), 1, 2 ...
                                  * select independent pair streams (a second `alignments[]` entry of the reference's JSON, e.g. the
                                  * IS 5000 mate-pair library of BASELINE.json configs[4]) */
-    uint32_t reserved;          /* 0 */
+    uint32_t repeats;           /* 0 = i.i.d. sequence everywhere.  Otherwise the stress workload: bits 0-7 = period P >= 4,
+                                 * bits 8-15 = copies C: gap classes by (global gap index) mod P — class 0: the region at the gap's LEFT
+                                 * edge is a copy of a repeat family shared by C such gaps (0.5-5 kb, ending up to 200 bases before the
+                                 * gap or reaching up to 400 bases into it; every other copy reverse-complemented); classes 1 and 2: the
+                                 * two of them share a 2-copy repeat at the gap's RIGHT edge; class 3: a low-complexity run (unit of 1-3
+                                 * bases, 40-99 bases long) inside the left flank; the other classes stay unique.  Reads that lie wholly
+                                 * inside a repeat copy are reported with MAPQ 0, as an aligner would. */
 } gf_synth_cfg;
 
 typedef struct {
@@ -53,12 +59,72 @@ GFS_HD uint64_t gfs_mix(uint64_t z) {
 GFS_HD uint64_t gfs_block(const gf_synth_cfg* c, uint32_t scaffold, uint64_t block) {
     return gfs_mix(c->seed ^ gfs_mix(((uint64_t)scaffold << 40) ^ block));
 }
-GFS_HD uint32_t gfs_base(const gf_synth_cfg* c, uint32_t scaffold, uint64_t pos) {
-    return (uint32_t)(gfs_block(c, scaffold, pos >> 5) >> (2 * (pos & 31))) & 3u;
-}
-
 GFS_HD uint64_t gfs_gap_start(const gf_synth_cfg* c, uint32_t j) { /* j-th gap (0-based) of any scaffold */
     return (uint64_t)(j + 1) * c->scaffold_len / (c->gaps_per_scaffold + 1) - c->gap_len / 2;
+}
+
+/* ---- planted repeats (cfg.repeats != 0): what, if anything, is planted at gap j of a scaffold */
+#define GFS_REP_MAXLEN 5000u
+typedef struct {
+    uint32_t kind;     /* 0 nothing, 1 copy of a repeat family, 2 low-complexity run */
+    uint32_t rev;      /* kind 1: this copy is the reverse complement of the family sequence */
+    uint64_t lo, hi;   /* scaffold interval [lo, hi) */
+    uint64_t fam;      /* kind 1: family id; kind 2: the run's hash (unit length and bases) */
+} gfs_rep;
+GFS_HD void gfs_gap_repeat(const gf_synth_cfg* c, uint32_t scaffold, uint32_t j, gfs_rep* o) {
+    const uint32_t P = c->repeats & 0xFFu, C = (c->repeats >> 8) & 0xFFu;
+    o->kind = 0; o->rev = 0; o->lo = o->hi = 0; o->fam = 0;
+    if (P < 4) return;
+    const uint64_t gid = (uint64_t)scaffold * c->gaps_per_scaffold + j, grp = gid / P;
+    const uint32_t cls = (uint32_t)(gid % P);
+    const uint64_t gs = gfs_gap_start(c, j), ge = gs + c->gap_len;
+    if (cls <= 2) {
+        o->kind = 1;
+        o->fam = cls == 0 ? 1 + grp / (C ? C : 1u) : 0x4000000000ull + grp;
+        const uint64_t h = gfs_mix(c->seed ^ gfs_mix(0xF00D5EED00000000ull + o->fam));
+        const uint64_t len = 500 + h % (GFS_REP_MAXLEN - 499);
+        const int64_t e = (int64_t)((h >> 24) % 600) - 200;      /* > 0: reaches e bases into the gap; < 0: ends -e bases before it */
+        o->rev = (uint32_t)(gfs_mix(gid ^ h) & 1u);
+        if (cls == 0) { o->hi = (uint64_t)((int64_t)gs + e); o->lo = o->hi - len; }
+        else { o->lo = (uint64_t)((int64_t)ge - e); o->hi = o->lo + len; }
+    } else if (cls == 3) {
+        o->kind = 2;
+        o->fam = gfs_mix(c->seed ^ gfs_mix(0x10C0AAAA00000000ull + gid));
+        const uint64_t run = 40 + (o->fam >> 8) % 60;
+        o->hi = gs - 20 - (o->fam >> 16) % 100;
+        o->lo = o->hi - run;
+    }
+}
+/* base of a planted interval at scaffold position pos (lo <= pos < hi) */
+GFS_HD uint32_t gfs_rep_base(const gf_synth_cfg* c, const gfs_rep* r, uint64_t pos) {
+    if (r->kind == 2) {
+        const uint32_t ul = 1 + (uint32_t)(r->fam % 3);
+        return (uint32_t)(r->fam >> (32 + 2 * ((pos - r->lo) % ul))) & 3u;
+    }
+    const uint64_t off = r->rev ? (r->hi - 1 - pos) : (pos - r->lo);
+    const uint32_t b = (uint32_t)(gfs_mix(c->seed ^ gfs_mix(0x5EC0000000000000ull ^ (r->fam << 24) ^ (off >> 5))) >> (2 * (off & 31))) & 3u;
+    return r->rev ? 3u - b : b;
+}
+/* the planted interval that holds pos, if any (intervals stay within GFS_REP_MAXLEN + 400 bases of their gap and gaps are further
+ * apart than twice that: only the two gaps next to pos can matter) */
+GFS_HD int gfs_find_repeat(const gf_synth_cfg* c, uint32_t scaffold, uint64_t pos, gfs_rep* o) {
+    const uint64_t jj = pos * (c->gaps_per_scaffold + 1) / c->scaffold_len;   /* gaps jj-1 (left of pos) and jj (right of it) */
+    for (int d = -1; d <= 0; ++d) {
+        const int64_t j = (int64_t)jj + d;
+        if (j < 0 || j >= (int64_t)c->gaps_per_scaffold) continue;
+        gfs_gap_repeat(c, scaffold, (uint32_t)j, o);
+        if (o->kind && pos >= o->lo && pos < o->hi) return 1;
+    }
+    o->kind = 0;
+    return 0;
+}
+
+GFS_HD uint32_t gfs_base(const gf_synth_cfg* c, uint32_t scaffold, uint64_t pos) {
+    if (c->repeats) {
+        gfs_rep r;
+        if (gfs_find_repeat(c, scaffold, pos, &r)) return gfs_rep_base(c, &r, pos);
+    }
+    return (uint32_t)(gfs_block(c, scaffold, pos >> 5) >> (2 * (pos & 31))) & 3u;
 }
 
 GFS_HD void gfs_make_pair(const gf_synth_cfg* c, uint64_t pair, gfs_pair* o) {
@@ -135,6 +201,12 @@ GFS_HD void gfs_make_records(const gf_synth_cfg* c, uint64_t pair, const gfs_pai
     gfs_align(c, p->p[0], &al[0]);
     gfs_align(c, p->p[1], &al[1]);
     const uint64_t L = c->read_len;
+    uint32_t in_rep[2] = {0, 0};   /* the end lies wholly inside a copy of a repeat family: an aligner reports MAPQ 0 */
+    if (c->repeats)
+        for (int i = 0; i < 2; ++i) {
+            gfs_rep r;
+            in_rep[i] = gfs_find_repeat(c, p->s[i], p->p[i], &r) && r.kind == 1 && p->p[i] + L <= r.hi;
+        }
     for (int i = 0; i < 2; ++i) {
         const int j = 1 - i;
         const uint32_t m = al[i].mapped, mm = al[j].mapped;
@@ -153,7 +225,7 @@ GFS_HD void gfs_make_records(const gf_synth_cfg* c, uint64_t pair, const gfs_pai
             const int32_t span = (int32_t)(hi - lo);
             tlen = p->p[i] <= p->p[j] ? span : -span;
         }
-        const uint32_t mapq = m ? (p->mapq0[i] ? 0u : 60u) : 0u;
+        const uint32_t mapq = m ? ((p->mapq0[i] || in_rep[i]) ? 0u : 60u) : 0u;
         const uint32_t clip = m ? al[i].clipflag : 0u;
         const uint64_t rid = 2 * pair + mate_no;
         out[i][0] = pos; out[i][1] = mpos; out[i][2] = (uint32_t)tlen; out[i][3] = ref; out[i][4] = mref;

@@ -19,7 +19,7 @@ HIT = np.dtype([("gap", "<u4"), ("read", "<u4")])
 SYNTH_CFG = np.dtype([("seed", "<u8"), ("scaffold_len", "<u8"), ("n_scaffolds", "<u4"), ("gaps_per_scaffold", "<u4"),
                       ("gap_len", "<u4"), ("read_len", "<u4"), ("insert_mean", "<u4"), ("insert_sd", "<u4"),
                       ("err_q16", "<u4"), ("mapq0_q16", "<u4"), ("chimeric_q16", "<u4"), ("flank_len", "<u4"),
-                      ("library", "<u4"), ("reserved", "<u4")])
+                      ("library", "<u4"), ("repeats", "<u4")])
 
 
 def lib():
@@ -119,10 +119,12 @@ def unpack_reads(packed, read_len):
 
 
 def synth_cfg(seed=20260002, scaffold_len=5_000_000, n_scaffolds=50, gaps_per_scaffold=20, gap_len=2000, read_len=150,
-              insert_mean=300, insert_sd=30, err=0.005, mapq0=0.02, chimeric=0.01, flank_len=300, library=0):
+              insert_mean=300, insert_sd=30, err=0.005, mapq0=0.02, chimeric=0.01, flank_len=300, library=0, repeat_period=0,
+              repeat_copies=50):
     c = np.zeros(1, dtype=SYNTH_CFG)
     c[0] = (seed, scaffold_len, n_scaffolds, gaps_per_scaffold, gap_len, read_len, insert_mean, insert_sd,
-            int(round(err * 65536)), int(round(mapq0 * 65536)), int(round(chimeric * 65536)), flank_len, library, 0)
+            int(round(err * 65536)), int(round(mapq0 * 65536)), int(round(chimeric * 65536)), flank_len, library,
+            (int(repeat_period) & 0xFF) | ((int(repeat_copies) & 0xFF) << 8) if repeat_period else 0)
     return c
 
 

@@ -333,3 +333,40 @@ def test_two_and_four_gaps_per_cu_give_the_same_contigs(gf, threads):
         for k, kv in ((31, 29), (41, 39)):
             assert got2.get((g, k, kv), []) == CO.assemble_pool(p, 150, k, kv), (g, k, kv)
     assert n > 20
+
+
+@pytest.mark.parametrize("kk", [(31, 29), (51, 49)])
+def test_pools_beyond_the_callers_bound_take_the_second_launch(gf, kk):
+    """asm_max_pool_reads bounds the workspace slice of the main launch; a deeper pool (a flank inside a repeat) is not an error:
+    it is listed and assembled by the second launch with slices of asm_big_pool_reads rows — same contigs as the oracle, no
+    gap_error.  A pool beyond asm_big_pool_reads is the documented limit: its gap_error is set and the host call reports the pool."""
+    rng = np.random.RandomState(kk[0])
+    L = 150
+    pools = []
+    for i in range(24):
+        g = LUT[rng.randint(0, 4, 600 + 40 * i)].tobytes()
+        depth = 4 if i % 5 else 40                      # every fifth pool is ten times as deep
+        reads = []
+        for _ in range(int(depth * len(g) / L) + 4):
+            s0 = rng.randint(0, len(g) - L + 1)
+            r = bytearray(g[s0:s0 + L])
+            for p in np.nonzero(rng.rand(L) < 0.004)[0]:
+                r[p] = b"ACGT"[(b"ACGT".index(bytes([r[p]])) + 1 + rng.randint(3)) % 4]
+            reads.append(rc(bytes(r)) if rng.randint(2) else bytes(r))
+        pools.append(b"".join(reads))
+    sizes = [len(p) // L for p in pools]
+    assert min(sizes) < 40 and max(sizes) > 300
+    want = [CO.assemble_pool(p, L, kk[0], kk[1]) for p in pools]
+    try:
+        for bound in (64, 1):                            # some / all pools beyond the bound
+            gf.set_option("asm_max_pool_reads", bound)
+            got, _ = _gpu_assemble(gf, pools, L, [kk])
+            for i in range(len(pools)):
+                assert got.get((i, kk[0], kk[1]), []) == want[i], (bound, i, sizes[i])
+        gf.set_option("asm_big_pool_reads", 200)         # the deep pools are beyond the second launch's slices too
+        gf.set_option("asm_max_pool_reads", 64)
+        with pytest.raises(Exception):
+            _gpu_assemble(gf, pools, L, [kk])
+    finally:
+        gf.set_option("asm_max_pool_reads", 0)
+        gf.set_option("asm_big_pool_reads", 131072)

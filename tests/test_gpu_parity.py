@@ -100,13 +100,15 @@ def test_screen_and_tagger_synthetic(gf, seed, n_pairs, L, k):
     exp = CO.screen_reads(c["reads_blob"], L, c["flanks"], k)
     assert _same(hits, exp) and len(exp) > 100
     if L <= 250:      # the partitioned filters (packed reads up to 64 bytes) on the same reads, with a 2^27-bit bitmap:
-        for variant in (14, 16, 17):  # 16 buckets with per-wave rows / 256 buckets with the workgroup sort and 4-byte pairs (whole-line stores where they fit; 17: unaligned runs)
+        for variant, ext in ((16, 1), (17, 1), (16, 0)):  # 256 buckets with the workgroup sort and 4-byte pairs (whole-line stores where they fit; 17: unaligned runs); seeds with / without the neighbour check
             gf.set_option("screen_variant", variant)
+            gf.set_option("screen_ext", ext)
             gf.set_option("bitmap_log2", 27)
             try:
-                assert _same(gf.screen_reads(packed, L, k), exp), variant
+                assert _same(gf.screen_reads(packed, L, k), exp), (variant, ext)
             finally:
                 gf.set_option("screen_variant", 0)
+                gf.set_option("screen_ext", 1)
                 gf.set_option("bitmap_log2", 0)
     for (IS, sd) in ((max(300, L + 100), 30), (5000, 500)):
         th = gf.tag_alignments(c["recs"], IS, sd)
@@ -240,6 +242,49 @@ def test_synthetic_generator_matches_oracle_bit_for_bit(gf):
     assert _same(gf.tag_alignments(recs, 300, 30), CO.tag_alignments(recs, g2, 300, 30))
 
 
+@pytest.mark.parametrize("n_big", [16385, 40000, 150001])
+def test_device_pools_keep_gaps_with_more_keys_than_the_lds_sort_holds(gf, n_big):
+    """A gap whose flank sits in a repeat recruits far more reads than the 16 384 keys one LDS sort holds (the reference has no
+    bound: run_multi_threads_discordant.py:209-241 flushes any number of records).  Such a gap is sorted in place in global memory
+    — same pools as numpy's sort + unique, no error flag, the neighbours untouched."""
+    import torch
+    from gappadder_amd import _lib as B
+    c = S.small_case(seed=33, n_pairs=600)
+    gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
+    n_gaps, L, rb = len(c["gaps"]), 150, 38
+    assert n_gaps >= 3
+    rng = np.random.RandomState(n_big)
+    n_reads = 400_000
+    per_gap = {0: rng.randint(0, n_reads, 900), 1: rng.randint(0, n_reads, n_big), 2: rng.randint(0, n_reads, 17000)}
+    per_gap[1][::7] = per_gap[1][0]                      # many duplicates of one key
+    if n_big > 20000: per_gap[1][5000:12000] = np.arange(7000) * 2 + 1     # a run of right mates
+    keys = np.concatenate([(np.uint64(g) << np.uint64(32)) | v.astype(np.uint64) for g, v in per_gap.items()])
+    rng.shuffle(keys)
+    dev = torch.device("cuda:0")
+    d_reads = torch.randint(0, 256, (n_reads, rb), dtype=torch.uint8, device=dev)
+    d_keys = torch.from_numpy(keys.view(np.int64)).to(dev)
+    d_nk = torch.tensor([len(keys), 0, 0, 0], dtype=torch.int32, device=dev)
+    pool_cap = len(keys) + 8
+    d_pool = torch.zeros(pool_cap * rb, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_gaps + 1, dtype=torch.int64, device=dev)
+    d_ids = torch.zeros(pool_cap, dtype=torch.int32, device=dev)
+    d_err = torch.zeros(4, dtype=torch.int32, device=dev)
+    assert B.lib().gf_build_pools_dev(gf.handle, d_reads.data_ptr(), n_reads, L, d_keys.data_ptr(), d_nk.data_ptr(), len(keys), d_pool.data_ptr(),
+                                      pool_cap, d_off.data_ptr(), d_ids.data_ptr(), d_err.data_ptr()) == 0
+    gf.sync()
+    assert int(d_err[0]) == 0
+    off = d_off.cpu().numpy()
+    ids = d_ids.cpu().numpy().astype(np.uint32)
+    reads = d_reads.cpu().numpy()
+    pool = d_pool.cpu().numpy().reshape(pool_cap, rb)
+    for g in range(n_gaps):
+        u = np.unique(per_gap[g]) if g in per_gap else np.zeros(0, np.int64)
+        want = u[np.lexsort((u >> 1, u & 1))].astype(np.uint32)      # (mate, pair): left-file stream order, then right-file order
+        got = ids[off[g]:off[g + 1]]
+        assert len(got) == len(want) and (got == want).all(), g
+        assert (pool[off[g]:off[g + 1]] == reads[want]).all(), g
+
+
 def test_device_pools_follow_the_reference_fastq_join_order(gf):
     """gf_build_pools_dev: keys from screen (+mates), tagger and second hop -> per-gap pools ordered (mate, pair)."""
     import torch
@@ -314,9 +359,9 @@ def test_device_pools_follow_the_reference_fastq_join_order(gf):
         assert gseqs == [x[0] for x in e]
 
 
-@pytest.mark.parametrize("variant", [13, 9, 14])
+@pytest.mark.parametrize("variant", [13, 9, 16])
 def test_screen_filter_variants_agree(gf, variant):
-    """Every filter kernel (pipelined = 13, plain L2 bitmap = 9, partitioned = 14 / 16) gives the oracle's hits."""
+    """Every filter kernel (pipelined = 13, plain L2 bitmap = 9, partitioned = 16 / 17) gives the oracle's hits."""
     from gappadder_amd.hip_api import GapFill
     c = S.small_case(seed=41, n_pairs=25000)
     gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
@@ -328,20 +373,23 @@ def test_screen_filter_variants_agree(gf, variant):
         for n in (len(packed), 1000, 769, 1):
             assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (variant, n)
         assert _same(gf.screen_reads(packed, c["L"], 51), exp51)
-        for bl in (16, 19, 22, 26, 28):  # 26: level-1 bitmap beyond the L2 -> the plain kernel also asks the 2^24-bit reduction;
-            gf.set_option("bitmap_log2", bl)   # 28: the partitioned filter uses 16 buckets instead of 8
+        for bl in (16, 19, 22, 26, 28, 29):  # 26: level-1 bitmap beyond the L2 -> the plain kernel also asks the 2^24-bit reduction;
+            gf.set_option("bitmap_log2", bl)      # (the partitioned filter exists for 2^27 and 2^28 bits: the plain kernel otherwise)
             assert _same(gf.screen_reads(packed, c["L"], 31), exp31), (variant, bl)
-        if variant == 14:      # the 256-bucket partitioned filter (variant 16) exists for 2^27- and 2^28-bit bitmaps
-            for v256 in (16, 17):   # pass A with whole-line stores / with unaligned runs
+        if variant == 16:      # the 256-bucket partitioned filter exists for 2^27- and 2^28-bit bitmaps
+            exp41 = CO.screen_reads(c["reads_blob"], c["L"], c["flanks"], 41)
+            for v256, ext in ((16, 1), (17, 1), (16, 0)):   # pass A with whole-line stores / with unaligned runs; seeds with / without the neighbour check
                 gf.set_option("screen_variant", v256)
+                gf.set_option("screen_ext", ext)
                 for bl in (27, 28):
                     gf.set_option("bitmap_log2", bl)
                     for n in (len(packed), 1000, 769, 1):
-                        assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (v256, bl, n)
-                    assert _same(gf.screen_reads(packed, c["L"], 51), exp51), (v256, bl)
-                    assert _same(gf.screen_reads(packed, c["L"], 41), CO.screen_reads(c["reads_blob"], c["L"], c["flanks"], 41)), (v256, bl)
+                        assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (v256, ext, bl, n)
+                    assert _same(gf.screen_reads(packed, c["L"], 51), exp51), (v256, ext, bl)
+                    assert _same(gf.screen_reads(packed, c["L"], 41), exp41), (v256, ext, bl)
     finally:
         gf.set_option("screen_variant", 0)
+        gf.set_option("screen_ext", 1)
         gf.set_option("bitmap_log2", 0)
 
 
@@ -489,7 +537,7 @@ def test_tagger_on_human_scale_layout_uses_the_fine_bin_map(gf):
 
 
 def test_partitioned_filter_probes_in_place_when_a_bucket_part_runs_full(gf):
-    """Degenerate input for the partitioned filter (screen_variant 14): 60 000 poly-A reads put every probe into ONE bucket, eight
+    """Degenerate input for the partitioned filter: 60 000 poly-A reads put every probe into ONE bucket, eight
     times what a writer's part of it holds, so most pairs take the in-place path; the hits must still be the oracle's (the flank
     of gap 0 ends in a poly-A run, so those reads are real hits)."""
     from gappadder_amd.hip_api import GapFill
@@ -504,8 +552,6 @@ def test_partitioned_filter_probes_in_place_when_a_bucket_part_runs_full(gf):
     exp = CO.screen_reads(blob, L, flanks, 31)
     assert len(exp) > 60000
     try:
-        gf.set_option("screen_variant", 14)
-        assert _same(gf.screen_reads(packed, L, 31, cap=1 << 18), exp)
         gf.set_option("bitmap_log2", 27)
         for v256 in (16, 17):                      # 256 buckets, 4-byte pairs (whole-line stores / unaligned runs): the same degenerate reads overflow a workgroup's part — a full part is tested on the spot and resolved by the lane itself
             gf.set_option("screen_pf4_cap8", 0)
@@ -542,11 +588,15 @@ def test_human_scale_key_set_all_filter_kernels_agree_on_20M_reads(gf):
     packed = d_reads[:2 * n_pairs * rb].cpu().numpy().reshape(-1, rb)
     res = {}
     try:
-        for variant in (0, 17, 14, 9):
+        for variant in (0, 17, 9):
             gf.set_option("screen_variant", variant)
             res[variant] = gf.screen_reads(packed, L, k, cap=1 << 20)
+        gf.set_option("screen_variant", 0)
+        gf.set_option("screen_ext", 0)           # 16-base seeds as they are (no neighbour check in the resolve step)
+        res[14] = gf.screen_reads(packed, L, k, cap=1 << 20)
     finally:
         gf.set_option("screen_variant", 0)
+        gf.set_option("screen_ext", 1)
     assert len(res[0]) > 20_000 and _same(res[0], res[14]) and _same(res[0], res[9]) and _same(res[0], res[17])   # (0 = the 256-bucket 4-byte-pair filter, whole-line stores; 17 = unaligned runs)
     try:   # a short pair list: most pairs that are in the exact set take the serial path
         gf.set_option("screen_pf4_cap8", 1 << 16)

@@ -1,0 +1,163 @@
+"""The hot path on a REPEAT-BEARING draft (VERDICT r3 "missing 2"): every config of BASELINE.json is i.i.d. sequence, where no flank
+k-mer is shared and pools hold a few hundred reads.  Here every fourth gap sits at a copy of a repeat family shared by 200 gaps
+(0.5-5 kb, either strand), two of every four share a 2-copy repeat, one carries a low-complexity run in its flank
+(include/gf_synth.h, `repeats`): reads hit up to a hundred gaps at once (the verification's overflow path), a gap's key list
+outgrows the LDS sort, pools outgrow the workspace slices of the assembly's main launch — and nothing may be lost: screen, tagger,
+pools and contigs equal the oracle's, no error flag anywhere (the reference has no bound on a pool,
+run_multi_threads_discordant.py:209-241, and runs KMC / Velvet on whatever it holds, assemble_gaps.py:82-136)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+L, K, KV = 150, 31, 29
+N_PAIRS = 2_400_000          # 4.8 M reads = 30 x of 16 x 1.5 Mb
+
+
+@pytest.fixture(scope="module")
+def gf():
+    from gappadder_amd.hip_api import GapFill
+    g = GapFill(0)
+    yield g
+    g.close()
+
+
+@pytest.fixture(scope="module")
+def work():
+    from gappadder_amd.hip_api import GapFill
+    cfg = GapFill.synth_cfg(seed=5, scaffold_len=1_500_000, n_scaffolds=16, gaps_per_scaffold=100, gap_len=2000, repeat_period=4,
+                            repeat_copies=200)
+    ocfg = np.frombuffer(cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
+    gaps, flanks = GapFill.synth_layout(cfg)
+    ogaps, oflanks = CO.synth_layout(ocfg)
+    assert gaps.tobytes() == ogaps.astype(gaps.dtype).tobytes() and flanks == oflanks
+    packed, recs = CO.synth_pairs(ocfg, 0, N_PAIRS)
+    blob = CO.unpack_reads(packed, L)
+    return dict(cfg=cfg, ocfg=ocfg, gaps=gaps, flanks=flanks, packed=packed, recs=recs, blob=blob)
+
+
+def _same(a, b):
+    return len(a) == len(b) and a.tobytes() == np.ascontiguousarray(b).astype(a.dtype).tobytes()
+
+
+def test_device_generator_plants_the_same_repeats_as_the_oracle(gf, work):
+    import torch
+    from gappadder_amd import _lib as B
+    n = 100_000
+    rb = B.lib().gf_packed_read_bytes(L)
+    d_reads = torch.zeros(2 * n * rb, dtype=torch.uint8, device="cuda")
+    d_recs = torch.zeros(2 * n * 32, dtype=torch.uint8, device="cuda")
+    first = 1_000_000
+    gf.synth_pairs_dev(work["cfg"], first, n, d_reads.data_ptr(), d_recs.data_ptr())
+    gf.sync()
+    packed, recs = CO.synth_pairs(work["ocfg"], first, n)
+    assert d_reads.cpu().numpy().tobytes() == packed.tobytes()
+    assert d_recs.cpu().numpy().tobytes() == recs.tobytes()
+    # the flanks of the class-0 gaps (every fourth) are copies of two families, either strand: many gaps per flank k-mer
+    shared = {}
+    for g in range(0, len(work["flanks"]), 4):
+        w = work["flanks"][g][0][-60:]
+        shared[w] = shared.get(w, 0) + 1
+    assert max(shared.values()) >= 40
+    assert (recs["mapq"] == 0).mean() > 0.05        # reads inside repeat copies are reported with MAPQ 0
+
+
+def test_screen_and_tagger_on_repeats_equal_the_oracle(gf, work):
+    gf.set_gaps(work["gaps"], 16, work["flanks"])
+    exp = CO.screen_reads(work["blob"], L, work["flanks"], K)
+    per_read = np.bincount(exp["read"])
+    assert per_read.max() > 16        # reads that hit more gaps than one verification lane lists: the overflow pass
+    got = gf.screen_reads(work["packed"], L, K, cap=len(exp) + 1024)
+    assert _same(got, exp)
+    try:                              # the repeat mask: flank k-mers shared by more than 8 gaps leave the index
+        gf.set_option("max_gaps_per_kmer", 8)
+        exp8 = CO.screen_reads(work["blob"], L, work["flanks"], K, max_gaps_per_kmer=8)
+        assert len(exp8) < len(exp) // 4
+        assert _same(gf.screen_reads(work["packed"], L, K, cap=len(exp) + 1024), exp8)
+    finally:
+        gf.set_option("max_gaps_per_kmer", 0)
+    th = gf.tag_alignments(work["recs"], 300, 30)
+    assert _same(th, CO.tag_alignments(work["recs"], work["gaps"], 300, 30)) and len(th) > 10000
+
+
+def test_deep_pools_are_built_and_assembled_without_loss(gf, work):
+    """Device pipeline on the repeat workload: keys (screen hits + mates, tagger hits) -> pools -> assembly.  The class-0 gaps'
+    key lists exceed the 16 384 keys of one LDS sort and their pools the 2 000-row slices given to the assembly's main launch."""
+    import torch
+    from gappadder_amd import _lib as B
+    lib = B.lib()
+    gf.set_gaps(work["gaps"], 16, work["flanks"])
+    packed, recs = work["packed"], work["recs"]
+    n_gaps, n_reads = len(work["gaps"]), packed.shape[0]
+    hits = CO.screen_reads(work["blob"], L, work["flanks"], K)
+    th = CO.tag_alignments(recs, work["gaps"], 300, 30)
+    # expected pools: the set of (gap, read) keys, per gap ordered (mate, pair)
+    kg = np.concatenate([hits["gap"], hits["gap"], th["gap"]]).astype(np.uint64)
+    kr = np.concatenate([hits["read"], hits["read"] ^ 1, recs["read"][th["rec"]].astype(np.uint32) ^ th["to_mate"].astype(np.uint32)]).astype(np.uint64)
+    raw_per_gap = np.bincount(kg.astype(np.int64), minlength=n_gaps)
+    assert raw_per_gap.max() > 16384
+    keys = np.unique((kg << np.uint64(32)) | kr)
+    eg, er = (keys >> np.uint64(32)).astype(np.int64), (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    order = np.lexsort((er >> 1, er & 1, eg))
+    eg, er = eg[order], er[order]
+    exp_off = np.concatenate([[0], np.cumsum(np.bincount(eg, minlength=n_gaps))])
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=np.uint8).copy()).to(dev)
+    d_reads, d_recs, d_sh, d_th = t(packed), t(recs), t(hits.astype(B.HIT)), t(th.astype(B.TAGHIT))
+    cnts = torch.tensor([len(hits), len(th), 0, 0], dtype=torch.int32, device=dev)
+    key_cap = 2 * len(hits) + len(th) + 64
+    d_keys = torch.zeros(key_cap, dtype=torch.int64, device=dev)
+    d_nk = torch.zeros(4, dtype=torch.int32, device=dev)
+    pool_cap = len(keys) + 64
+    d_pool = torch.zeros(pool_cap * 38, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_gaps + 1, dtype=torch.int64, device=dev)
+    d_ids = torch.zeros(pool_cap, dtype=torch.int32, device=dev)
+    d_err = torch.zeros(4, dtype=torch.int32, device=dev)
+    h = gf.handle
+    assert lib.gf_pool_keys_reset(h, d_nk.data_ptr()) == 0
+    assert lib.gf_pool_keys_from_screen_dev(h, d_sh.data_ptr(), cnts.data_ptr(), len(hits), 1, d_keys.data_ptr(), key_cap, d_nk.data_ptr()) == 0
+    assert lib.gf_pool_keys_from_tags_dev(h, d_recs.data_ptr(), d_th.data_ptr(), cnts.data_ptr() + 4, len(th), None, 0, d_keys.data_ptr(), key_cap,
+                                          d_nk.data_ptr()) == 0
+    assert lib.gf_build_pools_dev(h, d_reads.data_ptr(), n_reads, L, d_keys.data_ptr(), d_nk.data_ptr(), key_cap, d_pool.data_ptr(), pool_cap,
+                                  d_off.data_ptr(), d_ids.data_ptr(), d_err.data_ptr()) == 0
+    gf.sync()
+    assert int(d_err[0]) == 0
+    off = d_off.cpu().numpy()
+    assert (off == exp_off).all()
+    assert (d_ids.cpu().numpy()[:len(er)].astype(np.uint32) == er).all()
+    sizes = np.diff(off)
+    assert sizes.max() > 5000 and np.median(sizes) < 1000
+    # assembly: slices of 2 000 rows for the main launch, the deep pools through the second launch
+    ccap, scap = 1 << 20, 1 << 28
+    d_ctg = torch.zeros(ccap * 32, dtype=torch.uint8, device=dev)
+    d_seq = torch.zeros(scap, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(8, dtype=torch.int32, device=dev)
+    d_gerr = torch.zeros(n_gaps, dtype=torch.int32, device=dev)
+    ks, kvs = (C.c_int * 1)(K), (C.c_int * 1)(KV)
+    gf.set_option("asm_max_pool_reads", 2000)
+    try:
+        assert lib.gf_assemble_multi_dev(h, d_pool.data_ptr(), None, d_off.data_ptr(), n_gaps, pool_cap, L, ks, kvs, 1, 2, 40, d_ctg.data_ptr(), ccap,
+                                         d_cnt.data_ptr(), d_seq.data_ptr(), scap, d_cnt.data_ptr() + 8, d_gerr.data_ptr()) == 0
+        gf.sync()
+    finally:
+        gf.set_option("asm_max_pool_reads", 0)
+    cnt = d_cnt.cpu().numpy()
+    nc, ns = int(cnt[0]), int(cnt[2:4].view(np.uint64)[0])
+    assert int(d_gerr.abs().sum()) == 0 and nc <= ccap and ns <= scap
+    ctg = np.frombuffer(d_ctg[:nc * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
+    seq = d_seq[:ns].cpu().numpy().tobytes()
+    by_gap = {}
+    for x in ctg:
+        by_gap.setdefault(int(x["gap"]), []).append((seq[int(x["seq_off"]):int(x["seq_off"]) + int(x["length"])].decode(), int(x["n_nodes"]), int(x["cov_sum"])))
+    deep = np.argsort(sizes)[-3:].tolist()
+    sample = deep + list(range(0, 48)) + [n_gaps - 1]
+    pool = d_pool.cpu().numpy().reshape(pool_cap, 38)
+    for g in sample:
+        blob = CO.unpack_reads(pool[off[g]:off[g + 1]], L)
+        exp = CO.assemble_pool(blob, L, K, KV)
+        got = sorted(by_gap.get(g, []), key=lambda c: (-len(c[0]), c[0]))
+        assert got == exp, (g, int(sizes[g]))

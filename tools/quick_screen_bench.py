@@ -1,7 +1,6 @@
 """Scratch measurement: screen filter kernel on uniform-random packed reads resident in HBM (not the bench)."""
 import ctypes as C
 import sys, os, time
-os.environ.setdefault("GF_DIAGNOSTICS", "1")   # allows the screen_np_override timing knob
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
@@ -30,7 +29,7 @@ for bl, var in itertools.product(([0] if len(sys.argv) <= 4 else [int(x) for x i
     gf.set_option("bitmap_log2", bl)
     gf.set_option("screen_lds_log2_max", int(os.environ.get("LDSMAX", "20")))
     gf.set_option("screen_variant", var % 100)
-    gf.set_option("screen_np_override", (var // 1000) - 1 if var >= 1000 else -1)
+    gf.set_option("screen_ext", int(os.environ.get("EXT", "1")))
     t = time.time()
     gf.set_gaps(gaps, int(gaps["scaffold"].max()) + 1, flanks)
     dev = torch.device("cuda:0")
