@@ -90,7 +90,7 @@ def launch_ranks(args):
     s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if torch.cuda.device_count() < args.gpus and "GF_BENCH_BACKEND" not in env:     # (device_count does not initialise the GPU)
+    if torch.cuda.device_count() < args.gpus and "GF_BENCH_BACKEND" not in env:     # (the ranks are a spawned child either way: never an exec of this process)
         env.update(GF_BENCH_BACKEND="gloo", GF_BENCH_ONE_GPU="1")
         sys.stderr.write("bench.py: %d rank(s) on %d GPU(s): ranks share cuda:0, collectives over gloo\n" % (args.gpus, torch.cuda.device_count()))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
@@ -128,8 +128,8 @@ def main():
                                                         "correct_per_s": c5.get("gaps_closed_correct_per_s"), "ms_per_step": c5["ms_per_step"]}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -142,11 +142,19 @@ def run(args):
     # GF_BENCH_BACKEND=gloo + GF_BENCH_ONE_GPU=1: the multi-rank code path with every rank on cuda:0 (single-GPU boxes, the
     # 2-rank GPU test); the real runs use nccl (= RCCL) with one GPU per rank
     backend = os.environ.get("GF_BENCH_BACKEND", "nccl")
-    if os.environ.get("GF_BENCH_ONE_GPU"):
+    one_gpu = bool(os.environ.get("GF_BENCH_ONE_GPU"))
+    if one_gpu:
         local = 0
-    if world > 1:
+    # GF_BENCH_FORCE_EXCHANGE=1: the multi-rank code path — process group, side stream, second-hop union, owner exchange, final gather —
+    # at ANY world size, world 1 included: on a one-GPU box this is how the `nccl` (= RCCL) branch of the collectives gets executed
+    multi = world > 1 or os.environ.get("GF_BENCH_FORCE_EXCHANGE") == "1"
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29655")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -187,7 +195,7 @@ def run(args):
     # (one per library: the tagger caches its coarse bin map per insert-size window)
     gf2s = [gf if serial else GapFill(local) for _ in lib_defs]
     stream = None
-    if world > 1:
+    if multi:
         # the collectives are ordered against the kernels by running everything on ONE torch side stream (not the legacy
         # default stream): the library adopts it
         stream = torch.cuda.Stream(device=dev)
@@ -272,7 +280,7 @@ def run(args):
         assert n_th <= lb.hit_cap
         th = np.frombuffer(lb.d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
         lb.row_cap = 2 * int((th["kind"] == B.KIND_DISCORDANT).sum()) + 4096
-        if world > 1:
+        if multi:
             rc_t = torch.tensor([lb.row_cap], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(rc_t, op=dist.ReduceOp.MAX)
             lb.row_cap = int(rc_t)
@@ -285,23 +293,43 @@ def run(args):
         lb.d_rows = torch.empty(lb.row_cap * 16, dtype=torch.uint8, device=dev)
         lb.d_row_gap = torch.empty(lb.row_cap, dtype=torch.int32, device=dev)
 
+    # Multi-rank runs: HIP-event spans of the parts of a step that do not shrink with the number of ranks (the union of the ranks'
+    # second-hop rows, merged on every rank) or that exist only there (the owner exchange: pack, all-gather of counts, all-to-all,
+    # merge) — `fixed_ms` of the line, for the scaling prediction of DESIGN.md §6
+    fixed_spans, fixed_on = [], [False]
+
+    def fixed_mark():
+        if not fixed_on[0]:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def fixed_span(name, e0):
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            fixed_spans.append((name, e0, e1))
+
     def hop_and_keys(lb):
         rc = lib.gf_second_hop_table_dev(lb.h2, lb.d_recs.data_ptr(), lb.d_thits.data_ptr(), lb.cp + 16, lb.hit_cap, lb.d_rows.data_ptr(),
                                          lb.d_row_gap.data_ptr(), lb.row_cap, lb.cp + 116)
         assert rc == 0, rc
-        if world == 1:
+        if not multi:
             rows_p, rowgap_p, nrows_p, rcap, hh = lb.d_rows.data_ptr(), lb.d_row_gap.data_ptr(), lb.cp + 116, lb.row_cap, lb.h2
         else:
             # the reads are sharded, the second hop is not: a MAPQ-0 record is linked to discordant mates of ANY rank's reads
             # (collect_discordant_low_mapq_reads.py reads the whole discordant_reads_pos file), so the ranks all-gather their
             # rows (fixed-size slots) and every rank sorts the union
             assert lib.gf_stream_wait(h, lb.h2) == 0
+            ev0 = fixed_mark()
             all_gather(lb.d_rows_all, lb.d_rows)
             all_gather(lb.d_rowgap_all, lb.d_row_gap)
             all_gather(lb.d_nrows_all, lb.d_cnt[29:30])
             assert lib.gf_second_hop_table_merge_dev(h, lb.d_rows_all.data_ptr(), lb.d_rowgap_all.data_ptr(), lb.d_nrows_all.data_ptr(), world,
                                                      lb.row_cap, lb.d_rows_u.data_ptr(), lb.d_rowgap_u.data_ptr(), world * lb.row_cap,
                                                      lb.d_nrows_u.data_ptr()) == 0
+            fixed_span("second_hop_union", ev0)
             rows_p, rowgap_p, nrows_p, rcap, hh = lb.d_rows_u.data_ptr(), lb.d_rowgap_u.data_ptr(), lb.d_nrows_u.data_ptr(), world * lb.row_cap, h
         rc = lib.gf_tag_low_mapq_table_dev(hh, lb.d_low.data_ptr(), lb.cp + 112, lb.hit_cap, rows_p, nrows_p, rcap, lb.d_lhits.data_ptr(),
                                            lb.hit_cap, lb.cp + 32)
@@ -330,7 +358,7 @@ def run(args):
     rows_lib = [int(lb.d_pool_off[-1]) for lb in libs]
     # largest merged pool (all libraries, all ranks): bounds the assembly's per-workgroup workspace slices
     per_gap = sum((lb.d_pool_off[1:] - lb.d_pool_off[:-1]) for lb in libs).to(coll_dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(per_gap, op=dist.ReduceOp.SUM)
     max_pool_rows = int(per_gap.max())
     # bound on the rows of one pool = the workspace slice of the assembly's main launch.  Deeper pools are not an error (they take the
@@ -350,7 +378,7 @@ def run(args):
     pool_ptr = [d_pools.data_ptr() + l * lib_cap * rb for l in range(n_lib)]
     d_xerr = torch.zeros(4, dtype=torch.int32, device=dev)
     d_libcnt = torch.zeros(n_lib * n_gaps, dtype=torch.int32, device=dev)         # [n_lib][n_gaps]
-    if world > 1:
+    if multi:
         owner = SH.gap_owner(n_gaps, world).to(dev)
         per_dst = torch.zeros(n_lib, world, dtype=torch.int64, device=dev)
         for l, lb in enumerate(libs):
@@ -369,7 +397,7 @@ def run(args):
     else:
         slot_cap = lib_cap
         merged_cap = max(4096, int(1.25 * sum(rows_lib)) + 1024)
-    need_merge = world > 1 or n_lib > 1
+    need_merge = multi or n_lib > 1
     d_merged = torch.empty(merged_cap * rb + 64, dtype=torch.uint8, device=dev) if need_merge else None
     d_moff = torch.zeros(n_gaps + 1, dtype=torch.int64, device=dev)
     contig_cap, seq_cap = (64 * n_gaps + 4096) * len(kk), (24576 * n_gaps + (1 << 20)) * len(kk)
@@ -394,7 +422,7 @@ def run(args):
         assert lib.gf_memset_dev(h, ap_ + 16, 0, 16) == 0
         if not need_merge:
             asm_ptr, asm_off, asm_rows = pool_ptr[0], libs[0].d_pool_off.data_ptr(), lib_cap
-        elif world == 1:
+        elif not multi:
             for l, lb in enumerate(libs):
                 assert lib.gf_pool_counts_dev(h, lb.d_pool_off.data_ptr(), n_gaps, d_libcnt.data_ptr() + 4 * l * n_gaps) == 0
             assert lib.gf_pools_merge_dev(h, d_pools.data_ptr(), lib_cap, d_libcnt.data_ptr(), n_lib, 1, n_gaps, L, 0, 1, batch,
@@ -410,7 +438,9 @@ def run(args):
             def merge(recv, cap, all_cnt):
                 assert lib.gf_pools_merge_dev(h, recv.data_ptr(), cap, all_cnt.data_ptr(), n_lib, world, n_gaps, L, rank, world, batch,
                                               d_merged.data_ptr(), merged_cap, d_moff.data_ptr(), d_xerr.data_ptr()) == 0
+            ev0 = fixed_mark()
             xchg.run(pack, merge)
+            fixed_span("owner_exchange", ev0)
             asm_ptr, asm_off, asm_rows = d_merged.data_ptr(), d_moff.data_ptr(), merged_cap
         rc = lib.gf_assemble_multi_dev(h, asm_ptr, None, asm_off, n_gaps, asm_rows, L, k_arr, kv_arr, len(kk), 2, 40,
                                        d_ctg.data_ptr(), contig_cap, ap_, d_seq.data_ptr(), seq_cap, ap_ + 8, d_gap_err.data_ptr())
@@ -430,7 +460,7 @@ def run(args):
     def barrier():
         sync_all()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -445,10 +475,15 @@ def run(args):
     d_astat.zero_()
     torch.cuda.synchronize()
     [g_.timing(True) for g_ in {id(x): x for x in [gf] + gf2s}.values()]
+    fixed_on[0] = multi
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    fixed_on[0] = False
+    fixed_ms = {}
+    for name, e0, e1 in fixed_spans:
+        fixed_ms[name] = fixed_ms.get(name, 0.0) + e0.elapsed_time(e1) / args.steps
     ctxs = list({id(x): x for x in [gf] + gf2s}.values())
 
     def ktime(idx):     # (total ms, launches) of one kernel group over all contexts
@@ -458,7 +493,7 @@ def run(args):
                                              ("tag_alignments", B.KERNEL_TAG), ("tag_low_mapq", B.KERNEL_LOWMAPQ),
                                              ("pools", B.KERNEL_POOL), ("assemble", B.KERNEL_ASSEMBLE), ("pick_anchored", B.KERNEL_PICK))}
     [g_.timing(False) for g_ in {id(x): x for x in [gf] + gf2s}.values()]
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -499,7 +534,7 @@ def run(args):
     truth = truth_check(cfg0, gaps, flanks, ctg, seq_host, d_best.cpu().numpy().view(np.uint64), GapFill)
     assert truth["closed"] == n_closed_local, (truth["closed"], n_closed_local)
     n_correct = truth["correct"]
-    if world > 1:
+    if multi:
         red = torch.tensor([n_closed_local, n_ctg, gaps_with_contig, asm_rows_total, n_correct], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
         n_closed, n_ctg_all, gaps_with_contig, asm_rows_total, n_correct = (int(x) for x in red)
@@ -544,13 +579,16 @@ def run(args):
                " (libraries merged in library order)" if n_lib > 1 else ""))
         out = {
             "metric": "reads_screened_per_s", "value": n_screened / step_s, "unit": "reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            # (ranks that share one GPU — the functional mode of a box with fewer GPUs than ranks — are not a scaling point: the line
+            #  reports the PHYSICAL GPUs, the ranks beside them, and no scaling claim)
+            "n_gpus": 1 if one_gpu else world, "ranks": world, "functional_mode": bool(one_gpu and world > 1),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+            "higher_is_better": True, "scaling": None if (one_gpu and world > 1) else "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": wl, "reads_total": n_screened, "reads_per_gpu": sum(lb.n_reads for lb in libs), "gaps": n_gaps,
                        "k_pairs": [list(p) for p in kk],
-                       "collectives": ("none (one rank)" if world == 1 else "RCCL (nccl backend), one GPU per rank" if backend == "nccl" else
+                       "collectives": ("none (one rank)" if not multi else "RCCL (nccl backend), one GPU per rank" if backend == "nccl" else
                                        "%s through host memory%s" % (backend, ", all ranks on cuda:0 (functional mode)" if os.environ.get("GF_BENCH_ONE_GPU") else "")),
-                       "sharding": ("single GPU: all reads and all gaps on one device" if world == 1 else
+                       "sharding": ("single GPU: all reads and all gaps on one device" if not multi else
                                     "the same reads split over the ranks (contiguous pair ranges), gaps + flank index replicated; per-gap pools "
                                     "sent to one owner rank per gap (batches of %d gaps round-robin; device pack + all-gather of counts + "
                                     "equal-slot all-to-all + device merge, no host sync), every gap assembled once by its owner from all "
@@ -592,6 +630,11 @@ def run(args):
                                    + ("; k-mer figures are rank 0's gaps x world" if world > 1 else "")}
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
+        if multi:
+            out["fixed_ms"] = dict(fixed_ms, note="per step and rank, HIP-event spans on the step's stream: second_hop_union = all-gather of the "
+                                                  "ranks' second-hop rows + their merge, the same on every rank whatever their number; owner_exchange = pack + "
+                                                  "all-gather of counts + all-to-all + merge of the per-gap pools (exists only in multi-rank runs)")
+            out["config"]["forced_exchange_at_world_1"] = world == 1
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, libs, flanks, gaps, L, kk, asm_pool_t, asm_off_t, ctg, d_seq, n_seq, d_best, step_s,
                                                n_screened, B, rb)
@@ -666,6 +709,8 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
     flags must equal the oracle's / the host picker's."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle as CO
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sample_check as SC      # the comparisons themselves live with the tests (tests/test_sample_check.py plants wrong hits, bases and picks)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # a cgroup CPU quota (cpu.max "quota period") caps the usable cores below the visible ones
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -691,11 +736,9 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
         t2 = time.perf_counter()
         n_hits, n_th = int(lb.d_cnt[0]), int(lb.d_cnt[4])
         hits = np.frombuffer(lb.d_hits[:n_hits * 8].cpu().numpy().tobytes(), dtype=B.HIT)
-        sub = np.sort(hits[hits["read"] < n_s], order=["gap", "read"])
-        ok = ok and len(sub) == len(ohits) and sub.tobytes() == ohits.astype(B.HIT).tobytes()
+        ok = ok and SC.hits_equal(hits, ohits, n_s)
         th = np.frombuffer(lb.d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
-        tsub = np.sort(th[th["rec"] < n_s], order=["rec", "gap", "kind", "to_mate"])
-        ok_tag = ok_tag and len(tsub) == len(otags) and tsub.tobytes() == np.sort(otags.astype(B.TAGHIT), order=["rec", "gap", "kind", "to_mate"]).tobytes()
+        ok_tag = ok_tag and SC.taghits_equal(th, otags, n_s)
         t_rec += max(1e-3, (t1 - t0) - t_build) + (t2 - t1)
         n_rec += n_s
         n_ohits += len(ohits)
@@ -711,34 +754,9 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
     with ThreadPoolExecutor(max_workers=cores) as ex:   # gaps are independent (assemble_gaps.py:296-299 uses a process pool)
         exp = list(ex.map(lambda g: [CO.assemble_pool(pblob[int(pool_off[g]) * L:int(pool_off[g + 1]) * L], L, k, kv) for k, kv in kk], range(n_g)))
     t4 = time.perf_counter()
-    ok_asm, ok_pick = True, True
     best = d_best.cpu().numpy().view(np.uint64)
-    from oracle import gp_oracle as PO
-    for g in range(n_g):
-        want, idx = [], []
-        for (k, kv), e in zip(kk, exp[g]):
-            rows = np.nonzero((ctg["gap"] == g) & (ctg["k"] == k))[0]
-            mine = sorted((seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode(), int(c["n_nodes"]), int(c["cov_sum"]))
-                          for c in ctg[rows])
-            ok_asm = ok_asm and mine == sorted(e)
-            # the picker sees the gap's contigs in the order the device listed them (ties between equal spans go to the earlier contig)
-            for i in rows:
-                want.append(("c%d" % i, seq[int(ctg[i]["seq_off"]):int(ctg[i]["seq_off"]) + int(ctg[i]["length"])].decode()))
-                idx.append(int(i))
-        # oracle/gp_oracle.py::pick_gap = the reference's selection (pick_contigs.py:97-358, pinned on its own answers) on the exact-anchor
-        # stand-in's hits; scores 30 then 15 (assemble_gaps.py:336, 365)
-        order = sorted(range(len(idx)), key=lambda i: idx[i])
-        want, idx = [want[i] for i in order], [idx[i] for i in order]
-        exp_word = 0
-        for a_len in (30, 15):
-            seqs, ctgs_txt = PO.pick_gap("0_1", want, flanks[g][0], flanks[g][1], a_len)
-            if seqs:
-                hdr, body = seqs.split("\n")[:2]
-                ci = idx[[n for n, _ in want].index(hdr[len(">0_1_"):])]
-                rev = int(ctgs_txt.split("\n")[1] != dict(want)["c%d" % ci])
-                exp_word = (a_len << 56) | (len(body) << 32) | ((0x7FFFFFFF - ci) << 1) | rev
-                break
-        ok_pick = ok_pick and exp_word == int(best[g])
+    ok_asm = SC.contigs_equal(ctg, seq, exp, kk, n_g)
+    ok_pick = SC.picks_equal(ctg, seq, best, flanks, kk, n_g)
     # whole-step CPU time extrapolated from the two samples (recruit scales with reads, assembly with gaps)
     cpu_step = t_build + t_rec * (n_screened / n_rec) + (t4 - t3) * (len(gaps) / n_g)
     return {"value": n_screened / cpu_step, "unit": "reads/s", "cores": cores, "kind": "port",

@@ -1275,6 +1275,7 @@ struct VerifyParams {
     const uint32_t* foff;
     uint32_t* overflow;      // counter: candidates whose (position, gap) list exceeded list_cap
     uint32_t* overflow_list; // their read ids (re-verified by a second launch with a large list), or null
+    uint32_t vlist;          // seed-and-extend kernel: gap entries per candidate (VEXT_LIST / VEXT_LIST_BIG)
 };
 
 __device__ __forceinline__ uint32_t packed_word(const VerifyParams& P, uint64_t w) {
@@ -1556,9 +1557,12 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
 // the diagonal by XOR of 16-base words against the 2-bit packed flanks (0.15 MB at C2: L2/L1 resident):
 //   hit(gap)  <=>  some seed/occurrence of that gap has  left_ext + 16 + right_ext >= k,
 // extensions capped by k - 16, the read ends, the nearest read N, and the flank's room inside its ACGT run.
-// Palindromic 16-mers are tried on both strands.  Candidates that collect more than VEXT_LIST gap entries go to the table
-// kernel through the overflow list.
-constexpr uint32_t VEXT_LIST = 16;
+// Palindromic 16-mers are tried on both strands.  A candidate lists its gaps in LDS: VEXT_LIST entries in the first pass (64
+// candidates per wave); the reads that hit more gaps than that — reads inside a repeat shared by many flanks — go through the
+// overflow list to a second launch of this kernel with VEXT_LIST_BIG entries and a few candidates per wave, and only what outgrows
+// that as well to the table kernel.  (Round 3 sent every overflow straight to the table kernel: on the planted-repeat workload,
+// where 0.5 M reads hit 30-50 gaps each, that pass took 460 ms of a 475-ms step.)
+constexpr uint32_t VEXT_LIST = 16, VEXT_LIST_BIG = 1024, VEXT_BATCH_BIG = 8;
 
 
 __device__ __forceinline__ uint32_t fl32(const uint32_t* words, uint32_t base) {   // 16 bases from base offset `base`, MSB-first words
@@ -1607,7 +1611,7 @@ __device__ __forceinline__ bool ext_hit(const uint32_t* row, uint32_t qs, const 
 }
 
 __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
-    extern __shared__ uint32_t sm[];   // rows [64][rwp] | nmask [64][nmw] | slots [64][np] | lists [64][VEXT_LIST] | cnt [64]
+    extern __shared__ uint32_t sm[];   // rows [64][rwp] | nmask [64][nmw] | slots [64][np] | cnt [64] | lists [batch][vlist]
     constexpr uint32_t OBUF = 128;
     __shared__ gf_hit obuf[OBUF];
     __shared__ uint32_t obuf_n;
@@ -1618,8 +1622,9 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
     uint32_t* rows = sm;
     uint32_t* nmr = rows + 64 * rwp;
     uint32_t* slots = nmr + 64 * nmw;
-    uint32_t* lists = slots + 64 * P.np;
-    uint32_t* cnt = lists + 64 * VEXT_LIST;
+    uint32_t* cnt = slots + 64 * P.np;
+    uint32_t* lists = cnt + 64;
+    const uint32_t VL = P.vlist;
     const uint32_t n_cand = *P.n_cand;
     const uint32_t W = P.k - 16;
     const uint32_t bsz = P.batch;
@@ -1711,13 +1716,13 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
                 }
                 if (hit) {
                     const uint32_t g = fid >> 1;
-                    uint32_t* lj = lists + j * VEXT_LIST;
-                    const uint32_t have = cnt[j] < VEXT_LIST ? cnt[j] : VEXT_LIST;
+                    uint32_t* lj = lists + j * VL;
+                    const uint32_t have = cnt[j] < VL ? cnt[j] : VL;
                     bool dup = false;
                     for (uint32_t e = 0; e < have; ++e) dup = dup || lj[e] == g;
                     if (!dup) {
                         const uint32_t e = atomicAdd(&cnt[j], 1u);
-                        if (e < VEXT_LIST) lj[e] = g;
+                        if (e < VL) lj[e] = g;
                     }
                 }
                 if ((info >> 17) & 1u) break;
@@ -1728,7 +1733,7 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
         // per candidate: distinct gaps -> hits (a list that ran over goes to the table kernel)
         {
             const uint32_t n = lane < nb ? cnt[lane] : 0;
-            const bool over = n > VEXT_LIST;
+            const bool over = n > VL;
             const unsigned long long ob = __ballot(over);
             if (ob) {
                 uint32_t base = 0;
@@ -1736,8 +1741,8 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
                 base = __shfl(base, 0);
                 if (over && P.overflow_list) P.overflow_list[base + __popcll(ob & ((1ull << lane) - 1))] = my_r;
             }
-            const uint32_t* lj = lists + lane * VEXT_LIST;
-            for (uint32_t d = 0; d < VEXT_LIST; ++d) {
+            const uint32_t* lj = lists + (lane < nb ? lane : 0) * VL;
+            for (uint32_t d = 0; d < VL; ++d) {
                 bool emit = !over && d < n;
                 uint32_t g = 0;
                 if (emit) {
@@ -1979,21 +1984,41 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.overflow = d_cnt + 2;
     V.overflow_list = (uint32_t*)ctx->cand2.p;
     V.sval = ix.d_sval; V.occ = ix.d_occ; V.fpk = ix.d_fpk; V.foff = ix.d_foff;
-    if (ctx->screen_verify_ext && V.min_hits == 1 && ix.max_gaps_per_kmer == 0 && ix.ext_ok && V.np >= 1 && V.np <= 32) {
+    V.vlist = VEXT_LIST;
+    const bool use_ext = ctx->screen_verify_ext && V.min_hits == 1 && ix.max_gaps_per_kmer == 0 && ix.ext_ok && V.np >= 1 && V.np <= 32;
+    if (use_ext) {
         // seed-and-extend kernel instead of the k-mer table (same hits; see screen_verify_ext_kernel)
         const size_t rwp = (rb + 24) / 4 + 1 + 4, nmw = d_nmask ? V.nmw : 0;
-        const size_t lds2 = 64 * (rwp + nmw + V.np + VEXT_LIST + 1) * 4;
-        LaunchTimer tm(ctx, GF_KERNEL_VERIFY);
-        hipLaunchKernelGGL(screen_verify_ext_kernel, dim3(grid2), dim3(64), lds2, ctx->stream, V);
+        {
+            const size_t lds2 = (64 * (rwp + nmw + V.np + 1) + (size_t)V.batch * V.vlist) * 4;
+            LaunchTimer tm(ctx, GF_KERNEL_VERIFY);
+            hipLaunchKernelGGL(screen_verify_ext_kernel, dim3(grid2), dim3(64), lds2, ctx->stream, V);
+        }
+        // pass 2: the reads that hit more than VEXT_LIST gaps (repeats shared by many flanks), a few per wave with a long list each;
+        // what outgrows that too is queued for the table kernel (the old candidate list is free by now)
+        V.cand = (const uint32_t*)ctx->cand2.p;
+        V.n_cand = d_cnt + 2;
+        V.overflow = d_cnt + 3;
+        V.overflow_list = (uint32_t*)ctx->cand.p;
+        V.vlist = VEXT_LIST_BIG;
+        V.batch = VEXT_BATCH_BIG;
+        {
+            const size_t lds2 = (64 * (rwp + nmw + V.np + 1) + (size_t)V.batch * V.vlist) * 4;
+            LaunchTimer tm(ctx, GF_KERNEL_VERIFY);
+            hipLaunchKernelGGL(screen_verify_ext_kernel, dim3(grid2), dim3(64), lds2, ctx->stream, V);
+        }
+        V.cand = (const uint32_t*)ctx->cand.p;
+        V.n_cand = d_cnt + 3;
+        V.batch = (uint32_t)std::min(64, std::max(1, ctx->screen_verify_batch));
     } else {
         launch_verify(V);
+        V.cand = (const uint32_t*)ctx->cand2.p;
+        V.n_cand = d_cnt + 2;
     }
     GF_HIP(ctx, hipGetLastError());
-    // pass 2: the queued reads with a list as large as LDS allows; overflowing that is an error (d_cnt[1])
+    // last pass: the queued reads through the k-mer table with a list as large as LDS allows; overflowing that is an error (d_cnt[1])
     size_t want = ix.max_gaps_per_kmer ? (size_t)npos * ix.max_gaps_per_kmer : 15000;
     V.list_cap = (uint32_t)std::min<size_t>(std::max<size_t>(want, 1024), 15000);
-    V.cand = (const uint32_t*)ctx->cand2.p;
-    V.n_cand = d_cnt + 2;
     V.overflow = d_cnt + 1;
     V.overflow_list = nullptr;
     launch_verify(V);

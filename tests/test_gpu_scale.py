@@ -309,8 +309,27 @@ def test_two_rank_owner_assembly_equals_the_single_process_run(tmp_path, config,
     assert ja["contigs"] == jb["contigs"] and len(ja["contigs"]) > 100
     assert ja["gaps_closed"] == jb["gaps_closed"]
     assert a["counts"]["gaps_closed_correct"] == b["counts"]["gaps_closed_correct"] <= a["counts"]["gaps_closed"]   # every closed gap of both runs went through the truth check
-    assert a["counts"]["assembled_pool_reads"] == b["counts"]["assembled_pool_reads"] and b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert a["counts"]["assembled_pool_reads"] == b["counts"]["assembled_pool_reads"]
+    assert b["ranks"] == 2 and b["n_gpus"] == 1 and b["functional_mode"] and b["scaling"] is None      # two ranks on ONE GPU are not a scaling point
+    assert b["fixed_ms"]["second_hop_union"] > 0 and b["fixed_ms"]["owner_exchange"] > 0
     assert abs(a["gaps_per_s"] * a["ms_per_step"] - b["gaps_per_s"] * b["ms_per_step"]) < 1e-3 * a["gaps_per_s"] * a["ms_per_step"]   # same gaps, counted once
+
+
+@pytest.mark.parametrize("config,extra", [("C2", ["--reads", "6000000"]), ("C5", ["--reads", "4000000", "--mp-reads", "2000000"])])
+def test_rccl_branch_runs_at_world_one_and_changes_nothing(tmp_path, config, extra):
+    """A one-GPU box cannot run two RCCL ranks, but it can run ONE: GF_BENCH_FORCE_EXCHANGE=1 takes the multi-rank code path — process
+    group on the `nccl` backend (= RCCL), side stream, all-gather of the second-hop rows + their merge, OwnerExchange (device pack,
+    all_gather_into_tensor of the counts, all_to_all_single of the slots, device merge), all-reduces of the results, final gather —
+    with world size 1, on device tensors.  Same contigs, pools and closed gaps as the plain single-process run."""
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    argv = ["--config", config, "--steps", "2", "--warmup", "0", "--no-cpu", "--no-extras"] + extra
+    a = _bench(argv + ["--dump-contigs", one])
+    b = _bench(argv + ["--dump-contigs", two], env_extra={"GF_BENCH_FORCE_EXCHANGE": "1", "GF_BENCH_BACKEND": "nccl", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29633"})
+    ja, jb = json.load(open(one)), json.load(open(two))
+    assert ja["contigs"] == jb["contigs"] and len(ja["contigs"]) > 100 and ja["gaps_closed"] == jb["gaps_closed"]
+    assert a["counts"] == b["counts"]
+    assert "RCCL" in b["config"]["collectives"] and b["config"]["forced_exchange_at_world_1"] and b["n_gpus"] == 1
+    assert b["fixed_ms"]["second_hop_union"] > 0 and b["fixed_ms"]["owner_exchange"] > 0 and b["final_gather_ms"] >= 0
 
 
 def test_bench_launches_its_own_ranks_from_a_bare_shell(tmp_path):
@@ -324,7 +343,7 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell(tmp_path):
                        stderr=subprocess.PIPE, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     b = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert b["n_gpus"] == 2 and "gloo" in b["config"]["collectives"] and "ranks share cuda:0" in r.stderr.decode()
+    assert b["ranks"] == 2 and b["n_gpus"] == 1 and b["functional_mode"] and "gloo" in b["config"]["collectives"] and "ranks share cuda:0" in r.stderr.decode()
     assert json.load(open(one))["contigs"] == json.load(open(two))["contigs"]
     assert a["counts"]["assembled_pool_reads"] == b["counts"]["assembled_pool_reads"]
 
