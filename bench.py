@@ -159,6 +159,10 @@ def run(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        dist.barrier()
+        # RCCL prints a version banner through C stdio when its first communicator comes up; stdout being a pipe, it would sit in
+        # the C buffer until exit and land BEHIND rank 0's JSON line: flush it out now
+        C.CDLL(None).fflush(None)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -534,6 +538,9 @@ def run(args):
     truth = truth_check(cfg0, gaps, flanks, ctg, seq_host, d_best.cpu().numpy().view(np.uint64), GapFill)
     assert truth["closed"] == n_closed_local, (truth["closed"], n_closed_local)
     n_correct = truth["correct"]
+    census = None
+    if not multi and n_closed_local:      # (runs that close gaps at all: with the 300-bp library alone every 2-kb gap is a coverage hole)
+        census = open_gap_census(cfg0, gaps, ctg, seq_host, d_best.cpu().numpy().view(np.uint64), GapFill)
     if multi:
         red = torch.tensor([n_closed_local, n_ctg, gaps_with_contig, asm_rows_total, n_correct], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
@@ -602,7 +609,7 @@ def run(args):
                                    "read ids recovered from positions — on key sets beyond an L2 as at C4/C5; the software-pipelined "
                                    "screen_filter_pipe_kernel otherwise, as at C2)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.config, int(reads_per_launch), L, k_s),
+                         "traffic": pmc_traffic(args.config, int(reads_per_launch), L, k_s, filt_ms, lib.gf_screen_kernels(h).decode()),
                          "algorithmic_bytes_per_launch": int(reads_per_launch * rb), "avg_launch_ms": filt_ms,
                          "frac_of_measured_copy_6290": achieved / 6290.0},
             "phases_ms": phases,
@@ -628,6 +635,8 @@ def run(args):
                            "achieved_GBps": asm_bytes / (asm_ms * 1e-3) / 1e9 if asm_ms else None,
                            "note": "per step; k-mers seen fewer than min_count times are stopped by the bit-array pre-count and never counted exactly"
                                    + ("; k-mer figures are rank 0's gaps x world" if world > 1 else "")}
+        if census is not None:
+            out["open_gap_census"] = census
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
         if multi:
@@ -673,6 +682,57 @@ def truth_check(cfg, gaps, flanks, ctg, seq, best, GapFill):
     return {"closed": closed, "correct": correct, "wrong": wrong, "causes": causes}
 
 
+def open_gap_census(cfg, gaps, ctg, seq, best, GapFill, max_gaps=256, W=25):
+    """Why is a gap still open?  For (a sample of) the gaps without a pick: the true sequence of the gap and its flank ends
+    (gf_synth_truth) is cut into W-mers, and every W-mer is looked up in the gap's contigs (either strand):
+      no_contigs                 the assembly emitted nothing for the gap
+      spanning_contig_unpicked   one contig holds every W-mer from the left anchor to the right anchor — the picker should have closed it
+      anchor_differs             one contig holds every W-mer of the gap proper but not of a 30-base anchor: the contig's copy of the
+                                 flank end differs from the draft's (what `bwa mem -T 30` tolerates and the exact anchors do not)
+      coverage_hole              some true W-mers are in no contig at all (a stretch no k-mer survived min-count / error removal for)
+      fragmented                 every true W-mer is in some contig, but no single contig carries them all (an unresolved branch)
+    The reference has no such tool (its evaluation compares picked sequences, validate_gap_seqs.py:5-75); this is the census
+    VERDICT r3 (next 7) asks for before an alignment-grade anchor is worth building."""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    open_gaps = np.nonzero(best == 0)[0]
+    n_open = len(open_gaps)
+    if n_open > max_gaps:
+        open_gaps = open_gaps[np.linspace(0, n_open - 1, max_gaps).astype(np.int64)]
+    order = np.argsort(ctg["gap"], kind="stable")
+    gsorted = ctg["gap"][order]
+    out = {"no_contigs": 0, "spanning_contig_unpicked": 0, "anchor_differs": 0, "coverage_hole": 0, "fragmented": 0}
+    hole_sizes = []
+    fl = int(cfg["flank_len"][0])
+    for g in open_gaps:
+        st, en, sc = int(gaps[g]["start"]), int(gaps[g]["end"]), int(gaps[g]["scaffold"])
+        T = GapFill.synth_truth(cfg, sc, st - fl, en - st + 2 * fl).encode()
+        lo, hi = np.searchsorted(gsorted, g), np.searchsorted(gsorted, g, side="right")
+        sets = []
+        for i in order[lo:hi]:
+            c = seq[int(ctg[i]["seq_off"]):int(ctg[i]["seq_off"]) + int(ctg[i]["length"])]
+            for s_ in (c, c.translate(comp)[::-1]):
+                sets.append({s_[j:j + W] for j in range(len(s_) - W + 1)})
+        if not sets:
+            out["no_contigs"] += 1
+            continue
+        a0, a1 = fl - 5 - 30, fl + (en - st) + 5 + 30            # [left anchor start, right anchor end)
+        i0, i1 = fl - 5, fl + (en - st) + 5                      # the gap proper + the 5 bases either side the flanks leave out
+        ps = range(a0, a1 - W + 1)
+        cover = [[T[p:p + W] in s_ for s_ in sets] for p in ps]
+        if any(all(cover[j][c_] for j in range(len(ps))) for c_ in range(len(sets))):
+            out["spanning_contig_unpicked"] += 1
+        elif any(all(cover[j][c_] for j, p in enumerate(ps) if i0 <= p and p + W <= i1) for c_ in range(len(sets))):
+            out["anchor_differs"] += 1
+        elif not all(any(row) for row in cover):
+            out["coverage_hole"] += 1
+            hole_sizes.append(sum(1 for row in cover if not any(row)))
+        else:
+            out["fragmented"] += 1
+    out.update(open_gaps=int(n_open), classified=int(len(open_gaps)), word=W,
+               median_uncovered_words_in_a_hole=(int(np.median(hole_sizes)) if hole_sizes else None))
+    return out
+
+
 def child_run(argv):
     """The same step on another BASELINE.json configuration, measured by the same code in a child process (never an exec of a
     process that has touched the GPU)."""
@@ -683,20 +743,34 @@ def child_run(argv):
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
         return {key: d[key] for key in ("value", "ms_per_step", "steps", "warmup", "gaps_per_s", "gaps_closed_per_s", "gaps_closed_correct_per_s",
                                         "phases_ms", "counts", "closed_truth_check", "assembly")} | \
+               ({"open_gap_census": d["open_gap_census"]} if "open_gap_census" in d else {}) | \
                {"workload": d["config"]["workload"], "roofline_frac": d["roofline"]["frac"], "filter_ms": d["roofline"]["avg_launch_ms"]}
     except Exception as e:      # the headline line must not depend on an extra
         return {"error": repr(e)[:300], "stderr_tail": (r.stderr.decode()[-400:] if r is not None else "")}
 
 
-def pmc_traffic(config, reads_per_launch, L, k):
-    """Bytes per launch of the dominant kernel from the committed PMC passes (profiles/r03_traffic_<config>.json: rocprofv3 --pmc
-    FETCH_SIZE and WRITE_SIZE in separate runs of this same command, gfx950 x2 correction applied to FETCH_SIZE).  Counters
-    cannot be collected from inside the timed run; null when no committed profile matches this configuration."""
-    for name in ("r03_traffic_%s.json" % config.lower(), "r02_traffic_%s.json" % config.lower()):
+def pmc_traffic(config, reads_per_launch, L, k, launch_ms, launched):
+    """Bytes per launch of the dominant kernel group from the committed PMC passes (profiles/rNN_traffic_<config>.json, newest round
+    first: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this same command, gfx950 x2 correction applied to FETCH_SIZE).
+    Counters cannot be collected from inside the timed run, so the file must be shown to describe THIS build: same workload, the filter's
+    kernels under exactly the names this build launched (gf_screen_kernels), and their rocprof launch times within 15 % of the launch
+    time measured in this run —
+    otherwise null (a kernel change without a re-profile must not leave a stale ratio in the line)."""
+    import glob
+    want = [w for w in launched.split(",") if w]      # gf_screen_kernels: what this build launched for the filter, template arguments included
+    if not want:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % config.lower())), reverse=True):
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if t["reads_per_launch"] == reads_per_launch and t["read_len"] == L and t["k"] == k:
-                return t["traffic_bytes_per_launch"]
+            t = json.load(open(path))
+            names = list(t["kernels"])
+            if t["reads_per_launch"] != reads_per_launch or t["read_len"] != L or t["k"] != k:
+                continue
+            if not all(any(w in n for n in names) for w in want) or not all(any(w in n for w in want) for n in names):
+                continue
+            if abs(t["rocprof_avg_launch_ns_sum"] * 1e-6 - launch_ms) > 0.15 * launch_ms:
+                continue
+            return t["traffic_bytes_per_launch"]
         except Exception:
             pass
     return None

@@ -156,6 +156,7 @@ void gf_destroy(gf_ctx* ctx) {
 }
 
 const char* gf_last_error(gf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char* gf_screen_kernels(gf_ctx* ctx) { return ctx ? ctx->screen_kernels.c_str() : ""; }
 
 int gf_set_stream(gf_ctx* ctx, void* s) {
     if (!ctx) return GF_E_INVAL;

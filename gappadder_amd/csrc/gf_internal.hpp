@@ -73,6 +73,7 @@ struct gf_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string last_error;
+    std::string screen_kernels;   // the filter kernels the last gf_screen_reads[_dev] launched (gf_screen_kernels)
     gf_ctx* after_filter = nullptr;   // one-shot: this context's stream waits for the end of the next filter pass of the owner (gf_stream_wait_after_filter)
     int n_cu = 256;
 

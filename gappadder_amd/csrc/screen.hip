@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
 // overflow list to a second launch of this kernel with VEXT_LIST_BIG entries and a few candidates per wave, and only what outgrows
 // that as well to the table kernel.  (Round 3 sent every overflow straight to the table kernel: on the planted-repeat workload,
 // where 0.5 M reads hit 30-50 gaps each, that pass took 460 ms of a 475-ms step.)
-constexpr uint32_t VEXT_LIST = 16, VEXT_LIST_BIG = 1024, VEXT_BATCH_BIG = 8;
+constexpr uint32_t VEXT_LIST = 16, VEXT_LIST_BIG = 256, VEXT_BATCH_BIG = 8;   // (8 x 256 slots = 8 KiB per wave: a dozen waves per CU; the long list is a hash SET of gaps, full at 192)
 
 
 __device__ __forceinline__ uint32_t fl32(const uint32_t* words, uint32_t base) {   // 16 bases from base offset `base`, MSB-first words
@@ -1625,6 +1625,7 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
     uint32_t* cnt = slots + 64 * P.np;
     uint32_t* lists = cnt + 64;
     const uint32_t VL = P.vlist;
+    const bool SET = VL > VEXT_LIST;   // (then a power of two)
     const uint32_t n_cand = *P.n_cand;
     const uint32_t W = P.k - 16;
     const uint32_t bsz = P.batch;
@@ -1638,6 +1639,7 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
             stage_read(P, row + 4, rw, my_r, lane < nb);
             for (uint32_t i = 0; i < nmw; ++i) nmr[lane * nmw + i] = lane < nb ? P.nmask[(uint64_t)my_r * P.nmw + i] : 0;
             cnt[lane] = 0;
+            if (SET) for (uint32_t i = lane; i < bsz * VL; i += 64) lists[i] = EMPTY32;
         }
         __syncthreads();
         // exact-set lookup of every aligned 16-mer of my candidate: slot of the match, or EMPTY32
@@ -1717,12 +1719,23 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
                 if (hit) {
                     const uint32_t g = fid >> 1;
                     uint32_t* lj = lists + j * VL;
-                    const uint32_t have = cnt[j] < VL ? cnt[j] : VL;
-                    bool dup = false;
-                    for (uint32_t e = 0; e < have; ++e) dup = dup || lj[e] == g;
-                    if (!dup) {
-                        const uint32_t e = atomicAdd(&cnt[j], 1u);
-                        if (e < VL) lj[e] = g;
+                    if (SET) {   // long list = a hash set of the gaps (one CAS claims a slot: the seeds of one candidate, worked on by several lanes, cannot list a gap twice)
+                        uint32_t hs = (g * 0x9E3779B1u) & (VL - 1);
+                        for (uint32_t pr = 0;; ++pr) {
+                            if (pr == VL) { cnt[j] = VL + 1; break; }
+                            const uint32_t old = atomicCAS(&lj[hs], EMPTY32, g);
+                            if (old == EMPTY32) { atomicAdd(&cnt[j], 1u); break; }
+                            if (old == g) break;
+                            hs = (hs + 1) & (VL - 1);
+                        }
+                    } else {
+                        const uint32_t have = cnt[j] < VL ? cnt[j] : VL;
+                        bool dup = false;
+                        for (uint32_t e = 0; e < have; ++e) dup = dup || lj[e] == g;
+                        if (!dup) {
+                            const uint32_t e = atomicAdd(&cnt[j], 1u);
+                            if (e < VL) lj[e] = g;
+                        }
                     }
                 }
                 if ((info >> 17) & 1u) break;
@@ -1733,7 +1746,7 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
         // per candidate: distinct gaps -> hits (a list that ran over goes to the table kernel)
         {
             const uint32_t n = lane < nb ? cnt[lane] : 0;
-            const bool over = n > VL;
+            const bool over = SET ? n > VL - VL / 4 : n > VL;
             const unsigned long long ob = __ballot(over);
             if (ob) {
                 uint32_t base = 0;
@@ -1743,14 +1756,15 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
             }
             const uint32_t* lj = lists + (lane < nb ? lane : 0) * VL;
             for (uint32_t d = 0; d < VL; ++d) {
-                bool emit = !over && d < n;
+                bool emit = !over && (SET ? n > 0 : d < n);
                 uint32_t g = 0;
                 if (emit) {
                     g = lj[d];
-                    for (uint32_t e = 0; e < d; ++e) emit = emit && lj[e] != g;
+                    if (SET) emit = g != EMPTY32;
+                    else for (uint32_t e = 0; e < d; ++e) emit = emit && lj[e] != g;
                 }
                 const unsigned long long bal = __ballot(emit);
-                if (!bal) { if (!__any(d + 1 < n && !over)) break; else continue; }
+                if (!bal) { if (!SET && !__any(d + 1 < n && !over)) break; else continue; }
                 const uint32_t base = obuf_n;
                 if (emit) obuf[base + __popcll(bal & ((1ull << lane) - 1))] = gf_hit{g, my_r};
                 __syncthreads();
@@ -1866,6 +1880,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
 #undef GF_PKX
 #undef GF_PKN
 #undef GF_PK
+        ctx->screen_kernels = "screen_filter_pipe_kernel<" + std::to_string(nch) + ", " + std::to_string(npt) + ", " + ((int)F.np == npt || npt > 5 ? "true" : "false") + ">";
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(wk, dim3((unsigned)std::min<size_t>((tiles64 + nw - 1) / nw, ctx->n_cu)), dim3((unsigned)(nw * 64)),
                            w_bm_bytes + nw * w_per_wave, ctx->stream, F, (uint32_t)w_slice_words);
@@ -1910,6 +1925,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.chunk_b = (uint8_t*)(ws + b_cnt + b_seen + b_fill + (size_t)Q.cap8 * 12);
         Q.pairs = (uint32_t*)(ws + b_cnt + b_seen + b_fill + b_c8);
         GF_HIP(ctx, hipMemsetAsync(ws + b_cnt - 256, 0, 256 + b_seen, ctx->stream));
+        ctx->screen_kernels = std::string(lines ? "pf4_scatter_lines_kernel<" : "pf4_scatter_kernel<") + std::to_string(grp) + "u, " +
+                              (((F.first2 & 7u) == 0 && (F.stride2 & 7u) == 0) ? "true" : "false") + ">,pf4_probe_kernel,pf4_resolve_kernel,pf4_list_kernel";
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         if (lines) {
             const bool bytes = (F.first2 & 7u) == 0 && (F.stride2 & 7u) == 0;
@@ -1932,6 +1949,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     } else {
         const size_t n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
         const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->n_cu * 8);
+        ctx->screen_kernels = "screen_filter_kernel<9>";
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         hipLaunchKernelGGL(screen_filter_kernel<9>, dim3(grid), dim3(256), TILE_READS * rb + 16, ctx->stream, F);
     }

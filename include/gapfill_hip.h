@@ -88,6 +88,10 @@ int gf_init(int device_ordinal, gf_ctx** out);
 void gf_destroy(gf_ctx* ctx);
 const char* gf_strerror(int code);
 const char* gf_last_error(gf_ctx* ctx);       /* text of the last HIP error seen by this ctx */
+/* the filter kernels the last gf_screen_reads[_dev] call launched, comma separated, as a profiler names them without namespace and
+ * argument list (e.g. "pf4_scatter_lines_kernel<3u, false>,pf4_probe_kernel,pf4_resolve_kernel,pf4_list_kernel"): lets a caller
+ * tie a committed rocprofv3 summary to the build that is running */
+const char* gf_screen_kernels(gf_ctx* ctx);
 int gf_set_stream(gf_ctx* ctx, void* hip_stream); /* adopt a caller's hipStream_t (NULL: back to the ctx's own) */
 int gf_sync(gf_ctx* ctx);
 /* Two contexts on one device run their work on two streams (e.g. the k-mer screen on one, the alignment tagger on the

@@ -294,7 +294,7 @@ def _bench(argv, env_extra=None, timeout=1500, nproc=1):
                "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + argv
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    return json.loads(r.stdout.decode().strip().splitlines()[-1])
+    return json.loads([l for l in r.stdout.decode().strip().splitlines() if l.startswith("{")][-1])
 
 
 @pytest.mark.parametrize("config,extra", [("C2", ["--reads", "6000000"]), ("C5", ["--reads", "4000000", "--mp-reads", "2000000"])])

@@ -361,3 +361,36 @@ def test_high_quality_reads_that_bridge_two_contigs_are_appended(tmp_path):
     got = read_fasta(wf + "velvet_temp/0_1/contigs.fa")
     assert got == [("o1", c1), ("o2", c2), ("o3", c3), ("bridge", g[350:500]), ("bridge_rc", revcomp(g[360:510]))]
     assert not os.path.exists(wf + "velvet_temp/0_1/original_contigs_before_merging.fa")
+
+
+def test_open_gap_census_tells_the_causes_apart():
+    """bench.py::open_gap_census on hand-built contig sets: a spanning contig, a contig whose copy of an anchor differs, a hole in the
+    coverage, two contigs that overlap without being joined, and a gap without contigs each land in their own class."""
+    import numpy as np
+    import bench
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    from gappadder_amd.pick_contigs import revcomp
+    cfg = GapFill.synth_cfg(seed=78, scaffold_len=200_000, n_scaffolds=1, gaps_per_scaffold=6, gap_len=500)
+    gaps, _ = GapFill.synth_layout(cfg)
+    sets = []
+    for g in range(6):
+        st, en = int(gaps[g]["start"]), int(gaps[g]["end"])
+        t = GapFill.synth_truth(cfg, 0, st - 100, en - st + 200)        # t[100] = first gap base; anchors t[65:95], t[605:635]
+        if g == 0: sets.append([revcomp(t)])                            # everything on one contig (reverse strand)
+        if g == 1: sets.append([t[:80] + ("A" if t[80] != "A" else "C") + t[81:]])        # a substitution inside the left anchor
+        if g == 2: sets.append([t[:330], t[370:]])                      # 40 true bases in no contig
+        if g == 3: sets.append([t[:400], t[340:]])                      # overlapping halves, never joined
+        if g == 4: sets.append([])
+        if g == 5: sets.append([t])                                     # closed: not part of the census
+    flat = [(g, s) for g, cs in enumerate(sets) for s in cs]
+    ctg = np.zeros(len(flat), dtype=B.CONTIG)
+    off = 0
+    for i, (g, s) in enumerate(flat):
+        ctg[i] = (g, 31, 29, len(s) - 28, len(s), 0, 0, off)
+        off += len(s)
+    best = np.zeros(6, dtype=np.uint64)
+    best[5] = 1
+    r = bench.open_gap_census(cfg, gaps, ctg, "".join(s for _, s in flat).encode(), best, GapFill)
+    assert r["open_gaps"] == 5 and r["classified"] == 5
+    assert (r["spanning_contig_unpicked"], r["anchor_differs"], r["coverage_hole"], r["fragmented"], r["no_contigs"]) == (1, 1, 1, 1, 1), r
