@@ -250,8 +250,12 @@ def merge_contigs(gf, working_folder, id_list, kmer_len_quick=10, params=None):
         nodup = drop_contained(r) if len(r) <= MAX_SET else r
         _write_fasta(folder + "contigs.fa_no_dup.fa", nodup)
         if os.path.getsize(folder + "contigs.fa_no_dup.fa") > 1000000 or len(nodup) > MAX_SET:      # MergeContigs.py:70-74
-            os.replace(folder + "contigs.fa", folder + "original_contigs_before_merging.fa")
-            os.replace(folder + "contigs.fa_no_dup.fa", folder + "contigs.fa")
+            try:
+                os.replace(folder + "contigs.fa", folder + "original_contigs_before_merging.fa")
+                os.replace(folder + "contigs.fa_no_dup.fa", folder + "contigs.fa")
+            except OSError as e:
+                import sys
+                sys.stderr.write("contig merging: gap %s keeps its contigs (%r)\n" % (gid, e))
             done[gid] = 0
             continue
         work.append((gid, folder, nodup, [(n, s.upper()) for n, s in nodup if MIN_NODE <= len(s) <= MAX_NODE]))
@@ -284,7 +288,13 @@ def merge_contigs(gf, working_folder, id_list, kmer_len_quick=10, params=None):
         merged_recs = [(n, s) for n, s, _ in new] + nodup
         _write_fasta(folder + "contigs.fa_no_dup.fa.merged.fa", merged_recs, 60)                  # ContigsMerger dumps 60 columns
         final = drop_contained(merged_recs)
-        os.replace(folder + "contigs.fa", folder + "original_contigs_before_merging.fa")
-        _write_fasta(folder + "contigs.fa", final)
-        done[gid] = len(new)
+        try:            # per gap: a failed write leaves THIS gap's contigs.fa as it was (the merged set goes to a temporary name first)
+            _write_fasta(folder + "contigs.fa.merged.tmp", final)
+            os.replace(folder + "contigs.fa", folder + "original_contigs_before_merging.fa")
+            os.replace(folder + "contigs.fa.merged.tmp", folder + "contigs.fa")
+            done[gid] = len(new)
+        except OSError as e:
+            import sys
+            sys.stderr.write("contig merging: gap %s keeps its contigs (%r)\n" % (gid, e))
+            done[gid] = 0
     return done

@@ -74,6 +74,17 @@ def run_assembly(id):
     assemble_ids([id])
 
 
+def _clipped_at(read, i, contig, j, seed_len, budget=2):
+    """The ungapped alignment of `read` to `contig` through the exact seed read[i:i+seed_len] == contig[j:j+seed_len]: clipped when a read
+    end lies beyond the contig's end or more than `budget` mismatches separate it from the seed."""
+    start = j - i                                        # contig offset of the read's first base
+    if start < 0 or start + len(read) > len(contig):
+        return True
+    left = sum(1 for a, b in zip(read[:i], contig[start:j]) if a != b)
+    right = sum(1 for a, b in zip(read[i + seed_len:], contig[j + seed_len:start + len(read)]) if a != b)
+    return left > budget or right > budget
+
+
 class GapAssembler:
     def __init__(self, sf_fai, sf_pos, n_jobs, working_space, kmer_list=None, gf=None, bam_list=None, samtools_path=None):
         global kmer_len_list, working_folder, _gf
@@ -106,9 +117,12 @@ class GapAssembler:
         a best-effort step — each gap is its own Pool task and a failed one leaves its contigs.fa alone —, so a failure here is
         reported and the pipeline goes on with the contigs as they are."""
         from .MergeContigs import merge_contigs
+        from ._lib import GapFillError
         try:
             return merge_contigs(_ctx(), working_folder, fa_list)
-        except Exception as e:          # noqa: BLE001 — any failure of this optional step must not take the picking down
+        except GapFillError:            # a faulted kernel / HIP error: the context is not fit to go on picking and assembling with
+            raise
+        except (OSError, ValueError) as e:      # host-side trouble with one gap's files: the optional step is skipped, the picks go on
             import sys
             sys.stderr.write("contig merging skipped for %d gaps: %r\n" % (len(fa_list), e))
             return {}
@@ -118,9 +132,12 @@ class GapAssembler:
         (gap_reads_high_quality/{id}.fastq, MAPQ 60 only) that align CLIPPED to at least two of its merged contigs are bridges
         between them; the merged contigs.fa is dropped, the assembly's own contigs come back (original_contigs_before_merging.fa)
         and the bridging reads are appended as FASTA records, so that the next merge can chain through them.  `bwa mem` is replaced
-        by exact matching: a read aligns clipped to a contig when they share an exact stretch of seed_len bases (bwa's default
-        output threshold -T 30) on either strand and the read does not lie inside the contig as a whole.  Returns the number of
-        reads appended."""
+        by seed and extend: a read aligns to a contig when they share an exact stretch of seed_len bases (bwa's default output
+        threshold -T 30) on either strand, and the alignment is CLIPPED (is_qualified_clipped(cigar, 1), :196-203) when, extended from
+        the seed without gaps, a read end runs off the contig or gathers more than two mismatches on its way there — a read that lies
+        inside a contig with a sequencing error or two is an end-to-end alignment for bwa and no bridge.  One deviation in
+        the file handling: the reference removes contigs.fa when original_contigs_before_merging.fa is missing (:206-210); here the
+        merged file stays.  Returns the number of reads appended."""
         from .pick_contigs import read_fasta, revcomp
         n_added = 0
         for gid in id_list:
@@ -139,18 +156,25 @@ class GapAssembler:
                     f.readline()
                     f.readline()
                     reads.setdefault(h[1:].split()[0], seq)
-            seeds = {}                                                                    # seed -> contigs that hold it
+            seeds = {}                                                                    # seed -> (contig, strand, offset) of its first occurrence per contig and strand
+            strands = []
             for ci, (_, s) in enumerate(contigs):
-                for strand in (s, revcomp(s)):
+                for st, strand in enumerate((s, revcomp(s))):
+                    strands.append(strand)
+                    seen_here = set()
                     for i in range(len(strand) - seed_len + 1):
-                        seeds.setdefault(strand[i:i + seed_len], set()).add(ci)
+                        w = strand[i:i + seed_len]
+                        if w not in seen_here:
+                            seen_here.add(w)
+                            seeds.setdefault(w, []).append((ci, st, i))
             bridges = []
             for rid, seq in reads.items():
                 su = seq.upper()
-                hit = set()
+                clipped = set()
                 for i in range(len(su) - seed_len + 1):
-                    hit |= seeds.get(su[i:i + seed_len], set())
-                clipped = [ci for ci in hit if su not in contigs[ci][1] and revcomp(su) not in contigs[ci][1]]
+                    for ci, st, j in seeds.get(su[i:i + seed_len], ()):
+                        if ci not in clipped and _clipped_at(su, i, strands[2 * ci + st], j, seed_len):
+                            clipped.add(ci)
                 if len(clipped) >= 2:                                                     # clipped at two contigs at least (:213)
                     bridges.append((rid, seq))
             if os.path.exists(d + "original_contigs_before_merging.fa"):                  # (:206-210)

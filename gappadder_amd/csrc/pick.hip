@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void pick_anchor_kernel(PickParams P) {
         if (has_long) best = pick_span(any + 4, mn + 4, mx + 4, alp[4 * ANCHOR_MAX], al, &orient);
         if (!best) { best = pick_span(any, mn, mx, as[4 * ANCHOR_MAX], a, &orient); alen = a; }
         if (!best) continue;
-        const unsigned long long val = ((unsigned long long)alen << 56) | ((unsigned long long)(best & 0xFFFFFFu) << 32) |
+        if (best > 0xFFFFFFu) best = 0xFFFFFFu;   // the span field has 24 bits: a longer span saturates (it still outranks every shorter one), it never wraps
+        const unsigned long long val = ((unsigned long long)alen << 56) | ((unsigned long long)best << 32) |
                                        ((unsigned long long)(0x7FFFFFFFu - ci) << 1) | orient;
         const unsigned long long old = atomicMax(P.gap_best + c.gap, val);
         if (old == 0) atomicAdd(P.n_closed, 1u);

@@ -574,9 +574,8 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
     uint32_t* stage = carry + 2 * PF2_NB * LN;
     uint32_t* hist3 = stage + PF2_NB * (ST + 1);
     uint32_t* written2 = hist3 + 3 * PF2_NB;   // generated so far (<= cap) | open line's carry buffer << 31
-    uint32_t* desc = written2 + 2 * PF2_NB;    // c | sel << 5 | part runs full << 7 | (total & ~31) << 8
-    uint32_t* offs = desc + PF2_NB;            // the bucket's whole lines in `sent`
-    uint32_t* lga = offs + PF2_NB;             // lines that leave in this group: line index in `pairs` — [0, 256): completed open lines; behind: the lines of `sent`
+    uint32_t* desc = written2 + 2 * PF2_NB;    // per bucket TWO words: c | sel << 5 | part runs full << 7 | (total & ~31) << 8, and where the bucket's whole lines start in `sent`
+    uint32_t* lga = desc + 2 * PF2_NB;             // lines that leave in this group: line index in `pairs` — [0, 256): completed open lines; behind: the lines of `sent`
     uint32_t* lsrc = lga + NLINE;              // ... and where the line stands in LDS (word index from `sent`)
     uint32_t* cnt = lsrc + NLINE;              // [g & 1] completed open lines, [2 + (g & 1)] words of `sent` taken
     const uint32_t writer = blockIdx.x;
@@ -663,8 +662,12 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
             const bool done = total >= LN;
             stage[i * (ST + 1) + (g % ST)] = t_old;
             written2[(wsel ^ 1u) * PF2_NB + i] = (t_old + ne) | ((sel ^ (done ? 1u : 0u)) << 31);
-            desc[i] = c | (sel << 5) | ((n_new > ne ? 1u : 0u) << 7) | (full << 8);
-            if (full > LN) offs[i] = atomicAdd(&cnt[2 + (g & 1u)], full - LN);   // whole lines between the open line and the tail
+            // (both words of a bucket leave and are fetched as ONE 8-byte LDS access: an instruction fewer per pair in the placement, and 8-byte
+            //  accesses spread over 64 banks)
+            uint2 dv;
+            dv.x = c | (sel << 5) | ((n_new > ne ? 1u : 0u) << 7) | (full << 8);
+            dv.y = full > LN ? atomicAdd(&cnt[2 + (g & 1u)], full - LN) : 0u;    // whole lines between the open line and the tail
+            reinterpret_cast<uint2*>(desc)[i] = dv;
             const unsigned long long bal = __ballot(done);
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&cnt[g & 1u], (uint32_t)__popcll(bal));   // (the four waves' lists follow each other in any order)
@@ -683,8 +686,9 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
 #pragma unroll
             for (uint32_t u = 0; u < G; ++u) {   // the buckets' words first: independent LDS reads
                 const uint32_t b = pk[q][u] >> (32 - PF2_NB_LOG2);
-                dsc[u] = desc[b];
-                of[u] = offs[b];    // (stale unless the bucket has whole lines between: used only then)
+                const uint2 dv = reinterpret_cast<const uint2*>(desc)[b];
+                dsc[u] = dv.x;
+                of[u] = dv.y;       // (only read when the bucket has whole lines between)
             }
 #pragma unroll
             for (uint32_t u = 0; u < G; ++u)

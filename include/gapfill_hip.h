@@ -350,7 +350,8 @@ int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const vo
  * anchor_len << 56 | (span + 1) << 32 | (0x7FFFFFFF - contig index) << 1 | reverse strand: the longest span wins, the earlier
  * contig on ties (:313-321), and a pick at a longer anchor outranks every pick at a shorter one (the pipeline tries 15 only on
  * what 30 left open); 0 = no contig of the gap is anchored = gap not closed; *d_n_closed (u32, caller zeroes) counts the gaps
- * that became non-zero. */
+ * that became non-zero.  The span field holds 24 bits: a span + 1 of 2^24 bases or more saturates at 0xFFFFFF (it still wins over
+ * every shorter span and the gap counts as closed; contigs of the per-gap assembly are three orders of magnitude shorter). */
 int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
                          int anchor_len, void* d_gap_best, void* d_n_closed);
 /* both scores of the pipeline in ONE pass over the contigs (anchor_len_short < anchor_len; 0: anchor_len only): the same words as

@@ -351,10 +351,13 @@ def test_high_quality_reads_that_bridge_two_contigs_are_appended(tmp_path):
     wf = str(tmp_path) + "/"
     os.makedirs(wf + "velvet_temp/0_1")
     os.makedirs(wf + "gap_reads_high_quality")
-    open(wf + "velvet_temp/0_1/contigs.fa", "w").write(">merged_1\n%s\n>merged_2\n%s\n" % (c1, c2))
+    open(wf + "velvet_temp/0_1/contigs.fa", "w").write(">merged_1\n%s\n>merged_2\n%s\n>merged_3\n%s\n" % (c1, c2, g[60:330]))
     open(wf + "velvet_temp/0_1/original_contigs_before_merging.fa", "w").write(">o1\n%s\n>o2\n%s\n>o3\n%s\n" % (c1, c2, c3))
+    # ("inside_err": a read that lies inside BOTH overlapping contigs of a second pair with one sequencing error — an end-to-end alignment
+    #  for bwa, no bridge: ADVICE r3)
     reads = [("bridge", g[350:500]), ("inside", g[100:250]), ("one_side", g[380:430] + _rnd(rng, 100)), ("bridge_rc", revcomp(g[360:510])),
-             ("bridge", g[0:150]), ("short_overlap", g[390:400] + _rnd(rng, 140))]
+             ("bridge", g[0:150]), ("short_overlap", g[390:400] + _rnd(rng, 140)),
+             ("inside_err", g[120:190] + ("A" if g[190] != "A" else "C") + g[191:270])]
     open(wf + "gap_reads_high_quality/0_1.fastq", "w").write("".join("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)) for n, s in reads))
     ga = AG.GapAssembler("x.fai", "x.pos", 1, wf, kmer_list=[(31, 29)], gf=object())
     assert ga.collect_high_quality_unmap_to_contigs_reads(["0_1", "0_2"]) == 2
