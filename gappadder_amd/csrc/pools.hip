@@ -15,7 +15,7 @@
 
 namespace gf {
 
-constexpr uint32_t POOL_SORT_MAX = 16384;  // keys of one gap sorted in LDS at a time (64 KiB); longer key lists: chunks of this size + passes over the segment
+constexpr uint32_t POOL_SORT_LDS = 4096;   // keys of one gap sorted in LDS at a time (16 KiB); longer key lists: chunks of this size + passes over the segment
 
 __global__ void keys_from_screen_kernel(const gf_hit* hits, const uint32_t* n_hits, uint32_t hit_cap, int pairs,
                                         unsigned long long* keys, uint32_t key_cap, uint32_t* n_keys) {
@@ -165,7 +165,7 @@ __global__ void pool_scatter_kernel(const unsigned long long* keys, const uint32
 // LDS-privatised forms of the two kernels above (used while one counter per gap fits in LDS): keys of one batch come in
 // random gap order, so the per-wave grouping loops run ~64 rounds; here every block counts its slice of the keys into an LDS
 // histogram with LDS atomics and touches the global counters once per non-empty bin
-__global__ __launch_bounds__(256) void pool_hist_lds_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap,
+__global__ __launch_bounds__(1024) void pool_hist_lds_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap,
                                                             uint32_t n_gaps, uint32_t* cnt) {
     extern __shared__ uint32_t hist[];
     const uint32_t n = *n_keys < key_cap ? *n_keys : key_cap;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void pool_hist_lds_kernel(const unsigned long 
         if (hist[i]) atomicAdd(&cnt[i], hist[i]);
 }
 
-__global__ __launch_bounds__(256) void pool_scatter_lds_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap,
+__global__ __launch_bounds__(1024) void pool_scatter_lds_kernel(const unsigned long long* keys, const uint32_t* n_keys, uint32_t key_cap,
                                                                uint32_t n_gaps, const uint32_t* seg_off, uint32_t* cursor, uint32_t* seg) {
     extern __shared__ uint32_t hist[];   // pass 1: this block's count per gap; pass 2: its next free position per gap
     const uint32_t n = *n_keys < key_cap ? *n_keys : key_cap;
@@ -231,28 +231,26 @@ __device__ __forceinline__ void lds_sort_network(uint32_t* sk, uint32_t m, uint3
     }
 }
 
-// one workgroup per gap: sort of the gap's keys, duplicates dropped, written back in place.  Up to POOL_SORT_MAX keys in LDS; a
+// one workgroup per gap: sort of the gap's keys, duplicates dropped, written back in place.  Up to C keys in LDS; a
 // gap with more (a flank inside a repeat, a collapsed region: the reference has no bound, run_multi_threads_discordant.py:209-241)
-// is sorted in place in global memory by the same network — chunks of POOL_SORT_MAX keys in LDS, the strides beyond a chunk as
+// is sorted in place in global memory by the same network — chunks of C keys in LDS, the strides beyond a chunk as
 // passes over the segment (the workgroup's own stores are visible to it after a barrier) — slower, never dropped.
 __global__ __launch_bounds__(256) void pool_sort_unique_kernel(uint32_t n_gaps, const uint32_t* seg_off, uint32_t* seg,
-                                                              uint32_t* ucnt, uint32_t* error) {
+                                                              uint32_t* ucnt, uint32_t C /* keys the LDS buffer holds, a power of two */) {
     extern __shared__ uint32_t sk[];
     __shared__ uint32_t s_n;
-    (void)error;
     for (uint32_t g = blockIdx.x; g < n_gaps; g += gridDim.x) {
         const uint32_t a = seg_off[g], n = seg_off[g + 1] - a;
         if (n == 0) { if (threadIdx.x == 0) ucnt[g] = 0; continue; }
         uint32_t m = 1;
         while (m < n) m <<= 1;
-        const bool big = n > POOL_SORT_MAX;
+        const bool big = n > C;
         if (threadIdx.x == 0) s_n = 0;
         if (!big) {
             for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) sk[i] = i < n ? seg[a + i] : 0xFFFFFFFFu;
             __syncthreads();
             lds_sort_network(sk, m, 2);
         } else {
-            constexpr uint32_t C = POOL_SORT_MAX;
             uint32_t* S = seg + a;
             auto chunks = [&](uint32_t first_size) {   // every chunk of C keys through LDS
                 for (uint32_t c0 = 0; c0 < n; c0 += C) {
@@ -323,6 +321,29 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(uint32_t n_gaps, const
         const uint32_t ur = (rb & 1) ? rb : rb / 2;
         const uint64_t units64 = (uint64_t)n * ur;
         const uint32_t units = units64 < 0xFFFFFFFFull ? (uint32_t)units64 : 0xFFFFFFFFu;
+        if (rb == 38) {   // 150-base reads: 19 units per read — a division by a constant, and four units of a thread in flight (every unit is two
+                          // dependent loads: the key, then the read's bytes)
+            const uint16_t* src = reinterpret_cast<const uint16_t*>(reads);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(pool) + p0 * 19;
+            const uint64_t room = pool_cap_reads > p0 ? pool_cap_reads - p0 : 0;
+            const uint32_t lim = (uint64_t)units < room * 19 ? units : (uint32_t)(room * 19);
+            for (uint32_t i0 = threadIdx.x; i0 < lim; i0 += 4 * blockDim.x) {
+                uint32_t rd[4], bb[4];
+                uint16_t v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = i0 + q * blockDim.x, j = i / 19u;
+                    bb[q] = i - j * 19u;
+                    const uint32_t key = i < lim ? seg[s0 + j] : 0u;
+                    rd[q] = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (i0 + q * blockDim.x < lim && rd[q] < n_reads) ? src[(uint64_t)rd[q] * 19 + bb[q]] : (uint16_t)0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i0 + q * blockDim.x < lim && rd[q] < n_reads) dst[i0 + q * blockDim.x] = v[q];
+            }
+        } else
         for (uint32_t i = threadIdx.x; i < units; i += blockDim.x) {
             const uint32_t j = i / ur, b = i - j * ur;
             if (p0 + j >= pool_cap_reads) break;
@@ -571,9 +592,10 @@ int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, 
     LaunchTimer tm(ctx, GF_KERNEL_POOL);
     const unsigned blocks = ctx->n_cu * 4;
     const bool lds_bins = ng && (size_t)ng * 4 <= 128 * 1024;     // one LDS counter per gap
-    const unsigned lblocks = std::min<unsigned>(ctx->n_cu, 64);   // few, large slices: global atomics ~ blocks x non-empty bins
+    const unsigned lblocks = std::min<unsigned>(ctx->n_cu, 64);   // few, large slices: global atomics ~ blocks x non-empty bins; 16 waves each
+                                                                  // (4-wave blocks left each of the 64 CUs waiting on its own key loads: 0.29 + 0.47 ms per 10 M keys)
     if (lds_bins) {
-        hipLaunchKernelGGL(pool_hist_lds_kernel, dim3(lblocks), dim3(256), (size_t)ng * 4, ctx->stream, (const unsigned long long*)d_keys,
+        hipLaunchKernelGGL(pool_hist_lds_kernel, dim3(lblocks), dim3(1024), (size_t)ng * 4, ctx->stream, (const unsigned long long*)d_keys,
                            (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, cnt);
     } else if (ng) {
         hipLaunchKernelGGL(pool_hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_keys,
@@ -582,13 +604,15 @@ int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, 
     hipLaunchKernelGGL(pool_scan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, cnt, ng, (void*)seg_off, cursor);
     if (ng) {
         if (lds_bins)
-            hipLaunchKernelGGL(pool_scatter_lds_kernel, dim3(lblocks), dim3(256), (size_t)ng * 4, ctx->stream, (const unsigned long long*)d_keys,
+            hipLaunchKernelGGL(pool_scatter_lds_kernel, dim3(lblocks), dim3(1024), (size_t)ng * 4, ctx->stream, (const unsigned long long*)d_keys,
                                (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, seg_off, cursor, seg);
         else
             hipLaunchKernelGGL(pool_scatter_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_keys,
                                (const uint32_t*)d_n_keys, (uint32_t)key_cap, ng, seg_off, cursor, seg);
-        hipLaunchKernelGGL(pool_sort_unique_kernel, dim3(std::min<unsigned>(ng, ctx->n_cu * 2)), dim3(256), POOL_SORT_MAX * 4,
-                           ctx->stream, ng, seg_off, seg, ucnt, (uint32_t*)d_error);
+        // LDS per workgroup: 4 096 keys (16 KiB, nine workgroups per CU) cover the pools of every BASELINE configuration; a longer key list is
+        // sorted in chunks of that size + passes over its segment.  (64 KiB per workgroup — two per CU — for every gap: 0.68 ms at C4.)
+        hipLaunchKernelGGL(pool_sort_unique_kernel, dim3(std::min<unsigned>(ng, ctx->n_cu * 8)), dim3(256), POOL_SORT_LDS * 4,
+                           ctx->stream, ng, seg_off, seg, ucnt, POOL_SORT_LDS);
     }
     hipLaunchKernelGGL(pool_scan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, ucnt, ng, d_pool_off, (uint32_t*)nullptr);
     if (ng && pool_cap_reads) {
