@@ -257,6 +257,24 @@ struct Arr {
     __device__ __forceinline__ void and_(uint32_t i, uint32_t v) const { if (lds) atomicAnd(&g_lds[off + i], v); else atomicAnd(g + i, v); }
 };
 
+// unitig-internal successor of an ORIENTED node o = 2 * node + orientation.  In LDS one 16-bit entry per oriented node (an LDS plan
+// holds fewer than 32 767 nodes: an oriented node fits 16 bits, 0xFFFF = none) — half a word per entry instead of one; in global memory
+// two 32-bit arrays (orientation 0, orientation 1)
+struct SuccArr {
+    bool lds;
+    uint32_t off;        // LDS: word offset of the 2 * nb 16-bit entries
+    uint32_t* g;         // global: succ0 at g, succ1 at g + gstride
+    uint32_t gstride;
+    __device__ __forceinline__ uint32_t get(uint32_t o) const {
+        if (lds) { const uint32_t v = reinterpret_cast<const uint16_t*>(&g_lds[off])[o]; return v == 0xFFFFu ? EMPTY32 : v; }
+        return g[(o & 1u) * gstride + (o >> 1)];
+    }
+    __device__ __forceinline__ void set(uint32_t o, uint32_t v) const {
+        if (lds) reinterpret_cast<uint16_t*>(&g_lds[off])[o] = (uint16_t)v;      // (EMPTY32 -> 0xFFFF)
+        else g[(o & 1u) * gstride + (o >> 1)] = v;
+    }
+};
+
 // 8-byte pairs in LDS (word offset, 8-byte aligned) or global memory, read and written whole
 // In LDS a pair is ONE 32-bit word {high half << 16 | low half}: both halves of every pair the graph phase keeps there (an oriented
 // node and a distance / a rank / a base code) stay below 65 535 because an LDS plan holds fewer than 32 767 nodes.  "No arc" is a value
@@ -1085,19 +1103,22 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         ntab.g = gtab;
         const uint32_t want = n_surv + n_surv / 32 + 64;   // (measured: 4 129 nodes for 4 089 survivors)
         // (plan 2 = plan 1 with 5/4 instead of 3/2 table slots per node: 6.5 words)
-        for (int attempt = want <= r_words / 9 ? 0 : want <= r_words / 7 ? 1 : want <= 2 * r_words / 13 ? 2 : 3; attempt < 4; ++attempt) {
+        // (words per node: inst_of + meta + the two successors of 16 bits each = 3, + the table's 3/2 (plan 2: 5/4) slots of two words, + in
+        //  plan 0 one 32-bit pair per oriented node: 8 / 6 / 5.5.  Round 3 kept the successors as two 32-bit words — 9 / 7 / 6.5 —, and a
+        //  tenth of C5's gaps fell out of every LDS plan, taking three to four times as long as the others)
+        for (int attempt = want <= r_words / 8 ? 0 : want <= r_words / 6 ? 1 : want <= 2 * r_words / 11 ? 2 : 3; attempt < 4; ++attempt) {
             graph_lds = false;
             j_lds = false;
             if (attempt < 3) {
-                const uint32_t room = attempt == 0 ? r_words / 9 : attempt == 1 ? r_words / 7 : 2 * r_words / 13;
-                nb = (uint32_t)(node_bound < room ? node_bound : room);
+                const uint32_t room = (attempt == 0 ? r_words / 8 : attempt == 1 ? r_words / 6 : 2 * r_words / 11) & ~1u;   // (even: the table behind the arrays stays 8-byte aligned)
+                nb = (uint32_t)(node_bound < room ? node_bound + 1 : room) & ~1u;
                 if (nb < n_surv || nb < 64) continue;       // cannot even hold one node per survivor
                 graph_lds = true;
                 j_lds = attempt == 0;
             }
             ntab.lds = graph_lds;
-            ntab.off = R + 4 * nb;
-            ntab.cap = graph_lds ? ((r_words - (j_lds ? 6 : 4) * nb) / 2) : gcap;
+            ntab.off = R + 3 * nb;
+            ntab.cap = graph_lds ? ((r_words - (j_lds ? 5 : 3) * nb) / 2) : gcap;
             cand_on = graph_lds && 2ull * ntab.cap <= 4ull * n_unit;   // (the slice of the pair workspace holds two words per slot)
             if (graph_lds) {
                 for (uint32_t i = tid; i < ntab.cap; i += ASM_THREADS) ntab.store(i, EMPTY64);
@@ -1162,12 +1183,11 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         ASM_STAMP(3);
 
         // ---- P3.5: dense node indices.  slot.id <- node index; inst_of / meta / succ arrays
-        // LDS: [inst_of | meta | succ0 | succ1] at R, pairs behind the table;  global: inst_of = list_b, [meta | succ0 | succ1] in
+        // LDS: [inst_of | meta | succ (16 bits per oriented node)] at R, pairs behind the table;  global: inst_of = list_b, [meta | succ0 | succ1] in
         // the node workspace, pairs in the jump workspace
         const Arr inst_of{graph_lds, R, list_b};
         const Arr nmeta{graph_lds, R + astride, garr};
-        const Arr succ0{graph_lds, R + 2 * astride, garr + astride};
-        const Arr succ1{graph_lds, R + 3 * astride, garr + 2 * astride};
+        const SuccArr succ{graph_lds, R + 2 * astride, garr + astride, astride};
         uint32_t Joff = j_lds ? ntab.off + 2 * ntab.cap : 0;
         Pairs J{j_lds, Joff, reinterpret_cast<unsigned long long*>(P.jump + 4 * inst_off)};
         uint32_t* rec = list_b + (graph_lds ? 0 : n_nodes);           // emitted-walk records, 4 words each
@@ -1177,8 +1197,8 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             const unsigned long long v = ntab.load(sl);
             inst_of.set(ni, (uint32_t)v);
             nmeta.set(ni, (uint32_t)(v >> 32) & (node_fp_on ? (1u << NODE_FP_SHIFT) - 1u : 0xFFFFFFFFu));   // (without the fingerprint)
-            succ0.set(ni, EMPTY32);
-            succ1.set(ni, EMPTY32);
+            succ.set(2 * ni, EMPTY32);
+            succ.set(2 * ni + 1, EMPTY32);
             ntab.set_id(sl, ni);
         }
         wg_phase_sync();
@@ -1217,7 +1237,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
         auto inb = [&](uint32_t o) -> uint32_t { return in_bits(adj(o), o & 1); };
         auto has_pred = [&](uint32_t o) { return (nmeta.get(o >> 1) & ((o & 1) ? M_START1 : M_START0)) != 0; };   // internal predecessor
         auto is_dead = [&](uint32_t o) { return (nmeta.get(o >> 1) & M_DEAD) != 0; };
-        auto succ_get = [&](uint32_t o) -> uint32_t { return ((o & 1) ? succ1 : succ0).get(o >> 1); };
+        auto succ_get = [&](uint32_t o) -> uint32_t { return succ.get(o); };
 
         uint32_t n_emit = 0;
         bool cacc_lds = false;
@@ -1242,7 +1262,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                     const uint32_t c = d ? c1 : c0;
                     const uint32_t y = (ntab.id(c >> 1) << 1) | (c & 1u);
                     if (__popc(inb(y)) != 1) continue;
-                    (d ? succ1 : succ0).set(ni, y);
+                    succ.set(2 * ni + d, y);
                     nmeta.or_(y >> 1, (y & 1) ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
                 }
             }
@@ -1257,7 +1277,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                 const uint32_t y = find_oriented(shift_in(cur, __ffs(ob) - 1, kv));
                 if (y == EMPTY32) continue;
                 if (__popc(inb(y)) != 1) continue;
-                (d ? succ1 : succ0).set(ni, y);
+                succ.set(2 * ni + d, y);
                 nmeta.or_(y >> 1, (y & 1) ? M_START1 : M_START0);  // here the flag means "has an internal predecessor"
             }
         }
@@ -1417,9 +1437,9 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                 if (__popc(pb) != 1) continue;
                 const uint32_t y = find_oriented(shift_in(node_seq(p), __ffs(pb) - 1, kv));
                 if (y == EMPTY32 || is_gone(y) || __popc(inb(y)) != 1) continue;
-                ((p & 1) ? succ1 : succ0).set(p >> 1, y);
+                succ.set(p, y);
                 nmeta.or_(y >> 1, (y & 1) ? M_START1 : M_START0);
-                ((y & 1) ? succ0 : succ1).set(y >> 1, p ^ 1u);                   // the reverse link y' -> p'
+                succ.set(y ^ 1u, p ^ 1u);                                       // the reverse link y' -> p'
                 nmeta.or_(p >> 1, (p & 1) ? M_START0 : M_START1);
             }
             graph_sync();

@@ -311,7 +311,7 @@ int gf_pool_keys_all_dev(gf_ctx* ctx, const void* d_hits, const void* d_n_hits, 
 int gf_pool_keys_from_second_hop_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghits, const void* d_n_taghits,
                                      size_t hit_cap, const void* d_row_gap, void* d_keys, size_t key_cap, void* d_n_keys);
 /* keys -> d_pool_off (n_gaps+1 x u64), d_pool_packed (pool_cap_reads reads), d_pool_read_ids (u32 per pooled read, or
- * null).  A gap may have any number of keys (up to 16 384 are sorted in LDS, longer lists in place in global memory: slower, never
+ * null).  A gap may have any number of keys (up to 4 096 are sorted in LDS, longer lists in place in global memory: slower, never
  * dropped — the reference has no bound either, run_multi_threads_discordant.py:209-241).  *d_error (u32): bit 31 set =
  * d_pool_off[n_gaps] > pool_cap_reads, the pool buffer was too small (reads beyond it are not written; d_pool_off stays exact). */
 int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, int read_len, const void* d_keys,
