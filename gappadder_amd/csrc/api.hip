@@ -210,6 +210,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "asm_stats_ptr")) { ctx->asm_stats = (void*)(uintptr_t)value; return GF_OK; }
     if (!strcmp(name, "tag_light")) { ctx->tag_light = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_keyslot")) { ctx->asm_keyslot = value != 0; return GF_OK; }
+    if (!strcmp(name, "asm_pre_frac8")) { if (value < 1 || value > 7) return GF_E_INVAL; ctx->asm_pre_frac8 = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_precount")) { ctx->asm_precount = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_ranked")) { ctx->asm_ranked = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_max_pool_reads")) { if (value < 0 || value > 0x3FFFFFFF) return GF_E_INVAL; ctx->asm_max_pool_reads = value; return GF_OK; }

@@ -65,6 +65,7 @@ struct AsmParams {
     uint32_t keyslot;          // allow the key-in-slot count phase
     uint32_t ranked;           // allow the ranked table behind the pre-count
     uint32_t precount;         // allow the bit-array pre-count (k-mers seen fewer than min_count times never enter the table)
+    uint32_t pre_frac8;        // eighths of the LDS region the pre-count's bit arrays may take under an LDS table (option asm_pre_frac8)
     unsigned long long* stats; // or null: [0] += read windows, [1] += k-mers counted exactly, [2] += surviving k-mers, [3] += nodes (the
                                // assembly's algorithmic bytes, SURVEY.md §8d: 38 B x pool reads + 2 x 20 B x distinct k-mers + contig bases)
     unsigned long long* dbg;   // diagnostic runs only: 16 wall-clock stamps per gap (100 MHz), or null
@@ -432,6 +433,9 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
 
     // gaps are handed out through one counter: pool sizes differ, a static stride left CUs idle behind the largest gaps
     __shared__ uint32_t s_gap, s_cand;
+    constexpr uint32_t ERQ = NT / 4;      // candidate heads / removed heads of an error-removal round kept in LDS (more: the pair workspace)
+    __shared__ uint32_t s_erq[ERQ], s_arco[ERQ], s_narc;
+    __shared__ unsigned long long s_arcv[ERQ];
     __shared__ uint32_t s_scan[ASM_THREADS / 64];
     for (;;) {
         __syncthreads();
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             if (pre && !pre_built) {   // 8 bits per window when they fit: half of the LDS region under an LDS table, all of it otherwise
                 uint32_t lg = 11;
                 while ((1u << lg) < 8 * n_inst && lg < 22) ++lg;
-                const uint32_t maxw = (use_lds ? r_words / 2 : r_words) / levels;
+                const uint32_t maxw = (use_lds ? (uint32_t)((uint64_t)r_words * P.pre_frac8 / 8) : r_words) / levels;
                 while (lg > 11 && (1u << (lg - 5)) > maxw) --lg;
                 pre = (1u << (lg - 5)) <= maxw;
                 pre_log2 = lg;
@@ -1323,21 +1327,27 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             return uni_key(y, ty) < uni_key(x, tx);
         };
         for (uint32_t round = 0; round < P.simplify; ++round) {
-            if (tid == 0) { s_cnt[7] = 0; s_cand = 0; }
+            if (tid == 0) { s_cnt[7] = 0; s_cand = 0; s_narc = 0; }
             __syncthreads();
             // candidate heads first (live, no internal predecessor, exactly one arc in) into a queue — the pairs are idle before the
             // ranking —, then one candidate per thread: the evaluation is a serial chain of walks and look-ups (3-40 us each), and
             // a thread that found three candidates in its own stride set the pace of the whole phase
+            // (Plan 1 keeps the pairs in the GLOBAL slice until the ranking, and a phase that hands data over through global memory ends
+            //  with an L1 invalidate — 1.7 us, eighteen of them in three rounds.  The rounds therefore keep their hand-overs in LDS while they
+            //  fit: the queue in s_erq, the removed heads and their arcs in s_arco / s_arcv.)
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
                 if (is_dead(o) || has_pred(o) || __popc(inb(o)) != 1) continue;
-                J.store(atomicAdd(&s_cand, 1u), o);
+                const uint32_t qi = atomicAdd(&s_cand, 1u);
+                if (qi < ERQ) s_erq[qi] = o; else J.store(qi, o);
             }
-            graph_sync();
+            __syncthreads();
             const uint32_t n_cand = s_cand;
+            const bool er_lds = graph_lds && n_cand <= ERQ;      // the queue went through LDS
+            if (!er_lds) wg_phase_sync();
             // dealt round-robin over the WAVES (candidate q -> wave q mod 16): every wave gets as few divergent lanes as possible and
             // all waves' latency chains overlap (packing them into the first waves measured slower than no queue at all)
             for (uint32_t qi = (tid & 63) * (ASM_THREADS / 64) + (tid >> 6); qi < n_cand; qi += ASM_THREADS) {
-                const uint32_t o = (uint32_t)J.load(qi);
+                const uint32_t o = qi < ERQ ? s_erq[qi] : (uint32_t)J.load(qi);
                 const uint32_t ib = inb(o);
                 uint32_t t, n;
                 unsigned long long cx;
@@ -1395,12 +1405,17 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                 if (go) {   // both end nodes: the reverse orientation of a tip does not qualify by itself (its head has no predecessor)
                     nmeta.or_(o >> 1, M_KILL);
                     nmeta.or_(t >> 1, M_KILL);
-                    s_cnt[7] = 1;
+                    atomicAdd(&s_cnt[7], 2u);      // (at most two heads — X and its reverse — per removed unitig)
                 }
             }
-            graph_sync();
-            if (!s_cnt[7]) break;                                               // nothing to remove
-            // the killed heads remember the arc that enters them (the pairs are not in use before the ranking)
+            if (er_lds) __syncthreads(); else wg_phase_sync();
+            const uint32_t kill_bound = s_cnt[7];
+            if (!kill_bound) break;                                             // nothing to remove
+            // The removed heads remember the arc that enters them — on the snapshot, before any arc is cleared: in an LDS list when they
+            // are few (then the passes below visit the list, not every oriented node), in the pair workspace otherwise.
+            const bool arcs_lds = kill_bound <= ERQ;
+            const bool round_lds = er_lds && arcs_lds;
+            auto er_sync = [&]() { if (round_lds) __syncthreads(); else wg_phase_sync(); };
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
                 if (is_dead(o) || has_pred(o) || !(nmeta.get(o >> 1) & M_KILL)) continue;
                 const uint32_t ib = inb(o);
@@ -1410,26 +1425,35 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                     const uint32_t p = find_oriented(shift_in_front(hs, __ffs(ib) - 1, kv));
                     if (p != EMPTY32) arc = ((unsigned long long)kbase(hs, kv - 1) << 32) | p;
                 }
-                J.store(o, arc);
+                if (arcs_lds) {
+                    const uint32_t qi = atomicAdd(&s_narc, 1u);
+                    s_arco[qi] = o;
+                    s_arcv[qi] = arc;
+                } else J.store(o, arc);
             }
-            graph_sync();
+            er_sync();
+            const uint32_t n_arc = arcs_lds ? s_narc : n_or;
             // arcs into the removed unitigs are cleared at their sources; the heads walk their unitigs and mark the nodes dead
-            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                if (has_pred(o) || !(nmeta.get(o >> 1) & M_KILL) || (nmeta.get(o >> 1) & M_DEAD)) continue;
-                const unsigned long long arc = J.load(o);
+            for (uint32_t i = tid; i < n_arc; i += ASM_THREADS) {
+                const uint32_t o = arcs_lds ? s_arco[i] : i;
+                if (!arcs_lds && (has_pred(o) || !(nmeta.get(o >> 1) & M_KILL) || (nmeta.get(o >> 1) & M_DEAD))) continue;
+                const unsigned long long arc = arcs_lds ? s_arcv[i] : J.load(o);
                 if (arc != NO_ARC) {
                     const uint32_t p = (uint32_t)arc, c = (uint32_t)(arc >> 32);
                     nmeta.and_(p >> 1, ~((p & 1) ? (1u << (4 + (3 - c))) : (1u << c)));
                 }
                 for (uint32_t cur = o; cur != EMPTY32; cur = succ_get(cur)) nmeta.or_(cur >> 1, M_DEADMARK);
             }
-            graph_sync();
+            er_sync();
             // junctions that lost a branch: with one successor left, the edge to it may have become unitig-internal (both directions)
             auto is_gone = [&](uint32_t o) { return (nmeta.get(o >> 1) & (M_DEAD | M_DEADMARK)) != 0; };
-            for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
-                const uint32_t m = nmeta.get(o >> 1);
-                if (has_pred(o) || !(m & M_KILL) || (m & M_DEAD)) continue;      // the heads removed in this round hold their arc
-                const unsigned long long arc = J.load(o);
+            for (uint32_t i = tid; i < n_arc; i += ASM_THREADS) {
+                const uint32_t o = arcs_lds ? s_arco[i] : i;
+                if (!arcs_lds) {
+                    const uint32_t m = nmeta.get(o >> 1);
+                    if (has_pred(o) || !(m & M_KILL) || (m & M_DEAD)) continue;  // the heads removed in this round hold their arc
+                }
+                const unsigned long long arc = arcs_lds ? s_arcv[i] : J.load(o);
                 if (arc == NO_ARC) continue;
                 const uint32_t p = (uint32_t)arc;
                 if (is_gone(p)) continue;
@@ -1442,13 +1466,13 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                 succ.set(y ^ 1u, p ^ 1u);                                       // the reverse link y' -> p'
                 nmeta.or_(p >> 1, (p & 1) ? M_START0 : M_START1);
             }
-            graph_sync();
+            er_sync();
             for (uint32_t ni = tid; ni < n_nodes; ni += ASM_THREADS) {
                 const uint32_t m = nmeta.get(ni);
                 if ((m & M_DEADMARK) && !(m & M_DEAD)) nmeta.or_(ni, M_DEAD);
                 if (m & M_KILL) nmeta.and_(ni, ~M_KILL);
             }
-            graph_sync();
+            er_sync();
         }
 
         ASM_STAMP(7);
@@ -1666,6 +1690,7 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     P.n_gap_list = nullptr;
     P.keyslot = (uint32_t)ctx->asm_keyslot;
     P.precount = (uint32_t)ctx->asm_precount;
+    P.pre_frac8 = (uint32_t)ctx->asm_pre_frac8;
     P.ranked = (uint32_t)ctx->asm_ranked;
     const uint32_t rb = (uint32_t)((read_len + 3) / 4);
     P.reads32 = (const uint32_t*)d_pool;

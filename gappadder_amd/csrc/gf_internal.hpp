@@ -104,6 +104,7 @@ struct gf_ctx {
     long asm_big_pool_reads = 131072;   // ... and pools beyond asm_max_pool_reads go to a second launch whose slices hold this many rows (a pool beyond this sets its gap_error)
     int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
     int asm_ranked = 1;          // count phase: ranked (perfect-hash) table behind the pre-count (k > 32, LDS)
+    int asm_pre_frac8 = 5;       // count phase: eighths of the LDS region the pre-count's bit arrays may take under an LDS table
     int asm_precount = 1;        // count phase: bit-array pre-count in LDS when min_count is 2 or 3 (0: every window goes to the table)
     void* asm_stats = nullptr;  // device u64[4], added to by every assembled gap: windows, k-mers counted exactly, surviving k-mers, nodes (option asm_stats_ptr)
     void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)
