@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
     // gaps are handed out through one counter: pool sizes differ, a static stride left CUs idle behind the largest gaps
     __shared__ uint32_t s_gap, s_cand;
     constexpr uint32_t ERQ = NT / 4;      // candidate heads / removed heads of an error-removal round kept in LDS (more: the pair workspace)
-    __shared__ uint32_t s_erq[ERQ], s_arco[ERQ], s_narc;
+    __shared__ uint32_t s_erq[ERQ], s_arco[ERQ], s_narc, s_jflag[3];
     __shared__ unsigned long long s_arcv[ERQ];
     __shared__ uint32_t s_scan[ASM_THREADS / 64];
     for (;;) {
@@ -1496,9 +1496,11 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             J.store(o, pr);
         }
         graph_sync();
+        // (one barrier per round: three "something changed" flags in rotation — the flag of round jr + 2 is cleared behind the barrier of
+        //  round jr, a whole round before anybody sets it; the pairs themselves need no barrier between rounds, see above)
+        if (tid < 3) s_jflag[tid] = 0;
+        __syncthreads();
         for (int jr = 0; jr < 24; ++jr) {
-            if (tid == 0) s_cnt[7] = 0;
-            __syncthreads();
             bool changed = false;
             for (uint32_t o = tid; o < n_or; o += ASM_THREADS) {
                 const unsigned long long a0 = J.load(o);
@@ -1510,10 +1512,10 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
                 J.store(o, ((unsigned long long)((uint32_t)(a0 >> 32) + (uint32_t)(a1 >> 32)) << 32) | pb);
                 changed = true;
             }
-            if (changed) s_cnt[7] = 1;
+            if (changed) s_jflag[jr % 3] = 1;
             __syncthreads();
-            if (!s_cnt[7]) break;
-            __syncthreads();
+            if (tid == 0) s_jflag[(jr + 2) % 3] = 0;
+            if (!s_jflag[jr % 3]) break;
         }
         graph_sync();
         // tails publish {tail, length} in their head's pair (heads are not read as ancestors any more)
@@ -1625,6 +1627,43 @@ __global__ void fill_empty_kernel(unsigned long long* t, uint64_t n) {
         t[i] = 0x00000000FFFFFFFFull;
 }
 
+// Deepest pools first (longest-processing-time order): the workgroups take gaps from one counter, and a gap of three times the average
+// depth handed out last keeps its CU busy for a millisecond after the others have run dry — per launch.  One workgroup sorts the gaps
+// into 256 depth classes (a counting sort; the order inside a class does not matter) and the launch walks that list.
+__global__ __launch_bounds__(1024) void asm_order_kernel(const uint64_t* pool_off, uint32_t n_pools, uint32_t* order, uint32_t* n_order) {
+    __shared__ uint32_t s_max, s_bin[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_max = 1; *n_order = n_pools; }
+    if (tid < 256) s_bin[tid] = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (uint32_t g = tid; g < n_pools; g += 1024) {
+        const uint64_t n = pool_off[g + 1] - pool_off[g];
+        mx = n > mx ? (uint32_t)(n < 0xFFFFFFu ? n : 0xFFFFFFu) : mx;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t y = __shfl_xor(mx, d); mx = y > mx ? y : mx; }
+    if ((tid & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const uint32_t top = s_max;
+    auto cls = [&](uint32_t g) -> uint32_t {
+        uint64_t n = pool_off[g + 1] - pool_off[g];
+        if (n > top) n = top;                       // (also a pool_off that runs backwards: the kernel refuses that gap itself)
+        return 255u - (uint32_t)(n * 255u / top);   // deepest -> class 0
+    };
+    for (uint32_t g = tid; g < n_pools; g += 1024) atomicAdd(&s_bin[cls(g)], 1u);
+    __syncthreads();
+    if (tid < 64) {   // exclusive scan of the 256 classes, four per lane
+        uint32_t v[4], run = 0;
+        for (int q = 0; q < 4; ++q) { v[q] = s_bin[tid * 4 + q]; run += v[q]; }
+        uint32_t inc = run;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if ((int)tid >= d) inc += y; }
+        uint32_t base = inc - run;
+        for (int q = 0; q < 4; ++q) { s_bin[tid * 4 + q] = base; base += v[q]; }
+    }
+    __syncthreads();
+    for (uint32_t g = tid; g < n_pools; g += 1024) order[atomicAdd(&s_bin[cls(g)], 1u)] = g;
+}
+
 constexpr unsigned ASM_BIG_WGS = 8;   // workgroups (= workspace slices) of the launch that takes the pools beyond asm_max_pool_reads
 
 int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
@@ -1677,17 +1716,22 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     if (n_pools == 0) return GF_OK;
     if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
     uint32_t* d_next = (uint32_t*)ctx->counters.p + 8;   // [8] work counter, [9] the second launch's, [10] pools listed for it
-    if (slice_rows && (rc = ensure(ctx, ctx->asm_big, n_pools * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->asm_big, 2 * n_pools * 4 + 64))) return rc;   // [pools listed for the second launch][gaps in launch order]
     // append: a further (k, kv) pair of the same call adds to the contig list and keeps the error flags of the earlier pairs
     if (append) zero_regions(ctx, ZeroList{{d_next, nullptr, nullptr, nullptr}, {3, 0, 0, 0}});
     else zero_regions(ctx, ZeroList{{(uint32_t*)d_n_contigs, (uint32_t*)d_seq_len, (uint32_t*)d_gap_error, d_next}, {1, 2, (uint32_t)n_pools, 3}});
+    // launch order: the deepest pools first.  The list of an earlier (k, kv) pair of the same call is still good (`append`: same pools).
+    uint32_t* d_order = (uint32_t*)ctx->asm_big.p + n_pools;
+    const bool ordered = n_pools >= 4 * (size_t)ctx->n_cu && !d_cnt_keys;
+    if (ordered && !append)
+        hipLaunchKernelGGL(asm_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint64_t*)d_pool_off, (uint32_t)n_pools, d_order, d_next + 3);
     AsmParams P;
     P.next_gap = d_next;
     P.slice_base = 0;
     P.big_list = slice_rows ? (uint32_t*)ctx->asm_big.p : nullptr;
     P.n_big = d_next + 2;
-    P.gap_list = nullptr;
-    P.n_gap_list = nullptr;
+    P.gap_list = ordered ? d_order : nullptr;
+    P.n_gap_list = ordered ? d_next + 3 : nullptr;
     P.keyslot = (uint32_t)ctx->asm_keyslot;
     P.precount = (uint32_t)ctx->asm_precount;
     P.pre_frac8 = (uint32_t)ctx->asm_pre_frac8;
