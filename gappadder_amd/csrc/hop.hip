@@ -1,25 +1,19 @@
 // Second-hop table on the device.  The reference inverts every `discordant` list line into "mateScaffold matePos srcScaffold
 // srcGap", runs sort(1) -k1n -k2n -k3n -k4n over the file and splits it per mate scaffold (run_multi_threads_discordant.py:19-122);
 // collect_discordant_low_mapq_reads.py:4-28 then looks MAPQ-0 records up in it.  Here the rows are cut from the tagger's hits
-// where they are (HBM), sorted with one rocPRIM radix sort, and the look-up arrays of the second-hop kernel (unique positions per
-// scaffold + row ranges) are derived from them by one small kernel — no host copy, no host sort, nothing cached between batches.
+// where they are (HBM), sorted by a counting sort into buckets + one LDS sort per bucket, and the look-up arrays of the second-hop kernel
+// (unique positions per scaffold + row ranges) are derived from them by three small kernels — no host copy, no host sort, no library sort,
+// nothing cached between batches.
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "gf_internal.hpp"
 
 namespace gf {
 
-__global__ __launch_bounds__(256) void hop_fill_kernel(unsigned long long* keys, uint32_t n, unsigned long long v, uint32_t* n_rows) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_rows = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[i] = v;
-}
-
 // one row per DISCORDANT hit whose mate lies on a known scaffold: key = mate scaffold << 32 | mate position, value = gap index
 __global__ __launch_bounds__(256) void hop_extract_kernel(const gf_alnrec* recs, const gf_taghit* hits, const uint32_t* n_hits, uint32_t hit_cap,
                                                           uint32_t n_scaffolds, unsigned long long* keys, uint32_t* vals, uint32_t row_cap,
-                                                          uint32_t* n_rows) {
+                                                          uint32_t* n_rows, uint32_t* max_pos) {
     const uint32_t n = *n_hits < hit_cap ? *n_hits : hit_cap;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_round = (n + 63) & ~63u;
@@ -38,11 +32,155 @@ __global__ __launch_bounds__(256) void hop_extract_kernel(const gf_alnrec* recs,
         }
         const unsigned long long bal = __ballot(take);
         if (!bal) continue;
+        {
+            uint32_t mp = take ? (uint32_t)key : 0u;
+            for (int d = 32; d >= 1; d >>= 1) { const uint32_t y = __shfl_xor(mp, d); mp = y > mp ? y : mp; }
+            if (lane == 0) atomicMax(max_pos, mp);
+        }
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(n_rows, (uint32_t)__popcll(bal));   // may exceed row_cap: consumers clamp, the host variant reports it
         base = __shfl(base, 0);
         const uint32_t o = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1));
         if (take && o < row_cap) { keys[o] = key; vals[o] = gap; }
+    }
+}
+
+// ---- the rows sorted by (mate scaffold, mate position) without a library sort.  rocPRIM's radix_sort_pairs falls back to its merge sort
+// for a few hundred thousand rows — two kernels, 0.9 ms per C4 step for 3.4e5 padded rows: nearly the whole second-hop phase.  The keys are
+// spread evenly (mates of chimeric pairs), so: a counting sort into <= 16 384 buckets by (scaffold, top bits of the position) — the split of
+// the position follows the largest position seen —, then every bucket (tens of rows) is sorted by one wave in LDS with the all-ascending
+// bitonic network on (position << 32 | gap) words; a bucket beyond the LDS buffer is sorted in place in global memory by the same
+// network (chunks through LDS + passes over the bucket).  Order among equal keys: by gap index (the reference's sort breaks the tie
+// by source scaffold and gap, `-k3n -k4n`: the same for gaps listed in scaffold order).
+constexpr uint32_t HOP_BUCKETS_LOG2 = 14, HOP_SORT_LDS = 1024;
+struct HopBuckets {
+    uint32_t scaf_bits, sub_bits, pos_shift, n_buckets;
+};
+__device__ __forceinline__ HopBuckets hop_buckets(uint32_t n_scaffolds, uint32_t max_pos) {
+    HopBuckets h;
+    h.scaf_bits = 0;
+    while (h.scaf_bits < 32 && (n_scaffolds >> h.scaf_bits) != 0) ++h.scaf_bits;     // the sentinel scaffold n_scaffolds included
+    h.sub_bits = h.scaf_bits < HOP_BUCKETS_LOG2 ? HOP_BUCKETS_LOG2 - h.scaf_bits : 0;
+    uint32_t pb = 0;
+    while (pb < 32 && (max_pos >> pb) != 0) ++pb;
+    h.pos_shift = pb > h.sub_bits ? pb - h.sub_bits : 0;
+    h.n_buckets = (n_scaffolds + 1) << h.sub_bits;
+    return h;
+}
+__device__ __forceinline__ uint32_t hop_bucket_of(const HopBuckets& h, unsigned long long key) {
+    const uint32_t sub = (uint32_t)key >> h.pos_shift;
+    return ((uint32_t)(key >> 32) << h.sub_bits) | (sub < (1u << h.sub_bits) ? sub : (1u << h.sub_bits) - 1u);
+}
+__global__ __launch_bounds__(256) void hop_bucket_count_kernel(const unsigned long long* keys, const uint32_t* n_rows, uint32_t row_cap, uint32_t n_scaffolds,
+                                                               const uint32_t* max_pos, uint32_t* cnt) {
+    const uint32_t n = *n_rows < row_cap ? *n_rows : row_cap;
+    const HopBuckets h = hop_buckets(n_scaffolds, *max_pos);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&cnt[hop_bucket_of(h, keys[i])], 1u);
+}
+// exclusive scan of the bucket counts (one workgroup; <= 2^15 buckets); cursor = a copy of the offsets
+__global__ __launch_bounds__(1024) void hop_bucket_scan_kernel(const uint32_t* cnt, uint32_t n_scaffolds, const uint32_t* max_pos, uint32_t* off, uint32_t* cursor) {
+    __shared__ uint32_t part[1024];
+    const uint32_t nb = hop_buckets(n_scaffolds, *max_pos).n_buckets, tid = threadIdx.x;
+    const uint32_t chunk = (nb + 1023) / 1024, a = tid * chunk < nb ? tid * chunk : nb, b = a + chunk < nb ? a + chunk : nb;
+    uint32_t c = 0;
+    for (uint32_t i = a; i < b; ++i) c += cnt[i];
+    part[tid] = c;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t i = a; i < b; ++i) { off[i] = run; cursor[i] = run; run += cnt[i]; }
+    if (tid == 1023) off[nb] = part[1023];
+}
+__global__ __launch_bounds__(256) void hop_bucket_scatter_kernel(const unsigned long long* keys, const uint32_t* vals, const uint32_t* n_rows, uint32_t row_cap,
+                                                                 uint32_t n_scaffolds, const uint32_t* max_pos, uint32_t* cursor, unsigned long long* k_out,
+                                                                 uint32_t* v_out) {
+    const uint32_t n = *n_rows < row_cap ? *n_rows : row_cap;
+    const HopBuckets h = hop_buckets(n_scaffolds, *max_pos);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i];
+        const uint32_t at = atomicAdd(&cursor[hop_bucket_of(h, k)], 1u);
+        k_out[at] = k;
+        v_out[at] = vals[i];
+    }
+}
+// all-ascending bitonic network on 64-bit words in LDS (see pools.hip: padding words at the top never move); one wave
+__device__ __forceinline__ void hop_lds_network(unsigned long long* sk, uint32_t m, uint32_t first_size) {
+    const uint32_t lane = threadIdx.x;
+    auto cleaners = [&](uint32_t from_stride) {
+        for (uint32_t stride = from_stride; stride > 0; stride >>= 1) {
+            for (uint32_t t = lane; t < (m >> 1); t += 64) {
+                const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const unsigned long long x = sk[lo], y = sk[hi];
+                if (x > y) { sk[lo] = y; sk[hi] = x; }
+            }
+            __syncthreads();
+        }
+    };
+    if (first_size == 0) { cleaners(m >> 1); return; }
+    for (uint32_t size = first_size; size <= m; size <<= 1) {
+        for (uint32_t t = lane; t < (m >> 1); t += 64) {
+            const uint32_t half = size >> 1, blk = t / half, j = t - blk * half;
+            const uint32_t lo = blk * size + j, hi = blk * size + size - 1 - j;
+            const unsigned long long x = sk[lo], y = sk[hi];
+            if (x > y) { sk[lo] = y; sk[hi] = x; }
+        }
+        __syncthreads();
+        cleaners(size >> 2);
+    }
+}
+// one wave per bucket: its rows as (position << 32 | gap) words, sorted, written back in place
+__global__ __launch_bounds__(64) void hop_bucket_sort_kernel(const uint32_t* off, uint32_t n_scaffolds, const uint32_t* max_pos, unsigned long long* k_out, uint32_t* v_out) {
+    __shared__ unsigned long long sk[HOP_SORT_LDS];
+    const uint32_t nb = hop_buckets(n_scaffolds, *max_pos).n_buckets, lane = threadIdx.x;
+    constexpr uint32_t C = HOP_SORT_LDS;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t a = off[b], n = off[b + 1] - a;
+        if (n < 2) continue;
+        const unsigned long long hi32 = k_out[a] & 0xFFFFFFFF00000000ull;       // the bucket's scaffold
+        auto get = [&](uint32_t i) -> unsigned long long { return (k_out[a + i] << 32) | v_out[a + i]; };
+        auto put = [&](uint32_t i, unsigned long long w) { k_out[a + i] = hi32 | (w >> 32); v_out[a + i] = (uint32_t)w; };
+        uint32_t m = 1;
+        while (m < n) m <<= 1;
+        __syncthreads();
+        if (n <= C) {
+            for (uint32_t i = lane; i < m; i += 64) sk[i] = i < n ? get(i) : ~0ull;
+            __syncthreads();
+            hop_lds_network(sk, m, 2);
+            for (uint32_t i = lane; i < n; i += 64) put(i, sk[i]);
+            __syncthreads();
+            continue;
+        }
+        // a bucket beyond the LDS buffer (all mates at one place): chunks through LDS, the wide strides in global memory
+        auto chunks = [&](uint32_t first_size) {
+            for (uint32_t c0 = 0; c0 < n; c0 += C) {
+                for (uint32_t i = lane; i < C; i += 64) sk[i] = c0 + i < n ? get(c0 + i) : ~0ull;
+                __syncthreads();
+                hop_lds_network(sk, C, first_size);
+                for (uint32_t i = lane; i < C; i += 64) if (c0 + i < n) put(c0 + i, sk[i]);
+                __syncthreads();
+            }
+        };
+        auto cmpx = [&](uint32_t lo, uint32_t hi) {
+            if (hi < n) { const unsigned long long x = get(lo), y = get(hi); if (x > y) { put(lo, y); put(hi, x); } }
+        };
+        chunks(2);
+        for (uint32_t size = 2 * C; size <= m; size <<= 1) {
+            for (uint32_t t = lane; t < (m >> 1); t += 64) {
+                const uint32_t half = size >> 1, blk = t / half, j = t - blk * half;
+                cmpx(blk * size + j, blk * size + size - 1 - j);
+            }
+            __syncthreads();
+            for (uint32_t stride = size >> 2; stride >= C; stride >>= 1) {
+                for (uint32_t t = lane; t < (m >> 1); t += 64) { const uint32_t lo = 2 * t - (t & (stride - 1)); cmpx(lo, lo + stride); }
+                __syncthreads();
+            }
+            chunks(0);
+        }
     }
 }
 
@@ -178,29 +316,35 @@ int gf_second_hop_table_dev(gf_ctx* ctx, const void* d_recs, const void* d_taghi
         return GF_E_INVAL;
     if (ctx->n_scaffolds == 0 || !ctx->d_gaps) return GF_E_STATE;
     GF_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned end_bit = 33;   // position bits + enough scaffold bits to order the sentinel n_scaffolds << 32 last
-    while (end_bit < 64 && (ctx->n_scaffolds >> (end_bit - 32)) != 0) ++end_bit;
-    size_t temp_bytes = 0;
-    unsigned long long* nullk = nullptr;
-    uint32_t* nullv = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, nullk, nullk, nullv, nullv, row_cap, 0, end_bit, ctx->stream) != hipSuccess) return GF_E_NODEV;
-    const size_t b_k = (row_cap * 8 + 255) & ~(size_t)255, b_v = (row_cap * 4 + 255) & ~(size_t)255;
+    uint32_t scaf_bits = 0;   // (as hop_buckets)
+    while (scaf_bits < 32 && (ctx->n_scaffolds >> scaf_bits) != 0) ++scaf_bits;
+    const uint32_t sub_bits = scaf_bits < HOP_BUCKETS_LOG2 ? HOP_BUCKETS_LOG2 - scaf_bits : 0;
+    const size_t nb_max = ((size_t)ctx->n_scaffolds + 1) << sub_bits;
+    const size_t b_k = (row_cap * 8 + 255) & ~(size_t)255, b_v = (row_cap * 4 + 255) & ~(size_t)255, b_b = ((nb_max + 2) * 4 + 255) & ~(size_t)255;
     int rc;
-    if ((rc = ensure(ctx, ctx->rowgap, 2 * b_k + 2 * b_v + temp_bytes + 256))) return rc;
+    if ((rc = ensure(ctx, ctx->rowgap, 2 * b_k + 2 * b_v + 3 * b_b + 256))) return rc;
     ctx->rowgap_rows.clear();   // the buffer is sort scratch now: gf_pool_keys_from_tags_dev's cached row -> gap map is gone
     uint8_t* w = (uint8_t*)ctx->rowgap.p;
     unsigned long long* k_in = (unsigned long long*)w;
     unsigned long long* k_out = (unsigned long long*)(w + b_k);
     uint32_t* v_in = (uint32_t*)(w + 2 * b_k);
     uint32_t* v_out = (uint32_t*)(w + 2 * b_k + b_v);
-    void* temp = w + 2 * b_k + 2 * b_v;
+    uint32_t* cnt = (uint32_t*)(w + 2 * b_k + 2 * b_v);          // [nb_max + 1] bucket counts, then one word: the largest mate position
+    uint32_t* off = (uint32_t*)(w + 2 * b_k + 2 * b_v + b_b);
+    uint32_t* cursor = (uint32_t*)(w + 2 * b_k + 2 * b_v + 2 * b_b);
+    uint32_t* max_pos = cnt + nb_max + 1;
     LaunchTimer tm(ctx, GF_KERNEL_LOWMAPQ);
     const unsigned grid = (unsigned)std::min<size_t>((row_cap + 255) / 256, (size_t)ctx->n_cu * 4);
-    hipLaunchKernelGGL(hop_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, k_in, (uint32_t)row_cap, (unsigned long long)ctx->n_scaffolds << 32,
-                       (uint32_t*)d_n_rows);
+    zero_regions(ctx, ZeroList{{cnt, (uint32_t*)d_n_rows, nullptr, nullptr}, {(uint32_t)(nb_max + 2), 1, 0, 0}});
     hipLaunchKernelGGL(hop_extract_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, (const gf_alnrec*)d_recs, (const gf_taghit*)d_taghits,
-                       (const uint32_t*)d_n_taghits, (uint32_t)hit_cap, ctx->n_scaffolds, k_in, v_in, (uint32_t)row_cap, (uint32_t*)d_n_rows);
-    if (rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, row_cap, 0, end_bit, ctx->stream) != hipSuccess) return GF_E_NODEV;
+                       (const uint32_t*)d_n_taghits, (uint32_t)hit_cap, ctx->n_scaffolds, k_in, v_in, (uint32_t)row_cap, (uint32_t*)d_n_rows, max_pos);
+    hipLaunchKernelGGL(hop_bucket_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, k_in, (const uint32_t*)d_n_rows, (uint32_t)row_cap, ctx->n_scaffolds,
+                       max_pos, cnt);
+    hipLaunchKernelGGL(hop_bucket_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, ctx->n_scaffolds, max_pos, off, cursor);
+    hipLaunchKernelGGL(hop_bucket_scatter_kernel, dim3(grid), dim3(256), 0, ctx->stream, k_in, v_in, (const uint32_t*)d_n_rows, (uint32_t)row_cap,
+                       ctx->n_scaffolds, max_pos, cursor, k_out, v_out);
+    hipLaunchKernelGGL(hop_bucket_sort_kernel, dim3((unsigned)std::min<size_t>(nb_max, (size_t)ctx->n_cu * 16)), dim3(64), 0, ctx->stream, off, ctx->n_scaffolds,
+                       max_pos, k_out, v_out);
     hipLaunchKernelGGL(hop_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, k_out, v_out, (const uint32_t*)d_n_rows, (uint32_t)row_cap,
                        (const gf_gap*)ctx->d_gaps, (gf_dpos*)d_rows, (uint32_t*)d_row_gap);
     GF_HIP(ctx, hipGetLastError());

@@ -780,7 +780,7 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
     const FilterParams& P = Q.F;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t slice_words = 1u << (P.bm_log2 - PF2_NB_LOG2 - 5);
-    const uint32_t sh_bm = 32 - P.bm_log2;
+    const uint32_t sh_w = 45 - P.bm_log2, sh_b1 = 40 - P.bm_log2;   // entry -> word of the slice / first bit inside the word (the second: entry bits 8..12)
     unsigned long long* obuf = reinterpret_cast<unsigned long long*>(sm + slice_words + wv * (3 * PF4_OBUF + 2 * PF2_PEND));
     unsigned long long* pend = obuf + PF4_OBUF;
     uint32_t* obx = reinterpret_cast<uint32_t*>(pend + PF2_PEND);
@@ -884,18 +884,20 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
 #pragma unroll
                 for (int c = 0; c < PB / 4; ++c) { pr[4 * c] = nx4[c].x; pr[4 * c + 1] = nx4[c].y; pr[4 * c + 2] = nx4[c].z; pr[4 * c + 3] = nx4[c].w; }
                 if (i0 + PB * 64 < n) fetch(i0 + PB * 64);
-                // both bits of every key in its word of the slice: the trip's sixteen LDS reads first (independent), then the tests
+                // both bits of every key in its word of the slice: the trip's sixteen LDS reads first (independent), then the tests.  An entry
+                // is key bits << 8 | octet and the bucket's 8 bits are the same for the whole slice, so the word index is ONE shift of the
+                // entry (its top bm_log2 - 13 bits: always inside the slice) and each bit index one bit-field extract — the pass is bound by
+                // its vector instructions (PMC: 30 per pair), not by LDS or HBM
                 uint32_t wd[PB], passm = 0;
 #pragma unroll
-                for (int u = 0; u < PB; ++u) {
-                    const uint32_t pos = i0 + ((u >> 2) * 64 + lane) * 4 + (u & 3);
-                    const uint32_t h = ((b << (32 - PF2_NB_LOG2)) | (pr[u] >> 8)) >> sh_bm;   // bit index in the whole bitmap; its top 8 bits = b
-                    wd[u] = pos < n ? sm[(h >> 5) & (slice_words - 1)] : 0u;
-                }
+                for (int u = 0; u < PB; ++u) wd[u] = sm[pr[u] >> sh_w];
 #pragma unroll
-                for (int u = 0; u < PB; ++u) {
-                    const uint32_t pk = (b << (32 - PF2_NB_LOG2)) | (pr[u] >> 8);
-                    passm |= ((wd[u] >> ((pk >> sh_bm) & 31)) & (wd[u] >> (pk & 31)) & 1u) << u;
+                for (int u = 0; u < PB; ++u)
+                    passm |= ((wd[u] >> ((pr[u] >> sh_b1) & 31u)) & (wd[u] >> ((pr[u] >> 8) & 31u)) & 1u) << u;
+                if (i0 + PB * 64 > n) {   // the part's last trip: entries behind its end do not count
+#pragma unroll
+                    for (int u = 0; u < PB; ++u)
+                        if (i0 + ((u >> 2) * 64 + lane) * 4 + (u & 3) >= n) passm &= ~(1u << u);
                 }
                 if (!__any(passm != 0)) continue;
 #pragma unroll
