@@ -307,6 +307,36 @@ struct LowParams {
     uint32_t* n_out;
 };
 
+// largest index uq in [first, hi) with upos[uq] <= lim, or `first - 1` when there is none: upos ascends inside a scaffold and the positions
+// (mates of chimeric pairs) are spread evenly, so the search starts from the interpolated place and gallops — three or four loads instead
+// of the seventeen of a bisection over 1.7e5 positions (the second hop was 0.55 ms of look-ups into an L2-resident array)
+__device__ __forceinline__ uint32_t hop_upper(const uint32_t* upos, uint32_t first, uint32_t hi, uint64_t lim) {
+    if (first >= hi) return first - 1;
+    uint32_t lo = first;                       // invariant: everything below lo is <= lim, everything from hi on is > lim
+    const uint32_t p0 = upos[first], p1 = upos[hi - 1];
+    if ((uint64_t)p0 > lim) return first - 1;
+    if ((uint64_t)p1 <= lim) return hi - 1;
+    uint32_t g = first + (uint32_t)(((lim - p0) * (uint64_t)(hi - 1 - first)) / (uint64_t)(p1 - p0));   // p0 <= lim < p1
+    if ((uint64_t)upos[g] <= lim) {
+        lo = g + 1;
+        for (uint32_t st = 1; lo < hi; st <<= 1) {         // gallop up
+            const uint32_t t = lo + st - 1 < hi - 1 ? lo + st - 1 : hi - 1;
+            if ((uint64_t)upos[t] <= lim) lo = t + 1; else { hi = t; break; }
+        }
+    } else {
+        hi = g;
+        for (uint32_t st = 1; lo < hi; st <<= 1) {         // gallop down
+            const uint32_t t = hi > lo + st ? hi - st : lo;
+            if ((uint64_t)upos[t] > lim) hi = t; else { lo = t + 1; break; }
+        }
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)upos[mid] <= lim) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+
 __global__ __launch_bounds__(256) void low_mapq_kernel(LowParams P) {
     __shared__ gf_taghit whits[4][WHCAP];
     WaveHits hb{whits[threadIdx.x >> 6], 0};
@@ -331,15 +361,9 @@ __global__ __launch_bounds__(256) void low_mapq_kernel(LowParams P) {
             if (!(lane & 1) && h < n_half) {
                 const uint32_t pos = v[u].x, ref = v[u].w, mapq = (nb_y >> 16) & 0xFF;
                 if (mapq == 0 && ref < P.n_scaffolds) {
-                    uint32_t lo = P.scaf_off[ref], hi = P.scaf_off[ref + 1];
-                    const uint32_t first = lo;
-                    const uint64_t lim = (uint64_t)pos + 199;  // largest q <= pos+199
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if ((uint64_t)P.upos[mid] <= lim) lo = mid + 1; else hi = mid;
-                    }
-                    if (lo > first) {
-                        const uint32_t uq = lo - 1;
+                    const uint32_t first = P.scaf_off[ref];
+                    const uint32_t uq = hop_upper(P.upos, first, P.scaf_off[ref + 1], (uint64_t)pos + 199);  // largest q <= pos+199
+                    if (uq + 1 > first) {
                         if ((uint64_t)P.upos[uq] + 299 >= pos) {
                             row = P.urow[uq];
                             row_end = P.urow[uq + 1];
@@ -372,15 +396,9 @@ __global__ __launch_bounds__(256) void low_mapq_compact_kernel(LowParams P) {
             const gf_lowrec e = P.low[i];
             rec = e.rec;
             if (e.ref < P.n_scaffolds) {
-                uint32_t lo = P.scaf_off[e.ref], hi = P.scaf_off[e.ref + 1];
-                const uint32_t first = lo;
-                const uint64_t lim = (uint64_t)e.pos + 199;  // largest q <= pos+199
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if ((uint64_t)P.upos[mid] <= lim) lo = mid + 1; else hi = mid;
-                }
-                if (lo > first) {
-                    const uint32_t uq = lo - 1;
+                const uint32_t first = P.scaf_off[e.ref];
+                const uint32_t uq = hop_upper(P.upos, first, P.scaf_off[e.ref + 1], (uint64_t)e.pos + 199);  // largest q <= pos+199
+                if (uq + 1 > first) {
                     if ((uint64_t)P.upos[uq] + 299 >= e.pos) {
                         row = P.urow[uq];
                         row_end = P.urow[uq + 1];
