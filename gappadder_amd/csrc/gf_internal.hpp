@@ -52,7 +52,7 @@ struct FlankIndex {
     // ext = mask over the 2-base codes (nearest base first) left of the canonical 16-mer | the same for the right side << 16,
     // OR-ed over all occurrences (an occurrence with one neighbour sets the whole nibble of that base; no neighbour: nothing)
     uint32_t* d_sgrp = nullptr;
-    size_t n_kmers = 0, n_s16 = 0;
+    size_t n_kmers = 0, n_s16 = 0, n_occ = 0;   // (n_occ: entries of d_occ)
     uint32_t max_gaps_per_kmer = 0;
 };
 

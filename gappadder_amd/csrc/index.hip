@@ -145,6 +145,7 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
     ix.stride = k - 15;
     ix.n_kmers = ent.size();
     ix.n_s16 = s16.size();
+    ix.n_occ = occ.size();
     ix.max_gaps_per_kmer = ctx->max_gaps_per_kmer;
 
     // level 3 table

@@ -342,6 +342,7 @@ int build_flank_index_dev(gf_ctx* ctx, int k, FlankIndex& ix) {
     }
     ix.n_kmers = cnt[2];
     ix.n_s16 = cnt[3];
+    ix.n_occ = cnt[1];
     // ---- level 3 table
     ix.t_log2 = std::max(8, ceil_log2_sz(2 * (size_t)cnt[2] + 2));
     const size_t tcap = (size_t)1 << ix.t_log2;

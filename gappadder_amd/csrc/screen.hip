@@ -1282,6 +1282,7 @@ struct VerifyParams {
     uint32_t* overflow;      // counter: candidates whose (position, gap) list exceeded list_cap
     uint32_t* overflow_list; // their read ids (re-verified by a second launch with a large list), or null
     uint32_t vlist;          // seed-and-extend kernel: gap entries per candidate (VEXT_LIST / VEXT_LIST_BIG)
+    uint32_t n_occ;          // entries of the occurrence lists in all
 };
 
 __device__ __forceinline__ uint32_t packed_word(const VerifyParams& P, uint64_t w) {
@@ -1683,68 +1684,105 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
             }
         }
         __syncthreads();
-        // one work item per (candidate, aligned 16-mer); 64 items at a time
+        // one work item per (candidate, aligned 16-mer)
         const uint32_t n_items = nb * P.np;
-        for (uint32_t i = lane; i < n_items; i += 64) {
-            const uint32_t j = i / P.np, q = i - j * P.np;
-            const uint32_t slot = slots[i];
-            if (slot == EMPTY32) continue;
-            const uint32_t* row = rows + j * rwp + 4;
-            const uint32_t qs = P.first + q * P.stride;
-            const uint32_t w16 = stream32(row, 2 * qs);
+        // what the walks below need of an item: the seed's place in the read and how far an extension may run (wave-uniform in the long-list pass)
+        struct Item { const uint32_t* row; uint32_t j, qs; bool ro, pal, ok; uint32_t baseL, baseR; };
+        auto item_of = [&](uint32_t i) -> Item {
+            Item it;
+            it.j = i / P.np;
+            const uint32_t q = i - it.j * P.np;
+            it.row = rows + it.j * rwp + 4;
+            it.qs = P.first + q * P.stride;
+            const uint32_t w16 = stream32(it.row, 2 * it.qs);
             const uint32_t key = canon16(w16);
-            const bool ro = key != w16, pal = revpairs32(~key) == key;
+            it.ro = key != w16;
+            it.pal = revpairs32(~key) == key;
+            it.ok = true;
             uint32_t nl = 64, nr = 64;
             if (nmw) {
-                const uint32_t* m = nmr + j * nmw;
-                if (nbits64(m, (int)nmw, (int)qs) & 0xFFFFull) continue;      // an N inside the seed: no k-mer through it counts
-                const uint64_t lb = nbits64(m, (int)nmw, (int)qs - 64), rbits = nbits64(m, (int)nmw, (int)qs + 16);
+                const uint32_t* m = nmr + it.j * nmw;
+                if (nbits64(m, (int)nmw, (int)it.qs) & 0xFFFFull) it.ok = false;      // an N inside the seed: no k-mer through it counts
+                const uint64_t lb = nbits64(m, (int)nmw, (int)it.qs - 64), rbits = nbits64(m, (int)nmw, (int)it.qs + 16);
                 nl = lb ? (uint32_t)__builtin_clzll(lb) : 64;
                 nr = rbits ? (uint32_t)__builtin_ctzll(rbits) : 64;
             }
-            uint32_t baseL = W < qs ? W : qs, baseR = P.read_len - (qs + 16);
-            baseL = baseL < nl ? baseL : nl;
-            baseR = baseR < W ? baseR : W;
-            baseR = baseR < nr ? baseR : nr;
-            uint32_t oi = P.sval[slot];
-            for (;;) {
-                const uint32_t fid = P.occ[2 * oi], info = P.occ[2 * oi + 1];
-                const uint32_t f = info & 0xFFFFu, lroom = (info >> 18) & 63u, rroom = (info >> 24) & 63u;
-                const bool fo = (info >> 16) & 1u;
-                const uint32_t* fw = P.fpk + P.foff[fid];
-                bool hit = false;
+            it.baseL = W < it.qs ? W : it.qs;
+            it.baseR = P.read_len - (it.qs + 16);
+            it.baseL = it.baseL < nl ? it.baseL : nl;
+            it.baseR = it.baseR < W ? it.baseR : W;
+            it.baseR = it.baseR < nr ? it.baseR : nr;
+            return it;
+        };
+        // one occurrence {flank, info} of the item's 16-mer: does a k-mer of the read through the seed equal the flank's there?
+        auto occ_hits = [&](const Item& it, uint32_t fid, uint32_t info) -> bool {
+            const uint32_t f = info & 0xFFFFu, lroom = (info >> 18) & 63u, rroom = (info >> 24) & 63u;
+            const bool fo = (info >> 16) & 1u;
+            const uint32_t* fw = P.fpk + P.foff[fid];
+            bool hit = false;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const bool same = t == 0 ? (ro == fo) : (ro != fo);
-                    if (t == 1 && !pal) break;
-                    const uint32_t capL = baseL < (same ? lroom : rroom) ? baseL : (same ? lroom : rroom);
-                    const uint32_t capR = baseR < (same ? rroom : lroom) ? baseR : (same ? rroom : lroom);
-                    if (capL + capR + 16 < P.k) continue;
-                    hit = hit || ext_hit(row, qs, fw, f, same, capL, capR, P.k);
-                }
-                if (hit) {
-                    const uint32_t g = fid >> 1;
-                    uint32_t* lj = lists + j * VL;
-                    if (SET) {   // long list = a hash set of the gaps (one CAS claims a slot: the seeds of one candidate, worked on by several lanes, cannot list a gap twice)
+            for (int t = 0; t < 2; ++t) {
+                const bool same = t == 0 ? (it.ro == fo) : (it.ro != fo);
+                if (t == 1 && !it.pal) break;
+                const uint32_t capL = it.baseL < (same ? lroom : rroom) ? it.baseL : (same ? lroom : rroom);
+                const uint32_t capR = it.baseR < (same ? rroom : lroom) ? it.baseR : (same ? rroom : lroom);
+                if (capL + capR + 16 < P.k) continue;
+                hit = hit || ext_hit(it.row, it.qs, fw, f, same, capL, capR, P.k);
+            }
+            return hit;
+        };
+        if (SET) {
+            // long-list pass: the reads here sit in repeats, their seeds' occurrence lists hold tens to hundreds of entries — ONE item at a
+            // time, its occurrences spread over the lanes (a lane per (read, seed) walked such a list alone: 18 ms on the stress bench).  The
+            // gap list is a hash set: one CAS claims a slot, so lanes cannot list a gap twice.
+            for (uint32_t i = 0; i < n_items; ++i) {
+                const uint32_t slot = slots[i];
+                if (slot == EMPTY32) continue;
+                const Item it = item_of(i);
+                if (!it.ok) continue;
+                uint32_t* lj = lists + it.j * VL;
+                for (uint32_t oi0 = P.sval[slot];; oi0 += 64) {
+                    const uint32_t oi = oi0 + lane;
+                    const bool in = oi < P.n_occ;
+                    const uint32_t fid = in ? P.occ[2 * (size_t)oi] : 0u, info = in ? P.occ[2 * (size_t)oi + 1] : (1u << 17);
+                    const unsigned long long lastb = __ballot((info >> 17) & 1u);
+                    const uint32_t n_here = lastb ? (uint32_t)__ffsll((long long)lastb) : 64u;      // lanes below belong to this 16-mer's list
+                    if (lane < n_here && occ_hits(it, fid, info)) {
+                        const uint32_t g = fid >> 1;
                         uint32_t hs = (g * 0x9E3779B1u) & (VL - 1);
                         for (uint32_t pr = 0;; ++pr) {
-                            if (pr == VL) { cnt[j] = VL + 1; break; }
+                            if (pr == VL) { cnt[it.j] = VL + 1; break; }
                             const uint32_t old = atomicCAS(&lj[hs], EMPTY32, g);
-                            if (old == EMPTY32) { atomicAdd(&cnt[j], 1u); break; }
+                            if (old == EMPTY32) { atomicAdd(&cnt[it.j], 1u); break; }
                             if (old == g) break;
                             hs = (hs + 1) & (VL - 1);
                         }
-                    } else {
-                        const uint32_t have = cnt[j] < VL ? cnt[j] : VL;
-                        bool dup = false;
-                        for (uint32_t e = 0; e < have; ++e) dup = dup || lj[e] == g;
-                        if (!dup) {
-                            const uint32_t e = atomicAdd(&cnt[j], 1u);
-                            if (e < VL) lj[e] = g;
-                        }
+                    }
+                    if (lastb) break;
+                }
+            }
+        } else
+        for (uint32_t i = lane; i < n_items; i += 64) {
+            const uint32_t slot = slots[i];
+            if (slot == EMPTY32) continue;
+            const Item it = item_of(i);
+            if (!it.ok) continue;
+            const uint32_t j = it.j;
+            uint32_t oi = P.sval[slot];
+            for (;;) {
+                const uint32_t fid = P.occ[2 * (size_t)oi], info = P.occ[2 * (size_t)oi + 1];
+                if (occ_hits(it, fid, info)) {
+                    const uint32_t g = fid >> 1;
+                    uint32_t* lj = lists + j * VL;
+                    const uint32_t have = cnt[j] < VL ? cnt[j] : VL;
+                    bool dup = false;
+                    for (uint32_t e = 0; e < have; ++e) dup = dup || lj[e] == g;
+                    if (!dup) {
+                        const uint32_t e = atomicAdd(&cnt[j], 1u);
+                        if (e < VL) lj[e] = g;
                     }
                 }
-                if ((info >> 17) & 1u) break;
+                if (((info >> 17) & 1u) || cnt[j] > VL) break;      // (a list that has run over: the read goes to the long-list pass as a whole)
                 ++oi;
             }
         }
@@ -2008,6 +2046,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.overflow = d_cnt + 2;
     V.overflow_list = (uint32_t*)ctx->cand2.p;
     V.sval = ix.d_sval; V.occ = ix.d_occ; V.fpk = ix.d_fpk; V.foff = ix.d_foff;
+    V.n_occ = (uint32_t)ix.n_occ;
     V.vlist = VEXT_LIST;
     const bool use_ext = ctx->screen_verify_ext && V.min_hits == 1 && ix.max_gaps_per_kmer == 0 && ix.ext_ok && V.np >= 1 && V.np <= 32;
     if (use_ext) {
