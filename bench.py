@@ -833,11 +833,12 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
     best = d_best.cpu().numpy().view(np.uint64)
     ok_asm = SC.contigs_equal(ctg, seq, exp, kk, n_g)
     ok_pick = SC.picks_equal(ctg, seq, best, flanks, kk, n_g)
-    # whole-step CPU time extrapolated from the two samples (recruit scales with reads, assembly with gaps)
-    cpu_step = t_build + t_rec * (n_screened / n_rec) + (t4 - t3) * (len(gaps) / n_g)
+    # whole-step CPU time extrapolated from the two samples (recruit scales with reads, assembly with gaps).  The flank k-mer table is
+    # built once per run on either side (the GPU's index build is outside the timed step too): reported beside, not charged per step
+    cpu_step = t_rec * (n_screened / n_rec) + (t4 - t3) * (len(gaps) / n_g)
     return {"value": n_screened / cpu_step, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "flank k-mer table %.2f s (once); recruit, OpenMP %d threads — %s; assembly: pools of the first %d gaps at %s (%.2f s, same thread count); value = reads / "
-                      "(table + sample times scaled to the whole step); oracle/gp_oracle.c" % (t_build, cores, "; ".join(notes), n_g, ",".join("%d/%d" % p for p in kk), t4 - t3),
+            "sample": "flank k-mer table %.2f s (once per run, not part of a step: `table_build_s`); recruit, OpenMP %d threads — %s; assembly: pools of the first %d gaps at %s (%.2f s, same thread count); value = reads / "
+                      "(sample times scaled to the whole step); oracle/gp_oracle.c" % (t_build, cores, "; ".join(notes), n_g, ",".join("%d/%d" % p for p in kk), t4 - t3),
             "recruit_reads_per_s": n_rec / t_rec, "table_build_s": t_build, "assembly_gaps_per_s": n_g / (t4 - t3),
             "parity_on_sample": bool(ok and ok_asm and ok_pick), "parity_recruit": bool(ok), "parity_assembly": bool(ok_asm),
             "parity_pick": bool(ok_pick), "sample_hits": int(n_ohits), "sample_contigs": int(sum(len(e) for ee in exp for e in ee))}
