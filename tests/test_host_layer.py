@@ -397,3 +397,29 @@ def test_open_gap_census_tells_the_causes_apart():
     r = bench.open_gap_census(cfg, gaps, ctg, "".join(s for _, s in flat).encode(), best, GapFill)
     assert r["open_gaps"] == 5 and r["classified"] == 5
     assert (r["spanning_contig_unpicked"], r["anchor_differs"], r["coverage_hole"], r["fragmented"], r["no_contigs"]) == (1, 1, 1, 1, 1), r
+
+
+def test_roofline_traffic_is_quoted_only_from_a_profile_of_the_running_build(tmp_path, monkeypatch):
+    """bench.py::pmc_traffic: the committed rocprofv3 summary must name exactly the kernels the library launched (gf_screen_kernels,
+    template arguments included), describe the same workload, and its launch times must be within 15 % of the run's — otherwise the
+    line carries `traffic: null` instead of a stale ratio."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    names = ["void gf::pf4_scatter_lines_kernel<3u, false>(gf::Part4Params, unsigned int)", "gf::pf4_probe_kernel(gf::Part4Params)",
+             "gf::pf4_resolve_kernel(gf::Part4Params)", "gf::pf4_list_kernel(gf::Part4Params)"]
+    t = {"reads_per_launch": 900_000_000, "read_len": 150, "k": 51, "kernels": {n: {} for n in names}, "traffic_bytes_per_launch": 7.4e10,
+         "rocprof_avg_launch_ns_sum": 15.4e6}
+    (prof / "r04_traffic_c4.json").write_text(json.dumps(t))
+    launched = "pf4_scatter_lines_kernel<3u, false>,pf4_probe_kernel,pf4_resolve_kernel,pf4_list_kernel"
+    assert bench.pmc_traffic("C4", 900_000_000, 150, 51, 15.2, launched) == 7.4e10
+    assert bench.pmc_traffic("C4", 900_000_000, 150, 51, 12.0, launched) is None                       # this run is 22 % faster: another build
+    assert bench.pmc_traffic("C4", 900_000_000, 150, 51, 15.2, launched.replace("false", "true")) is None    # another instantiation of pass A
+    assert bench.pmc_traffic("C4", 900_000_000, 150, 51, 15.2, launched.replace("pf4_scatter_lines", "pf4_scatter")) is None
+    assert bench.pmc_traffic("C4", 450_000_000, 150, 51, 15.2, launched) is None                      # another workload
+    assert bench.pmc_traffic("C4", 900_000_000, 150, 51, 15.2, "") is None
+    older = dict(t, kernels={n.replace("false", "true"): {} for n in names})                              # an older round's file beside it: skipped, the newer one still counts
+    (prof / "r03_traffic_c4.json").write_text(json.dumps(older))
+    assert bench.pmc_traffic("C4", 900_000_000, 150, 51, 15.2, launched) == 7.4e10
