@@ -47,8 +47,10 @@ PRESETS = {
     # family (0.5-5 kb, either strand), two of every eight at the copies of a 2-copy repeat, one with a low-complexity run in its
     # flank (include/gf_synth.h `repeats`).  Reads hit up to 50 gaps at once, pools of the repeat gaps hold thousands of reads.
     "C2R": (20260002, 5_000_000, 50, 20, 2000, 50_000_000, [(31, 29)]),
+    # ... and the human-scale draft with planted repeats (every 16th gap at a copy of a 50-copy family: 1 240 repeat gaps in 25 families)
+    "C4R": (20260004, 5_000_000, 620, 32, 2000, 900_000_000, [(51, 49)]),
 }
-REPEATS = {"C2R": (8, 50)}   # config -> (period, copies) of the planted repeats
+REPEATS = {"C2R": (8, 50), "C4R": (16, 50)}   # config -> (period, copies) of the planted repeats
 # Mate-pair library of C5.  SURVEY.md §8d says "extra 100 M records" = 4.8x: at KMC's min-count 2 a k-mer of the gap interior (covered by
 # this library only) is then missing with P = e^-3.9 (1 + 3.9) = 10 % per position, so no 2-kb gap can close (measured on the GPU:
 # 0 of 19 840; tools/closure_experiment.py: 0/6 at 4.8x, 1/6 at 10x, 28/30 at 15x, 30/30 at 19x).  The bench therefore draws
@@ -211,6 +213,8 @@ def run(args):
                              insert_mean=300, insert_sd=30, repeat_period=rep_p, repeat_copies=rep_c)
     gaps, flanks = GapFill.synth_layout(cfg0)
     n_gaps = len(gaps)
+    if os.environ.get("GF_BENCH_MAX_GAPS_PER_KMER"):     # the repeat mask: flank k-mers shared by more gaps than this leave the index (experiments on the repeat drafts)
+        gf.set_option("max_gaps_per_kmer", int(os.environ["GF_BENCH_MAX_GAPS_PER_KMER"]))
     gf.set_gaps(gaps, int(cfg0["n_scaffolds"][0]), flanks)
     for g2 in gf2s:
         if g2 is not gf:
@@ -276,9 +280,15 @@ def run(args):
         assert rc == 0, rc
 
     # ---- sizing pass (untimed): second-hop table rows, pooled reads, exchange slots ----
+    screen_dropped = 0
     for lb in libs:
         recruit(lb)
+        nd = C.c_size_t(0)
+        assert lib.gf_screen_last_overflow(h, C.byref(nd)) == 0
+        screen_dropped += nd.value          # reads with more (position, gap) matches than the verification lists (low-complexity reads against hundreds of flanks)
     sync_all()
+    if args.config in ("C2", "C3", "C4", "C5"):
+        assert screen_dropped == 0, screen_dropped
     for lb in libs:
         n_th = int(lb.d_cnt[4])
         assert n_th <= lb.hit_cap
@@ -406,7 +416,8 @@ def run(args):
     need_merge = multi or n_lib > 1
     d_merged = torch.empty(merged_cap * rb + 64, dtype=torch.uint8, device=dev) if need_merge else None
     d_moff = torch.zeros(n_gaps + 1, dtype=torch.int64, device=dev)
-    contig_cap, seq_cap = (64 * n_gaps + 4096) * len(kk), (24576 * n_gaps + (1 << 20)) * len(kk)
+    # (contigs: a few dozen per gap and k on an i.i.d. draft; the deep pools of a repeat-bearing draft fragment into many more: room grows with the pooled reads)
+    contig_cap, seq_cap = (64 * n_gaps + 4096 + sum(rows_lib) // 4) * len(kk), (24576 * n_gaps + (1 << 20) + 32 * sum(rows_lib)) * len(kk)
     d_ctg = torch.empty(contig_cap * 32, dtype=torch.uint8, device=dev)
     d_seq = torch.empty(seq_cap, dtype=torch.uint8, device=dev)
     d_gap_err = torch.zeros(n_gaps, dtype=torch.int32, device=dev)
@@ -619,7 +630,7 @@ def run(args):
                            "(GF_BENCH_TWO_STREAMS=1 runs tagger + second hop on a second stream beside the filter: same step time within 1-3 %)",
             "counts": {"libraries": {lb.name: lb.counts for lb in libs}, "assembled_pool_reads": asm_rows_total, "contigs": n_ctg_all,
                        "gaps_with_contig": gaps_with_contig, "gaps_closed": n_closed, "gaps_closed_correct": n_correct,
-                       "largest_pool_reads": max_pool_rows, "assembly_slice_rows": asm_bound,
+                       "largest_pool_reads": max_pool_rows, "assembly_slice_rows": asm_bound, "screen_reads_not_verified_in_full": screen_dropped,
                        "pools_beyond_the_slice": int((per_gap > asm_bound).sum())},
             "closed_truth_check": {"what": "the picked sequence of EVERY closed gap (pick_contigs.py:341-349 slice of the winning contig) compared with the "
                                            "true bases behind the planted N-run, regenerated from include/gf_synth.h: genome[start-5 : end+6] on the forward "

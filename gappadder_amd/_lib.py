@@ -63,6 +63,7 @@ def lib():
         "gf_strerror": (C.c_char_p, [i32]),
         "gf_last_error": (C.c_char_p, [vp]),
         "gf_screen_kernels": (C.c_char_p, [vp]),
+        "gf_screen_last_overflow": (i32, [vp, vp]),
         "gf_set_stream": (i32, [vp, vp]),
         "gf_sync": (i32, [vp]),
         "gf_stream_wait": (i32, [vp, vp]),

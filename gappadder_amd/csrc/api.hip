@@ -309,6 +309,18 @@ int gf_screen_reads_dev(gf_ctx* ctx, const void* d_reads, const void* d_nmask, s
     return launch_screen(ctx, *ix, d_reads, d_nmask, n_reads, read_len, min_hits, d_out, cap, d_n_out);
 }
 
+int gf_screen_last_overflow(gf_ctx* ctx, size_t* n_reads_dropped) {
+    if (!ctx || !n_reads_dropped) return GF_E_INVAL;
+    *n_reads_dropped = 0;
+    if (!ctx->counters.p) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t v = 0;
+    GF_HIP(ctx, hipMemcpyAsync(&v, (uint32_t*)ctx->counters.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_reads_dropped = v;
+    return GF_OK;
+}
+
 int gf_screen_reads(gf_ctx* ctx, const uint8_t* packed, const uint32_t* n_mask, size_t n_reads, int read_len, int k,
                     int min_hits, gf_hit* out, size_t cap, size_t* n_out) {
     if (!ctx || !n_out || (n_reads && !packed) || (cap && !out) || read_len <= 0) return GF_E_INVAL;

@@ -1747,15 +1747,26 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
                     const uint32_t fid = in ? P.occ[2 * (size_t)oi] : 0u, info = in ? P.occ[2 * (size_t)oi + 1] : (1u << 17);
                     const unsigned long long lastb = __ballot((info >> 17) & 1u);
                     const uint32_t n_here = lastb ? (uint32_t)__ffsll((long long)lastb) : 64u;      // lanes below belong to this 16-mer's list
-                    if (lane < n_here && occ_hits(it, fid, info)) {
+                    if (lane < n_here) {
+                        // a gap that is listed already needs no second proof: a low-complexity 16-mer stands at fifty offsets of the same
+                        // flank, and the extension is a hundred instructions and four loads, the set look-up five
                         const uint32_t g = fid >> 1;
                         uint32_t hs = (g * 0x9E3779B1u) & (VL - 1);
-                        for (uint32_t pr = 0;; ++pr) {
-                            if (pr == VL) { cnt[it.j] = VL + 1; break; }
-                            const uint32_t old = atomicCAS(&lj[hs], EMPTY32, g);
-                            if (old == EMPTY32) { atomicAdd(&cnt[it.j], 1u); break; }
-                            if (old == g) break;
+                        bool listed = false;
+                        for (uint32_t pr = 0; pr < VL; ++pr) {
+                            const uint32_t x = lj[hs];
+                            if (x == g) { listed = true; break; }
+                            if (x == EMPTY32) break;
                             hs = (hs + 1) & (VL - 1);
+                        }
+                        if (!listed && occ_hits(it, fid, info)) {
+                            for (uint32_t pr = 0;; ++pr) {      // (from the first free or foreign slot the look-up stopped at)
+                                if (pr == VL) { cnt[it.j] = VL + 1; break; }
+                                const uint32_t old = atomicCAS(&lj[hs], EMPTY32, g);
+                                if (old == EMPTY32) { atomicAdd(&cnt[it.j], 1u); break; }
+                                if (old == g) break;
+                                hs = (hs + 1) & (VL - 1);
+                            }
                         }
                     }
                     if (lastb) break;
@@ -1771,13 +1782,13 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
             uint32_t oi = P.sval[slot];
             for (;;) {
                 const uint32_t fid = P.occ[2 * (size_t)oi], info = P.occ[2 * (size_t)oi + 1];
-                if (occ_hits(it, fid, info)) {
+                {
                     const uint32_t g = fid >> 1;
                     uint32_t* lj = lists + j * VL;
                     const uint32_t have = cnt[j] < VL ? cnt[j] : VL;
                     bool dup = false;
                     for (uint32_t e = 0; e < have; ++e) dup = dup || lj[e] == g;
-                    if (!dup) {
+                    if (!dup && occ_hits(it, fid, info)) {      // (a gap that is listed already needs no second proof)
                         const uint32_t e = atomicAdd(&cnt[j], 1u);
                         if (e < VL) lj[e] = g;
                     }

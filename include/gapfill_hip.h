@@ -194,6 +194,12 @@ int gf_screen_reads(gf_ctx* ctx, const uint8_t* packed_reads, const uint32_t* n_
 /* device variant: d_out order is unspecified; *d_n_out (device u32, zeroed by the call) = hits produced. */
 int gf_screen_reads_dev(gf_ctx* ctx, const void* d_packed_reads, const void* d_n_mask_or_null, size_t n_reads,
                         int read_len, int k, int min_hits, void* d_out, size_t cap, void* d_n_out);
+/* The device variant cannot return GF_E_UNSUPPORTED for the one thing the verification may not be able to finish — a read with more
+ * than 15 000 (k-mer position, gap) matches, i.e. a low-complexity read against hundreds of flanks that share its k-mers: such a read
+ * is counted and its hits are incomplete.  This reads the counter of the LAST gf_screen_reads_dev call on this context (it waits for
+ * the context's stream); 0 = every read was verified in full.  The remedy on such drafts is the repeat mask, option
+ * "max_gaps_per_kmer". */
+int gf_screen_last_overflow(gf_ctx* ctx, size_t* n_reads_dropped);
 
 /* ---- a-2: alignment-record tagger (GapReadsCollector.parse_reads_fall_in_gaps_one_scaffold[_short_is],
  * collect_reads_for_gaps.py:68-263; mode switch at IS >= 750, :275).  Host variant: sorted by
