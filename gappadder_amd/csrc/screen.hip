@@ -1569,6 +1569,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
 // overflow list to a second launch of this kernel with VEXT_LIST_BIG entries and a few candidates per wave, and only what outgrows
 // that as well to the table kernel.  (Round 3 sent every overflow straight to the table kernel: on the planted-repeat workload,
 // where 0.5 M reads hit 30-50 gaps each, that pass took 460 ms of a 475-ms step.)
+constexpr uint32_t VEXT_WALK_MAX = 96;   // occurrences one lane of the first pass walks for a (read, seed) before it hands the read to the long-list pass
 constexpr uint32_t VEXT_LIST = 16, VEXT_LIST_BIG = 256, VEXT_BATCH_BIG = 8;   // (8 x 256 slots = 8 KiB per wave: a dozen waves per CU; the long list is a hash SET of gaps, full at 192)
 
 
@@ -1780,7 +1781,8 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
             if (!it.ok) continue;
             const uint32_t j = it.j;
             uint32_t oi = P.sval[slot];
-            for (;;) {
+            for (uint32_t steps = 0;; ++steps) {
+                if (steps == VEXT_WALK_MAX) { cnt[j] = VL + 1; break; }      // a long occurrence list (a 16-mer that stands in hundreds of flanks): the long-list pass walks it 64 entries at a time
                 const uint32_t fid = P.occ[2 * (size_t)oi], info = P.occ[2 * (size_t)oi + 1];
                 {
                     const uint32_t g = fid >> 1;
