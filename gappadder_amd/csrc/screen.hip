@@ -1570,7 +1570,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
 // that as well to the table kernel.  (Round 3 sent every overflow straight to the table kernel: on the planted-repeat workload,
 // where 0.5 M reads hit 30-50 gaps each, that pass took 460 ms of a 475-ms step.)
 constexpr uint32_t VEXT_WALK_MAX = 96;   // occurrences one lane of the first pass walks for a (read, seed) before it hands the read to the long-list pass
-constexpr uint32_t VEXT_LIST = 16, VEXT_LIST_BIG = 256, VEXT_BATCH_BIG = 8;   // (8 x 256 slots = 8 KiB per wave: a dozen waves per CU; the long list is a hash SET of gaps, full at 192)
+constexpr uint32_t VEXT_LIST = 16, VEXT_LIST_BIG = 256, VEXT_BATCH_BIG = 8, VEXT_LIST_HUGE = 2048, VEXT_BATCH_HUGE = 2;   // (8 x 256 slots = 8 KiB per wave: a dozen waves per CU; the long list is a hash SET of gaps, full at 192)
 
 
 __device__ __forceinline__ uint32_t fl32(const uint32_t* words, uint32_t base) {   // 16 bases from base offset `base`, MSB-first words
@@ -1866,7 +1866,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     if ((rc = ensure(ctx, ctx->cand, std::max<size_t>(n_reads, 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
     uint32_t* d_cnt = (uint32_t*)ctx->counters.p;  // [0] n_cand, [1] overflow
-    zero_regions(ctx, ZeroList{{d_cnt, (uint32_t*)d_n_out, nullptr, nullptr}, {4, 1, 0, 0}});  // [0] n_cand [1] error overflow [2] n_cand2
+    zero_regions(ctx, ZeroList{{d_cnt, (uint32_t*)d_n_out, nullptr, nullptr}, {5, 1, 0, 0}});  // [0] n_cand [1] error overflow [2] [3] [4] the overflow lists of the verification passes
     if (n_reads == 0) return GF_OK;
 
     FilterParams F;
@@ -2072,19 +2072,23 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         }
         // pass 2: the reads that hit more than VEXT_LIST gaps (repeats shared by many flanks), a few per wave with a long list each;
         // what outgrows that too is queued for the table kernel (the old candidate list is free by now)
-        V.cand = (const uint32_t*)ctx->cand2.p;
-        V.n_cand = d_cnt + 2;
-        V.overflow = d_cnt + 3;
-        V.overflow_list = (uint32_t*)ctx->cand.p;
-        V.vlist = VEXT_LIST_BIG;
-        V.batch = VEXT_BATCH_BIG;
-        {
+        // ... and a third pass for the reads that hit more gaps than THAT set holds (a homopolymer run shared by hundreds of flanks): two
+        // reads per wave, 2 048 slots each.  The lists alternate between the two candidate buffers.
+        const uint32_t big_vl[2] = {VEXT_LIST_BIG, VEXT_LIST_HUGE}, big_batch[2] = {VEXT_BATCH_BIG, VEXT_BATCH_HUGE};
+        uint32_t* bufs[2] = {(uint32_t*)ctx->cand2.p, (uint32_t*)ctx->cand.p};
+        for (int ps = 0; ps < 2; ++ps) {
+            V.cand = bufs[ps & 1];
+            V.n_cand = d_cnt + 2 + ps;
+            V.overflow = d_cnt + 3 + ps;
+            V.overflow_list = bufs[(ps + 1) & 1];
+            V.vlist = big_vl[ps];
+            V.batch = big_batch[ps];
             const size_t lds2 = (64 * (rwp + nmw + V.np + 1) + (size_t)V.batch * V.vlist) * 4;
             LaunchTimer tm(ctx, GF_KERNEL_VERIFY);
             hipLaunchKernelGGL(screen_verify_ext_kernel, dim3(grid2), dim3(64), lds2, ctx->stream, V);
         }
-        V.cand = (const uint32_t*)ctx->cand.p;
-        V.n_cand = d_cnt + 3;
+        V.cand = bufs[0];
+        V.n_cand = d_cnt + 4;
         V.batch = (uint32_t)std::min(64, std::max(1, ctx->screen_verify_batch));
     } else {
         launch_verify(V);

@@ -772,22 +772,24 @@ def test_flank_index_degenerate_inputs(gf):
 
 
 def test_a_read_with_more_matches_than_the_verification_lists_is_reported_not_lost_silently(gf):
-    """The documented hard limit of the screen: 15 000 (k-mer position, gap) matches per read.  A poly-A read against 300 flanks that
-    end in a poly-A run has 120 x 300 of them: the host call says GF_E_UNSUPPORTED, the device call counts the read
-    (gf_screen_last_overflow) — and with the repeat mask (max_gaps_per_kmer) the same reads go through and equal the oracle."""
+    """Reads that share their k-mers with hundreds of flanks: a poly-A read against 300 flanks that end in a poly-A run is listed in full
+    by the third seed-and-extend pass (sets of 1 536 gaps per read) and equals the oracle.  The documented hard limit lies beyond that:
+    against 1 700 such flanks the read falls to the k-mer-table pass, whose 15 000 (k-mer position, gap) entries it exceeds (120 x 1 700) —
+    the host call says GF_E_UNSUPPORTED, the device call counts the read (gf_screen_last_overflow) —, and with the repeat mask
+    (max_gaps_per_kmer) the same reads go through and equal the oracle."""
     import ctypes as C
     import torch
     from gappadder_amd import _lib as B
     from gappadder_amd.hip_api import GapFill
     rng = np.random.RandomState(5)
     lut = np.frombuffer(b"ACGT", np.uint8)
-    n_gaps, L = 300, 150
-    gaps = np.zeros(n_gaps, dtype=B.GAP)
+    n_all, L = 1700, 150
+    gaps = np.zeros(n_all, dtype=B.GAP)
     gaps["scaffold"] = 0
-    gaps["start"] = (np.arange(n_gaps) + 1) * 20000
+    gaps["start"] = (np.arange(n_all) + 1) * 20000
     gaps["end"] = gaps["start"] + 500
-    gaps["idx_in_scaffold"] = np.arange(n_gaps) + 1
-    flanks = [(lut[rng.randint(0, 4, 255)].tobytes().decode() + "A" * 40, lut[rng.randint(0, 4, 295)].tobytes().decode()) for _ in range(n_gaps)]
+    gaps["idx_in_scaffold"] = np.arange(n_all) + 1
+    flanks = [(lut[rng.randint(0, 4, 255)].tobytes().decode() + "A" * 40, lut[rng.randint(0, 4, 295)].tobytes().decode()) for _ in range(n_all)]
     reads = [lut[rng.randint(0, 4, L)].tobytes() for _ in range(2000)]
     for i in range(0, 64, 2):
         reads[i] = b"A" * L
@@ -795,14 +797,19 @@ def test_a_read_with_more_matches_than_the_verification_lists_is_reported_not_lo
         reads[100 + g] = flanks[g][0][60:60 + L].encode()
     blob = b"".join(reads)
     packed, _ = GapFill.pack_reads(blob, L)
-    gf.set_gaps(gaps, 1, flanks)
+    nd = C.c_size_t(0)
+    gf.set_gaps(gaps[:300], 1, flanks[:300])                   # 300 gaps per poly-A read: the seed-and-extend passes list them all
+    exp300 = CO.screen_reads(blob, L, flanks[:300], 31)
+    assert np.bincount(exp300["read"]).max() == 300
+    assert _same(gf.screen_reads(packed, L, 31, cap=len(exp300) + 64), exp300)
+    assert B.lib().gf_screen_last_overflow(gf.handle, C.byref(nd)) == 0 and nd.value == 0
+    gf.set_gaps(gaps, 1, flanks)                               # 1 700: beyond every list
     with pytest.raises(B.GapFillError):
-        gf.screen_reads(packed, L, 31)
+        gf.screen_reads(packed, L, 31, cap=1 << 20)
     d_reads = torch.from_numpy(packed.reshape(-1).copy()).cuda()
     d_out = torch.zeros(1 << 20, 2, dtype=torch.int32, device="cuda")
     d_n = torch.zeros(4, dtype=torch.int32, device="cuda")
     assert B.lib().gf_screen_reads_dev(gf.handle, d_reads.data_ptr(), None, len(reads), L, 31, 1, d_out.data_ptr(), d_out.shape[0], d_n.data_ptr()) == 0
-    nd = C.c_size_t(0)
     assert B.lib().gf_screen_last_overflow(gf.handle, C.byref(nd)) == 0 and nd.value == 32
     try:
         gf.set_option("max_gaps_per_kmer", 8)
