@@ -386,6 +386,8 @@ def run(args):
         gf.set_option("asm_simplify", int(os.environ["GF_BENCH_ASM_SIMPLIFY"]))
     if os.environ.get("GF_BENCH_ASM_PRE_FRAC8"):     # count phase: share of the LDS region the pre-count bit arrays may take (eighths; experiments)
         gf.set_option("asm_pre_frac8", int(os.environ["GF_BENCH_ASM_PRE_FRAC8"]))
+    if os.environ.get("GF_BENCH_ASM_SWEEP"):         # 0: one assembly launch per (k, kv) pair instead of the fused sweep (experiments)
+        gf.set_option("asm_sweep", int(os.environ["GF_BENCH_ASM_SWEEP"]))
     if os.environ.get("GF_BENCH_ASM_THREADS"):       # threads per gap in the assembly kernel (1024 / 512 / 256; default: by the pool bound)
         gf.set_option("asm_threads", int(os.environ["GF_BENCH_ASM_THREADS"]))
     lib_cap = max(4096, int(1.25 * max(rows_lib)) + 1024)            # rows of one library's pool array

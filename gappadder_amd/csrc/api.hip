@@ -210,6 +210,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "asm_stats_ptr")) { ctx->asm_stats = (void*)(uintptr_t)value; return GF_OK; }
     if (!strcmp(name, "tag_light")) { ctx->tag_light = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_keyslot")) { ctx->asm_keyslot = value != 0; return GF_OK; }
+    if (!strcmp(name, "asm_sweep")) { if (value < 0 || value > 1) return GF_E_INVAL; ctx->asm_sweep = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_pre_frac8")) { if (value < 1 || value > 7) return GF_E_INVAL; ctx->asm_pre_frac8 = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_precount")) { ctx->asm_precount = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_ranked")) { ctx->asm_ranked = value != 0; return GF_OK; }
@@ -433,6 +434,11 @@ int gf_assemble_multi_dev(gf_ctx* ctx, const void* d_pool, const void* d_nmask, 
         (contig_cap && !d_contigs) || (seq_cap && !d_seq) || n_k < 1 || !k_list || !kv_list)
         return GF_E_INVAL;
     GF_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_k == 3 && !d_nmask && k_list[0] == 31 && k_list[1] == 41 && k_list[2] == 51 && kv_list[0] == 29 && kv_list[1] == 39 && kv_list[2] == 49) {
+        const int rc = launch_assemble_sweep(ctx, d_pool, d_pool_off, n_pools, total_reads, read_len, min_count, min_contig, d_contigs, contig_cap,
+                                             d_n_contigs, d_seq, seq_cap, d_seq_len, d_gap_error);
+        if (rc != GF_E_UNSUPPORTED) return rc;
+    }
     for (int i = 0; i < n_k; ++i) {   // the (k, k_velvet) loop of run_assembly (assemble_gaps.py:87-122); one contig list
         const int rc = launch_assemble(ctx, d_pool, d_nmask, d_pool_off, n_pools, total_reads, read_len, k_list[i], kv_list[i], min_count,
                                        min_contig, d_contigs, contig_cap, d_n_contigs, d_seq, seq_cap, d_seq_len, d_gap_error, nullptr,

@@ -43,6 +43,7 @@ struct AsmParams {
     uint32_t simplify;         // rounds of tip clipping + bubble popping (0: raw unitigs)
     uint32_t slice_rows;       // > 0: the workspace holds one slice of this many pool rows per workgroup
     uint64_t slice_base;       // ... the first of them starts at this instance offset
+    uint64_t slice_stride;     // ... and they lie this many instances apart (slice_rows x the unit of this launch, or of the largest unit of a sweep)
     // pools beyond slice_rows are not refused: the launch lists them (big_list, *n_big) and a second, small launch takes them from
     // that list (gap_list, *n_gap_list) with slices of its own, sized for deep pools (option asm_big_pool_reads)
     uint32_t* big_list;
@@ -416,14 +417,24 @@ __device__ __forceinline__ void wg_phase_sync() {
 // vector instructions were v_readlane reloads of spilled scalars)
 // PIPE: the launch is the pipeline's (no N masks, no count-only output); FIT: every pool fits its share of the LDS (the host
 // checked) — the per-window tests of those cases fold away with the rest
-template <bool W, int NT, int KC, bool PIPE, bool FIT>   // FIT: every pool fits its share of the LDS
-__global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
+// the static LDS of a workgroup (one set whatever the number of (k, kv) bodies a kernel runs one after the other)
+template <int NT>
+struct AsmShared {
+    unsigned long long seq[2];          // [0] bases to emit  [1] global base offset
+    unsigned long long arcv[NT / 4];    // error removal: the arc that enters a removed head
+    uint32_t cnt[8];                    // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes [6] LDS table overflow
+    uint32_t gap, cand, narc, jflag[3];
+    uint32_t erq[NT / 4], arco[NT / 4]; // error removal: candidate heads of a round, removed heads
+    uint32_t scan[NT / 64];
+};
+template <bool W, int NT, int KC, bool PIPE, bool FIT, bool ONE = false>   // FIT: every pool fits its share of the LDS; ONE: the caller's gap only
+__device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>& sh, const uint32_t one_gap = 0) {
     static_assert(KC == 0 || (KC > 32) == W, "W = k > 32");
     const uint32_t* const nmask = PIPE ? nullptr : P.nmask;
     uint64_t* const cnt_keys = PIPE ? nullptr : P.cnt_keys;   // (4 waves per SIMD = 16 per CU for every NT: <= 128 VGPRs)
     constexpr uint32_t ASM_THREADS = NT;
-    __shared__ uint32_t s_cnt[8];  // [0] survivors [1] emitted walks [2] contig base [3] error [4] distinct k-mers [5] nodes [6] LDS table overflow
-    __shared__ unsigned long long s_seq[2];  // [0] bases to emit  [1] global base offset
+    uint32_t (&s_cnt)[8] = sh.cnt;
+    unsigned long long (&s_seq)[2] = sh.seq;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     const uint32_t PK = KC ? (uint32_t)KC : P.k, PKV = KC ? (uint32_t)(KC - 2) : P.kv;
@@ -432,20 +443,28 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
     const uint32_t per = PK - PKV + 1;
 
     // gaps are handed out through one counter: pool sizes differ, a static stride left CUs idle behind the largest gaps
-    __shared__ uint32_t s_gap, s_cand;
+    uint32_t &s_gap = sh.gap, &s_cand = sh.cand, &s_narc = sh.narc;
     constexpr uint32_t ERQ = NT / 4;      // candidate heads / removed heads of an error-removal round kept in LDS (more: the pair workspace)
-    __shared__ uint32_t s_erq[ERQ], s_arco[ERQ], s_narc, s_jflag[3];
-    __shared__ unsigned long long s_arcv[ERQ];
-    __shared__ uint32_t s_scan[ASM_THREADS / 64];
-    for (;;) {
+    uint32_t (&s_erq)[ERQ] = sh.erq;
+    uint32_t (&s_arco)[ERQ] = sh.arco;
+    uint32_t (&s_jflag)[3] = sh.jflag;
+    unsigned long long (&s_arcv)[ERQ] = sh.arcv;
+    uint32_t (&s_scan)[ASM_THREADS / 64] = sh.scan;
+    for (bool first = true;; first = false) {
         __syncthreads();
-        if (tid == 0) s_gap = atomicAdd(P.next_gap, 1u);
-        __syncthreads();
-        uint32_t g = s_gap;
-        if (P.gap_list) {
-            if (g >= *P.n_gap_list) break;
-            g = P.gap_list[g];
-        } else if (g >= P.n_pools) break;
+        uint32_t g;
+        if (ONE) {
+            if (!first) break;
+            g = one_gap;
+        } else {
+            if (tid == 0) s_gap = atomicAdd(P.next_gap, 1u);
+            __syncthreads();
+            g = s_gap;
+            if (P.gap_list) {
+                if (g >= *P.n_gap_list) break;
+                g = P.gap_list[g];
+            } else if (g >= P.n_pools) break;
+        }
         const uint64_t r0 = P.pool_off[g], r1 = P.pool_off[g + 1];
         if (r1 < r0 || r1 > P.total_reads) {   // pool_off beyond the pool array (an overflowed gf_build_pools_dev): refuse the gap
             if (tid == 0) P.gap_error[g] = ASM_ERR_IDS;
@@ -466,7 +485,7 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
             }
             continue;
         }
-        const uint64_t inst_off = P.slice_rows ? P.slice_base + (uint64_t)blockIdx.x * P.slice_rows * unit : r0 * unit;
+        const uint64_t inst_off = P.slice_rows ? P.slice_base + (uint64_t)blockIdx.x * P.slice_stride : r0 * unit;
         if (n_unit64 >= (1ull << 30) || n_r >= (1u << (31 - INST_OFF_BITS)) - 1) {  // ids are 31-bit: read << 10 | offset (bit 31: INST_WEAK)
             if (tid == 0) P.gap_error[g] = ASM_ERR_IDS;
             continue;
@@ -1622,6 +1641,34 @@ __global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
     }
 }
 
+template <bool W, int NT, int KC, bool PIPE, bool FIT>
+__global__ __launch_bounds__(NT, 4) void assemble_kernel(AsmParams P) {
+    __shared__ AsmShared<NT> sh;
+    assemble_body<W, NT, KC, PIPE, FIT>(P, sh);
+}
+// The (k, k_velvet) loop of run_assembly (assemble_gaps.py:87-122) inside ONE launch, for the pipeline's sweep 31/29, 41/39, 51/49: a
+// workgroup takes a gap and assembles it three times, then takes the next one.  One tail instead of three (a launch ends when its
+// slowest workgroup does), one walk over the gap list, and a gap's contigs stay in (k, kv) order in the contig list — the order the
+// reference writes them to the merged contig file (assemble_gaps.py:124-133), which breaks ties between equal picks.  The bodies share
+// the workgroup's static LDS and its workspace slice (strided for the largest unit of the three).
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void assemble_sweep_kernel(AsmParams P31, AsmParams P41, AsmParams P51) {
+    __shared__ AsmShared<NT> sh;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) sh.gap = atomicAdd(P31.next_gap, 1u);
+        __syncthreads();
+        uint32_t g = sh.gap;
+        if (P31.gap_list) {
+            if (g >= *P31.n_gap_list) break;
+            g = P31.gap_list[g];
+        } else if (g >= P31.n_pools) break;
+        assemble_body<false, NT, 31, true, true, true>(P31, sh, g);
+        assemble_body<true, NT, 41, true, true, true>(P41, sh, g);
+        assemble_body<true, NT, 51, true, true, true>(P51, sh, g);
+    }
+}
+
 __global__ void fill_empty_kernel(unsigned long long* t, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         t[i] = 0x00000000FFFFFFFFull;
@@ -1666,14 +1713,16 @@ __global__ __launch_bounds__(1024) void asm_order_kernel(const uint64_t* pool_of
 
 constexpr unsigned ASM_BIG_WGS = 8;   // workgroups (= workspace slices) of the launch that takes the pools beyond asm_max_pool_reads
 
-int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
-                    size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig, void* d_contigs,
-                    size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len, void* d_gap_error,
-                    void* d_cnt_keys, void* d_cnt_counts, size_t cnt_cap, bool append) {
-    if (k < 16 || k > 64 || read_len < k || read_len > 1000) return GF_E_UNSUPPORTED;
-    if (!d_cnt_keys && (kv < 15 || kv >= k || !(kv & 1))) return GF_E_UNSUPPORTED;
-    if (n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull) return GF_E_INVAL;
-    const uint32_t unit = d_cnt_keys ? read_len - k + 1 : read_len - kv + 1;
+namespace {
+// threads per gap, grid and workspace slices of an assembly launch
+struct AsmGeom {
+    int nt;
+    unsigned per_cu, grid;
+    uint32_t unit;                       // workspace instances per pool row (of the largest unit, for a sweep)
+    uint64_t slice_rows, big_rows, big_base, n_inst;
+};
+AsmGeom asm_geometry(const gf_ctx* ctx, size_t n_pools, size_t total_reads, int read_len, uint32_t unit) {
+    AsmGeom G;
     // threads per gap: option asm_threads (1024 / 512 / 256), or automatic: two gaps per CU (512) when the caller's bound on the
     // largest pool (asm_max_pool_reads) leaves room for the tables in half of a CU's LDS and there are gaps enough to keep every CU
     // busy with pairs of them.  Measured on MI355X (us per gap and CU at 1024 / 512 threads): C4's 313-read pools at k = 51: 221 /
@@ -1681,40 +1730,131 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     // on its LDS pipeline, not short of ready waves —, the gain is what the barriers and the serial error-removal walks left idle.
     // C2 (1 000 gaps = 4 per CU: latency per gap counts) 0.59 / 0.82 ms; C5's 722-read pools fall out of the LDS plans at 76 KiB (142
     // / 268 ms); four gaps per CU (256 threads, 38 KiB) push C4's graph phases into the global slice: 37 ms.
-    int nt = ctx->asm_threads;
-    if (nt != 1024 && nt != 512 && nt != 256)
-        nt = (ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * ((read_len + 3) / 4) <= 28 * 1024 &&
-              n_pools >= 8 * (size_t)ctx->n_cu) ? 512 : 1024;
-    const unsigned per_cu = 1024u / (unsigned)nt;
-    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(n_pools, (size_t)ctx->n_cu * per_cu));
+    G.nt = ctx->asm_threads;
+    if (G.nt != 1024 && G.nt != 512 && G.nt != 256)
+        G.nt = (ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * ((read_len + 3) / 4) <= 28 * 1024 &&
+                n_pools >= 8 * (size_t)ctx->n_cu) ? 512 : 1024;
+    G.per_cu = 1024u / (unsigned)G.nt;
+    G.grid = (unsigned)std::max<size_t>(1, std::min<size_t>(n_pools, (size_t)ctx->n_cu * G.per_cu));
+    G.unit = unit;
     // workspace units (see the kernel): one slice per pool row, or — when the caller bounds the rows of one pool (option
     // asm_max_pool_reads; the host entry points know their pools) — one slice of that many rows per workgroup
-    const uint64_t slice_rows = ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * grid < total_reads ? (uint64_t)ctx->asm_max_pool_reads : 0;
+    G.slice_rows = ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * G.grid < total_reads ? (uint64_t)ctx->asm_max_pool_reads : 0;
     // pools beyond that bound (a flank inside a repeat recruits thousands of reads; the reference runs KMC and Velvet on whatever
     // the pool holds) go to a second launch of ASM_BIG_WGS workgroups with slices of asm_big_pool_reads rows; only a pool beyond
     // THAT sets its gap_error
-    const uint64_t big_rows = slice_rows ? std::min<uint64_t>(std::max<uint64_t>((uint64_t)std::max(0l, ctx->asm_big_pool_reads), slice_rows), total_reads) : 0;
-    const uint64_t big_base = slice_rows * grid * unit;
-    const uint64_t n_inst = slice_rows ? big_base + big_rows * ASM_BIG_WGS * unit : (uint64_t)total_reads * unit;
+    G.big_rows = G.slice_rows ? std::min<uint64_t>(std::max<uint64_t>((uint64_t)std::max(0l, ctx->asm_big_pool_reads), G.slice_rows), total_reads) : 0;
+    G.big_base = G.slice_rows * G.grid * unit;
+    G.n_inst = G.slice_rows ? G.big_base + G.big_rows * ASM_BIG_WGS * unit : (uint64_t)total_reads * unit;
+    return G;
+}
+int asm_workspace(gf_ctx* ctx, const AsmGeom& G, bool jump) {
     int rc;
     {   // the table must be all-EMPTY (id 0xFFFFFFFF, meta 0) on entry; kernels leave it so, a fresh buffer is filled once
         void* before = ctx->asm_table.p;
-        if ((rc = ensure(ctx, ctx->asm_table, std::max<uint64_t>(n_inst, 1) * 4 * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->asm_table, std::max<uint64_t>(G.n_inst, 1) * 4 * 8))) return rc;
         if (ctx->asm_table.p != before) {
             const size_t words = ctx->asm_table.bytes / 8;
             hipLaunchKernelGGL(fill_empty_kernel, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream,
                                (unsigned long long*)ctx->asm_table.p, (uint64_t)words);
         }
     }
-    if ((rc = ensure(ctx, ctx->asm_surv, std::max<uint64_t>(n_inst, 1) * 2 * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->asm_nodes, std::max<uint64_t>(n_inst, 1) * 3 * 4))) return rc;
-    if (!d_cnt_keys && (rc = ensure(ctx, ctx->asm_jump, std::max<uint64_t>(n_inst, 1) * 4 * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->asm_surv, std::max<uint64_t>(G.n_inst, 1) * 2 * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->asm_nodes, std::max<uint64_t>(G.n_inst, 1) * 3 * 4))) return rc;
+    if (jump && (rc = ensure(ctx, ctx->asm_jump, std::max<uint64_t>(G.n_inst, 1) * 4 * 4))) return rc;
+    return GF_OK;
+}
+// the caller's buffers of an assembly call
+struct AsmIO {
+    const void *d_pool, *d_nmask, *d_pool_off;
+    size_t n_pools, total_reads;
+    int read_len, min_count, min_contig;
+    void* d_contigs; size_t contig_cap; void* d_n_contigs;
+    void* d_seq; size_t seq_cap; void* d_seq_len;
+    void* d_gap_error;
+    void *d_cnt_keys, *d_cnt_counts; size_t cnt_cap;
+};
+AsmParams asm_params(const gf_ctx* ctx, const AsmGeom& G, const AsmIO& io, int k, int kv) {
+    AsmParams P;
+    P.slice_base = 0;
+    P.slice_stride = G.slice_rows * G.unit;
+    P.keyslot = (uint32_t)ctx->asm_keyslot;
+    P.precount = (uint32_t)ctx->asm_precount;
+    P.pre_frac8 = (uint32_t)ctx->asm_pre_frac8;
+    P.ranked = (uint32_t)ctx->asm_ranked;
+    const uint32_t rb = (uint32_t)((io.read_len + 3) / 4);
+    P.reads32 = (const uint32_t*)io.d_pool;
+    P.n_words = ((uint64_t)io.total_reads * rb) / 4;
+    P.tail_bytes = (uint32_t)(((uint64_t)io.total_reads * rb) & 3);
+    P.nmask = (const uint32_t*)io.d_nmask;
+    P.pool_off = (const uint64_t*)io.d_pool_off;
+    P.n_pools = (uint32_t)io.n_pools;
+    P.total_reads = io.total_reads;
+    P.rb = rb; P.read_len = io.read_len; P.k = k; P.kv = kv; P.nmw = (io.read_len + 31) / 32;
+    P.min_count = io.min_count < 1 ? 1 : io.min_count;
+    P.min_contig = io.min_contig < 0 ? 0 : io.min_contig;
+    P.table = (unsigned long long*)ctx->asm_table.p;
+    P.surv = (uint32_t*)ctx->asm_surv.p;
+    P.nodes = (uint32_t*)ctx->asm_nodes.p;
+    P.jump = (uint32_t*)ctx->asm_jump.p;
+    P.simplify = (uint32_t)std::max(0, ctx->asm_simplify);
+    P.slice_rows = (uint32_t)G.slice_rows;
+    P.contigs = (gf_contig*)io.d_contigs;
+    P.contig_cap = (uint32_t)io.contig_cap;
+    P.n_contigs = (uint32_t*)io.d_n_contigs;
+    P.seq = (char*)io.d_seq;
+    P.seq_cap = io.seq_cap;
+    P.seq_len = (unsigned long long*)io.d_seq_len;
+    P.gap_error = (uint32_t*)io.d_gap_error;
+    P.cnt_keys = (uint64_t*)io.d_cnt_keys;
+    P.cnt_counts = (uint32_t*)io.d_cnt_counts;
+    P.cnt_cap = (uint32_t)std::min<size_t>(io.cnt_cap, 0xFFFFFFFFu);
+    P.dbg = (unsigned long long*)ctx->asm_dbg;
+    P.stats = (unsigned long long*)ctx->asm_stats;
+    // dynamic LDS (option asm_lds_kb, default all 152 KiB): the gap's packed reads, then meta + succ[2] of its nodes;
+    // whatever does not fit is read from / kept in global memory
+    P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS / G.per_cu, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
+    return P;
+}
+// every pool of the main launch within its share of the LDS
+bool asm_pools_fit(const AsmGeom& G, const AsmParams& P, int k) {
+    return G.slice_rows > 0 && (uint64_t)G.slice_rows * P.rb + 32 <= (uint64_t)P.lds_words * 4 / (k > 32 ? 2 : 3);
+}
+// the launch for the pools the main launch listed (none, as a rule: its workgroups leave at once)
+void asm_launch_big(gf_ctx* ctx, const AsmGeom& G, const AsmParams& P, uint32_t* next, const uint32_t* list, const uint32_t* n_list) {
+    AsmParams B = P;
+    B.next_gap = next;
+    B.slice_rows = (uint32_t)G.big_rows;
+    B.slice_stride = G.big_rows * G.unit;
+    B.slice_base = G.big_base;
+    B.big_list = nullptr;
+    B.gap_list = list;
+    B.n_gap_list = n_list;
+    B.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
+    hipLaunchKernelGGL((P.k <= 32 ? assemble_kernel<false, 1024, 0, false, false> : assemble_kernel<true, 1024, 0, false, false>),
+                       dim3(ASM_BIG_WGS), dim3(1024), (size_t)B.lds_words * 4, ctx->stream, B);
+}
+}  // namespace
+
+int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
+                    size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig, void* d_contigs,
+                    size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len, void* d_gap_error,
+                    void* d_cnt_keys, void* d_cnt_counts, size_t cnt_cap, bool append) {
+    if (k < 16 || k > 64 || read_len < k || read_len > 1000) return GF_E_UNSUPPORTED;
+    if (!d_cnt_keys && (kv < 15 || kv >= k || !(kv & 1))) return GF_E_UNSUPPORTED;
+    if (n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull) return GF_E_INVAL;
+    const AsmIO io{d_pool, d_nmask, d_pool_off, n_pools, total_reads, read_len, min_count, min_contig, d_contigs, contig_cap, d_n_contigs,
+                   d_seq, seq_cap, d_seq_len, d_gap_error, d_cnt_keys, d_cnt_counts, cnt_cap};
+    const AsmGeom G = asm_geometry(ctx, n_pools, total_reads, read_len, d_cnt_keys ? read_len - k + 1 : read_len - kv + 1);
+    const int nt = G.nt;
+    int rc;
+    if ((rc = asm_workspace(ctx, G, !d_cnt_keys))) return rc;
     if (n_pools == 0 && !append) {
         GF_HIP(ctx, hipMemsetAsync(d_n_contigs, 0, 4, ctx->stream));
         GF_HIP(ctx, hipMemsetAsync(d_seq_len, 0, 8, ctx->stream));
     }
     if (n_pools == 0) return GF_OK;
-    if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->counters, GF_COUNTER_BYTES))) return rc;
     uint32_t* d_next = (uint32_t*)ctx->counters.p + 8;   // [8] work counter, [9] the second launch's, [10] pools listed for it
     if ((rc = ensure(ctx, ctx->asm_big, 2 * n_pools * 4 + 64))) return rc;   // [pools listed for the second launch][gaps in launch order]
     // append: a further (k, kv) pair of the same call adds to the contig list and keeps the error flags of the earlier pairs
@@ -1725,75 +1865,73 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     const bool ordered = n_pools >= 4 * (size_t)ctx->n_cu && !d_cnt_keys;
     if (ordered && !append)
         hipLaunchKernelGGL(asm_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint64_t*)d_pool_off, (uint32_t)n_pools, d_order, d_next + 3);
-    AsmParams P;
+    AsmParams P = asm_params(ctx, G, io, k, kv);
     P.next_gap = d_next;
-    P.slice_base = 0;
-    P.big_list = slice_rows ? (uint32_t*)ctx->asm_big.p : nullptr;
+    P.big_list = G.slice_rows ? (uint32_t*)ctx->asm_big.p : nullptr;
     P.n_big = d_next + 2;
     P.gap_list = ordered ? d_order : nullptr;
     P.n_gap_list = ordered ? d_next + 3 : nullptr;
-    P.keyslot = (uint32_t)ctx->asm_keyslot;
-    P.precount = (uint32_t)ctx->asm_precount;
-    P.pre_frac8 = (uint32_t)ctx->asm_pre_frac8;
-    P.ranked = (uint32_t)ctx->asm_ranked;
-    const uint32_t rb = (uint32_t)((read_len + 3) / 4);
-    P.reads32 = (const uint32_t*)d_pool;
-    P.n_words = ((uint64_t)total_reads * rb) / 4;
-    P.tail_bytes = (uint32_t)(((uint64_t)total_reads * rb) & 3);
-    P.nmask = (const uint32_t*)d_nmask;
-    P.pool_off = (const uint64_t*)d_pool_off;
-    P.n_pools = (uint32_t)n_pools;
-    P.total_reads = total_reads;
-    P.rb = rb; P.read_len = read_len; P.k = k; P.kv = kv; P.nmw = (read_len + 31) / 32;
-    P.min_count = min_count < 1 ? 1 : min_count;
-    P.min_contig = min_contig < 0 ? 0 : min_contig;
-    P.table = (unsigned long long*)ctx->asm_table.p;
-    P.surv = (uint32_t*)ctx->asm_surv.p;
-    P.nodes = (uint32_t*)ctx->asm_nodes.p;
-    P.jump = (uint32_t*)ctx->asm_jump.p;
-    P.simplify = (uint32_t)std::max(0, ctx->asm_simplify);
-    P.slice_rows = (uint32_t)slice_rows;
-    P.contigs = (gf_contig*)d_contigs;
-    P.contig_cap = (uint32_t)contig_cap;
-    P.n_contigs = (uint32_t*)d_n_contigs;
-    P.seq = (char*)d_seq;
-    P.seq_cap = seq_cap;
-    P.seq_len = (unsigned long long*)d_seq_len;
-    P.gap_error = (uint32_t*)d_gap_error;
-    P.cnt_keys = (uint64_t*)d_cnt_keys;
-    P.cnt_counts = (uint32_t*)d_cnt_counts;
-    P.cnt_cap = (uint32_t)std::min<size_t>(cnt_cap, 0xFFFFFFFFu);
-    P.dbg = (unsigned long long*)ctx->asm_dbg;
-    P.stats = (unsigned long long*)ctx->asm_stats;
-    // dynamic LDS (option asm_lds_kb, default all 152 KiB): the gap's packed reads, then meta + succ[2] of its nodes;
-    // whatever does not fit is read from / kept in global memory
-    P.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS / per_cu, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
     {
         LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
         void (*kern)(AsmParams) = nt == 1024 ? (k <= 32 ? assemble_kernel<false, 1024, 0, false, false> : assemble_kernel<true, 1024, 0, false, false>)
                                   : nt == 512 ? (k <= 32 ? assemble_kernel<false, 512, 0, false, false> : assemble_kernel<true, 512, 0, false, false>)
                                               : (k <= 32 ? assemble_kernel<false, 256, 0, false, false> : assemble_kernel<true, 256, 0, false, false>);
         // the pipeline's launches: k / kv one of its pairs, no N masks, no count-only output; every pool within its share of the LDS
-        const bool pools_fit = slice_rows > 0 && (uint64_t)slice_rows * rb + 32 <= (uint64_t)P.lds_words * 4 / (k > 32 ? 2 : 3);
+        const bool pools_fit = asm_pools_fit(G, P, k);
         if (kv == k - 2 && nt >= 512 && !d_nmask && !d_cnt_keys) {
             if (k == 51 && pools_fit) kern = nt == 1024 ? assemble_kernel<true, 1024, 51, true, true> : assemble_kernel<true, 512, 51, true, true>;
             if (k == 41 && pools_fit) kern = nt == 1024 ? assemble_kernel<true, 1024, 41, true, true> : assemble_kernel<true, 512, 41, true, true>;
             if (k == 31) kern = pools_fit ? (nt == 1024 ? assemble_kernel<false, 1024, 31, true, true> : assemble_kernel<false, 512, 31, true, true>)
                                           : (nt == 1024 ? assemble_kernel<false, 1024, 31, true, false> : assemble_kernel<false, 512, 31, true, false>);
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), (size_t)P.lds_words * 4, ctx->stream, P);
-        if (slice_rows) {   // the pools the launch above listed (none, as a rule: the workgroups leave at once)
-            AsmParams B = P;
-            B.next_gap = d_next + 1;
-            B.slice_rows = (uint32_t)big_rows;
-            B.slice_base = big_base;
-            B.big_list = nullptr;
-            B.gap_list = (const uint32_t*)ctx->asm_big.p;
-            B.n_gap_list = d_next + 2;
-            B.lds_words = std::min<uint32_t>(ASM_LDS_MAX_WORDS, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
-            hipLaunchKernelGGL((k <= 32 ? assemble_kernel<false, 1024, 0, false, false> : assemble_kernel<true, 1024, 0, false, false>),
-                               dim3(ASM_BIG_WGS), dim3(1024), (size_t)B.lds_words * 4, ctx->stream, B);
-        }
+        hipLaunchKernelGGL(kern, dim3(G.grid), dim3(nt), (size_t)P.lds_words * 4, ctx->stream, P);
+        if (G.slice_rows) asm_launch_big(ctx, G, P, d_next + 1, (const uint32_t*)ctx->asm_big.p, d_next + 2);
+    }
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
+// The pipeline's sweep (k, kv) = (31, 29), (41, 39), (51, 49) in one launch (assemble_sweep_kernel).  Returns GF_E_UNSUPPORTED, before
+// it has touched anything, when the call is not of that shape — the caller then launches per (k, kv).
+int launch_assemble_sweep(gf_ctx* ctx, const void* d_pool, const void* d_pool_off, size_t n_pools, size_t total_reads, int read_len,
+                          int min_count, int min_contig, void* d_contigs, size_t contig_cap, void* d_n_contigs, void* d_seq,
+                          size_t seq_cap, void* d_seq_len, void* d_gap_error) {
+    static const int KS[3] = {31, 41, 51};
+    if (!ctx->asm_sweep || read_len < 51 || read_len > 1000 || n_pools == 0 || n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull)
+        return GF_E_UNSUPPORTED;
+    const AsmIO io{d_pool, nullptr, d_pool_off, n_pools, total_reads, read_len, min_count, min_contig, d_contigs, contig_cap, d_n_contigs,
+                   d_seq, seq_cap, d_seq_len, d_gap_error, nullptr, nullptr, 0};
+    const AsmGeom G = asm_geometry(ctx, n_pools, total_reads, read_len, (uint32_t)read_len - 29 + 1);
+    if (G.nt < 512) return GF_E_UNSUPPORTED;
+    AsmParams P[3];
+    for (int i = 0; i < 3; ++i) {
+        P[i] = asm_params(ctx, G, io, KS[i], KS[i] - 2);
+        if (!asm_pools_fit(G, P[i], KS[i])) return GF_E_UNSUPPORTED;
+    }
+    int rc;
+    if ((rc = asm_workspace(ctx, G, true))) return rc;
+    if ((rc = ensure(ctx, ctx->counters, GF_COUNTER_BYTES))) return rc;
+    // [16] work counter, [17] gaps in the launch order, [18 + i] the work counter of pair i's launch for listed pools, [21 + i] pools listed
+    uint32_t* d_next = (uint32_t*)ctx->counters.p + 16;
+    if ((rc = ensure(ctx, ctx->asm_big, 4 * n_pools * 4 + 64))) return rc;   // [listed by pair 0][pair 1][pair 2][gaps in launch order]
+    zero_regions(ctx, ZeroList{{(uint32_t*)d_n_contigs, (uint32_t*)d_seq_len, (uint32_t*)d_gap_error, d_next}, {1, 2, (uint32_t)n_pools, 8}});
+    uint32_t* d_order = (uint32_t*)ctx->asm_big.p + 3 * n_pools;
+    const bool ordered = n_pools >= 4 * (size_t)ctx->n_cu;
+    if (ordered)
+        hipLaunchKernelGGL(asm_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint64_t*)d_pool_off, (uint32_t)n_pools, d_order, d_next + 1);
+    for (int i = 0; i < 3; ++i) {
+        P[i] = asm_params(ctx, G, io, KS[i], KS[i] - 2);   // (again: the workspace pointers)
+        P[i].next_gap = d_next;
+        P[i].big_list = (uint32_t*)ctx->asm_big.p + (size_t)i * n_pools;
+        P[i].n_big = d_next + 5 + i;
+        P[i].gap_list = ordered ? d_order : nullptr;
+        P[i].n_gap_list = ordered ? d_next + 1 : nullptr;
+    }
+    {
+        LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
+        if (G.nt == 1024) hipLaunchKernelGGL(assemble_sweep_kernel<1024>, dim3(G.grid), dim3(1024), (size_t)P[0].lds_words * 4, ctx->stream, P[0], P[1], P[2]);
+        else hipLaunchKernelGGL(assemble_sweep_kernel<512>, dim3(G.grid), dim3(512), (size_t)P[0].lds_words * 4, ctx->stream, P[0], P[1], P[2]);
+        for (int i = 0; i < 3; ++i) asm_launch_big(ctx, G, P[i], d_next + 2 + i, P[i].big_list, P[i].n_big);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;

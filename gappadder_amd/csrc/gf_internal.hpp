@@ -104,6 +104,7 @@ struct gf_ctx {
     long asm_big_pool_reads = 131072;   // ... and pools beyond asm_max_pool_reads go to a second launch whose slices hold this many rows (a pool beyond this sets its gap_error)
     int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
     int asm_ranked = 1;          // count phase: ranked (perfect-hash) table behind the pre-count (k > 32, LDS)
+    int asm_sweep = 0;           // 1: gf_assemble_multi_dev runs the sweep 31/29, 41/39, 51/49 in one launch (measured 1 % slower than one launch per pair: DESIGN.md §5)
     int asm_pre_frac8 = 5;       // count phase: eighths of the LDS region the pre-count's bit arrays may take under an LDS table
     int asm_precount = 1;        // count phase: bit-array pre-count in LDS when min_count is 2 or 3 (0: every window goes to the table)
     void* asm_stats = nullptr;  // device u64[4], added to by every assembled gap: windows, k-mers counted exactly, surviving k-mers, nodes (option asm_stats_ptr)
@@ -186,6 +187,10 @@ int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* ta
                     size_t cap, void* d_n_out, const void* d_low, const void* d_n_low, size_t low_cap);
 
 // assemble.hip
+constexpr size_t GF_COUNTER_BYTES = 128;   // ctx->counters: [0, 8) screen, [8, 16) assembly / merge, [16, 32) the assembly sweep
+int launch_assemble_sweep(gf_ctx* ctx, const void* d_pool, const void* d_pool_off, size_t n_pools, size_t total_reads, int read_len,
+                          int min_count, int min_contig, void* d_contigs, size_t contig_cap, void* d_n_contigs, void* d_seq,
+                          size_t seq_cap, void* d_seq_len, void* d_gap_error);
 int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const void* d_pool_off, size_t n_pools,
                     size_t total_reads, int read_len, int k, int kv, int min_count, int min_contig, void* d_contigs,
                     size_t contig_cap, void* d_n_contigs, void* d_seq, size_t seq_cap, void* d_seq_len, void* d_gap_error,

@@ -310,7 +310,7 @@ int gf_quick_check_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off,
         return GF_E_INVAL;
     GF_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->counters, GF_COUNTER_BYTES))) return rc;
     uint32_t* d_next = (uint32_t*)ctx->counters.p + 9;
     uint32_t* d_err = (uint32_t*)d_n_out + 1;   // the caller's second word: skipped sets (bit 0: a contig shorter than 30 bases, bit 1: more contigs than max_set_contigs)
     zero_regions(ctx, ZeroList{{(uint32_t*)d_n_out, d_next, nullptr, nullptr}, {2, 1, 0, 0}});
@@ -399,7 +399,7 @@ int gf_overlap_evaluate_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig
     }
     GF_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->counters, GF_COUNTER_BYTES))) return rc;
     uint32_t* d_next = (uint32_t*)ctx->counters.p + 11;
     zero_regions(ctx, ZeroList{{d_next, nullptr, nullptr, nullptr}, {1, 0, 0, 0}});
     if (!n_pairs) return GF_OK;

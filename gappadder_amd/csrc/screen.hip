@@ -1864,7 +1864,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     if (rb > 250) return GF_E_UNSUPPORTED;
     int rc;
     if ((rc = ensure(ctx, ctx->cand, std::max<size_t>(n_reads, 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->counters, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->counters, GF_COUNTER_BYTES))) return rc;
     uint32_t* d_cnt = (uint32_t*)ctx->counters.p;  // [0] n_cand, [1] overflow
     zero_regions(ctx, ZeroList{{d_cnt, (uint32_t*)d_n_out, nullptr, nullptr}, {5, 1, 0, 0}});  // [0] n_cand [1] error overflow [2] [3] [4] the overflow lists of the verification passes
     if (n_reads == 0) return GF_OK;

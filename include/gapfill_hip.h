@@ -118,7 +118,9 @@ int gf_stream_wait_after_filter(gf_ctx* waiter, gf_ctx* producer);
  * Assembly: "asm_simplify" (rounds of tip clipping + bubble popping — Velvet's defaults, which the reference runs with
  * (assemble_gaps.py:117); default 8 (where the rounds have converged), 0 = raw unitigs), "asm_max_pool_reads" (device variants: upper bound on the rows of one
  * pool; the assembly workspace is then one slice of that size per workgroup instead of one per pool row — a pool beyond the bound
- * sets its gap_error; 0 = no bound). */
+ * sets its gap_error; 0 = no bound), "asm_sweep" (1: gf_assemble_multi_dev runs the k list 31/29, 41/39, 51/49 as ONE launch in which a
+ * workgroup assembles a gap three times — same contigs, a gap's contigs in (k, kv) order; default 0 = one launch per pair, which measured
+ * 1 % faster at C5). */
 int gf_set_option(gf_ctx* ctx, const char* name, long value);
 
 /* ---- gaps + flanks (gnrt_pos_true_seqs.py:12-100 defines them; host-side there and here) ----------- */

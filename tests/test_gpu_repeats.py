@@ -132,7 +132,7 @@ def test_deep_pools_are_built_and_assembled_without_loss(gf, work):
     sizes = np.diff(off)
     assert sizes.max() > 5000 and np.median(sizes) < 1000
     # assembly: slices of 2 000 rows for the main launch, the deep pools through the second launch
-    ccap, scap = 1 << 20, 1 << 28
+    ccap, scap = 1 << 21, 1 << 28
     d_ctg = torch.zeros(ccap * 32, dtype=torch.uint8, device=dev)
     d_seq = torch.zeros(scap, dtype=torch.uint8, device=dev)
     d_cnt = torch.zeros(8, dtype=torch.int32, device=dev)
@@ -161,3 +161,38 @@ def test_deep_pools_are_built_and_assembled_without_loss(gf, work):
         exp = CO.assemble_pool(blob, L, K, KV)
         got = sorted(by_gap.get(g, []), key=lambda c: (-len(c[0]), c[0]))
         assert got == exp, (g, int(sizes[g]))
+    # the pipeline's sweep 31/29, 41/39, 51/49: one fused launch (option asm_sweep, a workgroup assembles a gap three times) against one
+    # launch per pair — the same contigs, a gap's contigs in (k, kv) order in the list, the pools beyond the slices through the
+    # second launches of all three pairs
+    ks3, kvs3 = (C.c_int * 3)(31, 41, 51), (C.c_int * 3)(29, 39, 49)
+    runs = {}
+    for sweep in (1, 0):
+        gf.set_option("asm_max_pool_reads", 1200)
+        gf.set_option("asm_sweep", sweep)
+        try:
+            assert lib.gf_assemble_multi_dev(h, d_pool.data_ptr(), None, d_off.data_ptr(), n_gaps, pool_cap, L, ks3, kvs3, 3, 2, 40, d_ctg.data_ptr(),
+                                             ccap, d_cnt.data_ptr(), d_seq.data_ptr(), scap, d_cnt.data_ptr() + 8, d_gerr.data_ptr()) == 0
+            gf.sync()
+        finally:
+            gf.set_option("asm_max_pool_reads", 0)
+            gf.set_option("asm_sweep", 0)
+        cnt = d_cnt.cpu().numpy()
+        nc, ns = int(cnt[0]), int(cnt[2:4].view(np.uint64)[0])
+        ge = d_gerr.cpu().numpy()
+        assert nc <= ccap and ns <= scap, (sweep, nc, ns)
+        assert not ge.any(), (sweep, np.nonzero(ge)[0][:8].tolist(), ge[ge != 0][:8].tolist(), sizes[ge != 0][:8].tolist())
+        ctg = np.frombuffer(d_ctg[:nc * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
+        seq = d_seq[:ns].cpu().numpy().tobytes()
+        per = {}
+        for x in ctg:
+            per.setdefault(int(x["gap"]), []).append((int(x["k"]), seq[int(x["seq_off"]):int(x["seq_off"]) + int(x["length"])], int(x["n_nodes"]), int(x["cov_sum"])))
+        for g, lst in per.items():
+            assert [c[0] for c in lst] == sorted(c[0] for c in lst), g      # (k, kv) order inside a gap
+        runs[sweep] = {g: sorted(lst) for g, lst in per.items()}
+    assert (sizes > 1200).sum() >= 3 and len(runs[1]) == len(runs[0]) > n_gaps // 2
+    assert runs[1] == runs[0]
+    for g in deep[-1:] + list(range(8)):
+        blob = CO.unpack_reads(pool[off[g]:off[g + 1]], L)
+        for k, kv in ((31, 29), (41, 39), (51, 49)):
+            exp = sorted((k, s.encode(), n, cov) for s, n, cov in CO.assemble_pool(blob, L, k, kv))
+            assert [c for c in runs[1].get(g, []) if c[0] == k] == exp, (g, k)
