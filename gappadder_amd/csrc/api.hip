@@ -146,9 +146,10 @@ void gf_destroy(gf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
-    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->binmap, &ctx->binmap_fine, &ctx->bam_stream, &ctx->bam_recs, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->asm_jump, &ctx->asm_big, &ctx->rowgap, &ctx->pool_ws, &ctx->xchg_ws, &ctx->xchg_ws2, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->tag_stage, &ctx->bam_stream, &ctx->bam_recs, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->asm_jump, &ctx->asm_big, &ctx->rowgap, &ctx->pool_ws, &ctx->xchg_ws, &ctx->xchg_ws2, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
         if (b->p) (void)hipFree(b->p);
     for (auto& kv : ctx->anchor_tabs) if (kv.second.p) (void)hipFree(kv.second.p);
+    drop_tag_maps(ctx);
     if (ctx->d_gaps) (void)hipFree(ctx->d_gaps);
     if (ctx->d_scaf_off) (void)hipFree(ctx->d_scaf_off);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -225,8 +226,8 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
         ctx->index.clear();
         return GF_OK;
     }
-    if (!strcmp(name, "tag_bins_log2")) { ctx->tag_bins_log2 = std::max(13, std::min(19, (int)value)); ctx->bin_dist2 = -1; return GF_OK; }
-    if (!strcmp(name, "tag_fine_log2")) { ctx->tag_fine_log2 = std::max(20, std::min(28, (int)value)); ctx->bin_dist2 = -1; return GF_OK; }
+    if (!strcmp(name, "tag_bins_log2")) { ctx->tag_bins_log2 = std::max(13, std::min(19, (int)value)); drop_tag_maps(ctx); return GF_OK; }
+    if (!strcmp(name, "tag_fine_log2")) { ctx->tag_fine_log2 = std::max(20, std::min(28, (int)value)); drop_tag_maps(ctx); return GF_OK; }
     if (!strcmp(name, "tag_nt")) { ctx->tag_nt = value != 0; return GF_OK; }
     if (!strcmp(name, "screen_pf4_cap8")) { ctx->screen_pf4_cap8 = (int)value; return GF_OK; }
     if (!strcmp(name, "screen_ext")) { ctx->screen_ext = value != 0; return GF_OK; }
@@ -251,7 +252,7 @@ int gf_set_gaps(gf_ctx* ctx, const gf_gap* gaps, size_t n_gaps, uint32_t n_scaff
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
     ctx->index.clear();
     ctx->gaps.assign(gaps, gaps + n_gaps);
-    ctx->bin_dist2 = -1;
+    drop_tag_maps(ctx);
     ctx->low_rows.clear();
     ctx->rowgap_rows.clear();
     ctx->n_scaffolds = n_scaffolds;

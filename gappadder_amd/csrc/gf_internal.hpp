@@ -109,21 +109,27 @@ struct gf_ctx {
     int asm_precount = 1;        // count phase: bit-array pre-count in LDS when min_count is 2 or 3 (0: every window goes to the table)
     void* asm_stats = nullptr;  // device u64[4], added to by every assembled gap: windows, k-mers counted exactly, surviving k-mers, nodes (option asm_stats_ptr)
     void* asm_dbg = nullptr;  // diagnostic: device buffer for per-gap phase stamps (option asm_dbg_ptr)
-    // tagger coarse bin map (rebuilt when dist2 changes)
-    std::vector<uint32_t> bin_host;
+    // tagger bin maps, one per dist2 (a pipeline tags every library with its own window; the four last used stay): the device copy is
+    // [bits | n_scaffolds + 1 bit offsets | per bin: the first gap of the scaffold whose right window reaches the bin]
+    struct TagMap {
+        int dist2 = -1, shift = 0;
+        uint32_t words = 0, fine_words = 0, fine_shift = 0;
+        uint64_t used = 0;
+        gf::DevBuf map, fine;
+    };
+    std::vector<TagMap> tag_maps;
+    uint64_t tag_map_clock = 0;
     // tagger: bits of the LDS bin map and of the global one behind it; non-temporal record loads.  Measured on the C4 layout (200 M
     // records, rocprof): 2^25-bit global map 2.24 ms; + nt loads (the record stream no longer evicts the map from the L2s) 1.90 ms;
     // 2^23 bits + nt 1.82 ms; 32 / 64 KiB LDS maps 2.85 / 3.13 ms (fewer workgroups per CU)
     int tag_bins_log2 = 17, tag_fine_log2 = 23, tag_nt = 1;
-    int bin_dist2 = -1, bin_shift = 0;
-    uint32_t bin_words = 0, fine_words = 0, fine_shift = 0;
     // second-hop table cache
     std::vector<uint32_t> low_rows, rowgap_rows;
     std::map<int, gf::DevBuf> anchor_tabs;   // by anchor length: the flank anchors of gf_pick_anchored_dev (dropped by gf_set_gaps)
     size_t low_b1 = 0, low_b2 = 0;
 
     // scratch
-    gf::DevBuf cand, cand2, part_ws, binmap, binmap_fine, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, asm_jump, asm_big, rowgap, pool_ws, xchg_ws, xchg_ws2, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, part_ws, tag_stage, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, asm_jump, asm_big, rowgap, pool_ws, xchg_ws, xchg_ws2, counters, stage_in, stage_out, stage_aux, table;
     size_t bam_n_recs = 0;       // alignment records gf_bam_pack left in bam_recs (for gf_tag_*_bam)
     size_t bam_stream_len = 0;   // inflated BAM bytes gf_bgzf_inflate left in bam_stream
     // timing
@@ -137,6 +143,7 @@ namespace gf {
 
 int set_hip_error(gf_ctx* ctx, hipError_t e, const char* what);
 int ensure(gf_ctx* ctx, DevBuf& b, size_t bytes);
+void drop_tag_maps(gf_ctx* ctx);   // (tagger.hip) frees the tagger's bin maps: the gaps or the map sizes changed
 
 #define GF_HIP(ctx, call)                                          \
     do {                                                           \

@@ -24,6 +24,7 @@ struct TagParams {
     // coarse bin map: bit (bin_off[s] + (POS >> bin_shift)) is set iff some window of scaffold s touches that bin
     const uint32_t* bin_bits;
     const uint32_t* bin_off;  // n_scaffolds + 1
+    const uint32_t* bin_first; // per bin: index of the first gap (of the scaffold) whose right window reaches the bin's first position
     uint32_t bin_shift, bin_words;
     uint32_t off_words;       // > 0: the n_scaffolds + 1 offsets follow the bits in the staged LDS copy as well
     // fine bin map (global, L2-resident, <= 4 MiB): same test on narrower bins for the records the LDS map lets through.
@@ -38,6 +39,7 @@ struct TagParams {
     gf_lowrec* low;
     uint32_t low_cap;
     uint32_t* n_low;
+    gf_lowrec* low_stage;     // LOWSTAGE entries per wave of the launch: where a wave collects its MAPQ==0 records (see flush_low)
 };
 
 // A single global counter serialises returning atomics at ~11 ns each (MI355X_MICROARCH.md "dequeue"/"fanin" rows), so hits are
@@ -75,9 +77,9 @@ __device__ __forceinline__ void emit_hit(bool want, const gf_taghit& h, WaveHits
 
 // Records are streamed as whole 1-KiB wave loads (16 B per lane, consecutive lanes = consecutive 16-B halves):
 // the even lane of a pair holds {pos, mate_pos, tlen, ref}, the odd lane {mate_ref, flag|mapq|clip, read id}.
-// Even lanes run the coarse bin test; the rare survivors pull their second half from the neighbour lane.
+// Two loads = 64 records; lane L gathers record L's fields from the lanes that hold its halves (tag_kernel).
 struct LiveRec { uint32_t pos, ref, mate_ref, meta; int32_t tlen; uint32_t rec; };   // a record that passed the bin map
-constexpr uint32_t LIVEQ = 96;   // per wave: < 64 waiting + <= 32 from one 1-KiB load
+constexpr uint32_t LIVEQ = 96;   // per wave: < 64 waiting + what one step adds (a step that would overflow it drains first)
 // With a second, finer map in global memory (human scale) the records that pass the LDS map (a twentieth) are not looked up in it on
 // the spot — nearly every 1-KiB step has such a lane, and the whole wave then waits for two dependent global loads (PMC: waves wait
 // 79 % of their cycles in a kernel that only streams) — but queued with 12 bytes each and sifted 64 at a time; the few that pass
@@ -88,6 +90,7 @@ __device__ __forceinline__ void tag_wave_sync() {   // LDS hand-off between lane
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+constexpr uint32_t LOWSTAGE = 1024;   // MAPQ==0 records a wave collects before it appends them to the list
 constexpr int TAG_UNROLL = 8;  // 8 KiB (256 records) per wave and stage, two stages in flight
 
 // NW waves per workgroup.  BINS_LDS: the coarse bin map is staged in LDS (the stand-alone form: 33 KiB of LDS per workgroup at
@@ -98,24 +101,44 @@ template <int NW, bool BINS_LDS, bool NT = false, bool FINEQ = false>
 __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
     extern __shared__ uint32_t bins_lds[];  // the whole bin map (16 or 64 KiB), staged once per workgroup
     __shared__ gf_taghit whits[NW][WHCAP];
-    constexpr uint32_t LOWBUF = NW > 4 ? 64 : 128;    // MAPQ==0 records buffered per wave (one global atomic per ~32-128 of them)
-    __shared__ gf_lowrec lowbuf[NW][LOWBUF];
     __shared__ LiveRec liveq[NW][LIVEQ];
     __shared__ CandRec candq[FINEQ ? NW : 1][FINEQ ? CANDQ : 1];
-    uint32_t low_n = 0;                 // wave-uniform
+    // MAPQ==0 records (2 % of a library) leave through ONE counter, and returning atomics on one address are served at ~11-15 ns
+    // each: flushing a 64-entry LDS buffer per wave straight to the list, the 900 M records of C4 needed 360 000 of them — 4 of the
+    // kernel's 5.2 ms; the stream ran at 4.9 instead of 6.0 TB/s.  The LDS buffer (whole 768-byte runs: single 12-byte stores left
+    // partial lines in L2) now empties into the wave's private slice of a global staging buffer, without an atomic, and the slice
+    // moves to the list 1 000 records at a time: a twentieth of the atomics.
+    constexpr uint32_t LOWBUF = 64;
+    __shared__ gf_lowrec lowbuf[NW][LOWBUF];
+    uint32_t low_n = 0, stage_n = 0;    // wave-uniform: records in the LDS buffer, in the staging slice
     WaveHits hb{whits[threadIdx.x >> 6], 0};
     if (BINS_LDS) for (uint32_t i = threadIdx.x; i < P.bin_words + P.off_words; i += blockDim.x) bins_lds[i] = P.bin_bits[i];   // (bits, then offsets: one array)
     const uint32_t* bins = BINS_LDS ? bins_lds : P.bin_bits;
     const uint32_t* boff = BINS_LDS && P.off_words ? bins_lds + P.bin_words : P.bin_off;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    gf_lowrec* wlow = lowbuf[threadIdx.x >> 6];
-    auto flush_low = [&]() {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    gf_lowrec* const wlow = lowbuf[threadIdx.x >> 6];
+    gf_lowrec* const wstage = P.low ? P.low_stage + wave * LOWSTAGE : nullptr;
+    auto flush_stage = [&]() {
         uint32_t gb = 0;
-        if (lane == 0) gb = atomicAdd(P.n_low, low_n);
+        if (lane == 0) gb = atomicAdd(P.n_low, stage_n);
         gb = __shfl(gb, 0);
-        for (uint32_t i = lane; i < low_n; i += 64)
-            if (gb + i < P.low_cap) P.low[gb + i] = wlow[i];
+        const uint32_t fit = gb < P.low_cap ? (stage_n < P.low_cap - gb ? stage_n : P.low_cap - gb) : 0;
+        // the wave reads its own stores back from L2 (a store is acknowledged once it is there; the loads bypass the CU's L1,
+        // which may still hold the slice as the previous flush read it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t* src32 = reinterpret_cast<const uint32_t*>(wstage);
+        uint32_t* dst32 = reinterpret_cast<uint32_t*>(P.low + gb);
+        for (uint32_t i = lane; i < 3 * fit; i += 64) dst32[i] = __hip_atomic_load(src32 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stage_n = 0;
+    };
+    auto flush_low = [&]() {   // LDS buffer -> staging slice
+        if (stage_n + low_n > LOWSTAGE) flush_stage();
+        const uint32_t* src32 = reinterpret_cast<const uint32_t*>(wlow);
+        uint32_t* dst32 = reinterpret_cast<uint32_t*>(wstage + stage_n);
+        for (uint32_t i = lane; i < 3 * low_n; i += 64) dst32[i] = src32[i];
+        stage_n += low_n;
         low_n = 0;
     };
     // ---- per-wave queue of records that passed the bin map
@@ -131,24 +154,26 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
             r.pos = q.pos; r.ref = q.ref; r.tlen = q.tlen; r.mate_ref = q.mate_ref;
             r.flag = (uint16_t)(q.meta & 0xFFFF); r.mapq = (uint8_t)((q.meta >> 16) & 0xFF); r.clipflag = (uint8_t)(q.meta >> 24);
             rec = q.rec;
-            g = P.scaf_off[r.ref];
             g_end = P.scaf_off[r.ref + 1];
-            // first gap whose right window can still reach POS: end + dist2 > pos  (ends ascend)
-            uint32_t lo = g, hi = g_end;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if ((int64_t)P.gaps[mid].end + P.dist2 > (int64_t)r.pos) hi = mid; else lo = mid + 1;
-            }
-            g = lo;
+            // the first gap whose right window reaches the record's BIN (one load; the map's third part) — gaps between it and the first
+            // one whose window reaches POS itself (end + dist2 > pos; two gaps within one bin) fall through the walk below untagged
+            g = P.bin_first[boff[r.ref] + (r.pos >> P.bin_shift)];
         }
         const int64_t pos = r.pos;
-        // walk the (few) gaps whose windows can contain POS; lanes without work idle through the ballots
-        while (true) {
-            bool more = live && g < g_end && (int64_t)P.gaps[g].start - P.dist2 < pos;
+        // walk the (few) gaps whose windows can contain POS; lanes without work idle through the ballots.  The first two gaps are
+        // loaded together (the walk ends at the first gap whose left window starts behind POS: as a rule the second one), so the
+        // common walk is two dependent round trips — bin -> first gap, gaps — instead of four
+        gf_gap gq[2] = {};
+        if (live && g < g_end) gq[0] = P.gaps[g];
+        if (live && g + 1 < g_end) gq[1] = P.gaps[g + 1];
+        for (uint32_t it = 0;; ++it) {
+            gf_gap gp = it == 0 ? gq[0] : gq[1];
+            if (it >= 2 && live && g < g_end) gp = P.gaps[g];
+            const bool more = live && g < g_end && (int64_t)gp.start - P.dist2 < pos;
+            live = more;          // (a lane whose walk has ended stays out: every lane still walking is at its first gap + it)
             if (!__any(more)) break;
             bool clip = false, pair = false, unmap = false;
             if (more) {
-                const gf_gap gp = P.gaps[g];
                 const int64_t il = (int64_t)gp.start - pos, ir = pos - (int64_t)gp.end;
                 int tag = -1;  // 0: 0c, 1: 0d, 2: 1c, 3: 1d
                 if (il >= 0 && il < P.dist2) tag = il <= P.clip_dist ? 0 : 1;
@@ -178,7 +203,6 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
         tag_wave_sync();
         live_n = base;
     };
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n_half = 2 * P.n;                       // 16-byte halves
     const uint64_t chunk = 64ull * TAG_UNROLL;             // halves per wave iteration
@@ -232,21 +256,26 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
 #pragma unroll
         for (int u = 0; u < TAG_UNROLL; ++u) v[u] = vn[u];
         fetch(h0 + n_waves * chunk);
+        // Two 1-KiB loads hold 64 records as 128 halves, even lanes {pos, mate_pos, tlen, ref}, odd lanes {mate_ref, flag|mapq|clip, ..}:
+        // lane L takes record L of the 64 — its halves sit in lanes 2L and 2L + 1 of the first load (L < 32) or of the second — so
+        // that every step below works on 64 records, not on the 32 even lanes of one load (the kernel issues ~60 instructions per step
+        // whatever the number of busy lanes: at 13 % of the records passing the map, the long-insert library, it was issue-bound).
+        const uint32_t s0 = (lane << 1) & 63u, s1 = s0 + 1;
+        const bool upper = lane >= 32;
 #pragma unroll
-        for (int u = 0; u < TAG_UNROLL; ++u) {
-            const uint64_t h = h0 + 64ull * u + lane;
-            // neighbour's half (odd lane -> second half of the even lane's record)
-            uint4 nb;
-            nb.x = __shfl_down(v[u].x, 1);
-            nb.y = __shfl_down(v[u].y, 1);
-            bool live = !(lane & 1) && h < n_half;
+        for (int u = 0; u < TAG_UNROLL; u += 2) {
+            auto gather = [&](uint32_t a, uint32_t b, uint32_t sl) -> uint32_t {
+                const uint32_t x = __shfl(a, sl), y = __shfl(b, sl);
+                return upper ? y : x;
+            };
+            const uint64_t h = h0 + 64ull * u + 2ull * lane;      // first half of this lane's record
             gf_alnrec r = {};
-            if (live) {
-                r.pos = v[u].x; r.mate_pos = v[u].y; r.tlen = (int32_t)v[u].z; r.ref = v[u].w;
-                live = r.ref < P.n_scaffolds;
-            }
+            r.pos = gather(v[u].x, v[u + 1].x, s0);
+            r.ref = gather(v[u].w, v[u + 1].w, s0);               // (halves beyond the input carry ref = 0xFFFFFFFF)
+            const uint32_t meta = gather(v[u].y, v[u + 1].y, s1);
+            bool live = h < n_half && r.ref < P.n_scaffolds;
             if (P.low) {   // wave-uniform: compact the MAPQ==0 records for the second hop
-                const bool z = live && ((nb.y >> 16) & 0xFF) == 0;
+                const bool z = live && ((meta >> 16) & 0xFF) == 0;
                 const unsigned long long zb = __ballot(z);
                 if (zb) {
                     const uint32_t cnt = (uint32_t)__popcll(zb);
@@ -262,8 +291,10 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
             if (FINEQ) {   // (launched with FINEQ only when the fine map exists)
                 const unsigned long long cb = __ballot(live);
                 if (!cb) continue;
+                const uint32_t cnt = (uint32_t)__popcll(cb);
+                if (cand_n + cnt > CANDQ) sift();                  // (cand_n < 64 on entry: one sift empties the queue)
                 if (live) wcand[cand_n + __popcll(cb & ((1ull << lane) - 1))] = CandRec{r.pos, r.ref, (uint32_t)(h >> 1)};
-                cand_n += (uint32_t)__popcll(cb);   // < 64 + 32 <= CANDQ
+                cand_n += cnt;
                 tag_wave_sync();
                 if (cand_n >= 64) sift();
                 continue;
@@ -272,16 +303,19 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
                 const uint32_t f0 = P.fine_off[r.ref], fi = r.pos >> P.fine_shift, fb = f0 + fi;
                 live = fi < P.fine_off[r.ref + 1] - f0 && ((P.fine_bits[fb >> 5] >> (fb & 31)) & 1u);
             }
-            // survivors (a few per mille) are queued; the window search below runs on 64 of them at a time instead of
-            // once per 1-KiB load with one or two busy lanes
+            // survivors (a few per mille to a tenth) are queued; the window search runs on 64 of them at a time instead of once per
+            // load with a few busy lanes
             const unsigned long long lb = __ballot(live);
             if (!lb) continue;
+            const uint32_t tlen = gather(v[u].z, v[u + 1].z, s0), mate_ref = gather(v[u].x, v[u + 1].x, s1);
+            const uint32_t cnt = (uint32_t)__popcll(lb);
+            if (live_n + cnt > LIVEQ) drain();                     // (live_n < 64 on entry: one drain empties the queue)
             if (live) {
                 LiveRec q;
-                q.pos = r.pos; q.ref = r.ref; q.tlen = r.tlen; q.mate_ref = nb.x; q.meta = nb.y; q.rec = (uint32_t)(h >> 1);
+                q.pos = r.pos; q.ref = r.ref; q.tlen = (int32_t)tlen; q.mate_ref = mate_ref; q.meta = meta; q.rec = (uint32_t)(h >> 1);
                 wlive[live_n + __popcll(lb & ((1ull << lane) - 1))] = q;
             }
-            live_n += (uint32_t)__popcll(lb);   // < 64 + 32 <= LIVEQ
+            live_n += cnt;
             tag_wave_sync();
             if (live_n >= 64) drain();
         }
@@ -289,6 +323,7 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
     if (FINEQ) while (cand_n) sift();
     while (live_n) drain();
     if (P.low && low_n) flush_low();
+    if (P.low && stage_n) flush_stage();
     if (hb.n) flush_wave_hits(hb, P.out, P.cap, P.n_out);
 }
 
@@ -427,15 +462,34 @@ static unsigned stream_grid(gf_ctx* ctx, size_t n) {
     return (unsigned)std::max<size_t>(1, std::min<size_t>(blocks, (size_t)ctx->n_cu * 8));
 }
 
-// Coarse bin map of the gap windows for one dist2 (host build: n_gaps work; cached until gaps or dist2 change).
+void drop_tag_maps(gf_ctx* ctx) {
+    if (ctx->tag_maps.empty()) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (gf_ctx::TagMap& m : ctx->tag_maps) {
+        if (m.map.p) (void)hipFree(m.map.p);
+        if (m.fine.p) (void)hipFree(m.fine.p);
+    }
+    ctx->tag_maps.clear();
+}
+
+// Coarse bin map of the gap windows for one dist2 (host build: n_gaps work; kept until the gaps change, the four last used dist2).
 // Bits cover, per scaffold, positions 0 .. last window end; everything beyond has no window.
-static int ensure_bin_map(gf_ctx* ctx, int dist2) {
-    if (ctx->bin_dist2 == dist2 && ctx->binmap.p) return GF_OK;
+static int ensure_bin_map(gf_ctx* ctx, int dist2, gf_ctx::TagMap** out) {
+    for (gf_ctx::TagMap& m : ctx->tag_maps)
+        if (m.dist2 == dist2 && m.map.p) { m.used = ++ctx->tag_map_clock; *out = &m; return GF_OK; }
+    if (ctx->tag_maps.size() >= 4) {   // drop the one that was not used for the longest time
+        size_t old = 0;
+        for (size_t i = 1; i < ctx->tag_maps.size(); ++i) if (ctx->tag_maps[i].used < ctx->tag_maps[old].used) old = i;
+        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->tag_maps[old].map.p) (void)hipFree(ctx->tag_maps[old].map.p);
+        if (ctx->tag_maps[old].fine.p) (void)hipFree(ctx->tag_maps[old].fine.p);
+        ctx->tag_maps.erase(ctx->tag_maps.begin() + (long)old);
+    }
+    gf_ctx::TagMap M;
     const int64_t d2 = dist2 > 0 ? dist2 : 0;
     std::vector<uint64_t> span(ctx->n_scaffolds, 0);  // exclusive end of the covered positions per scaffold
     for (const gf_gap& g : ctx->gaps) span[g.scaffold] = std::max<uint64_t>(span[g.scaffold], (uint64_t)g.end + d2);
-    uint64_t total = 0;
-    for (uint64_t v : span) total += v;
     auto nbits = [&](int sh) { uint64_t t = 0; for (uint64_t v : span) t += (v >> sh) + (v ? 1 : 0); return t; };
     // one map = bit words followed by the n_scaffolds+1 bit offsets
     auto build = [&](int shift, std::vector<uint32_t>& h, uint32_t& words) {
@@ -456,7 +510,7 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
     int shift = 6;
     while (nbits(shift) > (1u << ctx->tag_bins_log2)) ++shift;  // <= 16 KiB of LDS by default (measured: an 8 KiB map sends more records down the slow path and loses)
     uint32_t words = 0;
-    std::vector<uint32_t>& h = ctx->bin_host;
+    std::vector<uint32_t> h;
     build(shift, h, words);
     // Many gaps on a large genome (human scale: 19 840 windows over 3.1 Gb) leave a 16-KiB map with 24-kb bins, a fifth of them
     // set: then a 64-KiB map (6-kb bins, a twentieth set) shared by ONE 16-wave workgroup per CU takes its place — the same 16 waves
@@ -470,15 +524,33 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
             build(shift, h, words);
         }
     }
-    int rc = ensure(ctx, ctx->binmap, h.size() * 4);
+    uint64_t set_bits = 0;
+    for (uint32_t i = 0; i < words; ++i) set_bits += (uint64_t)__builtin_popcount(h[i]);
+    // Behind the offsets: per bin, the first gap of the scaffold whose RIGHT window still reaches the bin's first position
+    // (end + dist2 > bin << shift; ends ascend) — where the window search of a record in that bin starts.  It replaces a binary
+    // search over the scaffold's gaps (five dependent loads at 32 gaps per scaffold) by one load.
+    {
+        const size_t n_off = (size_t)ctx->n_scaffolds + 1;
+        const uint32_t total_bits = h[words + ctx->n_scaffolds];
+        std::vector<uint32_t> first(total_bits, 0);
+        size_t g = 0;
+        for (uint32_t s = 0; s < ctx->n_scaffolds; ++s) {
+            while (g < ctx->gaps.size() && ctx->gaps[g].scaffold < s) ++g;
+            const uint32_t b0 = h[words + s], nb = h[words + s + 1] - b0;
+            for (uint32_t b = 0; b < nb; ++b) {
+                while (g < ctx->gaps.size() && ctx->gaps[g].scaffold == s && (int64_t)ctx->gaps[g].end + d2 <= ((int64_t)b << shift)) ++g;
+                first[b0 + b] = (uint32_t)g;   // (== the scaffold's last gap + 1 when no window reaches the bin)
+            }
+        }
+        h.resize(words + n_off);
+        h.insert(h.end(), first.begin(), first.end());
+    }
+    int rc = ensure(ctx, M.map, h.size() * 4);
     if (rc) return rc;
-    GF_HIP(ctx, hipMemcpyAsync(ctx->binmap.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(M.map.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // Human-scale genomes leave the LDS map with ~24 kb bins, a third of them set by 20 000 gaps: a second, finer map in
     // global memory (<= 2^25 bits, stays in L2) restores the per-mille pass rate before the window search.
-    ctx->fine_words = 0;
-    uint64_t set_bits = 0;
-    for (uint32_t i = 0; i < words; ++i) set_bits += (uint64_t)__builtin_popcount(h[i]);
     if (shift > 9 && set_bits * 20 > nbits(shift)) {   // worth a second look-up only when the LDS map passes > 5 %
         int fs = 7;
         while (nbits(fs) > (1u << ctx->tag_fine_log2)) ++fs;
@@ -494,19 +566,21 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2) {
             for (uint32_t i = 0; i < fw; ++i) set_fine += (uint64_t)__builtin_popcount(hf[i]);
             const double cover_lds = (double)set_bits * (double)(1ull << shift), cover_fine = (double)set_fine * (double)(1ull << fs);
             if (cover_fine <= 0.6 * cover_lds) {
-                rc = ensure(ctx, ctx->binmap_fine, hf.size() * 4);
-                if (rc) return rc;
-                GF_HIP(ctx, hipMemcpyAsync(ctx->binmap_fine.p, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                rc = ensure(ctx, M.fine, hf.size() * 4);
+                if (rc) { (void)hipFree(M.map.p); return rc; }
+                GF_HIP(ctx, hipMemcpyAsync(M.fine.p, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
                 GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                ctx->fine_words = fw;
-                ctx->fine_shift = fs;
+                M.fine_words = fw;
+                M.fine_shift = fs;
             }
         }
     }
-    ctx->bin_dist2 = dist2;
-    ctx->bin_shift = shift;
-    ctx->bin_words = words;
-    (void)total;
+    M.dist2 = dist2;
+    M.shift = shift;
+    M.words = words;
+    M.used = ++ctx->tag_map_clock;
+    ctx->tag_maps.push_back(M);
+    *out = &ctx->tag_maps.back();
     return GF_OK;
 }
 
@@ -534,40 +608,51 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
     P.out = (gf_taghit*)d_out;
     P.cap = (uint32_t)cap;
     P.n_out = (uint32_t*)d_n_out;
-    int rc = ensure_bin_map(ctx, P.dist2);
+    gf_ctx::TagMap* M = nullptr;
+    int rc = ensure_bin_map(ctx, P.dist2, &M);
     if (rc) return rc;
-    P.bin_bits = (const uint32_t*)ctx->binmap.p;
-    P.bin_off = P.bin_bits + ctx->bin_words;
-    P.bin_shift = ctx->bin_shift;
-    P.bin_words = ctx->bin_words;
+    P.bin_bits = (const uint32_t*)M->map.p;
+    P.bin_off = P.bin_bits + M->words;
+    P.bin_first = P.bin_off + ctx->n_scaffolds + 1;
+    P.bin_shift = M->shift;
+    P.bin_words = M->words;
     P.off_words = ctx->n_scaffolds + 1 <= 2048 ? ctx->n_scaffolds + 1 : 0;   // the per-scaffold offsets ride along in LDS when they are few
-    size_t lds_map = ((size_t)ctx->bin_words + P.off_words) * 4;
+    size_t lds_map = ((size_t)M->words + P.off_words) * 4;
     // the 16-wave form keeps TAG16_STATIC_LDS bytes of queues and buffers beside the staged map: when the two do not fit a CU's LDS
     // the per-scaffold offsets stay in global memory
-    if ((size_t)ctx->bin_words * 4 > 32 * 1024 && TAG16_STATIC_LDS + lds_map > 160 * 1024) {
+    if ((size_t)M->words * 4 > 32 * 1024 && TAG16_STATIC_LDS + lds_map > 160 * 1024) {
         P.off_words = 0;
-        lds_map = (size_t)ctx->bin_words * 4;
+        lds_map = (size_t)M->words * 4;
         if (TAG16_STATIC_LDS + lds_map > 160 * 1024) return GF_E_UNSUPPORTED;   // (a 64-KiB map is the largest ensure_bin_map builds)
     }
-    P.fine_bits = ctx->fine_words ? (const uint32_t*)ctx->binmap_fine.p : nullptr;
-    P.fine_off = P.fine_bits ? P.fine_bits + ctx->fine_words : nullptr;
-    P.fine_shift = ctx->fine_shift;
+    P.fine_bits = M->fine_words ? (const uint32_t*)M->fine.p : nullptr;
+    P.fine_off = P.fine_bits ? P.fine_bits + M->fine_words : nullptr;
+    P.fine_shift = M->fine_shift;
+    const size_t map_bytes = (size_t)M->words * 4;
+    // workgroups x waves of the variant that runs (the staging buffer of the MAPQ-0 by-product has a slice per wave)
+    const bool big_map = map_bytes > 32 * 1024;
+    const unsigned nw = ctx->tag_light ? 1u : big_map ? 16u : 4u;
+    const unsigned grid = ctx->tag_light ? 4 * stream_grid(ctx, n)
+                          : big_map ? (unsigned)std::max<size_t>(1, std::min<size_t>((n + 1023) / 1024, (size_t)ctx->n_cu)) : stream_grid(ctx, n);
+    P.low_stage = nullptr;
+    if (P.low) {
+        if ((rc = ensure(ctx, ctx->tag_stage, (size_t)grid * nw * LOWSTAGE * sizeof(gf_lowrec)))) return rc;
+        P.low_stage = (gf_lowrec*)ctx->tag_stage.p;
+    }
     {
         LaunchTimer tm(ctx, GF_KERNEL_TAG);
         if (ctx->tag_light)   // one-wave workgroups without the LDS bin map: co-resident with the k-mer filter's workgroups
-            hipLaunchKernelGGL((tag_kernel<1, false>), dim3(4 * stream_grid(ctx, n)), dim3(64), 0, ctx->stream, P);
-        else if ((size_t)ctx->bin_words * 4 > 32 * 1024 && P.fine_bits)   // the 64-KiB map: one 16-wave workgroup per CU
-            hipLaunchKernelGGL((tag_kernel<16, true, true, true>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + 1023) / 1024, (size_t)ctx->n_cu))), dim3(1024),
-                               lds_map, ctx->stream, P);
-        else if ((size_t)ctx->bin_words * 4 > 32 * 1024)
-            hipLaunchKernelGGL((tag_kernel<16, true, true, false>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + 1023) / 1024, (size_t)ctx->n_cu))), dim3(1024),
-                               lds_map, ctx->stream, P);
+            hipLaunchKernelGGL((tag_kernel<1, false>), dim3(grid), dim3(64), 0, ctx->stream, P);
+        else if (big_map && P.fine_bits)   // the 64-KiB map: one 16-wave workgroup per CU
+            hipLaunchKernelGGL((tag_kernel<16, true, true, true>), dim3(grid), dim3(1024), lds_map, ctx->stream, P);
+        else if (big_map)
+            hipLaunchKernelGGL((tag_kernel<16, true, true, false>), dim3(grid), dim3(1024), lds_map, ctx->stream, P);
         else if (ctx->tag_nt && P.fine_bits)
-            hipLaunchKernelGGL((tag_kernel<4, true, true, true>), dim3(stream_grid(ctx, n)), dim3(256), lds_map, ctx->stream, P);
+            hipLaunchKernelGGL((tag_kernel<4, true, true, true>), dim3(grid), dim3(256), lds_map, ctx->stream, P);
         else if (ctx->tag_nt)
-            hipLaunchKernelGGL((tag_kernel<4, true, true>), dim3(stream_grid(ctx, n)), dim3(256), lds_map, ctx->stream, P);
+            hipLaunchKernelGGL((tag_kernel<4, true, true>), dim3(grid), dim3(256), lds_map, ctx->stream, P);
         else
-            hipLaunchKernelGGL((tag_kernel<4, true>), dim3(stream_grid(ctx, n)), dim3(256), lds_map, ctx->stream, P);
+            hipLaunchKernelGGL((tag_kernel<4, true>), dim3(grid), dim3(256), lds_map, ctx->stream, P);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;

@@ -536,6 +536,28 @@ def test_tagger_on_human_scale_layout_uses_the_fine_bin_map(gf):
         assert _same(th, CO.tag_alignments(recs, gaps, d2, cd)) and len(th) > 1000
 
 
+def test_tagger_keeps_a_bin_map_per_library_and_starts_the_window_search_from_the_bin(gf):
+    """One context tags several libraries in turn (a pipeline does: short inserts, then mate pairs, per batch): the bin map of every
+    dist2 stays cached (six insert sizes: the oldest maps are dropped and rebuilt), and the window search starts at the gap the
+    map's third part names for the record's bin — also where a bin holds several gaps (1-kb gaps every 4 kb, bins of 64 b to 8 kb)
+    and where windows of 13 kb overlap a dozen gaps either side."""
+    from gappadder_amd.hip_api import GapFill
+    for scaffold_len, n_scaf, per, gap_len in ((400_000, 6, 90, 1000), (5_000_000, 40, 32, 2000)):
+        cfg = GapFill.synth_cfg(seed=77, scaffold_len=scaffold_len, n_scaffolds=n_scaf, gaps_per_scaffold=per, gap_len=gap_len)
+        gaps, flanks = GapFill.synth_layout(cfg)
+        gf.set_gaps(gaps, n_scaf, flanks)
+        ocfg = np.frombuffer(cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
+        _, recs = CO.synth_pairs(ocfg, 0, 300_000)
+        want = {}
+        for rnd in range(2):
+            for ins, sd in ((300, 30), (5000, 500), (800, 60), (300, 30), (10000, 1000), (2000, 100), (150, 10), (5000, 500)):
+                if (ins, sd) not in want:
+                    want[(ins, sd)] = CO.tag_alignments(recs, gaps, ins, sd)
+                th = gf.tag_alignments(recs, ins, sd, cap=1 << 22)
+                assert _same(th, want[(ins, sd)]), (scaffold_len, rnd, ins, sd)
+        assert len(want[(10000, 1000)]) > len(want[(300, 30)]) > 400
+
+
 def test_partitioned_filter_probes_in_place_when_a_bucket_part_runs_full(gf):
     """Degenerate input for the partitioned filter: 60 000 poly-A reads put every probe into ONE bucket, eight
     times what a writer's part of it holds, so most pairs take the in-place path; the hits must still be the oracle's (the flank
