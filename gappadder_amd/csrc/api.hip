@@ -146,7 +146,7 @@ void gf_destroy(gf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
     for (auto& kv : ctx->index) free_flank_index(ctx, kv.second);
-    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->tag_stage, &ctx->bam_stream, &ctx->bam_recs, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->asm_jump, &ctx->asm_big, &ctx->rowgap, &ctx->pool_ws, &ctx->xchg_ws, &ctx->xchg_ws2, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
+    for (DevBuf* b : {&ctx->cand, &ctx->cand2, &ctx->part_ws, &ctx->tag_stage, &ctx->verify_stage, &ctx->bam_stream, &ctx->bam_recs, &ctx->asm_table, &ctx->asm_surv, &ctx->asm_nodes, &ctx->asm_jump, &ctx->asm_big, &ctx->rowgap, &ctx->pool_ws, &ctx->xchg_ws, &ctx->xchg_ws2, &ctx->counters, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux, &ctx->table})
         if (b->p) (void)hipFree(b->p);
     for (auto& kv : ctx->anchor_tabs) if (kv.second.p) (void)hipFree(kv.second.p);
     drop_tag_maps(ctx);

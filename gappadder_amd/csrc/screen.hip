@@ -1283,6 +1283,7 @@ struct VerifyParams {
     uint32_t* overflow_list; // their read ids (re-verified by a second launch with a large list), or null
     uint32_t vlist;          // seed-and-extend kernel: gap entries per candidate (VEXT_LIST / VEXT_LIST_BIG)
     uint32_t n_occ;          // entries of the occurrence lists in all
+    gf_hit* stage;           // seed-and-extend kernel: VEXT_STAGE hits per workgroup, collected before they join the hit list
 };
 
 __device__ __forceinline__ uint32_t packed_word(const VerifyParams& P, uint64_t w) {
@@ -1569,6 +1570,7 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(VerifyParams P) {
 // overflow list to a second launch of this kernel with VEXT_LIST_BIG entries and a few candidates per wave, and only what outgrows
 // that as well to the table kernel.  (Round 3 sent every overflow straight to the table kernel: on the planted-repeat workload,
 // where 0.5 M reads hit 30-50 gaps each, that pass took 460 ms of a 475-ms step.)
+constexpr uint32_t VEXT_STAGE = 1024;    // hits a wave collects in its slice of the staging buffer before one atomic appends them to the list
 constexpr uint32_t VEXT_WALK_MAX = 96;   // occurrences one lane of the first pass walks for a (read, seed) before it hands the read to the long-list pass
 constexpr uint32_t VEXT_LIST = 16, VEXT_LIST_BIG = 256, VEXT_BATCH_BIG = 8, VEXT_LIST_HUGE = 2048, VEXT_BATCH_HUGE = 2;   // (8 x 256 slots = 8 KiB per wave: a dozen waves per CU; the long list is a hash SET of gaps, full at 192)
 
@@ -1625,6 +1627,28 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
     __shared__ uint32_t obuf_n;
     const uint32_t lane = threadIdx.x;
     if (lane == 0) obuf_n = 0;
+    // The hit list has ONE counter, and returning atomics on one address are served at 11-15 ns each: the LDS buffer (>= 64 hits)
+    // empties into the wave's slice of a global staging buffer, and the slice joins the list a thousand hits at a time (C4: 3.8 M
+    // hits per step were 47 000 atomics — half of the kernel's time on that counter's queue).
+    gf_hit* const stage = P.stage + (size_t)blockIdx.x * VEXT_STAGE;
+    uint32_t stage_n = 0;   // wave-uniform
+    auto flush_stage = [&]() {
+        uint32_t gb = 0;
+        if (lane == 0) gb = atomicAdd(P.n_out, stage_n);
+        gb = __shfl(gb, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's own stores are in L2; read them back from there (not from L1)
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(stage);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(P.out);
+        static_assert(sizeof(gf_hit) == 8, "hits move as 64-bit words");
+        for (uint32_t q = lane; q < stage_n; q += 64)
+            if (gb + q < P.cap) dst[gb + q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stage_n = 0;
+    };
+    auto put_out = [&](uint32_t nn) {   // obuf[0, nn) -> staging slice
+        if (stage_n + nn > VEXT_STAGE) flush_stage();
+        for (uint32_t q = lane; q < nn; q += 64) stage[stage_n + q] = obuf[q];
+        stage_n += nn;
+    };
     const uint32_t rw = (P.rb + 24) / 4 + 1, rwp = rw + 4;
     const uint32_t nmw = P.nmask ? P.nmw : 0;
     uint32_t* rows = sm;
@@ -1828,12 +1852,7 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
                 if (lane == 0) obuf_n = base + (uint32_t)__popcll(bal);
                 __syncthreads();
                 if (obuf_n >= OBUF - 64) {
-                    const uint32_t nn = obuf_n;
-                    uint32_t gb = 0;
-                    if (lane == 0) gb = atomicAdd(P.n_out, nn);
-                    gb = __shfl(gb, 0);
-                    for (uint32_t q = lane; q < nn; q += 64)
-                        if (gb + q < P.cap) P.out[gb + q] = obuf[q];
+                    put_out(obuf_n);
                     __syncthreads();
                     if (lane == 0) obuf_n = 0;
                     __syncthreads();
@@ -1843,14 +1862,8 @@ __global__ __launch_bounds__(64) void screen_verify_ext_kernel(VerifyParams P) {
         __syncthreads();
     }
     __syncthreads();
-    if (obuf_n) {
-        const uint32_t nn = obuf_n;
-        uint32_t gb = 0;
-        if (lane == 0) gb = atomicAdd(P.n_out, nn);
-        gb = __shfl(gb, 0);
-        for (uint32_t q = lane; q < nn; q += 64)
-            if (gb + q < P.cap) P.out[gb + q] = obuf[q];
-    }
+    if (obuf_n) put_out(obuf_n);
+    if (stage_n) flush_stage();
 }
 
 int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const void* d_nmask, size_t n_reads,
@@ -2044,6 +2057,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.out = (gf_hit*)d_out;
     V.cap = (uint32_t)cap;
     V.n_out = (uint32_t*)d_n_out;
+    V.stage = nullptr;
     const unsigned grid2 = (unsigned)ctx->n_cu * 32;  // one wave per block, every wave slot of the chip
     auto launch_verify = [&](const VerifyParams& VP) {
         const size_t lds2 = (64 * ((rb + 24) / 4 + 1) + VP.list_cap) * 4;
@@ -2063,6 +2077,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
     V.vlist = VEXT_LIST;
     const bool use_ext = ctx->screen_verify_ext && V.min_hits == 1 && ix.max_gaps_per_kmer == 0 && ix.ext_ok && V.np >= 1 && V.np <= 32;
     if (use_ext) {
+        if ((rc = ensure(ctx, ctx->verify_stage, (size_t)grid2 * VEXT_STAGE * sizeof(gf_hit)))) return rc;
+        V.stage = (gf_hit*)ctx->verify_stage.p;
         // seed-and-extend kernel instead of the k-mer table (same hits; see screen_verify_ext_kernel)
         const size_t rwp = (rb + 24) / 4 + 1 + 4, nmw = d_nmask ? V.nmw : 0;
         {
