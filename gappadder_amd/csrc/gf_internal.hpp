@@ -194,6 +194,11 @@ int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* ta
                     size_t cap, void* d_n_out, const void* d_low, const void* d_n_low, size_t low_cap);
 
 // assemble.hip
+// second hop: hashed bit map of the table rows' neighbourhoods (hop.hip builds it, tagger.hip asks it)
+constexpr uint32_t HOP_NEAR_LOG2 = 22, HOP_NEAR_SHIFT = 9;
+__host__ __device__ inline uint32_t hop_near_bit(uint32_t scaffold, uint32_t bin) {
+    return ((scaffold * 0x9E3779B1u) ^ (bin * 0x85EBCA77u) ^ (bin >> 13)) >> (32 - HOP_NEAR_LOG2);
+}
 constexpr size_t GF_COUNTER_BYTES = 128;   // ctx->counters: [0, 8) screen, [8, 16) assembly / merge, [16, 32) the assembly sweep
 int launch_assemble_sweep(gf_ctx* ctx, const void* d_pool, const void* d_pool_off, size_t n_pools, size_t total_reads, int read_len,
                           int min_count, int min_contig, void* d_contigs, size_t contig_cap, void* d_n_contigs, void* d_seq,

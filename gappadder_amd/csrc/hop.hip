@@ -262,9 +262,10 @@ constexpr uint32_t HOP_TB = 256;   // blocks of the table build
 __device__ __forceinline__ bool hop_first(const gf_dpos* rows, uint32_t r) {
     return r == 0 || rows[r].mate_scaffold != rows[r - 1].mate_scaffold || rows[r].mate_pos != rows[r - 1].mate_pos;
 }
-__global__ __launch_bounds__(256) void hop_table_count_kernel(const gf_dpos* rows, const uint32_t* n_rows, uint32_t row_cap, uint32_t* blk_cnt) {
+__global__ __launch_bounds__(256) void hop_table_count_kernel(const gf_dpos* rows, const uint32_t* n_rows, uint32_t row_cap, uint32_t* blk_cnt, uint32_t* near_bits) {
     __shared__ uint32_t s_c;
     if (threadIdx.x == 0) s_c = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < (1u << (HOP_NEAR_LOG2 - 5)); i += HOP_TB * 256) near_bits[i] = 0;   // (set by the launch that follows)
     __syncthreads();
     const uint32_t n = *n_rows < row_cap ? *n_rows : row_cap;
     const uint32_t chunk = (n + HOP_TB - 1) / HOP_TB, a = blockIdx.x * chunk < n ? blockIdx.x * chunk : n, b = a + chunk < n ? a + chunk : n;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void hop_table_count_kernel(const gf_dpos* row
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_c;
 }
 __global__ __launch_bounds__(256) void hop_table_write_kernel(const gf_dpos* rows, const uint32_t* n_rows, uint32_t row_cap, const uint32_t* blk_cnt,
-                                                              uint32_t* upos, uint32_t* urow, uint32_t* n_unique) {
+                                                              uint32_t* upos, uint32_t* urow, uint32_t* n_unique, uint32_t* near_bits) {
     __shared__ uint32_t s_w[4], s_base, s_run;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t n = *n_rows < row_cap ? *n_rows : row_cap;
@@ -299,7 +300,13 @@ __global__ __launch_bounds__(256) void hop_table_write_kernel(const gf_dpos* row
         __syncthreads();
         uint32_t u = run + (uint32_t)__popcll(bal & ((1ull << lane) - 1));
         for (uint32_t q = 0; q < w; ++q) u += s_w[q];
-        if (f) { upos[u] = rows[r].mate_pos; urow[u] = r; }
+        if (f) {
+            const uint32_t q = rows[r].mate_pos, sc = rows[r].mate_scaffold;
+            upos[u] = q; urow[u] = r;
+            // a record at pos matches this row iff q - 199 <= pos <= q + 299 (collect_discordant_low_mapq_reads.py:62-71): its bins
+            const uint32_t b0 = (q > 199 ? q - 199 : 0) >> HOP_NEAR_SHIFT, b1 = (uint32_t)(((uint64_t)q + 299 < 0xFFFFFFFFull ? (uint64_t)q + 299 : 0xFFFFFFFFull) >> HOP_NEAR_SHIFT);
+            for (uint32_t bn = b0; bn <= b1; ++bn) { const uint32_t bit = hop_near_bit(sc, bn); atomicOr(&near_bits[bit >> 5], 1u << (bit & 31)); }
+        }
         run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
     }
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256) void hop_table_soff_kernel(const gf_dpos* rows
 
 // tagger.hip; *d_n_out must be zero already
 int launch_low_mapq_devtable(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const uint32_t* upos, const uint32_t* urow,
-                             const uint32_t* soff, void* d_out, size_t cap, void* d_n_out);
+                             const uint32_t* soff, const uint32_t* near_bits, void* d_out, size_t cap, void* d_n_out);
 
 }  // namespace gf
 
@@ -398,22 +405,24 @@ int gf_tag_low_mapq_table_dev(gf_ctx* ctx, const void* d_low, const void* d_n_lo
     const size_t b1 = (row_cap * 4 + 255) & ~(size_t)255, b2 = ((row_cap + 1) * 4 + 255) & ~(size_t)255, b3 = ((size_t)ctx->n_scaffolds + 1) * 4;
     int rc;
     const size_t b3a = (b3 + 255) & ~(size_t)255;
-    if ((rc = ensure(ctx, ctx->table, b1 + b2 + b3a + (HOP_TB + 1) * 4 + 64))) return rc;
+    const size_t b4 = (((size_t)HOP_TB + 1) * 4 + 255) & ~(size_t)255, b5 = (size_t)1 << (HOP_NEAR_LOG2 - 3);
+    if ((rc = ensure(ctx, ctx->table, b1 + b2 + b3a + b4 + b5 + 64))) return rc;
     ctx->low_rows.clear();   // the cached host-table copy in ctx->table is gone
     uint8_t* base = (uint8_t*)ctx->table.p;
     uint32_t* upos = (uint32_t*)base;
     uint32_t* urow = (uint32_t*)(base + b1);
     uint32_t* soff = (uint32_t*)(base + b1 + b2);
     uint32_t* blk_cnt = (uint32_t*)(base + b1 + b2 + b3a);   // [HOP_TB] firsts per block, [HOP_TB] unique positions in all
+    uint32_t* near_bits = (uint32_t*)(base + b1 + b2 + b3a + b4);   // 2^HOP_NEAR_LOG2 bits: the positions a row lies near, hashed
     {
         LaunchTimer tm(ctx, GF_KERNEL_LOWMAPQ);
-        hipLaunchKernelGGL(hop_table_count_kernel, dim3(HOP_TB), dim3(256), 0, ctx->stream, (const gf_dpos*)d_rows, (const uint32_t*)d_n_rows, (uint32_t)row_cap, blk_cnt);
+        hipLaunchKernelGGL(hop_table_count_kernel, dim3(HOP_TB), dim3(256), 0, ctx->stream, (const gf_dpos*)d_rows, (const uint32_t*)d_n_rows, (uint32_t)row_cap, blk_cnt, near_bits);
         hipLaunchKernelGGL(hop_table_write_kernel, dim3(HOP_TB), dim3(256), 0, ctx->stream, (const gf_dpos*)d_rows, (const uint32_t*)d_n_rows, (uint32_t)row_cap,
-                           blk_cnt, upos, urow, blk_cnt + HOP_TB);
+                           blk_cnt, upos, urow, blk_cnt + HOP_TB, near_bits);
         hipLaunchKernelGGL(hop_table_soff_kernel, dim3((ctx->n_scaffolds + 256) / 256), dim3(256), 0, ctx->stream, (const gf_dpos*)d_rows, urow, blk_cnt + HOP_TB,
                            ctx->n_scaffolds, soff, (uint32_t*)d_n_out);
     }
-    return launch_low_mapq_devtable(ctx, d_low, d_n_low, low_cap, upos, urow, soff, d_out, cap, d_n_out);
+    return launch_low_mapq_devtable(ctx, d_low, d_n_low, low_cap, upos, urow, soff, near_bits, d_out, cap, d_n_out);
 }
 
 }  // extern "C"
