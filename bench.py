@@ -545,6 +545,9 @@ def run(args):
     asm_off_t = d_moff if need_merge else libs[0].d_pool_off
     asm_pool_t = d_merged if need_merge else d_pools
     asm_rows_total = int(asm_off_t[-1])
+    _t, _m, _l = C.c_int(0), C.c_uint32(0), C.c_uint32(0)     # the last (k, kv) pair's launches: threads per gap, gaps handed to the 1 024-thread launch, pools beyond the bound
+    assert lib.gf_assemble_last_launch(gf.handle, C.byref(_t), C.byref(_m), C.byref(_l)) == 0
+    asm_launch = {"threads_per_gap": _t.value, "gaps_to_the_whole_cu_launch": _m.value, "pools_to_the_last_launch": _l.value}
     ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
     n_closed, n_ctg_all, gaps_with_contig = n_closed_local, n_ctg, int(len(np.unique(ctg["gap"])))
     gather_ms = None
@@ -633,7 +636,7 @@ def run(args):
             "counts": {"libraries": {lb.name: lb.counts for lb in libs}, "assembled_pool_reads": asm_rows_total, "contigs": n_ctg_all,
                        "gaps_with_contig": gaps_with_contig, "gaps_closed": n_closed, "gaps_closed_correct": n_correct,
                        "largest_pool_reads": max_pool_rows, "assembly_slice_rows": asm_bound, "screen_reads_not_verified_in_full": screen_dropped,
-                       "pools_beyond_the_slice": int((per_gap > asm_bound).sum())},
+                       "pools_beyond_the_slice": int((per_gap > asm_bound).sum()), "assembly_last_launch": asm_launch},
             "closed_truth_check": {"what": "the picked sequence of EVERY closed gap (pick_contigs.py:341-349 slice of the winning contig) compared with the "
                                            "true bases behind the planted N-run, regenerated from include/gf_synth.h: genome[start-5 : end+6] on the forward "
                                            "strand, genome[start-6 : end+5] when the contig is reverse-complemented (the reference's slice keeps one anchor base)",

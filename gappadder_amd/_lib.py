@@ -96,6 +96,7 @@ def lib():
         "gf_assemble": (i32, [vp, vp, vp, vp, sz, i32, vp, vp, i32, i32, i32, vp, sz, szp, vp, sz, szp]),
         "gf_assemble_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, i32, i32, i32, i32, vp, sz, vp, vp, sz, vp, vp]),
         "gf_assemble_multi_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, vp, vp, i32, i32, i32, vp, sz, vp, vp, sz, vp, vp]),
+        "gf_assemble_last_launch": (i32, [vp, vp, vp, vp]),
         "gf_pool_counts_dev": (i32, [vp, vp, sz, vp]),
         "gf_pools_pack_for_owners_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
         "gf_pools_merge_dev": (i32, [vp, vp, sz, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz, vp, vp]),

@@ -449,6 +449,20 @@ int gf_assemble_multi_dev(gf_ctx* ctx, const void* d_pool, const void* d_nmask, 
     return GF_OK;
 }
 
+int gf_assemble_last_launch(gf_ctx* ctx, int* threads_per_gap, uint32_t* to_middle, uint32_t* to_last) {
+    if (!ctx || !threads_per_gap || !to_middle || !to_last) return GF_E_INVAL;
+    *threads_per_gap = ctx->asm_last_threads;
+    *to_middle = *to_last = 0;
+    if (!ctx->counters.p || !ctx->asm_last_threads) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t c[6] = {};
+    GF_HIP(ctx, hipMemcpyAsync(c, (uint32_t*)ctx->counters.p + 8, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->asm_last_split) { *to_middle = c[2]; *to_last = c[5]; }
+    else *to_last = c[2];
+    return GF_OK;
+}
+
 int gf_assemble(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, const uint64_t* pool_off, size_t n_pools,
                 int read_len, const int* k_list, const int* kv_list, int n_k, int min_count, int min_contig,
                 gf_contig* contigs, size_t contig_cap, size_t* n_contigs, char* seq, size_t seq_cap, size_t* seq_len) {

@@ -24,6 +24,7 @@ namespace gf {
 // or 256 (four per CU, 38 KiB each).  The CU runs 16 waves either way; with several gaps per CU one gap's barriers and its
 // poorly parallel phases (graph construction over a few thousand survivors, error-removal walks, ranking rounds) overlap another
 // gap's work instead of leaving waves idle.
+constexpr uint32_t ASM_DEFER_STAY = 64;   // gaps of a main launch that stay in it although their graph will not fit its share of the LDS (see `defer`)
 constexpr uint32_t ASM_LDS_MAX_WORDS = 38 * 1024;  // 152 KiB of dynamic LDS per CU: staged reads, then tables and per-node arrays
 
 struct AsmParams {
@@ -43,6 +44,9 @@ struct AsmParams {
     uint32_t simplify;         // rounds of tip clipping + bubble popping (0: raw unitigs)
     uint32_t slice_rows;       // > 0: the workspace holds one slice of this many pool rows per workgroup
     uint64_t slice_base;       // ... the first of them starts at this instance offset
+    uint32_t* defer_tickets;   // (defer) counter of the gaps that asked to leave because of their GRAPH: the first ASM_DEFER_STAY of them stay
+    uint32_t defer;            // 1: a gap whose count table does not fit the LDS is not counted in the global slice but listed (big_list) for the next launch
+    uint32_t accept_rows;      // ... and the launch takes the pools of up to this many rows (<= slice_rows), lists the others
     uint64_t slice_stride;     // ... and they lie this many instances apart (slice_rows x the unit of this launch, or of the largest unit of a sweep)
     // pools beyond slice_rows are not refused: the launch lists them (big_list, *n_big) and a second, small launch takes them from
     // that list (gap_list, *n_gap_list) with slices of its own, sized for deep pools (option asm_big_pool_reads)
@@ -478,7 +482,7 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
         const uint64_t n_unit64 = (uint64_t)n_r * unit;
         // workspace slice: per pool row (slice_rows == 0), or one private slice per workgroup that every gap it takes re-uses
         // (kernels leave their slice EMPTY) — sized by the caller's bound on the rows of one pool
-        if (P.slice_rows && n_r > P.slice_rows) {
+        if (P.slice_rows && n_r > P.accept_rows) {
             if (tid == 0) {
                 if (P.big_list) P.big_list[atomicAdd(P.n_big, 1u)] = g;   // (at most n_pools entries)
                 else P.gap_error[g] |= ASM_ERR_IDS;
@@ -541,9 +545,14 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
         // levels are dead once the bits are up and lie under the table.
         bool pre_built = false;
         uint32_t pre_log2 = 0;
+        bool deferred = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool use_lds = attempt == 0 && r_words / 2 >= 1024;
             if (attempt == 0 && !use_lds) continue;
+            // no room in this launch's share of the LDS (foreseen below, or the table ran full): with two gaps per CU the gap is handed to
+            // the launch that gives it a whole CU's LDS instead of being counted in the global slice (several times as slow; nothing
+            // global but the workgroup's own lists was touched)
+            if (attempt == 1 && P.defer) { deferred = true; break; }
             tab.lds = use_lds;
             tab.off = R;
             tab.cap = use_lds ? r_words / 2 : gcap;
@@ -703,6 +712,20 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                     tab.cap = n_set + ovf_cap;
                 }
                 __syncthreads();
+                // The set bits also say how many nodes the graph will have (k-mers that share a bit and k-mers that reach a bit without
+                // reaching min_count about cancel: the survivors are 0.9-1.0 of the set bits): when no LDS plan of this launch holds that many
+                // (plan 2: 5.5 words per node) the gap would build, link, clean and rank its graph in the global slice — three to six times
+                // as slow per phase, and its traffic slows the neighbours — so it goes to the launch with a whole CU's LDS now, a tenth of
+                // its work done.
+                // (The first ASM_DEFER_STAY such gaps of a launch stay: a handful of them — C4 has eight — is not worth a further launch, which
+                //  lasts as long as its slowest gap at least.)
+                if (P.defer && n_set + n_set / 32 + 64 > 2 * r_words / 11) {
+                    if (tid == 0) s_cand = atomicAdd(P.defer_tickets, 1u);
+                    __syncthreads();
+                    const bool leave = s_cand >= ASM_DEFER_STAY;
+                    __syncthreads();
+                    if (leave) { deferred = true; break; }
+                }
             }
 #ifndef GF_KS_COMPLEMENT_LDS
 #define GF_KS_COMPLEMENT_LDS 0
@@ -1035,6 +1058,10 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
             __syncthreads();
             if (tid == 0) { s_cnt[4] = 0; s_cnt[6] = 0; }
             __syncthreads();
+        }
+        if (deferred) {
+            if (tid == 0) P.big_list[atomicAdd(P.n_big, 1u)] = g;
+            continue;
         }
         const bool tab_global = !tab.lds;
         const uint32_t n_dist = s_cnt[4] < n_unit ? s_cnt[4] : n_unit;
@@ -1717,11 +1744,44 @@ namespace {
 // threads per gap, grid and workspace slices of an assembly launch
 struct AsmGeom {
     int nt;
+    bool auto_nt;                        // the thread count was chosen here, not by option asm_threads
+    uint32_t deep_rows;                  // > 0: pools beyond this many rows leave the main launch (512 threads per gap) for one with 1 024
     unsigned per_cu, grid;
     uint32_t unit;                       // workspace instances per pool row (of the largest unit, for a sweep)
     uint64_t slice_rows, big_rows, big_base, n_inst;
 };
-AsmGeom asm_geometry(const gf_ctx* ctx, size_t n_pools, size_t total_reads, int read_len, uint32_t unit) {
+// The deepest pool whose count phase still runs in LDS with `lds_words` of dynamic LDS (the kernel's own test before its LDS attempt:
+// staged pool, pre-count bit arrays, a table for a twelfth of the windows at 3/4 load).  Beyond it the count table of a gap lives in the
+// global slice and the gap takes several times as long — measured on C4's layout at 512 threads per gap (76 KiB): pools of 313 / 421 /
+// 530 reads on average 10.4 / 13.7 / 34.2 ms per 19 840 gaps, against 12.7 / 15.5 / 18.4 ms at 1 024 threads (152 KiB).
+uint32_t asm_lds_count_rows(const gf_ctx* ctx, uint32_t lds_words, int read_len, int k, int min_count) {
+    const uint32_t rb = (uint32_t)((read_len + 3) / 4), npos = (uint32_t)(read_len - k + 1);
+    const uint32_t levels = (uint32_t)(min_count < 1 ? 1 : min_count);
+    auto fits = [&](uint32_t n_r) {
+        const uint32_t pool_words = (((uint32_t)(((uint64_t)n_r * rb + 3) / 4)) + 8) & ~1u;
+        if (pool_words + 2048 > lds_words) return false;
+        const uint32_t r_words = lds_words - pool_words;
+        const uint64_t n_inst = (uint64_t)n_r * npos;
+        bool pre = ctx->asm_precount && levels >= 2 && levels <= 3 && k <= 62;
+        uint32_t pre_words = 0;
+        if (pre) {
+            uint32_t lg = 11;
+            while ((1ull << lg) < 8 * n_inst && lg < 22) ++lg;
+            const uint32_t maxw = (uint32_t)((uint64_t)r_words * (uint32_t)ctx->asm_pre_frac8 / 8) / levels;
+            while (lg > 11 && (1u << (lg - 5)) > maxw) --lg;
+            pre = (1u << (lg - 5)) <= maxw;
+            pre_words = pre ? 1u << (lg - 5) : 0u;
+        }
+        const uint32_t cap = (r_words - pre_words) / 2, limit = cap - cap / 4;
+        return n_inst / (pre ? 12 : 4) <= limit;
+    };
+    uint32_t lo = 0, hi = 1u << 16;   // fits(lo), !fits(hi)
+    if (!fits(1)) return 0;
+    lo = 1;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (fits(mid)) lo = mid; else hi = mid; }
+    return lo;
+}
+AsmGeom asm_geometry(const gf_ctx* ctx, size_t n_pools, size_t total_reads, int read_len, uint32_t unit, uint32_t deep_rows_512) {
     AsmGeom G;
     // threads per gap: option asm_threads (1024 / 512 / 256), or automatic: two gaps per CU (512) when the caller's bound on the
     // largest pool (asm_max_pool_reads) leaves room for the tables in half of a CU's LDS and there are gaps enough to keep every CU
@@ -1731,9 +1791,15 @@ AsmGeom asm_geometry(const gf_ctx* ctx, size_t n_pools, size_t total_reads, int 
     // C2 (1 000 gaps = 4 per CU: latency per gap counts) 0.59 / 0.82 ms; C5's 722-read pools fall out of the LDS plans at 76 KiB (142
     // / 268 ms); four gaps per CU (256 threads, 38 KiB) push C4's graph phases into the global slice: 37 ms.
     G.nt = ctx->asm_threads;
-    if (G.nt != 1024 && G.nt != 512 && G.nt != 256)
-        G.nt = (ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads * ((read_len + 3) / 4) <= 28 * 1024 &&
-                n_pools >= 8 * (size_t)ctx->n_cu) ? 512 : 1024;
+    G.auto_nt = G.nt != 1024 && G.nt != 512 && G.nt != 256;
+    // ... and the count phase of MOST pools still runs in the LDS of half a CU (deep_rows_512: asm_lds_count_rows at 76 KiB; the pools
+    // beyond it are then listed for a launch with 1 024 threads per gap, see launch_assemble).  What the host knows of the pools is the
+    // caller's bound, their maximum or 99th percentile — 1.3-1.4 x their mean in every workload measured (C4 442 / 313, C5 916 / 722,
+    // C4 with 1.5 G reads 703 / 530): "the mean pool fits" is read as bound <= 4/3 x deep_rows_512.
+    if (G.auto_nt)
+        G.nt = (ctx->asm_max_pool_reads > 0 && n_pools >= 8 * (size_t)ctx->n_cu && deep_rows_512 > 0 &&
+                (uint64_t)ctx->asm_max_pool_reads * 3 <= (uint64_t)deep_rows_512 * 4) ? 512 : 1024;
+    G.deep_rows = G.auto_nt && G.nt == 512 ? deep_rows_512 : 0;
     G.per_cu = 1024u / (unsigned)G.nt;
     G.grid = (unsigned)std::max<size_t>(1, std::min<size_t>(n_pools, (size_t)ctx->n_cu * G.per_cu));
     G.unit = unit;
@@ -1778,6 +1844,9 @@ AsmParams asm_params(const gf_ctx* ctx, const AsmGeom& G, const AsmIO& io, int k
     AsmParams P;
     P.slice_base = 0;
     P.slice_stride = G.slice_rows * G.unit;
+    P.accept_rows = (uint32_t)G.slice_rows;
+    P.defer = 0;
+    P.defer_tickets = nullptr;
     P.keyslot = (uint32_t)ctx->asm_keyslot;
     P.precount = (uint32_t)ctx->asm_precount;
     P.pre_frac8 = (uint32_t)ctx->asm_pre_frac8;
@@ -1818,13 +1887,14 @@ AsmParams asm_params(const gf_ctx* ctx, const AsmGeom& G, const AsmIO& io, int k
 }
 // every pool of the main launch within its share of the LDS
 bool asm_pools_fit(const AsmGeom& G, const AsmParams& P, int k) {
-    return G.slice_rows > 0 && (uint64_t)G.slice_rows * P.rb + 32 <= (uint64_t)P.lds_words * 4 / (k > 32 ? 2 : 3);
+    return G.slice_rows > 0 && (uint64_t)P.accept_rows * P.rb + 32 <= (uint64_t)P.lds_words * 4 / (k > 32 ? 2 : 3);
 }
 // the launch for the pools the main launch listed (none, as a rule: its workgroups leave at once)
 void asm_launch_big(gf_ctx* ctx, const AsmGeom& G, const AsmParams& P, uint32_t* next, const uint32_t* list, const uint32_t* n_list) {
     AsmParams B = P;
     B.next_gap = next;
     B.slice_rows = (uint32_t)G.big_rows;
+    B.accept_rows = (uint32_t)G.big_rows;
     B.slice_stride = G.big_rows * G.unit;
     B.slice_base = G.big_base;
     B.big_list = nullptr;
@@ -1845,8 +1915,9 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     if (n_pools >= 0xFFFFFFFFull || contig_cap > 0xFFFFFFFFull) return GF_E_INVAL;
     const AsmIO io{d_pool, d_nmask, d_pool_off, n_pools, total_reads, read_len, min_count, min_contig, d_contigs, contig_cap, d_n_contigs,
                    d_seq, seq_cap, d_seq_len, d_gap_error, d_cnt_keys, d_cnt_counts, cnt_cap};
-    const AsmGeom G = asm_geometry(ctx, n_pools, total_reads, read_len, d_cnt_keys ? read_len - k + 1 : read_len - kv + 1);
-    const int nt = G.nt;
+    const uint32_t lds_half = std::min<uint32_t>(ASM_LDS_MAX_WORDS / 2, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
+    const uint32_t deep512 = d_cnt_keys ? 0u : asm_lds_count_rows(ctx, lds_half, read_len, k, min_count);
+    const AsmGeom G = asm_geometry(ctx, n_pools, total_reads, read_len, d_cnt_keys ? read_len - k + 1 : read_len - kv + 1, deep512);
     int rc;
     if ((rc = asm_workspace(ctx, G, !d_cnt_keys))) return rc;
     if (n_pools == 0 && !append) {
@@ -1855,37 +1926,66 @@ int launch_assemble(gf_ctx* ctx, const void* d_pool, const void* d_nmask, const 
     }
     if (n_pools == 0) return GF_OK;
     if ((rc = ensure(ctx, ctx->counters, GF_COUNTER_BYTES))) return rc;
-    uint32_t* d_next = (uint32_t*)ctx->counters.p + 8;   // [8] work counter, [9] the second launch's, [10] pools listed for it
-    if ((rc = ensure(ctx, ctx->asm_big, 2 * n_pools * 4 + 64))) return rc;   // [pools listed for the second launch][gaps in launch order]
+    // [8] work counter, [9] the last launch's, [10] pools listed by the main launch, [11] gaps in the launch order, [12] the middle launch's
+    // work counter, [13] pools listed by the middle launch, [14] tickets of the gaps that would leave the main launch for their graph's sake
+    uint32_t* d_next = (uint32_t*)ctx->counters.p + 8;
+    if ((rc = ensure(ctx, ctx->asm_big, 3 * n_pools * 4 + 64))) return rc;   // [listed by the main launch][gaps in launch order][listed by the middle launch]
     // append: a further (k, kv) pair of the same call adds to the contig list and keeps the error flags of the earlier pairs
-    if (append) zero_regions(ctx, ZeroList{{d_next, nullptr, nullptr, nullptr}, {3, 0, 0, 0}});
-    else zero_regions(ctx, ZeroList{{(uint32_t*)d_n_contigs, (uint32_t*)d_seq_len, (uint32_t*)d_gap_error, d_next}, {1, 2, (uint32_t)n_pools, 3}});
+    if (append) zero_regions(ctx, ZeroList{{d_next, d_next + 4, nullptr, nullptr}, {3, 3, 0, 0}});
+    else zero_regions(ctx, ZeroList{{(uint32_t*)d_n_contigs, (uint32_t*)d_seq_len, (uint32_t*)d_gap_error, d_next}, {1, 2, (uint32_t)n_pools, 7}});
     // launch order: the deepest pools first.  The list of an earlier (k, kv) pair of the same call is still good (`append`: same pools).
-    uint32_t* d_order = (uint32_t*)ctx->asm_big.p + n_pools;
+    uint32_t* d_list1 = (uint32_t*)ctx->asm_big.p;
+    uint32_t* d_order = d_list1 + n_pools;
+    uint32_t* d_list2 = d_list1 + 2 * n_pools;
     const bool ordered = n_pools >= 4 * (size_t)ctx->n_cu && !d_cnt_keys;
     if (ordered && !append)
         hipLaunchKernelGGL(asm_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint64_t*)d_pool_off, (uint32_t)n_pools, d_order, d_next + 3);
-    AsmParams P = asm_params(ctx, G, io, k, kv);
-    P.next_gap = d_next;
-    P.big_list = G.slice_rows ? (uint32_t*)ctx->asm_big.p : nullptr;
-    P.n_big = d_next + 2;
-    P.gap_list = ordered ? d_order : nullptr;
-    P.n_gap_list = ordered ? d_next + 3 : nullptr;
-    {
-        LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
+    // the kernel of a launch: the generic one, or — the pipeline's launches: k / kv one of its pairs, no N masks, no count-only output —
+    // the instantiation for that k (and for "every pool within its share of the LDS")
+    auto kernel_of = [&](const AsmGeom& g, const AsmParams& q) -> void (*)(AsmParams) {
+        const int nt = g.nt;
         void (*kern)(AsmParams) = nt == 1024 ? (k <= 32 ? assemble_kernel<false, 1024, 0, false, false> : assemble_kernel<true, 1024, 0, false, false>)
                                   : nt == 512 ? (k <= 32 ? assemble_kernel<false, 512, 0, false, false> : assemble_kernel<true, 512, 0, false, false>)
                                               : (k <= 32 ? assemble_kernel<false, 256, 0, false, false> : assemble_kernel<true, 256, 0, false, false>);
-        // the pipeline's launches: k / kv one of its pairs, no N masks, no count-only output; every pool within its share of the LDS
-        const bool pools_fit = asm_pools_fit(G, P, k);
+        const bool pools_fit = asm_pools_fit(g, q, k);
         if (kv == k - 2 && nt >= 512 && !d_nmask && !d_cnt_keys) {
             if (k == 51 && pools_fit) kern = nt == 1024 ? assemble_kernel<true, 1024, 51, true, true> : assemble_kernel<true, 512, 51, true, true>;
             if (k == 41 && pools_fit) kern = nt == 1024 ? assemble_kernel<true, 1024, 41, true, true> : assemble_kernel<true, 512, 41, true, true>;
             if (k == 31) kern = pools_fit ? (nt == 1024 ? assemble_kernel<false, 1024, 31, true, true> : assemble_kernel<false, 512, 31, true, true>)
                                           : (nt == 1024 ? assemble_kernel<false, 1024, 31, true, false> : assemble_kernel<false, 512, 31, true, false>);
         }
-        hipLaunchKernelGGL(kern, dim3(G.grid), dim3(nt), (size_t)P.lds_words * 4, ctx->stream, P);
-        if (G.slice_rows) asm_launch_big(ctx, G, P, d_next + 1, (const uint32_t*)ctx->asm_big.p, d_next + 2);
+        return kern;
+    };
+    AsmParams P = asm_params(ctx, G, io, k, kv);
+    P.next_gap = d_next;
+    P.big_list = G.slice_rows ? d_list1 : nullptr;
+    P.n_big = d_next + 2;
+    P.gap_list = ordered ? d_order : nullptr;
+    P.n_gap_list = ordered ? d_next + 3 : nullptr;
+    // Three launches at most.  Main: every workgroup slot of the chip (two gaps per CU at 512 threads).  With two gaps per CU a gap has 76 KiB
+    // of LDS, and a pool whose count table does not stay there takes several times as long: the pools too deep by the kernel's own estimate
+    // (asm_lds_count_rows) are listed unseen, those whose table runs full (shallow coverage of a long region: many distinct k-mers per window)
+    // when it happens, and the list goes to a MIDDLE launch with 1 024 threads and a whole CU's LDS per gap.  Last: the pools beyond the caller's bound (asm_launch_big).
+    const bool split = G.slice_rows > 0 && G.deep_rows > 0;
+    if (split) { P.accept_rows = (uint32_t)std::min<uint64_t>(G.deep_rows, G.slice_rows); P.defer = 1; P.defer_tickets = d_next + 6; }
+    ctx->asm_last_threads = G.nt;
+    ctx->asm_last_split = split;
+    {
+        LaunchTimer tm(ctx, GF_KERNEL_ASSEMBLE);
+        hipLaunchKernelGGL(kernel_of(G, P), dim3(G.grid), dim3(G.nt), (size_t)P.lds_words * 4, ctx->stream, P);
+        if (split) {
+            AsmGeom G2 = G;
+            G2.nt = 1024; G2.per_cu = 1;
+            G2.grid = (unsigned)std::max<size_t>(1, std::min<size_t>(n_pools, (size_t)ctx->n_cu));   // (<= the main launch's grid: its slices are re-used)
+            AsmParams D = asm_params(ctx, G2, io, k, kv);
+            D.next_gap = d_next + 4;
+            D.gap_list = d_list1;
+            D.n_gap_list = d_next + 2;
+            D.big_list = d_list2;
+            D.n_big = d_next + 5;
+            hipLaunchKernelGGL(kernel_of(G2, D), dim3(G2.grid), dim3(1024), (size_t)D.lds_words * 4, ctx->stream, D);
+            asm_launch_big(ctx, G, D, d_next + 1, d_list2, d_next + 5);
+        } else if (G.slice_rows) asm_launch_big(ctx, G, P, d_next + 1, d_list1, d_next + 2);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
@@ -1901,7 +2001,11 @@ int launch_assemble_sweep(gf_ctx* ctx, const void* d_pool, const void* d_pool_of
         return GF_E_UNSUPPORTED;
     const AsmIO io{d_pool, nullptr, d_pool_off, n_pools, total_reads, read_len, min_count, min_contig, d_contigs, contig_cap, d_n_contigs,
                    d_seq, seq_cap, d_seq_len, d_gap_error, nullptr, nullptr, 0};
-    const AsmGeom G = asm_geometry(ctx, n_pools, total_reads, read_len, (uint32_t)read_len - 29 + 1);
+    const uint32_t lds_half = std::min<uint32_t>(ASM_LDS_MAX_WORDS / 2, (uint32_t)std::max(4, ctx->asm_lds_pool_kb) * 256);
+    uint32_t deep512 = 0xFFFFFFFFu;   // (no middle launch here: two gaps per CU only when every pool's count phase fits 76 KiB at every k)
+    for (int i = 0; i < 3; ++i) deep512 = std::min(deep512, asm_lds_count_rows(ctx, lds_half, read_len, KS[i], min_count));
+    if (ctx->asm_max_pool_reads > 0 && (uint64_t)ctx->asm_max_pool_reads > deep512) deep512 = 0;
+    const AsmGeom G = asm_geometry(ctx, n_pools, total_reads, read_len, (uint32_t)read_len - 29 + 1, deep512);
     if (G.nt < 512) return GF_E_UNSUPPORTED;
     AsmParams P[3];
     for (int i = 0; i < 3; ++i) {

@@ -104,6 +104,8 @@ struct gf_ctx {
     long asm_big_pool_reads = 131072;   // ... and pools beyond asm_max_pool_reads go to a second launch whose slices hold this many rows (a pool beyond this sets its gap_error)
     int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
     int asm_ranked = 1;          // count phase: ranked (perfect-hash) table behind the pre-count (k > 32, LDS)
+    int asm_last_threads = 0;    // the last launch_assemble: threads per gap of its main launch ...
+    bool asm_last_split = false; // ... and whether a middle launch (1 024 threads per gap) followed it (gf_assemble_last_launch)
     int asm_sweep = 0;           // 1: gf_assemble_multi_dev runs the sweep 31/29, 41/39, 51/49 in one launch (measured 1 % slower than one launch per pair: DESIGN.md §5)
     int asm_pre_frac8 = 5;       // count phase: eighths of the LDS region the pre-count's bit arrays may take under an LDS table
     int asm_precount = 1;        // count phase: bit-array pre-count in LDS when min_count is 2 or 3 (0: every window goes to the table)

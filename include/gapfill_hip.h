@@ -255,6 +255,12 @@ int gf_assemble_multi_dev(gf_ctx* ctx, const void* d_pool_packed, const void* d_
                           size_t n_pools, size_t total_reads, int read_len, const int* k_list, const int* kv_list, int n_k,
                           int min_count, int min_contig, void* d_contigs, size_t contig_cap, void* d_n_contigs, void* d_seq,
                           size_t seq_cap, void* d_seq_len, void* d_gap_error);
+/* What the LAST assembly launch group of this context did (the last (k, kv) pair of a multi-k call): threads per gap of its main launch
+ * (1024: one gap per CU; 512: two, each with half of the CU's LDS), the gaps that left it for the middle launch (1 024 threads: pools
+ * too deep for, or graphs too large for, half a CU's LDS) and the pools beyond asm_max_pool_reads that the last launch took.
+ * Synchronises the stream.  Diagnostic: results never depend on it. */
+int gf_assemble_last_launch(gf_ctx* ctx, int* threads_per_gap, uint32_t* to_middle, uint32_t* to_last);
+
 /* counted canonical k-mers of ONE pool, ascending (what `kmc_dump -ci0` lists after `kmc -k{k}`, assemble_gaps.py:96-102).
  * kmers: 2 x uint64 per k-mer (hi, lo), left-aligned KmerUtils layout; counts capped at 10^7 (-cs10000000). */
 int gf_count_kmers(gf_ctx* ctx, const uint8_t* pool_packed, const uint32_t* pool_n_mask_or_null, size_t n_reads,

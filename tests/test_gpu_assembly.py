@@ -370,3 +370,50 @@ def test_pools_beyond_the_callers_bound_take_the_second_launch(gf, kk):
     finally:
         gf.set_option("asm_max_pool_reads", 0)
         gf.set_option("asm_big_pool_reads", 131072)
+
+
+def test_gaps_that_do_not_fit_half_a_cu_move_to_the_whole_cu_launch(gf):
+    """With thousands of gaps the main launch runs two gaps per CU (512 threads, 76 KiB of LDS each); a pool too deep for its count
+    table to stay in that LDS is listed unseen, a pool whose table runs full or whose graph will not fit (shallow coverage of a long
+    region: many distinct k-mers per read) when that shows, and a middle launch with 1 024 threads and a whole CU's LDS per gap takes
+    the list — instead of the global-memory plans that cost three to six times as much.  Same contigs as the launch that gives every
+    gap a whole CU, and as the oracle."""
+    import ctypes as C
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    rng = np.random.RandomState(77)
+    L, n_pools = 150, 2304
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    pools = []
+    for i in range(n_pools):
+        kind = i % 8
+        if kind < 5:   glen, depth = 1200 + 100 * (i % 13), 25          # the usual gap: 200-400 reads
+        elif kind < 7: glen, depth = 2400, 32                           # a deep pool: > 484 reads (listed unseen at k = 51)
+        else:          glen, depth = 9000, 6                            # shallow coverage of a long region: 360 reads, > 8 000 distinct k-mers
+        g = LUT[rng.randint(0, 4, glen)]
+        n = int(depth * glen / L)
+        st = rng.randint(0, glen - L + 1, n)
+        r = g[st[:, None] + np.arange(L)[None, :]]
+        err = rng.rand(n, L) < 0.004
+        r = np.where(err, LUT[(np.searchsorted(LUT, r) + 1 + rng.randint(0, 3, (n, L))) % 4], r)
+        flip = rng.randint(0, 2, n).astype(bool)
+        r[flip] = comp[r[flip][:, ::-1]]
+        pools.append(np.ascontiguousarray(r).tobytes())
+    sizes = np.array([len(p) // L for p in pools])
+    assert sizes.max() < 640 and (sizes > 484).sum() > 400
+    kk = [(51, 49)]
+    got, _ = _gpu_assemble(gf, pools, L, kk)
+    t, m, l = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
+    assert B.lib().gf_assemble_last_launch(gf.handle, C.byref(t), C.byref(m), C.byref(l)) == 0
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count * 8 <= n_pools:      # (MI355X: 256 CUs)
+        assert t.value == 512 and m.value > (sizes > 484).sum() + 100 and l.value == 0, (t.value, m.value, l.value)
+    gf.set_option("asm_threads", 1024)
+    try:
+        ref, _ = _gpu_assemble(gf, pools, L, kk)
+    finally:
+        gf.set_option("asm_threads", 0)
+    assert got == ref and len(got) >= n_pools
+    for i in list(range(0, 64)) + list(range(n_pools - 16, n_pools)):
+        assert got.get((i, 51, 49), []) == CO.assemble_pool(pools[i], L, 51, 49), (i, int(sizes[i]))
