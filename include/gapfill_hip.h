@@ -111,8 +111,9 @@ int gf_stream_wait_after_filter(gf_ctx* waiter, gf_ctx* producer);
  * partitioned filter drops seeds whose neighbouring bases are none of the flanks'; 0: 16-base seeds as they are),
  * "screen_verify_ext" (1: seed-and-extend verification when min_hits == 1), "screen_verify_gate",
  * "screen_verify_batch", "screen_stream_policy", "screen_lds_log2_max", "screen_pf4_cap8",
- * "asm_keyslot", "asm_precount", "asm_ranked", "asm_lds_pool_kb", "asm_threads" (threads per gap: 1024 / 512 / 256, 0 = by the pool
- * bound), "asm_stats_ptr" (device u64[4] the assembly adds its window / k-mer / survivor / node counts to), "asm_dbg_ptr".
+ * "asm_keyslot", "asm_precount", "asm_ranked", "asm_lds_pool_kb", "asm_threads" (threads per gap: 1024 / 512 / 256; 0 = automatic:
+ * 512 — two gaps per CU — when there are >= 8 gaps per CU and asm_max_pool_reads says that most pools fit half a CU's LDS, the gaps
+ * that do not are handed to a second launch with 1024), "asm_stats_ptr" (device u64[4] the assembly adds its window / k-mer / survivor / node counts to), "asm_dbg_ptr".
  * Tagger: "tag_light" (1: one-wave workgroups that read the coarse bin map through L1/L2 instead of staging it in LDS — same hits;
  * for a pipeline that runs the tagger on a second context beside the k-mer filter, whose workgroups own most of every CU's LDS).
  * Assembly: "asm_simplify" (rounds of tip clipping + bubble popping — Velvet's defaults, which the reference runs with
