@@ -321,27 +321,39 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(uint32_t n_gaps, const
         const uint32_t ur = (rb & 1) ? rb : rb / 2;
         const uint64_t units64 = (uint64_t)n * ur;
         const uint32_t units = units64 < 0xFFFFFFFFull ? (uint32_t)units64 : 0xFFFFFFFFu;
-        if (rb == 38) {   // 150-base reads: 19 units per read — a division by a constant, and four units of a thread in flight (every unit is two
-                          // dependent loads: the key, then the read's bytes)
-            const uint16_t* src = reinterpret_cast<const uint16_t*>(reads);
-            uint16_t* dst = reinterpret_cast<uint16_t*>(pool) + p0 * 19;
+        if (rb == 38) {   // 150-base reads: ten units per read — nine dwords and the last two bytes (a read starts at a multiple of 38 bytes: the
+                          // dwords are 2-byte aligned, which the memory system takes as it is) —, a division by a constant, and four units of a
+                          // thread in flight (every unit is two dependent loads: the key, then the read's bytes)
+            typedef uint32_t u32_a2 __attribute__((aligned(2)));
+            const uint8_t* src = reads;
+            uint8_t* dst = pool + p0 * 38;
             const uint64_t room = pool_cap_reads > p0 ? pool_cap_reads - p0 : 0;
-            const uint32_t lim = (uint64_t)units < room * 19 ? units : (uint32_t)(room * 19);
+            const uint64_t units10 = (uint64_t)n * 10;
+            const uint32_t lim = (uint32_t)(units10 < room * 10 ? units10 : room * 10);   // (a gap's pool is far below 4 G units)
             for (uint32_t i0 = threadIdx.x; i0 < lim; i0 += 4 * blockDim.x) {
-                uint32_t rd[4], bb[4];
-                uint16_t v[4];
+                uint32_t rd[4], bb[4], v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint32_t i = i0 + q * blockDim.x, j = i / 19u;
-                    bb[q] = i - j * 19u;
+                    const uint32_t i = i0 + q * blockDim.x, j = i / 10u;
+                    bb[q] = i - j * 10u;
                     const uint32_t key = i < lim ? seg[s0 + j] : 0u;
                     rd[q] = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (i0 + q * blockDim.x < lim && rd[q] < n_reads) ? src[(uint64_t)rd[q] * 19 + bb[q]] : (uint16_t)0;
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = 0;
+                    if (i0 + q * blockDim.x < lim && rd[q] < n_reads) {
+                        const uint8_t* a = src + (uint64_t)rd[q] * 38 + 4 * bb[q];
+                        v[q] = bb[q] < 9 ? *reinterpret_cast<const u32_a2*>(a) : (uint32_t)*reinterpret_cast<const uint16_t*>(a);
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (i0 + q * blockDim.x < lim && rd[q] < n_reads) dst[i0 + q * blockDim.x] = v[q];
+                    if (i0 + q * blockDim.x < lim && rd[q] < n_reads) {
+                        const uint32_t i = i0 + q * blockDim.x;
+                        uint8_t* a = dst + (uint64_t)(i / 10u) * 38 + 4 * bb[q];
+                        if (bb[q] < 9) *reinterpret_cast<u32_a2*>(a) = v[q]; else *reinterpret_cast<uint16_t*>(a) = (uint16_t)v[q];
+                    }
             }
         } else
         for (uint32_t i = threadIdx.x; i < units; i += blockDim.x) {
