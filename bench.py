@@ -175,6 +175,8 @@ def run(args):
     from gappadder_amd.hip_api import GapFill
 
     seed, slen, nscf, gps, glen, dreads, kk = PRESETS[args.config]
+    if os.environ.get("GF_BENCH_KPAIRS"):            # diagnostics: other (k, kv) pairs than the config's, "31,29;41,39" (the line then names them)
+        kk = [tuple(int(x) for x in p.split(",")) for p in os.environ["GF_BENCH_KPAIRS"].split(";")]
     total_reads = (args.reads or dreads) // 2 * 2
     L = 150
     # (name, IS, sd, library number, records, pull the mates of k-mer-screen hits?)  A read that shares a k-mer with a flank lies AT

@@ -526,8 +526,8 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                 g_lds[i] = v;
             }
         }
-        const uint32_t R = pool_words;   // word offset of region R in the dynamic LDS
-        const uint32_t r_words = P.lds_words - pool_words;
+        uint32_t R = pool_words;   // word offset of region R in the dynamic LDS
+        uint32_t r_words = P.lds_words - pool_words;   // (both change once: when the graph phase takes the staged pool's place, below)
         if (tid < 8) s_cnt[tid] = 0;
         if (tid < 2) s_seq[tid] = 0;
         __syncthreads();
@@ -1156,6 +1156,17 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
         // (words per node: inst_of + meta + the two successors of 16 bits each = 3, + the table's 3/2 (plan 2: 5/4) slots of two words, + in
         //  plan 0 one 32-bit pair per oriented node: 8 / 6 / 5.5.  Round 3 kept the successors as two 32-bit words — 9 / 7 / 6.5 —, and a
         //  tenth of C5's gaps fell out of every LDS plan, taking three to four times as long as the others)
+        // No LDS plan holds this graph beside the staged pool, but one does in its place (C5 at k = 31: 7 % of the gaps, up to 8 100 nodes
+        // beside 900 reads): the graph gets the pool's LDS and the reads are fetched from global memory from here on — the pool is a few
+        // dozen KiB in L2, the graph phases touch each node's window a few times; the alternative, every table and array of the graph in the
+        // global slice, cost such gaps three to four times the time of the others.  (The count table and the bit arrays are dead by now.)
+        // Only with one gap per CU: with two (NT = 512) the gap goes to the launch that has a whole CU for it (`defer`), and the kernels whose
+        // pools all fit the LDS keep "the reads are in LDS" as a compile-time fact in their graph phases (C4: 10.4 against 10.6 ms).
+        if (NT == 1024 && V.lds && want > 2 * r_words / 11 && (uint64_t)want * 11 <= 2 * (uint64_t)P.lds_words) {
+            V.lds = false;
+            R = 0;
+            r_words = P.lds_words;
+        }
         for (int attempt = want <= r_words / 8 ? 0 : want <= r_words / 6 ? 1 : want <= 2 * r_words / 11 ? 2 : 3; attempt < 4; ++attempt) {
             graph_lds = false;
             j_lds = false;
