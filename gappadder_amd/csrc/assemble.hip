@@ -1146,7 +1146,7 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
         // successor, and the links phase reads it instead of finding the shifted kv-mer in the node table again (derive, reverse
         // complement, hash, probe, verify: 34 of a C4 gap's 314 us).  Equal values race when the out-degree is 1; otherwise unused.
         bool cand_on = false;
-        uint32_t* const scand = P.jump + 4 * inst_off;
+        uint16_t* const scand = reinterpret_cast<uint16_t*>(P.jump + 4 * inst_off);   // 16 bits per entry: the table of an LDS plan has fewer than 32 768 slots
         const bool node_fp_on = PK - PKV <= 3;   // see node_upsert
         uint32_t nb = 0, n_nodes = 0;
         Tab ntab;
@@ -1180,7 +1180,7 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
             ntab.lds = graph_lds;
             ntab.off = R + 3 * nb;
             ntab.cap = graph_lds ? ((r_words - (j_lds ? 5 : 3) * nb) / 2) : gcap;
-            cand_on = graph_lds && 2ull * ntab.cap <= 4ull * n_unit;   // (the slice of the pair workspace holds two words per slot)
+            cand_on = graph_lds && 2ull * ntab.cap <= 4ull * n_unit && ntab.cap <= 32768;   // (the slice of the pair workspace holds two words per slot; an entry is slot << 1 | orientation in 16 bits)
             if (graph_lds) {
                 for (uint32_t i = tid; i < ntab.cap; i += ASM_THREADS) ntab.store(i, EMPTY64);
                 __syncthreads();
@@ -1224,8 +1224,8 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                         ntab.or_meta(ps, pd ? (1u << (4 + (3 - c_out))) : (1u << c_out));
                         ntab.or_meta(sl, d ? (1u << (3 - c_in)) : (1u << (4 + c_in)));
                         if (cand_on) {
-                            scand[2 * ps + pd] = (sl << 1) | d;                  // (prev, pd) -> (this, d)
-                            scand[2 * sl + (d ^ 1u)] = (ps << 1) | (pd ^ 1u);    // and the same edge read from the other strand
+                            scand[2 * ps + pd] = (uint16_t)((sl << 1) | d);                  // (prev, pd) -> (this, d)
+                            scand[2 * sl + (d ^ 1u)] = (uint16_t)((ps << 1) | (pd ^ 1u));    // and the same edge read from the other strand
                         }
                     }
                     ps = sl; pd = d;
@@ -1316,8 +1316,8 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                 if (__popc(o0) != 1 && __popc(o1) != 1) continue;
                 const uint32_t sl = list_a[ni];
                 // (written by other waves two phase barriers ago; read from L2 like every hand-over through global memory)
-                const uint32_t c0 = __popc(o0) == 1 ? __hip_atomic_load(&scand[2 * sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                const uint32_t c1 = __popc(o1) == 1 ? __hip_atomic_load(&scand[2 * sl + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                const uint32_t cw = __hip_atomic_load(reinterpret_cast<const uint32_t*>(scand) + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // both orientations' entries
+                const uint32_t c0 = cw & 0xFFFFu, c1 = cw >> 16;
                 for (uint32_t d = 0; d < 2; ++d) {
                     if (__popc(d ? o1 : o0) != 1) continue;
                     const uint32_t c = d ? c1 : c0;
