@@ -1356,16 +1356,19 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
         auto cov_of = [&](uint32_t m) -> unsigned long long {
             return ((unsigned long long)(m >> M_MULT_SHIFT) << 32) | ((m & M_WEAK) ? 0u : 1u);   // (nmeta carries no fingerprint)
         };
+        // (a round has a dozen candidates per gap — 9 at C4, 38 at C5's k = 31 — and lasts as long as the slowest one's chain of walks and
+        //  look-ups: a step of the walk asks for the node's successor and its coverage TOGETHER, one LDS round trip instead of two)
         auto walk = [&](uint32_t h, uint32_t limit, uint32_t& tail, uint32_t& n, unsigned long long& cov) -> bool {
             uint32_t cur = h;
             n = 1;
-            cov = cov_of(nmeta.get(h >> 1));     // the coverage sum rides along: no second walk when two unitigs are compared
+            cov = 0;                             // the coverage sum rides along: no second walk when two unitigs are compared
             for (;;) {
                 const uint32_t nx = succ_get(cur);
+                const uint32_t m = nmeta.get(cur >> 1);
+                cov += cov_of(m);
                 if (nx == EMPTY32) break;
                 if (n == limit) return false;
                 cur = nx;
-                cov += cov_of(nmeta.get(cur >> 1));
                 ++n;
             }
             tail = cur;
