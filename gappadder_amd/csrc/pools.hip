@@ -316,11 +316,7 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(uint32_t n_gaps, const
         const unsigned long long p0 = pool_off[g], p1 = pool_off[g + 1];
         const uint32_t n = (uint32_t)(p1 - p0);
         const uint32_t s0 = seg_off[g];
-        // a read starts at read * rb in both arrays: 2-byte units when rb is even (L = 150: 19 units), bytes otherwise;
-        // (unit index) / (units per read) in 32 bits — a gap's pool is far below 4 GB
-        const uint32_t ur = (rb & 1) ? rb : rb / 2;
-        const uint64_t units64 = (uint64_t)n * ur;
-        const uint32_t units = units64 < 0xFFFFFFFFull ? (uint32_t)units64 : 0xFFFFFFFFu;
+        // a read starts at read * rb in both arrays; (unit index) / (units per read) in 32 bits — a gap's pool is far below 4 GB
         if (rb == 38) {   // 150-base reads: ten units per read — nine dwords and the last two bytes (a read starts at a multiple of 38 bytes: the
                           // dwords are 2-byte aligned, which the memory system takes as it is) —, a division by a constant, and four units of a
                           // thread in flight (every unit is two dependent loads: the key, then the read's bytes)
@@ -355,15 +351,23 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(uint32_t n_gaps, const
                         if (bb[q] < 9) *reinterpret_cast<u32_a2*>(a) = v[q]; else *reinterpret_cast<uint16_t*>(a) = (uint16_t)v[q];
                     }
             }
-        } else
-        for (uint32_t i = threadIdx.x; i < units; i += blockDim.x) {
-            const uint32_t j = i / ur, b = i - j * ur;
-            if (p0 + j >= pool_cap_reads) break;
-            const uint32_t key = seg[s0 + j];
-            const uint32_t read = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
-            if (read >= n_reads) continue;
-            if (rb & 1) pool[(p0 + j) * rb + b] = reads[(uint64_t)read * rb + b];
-            else reinterpret_cast<uint16_t*>(pool)[(p0 + j) * ur + b] = reinterpret_cast<const uint16_t*>(reads)[(uint64_t)read * ur + b];
+        } else {   // any other read length: dword units at whatever alignment read * rb has (the memory system takes unaligned dwords), the
+                   // last unit of a read its rb & 3 bytes
+            typedef uint32_t u32_a1 __attribute__((aligned(1)));
+            const uint32_t ud = (rb + 3) / 4, tail = rb & 3;
+            const uint64_t unitsd = (uint64_t)n * ud;
+            const uint32_t limd = unitsd < 0xFFFFFFFFull ? (uint32_t)unitsd : 0xFFFFFFFFu;
+            for (uint32_t i = threadIdx.x; i < limd; i += blockDim.x) {
+                const uint32_t j = i / ud, b = i - j * ud;
+                if (p0 + j >= pool_cap_reads) break;
+                const uint32_t key = seg[s0 + j];
+                const uint32_t read = ((key & 0x7FFFFFFFu) << 1) | (key >> 31);
+                if (read >= n_reads) continue;
+                const uint8_t* a = reads + (uint64_t)read * rb + 4 * b;
+                uint8_t* d = pool + (p0 + j) * rb + 4 * b;
+                if (tail == 0 || b + 1 < ud) *reinterpret_cast<u32_a1*>(d) = *reinterpret_cast<const u32_a1*>(a);
+                else for (uint32_t t = 0; t < tail; ++t) d[t] = a[t];
+            }
         }
         if (pool_ids)
             for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {

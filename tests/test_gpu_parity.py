@@ -285,12 +285,13 @@ def test_device_pools_keep_gaps_with_more_keys_than_the_lds_sort_holds(gf, n_big
         assert (pool[off[g]:off[g + 1]] == reads[want]).all(), g
 
 
-def test_device_pools_follow_the_reference_fastq_join_order(gf):
+@pytest.mark.parametrize("L_case", [150, 100, 101, 250])     # packed rows of 38 (the dword-and-a-half fast path), 25, 26 and 63 bytes
+def test_device_pools_follow_the_reference_fastq_join_order(gf, L_case):
     """gf_build_pools_dev: keys from screen (+mates), tagger and second hop -> per-gap pools ordered (mate, pair)."""
     import torch
     from gappadder_amd import _lib as B
     from gappadder_amd.hip_api import GapFill
-    c = S.small_case(seed=31, n_pairs=9000)
+    c = S.small_case(seed=31, n_pairs=9000, L=L_case, insert=max(300, L_case + 100))
     L, n = c["L"], c["n_reads"]
     gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
     packed, _ = GapFill.pack_reads(c["reads_blob"], L)
@@ -325,7 +326,8 @@ def test_device_pools_follow_the_reference_fastq_join_order(gf):
     d_keys = torch.zeros(key_cap, dtype=torch.int64, device=dev)
     d_nk = torch.zeros(4, dtype=torch.int32, device=dev)
     pool_cap = len(keys) + 8
-    d_pool = torch.zeros(pool_cap * 38, dtype=torch.uint8, device=dev)
+    rb = packed.shape[1]
+    d_pool = torch.zeros(pool_cap * rb, dtype=torch.uint8, device=dev)
     d_off = torch.zeros(len(c["gaps"]) + 1, dtype=torch.int64, device=dev)
     d_ids = torch.zeros(pool_cap, dtype=torch.int32, device=dev)
     d_err = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -343,7 +345,7 @@ def test_device_pools_follow_the_reference_fastq_join_order(gf):
     assert int(d_err[0]) == 0 and int(d_nk[0]) == 2 * len(shits) + len(thits) + len(lhits)
     off = d_off.cpu().numpy()
     ids = d_ids.cpu().numpy().astype(np.uint32)
-    pool = d_pool.cpu().numpy().reshape(pool_cap, 38)
+    pool = d_pool.cpu().numpy().reshape(pool_cap, rb)
     assert off[-1] == len(keys)
     for g in range(len(c["gaps"])):
         want = sorted(exp.get(g, []), key=lambda r: (r & 1, r >> 1))
