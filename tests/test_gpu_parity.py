@@ -429,6 +429,53 @@ def test_one_pass_tagger_with_mapq0_compaction_equals_two_passes(gf):
     assert _same(got_t, thits) and _same(got_l, lhits) and len(lhits) > 0
 
 
+def test_mapq0_list_survives_many_flushes_of_the_staging_slices(gf):
+    """The MAPQ-0 by-product of the tagger leaves through per-wave staging slices of 1 024 records (tagger.hip): with 12 M records,
+    70 % of them MAPQ 0, every wave fills and empties its slice several times.  The list must hold exactly the MAPQ-0 records with a
+    valid scaffold — each once, with its position and record index — and the tagger's hits must not change."""
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    cfg = GapFill.synth_cfg(seed=9, scaffold_len=5_000_000, n_scaffolds=620, gaps_per_scaffold=32, gap_len=2000)   # (the 64-KiB bin map: 16-wave workgroups)
+    gaps, flanks = GapFill.synth_layout(cfg)
+    gf.set_gaps(gaps, 620, flanks)
+    n_pairs = 6_000_000
+    dev = torch.device("cuda:0")
+    rb = B.lib().gf_packed_read_bytes(150)
+    d_reads = torch.empty(2 * n_pairs * rb + 64, dtype=torch.uint8, device=dev)
+    d_recs = torch.empty(2 * n_pairs * 32, dtype=torch.uint8, device=dev)
+    gf.synth_pairs_dev(cfg, 0, n_pairs, d_reads.data_ptr(), d_recs.data_ptr())
+    gf.sync()
+    del d_reads
+    recs = np.frombuffer(d_recs.cpu().numpy().tobytes(), dtype=B.ALNREC).copy()
+    rng = np.random.RandomState(4)
+    recs["mapq"][rng.rand(len(recs)) < 0.7] = 0
+    recs["ref"][rng.rand(len(recs)) < 0.01] = 0xFFFFFFFF          # unplaced records: not listed
+    d_recs.copy_(torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy()))
+    n = len(recs)
+    cap = 1 << 22
+    d_t = torch.zeros(cap * 12, dtype=torch.uint8, device=dev)
+    d_low = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(8, dtype=torch.int32, device=dev)
+    L, h, cp = B.lib(), gf.handle, d_cnt.data_ptr()
+    assert L.gf_tag_alignments_low_dev(h, d_recs.data_ptr(), n, 300, 30, 250, 30, d_t.data_ptr(), cap, cp, d_low.data_ptr(), n, cp + 4) == 0
+    gf.sync()
+    cnt = d_cnt.cpu().numpy()
+    want = np.nonzero((recs["mapq"] == 0) & (recs["ref"] < 620))[0]
+    assert int(cnt[1]) == len(want) > 8_000_000
+    low = np.frombuffer(d_low[:len(want) * 12].cpu().numpy().tobytes(), dtype=np.dtype([("pos", "<u4"), ("ref", "<u4"), ("rec", "<u4")]))
+    order = np.argsort(low["rec"], kind="stable")
+    assert (low["rec"][order] == want).all()
+    assert (low["pos"][order] == recs["pos"][want]).all() and (low["ref"][order] == recs["ref"][want]).all()
+    assert L.gf_tag_alignments_dev(h, d_recs.data_ptr(), n, 300, 30, 250, 30, d_low.data_ptr(), cap, cp + 8) == 0      # (d_low re-used as a hit buffer)
+    gf.sync()
+    cnt = d_cnt.cpu().numpy()
+    assert int(cnt[0]) == int(cnt[2]) > 1000
+    a = np.sort(np.frombuffer(d_t[:int(cnt[0]) * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT), order=["rec", "gap", "kind"])
+    b = np.sort(np.frombuffer(d_low[:int(cnt[2]) * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT), order=["rec", "gap", "kind"])
+    assert a.tobytes() == b.tobytes()
+
+
 def test_c3_full_size_recruit_matches_oracle(gf):
     """BASELINE.json configs[2] at full size (E. coli-scale: 1 scaffold of 4.6 Mb, 200 gaps x 1 kb, 5 M 150-bp reads, k=41):
     every screen hit and every tagger hit of the GPU equals the oracle's."""
