@@ -476,6 +476,42 @@ def test_mapq0_list_survives_many_flushes_of_the_staging_slices(gf):
     assert a.tobytes() == b.tobytes()
 
 
+def test_every_read_a_hit_fills_the_verification_staging_slices(gf):
+    """10 M reads cut out of the flanks themselves: every read hits (exactly) its gap, so every wave of the seed-and-extend verification
+    collects more hits than its staging slice holds (1 024) and appends to the hit list several times."""
+    from gappadder_amd.hip_api import GapFill
+    cfg = GapFill.synth_cfg(seed=20260002, scaffold_len=5_000_000, n_scaffolds=10, gaps_per_scaffold=100, gap_len=1000)
+    gaps, flanks = GapFill.synth_layout(cfg)
+    gf.set_gaps(gaps, 10, flanks)
+    L, n = 150, 10_000_000
+    rng = np.random.RandomState(8)
+    text = np.frombuffer("".join(f[0] + f[1] for f in flanks).encode(), dtype=np.uint8)
+    flen = np.array([[len(f[0]), len(f[1])] for f in flanks], dtype=np.int64).reshape(-1)
+    fstart = np.concatenate([[0], np.cumsum(flen)[:-1]])
+    side = rng.randint(0, 2 * len(flanks), n)
+    assert flen.min() >= L
+    off = (rng.rand(n) * (flen[side] - L + 1)).astype(np.int64)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    hits = []
+    exp_gap = (side // 2).astype(np.uint32)
+    chunk = 1_000_000
+    packed = []
+    for a in range(0, n, chunk):
+        idx = (fstart[side[a:a + chunk]] + off[a:a + chunk])[:, None] + np.arange(L)[None, :]
+        r = text[idx]
+        flip = rng.randint(0, 2, len(r)).astype(bool)
+        r[flip] = comp[r[flip][:, ::-1]]
+        assert not (r == ord("N")).any()
+        packed.append(GapFill.pack_reads(r.tobytes(), L)[0])
+    packed = np.concatenate(packed)
+    got = gf.screen_reads(packed, L, 31, cap=n + (1 << 20))
+    assert len(got) == n, (len(got), n)      # (random flanks share no 31-mer: one gap per read)
+    assert (got["read"][np.argsort(got["read"], kind="stable")] == np.arange(n, dtype=np.uint32)).all()
+    order = np.argsort(got["read"], kind="stable")
+    assert (got["gap"][order] == exp_gap).all()
+
+
 def test_c3_full_size_recruit_matches_oracle(gf):
     """BASELINE.json configs[2] at full size (E. coli-scale: 1 scaffold of 4.6 Mb, 200 gaps x 1 kb, 5 M 150-bp reads, k=41):
     every screen hit and every tagger hit of the GPU equals the oracle's."""
