@@ -528,6 +528,10 @@ def run(args):
         sys.stderr.write("assembly phases of the last (k, kv) launch, us per gap (%d gaps with reads): " % len(d) +
                          ", ".join("%s %.1f (max %.1f)" % (nm, ph[:, i].mean(), ph[:, i].max()) for i, nm in enumerate(names)) +
                          "; total %.1f\n" % ph.sum(1).mean())
+        sub = d[(d[:, 8] > d[:, 0]) & (d[:, 9] >= d[:, 8])]
+        if len(sub):   # the count phase's parts (gaps whose pre-count ran): bit arrays, prefixes + table init, exact pass
+            sys.stderr.write("  count phase: pre-count pass %.1f, prefixes + table init %.1f, exact pass %.1f us (%d gaps)\n"
+                             % ((sub[:, 8] - sub[:, 0]).mean() / 100.0, (sub[:, 9] - sub[:, 8]).mean() / 100.0, (sub[:, 1] - sub[:, 9]).mean() / 100.0, len(sub)))
         sys.stderr.write("  windows %.0f, counted %.0f, survivors %.0f, nodes %.0f (max %d); count table global in %.0f %% of the gaps; graph plan LDS / LDS + global pairs / global: %s\n"
                          % (d[:, 13].mean(), d[:, 10].mean(), d[:, 12].mean(), d[:, 14].mean(), d[:, 14].max(), 100.0 * d[:, 11].mean(),
                             " / ".join("%.0f %%" % (100.0 * (d[:, 15] == v).mean()) for v in (0, 1, 2))))

@@ -617,8 +617,13 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                 }
             }
             const uint32_t chunks = (npos + S - 1) / S, n_items = n_r * chunks;
-            // body(read, offset, canonical key, forward, reverse complement) -> true = call me again with the same window
-            auto for_windows = [&](auto&& body) {
+            // body(read, offset, canonical key, forward, reverse complement, hint) -> true = call me again with the same window.
+            // hint(canonical key) runs one window AHEAD of body: it issues the first LDS reads of a window's look-up (the word of its pre-count
+            // bit, the prefix of that word) before the body of the window in front works through its own chain of dependent LDS accesses —
+            // table slot, CAS —, so a window's chain is two round trips shorter (the exact pass was 3.2 x the bit-array pass per window,
+            // and all of the difference was waiting: PMC, §4)
+            auto for_windows = [&](auto&& body, auto&& hint, auto ahead_c) {
+                constexpr bool AHEAD = decltype(ahead_c)::value;   // false: hint and body of a window together (the bit-array pass: its chain is short, the second window's state only costs registers)
                 const uint32_t dr = ASM_THREADS / chunks, dc = ASM_THREADS - dr * chunks;
                 uint32_t r = tid / chunks, c = tid - r * chunks;
                 for (uint32_t item = tid; item < n_items; item += ASM_THREADS, r += dr, c += dc) {
@@ -629,32 +634,85 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                     K128 fw = pv_kmer_at<W>(V, r, p, k);
                     K128 rc = revcomp_w<W>(fw, k);
                     uint32_t nxt = pv_stream32(V, (uint64_t)r * V.rb * 8 + 2ull * (p + PK));   // the bases behind the window
+                    K128 key = rc < fw ? rc : fw;
+                    if constexpr (!AHEAD) {
+                        for (;;) {
+                            bool ok = true;
+                            if (nmask) {
+                                for (uint32_t q = p; q < p + PK; ++q)
+                                    if ((nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { ok = false; break; }
+                            }
+                            if (ok) {
+                                key = rc < fw ? rc : fw;
+                                const auto h0 = hint(key);
+                                while (body(r, p, key, fw, rc, h0)) {}
+                            }
+                            if (++p >= pe) break;
+                            const uint64_t b = nxt >> 30;
+                            nxt <<= 2;
+                            if constexpr (W) {   // k > 32: the new base lands in the low word
+                                const int sh = 128 - 2 * k;
+                                fw.hi = (fw.hi << 2) | (fw.lo >> 62);
+                                fw.lo = (fw.lo << 2) | (b << sh);
+                                rc.lo = ((rc.lo >> 2) | (rc.hi << 62)) & (~0ull << sh);
+                                rc.hi = (rc.hi >> 2) | ((3ull - b) << 62);
+                            } else {
+                                const int sh = 64 - 2 * k;
+                                fw.hi = (fw.hi << 2) | (b << sh);
+                                rc.hi = ((rc.hi >> 2) | ((3ull - b) << 62)) & (~0ull << sh);
+                            }
+                        }
+                        continue;
+                    }
+                    auto h = hint(key);
                     for (;;) {
+                        // the next window: rolled, canonical, hinted
+                        const bool more = p + 1 < pe;
+                        K128 fw1 = fw, rc1 = rc;
+                        {
+                            const uint64_t b = nxt >> 30;
+                            nxt <<= 2;
+                            if constexpr (W) {   // k > 32: the new base lands in the low word
+                                const int sh = 128 - 2 * k;
+                                fw1.hi = (fw.hi << 2) | (fw.lo >> 62);
+                                fw1.lo = (fw.lo << 2) | (b << sh);
+                                rc1.lo = ((rc.lo >> 2) | (rc.hi << 62)) & (~0ull << sh);
+                                rc1.hi = (rc.hi >> 2) | ((3ull - b) << 62);
+                            } else {
+                                const int sh = 64 - 2 * k;
+                                fw1.hi = (fw.hi << 2) | (b << sh);
+                                rc1.hi = ((rc.hi >> 2) | ((3ull - b) << 62)) & (~0ull << sh);
+                            }
+                        }
+                        const K128 key1 = rc1 < fw1 ? rc1 : fw1;
+                        auto h1 = h;
+                        if (more) h1 = hint(key1);
                         bool ok = true;
                         if (nmask) {
                             for (uint32_t q = p; q < p + PK; ++q)
                                 if ((nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { ok = false; break; }
                         }
                         if (ok) {
-                            const K128 key = rc < fw ? rc : fw;
-                            while (body(r, p, key, fw, rc)) {}
+                            while (body(r, p, key, fw, rc, h)) {}
                         }
-                        if (++p >= pe) break;
-                        const uint64_t b = nxt >> 30;
-                        nxt <<= 2;
-                        if constexpr (W) {   // k > 32: the new base lands in the low word
-                            const int sh = 128 - 2 * k;
-                            fw.hi = (fw.hi << 2) | (fw.lo >> 62);
-                            fw.lo = (fw.lo << 2) | (b << sh);
-                            rc.lo = ((rc.lo >> 2) | (rc.hi << 62)) & (~0ull << sh);
-                            rc.hi = (rc.hi >> 2) | ((3ull - b) << 62);
-                        } else {
-                            const int sh = 64 - 2 * k;
-                            fw.hi = (fw.hi << 2) | (b << sh);
-                            rc.hi = ((rc.hi >> 2) | ((3ull - b) << 62)) & (~0ull << sh);
-                        }
+                        if (!more) break;
+                        ++p;
+                        fw = fw1; rc = rc1; key = key1; h = h1;
                     }
                 }
+            };
+            struct WinHint { uint64_t x; uint32_t word, pfx; };   // the window's hash (computed once, here), then what was read ahead
+            auto no_hint = [](const K128& key) -> WinHint { return WinHint{hash_p1<W>(key), 0u, 0u}; };
+            // (word of the k-mer's pre-count bit in the last level, and — ranked tables — the prefix of that word)
+            auto fin_hint = [&](const K128& key) -> WinHint {
+                const uint64_t x = hash_p1<W>(key);
+                const uint32_t b = (uint32_t)(x >> 32) >> (32 - pre_log2);
+                return WinHint{x, g_lds[R + (b >> 5)], 0u};
+            };
+            auto rank_hint = [&](const K128& key) -> WinHint {
+                const uint64_t x = hash_p1<W>(key);
+                const uint32_t b = (uint32_t)(x >> 32) >> (32 - pre_log2);
+                return WinHint{x, g_lds[R + (b >> 5)], (uint32_t)reinterpret_cast<const uint16_t*>(&g_lds[R + pre_words])[b >> 5]};
             };
             if (pre && !pre_built) {
                 for (uint32_t i = tid; i < levels * pre_words; i += ASM_THREADS) g_lds[R + i] = 0;
@@ -662,15 +720,15 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                 uint32_t* fin = &g_lds[R];
                 uint32_t* up1 = fin + pre_words;
                 uint32_t* up2 = up1 + pre_words;
-                for_windows([&](uint32_t, uint32_t, const K128& key, const K128&, const K128&) -> bool {
-                    const uint32_t b = (uint32_t)(hash_p1<W>(key) >> 32) >> (32 - pre_log2);
+                for_windows([&](uint32_t, uint32_t, const K128&, const K128&, const K128&, const WinHint& hw) -> bool {
+                    const uint32_t b = (uint32_t)(hw.x >> 32) >> (32 - pre_log2);
                     const uint32_t w = b >> 5, m = 1u << (b & 31);
-                    if (fin[w] & m) return false;                       // already up: most windows at sequencing depth
+                    if (hw.word & m) return false;                      // already up: most windows at sequencing depth (a bit that went up since the hint was taken only costs the steps below: they are idempotent)
                     if (!(atomicOr(&up1[w], m) & m)) return false;      // first occurrence
                     if (levels == 3 && !(atomicOr(&up2[w], m) & m)) return false;
                     atomicOr(&fin[w], m);
                     return false;
-                });
+                }, fin_hint, std::false_type{});
                 __syncthreads();
                 ASM_STAMP(8);
                 pre_built = true;
@@ -746,16 +804,15 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                 constexpr bool LDS = decltype(lds_c)::value;
                 Tab t = tab;
                 t.lds = LDS;
-                for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128&, const K128&) -> bool {
+                auto keyslot_body = [&](uint32_t r, uint32_t p, const K128& key, const K128&, const K128&, const WinHint& hw) -> bool {
                     const unsigned long long keyhi = key.hi;
-                    const uint64_t x = hash_p1<W>(key);
+                    const uint64_t x = hw.x;
                     uint32_t lo_sl = 0, n_sl = t.cap;                                  // probe region [lo_sl, lo_sl + n_sl)
                     if (LDS && ranked) {   // the slot of the k-mer's pre-count bit first (see `ranked`), the hashed overflow region behind it
-                        const uint32_t* fin = &g_lds[R];
                         const uint32_t b = (uint32_t)(x >> 32) >> (32 - pre_log2);
-                        const uint32_t word = fin[b >> 5];
+                        const uint32_t word = hw.word;
                         if (!((word >> (b & 31)) & 1u)) return false;
-                        const uint32_t rnk = reinterpret_cast<const uint16_t*>(fin + pre_words)[b >> 5] + (uint32_t)__popc(word & ((1u << (b & 31)) - 1u));
+                        const uint32_t rnk = hw.pfx + (uint32_t)__popc(word & ((1u << (b & 31)) - 1u));
                         unsigned long long v = t.load(rnk);
                         if (v == kempty) {
                             v = t.cas(rnk, kempty, keyhi ^ xm);
@@ -804,7 +861,8 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                     }
                     if (!placed) { if (LDS) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_KTABLE); }
                     return false;
-                });
+                };
+                if (LDS && ranked) for_windows(keyslot_body, rank_hint, std::true_type{}); else for_windows(keyslot_body, no_hint, std::false_type{});
                 };
                 auto count_keyslot_strided = [&](auto lds_c) {
                 constexpr bool LDS = decltype(lds_c)::value;
@@ -903,8 +961,8 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                 // probe loop, which the SIMT control flow runs only after every lane of the wave has left that loop — a lane
                 // spinning inside it would wait for an owner in its own wave forever.  It leaves the probe loop and is called
                 // again with the same window, by which time an owner in its wave has published.
-                for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128&, const K128&) -> bool {
-                    const uint64_t x = hash_p1<W>(key);
+                for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128&, const K128&, const WinHint& hw) -> bool {
+                    const uint64_t x = hw.x;
                     if (pre && !pre_pass(x)) return false;
                     const uint32_t inst = make_inst(r, p);
                     bool placed = false, retry = false;
@@ -957,22 +1015,20 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                     if (retry) return true;
                     if (!placed) { if (LDS) s_cnt[6] = 1; else atomicOr(&s_cnt[3], ASM_ERR_KTABLE); }
                     return false;
-                });
+                }, no_hint, std::false_type{});
                 };
                 count_keyslot_wide(std::false_type{});   // (keyslot_w implies the global table: no LDS instantiation — the kernel is at the edge of its registers and every unused path costs the used ones)
             } else if (fpslot) {
-                const uint32_t* fin = &g_lds[R];
-                const uint16_t* pfx = reinterpret_cast<const uint16_t*>(fin + pre_words);
-                for_windows([&](uint32_t r, uint32_t p, const K128& key, const K128& fw, const K128& rc) -> bool {
-                    const uint64_t x = hash_p1<W>(key);
+                auto fpslot_body = [&](uint32_t r, uint32_t p, const K128&, const K128& fw, const K128& rc, const WinHint& hw) -> bool {
+                    const uint64_t x = hw.x;
                     const unsigned long long fp = (x >> 34) << 32;                    // 30 bits, in place
                     const unsigned long long mine = fp | make_inst(r, p);   // (count - 1 = 0 in bits 62..63)
                     uint32_t sl, lo_sl = 0, n_sl = tab.cap;                            // probe region [lo_sl, lo_sl + n_sl)
                     if (ranked) {
                         const uint32_t b = (uint32_t)(x >> 32) >> (32 - pre_log2);
-                        const uint32_t word = fin[b >> 5];
+                        const uint32_t word = hw.word;
                         if (!((word >> (b & 31)) & 1u)) return false;
-                        const uint32_t rnk = pfx[b >> 5] + (uint32_t)__popc(word & ((1u << (b & 31)) - 1u));
+                        const uint32_t rnk = hw.pfx + (uint32_t)__popc(word & ((1u << (b & 31)) - 1u));
                         unsigned long long v = tab.load(rnk);
                         if ((uint32_t)v == EMPTY32) {
                             v = tab.cas(rnk, EMPTY64, mine);
@@ -1030,7 +1086,8 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                     }
                     if (!placed) s_cnt[6] = 1;
                     return false;
-                });
+                };
+                if (ranked) for_windows(fpslot_body, rank_hint, std::true_type{}); else for_windows(fpslot_body, no_hint, std::false_type{});
             } else
             for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
                 if (use_lds && s_cnt[6]) break;
