@@ -1626,7 +1626,17 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                 const unsigned long long a1 = J.load(pa);
                 const uint32_t pb = (uint32_t)a1;
                 if (pb == pa) continue;                                     // parent is a head (or this is a finished cycle hop)
-                J.store(o, ((unsigned long long)((uint32_t)(a0 >> 32) + (uint32_t)(a1 >> 32)) << 32) | pb);
+                // three jumps per round (the ancestor's ancestor, and its ancestor, as well): half the rounds — each a barrier — for the same number of loads
+                uint32_t anc = pb, dist = (uint32_t)(a0 >> 32) + (uint32_t)(a1 >> 32);
+#pragma unroll
+                for (int hop = 0; hop < 2; ++hop) {
+                    const unsigned long long ax = J.load(anc);
+                    const uint32_t px = (uint32_t)ax;
+                    if (px == anc) break;
+                    dist += (uint32_t)(ax >> 32);
+                    anc = px;
+                }
+                J.store(o, ((unsigned long long)dist << 32) | anc);
                 changed = true;
             }
             if (changed) s_jflag[jr % 3] = 1;
