@@ -528,6 +528,10 @@ def run(args):
         sys.stderr.write("assembly phases of the last (k, kv) launch, us per gap (%d gaps with reads): " % len(d) +
                          ", ".join("%s %.1f (max %.1f)" % (nm, ph[:, i].mean(), ph[:, i].max()) for i, nm in enumerate(names)) +
                          "; total %.1f\n" % ph.sum(1).mean())
+        tot = ph.sum(1)
+        sys.stderr.write("  per-gap total, percentiles 50 / 90 / 99 / 99.9 / max: %s us; the slowest 1 %% of the gaps take %.1f %% of the time\n"
+                         % (" / ".join("%.0f" % np.percentile(tot, q) for q in (50, 90, 99, 99.9, 100)),
+                            100.0 * np.sort(tot)[-max(1, len(tot) // 100):].sum() / tot.sum()))
         sub = d[(d[:, 8] > d[:, 0]) & (d[:, 9] >= d[:, 8])]
         if len(sub):   # the count phase's parts (gaps whose pre-count ran): bit arrays, prefixes + table init, exact pass
             sys.stderr.write("  count phase: pre-count pass %.1f, prefixes + table init %.1f, exact pass %.1f us (%d gaps)\n"
