@@ -608,7 +608,10 @@ int gf_build_pools_dev(gf_ctx* ctx, const void* d_packed_reads, size_t n_reads, 
     LaunchTimer tm(ctx, GF_KERNEL_POOL);
     const unsigned blocks = ctx->n_cu * 4;
     const bool lds_bins = ng && (size_t)ng * 4 <= 128 * 1024;     // one LDS counter per gap
-    const unsigned lblocks = std::min<unsigned>(ctx->n_cu, 64);   // few, large slices: global atomics ~ blocks x non-empty bins; 16 waves each
+    // slices of at least 16 384 keys, one block per CU at most (64 at least): a block streams its slice with one load per thread in flight
+    // — the two kernels wait on that, not on the atomics: 64 blocks for C4's 10 M keys 0.25 ms each, 256 blocks 0.16 —, and its global
+    // atomics are one per non-empty bin
+    const unsigned lblocks = (unsigned)std::min<size_t>(ctx->n_cu, std::max<size_t>(64, key_cap / 16384));
                                                                   // (4-wave blocks left each of the 64 CUs waiting on its own key loads: 0.29 + 0.47 ms per 10 M keys)
     if (lds_bins) {
         hipLaunchKernelGGL(pool_hist_lds_kernel, dim3(lblocks), dim3(1024), (size_t)ng * 4, ctx->stream, (const unsigned long long*)d_keys,
