@@ -58,11 +58,6 @@ REPEATS = {"C2R": (8, 50), "C4R": (16, 50)}   # config -> (period, copies) of th
 MP_READS_DEFAULT = 400_000_000
 
 
-class Lib:
-    """One read library (an `alignments[]` / `raw_reads[]` entry of the reference's JSON) resident on this rank."""
-    pass
-
-
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +168,7 @@ def run(args):
     from gappadder_amd import _lib as B
     from gappadder_amd import sharding as SH
     from gappadder_amd.hip_api import GapFill
+    from gappadder_amd.pipeline import DeviceLibrary, Pipeline
 
     seed, slen, nscf, gps, glen, dreads, kk = PRESETS[args.config]
     if os.environ.get("GF_BENCH_KPAIRS"):            # diagnostics: other (k, kv) pairs than the config's, "31,29;41,39" (the line then names them)
@@ -188,27 +184,17 @@ def run(args):
     if args.config == "C5":
         mp = MP_READS_DEFAULT if args.mp_reads < 0 else args.mp_reads
         lib_defs.append(("mate-pair", 5000, 500, 1, mp // 2 * 2, int(os.environ.get("GF_BENCH_MP_PAIRS", "0"))))
-    n_lib = len(lib_defs)
 
     lib = B.lib()
     rb = lib.gf_packed_read_bytes(L)
     gf = GapFill(local)
-    # second context = second HIP stream on the same device: the alignment tagger + second hop are independent of the k-mer
-    # screen until the pools are built
     # One stream by default: every placement of the tagger beside the screen was measured (beside the filter, beside the verification
     # pass, as one-wave workgroups next to the filter's) and gave the SUM of the stand-alone times within 1-3 % (C4: 68.0 / 70.3 / 69.0
     # vs 68.3 ms in a row) — the kernels take turns on the memory system; in a row every kernel's HIP-event span is its own duration.
-    # GF_BENCH_TWO_STREAMS=1: tagger + second hop on a second context / stream beside the filter.
-    serial = os.environ.get("GF_BENCH_TWO_STREAMS", "0") != "1"
+    # GF_BENCH_TWO_STREAMS=1: tagger + second hop on a second context / stream beside the filter
     # (one per library: the tagger caches its coarse bin map per insert-size window)
+    serial = os.environ.get("GF_BENCH_TWO_STREAMS", "0") != "1"
     gf2s = [gf if serial else GapFill(local) for _ in lib_defs]
-    stream = None
-    if multi:
-        # the collectives are ordered against the kernels by running everything on ONE torch side stream (not the legacy
-        # default stream): the library adopts it
-        stream = torch.cuda.Stream(device=dev)
-        assert lib.gf_set_stream(gf.handle, C.c_void_p(stream.cuda_stream)) == 0
-    h = gf.handle
 
     rep_p, rep_c = REPEATS.get(args.config, (0, 50))
     cfg0 = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L,
@@ -224,164 +210,36 @@ def run(args):
             # (GF_BENCH_TAG_LIGHT=1: the one-wave tagger variant that fits on the CUs whose LDS the filter owns — measured: no gain, the two
             # kernels contend for the memory system, C4 78.6 vs 77.4 ms)
             g2.set_option("tag_light", int(os.environ.get("GF_BENCH_TAG_LIGHT", "0")))
-    batch = SH.owner_batch(n_gaps, world)
+
+    # The whole step lives in the package (gappadder_amd/pipeline.py: residency, sizing pass, capacities, recruit -> hop -> keys -> pools ->
+    # merge / owner exchange -> assembly -> pick): this file generates the inputs, calls it and times it
+    pipe = Pipeline(gf, n_gaps, L, kk, device=dev, world=world, rank=rank, backend=backend, force_exchange=multi and world == 1)
+    pipe.tag_after_filter = not serial and os.environ.get("GF_BENCH_TAG_AFTER_FILTER", "0") == "1"
+    h = gf.handle
 
     # ---- inputs resident in HBM (torch = device-memory plumbing) ----
     libs = []
     for name, is_mean, is_sd, lib_no, n_total, pull_mates in lib_defs:
-        lb = Lib()
-        lb.name, lb.is_mean, lb.is_sd, lb.pull_mates = name, is_mean, is_sd, pull_mates
-        lb.h2 = gf2s[len(libs)].handle
-        lb.cfg = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L,
-                                   insert_mean=is_mean, insert_sd=is_sd, library=lib_no, repeat_period=rep_p, repeat_copies=rep_c)
+        cfg = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L,
+                                insert_mean=is_mean, insert_sd=is_sd, library=lib_no, repeat_period=rep_p, repeat_copies=rep_c)
         p0, p1 = SH.shard_range(n_total // 2, rank, world)          # strong scaling: the same pairs, split
-        lb.first_pair, lb.n_pairs, lb.n_reads, lb.n_total = p0, p1 - p0, 2 * (p1 - p0), n_total
-        lb.d_reads = torch.empty(lb.n_reads * rb + 64, dtype=torch.uint8, device=dev)
-        lb.d_recs = torch.empty(max(1, lb.n_reads) * 32, dtype=torch.uint8, device=dev)
-        gf.synth_pairs_dev(lb.cfg, lb.first_pair, lb.n_pairs, lb.d_reads.data_ptr(), lb.d_recs.data_ptr())
-        lb.hit_cap = max(1 << 20, lb.n_reads // 8)
-        lb.d_hits = torch.empty(lb.hit_cap * 8, dtype=torch.uint8, device=dev)
-        lb.d_thits = torch.empty(lb.hit_cap * 12, dtype=torch.uint8, device=dev)
-        lb.d_lhits = torch.empty(lb.hit_cap * 12, dtype=torch.uint8, device=dev)
-        lb.d_low = torch.empty(lb.hit_cap * 12, dtype=torch.uint8, device=dev)   # MAPQ==0 records compacted by the tagger (2 %)
-        lb.key_cap = 4 * lb.hit_cap
-        lb.d_keys = torch.empty(lb.key_cap, dtype=torch.int64, device=dev)
-        lb.d_pool_off = torch.zeros(n_gaps + 1, dtype=torch.int64, device=dev)
-        # counters (device u32): 0 screen hits, 4 tagger hits, 8 second-hop hits, 12 keys, 24 pool error, 28 MAPQ==0 records,
-        # 29 second-hop table rows
-        lb.d_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
-        lb.cp = lb.d_cnt.data_ptr()
-        libs.append(lb)
+        n_reads = 2 * (p1 - p0)
+        d_reads = torch.empty(n_reads * rb + 64, dtype=torch.uint8, device=dev)
+        d_recs = torch.empty(max(1, n_reads) * 32, dtype=torch.uint8, device=dev)
+        gf.synth_pairs_dev(cfg, p0, p1 - p0, d_reads.data_ptr(), d_recs.data_ptr())
+        lb = DeviceLibrary(name, is_mean, is_sd, n_reads, d_reads, d_recs, pull_mates=pull_mates, n_total=n_total, first_pair=p0,
+                           tag_ctx=None if gf2s[len(libs)] is gf else gf2s[len(libs)])
+        lb.cfg = cfg
+        libs.append(pipe.add_library(lb))
     gf.sync()
-    gaps_n = n_gaps
-
-    # the reference recruits once, then assembles at every k (assemble_gaps.py:87-122): the screen runs at the SMALLEST k of the
-    # sweep — a read that shares a 51-mer with a flank shares its 31-mers too, so this is the superset every assembly k needs
-    k_screen = min(a for a, _ in kk)
-
-    def all_gather(dst, src):
-        SH.all_gather_slots(dst, src, backend)
-
-    def sync_all():
-        gf.sync()
-        for g2 in gf2s:
-            g2.sync()
-
-    tag_after_filter = not serial and os.environ.get("GF_BENCH_TAG_AFTER_FILTER", "0") == "1"
-
-    def recruit(lb):
-        assert lib.gf_stream_wait(lb.h2, h) == 0          # the previous consumers of the tagger buffers are done
-        if tag_after_filter:
-            # the tagger (a pure 32-B-record stream) starts when the k-mer FILTER has finished and runs beside the latency-bound
-            # verification pass: beside the filter the two only took turns on the memory system (C4: 36.5 ms together, 26.6 + 10.5 alone)
-            assert lib.gf_stream_wait_after_filter(lb.h2, h) == 0
-        rc = lib.gf_screen_reads_dev(h, lb.d_reads.data_ptr(), None, lb.n_reads, L, k_screen, 1, lb.d_hits.data_ptr(), lb.hit_cap, lb.cp)
-        assert rc == 0, rc
-        rc = lib.gf_tag_alignments_low_dev(lb.h2, lb.d_recs.data_ptr(), lb.n_reads, lb.is_mean, lb.is_sd, 250, 30, lb.d_thits.data_ptr(),
-                                           lb.hit_cap, lb.cp + 16, lb.d_low.data_ptr(), lb.hit_cap, lb.cp + 112)
-        assert rc == 0, rc
+    k_screen = pipe.k_screen
 
     # ---- sizing pass (untimed): second-hop table rows, pooled reads, exchange slots ----
-    screen_dropped = 0
-    for lb in libs:
-        recruit(lb)
-        nd = C.c_size_t(0)
-        assert lib.gf_screen_last_overflow(h, C.byref(nd)) == 0
-        screen_dropped += nd.value          # reads with more (position, gap) matches than the verification lists (low-complexity reads against hundreds of flanks)
-    sync_all()
+    pipe.prepare()
+    screen_dropped = pipe.screen_dropped
     if args.config in ("C2", "C3", "C4", "C5"):
         assert screen_dropped == 0, screen_dropped
-    for lb in libs:
-        n_th = int(lb.d_cnt[4])
-        assert n_th <= lb.hit_cap
-        th = np.frombuffer(lb.d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
-        lb.row_cap = 2 * int((th["kind"] == B.KIND_DISCORDANT).sum()) + 4096
-        if multi:
-            rc_t = torch.tensor([lb.row_cap], dtype=torch.int64, device=coll_dev)
-            dist.all_reduce(rc_t, op=dist.ReduceOp.MAX)
-            lb.row_cap = int(rc_t)
-            lb.d_rows_all = torch.empty(world * lb.row_cap * 16, dtype=torch.uint8, device=dev)
-            lb.d_rowgap_all = torch.empty(world * lb.row_cap, dtype=torch.int32, device=dev)
-            lb.d_nrows_all = torch.zeros(world, dtype=torch.int32, device=dev)
-            lb.d_rows_u = torch.empty(world * lb.row_cap * 16, dtype=torch.uint8, device=dev)
-            lb.d_rowgap_u = torch.empty(world * lb.row_cap, dtype=torch.int32, device=dev)
-            lb.d_nrows_u = torch.zeros(4, dtype=torch.int32, device=dev)
-        lb.d_rows = torch.empty(lb.row_cap * 16, dtype=torch.uint8, device=dev)
-        lb.d_row_gap = torch.empty(lb.row_cap, dtype=torch.int32, device=dev)
-
-    # Multi-rank runs: HIP-event spans of the parts of a step that do not shrink with the number of ranks (the union of the ranks'
-    # second-hop rows, merged on every rank) or that exist only there (the owner exchange: pack, all-gather of counts, all-to-all,
-    # merge) — `fixed_ms` of the line, for the scaling prediction of DESIGN.md §6
-    fixed_spans, fixed_on = [], [False]
-
-    def fixed_mark():
-        if not fixed_on[0]:
-            return None
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
-
-    def fixed_span(name, e0):
-        if e0 is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            fixed_spans.append((name, e0, e1))
-
-    def hop_and_keys(lb):
-        rc = lib.gf_second_hop_table_dev(lb.h2, lb.d_recs.data_ptr(), lb.d_thits.data_ptr(), lb.cp + 16, lb.hit_cap, lb.d_rows.data_ptr(),
-                                         lb.d_row_gap.data_ptr(), lb.row_cap, lb.cp + 116)
-        assert rc == 0, rc
-        if not multi:
-            rows_p, rowgap_p, nrows_p, rcap, hh = lb.d_rows.data_ptr(), lb.d_row_gap.data_ptr(), lb.cp + 116, lb.row_cap, lb.h2
-        else:
-            # the reads are sharded, the second hop is not: a MAPQ-0 record is linked to discordant mates of ANY rank's reads
-            # (collect_discordant_low_mapq_reads.py reads the whole discordant_reads_pos file), so the ranks all-gather their
-            # rows (fixed-size slots) and every rank sorts the union
-            assert lib.gf_stream_wait(h, lb.h2) == 0
-            ev0 = fixed_mark()
-            all_gather(lb.d_rows_all, lb.d_rows)
-            all_gather(lb.d_rowgap_all, lb.d_row_gap)
-            all_gather(lb.d_nrows_all, lb.d_cnt[29:30])
-            assert lib.gf_second_hop_table_merge_dev(h, lb.d_rows_all.data_ptr(), lb.d_rowgap_all.data_ptr(), lb.d_nrows_all.data_ptr(), world,
-                                                     lb.row_cap, lb.d_rows_u.data_ptr(), lb.d_rowgap_u.data_ptr(), world * lb.row_cap,
-                                                     lb.d_nrows_u.data_ptr()) == 0
-            fixed_span("second_hop_union", ev0)
-            rows_p, rowgap_p, nrows_p, rcap, hh = lb.d_rows_u.data_ptr(), lb.d_rowgap_u.data_ptr(), lb.d_nrows_u.data_ptr(), world * lb.row_cap, h
-        rc = lib.gf_tag_low_mapq_table_dev(hh, lb.d_low.data_ptr(), lb.cp + 112, lb.hit_cap, rows_p, nrows_p, rcap, lb.d_lhits.data_ptr(),
-                                           lb.hit_cap, lb.cp + 32)
-        assert rc == 0, rc
-        if hh is not h:
-            assert lib.gf_stream_wait(h, lb.h2) == 0          # pools need the tagger's and the second hop's hits
-        assert lib.gf_pool_keys_all_dev(h, lb.d_hits.data_ptr(), lb.cp, lb.hit_cap, lb.pull_mates, lb.d_recs.data_ptr(), lb.d_thits.data_ptr(), lb.cp + 16,
-                                        lb.hit_cap, lb.d_lhits.data_ptr(), lb.cp + 32, lb.hit_cap, rowgap_p,
-                                        lb.d_keys.data_ptr(), lb.key_cap, lb.cp + 48) == 0
-
-    def build_pools(lb, pool_ptr, pool_cap):
-        assert lib.gf_build_pools_dev(h, lb.d_reads.data_ptr(), lb.n_reads, L, lb.d_keys.data_ptr(), lb.cp + 48, lb.key_cap, pool_ptr,
-                                      pool_cap, lb.d_pool_off.data_ptr(), None, lb.cp + 96) == 0
-
-    def sizing_pools():
-        for lb in libs:
-            hop_and_keys(lb)
-            build_pools(lb, None, 0)        # offsets only
-    if stream is not None:
-        with torch.cuda.stream(stream):
-            sizing_pools()
-    else:
-        sizing_pools()
-    sync_all()
-    torch.cuda.synchronize()
-    rows_lib = [int(lb.d_pool_off[-1]) for lb in libs]
-    # largest merged pool (all libraries, all ranks): bounds the assembly's per-workgroup workspace slices
-    per_gap = sum((lb.d_pool_off[1:] - lb.d_pool_off[:-1]) for lb in libs).to(coll_dev)
-    if multi:
-        dist.all_reduce(per_gap, op=dist.ReduceOp.SUM)
-    max_pool_rows = int(per_gap.max())
-    # bound on the rows of one pool = the workspace slice of the assembly's main launch.  Deeper pools are not an error (they take the
-    # assembly's second launch, option asm_big_pool_reads), so the bound needs no safety margin, and where a few repeat gaps hold many
-    # times the reads of the others (C2R) it follows the bulk of the pools, not the deepest one
-    asm_bound = max_pool_rows if max_pool_rows <= 4096 else max(4096, int(np.percentile(per_gap.cpu().numpy(), 99)))
-    gf.set_option("asm_max_pool_reads", asm_bound)
+    max_pool_rows, asm_bound, per_gap = pipe.max_pool_rows, pipe.asm_bound, pipe.per_gap
     if os.environ.get("GF_BENCH_SCREEN_VARIANT"):    # filter kernel (experiments: 17 = pass A with unaligned runs)
         gf.set_option("screen_variant", int(os.environ["GF_BENCH_SCREEN_VARIANT"]))
     if os.environ.get("GF_BENCH_ASM_SIMPLIFY"):      # rounds of tip clipping + bubble popping (experiments; the parity sample then disagrees unless it is 2)
@@ -392,98 +250,8 @@ def run(args):
         gf.set_option("asm_sweep", int(os.environ["GF_BENCH_ASM_SWEEP"]))
     if os.environ.get("GF_BENCH_ASM_THREADS"):       # threads per gap in the assembly kernel (1024 / 512 / 256; default: by the pool bound)
         gf.set_option("asm_threads", int(os.environ["GF_BENCH_ASM_THREADS"]))
-    lib_cap = max(4096, int(1.25 * max(rows_lib)) + 1024)            # rows of one library's pool array
-    # local pool arrays: [n_lib][lib_cap] rows (slot l = library l: the source layout of gf_pools_merge_dev)
-    d_pools = torch.empty(n_lib * lib_cap * rb + 64, dtype=torch.uint8, device=dev)
-    pool_ptr = [d_pools.data_ptr() + l * lib_cap * rb for l in range(n_lib)]
-    d_xerr = torch.zeros(4, dtype=torch.int32, device=dev)
-    d_libcnt = torch.zeros(n_lib * n_gaps, dtype=torch.int32, device=dev)         # [n_lib][n_gaps]
-    if multi:
-        owner = SH.gap_owner(n_gaps, world).to(dev)
-        per_dst = torch.zeros(n_lib, world, dtype=torch.int64, device=dev)
-        for l, lb in enumerate(libs):
-            cnt = (lb.d_pool_off[1:] - lb.d_pool_off[:-1])
-            per_dst[l].index_add_(0, owner, cnt)
-        mx = per_dst.max().to(coll_dev)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        slot_cap = max(1024, int(1.25 * int(mx)) + 256)
-        mine = per_dst[:, rank].sum().to(coll_dev)
-        recv_rows = mine.clone()
-        dist.all_reduce(recv_rows, op=dist.ReduceOp.SUM)    # upper bound of what any owner receives: every rank's rows for it
-        tot = torch.stack([per_dst[:, r].sum() for r in range(world)]).to(coll_dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        merged_cap = max(4096, int(1.25 * int(tot.max())) + 1024)
-        xchg = SH.OwnerExchange(world, n_lib, n_gaps, slot_cap, rb, dev, backend)
-    else:
-        slot_cap = lib_cap
-        merged_cap = max(4096, int(1.25 * sum(rows_lib)) + 1024)
-    need_merge = multi or n_lib > 1
-    d_merged = torch.empty(merged_cap * rb + 64, dtype=torch.uint8, device=dev) if need_merge else None
-    d_moff = torch.zeros(n_gaps + 1, dtype=torch.int64, device=dev)
-    # (contigs: a few dozen per gap and k on an i.i.d. draft; the deep pools of a repeat-bearing draft fragment into many more: room grows with the pooled reads)
-    contig_cap, seq_cap = (64 * n_gaps + 4096 + sum(rows_lib) // 4) * len(kk), (24576 * n_gaps + (1 << 20) + 32 * sum(rows_lib)) * len(kk)
-    d_ctg = torch.empty(contig_cap * 32, dtype=torch.uint8, device=dev)
-    d_seq = torch.empty(seq_cap, dtype=torch.uint8, device=dev)
-    d_gap_err = torch.zeros(n_gaps, dtype=torch.int32, device=dev)
-    d_best = torch.zeros(n_gaps, dtype=torch.int64, device=dev)
-    # assembly counters: 0 contigs (u32), 2-3 contig bases (u64), 4 gaps closed (u32)
-    d_acnt = torch.zeros(8, dtype=torch.int32, device=dev)
-    ap_ = d_acnt.data_ptr()
-    k_arr = (C.c_int * len(kk))(*[a for a, _ in kk])
-    kv_arr = (C.c_int * len(kk))(*[b for _, b in kk])
-
-    def step():
-        for lb in libs:
-            recruit(lb)
-        for l, lb in enumerate(libs):
-            hop_and_keys(lb)
-            build_pools(lb, pool_ptr[l], lib_cap)
-        # (zeroed through the library = on its stream; a torch op here would run on torch's stream)
-        assert lib.gf_memset_dev(h, d_xerr.data_ptr(), 0, 16) == 0 and lib.gf_memset_dev(h, d_best.data_ptr(), 0, 8 * n_gaps) == 0
-        assert lib.gf_memset_dev(h, ap_ + 16, 0, 16) == 0
-        if not need_merge:
-            asm_ptr, asm_off, asm_rows = pool_ptr[0], libs[0].d_pool_off.data_ptr(), lib_cap
-        elif not multi:
-            for l, lb in enumerate(libs):
-                assert lib.gf_pool_counts_dev(h, lb.d_pool_off.data_ptr(), n_gaps, d_libcnt.data_ptr() + 4 * l * n_gaps) == 0
-            assert lib.gf_pools_merge_dev(h, d_pools.data_ptr(), lib_cap, d_libcnt.data_ptr(), n_lib, 1, n_gaps, L, 0, 1, batch,
-                                          d_merged.data_ptr(), merged_cap, d_moff.data_ptr(), d_xerr.data_ptr()) == 0
-            asm_ptr, asm_off, asm_rows = d_merged.data_ptr(), d_moff.data_ptr(), merged_cap
-        else:
-            # the one exchange step: rows regrouped by owner rank, counts all-gathered, slots all-to-all'ed
-            # (equal-sized slots: no host sizes, no host sync), owners merge in (library, source rank) order
-            def pack(l, send, cap, cnt):
-                assert lib.gf_pools_pack_for_owners_dev(h, pool_ptr[l], libs[l].d_pool_off.data_ptr(), n_gaps, L, world, batch, l, n_lib,
-                                                        send.data_ptr(), cap, cnt.data_ptr(), d_xerr.data_ptr()) == 0
-
-            def merge(recv, cap, all_cnt):
-                assert lib.gf_pools_merge_dev(h, recv.data_ptr(), cap, all_cnt.data_ptr(), n_lib, world, n_gaps, L, rank, world, batch,
-                                              d_merged.data_ptr(), merged_cap, d_moff.data_ptr(), d_xerr.data_ptr()) == 0
-            ev0 = fixed_mark()
-            xchg.run(pack, merge)
-            fixed_span("owner_exchange", ev0)
-            asm_ptr, asm_off, asm_rows = d_merged.data_ptr(), d_moff.data_ptr(), merged_cap
-        rc = lib.gf_assemble_multi_dev(h, asm_ptr, None, asm_off, n_gaps, asm_rows, L, k_arr, kv_arr, len(kk), 2, 40,
-                                       d_ctg.data_ptr(), contig_cap, ap_, d_seq.data_ptr(), seq_cap, ap_ + 8, d_gap_err.data_ptr())
-        assert rc == 0, rc
-        # which gaps are closed: both flanks anchored on one contig (pick_contigs.py:64-358; scores 30 then 15, assemble_gaps.py:336, 365)
-        assert lib.gf_pick_anchored2_dev(h, d_ctg.data_ptr(), ap_, contig_cap, d_seq.data_ptr(), 30, 15, d_best.data_ptr(), ap_ + 16) == 0
-
-    def run_steps(n):
-        if stream is not None:
-            with torch.cuda.stream(stream):
-                for _ in range(n):
-                    step()
-        else:
-            for _ in range(n):
-                step()
-
-    def barrier():
-        sync_all()
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
+    n_lib = len(libs)
+    need_merge = pipe.need_merge
 
     d_astat = torch.zeros(4, dtype=torch.int64, device=dev)      # windows, k-mers counted exactly, surviving k-mers, nodes (all steps, all k)
     gf.set_option("asm_stats_ptr", d_astat.data_ptr())
@@ -491,21 +259,22 @@ def run(args):
     if os.environ.get("GF_BENCH_ASM_PROBE"):      # diagnostic (needs GF_DIAGNOSTICS=1): per-gap phase stamps of the LAST assembly launch
         d_dbg = torch.zeros(n_gaps * 16, dtype=torch.int64, device=dev)
         gf.set_option("asm_dbg_ptr", d_dbg.data_ptr())
-    run_steps(args.warmup)
-    barrier()
+    pipe.step(args.warmup)
+    pipe.barrier()
     d_astat.zero_()
     torch.cuda.synchronize()
-    [g_.timing(True) for g_ in {id(x): x for x in [gf] + gf2s}.values()]
-    fixed_on[0] = multi
+    ctxs = pipe.contexts()
+    [g_.timing(True) for g_ in ctxs]
+    # Multi-rank runs: HIP-event spans of the parts of a step that do not shrink with the number of ranks (the union of the ranks'
+    # second-hop rows, merged on every rank) or that exist only there (the owner exchange: pack, all-gather of counts, all-to-all,
+    # merge) — `fixed_ms` of the line, for the scaling prediction of DESIGN.md §6
+    pipe.fixed_on = multi
     t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
+    pipe.step(args.steps)
+    pipe.barrier()
     dt = time.perf_counter() - t0
-    fixed_on[0] = False
-    fixed_ms = {}
-    for name, e0, e1 in fixed_spans:
-        fixed_ms[name] = fixed_ms.get(name, 0.0) + e0.elapsed_time(e1) / args.steps
-    ctxs = list({id(x): x for x in [gf] + gf2s}.values())
+    pipe.fixed_on = False
+    fixed_ms = pipe.fixed_ms(args.steps)
 
     def ktime(idx):     # (total ms, launches) of one kernel group over all contexts
         tt = [g_.kernel_time(idx) for g_ in ctxs]
@@ -513,7 +282,7 @@ def run(args):
     kt = {name: ktime(idx) for name, idx in (("screen_filter", B.KERNEL_SCREEN), ("screen_verify", B.KERNEL_VERIFY),
                                              ("tag_alignments", B.KERNEL_TAG), ("tag_low_mapq", B.KERNEL_LOWMAPQ),
                                              ("pools", B.KERNEL_POOL), ("assemble", B.KERNEL_ASSEMBLE), ("pick_anchored", B.KERNEL_PICK))}
-    [g_.timing(False) for g_ in {id(x): x for x in [gf] + gf2s}.values()]
+    [g_.timing(False) for g_ in ctxs]
     if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -542,33 +311,24 @@ def run(args):
     # ---- results of the last step ----
     astat = (d_astat.cpu().numpy().astype(np.float64) / max(1, args.steps))      # per step (this rank's gaps)
     gf.set_option("asm_stats_ptr", 0)
-    acnt = d_acnt.cpu().numpy()
-    n_ctg, n_seq, n_closed_local = int(acnt[0]), int(acnt[2:4].view(np.uint64)[0]), int(acnt[4])
-    xerr = int(d_xerr[0])
-    for lb in libs:
-        c = lb.d_cnt.cpu().numpy()
-        lb.counts = {"screen_hits": int(c[0]), "tagger_hits": int(c[4]), "second_hop_hits": int(c[8]), "pool_keys": int(c[12]),
-                     "pooled_reads": int(lb.d_pool_off[-1])}
-        assert int(c[0]) <= lb.hit_cap and int(c[4]) <= lb.hit_cap and int(c[8]) <= lb.hit_cap and int(c[12]) <= lb.key_cap
-        assert int(c[28]) <= lb.hit_cap and int(c[29]) <= lb.row_cap and int(c[24]) == 0, (int(c[24]), int(c[28]), int(c[29]))
-    assert xerr == 0 and int(d_gap_err.sum()) == 0 and n_ctg <= contig_cap and n_seq <= seq_cap, (xerr, int(d_gap_err.sum()), n_ctg, n_seq)
-    asm_off_t = d_moff if need_merge else libs[0].d_pool_off
-    asm_pool_t = d_merged if need_merge else d_pools
-    asm_rows_total = int(asm_off_t[-1])
+    res = pipe.fetch()          # synchronises; raises on any capacity / overflow flag of the step
+    n_ctg, n_seq, n_closed_local = res.n_contigs, res.n_seq, res.n_closed
+    asm_off_t, asm_pool_t, asm_rows_total = res.asm_off_t, res.asm_pool_t, res.asm_rows_total
+    d_seq, d_best = pipe.d_seq, pipe.d_best
     _t, _m, _l = C.c_int(0), C.c_uint32(0), C.c_uint32(0)     # the last (k, kv) pair's launches: threads per gap, gaps handed to the 1 024-thread launch, pools beyond the bound
     assert lib.gf_assemble_last_launch(gf.handle, C.byref(_t), C.byref(_m), C.byref(_l)) == 0
     asm_launch = {"threads_per_gap": _t.value, "gaps_to_the_whole_cu_launch": _m.value, "pools_to_the_last_launch": _l.value}
-    ctg = np.frombuffer(d_ctg[:n_ctg * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
+    ctg = res.contigs
     n_closed, n_ctg_all, gaps_with_contig = n_closed_local, n_ctg, int(len(np.unique(ctg["gap"])))
     gather_ms = None
     # ground truth (untimed): the sequence picked for every closed gap of this rank against the true bases behind the planted gap
-    seq_host = d_seq[:n_seq].cpu().numpy().tobytes()
-    truth = truth_check(cfg0, gaps, flanks, ctg, seq_host, d_best.cpu().numpy().view(np.uint64), GapFill)
+    seq_host = res.seq
+    truth = truth_check(cfg0, gaps, flanks, ctg, seq_host, res.best, GapFill)
     assert truth["closed"] == n_closed_local, (truth["closed"], n_closed_local)
     n_correct = truth["correct"]
     census = None
     if not multi and n_closed_local:      # (runs that close gaps at all: with the 300-bp library alone every 2-kb gap is a coverage hole)
-        census = open_gap_census(cfg0, gaps, ctg, seq_host, d_best.cpu().numpy().view(np.uint64), GapFill)
+        census = open_gap_census(cfg0, gaps, ctg, seq_host, res.best, GapFill)
     if multi:
         red = torch.tensor([n_closed_local, n_ctg, gaps_with_contig, asm_rows_total, n_correct], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
@@ -577,7 +337,7 @@ def run(args):
         # of every closed gap — or every contig when --dump-contigs asks for the full comparison
         tg = time.perf_counter()
         seq_local = seq_host
-        best = d_best.cpu().numpy().view(np.uint64)
+        best = res.best
         if args.dump_contigs:
             sel = range(n_ctg)
         else:
@@ -627,7 +387,7 @@ def run(args):
                                     "the same reads split over the ranks (contiguous pair ranges), gaps + flank index replicated; per-gap pools "
                                     "sent to one owner rank per gap (batches of %d gaps round-robin; device pack + all-gather of counts + "
                                     "equal-slot all-to-all + device merge, no host sync), every gap assembled once by its owner from all "
-                                    "ranks' recruits; final gather of the closed gaps' contigs on rank 0" % batch)},
+                                    "ranks' recruits; final gather of the closed gaps' contigs on rank 0" % pipe.batch)},
             "gaps_per_s": n_gaps / step_s,
             "gaps_closed_per_s": n_closed / step_s,
             "gaps_closed_correct_per_s": n_correct / step_s,

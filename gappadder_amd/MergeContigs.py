@@ -240,6 +240,15 @@ def merge_edges(gf, working_folder, id_list, kmer_len_quick=10, params=None):
     return out
 
 
+def _swap_in(folder, new_name):
+    """contigs.fa := folder/new_name, the assembly's own contigs kept as original_contigs_before_merging.fa.  The backup is a COPY
+    and contigs.fa is replaced in one rename, so that a failure at either step leaves the gap WITH a contigs.fa (the picking and
+    bridging steps that follow look for it)."""
+    import shutil
+    shutil.copyfile(folder + "contigs.fa", folder + "original_contigs_before_merging.fa")
+    os.replace(folder + new_name, folder + "contigs.fa")
+
+
 def merge_contigs(gf, working_folder, id_list, kmer_len_quick=10, params=None):
     """merge_contigs (MergeContigs.py:66-99) for every gap of id_list.  Returns {gap id: number of NEW_CONTIG_MERGE records}."""
     ids, recs = _sets(working_folder, id_list)
@@ -251,8 +260,7 @@ def merge_contigs(gf, working_folder, id_list, kmer_len_quick=10, params=None):
         _write_fasta(folder + "contigs.fa_no_dup.fa", nodup)
         if os.path.getsize(folder + "contigs.fa_no_dup.fa") > 1000000 or len(nodup) > MAX_SET:      # MergeContigs.py:70-74
             try:
-                os.replace(folder + "contigs.fa", folder + "original_contigs_before_merging.fa")
-                os.replace(folder + "contigs.fa_no_dup.fa", folder + "contigs.fa")
+                _swap_in(folder, "contigs.fa_no_dup.fa")
             except OSError as e:
                 import sys
                 sys.stderr.write("contig merging: gap %s keeps its contigs (%r)\n" % (gid, e))
@@ -290,8 +298,7 @@ def merge_contigs(gf, working_folder, id_list, kmer_len_quick=10, params=None):
         final = drop_contained(merged_recs)
         try:            # per gap: a failed write leaves THIS gap's contigs.fa as it was (the merged set goes to a temporary name first)
             _write_fasta(folder + "contigs.fa.merged.tmp", final)
-            os.replace(folder + "contigs.fa", folder + "original_contigs_before_merging.fa")
-            os.replace(folder + "contigs.fa.merged.tmp", folder + "contigs.fa")
+            _swap_in(folder, "contigs.fa.merged.tmp")
             done[gid] = len(new)
         except OSError as e:
             import sys

@@ -1898,9 +1898,11 @@ AsmGeom asm_geometry(const gf_ctx* ctx, size_t n_pools, size_t total_reads, int 
 int asm_workspace(gf_ctx* ctx, const AsmGeom& G, bool jump) {
     int rc;
     {   // the table must be all-EMPTY (id 0xFFFFFFFF, meta 0) on entry; kernels leave it so, a fresh buffer is filled once
-        void* before = ctx->asm_table.p;
+        // (a re-created buffer is recognised by its SIZE: hipFree + hipMalloc of a larger one may hand back the same base address)
+        const void* before = ctx->asm_table.p;
+        const size_t bytes_before = ctx->asm_table.bytes;
         if ((rc = ensure(ctx, ctx->asm_table, std::max<uint64_t>(G.n_inst, 1) * 4 * 8))) return rc;
-        if (ctx->asm_table.p != before) {
+        if (ctx->asm_table.p != before || ctx->asm_table.bytes != bytes_before) {
             const size_t words = ctx->asm_table.bytes / 8;
             hipLaunchKernelGGL(fill_empty_kernel, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream,
                                (unsigned long long*)ctx->asm_table.p, (uint64_t)words);
@@ -2118,6 +2120,9 @@ int launch_assemble_sweep(gf_ctx* ctx, const void* d_pool, const void* d_pool_of
         else hipLaunchKernelGGL(assemble_sweep_kernel<512>, dim3(G.grid), dim3(512), (size_t)P[0].lds_words * 4, ctx->stream, P[0], P[1], P[2]);
         for (int i = 0; i < 3; ++i) asm_launch_big(ctx, G, P[i], d_next + 2 + i, P[i].big_list, P[i].n_big);
     }
+    // gf_assemble_last_launch describes a per-pair launch group (its counters are counters[8..13]): after a sweep it reports zeros
+    ctx->asm_last_threads = 0;
+    ctx->asm_last_split = false;
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
 }

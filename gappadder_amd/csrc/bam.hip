@@ -502,6 +502,66 @@ __global__ __launch_bounds__(256) void bam_fetch_kernel(const uint8_t* stream, c
     for (uint64_t k = lane; k < len; k += 64) d[k] = s[k];
 }
 
+// The record chain of the inflated stream in ctx->bam_stream: per 64-KiB segment the offset of the first record that starts in it
+// (guess -> walk -> check rounds until every segment's entry equals its predecessor's exit) and the exclusive scan of the segments'
+// record counts.  Workspace in ctx->pool_ws; `extra_ws` more bytes are reserved behind it for the caller (*d_extra).
+void bam_scan_launch(gf_ctx* ctx, const uint32_t* cnt, uint32_t n, unsigned long long* off) {
+    hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, n, off);
+}
+
+int bam_chain(gf_ctx* ctx, size_t n_bytes, size_t first, size_t n_ref, unsigned long long** d_guess_out, unsigned long long** d_rec_off_out, uint64_t* n_seg_out,
+              size_t* n_recs, size_t* n_consumed, size_t extra_ws, uint8_t** d_extra) {
+    int rc;
+    const uint64_t n_seg = (n_bytes - first + BAM_SEG - 1) / BAM_SEG;
+    if (n_seg >= 0xFFFFFFFFull) return GF_E_UNSUPPORTED;
+    const size_t b_g = (n_seg * 8 + 63) & ~(size_t)63, b_c = (n_seg * 4 + 63) & ~(size_t)63, b_o = ((n_seg + 1) * 8 + 63) & ~(size_t)63,
+                 b_t = (n_seg + 63) & ~(size_t)63;
+    if ((rc = ensure(ctx, ctx->pool_ws, 2 * b_g + b_c + b_o + b_t + 128 + extra_ws))) return rc;
+    uint8_t* wsp = (uint8_t*)ctx->pool_ws.p;
+    unsigned long long* d_guess = (unsigned long long*)wsp;
+    unsigned long long* d_exit = (unsigned long long*)(wsp + b_g);
+    uint32_t* d_cnt = (uint32_t*)(wsp + 2 * b_g);
+    unsigned long long* d_off = (unsigned long long*)(wsp + 2 * b_g + b_c);
+    uint8_t* d_todo = wsp + 2 * b_g + b_c + b_o;
+    uint32_t* d_flags = (uint32_t*)(wsp + 2 * b_g + b_c + b_o + b_t);   // [0] mismatches
+    *d_extra = wsp + 2 * b_g + b_c + b_o + b_t + 128;
+    const BamStream B{(const uint8_t*)ctx->bam_stream.p, (uint64_t)n_bytes, (uint64_t)first, (int32_t)n_ref};
+    const unsigned grid = (unsigned)((n_seg + 255) / 256);
+    LaunchTimer tm(ctx, GF_KERNEL_INGEST);
+    hipLaunchKernelGGL(bam_guess_kernel, dim3(grid), dim3(256), 0, ctx->stream, B, n_seg, d_guess);
+    hipLaunchKernelGGL(bam_walk_kernel, dim3(grid), dim3(256), 0, ctx->stream, B, n_seg, d_guess, d_exit, d_cnt, (const uint8_t*)nullptr);
+    for (uint64_t round = 0;; ++round) {
+        uint32_t fl[1] = {0};
+        GF_HIP(ctx, hipMemsetAsync(d_flags, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(bam_check_kernel, dim3(grid), dim3(256), 0, ctx->stream, n_seg, d_guess, d_exit, d_todo, d_flags);
+        GF_HIP(ctx, hipMemcpyAsync(fl, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (fl[0] == 0) break;
+        if (round > n_seg) return GF_E_FORMAT;
+        hipLaunchKernelGGL(bam_walk_kernel, dim3(grid), dim3(256), 0, ctx->stream, B, n_seg, d_guess, d_exit, d_cnt, (const uint8_t*)d_todo);
+    }
+    hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_cnt, (uint32_t)n_seg, d_off);
+    unsigned long long total = 0, last_exit = 0;
+    GF_HIP(ctx, hipMemcpyAsync(&total, d_off + n_seg, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(&last_exit, d_exit + (n_seg - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((last_exit & BAM_TAIL) && (last_exit & ~BAM_TAIL) + 4 <= n_bytes) {   // the chain stopped early: incomplete record, or corrupt?
+        int32_t bs = 0;
+        GF_HIP(ctx, hipMemcpyAsync(&bs, B.p + (last_exit & ~BAM_TAIL), 4, hipMemcpyDeviceToHost, ctx->stream));
+        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (bs < 32) {
+            ctx->last_error = "BAM record at inflated offset " + std::to_string(last_exit & ~BAM_TAIL) + " has block_size " + std::to_string(bs);
+            return GF_E_FORMAT;
+        }
+    }
+    *n_recs = (size_t)total;
+    *n_consumed = (size_t)(last_exit & ~BAM_TAIL);
+    *d_guess_out = d_guess;
+    *d_rec_off_out = d_off;
+    *n_seg_out = n_seg;
+    return GF_OK;
+}
+
 }  // namespace gf
 
 using namespace gf;
@@ -598,51 +658,17 @@ int gf_bam_pack(gf_ctx* ctx, const uint8_t* stream_or_null, size_t n_bytes, size
         return GF_E_STATE;   // no stream left on the device by gf_bgzf_inflate, or a different length
     }
     if (first == n_bytes) return GF_OK;
-    const uint64_t n_seg = (n_bytes - first + BAM_SEG - 1) / BAM_SEG;
-    if (n_seg >= 0xFFFFFFFFull) return GF_E_UNSUPPORTED;
-    const size_t b_g = (n_seg * 8 + 63) & ~(size_t)63, b_c = (n_seg * 4 + 63) & ~(size_t)63, b_o = ((n_seg + 1) * 8 + 63) & ~(size_t)63,
-                 b_t = (n_seg + 63) & ~(size_t)63, b_map = (n_ref * 4 + 63) & ~(size_t)63;
-    if ((rc = ensure(ctx, ctx->pool_ws, 2 * b_g + b_c + b_o + b_t + b_map + 128))) return rc;
-    uint8_t* wsp = (uint8_t*)ctx->pool_ws.p;
-    unsigned long long* d_guess = (unsigned long long*)wsp;
-    unsigned long long* d_exit = (unsigned long long*)(wsp + b_g);
-    uint32_t* d_cnt = (uint32_t*)(wsp + 2 * b_g);
-    unsigned long long* d_off = (unsigned long long*)(wsp + 2 * b_g + b_c);
-    uint8_t* d_todo = wsp + 2 * b_g + b_c + b_o;
-    uint32_t* d_map = (uint32_t*)(wsp + 2 * b_g + b_c + b_o + b_t);
-    uint32_t* d_flags = (uint32_t*)(wsp + 2 * b_g + b_c + b_o + b_t + b_map);   // [0] mismatches
+    unsigned long long *d_guess = nullptr, *d_off = nullptr;
+    uint64_t n_seg = 0;
+    uint8_t* d_extra = nullptr;
+    const size_t b_map = (n_ref * 4 + 63) & ~(size_t)63;
+    if ((rc = bam_chain(ctx, n_bytes, first, n_ref, &d_guess, &d_off, &n_seg, n_recs, n_consumed, b_map + 64, &d_extra))) return rc;
+    uint32_t* d_map = (uint32_t*)d_extra;
     if (n_ref) GF_HIP(ctx, hipMemcpyAsync(d_map, ref_map, n_ref * 4, hipMemcpyHostToDevice, ctx->stream));
     const BamStream B{(const uint8_t*)ctx->bam_stream.p, (uint64_t)n_bytes, (uint64_t)first, (int32_t)n_ref};
     const unsigned grid = (unsigned)((n_seg + 255) / 256);
+    const unsigned long long total = *n_recs;
     LaunchTimer tm(ctx, GF_KERNEL_INGEST);
-    hipLaunchKernelGGL(bam_guess_kernel, dim3(grid), dim3(256), 0, ctx->stream, B, n_seg, d_guess);
-    hipLaunchKernelGGL(bam_walk_kernel, dim3(grid), dim3(256), 0, ctx->stream, B, n_seg, d_guess, d_exit, d_cnt, (const uint8_t*)nullptr);
-    for (uint64_t round = 0;; ++round) {
-        uint32_t fl[1] = {0};
-        GF_HIP(ctx, hipMemsetAsync(d_flags, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(bam_check_kernel, dim3(grid), dim3(256), 0, ctx->stream, n_seg, d_guess, d_exit, d_todo, d_flags);
-        GF_HIP(ctx, hipMemcpyAsync(fl, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
-        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (fl[0] == 0) break;
-        if (round > n_seg) return GF_E_FORMAT;
-        hipLaunchKernelGGL(bam_walk_kernel, dim3(grid), dim3(256), 0, ctx->stream, B, n_seg, d_guess, d_exit, d_cnt, (const uint8_t*)d_todo);
-    }
-    hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_cnt, (uint32_t)n_seg, d_off);
-    unsigned long long total = 0, last_exit = 0;
-    GF_HIP(ctx, hipMemcpyAsync(&total, d_off + n_seg, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GF_HIP(ctx, hipMemcpyAsync(&last_exit, d_exit + (n_seg - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if ((last_exit & BAM_TAIL) && (last_exit & ~BAM_TAIL) + 4 <= n_bytes) {   // the chain stopped early: incomplete record, or corrupt?
-        int32_t bs = 0;
-        GF_HIP(ctx, hipMemcpyAsync(&bs, B.p + (last_exit & ~BAM_TAIL), 4, hipMemcpyDeviceToHost, ctx->stream));
-        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (bs < 32) {
-            ctx->last_error = "BAM record at inflated offset " + std::to_string(last_exit & ~BAM_TAIL) + " has block_size " + std::to_string(bs);
-            return GF_E_FORMAT;
-        }
-    }
-    *n_recs = (size_t)total;
-    *n_consumed = (size_t)(last_exit & ~BAM_TAIL);
     ctx->bam_n_recs = 0;
     if (total > cap_recs) return GF_E_NOSPACE;
     if (total) {

@@ -50,8 +50,9 @@ __global__ void keys_from_tags_kernel(const gf_alnrec* recs, const gf_taghit* hi
         const uint32_t i = i0 + threadIdx.x;
         if (i < n) {
             const gf_taghit h = hits[i];
-            const uint32_t read = (uint32_t)recs[h.rec].read ^ (h.to_mate ? 1u : 0u);
-            const uint32_t gap = row_gap ? row_gap[h.gap] : h.gap;
+            // (a record without a read — QNAME in no FASTQ record, gf_read_join_dev — recruits nothing: its key names no gap)
+            const uint32_t own = (uint32_t)recs[h.rec].read, read = own ^ (h.to_mate ? 1u : 0u);
+            const uint32_t gap = own == 0xFFFFFFFFu ? 0xFFFFFFFFu : (row_gap ? row_gap[h.gap] : h.gap);
             const uint32_t o = s_base + threadIdx.x;
             if (o < key_cap) keys[o] = ((unsigned long long)gap << 32) | read;
         }
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(256) void keys_all_kernel(const gf_hit* hits, const
         } else {
             const bool second = i >= (uint64_t)n1 + n2;
             const gf_taghit h = second ? lhits[i - n1 - n2] : thits[i - n1];
-            const uint32_t read = (uint32_t)recs[h.rec].read ^ (h.to_mate ? 1u : 0u);
-            const uint32_t gap = second ? row_gap[h.gap] : h.gap;
+            const uint32_t own = (uint32_t)recs[h.rec].read, read = own ^ (h.to_mate ? 1u : 0u);
+            const uint32_t gap = own == 0xFFFFFFFFu ? 0xFFFFFFFFu : (second ? row_gap[h.gap] : h.gap);   // no read (gf_read_join_dev): no gap
             const uint64_t o = (uint64_t)n1 * per + (i - n1);
             if (o < key_cap) keys[o] = ((unsigned long long)gap << 32) | read;
         }

@@ -188,6 +188,41 @@ int gf_tag_low_mapq_bam(gf_ctx* ctx, const gf_dpos* table, size_t n_rows, gf_tag
  * copying every inflated byte back.  *n_bytes = total size; GF_E_NOSPACE when cap is smaller. */
 int gf_bam_fetch(gf_ctx* ctx, const uint64_t* begin, const uint64_t* end, size_t n, uint8_t* dst, size_t cap, size_t* n_bytes);
 
+/* ---- files -> a library RESIDENT in HBM (the device pipeline of the CLI, gappadder_amd/device_collect.py; csrc/resident.hip).
+ * The reference joins alignments and reads by NAME (list lines carry QNAME, collect_reads_for_gaps.py:119-159; the FASTQ line machine
+ * looks the id of every record up in {readId -> set(gapKey)}, run_multi_threads_discordant.py:153-185, 209-241); the device pipeline
+ * addresses reads by index (gf_alnrec.read = 2 * FASTQ record number + mate), which these calls establish once per library. */
+/* 64-bit hash of the id of every record of a FASTQ chunk on the device — the id as the reference cuts it: first whitespace token of the
+ * header line, up to the first '/', first character ('@') dropped (run_multi_threads_discordant.py:212-214) — and the length of the
+ * longest sequence line (atomicMax into *d_max_len, u32: the caller zeroes it).  d_hdr_begin as written by gf_fastq_pack_dev. */
+int gf_fastq_index_dev(gf_ctx* ctx, const void* d_text, size_t n_bytes, const void* d_hdr_begin, size_t n_reads, void* d_id_hash /* u64[n_reads] */,
+                       void* d_max_len);
+/* gf_bam_pack for a resident library: the records of the inflated stream gf_bgzf_inflate left on the device are APPENDED to the caller's
+ * device array d_recs at index rec_base (capacity rec_cap records), with
+ *   d_qhash[rec]     the same 64-bit hash of the record's QNAME (raw, as the reference compares it), or NULL;
+ *   d_names / d_name_off[rec]  the QNAME bytes back to back in a caller's arena (appended at name_base, capacity name_cap bytes) and the
+ *                    offset of each (d_name_off[rec_base + n] = end of the last), or NULL: the host later fetches the names of the few
+ *                    records that produce a hit (gf_fetch_slices) for the list files of the reference's file contract;
+ *   d_ref_seen[scaffold] |= 1 for a record on that scaffold, |= 2 for a MAPQ-0 record (u32 per .fai scaffold, caller zeroes), or NULL:
+ *                    which per-scaffold list files the reference would have opened (collect_reads_for_gaps.py:93-102).
+ * gf_alnrec.read is left 0xFFFFFFFF ("no read") until gf_read_join_dev.  *n_recs / *n_name_bytes = what the chunk holds; GF_E_NOSPACE
+ * (nothing written) when a capacity is too small: grow and call again, the stream is still there. */
+int gf_bam_append_dev(gf_ctx* ctx, size_t n_bytes, size_t first, const uint32_t* ref_map, size_t n_ref, void* d_recs, size_t rec_base, size_t rec_cap,
+                      void* d_qhash_or_null, void* d_names_or_null, size_t name_base, size_t name_cap, void* d_name_off_or_null,
+                      void* d_ref_seen_or_null, size_t n_scaffolds, size_t* n_recs, size_t* n_name_bytes, size_t* n_consumed);
+/* the join: gf_alnrec.read = 2 * (number of the FASTQ record whose id hash equals the record's QNAME hash) + (FLAG & 0x40 ? 0 : 1), or
+ * 0xFFFFFFFF when there is none (such a record recruits nothing).  d_id_hash = the ids of ONE mate file (both files of a pair carry the
+ * same ids in the same order: the caller checks that).  d_stats (u32[4], written): [0] ids that occur more than once, [1] records
+ * without a read.  By hash: the caller verifies the names of the records that matter (the hits) and fails loudly on a mismatch. */
+int gf_read_join_dev(gf_ctx* ctx, const void* d_id_hash, size_t n_ids, void* d_recs, const void* d_qhash, size_t n_recs, void* d_stats);
+/* gf_bam_fetch on any device buffer: slices [begin[i], end[i]) of d_src back to back into the host buffer dst */
+int gf_fetch_slices(gf_ctx* ctx, const void* d_src, size_t src_len, const uint64_t* begin, const uint64_t* end, size_t n, uint8_t* dst, size_t cap,
+                    size_t* n_bytes);
+/* d_dst[i] = row d_ids[i] of d_src for i < min(*d_n, cap) (rows of row_bytes, a multiple of 4; *d_n a device u64 — e.g. d_pool_off[n_gaps];
+ * an id beyond n_src_rows yields all-ones): the N masks of pooled reads from the read ids gf_build_pools_dev reports */
+int gf_gather_rows_dev(gf_ctx* ctx, const void* d_src, size_t n_src_rows, size_t row_bytes, const void* d_ids, const void* d_n, size_t cap,
+                       void* d_dst);
+
 /* ---- north-star flank-k-mer screen ("flank-k-mer lookup to tag reads") ------------------------------
  * Emits (gap, read) for every read that has >= min_hits k-mer positions whose canonical k-mer occurs in the
  * gap's flank k-mer set (predicate shape of IsReadContainingFreqKmers, KmerUtils.cpp:215-241, on canonical
