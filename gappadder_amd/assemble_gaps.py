@@ -17,6 +17,24 @@ working_folder = ""
 min_count = 2        # KMC's default -ci (the reference passes none, assemble_gaps.py:96)
 min_contig = 40      # velvetg -min_contig_lgth 40 (:117)
 _gf = None
+_first_round = None  # `-c All` on resident libraries: {gap id: {(k, kv): [(seq, n_nodes, cov_sum)]}} of the device pipeline (set_first_round)
+
+
+def set_first_round(res):
+    """The first assembly round already ran on the device, on the pools the Collect stage left in HBM (device_collect.py): the next
+    assemble_ids call writes ITS contigs instead of reading the per-gap FASTQ files back and assembling them again.  Later rounds
+    (pools grown by the both-unmapped recruitment, assemble_gaps.py:349-351) go through the files as before.  res: pipeline.Results
+    with .keys (gap ids) and .k_pairs."""
+    global _first_round
+    per = {}
+    ctg, seq = res.contigs, res.seq
+    order = sorted(range(len(ctg)), key=lambda i: (int(ctg[i]["gap"]), int(ctg[i]["k"]), int(ctg[i]["kv"]), -int(ctg[i]["length"]),
+                                                    seq[int(ctg[i]["seq_off"]):int(ctg[i]["seq_off"]) + int(ctg[i]["length"])]))
+    for i in order:          # the host entry point's order: length descending, then sequence
+        c = ctg[i]
+        per.setdefault(res.keys[int(c["gap"])], {}).setdefault((int(c["k"]), int(c["kv"])), []).append(
+            (seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode(), int(c["n_nodes"]), int(c["cov_sum"])))
+    _first_round = {"contigs": per, "pairs": set(res.k_pairs), "read_len": res.read_len}
 
 
 def _ctx():
@@ -42,16 +60,26 @@ def format_contigs(contigs):
 
 def assemble_ids(ids, gf=None):
     """run_assembly for a batch of gap ids (assemble_gaps.py:82-136)."""
+    global _first_round
     gf = gf or _ctx()
     ids = [i for i in ids if os.path.exists("%sgap_reads/%s.fastq" % (working_folder, i))]   # :272-274
     if not ids:
         return
-    pools = [fastq_io.read_fastq_seqs("%sgap_reads/%s.fastq" % (working_folder, i)) for i in ids]
-    packed, nm, off, L = fastq_io.pack_pools(pools)
     pairs = [(int(k), int(kv)) for k, kv in kmer_len_list]
-    usable = [(k, velvet_kv(kv)) for k, kv in pairs if 16 <= k <= min(64, L) and 15 <= velvet_kv(kv) < k]
     per = {}
-    if usable:
+    first, _first_round = _first_round, None
+    if first is not None:       # contigs of the device pipeline (same pools, same kernel, no trip through the files)
+        L = first["read_len"]
+        usable = [(k, velvet_kv(kv)) for k, kv in pairs if 16 <= k <= min(64, L) and 15 <= velvet_kv(kv) < k]
+        assert set(usable) == first["pairs"], (usable, first["pairs"])
+        for g, gid in enumerate(ids):
+            for pair, lst in first["contigs"].get(gid, {}).items():
+                per[(g,) + pair] = lst
+    else:
+        pools = [fastq_io.read_fastq_seqs("%sgap_reads/%s.fastq" % (working_folder, i)) for i in ids]
+        packed, nm, off, L = fastq_io.pack_pools(pools)
+        usable = [(k, velvet_kv(kv)) for k, kv in pairs if 16 <= k <= min(64, L) and 15 <= velvet_kv(kv) < k]
+    if usable and first is None:
         ctg, seq = gf.assemble(packed, off, L, usable, min_count, min_contig, n_mask=nm)
         for c in ctg:
             per.setdefault((int(c["gap"]), int(c["k"]), int(c["kv"])), []).append(

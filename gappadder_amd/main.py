@@ -60,6 +60,26 @@ def prepare_folders(alignments, wf):
     return folders
 
 
+def collect_per_scaffold(cfg, gf, sf_fai, sf_gap_pos, folders, anchor_mapq, clip_dist, wf):
+    """The reference's Collect stage call for call (main.py:226-270): a `samtools view` pipe per scaffold (or one decode pass over the
+    BAM in builtin mode), list files, then the FASTQ join on the host."""
+    for (bam, is_, sd), folder, (left, right) in zip(cfg["alignments"], folders, cfg["raw_reads"]):
+        MultiThrdReadsCollector(sf_fai, bam, sf_gap_pos, anchor_mapq, gf).dispath_collect_jobs(
+            cfg["nthreads"], cfg["samtools"], is_, sd, clip_dist, folder)
+        drc = DiscordantReadsCollector(sf_fai, bam, folder, cfg["nthreads"], gf, cfg["samtools"])
+        drc.collect_discordant_regions_v2(folder + "discordant_reads_pos.txt")
+        drc.dispath_collect_jobs()
+        extra = None
+        if cfg["kmer_screen"]:
+            from .kmer_recruit import screen_fastq_pair
+            extra = screen_fastq_pair(gf, sf_fai, sf_gap_pos, wf, left, right, cfg["kmer_screen"])
+        drc.merge_dispatch_reads_for_gaps_v2(left, right, extra)
+        drc.dispatch_high_quality_reads_for_gaps(left, right)
+    rm = ReadsMerger()
+    for name in ("gap_reads", "gap_reads_alignment", "gap_reads_high_quality"):
+        rm.merge_reads_v2(sf_fai, sf_gap_pos, folders, name, wf + MERGE_FOLDER, cfg["nthreads"])
+
+
 def main_func(command, sf_config):
     cfg = parse_configuration(sf_config)
     wf = cfg["wf"]
@@ -80,30 +100,38 @@ def main_func(command, sf_config):
         dgp.gnrt_gap_positions(cfg["min_gap"])
         dgp.get_gap_flank_seqs(cfg["draft"], sf_gap_pos, cfg["flank"], sf_fai, wf)
     gf = GapFill(int(os.environ.get("GF_DEVICE", "0"))) if command in ("Collect", "Assembly", "All") else None
+    first_round = None
     if command in ("Collect", "All"):
         folders = prepare_folders(cfg["alignments"], wf)
         if len(cfg["alignments"]) != len(cfg["raw_reads"]):
             raise SystemExit("# of alignment files and # of raw reads do not match!!!!!")
-        for (bam, is_, sd), folder, (left, right) in zip(cfg["alignments"], folders, cfg["raw_reads"]):
-            MultiThrdReadsCollector(sf_fai, bam, sf_gap_pos, anchor_mapq, gf).dispath_collect_jobs(
-                cfg["nthreads"], cfg["samtools"], is_, sd, clip_dist, folder)
-            drc = DiscordantReadsCollector(sf_fai, bam, folder, cfg["nthreads"], gf, cfg["samtools"])
-            drc.collect_discordant_regions_v2(folder + "discordant_reads_pos.txt")
-            drc.dispath_collect_jobs()
-            extra = None
-            if cfg["kmer_screen"]:
-                from .kmer_recruit import screen_fastq_pair
-                extra = screen_fastq_pair(gf, sf_fai, sf_gap_pos, wf, left, right, cfg["kmer_screen"])
-            drc.merge_dispatch_reads_for_gaps_v2(left, right, extra)
-            drc.dispatch_high_quality_reads_for_gaps(left, right)
-        rm = ReadsMerger()
-        for name in ("gap_reads", "gap_reads_alignment", "gap_reads_high_quality"):
-            rm.merge_reads_v2(sf_fai, sf_gap_pos, folders, name, wf + MERGE_FOLDER, cfg["nthreads"])
+        done = False
+        if bam_io.is_builtin(cfg["samtools"]) and os.environ.get("GF_DEVICE_COLLECT", "1") != "0":
+            # libraries resident in HBM, one pass over every file, the pipeline bench.py times (device_collect.py); with `-c All` the
+            # first assembly round runs on the pools where they are
+            from .device_collect import DeviceCollector, DeviceCollectUnsupported
+            try:
+                dc = DeviceCollector(gf, cfg, sf_fai, sf_gap_pos, anchor_mapq, clip_dist, kmers=cfg["kmers"] if command == "All" else None)
+                res = dc.run(folders, wf + MERGE_FOLDER)
+                done = True
+                if command == "All" and res.k_pairs:
+                    first_round = res
+                if os.environ.get("GF_TIMINGS"):
+                    sys.stderr.write("device collect: " + ", ".join("%s %.3f s" % kv for kv in dc.t.items()) + "\n")
+                    if os.environ["GF_TIMINGS"] not in ("1", ""):
+                        with open(os.environ["GF_TIMINGS"], "w") as f:
+                            json.dump({"seconds": dc.t, "libraries": [dict(lb.counts, reads=lb.n_reads, records=lb.n_recs) for lb in dc.libs]}, f)
+            except DeviceCollectUnsupported as e:
+                sys.stderr.write("device-resident Collect not used (%s): per-scaffold path\n" % e)
+        if not done:
+            collect_per_scaffold(cfg, gf, sf_fai, sf_gap_pos, folders, anchor_mapq, clip_dist, wf)
     if command in ("Assembly", "All"):
         for s in SUB_MERGED:
             os.makedirs(wf + MERGE_FOLDER + s, exist_ok=True)
         ga = assemble_gaps.GapAssembler(sf_fai, sf_gap_pos, cfg["nthreads"], wf + MERGE_FOLDER, cfg["kmers"], gf,
                                         bam_list=[bam for bam, _, _ in cfg["alignments"]], samtools_path=cfg["samtools"])
+        if first_round is not None:
+            assemble_gaps.set_first_round(first_round)
         res = ga.assemble_pipeline()
         print("assembled %d gaps, %d closed (picked_seqs.fa), %d with an extended (partial) fill, %d gaps got both-unmapped pairs in the "
               "second round, contigs merged in %d gap rounds (%d bridging high-quality reads); contigs in %svelvet_temp/*/contigs.fa"

@@ -87,6 +87,7 @@ class Pipeline:
             self.stream = torch.cuda.Stream(device=self.dev)
             self._chk(self.lib.gf_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)), "gf_set_stream")
         self.tag_after_filter = False
+        self.assemble_in_step = True      # False: step() stops at the pools; the caller runs assemble() itself (N masks of file-born pools)
         self.fixed_spans, self.fixed_on = [], False
         self.screen_dropped = 0
         self.prepared = False
@@ -344,7 +345,7 @@ class Pipeline:
             self.xchg.run(pack, merge)
             self._fixed_span("owner_exchange", ev0)
             self.asm_ptr, self.asm_off, self.asm_rows = self.d_merged.data_ptr(), self.d_moff.data_ptr(), self.merged_cap
-        if self.kk:
+        if self.kk and self.assemble_in_step:
             self.assemble()
 
     def assemble(self, d_nmask=None):

@@ -261,3 +261,84 @@ def test_builtin_bam_mode_writes_the_same_tree_as_the_samtools_pipes(run, tmp_pa
             assert got[rel] == ref_tree[rel], rel
         else:
             assert sorted(got[rel].splitlines()) == sorted(ref_tree[rel].splitlines()), rel
+
+
+def _run_stages(cfgp, stages, env=None):
+    from gappadder_amd import main as M
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        for stage in stages:
+            M.main(["-c", stage, "-g", cfgp])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _same_tree(got, ref_tree):
+    assert sorted(got) == sorted(ref_tree)
+    for rel in ref_tree:
+        if "/scaffold_reads_list_all/" in rel or "/discordant_reads_list/" in rel or rel.endswith(".fastq") or rel.endswith(".fa"):
+            assert got[rel] == ref_tree[rel], rel
+        else:
+            assert sorted(got[rel].splitlines()) == sorted(ref_tree[rel].splitlines()), rel
+
+
+def test_all_in_one_on_resident_libraries_writes_the_same_tree(run, tmp_path):
+    """`-c All` with software_path.samtools = "builtin": BAM and FASTQ are read once into HBM, gappadder_amd/pipeline.py recruits,
+    pools, assembles and picks on the device (the chain bench.py times), and every file of the reference's working folder is WRITTEN
+    FROM those results — the first assembly round included (no trip of the pools through gap_reads/*.fastq).  The tree must equal the
+    staged run through the `samtools view` pipes."""
+    case, _, ref_tree = run
+    cfgp, wf, _ = PU.materialise(case, str(tmp_path), kmers=((31, 29), (41, 39), (41, 38)), builtin_bam=True)
+    import json
+    tfile = os.path.join(str(tmp_path), "timings.json")
+    _run_stages(cfgp, ["All"], env={"GF_TIMINGS": tfile})
+    _same_tree(PU.tree(wf), ref_tree)
+    t = json.load(open(tfile))
+    assert {"ingest_fastq", "ingest_bam", "join", "recruit_and_pools", "assemble_and_pick", "write_files"} <= set(t["seconds"])
+    assert len(t["libraries"]) == len(case.libs) and all(l["records"] > 0 for l in t["libraries"])
+
+
+def test_resident_libraries_in_many_small_chunks(run, tmp_path):
+    """The same with 3-KiB file chunks: FASTQ pieces cut at record boundaries, BGZF blocks and BAM records that straddle pieces."""
+    case, _, ref_tree = run
+    cfgp, wf, _ = PU.materialise(case, str(tmp_path), kmers=((31, 29), (41, 39), (41, 38)), builtin_bam=True)
+    _run_stages(cfgp, ["Preprocess", "Collect", "Assembly"], env={"GF_INGEST_CHUNK_BYTES": "3000"})
+    _same_tree(PU.tree(wf), ref_tree)
+
+
+def test_resident_path_equals_the_per_scaffold_path_with_the_kmer_screen(tmp_path):
+    """parameters.kmer_screen on resident libraries (the screen runs inside the pipeline's step) against the host join of
+    kmer_recruit.py: same gap_reads, same left/right_reads.list."""
+    case = Case("twolib")
+    trees = []
+    for sub, env in (("a", {}), ("b", {"GF_DEVICE_COLLECT": "0"})):
+        root = os.path.join(str(tmp_path), sub)
+        os.makedirs(root)
+        cfgp, wf, _ = PU.materialise(case, root, kmer_screen=31, builtin_bam=True)
+        _run_stages(cfgp, ["Preprocess", "Collect"], env=env)
+        trees.append(PU.tree(wf))
+    _same_tree(trees[0], trees[1])
+    assert any(k.endswith("gap_reads/0_1.fastq") for k in trees[0])
+
+
+def test_inputs_the_resident_path_does_not_take_fall_back_to_the_per_scaffold_path(run, tmp_path, capfd):
+    """A FASTQ pair whose mates are not in the same order (here: the right file reversed) is joined by name on the host, as the
+    reference does; the device path says so and steps aside."""
+    case, _, _ = run
+    cfgp, wf, _ = PU.materialise(case, str(tmp_path), builtin_bam=True)
+    fq2 = os.path.join(str(tmp_path), "data", "lib0_2.fq")
+    lines = open(fq2).read().splitlines()
+    recs = ["\n".join(lines[i:i + 4]) + "\n" for i in range(0, len(lines), 4)]
+    open(fq2, "w").write("".join(recs[::-1]))
+    _run_stages(cfgp, ["Preprocess", "Collect"])
+    assert "do not carry the same ids in the same order" in capfd.readouterr().err
+    got = PU.tree(wf)
+    for rel, txt in case.expected.items():          # same recruits; the right-file records of a pool now come in the reversed file's order
+        if "/gap_reads/" in rel and rel.startswith("1_"):
+            split = lambda t: sorted("\n".join(t.splitlines()[i:i + 4]) for i in range(0, len(t.splitlines()), 4))
+            assert split(got[rel]) == split(txt), rel
