@@ -359,15 +359,15 @@ int gf_fastq_pack_dev(gf_ctx* ctx, const void* d_text, size_t n_bytes, int read_
     const unsigned long long n_lines = n_nl + (last != '\n' ? 1 : 0);
     unsigned long long n_reads = n_lines / 4;
     uint32_t status = (n_lines & 3) ? 2u : 0u;                      // trailing partial record: ignored, flagged
+    // the quality line of the last record has no newline: complete when `text` is a whole file, possibly cut when it is a piece of one
+    // (the caller of a piece then drops that record and brings its bytes back with the next piece)
+    if (last != '\n' && n_reads && n_nl == 4 * n_reads - 1) status |= 8u;
     if (n_reads > cap_reads) { status |= 4u; }                      // capacity: *d_n_reads reports the number found
     const unsigned long long n_do = n_reads < cap_reads ? n_reads : cap_reads;
     GF_HIP(ctx, hipMemcpyAsync(d_n_reads, &n_reads, 8, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(nl_mark_kernel, dim3((unsigned)n_tiles), dim3(ING_THREADS), 0, ctx->stream, (const uint8_t*)d_text, (uint64_t)n_bytes,
                        off, (uint64_t)slots, hdr, sb, se);
     if (n_do) {
-        if (last != '\n' && n_nl == 4 * n_reads - 1 && n_reads <= cap_reads) {
-            // the final quality line has no newline: nothing to fix (the sequence line of the last record is terminated)
-        }
         hipLaunchKernelGGL(fastq_pack_kernel, dim3((unsigned)((n_do + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)d_text,
                            (uint64_t)n_bytes, (uint64_t)n_do, sb, se, (uint32_t)read_len, (uint8_t*)d_packed,
                            (uint32_t*)d_n_mask_or_null, (uint32_t*)d_status);

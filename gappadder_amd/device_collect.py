@@ -46,34 +46,6 @@ class _Restart(Exception):
         self.read_len = read_len
 
 
-def _fastq_chunks(path, chunk_bytes):
-    """(file offset, bytes) pieces of a FASTQ file, each starting at a record boundary and holding whole 4-line records (the
-    last one: whatever is left, the pack kernel flags a trailing partial record)."""
-    off, carry = 0, b""
-    with open(path, "rb") as f:
-        while True:
-            piece = f.read(chunk_bytes)
-            data = carry + piece if carry else piece
-            if not piece:
-                if data:
-                    yield off, data
-                return
-            nl = data.count(b"\n")
-            drop = nl % 4
-            pos = len(data)
-            for _ in range(drop + 1):          # newline number nl - drop (1-based) ends the last whole record
-                pos = data.rfind(b"\n", 0, pos)
-                if pos < 0:
-                    break
-            if nl < 4 or pos < 0:
-                carry = data                   # not even one record yet
-                continue
-            cut = pos + 1
-            yield off, data[:cut]
-            off += cut
-            carry = data[cut:]
-
-
 def _guess_read_len(paths, n_records=4096):
     L = 0
     for p in paths:
@@ -115,43 +87,79 @@ class DeviceCollector:
 
     # ---- FASTQ pair -> packed reads [n_pairs][2][rb] (+ masks), id hashes, record offsets -----------------------------------
     def _ingest_fastq(self, path, L):
+        """One mate file -> (records, packed reads, N masks, id hashes, header offsets (+ the file size)), all on the device.  The file
+        is read in pieces straight into a pinned buffer and copied to HBM as it is; the pack kernel itself finds where the last whole
+        4-line record of a piece ends (hdr_begin[n]), the few bytes behind it are carried in front of the next piece — no host pass
+        over the text."""
         lib, h, dev, gf = self.lib, self.h, self.dev, self.gf
         rb, nmw = lib.gf_packed_read_bytes(L), (L + 31) // 32
         packed, masks, hashes, hdrs = [], [], [], []
         d_cnt = torch.zeros(4, dtype=torch.int64, device=dev)        # [0] n_reads (u64), [1] status (u32), [2] max_len (u32)
         size = os.path.getsize(path)
-        n_total = 0
-        for off, data in _fastq_chunks(path, self.chunk_bytes):
-            d_text = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
-            cap = data.count(b"\n") // 4 + 2
-            d_p = torch.empty(cap * rb, dtype=torch.uint8, device=dev)
-            d_m = torch.empty(cap * nmw, dtype=torch.int32, device=dev)
-            d_h = torch.empty(cap + 1, dtype=torch.int64, device=dev)
-            d_cnt.zero_()
-            torch.cuda.synchronize()
-            self._chk(lib.gf_fastq_pack_dev(h, d_text.data_ptr(), len(data), L, d_p.data_ptr(), cap, d_m.data_ptr(), d_h.data_ptr(),
-                                            d_cnt.data_ptr(), d_cnt.data_ptr() + 8), "gf_fastq_pack_dev")
-            gf.sync()
-            n = int(d_cnt[0])
-            st = int(d_cnt[1]) & 0xFFFFFFFF
-            if st & 4 or n > cap:
-                raise RuntimeError("FASTQ ingest: record capacity %d < %d" % (cap, n))
-            d_id = torch.empty(max(1, n), dtype=torch.int64, device=dev)
-            self._chk(lib.gf_fastq_index_dev(h, d_text.data_ptr(), len(data), d_h.data_ptr(), n, d_id.data_ptr(), d_cnt.data_ptr() + 16),
-                      "gf_fastq_index_dev")
-            gf.sync()
-            mx = int(d_cnt[2]) & 0xFFFFFFFF
-            if mx > L:
-                raise _Restart(mx)
-            packed.append(d_p[:n * rb])
-            masks.append(d_m[:n * nmw])
-            hashes.append(d_id[:n])
-            hdrs.append(d_h[:n] + off)
-            n_total += n
-            del d_text
+        chunk = max(4096, min(self.chunk_bytes, size))
+        slack = 1 << 16                                             # room for the carried tail: a record longer than this is no short read
+        pin = self._pinned(chunk + slack)
+        view = memoryview(pin.numpy())
+        d_text = torch.empty(chunk + slack + 64, dtype=torch.uint8, device=dev)
+        n_total, off, carry = 0, 0, 0
+        with open(path, "rb", buffering=0) as f:
+            while True:
+                got = f.readinto(view[carry:carry + chunk])
+                total = carry + (got or 0)
+                if total == 0:
+                    break
+                last = not got or off + total >= size
+                d_text[:total].copy_(pin[:total], non_blocking=True)
+                cap = total // max(8, L) + 16
+                while True:
+                    d_p = torch.empty(cap * rb, dtype=torch.uint8, device=dev)
+                    d_m = torch.empty(cap * nmw, dtype=torch.int32, device=dev)
+                    d_h = torch.empty(cap + 1, dtype=torch.int64, device=dev)
+                    d_cnt.zero_()
+                    torch.cuda.synchronize()
+                    self._chk(lib.gf_fastq_pack_dev(h, d_text.data_ptr(), total, L, d_p.data_ptr(), cap, d_m.data_ptr(), d_h.data_ptr(),
+                                                    d_cnt.data_ptr(), d_cnt.data_ptr() + 8), "gf_fastq_pack_dev")
+                    gf.sync()
+                    n, st = int(d_cnt[0]), int(d_cnt[1])
+                    if n <= cap and not (st & 4):
+                        break
+                    cap = n + 16                                    # reads shorter than promised: more records than estimated
+                if not last and (st & 8):
+                    n -= 1                                          # the piece ends inside the quality line of its last record
+                if not last:
+                    if n == 0:
+                        raise DeviceCollectUnsupported("a FASTQ record of %s is longer than %d bytes" % (path, chunk))
+                    end = int(d_h[n])                               # where the last whole record of the piece ends
+                else:
+                    end = total
+                d_id = torch.empty(max(1, n), dtype=torch.int64, device=dev)
+                self._chk(lib.gf_fastq_index_dev(h, d_text.data_ptr(), end, d_h.data_ptr(), n, d_id.data_ptr(), d_cnt.data_ptr() + 16),
+                          "gf_fastq_index_dev")
+                gf.sync()
+                mx = int(d_cnt[2]) & 0xFFFFFFFF
+                if mx > L:
+                    raise _Restart(mx)
+                packed.append(d_p[:n * rb])
+                masks.append(d_m[:n * nmw])
+                hashes.append(d_id[:n])
+                hdrs.append(d_h[:n] + off)
+                n_total += n
+                carry = total - end
+                if carry > slack:
+                    raise DeviceCollectUnsupported("a FASTQ record of %s is longer than %d bytes" % (path, slack))
+                if carry:
+                    view[:carry] = bytes(view[end:total])
+                off += end
+                if last:
+                    break
         hdr = torch.cat(hdrs + [torch.tensor([size], dtype=torch.int64, device=dev)]) if hdrs else torch.tensor([size], dtype=torch.int64, device=dev)
         cat = lambda xs, dt: torch.cat(xs) if xs else torch.empty(0, dtype=dt, device=dev)
         return n_total, cat(packed, torch.uint8), cat(masks, torch.int32), cat(hashes, torch.int64), hdr
+
+    def _pinned(self, n):
+        if getattr(self, "_pin", None) is None or self._pin.numel() < n:
+            self._pin = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        return self._pin
 
     def _ingest_pair(self, left, right, L):
         dev, rb, nmw = self.dev, self.lib.gf_packed_read_bytes(L), (L + 31) // 32

@@ -6,6 +6,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 
 from . import assemble_gaps
 from . import bam_io
@@ -95,13 +96,17 @@ def main_func(command, sf_config):
         for fn in os.listdir(wf):
             p = os.path.join(wf, fn)
             shutil.rmtree(p) if os.path.isdir(p) else os.remove(p)
+    timings = {"stages_s": {}}      # GF_TIMINGS=<file>: wall time per stage (+ the device Collect's own split) as JSON
     if command in ("Preprocess", "All"):
+        t0 = time.perf_counter()
         dgp = DGProcessor(cfg["draft"], sf_gap_pos)
         dgp.gnrt_gap_positions(cfg["min_gap"])
         dgp.get_gap_flank_seqs(cfg["draft"], sf_gap_pos, cfg["flank"], sf_fai, wf)
+        timings["stages_s"]["preprocess"] = time.perf_counter() - t0
     gf = GapFill(int(os.environ.get("GF_DEVICE", "0"))) if command in ("Collect", "Assembly", "All") else None
     first_round = None
     if command in ("Collect", "All"):
+        t0 = time.perf_counter()
         folders = prepare_folders(cfg["alignments"], wf)
         if len(cfg["alignments"]) != len(cfg["raw_reads"]):
             raise SystemExit("# of alignment files and # of raw reads do not match!!!!!")
@@ -116,16 +121,17 @@ def main_func(command, sf_config):
                 done = True
                 if command == "All" and res.k_pairs:
                     first_round = res
-                if os.environ.get("GF_TIMINGS"):
-                    sys.stderr.write("device collect: " + ", ".join("%s %.3f s" % kv for kv in dc.t.items()) + "\n")
-                    if os.environ["GF_TIMINGS"] not in ("1", ""):
-                        with open(os.environ["GF_TIMINGS"], "w") as f:
-                            json.dump({"seconds": dc.t, "libraries": [dict(lb.counts, reads=lb.n_reads, records=lb.n_recs) for lb in dc.libs]}, f)
+                timings["seconds"] = dc.t
+                timings["libraries"] = [dict(lb.counts, reads=lb.n_reads, records=lb.n_recs) for lb in dc.libs]
+                timings["gaps"] = len(res.keys)
+                timings["gaps_closed_on_device"] = int(res.n_closed)
             except DeviceCollectUnsupported as e:
                 sys.stderr.write("device-resident Collect not used (%s): per-scaffold path\n" % e)
         if not done:
             collect_per_scaffold(cfg, gf, sf_fai, sf_gap_pos, folders, anchor_mapq, clip_dist, wf)
+        timings["stages_s"]["collect" + ("_and_first_assembly_round" if first_round is not None else "")] = time.perf_counter() - t0
     if command in ("Assembly", "All"):
+        t0 = time.perf_counter()
         for s in SUB_MERGED:
             os.makedirs(wf + MERGE_FOLDER + s, exist_ok=True)
         ga = assemble_gaps.GapAssembler(sf_fai, sf_gap_pos, cfg["nthreads"], wf + MERGE_FOLDER, cfg["kmers"], gf,
@@ -137,6 +143,14 @@ def main_func(command, sf_config):
               "second round, contigs merged in %d gap rounds (%d bridging high-quality reads); contigs in %svelvet_temp/*/contigs.fa"
               % (res["gaps"], res["closed"], res.get("extended", 0), res["second_round_gaps"], res["gaps_with_merged_contigs"],
                  res["bridging_reads"], wf + MERGE_FOLDER))
+        timings["stages_s"]["assembly_rounds"] = time.perf_counter() - t0
+        timings["assembly"] = res
+    if os.environ.get("GF_TIMINGS"):
+        sys.stderr.write("stages: " + ", ".join("%s %.3f s" % kv for kv in timings["stages_s"].items()) +
+                         ("; device collect: " + ", ".join("%s %.3f s" % kv for kv in timings["seconds"].items()) if "seconds" in timings else "") + "\n")
+        if os.environ["GF_TIMINGS"] not in ("1", ""):
+            with open(os.environ["GF_TIMINGS"], "w") as f:
+                json.dump(timings, f)
 
 
 def main(argv=None):

@@ -143,7 +143,8 @@ size_t gf_packed_read_bytes(int read_len);
  * record r, padded with masked A (N) up to read_len.  hdr_begin[r] = byte offset of record r's '@' line (ids are cut from the
  * host's copy of the text: first whitespace token, up to '/', :212-214); needs cap_reads + 1 entries.
  * *n_reads = records found (may exceed cap_reads: GF_E_NOSPACE from the host variant, status bit 4 from the device variant).
- * status bits: 1 = a sequence line longer than read_len was truncated, 2 = trailing partial record ignored, 4 = capacity. */
+ * status bits: 1 = a sequence line longer than read_len was truncated, 2 = trailing partial record ignored, 4 = capacity,
+ * 8 = the quality line of the last record ends without a newline (a whole file: fine; a piece of one: that record may be cut). */
 int gf_fastq_pack(gf_ctx* ctx, const char* text, size_t n_bytes, int read_len, uint8_t* packed, size_t cap_reads,
                   uint32_t* n_mask_or_null, uint64_t* hdr_begin_or_null, size_t* n_reads, uint32_t* status);
 /* device variant: d_n_reads = u64, d_status = u32 (both written by the call; it synchronises the stream once to size the

@@ -1,0 +1,65 @@
+"""The CLI on FILES of the synthetic workload (tools/synth_files) against the device-resident run of the same workload: the path
+bench.py times and the path a user invokes must recruit the same reads and close the same gaps."""
+import os
+
+import numpy as np
+import pytest
+
+import synth_files_util as SF
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_on_files_equals_the_device_resident_run(tmp_path):
+    import torch
+    from gappadder_amd import main as M
+    from gappadder_amd.hip_api import GapFill
+    from gappadder_amd.pipeline import DeviceLibrary, Pipeline
+    seed, slen, nscf, gps, glen, L = 20260007, 400_000, 3, 4, 120, 150
+    libs = [(300, 30, 60_000), (2000, 200, 20_000)]
+    kk = [(31, 29), (41, 39)]
+    cfgp, wf = SF.write_case(str(tmp_path), seed, slen, nscf, gps, glen, libs, kk, kmer_screen=31)
+    M.main(["-c", "All", "-g", cfgp])
+    # the same workload synthesised straight into HBM, through the same Pipeline
+    gf = GapFill(0)
+    cfg0 = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L)
+    gaps, flanks = GapFill.synth_layout(cfg0)
+    gf.set_gaps(gaps, nscf, flanks)
+    pipe = Pipeline(gf, len(gaps), L, kk, keep_read_ids=True)
+    rb = 38
+    for no, (is_, sd, n_pairs) in enumerate(libs):
+        cfg = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L, insert_mean=is_,
+                                insert_sd=sd, library=no)
+        d_reads = torch.empty(2 * n_pairs * rb + 64, dtype=torch.uint8, device="cuda")
+        d_recs = torch.empty(2 * n_pairs * 32, dtype=torch.uint8, device="cuda")
+        gf.synth_pairs_dev(cfg, 0, n_pairs, d_reads.data_ptr(), d_recs.data_ptr())
+        pipe.add_library(DeviceLibrary("lib%d" % no, is_, sd, 2 * n_pairs, d_reads, d_recs))
+    gf.sync()
+    pipe.prepare()
+    pipe.step()
+    res = pipe.fetch()
+    keys = ["%d_%d" % (int(g["scaffold"]), int(g["idx_in_scaffold"])) for g in gaps]
+    n_pooled = 0
+    for no, lb in enumerate(pipe.libs):
+        off = lb.d_pool_off.cpu().numpy()
+        ids = lb.d_ids[:int(off[-1])].cpu().numpy()
+        folder = "%s%d_is%d/gap_reads/" % (wf, no + 1, libs[no][0])
+        for g, key in enumerate(keys):
+            want = ["@r%d_%d" % (i >> 1, (i & 1) + 1) for i in ids[int(off[g]):int(off[g + 1])]]
+            got = open(folder + key + ".fastq").read().splitlines()[0::4] if os.path.exists(folder + key + ".fastq") else []
+            assert got == want, (no, key)
+            n_pooled += len(want)
+    assert n_pooled > 1500
+    # closed gaps: the first pick of the CLI (merge in between may close more) holds at least the device's closed set, with its sequences
+    picked = {}
+    for blk in open(wf + "picked_seqs.fa").read().split(">")[1:]:
+        h, s = blk.split("\n", 1)
+        picked["_".join(h.split("_")[:2])] = s.replace("\n", "")
+    closed = [keys[g] for g in np.nonzero(res.best)[0]]
+    assert len(closed) >= 6 and set(closed) <= set(picked)
+    truth_ok = 0
+    for g in np.nonzero(res.best)[0]:
+        st, en, sc = int(gaps[g]["start"]), int(gaps[g]["end"]), int(gaps[g]["scaffold"])
+        t = (GapFill.synth_truth(cfg0, sc, st - 5, en - st + 11), GapFill.synth_truth(cfg0, sc, st - 6, en - st + 11))
+        truth_ok += picked[keys[g]] in t
+    assert truth_ok >= len(closed) - 1

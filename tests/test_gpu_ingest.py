@@ -64,9 +64,9 @@ def test_fastq_pack_edge_cases(gf):
     L = 50
     text = _fastq(rng, 40, L)
     # last line without its newline
-    packed, nm, hdr, st = gf.fastq_pack(text[:-1], L)
+    packed, nm, hdr, st = gf.fastq_pack(text[:-1], L)          # (status bit 8 says so: a whole file is complete, a piece of one may be cut there)
     ep, em, eh, en = _expect(text, L)
-    assert st == 0 and np.array_equal(packed, ep) and np.array_equal(nm, em) and np.array_equal(hdr, eh)
+    assert st == 8 and np.array_equal(packed, ep) and np.array_equal(nm, em) and np.array_equal(hdr, eh)
     # CRLF line ends
     crlf = text.replace(b"\n", b"\r\n")
     packed, nm, hdr, st = gf.fastq_pack(crlf, L)
