@@ -199,7 +199,9 @@ def run(args):
     # vs 68.3 ms in a row) — the kernels take turns on the memory system; in a row every kernel's HIP-event span is its own duration.
     # GF_BENCH_TWO_STREAMS=1: tagger + second hop on a second context / stream beside the filter
     # (one per library: the tagger caches its coarse bin map per insert-size window)
-    serial = os.environ.get("GF_BENCH_TWO_STREAMS", "0") != "1"
+    # GF_BENCH_TAG_AHEAD=1: the tagger of the NEXT step runs on a second stream beside this step's assembly (Pipeline.tag_ahead)
+    tag_ahead = os.environ.get("GF_BENCH_TAG_AHEAD", "0") == "1"
+    serial = os.environ.get("GF_BENCH_TWO_STREAMS", "0") != "1" and not tag_ahead
     gf2s = [gf if serial else GapFill(local) for _ in lib_defs]
 
     rep_p, rep_c = REPEATS.get(args.config, (0, 50))
@@ -215,12 +217,13 @@ def run(args):
             g2.set_gaps(gaps, int(cfg0["n_scaffolds"][0]), None)
             # (GF_BENCH_TAG_LIGHT=1: the one-wave tagger variant that fits on the CUs whose LDS the filter owns — measured: no gain, the two
             # kernels contend for the memory system, C4 78.6 vs 77.4 ms)
-            g2.set_option("tag_light", int(os.environ.get("GF_BENCH_TAG_LIGHT", "0")))
+            g2.set_option("tag_light", int(os.environ.get("GF_BENCH_TAG_LIGHT", "1" if tag_ahead else "0")))
 
     # The whole step lives in the package (gappadder_amd/pipeline.py: residency, sizing pass, capacities, recruit -> hop -> keys -> pools ->
     # merge / owner exchange -> assembly -> pick): this file generates the inputs, calls it and times it
     pipe = Pipeline(gf, n_gaps, L, kk, device=dev, world=world, rank=rank, backend=backend, force_exchange=multi and world == 1)
     pipe.tag_after_filter = not serial and os.environ.get("GF_BENCH_TAG_AFTER_FILTER", "0") == "1"
+    pipe.tag_ahead = tag_ahead
     h = gf.handle
 
     # ---- inputs resident in HBM (torch = device-memory plumbing) ----
@@ -335,6 +338,21 @@ def run(args):
     census = None
     if not multi and n_closed_local:      # (runs that close gaps at all: with the 300-bp library alone every 2-kb gap is a coverage hole)
         census = open_gap_census(cfg0, gaps, ctg, seq_host, res.best, GapFill)
+    merge_round = None
+    if not multi and n_closed_local and os.environ.get("GF_BENCH_MERGE", "1") != "0":
+        # The reference merges a gap's contigs before it picks (assemble_gaps.py:301-306, 335-339); the timed step picks first, and the
+        # gaps it leaves open go through the contig merger + a second pick here, AFTER the timed region (host path search: its time is
+        # reported, not charged to the step)
+        tm0 = time.perf_counter()
+        mg = pipe.merge_open_gaps(res)
+        tm = time.perf_counter() - tm0
+        merge_round = {"gaps_tried": mg["gaps_tried"], "gaps_with_new_contigs": mg["gaps_with_new_contigs"], "new_contigs": mg["new_contigs"],
+                       "gaps_closed_by_merging": len(mg["closed"]), "seconds_untimed": tm}
+        if mg["closed"]:
+            c2, s2, b2 = mg["arrays"]
+            t2 = truth_check(cfg0, gaps, flanks, c2, s2, b2, GapFill)
+            merge_round.update(closed_correct=t2["correct"], gaps_closed_total=n_closed_local + len(mg["closed"]),
+                               gaps_closed_correct_total=n_correct + t2["correct"])
     if multi:
         red = torch.tensor([n_closed_local, n_ctg, gaps_with_contig, asm_rows_total, n_correct], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
@@ -431,6 +449,8 @@ def run(args):
                                    + ("; k-mer figures are rank 0's gaps x world" if world > 1 else "")}
         if census is not None:
             out["open_gap_census"] = census
+        if merge_round is not None:
+            out["contig_merge_round"] = merge_round
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
         if multi:
@@ -583,6 +603,7 @@ def child_run(argv):
         return {key: d[key] for key in ("value", "ms_per_step", "steps", "warmup", "gaps_per_s", "gaps_closed_per_s", "gaps_closed_correct_per_s",
                                         "phases_ms", "counts", "closed_truth_check", "assembly")} | \
                ({"open_gap_census": d["open_gap_census"]} if "open_gap_census" in d else {}) | \
+               ({"contig_merge_round": d["contig_merge_round"]} if "contig_merge_round" in d else {}) | \
                {"workload": d["config"]["workload"], "roofline_frac": d["roofline"]["frac"], "filter_ms": d["roofline"]["avg_launch_ms"]}
     except Exception as e:      # the headline line must not depend on an extra
         return {"error": repr(e)[:300], "stderr_tail": (r.stderr.decode()[-400:] if r is not None else "")}

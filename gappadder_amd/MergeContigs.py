@@ -249,31 +249,15 @@ def _swap_in(folder, new_name):
     os.replace(folder + new_name, folder + "contigs.fa")
 
 
-def merge_contigs(gf, working_folder, id_list, kmer_len_quick=10, params=None):
-    """merge_contigs (MergeContigs.py:66-99) for every gap of id_list.  Returns {gap id: number of NEW_CONTIG_MERGE records}."""
-    ids, recs = _sets(working_folder, id_list)
-    work = []                                                  # (gid, folder, de-duplicated records, node records)
-    done = {}
-    for gid, r in zip(ids, recs):
-        folder = "%svelvet_temp/%s/" % (working_folder, gid)
-        nodup = drop_contained(r) if len(r) <= MAX_SET else r
-        _write_fasta(folder + "contigs.fa_no_dup.fa", nodup)
-        if os.path.getsize(folder + "contigs.fa_no_dup.fa") > 1000000 or len(nodup) > MAX_SET:      # MergeContigs.py:70-74
-            try:
-                _swap_in(folder, "contigs.fa_no_dup.fa")
-            except OSError as e:
-                import sys
-                sys.stderr.write("contig merging: gap %s keeps its contigs (%r)\n" % (gid, e))
-            done[gid] = 0
-            continue
-        work.append((gid, folder, nodup, [(n, s.upper()) for n, s in nodup if MIN_NODE <= len(s) <= MAX_NODE]))
-    sets = [[s for _, s in nodes] for _, _, _, nodes in work]
+def merge_sets(gf, rec_sets, kmer_len_quick=10, params=None):
+    """The merger on contig sets in memory: rec_sets = [[(name, seq)]] (one set per gap, already de-duplicated) -> per set
+    {"nodes": the records that took part, "edges": [(i, j, mode, overlap)], "new": [(NEW_CONTIG_MERGE_n, seq, path)]}.
+    Two batched GPU calls for the graph edges of all sets + one per path step for the merged strings."""
+    nodes_of = [[(n, s.upper()) for n, s in r if MIN_NODE <= len(s) <= MAX_NODE] for r in rec_sets]
+    sets = [[s for _, s in nodes] for nodes in nodes_of]
     adjs, edges = graph_edges(gf, sets, kmer_len_quick, params)
     jobs, owner = [], []
-    for wi, ((gid, folder, nodup, nodes), adj, ed) in enumerate(zip(work, adjs, edges)):
-        with open(folder + "merge_edges.txt", "w") as f:
-            for i, j, mode, ov in ed:
-                f.write("%s %s %s %s %s %d\n" % (nodes[i // 2][0], "-" if i & 1 else "+", nodes[j // 2][0], "-" if j & 1 else "+", mode, ov))
+    for wi, (nodes, adj, ed) in enumerate(zip(nodes_of, adjs, edges)):
         node_seqs = []
         for _, s in nodes:
             node_seqs += [s, revcomp(s)]
@@ -287,9 +271,35 @@ def merge_contigs(gf, working_folder, id_list, kmer_len_quick=10, params=None):
     per = {}
     for wi, (nodes_p, seq) in zip(owner, zip(jobs, merged)):
         per.setdefault(wi, []).append((nodes_p[1], seq))
-    for wi, (gid, folder, nodup, nodes) in enumerate(work):
+    return [{"nodes": nodes, "edges": ed,
+             "new": [("NEW_CONTIG_MERGE_%d" % (q + 1), seq, path) for q, (path, seq) in enumerate(per.get(wi, []))]}
+            for wi, (nodes, ed) in enumerate(zip(nodes_of, edges))]
+
+
+def merge_contigs(gf, working_folder, id_list, kmer_len_quick=10, params=None):
+    """merge_contigs (MergeContigs.py:66-99) for every gap of id_list.  Returns {gap id: number of NEW_CONTIG_MERGE records}."""
+    ids, recs = _sets(working_folder, id_list)
+    work = []                                                  # (gid, folder, de-duplicated records)
+    done = {}
+    for gid, r in zip(ids, recs):
+        folder = "%svelvet_temp/%s/" % (working_folder, gid)
+        nodup = drop_contained(r) if len(r) <= MAX_SET else r
+        _write_fasta(folder + "contigs.fa_no_dup.fa", nodup)
+        if os.path.getsize(folder + "contigs.fa_no_dup.fa") > 1000000 or len(nodup) > MAX_SET:      # MergeContigs.py:70-74
+            try:
+                _swap_in(folder, "contigs.fa_no_dup.fa")
+            except OSError as e:
+                import sys
+                sys.stderr.write("contig merging: gap %s keeps its contigs (%r)\n" % (gid, e))
+            done[gid] = 0
+            continue
+        work.append((gid, folder, nodup))
+    for (gid, folder, nodup), m in zip(work, merge_sets(gf, [w[2] for w in work], kmer_len_quick, params)):
+        nodes, new = m["nodes"], m["new"]
+        with open(folder + "merge_edges.txt", "w") as f:
+            for i, j, mode, ov in m["edges"]:
+                f.write("%s %s %s %s %s %d\n" % (nodes[i // 2][0], "-" if i & 1 else "+", nodes[j // 2][0], "-" if j & 1 else "+", mode, ov))
         names = [n for n, _ in nodes]
-        new = [("NEW_CONTIG_MERGE_%d" % (q + 1), seq, path) for q, (path, seq) in enumerate(per.get(wi, []))]
         with open(folder + "contigs.fa_no_dup.fa.merge.info", "w") as f:
             for name, _, path in new:
                 f.write("%s   %s\n" % (name, " ".join(_node_name(names, v) for v in path)))

@@ -11,6 +11,7 @@ NO_REF = 0xFFFFFFFF
 CIGAR_OPS = "MIDNSHP=X"
 SEQ_CODES = "=ACMGRSVTWYHKDBN"
 BUILTIN = "builtin"
+_NIBBLE_PAIRS = np.array([(ord(SEQ_CODES[b >> 4]) | (ord(SEQ_CODES[b & 15]) << 8)) for b in range(256)], dtype="<u2")   # SEQ byte -> its two characters
 
 
 def is_builtin(samtools_path):
@@ -101,11 +102,9 @@ class BamCols:
         if l_seq == 0:
             return "*", "*"
         nib = np.frombuffer(r[p:p + (l_seq + 1) // 2], dtype=np.uint8)
-        codes = np.empty(2 * len(nib), dtype=np.uint8)
-        codes[0::2], codes[1::2] = nib >> 4, nib & 15
-        seq = "".join(SEQ_CODES[c] for c in codes[:l_seq])
+        seq = _NIBBLE_PAIRS[nib].tobytes()[:l_seq].decode()          # two bases per byte through a 256-entry table
         q = np.frombuffer(r[p + (l_seq + 1) // 2:p + (l_seq + 1) // 2 + l_seq], dtype=np.uint8)
-        qual = "*" if len(q) and q[0] == 0xFF else bytes(q + 33).decode()
+        qual = "*" if len(q) and q[0] == 0xFF else (q + 33).tobytes().decode()
         return seq, qual
 
 

@@ -87,6 +87,10 @@ class Pipeline:
             self.stream = torch.cuda.Stream(device=self.dev)
             self._chk(self.lib.gf_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)), "gf_set_stream")
         self.tag_after_filter = False
+        # True: the alignment tagger of the NEXT step's records is launched on the libraries' second stream right after this step's pools
+        # are built, i.e. beside the assembly (latency-bound, little HBM traffic) instead of in a row with the memory-bound filter: a
+        # software pipeline over successive steps (every step still runs one tagger pass; prepare() launches the first)
+        self.tag_ahead = False
         self.assemble_in_step = True      # False: step() stops at the pools; the caller runs assemble() itself (N masks of file-born pools)
         self.fixed_spans, self.fixed_on = [], False
         self.screen_dropped = 0
@@ -130,9 +134,9 @@ class Pipeline:
         return lb
 
     # ---- the phases of a step ---------------------------------------------------------------------------------------------
-    def recruit(self, lb):
+    def recruit(self, lb, tagger=True):
         lib, h = self.lib, self.h
-        if lb.second_stream:
+        if lb.second_stream and tagger:
             self._chk(lib.gf_stream_wait(lb.h2, h), "gf_stream_wait")          # the previous consumers of the tagger buffers are done
             if self.tag_after_filter:
                 # the tagger (a pure 32-B-record stream) starts when the k-mer FILTER has finished and runs beside the latency-bound
@@ -141,9 +145,13 @@ class Pipeline:
         if lb.screen:
             self._chk(lib.gf_screen_reads_dev(h, lb.d_reads.data_ptr(), lb.d_nmask.data_ptr() if lb.d_nmask is not None else None, lb.n_reads,
                                               self.L, self.k_screen, 1, lb.d_hits.data_ptr(), lb.hit_cap, lb.cp), "gf_screen_reads_dev")
-        self._chk(lib.gf_tag_alignments_low_dev(lb.h2, lb.d_recs.data_ptr(), lb.n_recs, lb.is_mean, lb.is_sd, self.clip_dist, self.anchor_mapq,
-                                                lb.d_thits.data_ptr(), lb.hit_cap, lb.cp + 4 * CNT_TAG, lb.d_low.data_ptr(), lb.hit_cap,
-                                                lb.cp + 4 * CNT_LOW), "gf_tag_alignments_low_dev")
+        if tagger:
+            self.tagger(lb)
+
+    def tagger(self, lb):
+        self._chk(self.lib.gf_tag_alignments_low_dev(lb.h2, lb.d_recs.data_ptr(), lb.n_recs, lb.is_mean, lb.is_sd, self.clip_dist, self.anchor_mapq,
+                                                     lb.d_thits.data_ptr(), lb.hit_cap, lb.cp + 4 * CNT_TAG, lb.d_low.data_ptr(), lb.hit_cap,
+                                                     lb.cp + 4 * CNT_LOW), "gf_tag_alignments_low_dev")
 
     def _fixed_mark(self):
         if not self.fixed_on:
@@ -303,6 +311,10 @@ class Pipeline:
         self.k_arr = (C.c_int * nk)(*[a for a, _ in self.kk])
         self.kv_arr = (C.c_int * nk)(*[b for _, b in self.kk])
         torch.cuda.synchronize()
+        if self.tag_ahead:          # the first step's tagger pass (untimed, like a warm-up step's)
+            assert all(lb.second_stream for lb in self.libs), "tag_ahead needs DeviceLibrary(tag_ctx=...)"
+            self._on_stream(lambda: [self.tagger(lb) for lb in self.libs])
+            self.sync()
         self.prepared = True
 
     def _check_cap(self, n, cap, what, lb):
@@ -313,10 +325,14 @@ class Pipeline:
     def _step(self):
         lib, h, n_gaps, n_lib, L = self.lib, self.h, self.n_gaps, len(self.libs), self.L
         for lb in self.libs:
-            self.recruit(lb)
+            self.recruit(lb, tagger=not self.tag_ahead)
         for l, lb in enumerate(self.libs):
             self.hop_and_keys(lb)
             self.build_pools(lb, self.pool_ptr[l], self.lib_cap)
+        if self.tag_ahead:
+            for lb in self.libs:        # the next step's tagger pass: behind every consumer of this step's hits, beside the assembly
+                self._chk(lib.gf_stream_wait(lb.h2, h), "gf_stream_wait")
+                self.tagger(lb)
         # (zeroed through the library = on its stream; a torch op here would run on torch's stream)
         self._chk(lib.gf_memset_dev(h, self.d_xerr.data_ptr(), 0, 16) or lib.gf_memset_dev(h, self.d_best.data_ptr(), 0, 8 * max(1, n_gaps))
                   or lib.gf_memset_dev(h, self.ap + 16, 0, 16), "gf_memset_dev")
@@ -408,6 +424,56 @@ class Pipeline:
             r.pool_off = r.asm_off_t.cpu().numpy().astype(np.int64)
             r.pool_rows = r.asm_pool_t[:r.asm_rows_total * self.rb].cpu().numpy().reshape(-1, self.rb)
         return r
+
+    def merge_open_gaps(self, res):
+        """The reference merges a gap's contigs BEFORE it picks (assemble_gaps.py:301-306, 335-339: run_contigs_merge, then
+        pick_full_constructed_contigs); the step picks first, so only the gaps that pick left open can gain from merging: their
+        contigs go through the contig merger (MergeContigs.merge_sets: exact-containment dedup, all-pairs prefilter + overlap
+        evaluation on the GPU, path search on the host) and the NEW_CONTIG_MERGE sequences through a second pick on the device.
+        res: fetch()'s Results.  Returns {"gaps_tried", "gaps_with_new_contigs", "new_contigs", "closed": {gap: (anchor, span + 1,
+        index into "contigs", reverse)}, "contigs": [(gap, seq)]}."""
+        from .MergeContigs import MAX_SET, drop_contained, merge_sets
+        ctg, seq = res.contigs, res.seq
+        open_gaps = np.nonzero(res.best == 0)[0]
+        order = np.argsort(ctg["gap"], kind="stable")
+        gs = ctg["gap"][order]
+        lo, hi = np.searchsorted(gs, open_gaps), np.searchsorted(gs, open_gaps, side="right")
+        sets, gaps_of = [], []
+        for g, a, z in zip(open_gaps, lo, hi):
+            if z - a >= 2:
+                recs = [("c%d" % i, seq[int(ctg[i]["seq_off"]):int(ctg[i]["seq_off"]) + int(ctg[i]["length"])].decode()) for i in order[a:z]]
+                recs = drop_contained(recs) if len(recs) <= MAX_SET else recs
+                if 2 <= len(recs) <= MAX_SET:
+                    sets.append(recs)
+                    gaps_of.append(int(g))
+        out = {"gaps_tried": len(sets), "gaps_with_new_contigs": 0, "new_contigs": 0, "closed": {}, "contigs": []}
+        if not sets:
+            return out
+        new = []
+        for g, m in zip(gaps_of, merge_sets(self.gf, sets)):
+            out["gaps_with_new_contigs"] += bool(m["new"])
+            new += [(g, s) for _, s, _ in m["new"]]
+        out["new_contigs"], out["contigs"] = len(new), new
+        if not new:
+            return out
+        c2 = np.zeros(len(new), dtype=B.CONTIG)
+        off = 0
+        for i, (g, s) in enumerate(new):
+            c2[i] = (g, 0, 0, 0, len(s), 0, 0, off)
+            off += len(s)
+        d_c2 = torch.from_numpy(c2.view(np.uint8).copy()).to(self.dev)
+        d_s2 = torch.from_numpy(np.frombuffer("".join(s for _, s in new).encode(), dtype=np.uint8).copy()).to(self.dev)
+        d_b2 = torch.zeros(max(1, self.n_gaps), dtype=torch.int64, device=self.dev)
+        d_n2 = torch.tensor([len(new), 0, 0, 0], dtype=torch.int32, device=self.dev)
+        torch.cuda.synchronize()
+        a0, a1 = self.anchors[0], (self.anchors[1] if len(self.anchors) > 1 else 0)
+        self._chk(self.lib.gf_pick_anchored2_dev(self.h, d_c2.data_ptr(), d_n2.data_ptr(), len(new), d_s2.data_ptr(), a0, a1, d_b2.data_ptr(),
+                                                 d_n2.data_ptr() + 8), "gf_pick_anchored2_dev")
+        self.gf.sync()
+        b2 = d_b2[:self.n_gaps].cpu().numpy().view(np.uint64)
+        out["closed"] = {int(g): decode_best(b2[g]) for g in np.nonzero(b2)[0]}
+        out["arrays"] = (c2, "".join(s for _, s in new).encode(), b2)       # the second pick's contig table, bases and pick words
+        return out
 
     def fixed_ms(self, steps):
         out = {}
