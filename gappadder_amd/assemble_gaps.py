@@ -184,25 +184,31 @@ class GapAssembler:
                     f.readline()
                     f.readline()
                     reads.setdefault(h[1:].split()[0], seq)
-            seeds = {}                                                                    # seed -> (contig, strand, offset) of its first occurrence per contig and strand
+            seeds = {}                                                                    # seed -> its occurrences (contig, strand, offset), at most MAX_OCC per contig and strand
             strands = []
+            MAX_OCC = 8
             for ci, (_, s) in enumerate(contigs):
                 for st, strand in enumerate((s, revcomp(s))):
                     strands.append(strand)
-                    seen_here = set()
+                    seen_here = {}
                     for i in range(len(strand) - seed_len + 1):
                         w = strand[i:i + seed_len]
-                        if w not in seen_here:
-                            seen_here.add(w)
+                        n_here = seen_here.get(w, 0)
+                        if n_here < MAX_OCC:          # a seed repeated inside a contig: every placement is a candidate
+                            seen_here[w] = n_here + 1
                             seeds.setdefault(w, []).append((ci, st, i))
             bridges = []
             for rid, seq in reads.items():
                 su = seq.upper()
-                clipped = set()
+                placed = {}                                                               # contig -> {(strand, start of the read): clipped?}
                 for i in range(len(su) - seed_len + 1):
                     for ci, st, j in seeds.get(su[i:i + seed_len], ()):
-                        if ci not in clipped and _clipped_at(su, i, strands[2 * ci + st], j, seed_len):
-                            clipped.add(ci)
+                        key = (st, j - i)
+                        if key not in placed.setdefault(ci, {}):
+                            placed[ci][key] = _clipped_at(su, i, strands[2 * ci + st], j, seed_len)
+                # clipped at a contig = it shares a seed with it and NO candidate placement aligns end to end (bwa reports the
+                # best alignment: a read that fits somewhere in the contig is no bridge, whatever its other seed hits look like)
+                clipped = [ci for ci, pl in placed.items() if all(pl.values())]
                 if len(clipped) >= 2:                                                     # clipped at two contigs at least (:213)
                     bridges.append((rid, seq))
             if os.path.exists(d + "original_contigs_before_merging.fa"):                  # (:206-210)

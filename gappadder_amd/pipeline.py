@@ -268,6 +268,9 @@ class Pipeline:
         # times the reads of the others it follows the bulk of the pools, not the deepest one
         self.asm_bound = self.max_pool_rows if self.max_pool_rows <= 4096 else max(4096, int(np.percentile(self.per_gap, 99)))
         self.gf.set_option("asm_max_pool_reads", max(1, self.asm_bound))
+        # ... and the slices of that last launch hold the deepest pool actually present (the library's default, 131 072 rows x 8 slices, is
+        # 7-9 GB of workspace per context whether or not a pool needs it: ADVICE r4)
+        self.gf.set_option("asm_big_pool_reads", max(1, min(0x1FFFFF, self.max_pool_rows)))
         self.lib_cap = max(4096, int(1.25 * max(self.rows_lib)) + 1024)            # rows of one library's pool array
         # local pool arrays: [n_lib][lib_cap] rows (slot l = library l: the source layout of gf_pools_merge_dev)
         self.d_pools = self._u8(n_lib * self.lib_cap * rb + 64)

@@ -423,3 +423,30 @@ def test_roofline_traffic_is_quoted_only_from_a_profile_of_the_running_build(tmp
     older = dict(t, kernels={n.replace("false", "true"): {} for n in names})                              # an older round's file beside it: skipped, the newer one still counts
     (prof / "r03_traffic_c4.json").write_text(json.dumps(older))
     assert bench.pmc_traffic("C4", 900_000_000, 150, 51, 15.2, launched) == 7.4e10
+
+
+def test_a_read_that_fits_at_a_second_occurrence_of_its_seed_is_no_bridge(tmp_path):
+    """A contig with an internal repeat: a read that lies wholly inside the SECOND copy shares its seeds with the first copy
+    too, where its extension runs off or mismatches — bwa reports the end-to-end alignment, so the read is not clipped at that contig."""
+    from gappadder_amd import assemble_gaps as AG
+    from gappadder_amd.pick_contigs import read_fasta
+    rng = np.random.default_rng(21)
+    rep = _rnd(rng, 60)
+    a, b, c = _rnd(rng, 120), _rnd(rng, 150), _rnd(rng, 200)
+    c1 = a + rep + b + rep + c                      # the repeat twice, different neighbourhoods
+    c2, c3 = _rnd(rng, 300), _rnd(rng, 300)
+    wf = str(tmp_path) + "/"
+    os.makedirs(wf + "velvet_temp/0_1")
+    os.makedirs(wf + "gap_reads_high_quality")
+    fa = ">m1\n%s\n>m2\n%s\n>m3\n%s\n" % (c1, c2, c3)
+    open(wf + "velvet_temp/0_1/contigs.fa", "w").write(fa)
+    second = len(a) + len(rep) + len(b)             # start of the second copy
+    inside_second = c1[second - 40:second + 100]    # fits end to end there; at the first copy its flanks mismatch
+    real_bridge = c1[-80:] + c2[:70]                # clipped at m1 and at m2
+    half = c2[-75:] + _rnd(rng, 75)                 # clipped at m2 only
+    reads = [("inside_second", inside_second), ("real_bridge", real_bridge), ("half", half), ("rep_and_m3", inside_second[:90] + c3[:60])]
+    open(wf + "gap_reads_high_quality/0_1.fastq", "w").write("".join("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)) for n, s in reads))
+    ga = AG.GapAssembler("x.fai", "x.pos", 1, wf, kmer_list=[(31, 29)], gf=object())
+    assert ga.collect_high_quality_unmap_to_contigs_reads(["0_1"]) == 2
+    got = [n for n, _ in read_fasta(wf + "velvet_temp/0_1/contigs.fa")]
+    assert got == ["m1", "m2", "m3", "real_bridge", "rep_and_m3"]
