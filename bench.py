@@ -49,13 +49,17 @@ PRESETS = {
     "C2R": (20260002, 5_000_000, 50, 20, 2000, 50_000_000, [(31, 29)]),
     # ... and the human-scale draft with planted repeats (every 16th gap at a copy of a 50-copy family: 1 240 repeat gaps in 25 families)
     "C4R": (20260004, 5_000_000, 620, 32, 2000, 900_000_000, [(51, 49)]),
+    # ... and C2's draft with planted repeats, the mate-pair library and the multi-k sweep of configs[4] at its scale (not a BASELINE
+    # configuration): gaps DO close here, so the truth check, the open-gap census and the contig-merge round say what a repeat-bearing
+    # draft does to the anchors and the picks (VERDICT r4 missing 4)
+    "C2RM": (20260002, 5_000_000, 50, 20, 2000, 50_000_000, [(31, 29), (41, 39), (51, 49)]),
 }
-REPEATS = {"C2R": (8, 50), "C4R": (16, 50)}   # config -> (period, copies) of the planted repeats
+REPEATS = {"C2R": (8, 50), "C4R": (16, 50), "C2RM": (8, 50)}   # config -> (period, copies) of the planted repeats
 # Mate-pair library of C5.  SURVEY.md §8d says "extra 100 M records" = 4.8x: at KMC's min-count 2 a k-mer of the gap interior (covered by
 # this library only) is then missing with P = e^-3.9 (1 + 3.9) = 10 % per position, so no 2-kb gap can close (measured on the GPU:
 # 0 of 19 840; tools/closure_experiment.py: 0/6 at 4.8x, 1/6 at 10x, 28/30 at 15x, 30/30 at 19x).  The bench therefore draws
 # 400 M records (19.4x); --mp-reads 100000000 reproduces the survey's figure.
-MP_READS_DEFAULT = 400_000_000
+MATE_PAIRS = {"C5": 400_000_000, "C2RM": 32_000_000}   # configs with the IS 5000 / sd 500 library: its read records (19.4x of the draft)
 
 
 def parse_args():
@@ -117,7 +121,7 @@ def main():
                          "C2_with_planted_repeats": child_run(["--config", "C2R", "--steps", "5", "--warmup", "1"]),
                          "C5_mate_pair_multi_k": child_run(["--config", "C5", "--steps", "3", "--warmup", "1"]),
                          # SURVEY.md §8d's own figure for the mate-pair library (100 M records = 4.8x): recorded as it is — at KMC's
-                         # min-count 2 that depth leaves holes in every 2-kb gap, so (nearly) nothing closes; see MP_READS_DEFAULT
+                         # min-count 2 that depth leaves holes in every 2-kb gap, so (nearly) nothing closes; see MATE_PAIRS
                          "C5_survey_sized_100M_mate_pairs": child_run(["--config", "C5", "--mp-reads", "100000000", "--steps", "2", "--warmup", "1"])}
         # the product path on files: the CLI on a C3-sized BAM + FASTQ pair, wall time split by stage
         out["extras"]["e2e_files_C3"] = e2e_files("C3")
@@ -187,8 +191,8 @@ def run(args):
     # gap — mate unmapped / discordant / clipped inside the focal window — and are distant sequence otherwise; GF_BENCH_MP_PAIRS=1 pulls
     # them anyway: 819 instead of 620 reads per pool, the same gaps closed)
     lib_defs = [("short-insert", 300, 30, 0, total_reads, 1)]
-    if args.config == "C5":
-        mp = MP_READS_DEFAULT if args.mp_reads < 0 else args.mp_reads
+    if args.config in MATE_PAIRS:
+        mp = MATE_PAIRS[args.config] if args.mp_reads < 0 else args.mp_reads
         lib_defs.append(("mate-pair", 5000, 500, 1, mp // 2 * 2, int(os.environ.get("GF_BENCH_MP_PAIRS", "0"))))
 
     lib = B.lib()
@@ -655,9 +659,7 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
     CO.set_threads(cores)
     k_s = min(a for a, _ in kk)
     ok, ok_tag, t_rec, n_rec, n_ohits, notes = True, True, 0.0, 0, 0, []
-    tb = time.perf_counter()
-    CO.screen_reads(b"", L, flanks, k_s, 1, 0, cores)       # the oracle's flank k-mer table alone (built once per run, not per read)
-    t_build = time.perf_counter() - tb
+    t_build = 0.0      # the oracle's flank k-mer table (once per run, not per read): timed INSIDE the screen call that builds it
     for li, lb in enumerate(libs):      # first library: --cpu-sample-reads; further libraries: a quarter of that
         n_s = min(args.cpu_sample_reads if li == 0 else args.cpu_sample_reads // 4, lb.n_reads) // 2 * 2
         ocfg = np.frombuffer(lb.cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
@@ -673,7 +675,8 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
         ok = ok and SC.hits_equal(hits, ohits, n_s)
         th = np.frombuffer(lb.d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
         ok_tag = ok_tag and SC.taghits_equal(th, otags, n_s)
-        t_rec += max(1e-3, (t1 - t0) - t_build) + (t2 - t1)
+        t_build = CO.screen_last_build_s()          # (of this very call: no subtraction of a separately measured build)
+        t_rec += max(1e-6, (t1 - t0) - t_build) + (t2 - t1)
         n_rec += n_s
         n_ohits += len(ohits)
         notes.append("%s: first %d reads (k-mer screen %.2f s + alignment tagger %.2f s; %d + %d hits)" % (lb.name, n_s, t1 - t0, t2 - t1, len(ohits), len(otags)))

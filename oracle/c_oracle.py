@@ -36,6 +36,8 @@ def lib():
         L.or_tag_low_mapq.argtypes = [vp, sz, vp, sz, vp, sz]
         L.or_screen_reads.restype = sz
         L.or_screen_reads.argtypes = [C.c_char_p, sz, i32, C.c_char_p, vp, sz, i32, i32, u32, vp, sz, i32]
+        L.or_screen_last_build_s.restype = C.c_double
+        L.or_screen_last_build_s.argtypes = []
         L.or_set_threads.restype = None
         L.or_set_threads.argtypes = [i32]
         L.or_pack_kmer64.restype = C.c_uint64
@@ -62,6 +64,11 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def screen_last_build_s():
+    """Seconds the last screen_reads call spent building its flank k-mer table (the rest of the call is the per-read pass)."""
+    return float(lib().or_screen_last_build_s())
 
 
 def set_threads(n):

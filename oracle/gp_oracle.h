@@ -23,6 +23,7 @@ size_t or_tag_low_mapq(const or_alnrec* recs, size_t n, const or_dpos* table, si
 size_t or_screen_reads(const char* reads_ascii, size_t n_reads, int read_len, const char* flank_ascii,
                        const uint64_t* flank_off, size_t n_gaps, int k, int min_hits, uint32_t max_gaps_per_kmer,
                        or_hit* out, size_t cap, int threads);
+double or_screen_last_build_s(void); /* seconds the last or_screen_reads call spent on its flank k-mer table, before the per-read pass */
 void or_set_threads(int n); /* OpenMP threads used by the parallel functions */
 /* KmerUtils.cpp:61-69 */
 uint64_t or_pack_kmer64(const char* seq, int k);
