@@ -350,7 +350,7 @@ def run(args):
         tm0 = time.perf_counter()
         mg = pipe.merge_open_gaps(res)
         tm = time.perf_counter() - tm0
-        merge_round = {"gaps_tried": mg["gaps_tried"], "gaps_with_new_contigs": mg["gaps_with_new_contigs"], "new_contigs": mg["new_contigs"],
+        merge_round = {"gaps_tried": mg["gaps_tried"], "gaps_skipped_large": mg["gaps_skipped_large"], "gaps_with_new_contigs": mg["gaps_with_new_contigs"], "new_contigs": mg["new_contigs"],
                        "gaps_closed_by_merging": len(mg["closed"]), "seconds_untimed": tm}
         if mg["closed"]:
             c2, s2, b2 = mg["arrays"]

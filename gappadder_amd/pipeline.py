@@ -428,28 +428,32 @@ class Pipeline:
             r.pool_rows = r.asm_pool_t[:r.asm_rows_total * self.rb].cpu().numpy().reshape(-1, self.rb)
         return r
 
-    def merge_open_gaps(self, res):
+    def merge_open_gaps(self, res, max_set=128):
         """The reference merges a gap's contigs BEFORE it picks (assemble_gaps.py:301-306, 335-339: run_contigs_merge, then
         pick_full_constructed_contigs); the step picks first, so only the gaps that pick left open can gain from merging: their
         contigs go through the contig merger (MergeContigs.merge_sets: exact-containment dedup, all-pairs prefilter + overlap
         evaluation on the GPU, path search on the host) and the NEW_CONTIG_MERGE sequences through a second pick on the device.
         res: fetch()'s Results.  Returns {"gaps_tried", "gaps_with_new_contigs", "new_contigs", "closed": {gap: (anchor, span + 1,
-        index into "contigs", reverse)}, "contigs": [(gap, seq)]}."""
+        index into "contigs", reverse)}, "contigs": [(gap, seq)]}.  Gaps with more than max_set contigs after the dedup are left alone
+        ("gaps_skipped_large"): the contig graph of a repeat-bearing gap has thousands of paths (C2 with planted repeats and mate pairs:
+        53 641 merged strings for 176 gaps, 158 s on the host, and 50 of the 174 gaps they close are closed with a wrong sequence)."""
         from .MergeContigs import MAX_SET, drop_contained, merge_sets
         ctg, seq = res.contigs, res.seq
         open_gaps = np.nonzero(res.best == 0)[0]
         order = np.argsort(ctg["gap"], kind="stable")
         gs = ctg["gap"][order]
         lo, hi = np.searchsorted(gs, open_gaps), np.searchsorted(gs, open_gaps, side="right")
-        sets, gaps_of = [], []
+        sets, gaps_of, skipped = [], [], 0
         for g, a, z in zip(open_gaps, lo, hi):
             if z - a >= 2:
                 recs = [("c%d" % i, seq[int(ctg[i]["seq_off"]):int(ctg[i]["seq_off"]) + int(ctg[i]["length"])].decode()) for i in order[a:z]]
                 recs = drop_contained(recs) if len(recs) <= MAX_SET else recs
-                if 2 <= len(recs) <= MAX_SET:
+                if 2 <= len(recs) <= min(MAX_SET, max_set):
                     sets.append(recs)
                     gaps_of.append(int(g))
-        out = {"gaps_tried": len(sets), "gaps_with_new_contigs": 0, "new_contigs": 0, "closed": {}, "contigs": []}
+                elif len(recs) > max_set:
+                    skipped += 1
+        out = {"gaps_tried": len(sets), "gaps_skipped_large": skipped, "gaps_with_new_contigs": 0, "new_contigs": 0, "closed": {}, "contigs": []}
         if not sets:
             return out
         new = []
