@@ -478,15 +478,21 @@ int gf_assemble(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, const 
     const size_t rb = gf_packed_read_bytes(read_len), nmw = (size_t)(read_len + 31) / 32;
     int rc;
     // the host knows its pools: bound the per-workgroup workspace slices by the largest one
+    // (... and the slices of the launch for deeper pools hold the deepest pool of THIS call, whatever a device pipeline on the same
+    //  context sized them for: the option asm_big_pool_reads only ever raises that)
     struct MaxRows {
-        gf_ctx* c; long saved;
-        MaxRows(gf_ctx* c_, long v) : c(c_), saved(c_->asm_max_pool_reads) { c->asm_max_pool_reads = v; }
-        ~MaxRows() { c->asm_max_pool_reads = saved; }
+        gf_ctx* c; long saved, saved_big;
+        MaxRows(gf_ctx* c_, long v, long big) : c(c_), saved(c_->asm_max_pool_reads), saved_big(c_->asm_big_pool_reads) {
+            c->asm_max_pool_reads = v;
+            c->asm_big_pool_reads = std::max(saved_big, big);
+        }
+        ~MaxRows() { c->asm_max_pool_reads = saved; c->asm_big_pool_reads = saved_big; }
     };
     size_t max_rows = 1;
     for (size_t g = 0; g < n_pools; ++g) max_rows = std::max<size_t>(max_rows, (size_t)(pool_off[g + 1] - pool_off[g]));
+    const size_t deepest = max_rows;
     if (ctx->asm_max_pool_reads > 0) max_rows = std::min<size_t>(max_rows, (size_t)ctx->asm_max_pool_reads);   // (a caller's own, lower bound stays: deeper pools take the second launch)
-    MaxRows bound(ctx, (long)std::min<size_t>(max_rows, 0x3FFFFFFF));
+    MaxRows bound(ctx, (long)std::min<size_t>(max_rows, 0x3FFFFFFF), (long)std::min<size_t>(deepest, 0x1FFFFF));
     // device staging: [pool | pool_off | gap_error | counters | contigs | seq]
     const size_t b_pool = (total * rb + 63) & ~(size_t)63, b_off = ((n_pools + 1) * 8 + 63) & ~(size_t)63,
                  b_err = (n_pools * 4 + 63) & ~(size_t)63, b_ctg = (contig_cap * sizeof(gf_contig) + 63) & ~(size_t)63;
