@@ -363,10 +363,34 @@ def test_pools_beyond_the_callers_bound_take_the_second_launch(gf, kk):
             got, _ = _gpu_assemble(gf, pools, L, [kk])
             for i in range(len(pools)):
                 assert got.get((i, kk[0], kk[1]), []) == want[i], (bound, i, sizes[i])
-        gf.set_option("asm_big_pool_reads", 200)         # the deep pools are beyond the second launch's slices too
+        # The deep pools are beyond the last launch's slices too.  The HOST call knows its pools and sizes those slices for its deepest one
+        # (an option a device pipeline left on the context only ever gets raised: the CLI's later rounds share the context with it) ...
+        gf.set_option("asm_big_pool_reads", 200)
         gf.set_option("asm_max_pool_reads", 64)
-        with pytest.raises(Exception):
-            _gpu_assemble(gf, pools, L, [kk])
+        got, _ = _gpu_assemble(gf, pools, L, [kk])
+        for i in range(len(pools)):
+            assert got.get((i, kk[0], kk[1]), []) == want[i], ("host, small option", i, sizes[i])
+        # ... the DEVICE entry point takes the option as it stands: a pool beyond it is the documented limit — its gap_error is set, the
+        # others are assembled
+        import ctypes as C
+        import torch
+        from gappadder_amd import _lib as B
+        lib = B.lib()
+        from gappadder_amd.hip_api import GapFill
+        packed, _ = GapFill.pack_reads(b"".join(pools), L)
+        off = np.cumsum([0] + sizes).astype(np.int64)
+        d_pool = torch.from_numpy(packed.reshape(-1).copy()).cuda()
+        d_off = torch.from_numpy(off).cuda()
+        d_ctg = torch.zeros(8192 * 32, dtype=torch.uint8, device="cuda")
+        d_seq = torch.zeros(1 << 22, dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros(8, dtype=torch.int32, device="cuda")
+        d_err = torch.zeros(len(pools), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        assert lib.gf_assemble_dev(gf.handle, d_pool.data_ptr(), None, d_off.data_ptr(), len(pools), int(off[-1]), L, kk[0], kk[1], 2, 40,
+                                   d_ctg.data_ptr(), 8192, d_cnt.data_ptr(), d_seq.data_ptr(), 1 << 22, d_cnt.data_ptr() + 8, d_err.data_ptr()) == 0
+        gf.sync()
+        err = d_err.cpu().numpy()
+        assert [bool(e) for e in err] == [n > 200 for n in sizes] and any(err) and not all(err)
     finally:
         gf.set_option("asm_max_pool_reads", 0)
         gf.set_option("asm_big_pool_reads", 131072)
