@@ -225,7 +225,9 @@ def run(args):
 
     # The whole step lives in the package (gappadder_amd/pipeline.py: residency, sizing pass, capacities, recruit -> hop -> keys -> pools ->
     # merge / owner exchange -> assembly -> pick): this file generates the inputs, calls it and times it
-    pipe = Pipeline(gf, n_gaps, L, kk, device=dev, world=world, rank=rank, backend=backend, force_exchange=multi and world == 1)
+    # GF_BENCH_TAG_KEYS=0: the tagger streams the 32-byte records themselves instead of their 8-byte key column (ablation)
+    key_column = os.environ.get("GF_BENCH_TAG_KEYS", "1") != "0"
+    pipe = Pipeline(gf, n_gaps, L, kk, device=dev, world=world, rank=rank, backend=backend, force_exchange=multi and world == 1, key_column=key_column)
     pipe.tag_after_filter = not serial and os.environ.get("GF_BENCH_TAG_AFTER_FILTER", "0") == "1"
     pipe.tag_ahead = tag_ahead
     h = gf.handle
@@ -397,7 +399,7 @@ def run(args):
         wl = ("%s: %d gaps x %d bp in %d x %.1f Mb scaffolds; %s; k/kv %s; step = k-mer screen (k=%d) + alignment tagger + second hop + per-gap "
               "pools%s + per-gap assembly + flank anchoring" %
               (args.config, n_gaps, glen, nscf, slen / 1e6,
-               " + ".join("%s library IS %d/%d: %d x %d-bp read records (+ as many 32-B alignment records)%s" % (lb.name, lb.is_mean, lb.is_sd, lb.n_total, L, "" if lb.pull_mates else ", screen hits without their mates")
+               " + ".join(("%s library IS %d/%d: %d x %d-bp read records (+ as many 32-B alignment records" + (" and their 8-B key column" if key_column else "") + ")%s") % (lb.name, lb.is_mean, lb.is_sd, lb.n_total, L, "" if lb.pull_mates else ", screen hits without their mates")
                           for lb in libs),
                ",".join("%d/%d" % p for p in kk), k_s,
                " (libraries merged in library order)" if n_lib > 1 else ""))

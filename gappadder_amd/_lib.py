@@ -98,6 +98,8 @@ def lib():
         "gf_pool_keys_from_second_hop_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, sz, vp]),
         "gf_tag_alignments_low_dev": (i32, [vp, vp, sz, i32, i32, i32, i32, vp, sz, vp, vp, sz, vp]),
         "gf_tag_low_mapq_compact_dev": (i32, [vp, vp, vp, sz, vp, sz, vp, sz, vp]),
+        "gf_alnrec_keys_dev": (i32, [vp, vp, sz, vp]),
+        "gf_tag_alignments_keys_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, i32, vp, sz, vp, vp, sz, vp]),
         "gf_assemble": (i32, [vp, vp, vp, vp, sz, i32, vp, vp, i32, i32, i32, vp, sz, szp, vp, sz, szp]),
         "gf_assemble_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, i32, i32, i32, i32, vp, sz, vp, vp, sz, vp, vp]),
         "gf_assemble_multi_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, vp, vp, i32, i32, i32, vp, sz, vp, vp, sz, vp, vp]),

@@ -209,6 +209,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "screen_variant")) { ctx->screen_variant = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_dbg_ptr")) { ctx->asm_dbg = (void*)(uintptr_t)value; return GF_OK; }
     if (!strcmp(name, "asm_stats_ptr")) { ctx->asm_stats = (void*)(uintptr_t)value; return GF_OK; }
+    if (!strcmp(name, "tag_dbg")) { if (!getenv("GF_DIAGNOSTICS")) return GF_E_INVAL; ctx->tag_dbg = (int)value; return GF_OK; }
     if (!strcmp(name, "tag_light")) { ctx->tag_light = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_keyslot")) { ctx->asm_keyslot = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_sweep")) { if (value < 0 || value > 1) return GF_E_INVAL; ctx->asm_sweep = (int)value; return GF_OK; }
@@ -366,6 +367,19 @@ int gf_tag_alignments_low_dev(gf_ctx* ctx, const void* d_recs, size_t n, int ins
     if (!ctx || !d_n_out || !d_n_low || (n && !d_recs) || (cap && !d_out) || (low_cap && !d_low)) return GF_E_INVAL;
     GF_HIP(ctx, hipSetDevice(ctx->device));
     return launch_tag(ctx, d_recs, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n_out, d_low, low_cap, d_n_low);
+}
+
+int gf_alnrec_keys_dev(gf_ctx* ctx, const void* d_recs, size_t n, void* d_keys) {
+    if (!ctx || !d_keys || (n && !d_recs)) return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_alnrec_keys(ctx, d_recs, n, d_keys);
+}
+
+int gf_tag_alignments_keys_dev(gf_ctx* ctx, const void* d_recs, const void* d_keys, size_t n, int insert_size, int sd, int clip_dist, int anchor_mapq,
+                               void* d_out, size_t cap, void* d_n_out, void* d_low, size_t low_cap, void* d_n_low) {
+    if (!ctx || !d_n_out || (n && (!d_recs || !d_keys)) || (cap && !d_out)) return GF_E_INVAL;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_tag(ctx, d_recs, n, insert_size, sd, clip_dist, anchor_mapq, d_out, cap, d_n_out, d_low, low_cap, d_n_low, d_keys);
 }
 
 int gf_tag_low_mapq_compact_dev(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const gf_dpos* table,

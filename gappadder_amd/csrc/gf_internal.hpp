@@ -95,6 +95,7 @@ struct gf_ctx {
     int screen_ext = 1;          // 256-bucket filter: check the bases next to a seed against the flanks' (0: 16-base seeds as they are)
     int screen_pf4_cap8 = 0;     // tests: capacity of the 4-byte filter's pair list (0: sized from the reads)
     int screen_lds_log2_max = 20;   // coarse LDS bitmap of the screen: at most 2^20 bits (128 KiB)
+    int tag_dbg = 0;             // diagnostics of the key-column tagger (option tag_dbg, refused unless GF_DIAGNOSTICS is set)
     int tag_light = 0;           // alignment tagger: one-wave workgroups, bin map through L1/L2 (runs beside the k-mer filter)
     int asm_lds_pool_kb = 152;
     int asm_threads = 0;         // threads per gap in the assembly kernel: 1024 / 512 / 256, 0 = by the pool bound (assemble.hip)
@@ -191,7 +192,8 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
                   int read_len, int min_hits, void* d_out, size_t cap, void* d_n_out);
 // tagger.hip
 int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist, int anchor_mapq,
-               void* d_out, size_t cap, void* d_n_out, void* d_low, size_t low_cap, void* d_n_low);
+               void* d_out, size_t cap, void* d_n_out, void* d_low, size_t low_cap, void* d_n_low, const void* d_keys = nullptr);
+int launch_alnrec_keys(gf_ctx* ctx, const void* d_recs, size_t n, void* d_keys);
 int launch_low_mapq(gf_ctx* ctx, const void* d_recs, size_t n, const gf_dpos* table, size_t n_rows, void* d_out,
                     size_t cap, void* d_n_out, const void* d_low, const void* d_n_low, size_t low_cap);
 

@@ -15,6 +15,8 @@ namespace gf {
 
 struct TagParams {
     const gf_alnrec* recs;
+    uint32_t dbg;             // diagnostics (option tag_dbg; results change): 1 no MAPQ-0 by-product, 2 no bin test (nothing passes), 4 candidates dropped unsifted
+    const uint2* keys;        // KEYS variants: {pos, ref | (mapq == 0) << 31} per record (gf_alnrec_keys_dev), n + 1 entries
     uint64_t n;
     const gf_gap* gaps;
     const uint32_t* scaf_off;
@@ -97,12 +99,16 @@ constexpr int TAG_UNROLL = 8;  // 8 KiB (256 records) per wave and stage, two st
 // human scale); BINS_LDS = false reads it through L1/L2 instead and runs one-wave workgroups with ~6 KiB of LDS, so that the
 // tagger's workgroups fit on the CUs NEXT TO the k-mer filter's (which own 137-151 KiB of every CU's LDS but leave most of its
 // issue slots idle: PMC SQ_WAIT_ANY 53-77 %) — the "light" variant a pipeline launches on its second stream.
-template <int NW, bool BINS_LDS, bool NT = false, bool FINEQ = false>
+// KEYS: the stream is the 8-byte KEY COLUMN of the records — {pos, ref | (mapq == 0) << 31}, built once at ingest — instead of the 32-byte
+// records themselves: 99 % of the records are decided by (scaffold, position) alone, and the by-product needs one more bit; the full record is
+// fetched only for what passes the bin maps (the path the fine-map queue already had).  A quarter of the bytes per record for the stream.
+template <int NW, bool BINS_LDS, bool NT = false, bool FINEQ = false, bool KEYS = false>
 __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
+    constexpr bool CQ = FINEQ || KEYS;   // records that pass the LDS map wait in the candidate queue (fine map, then the record's fetch)
     extern __shared__ uint32_t bins_lds[];  // the whole bin map (16 or 64 KiB), staged once per workgroup
     __shared__ gf_taghit whits[NW][WHCAP];
     __shared__ LiveRec liveq[NW][LIVEQ];
-    __shared__ CandRec candq[FINEQ ? NW : 1][FINEQ ? CANDQ : 1];
+    __shared__ CandRec candq[CQ ? NW : 1][CQ ? CANDQ : 1];
     // MAPQ==0 records (2 % of a library) leave through ONE counter, and returning atomics on one address are served at ~11-15 ns
     // each: flushing a 64-entry LDS buffer per wave straight to the list, the 900 M records of C4 needed 360 000 of them — 4 of the
     // kernel's 5.2 ms; the stream ran at 4.9 instead of 6.0 TB/s.  The LDS buffer (whole 768-byte runs: single 12-byte stores left
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
     const uint64_t chunk = 64ull * TAG_UNROLL;             // halves per wave iteration
     const uint4* src = reinterpret_cast<const uint4*>(P.recs);
     // ---- per-wave queue of records that passed the LDS map and wait for the fine map (FINEQ)
-    CandRec* wcand = candq[FINEQ ? threadIdx.x >> 6 : 0];
+    CandRec* wcand = candq[CQ ? threadIdx.x >> 6 : 0];
     uint32_t cand_n = 0;   // wave-uniform
     auto sift = [&]() {    // fine-map test of the last min(64, cand_n) queued records, one per lane
         const uint32_t base = cand_n > 64 ? cand_n - 64 : 0;
@@ -216,8 +222,10 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
         CandRec c = {};
         if (live) {
             c = wcand[base + lane];
-            const uint32_t f0 = P.fine_off[c.ref], fi = c.pos >> P.fine_shift, fb = f0 + fi;
-            live = fi < P.fine_off[c.ref + 1] - f0 && ((P.fine_bits[fb >> 5] >> (fb & 31)) & 1u);
+            if (FINEQ || P.fine_bits) {   // (KEYS without a fine map: the queue only gathers the records to fetch)
+                const uint32_t f0 = P.fine_off[c.ref], fi = c.pos >> P.fine_shift, fb = f0 + fi;
+                live = fi < P.fine_off[c.ref + 1] - f0 && ((P.fine_bits[fb >> 5] >> (fb & 31)) & 1u);
+            }
         }
         tag_wave_sync();
         cand_n = base;
@@ -236,6 +244,66 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
             if (live_n >= 64) drain();
         }
     };
+    if constexpr (KEYS) {
+        // the key column: 16 bytes = two records per lane and load, TAG_UNROLL loads (1 024 records per wave) in flight behind the chunk at work
+        const uint4* ksrc = reinterpret_cast<const uint4*>(P.keys);
+        const uint64_t n_k16 = (P.n + 1) / 2;
+        const uint64_t kchunk = 64ull * TAG_UNROLL;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* ksrc4 = reinterpret_cast<const u32x4*>(ksrc);
+        // (plain loops, no lambda and no named pad value: anything whose address a closure takes goes to scratch memory — the first form of
+        //  this loop kept its sixteen prefetched keys there, 144 bytes per lane, and ran no faster than the 32-byte stream)
+        u32x4 kn[TAG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TAG_UNROLL; ++u) {
+            const uint64_t h = wave * kchunk + 64ull * u + lane;
+            kn[u] = h < n_k16 ? __builtin_nontemporal_load(ksrc4 + h) : u32x4{0u, 0x7FFFFFFFu, 0u, 0x7FFFFFFFu};
+        }
+        for (uint64_t h0 = wave * kchunk; h0 < n_k16; h0 += n_waves * kchunk) {
+            u32x4 v[TAG_UNROLL];
+#pragma unroll
+            for (int u = 0; u < TAG_UNROLL; ++u) v[u] = kn[u];
+#pragma unroll
+            for (int u = 0; u < TAG_UNROLL; ++u) {
+                const uint64_t h = h0 + n_waves * kchunk + 64ull * u + lane;
+                kn[u] = h < n_k16 ? __builtin_nontemporal_load(ksrc4 + h) : u32x4{0u, 0x7FFFFFFFu, 0u, 0x7FFFFFFFu};
+            }
+#pragma unroll
+            for (int u = 0; u < TAG_UNROLL; ++u) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const uint64_t rec = 2 * (h0 + 64ull * u + lane) + half;
+                    const uint32_t pos = half ? v[u].z : v[u].x, w = half ? v[u].w : v[u].y;
+                    const uint32_t ref = w & 0x7FFFFFFFu;
+                    bool live = rec < P.n && ref < P.n_scaffolds;
+                    if (P.low) {   // wave-uniform: compact the MAPQ==0 records for the second hop
+                        const bool z = live && (w >> 31) && !(P.dbg & 1u);
+                        const unsigned long long zb = __ballot(z);
+                        if (zb) {
+                            const uint32_t cnt = (uint32_t)__popcll(zb);
+                            if (low_n + cnt > LOWBUF) flush_low();
+                            if (z) wlow[low_n + __popcll(zb & ((1ull << lane) - 1))] = gf_lowrec{pos, ref, (uint32_t)rec};
+                            low_n += cnt;
+                        }
+                    }
+                    if (P.dbg & 2u) live = false;
+                    if (live) {
+                        const uint32_t b0 = boff[ref], nbin = boff[ref + 1] - b0, bi = pos >> P.bin_shift;
+                        live = bi < nbin && ((bins[(b0 + bi) >> 5] >> ((b0 + bi) & 31)) & 1u);
+                    }
+                    if (P.dbg & 4u) live = false;
+                    const unsigned long long cb = __ballot(live);
+                    if (!cb) continue;
+                    const uint32_t cnt = (uint32_t)__popcll(cb);
+                    if (cand_n + cnt > CANDQ) sift();                  // (cand_n < 64 on entry: one sift empties the queue)
+                    if (live) wcand[cand_n + __popcll(cb & ((1ull << lane) - 1))] = CandRec{pos, ref, (uint32_t)rec};
+                    cand_n += cnt;
+                    tag_wave_sync();
+                    if (cand_n >= 64) sift();
+                }
+            }
+        }
+    } else {
     // software pipeline: the next chunk's loads are issued before the current chunk is processed
     uint4 vn[TAG_UNROLL];
     auto fetch = [&](uint64_t h0) {
@@ -320,11 +388,26 @@ __global__ __launch_bounds__(64 * NW) void tag_kernel(TagParams P) {
             if (live_n >= 64) drain();
         }
     }
-    if (FINEQ) while (cand_n) sift();
+    }
+    if (CQ) while (cand_n) sift();
     while (live_n) drain();
     if (P.low && low_n) flush_low();
     if (P.low && stage_n) flush_stage();
     if (hb.n) flush_wave_hits(hb, P.out, P.cap, P.n_out);
+}
+
+// the key column of a record array: {pos, ref | (mapq == 0) << 31}; an unplaced record ('*': ref 0xFFFFFFFF) keeps an invalid scaffold; entry
+// n (the pad of an odd count: the tagger loads two keys at a time) is invalid too
+__global__ __launch_bounds__(256) void alnrec_keys_kernel(const gf_alnrec* recs, uint64_t n, uint2* keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint2 k = make_uint2(0u, 0x7FFFFFFFu);
+    if (i < n) {
+        const uint4 a = reinterpret_cast<const uint4*>(recs)[2 * i], b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];
+        const uint32_t ref = a.w < 0x7FFFFFFFu ? a.w : 0x7FFFFFFFu, mapq = (b.y >> 16) & 0xFFu;
+        k = make_uint2(a.x, ref | (mapq == 0 ? 0x80000000u : 0u));
+    }
+    keys[i] = k;
 }
 
 // (gf_internal.hpp: HOP_NEAR_LOG2, HOP_NEAR_SHIFT, hop_near_bit)
@@ -595,8 +678,15 @@ static int ensure_bin_map(gf_ctx* ctx, int dist2, gf_ctx::TagMap** out) {
     return GF_OK;
 }
 
+int launch_alnrec_keys(gf_ctx* ctx, const void* d_recs, size_t n, void* d_keys) {
+    LaunchTimer tm(ctx, GF_KERNEL_INGEST);
+    hipLaunchKernelGGL(alnrec_keys_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, (const gf_alnrec*)d_recs, (uint64_t)n, (uint2*)d_keys);
+    GF_HIP(ctx, hipGetLastError());
+    return GF_OK;
+}
+
 int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist, int anchor_mapq,
-               void* d_out, size_t cap, void* d_n_out, void* d_low, size_t low_cap, void* d_n_low) {
+               void* d_out, size_t cap, void* d_n_out, void* d_low, size_t low_cap, void* d_n_low, const void* d_keys) {
     if (!ctx->d_gaps) return GF_E_STATE;
     if (n >= 0xFFFFFFFFull || cap > 0xFFFFFFFFull) return GF_E_INVAL;
     zero_regions(ctx, ZeroList{{(uint32_t*)d_n_out, (uint32_t*)d_n_low, nullptr, nullptr}, {1, d_n_low ? 1u : 0u, 0, 0}});
@@ -607,6 +697,8 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
     P.n_low = (uint32_t*)d_n_low;
     if (!d_low || !d_n_low) { P.low = nullptr; P.n_low = nullptr; }
     P.recs = (const gf_alnrec*)d_recs;
+    P.keys = (const uint2*)d_keys;
+    P.dbg = (uint32_t)ctx->tag_dbg;
     P.n = n;
     P.gaps = ctx->d_gaps;
     P.scaf_off = ctx->d_scaf_off;
@@ -652,6 +744,10 @@ int launch_tag(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int s
     }
     {
         LaunchTimer tm(ctx, GF_KERNEL_TAG);
+        if (d_keys && !ctx->tag_light) {   // the key column as the stream (gf_tag_alignments_keys_dev)
+            if (big_map) hipLaunchKernelGGL((tag_kernel<16, true, true, false, true>), dim3(grid), dim3(1024), lds_map, ctx->stream, P);
+            else hipLaunchKernelGGL((tag_kernel<4, true, true, false, true>), dim3(grid), dim3(256), lds_map, ctx->stream, P);
+        } else
         if (ctx->tag_light)   // one-wave workgroups without the LDS bin map: co-resident with the k-mer filter's workgroups
             hipLaunchKernelGGL((tag_kernel<1, false>), dim3(grid), dim3(64), 0, ctx->stream, P);
         else if (big_map && P.fine_bits)   // the 64-KiB map: one 16-wave workgroup per CU

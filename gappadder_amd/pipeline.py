@@ -43,7 +43,7 @@ class DeviceLibrary:
     over all ranks, `first_pair` = this rank's first pair (contiguous shards)."""
 
     def __init__(self, name, is_mean, is_sd, n_reads, d_reads, d_recs, n_recs=None, pull_mates=1, d_nmask=None, n_total=None,
-                 first_pair=0, tag_ctx=None, screen=True):
+                 first_pair=0, tag_ctx=None, screen=True, d_rec_keys=None):
         self.name, self.is_mean, self.is_sd, self.pull_mates = name, int(is_mean), int(is_sd), int(pull_mates)
         self.n_reads, self.d_reads, self.d_recs, self.d_nmask = int(n_reads), d_reads, d_recs, d_nmask
         self.n_recs = int(n_reads if n_recs is None else n_recs)
@@ -51,6 +51,7 @@ class DeviceLibrary:
         self.first_pair, self.n_pairs = int(first_pair), self.n_reads // 2
         self.tag_ctx = tag_ctx          # a second GapFill (second stream) for the tagger + second hop, or None: the pipeline's
         self.screen = bool(screen)      # False: alignment-based recruitment only (the reference's own mode)
+        self.d_rec_keys = d_rec_keys    # the records' key column (gf_alnrec_keys_dev); None: Pipeline.add_library builds it
         self.counts = {}
 
 
@@ -61,12 +62,16 @@ class Results:
 
 class Pipeline:
     def __init__(self, gf, n_gaps, read_len, k_pairs, device=None, world=1, rank=0, backend="nccl", force_exchange=False,
-                 min_count=2, min_contig=40, anchors=(30, 15), clip_dist=250, anchor_mapq=30, k_screen=None, keep_read_ids=False):
+                 min_count=2, min_contig=40, anchors=(30, 15), clip_dist=250, anchor_mapq=30, k_screen=None, keep_read_ids=False,
+                 key_column=True):
         """gf: a GapFill whose gaps (and flanks, when a library is screened) are set.  k_pairs: [(k, k_velvet)] of
         assemble_gaps.py:87-122.  The screen runs at the SMALLEST k of the list: a read that shares a 51-mer with a flank shares
         its 31-mers too, so this is the superset every assembly k needs (the reference recruits once, then assembles at every k).
         anchors: flank-anchor lengths of the two pick rounds (the reference's bwa scores 30 then 15, assemble_gaps.py:336, 365);
-        clip_dist / anchor_mapq: main.py:215-216."""
+        clip_dist / anchor_mapq: main.py:215-216.  key_column: the libraries keep an 8-byte key per alignment record beside the records
+        ({pos, scaffold | MAPQ-0 bit}, built once when a library is added: 7.2 GB for C4's 900 M records) and the tagger streams THAT —
+        a record far from every gap, 99 % of a BAM, is decided by (scaffold, position) alone (the reference's `focal_region.has_key(POS)`,
+        collect_reads_for_gaps.py:104) — fetching the 32-byte record only of what passes its bin maps."""
         self.gf, self.lib, self.h = gf, B.lib(), gf.handle
         self.n_gaps, self.L, self.kk = int(n_gaps), int(read_len), [(int(a), int(b)) for a, b in k_pairs]
         self.rb = self.lib.gf_packed_read_bytes(self.L)
@@ -78,6 +83,7 @@ class Pipeline:
         self.clip_dist, self.anchor_mapq = int(clip_dist), int(anchor_mapq)
         self.k_screen = int(k_screen) if k_screen else (min(a for a, _ in self.kk) if self.kk else 31)
         self.keep_read_ids = bool(keep_read_ids)
+        self.key_column = bool(key_column)
         self.libs = []
         self.batch = SH.owner_batch(self.n_gaps, self.world)
         self.stream = None
@@ -130,6 +136,11 @@ class Pipeline:
         lb.d_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
         lb.cp = lb.d_cnt.data_ptr()
         lb.d_ids = None
+        if self.key_column and lb.d_rec_keys is None:
+            lb.d_rec_keys = torch.empty(lb.n_recs + 1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            self._chk(self.lib.gf_alnrec_keys_dev(self.h, lb.d_recs.data_ptr(), lb.n_recs, lb.d_rec_keys.data_ptr()), "gf_alnrec_keys_dev")
+            self.gf.sync()
         self.libs.append(lb)
         return lb
 
@@ -149,6 +160,11 @@ class Pipeline:
             self.tagger(lb)
 
     def tagger(self, lb):
+        if self.key_column and lb.d_rec_keys is not None:
+            self._chk(self.lib.gf_tag_alignments_keys_dev(lb.h2, lb.d_recs.data_ptr(), lb.d_rec_keys.data_ptr(), lb.n_recs, lb.is_mean, lb.is_sd, self.clip_dist,
+                                                          self.anchor_mapq, lb.d_thits.data_ptr(), lb.hit_cap, lb.cp + 4 * CNT_TAG, lb.d_low.data_ptr(),
+                                                          lb.hit_cap, lb.cp + 4 * CNT_LOW), "gf_tag_alignments_keys_dev")
+            return
         self._chk(self.lib.gf_tag_alignments_low_dev(lb.h2, lb.d_recs.data_ptr(), lb.n_recs, lb.is_mean, lb.is_sd, self.clip_dist, self.anchor_mapq,
                                                      lb.d_thits.data_ptr(), lb.hit_cap, lb.cp + 4 * CNT_TAG, lb.d_low.data_ptr(), lb.hit_cap,
                                                      lb.cp + 4 * CNT_LOW), "gf_tag_alignments_low_dev")

@@ -314,6 +314,15 @@ typedef struct {
 int gf_tag_alignments_low_dev(gf_ctx* ctx, const void* d_recs, size_t n, int insert_size, int sd, int clip_dist,
                               int anchor_mapq, void* d_out, size_t cap, void* d_n_out, void* d_low /* gf_lowrec */,
                               size_t low_cap, void* d_n_low /* u32 */);
+/* The same pass over a library that keeps a KEY COLUMN beside its records: 8 bytes per record, {pos, ref | (mapq == 0) << 31}, n + 1 entries
+ * (gf_alnrec_keys_dev builds it from the records, once, at ingest).  99 % of the records of a BAM lie far from every gap and are decided by
+ * (scaffold, position) alone — the reference's `focal_region.has_key(POS)` (collect_reads_for_gaps.py:104) —, the MAPQ-0 by-product needs one
+ * more bit: the tagger streams the key column (a quarter of the bytes) and fetches the 32-byte record only of what passes its bin maps.
+ * Same hits, same MAPQ-0 list as gf_tag_alignments_low_dev (order unspecified in both). */
+int gf_alnrec_keys_dev(gf_ctx* ctx, const void* d_recs, size_t n, void* d_keys /* 8 * (n + 1) bytes */);
+int gf_tag_alignments_keys_dev(gf_ctx* ctx, const void* d_recs, const void* d_keys, size_t n, int insert_size, int sd, int clip_dist,
+                               int anchor_mapq, void* d_out, size_t cap, void* d_n_out, void* d_low /* gf_lowrec or NULL */, size_t low_cap,
+                               void* d_n_low /* u32 or NULL */);
 int gf_tag_low_mapq_compact_dev(gf_ctx* ctx, const void* d_low, const void* d_n_low, size_t low_cap, const gf_dpos* table,
                                 size_t n_rows, void* d_out, size_t cap, void* d_n_out);
 /* The second-hop table itself on the device (replaces collect_discordant_regions_v2 + sort(1) + the per-scaffold split,

@@ -213,3 +213,58 @@ def test_rows_gathered_by_index(gf):
     got = d_dst.cpu().numpy().view(np.uint32).reshape(6, 5)
     assert (got[0] == src[3]).all() and (got[1] == src[3]).all() and (got[2] == src[49]).all() and (got[3] == src[0]).all()
     assert (got[4] == 0xFFFFFFFF).all() and (got[5] == 0x55555555).all()
+
+
+@pytest.mark.parametrize("layout,is_,sd,n_pairs", [("small", 300, 30, 150_001), ("small", 5000, 500, 60_000), ("human", 300, 30, 1_500_000),
+                                                     ("human", 5000, 500, 700_000), ("small", 300, 30, 0), ("small", 300, 30, 1)])
+def test_tagger_on_the_key_column_equals_the_tagger_on_the_records(gf, layout, is_, sd, n_pairs):
+    """gf_tag_alignments_keys_dev streams {pos, ref | mapq0} (8 bytes per record, gf_alnrec_keys_dev) and fetches the 32-byte record only of
+    what passes the bin maps: same hits and the same MAPQ-0 list as gf_tag_alignments_low_dev — 4-wave and 16-wave forms, with and without
+    the fine map, short- and long-insert branch, odd record counts, unplaced records."""
+    import torch
+    from gappadder_amd import _lib as B
+    from gappadder_amd.hip_api import GapFill
+    lib = B.lib()
+    if layout == "small":
+        cfg = GapFill.synth_cfg(seed=77, scaffold_len=400_000, n_scaffolds=7, gaps_per_scaffold=6, gap_len=1500, insert_mean=is_, insert_sd=sd, library=1)
+    else:      # the human-scale layout: 64-KiB bin map, one 16-wave workgroup per CU, fine map where it is selective
+        cfg = GapFill.synth_cfg(seed=20260004, scaffold_len=5_000_000, n_scaffolds=620, gaps_per_scaffold=32, gap_len=2000, insert_mean=is_, insert_sd=sd,
+                                library=1 if is_ > 1000 else 0)
+    gaps, _ = GapFill.synth_layout(cfg)
+    gf.set_gaps(gaps, int(cfg["n_scaffolds"][0]), None)
+    n = 2 * n_pairs
+    n_use = max(0, n - 1) if n_pairs == 150_001 else n          # an odd count once
+    d_reads = torch.empty(max(1, n) * 38 + 64, dtype=torch.uint8, device="cuda")
+    d_recs = torch.zeros(max(1, n) * 32, dtype=torch.uint8, device="cuda")
+    if n_pairs:
+        gf.synth_pairs_dev(cfg, 0, n_pairs, d_reads.data_ptr(), d_recs.data_ptr())
+    gf.sync()
+    if n_use >= 40:     # a few unplaced records ('*') and a scaffold beyond the .fai
+        r = d_recs.view(torch.int32).view(-1, 8)
+        r[5, 3] = -1
+        r[17, 3] = int(cfg["n_scaffolds"][0]) + 3
+    cap = max(1024, n // 4)
+    outs = []
+    for keyed in (False, True):
+        d_hits = torch.zeros(cap * 12, dtype=torch.uint8, device="cuda")
+        d_low = torch.zeros(cap * 12, dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+        d_keys = torch.full((n_use + 1,), -1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        if keyed:
+            assert lib.gf_alnrec_keys_dev(gf.handle, d_recs.data_ptr(), n_use, d_keys.data_ptr()) == 0
+            assert lib.gf_tag_alignments_keys_dev(gf.handle, d_recs.data_ptr(), d_keys.data_ptr(), n_use, is_, sd, 250, 30, d_hits.data_ptr(), cap, d_cnt.data_ptr(),
+                                                  d_low.data_ptr(), cap, d_cnt.data_ptr() + 4) == 0
+        else:
+            assert lib.gf_tag_alignments_low_dev(gf.handle, d_recs.data_ptr(), n_use, is_, sd, 250, 30, d_hits.data_ptr(), cap, d_cnt.data_ptr(),
+                                                 d_low.data_ptr(), cap, d_cnt.data_ptr() + 4) == 0
+        gf.sync()
+        nh, nl = int(d_cnt[0]), int(d_cnt[1])
+        assert nh <= cap and nl <= cap
+        hits = np.frombuffer(d_hits[:nh * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
+        low = np.frombuffer(d_low[:nl * 12].cpu().numpy().tobytes(), dtype=np.dtype([("pos", "<u4"), ("ref", "<u4"), ("rec", "<u4")]))
+        outs.append((np.sort(hits, order=["rec", "gap", "kind", "to_mate"]), np.sort(low, order=["rec"])))
+    assert len(outs[0][0]) == len(outs[1][0]) and (outs[0][0] == outs[1][0]).all()
+    assert len(outs[0][1]) == len(outs[1][1]) and (outs[0][1] == outs[1][1]).all()
+    if n_pairs >= 60_000:
+        assert len(outs[0][0]) > 100 and len(outs[0][1]) > 100
