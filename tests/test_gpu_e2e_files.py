@@ -63,3 +63,13 @@ def test_cli_on_files_equals_the_device_resident_run(tmp_path):
         t = (GapFill.synth_truth(cfg0, sc, st - 5, en - st + 11), GapFill.synth_truth(cfg0, sc, st - 6, en - st + 11))
         truth_ok += picked[keys[g]] in t
     assert truth_ok >= len(closed) - 1
+    # the contig-merge round for the gaps the step left open (Pipeline.merge_open_gaps): only open gaps, every pick confirmed by the host picker
+    from gappadder_amd.pick_contigs import pick_gap_sequence
+    mg = pipe.merge_open_gaps(res)
+    open_gaps = set(int(g) for g in np.nonzero(res.best == 0)[0])
+    assert set(mg["closed"]) <= open_gaps and mg["gaps_tried"] <= len(open_gaps)
+    for g, (a_len, span1, ci, rev) in mg["closed"].items():
+        gg, contig = mg["contigs"][ci]
+        assert gg == g
+        r = pick_gap_sequence([("c", contig)], flanks[g][0], flanks[g][1], a_len)
+        assert r is not None and len(r[1]) == span1 and (r[2] != contig) == bool(rev), g
