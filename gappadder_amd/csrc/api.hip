@@ -492,13 +492,13 @@ int gf_assemble(gf_ctx* ctx, const uint8_t* pool, const uint32_t* n_mask, const 
     const size_t rb = gf_packed_read_bytes(read_len), nmw = (size_t)(read_len + 31) / 32;
     int rc;
     // the host knows its pools: bound the per-workgroup workspace slices by the largest one
-    // (... and the slices of the launch for deeper pools hold the deepest pool of THIS call, whatever a device pipeline on the same
-    //  context sized them for: the option asm_big_pool_reads only ever raises that)
+    // (... and the slices of the launch for deeper pools hold exactly the deepest pool of THIS call — neither what a device pipeline on
+    //  the same context sized them for nor the option's default of 131 072 rows x 8 slices, 7-9 GB whether or not a pool needs it: ADVICE r4)
     struct MaxRows {
         gf_ctx* c; long saved, saved_big;
         MaxRows(gf_ctx* c_, long v, long big) : c(c_), saved(c_->asm_max_pool_reads), saved_big(c_->asm_big_pool_reads) {
             c->asm_max_pool_reads = v;
-            c->asm_big_pool_reads = std::max(saved_big, big);
+            c->asm_big_pool_reads = big;
         }
         ~MaxRows() { c->asm_max_pool_reads = saved; c->asm_big_pool_reads = saved_big; }
     };
