@@ -46,7 +46,10 @@ class _Restart(Exception):
         self.read_len = read_len
 
 
-def _guess_read_len(paths, n_records=4096):
+def _guess_read_len(paths, n_records=None):
+    """Longest sequence line among the first records of every file (GF_INGEST_GUESS_RECORDS, default 4 096): the packed row size; a longer
+    read further down restarts the ingest at its length."""
+    n_records = int(os.environ.get("GF_INGEST_GUESS_RECORDS", 4096)) if n_records is None else n_records
     L = 0
     for p in paths:
         with open(p, "rb") as f:

@@ -124,6 +124,7 @@ def main_func(command, sf_config):
                 timings["seconds"] = dc.t
                 timings["libraries"] = [dict(lb.counts, reads=lb.n_reads, records=lb.n_recs) for lb in dc.libs]
                 timings["gaps"] = len(res.keys)
+                timings["read_len"] = res.read_len        # the packed row length: the longest read of all libraries
                 timings["gaps_closed_on_device"] = int(res.n_closed)
             except DeviceCollectUnsupported as e:
                 sys.stderr.write("device-resident Collect not used (%s): per-scaffold path\n" % e)

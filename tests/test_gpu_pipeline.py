@@ -342,3 +342,48 @@ def test_inputs_the_resident_path_does_not_take_fall_back_to_the_per_scaffold_pa
         if "/gap_reads/" in rel and rel.startswith("1_"):
             split = lambda t: sorted("\n".join(t.splitlines()[i:i + 4]) for i in range(0, len(t.splitlines()), 4))
             assert split(got[rel]) == split(txt), rel
+
+
+def test_resident_path_with_n_bases_ragged_reads_and_a_late_long_read(tmp_path):
+    """Reads with N, reads of different lengths (packed at the longest, the tail masked) and a read longer than the first ones promised
+    (the ingest restarts at its length): the N masks travel with the pooled reads through the library merge into the first assembly
+    round on the device.  `-c All` on resident libraries must write the tree of the per-scaffold path, contigs included."""
+    import random
+    case = Case("twolib")
+    rng = random.Random(11)
+
+    def mutate(fq, lib_no):
+        lines = fq.splitlines()
+        for r in range(len(lines) // 4):
+            s, q = lines[4 * r + 1], lines[4 * r + 3]
+            if r % 9 == 0:                                   # an N somewhere
+                p = rng.randrange(len(s))
+                s = s[:p] + "N" + s[p + 1:]
+            if lib_no == 1 and r % 3 == 0:                   # ragged: 110-149 bases
+                n = rng.randrange(110, len(s))
+                s, q = s[:n], q[:n]
+            if lib_no == 0 and r == len(lines) // 4 - 7:     # one longer read near the end of the file
+                s, q = s + "ACGTTGCA", q + "IIIIIIII"
+            lines[4 * r + 1], lines[4 * r + 3] = s, q
+        return "\n".join(lines) + "\n"
+
+    trees = []
+    for sub, env in (("resident", {"GF_INGEST_GUESS_RECORDS": "50"}), ("per_scaffold", {"GF_DEVICE_COLLECT": "0"})):
+        rng.seed(11)                                         # the same mutations for both runs
+        root = os.path.join(str(tmp_path), sub)
+        os.makedirs(root)
+        cfgp, wf, _ = PU.materialise(case, root, kmers=((31, 29), (41, 39)), builtin_bam=True)
+        for i in range(len(case.libs)):
+            for m in (1, 2):
+                p = os.path.join(root, "data", "lib%d_%d.fq" % (i, m))
+                text = open(p).read()
+                open(p, "w").write(mutate(text, i))
+        tfile = os.path.join(root, "timings.json")
+        _run_stages(cfgp, ["All"], env=dict(env, GF_TIMINGS=tfile))
+        trees.append(PU.tree(wf))
+        if sub == "resident":     # the first 50 records promised 150 bases; the ingest restarted at the long read's 158
+            import json
+            assert json.load(open(tfile))["read_len"] == 158
+    _same_tree(trees[0], trees[1])
+    assert any("N" in v for k, v in trees[0].items() if k.startswith("merged/gap_reads/"))
+    assert sum(v.count(">") for k, v in trees[0].items() if k.endswith("/contigs.fa")) > 10
