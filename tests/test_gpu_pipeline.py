@@ -387,3 +387,36 @@ def test_resident_path_with_n_bases_ragged_reads_and_a_late_long_read(tmp_path):
     _same_tree(trees[0], trees[1])
     assert any("N" in v for k, v in trees[0].items() if k.startswith("merged/gap_reads/"))
     assert sum(v.count(">") for k, v in trees[0].items() if k.endswith("/contigs.fa")) > 10
+
+
+def test_resident_path_with_orphan_and_secondary_alignment_records(tmp_path):
+    """Alignment records whose QNAME is in no FASTQ record (an orphan: the reference lists it and then finds nothing to pull), secondary
+    copies of records (FLAG 0x100: the reference reads them like any other line) and hard clips: same tree from both paths."""
+    case = Case("edge")
+
+    class Mutated:
+        pass
+    c = Mutated()
+    c.draft_fa, c.fai, c.meta = case.draft_fa, case.fai, case.meta
+    c.libs = []
+    for lib in case.libs:
+        out = []
+        for i, line in enumerate(lib["sam"].splitlines()):
+            out.append(line)
+            f = line.split("\t")
+            if i % 40 == 0 and len(f) > 10:
+                out.append("\t".join([f[0] + "_orphan"] + f[1:]))                                   # a name no FASTQ record has
+            if i % 55 == 0 and len(f) > 10:
+                out.append("\t".join([f[0], str(int(f[1]) | 0x100)] + f[2:5] + [f[5].replace("S", "H")] + f[6:]))   # secondary copy, hard clips
+        c.libs.append(dict(lib, sam="\n".join(out) + "\n"))
+    trees = []
+    for sub, env in (("resident", {}), ("per_scaffold", {"GF_DEVICE_COLLECT": "0"})):
+        root = os.path.join(str(tmp_path), sub)
+        os.makedirs(root)
+        cfgp, wf, _ = PU.materialise(c, root, kmers=((31, 29),), builtin_bam=True)
+        _run_stages(cfgp, ["Preprocess", "Collect"], env=env)
+        trees.append(PU.tree(wf))
+    _same_tree(trees[0], trees[1])
+    lists = "".join(v for k, v in trees[0].items() if "/scaffold_reads_list_all/" in k)
+    assert "_orphan " in lists
+    assert not any("_orphan" in v for k, v in trees[0].items() if k.endswith(".fastq"))
