@@ -307,11 +307,11 @@ class DeviceCollector:
         for lb in libs:
             pipe.add_library(lb)
         t0 = time.perf_counter()
-        pipe.prepare()
-        self._tick("sizing_pass", t0)
+        pipe.prepare()                       # recruits every library once (hits, second-hop rows, pool keys) and sizes the buffers from that
+        self._tick("recruit_and_sizing", t0)
         t0 = time.perf_counter()
-        pipe.step()
-        self._tick("recruit_and_pools", t0)
+        pipe.finish()                        # ... the pools from the keys it left (no second recruit: a one-shot run)
+        self._tick("pools", t0)
         d_mask = None
         if kk:
             t0 = time.perf_counter()

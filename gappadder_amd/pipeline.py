@@ -341,12 +341,16 @@ class Pipeline:
             raise RuntimeError("library %s: %d %s exceed the capacity %d (add_library(hit_cap=...))" % (lb.name, n, what, cap))
 
     # ---- one pass of the hot path (enqueued; no host synchronisation) ------------------------------------------------------
-    def _step(self):
+    def _step(self, recruited=False):
+        """recruited: the hit lists, second-hop rows and pool keys of the libraries are in place already (the sizing pass just left them:
+        finish()) — only the pools are built."""
         lib, h, n_gaps, n_lib, L = self.lib, self.h, self.n_gaps, len(self.libs), self.L
-        for lb in self.libs:
-            self.recruit(lb, tagger=not self.tag_ahead)
+        if not recruited:
+            for lb in self.libs:
+                self.recruit(lb, tagger=not self.tag_ahead)
         for l, lb in enumerate(self.libs):
-            self.hop_and_keys(lb)
+            if not recruited:
+                self.hop_and_keys(lb)
             self.build_pools(lb, self.pool_ptr[l], self.lib_cap)
         if self.tag_ahead:
             for lb in self.libs:        # the next step's tagger pass: behind every consumer of this step's hits, beside the assembly
@@ -401,6 +405,12 @@ class Pipeline:
             for _ in range(n):
                 self._step()
         self._on_stream(run)
+
+    def finish(self):
+        """A one-shot run (the CLI): prepare() has recruited every library once to size the buffers, and its hits and pool keys are still
+        there — build the pools from them (and assemble, unless assemble_in_step is off) instead of recruiting a second time."""
+        assert self.prepared, "Pipeline.prepare() first"
+        self._on_stream(lambda: self._step(recruited=True))
 
     def barrier(self):
         self.sync()

@@ -299,7 +299,7 @@ def test_all_in_one_on_resident_libraries_writes_the_same_tree(run, tmp_path):
     _run_stages(cfgp, ["All"], env={"GF_TIMINGS": tfile})
     _same_tree(PU.tree(wf), ref_tree)
     t = json.load(open(tfile))
-    assert {"ingest_fastq", "ingest_bam", "join", "recruit_and_pools", "assemble_and_pick", "write_files"} <= set(t["seconds"])
+    assert {"ingest_fastq", "ingest_bam", "join", "recruit_and_sizing", "pools", "assemble_and_pick", "write_files"} <= set(t["seconds"])
     assert len(t["libraries"]) == len(case.libs) and all(l["records"] > 0 for l in t["libraries"])
 
 
