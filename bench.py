@@ -569,7 +569,9 @@ def e2e_files(config="C3"):
     root = tempfile.mkdtemp(prefix="gf_e2e_", dir=os.environ.get("GF_E2E_DIR") or None)
     try:
         t0 = time.perf_counter()
-        cfgp, wf = SF.write_case(root, seed, slen, nscf, gps, glen, [(300, 30, dreads // 2)], kk, nthreads=max(1, (os.cpu_count() or 2) // 2))
+        # (parameters.kmer_screen = the smallest k: the CLI recruits like the step above — alignment tagger + second hop + flank-k-mer screen)
+        cfgp, wf = SF.write_case(root, seed, slen, nscf, gps, glen, [(300, 30, dreads // 2)], kk, kmer_screen=min(a for a, _ in kk),
+                                 nthreads=max(1, (os.cpu_count() or 2) // 2))
         t_gen = time.perf_counter() - t0
         sizes = {fn: os.path.getsize(os.path.join(root, "data", fn)) for fn in sorted(os.listdir(os.path.join(root, "data")))}
         tfile = os.path.join(root, "timings.json")
@@ -582,7 +584,13 @@ def e2e_files(config="C3"):
         t = json.load(open(tfile))
         n_picked = open(wf + "picked_seqs.fa").read().count(">") if os.path.exists(wf + "picked_seqs.fa") else 0
         device_s = sum(t.get("seconds", {}).values())
-        return {"what": "python -m gappadder_amd.main -c All on the %s files (draft FASTA %.1f MB, BAM %.1f MB, FASTQ 2 x %.1f MB), "
+        # the same configuration synthesised straight into HBM (a child run of this file): the CLI on files must have recruited exactly that
+        dev = child_run(["--config", config, "--steps", "1", "--warmup", "0"])
+        same = None
+        if "counts" in dev and t.get("libraries"):
+            a, b = list(dev["counts"]["libraries"].values())[0], t["libraries"][0]
+            same = all(int(a[key]) == int(b[key]) for key in ("screen_hits", "tagger_hits", "second_hop_hits", "pool_keys", "pooled_reads"))
+        return {"same_recruits_as_the_device_resident_run": same, "what": "python -m gappadder_amd.main -c All on the %s files (draft FASTA %.1f MB, BAM %.1f MB, FASTQ 2 x %.1f MB), "
                         "software_path.samtools = builtin; wall time of the child process, interpreter start-up and imports included"
                         % (config, sizes.get("draft.fa", 0) / 1e6, sizes.get("lib0.bam", 0) / 1e6, sizes.get("lib0_1.fq", 0) / 1e6),
                 "reads": dreads, "wall_s": wall, "reads_per_s_end_to_end": dreads / wall,

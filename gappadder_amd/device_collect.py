@@ -441,10 +441,11 @@ class DeviceCollector:
                     with open(folder + "discordant_reads_list/%s_cluster_by_discordant_reads_%s.list" % (names[s], side), "w") as f:
                         f.write("".join(l + "\n" for l in d[side]))
             # -- left_reads.list / right_reads.list (run_multi_threads_discordant.py:187-194, 262-268)
+            screen_map = self._screen_hit_map(lb, keys, mm) if lb.screen else {}
             for side in ("left", "right"):
                 m = drc._read_gap_map(names, side, False)
-                if lb.screen:
-                    self._add_screen_hits(lb, m, side, keys, mm)
+                for rid, ks in screen_map.items():        # the hit read and its mate: both files (kmer_recruit.py)
+                    m.setdefault(rid, {}).update(ks)
                 with open(folder + side + "_reads.list", "w") as f:
                     f.write("".join("%s %s\n" % (g, r) for r, gs in m.items() for g in gs))
             # -- per-gap FASTQ files from the pooled read ids (run_multi_threads_discordant.py:209-241, 283-316: left file's
@@ -506,18 +507,21 @@ class DeviceCollector:
                 raise RuntimeError("read-name join: alignment record %r was joined to FASTQ record %r of %s (64-bit hash collision)"
                                    % (qn[i], rid.decode(), lb.left))
 
-    def _add_screen_hits(self, lb, m, side, keys, mm):
-        """k-mer-screen recruits (parameters.kmer_screen) in the {readId: {gapKey}} map of one mate file, like kmer_recruit.py."""
+    def _screen_hit_map(self, lb, keys, mm):
+        """k-mer-screen recruits (parameters.kmer_screen) as {readId: {gapKey: 1}}, for left_reads.list / right_reads.list (kmer_recruit.py)."""
         c = lb.d_cnt.cpu().numpy()
         n = int(c[CNT_SCREEN])
-        hits = np.frombuffer(lb.d_hits[:n * 8].cpu().numpy().tobytes(), dtype=B.HIT)
         if not n:
-            return
-        pairs = np.unique(hits["read"].astype(np.int64) >> 1)
+            return {}
+        hits = np.frombuffer(lb.d_hits[:n * 8].cpu().numpy().tobytes(), dtype=B.HIT)
+        pair_of = hits["read"].astype(np.int64) >> 1
+        pairs, inv = np.unique(pair_of, return_inverse=True)
         b, e = self._offsets(lb, 0, pairs)
-        rid_of = {int(p): self._record(mm[0], int(b_), int(e_), b"")[0].decode() for p, b_, e_ in zip(pairs, b, e)}
-        for hgt in hits:
-            m.setdefault(rid_of[int(hgt["read"]) >> 1], {})[keys[int(hgt["gap"])]] = 1      # the hit read and its mate: both files
+        rids = [self._record(mm[0], int(b_), int(e_), b"")[0].decode() for b_, e_ in zip(b, e)]
+        out = {}
+        for i, g in zip(inv.tolist(), hits["gap"].tolist()):
+            out.setdefault(rids[i], {})[keys[g]] = 1
+        return out
 
     def _write_pool_fastq(self, lb, d, keys, off, ids, mm, merged):
         os.makedirs(d, exist_ok=True)
