@@ -73,3 +73,20 @@ def test_cli_on_files_equals_the_device_resident_run(tmp_path):
         assert gg == g
         r = pick_gap_sequence([("c", contig)], flanks[g][0], flanks[g][1], a_len)
         assert r is not None and len(r[1]) == span1 and (r[2] != contig) == bool(rev), g
+
+
+def test_bench_e2e_extra_at_full_c3_size():
+    """bench.py's `e2e_files_C3` extra as the driver runs it: the CLI (`-c All`, builtin BAM, k-mer screen on) on the C3-sized files recruits
+    exactly what the device-resident run of C3 recruits (5 M reads: screen, tagger, second hop, pool keys, pooled reads) and closes every gap."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--e2e-only", "C3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert "error" not in d, d
+    assert d["same_recruits_as_the_device_resident_run"] is True
+    assert d["reads"] == 5_000_000 and d["gaps"] == 200 and d["picked_seqs"] == 200
+    assert d["libraries"][0]["screen_hits"] > 100_000 and d["libraries"][0]["pooled_reads"] > 200_000
+    assert set(d["device_collect_s"]) >= {"ingest_fastq", "ingest_bam", "join", "recruit_and_sizing", "pools", "assemble_and_pick", "write_files"}
