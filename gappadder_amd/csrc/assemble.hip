@@ -400,6 +400,18 @@ __device__ __forceinline__ K128 shift_in_front(K128 v, uint32_t c, int len) {
 // in the global fallback): the vector L1 is write-through, so after every wave's vmcnt(0) (part of the barrier) the stores
 // are in L2; one lane then invalidates this CU's L1 (acquire, agent scope = buffer_inv sc1, ~1.7 us) so that lines cached
 // before an atomic or a rewrite are not served stale.  Replaces 1024 x __threadfence() (L2 write-back + invalidate each).
+// does the window [p, p + len) of a read touch a masked base (N, or the padding behind a short read)?  row = the read's mask words (bit i = base
+// i), nmw of them; len <= 64, so the window spans at most three words: one 96-bit shift instead of a loop over the window's bases (the host
+// entry points pass masks for every FASTQ-born pool: the loop was 41 global loads per window and pass at k = 41 — 56 ms for a launch that
+// takes 2 ms without masks, rocprofv3 of the CLI, profiles/r05_kernel_stats_e2e_c3.csv)
+__device__ __forceinline__ bool window_masked(const uint32_t* row, uint32_t nmw, uint32_t p, uint32_t len) {
+    const uint32_t w = p >> 5, sh = p & 31;
+    const uint64_t lo = (uint64_t)row[w] | ((uint64_t)(w + 1 < nmw ? row[w + 1] : 0u) << 32);
+    const uint64_t hi = w + 2 < nmw ? row[w + 2] : 0u;
+    const uint64_t a = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    return (len >= 64 ? a : a & ((1ull << len) - 1)) != 0;
+}
+
 __device__ __forceinline__ void wg_phase_sync() {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -638,10 +650,7 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                     if constexpr (!AHEAD) {
                         for (;;) {
                             bool ok = true;
-                            if (nmask) {
-                                for (uint32_t q = p; q < p + PK; ++q)
-                                    if ((nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { ok = false; break; }
-                            }
+                            if (nmask) ok = !window_masked(nmask + (r0 + r) * P.nmw, P.nmw, p, PK);
                             if (ok) {
                                 key = rc < fw ? rc : fw;
                                 const auto h0 = hint(key);
@@ -688,10 +697,7 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                         auto h1 = h;
                         if (more) h1 = hint(key1);
                         bool ok = true;
-                        if (nmask) {
-                            for (uint32_t q = p; q < p + PK; ++q)
-                                if ((nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { ok = false; break; }
-                        }
+                        if (nmask) ok = !window_masked(nmask + (r0 + r) * P.nmw, P.nmw, p, PK);
                         if (ok) {
                             while (body(r, p, key, fw, rc, h)) {}
                         }
@@ -878,10 +884,7 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                     const unsigned long long fw = pv_kmer_at<false>(V, rr, pp, k).hi;
                     const unsigned long long rc = revcomp_w<false>(K128{fw, 0}, k).hi;
                     valid = true;
-                    if (nmask) {
-                        for (uint32_t q = pp; q < pp + PK; ++q)
-                            if ((nmask[(r0 + rr) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { valid = false; break; }
-                    }
+                    if (nmask) valid = !window_masked(nmask + (r0 + rr) * P.nmw, P.nmw, pp, PK);
                     return fw < rc ? fw : rc;
                 };
                 // insert / count one k-mer; v = the slot's content as loaded by the caller (may be stale: every decision below is
@@ -1092,12 +1095,7 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
             for (uint32_t inst_i = tid; inst_i < n_inst; inst_i += ASM_THREADS) {
                 if (use_lds && s_cnt[6]) break;
                 const uint32_t r = inst_i / npos, p = inst_i - r * npos;
-                if (nmask) {
-                    bool bad = false;
-                    for (uint32_t q = p; q < p + PK; ++q)
-                        if ((nmask[(r0 + r) * P.nmw + (q >> 5)] >> (q & 31)) & 1u) { bad = true; break; }
-                    if (bad) continue;
-                }
+                if (nmask && window_masked(nmask + (r0 + r) * P.nmw, P.nmw, p, PK)) continue;
                 const uint32_t inst = make_inst(r, p);
                 const K128 key = canonical_w<W>(pv_kmer<W>(V, inst, k), k);
                 bool fresh;

@@ -319,6 +319,11 @@ class DeviceCollector:
             pipe.assemble(d_mask.data_ptr() if d_mask is not None else None)
             self._tick("assemble_and_pick", t0)
         res = pipe.fetch()
+        # the context goes on to the reference's later rounds (host entry points, pools that GROW: assemble_gaps.py:349-351): the bounds the
+        # pipeline derived from ITS pools must not outlive it — a stale asm_max_pool_reads sent most second-round pools of a C3-sized run to
+        # the eight workgroups of the deep-pool launch (3 x 27 ms instead of 3 ms)
+        gf.set_option("asm_max_pool_reads", 0)
+        gf.set_option("asm_big_pool_reads", 131072)
         res.keys, res.k_pairs, res.read_len = keys, kk, L
         self.pipe, self.libs = pipe, libs
         if write_files:

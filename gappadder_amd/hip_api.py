@@ -207,6 +207,8 @@ class GapFill:
         kvs = np.asarray([b for _, b in kk], dtype=np.int32)
         if n_mask is not None:
             n_mask = np.ascontiguousarray(n_mask, dtype=np.uint32)
+            if not n_mask.any():      # no N, no ragged read: the launches specialised for mask-free pools (k as a compile-time constant) apply
+                n_mask = None
         ccap, scap = 1024, 1 << 16
         while True:
             ctg = np.zeros(ccap, dtype=B.CONTIG)
