@@ -332,6 +332,20 @@ def test_rccl_branch_runs_at_world_one_and_changes_nothing(tmp_path, config, ext
     assert b["fixed_ms"]["second_hop_union"] > 0 and b["fixed_ms"]["owner_exchange"] > 0 and b["final_gather_ms"] >= 0
 
 
+@pytest.mark.parametrize("env", [{"GF_BENCH_TAG_AHEAD": "1"}, {"GF_BENCH_TWO_STREAMS": "1"}, {"GF_BENCH_TAG_KEYS": "0"}])
+def test_stream_and_layout_variants_of_the_step_change_nothing(tmp_path, env):
+    """The step's options that move work between streams (Pipeline.tag_ahead: the next step's tagger beside this step's assembly; the tagger
+    on a second stream beside the filter) or change what the tagger streams (the 32-byte records instead of their key column) leave contigs,
+    counts and closed gaps as they are — three steps in a row, so that the pipelined tagger's hand-over between steps is exercised."""
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    argv = ["--config", "C5", "--reads", "4000000", "--mp-reads", "2000000", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extras"]
+    a = _bench(argv + ["--dump-contigs", one])
+    b = _bench(argv + ["--dump-contigs", two], env_extra=env)
+    ja, jb = json.load(open(one)), json.load(open(two))
+    assert ja["contigs"] == jb["contigs"] and len(ja["contigs"]) > 100 and ja["gaps_closed"] == jb["gaps_closed"]
+    assert a["counts"] == b["counts"]
+
+
 def test_bench_launches_its_own_ranks_from_a_bare_shell(tmp_path):
     """`python bench.py --gpus 2` without torch.distributed.run around it (no WORLD_SIZE in the environment): bench.py starts the
     ranks as a child process; on this one-GPU box they share cuda:0 and talk over gloo.  Same contigs as the single-process run."""
