@@ -120,18 +120,14 @@ class Pipeline:
 
     def add_library(self, lb, hit_cap=None):
         """Registers a library and allocates its recruit buffers.  hit_cap (hits of one kind per step) defaults to an eighth of the
-        reads — the screen finds 0.5 %, the tagger 1-2 % on the BASELINE workloads —; a step that finds more fails loudly."""
+        reads — the screen finds 0.5 %, the tagger 1-2 % on the BASELINE workloads —; prepare() grows the buffers of a library that finds
+        more (the device calls report their counts beyond the capacity) and sizes again; a STEP that outgrows them later fails loudly
+        in fetch()."""
         assert not self.prepared
         dev = self.dev
         lb.h2 = lb.tag_ctx.handle if lb.tag_ctx is not None else self.h
         lb.second_stream = lb.h2.value != self.h.value
-        lb.hit_cap = int(hit_cap) if hit_cap else max(1 << 20, max(lb.n_reads, lb.n_recs) // 8)
-        lb.d_hits = self._u8(lb.hit_cap * 8)
-        lb.d_thits = self._u8(lb.hit_cap * 12)
-        lb.d_lhits = self._u8(lb.hit_cap * 12)
-        lb.d_low = self._u8(lb.hit_cap * 12)           # MAPQ==0 records compacted by the tagger (2 % of a typical BAM)
-        lb.key_cap = 4 * lb.hit_cap
-        lb.d_keys = torch.empty(lb.key_cap, dtype=torch.int64, device=dev)
+        self._alloc_hit_buffers(lb, int(hit_cap) if hit_cap else max(1 << 20, max(lb.n_reads, lb.n_recs) // 8))
         lb.d_pool_off = torch.zeros(self.n_gaps + 1, dtype=torch.int64, device=dev)
         lb.d_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
         lb.cp = lb.d_cnt.data_ptr()
@@ -143,6 +139,15 @@ class Pipeline:
             self.gf.sync()
         self.libs.append(lb)
         return lb
+
+    def _alloc_hit_buffers(self, lb, hit_cap):
+        lb.hit_cap = int(hit_cap)
+        lb.d_hits = self._u8(lb.hit_cap * 8)
+        lb.d_thits = self._u8(lb.hit_cap * 12)
+        lb.d_lhits = self._u8(lb.hit_cap * 12)
+        lb.d_low = self._u8(lb.hit_cap * 12)           # MAPQ==0 records compacted by the tagger (2 % of a typical BAM)
+        lb.key_cap = 4 * lb.hit_cap
+        lb.d_keys = torch.empty(lb.key_cap, dtype=torch.int64, device=self.dev)
 
     # ---- the phases of a step ---------------------------------------------------------------------------------------------
     def recruit(self, lb, tagger=True):
@@ -227,21 +232,38 @@ class Pipeline:
         return fn()
 
     # ---- sizing pass (untimed): second-hop table rows, pooled reads, exchange slots, assembly workspace --------------------
-    def prepare(self, strict_screen=False):
+    def prepare(self, strict_screen=False, _depth=0):
         import torch.distributed as dist
         lib, h, dev, world, n_gaps, rb = self.lib, self.h, self.dev, self.world, self.n_gaps, self.rb
         n_lib = len(self.libs)
         assert n_lib >= 1
         torch.cuda.synchronize()
-        self.screen_dropped = 0
-        for lb in self.libs:
-            self._on_stream(lambda: self.recruit(lb))
-            if lb.screen:
-                nd = C.c_size_t(0)
-                self._chk(lib.gf_screen_last_overflow(h, C.byref(nd)), "gf_screen_last_overflow")
-                # reads with more (position, gap) matches than the verification lists (low-complexity reads against hundreds of flanks)
-                self.screen_dropped += nd.value
-        self.sync()
+        for attempt in range(4):
+            self.screen_dropped = 0
+            for lb in self.libs:
+                self._on_stream(lambda: self.recruit(lb))
+                if lb.screen:
+                    nd = C.c_size_t(0)
+                    self._chk(lib.gf_screen_last_overflow(h, C.byref(nd)), "gf_screen_last_overflow")
+                    # reads with more (position, gap) matches than the verification lists (low-complexity reads against hundreds of flanks)
+                    self.screen_dropped += nd.value
+            self.sync()
+            # a library that recruits more than an eighth of its reads (dense gaps, short scaffolds): the device calls report how many hits
+            # they found beyond the capacity — the hit buffers grow to that and the pass runs again (the reference has no such bound)
+            grown = False
+            for lb in self.libs:
+                c = lb.d_cnt.cpu().numpy()
+                need = max(int(c[CNT_SCREEN]) if lb.screen else 0, int(c[CNT_TAG]), int(c[CNT_LOW]))
+                if need > lb.hit_cap:
+                    self._alloc_hit_buffers(lb, int(1.25 * need) + 1024)
+                    grown = True
+            if self.multi:      # (every rank repeats the pass together: the sizes below are all-reduced)
+                g_t = torch.tensor([int(grown)], dtype=torch.int64, device=self.coll_dev)
+                dist.all_reduce(g_t, op=dist.ReduceOp.MAX)
+                grown = bool(int(g_t))
+            if not grown:
+                break
+            torch.cuda.synchronize()
         if strict_screen and self.screen_dropped:
             raise RuntimeError("%d reads were not verified in full by the k-mer screen" % self.screen_dropped)
         for lb in self.libs:
@@ -270,8 +292,20 @@ class Pipeline:
         self._on_stream(sizing_pools)
         self.sync()
         torch.cuda.synchronize()
-        for lb in self.libs:
-            self._check_cap(int(lb.d_cnt[CNT_KEYS]), lb.key_cap, "pool keys", lb)
+        again = False
+        for lb in self.libs:      # second-hop hits and pool keys have their own counts: grow for them too, then size everything once more
+            n_hop, n_keys = int(lb.d_cnt[CNT_HOP]), int(lb.d_cnt[CNT_KEYS])
+            if n_hop > lb.hit_cap or n_keys > lb.key_cap:
+                self._alloc_hit_buffers(lb, int(1.25 * max(n_hop, (n_keys + 3) // 4)) + 1024)
+                again = True
+        if self.multi:
+            g_t = torch.tensor([int(again)], dtype=torch.int64, device=self.coll_dev)
+            dist.all_reduce(g_t, op=dist.ReduceOp.MAX)
+            again = bool(int(g_t))
+        if again:
+            if _depth >= 3:
+                raise RuntimeError("the hit buffers keep overflowing (%s)" % ", ".join("%s: %d" % (lb.name, lb.hit_cap) for lb in self.libs))
+            return self.prepare(strict_screen, _depth + 1)
         self.rows_lib = [int(lb.d_pool_off[-1]) for lb in self.libs]
         # largest merged pool (all libraries, all ranks): bounds the assembly's per-workgroup workspace slices
         per_gap = sum((lb.d_pool_off[1:] - lb.d_pool_off[:-1]) for lb in self.libs).to(self.coll_dev)

@@ -268,3 +268,38 @@ def test_tagger_on_the_key_column_equals_the_tagger_on_the_records(gf, layout, i
     assert len(outs[0][1]) == len(outs[1][1]) and (outs[0][1] == outs[1][1]).all()
     if n_pairs >= 60_000:
         assert len(outs[0][0]) > 100 and len(outs[0][1]) > 100
+
+
+def test_pipeline_grows_hit_buffers_that_start_too_small(gf):
+    """Pipeline.prepare(): a library that recruits more hits than its buffers hold (here: a capacity of 64 hits) makes the sizing pass grow them
+    and run again — same pools, contigs and picks as with the default capacity; nothing is lost, nothing raises."""
+    import torch
+    from gappadder_amd.hip_api import GapFill
+    from gappadder_amd.pipeline import DeviceLibrary, Pipeline
+    seed, slen, nscf, gps, glen, L, n_pairs = 31, 300_000, 2, 5, 150, 150, 40_000
+    cfg = GapFill.synth_cfg(seed=seed, scaffold_len=slen, n_scaffolds=nscf, gaps_per_scaffold=gps, gap_len=glen, read_len=L)
+    gaps, flanks = GapFill.synth_layout(cfg)
+    gf.set_gaps(gaps, nscf, flanks)
+    out = []
+    for cap in (None, 64):
+        d_reads = torch.empty(2 * n_pairs * 38 + 64, dtype=torch.uint8, device="cuda")
+        d_recs = torch.empty(2 * n_pairs * 32, dtype=torch.uint8, device="cuda")
+        gf.synth_pairs_dev(cfg, 0, n_pairs, d_reads.data_ptr(), d_recs.data_ptr())
+        gf.sync()
+        pipe = Pipeline(gf, len(gaps), L, [(31, 29)], keep_read_ids=True)
+        lb = pipe.add_library(DeviceLibrary("x", 300, 30, 2 * n_pairs, d_reads, d_recs), hit_cap=cap)
+        pipe.prepare()
+        pipe.finish()
+        res = pipe.fetch(pools=True)
+        assert lb.counts["tagger_hits"] > 64 and lb.counts["screen_hits"] > 64 and lb.hit_cap >= lb.counts["pool_keys"] // 4
+        ctg = sorted((int(c["gap"]), res.seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])]) for c in res.contigs)
+        from gappadder_amd.pipeline import decode_best
+        picks = []                 # (the pick word names its contig by index in the device list, whose order is unspecified: compare the contigs)
+        for g, b in enumerate(res.best.tolist()):
+            if b:
+                a_len, span1, ci, rev = decode_best(b)
+                c = res.contigs[ci]
+                picks.append((g, a_len, span1, rev, res.seq[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])]))
+        out.append((lb.counts, res.pool_off.tolist(), res.pool_rows.tobytes(), ctg, picks))
+        gf.set_option("asm_max_pool_reads", 0)
+    assert out[0] == out[1] and len(out[0][3]) > 5
