@@ -122,7 +122,7 @@ def main_func(command, sf_config):
                 if command == "All" and res.k_pairs:
                     first_round = res
                 timings["seconds"] = dc.t
-                timings["libraries"] = [dict(lb.counts, reads=lb.n_reads, records=lb.n_recs) for lb in dc.libs]
+                timings["libraries"] = [dict(lb.counts, reads=lb.n_reads, records=lb.n_recs, records_without_a_read=lb.records_without_a_read) for lb in dc.libs]
                 timings["gaps"] = len(res.keys)
                 timings["read_len"] = res.read_len        # the packed row length: the longest read of all libraries
                 timings["gaps_closed_on_device"] = int(res.n_closed)
