@@ -3,6 +3,7 @@ decoded on the GPU (gf_bgzf_inflate + gf_bam_pack, csrc/bam.hip); the host only 
 the few records that produce a hit.  The records and columns equal what sam_io.decode gives for the `samtools view` lines of
 the same file (the reference's input, collect_reads_for_gaps.py:76-91), in file order — one pass over the whole BAM instead
 of one `samtools view <bam> <scaffold>` pipe per scaffold (run_multi_threads_collect_reads.py:30-32)."""
+import io
 import struct
 
 import numpy as np
@@ -157,22 +158,51 @@ def decode_file(gf, path, fai_names, chunk_bytes=256 << 20):
     return decode_chunks(gf, read_file_chunks(path, chunk_bytes), fai_names)
 
 
-def write_fai(sf_fasta):
-    """`samtools faidx` stand-in for the builtin mode: NAME LENGTH OFFSET LINEBASES LINEWIDTH per sequence."""
-    rows, cur = [], None
-    with open(sf_fasta, "rb") as f:
-        off = 0
-        for line in f:
-            if line.startswith(b">"):
-                if cur:
-                    rows.append(cur)
-                cur = [line[1:].split()[0].decode(), 0, off + len(line), 0, 0]
-            elif cur is not None and line.strip():
-                if cur[3] == 0:
-                    cur[3], cur[4] = len(line.rstrip(b"\r\n")), len(line)
-                cur[1] += len(line.rstrip(b"\r\n"))
-            off += len(line)
+def _fai_rows_slow(data):
+    rows, cur, off = [], None, 0
+    for line in io.BytesIO(data):
+        if line.startswith(b">"):
+            if cur:
+                rows.append(cur)
+            cur = [line[1:].split()[0].decode(), 0, off + len(line), 0, 0]
+        elif cur is not None and line.strip():
+            if cur[3] == 0:
+                cur[3], cur[4] = len(line.rstrip(b"\r\n")), len(line)
+            cur[1] += len(line.rstrip(b"\r\n"))
+        off += len(line)
     if cur:
         rows.append(cur)
+    return rows
+
+
+def write_fai(sf_fasta):
+    """`samtools faidx` stand-in for the builtin mode: NAME LENGTH OFFSET LINEBASES LINEWIDTH per sequence.  Plain records (LF line
+    ends, no blank or white-space lines) are measured with byte searches — a 250-Mb draft is 4 M lines; anything else takes the
+    line loop."""
+    with open(sf_fasta, "rb") as f:
+        data = f.read()
+    # (bytes.strip() takes " \t\n\r\v\f": a line of those alone is skipped by the line loop)
+    if any(c in data for c in (b"\r", b"\t", b"\x0b", b"\x0c", b" \n", b"\n\n")) or not data.startswith(b">"):
+        rows = _fai_rows_slow(data)
+    else:
+        rows, at = [], 0
+        while at < len(data):
+            nxt = data.find(b"\n>", at)
+            end = nxt + 1 if nxt >= 0 else len(data)
+            h_end = data.find(b"\n", at, end)
+            if h_end < 0:                          # a header without a line end closes the file
+                rows.append([data[at + 1:end].split()[0].decode(), 0, end, 0, 0])
+                break
+            body0 = h_end + 1
+            l1 = data.find(b"\n", body0, end)
+            n_nl = data.count(b"\n", body0, end)
+            if body0 == end:
+                lb = lw = 0
+            elif l1 < 0:
+                lb = lw = end - body0
+            else:
+                lb, lw = l1 - body0, l1 - body0 + 1
+            rows.append([data[at + 1:h_end].split()[0].decode(), end - body0 - n_nl, body0, lb, lw])
+            at = end
     with open(sf_fasta + ".fai", "w") as f:
         f.write("".join("%s\t%d\t%d\t%d\t%d\n" % tuple(r) for r in rows))

@@ -17,6 +17,7 @@ this build has no aligner: a read is recruited for a gap when it shares at least
 definition of this build (bwa is an unpinned third-party tool, absent here: parity unpinned for this step), checked against
 the oracle's k-mer predicate."""
 import os
+import shutil
 import subprocess
 
 from . import bam_io
@@ -27,15 +28,27 @@ from .hip_api import GapFill
 
 def run_collect_both_unmapped(sf_bam, samtools_path, gf=None):
     sf_both_unmap = sf_bam + ".both_unmapped.sam"
-    with open(sf_both_unmap, "w") as f:
-        if bam_io.is_builtin(samtools_path):      # `samtools view -f 12`: both FLAG bits 4 and 8 set; the 11 mandatory columns
-            for recs, cols in bam_io.decode_file(gf or GapFill(0), sf_bam, []):
+    if bam_io.is_builtin(samtools_path):      # `samtools view -f 12`: both FLAG bits 4 and 8 set; the 11 mandatory columns
+        # the records' bytes come back from the device in one gather per piece of the file; both files are formatted from them in one
+        # host pass (gf_bam_records_text) — the .fq needs no second reading of the .sam
+        import numpy as np
+        from . import textio
+        gf = gf or GapFill(0)
+        with open(sf_both_unmap, "wb") as f, open(sf_bam + ".both_unmapped.fq", "wb") as fout:
+            for recs, cols in bam_io.decode_file(gf, sf_bam, []):
                 both = ((recs["flag"] & 12) == 12).nonzero()[0]
-                cols.prefetch(both)
-                for i in both:
-                    f.write("\t".join(cols[int(i)] + list(cols.seq_qual(int(i)))) + "\n")
-        else:
-            subprocess.run([samtools_path, "view", "-f", "12", sf_bam], check=True, stdout=f)
+                if not len(both):
+                    continue
+                begin = cols.rb[both]
+                end = np.append(cols.rb[1:], np.uint64(cols.end))[both]
+                blob = gf.bam_fetch(begin, end)
+                at = np.concatenate([[0], np.cumsum((end - begin).astype(np.int64))[:-1]]).astype(np.uint64)
+                sam, fq = textio.bam_records_text(blob, at, cols.names, gf.handle)
+                f.write(sam)
+                fout.write(fq)
+        return
+    with open(sf_both_unmap, "w") as f:
+        subprocess.run([samtools_path, "view", "-f", "12", sf_bam], check=True, stdout=f)
     with open(sf_both_unmap) as fin, open(sf_bam + ".both_unmapped.fq", "w") as fout:
         for line in fin:
             fields = line.split()
@@ -56,17 +69,15 @@ def kmer_recruit_unmapped(gf, gap_contigs, names, seqs, k, min_hits=1):
     gaps["idx_in_scaffold"] = np.arange(n_gaps) + 1
     # the contigs of a gap, joined by N (k-mers touching a non-ACGT byte are not indexed), play the role of a flank
     gf.set_gaps(gaps, 1, [("N".join(c), "") for c in gap_contigs])
-    mate = {}
-    for i, nm in enumerate(names):
-        mate[nm] = i
-    by_len = {}
-    for i, s in enumerate(seqs):
-        by_len.setdefault(len(s), []).append(i)
+    mate = dict(zip(names, range(len(names))))                # (a name that occurs twice: its last record, as an assignment loop leaves it)
+    lens = np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs))
     got = [set() for _ in range(n_gaps)]
-    for L, idx in by_len.items():
+    for L in np.unique(lens).tolist():
         if L < k:
             continue
-        packed, nm, _, _ = fastq_io.pack_pools([[seqs[i] for i in idx]])
+        idx = np.nonzero(lens == L)[0].tolist()
+        # one length per group: the sequences back to back are the packer's input as they are
+        packed, nm = GapFill.pack_reads("".join([seqs[i] for i in idx]).encode(), L, with_mask=True)
         for h in gf.screen_reads(packed, L, k, min_hits, n_mask=nm):
             i = idx[int(h["read"])]
             g = int(h["gap"])
@@ -88,21 +99,33 @@ class BothUnmappedReadsCollector:
         wf = self.wf
         for sf_bam in bam_list:
             run_collect_both_unmapped(sf_bam, self.samtools_path, self.gf)
-        with open(wf + "both_unmapped.fq", "w") as fout:                                   # `cat` of the per-BAM files (:197-202)
+        with open(wf + "both_unmapped.fq", "wb") as fout:                                  # `cat` of the per-BAM files (:197-202)
             for sf_bam in bam_list:
-                with open(sf_bam + ".both_unmapped.fq") as f:
-                    fout.write(f.read())
-        self.reads = {}                                                                    # head -> "seq\n+\nqual\n" (:205-220)
+                with open(sf_bam + ".both_unmapped.fq", "rb") as f:
+                    shutil.copyfileobj(f, fout, 16 << 20)
         with open(wf + "both_unmapped.fq") as fin:
             lines = fin.read().split("\n")
-        for i in range(0, len(lines) - 3, 4):
-            self.reads[lines[i].rstrip()[1:]] = "".join(l.rstrip() + "\n" for l in lines[i + 1:i + 4])
+        # head -> "seq\n+\nqual\n" (:205-220), one entry per four lines while three more lines follow; a head seen again keeps its place
+        # and takes the later record (what assigning in a loop does) — built column-wise: a C2-sized run holds 1.6 M of these records
+        n = max(0, (len(lines) - 3 + 3) // 4)
+        self.reads = dict(zip([h.rstrip()[1:] for h in lines[0:4 * n:4]],
+                              [a.rstrip() + "\n" + b.rstrip() + "\n" + c.rstrip() + "\n"
+                               for a, b, c in zip(lines[1:4 * n:4], lines[2:4 * n:4], lines[3:4 * n:4])]))
+        del lines
+        reads = self.reads
         with open(wf + "both_unmapped_1.fq", "w") as f_left, open(wf + "both_unmapped_2.fq", "w") as f_right:
-            for key in self.reads:                                                         # insertion order
+            left, right = [], []
+            for key, rec in reads.items():                                                 # insertion order
                 if key[-1] == "1":
                     read_id = key[:-2]
-                    f_left.write("@" + read_id + "\n" + self.reads[key])
-                    f_right.write("@" + read_id + "\n" + self.reads[read_id + "_2"])       # KeyError if absent, as in the reference
+                    left.append("@" + read_id + "\n" + rec)
+                    right.append("@" + read_id + "\n" + reads[read_id + "_2"])            # KeyError if absent, as in the reference
+                    if len(left) >= 65536:
+                        f_left.write("".join(left))
+                        f_right.write("".join(right))
+                        left, right = [], []
+            f_left.write("".join(left))
+            f_right.write("".join(right))
         self.align_unmapped_to_contigs(id_list)
 
     def align_unmapped_to_contigs(self, fa_list):

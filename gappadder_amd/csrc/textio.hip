@@ -1,0 +1,174 @@
+// textio.hip — host-side text of the reference's FILE contract, for the records that leave the device pipeline (no GPU work here:
+// this is the formatting a run does once per recruited read, which a CPython loop does at a few hundred thousand records per second).
+//   gf_bam_records_text    BAM alignment records -> SAM lines (`samtools view`'s eleven mandatory columns) and the both-unmapped FASTQ
+//                          form of collect_both_unmapped_reads.py:14-33
+//   gf_fastq_records_text  FASTQ records of the input files -> the records as run_multi_threads_discordant.py:212-221 re-writes them
+//                          into the per-gap files
+#include <cstring>
+
+#include "gf_internal.hpp"
+
+namespace gf {
+namespace {
+
+struct Sink {   // counts always, writes while the capacity lasts
+    char* p;
+    size_t cap, len = 0;
+    Sink(char* p_, size_t cap_) : p(p_), cap(p_ ? cap_ : 0) {}
+    void put(const void* s, size_t n) {
+        if (len + n <= cap) memcpy(p + len, s, n);
+        len += n;
+    }
+    void ch(char c) {
+        if (len < cap) p[len] = c;
+        ++len;
+    }
+    void num(long long v) {
+        char b[24];
+        int n = 0;
+        unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) b[n++] = '-';
+        while (n) ch(b[--n]);
+    }
+    char* room(size_t n) {   // n bytes to fill in place, or null when they do not fit (they are counted either way)
+        char* r = len + n <= cap ? p + len : nullptr;
+        len += n;
+        return r;
+    }
+};
+
+inline int32_t le32(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24); }
+inline uint32_t le16(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+inline bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }   // what bytes.split() / bytes.rstrip() take
+int set_error(gf_ctx* ctx, int code, const std::string& what) {
+    if (ctx) ctx->last_error = what;
+    return code;
+}
+
+}  // namespace
+}  // namespace gf
+
+using namespace gf;
+
+extern "C" {
+
+int gf_bam_records_text(gf_ctx* ctx, const uint8_t* blob, size_t blob_len, const uint64_t* rec_begin, size_t n_recs, const char* ref_names, size_t n_ref,
+                        char* sam, size_t sam_cap, size_t* sam_len, char* fq_or_null, size_t fq_cap, size_t* fq_len) {
+    if (!sam_len || !fq_len || (n_recs && (!blob || !rec_begin)) || (n_ref && !ref_names)) return GF_E_INVAL;
+    static const char SEQ_CODES[] = "=ACMGRSVTWYHKDBN", CIGAR_OPS[] = "MIDNSHP=X";
+    std::vector<std::pair<const char*, size_t>> names(n_ref);
+    {
+        const char* p = ref_names;
+        for (size_t i = 0; i < n_ref; ++i) {
+            const size_t l = strlen(p);
+            names[i] = {p, l};
+            p += l + 1;
+        }
+    }
+    Sink S(sam, sam_cap), F(fq_or_null, fq_cap);
+    for (size_t i = 0; i < n_recs; ++i) {
+        const uint64_t o = rec_begin[i];
+        if (o + 36 > blob_len) return set_error(ctx, GF_E_FORMAT, "gf_bam_records_text: record " + std::to_string(i) + " starts beyond the bytes given");
+        const uint8_t* r = blob + o;
+        const int64_t block = le32(r);
+        const int32_t ref = le32(r + 4), pos = le32(r + 8), l_seq = le32(r + 20), mref = le32(r + 24), mpos = le32(r + 28), tlen = le32(r + 32);
+        const uint32_t l_name = r[12], mapq = r[13], n_cig = le16(r + 16), flag = le16(r + 18);
+        const uint64_t need = 36ull + l_name + 4ull * n_cig + (l_seq > 0 ? ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq : 0);
+        if (block < 32 || l_seq < 0 || l_name == 0 || need > (uint64_t)block + 4 || o + 4 + (uint64_t)block > blob_len)
+            return set_error(ctx, GF_E_FORMAT, "gf_bam_records_text: record " + std::to_string(i) + " is not a whole BAM alignment record");
+        if (ref >= (int64_t)n_ref || mref >= (int64_t)n_ref)
+            return set_error(ctx, GF_E_FORMAT, "gf_bam_records_text: record " + std::to_string(i) + " names a reference the header does not hold");
+        const uint8_t* qname = r + 36;
+        const size_t qn = l_name - 1;
+        const uint8_t* cig = qname + l_name;
+        const uint8_t* seq = cig + 4 * n_cig;
+        const uint8_t* qual = seq + ((size_t)l_seq + 1) / 2;
+        S.put(qname, qn); S.ch('\t');
+        S.num(flag); S.ch('\t');
+        if (ref >= 0) S.put(names[ref].first, names[ref].second); else S.ch('*');
+        S.ch('\t'); S.num((long long)pos + 1); S.ch('\t'); S.num(mapq); S.ch('\t');
+        if (n_cig == 0) S.ch('*');
+        for (uint32_t c = 0; c < n_cig; ++c) {
+            const uint32_t v = (uint32_t)le32(cig + 4 * c);
+            if ((v & 15) > 8) return set_error(ctx, GF_E_FORMAT, "gf_bam_records_text: record " + std::to_string(i) + " holds an unknown CIGAR operation");
+            S.num(v >> 4);
+            S.ch(CIGAR_OPS[v & 15]);
+        }
+        S.ch('\t');
+        if (mref < 0) S.ch('*'); else if (mref == ref) S.ch('='); else S.put(names[mref].first, names[mref].second);
+        S.ch('\t'); S.num((long long)mpos + 1); S.ch('\t'); S.num(tlen); S.ch('\t');
+        const size_t sam_seq_at = S.len;
+        if (l_seq == 0) {
+            S.put("*\t*", 3);
+        } else {
+            if (char* d = S.room((size_t)l_seq)) {
+                for (int32_t b = 0; b < l_seq; ++b) d[b] = SEQ_CODES[(seq[b >> 1] >> ((~b & 1) << 2)) & 15];
+            }
+            S.ch('\t');
+            if (qual[0] == 0xFF) S.ch('*');
+            else if (char* d = S.room((size_t)l_seq)) {
+                for (int32_t b = 0; b < l_seq; ++b) d[b] = (char)(qual[b] + 33);
+            }
+        }
+        const size_t sam_end = S.len;
+        S.ch('\n');
+        {   // `@{QNAME}_2` when FLAG > 128 — a comparison, not a bit test (collect_both_unmapped_reads.py:26) — else `_1`
+            F.ch('@'); F.put(qname, qn); F.put(flag > 128 ? "_2\n" : "_1\n", 3);
+            // SEQ, `+`, QUAL: the two columns just written (they are only there when the SAM buffer held them: size first, then fill both)
+            const size_t seq_len = l_seq == 0 ? 1 : (size_t)l_seq, qual_len = sam_end - sam_seq_at - seq_len - 1;
+            if (sam_end <= S.cap) {
+                F.put(sam + sam_seq_at, seq_len); F.put("\n+\n", 3); F.put(sam + sam_seq_at + seq_len + 1, qual_len); F.ch('\n');
+            } else {
+                F.len += seq_len + 3 + qual_len + 1;
+            }
+        }
+    }
+    *sam_len = S.len;
+    *fq_len = F.len;
+    if (S.len > S.cap || (fq_or_null && F.len > F.cap)) return GF_E_NOSPACE;   // (without a FASTQ buffer that form is only sized)
+    return GF_OK;
+}
+
+int gf_fastq_records_text(gf_ctx* ctx, const uint8_t* const* files, const uint64_t* file_len, size_t n_files, const uint64_t* begin, const uint64_t* end,
+                          const uint8_t* which, const char* const* suffix, size_t n, char* out, size_t cap, uint64_t* out_end, char* ids_or_null,
+                          size_t ids_cap, uint64_t* ids_end_or_null, size_t* out_len, size_t* ids_len) {
+    if (!out_len || (n && (!files || !file_len || !begin || !end || !which || !out_end || !suffix))) return GF_E_INVAL;
+    Sink O(out, cap), I(ids_or_null, ids_cap);
+    for (size_t i = 0; i < n; ++i) {
+        if (which[i] >= n_files || begin[i] > end[i] || end[i] > file_len[which[i]]) return GF_E_INVAL;
+        const uint8_t* p = files[which[i]] + begin[i];
+        const uint8_t* const e = files[which[i]] + end[i];
+        const uint8_t* line[4];
+        size_t len[4] = {0, 0, 0, 0};
+        for (int l = 0; l < 4; ++l) {   // (a record cut short has empty lines behind what is there, as in the reference's slice + pad)
+            line[l] = p;
+            const uint8_t* nl = p < e ? (const uint8_t*)memchr(p, '\n', (size_t)(e - p)) : nullptr;
+            len[l] = (size_t)((nl ? nl : e) - p);
+            p = nl ? nl + 1 : e;
+        }
+        // the id: first whitespace-separated word of the header, up to its first '/', without its first character (the '@')
+        const uint8_t* h = line[0];
+        const uint8_t* const he = h + len[0];
+        while (h < he && is_space(*h)) ++h;
+        const uint8_t* t = h;
+        while (t < he && !is_space(*t) && *t != '/') ++t;
+        if (h < t) ++h;
+        for (int l = 1; l < 4; l += 2)
+            while (len[l] && is_space(line[l][len[l] - 1])) --len[l];
+        const size_t sl = strlen(suffix[which[i]]);
+        O.ch('@'); O.put(h, (size_t)(t - h)); O.put(suffix[which[i]], sl); O.ch('\n');
+        O.put(line[1], len[1]); O.put("\n+\n", 3); O.put(line[3], len[3]); O.ch('\n');
+        out_end[i] = O.len;
+        if (ids_end_or_null) {
+            I.put(h, (size_t)(t - h));
+            ids_end_or_null[i] = I.len;
+        }
+    }
+    *out_len = O.len;
+    if (ids_len) *ids_len = I.len;
+    if (O.len > O.cap || (ids_or_null && I.len > I.cap)) return GF_E_NOSPACE;
+    return GF_OK;
+}
+
+}  // extern "C"

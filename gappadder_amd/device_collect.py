@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 from . import _lib as B
+from . import textio
 from . import bam_io
 from . import sam_io
 from .pipeline import CNT_HOP, CNT_ROWS, CNT_SCREEN, CNT_TAG, DeviceLibrary, Pipeline
@@ -402,24 +403,25 @@ class DeviceCollector:
             recs = np.frombuffer(lb.d_recs.view(-1, 4)[torch.from_numpy(hit_recs).to(self.dev)].cpu().numpy().tobytes(), dtype=B.ALNREC) \
                 if len(hit_recs) else np.zeros(0, dtype=B.ALNREC)
             qn = self._fetch_names(lb, hit_recs)
-            at = {int(r): i for i, r in enumerate(hit_recs)}
+            at_th = np.searchsorted(hit_recs, th["rec"].astype(np.int64))       # row of `recs` / `qn` per tagger hit
+            at_lh = np.searchsorted(hit_recs, lh["rec"].astype(np.int64))
             mm = [self._mmap(lb.left), self._mmap(lb.right)]
             self._verify_join(lb, recs, qn, mm[0])
             # -- scaffold lists (collect_reads_for_gaps.py:93-159): a scaffold with gaps gets its pair of files once a record of it was seen
             out = {names[s]: {"left": [], "right": []} for s in range(len(names)) if (lb.seen[s] & 1) and s in with_gaps}
-            for hgt in th:
-                r = recs[at[int(hgt["rec"])]]
-                q = qn[at[int(hgt["rec"])]]
-                g = gaps[hgt["gap"]]
-                own = "left" if int(r["flag"]) & 0x40 else "right"
-                side = ("right" if own == "left" else "left") if hgt["to_mate"] else own
-                if hgt["kind"] == B.KIND_DISCORDANT:
-                    rnext = "*" if r["mate_ref"] == NO_READ else "=" if r["mate_ref"] == r["ref"] else names[int(r["mate_ref"])]
-                    line = "%s %d %d discordant %d %s %d %d" % (q, g["idx_in_scaffold"], r["mapq"], r["pos"], rnext, r["mate_pos"],
-                                                              int(g["end"]) - int(g["start"]))
+            R, G = recs[at_th], gaps[th["gap"]]
+            g_len = (G["end"].astype(np.int64) - G["start"].astype(np.int64)).tolist()
+            for q, flag, ref, pos, mapq, mref, mpos, kind, to_mate, g_idx, gl in zip(
+                    [qn[i] for i in at_th.tolist()], R["flag"].tolist(), R["ref"].tolist(), R["pos"].tolist(), R["mapq"].tolist(),
+                    R["mate_ref"].tolist(), R["mate_pos"].tolist(), th["kind"].tolist(), th["to_mate"].tolist(), G["idx_in_scaffold"].tolist(), g_len):
+                own = "left" if flag & 0x40 else "right"
+                side = ("right" if own == "left" else "left") if to_mate else own
+                if kind == B.KIND_DISCORDANT:
+                    rnext = "*" if mref == NO_READ else "=" if mref == ref else names[mref]
+                    line = "%s %d %d discordant %d %s %d %d" % (q, g_idx, mapq, pos, rnext, mpos, gl)
                 else:
-                    line = "%s %d %d %s" % (q, g["idx_in_scaffold"], r["mapq"], B.KIND_NAMES[int(hgt["kind"])])
-                out[names[int(r["ref"])]][side].append(line)
+                    line = "%s %d %d %s" % (q, g_idx, mapq, B.KIND_NAMES[kind])
+                out[names[ref]][side].append(line)
             open(folder + "cluster_by_gap_reads_left.list", "w").close()
             open(folder + "cluster_by_gap_reads_right.list", "w").close()
             for s, d in out.items():
@@ -437,10 +439,11 @@ class DeviceCollector:
                    if (lb.seen[s] & 2) and os.path.exists(folder + "discordant_temp/" + names[s] + ".list")}
             if len(lh):
                 rr = rows[lh["gap"]]
-                for i in np.lexsort((rr["src_gap"], rr["src_scaffold"], lh["rec"])):
-                    r = recs[at[int(lh["rec"][i])]]
-                    hop[int(rr["mate_scaffold"][i])]["left" if int(r["flag"]) & 0x40 else "right"].append(
-                        "%s %d_%d %d" % (qn[at[int(lh["rec"][i])]], rr["src_scaffold"][i], rr["src_gap"][i], r["mapq"]))
+                order = np.lexsort((rr["src_gap"], rr["src_scaffold"], lh["rec"]))
+                R = recs[at_lh[order]]
+                for q, flag, mapq, ms, ss, sg in zip([qn[i] for i in at_lh[order].tolist()], R["flag"].tolist(), R["mapq"].tolist(),
+                                                     rr["mate_scaffold"][order].tolist(), rr["src_scaffold"][order].tolist(), rr["src_gap"][order].tolist()):
+                    hop[ms]["left" if flag & 0x40 else "right"].append("%s %d_%d %d" % (q, ss, sg, mapq))
             for s, d in hop.items():
                 for side in ("left", "right"):
                     with open(folder + "discordant_reads_list/%s_cluster_by_discordant_reads_%s.list" % (names[s], side), "w") as f:
@@ -459,8 +462,8 @@ class DeviceCollector:
             ids = lb.d_ids[:int(off[-1])].cpu().numpy().astype(np.int64)
             self._write_pool_fastq(lb, folder + "gap_reads/", keys, off, ids, mm, merged["gap_reads"])
             # -- high-quality subset: the scaffold-list lines with MAPQ == 60, no second hop (run_multi_threads_discordant.py:476, 548)
-            rd = recs["read"][[at[int(x)] for x in th["rec"]]].astype(np.int64) if len(th) else np.zeros(0, dtype=np.int64)
-            mq = recs["mapq"][[at[int(x)] for x in th["rec"]]] if len(th) else np.zeros(0, dtype=np.uint8)
+            rd = recs["read"][at_th].astype(np.int64) if len(th) else np.zeros(0, dtype=np.int64)
+            mq = recs["mapq"][at_th] if len(th) else np.zeros(0, dtype=np.uint8)
             ok = (mq == 60) & ((rd & 0xFFFFFFFF) != NO_READ)
             tgt = (rd[ok] & 0xFFFFFFFF) ^ th["to_mate"][ok].astype(np.int64)
             hq = np.unique(np.stack([th["gap"][ok].astype(np.int64), tgt & 1, tgt >> 1], axis=1), axis=0) if ok.any() else np.zeros((0, 3), dtype=np.int64)
@@ -488,7 +491,8 @@ class DeviceCollector:
     @staticmethod
     def _record(mm, b, e, suffix):
         """One FASTQ record as the reference re-writes it (run_multi_threads_discordant.py:212-221): `@{id}{suffix}`, the sequence,
-        a bare `+`, the qualities; (id, text)."""
+        a bare `+`, the qualities; (id, text).  The definition of what gf_fastq_records_text does for many records at once
+        (tests/test_textio_host.py compares the two); the run itself goes through that call."""
         h, s, _, q = (mm[b:e].split(b"\n") + [b"", b"", b""])[:4]
         f = h.split()
         rid = f[0].split(b"/")[0][1:].rstrip() if f else b""
@@ -506,11 +510,16 @@ class DeviceCollector:
         if not len(have):
             return
         b, e = self._offsets(lb, 0, rd[have] >> 1)
-        for i, b_, e_ in zip(have, b, e):
-            rid, _ = self._record(mm_left, int(b_), int(e_), b"")
-            if rid.decode() != qn[i]:
+        _, _, ids, ids_end = textio.fastq_records_text([mm_left], b, e, np.zeros(len(b), dtype=np.uint8), (b"",), want_ids=True, handle=self.h)
+        want = [qn[i].encode() for i in have.tolist()]
+        if ids.tobytes() == b"".join(want) and np.array_equal(ids_end.astype(np.int64), np.cumsum([len(w) for w in want])):
+            return
+        ids, at = ids.tobytes(), 0
+        for i, z in zip(have.tolist(), ids_end.tolist()):
+            if ids[at:z] != qn[i].encode():
                 raise RuntimeError("read-name join: alignment record %r was joined to FASTQ record %r of %s (64-bit hash collision)"
-                                   % (qn[i], rid.decode(), lb.left))
+                                   % (qn[i], ids[at:z].decode(), lb.left))
+            at = z
 
     def _screen_hit_map(self, lb, keys, mm):
         """k-mer-screen recruits (parameters.kmer_screen) as {readId: {gapKey: 1}}, for left_reads.list / right_reads.list (kmer_recruit.py)."""
@@ -522,7 +531,10 @@ class DeviceCollector:
         pair_of = hits["read"].astype(np.int64) >> 1
         pairs, inv = np.unique(pair_of, return_inverse=True)
         b, e = self._offsets(lb, 0, pairs)
-        rids = [self._record(mm[0], int(b_), int(e_), b"")[0].decode() for b_, e_ in zip(b, e)]
+        _, _, ids, ids_end = textio.fastq_records_text([mm[0]], b, e, np.zeros(len(b), dtype=np.uint8), (b"",), want_ids=True, handle=self.h)
+        ids = ids.tobytes().decode()
+        ends = ids_end.tolist()
+        rids = [ids[a:z] for a, z in zip([0] + ends[:-1], ends)]
         out = {}
         for i, g in zip(inv.tolist(), hits["gap"].tolist()):
             out.setdefault(rids[i], {})[keys[g]] = 1
@@ -541,11 +553,13 @@ class DeviceCollector:
             sel = np.nonzero(mate == m_)[0]
             if len(sel):
                 b[sel], e[sel] = self._offsets(lb, m_, ids[sel] >> 1)
-        suffix = (b"_1", b"_2")
+        # every pooled record re-written in one host pass (gf_fastq_records_text); a gap's file is a slice of that text
+        text, text_end = textio.fastq_records_text(mm, b, e, mate.astype(np.uint8), (b"_1", b"_2"), handle=self.h)
+        at = np.concatenate([[0], text_end.astype(np.int64)])
         for g in range(len(keys)):
             a, z = int(off[g]), int(off[g + 1])
             if z > a:
-                txt = b"".join(self._record(mm[int(mate[i])], int(b[i]), int(e[i]), suffix[int(mate[i])])[1] for i in range(a, z))
+                txt = text[int(at[a]):int(at[z])].tobytes()
                 with open(d + keys[g] + ".fastq", "wb") as f:
                     f.write(txt)
                 merged[g].append(txt)

@@ -224,6 +224,26 @@ int gf_fetch_slices(gf_ctx* ctx, const void* d_src, size_t src_len, const uint64
 int gf_gather_rows_dev(gf_ctx* ctx, const void* d_src, size_t n_src_rows, size_t row_bytes, const void* d_ids, const void* d_n, size_t cap,
                        void* d_dst);
 
+/* ---- host-side text of the reference's file contract, for the records that leave the device pipeline.  No GPU work: plain C loops
+ * over bytes the caller already holds (a run formats one record per recruited read; the reference does it in its FASTQ line machine,
+ * run_multi_threads_discordant.py:209-241, and through `samtools view`).  ctx may be NULL (it only carries the error text). */
+/* BAM alignment records, raw as in the inflated stream (record i starts at blob[rec_begin[i]] with its block_size field) ->
+ *   sam: the eleven mandatory SAM columns as `samtools view` prints them, one line per record: the builtin stand-in of
+ *        `samtools view -f 12` (collect_both_unmapped_reads.py:14-22)
+ *   fq:  the same records in that module's FASTQ form: `@{QNAME}_2` when FLAG > 128 (a comparison, :26) else `@{QNAME}_1`, SEQ, `+`, QUAL
+ *        (:24-33); NULL: sized only.
+ * ref_names = the header's n_ref reference names, NUL-terminated, back to back.  *sam_len / *fq_len = bytes needed; GF_E_NOSPACE when a
+ * given buffer is smaller (what was written is then incomplete), GF_E_FORMAT for bytes that are no BAM record. */
+int gf_bam_records_text(gf_ctx* ctx_or_null, const uint8_t* blob, size_t blob_len, const uint64_t* rec_begin, size_t n_recs, const char* ref_names,
+                        size_t n_ref, char* sam, size_t sam_cap, size_t* sam_len, char* fq_or_null, size_t fq_cap, size_t* fq_len);
+/* FASTQ records [begin[i], end[i]) of the file image files[which[i]] as the reference re-writes them into the per-gap files
+ * (run_multi_threads_discordant.py:212-221): `@{id}{suffix[which[i]]}` — id = the header's first word up to its first '/', without the
+ * '@' —, the sequence line, a bare `+`, the quality line, trailing white space dropped.  out_end[i] = where record i ends in `out`;
+ * ids_or_null / ids_end_or_null: the bare ids back to back.  *out_len / *ids_len = bytes needed, GF_E_NOSPACE when a buffer is smaller. */
+int gf_fastq_records_text(gf_ctx* ctx_or_null, const uint8_t* const* files, const uint64_t* file_len, size_t n_files, const uint64_t* begin,
+                          const uint64_t* end, const uint8_t* which, const char* const* suffix, size_t n, char* out, size_t cap, uint64_t* out_end,
+                          char* ids_or_null, size_t ids_cap, uint64_t* ids_end_or_null, size_t* out_len, size_t* ids_len);
+
 /* ---- north-star flank-k-mer screen ("flank-k-mer lookup to tag reads") ------------------------------
  * Emits (gap, read) for every read that has >= min_hits k-mer positions whose canonical k-mer occurs in the
  * gap's flank k-mer set (predicate shape of IsReadContainingFreqKmers, KmerUtils.cpp:215-241, on canonical
