@@ -46,11 +46,12 @@ def drop_contained(recs):
     """[(name, seq)] without the contigs that occur exactly, on either strand, inside another one (see the module text)."""
     seqs = [s.upper() for _, s in recs]
     rcs = [revcomp(s) for s in seqs]
-    keep = []
+    keep, kept_text = [], ""      # the kept contigs and their reverse complements, newline-separated: one substring search per candidate
     for i in sorted(range(len(recs)), key=lambda i: (-len(seqs[i]), i)):     # longest first: a contig lies inside one at least as long
         q = seqs[i]
-        if not any(q in seqs[j] or q in rcs[j] for j in keep):
+        if not keep or q not in kept_text:
             keep.append(i)
+            kept_text += "\n" + q + "\n" + rcs[i]
     return [recs[i] for i in sorted(keep)]
 
 

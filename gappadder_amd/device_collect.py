@@ -107,8 +107,10 @@ class DeviceCollector:
         d_text = torch.empty(chunk + slack + 64, dtype=torch.uint8, device=dev)
         n_total, off, carry = 0, 0, 0
         with open(path, "rb", buffering=0) as f:
+            file_at = 0
             while True:
-                got = f.readinto(view[carry:carry + chunk])
+                got = self._read_piece(f.fileno(), view[carry:carry + min(chunk, size - file_at)], file_at)
+                file_at += got
                 total = carry + (got or 0)
                 if total == 0:
                     break
@@ -159,6 +161,36 @@ class DeviceCollector:
         hdr = torch.cat(hdrs + [torch.tensor([size], dtype=torch.int64, device=dev)]) if hdrs else torch.tensor([size], dtype=torch.int64, device=dev)
         cat = lambda xs, dt: torch.cat(xs) if xs else torch.empty(0, dtype=dt, device=dev)
         return n_total, cat(packed, torch.uint8), cat(masks, torch.int32), cat(hashes, torch.int64), hdr
+
+    def _read_piece(self, fd, dst, file_at):
+        """The next len(dst) bytes of the file into the pinned buffer, read by a few threads at once (preadv releases the interpreter
+        lock; one thread copies out of the page cache at a fraction of what the memory system and the PCIe link behind it take)."""
+        n = len(dst)
+        n_thr = int(os.environ.get("GF_INGEST_READ_THREADS", "4"))
+        if n_thr <= 1 or n < (8 << 20):
+            parts = [(0, n)]
+        else:
+            step = -(-n // n_thr) + 4095 & ~4095
+            parts = [(a, min(n, a + step)) for a in range(0, n, step)]
+
+        def read(a, z):
+            at = a
+            while at < z:
+                r = os.preadv(fd, [dst[at:z]], file_at + at)
+                if r <= 0:
+                    break
+                at += r
+            return at - a
+        if len(parts) == 1:
+            return read(0, n)
+        if getattr(self, "_readers", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._readers = ThreadPoolExecutor(n_thr)
+        got = list(self._readers.map(lambda p: read(*p), parts))
+        for (a, z), g in zip(parts, got):       # a short part (the file shrank under us) ends the piece there
+            if g < z - a:
+                return a + g
+        return n
 
     def _pinned(self, n):
         if getattr(self, "_pin", None) is None or self._pin.numel() < n:
