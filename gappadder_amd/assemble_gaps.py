@@ -113,6 +113,118 @@ def _clipped_at(read, i, contig, j, seed_len, budget=2):
     return left > budget or right > budget
 
 
+MAX_SEED_OCC = 8       # occurrences of a seed kept per contig and strand: a seed repeated inside a contig makes every placement a candidate
+
+
+def _placements_by_lookup(strands, reads, seed_len):
+    """The definition: {read index: {contig: {(strand, contig offset of the read's first base): (i, j) of the FIRST seed found there}}}
+    — every window of every read looked up among the windows of every contig strand (at most MAX_SEED_OCC occurrences per contig
+    and strand, in offset order)."""
+    seeds = {}
+    for sid, strand in enumerate(strands):
+        seen_here = {}
+        for j in range(len(strand) - seed_len + 1):
+            w = strand[j:j + seed_len]
+            n_here = seen_here.get(w, 0)
+            if n_here < MAX_SEED_OCC:
+                seen_here[w] = n_here + 1
+                seeds.setdefault(w, []).append((sid, j))
+    out = {}
+    for r, su in enumerate(reads):
+        placed = {}
+        for i in range(len(su) - seed_len + 1):
+            for sid, j in seeds.get(su[i:i + seed_len], ()):
+                placed.setdefault(sid >> 1, {}).setdefault((sid & 1, j - i), (i, j))
+        if placed:
+            out[r] = placed
+    return out
+
+
+_CODE = None
+
+
+def _windows60(texts, seed_len):
+    """All seed_len-base windows (seed_len <= 32) of the ACGT strings `texts`, 2 bits per base: (value u64, text index, offset)."""
+    import numpy as np
+    global _CODE
+    if _CODE is None:
+        _CODE = np.zeros(256, dtype=np.uint64)
+        for c, v in zip(b"ACGT", range(4)):
+            _CODE[c] = v
+    lens = np.fromiter(map(len, texts), dtype=np.int64, count=len(texts))
+    flat = _CODE[np.frombuffer("".join(texts).encode(), dtype=np.uint8)]
+    n = len(flat) - seed_len + 1
+    if n <= 0:
+        z = np.zeros(0, dtype=np.int64)
+        return np.zeros(0, dtype=np.uint64), z, z
+    val = np.zeros(n, dtype=np.uint64)
+    for t in range(seed_len):                     # (thirty shifted adds over the whole gap's text: no per-window work in the interpreter)
+        val = (val << np.uint64(2)) | flat[t:t + n]
+    start = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    owner = np.repeat(np.arange(len(texts)), lens)[:n]
+    off = np.arange(n) - start[owner]
+    ok = off + seed_len <= lens[owner]            # windows that run into the next text are none
+    return val[ok], owner[ok], off[ok]
+
+
+def _placements_by_sort(strands, reads, seed_len):
+    """_placements_by_lookup for ACGT-only texts: the windows as 2-bit values, joined by sorting."""
+    import numpy as np
+    cv, cs, cj = _windows60(strands, seed_len)
+    rv, rr, ri = _windows60(reads, seed_len)
+    if not len(cv) or not len(rv):
+        return {}
+    # at most MAX_SEED_OCC occurrences per (strand, value), lowest offsets first
+    o = np.lexsort((cj, cv, cs))
+    cv, cs, cj = cv[o], cs[o], cj[o]
+    first = np.ones(len(cv), dtype=bool)
+    first[1:] = (cv[1:] != cv[:-1]) | (cs[1:] != cs[:-1])
+    grp_start = np.maximum.accumulate(np.where(first, np.arange(len(cv)), 0))
+    keep = np.arange(len(cv)) - grp_start < MAX_SEED_OCC
+    cv, cs, cj = cv[keep], cs[keep], cj[keep]
+    o = np.argsort(cv, kind="stable")
+    cv, cs, cj = cv[o], cs[o], cj[o]
+    lo, hi = np.searchsorted(cv, rv, "left"), np.searchsorted(cv, rv, "right")
+    cnt = hi - lo
+    if not cnt.any():
+        return {}
+    w = np.repeat(np.arange(len(rv)), cnt)                       # read window of every (window, occurrence) pair
+    e = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt) + np.repeat(lo, cnt)
+    r, i, sid, j = rr[w], ri[w], cs[e], cj[e]
+    diag = j - i
+    o = np.lexsort((i, diag, sid, r))                            # per (read, strand, diagonal) the lowest read offset first
+    r, i, sid, j, diag = r[o], i[o], sid[o], j[o], diag[o]
+    head = np.ones(len(r), dtype=bool)
+    head[1:] = (r[1:] != r[:-1]) | (sid[1:] != sid[:-1]) | (diag[1:] != diag[:-1])
+    out = {}
+    for r_, i_, sid_, j_ in zip(r[head].tolist(), i[head].tolist(), sid[head].tolist(), j[head].tolist()):
+        out.setdefault(r_, {}).setdefault(sid_ >> 1, {})[(sid_ & 1, j_ - i_)] = (i_, j_)
+    return out
+
+
+def bridging_reads(contigs, reads, seed_len=30):
+    """contigs: [(name, SEQUENCE)]; reads: {id: sequence} -> [(id, sequence)] of the reads that align CLIPPED to at least two contigs
+    (see GapAssembler.collect_high_quality_unmap_to_contigs_reads), in the order of `reads`."""
+    from .pick_contigs import revcomp
+    strands = []
+    for _, s in contigs:
+        strands += [s, revcomp(s)]
+    items = list(reads.items())
+    ups = [seq.upper() for _, seq in items]
+    plain = seed_len <= 32 and not (set("".join(strands)) | set("".join(ups))) - set("ACGT")
+    placements = (_placements_by_sort if plain else _placements_by_lookup)(strands, ups, seed_len)
+    bridges = []
+    for r, placed in sorted(placements.items()):
+        su = ups[r]
+        # clipped at a contig = it shares a seed with it and NO candidate placement aligns end to end (bwa reports the
+        # best alignment: a read that fits somewhere in the contig is no bridge, whatever its other seed hits look like)
+        clipped = [ci for ci, pl in placed.items()
+                   if all(_clipped_at(su, i, strands[2 * ci + st], j, seed_len) for (st, _), (i, j) in pl.items())]
+        if len(clipped) >= 2:                                                             # clipped at two contigs at least (:213)
+            bridges.append(items[r])
+    return bridges
+
+
 class GapAssembler:
     def __init__(self, sf_fai, sf_pos, n_jobs, working_space, kmer_list=None, gf=None, bam_list=None, samtools_path=None):
         global kmer_len_list, working_folder, _gf
@@ -184,33 +296,7 @@ class GapAssembler:
                     f.readline()
                     f.readline()
                     reads.setdefault(h[1:].split()[0], seq)
-            seeds = {}                                                                    # seed -> its occurrences (contig, strand, offset), at most MAX_OCC per contig and strand
-            strands = []
-            MAX_OCC = 8
-            for ci, (_, s) in enumerate(contigs):
-                for st, strand in enumerate((s, revcomp(s))):
-                    strands.append(strand)
-                    seen_here = {}
-                    for i in range(len(strand) - seed_len + 1):
-                        w = strand[i:i + seed_len]
-                        n_here = seen_here.get(w, 0)
-                        if n_here < MAX_OCC:          # a seed repeated inside a contig: every placement is a candidate
-                            seen_here[w] = n_here + 1
-                            seeds.setdefault(w, []).append((ci, st, i))
-            bridges = []
-            for rid, seq in reads.items():
-                su = seq.upper()
-                placed = {}                                                               # contig -> {(strand, start of the read): clipped?}
-                for i in range(len(su) - seed_len + 1):
-                    for ci, st, j in seeds.get(su[i:i + seed_len], ()):
-                        key = (st, j - i)
-                        if key not in placed.setdefault(ci, {}):
-                            placed[ci][key] = _clipped_at(su, i, strands[2 * ci + st], j, seed_len)
-                # clipped at a contig = it shares a seed with it and NO candidate placement aligns end to end (bwa reports the
-                # best alignment: a read that fits somewhere in the contig is no bridge, whatever its other seed hits look like)
-                clipped = [ci for ci, pl in placed.items() if all(pl.values())]
-                if len(clipped) >= 2:                                                     # clipped at two contigs at least (:213)
-                    bridges.append((rid, seq))
+            bridges = bridging_reads(contigs, reads, seed_len)
             if os.path.exists(d + "original_contigs_before_merging.fa"):                  # (:206-210)
                 os.replace(d + "original_contigs_before_merging.fa", d + "contigs.fa")
             with open(d + "contigs.fa", "a") as f:

@@ -98,6 +98,7 @@ struct BamAppend {
     unsigned long long* name_off;    // [rec] = offset into the arena (absolute), or null
     uint64_t name_base;
     uint32_t* ref_seen;              // per scaffold: |1 a record, |2 a MAPQ-0 record; or null
+    unsigned long long* rec_begin;   // per record of THIS chunk: offset of its block_size field in the inflated stream; or null
     uint32_t n_scaffolds;
 };
 
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void bam_append_kernel(BamStream2 B, uint64_t 
             A.qhash[idx] = name_hash_final(h);
         }
         if (A.name_off) A.name_off[idx] = A.name_base + noff;
+        if (A.rec_begin) A.rec_begin[idx] = o;
         if (A.names)
             for (uint32_t i = 0; i < nl; ++i) A.names[noff + i] = r[36 + i];
         noff += nl;
@@ -244,7 +246,7 @@ int gf_fastq_index_dev(gf_ctx* ctx, const void* d_text, size_t n_bytes, const vo
 
 int gf_bam_append_dev(gf_ctx* ctx, size_t n_bytes, size_t first, const uint32_t* ref_map, size_t n_ref, void* d_recs, size_t rec_base, size_t rec_cap,
                       void* d_qhash_or_null, void* d_names_or_null, size_t name_base, size_t name_cap, void* d_name_off_or_null,
-                      void* d_ref_seen_or_null, size_t n_scaffolds, size_t* n_recs, size_t* n_name_bytes, size_t* n_consumed) {
+                      void* d_ref_seen_or_null, size_t n_scaffolds, void* d_rec_begin_or_null, size_t* n_recs, size_t* n_name_bytes, size_t* n_consumed) {
     if (!ctx || !n_recs || !n_name_bytes || !n_consumed || !d_recs || (n_ref && !ref_map) || first > n_bytes || n_ref > 0x7FFFFFFF || rec_base > rec_cap)
         return GF_E_INVAL;
     *n_recs = 0;
@@ -285,6 +287,7 @@ int gf_bam_append_dev(gf_ctx* ctx, size_t n_bytes, size_t first, const uint32_t*
     A.name_off = d_name_off_or_null ? (unsigned long long*)d_name_off_or_null + rec_base : nullptr;
     A.name_base = name_base;
     A.ref_seen = (uint32_t*)d_ref_seen_or_null;
+    A.rec_begin = (unsigned long long*)d_rec_begin_or_null;
     A.n_scaffolds = (uint32_t)n_scaffolds;
     {
         LaunchTimer tm(ctx, GF_KERNEL_INGEST);

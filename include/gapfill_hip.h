@@ -205,12 +205,16 @@ int gf_fastq_index_dev(gf_ctx* ctx, const void* d_text, size_t n_bytes, const vo
  *                    offset of each (d_name_off[rec_base + n] = end of the last), or NULL: the host later fetches the names of the few
  *                    records that produce a hit (gf_fetch_slices) for the list files of the reference's file contract;
  *   d_ref_seen[scaffold] |= 1 for a record on that scaffold, |= 2 for a MAPQ-0 record (u32 per .fai scaffold, caller zeroes), or NULL:
- *                    which per-scaffold list files the reference would have opened (collect_reads_for_gaps.py:93-102).
+ *                    which per-scaffold list files the reference would have opened (collect_reads_for_gaps.py:93-102);
+ *   d_rec_begin[n]   for the n-th record of THIS chunk (not offset by rec_base; room for n_bytes / 36 + 1 entries) the offset of its
+ *                    block_size field in the inflated stream, or NULL: with the FLAGs in d_recs the caller selects records (e.g. both
+ *                    mates unmapped) and fetches their bytes while the stream is still there (gf_bam_fetch).
  * gf_alnrec.read is left 0xFFFFFFFF ("no read") until gf_read_join_dev.  *n_recs / *n_name_bytes = what the chunk holds; GF_E_NOSPACE
  * (nothing written) when a capacity is too small: grow and call again, the stream is still there. */
 int gf_bam_append_dev(gf_ctx* ctx, size_t n_bytes, size_t first, const uint32_t* ref_map, size_t n_ref, void* d_recs, size_t rec_base, size_t rec_cap,
                       void* d_qhash_or_null, void* d_names_or_null, size_t name_base, size_t name_cap, void* d_name_off_or_null,
-                      void* d_ref_seen_or_null, size_t n_scaffolds, size_t* n_recs, size_t* n_name_bytes, size_t* n_consumed);
+                      void* d_ref_seen_or_null, size_t n_scaffolds, void* d_rec_begin_or_null, size_t* n_recs, size_t* n_name_bytes,
+                      size_t* n_consumed);
 /* the join: gf_alnrec.read = 2 * (number of the FASTQ record whose id hash equals the record's QNAME hash) + (FLAG & 0x40 ? 0 : 1), or
  * 0xFFFFFFFF when there is none (such a record recruits nothing).  d_id_hash = the ids of ONE mate file (both files of a pair carry the
  * same ids in the same order: the caller checks that).  d_stats (u32[4], written): [0] ids that occur more than once, [1] records

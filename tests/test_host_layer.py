@@ -450,3 +450,40 @@ def test_a_read_that_fits_at_a_second_occurrence_of_its_seed_is_no_bridge(tmp_pa
     assert ga.collect_high_quality_unmap_to_contigs_reads(["0_1"]) == 2
     got = [n for n, _ in read_fasta(wf + "velvet_temp/0_1/contigs.fa")]
     assert got == ["m1", "m2", "m3", "real_bridge", "rep_and_m3"]
+
+
+def test_bridging_read_placements_by_sorting_equal_the_window_lookup():
+    """assemble_gaps._placements_by_sort (2-bit window values joined by sorting: the form a run uses for ACGT-only texts) against
+    _placements_by_lookup (every read window looked up among the contig windows: the definition) — repeats beyond the occurrence cap,
+    reads shorter than a seed, both strands, several contigs."""
+    import random
+    from gappadder_amd import assemble_gaps as A
+    from gappadder_amd.pick_contigs import revcomp
+    rng = random.Random(31)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    n_placed = 0
+    for it in range(120):
+        seed_len = rng.choice([6, 30, 32])
+        genome = rnd(rng.randint(100, 500))
+        if it % 3 == 0:
+            genome = genome[:40] + rnd(rng.randint(8, 40)) * rng.randint(2, 12) + genome[40:]
+        strands = []
+        for _ in range(rng.randint(0, 4)):
+            a = rng.randint(0, len(genome) - 20)
+            s = genome[a:a + rng.randint(10, 250)]
+            strands += [s, revcomp(s)]
+        reads = []
+        for _ in range(rng.randint(0, 25)):
+            a = rng.randint(0, len(genome) - 10)
+            s = list(genome[a:a + rng.randint(3, 100)])
+            for _ in range(rng.choice([0, 0, 1, 4])):
+                s[rng.randrange(len(s))] = rng.choice("ACGT")
+            reads.append("".join(s) if rng.random() < 0.5 else revcomp("".join(s)))
+        want = A._placements_by_lookup(strands, reads, seed_len)
+        assert A._placements_by_sort(strands, reads, seed_len) == want
+        n_placed += sum(len(pl) for p in want.values() for pl in p.values())
+    assert n_placed > 1000
+    # a text with a letter beyond ACGT takes the lookup (N equals N there)
+    contigs = [("a", "ACGTNACGTTGCA" * 3), ("b", "TTGACNCATGAC" * 3)]
+    reads = {"r1": "GTNACGTTGCAACGTNACG", "r2": "ACNCATGACTTGACNC"}
+    assert A.bridging_reads(contigs, reads, 8) == []
