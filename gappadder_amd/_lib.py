@@ -81,7 +81,7 @@ def lib():
         "gf_bam_pack": (i32, [vp, vp, sz, sz, vp, sz, vp, sz, vp, szp, szp]),
         "gf_fastq_pack_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp, vp, vp]),
         "gf_fastq_index_dev": (i32, [vp, vp, sz, vp, sz, vp, vp]),
-        "gf_bam_append_dev": (i32, [vp, sz, sz, vp, sz, vp, sz, sz, vp, vp, sz, sz, vp, vp, sz, szp, szp, szp]),
+        "gf_bam_append_dev": (i32, [vp, sz, sz, vp, sz, vp, sz, sz, vp, vp, sz, sz, vp, vp, sz, vp, szp, szp, szp]),
         "gf_read_join_dev": (i32, [vp, vp, sz, vp, vp, sz, vp]),
         "gf_fetch_slices": (i32, [vp, vp, sz, vp, vp, sz, vp, sz, szp]),
         "gf_gather_rows_dev": (i32, [vp, vp, sz, sz, vp, vp, sz, vp]),

@@ -26,9 +26,15 @@ from .gnrt_pos_true_seqs import read_fasta
 from .hip_api import GapFill
 
 
+PREPARED = set()      # BAM paths whose .both_unmapped.sam / .fq this process wrote already, on its one pass over the file (device_collect.py)
+
+
 def run_collect_both_unmapped(sf_bam, samtools_path, gf=None):
     sf_both_unmap = sf_bam + ".both_unmapped.sam"
     if bam_io.is_builtin(samtools_path):      # `samtools view -f 12`: both FLAG bits 4 and 8 set; the 11 mandatory columns
+        if os.path.abspath(sf_bam) in PREPARED and os.path.exists(sf_both_unmap) and os.path.exists(sf_bam + ".both_unmapped.fq"):
+            PREPARED.discard(os.path.abspath(sf_bam))
+            return
         # the records' bytes come back from the device in one gather per piece of the file; both files are formatted from them in one
         # host pass (gf_bam_records_text) — the .fq needs no second reading of the .sam
         import numpy as np

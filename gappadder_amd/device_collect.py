@@ -221,7 +221,52 @@ class DeviceCollector:
         return nl, d_reads, d_nmask, hl, hdr_l, hdr_r
 
     # ---- BAM -> resident records + QNAME hashes + QNAME arena --------------------------------------------------------------
-    def _ingest_bam(self, path, fai_names):
+    def _ingest_bam(self, path, fai_names, both_unmapped=False):
+        """both_unmapped: the records with both mates unmapped (FLAG bits 4 and 8) are written to `{path}.both_unmapped.sam` / `.fq` on the
+        way — the files collect_both_unmapped_reads.run_collect_both_unmapped makes from a second pass over the BAM; a run that goes on
+        to the assembly rounds (`-c All`) then has them already."""
+        lib, h, dev, gf = self.lib, self.h, self.dev, self.gf
+        f_sam = open(path + ".both_unmapped.sam", "wb") if both_unmapped else None
+        f_fq = open(path + ".both_unmapped.fq", "wb") if both_unmapped else None
+        try:
+            return self._ingest_bam_pieces(path, fai_names, f_sam, f_fq)
+        finally:
+            for f in (f_sam, f_fq):
+                if f is not None:
+                    f.close()
+
+    def _bam_pieces(self, path):
+        """The file in pieces of chunk_bytes, each read by several threads into the pinned buffer behind what the caller left unconsumed of
+        the piece before (the bytes of a BGZF block cut by the piece's end: the caller's `file_carry`, < 64 KiB)."""
+        size = os.path.getsize(path)
+        chunk = max(4096, min(self.chunk_bytes, size))
+        slack = 1 << 17
+        view = memoryview(self._pinned(chunk + slack).numpy())
+        self._bam_left = b""
+        with open(path, "rb", buffering=0) as f:
+            at = 0
+            while at < size:
+                left = self._bam_left
+                if len(left) > slack:
+                    raise ValueError("BGZF block of more than %d bytes in %s" % (slack, path))
+                view[slack - len(left):slack] = left
+                got = self._read_piece(f.fileno(), view[slack:slack + min(chunk, size - at)], at)
+                if got <= 0:
+                    break
+                at += got
+                yield view[slack - len(left):slack + got]
+
+    def _inflate(self, data, rec_carry):
+        """gf_bgzf_inflate of a piece that lies in the pinned buffer (no copy into a bytes object on the way) -> (stream length, bytes consumed);
+        what is not consumed is handed to the next piece."""
+        n, used = C.c_size_t(0), C.c_size_t(0)
+        arr = np.frombuffer(data, dtype=np.uint8)
+        self._chk(self.lib.gf_bgzf_inflate(self.h, C.cast(arr.ctypes.data, C.c_char_p), len(arr), rec_carry, len(rec_carry), None, 0, C.byref(n), C.byref(used)),
+                  "gf_bgzf_inflate")
+        self._bam_left = bytes(data[used.value:])
+        return int(n.value), int(used.value)
+
+    def _ingest_bam_pieces(self, path, fai_names, f_sam, f_fq):
         lib, h, dev, gf = self.lib, self.h, self.dev, self.gf
         index = {n: i for i, n in enumerate(fai_names)}
         size = os.path.getsize(path)
@@ -236,10 +281,9 @@ class DeviceCollector:
         file_carry, rec_carry = b"", b""
         nr, nb, used = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
         torch.cuda.synchronize()
-        for piece in bam_io.read_file_chunks(path, self.chunk_bytes):
-            data = file_carry + bytes(piece)
-            n_stream, consumed_file = gf.bgzf_inflate(data, rec_carry, want_host=False)
-            file_carry = data[consumed_file:]
+        for data in self._bam_pieces(path):     # (a view of the pinned buffer: what the last piece left over + the next bytes of the file)
+            n_stream, consumed_file = self._inflate(data, rec_carry)
+            file_carry = self._bam_left
             first = 0
             if ref_names is None:
                 hdr, want = None, 1 << 16
@@ -254,10 +298,11 @@ class DeviceCollector:
                     continue
                 ref_names, first = hdr
                 ref_map = np.array([index.get(n, bam_io.NO_REF) for n in ref_names], dtype=np.uint32)
+            d_rb = torch.empty(n_stream // 36 + 2, dtype=torch.int64, device=dev) if f_sam is not None else None   # (a record takes 36 bytes at least)
             while True:
                 rc = lib.gf_bam_append_dev(h, n_stream, first, B._p(ref_map), len(ref_map), d_recs.data_ptr(), n_recs, rec_cap, d_qh.data_ptr(),
                                            d_names.data_ptr(), n_name, name_cap, d_noff.data_ptr(), d_seen.data_ptr(), len(fai_names),
-                                           C.byref(nr), C.byref(nb), C.byref(used))
+                                           d_rb.data_ptr() if d_rb is not None else None, C.byref(nr), C.byref(nb), C.byref(used))
                 if rc != B.GF_E_NOSPACE:
                     break
                 if n_recs + nr.value > rec_cap:
@@ -270,6 +315,17 @@ class DeviceCollector:
                     d_names = torch.cat([d_names[:n_name], torch.empty(name_cap - n_name, dtype=torch.uint8, device=dev)])
                 torch.cuda.synchronize()
             self._chk(rc, "gf_bam_append_dev")
+            if d_rb is not None and nr.value:       # `samtools view -f 12` of this piece, while its inflated bytes are still on the device
+                flag = d_recs[4 * n_recs:4 * (n_recs + nr.value)].view(-1, 4)[:, 2] >> 32        # (gf_alnrec: FLAG at byte 20)
+                sel = ((flag & 12) == 12).nonzero().flatten()
+                if sel.numel():
+                    rb = torch.cat([d_rb[:nr.value], torch.tensor([used.value], dtype=torch.int64, device=dev)])
+                    begin, end = rb[sel].cpu().numpy().astype(np.uint64), rb[sel + 1].cpu().numpy().astype(np.uint64)
+                    at = np.concatenate([[0], np.cumsum((end - begin).astype(np.int64))[:-1]]).astype(np.uint64)
+                    sam, fq = textio.bam_records_text(gf.bam_fetch(begin, end), at, ref_names, h)
+                    f_sam.write(sam)
+                    f_fq.write(fq)
+            del d_rb
             n_recs += nr.value
             n_name += nb.value
             rec_carry = gf.bam_fetch([used.value], [n_stream]).tobytes() if used.value < n_stream else b""
@@ -284,7 +340,10 @@ class DeviceCollector:
         n_pairs, d_reads, d_nmask, d_idh, hdr_l, hdr_r = self._ingest_pair(left, right, L)
         self._tick("ingest_fastq", t0)
         t0 = time.perf_counter()
-        n_recs, d_recs, d_qh, d_names, n_name, d_noff, d_seen = self._ingest_bam(bam, fai_names)
+        n_recs, d_recs, d_qh, d_names, n_name, d_noff, d_seen = self._ingest_bam(bam, fai_names, both_unmapped=bool(self.kmers))
+        if self.kmers:
+            from . import collect_both_unmapped_reads
+            collect_both_unmapped_reads.PREPARED.add(os.path.abspath(bam))
         self._tick("ingest_bam", t0)
         t0 = time.perf_counter()
         d_stats = torch.zeros(4, dtype=torch.int32, device=self.dev)

@@ -90,3 +90,29 @@ def test_bench_e2e_extra_at_full_c3_size():
     assert d["reads"] == 5_000_000 and d["gaps"] == 200 and d["picked_seqs"] == 200
     assert d["libraries"][0]["screen_hits"] > 100_000 and d["libraries"][0]["pooled_reads"] > 200_000
     assert set(d["device_collect_s"]) >= {"ingest_fastq", "ingest_bam", "join", "recruit_and_sizing", "pools", "assemble_and_pick", "write_files"}
+
+
+def test_both_unmapped_files_of_the_single_pass_equal_the_second_pass(tmp_path):
+    """`-c All` on the device path writes {bam}.both_unmapped.sam / .fq while the BAM goes by (DeviceCollector._ingest_bam) and the second
+    round takes them as they are; a run of collect_both_unmapped_reads.run_collect_both_unmapped alone — a second decode of the whole
+    file — must write the same bytes, whatever the piece size of the first pass."""
+    from gappadder_amd import collect_both_unmapped_reads as CB
+    from gappadder_amd import main as M
+    from gappadder_amd.hip_api import GapFill
+    cfgp, wf = SF.write_case(str(tmp_path), 20260011, 300_000, 2, 3, 1000, [(300, 30, 40_000)], [(31, 29)], kmer_screen=31)   # gaps that swallow whole pairs
+    bam = os.path.join(str(tmp_path), "data", "lib0.bam")
+    os.environ["GF_INGEST_CHUNK_BYTES"] = str(300_000)        # several pieces
+    try:
+        M.main(["-c", "All", "-g", cfgp])
+    finally:
+        del os.environ["GF_INGEST_CHUNK_BYTES"]
+    first = {ext: open(bam + ".both_unmapped." + ext, "rb").read() for ext in ("sam", "fq")}
+    assert first["sam"].count(b"\n") > 200 and first["fq"].count(b"\n") == 4 * first["sam"].count(b"\n")
+    assert os.path.abspath(bam) not in CB.PREPARED             # the round took the prepared files (and only once)
+    for ext in ("sam", "fq"):
+        os.remove(bam + ".both_unmapped." + ext)
+    CB.run_collect_both_unmapped(bam, "builtin", GapFill(0))
+    for ext in ("sam", "fq"):
+        assert open(bam + ".both_unmapped." + ext, "rb").read() == first[ext]
+    flags = [int(l.split(b"\t")[1]) for l in first["sam"].splitlines()]
+    assert all(f & 12 == 12 for f in flags)

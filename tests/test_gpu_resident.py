@@ -104,6 +104,7 @@ def test_bam_records_append_to_a_resident_array_with_names_and_hashes_and_join_t
     d_noff = torch.zeros(cap + 1, dtype=torch.int64, device="cuda")
     d_names = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
     d_seen = torch.zeros(len(names), dtype=torch.int32, device="cuda")
+    d_rb = torch.zeros(cap + 1, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     nr, nb, used = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
     file_carry, rec_carry, first_done = b"", b"", False
@@ -118,10 +119,14 @@ def test_bam_records_append_to_a_resident_array_with_names_and_hashes_and_join_t
             first_done = True
         # a capacity that is too small is reported, nothing is written
         assert lib.gf_bam_append_dev(gf.handle, n_stream, first, B._p(ref_map), 3, d_recs.data_ptr(), n_total, n_total + 1, d_qh.data_ptr(), d_names.data_ptr(),
-                                     name_total, 1 << 16, d_noff.data_ptr(), d_seen.data_ptr(), 3, C.byref(nr), C.byref(nb), C.byref(used)) == B.GF_E_NOSPACE
+                                     name_total, 1 << 16, d_noff.data_ptr(), d_seen.data_ptr(), 3, None, C.byref(nr), C.byref(nb), C.byref(used)) == B.GF_E_NOSPACE
         assert nr.value > 1
         assert lib.gf_bam_append_dev(gf.handle, n_stream, first, B._p(ref_map), 3, d_recs.data_ptr(), n_total, cap, d_qh.data_ptr(), d_names.data_ptr(),
-                                     name_total, 1 << 16, d_noff.data_ptr(), d_seen.data_ptr(), 3, C.byref(nr), C.byref(nb), C.byref(used)) == 0
+                                     name_total, 1 << 16, d_noff.data_ptr(), d_seen.data_ptr(), 3, d_rb.data_ptr(), C.byref(nr), C.byref(nb), C.byref(used)) == 0
+        # the records' offsets in the inflated stream: each starts with its own block_size, the next one follows it
+        rb = d_rb[:nr.value].cpu().numpy().astype(np.uint64)
+        sizes = np.frombuffer(gf.bam_fetch(rb, rb + np.uint64(4)).tobytes(), dtype="<i4").astype(np.int64)
+        assert rb[0] == first and (rb[1:] == rb[:-1] + np.uint64(4) + sizes[:-1].astype(np.uint64)).all() and int(rb[-1]) + 4 + int(sizes[-1]) == used.value
         n_total += nr.value
         name_total += nb.value
         rec_carry = gf.bam_fetch([used.value], [n_stream]).tobytes() if used.value < n_stream else b""
