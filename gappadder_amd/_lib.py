@@ -86,7 +86,7 @@ def lib():
         "gf_fetch_slices": (i32, [vp, vp, sz, vp, vp, sz, vp, sz, szp]),
         "gf_gather_rows_dev": (i32, [vp, vp, sz, sz, vp, vp, sz, vp]),
         "gf_bam_records_text": (i32, [vp, vp, sz, vp, sz, vp, sz, vp, sz, szp, vp, sz, szp]),
-        "gf_fastq_records_text": (i32, [vp, vp, vp, sz, vp, vp, vp, vp, sz, vp, sz, vp, vp, sz, vp, szp, szp]),
+        "gf_fastq_records_text": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, sz, vp, sz, vp, vp, sz, vp, szp, szp]),
         "gf_screen_reads": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, szp]),
         "gf_screen_reads_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, sz, vp]),
         "gf_tag_alignments": (i32, [vp, vp, sz, i32, i32, i32, i32, vp, sz, szp]),

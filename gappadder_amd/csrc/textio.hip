@@ -4,6 +4,8 @@
 //                          form of collect_both_unmapped_reads.py:14-33
 //   gf_fastq_records_text  FASTQ records of the input files -> the records as run_multi_threads_discordant.py:212-221 re-writes them
 //                          into the per-gap files
+#include <unistd.h>
+
 #include <cstring>
 
 #include "gf_internal.hpp"
@@ -130,15 +132,36 @@ int gf_bam_records_text(gf_ctx* ctx, const uint8_t* blob, size_t blob_len, const
     return GF_OK;
 }
 
-int gf_fastq_records_text(gf_ctx* ctx, const uint8_t* const* files, const uint64_t* file_len, size_t n_files, const uint64_t* begin, const uint64_t* end,
-                          const uint8_t* which, const char* const* suffix, size_t n, char* out, size_t cap, uint64_t* out_end, char* ids_or_null,
-                          size_t ids_cap, uint64_t* ids_end_or_null, size_t* out_len, size_t* ids_len) {
-    if (!out_len || (n && (!files || !file_len || !begin || !end || !which || !out_end || !suffix))) return GF_E_INVAL;
-    Sink O(out, cap), I(ids_or_null, ids_cap);
-    for (size_t i = 0; i < n; ++i) {
+}  // extern "C"
+
+namespace gf {
+namespace {
+
+// records [lo, hi) re-written into O / I; lens[i] / id_lens[i] = bytes of record i (a worker's share of gf_fastq_records_text)
+int fastq_rewrite_range(gf_ctx* ctx, const uint8_t* const* files, const int* fds, const uint64_t* file_len, size_t n_files, const uint64_t* begin,
+                        const uint64_t* end, const uint8_t* which, const char* const* suffix, size_t lo, size_t hi, Sink& O, Sink& I, uint64_t* lens,
+                        uint64_t* id_lens, std::string* err) {
+    std::vector<uint8_t> buf;
+    for (size_t i = lo; i < hi; ++i) {
         if (which[i] >= n_files || begin[i] > end[i] || end[i] > file_len[which[i]]) return GF_E_INVAL;
-        const uint8_t* p = files[which[i]] + begin[i];
-        const uint8_t* const e = files[which[i]] + end[i];
+        const uint8_t* p;
+        const size_t rec_len = (size_t)(end[i] - begin[i]);
+        if (files) {
+            p = files[which[i]] + begin[i];
+        } else {   // one positioned read per record: a few hundred bytes each, no mapping of a file of many gigabytes to build and tear down
+            if (buf.size() < rec_len) buf.resize(rec_len + 256);
+            size_t got = 0;
+            while (got < rec_len) {
+                const ssize_t r = pread(fds[which[i]], buf.data() + got, rec_len - got, (off_t)(begin[i] + got));
+                if (r <= 0) {
+                    *err = "gf_fastq_records_text: record " + std::to_string(i) + " cannot be read from its file";
+                    return GF_E_FORMAT;
+                }
+                got += (size_t)r;
+            }
+            p = buf.data();
+        }
+        const uint8_t* const e = p + rec_len;
         const uint8_t* line[4];
         size_t len[4] = {0, 0, 0, 0};
         for (int l = 0; l < 4; ++l) {   // (a record cut short has empty lines behind what is there, as in the reference's slice + pad)
@@ -156,14 +179,39 @@ int gf_fastq_records_text(gf_ctx* ctx, const uint8_t* const* files, const uint64
         if (h < t) ++h;
         for (int l = 1; l < 4; l += 2)
             while (len[l] && is_space(line[l][len[l] - 1])) --len[l];
-        const size_t sl = strlen(suffix[which[i]]);
+        const size_t sl = strlen(suffix[which[i]]), at = O.len;
         O.ch('@'); O.put(h, (size_t)(t - h)); O.put(suffix[which[i]], sl); O.ch('\n');
         O.put(line[1], len[1]); O.put("\n+\n", 3); O.put(line[3], len[3]); O.ch('\n');
-        out_end[i] = O.len;
-        if (ids_end_or_null) {
+        lens[i] = O.len - at;
+        if (id_lens) {
             I.put(h, (size_t)(t - h));
-            ids_end_or_null[i] = I.len;
+            id_lens[i] = (uint64_t)(t - h);
         }
+    }
+    return GF_OK;
+}
+
+}  // namespace
+}  // namespace gf
+
+extern "C" {
+
+int gf_fastq_records_text(gf_ctx* ctx, const uint8_t* const* files_or_null, const int* fds_or_null, const uint64_t* file_len, size_t n_files,
+                          const uint64_t* begin, const uint64_t* end, const uint8_t* which, const char* const* suffix, size_t n, char* out, size_t cap,
+                          uint64_t* out_end, char* ids_or_null, size_t ids_cap, uint64_t* ids_end_or_null, size_t* out_len, size_t* ids_len) {
+    if (!out_len || (n && ((!files_or_null && !fds_or_null) || !file_len || !begin || !end || !which || !out_end || !suffix))) return GF_E_INVAL;
+    // (one thread: four workers with buffers of their own took as long — the time is the per-record page-cache access, which did not overlap)
+    Sink O(out, cap), I(ids_or_null, ids_cap);
+    std::vector<uint64_t> id_lens(ids_end_or_null ? n : 0);
+    std::string err;
+    const int rc = fastq_rewrite_range(ctx, files_or_null, fds_or_null, file_len, n_files, begin, end, which, suffix, 0, n, O, I, out_end,
+                                       ids_end_or_null ? id_lens.data() : nullptr, &err);
+    if (rc) return err.empty() ? rc : set_error(ctx, rc, err);
+    uint64_t run = 0, id_run = 0;
+    for (size_t i = 0; i < n; ++i) {   // lengths -> ends
+        run += out_end[i];
+        out_end[i] = run;
+        if (ids_end_or_null) { id_run += id_lens[i]; ids_end_or_null[i] = id_run; }
     }
     *out_len = O.len;
     if (ids_len) *ids_len = I.len;

@@ -32,27 +32,36 @@ def bam_records_text(blob, rec_begin, ref_names, handle=None):
 
 
 def fastq_records_text(files, begin, end, which, suffixes, want_ids=False, handle=None):
-    """files: buffers (mmap / bytes / uint8 arrays) of the FASTQ files; record i = files[which[i]][begin[i]:end[i]] -> (text, text_end[n])
-    or (text, text_end, ids, ids_end): the records as the reference re-writes them (`@{id}{suffixes[which[i]]}`, sequence, `+`, qualities),
-    back to back in one uint8 array; record i ends at text_end[i]."""
+    """files: the FASTQ files as buffers (mmap / bytes / uint8 arrays) or as open binary file objects / descriptors (then every record is
+    one positioned read); record i = files[which[i]][begin[i]:end[i]] -> (text, text_end[n]) or (text, text_end, ids, ids_end): the
+    records as the reference re-writes them (`@{id}{suffixes[which[i]]}`, sequence, `+`, qualities), back to back in one uint8 array;
+    record i ends at text_end[i]."""
+    import os
     lib = B.lib()
-    arrs = [np.frombuffer(f, dtype=np.uint8) if not isinstance(f, np.ndarray) else f for f in files]
+    by_fd = all(isinstance(f, int) or hasattr(f, "fileno") and not hasattr(f, "find") for f in files) and len(files) > 0
     n = len(begin)
     begin = np.ascontiguousarray(begin, dtype=np.uint64)
     end = np.ascontiguousarray(end, dtype=np.uint64)
     which = np.ascontiguousarray(which, dtype=np.uint8)
-    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
-    lens = np.array([len(a) for a in arrs], dtype=np.uint64)
-    sfx = (C.c_char_p * len(arrs))(*[bytes(s) for s in suffixes])
+    if by_fd:
+        fds = np.array([f if isinstance(f, int) else f.fileno() for f in files], dtype=np.int32)
+        lens = np.array([os.fstat(int(fd)).st_size for fd in fds], dtype=np.uint64)
+        ptrs = None
+    else:
+        arrs = [np.frombuffer(f, dtype=np.uint8) if not isinstance(f, np.ndarray) else f for f in files]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        lens = np.array([len(a) for a in arrs], dtype=np.uint64)
+        fds = None
+    sfx = (C.c_char_p * len(files))(*[bytes(s) for s in suffixes])
     out_end = np.zeros(max(1, n), dtype=np.uint64)
     ids_end = np.zeros(max(1, n), dtype=np.uint64) if want_ids else None
     n_out, n_ids = C.c_size_t(0), C.c_size_t(0)
-    # sized from the slices: the output of a record is at most its bytes + suffix + 4 (`@`, `+`, line ends of a record cut short)
+    # sized from the slices: the output of a record is at most its bytes + suffix + 6 (`@`, `+`, line ends of a record cut short)
     cap = int((end - begin).sum()) + n * (max(len(s) for s in suffixes) + 8) + 16 if n else 16
     out = np.empty(cap, dtype=np.uint8)
     ids = np.empty(int((end - begin).sum()) + 16 if want_ids else 1, dtype=np.uint8)
-    _chk(lib.gf_fastq_records_text(handle, ptrs, B._p(lens), len(arrs), B._p(begin), B._p(end), B._p(which), sfx, n, B._p(out), len(out), B._p(out_end),
-                                   B._p(ids) if want_ids else None, len(ids) if want_ids else 0, B._p(ids_end) if want_ids else None,
+    _chk(lib.gf_fastq_records_text(handle, ptrs, B._p(fds), B._p(lens), len(files), B._p(begin), B._p(end), B._p(which), sfx, n, B._p(out), len(out),
+                                   B._p(out_end), B._p(ids) if want_ids else None, len(ids) if want_ids else 0, B._p(ids_end) if want_ids else None,
                                    C.byref(n_out), C.byref(n_ids)), "gf_fastq_records_text", handle)
     if want_ids:
         return out[:n_out.value], out_end[:n], ids[:n_ids.value], ids_end[:n]

@@ -240,12 +240,14 @@ int gf_gather_rows_dev(gf_ctx* ctx, const void* d_src, size_t n_src_rows, size_t
  * given buffer is smaller (what was written is then incomplete), GF_E_FORMAT for bytes that are no BAM record. */
 int gf_bam_records_text(gf_ctx* ctx_or_null, const uint8_t* blob, size_t blob_len, const uint64_t* rec_begin, size_t n_recs, const char* ref_names,
                         size_t n_ref, char* sam, size_t sam_cap, size_t* sam_len, char* fq_or_null, size_t fq_cap, size_t* fq_len);
-/* FASTQ records [begin[i], end[i]) of the file image files[which[i]] as the reference re-writes them into the per-gap files
- * (run_multi_threads_discordant.py:212-221): `@{id}{suffix[which[i]]}` — id = the header's first word up to its first '/', without the
- * '@' —, the sequence line, a bare `+`, the quality line, trailing white space dropped.  out_end[i] = where record i ends in `out`;
- * ids_or_null / ids_end_or_null: the bare ids back to back.  *out_len / *ids_len = bytes needed, GF_E_NOSPACE when a buffer is smaller. */
-int gf_fastq_records_text(gf_ctx* ctx_or_null, const uint8_t* const* files, const uint64_t* file_len, size_t n_files, const uint64_t* begin,
-                          const uint64_t* end, const uint8_t* which, const char* const* suffix, size_t n, char* out, size_t cap, uint64_t* out_end,
+/* FASTQ records [begin[i], end[i]) of file which[i] — given as images in memory (files) or, when files is NULL, as open descriptors read
+ * with one pread per record (fds) — as the reference re-writes them into the per-gap files (run_multi_threads_discordant.py:212-221):
+ * `@{id}{suffix[which[i]]}` — id = the header's first word up to its first '/', without the '@' —, the sequence line, a bare `+`, the
+ * quality line, trailing white space dropped.  out_end[i] = where record i ends in `out`; ids_or_null / ids_end_or_null: the bare ids
+ * back to back.  *out_len / *ids_len = bytes needed, GF_E_NOSPACE when a buffer is smaller. */
+int gf_fastq_records_text(gf_ctx* ctx_or_null, const uint8_t* const* files_or_null, const int* fds_or_null, const uint64_t* file_len, size_t n_files,
+                          const uint64_t* begin, const uint64_t* end, const uint8_t* which, const char* const* suffix, size_t n, char* out, size_t cap,
+                          uint64_t* out_end,
                           char* ids_or_null, size_t ids_cap, uint64_t* ids_end_or_null, size_t* out_len, size_t* ids_len);
 
 /* ---- north-star flank-k-mer screen ("flank-k-mer lookup to tag reads") ------------------------------

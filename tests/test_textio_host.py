@@ -65,7 +65,7 @@ def test_bam_records_text_refuses_bytes_that_are_no_record():
         textio.bam_records_text(np.frombuffer(two, dtype=np.uint8), [0], ["a"])
 
 
-def test_fastq_records_text_equals_the_per_record_rewrite():
+def test_fastq_records_text_equals_the_per_record_rewrite(tmp_path):
     rng = random.Random(5)
     files = []
     for m in range(2):
@@ -99,6 +99,16 @@ def test_fastq_records_text_equals_the_per_record_rewrite():
     out, ids = out.tobytes(), ids.tobytes()
     assert out == b"".join(t for _, t in want) and ids == b"".join(r for r, _ in want)
     assert list(out_end) == list(np.cumsum([len(t) for _, t in want])) and list(ids_end) == list(np.cumsum([len(r) for r, _ in want]))
+    # the same records read by position from open files instead of images in memory
+    paths = []
+    for m, f in enumerate(files):
+        paths.append(str(tmp_path / ("m%d.fq" % m)))
+        open(paths[-1], "wb").write(f)
+    with open(paths[0], "rb") as f0, open(paths[1], "rb") as f1:
+        o2, e2, i2, ie2 = textio.fastq_records_text([f0, f1], begin, end, which, suffix, want_ids=True)
+        assert o2.tobytes() == out and i2.tobytes() == ids and list(e2) == list(out_end) and list(ie2) == list(ids_end)
+        with pytest.raises(B.GapFillError):
+            textio.fastq_records_text([f0, f1], [0], [len(files[0]) + 1], [0], suffix)
     out2, end2 = textio.fastq_records_text(files, begin[:3], end[:3], which[:3], suffix)
     assert out2.tobytes() == b"".join(t for _, t in want[:3]) and len(end2) == 3
     out3, end3 = textio.fastq_records_text(files, [], [], [], suffix)
