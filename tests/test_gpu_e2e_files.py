@@ -10,8 +10,10 @@ import synth_files_util as SF
 pytestmark = pytest.mark.gpu
 
 
-def test_cli_on_files_equals_the_device_resident_run(tmp_path):
+@pytest.mark.parametrize("record_reads", ["pread", "mmap"])
+def test_cli_on_files_equals_the_device_resident_run(tmp_path, record_reads, monkeypatch):
     import torch
+    monkeypatch.setenv("GF_RECORD_READS", record_reads)      # how the pooled FASTQ records are fetched from the input files (device_collect._RecordFiles)
     from gappadder_amd import main as M
     from gappadder_amd.hip_api import GapFill
     from gappadder_amd.pipeline import DeviceLibrary, Pipeline
