@@ -174,28 +174,41 @@ def _placements_by_sort(strands, reads, seed_len):
     rv, rr, ri = _windows60(reads, seed_len)
     if not len(cv) or not len(rv):
         return {}
-    # at most MAX_SEED_OCC occurrences per (strand, value), lowest offsets first
-    o = np.lexsort((cj, cv, cs))
+    # at most MAX_SEED_OCC occurrences per (strand, value), lowest offsets first: the windows come in (strand, offset) order, so ONE stable
+    # sort by value leaves every value's entries in that order
+    o = np.argsort(cv, kind="stable")
     cv, cs, cj = cv[o], cs[o], cj[o]
     first = np.ones(len(cv), dtype=bool)
     first[1:] = (cv[1:] != cv[:-1]) | (cs[1:] != cs[:-1])
     grp_start = np.maximum.accumulate(np.where(first, np.arange(len(cv)), 0))
     keep = np.arange(len(cv)) - grp_start < MAX_SEED_OCC
     cv, cs, cj = cv[keep], cs[keep], cj[keep]
-    o = np.argsort(cv, kind="stable")
-    cv, cs, cj = cv[o], cs[o], cj[o]
-    lo, hi = np.searchsorted(cv, rv, "left"), np.searchsorted(cv, rv, "right")
+    # every read window's run of equal contig values: the windows are looked up in sorted order (a binary search that starts where the last
+    # one ended), the run's end comes from the contig side's own run lengths, and both go back to the windows' (read, offset) order
+    run_first = np.ones(len(cv), dtype=bool)
+    run_first[1:] = cv[1:] != cv[:-1]
+    starts = np.flatnonzero(run_first)
+    run_end = np.repeat(np.append(starts[1:], len(cv)), np.diff(np.append(starts, len(cv))))
+    o = np.argsort(rv, kind="stable")
+    lo_s = np.searchsorted(cv, rv[o], "left")
+    at = np.minimum(lo_s, len(cv) - 1)
+    hi_s = np.where((lo_s < len(cv)) & (cv[at] == rv[o]), run_end[at], lo_s)
+    lo, hi = np.empty_like(lo_s), np.empty_like(lo_s)
+    lo[o], hi[o] = lo_s, hi_s
     cnt = hi - lo
     if not cnt.any():
         return {}
     w = np.repeat(np.arange(len(rv)), cnt)                       # read window of every (window, occurrence) pair
     e = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt) + np.repeat(lo, cnt)
     r, i, sid, j = rr[w], ri[w], cs[e], cj[e]
-    diag = j - i
-    o = np.lexsort((i, diag, sid, r))                            # per (read, strand, diagonal) the lowest read offset first
-    r, i, sid, j, diag = r[o], i[o], sid[o], j[o], diag[o]
+    # per (read, strand, diagonal) the lowest read offset: the pairs come in (read, read offset) order, so a stable sort by the
+    # combined key keeps the first seed of every diagonal in front
+    n_sid = len(strands)
+    key = ((r * n_sid + sid).astype(np.uint64) << np.uint64(32)) | (j - i + (1 << 31)).astype(np.uint64)
+    o = np.argsort(key, kind="stable")
+    key, r, i, sid, j = key[o], r[o], i[o], sid[o], j[o]
     head = np.ones(len(r), dtype=bool)
-    head[1:] = (r[1:] != r[:-1]) | (sid[1:] != sid[:-1]) | (diag[1:] != diag[:-1])
+    head[1:] = key[1:] != key[:-1]
     out = {}
     for r_, i_, sid_, j_ in zip(r[head].tolist(), i[head].tolist(), sid[head].tolist(), j[head].tolist()):
         out.setdefault(r_, {}).setdefault(sid_ >> 1, {})[(sid_ & 1, j_ - i_)] = (i_, j_)
@@ -209,6 +222,8 @@ def bridging_reads(contigs, reads, seed_len=30):
     strands = []
     for _, s in contigs:
         strands += [s, revcomp(s)]
+    if len(contigs) < 2:          # (a bridge is clipped at two contigs at least)
+        return []
     items = list(reads.items())
     ups = [seq.upper() for _, seq in items]
     plain = seed_len <= 32 and not (set("".join(strands)) | set("".join(ups))) - set("ACGT")
