@@ -899,18 +899,31 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
                     for (int u = 0; u < PB; ++u)
                         if (i0 + ((u >> 2) * 64 + lane) * 4 + (u & 3) >= n) passm &= ~(1u << u);
                 }
-                if (!__any(passm != 0)) continue;
+                // The passing entries (1.2 % at C4: a dozen per trip, nearly all lanes none or one) leave lane by lane, lowest bit first: one
+                // round per entry of the lane that holds most — two on average — where a ballot per entry SLOT ran sixteen rounds, nine of
+                // them with a taker.  The entry is picked from its sixteen registers by the four bits of its index.
+                for (;;) {
+                    const bool has = passm != 0;
+                    const unsigned long long bal = __ballot(has);
+                    if (!bal) break;
+                    const uint32_t u = has ? (uint32_t)__builtin_ctz(passm) : 0u;
+                    // (bit-field inserts under an all-ones / all-zeros mask: written as `c ? a : b` the compiler makes a dynamically indexed
+                    //  array of it — 128 bytes of scratch memory per lane)
+                    const uint32_t m0 = 0u - (u & 1u), m1 = 0u - ((u >> 1) & 1u), m2 = 0u - ((u >> 2) & 1u), m3 = 0u - ((u >> 3) & 1u);
+                    uint32_t s8[8], s4[4], s2[2];
 #pragma unroll
-                for (int u = 0; u < PB; ++u) {
+                    for (int q = 0; q < 8; ++q) s8[q] = (pr[2 * q + 1] & m0) | (pr[2 * q] & ~m0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s4[q] = (s8[2 * q + 1] & m1) | (s8[2 * q] & ~m1);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) s2[q] = (s4[2 * q + 1] & m2) | (s4[2 * q] & ~m2);
+                    const uint32_t e = (s2[1] & m3) | (s2[0] & ~m3);
                     const uint32_t pos = i0 + ((u >> 2) * 64 + lane) * 4 + (u & 3);
-                    const bool pass = (passm >> u) & 1u;
-                    const unsigned long long bal = __ballot(pass);
-                    if (bal) {
-                        if (pass) pend[pend_n + __popcll(bal & lt)] = ((unsigned long long)w << 56) | ((unsigned long long)pos << 32) | ((pr[u] & 255u) << 24) | (pr[u] >> 8);
-                        pend_n += (uint32_t)__popcll(bal);                    // < 64 + 64 <= PF2_PEND
-                        wave_lds_sync();
-                        if (pend_n >= 64) ask();
-                    }
+                    if (has) pend[pend_n + __popcll(bal & lt)] = ((unsigned long long)w << 56) | ((unsigned long long)pos << 32) | ((e & 255u) << 24) | (e >> 8);
+                    passm &= passm - 1u;
+                    pend_n += (uint32_t)__popcll(bal);                    // < 64 + 64 <= PF2_PEND
+                    wave_lds_sync();
+                    if (pend_n >= 64) ask();
                 }
             }
         }
