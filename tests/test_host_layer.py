@@ -487,3 +487,33 @@ def test_bridging_read_placements_by_sorting_equal_the_window_lookup():
     contigs = [("a", "ACGTNACGTTGCA" * 3), ("b", "TTGACNCATGAC" * 3)]
     reads = {"r1": "GTNACGTTGCAACGTNACG", "r2": "ACNCATGACTTGACNC"}
     assert A.bridging_reads(contigs, reads, 8) == []
+
+
+def test_both_unmapped_dictionary_and_mate_files_follow_the_line_loop(tmp_path, monkeypatch):
+    """collect_both_unmapped_reads builds {head: 'seq\\n+\\nqual\\n'} and the _1 / _2 files column-wise; the reference's line loop
+    (collect_both_unmapped_reads.py:205-236) on the same text — heads that repeat (later record, first position), trailing blanks, a
+    file that ends inside a record — must give the same dictionary, in the same order, and the same two files."""
+    import pytest
+    from gappadder_amd import collect_both_unmapped_reads as CB
+    text = ("@a_1 \nACGT\n+\nIIII\n@a_2\nTTTT \n+x\nJJJJ\n@b_2\nGG\n+\nII\n@b_1\nCC\t\n+\nKK\n"
+            "@a_1\nAAAA\n+\nLLLL\n@c_1\nAC\n+\nII\n@c_2\nGT\n+\nII\n@tail_1\nACG\n+")
+    bam = str(tmp_path / "x.bam")
+    open(bam + ".both_unmapped.fq", "w").write(text)
+    monkeypatch.setattr(CB, "run_collect_both_unmapped", lambda *a, **k: None)
+    monkeypatch.setattr(CB.BothUnmappedReadsCollector, "align_unmapped_to_contigs", lambda self, ids: {})
+    wf = str(tmp_path) + "/"
+    c = CB.BothUnmappedReadsCollector(wf, "builtin", gf=object())
+    c.collect_both_unmapped_reads([bam], [])
+    want = {}
+    lines = text.split("\n")
+    for i in range(0, len(lines) - 3, 4):
+        want[lines[i].rstrip()[1:]] = "".join(l.rstrip() + "\n" for l in lines[i + 1:i + 4])
+    assert list(c.reads.items()) == list(want.items()) and c.reads["a_1"] == "AAAA\n+\nLLLL\n" and "tail_1" not in c.reads
+    left = "".join("@" + k[:-2] + "\n" + v for k, v in want.items() if k[-1] == "1")
+    right = "".join("@" + k[:-2] + "\n" + want[k[:-2] + "_2"] for k in want if k[-1] == "1")
+    assert open(wf + "both_unmapped_1.fq").read() == left and open(wf + "both_unmapped_2.fq").read() == right
+    assert open(wf + "both_unmapped.fq").read() == text
+    # a `_1` record without its `_2`: KeyError, as in the reference
+    open(bam + ".both_unmapped.fq", "w").write("@z_1\nAC\n+\nII\n")
+    with pytest.raises(KeyError):
+        c.collect_both_unmapped_reads([bam], [])
