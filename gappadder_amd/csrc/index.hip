@@ -220,6 +220,7 @@ int build_flank_index(gf_ctx* ctx, int k, FlankIndex** out) {
         uint32_t h = hash_s16_bitmap(key, bl);
         bm[h >> 5] |= 1u << (h & 31);
         bm[h >> 5] |= 1u << hash_s16_bit2(key);   // second bit in the same word (blocked Bloom): kernels may test it too
+        if (bl >= S16_BIT3_MIN_LOG2) bm[h >> 5] |= 1u << hash_s16_bit3(key, bl);   // ... and a third one in the large bitmaps
     }
 
     // coarse copy for the LDS pre-filter: bit c = OR of the level-1 bits h with (h >> (bl - lds_log2)) == c

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void idx_s16_build_kernel(S16Build B) {
             while (atomicCAS(&B.sset[sl], EMPTY32, key) != EMPTY32) sl = (sl + 1) & smask;
             B.sval[sl] = i;
             const uint32_t h = hash_s16_bitmap(key, B.bm_log2);
-            atomicOr(&B.bm[h >> 5], (1u << (h & 31)) | (1u << hash_s16_bit2(key)));   // both bits of the key in one word
+            // both bits of the key in one word (three in the large bitmaps: hash_s16_bit3)
+            atomicOr(&B.bm[h >> 5], (1u << (h & 31)) | (1u << hash_s16_bit2(key)) | (B.bm_log2 >= S16_BIT3_MIN_LOG2 ? 1u << hash_s16_bit3(key, B.bm_log2) : 0u));
             const uint32_t c = h >> (B.bm_log2 - B.lds_log2);
             atomicOr(&B.cbm[c >> 5], 1u << (c & 31));
             if (B.mbm) {

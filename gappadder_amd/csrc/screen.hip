@@ -891,9 +891,13 @@ __global__ __launch_bounds__(1024) void pf4_probe_kernel(Part4Params Q) {
                 uint32_t wd[PB], passm = 0;
 #pragma unroll
                 for (int u = 0; u < PB; ++u) wd[u] = sm[pr[u] >> sh_w];
+                // (the pass is used with bitmaps of 2^27 / 2^28 bits: their keys carry a third bit, kmer_dev.hpp::hash_s16_bit3 — with it a
+                //  third fewer pairs go on to the exact set, whose 128-byte lines were 6.8 of this pass's 17.6 GB at C4)
 #pragma unroll
-                for (int u = 0; u < PB; ++u)
-                    passm |= ((wd[u] >> ((pr[u] >> sh_b1) & 31u)) & (wd[u] >> ((pr[u] >> 8) & 31u)) & 1u) << u;
+                for (int u = 0; u < PB; ++u) {
+                    const uint32_t b1 = (pr[u] >> sh_b1) & 31u, b2 = (pr[u] >> 8) & 31u;
+                    passm |= ((wd[u] >> b1) & (wd[u] >> b2) & (wd[u] >> s16_bit3_of(b1, b2)) & 1u) << u;
+                }
                 if (i0 + PB * 64 > n) {   // the part's last trip: entries behind its end do not count
 #pragma unroll
                     for (int u = 0; u < PB; ++u)
