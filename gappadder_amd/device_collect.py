@@ -252,8 +252,16 @@ class DeviceCollector:
         way — the files collect_both_unmapped_reads.run_collect_both_unmapped makes from a second pass over the BAM; a run that goes on
         to the assembly rounds (`-c All`) then has them already."""
         lib, h, dev, gf = self.lib, self.h, self.dev, self.gf
-        f_sam = open(path + ".both_unmapped.sam", "wb") if both_unmapped else None
-        f_fq = open(path + ".both_unmapped.fq", "wb") if both_unmapped else None
+        f_sam = f_fq = None
+        if both_unmapped:
+            try:
+                f_sam = open(path + ".both_unmapped.sam", "wb")
+                f_fq = open(path + ".both_unmapped.fq", "wb")
+            except OSError:        # the BAM's folder cannot be written: the second round, if it comes to one, reports that itself
+                if f_sam is not None:
+                    f_sam.close()
+                f_sam = f_fq = None
+        self.both_unmapped_written = f_sam is not None
         try:
             return self._ingest_bam_pieces(path, fai_names, f_sam, f_fq)
         finally:
@@ -367,7 +375,7 @@ class DeviceCollector:
         self._tick("ingest_fastq", t0)
         t0 = time.perf_counter()
         n_recs, d_recs, d_qh, d_names, n_name, d_noff, d_seen = self._ingest_bam(bam, fai_names, both_unmapped=bool(self.kmers))
-        if self.kmers:
+        if self.kmers and self.both_unmapped_written:
             from . import collect_both_unmapped_reads
             collect_both_unmapped_reads.PREPARED.add(os.path.abspath(bam))
         self._tick("ingest_bam", t0)
