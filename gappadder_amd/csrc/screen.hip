@@ -548,7 +548,7 @@ constexpr uint32_t PF4_LINE = 32;
 constexpr uint32_t pf4_stage_of(uint32_t G) { return G >= 4 ? 8u : 16u; }   // groups of fill history staged in LDS (what fits beside the lines)
 constexpr size_t pf4_lines_lds_bytes(size_t slice_words, uint32_t G) {
     return ((size_t)PF2_WAVES * slice_words + (size_t)G * PF2_WAVES * PF2_TILES * 64 + 2 * PF2_NB * PF4_LINE + PF2_NB * (pf4_stage_of(G) + 1) +
-            3 * PF2_NB + 2 * PF2_NB + PF2_NB + PF2_NB + 2 * (PF2_NB + (size_t)G * PF2_WAVES * PF2_TILES * 64 / PF4_LINE) + 8) * 4;
+            3 * PF2_NB + 2 * PF2_NB + 4 * PF2_NB + 2 * (PF2_NB + (size_t)G * PF2_WAVES * PF2_TILES * 64 / PF4_LINE) + 8) * 4;
 }
 template <int LO, int HI>
 __device__ __forceinline__ void vm_wait_range(uint32_t n) {   // s_waitcnt vmcnt(clamp(n, LO, HI)), n wave-uniform: the count is an immediate
@@ -574,8 +574,8 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
     uint32_t* stage = carry + 2 * PF2_NB * LN;
     uint32_t* hist3 = stage + PF2_NB * (ST + 1);
     uint32_t* written2 = hist3 + 3 * PF2_NB;   // generated so far (<= cap) | open line's carry buffer << 31
-    uint32_t* desc = written2 + 2 * PF2_NB;    // per bucket TWO words: c | sel << 5 | part runs full << 7 | (total & ~31) << 8, and where the bucket's whole lines start in `sent`
-    uint32_t* lga = desc + 2 * PF2_NB;             // lines that leave in this group: line index in `pairs` — [0, 256): completed open lines; behind: the lines of `sent`
+    uint32_t* desc = written2 + 2 * PF2_NB;    // per bucket FOUR words, see the bucket-word phase: where a pair of the group goes is base + its position, base one of three
+    uint32_t* lga = desc + 4 * PF2_NB;             // lines that leave in this group: line index in `pairs` — [0, 256): completed open lines; behind: the lines of `sent`
     uint32_t* lsrc = lga + NLINE;              // ... and where the line stands in LDS (word index from `sent`)
     uint32_t* cnt = lsrc + NLINE;              // [g & 1] completed open lines, [2 + (g & 1)] words of `sent` taken
     const uint32_t writer = blockIdx.x;
@@ -662,12 +662,17 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
             const bool done = total >= LN;
             stage[i * (ST + 1) + (g % ST)] = t_old;
             written2[(wsel ^ 1u) * PF2_NB + i] = (t_old + ne) | ((sel ^ (done ? 1u : 0u)) << 31);
-            // (both words of a bucket leave and are fetched as ONE 8-byte LDS access: an instruction fewer per pair in the placement, and 8-byte
-            //  accesses spread over 64 banks)
-            uint2 dv;
-            dv.x = c | (sel << 5) | ((n_new > ne ? 1u : 0u) << 7) | (full << 8);
-            dv.y = full > LN ? atomicAdd(&cnt[2 + (g & 1u)], full - LN) : 0u;    // whole lines between the open line and the tail
-            reinterpret_cast<uint2*>(desc)[i] = dv;
+            // A pair with position p_rel = c + rank goes to word base + p_rel of `sent`, base one of three by where p_rel lies (the
+            // placement picks it with two compares): the open line (p_rel < 32), the whole lines between (< full; they start at `of`), the
+            // tail = head of the next open line.  The four words leave and are fetched as ONE 16-byte LDS access; the fourth holds
+            // c | full / 32 << 5 | the pairs that fit the part << 14 (a rank beyond it: the part is full, the pair is tested on the spot).
+            const uint32_t of = full > LN ? atomicAdd(&cnt[2 + (g & 1u)], full - LN) : 0u;    // whole lines between the open line and the tail
+            uint4 dv;
+            dv.x = NSENT + sel * (PF2_NB * LN) + i * LN;
+            dv.y = of - LN;
+            dv.z = NSENT + (sel ^ 1u) * (PF2_NB * LN) + i * LN - full;
+            dv.w = c | ((full >> 5) << 5) | (ne << 14);        // (full / 32 <= 257: nine bits; ne <= 8 192: fourteen)
+            reinterpret_cast<uint4*>(desc)[i] = dv;
             const unsigned long long bal = __ballot(done);
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&cnt[g & 1u], (uint32_t)__popcll(bal));   // (the four waves' lists follow each other in any order)
@@ -679,41 +684,40 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
             }
         }
         __syncthreads();
-        uint32_t spilled = 0;
+        uint32_t spilled = 0, midm = 0;
+        const uint32_t dummy_word = (uint32_t)((cnt + 7) - sent);   // (an unused counter word takes the entries of dead lanes and of pairs beyond a full part)
 #pragma unroll
         for (uint32_t q = 0; q < PF2_TILES; ++q) {
-            uint32_t dsc[G], of[G];
+            uint4 dv[G];
 #pragma unroll
-            for (uint32_t u = 0; u < G; ++u) {   // the buckets' words first: independent LDS reads
-                const uint32_t b = pk[q][u] >> (32 - PF2_NB_LOG2);
-                const uint2 dv = reinterpret_cast<const uint2*>(desc)[b];
-                dsc[u] = dv.x;
-                of[u] = dv.y;       // (only read when the bucket has whole lines between)
+            for (uint32_t u = 0; u < G; ++u) dv[u] = reinterpret_cast<const uint4*>(desc)[pk[q][u] >> (32 - PF2_NB_LOG2)];   // the buckets' words first: independent LDS reads
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u) {   // straight-line: no branch per pair (the rare cases are collected as bit masks and handled behind the loop)
+                const uint32_t key = pk[q][u], m = dv[u].w;
+                const uint32_t p_rel = (m & LM) + rank[q][u];
+                const bool ok = rank[q][u] < (m >> 14);                      // (a dead lane's rank is EMPTY32: never below)
+                const bool lo = p_rel < LN, mid = !lo && (p_rel >> 5) < ((m >> 5) & 0x1FFu);   // (full is a multiple of 32)
+                const uint32_t at = (lo ? dv[u].x : mid ? dv[u].y : dv[u].z) + p_rel;
+                sent[ok ? at : dummy_word] = (key << 8) | ((wv * PF2_TILES + q) * 8 + (lane >> 3));
+                if (!ok) spilled |= 1u << (q * G + u);
+                if (ok && mid && (at & LM) == 0) midm |= 1u << (q * G + u);   // the first pair of a whole line between lists it
             }
-#pragma unroll
-            for (uint32_t u = 0; u < G; ++u)
-                if (rank[q][u] != EMPTY32) {
-                    const uint32_t key = pk[q][u], b = key >> (32 - PF2_NB_LOG2);
-                    const uint32_t e = (key << 8) | ((wv * PF2_TILES + q) * 8 + (lane >> 3));
-                    const uint32_t d = dsc[u], p_rel = (d & LM) + rank[q][u];
-                    if ((d & 128u) && rank[q][u] >= Q.cap - (written[b] & TMASK)) {   // a part that is full (degenerate inputs): tested on the spot, below
-                        spilled |= 1u << (q * G + u);
-                        continue;
-                    }
-                    const bool mid = p_rel >= LN && p_rel < (d >> 8);
-                    const uint32_t at = of[u] + p_rel - LN;
-                    const uint32_t open_at = NSENT + ((((d >> 5) ^ (p_rel >> 5 ? 1u : 0u)) & 1u) * (PF2_NB * LN)) + b * LN + (p_rel & LM);
-                    sent[mid ? at : open_at] = e;
-                    if (mid && (at & LM) == 0) {   // the line's first pair lists it
-                        lga[PF2_NB + (at >> 5)] = (b * Q.n_writers + writer) * cap_lines + (((written[b] & TMASK & ~LM) + p_rel) >> 5);
-                        lsrc[PF2_NB + (at >> 5)] = at;
-                    }
-                }
         }
-        if (spilled) {   // (static indices: a dynamically indexed pk[][] would live in scratch memory)
+        if (midm) {   // (static indices: a dynamically indexed pk[][] would live in scratch memory)
 #pragma unroll
             for (uint32_t x = 0; x < PF2_TILES * G; ++x)
-                if ((spilled >> x) & 1u) {
+                if ((midm >> x) & 1u) {
+                    const uint32_t q = x / G, u = x % G, b = pk[q][u] >> (32 - PF2_NB_LOG2);
+                    const uint4 d4 = reinterpret_cast<const uint4*>(desc)[b];
+                    const uint32_t p_rel = (d4.w & LM) + rank[q][u], at = d4.y + p_rel;
+                    lga[PF2_NB + (at >> 5)] = (b * Q.n_writers + writer) * cap_lines + (((written[b] & TMASK & ~LM) + p_rel) >> 5);
+                    lsrc[PF2_NB + (at >> 5)] = at;
+                }
+        }
+        if (spilled) {   // a part that is full (degenerate inputs): its pair is tested on the spot
+#pragma unroll
+            for (uint32_t x = 0; x < PF2_TILES * G; ++x)
+                if (((spilled >> x) & 1u) && rank[x / G][x % G] != EMPTY32) {
                     const uint32_t q = x / G, u = x % G, key = pk[q][u];
                     const uint32_t h = key >> (32 - P.bm_log2);
                     const uint32_t wd = P.bitmap[h >> 5];
