@@ -647,11 +647,16 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
 #pragma unroll
         for (uint32_t q = 0; q < PF2_TILES; ++q) {
             const bool live = t0 + q < n_tiles && (t0 + q) * 64 + lane < P.n_reads;
+            // (this kernel is launched with G == np — all probes of a read in one group —, so a tile's probes share ONE execution mask)
+            if (live) {
 #pragma unroll
-            for (uint32_t u = 0; u < G; ++u) {
-                const bool on = live && u < P.np;
-                pk[q][u] = on ? canon16(pk[q][u]) * S16_MUL : 0u;
-                rank[q][u] = on ? atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u) : EMPTY32;
+                for (uint32_t u = 0; u < G; ++u) {
+                    pk[q][u] = canon16(pk[q][u]) * S16_MUL;
+                    rank[q][u] = atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t u = 0; u < G; ++u) { pk[q][u] = 0u; rank[q][u] = EMPTY32; }
             }
         }
         __syncthreads();
