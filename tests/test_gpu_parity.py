@@ -364,6 +364,7 @@ def test_device_pools_follow_the_reference_fastq_join_order(gf, L_case):
 @pytest.mark.parametrize("variant", [13, 9, 16])
 def test_screen_filter_variants_agree(gf, variant):
     """Every filter kernel (pipelined = 13, plain L2 bitmap = 9, partitioned = 16 / 17) gives the oracle's hits."""
+    from gappadder_amd import _lib as B
     from gappadder_amd.hip_api import GapFill
     c = S.small_case(seed=41, n_pairs=25000)
     gf.set_gaps(c["gaps"], c["n_scaffolds"], c["flanks"])
@@ -389,6 +390,19 @@ def test_screen_filter_variants_agree(gf, variant):
                         assert _same(gf.screen_reads(packed[:n], c["L"], 31), exp31[exp31["read"] < n]), (v256, ext, bl, n)
                     assert _same(gf.screen_reads(packed, c["L"], 51), exp51), (v256, ext, bl)
                     assert _same(gf.screen_reads(packed, c["L"], 41), exp41), (v256, ext, bl)
+            # the whole-line pass A is instantiated per probes per read (1 ... 4): k = 51 above has three; k = 61 two, k = 45 four, and
+            # 100-base reads at k = 61 one
+            gf.set_option("screen_variant", 16)
+            gf.set_option("screen_ext", 1)
+            gf.set_option("bitmap_log2", 28)
+            for k in (61, 45):
+                assert _same(gf.screen_reads(packed, c["L"], k), CO.screen_reads(c["reads_blob"], c["L"], c["flanks"], k)), k
+                assert "pf4_scatter_lines_kernel<%du" % {61: 2, 45: 4}[k] in B.lib().gf_screen_kernels(gf.handle).decode()
+            c2 = S.small_case(seed=42, n_pairs=12000, L=100)
+            gf.set_gaps(c2["gaps"], c2["n_scaffolds"], c2["flanks"])
+            packed2, _ = GapFill.pack_reads(c2["reads_blob"], 100)
+            assert _same(gf.screen_reads(packed2, 100, 61), CO.screen_reads(c2["reads_blob"], 100, c2["flanks"], 61))
+            assert "pf4_scatter_lines_kernel<1u" in B.lib().gf_screen_kernels(gf.handle).decode()
     finally:
         gf.set_option("screen_variant", 0)
         gf.set_option("screen_ext", 1)
