@@ -16,7 +16,7 @@ the recruits of all ranks (the reference maps each gap to one Pool task, assembl
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the screen filter; algorithmic bytes = ceil(2L/8) per read,
 SURVEY.md §8d) and `cpu_baseline` (the oracle's C restatement — kind "port" — on the host cores on a bounded sample of the
-same workload, also checked bit-for-bit against the GPU's results on that sample).  At N=1 the default run appends `extras`:
+same workload — stripes over the WHOLE read and gap range, `parity_sample_ranges` — also checked bit-for-bit against the GPU's results on that sample).  At N=1 the default run appends `extras`:
 the same step on C2 (configs[1]) and on C5 (configs[4]: + mate-pair library IS 5000, k in {31,41,51}), each in a child process.
 """
 import argparse
@@ -72,7 +72,8 @@ def parse_args():
                          "C2R = C2's draft with planted repeats (stress workload)")
     ap.add_argument("--reads", type=int, default=0, help="read records of the first library, WHOLE JOB (default: the config's)")
     ap.add_argument("--mp-reads", type=int, default=-1, help="C5: read records of the mate-pair library, whole job (default 400 M = 19.4x; SURVEY.md §8d names 100 M)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000, help="reads of the first library the oracle sees, in stripes over the whole library (-1: all of them)")
+    ap.add_argument("--cpu-sample-gaps", type=int, default=256, help="gaps whose pools the oracle assembles and picks from, drawn over the whole gap list (-1: all)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C5 child runs that the default N=1 run appends as `extras`")
     ap.add_argument("--e2e-only", default="", help="run only the file-based end-to-end extra on this configuration (C2 / C3) and print its object")
@@ -653,9 +654,10 @@ def pmc_traffic(config, reads_per_launch, L, k, launch_ms, launched):
 
 def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_seq, d_best, gpu_step_s, n_screened, B, rb):
     """The oracle (oracle/gp_oracle.c, OpenMP over all host cores; kind "port") on a bounded sample of the same step:
-    k-mer screen + alignment tagger on the first --cpu-sample-reads reads of the first library, and the assembly of the first
-    gaps' pools at every (k, kv).  Also the checker: the GPU's hits on that prefix, its contigs for those gaps and its closed
-    flags must equal the oracle's / the host picker's."""
+    k-mer screen + alignment tagger on --cpu-sample-reads reads of the first library (a quarter of that of every further one) taken in
+    stripes over the whole library, and the assembly of --cpu-sample-gaps gaps' pools, drawn over the whole gap list, at every (k, kv).
+    Also the checker: the GPU's hits in those stripes, its contigs for those gaps and its closed flags must equal the oracle's / the
+    host picker's (`parity_sample`: "striped", or "complete" when the sample is everything)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle as CO
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -669,48 +671,78 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
         pass
     CO.set_threads(cores)
     k_s = min(a for a, _ in kk)
-    ok, ok_tag, t_rec, n_rec, n_ohits, notes = True, True, 0.0, 0, 0, []
+    ok, ok_tag, t_rec, n_rec, n_ohits, notes, where = True, True, 0.0, 0, 0, [], {}
     t_build = 0.0      # the oracle's flank k-mer table (once per run, not per read): timed INSIDE the screen call that builds it
-    for li, lb in enumerate(libs):      # first library: --cpu-sample-reads; further libraries: a quarter of that
-        n_s = min(args.cpu_sample_reads if li == 0 else args.cpu_sample_reads // 4, lb.n_reads) // 2 * 2
+    for li, lb in enumerate(libs):
+        # The sample lies in STRIPES over the whole library (tests/sample_check.py::stripes): its first and last pairs, a stripe across
+        # every place where a byte offset of the packed reads (rb per read), the 32-byte records or their 8-byte keys passes 4 GiB, one
+        # across every shard boundary of a 2 / 4 / 8-rank run, and seeded places between — or ALL reads (--cpu-sample-reads -1).
+        # First library: --cpu-sample-reads; further libraries: a quarter of that
+        want = lb.n_reads if args.cpu_sample_reads < 0 else min(args.cpu_sample_reads if li == 0 else args.cpu_sample_reads // 4, lb.n_reads)
+        pair_ranges = SC.stripes(lb.n_reads // 2, want // 2, strides=(2 * rb, 64, 16), seed=20260600 + li)
+        read_ranges = [(2 * a, 2 * n) for a, n in pair_ranges]
         ocfg = np.frombuffer(lb.cfg.tobytes(), dtype=CO.SYNTH_CFG).copy()
-        packed, recs = CO.synth_pairs(ocfg, lb.first_pair, n_s // 2)
-        blob = CO.unpack_reads(packed, L)
-        t0 = time.perf_counter()
-        ohits = CO.screen_reads(blob, L, flanks, k_s, 1, 0, cores)
-        t1 = time.perf_counter()
-        otags = CO.tag_alignments(recs, gaps, lb.is_mean, lb.is_sd)
-        t2 = time.perf_counter()
         n_hits, n_th = int(lb.d_cnt[0]), int(lb.d_cnt[4])
         hits = np.frombuffer(lb.d_hits[:n_hits * 8].cpu().numpy().tobytes(), dtype=B.HIT)
-        ok = ok and SC.hits_equal(hits, ohits, n_s)
         th = np.frombuffer(lb.d_thits[:n_th * 12].cpu().numpy().tobytes(), dtype=B.TAGHIT)
-        ok_tag = ok_tag and SC.taghits_equal(th, otags, n_s)
-        t_build = CO.screen_last_build_s()          # (of this very call: no subtraction of a separately measured build)
-        t_rec += max(1e-6, (t1 - t0) - t_build) + (t2 - t1)
+        n_s = t_scr = t_tag = 0
+        n_oh = n_ot = 0
+        for group in SC.chunks_of(pair_ranges, 8_000_000):       # one oracle call per group of stripes (one flank-table build each)
+            parts = [CO.synth_pairs(ocfg, lb.first_pair + a, n) for a, n in group]
+            packed, recs = np.concatenate([p_ for p_, _ in parts]), np.concatenate([r_ for _, r_ in parts])
+            del parts
+            blob = CO.unpack_reads(packed, L)
+            t0 = time.perf_counter()
+            ohits = CO.screen_reads(blob, L, flanks, k_s, 1, 0, cores)
+            t1 = time.perf_counter()
+            otags = CO.tag_alignments(recs, gaps, lb.is_mean, lb.is_sd)
+            t2 = time.perf_counter()
+            grp_reads = [(2 * a, 2 * n) for a, n in group]
+            ok = SC.hits_equal(hits, ohits, grp_reads) and ok
+            ok_tag = SC.taghits_equal(th, otags, grp_reads) and ok_tag
+            t_build = CO.screen_last_build_s()          # (of this very call: no subtraction of a separately measured build)
+            t_scr += max(1e-6, (t1 - t0) - t_build)
+            t_tag += t2 - t1
+            n_s += len(recs)
+            n_oh += len(ohits)
+            n_ot += len(otags)
+            del blob, packed, recs
+        t_rec += t_scr + t_tag
         n_rec += n_s
-        n_ohits += len(ohits)
-        notes.append("%s: first %d reads (k-mer screen %.2f s + alignment tagger %.2f s; %d + %d hits)" % (lb.name, n_s, t1 - t0, t2 - t1, len(ohits), len(otags)))
+        n_ohits += n_oh
+        complete = n_s == lb.n_reads
+        where[lb.name] = {"reads": n_s, "of": lb.n_reads, "complete": complete, "stripes": len(read_ranges),
+                          "read_ranges": [[a, a + n] for a, n in read_ranges]}
+        notes.append("%s: %s (k-mer screen %.2f s + alignment tagger %.2f s; %d + %d hits)" %
+                     (lb.name, "ALL %d reads" % n_s if complete else "%d reads in %d stripes over the whole library" % (n_s, len(read_ranges)),
+                      t_scr, t_tag, n_oh, n_ot))
     ok = ok and ok_tag
-    # assembly sample: the first gaps' pools exactly as the GPU assembled them (all libraries merged)
-    n_g = min(len(gaps), 256)
+    # assembly + pick sample: gaps drawn over the WHOLE gap list (first, last, one seeded gap in every part between; or all of them),
+    # their pools exactly as the GPU assembled them (all libraries merged)
+    gsel = SC.sample_gaps(len(gaps), len(gaps) if args.cpu_sample_gaps < 0 else args.cpu_sample_gaps, seed=20260610)
+    n_g = len(gsel)
     pool_off = off_t.cpu().numpy()
-    pool = pool_t[:int(pool_off[n_g]) * rb].cpu().numpy().reshape(-1, rb)
-    pblob = CO.unpack_reads(pool, L)
+    pblobs = [CO.unpack_reads(pool_t[int(pool_off[g]) * rb:int(pool_off[g + 1]) * rb].cpu().numpy().reshape(-1, rb), L) for g in gsel]
     seq = d_seq[:n_seq].cpu().numpy().tobytes()
     t3 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:   # gaps are independent (assemble_gaps.py:296-299 uses a process pool)
-        exp = list(ex.map(lambda g: [CO.assemble_pool(pblob[int(pool_off[g]) * L:int(pool_off[g + 1]) * L], L, k, kv) for k, kv in kk], range(n_g)))
+        exp = list(ex.map(lambda pb: [CO.assemble_pool(pb, L, k, kv) for k, kv in kk], pblobs))
     t4 = time.perf_counter()
     best = d_best.cpu().numpy().view(np.uint64)
-    ok_asm = SC.contigs_equal(ctg, seq, exp, kk, n_g)
-    ok_pick = SC.picks_equal(ctg, seq, best, flanks, kk, n_g)
+    ok_asm = SC.contigs_equal(ctg, seq, exp, kk, gsel)
+    ok_pick = SC.picks_equal(ctg, seq, best, flanks, kk, gsel)
+    striped = not all(w["complete"] for w in where.values()) or n_g < len(gaps)
     # whole-step CPU time extrapolated from the two samples (recruit scales with reads, assembly with gaps).  The flank k-mer table is
     # built once per run on either side (the GPU's index build is outside the timed step too): reported beside, not charged per step
     cpu_step = t_rec * (n_screened / n_rec) + (t4 - t3) * (len(gaps) / n_g)
     return {"value": n_screened / cpu_step, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "flank k-mer table %.2f s (once per run, not part of a step: `table_build_s`); recruit, OpenMP %d threads — %s; assembly: pools of the first %d gaps at %s (%.2f s, same thread count); value = reads / "
-                      "(sample times scaled to the whole step); oracle/gp_oracle.c" % (t_build, cores, "; ".join(notes), n_g, ",".join("%d/%d" % p for p in kk), t4 - t3),
+            "sample": "flank k-mer table %.2f s (once per run, not part of a step: `table_build_s`); recruit, OpenMP %d threads — %s; assembly + pick: pools of %s at %s "
+                      "(%.2f s, same thread count); value = reads / (sample times scaled to the whole step); oracle/gp_oracle.c"
+                      % (t_build, cores, "; ".join(notes), "ALL %d gaps" % n_g if n_g == len(gaps) else "%d gaps drawn over all %d (first, last, one seeded gap per part)" % (n_g, len(gaps)),
+                         ",".join("%d/%d" % p for p in kk), t4 - t3),
+            "parity_sample": "striped" if striped else "complete",
+            "parity_sample_ranges": dict(where, gaps={"n": n_g, "of": len(gaps), "first": gsel[0], "last": gsel[-1],
+                                                      "scaffolds_touched": int(len(np.unique(gaps["scaffold"][gsel])))}),
             "recruit_reads_per_s": n_rec / t_rec, "table_build_s": t_build, "assembly_gaps_per_s": n_g / (t4 - t3),
             "parity_on_sample": bool(ok and ok_asm and ok_pick), "parity_recruit": bool(ok), "parity_assembly": bool(ok_asm),
             "parity_pick": bool(ok_pick), "sample_hits": int(n_ohits), "sample_contigs": int(sum(len(e) for ee in exp for e in ee))}

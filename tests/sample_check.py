@@ -9,30 +9,118 @@ HIT = np.dtype([("gap", "<u4"), ("read", "<u4")])
 TAGHIT = np.dtype([("rec", "<u4"), ("gap", "<u4"), ("kind", "<u2"), ("to_mate", "<u2")])
 
 
-def hits_equal(gpu_hits, oracle_hits, n_sample):
-    """Screen hits (gap, read) of the reads [0, n_sample): the GPU's list (any order, all reads) against the oracle's (sample only)."""
-    sub = np.sort(np.ascontiguousarray(gpu_hits[gpu_hits["read"] < n_sample]).astype(HIT), order=["gap", "read"])
+def stripes(n_items, n_sample, strides=(), shard_worlds=(2, 4, 8), seed=1, n_random=4):
+    """Where the full-size sample lies: disjoint ranges [(first, n)] of ITEMS (read pairs) that together hold about n_sample items and
+    cover the whole array instead of its prefix: the first and the last items, one stripe across every place where a
+    byte offset `item * stride` passes 4 GiB (strides = bytes per item of the arrays the kernels index: packed reads, 32-byte records,
+    8-byte keys), one across every boundary between the shards of a `shard_worlds`-rank run (gappadder_amd/sharding.shard_range), and
+    n_random more at seeded places.  n_sample >= n_items: the whole array, one range."""
+    n_items, n_sample = int(n_items), int(n_sample)
+    if n_sample >= n_items:
+        return [(0, n_items)] if n_items else []
+    centres = []
+    for st in strides:
+        if n_items * int(st) > (1 << 32):
+            centres.append((1 << 32) // int(st))
+    for w in shard_worlds:
+        base, extra = divmod(n_items, w)
+        centres += [r * base + min(r, extra) for r in range(1, w)]
+    rng = np.random.RandomState(seed)
+    centres += [int(x) for x in rng.randint(0, n_items, n_random)]
+    centres = sorted(set(centres))
+    w = max(1, n_sample // (len(centres) + 2))
+    spans = [(0, min(w, n_items)), (max(0, n_items - w), n_items)] + [(max(0, c - w // 2), min(n_items, c - w // 2 + w)) for c in centres]
+    spans.sort()
+    merged = [list(spans[0])]
+    for a, b in spans[1:]:
+        if a <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], b)
+        else:
+            merged.append([a, b])
+    return [(a, b - a) for a, b in merged if b > a]
+
+
+def chunks_of(ranges, max_items):
+    """ranges cut into groups of at most max_items items (one oracle call per group: bounds the host memory of a complete comparison)."""
+    out, cur, n_cur = [], [], 0
+    for a, n in ranges:
+        while n:
+            take = min(n, max_items - n_cur)
+            cur.append((a, take))
+            a, n, n_cur = a + take, n - take, n_cur + take
+            if n_cur == max_items:
+                out.append(cur)
+                cur, n_cur = [], 0
+    if cur:
+        out.append(cur)
+    return out
+
+
+def to_sample(ids, sample):
+    """sample: an int n (the prefix [0, n)) or ranges [(first, n)] (sorted, disjoint) whose members the oracle saw back to back.
+    -> (mask of the ids inside the sample, their index in the oracle's numbering)."""
+    ids = np.asarray(ids).astype(np.int64)
+    if isinstance(sample, (int, np.integer)):
+        m = ids < int(sample)
+        return m, ids[m]
+    starts = np.array([a for a, _ in sample], dtype=np.int64)
+    lens = np.array([n for _, n in sample], dtype=np.int64)
+    assert (starts[1:] >= (starts + lens)[:-1]).all(), "sample ranges must be sorted and disjoint"
+    base = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    j = np.searchsorted(starts, ids, side="right") - 1
+    jj = np.maximum(j, 0)
+    m = (j >= 0) & (ids < starts[jj] + lens[jj])
+    return m, (ids - starts[jj] + base[jj])[m]
+
+
+def hits_equal(gpu_hits, oracle_hits, sample):
+    """Screen hits (gap, read) of the sampled reads: the GPU's list (any order, all reads, global read numbers) against the oracle's
+    (sample only, reads numbered as the oracle saw them).  sample: prefix length or read ranges (to_sample)."""
+    m, idx = to_sample(gpu_hits["read"], sample)
+    sub = np.ascontiguousarray(gpu_hits[m]).astype(HIT)
+    sub["read"] = idx
+    sub = np.sort(sub, order=["gap", "read"])
     want = np.sort(np.ascontiguousarray(oracle_hits).astype(HIT), order=["gap", "read"])
     return len(sub) == len(want) and sub.tobytes() == want.tobytes()
 
 
-def taghits_equal(gpu_tags, oracle_tags, n_sample):
-    """Tagger hits of the records [0, n_sample)."""
+def taghits_equal(gpu_tags, oracle_tags, sample):
+    """Tagger hits of the sampled records (prefix length or record ranges)."""
     order = ["rec", "gap", "kind", "to_mate"]
-    sub = np.sort(np.ascontiguousarray(gpu_tags[gpu_tags["rec"] < n_sample]).astype(TAGHIT), order=order)
+    m, idx = to_sample(gpu_tags["rec"], sample)
+    sub = np.ascontiguousarray(gpu_tags[m]).astype(TAGHIT)
+    sub["rec"] = idx
+    sub = np.sort(sub, order=order)
     want = np.sort(np.ascontiguousarray(oracle_tags).astype(TAGHIT), order=order)
     return len(sub) == len(want) and sub.tobytes() == want.tobytes()
+
+
+def sample_gaps(n_gaps, n_sample, seed=1):
+    """The gaps whose assembly and pick meet the oracle at full size: all of them when n_sample >= n_gaps, else the first, the last
+    and one at a seeded place inside each of n_sample - 2 equal parts of the gap list (every region of every scaffold range is drawn from)."""
+    n_gaps, n_sample = int(n_gaps), int(n_sample)
+    if n_sample >= n_gaps:
+        return list(range(n_gaps))
+    rng = np.random.RandomState(seed)
+    m = max(1, n_sample - 2)
+    edges = np.linspace(0, n_gaps, m + 1).astype(np.int64)
+    picks = [int(a + rng.randint(0, max(1, b - a))) for a, b in zip(edges[:-1], edges[1:])]
+    return sorted(set([0, n_gaps - 1] + picks))
 
 
 def _contig_text(ctg, seq, i):
     return seq[int(ctg[i]["seq_off"]):int(ctg[i]["seq_off"]) + int(ctg[i]["length"])].decode()
 
 
-def contigs_equal(ctg, seq, expected, kk, n_gaps):
-    """The device's contig records of gaps [0, n_gaps) (any order) against expected[g][i] = the oracle's [(sequence, n_nodes,
-    cov_sum)] of gap g at kk[i]."""
-    for g in range(n_gaps):
-        for (k, kv), e in zip(kk, expected[g]):
+def _gap_list(gaps):
+    return list(range(gaps)) if isinstance(gaps, (int, np.integer)) else [int(g) for g in gaps]
+
+
+def contigs_equal(ctg, seq, expected, kk, gaps):
+    """The device's contig records of the sampled gaps (any order) against expected[j][i] = the oracle's [(sequence, n_nodes,
+    cov_sum)] of the j-th sampled gap at kk[i].  gaps: n (the gaps [0, n)) or a list of gap numbers."""
+    for j, g in enumerate(_gap_list(gaps)):
+        for (k, kv), e in zip(kk, expected[j]):
             rows = np.nonzero((ctg["gap"] == g) & (ctg["k"] == k) & (ctg["kv"] == kv))[0]
             mine = sorted((_contig_text(ctg, seq, i), int(ctg[i]["n_nodes"]), int(ctg[i]["cov_sum"])) for i in rows)
             if mine != sorted(e):
@@ -58,5 +146,5 @@ def expected_pick_word(ctg, seq, g, flanks, kk):
     return 0
 
 
-def picks_equal(ctg, seq, best, flanks, kk, n_gaps):
-    return all(expected_pick_word(ctg, seq, g, flanks, kk) == int(best[g]) for g in range(n_gaps))
+def picks_equal(ctg, seq, best, flanks, kk, gaps):
+    return all(expected_pick_word(ctg, seq, g, flanks, kk) == int(best[g]) for g in _gap_list(gaps))

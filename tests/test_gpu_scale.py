@@ -365,13 +365,27 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell(tmp_path):
 @pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5"])
 def test_full_size_config_sample_parity(config):
     """BASELINE.json configs[1], [2], [3], [4] at FULL size on this GPU (reads generated on the device): all screen and tagger hits of
-    the oracle's read prefix (every library), the merged pools' assembly of 256 gaps at every (k, kv) and the closed flags equal
-    the oracle / the host picker; every gap recruits reads and yields contigs."""
+    the oracle's sample (every library) — STRIPES over the whole library: its first and last reads, the reads whose bytes straddle
+    offset 4 GiB of the packed reads / the records / the key column, the shard boundaries of 2 / 4 / 8 ranks, seeded places —, the
+    merged pools' assembly of 256 gaps drawn over the whole gap list (first and last included) at every (k, kv) and the closed flags
+    equal the oracle / the host picker; every gap recruits reads and yields contigs."""
     d = _bench(["--config", config, "--steps", "1", "--warmup", "0", "--no-extras"])
     cb = d["cpu_baseline"]
     assert cb["parity_recruit"] and cb["parity_assembly"] and cb["parity_pick"] and cb["parity_on_sample"], cb
     assert cb["sample_hits"] > 1000 and cb["sample_contigs"] > 100
     n_gaps = d["config"]["gaps"]
+    assert cb["parity_sample"] == "striped"
+    rg = cb["parity_sample_ranges"]
+    assert rg["gaps"]["first"] == 0 and rg["gaps"]["last"] == n_gaps - 1 and rg["gaps"]["n"] >= min(n_gaps, 250)
+    assert rg["gaps"]["scaffolds_touched"] >= min(250, {"C2": 50, "C3": 1, "C4": 620, "C5": 620}[config])
+    for name, w in rg.items():
+        if name == "gaps":
+            continue
+        r = w["read_ranges"]
+        assert r[0][0] == 0 and r[-1][1] == w["of"] and (w["complete"] or w["stripes"] >= 8), (name, w)       # from the first read to the last
+        for stride in (38, 32, 8):          # a library whose arrays pass 4 GiB: the read / record at that byte offset is in the sample
+            at = (1 << 32) // stride
+            assert w["of"] * stride <= (1 << 32) or any(a <= at < b for a, b in r), (name, stride)
     assert d["counts"]["gaps_with_contig"] == n_gaps
     want_reads = {"C2": 50_000_000, "C3": 5_000_000, "C4": 900_000_000, "C5": 1_300_000_000}[config]     # C5: 900 M + the 400 M mate-pair records that make 2-kb gaps closable (bench.py)
     assert d["config"]["reads_total"] == want_reads and d["n_gpus"] == 1
@@ -389,3 +403,17 @@ def test_full_size_config_sample_parity(config):
     else:
         assert d["counts"]["gaps_closed_correct"] == d["counts"]["gaps_closed"] or d["counts"]["gaps_closed"] == 0 or \
             d["counts"]["gaps_closed_correct"] >= 0.99 * d["counts"]["gaps_closed"], d["closed_truth_check"]
+
+
+def test_c2_full_size_complete_parity():
+    """BASELINE.json configs[1] ("bit-exact read-ID check") with NOTHING sampled: every one of the 50 M reads and records through the
+    oracle's k-mer screen and alignment tagger, every one of the 1 000 gaps' pools through the oracle's assembly and the host picker —
+    hit lists, contigs and pick words of the GPU step equal them (collect_reads_for_gaps.py:68-263, collect_discordant_low_mapq_reads.py:31-84
+    for the recruit rules)."""
+    d = _bench(["--config", "C2", "--steps", "1", "--warmup", "0", "--no-extras", "--cpu-sample-reads", "-1", "--cpu-sample-gaps", "-1"], timeout=2400)
+    cb = d["cpu_baseline"]
+    assert cb["parity_sample"] == "complete", cb["parity_sample"]
+    w = cb["parity_sample_ranges"]
+    assert w["short-insert"]["complete"] and w["short-insert"]["reads"] == 50_000_000 and w["gaps"]["n"] == w["gaps"]["of"] == 1000
+    assert cb["parity_recruit"] and cb["parity_assembly"] and cb["parity_pick"] and cb["parity_on_sample"], cb
+    assert cb["sample_hits"] == d["counts"]["libraries"]["short-insert"]["screen_hits"] > 100_000

@@ -127,3 +127,65 @@ def test_pick_check_knows_the_reference_slice_and_catches_a_wrong_pick():
     at = int(ctg[1]["seq_off"]) + 30 + 60 - 3
     wrong = bytearray(seq); wrong[at] = ord("A") if wrong[at] != ord("A") else ord("C")
     assert not SC.picks_equal(ctg, bytes(wrong), best, flanks, kk, 3)
+
+
+def test_stripes_cover_the_ends_the_4gib_crossings_and_the_shard_boundaries():
+    from gappadder_amd.sharding import shard_range
+    n_pairs, rb = 450_000_000, 38            # C4: 900 M reads
+    rg = SC.stripes(n_pairs, 2_000_000, strides=(2 * rb, 64, 16), seed=5)
+    starts, ends = [a for a, _ in rg], [a + n for a, n in rg]
+    assert all(e <= s for e, s in zip(ends[:-1], starts[1:])) and starts[0] == 0 and ends[-1] == n_pairs      # sorted, disjoint, first + last
+    assert 1_800_000 <= sum(n for _, n in rg) <= 2_000_000
+    inside = lambda p: any(a <= p < a + n for a, n in rg)
+    for stride in (2 * rb, 64, 16):          # the pair whose bytes straddle offset 4 GiB of each array, and its neighbours
+        p = (1 << 32) // stride
+        assert inside(p - 1) and inside(p) and inside(p + 1), stride
+    for world in (2, 4, 8):                  # both sides of every shard boundary (sharding.shard_range)
+        for r in range(1, world):
+            b = shard_range(n_pairs, r, world)[0]
+            assert inside(b - 1) and inside(b), (world, r)
+    assert SC.stripes(1000, 5000) == [(0, 1000)] and SC.stripes(1000, 1000) == [(0, 1000)]                   # complete
+    small = SC.stripes(100_000, 10_000, strides=(76,), seed=1)      # no 4-GiB crossing: ends + shard boundaries + seeded places
+    assert small[0][0] == 0 and small[-1][0] + small[-1][1] == 100_000 and len(small) >= 8
+    assert [sum(n for _, n in g) for g in SC.chunks_of([(0, 10), (50, 25), (100, 7)], 16)] == [16, 16, 10]
+    assert [x for g in SC.chunks_of([(0, 10), (50, 25), (100, 7)], 16) for x in g] == [(0, 10), (50, 6), (56, 16), (72, 3), (100, 7)]
+    gs = SC.sample_gaps(19840, 256, seed=3)
+    assert gs[0] == 0 and gs[-1] == 19839 and 250 <= len(gs) <= 256 and max(np.diff(gs)) < 2 * 19840 // 254 + 2
+    assert SC.sample_gaps(200, 256) == list(range(200))
+
+
+def test_range_samples_renumber_the_gpu_ids_and_catch_defects_in_any_stripe():
+    c, hits, tags = _case()
+    L, rng = c["L"], np.random.RandomState(4)
+    n_reads = len(c["reads_blob"]) // L
+    ranges = [(0, 1500), (4000, 2000), (n_reads - 1000, 1000)]                 # reads; the oracle sees them back to back
+    blob = b"".join(c["reads_blob"][a * L:(a + n) * L] for a, n in ranges)
+    want = CO.screen_reads(blob, L, c["flanks"], 31)
+    gpu = hits[rng.permutation(len(hits))].astype(B.HIT)
+    assert len(want) > 20 and SC.hits_equal(gpu, want, ranges)
+    for a, n in ranges:                                                        # a defect in EVERY stripe is seen, first and last read included
+        inside = np.nonzero((gpu["read"] >= a) & (gpu["read"] < a + n))[0]
+        assert len(inside), (a, n)
+        assert not SC.hits_equal(np.delete(gpu, inside[0]), want, ranges)
+        for rd in (a, a + n - 1):
+            extra = gpu[:1].copy(); extra["read"], extra["gap"] = rd, 1
+            if not ((gpu["read"] == rd) & (gpu["gap"] == 1)).any():
+                assert not SC.hits_equal(np.concatenate([gpu, extra]), want, ranges)
+    outside = gpu[:1].copy(); outside["read"] = 3000                           # between the stripes: not the checker's business
+    assert SC.hits_equal(np.concatenate([gpu, outside]), want, ranges)
+    recs = np.concatenate([c["recs"][a:a + n] for a, n in ranges])
+    wt = CO.tag_alignments(recs, c["gaps"], 300, 30)
+    gt = tags[rng.permutation(len(tags))].astype(B.TAGHIT)
+    assert len(wt) > 10 and SC.taghits_equal(gt, wt, ranges)
+    m, _ = SC.to_sample(gt["rec"], ranges)
+    j = int(np.nonzero(m)[0][-1])
+    bad = gt.copy(); bad["gap"][j] ^= 1
+    assert not SC.taghits_equal(bad, wt, ranges)
+    # contigs / picks of a gap LIST: expected[j] belongs to gaps[j]
+    ctg, seq, expected = _device_like_contigs(c, hits, np.random.RandomState(2))
+    sel = [g for g in range(len(c["gaps"])) if g % 2 == 1]
+    assert SC.contigs_equal(ctg, seq, [expected[g] for g in sel], KK, sel)
+    bad = ctg.copy(); i = int(np.nonzero(ctg["gap"] == sel[-1])[0][0]); bad["cov_sum"][i] += 1
+    assert not SC.contigs_equal(bad, seq, [expected[g] for g in sel], KK, sel)
+    j = int(np.nonzero(ctg["gap"] % 2 == 0)[0][0]); ok_elsewhere = ctg.copy(); ok_elsewhere["cov_sum"][j] += 1
+    assert SC.contigs_equal(ok_elsewhere, seq, [expected[g] for g in sel], KK, sel)       # a gap outside the sample
