@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void bam_name_bytes_kernel(BamStream2 B, uint6
             if (o + 4 > B.n) break;
             const int64_t bs = (int32_t)r_ld32(B.p + o);
             if (bs < 32 || o + 4 + (uint64_t)bs > B.n) break;
-            t += (uint32_t)B.p[o + 12] - 1u;      // l_read_name counts the NUL
+            const uint32_t l_nm = B.p[o + 12];
+            if (l_nm == 0 || 36 + (uint64_t)l_nm > (uint64_t)bs + 4) break;      // malformed record: the chain ends here (as in bam_append_kernel)
+            t += l_nm - 1u;      // l_read_name counts the NUL
             o += 4 + (uint64_t)bs;
         }
     name_bytes[s] = t;
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(256) void bam_append_kernel(BamStream2 B, uint64_t 
         const uint8_t* r = B.p + o;
         const int32_t ref = (int32_t)r_ld32(r + 4), mref = (int32_t)r_ld32(r + 24);
         const uint32_t l_name = r[12], n_cig = r_ld16(r + 16);
+        if (l_name == 0 || 36 + (uint64_t)l_name > (uint64_t)bs + 4) break;      // malformed (l_read_name counts the NUL; the name lies inside the block): chain break
         gf_alnrec a;
         a.pos = r_ld32(r + 8) + 1u;
         a.mate_pos = r_ld32(r + 28) + 1u;
@@ -311,6 +314,7 @@ int gf_read_join_dev(gf_ctx* ctx, const void* d_id_hash, size_t n_ids, void* d_r
     const size_t slots = (size_t)1 << t_log2;
     int rc;
     if ((rc = ensure(ctx, ctx->table, slots * 12 + 64))) return rc;
+    ctx->low_rows.clear();      // ctx->table no longer holds the host second-hop table launch_low_mapq may think it cached (as hop.hip does)
     unsigned long long* keys = (unsigned long long*)ctx->table.p;
     uint32_t* vals = (uint32_t*)((uint8_t*)ctx->table.p + slots * 8);
     GF_HIP(ctx, hipMemsetAsync(keys, 0, slots * 8, ctx->stream));

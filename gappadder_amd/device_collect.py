@@ -415,6 +415,7 @@ class DeviceCollector:
         gf.set_gaps(gaps, len(names), flanks)
         paths = [p for pair in cfg["raw_reads"] for p in pair]
         L = max(16, _guess_read_len(paths))
+        self.check_footprint(L)
         while True:
             if L > 1000:
                 raise DeviceCollectUnsupported("reads of %d bases" % L)
@@ -457,6 +458,32 @@ class DeviceCollector:
             self._write_files(pipe, libs, names, gaps, keys, folders, merge_folder)
             self.t["write_files"] = time.perf_counter() - t0
         return res
+
+    def footprint_bytes(self, L):
+        """Device bytes a run on this configuration's files needs, from the file sizes alone (an upper estimate, before anything is read):
+        per BAM the buffers of _ingest_bam_pieces (32-byte record + name hash + name offset per record at rec_cap = size / 24, the name arena
+        at size / 2) + the tagger's 8-byte key column; per FASTQ pair the packed reads, N masks, id hashes and record offsets; the
+        recruit buffers of Pipeline.add_library (hit_cap = an eighth of the reads: 8 + 12 + 12 + 12 + 4 x 8 bytes each); the streaming
+        buffers (text / compressed / inflated pieces).  Pools, contigs and the assembly workspace follow what is recruited (1-2 % of that)."""
+        rb, nmw = (L + 3) // 4, (L + 31) // 32
+        total = 6 * (self.chunk_bytes + (64 << 20))
+        for (bam, _, _), (left, right) in zip(self.cfg["alignments"], self.cfg["raw_reads"]):
+            bsz = os.path.getsize(bam)
+            n_rec = max(1 << 16, bsz // 24)
+            fq = os.path.getsize(left) + os.path.getsize(right)
+            n_reads = fq // (2 * 16 + 6) if L <= 16 else fq // (2 * L + 6)        # a record: id line, L bases, '+', L qualities (ids of 1+ characters)
+            total += n_rec * (32 + 8 + 8 + 8) + max(1 << 20, bsz // 2) + n_reads * (rb + 4 * nmw + 8 + 8)
+            total += (max(n_rec, n_reads) // 8 + (1 << 20)) * (8 + 12 + 12 + 12 + 32)
+        return int(1.1 * total)
+
+    def check_footprint(self, L):
+        """The device path keeps every library whole in HBM; inputs that cannot fit take the streaming per-scaffold path instead of
+        dying in an allocation halfway through the files."""
+        need = self.footprint_bytes(L)
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        limit = int(os.environ.get("GF_DEVICE_COLLECT_MAX_BYTES", "0")) or free
+        if need > limit:
+            raise DeviceCollectUnsupported("the libraries need about %.1f GB of device memory, %.1f GB are free" % (need / 1e9, limit / 1e9))
 
     def _usable_pairs(self, L):
         from .assemble_gaps import velvet_kv

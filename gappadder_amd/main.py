@@ -128,6 +128,25 @@ def main_func(command, sf_config):
                 timings["gaps_closed_on_device"] = int(res.n_closed)
             except DeviceCollectUnsupported as e:
                 sys.stderr.write("device-resident Collect not used (%s): per-scaffold path\n" % e)
+            except (RuntimeError, MemoryError) as e:
+                # out of device memory (torch's allocator or the library's GF_E_NOMEM) or a capacity of the one-shot step outgrown
+                # (Pipeline.fetch's "step overflow"): inputs the streaming per-scaffold path handles chunk by chunk must not crash the
+                # CLI — free the libraries, put the context back to its defaults, take that path.  Anything else is a real error.
+                import torch
+                from ._lib import GF_E_NOMEM, GF_E_NOSPACE, GapFillError
+                oom = isinstance(e, (torch.cuda.OutOfMemoryError, MemoryError)) or "out of memory" in str(e).lower() or "step overflow" in str(e) \
+                    or "keep overflowing" in str(e) or (isinstance(e, GapFillError) and e.code in (GF_E_NOMEM, GF_E_NOSPACE))
+                if not oom:
+                    raise
+                sys.stderr.write("device-resident Collect gave up (%s): per-scaffold path\n" % (str(e).splitlines()[0][:200],))
+                dc = res = first_round = None
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                gf.set_option("asm_max_pool_reads", 0)
+                gf.set_option("asm_big_pool_reads", 131072)
+                for key in ("seconds", "libraries", "gaps", "read_len", "gaps_closed_on_device"):
+                    timings.pop(key, None)
         if not done:
             collect_per_scaffold(cfg, gf, sf_fai, sf_gap_pos, folders, anchor_mapq, clip_dist, wf)
         timings["stages_s"]["collect" + ("_and_first_assembly_round" if first_round is not None else "")] = time.perf_counter() - t0

@@ -344,6 +344,56 @@ def test_inputs_the_resident_path_does_not_take_fall_back_to_the_per_scaffold_pa
             assert split(got[rel]) == split(txt), rel
 
 
+def test_libraries_beyond_the_device_memory_take_the_per_scaffold_path_and_its_time_is_measured(run, tmp_path, capfd):
+    """The resident path keeps every library whole in HBM: DeviceCollector.check_footprint estimates the need from the file sizes BEFORE
+    anything is read and steps aside when it does not fit (here: a limit of 1 MB through GF_DEVICE_COLLECT_MAX_BYTES); an allocation that
+    fails later (torch's OutOfMemoryError, GF_E_NOMEM, a capacity of the one-shot step outgrown) ends in the same fallback (main.py).
+    Same tree either way — and the wall time of both paths on the same files is measured: the fallback decodes the BAM once per stage
+    and joins the FASTQ by name on the host; it must stay within an order of magnitude of the resident path on inputs this small."""
+    import time
+    case, _, ref_tree = run
+    times = {}
+    for sub, env in (("resident", {}), ("fallback", {"GF_DEVICE_COLLECT_MAX_BYTES": "1000000"})):
+        root = os.path.join(str(tmp_path), sub)
+        os.makedirs(root)
+        cfgp, wf, _ = PU.materialise(case, root, kmers=((31, 29), (41, 39), (41, 38)), builtin_bam=True)
+        _run_stages(cfgp, ["Preprocess"])
+        t0 = time.perf_counter()
+        _run_stages(cfgp, ["Collect"], env=env)
+        times[sub] = time.perf_counter() - t0
+        err = capfd.readouterr().err
+        assert ("GB of device memory" in err) == (sub == "fallback"), err[-400:]
+        _run_stages(cfgp, ["Assembly"])
+        _same_tree(PU.tree(wf), ref_tree)
+    print("Collect on %s: resident path %.2f s, per-scaffold fallback %.2f s" % (case.name if hasattr(case, "name") else "golden case", times["resident"], times["fallback"]))
+    assert times["fallback"] < 10 * times["resident"] + 5.0, times
+
+
+def test_an_allocation_failure_inside_the_resident_path_ends_in_the_fallback(run, tmp_path, capfd, monkeypatch):
+    """torch.cuda.OutOfMemoryError raised in the middle of the resident Collect (planted in DeviceCollector._ingest_pair): the CLI frees the
+    libraries and runs the per-scaffold path; any OTHER RuntimeError still propagates."""
+    import torch
+    from gappadder_amd import device_collect as DC
+    case, _, ref_tree = run
+    cfgp, wf, _ = PU.materialise(case, str(tmp_path), kmers=((31, 29), (41, 39), (41, 38)), builtin_bam=True)
+    _run_stages(cfgp, ["Preprocess"])
+
+    def boom(self, *a, **k):
+        raise torch.cuda.OutOfMemoryError("HIP out of memory. Tried to allocate 1.00 TiB (planted by the test)")
+    monkeypatch.setattr(DC.DeviceCollector, "_ingest_pair", boom)
+    _run_stages(cfgp, ["Collect"])
+    assert "device-resident Collect gave up" in capfd.readouterr().err
+    monkeypatch.undo()
+    _run_stages(cfgp, ["Assembly"])
+    _same_tree(PU.tree(wf), ref_tree)
+
+    def other(self, *a, **k):
+        raise RuntimeError("something else entirely")
+    monkeypatch.setattr(DC.DeviceCollector, "_ingest_pair", other)
+    with pytest.raises(RuntimeError, match="something else"):
+        _run_stages(cfgp, ["Collect"])
+
+
 def test_resident_path_with_n_bases_ragged_reads_and_a_late_long_read(tmp_path):
     """Reads with N, reads of different lengths (packed at the longest, the tail masked) and a read longer than the first ones promised
     (the ingest restarts at its length): the N masks travel with the pooled reads through the library merge into the first assembly
