@@ -211,6 +211,7 @@ int gf_set_option(gf_ctx* ctx, const char* name, long value) {
     if (!strcmp(name, "asm_stats_ptr")) { ctx->asm_stats = (void*)(uintptr_t)value; return GF_OK; }
     if (!strcmp(name, "tag_dbg")) { if (!getenv("GF_DIAGNOSTICS")) return GF_E_INVAL; ctx->tag_dbg = (int)value; return GF_OK; }
     if (!strcmp(name, "tag_light")) { ctx->tag_light = value != 0; return GF_OK; }
+    if (!strcmp(name, "asm_tiebreak")) { if (value < 0 || value > 1) return GF_E_INVAL; ctx->asm_tiebreak = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_keyslot")) { ctx->asm_keyslot = value != 0; return GF_OK; }
     if (!strcmp(name, "asm_sweep")) { if (value < 0 || value > 1) return GF_E_INVAL; ctx->asm_sweep = (int)value; return GF_OK; }
     if (!strcmp(name, "asm_pre_frac8")) { if (value < 1 || value > 7) return GF_E_INVAL; ctx->asm_pre_frac8 = (int)value; return GF_OK; }

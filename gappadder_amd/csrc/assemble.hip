@@ -42,6 +42,7 @@ struct AsmParams {
     uint32_t* nodes;           // 3 words per instance: per-node meta + succ[2] when they do not fit in LDS
     uint32_t* jump;            // 4 words per instance: the unitig-ranking pairs of the oriented nodes when they do not fit in LDS
     uint32_t simplify;         // rounds of tip clipping + bubble popping (0: raw unitigs)
+    uint32_t tiebreak_counts;  // 1: between equal coverage the side with fewer WEAK nodes wins (option asm_tiebreak; 0: that rule is off)
     uint32_t slice_rows;       // > 0: the workspace holds one slice of this many pool rows per workgroup
     uint64_t slice_base;       // ... the first of them starts at this instance offset
     uint32_t* defer_tickets;   // (defer) counter of the gaps that asked to leave because of their GRAPH: the first ASM_DEFER_STAY of them stay
@@ -550,7 +551,7 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
         tab.g = gtab;
         bool keyslot = false, keyslot_w = false, fpslot_used = false;
         uint32_t* dist_inst = P.nodes + 3 * inst_off;   // key-slot mode: instance id of the q-th distinct k-mer
-        // Pre-count (min_count 2 or 3): one bit array per occurrence level in LDS; a k-mer's bit climbs one level per occurrence
+        // Pre-count (min_count 2): one bit array per occurrence level in LDS; a k-mer's bit climbs one level per occurrence
         // and only k-mers whose bit reached the last level are counted exactly afterwards.  At ~1 % read errors half of all
         // windows are k-mers seen once — they never enter the table, which then fits the LDS at a low load (a shared bit only
         // lets a k-mer through to the exact count: no k-mer is lost).  The last level sits at R, the table behind it; the lower
@@ -568,16 +569,16 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
             tab.lds = use_lds;
             tab.off = R;
             tab.cap = use_lds ? r_words / 2 : gcap;
-            // Key-slot mode (k <= 31, min_count <= 3, assembly): a slot holds the 62-bit canonical key itself plus a 2-bit
+            // Key-slot mode (k <= 31, min_count <= 2, assembly): a slot holds the 62-bit canonical key itself plus a 2-bit
             // saturating count in the spare low bits.  A repeat occurrence — most instances at
             // sequencing depth — costs one 8-byte read and a compare: no key re-derivation from the reads, and no atomic
             // once the count has saturated.  The instance id of each distinct k-mer goes to a side list (the node arrays
             // are idle here).
-            keyslot = P.keyslot && !W && k <= 31 && P.min_count <= 3 && !cnt_keys;
+            keyslot = P.keyslot && !W && k <= 31 && P.min_count <= 2 && !cnt_keys;   // (min_count <= 2: the 2-bit field tells count <= min_count + 1 from more)
             // wide variant (32 < k <= 63): a 16-byte slot = {hi, ~(lo | count)}, see count_keyslot_wide below.  Only for the
             // global table: in LDS the doubled slot size overflows pools that the 8-byte instance-id slots still hold
             // (measured at k=41, 214-read pools: 161 us against 105 us per gap).
-            const bool wide_ok = P.keyslot && W && k > 32 && k <= 62 && P.min_count <= 3 && !cnt_keys;   // (k <= 62: three spare bits in the 16-byte slot)
+            const bool wide_ok = P.keyslot && W && k > 32 && k <= 62 && P.min_count <= 2 && !cnt_keys;   // (k <= 62: three spare bits in the 16-byte slot)
             keyslot_w = wide_ok && !use_lds;
             // fingerprint slots (32 < k <= 63 in an LDS table over an LDS-staged pool): slot = instance id | 30-bit key fingerprint
             // << 32 | 2-bit saturating count << 62.  A probe that meets another key sees it in the fingerprint (no re-derivation of
@@ -589,7 +590,7 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
             fpslot_used = fpslot;
             // an LDS attempt that is bound to overflow is skipped: at ~1 % errors nearly half of all windows are distinct
             const uint32_t levels = P.min_count;
-            bool pre = P.precount && (keyslot || keyslot_w || fpslot) && levels >= 2 && levels <= 3;
+            bool pre = P.precount && (keyslot || keyslot_w || fpslot) && levels == 2;
             // (an LDS table that holds every key of a k <= 31 pool is filled faster without: see count_keyslot_strided)
             if (keyslot && use_lds && n_inst / 4 <= (r_words / 2) - (r_words / 2) / 4) pre = false;
             if (pre && !pre_built) {   // 8 bits per window when they fit: half of the LDS region under an LDS table, all of it otherwise
@@ -1149,7 +1150,10 @@ __device__ __forceinline__ void assemble_body(const AsmParams& P, AsmShared<NT>&
                         : keyslot_w ? (uint32_t)(~v[u] & 7ull)
                         : keyslot ? (uint32_t)((tab_global ? ~v[u] : (GF_KS_COMPLEMENT_LDS ? ~v[u] : v[u])) & 3ull) + 1u : (uint32_t)(v[u] >> 32);
                     keep = c >= P.min_count;
-                    if (!cnt_keys && (c < 4u ? c : 4u) <= P.min_count + 1) id |= INST_WEAK;   // (counts saturate at 4: the slots' 2-bit counters)
+                    // WEAK: seen at most min_count + 1 times.  c is the true count wherever that matters: the slot forms saturate at 4 and
+                    // are used at min_count <= 2 only (4 > min_count + 1), the instance-id slots count in 32 bits.  tiebreak_counts == 0:
+                    // the rule is off — nothing Velvet could not have known (cvtFaToFq drops the counts, assemble_gaps.py:56-79)
+                    if (!cnt_keys && P.tiebreak_counts && c <= P.min_count + 1) id |= INST_WEAK;
                     if (tab_global) {
                         if (keyslot_w) { tab.store(2 * sl[u], EMPTY64); tab.store(2 * sl[u] + 1, EMPTY64); }
                         else tab.store(sl[u], EMPTY64);
@@ -1841,7 +1845,7 @@ uint32_t asm_lds_count_rows(const gf_ctx* ctx, uint32_t lds_words, int read_len,
         if (pool_words + 2048 > lds_words) return false;
         const uint32_t r_words = lds_words - pool_words;
         const uint64_t n_inst = (uint64_t)n_r * npos;
-        bool pre = ctx->asm_precount && levels >= 2 && levels <= 3 && k <= 62;
+        bool pre = ctx->asm_precount && levels == 2 && k <= 62;
         uint32_t pre_words = 0;
         if (pre) {
             uint32_t lg = 11;
@@ -1948,6 +1952,7 @@ AsmParams asm_params(const gf_ctx* ctx, const AsmGeom& G, const AsmIO& io, int k
     P.nodes = (uint32_t*)ctx->asm_nodes.p;
     P.jump = (uint32_t*)ctx->asm_jump.p;
     P.simplify = (uint32_t)std::max(0, ctx->asm_simplify);
+    P.tiebreak_counts = ctx->asm_tiebreak ? 1u : 0u;
     P.slice_rows = (uint32_t)G.slice_rows;
     P.contigs = (gf_contig*)io.d_contigs;
     P.contig_cap = (uint32_t)io.contig_cap;

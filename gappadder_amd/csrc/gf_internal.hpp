@@ -103,7 +103,8 @@ struct gf_ctx {
                                  // (Velvet's defaults are on; 0: raw unitigs; measured: every C4 / C5 gap converges within two rounds)
     long asm_max_pool_reads = 0; // > 0: no pool has more rows than this (the assembly workspace is then one slice per workgroup, not per row)
     long asm_big_pool_reads = 131072;   // ... and pools beyond asm_max_pool_reads go to a second launch whose slices hold this many rows (a pool beyond this sets its gap_error)
-    int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 3 (0: instance ids)
+    int asm_tiebreak = 1;        // error removal, equal coverage: 1 = fewer weak nodes (k-mers seen <= min_count + 1 times) win; 0 = sequence order alone
+    int asm_keyslot = 1;         // count phase: key-in-slot LDS table when k <= 31 and min_count <= 2 (0: instance ids)
     int asm_ranked = 1;          // count phase: ranked (perfect-hash) table behind the pre-count (k > 32, LDS)
     int asm_last_threads = 0;    // the last launch_assemble: threads per gap of its main launch ...
     bool asm_last_split = false; // ... and whether a middle launch (1 024 threads per gap) followed it (gf_assemble_last_launch)

@@ -116,7 +116,10 @@ int gf_stream_wait_after_filter(gf_ctx* waiter, gf_ctx* producer);
  * that do not are handed to a second launch with 1024), "asm_stats_ptr" (device u64[4] the assembly adds its window / k-mer / survivor / node counts to), "asm_dbg_ptr".
  * Tagger: "tag_light" (1: one-wave workgroups that read the coarse bin map through L1/L2 instead of staging it in LDS — same hits;
  * for a pipeline that runs the tagger on a second context beside the k-mer filter, whose workgroups own most of every CU's LDS).
- * Assembly: "asm_simplify" (rounds of tip clipping + bubble popping — Velvet's defaults, which the reference runs with
+ * Assembly: "asm_tiebreak" (error removal between branches of EQUAL coverage: 1 (default) = the branch with fewer weak nodes — k-mers seen
+ * at most min_count + 1 times — wins, then sequence order; 0 = sequence order alone: the reference-shaped mode, nothing that Velvet
+ * could not have known, since cvtFaToFq drops the counts before Velvet reads a k-mer, assemble_gaps.py:56-79),
+ * "asm_simplify" (rounds of tip clipping + bubble popping — Velvet's defaults, which the reference runs with
  * (assemble_gaps.py:117); default 8 (where the rounds have converged), 0 = raw unitigs), "asm_max_pool_reads" (device variants: upper bound on the rows of one
  * pool; the assembly workspace is then one slice of that size per workgroup instead of one per pool row — a pool beyond the bound
  * sets its gap_error; 0 = no bound), "asm_sweep" (1: gf_assemble_multi_dev runs the k list 31/29, 41/39, 51/49 as ONE launch in which a

@@ -50,6 +50,8 @@ def lib():
         L.or_assemble_pool.argtypes = [C.c_char_p, sz, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
         L.or_assemble_pool2.restype = sz
         L.or_assemble_pool2.argtypes = [C.c_char_p, sz, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
+        L.or_assemble_pool3.restype = sz
+        L.or_assemble_pool3.argtypes = [C.c_char_p, sz, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
         L.or_quick_check.restype = sz
         L.or_quick_check.argtypes = [C.c_char_p, vp, sz, i32, vp, vp, sz]
         L.or_overlap_evaluate.restype = None
@@ -164,16 +166,19 @@ def count_kmers(reads_blob, read_len, k, min_count=2):
     return hi[:m], lo[:m], cnt[:m]
 
 
-def assemble_pool(reads_blob, read_len, k, kv, min_count=2, min_contig=40, simplify=8):
+def assemble_pool(reads_blob, read_len, k, kv, min_count=2, min_contig=40, simplify=8, tiebreak="counts"):
     """[(sequence, n_nodes, cov_sum)] sorted by (-length, sequence).  simplify = rounds of tip clipping + bubble popping, stopping
-    when a round removes nothing (8: the product's default = to convergence in practice, Velvet's defaults on; 0: raw unitigs)."""
+    when a round removes nothing (8: the product's default = to convergence in practice, Velvet's defaults on; 0: raw unitigs).
+    tiebreak: "counts" (default: fewer weak nodes win between equal coverage) or "none" (the reference-shaped mode: sequence order
+    alone, nothing Velvet could not have known — the product's option asm_tiebreak = 0)."""
+    tb = {"counts": 1, "none": 0}[tiebreak]
     n = len(reads_blob) // read_len
     cap = max(16, n * (read_len - k + 1))
     nn = np.zeros(cap, np.uint32); ln = np.zeros(cap, np.uint32); cv = np.zeros(cap, np.uint32)
     scap = max(1024, 8 * n * read_len)
     seq = np.zeros(scap, np.uint8)
     need = C.c_size_t(0)
-    m = lib().or_assemble_pool2(bytes(reads_blob), n, read_len, k, kv, min_count, min_contig, simplify, _p(nn), _p(ln), _p(cv), cap,
+    m = lib().or_assemble_pool3(bytes(reads_blob), n, read_len, k, kv, min_count, min_contig, simplify, tb, _p(nn), _p(ln), _p(cv), cap,
                                 _p(seq), scap, C.byref(need))
     assert m <= cap and need.value <= scap
     out, off = [], 0

@@ -565,8 +565,7 @@ size_t or_count_kmers(const char* reads, size_t n_reads, int L, int k, int min_c
     return w;
 }
 
-/* weak: one of the surviving k-mers the node came from was seen at most min_count + 1 times (counts saturate at 4, like the
- * kernel's 2-bit counters: with min_count >= 3 every node is weak and the rule below is void) */
+/* weak: one of the surviving k-mers the node came from was seen at most min_count + 1 times (the k-mer's true count) */
 typedef struct { k128 key; uint32_t mult; uint8_t out, in, dead, weak; } or_node;
 static long node_find(const or_node* nd, size_t n, k128 key) {
     size_t a = 0, b = n;
@@ -654,9 +653,11 @@ static void graph_unitigs(or_graph* G) {
 
 /* Velvet's default error removal (velvetg without -cov_cutoff: tip clipping + Tour Bus bubble popping), DEFINED
  * here on the unitig graph — Velvet itself is absent, and its coverage-based choices are coin flips on this input where every
- * surviving k-mer is one read (assemble_gaps.py:104-118), so ties are broken — north_star: "for fixed tie-breaking" — first by the
- * evidence the k-mer counts still hold (a sequencing error that made it past min_count was seen min_count times, rarely once more,
- * the true sequence many more: the side with FEWER WEAK nodes stays), then by an orientation-free sequence order:
+ * surviving k-mer is one read (assemble_gaps.py:104-118), so ties are broken — north_star: "for fixed tie-breaking" — in one of two
+ * modes.  tiebreak = 1 ("counts", the default): first by the evidence the k-mer counts still hold (a sequencing error that made it
+ * past min_count was seen min_count times, rarely once more, the true sequence many more: the side with FEWER WEAK nodes stays), then
+ * by an orientation-free sequence order.  tiebreak = 0 ("none", the reference-shaped mode): the sequence order alone — cvtFaToFq
+ * drops the counts before Velvet reads a k-mer (assemble_gaps.py:56-79), so nothing here uses what Velvet could not have known.
  *   X beats Y  :=  (cov X, then fewer weak nodes, then the SMALLER ukey) wins, preceded by (nodes) where lengths can differ.
  * One round decides on ONE snapshot of the graph, for every oriented unitig X (head h, tail t, n nodes):
  *  TIP     out-degree(t) == 0, in-degree(h) == 1 with predecessor p of out-degree >= 2, n <= kv (i.e. n + kv - 1 < 2 kv bases:
@@ -676,7 +677,7 @@ static int tip_shaped(const or_graph* G, uint32_t h) {
 static int beats(const or_graph* G, uint32_t y, uint32_t x, int with_len) {
     if (with_len && G->len[y] != G->len[x]) return G->len[y] > G->len[x];
     if (G->cov[y] != G->cov[x]) return G->cov[y] > G->cov[x];
-    if (G->wk[y] != G->wk[x]) return G->wk[y] < G->wk[x];
+    if (G->wk[y] != G->wk[x]) return G->wk[y] < G->wk[x];      /* (tiebreak 0: no node is ever marked weak, wk is 0 everywhere) */
     return k128_lt(G->ukey[y], G->ukey[x]);
 }
 /* alternative paths from tail q (q = p at depth 0) to s with exactly `remain` nodes; returns 1 when X must go */
@@ -749,7 +750,7 @@ static size_t simplify_round(or_graph* G) {
 /* contigs of one pool.  seq_out receives the sequences back to back (no terminators); per contig n_nodes[], length[],
  * cov_sum[].  simplify = rounds of tip clipping + bubble popping (0: raw unitigs; 2: the default of the product).
  * Returns the number of contigs (may exceed cap; *seq_need = bytes needed). */
-size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig, int simplify,
+size_t or_assemble_pool3(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig, int simplify, int tiebreak,
                          uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
                          size_t* seq_need) {
     *seq_need = 0;
@@ -773,8 +774,8 @@ size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv
         nd[nn].key = keys[i]; nd[nn].mult = (uint32_t)(j - i); nd[nn].out = nd[nn].in = nd[nn].dead = nd[nn].weak = 0; ++nn;
         i = j;
     }
-    for (size_t s = 0; s < ns; ++s) { /* weak k-mers mark their nodes */
-        if ((cn[s] < 4 ? cn[s] : 4u) > (uint32_t)(min_count < 1 ? 1 : min_count) + 1u) continue;
+    for (size_t s = 0; tiebreak && s < ns; ++s) { /* weak k-mers mark their nodes */
+        if (cn[s] > (uint32_t)(min_count < 1 ? 1 : min_count) + 1u) continue;
         k128 t = {hi[s], lo[s]};
         for (int o = 0; o < per; ++o) nd[node_find(nd, nn, k128_canon(k128_sub(t, o, kv), kv, NULL))].weak = 1;
     }
@@ -827,6 +828,12 @@ size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv
     free(ctg); free(G.head); free(G.tail); free(G.len); free(G.cov); free(G.wk); free(G.next); free(G.ukey); free(G.kill);
     free(nd); free(keys); free(hi); free(lo); free(cn);
     return nc;
+}
+
+size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig, int simplify,
+                         uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
+                         size_t* seq_need) {   /* the default tie-break ("counts") */
+    return or_assemble_pool3(reads, n_reads, L, k, kv, min_count, min_contig, simplify, 1, n_nodes, length, cov_sum, cap, seq_out, seq_cap, seq_need);
 }
 
 size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig,

@@ -38,6 +38,12 @@ size_t or_assemble_pool(const char* reads, size_t n_reads, int L, int k, int kv,
 size_t or_assemble_pool2(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig, int simplify,
                          uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
                          size_t* seq_need);
+/* ... and with the tie-break mode of the error removal spelled out: 1 = "counts" (between equal coverage the side with fewer weak
+ * nodes — k-mers seen at most min_count + 1 times — stays; or_assemble_pool2's mode), 0 = "none" (sequence order alone: nothing Velvet
+ * could not have known, assemble_gaps.py:56-79) */
+size_t or_assemble_pool3(const char* reads, size_t n_reads, int L, int k, int kv, int min_count, int min_contig, int simplify, int tiebreak,
+                         uint32_t* n_nodes, uint32_t* length, uint32_t* cov_sum, size_t cap, char* seq_out, size_t seq_cap,
+                         size_t* seq_need);
 /* f-3: the contig merger's all-pairs k-mer prefilter (QuickCheckerContigsMatch, ContigsCompactor.cpp:1982-2095) over the node list
  * [c0, revcomp(c0), c1, ...]; pairs (i <= j) in order; returns their number (may exceed cap).  Contigs of >= 30 bases. */
 typedef struct { double mismatch, indel, max_clip, frac_min_overlap, frac_loss, min_overlap, min_overlap_scaffold, relax; } or_ovl_params;

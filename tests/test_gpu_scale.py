@@ -377,7 +377,7 @@ def test_full_size_config_sample_parity(config):
     assert cb["parity_sample"] == "striped"
     rg = cb["parity_sample_ranges"]
     assert rg["gaps"]["first"] == 0 and rg["gaps"]["last"] == n_gaps - 1 and rg["gaps"]["n"] >= min(n_gaps, 250)
-    assert rg["gaps"]["scaffolds_touched"] >= min(250, {"C2": 50, "C3": 1, "C4": 620, "C5": 620}[config])
+    assert rg["gaps"]["scaffolds_touched"] >= min(200, {"C2": 50, "C3": 1, "C4": 620, "C5": 620}[config])      # (256 gaps drawn over 620 scaffolds: ~247 distinct ones)
     for name, w in rg.items():
         if name == "gaps":
             continue
