@@ -74,6 +74,9 @@ def parse_args():
     ap.add_argument("--mp-reads", type=int, default=-1, help="C5: read records of the mate-pair library, whole job (default 400 M = 19.4x; SURVEY.md §8d names 100 M)")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000, help="reads of the first library the oracle sees, in stripes over the whole library (-1: all of them)")
     ap.add_argument("--cpu-sample-gaps", type=int, default=256, help="gaps whose pools the oracle assembles and picks from, drawn over the whole gap list (-1: all)")
+    ap.add_argument("--asm-tiebreak", default="counts", choices=["counts", "none"],
+                    help="error removal between branches of equal coverage: counts (default: fewer weak k-mers win) or none (reference-shaped: "
+                         "sequence order alone, nothing Velvet could not have known, assemble_gaps.py:56-79); the oracle follows")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C5 child runs that the default N=1 run appends as `extras`")
     ap.add_argument("--e2e-only", default="", help="run only the file-based end-to-end extra on this configuration (C2 / C3) and print its object")
@@ -258,6 +261,7 @@ def run(args):
     max_pool_rows, asm_bound, per_gap = pipe.max_pool_rows, pipe.asm_bound, pipe.per_gap
     if os.environ.get("GF_BENCH_SCREEN_VARIANT"):    # filter kernel (experiments: 17 = pass A with unaligned runs)
         gf.set_option("screen_variant", int(os.environ["GF_BENCH_SCREEN_VARIANT"]))
+    gf.set_option("asm_tiebreak", 1 if args.asm_tiebreak == "counts" else 0)
     if os.environ.get("GF_BENCH_ASM_SIMPLIFY"):      # rounds of tip clipping + bubble popping (experiments; the parity sample then disagrees unless it is 2)
         gf.set_option("asm_simplify", int(os.environ["GF_BENCH_ASM_SIMPLIFY"]))
     if os.environ.get("GF_BENCH_ASM_PRE_FRAC8"):     # count phase: share of the LDS region the pre-count bit arrays may take (eighths; experiments)
@@ -412,7 +416,7 @@ def run(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": None if (one_gpu and world > 1) else "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": wl, "reads_total": n_screened, "reads_per_gpu": sum(lb.n_reads for lb in libs), "gaps": n_gaps,
-                       "k_pairs": [list(p) for p in kk],
+                       "k_pairs": [list(p) for p in kk], "asm_tiebreak": args.asm_tiebreak,
                        "collectives": ("none (one rank)" if not multi else "RCCL (nccl backend), one GPU per rank" if backend == "nccl" else
                                        "%s through host memory%s" % (backend, ", all ranks on cuda:0 (functional mode)" if os.environ.get("GF_BENCH_ONE_GPU") else "")),
                        "sharding": ("single GPU: all reads and all gaps on one device" if not multi else
@@ -726,7 +730,7 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
     seq = d_seq[:n_seq].cpu().numpy().tobytes()
     t3 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:   # gaps are independent (assemble_gaps.py:296-299 uses a process pool)
-        exp = list(ex.map(lambda pb: [CO.assemble_pool(pb, L, k, kv) for k, kv in kk], pblobs))
+        exp = list(ex.map(lambda pb: [CO.assemble_pool(pb, L, k, kv, tiebreak=args.asm_tiebreak) for k, kv in kk], pblobs))
     t4 = time.perf_counter()
     best = d_best.cpu().numpy().view(np.uint64)
     ok_asm = SC.contigs_equal(ctg, seq, exp, kk, gsel)

@@ -245,7 +245,31 @@ def test_an_error_seen_at_most_min_count_plus_one_times_loses_the_bubble_to_the_
         assert len(ctg4) == 1 and ctg4[0][0].encode() in (g, rc(g), h, rc(h))
         n_true += ctg4[0][0].encode() in (g, rc(g))
     assert 0 < n_true < 12                                              # ... and that order is not the truth's
-    # min_count 3: the 2-bit counters saturate at min_count + 1, every k-mer is weak and the rule is void (defined, checked on the GPU too)
-    reads3 = _cover(g, L) + [err_read, rc(err_read), err_read]
-    c3 = max(CO.assemble_pool(b"".join(reads3), L, 31, 29, min_count=3, simplify=2), key=lambda c: len(c[0]))[0].encode()
-    assert len(c3) > 600 and any(x[320:380] in c3 for x in (g, rc(g), h, rc(h)))
+    # min_count 3: weakness is defined on the TRUE count (seen at most min_count + 1 = 4 times): an error seen three times survives,
+    # is weak, and loses to the true allele — no counter width shapes the rule
+    for copies in ([err_read, rc(err_read), err_read], [err_read, rc(err_read), err_read, rc(err_read)]):
+        c3 = max(CO.assemble_pool(b"".join(_cover(g, L) + copies), L, 31, 29, min_count=3, simplify=2), key=lambda c: len(c[0]))[0].encode()
+        assert len(c3) > 600 and any(x[320:380] in c3 for x in (g, rc(g))), len(copies)
+
+
+def test_the_reference_shaped_mode_uses_no_counts():
+    """tiebreak="none" (the product's asm_tiebreak = 0): what Velvet could have known — every surviving k-mer once, no counts
+    (cvtFaToFq drops them, assemble_gaps.py:56-79).  A bubble between the true allele and an error seen twice ties on nodes and coverage
+    and goes to the smaller sequence, whichever allele that is; the answer does not change when the error is seen more often."""
+    rng = np.random.RandomState(31)
+    L = 100
+    n_true = n_same = 0
+    for trial in range(12):
+        g = LUT[rng.randint(0, 4, 700)].tobytes()
+        h = _mut(g, 350, 1 + trial % 3)
+        err_read = h[300:400]
+        picks = []
+        for n_err in (2, 3, 4, 9):
+            reads = _cover(g, L) + ([err_read, rc(err_read)] * 5)[:n_err]
+            ctg = CO.assemble_pool(b"".join(reads), L, 31, 29, simplify=2, tiebreak="none")
+            assert len(ctg) == 1 and ctg[0][0].encode() in (g, rc(g), h, rc(h))
+            picks.append(ctg[0][0].encode() in (g, rc(g)))
+        assert len(set(picks)) == 1, (trial, picks)           # the count of the error allele is not looked at
+        n_true += picks[0]
+        n_same += picks[0] == (CO.assemble_pool(b"".join(_cover(g, L) + [err_read, rc(err_read)]), L, 31, 29, simplify=2)[0][0].encode() in (g, rc(g)))
+    assert 0 < n_true < 12 and n_same < 12                    # sequence order is not the truth's; the default mode differs somewhere

@@ -76,7 +76,7 @@ def test_known_answers_on_gpu(gf):
 def test_min_count_and_min_contig_parameters(gf):
     c = S.small_case(seed=8, n_pairs=8000)
     pools = _pools_from_case(c)
-    for mc, ml in ((1, 40), (3, 40), (2, 29), (2, 200)):
+    for mc, ml in ((1, 40), (3, 40), (4, 40), (6, 40), (2, 29), (2, 200)):
         got, _ = _gpu_assemble(gf, pools, c["L"], [(31, 29)], min_count=mc, min_contig=ml)
         for g, p in enumerate(pools):
             assert got.get((g, 31, 29), []) == CO.assemble_pool(p, c["L"], 31, 29, mc, ml), (mc, ml, g)
@@ -272,20 +272,31 @@ def test_random_error_graphs_match_oracle(gf):
             reads += [bytes(r)] * 2
         pools.append(b"".join(reads))
     got, _ = _gpu_assemble(gf, pools, L, [(31, 29), (41, 39)])
-    n_diff_raw = 0
+    gf.set_option("asm_tiebreak", 0)
+    try:
+        got_none, _ = _gpu_assemble(gf, pools, L, [(31, 29), (41, 39)])      # the reference-shaped mode: no counts in the tie-break
+    finally:
+        gf.set_option("asm_tiebreak", 1)
+    n_diff_raw = n_diff_mode = 0
     for i, p in enumerate(pools):
         for k, kv in ((31, 29), (41, 39)):
             exp = CO.assemble_pool(p, L, k, kv)
             assert got.get((i, k, kv), []) == exp, (i, k, kv)
+            exp_none = CO.assemble_pool(p, L, k, kv, tiebreak="none")
+            assert got_none.get((i, k, kv), []) == exp_none, (i, k, kv, "none")
             n_diff_raw += exp != CO.assemble_pool(p, L, k, kv, simplify=0)
+            n_diff_mode += exp != exp_none
     assert n_diff_raw > 30      # the removal did something in most pools
+    assert n_diff_mode > 5      # ... and the two tie-break modes part ways in some of them
 
 
 @pytest.mark.parametrize("kk,L", [((31, 29), 100), ((51, 49), 150), ((41, 37), 150)])
 def test_weak_kmers_lose_the_ties_of_the_error_removal(gf, kk, L):
     """An error seen two, three and four times against the true allele (oracle: test_an_error_seen_at_most_min_count_plus_one_...):
     the kernel keeps the true allele like the oracle — key-slot, fingerprint and instance-id count tables (k 31 / 51, kv = k - 4 runs
-    without node fingerprints), LDS and global plans, min_count 2 and 3 (void rule) and 1."""
+    without node fingerprints), LDS and global plans, min_count 2, 3, 4 (weakness on the true count: the slot forms with their 2-bit
+    counters run at min_count <= 2 only) and 1 — and in the reference-shaped mode (asm_tiebreak = 0: no counts) like the oracle's
+    tiebreak="none"."""
     from test_assembly_oracle import _cover, _mut
     rng = np.random.RandomState(41)
     pools, truth = [], []
@@ -296,18 +307,26 @@ def test_weak_kmers_lose_the_ties_of_the_error_removal(gf, kk, L):
         reads = _cover(g, L) + [err, rc(err)] + [err] * (0 if trial < 6 else 1 if trial < 12 else 2)    # seen 2 / 3 / 4 times
         pools.append(b"".join(reads))
         truth.append(g)
-    for mc in (2, 3, 1):
+    n_modes_differ = 0
+    for mc, tb in ((2, "counts"), (3, "counts"), (4, "counts"), (1, "counts"), (2, "none"), (3, "none")):
         for lds_kb in (152, 8):
             gf.set_option("asm_lds_pool_kb", lds_kb)
+            gf.set_option("asm_tiebreak", 1 if tb == "counts" else 0)
             try:
                 got, _ = _gpu_assemble(gf, pools, L, [kk], min_count=mc)
             finally:
                 gf.set_option("asm_lds_pool_kb", 152)
+                gf.set_option("asm_tiebreak", 1)
             for i, p in enumerate(pools):
-                exp = CO.assemble_pool(p, L, kk[0], kk[1], min_count=mc)
-                assert got.get((i, kk[0], kk[1]), []) == exp, (i, mc, lds_kb)
-                if mc == 2 and i < 12:
+                exp = CO.assemble_pool(p, L, kk[0], kk[1], min_count=mc, tiebreak=tb)
+                assert got.get((i, kk[0], kk[1]), []) == exp, (i, mc, tb, lds_kb)
+                if mc == 2 and tb == "counts" and i < 12:
                     assert len(exp) == 1 and exp[0][0].encode() in (truth[i], rc(truth[i]))
+                if mc == 3 and tb == "counts" and 6 <= i < 12:       # seen three times at min_count 3: survives, weak (<= 4), loses
+                    assert any(t[400:500] in exp[0][0].encode() for t in (truth[i], rc(truth[i]))), i
+                if tb == "none" and lds_kb == 152:
+                    n_modes_differ += exp != CO.assemble_pool(p, L, kk[0], kk[1], min_count=mc)
+    assert n_modes_differ > 0       # the switch is alive: somewhere the sequence order picks the error allele
 
 
 @pytest.mark.parametrize("threads", [512, 256])
