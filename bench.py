@@ -421,8 +421,8 @@ def run(args):
                                        "%s through host memory%s" % (backend, ", all ranks on cuda:0 (functional mode)" if os.environ.get("GF_BENCH_ONE_GPU") else "")),
                        "sharding": ("single GPU: all reads and all gaps on one device" if not multi else
                                     "the same reads split over the ranks (contiguous pair ranges), gaps + flank index replicated; per-gap pools "
-                                    "sent to one owner rank per gap (batches of %d gaps round-robin; device pack + all-gather of counts + "
-                                    "equal-slot all-to-all + device merge, no host sync), every gap assembled once by its owner from all "
+                                    "sent to one owner rank per gap (batches of %d gaps round-robin; device pack + ONE all-to-all with exact split "
+                                    "sizes that also carries the per-gap counts + device merge, no host sync), every gap assembled once by its owner from all "
                                     "ranks' recruits; final gather of the closed gaps' contigs on rank 0" % pipe.batch)},
             "gaps_per_s": n_gaps / step_s,
             "gaps_closed_per_s": n_closed / step_s,
@@ -470,6 +470,17 @@ def run(args):
                                                   "ranks' second-hop rows + their merge, the same on every rank whatever their number; owner_exchange = pack + "
                                                   "all-gather of counts + all-to-all + merge of the per-gap pools (exists only in multi-rank runs)")
             out["config"]["forced_exchange_at_world_1"] = world == 1
+            n_lib_ = len(libs)
+            if getattr(pipe, "exact_exchange", False):
+                out["exchange"] = {"form": "exact split sizes (rows per source, owner and library from the sizing pass), per-gap counts inside the one all-to-all",
+                                   "bytes_sent_per_rank_and_step": int(pipe.xchg.bytes_sent), "header_bytes_per_peer": int(pipe.xchg.header_bytes),
+                                   "collectives_per_step": 1 + n_lib_,
+                                   "collectives": "1 all-to-all (pools + counts) + 1 all-gather per library (second-hop rows, their gaps and count in one packed slot)"}
+            else:
+                out["exchange"] = {"form": "equal slots padded to 1.25 x the largest block + all-gather of the counts (GF_XCHG=slots)",
+                                   "bytes_sent_per_rank_and_step": int((world - 1) * (n_lib_ * pipe.slot_cap * rb + n_lib_ * n_gaps * 4)),
+                                   "collectives_per_step": 2 + n_lib_,
+                                   "collectives": "1 all-gather (counts) + 1 all-to-all (slots) + 1 all-gather per library (second-hop rows)"}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, libs, flanks, gaps, L, kk, asm_pool_t, asm_off_t, ctg, d_seq, n_seq, d_best, step_s,
                                                n_screened, B, rb)

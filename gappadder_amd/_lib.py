@@ -109,6 +109,8 @@ def lib():
         "gf_pool_counts_dev": (i32, [vp, vp, sz, vp]),
         "gf_pools_pack_for_owners_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
         "gf_pools_merge_dev": (i32, [vp, vp, sz, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz, vp, vp]),
+        "gf_pools_pack_for_owners_v_dev": (i32, [vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "gf_pools_merge_v_dev": (i32, [vp, vp, vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz, vp, vp]),
         "gf_quick_check": (i32, [vp, C.c_char_p, vp, vp, sz, i32, vp, sz, szp]),
         "gf_quick_check_dev": (i32, [vp, vp, vp, vp, sz, sz, i32, vp, sz, vp]),
         "gf_overlap_evaluate": (i32, [vp, C.c_char_p, vp, vp, sz, vp, sz, vp, vp]),

@@ -406,17 +406,22 @@ __global__ __launch_bounds__(1024) void pool_counts_kernel(const unsigned long l
 }
 
 // block d: rows of the gaps owned by rank d, in gap order -> their row offset inside d's slot; cnt[g] for every gap
+// hdr (exact-size exchange): the counts of slot (d, lib) also go INTO the send buffer, as u32[n_gaps] at byte offset hdr[d] (zero for
+// the gaps d does not own), so that the all-to-all carries them and no separate all-gather of counts is needed
 __global__ __launch_bounds__(1024) void xchg_send_offsets_kernel(const unsigned long long* pool_off, uint32_t n_gaps, uint32_t world,
-                                                                 uint32_t batch, uint32_t* cnt, uint32_t* dst_off) {
+                                                                 uint32_t batch, uint32_t* cnt, uint32_t* dst_off, uint8_t* send,
+                                                                 const unsigned long long* hdr) {
     __shared__ uint32_t s_w[20];
     const uint32_t d = blockIdx.x;
     uint32_t carry = 0;
+    uint32_t* hc = hdr ? reinterpret_cast<uint32_t*>(send + hdr[d]) : nullptr;
     for (uint32_t g0 = 0; g0 < n_gaps; g0 += blockDim.x) {
         const uint32_t g = g0 + threadIdx.x;
         const bool mine = g < n_gaps && owner_of(g, batch, world) == d;
         const uint32_t n = mine ? (uint32_t)(pool_off[g + 1] - pool_off[g]) : 0u;
         uint32_t tot;
         const uint32_t ex = block_scan_excl(n, s_w, &tot);
+        if (hc && g < n_gaps) hc[g] = n;
         if (mine) { cnt[g] = n; dst_off[g] = carry + ex; }
         carry += tot;
         __syncthreads();
@@ -426,19 +431,23 @@ __global__ __launch_bounds__(1024) void xchg_send_offsets_kernel(const unsigned 
 // one workgroup per gap: its rows go to slot (owner * n_lib + lib) of the send buffer
 __global__ __launch_bounds__(256) void xchg_pack_kernel(const uint8_t* pool, const unsigned long long* pool_off, uint32_t n_gaps, uint32_t rb,
                                                         uint32_t world, uint32_t batch, uint32_t lib, uint32_t n_lib, const uint32_t* dst_off,
-                                                        uint8_t* send, uint64_t cap_rows, uint32_t* error) {
-    const uint32_t ur = (rb & 1) ? rb : rb / 2;
+                                                        uint8_t* send, uint64_t cap_rows_all, uint32_t* error,
+                                                        const unsigned long long* slot_base, const uint32_t* slot_cap) {
+    // slot_base / slot_cap (exact-size exchange): slot s starts at BYTE offset slot_base[s] of `send` (even when rb is even) and holds
+    // slot_cap[s] rows; null: equal slots of cap_rows_all rows, slot s at row s * cap_rows_all
+    const uint32_t ur = (rb & 1) ? rb : rb / 2, ub = (rb & 1) ? 1u : 2u;
     for (uint32_t g = blockIdx.x; g < n_gaps; g += gridDim.x) {
         const unsigned long long p0 = pool_off[g];
         uint32_t n = (uint32_t)(pool_off[g + 1] - p0);
         if (!n) continue;
         const uint32_t o = dst_off[g];
+        const uint64_t slot = (uint64_t)owner_of(g, batch, world) * n_lib + lib;
+        const uint64_t cap_rows = slot_cap ? slot_cap[slot] : cap_rows_all;
         if ((uint64_t)o + n > cap_rows) {   // slot too small: say so, send what fits
             if (threadIdx.x == 0) atomicOr(error, 0x40000000u);
             n = o < cap_rows ? (uint32_t)(cap_rows - o) : 0u;
         }
-        const uint64_t slot = (uint64_t)owner_of(g, batch, world) * n_lib + lib;
-        const uint64_t src0 = p0 * ur, dst0 = (slot * cap_rows + o) * ur;
+        const uint64_t src0 = p0 * ur, dst0 = (slot_base ? slot_base[slot] / ub : slot * cap_rows * ur) + (uint64_t)o * ur;
         const uint64_t units = (uint64_t)n * ur;
         if (rb & 1) for (uint64_t i = threadIdx.x; i < units; i += blockDim.x) send[dst0 + i] = pool[src0 + i];
         else for (uint64_t i = threadIdx.x; i < units; i += blockDim.x)
@@ -448,9 +457,14 @@ __global__ __launch_bounds__(256) void xchg_pack_kernel(const uint8_t* pool, con
 
 // blocks 0 .. n_slots-1: row offsets of my gaps inside slot i (a slot holds MY gaps' rows of one source, in gap order);
 // block n_slots: merged pool_off (u64, n_gaps + 1) = scan over my gaps of the rows of all sources
+// counts of slot q: cnt + q * n_gaps, or — exact-size exchange, the counts travel inside the received buffer — u32[n_gaps] at byte
+// offset cnt_base[q] of `src`
+__device__ __forceinline__ const uint32_t* slot_counts(const uint32_t* cnt, const uint8_t* src, const unsigned long long* cnt_base, uint32_t q, uint32_t n_gaps) {
+    return cnt_base ? reinterpret_cast<const uint32_t*>(src + cnt_base[q]) : cnt + (uint64_t)q * n_gaps;
+}
 __global__ __launch_bounds__(1024) void merge_offsets_kernel(const uint32_t* cnt /* [n_slots][n_gaps] */, uint32_t n_slots, uint32_t n_gaps,
                                                              uint32_t rank, uint32_t world, uint32_t batch, uint32_t* src_off /* [n_slots][n_gaps] */,
-                                                             unsigned long long* moff) {
+                                                             unsigned long long* moff, const uint8_t* src, const unsigned long long* cnt_base) {
     __shared__ uint32_t s_w[20];
     const uint32_t i = blockIdx.x;
     unsigned long long carry = 0;
@@ -459,8 +473,8 @@ __global__ __launch_bounds__(1024) void merge_offsets_kernel(const uint32_t* cnt
         const bool mine = g < n_gaps && owner_of(g, batch, world) == rank;
         uint32_t n = 0;
         if (mine) {
-            if (i < n_slots) n = cnt[(uint64_t)i * n_gaps + g];
-            else for (uint32_t q = 0; q < n_slots; ++q) n += cnt[(uint64_t)q * n_gaps + g];
+            if (i < n_slots) n = slot_counts(cnt, src, cnt_base, i, n_gaps)[g];
+            else for (uint32_t q = 0; q < n_slots; ++q) n += slot_counts(cnt, src, cnt_base, q, n_gaps)[g];
         }
         uint32_t tot;
         const uint32_t ex = block_scan_excl(n, s_w, &tot);
@@ -479,8 +493,9 @@ __global__ __launch_bounds__(1024) void merge_offsets_kernel(const uint32_t* cnt
 __global__ __launch_bounds__(256) void merge_copy_kernel(const uint8_t* src, uint64_t cap_rows, const uint32_t* cnt, const uint32_t* src_off,
                                                          uint32_t n_lib, uint32_t n_ranks_src, uint32_t n_gaps, uint32_t rb, uint32_t rank,
                                                          uint32_t world, uint32_t batch, const unsigned long long* moff, uint8_t* merged,
-                                                         uint64_t merged_cap_rows, uint32_t* error) {
-    const uint32_t ur = (rb & 1) ? rb : rb / 2;
+                                                         uint64_t merged_cap_rows, uint32_t* error, const unsigned long long* slot_base,
+                                                         const unsigned long long* cnt_base) {
+    const uint32_t ur = (rb & 1) ? rb : rb / 2, ub = (rb & 1) ? 1u : 2u;
     if (blockIdx.x == 0 && threadIdx.x == 0 && moff[n_gaps] > merged_cap_rows) atomicOr(error, 0x80000000u);
     for (uint32_t g = blockIdx.x; g < n_gaps; g += gridDim.x) {
         if (owner_of(g, batch, world) != rank) continue;
@@ -488,15 +503,16 @@ __global__ __launch_bounds__(256) void merge_copy_kernel(const uint8_t* src, uin
         for (uint32_t l = 0; l < n_lib; ++l)
             for (uint32_t r = 0; r < n_ranks_src; ++r) {
                 const uint64_t slot = (uint64_t)r * n_lib + l;
-                uint32_t n = cnt[slot * n_gaps + g];
+                const uint32_t n_all = slot_counts(cnt, src, cnt_base, (uint32_t)slot, n_gaps)[g];
+                uint32_t n = n_all;
                 if (!n) continue;
                 if (at + n > merged_cap_rows) n = at < merged_cap_rows ? (uint32_t)(merged_cap_rows - at) : 0u;
-                const uint64_t src0 = (slot * cap_rows + src_off[slot * n_gaps + g]) * ur, dst0 = at * ur;
+                const uint64_t src0 = (slot_base ? slot_base[slot] / ub : slot * cap_rows * ur) + (uint64_t)src_off[slot * n_gaps + g] * ur, dst0 = at * ur;
                 const uint64_t units = (uint64_t)n * ur;
                 if (rb & 1) for (uint64_t i = threadIdx.x; i < units; i += blockDim.x) merged[dst0 + i] = src[src0 + i];
                 else for (uint64_t i = threadIdx.x; i < units; i += blockDim.x)
                     reinterpret_cast<uint16_t*>(merged)[dst0 + i] = reinterpret_cast<const uint16_t*>(src)[src0 + i];
-                at += cnt[slot * n_gaps + g];
+                at += n_all;
             }
     }
 }
@@ -655,31 +671,54 @@ int gf_pool_counts_dev(gf_ctx* ctx, const void* d_pool_off, size_t n_gaps, void*
     return GF_OK;
 }
 
-int gf_pools_pack_for_owners_dev(gf_ctx* ctx, const void* d_pool, const void* d_pool_off, size_t n_gaps, int read_len, int world,
-                                 int batch, int lib, int n_lib, void* d_send, size_t cap_rows, void* d_cnt, void* d_error) {
+static int pools_pack_for_owners(gf_ctx* ctx, const void* d_pool, const void* d_pool_off, size_t n_gaps, int read_len, int world,
+                                 int batch, int lib, int n_lib, void* d_send, size_t cap_rows, const void* d_slot_base, const void* d_slot_cap,
+                                 const void* d_cnt_base, void* d_cnt, void* d_error) {
     if (!ctx || !d_pool_off || !d_send || !d_cnt || !d_error || world < 1 || batch < 1 || n_lib < 1 || lib < 0 || lib >= n_lib ||
         read_len <= 0 || n_gaps > 0xFFFFFFF0ull || cap_rows > 0xFFFFFFFFull)
         return GF_E_INVAL;
     if (!n_gaps) return GF_OK;
     GF_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ensure(ctx, ctx->xchg_ws, n_gaps * 4 + 256))) return rc;
+    if ((rc = ensure(ctx, ctx->xchg_ws, n_gaps * 4 + 256 + (size_t)world * 8))) return rc;
     uint32_t* dst_off = (uint32_t*)ctx->xchg_ws.p;
     const uint32_t rb = (uint32_t)gf_packed_read_bytes(read_len);
     LaunchTimer tm(ctx, GF_KERNEL_POOL);
+    // (the header offsets of THIS library's slots: entries (d * n_lib + lib) of d_cnt_base, gathered into a dense [world] table on the device)
+    unsigned long long* hdr = nullptr;
+    if (d_cnt_base) {
+        hdr = (unsigned long long*)((uint8_t*)ctx->xchg_ws.p + ((n_gaps * 4 + 255) & ~(size_t)255));
+        GF_HIP(ctx, hipMemcpy2DAsync(hdr, 8, (const unsigned long long*)d_cnt_base + lib, (size_t)n_lib * 8, 8, (size_t)world, hipMemcpyDeviceToDevice,
+                                     ctx->stream));
+    }
     hipLaunchKernelGGL(xchg_send_offsets_kernel, dim3((unsigned)world), dim3(1024), 0, ctx->stream, (const unsigned long long*)d_pool_off,
-                       (uint32_t)n_gaps, (uint32_t)world, (uint32_t)batch, (uint32_t*)d_cnt, dst_off);
+                       (uint32_t)n_gaps, (uint32_t)world, (uint32_t)batch, (uint32_t*)d_cnt, dst_off, (uint8_t*)d_send, (const unsigned long long*)hdr);
     hipLaunchKernelGGL(xchg_pack_kernel, dim3((unsigned)std::min<size_t>(n_gaps, (size_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
                        (const uint8_t*)d_pool, (const unsigned long long*)d_pool_off, (uint32_t)n_gaps, rb, (uint32_t)world, (uint32_t)batch,
-                       (uint32_t)lib, (uint32_t)n_lib, dst_off, (uint8_t*)d_send, (uint64_t)cap_rows, (uint32_t*)d_error);
+                       (uint32_t)lib, (uint32_t)n_lib, dst_off, (uint8_t*)d_send, (uint64_t)cap_rows, (uint32_t*)d_error,
+                       (const unsigned long long*)d_slot_base, (const uint32_t*)d_slot_cap);
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
 }
 
-int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const void* d_cnt, int n_lib, int n_src_ranks, size_t n_gaps,
-                       int read_len, int rank, int world, int batch, void* d_merged, size_t merged_cap_rows, void* d_merged_off,
-                       void* d_error) {
-    if (!ctx || !d_src || !d_cnt || !d_merged_off || !d_error || (merged_cap_rows && !d_merged) || n_lib < 1 || n_src_ranks < 1 ||
+int gf_pools_pack_for_owners_dev(gf_ctx* ctx, const void* d_pool, const void* d_pool_off, size_t n_gaps, int read_len, int world,
+                                 int batch, int lib, int n_lib, void* d_send, size_t cap_rows, void* d_cnt, void* d_error) {
+    return pools_pack_for_owners(ctx, d_pool, d_pool_off, n_gaps, read_len, world, batch, lib, n_lib, d_send, cap_rows, nullptr, nullptr, nullptr,
+                                 d_cnt, d_error);
+}
+
+int gf_pools_pack_for_owners_v_dev(gf_ctx* ctx, const void* d_pool, const void* d_pool_off, size_t n_gaps, int read_len, int world,
+                                   int batch, int lib, int n_lib, void* d_send, const void* d_slot_base, const void* d_slot_cap,
+                                   const void* d_cnt_base, void* d_cnt, void* d_error) {
+    if (!d_slot_base || !d_slot_cap) return GF_E_INVAL;
+    return pools_pack_for_owners(ctx, d_pool, d_pool_off, n_gaps, read_len, world, batch, lib, n_lib, d_send, 0, d_slot_base, d_slot_cap, d_cnt_base,
+                                 d_cnt, d_error);
+}
+
+static int pools_merge(gf_ctx* ctx, const void* d_src, size_t cap_rows, const void* d_slot_base, const void* d_cnt, const void* d_cnt_base,
+                       int n_lib, int n_src_ranks, size_t n_gaps, int read_len, int rank, int world, int batch, void* d_merged,
+                       size_t merged_cap_rows, void* d_merged_off, void* d_error) {
+    if (!ctx || !d_src || (!d_cnt && !d_cnt_base) || !d_merged_off || !d_error || (merged_cap_rows && !d_merged) || n_lib < 1 || n_src_ranks < 1 ||
         world < 1 || rank < 0 || rank >= world || batch < 1 || read_len <= 0 || n_gaps > 0xFFFFFFF0ull || cap_rows > 0xFFFFFFFFull)
         return GF_E_INVAL;
     GF_HIP(ctx, hipSetDevice(ctx->device));
@@ -691,13 +730,31 @@ int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const vo
     const uint32_t rb = (uint32_t)gf_packed_read_bytes(read_len);
     LaunchTimer tm(ctx, GF_KERNEL_POOL);
     hipLaunchKernelGGL(merge_offsets_kernel, dim3(n_slots + 1), dim3(1024), 0, ctx->stream, (const uint32_t*)d_cnt, n_slots, (uint32_t)n_gaps,
-                       (uint32_t)rank, (uint32_t)world, (uint32_t)batch, src_off, (unsigned long long*)d_merged_off);
+                       (uint32_t)rank, (uint32_t)world, (uint32_t)batch, src_off, (unsigned long long*)d_merged_off, (const uint8_t*)d_src,
+                       (const unsigned long long*)d_cnt_base);
     hipLaunchKernelGGL(merge_copy_kernel, dim3((unsigned)std::min<size_t>(n_gaps, (size_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
                        (const uint8_t*)d_src, (uint64_t)cap_rows, (const uint32_t*)d_cnt, src_off, (uint32_t)n_lib, (uint32_t)n_src_ranks,
                        (uint32_t)n_gaps, rb, (uint32_t)rank, (uint32_t)world, (uint32_t)batch, (const unsigned long long*)d_merged_off,
-                       (uint8_t*)d_merged, (uint64_t)merged_cap_rows, (uint32_t*)d_error);
+                       (uint8_t*)d_merged, (uint64_t)merged_cap_rows, (uint32_t*)d_error, (const unsigned long long*)d_slot_base,
+                       (const unsigned long long*)d_cnt_base);
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
+}
+
+int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const void* d_cnt, int n_lib, int n_src_ranks, size_t n_gaps,
+                       int read_len, int rank, int world, int batch, void* d_merged, size_t merged_cap_rows, void* d_merged_off,
+                       void* d_error) {
+    if (!d_cnt) return GF_E_INVAL;
+    return pools_merge(ctx, d_src, cap_rows, nullptr, d_cnt, nullptr, n_lib, n_src_ranks, n_gaps, read_len, rank, world, batch, d_merged,
+                       merged_cap_rows, d_merged_off, d_error);
+}
+
+int gf_pools_merge_v_dev(gf_ctx* ctx, const void* d_src, const void* d_slot_base, const void* d_cnt_base, int n_lib, int n_src_ranks,
+                         size_t n_gaps, int read_len, int rank, int world, int batch, void* d_merged, size_t merged_cap_rows,
+                         void* d_merged_off, void* d_error) {
+    if (!d_slot_base || !d_cnt_base) return GF_E_INVAL;
+    return pools_merge(ctx, d_src, 0, d_slot_base, nullptr, d_cnt_base, n_lib, n_src_ranks, n_gaps, read_len, rank, world, batch, d_merged,
+                       merged_cap_rows, d_merged_off, d_error);
 }
 
 }  // extern "C"

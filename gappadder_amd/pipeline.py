@@ -201,9 +201,15 @@ class Pipeline:
             if lb.second_stream:
                 self._chk(lib.gf_stream_wait(h, lb.h2), "gf_stream_wait")
             ev0 = self._fixed_mark()
-            SH.all_gather_slots(lb.d_rows_all, lb.d_rows, self.backend)
-            SH.all_gather_slots(lb.d_rowgap_all, lb.d_row_gap, self.backend)
-            SH.all_gather_slots(lb.d_nrows_all, lb.d_cnt[CNT_ROWS:CNT_ROWS + 1], self.backend)
+            # ONE all-gather: rows (16 B each), their gaps (4 B each) and the row count travel as one packed slot per rank
+            # (lb.d_hop_pack: the table kernel writes rows and gaps straight into it), unpacked by three strided device copies
+            rc16, pb = lb.row_cap * 16, lb.hop_pack_bytes
+            lb.d_hop_pack[pb - 16:pb - 12].copy_(lb.d_cnt[CNT_ROWS:CNT_ROWS + 1].view(torch.uint8))
+            SH.all_gather_slots(lb.d_hop_all, lb.d_hop_pack, self.backend)
+            pk = lb.d_hop_all.view(world, pb)
+            lb.d_rows_all.view(world, rc16).copy_(pk[:, :rc16])
+            lb.d_rowgap_all.view(torch.uint8).view(world, lb.row_cap * 4).copy_(pk[:, rc16:rc16 + lb.row_cap * 4])
+            lb.d_nrows_all.view(torch.uint8).view(world, 4).copy_(pk[:, pb - 16:pb - 12])
             self._chk(lib.gf_second_hop_table_merge_dev(h, lb.d_rows_all.data_ptr(), lb.d_rowgap_all.data_ptr(), lb.d_nrows_all.data_ptr(), world,
                                                         lb.row_cap, lb.d_rows_u.data_ptr(), lb.d_rowgap_u.data_ptr(), world * lb.row_cap,
                                                         lb.d_nrows_u.data_ptr()), "gf_second_hop_table_merge_dev")
@@ -281,8 +287,13 @@ class Pipeline:
                 lb.d_rows_u = self._u8(world * lb.row_cap * 16)
                 lb.d_rowgap_u = torch.empty(world * lb.row_cap, dtype=torch.int32, device=dev)
                 lb.d_nrows_u = torch.zeros(4, dtype=torch.int32, device=dev)
-            lb.d_rows = self._u8(lb.row_cap * 16)
-            lb.d_row_gap = torch.empty(lb.row_cap, dtype=torch.int32, device=dev)
+            # (rows, their gaps and — multi-rank runs — the row count in ONE buffer: the slot of the second hop's single all-gather)
+            lb.hop_pack_bytes = lb.row_cap * 20 + 16
+            lb.d_hop_pack = torch.zeros(lb.hop_pack_bytes, dtype=torch.uint8, device=dev)
+            lb.d_rows = lb.d_hop_pack[:lb.row_cap * 16]
+            lb.d_row_gap = lb.d_hop_pack[lb.row_cap * 16:lb.row_cap * 20].view(torch.int32)
+            if self.multi:
+                lb.d_hop_all = torch.zeros(world * lb.hop_pack_bytes, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
 
         def sizing_pools():
@@ -342,7 +353,15 @@ class Pipeline:
             tot = torch.stack([per_dst[:, r].sum() for r in range(world)]).to(self.coll_dev)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             self.merged_cap = max(4096, int(1.25 * int(tot.max())) + 1024)
-            self.xchg = SH.OwnerExchange(world, n_lib, n_gaps, self.slot_cap, rb, dev, self.backend)
+            # exact split sizes (default): rows per (source, owner, library) from this sizing pass, the same table on every rank — one
+            # all-to-all per step, nothing padded, the counts inside it.  GF_XCHG=slots: equal-sized slots padded to 1.25 x the largest
+            # block + an all-gather of the counts (the form of rounds 2-5)
+            self.exact_exchange = os.environ.get("GF_XCHG", "exact") != "slots"
+            if self.exact_exchange:
+                self.xchg_rows = SH.exchange_rows_table(per_dst, self.coll_dev, self.backend)
+                self.xchg = SH.ExactOwnerExchange(world, self.rank, n_lib, n_gaps, self.xchg_rows, rb, dev, self.backend)
+            else:
+                self.xchg = SH.OwnerExchange(world, n_lib, n_gaps, self.slot_cap, rb, dev, self.backend)
         else:
             self.slot_cap = self.lib_cap
             self.merged_cap = max(4096, int(1.25 * sum(self.rows_lib)) + 1024)
@@ -414,8 +433,20 @@ class Pipeline:
                 self._chk(lib.gf_pools_merge_dev(h, recv.data_ptr(), cap, all_cnt.data_ptr(), n_lib, self.world, n_gaps, L, self.rank, self.world,
                                                  self.batch, self.d_merged.data_ptr(), self.merged_cap, self.d_moff.data_ptr(), self.d_xerr.data_ptr()),
                           "gf_pools_merge_dev")
+            def pack_v(l, send, slot_base, slot_cap, cnt_base, cnt):
+                self._chk(lib.gf_pools_pack_for_owners_v_dev(h, self.pool_ptr[l], self.libs[l].d_pool_off.data_ptr(), n_gaps, L, self.world, self.batch,
+                                                             l, n_lib, send.data_ptr(), slot_base.data_ptr(), slot_cap.data_ptr(), cnt_base.data_ptr(),
+                                                             cnt.data_ptr(), self.d_xerr.data_ptr()), "gf_pools_pack_for_owners_v_dev")
+
+            def merge_v(recv, slot_base, cnt_base):
+                self._chk(lib.gf_pools_merge_v_dev(h, recv.data_ptr(), slot_base.data_ptr(), cnt_base.data_ptr(), n_lib, self.world, n_gaps, L, self.rank,
+                                                   self.world, self.batch, self.d_merged.data_ptr(), self.merged_cap, self.d_moff.data_ptr(),
+                                                   self.d_xerr.data_ptr()), "gf_pools_merge_v_dev")
             ev0 = self._fixed_mark()
-            self.xchg.run(pack, merge)
+            if self.exact_exchange:
+                self.xchg.run(pack_v, merge_v)
+            else:
+                self.xchg.run(pack, merge)
             self._fixed_span("owner_exchange", ev0)
             self.asm_ptr, self.asm_off, self.asm_rows = self.d_merged.data_ptr(), self.d_moff.data_ptr(), self.merged_cap
         if self.kk and self.assemble_in_step:

@@ -1,7 +1,8 @@
 """Multi-GPU layout of the hot path: one process per GPU, READS sharded (rank r owns a contiguous range of
 read pairs), gaps / flanks replicated, every gap ASSEMBLED ONCE by its owner rank from the recruits of all ranks (the reference
-maps each gap to one Pool task, assemble_gaps.py:296-299).  `OwnerExchange` is the one exchange step on the data path — device
-pack by owner, all-gather of the per-gap counts, equal-slot all-to-all, device merge — and `gather_bytes` the final gather of
+maps each gap to one Pool task, assemble_gaps.py:296-299).  `ExactOwnerExchange` is the one exchange step on the data path — device
+pack by owner, ONE all-to-all with exact split sizes that also carries the per-gap counts, device merge (`OwnerExchange`: the older
+form with equal-sized padded slots and an all-gather of the counts, kept as an option) — and `gather_bytes` the final gather of
 the closed sequences on rank 0 (north_star).  Backend-agnostic: `nccl` (= RCCL) on GPUs, `gloo` in the CPU tests and in the
 one-GPU multi-rank mode of bench.py."""
 import numpy as np
@@ -88,6 +89,71 @@ class OwnerExchange:
         all_gather_slots(self.all_cnt, self.lib_cnt, self.backend)
         all_to_all_slots(self.recv, self.send, self.backend)
         merge(self.recv, self.slot_cap, self.all_cnt)
+
+
+class ExactOwnerExchange:
+    """The same exchange with EXACT split sizes ("all-to-all-v of the recruited rows") and ONE collective: the chunk a
+    rank sends to peer d is  [per library: u32 counts of every gap (zero where d is not the owner)] [per library: the rows of d's gaps]
+    and holds exactly the rows the sizing pass found for (this rank, d, library) — `rows[src][dst][lib]`, the same table on every
+    rank —, so `all_to_all_single` runs with split-size lists that are host constants (no host sizes inside the step, no host sync),
+    nothing is padded, and the per-gap counts ride in the same collective instead of an all-gather of their own.  A step that produces
+    more rows for a slot than the table gives it sets the pack kernel's error bit (Pipeline.fetch raises); fewer rows leave the tail of
+    the slot unused (the counts say how many are valid).  Layout tables (device, one entry per slot s = peer * n_lib + lib):
+    `slot_base` (byte offset of the slot's rows), `slot_cap` (rows), `cnt_base` (byte offset of its counts) — for the send and for
+    the receive buffer; gf_pools_pack_for_owners_v_dev / gf_pools_merge_v_dev take them (the CPU test their numpy definitions)."""
+
+    def __init__(self, world, rank, n_lib, n_gaps, rows, row_bytes, device, backend):
+        rows = np.asarray(rows, dtype=np.int64).reshape(world, world, n_lib)
+        self.world, self.rank, self.n_lib, self.n_gaps, self.rb, self.backend = world, rank, n_lib, n_gaps, row_bytes, backend
+        self.rows = rows
+        hdr = n_lib * n_gaps * 4
+
+        def chunk(src, dst):      # bytes of the chunk src -> dst (a multiple of 16)
+            return (hdr + int(rows[src, dst].sum()) * row_bytes + 15) // 16 * 16
+
+        def tables(peers_rows, sizes):      # peers_rows[p][l] = rows of slot (p, l); sizes[p] = bytes of peer p's chunk
+            base, cap, cnt, at = [], [], [], 0
+            for p in range(world):
+                o = at + hdr
+                for l in range(n_lib):
+                    base.append(o)
+                    cap.append(int(peers_rows[p][l]))
+                    cnt.append(at + l * n_gaps * 4)
+                    o += int(peers_rows[p][l]) * row_bytes
+                at += sizes[p]
+            return (torch.tensor(base, dtype=torch.int64, device=device), torch.tensor(cap, dtype=torch.int32, device=device),
+                    torch.tensor(cnt, dtype=torch.int64, device=device))
+        self.in_splits = [chunk(rank, d) for d in range(world)]
+        self.out_splits = [chunk(s_, rank) for s_ in range(world)]
+        self.send = torch.zeros(max(16, sum(self.in_splits)), dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(max(16, sum(self.out_splits)), dtype=torch.uint8, device=device)
+        self.send_base, self.send_cap, self.send_cnt = tables(rows[rank], self.in_splits)
+        self.recv_base, self.recv_cap, self.recv_cnt = tables(rows[:, rank], self.out_splits)
+        self.lib_cnt = torch.zeros(n_lib * n_gaps, dtype=torch.int32, device=device)            # [n_lib][n_gaps], this rank's rows (by-product of the pack)
+        self.bytes_sent = sum(b for d, b in enumerate(self.in_splits) if d != rank)             # per step, to the other ranks
+        self.header_bytes = hdr
+
+    def run(self, pack, merge):
+        """pack(lib, send, slot_base, slot_cap, cnt_base, lib_cnt_of_that_library) per library; merge(recv, slot_base, cnt_base)."""
+        for l in range(self.n_lib):
+            pack(l, self.send, self.send_base, self.send_cap, self.send_cnt, self.lib_cnt[l * self.n_gaps:(l + 1) * self.n_gaps])
+        if self.backend == "nccl":
+            dist.all_to_all_single(self.recv, self.send, output_split_sizes=self.out_splits, input_split_sizes=self.in_splits)
+        else:
+            r_ = torch.empty(self.recv.shape, dtype=torch.uint8)
+            dist.all_to_all_single(r_, self.send.cpu(), output_split_sizes=self.out_splits, input_split_sizes=self.in_splits)
+            self.recv.copy_(r_)
+        merge(self.recv, self.recv_base, self.recv_cnt)
+
+
+def exchange_rows_table(per_dst_local, coll_device, backend):
+    """per_dst_local: int64 [n_lib, world] = rows this rank's sizing pass found per (library, owner rank).  All-gathered:
+    int64 numpy [src][dst][lib], the same on every rank (a one-off of the sizing pass, outside the step)."""
+    world = dist.get_world_size()
+    mine = per_dst_local.to(torch.int64).t().contiguous().to(coll_device)          # [dst][lib]
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return torch.stack(parts).cpu().numpy()
 
 
 def encode_contigs(records):

@@ -430,6 +430,19 @@ int gf_pools_merge_dev(gf_ctx* ctx, const void* d_src, size_t cap_rows, const vo
                        size_t n_gaps, int read_len, int rank, int world, int batch, void* d_merged, size_t merged_cap_rows,
                        void* d_merged_off, void* d_error);
 
+/* The same two steps for an EXACT-SIZE exchange (all-to-all-v of the recruited rows): the send / receive buffer is one
+ * byte array of per-peer chunks of different sizes, described by device tables with one entry per slot s = peer * n_lib + lib:
+ * d_slot_base[s] (u64) = byte offset of the slot's first row (even when the row size is even), d_slot_cap[s] (u32) = its rows,
+ * d_cnt_base[s] (u64, multiple of 4) = byte offset of the slot's per-gap counts u32[n_gaps] INSIDE the same buffer — pack writes them
+ * there (zero for gaps the peer does not own), merge reads them from there: the counts ride in the all-to-all, no all-gather of
+ * counts.  Error bits as above (bit 30: a step produced more rows for a slot than the table gives it). */
+int gf_pools_pack_for_owners_v_dev(gf_ctx* ctx, const void* d_pool_packed, const void* d_pool_off, size_t n_gaps, int read_len,
+                                   int world, int batch, int lib, int n_lib, void* d_send, const void* d_slot_base,
+                                   const void* d_slot_cap, const void* d_cnt_base_or_null, void* d_cnt, void* d_error);
+int gf_pools_merge_v_dev(gf_ctx* ctx, const void* d_src, const void* d_slot_base, const void* d_cnt_base, int n_lib,
+                         int n_src_ranks, size_t n_gaps, int read_len, int rank, int world, int batch, void* d_merged,
+                         size_t merged_cap_rows, void* d_merged_off, void* d_error);
+
 /* ---- §8f-1 on the device: flank anchoring (ContigsSelection, pick_contigs.py:64-358, with exact anchors instead of
  * `bwa mem -T {score}`: the last / first anchor_len bases of the left / right flank given to gf_set_gaps; 8 <= anchor_len <= 32;
  * the reference's scores are 30, then 15: assemble_gaps.py:336, 365).  Per contig the reference's pair choice (:149-297) on the

@@ -99,7 +99,48 @@ def _np_merge(recv, slot_cap, all_cnt, n_lib, world, n_gaps, rank, batch, rb):
     return (np.concatenate(out) if out else np.zeros((0, rb), np.uint8)), moff
 
 
-def _exchange_worker(rank, world, port, n_pairs, batch, q):
+def _np_pack_for_owners_v(rows, off, world, batch, lib, n_lib, send, slot_base, slot_cap, cnt_base, cnt, rb):
+    """Definition of gf_pools_pack_for_owners_v_dev: slot s = owner * n_lib + lib starts at BYTE slot_base[s] of the send buffer and
+    holds slot_cap[s] rows; its per-gap counts (zero where the peer is not the owner) go to u32[n_gaps] at byte cnt_base[s]."""
+    n_gaps = len(off) - 1
+    sv = send.numpy()
+    fill = [0] * world
+    for d in range(world):
+        hc = sv[int(cnt_base[d * n_lib + lib]):int(cnt_base[d * n_lib + lib]) + 4 * n_gaps].view(np.uint32)
+        hc[:] = 0
+    for g in range(n_gaps):
+        o = (g // batch) % world
+        n = int(off[g + 1] - off[g])
+        s_ = o * n_lib + lib
+        assert fill[o] + n <= int(slot_cap[s_])
+        at = int(slot_base[s_]) + fill[o] * rb
+        sv[at:at + n * rb] = rows[int(off[g]):int(off[g + 1])].reshape(-1)
+        fill[o] += n
+        cnt[g] = n
+        sv[int(cnt_base[s_]):int(cnt_base[s_]) + 4 * n_gaps].view(np.uint32)[g] = n
+
+
+def _np_merge_v(recv, slot_base, cnt_base, n_lib, world, n_gaps, rank, batch, rb):
+    """Definition of gf_pools_merge_v_dev: the counts are read from the received buffer itself."""
+    rv = recv.numpy()
+    cnt = np.stack([rv[int(cnt_base[s_]):int(cnt_base[s_]) + 4 * n_gaps].view(np.uint32) for s_ in range(world * n_lib)]).reshape(world, n_lib, n_gaps)
+    pos = np.zeros((world, n_lib), dtype=np.int64)
+    out, moff = [], [0]
+    for g in range(n_gaps):
+        n = 0
+        if (g // batch) % world == rank:
+            for l in range(n_lib):
+                for r in range(world):
+                    c = int(cnt[r, l, g])
+                    at = int(slot_base[r * n_lib + l]) + int(pos[r, l]) * rb
+                    out.append(rv[at:at + c * rb].reshape(c, rb).copy())
+                    pos[r, l] += c
+                    n += c
+        moff.append(moff[-1] + n)
+    return (np.concatenate(out) if out else np.zeros((0, rb), np.uint8)), moff
+
+
+def _exchange_worker(rank, world, port, n_pairs, batch, q, exact=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -122,14 +163,31 @@ def _exchange_worker(rank, world, port, n_pairs, batch, q):
         libs.append((rows, np.cumsum([0] + [len(p) for p in pools]).astype(np.int64)))
     n_gaps = len(gaps)
     assert batch == SH.owner_batch(n_gaps, world, batch)
-    x = SH.OwnerExchange(world, n_lib, n_gaps, 512, rb, torch.device("cpu"), "gloo")     # the class bench.py's step() drives
     res = {}
+    if exact:
+        # the sizing pass of Pipeline.prepare(): rows per (library, owner) on this rank, all-gathered into the [src][dst][lib] table
+        owner = SH.gap_owner(n_gaps, world, batch)
+        per_dst = torch.zeros(n_lib, world, dtype=torch.int64)
+        for l in range(n_lib):
+            per_dst[l].index_add_(0, owner, torch.from_numpy(np.diff(libs[l][1])))
+        table = SH.exchange_rows_table(per_dst, torch.device("cpu"), "gloo")
+        x = SH.ExactOwnerExchange(world, rank, n_lib, n_gaps, table, rb, torch.device("cpu"), "gloo")     # the class Pipeline.step() drives
+        assert sum(x.in_splits) == len(x.send) and all(b % 16 == 0 for b in x.in_splits + x.out_splits)
+        assert int(table[rank].sum()) * rb + world * x.header_bytes <= sum(x.in_splits) < int(table[rank].sum()) * rb + world * (x.header_bytes + 16)   # nothing padded
 
-    def pack(l, send, cap, cnt):
-        _np_pack_for_owners(libs[l][0], libs[l][1], world, batch, l, n_lib, send, cap, cnt.numpy(), rb)
+        def pack(l, send, slot_base, slot_cap, cnt_base, cnt):
+            _np_pack_for_owners_v(libs[l][0], libs[l][1], world, batch, l, n_lib, send, slot_base.numpy(), slot_cap.numpy(), cnt_base.numpy(), cnt.numpy(), rb)
 
-    def merge(recv, cap, all_cnt):
-        res["m"] = _np_merge(recv, cap, all_cnt, n_lib, world, n_gaps, rank, batch, rb)
+        def merge(recv, slot_base, cnt_base):
+            res["m"] = _np_merge_v(recv, slot_base.numpy(), cnt_base.numpy(), n_lib, world, n_gaps, rank, batch, rb)
+    else:
+        x = SH.OwnerExchange(world, n_lib, n_gaps, 512, rb, torch.device("cpu"), "gloo")     # the equal-slot form (GF_XCHG=slots)
+
+        def pack(l, send, cap, cnt):
+            _np_pack_for_owners(libs[l][0], libs[l][1], world, batch, l, n_lib, send, cap, cnt.numpy(), rb)
+
+        def merge(recv, cap, all_cnt):
+            res["m"] = _np_merge(recv, cap, all_cnt, n_lib, world, n_gaps, rank, batch, rb)
     x.run(pack, merge)
     x.run(pack, merge)                                       # a second step reuses the buffers
     merged, moff = res["m"]
@@ -138,11 +196,16 @@ def _exchange_worker(rank, world, port, n_pairs, batch, q):
     dist.destroy_process_group()
 
 
-def test_owner_exchange_gives_every_gap_one_owner_with_the_single_rank_pool():
-    """sharding.OwnerExchange — the exchange bench.py's step() runs at N > 1 (pack by owner, all-gather of the counts, equal-slot
-    all-to-all, merge) — on three gloo ranks with the kernels' definitions in numpy: every gap's merged pool sits at
-    exactly one rank (assemble_gaps.py:296-299: one owner per gap) and equals the pool a single process builds from all reads of both
-    libraries, libraries in order."""
+import pytest
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_owner_exchange_gives_every_gap_one_owner_with_the_single_rank_pool(exact):
+    """sharding.ExactOwnerExchange — the exchange Pipeline.step() runs at N > 1: pack by owner, ONE all-to-all with exact split sizes
+    (all-to-all-v) that also carries the per-gap counts, merge — and sharding.OwnerExchange, the older equal-slot form
+    with an all-gather of the counts (GF_XCHG=slots), on three gloo ranks with the kernels' definitions in numpy: every gap's merged
+    pool sits at exactly one rank (assemble_gaps.py:296-299: one owner per gap) and equals the pool a single process builds from all
+    reads of both libraries, libraries in order."""
     sys.path.insert(0, ROOT)
     from gappadder_amd import sharding as SH
     from oracle import c_oracle as CO
@@ -150,7 +213,7 @@ def test_owner_exchange_gives_every_gap_one_owner_with_the_single_rank_pool():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n_pairs, batch, q)) for r in range(world)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n_pairs, batch, q, exact)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict()

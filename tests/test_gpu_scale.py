@@ -315,6 +315,43 @@ def test_two_rank_owner_assembly_equals_the_single_process_run(tmp_path, config,
     assert abs(a["gaps_per_s"] * a["ms_per_step"] - b["gaps_per_s"] * b["ms_per_step"]) < 1e-3 * a["gaps_per_s"] * a["ms_per_step"]   # same gaps, counted once
 
 
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()       # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: one RCCL rank per GPU (the pool's boxes have one; the test runs the day a box has two)")
+@pytest.mark.parametrize("config,extra", [("C2", ["--reads", "6000000"]), ("C5", ["--reads", "4000000", "--mp-reads", "2000000"])])
+def test_two_rank_rccl_equals_single_process(tmp_path, config, extra):
+    """The real multi-GPU path: two ranks, ONE GPU EACH, backend `nccl` (= RCCL over xGMI) — the second hop's packed all-gather, the
+    exact-size all-to-all of the owner exchange, the all-reduces of the results and the final gather on device tensors.  Same contigs,
+    pools and closed gaps as the single-process run over all reads (one owner per gap, assemble_gaps.py:296-299)."""
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    argv = ["--config", config, "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras"] + extra
+    a = _bench(argv + ["--dump-contigs", one])
+    b = _bench(argv + ["--dump-contigs", two], env_extra={"GF_BENCH_BACKEND": "nccl", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, nproc=2)
+    ja, jb = json.load(open(one)), json.load(open(two))
+    assert ja["contigs"] == jb["contigs"] and len(ja["contigs"]) > 100 and ja["gaps_closed"] == jb["gaps_closed"]
+    assert a["counts"]["assembled_pool_reads"] == b["counts"]["assembled_pool_reads"]
+    assert a["counts"]["gaps_closed_correct"] == b["counts"]["gaps_closed_correct"]
+    assert b["ranks"] == 2 and b["n_gpus"] == 2 and not b["functional_mode"] and b["scaling"] == "strong" and "RCCL" in b["config"]["collectives"]
+    assert b["fixed_ms"]["second_hop_union"] > 0 and b["fixed_ms"]["owner_exchange"] > 0 and b["final_gather_ms"] >= 0
+
+
+def test_exact_size_exchange_equals_the_padded_slots(tmp_path):
+    """The owner exchange with exact split sizes and the counts inside the one all-to-all (default) against the equal-slot form with
+    its all-gather of counts (GF_XCHG=slots), two ranks on this box's GPU over gloo: same contigs; the exact form sends fewer bytes."""
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    argv = ["--config", "C5", "--reads", "4000000", "--mp-reads", "2000000", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras"]
+    env = {"GF_BENCH_BACKEND": "gloo", "GF_BENCH_ONE_GPU": "1"}
+    a = _bench(argv + ["--dump-contigs", one], env_extra=env, nproc=2)
+    b = _bench(argv + ["--dump-contigs", two], env_extra=dict(env, GF_XCHG="slots"), nproc=2)
+    assert json.load(open(one))["contigs"] == json.load(open(two))["contigs"] and a["counts"] == b["counts"]
+    xa, xb = a["exchange"], b["exchange"]
+    assert xa["form"].startswith("exact") and xb["form"].startswith("equal")
+    assert 0 < xa["bytes_sent_per_rank_and_step"] < xb["bytes_sent_per_rank_and_step"] and xa["collectives_per_step"] < xb["collectives_per_step"]
+
+
 @pytest.mark.parametrize("config,extra", [("C2", ["--reads", "6000000"]), ("C5", ["--reads", "4000000", "--mp-reads", "2000000"])])
 def test_rccl_branch_runs_at_world_one_and_changes_nothing(tmp_path, config, extra):
     """A one-GPU box cannot run two RCCL ranks, but it can run ONE: GF_BENCH_FORCE_EXCHANGE=1 takes the multi-rank code path — process
