@@ -32,6 +32,10 @@ KIND_CLIP, KIND_DISCORDANT, KIND_UNMAP, KIND_LOWMAPQ = 0, 1, 2, 3
 KIND_NAMES = {KIND_CLIP: "clip", KIND_DISCORDANT: "discordant", KIND_UNMAP: "unmap"}
 KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_SYNTH, KERNEL_COUNT, KERNEL_VERIFY, KERNEL_INGEST, KERNEL_PICK, KERNEL_MERGE = range(11)
 
+# words of the merge round's statistics (gf_merge_open_gaps_dev, u32[32])
+MG_N_PRE, MG_N_SETS, MG_SKIPPED, MG_N_PAIRS, MG_QC_FLAGS, MG_N_JOBS, MG_ERR, MG_N0, MG_N_EDGES, MG_SETS_WITH_JOBS = range(10)
+MG_WORDS = 32
+
 _lib = None
 
 
@@ -117,6 +121,8 @@ def lib():
         "gf_overlap_evaluate_dev": (i32, [vp, vp, vp, vp, vp, sz, vp, vp]),
         "gf_pick_anchored_dev": (i32, [vp, vp, vp, sz, vp, i32, vp, vp]),
         "gf_pick_anchored2_dev": (i32, [vp, vp, vp, sz, vp, i32, i32, vp, vp]),
+        "gf_pick_anchored2_from_dev": (i32, [vp, vp, vp, sz, vp, i32, i32, vp, vp, vp]),
+        "gf_merge_open_gaps_dev": (i32, [vp, vp, vp, sz, vp, vp, sz, vp, sz, vp, i32, i32, vp]),
         "gf_count_kmers": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp, sz, szp]),
         "gf_pool_keys_reset": (i32, [vp, vp]),
         "gf_pool_keys_from_screen_dev": (i32, [vp, vp, vp, sz, i32, vp, sz, vp]),

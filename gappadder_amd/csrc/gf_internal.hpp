@@ -133,7 +133,7 @@ struct gf_ctx {
     size_t low_b1 = 0, low_b2 = 0;
 
     // scratch
-    gf::DevBuf cand, cand2, part_ws, tag_stage, verify_stage, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, asm_jump, asm_big, rowgap, pool_ws, xchg_ws, xchg_ws2, counters, stage_in, stage_out, stage_aux, table;
+    gf::DevBuf cand, cand2, part_ws, tag_stage, verify_stage, bam_stream, bam_recs, asm_table, asm_surv, asm_nodes, asm_jump, asm_big, rowgap, pool_ws, xchg_ws, xchg_ws2, merge_ws, counters, stage_in, stage_out, stage_aux, table;
     size_t bam_n_recs = 0;       // alignment records gf_bam_pack left in bam_recs (for gf_tag_*_bam)
     size_t bam_stream_len = 0;   // inflated BAM bytes gf_bgzf_inflate left in bam_stream
     // timing

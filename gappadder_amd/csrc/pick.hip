@@ -45,6 +45,7 @@ struct PickParams {
     uint32_t n_gaps, a_s, a_l;
     unsigned long long* gap_best;
     uint32_t* n_closed;
+    const uint32_t* first;     // or null: only the contigs from *first on (the merged contigs a merge round appended)
 };
 
 __device__ __forceinline__ uint32_t pick_span(const bool* any, const uint32_t* mn, const uint32_t* mx, uint32_t fl, uint32_t a, uint32_t* orient) {
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void pick_anchor_kernel(PickParams P) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t a = P.a_s, al = P.a_l, ext = P.anc_l ? al - a : 0;
-    for (uint32_t ci = wave; ci < n; ci += n_waves) {
+    for (uint32_t ci = (P.first ? *P.first : 0u) + wave; ci < n; ci += n_waves) {
         const gf_contig c = P.contigs[ci];
         if (c.gap >= P.n_gaps || c.length < 2 * a) continue;
         const uint8_t* as = P.anc_s + (uint64_t)c.gap * ANCHOR_ROW;
@@ -174,8 +175,8 @@ static int anchor_table(gf_ctx* ctx, int anchor_len, const uint8_t** out) {
     return GF_OK;
 }
 
-int gf_pick_anchored2_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
-                          int anchor_len, int anchor_len_short, void* d_gap_best, void* d_n_closed) {
+static int pick_anchored2(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
+                          int anchor_len, int anchor_len_short, const void* d_first, void* d_gap_best, void* d_n_closed) {
     if (!ctx || !d_contigs || !d_n_contigs || !d_seq || !d_gap_best || !d_n_closed || anchor_len < 8 || anchor_len > ANCHOR_MAX ||
         contig_cap > 0xFFFFFFFFull || (anchor_len_short && (anchor_len_short < 8 || anchor_len_short >= anchor_len)))
         return GF_E_INVAL;
@@ -199,10 +200,22 @@ int gf_pick_anchored2_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_co
     P.n_gaps = (uint32_t)ng;
     P.gap_best = (unsigned long long*)d_gap_best;
     P.n_closed = (uint32_t*)d_n_closed;
+    P.first = (const uint32_t*)d_first;
     LaunchTimer tm(ctx, GF_KERNEL_PICK);
     hipLaunchKernelGGL(pick_anchor_kernel, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, P);
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
+}
+
+int gf_pick_anchored2_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
+                          int anchor_len, int anchor_len_short, void* d_gap_best, void* d_n_closed) {
+    return pick_anchored2(ctx, d_contigs, d_n_contigs, contig_cap, d_seq, anchor_len, anchor_len_short, nullptr, d_gap_best, d_n_closed);
+}
+
+int gf_pick_anchored2_from_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
+                               int anchor_len, int anchor_len_short, const void* d_first, void* d_gap_best, void* d_n_closed) {
+    if (!d_first) return GF_E_INVAL;
+    return pick_anchored2(ctx, d_contigs, d_n_contigs, contig_cap, d_seq, anchor_len, anchor_len_short, d_first, d_gap_best, d_n_closed);
 }
 
 int gf_pick_anchored_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,

@@ -285,6 +285,69 @@ class GapFill:
                   "gf_overlap_evaluate")
         return out
 
+    def merge_round(self, contig_sets, params=None, kmer_len_quick=10, max_set=128, open_gaps=None):
+        """The contig-merge round of the step (gf_merge_open_gaps_dev) on contig sets given from the host: contig_sets[g] = the contigs
+        of gap g; every gap counts as open unless open_gaps (booleans) says otherwise.  Returns (per gap the merged sequences in record
+        order, stats dict).  A test / tool entry: the pipeline calls the device function on the step's own contig list."""
+        n_gaps = len(contig_sets)
+        flat = [(g, c) for g, cs in enumerate(contig_sets) for c in cs]
+        n0 = len(flat)
+        cap = n0 + 4096 + 4 * n0
+        ctg = np.zeros(cap, dtype=B.CONTIG)
+        off = 0
+        for i, (g, c) in enumerate(flat):
+            ctg[i] = (g, 31, 29, max(1, len(c) - 28), len(c), 0, 0, off)
+            off += len(c)
+        blob = np.frombuffer("".join(c for _, c in flat).encode(), dtype=np.uint8)
+        seq_cap = off + (1 << 20) + 8 * off
+        best = np.zeros(max(1, n_gaps), dtype=np.uint64)
+        if open_gaps is not None:
+            best[:n_gaps] = [0 if o else 1 for o in open_gaps]
+        cnt = np.zeros(4, dtype=np.uint32)
+        cnt[0] = n0
+        cnt[2:4] = np.array([off], dtype=np.uint64).view(np.uint32)
+        pr = np.zeros(1, dtype=B.OVL_PARAMS)
+        p7 = tuple(self.MERGER_PARAMS if params is None else params)
+        pr[0] = p7[:7] + (0.0,)
+        bufs = []
+
+        def dev(nbytes, src=None):
+            p_ = C.c_void_p()
+            self._chk(self._L.gf_dev_alloc(self._h, max(64, int(nbytes)), C.byref(p_)), "gf_dev_alloc")
+            bufs.append(p_)
+            if src is not None and src.nbytes:
+                self._chk(self._L.gf_memcpy_h2d(self._h, p_, B._p(src), src.nbytes), "gf_memcpy_h2d")
+            return p_
+        try:
+            d_ctg, d_seq = dev(cap * 32, ctg[:max(1, n0)]), dev(seq_cap, blob)
+            d_cnt, d_best, d_stats = dev(16, cnt), dev(best.nbytes, best), dev(4 * B.MG_WORDS)
+            self._chk(self._L.gf_merge_open_gaps_dev(self._h, d_ctg, d_cnt, cap, d_seq, C.c_void_p(d_cnt.value + 8), seq_cap, d_best, n_gaps, B._p(pr),
+                                                     kmer_len_quick, max_set, d_stats), "gf_merge_open_gaps_dev")
+            self.sync()
+            st = np.zeros(B.MG_WORDS, dtype=np.uint32)
+            self._chk(self._L.gf_memcpy_d2h(self._h, B._p(st), d_stats, st.nbytes), "gf_memcpy_d2h")
+            self._chk(self._L.gf_memcpy_d2h(self._h, B._p(cnt), d_cnt, cnt.nbytes), "gf_memcpy_d2h")
+            n1, sl = int(cnt[0]), int(cnt[2:4].view(np.uint64)[0])
+            stats = {"gaps_tried": int(st[B.MG_N_SETS]), "gaps_skipped_large": int(st[B.MG_SKIPPED]), "pairs": int(st[B.MG_N_PAIRS]), "edges": int(st[B.MG_N_EDGES]),
+                     "new_contigs": int(st[B.MG_N_JOBS]), "gaps_with_new_contigs": int(st[B.MG_SETS_WITH_JOBS]), "error_bits": int(st[B.MG_ERR]),
+                     "prefilter_flags": int(st[B.MG_QC_FLAGS]), "contigs_before": int(st[B.MG_N0])}
+            if st[B.MG_ERR] or n1 > cap or sl > seq_cap:
+                raise RuntimeError("merge round: capacity flags %#x (contigs %d / %d, bases %d / %d)" % (int(st[B.MG_ERR]), n1, cap, sl, seq_cap))
+            out = [[] for _ in range(n_gaps)]
+            if n1 > n0:
+                new = np.zeros(n1 - n0, dtype=B.CONTIG)
+                self._chk(self._L.gf_memcpy_d2h(self._h, B._p(new), C.c_void_p(d_ctg.value + 32 * n0), new.nbytes), "gf_memcpy_d2h")
+                sq = np.zeros(max(1, sl), dtype=np.uint8)
+                self._chk(self._L.gf_memcpy_d2h(self._h, B._p(sq), d_seq, sl), "gf_memcpy_d2h")
+                sb = sq.tobytes()
+                for c in new:
+                    assert int(c["k"]) == 0 and int(c["kv"]) == 0
+                    out[int(c["gap"])].append(sb[int(c["seq_off"]):int(c["seq_off"]) + int(c["length"])].decode())
+            return out, stats
+        finally:
+            for p_ in bufs:
+                self._L.gf_dev_free(self._h, p_)
+
     # ---- timing -------------------------------------------------------------------------------------
     def timing(self, on=True):
         self._chk(self._L.gf_timing_enable(self._h, 1 if on else 0), "gf_timing_enable")

@@ -298,3 +298,107 @@ def test_a_gap_that_only_the_bridging_high_quality_reads_close(gf, tmp_path):
     assert res["bridging_reads"] == 1 and res["closed"] == 1, res
     picked = open(wf + "picked_seqs.fa").read().split("\n")
     assert picked[1] in (g[395:1006], g[394:1005])
+
+
+def _oracle_round(contig_sets, max_set=128):
+    """What the merge round must append per gap: the merger's NEW_CONTIG_MERGE sequences (oracle/gp_oracle.py::merger_new_contigs, pinned on
+    the reference binary's answers) of the exact-containment de-duplicated set, for sets of 2 .. max_set contigs after the dedup; contigs
+    outside 30 .. 8190 bases take no part (MergeContigs.merge_sets)."""
+    from gappadder_amd import MergeContigs as MC
+    from oracle import gp_oracle as O
+    out = []
+    for cs in contig_sets:
+        nodup = MC.drop_contained([("c%d" % i, s) for i, s in enumerate(cs)]) if 2 <= len(cs) <= 1024 else []
+        if not 2 <= len(nodup) <= max_set:
+            out.append([])
+            continue
+        nodes = [s.upper() for _, s in nodup if MC.MIN_NODE <= len(s) <= MC.MAX_NODE]
+        out.append([s for _, s in O.merger_new_contigs(nodes, CO.GAPPADDER_OVL)] if len(nodes) >= 2 else [])
+    return out
+
+
+def test_device_merge_round_reproduces_the_reference_binarys_merged_contigs(gf):
+    """gf_merge_open_gaps_dev — dedup, prefilter, overlap evaluation, graph, strongly connected components, roots / ends, shortest paths,
+    twin removal and the merged strings, all on the device without a host synchronisation — on the contig sets the reference's own
+    ContigsMerger answered (tests/golden/merger_kat.json.gz): every set's NEW_CONTIG_MERGE sequences in the reference's order
+    (GraphUtils.cpp:625-859, 1028-1178, 1258-1344, 1422-1454; ContigsCompactor.cpp:773-983, 1456-1520)."""
+    from gappadder_amd import MergeContigs as MC
+    cases = json.loads(gzip.open(os.path.join(GOLDEN, "merger_kat.json.gz")).read())
+    sets = [c["contigs"] for c in cases]
+    got, stats = gf.merge_round(sets)
+    want = _oracle_round(sets)
+    n_direct = 0
+    for gi, c in enumerate(cases):
+        assert got[gi] == want[gi], gi
+        if len(MC.drop_contained([("c%d" % i, s) for i, s in enumerate(c["contigs"])])) == len(c["contigs"]):
+            assert got[gi] == [x["seq"] for x in c["new"]], gi          # the reference binary's own answer
+            n_direct += 1
+    assert n_direct >= 30 and sum(len(g) for g in got) >= 40 and stats["error_bits"] == 0
+    assert stats["new_contigs"] == sum(len(g) for g in got) and stats["gaps_with_new_contigs"] == sum(1 for g in got if g)
+
+
+def test_device_merge_round_on_random_contig_sets(gf):
+    """Contig sets as a fragmented assembly leaves them — overlapping pieces of a genome on either strand, duplicates, contained pieces,
+    strangers, branches that make the graph fork and cycle (a repeat) — 120 gaps in one call, some of them closed (left alone):
+    device round == oracle, and == the host twin MergeContigs.merge_sets (two batched GPU calls + host path search)."""
+    from gappadder_amd import MergeContigs as MC
+    rng = np.random.default_rng(11)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.integers(0, 4, n)].tobytes().decode()
+    rc = lambda x: x[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    sets, open_gaps = [], []
+    for s in range(120):
+        g = rnd(int(rng.integers(600, 4000)))
+        if s % 7 == 0:                                   # a two-copy repeat: the graph forks and joins
+            rep = rnd(120)
+            g = g[:200] + rep + g[200:len(g) // 2] + rep + g[len(g) // 2:]
+        cs, at = [], 0
+        while at < len(g) - 80:
+            ln = int(rng.integers(80, 700))
+            c = g[at:at + ln]
+            if rng.integers(0, 50) == 0:                 # a substitution inside the overlap
+                q = int(rng.integers(0, len(c)))
+                c = c[:q] + "ACGT"[("ACGT".index(c[q]) + 1) % 4] + c[q + 1:]
+            cs.append(rc(c) if rng.integers(0, 2) else c)
+            at += max(20, ln - int(rng.integers(15, 120)))
+        if rng.integers(0, 3) == 0:
+            cs.append(cs[0])                             # a duplicate
+        if rng.integers(0, 3) == 0:
+            cs.append(g[100:160])                        # contained in a longer contig
+        if rng.integers(0, 4) == 0:
+            cs.append(rnd(200))                          # a stranger
+        order = rng.permutation(len(cs))
+        sets.append([cs[i] for i in order])
+        open_gaps.append(s % 10 != 3)
+    sets.append([rnd(100)])                              # one contig: nothing to merge
+    open_gaps.append(True)
+    sets.append([])
+    open_gaps.append(True)
+    got, stats = gf.merge_round(sets, open_gaps=open_gaps)
+    want = _oracle_round(sets)
+    host = MC.merge_sets(gf, [MC.drop_contained([("c%d" % i, s) for i, s in enumerate(cs)]) for cs in sets])
+    n_new = 0
+    for gi in range(len(sets)):
+        if not open_gaps[gi]:
+            assert got[gi] == [], gi                     # a closed gap is left alone
+            continue
+        assert got[gi] == want[gi], gi
+        if 2 <= len(MC.drop_contained([("c%d" % i, s) for i, s in enumerate(sets[gi])])) <= 128:
+            assert got[gi] == [s for _, s, _ in host[gi]["new"]], gi
+        n_new += len(got[gi])
+    assert n_new > 100 and stats["gaps_tried"] >= 100 and stats["error_bits"] == 0 and stats["edges"] > 300
+
+
+def test_device_merge_round_leaves_oversized_sets_alone(gf):
+    """A gap with more than max_set contigs after the dedup is skipped and counted (the host round does the same: the contig graph of a
+    repeat-bearing gap has thousands of paths); the gap beside it is merged."""
+    rng = np.random.default_rng(12)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.integers(0, 4, n)].tobytes().decode()
+    g = rnd(900)
+    sets = [[rnd(90) for _ in range(140)], [g[0:400], g[330:800], g[700:900]]]
+    got, stats = gf.merge_round(sets)
+    assert got[0] == [] and stats["gaps_skipped_large"] == 1 and stats["gaps_tried"] == 1
+    assert got[1] == _oracle_round(sets)[1] and len(got[1]) >= 1 and g in (got[1][0], got[1][0][::-1].translate(str.maketrans("ACGT", "TGCA")))
+    got8, stats8 = gf.merge_round(sets, max_set=2)
+    assert got8 == [[], []] and stats8["gaps_skipped_large"] == 2
