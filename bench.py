@@ -231,7 +231,10 @@ def run(args):
     # merge / owner exchange -> assembly -> pick): this file generates the inputs, calls it and times it
     # GF_BENCH_TAG_KEYS=0: the tagger streams the 32-byte records themselves instead of their 8-byte key column (ablation)
     key_column = os.environ.get("GF_BENCH_TAG_KEYS", "1") != "0"
-    pipe = Pipeline(gf, n_gaps, L, kk, device=dev, world=world, rank=rank, backend=backend, force_exchange=multi and world == 1, key_column=key_column)
+    # the contig-merge round runs inside the step (GF_BENCH_MERGE=0: off; GF_BENCH_MERGE=host: off in the step, the host round behind it, untimed)
+    merge_mode = os.environ.get("GF_BENCH_MERGE", "1")
+    pipe = Pipeline(gf, n_gaps, L, kk, device=dev, world=world, rank=rank, backend=backend, force_exchange=multi and world == 1, key_column=key_column,
+                    merge_in_step=merge_mode not in ("0", "host"))
     pipe.tag_after_filter = not serial and os.environ.get("GF_BENCH_TAG_AFTER_FILTER", "0") == "1"
     pipe.tag_ahead = tag_ahead
     h = gf.handle
@@ -350,16 +353,24 @@ def run(args):
     if not multi and n_closed_local:      # (runs that close gaps at all: with the 300-bp library alone every 2-kb gap is a coverage hole)
         census = open_gap_census(cfg0, gaps, ctg, seq_host, res.best, GapFill)
     merge_round = None
-    # (only while the open gaps are few: with every gap open — the survey-sized C5 — the merger's host path search runs for 13 s)
-    if not multi and n_closed_local and n_gaps - n_closed_local <= max(1000, n_gaps // 4) and os.environ.get("GF_BENCH_MERGE", "1") != "0":
-        # The reference merges a gap's contigs before it picks (assemble_gaps.py:301-306, 335-339); the timed step picks first, and the
-        # gaps it leaves open go through the contig merger + a second pick here, AFTER the timed region (host path search: its time is
-        # reported, not charged to the step)
+    if res.merge is not None:
+        # The reference merges a gap's contigs before it picks (assemble_gaps.py:301-306, 335-339).  The step picks, sends the contigs of the
+        # gaps that pick left open through the contig merger ON THE DEVICE (gf_merge_open_gaps_dev: dedup, prefilter, overlap evaluation,
+        # path search, merged strings; no host synchronisation) and picks again over the merged contigs — inside the timed region: the
+        # closed counts above include it
+        merge_round = dict(res.merge, inside_the_timed_step=True)
+        idx = 0x7FFFFFFF - ((res.best >> np.uint64(1)) & np.uint64(0x7FFFFFFF)).astype(np.int64)
+        by_merge = (res.best != 0) & (idx >= res.merge["contigs_before"])
+        wrong_by_merge = sum(1 for g_ in truth["wrong_gaps"] if by_merge[g_])
+        merge_round["closed_correct"] = int(by_merge.sum()) - wrong_by_merge        # (of the gaps a MERGED contig closes: equal to the true sequence)
+        merge_round["gaps_closed_without_merging"] = int((res.best != 0).sum() - by_merge.sum())
+    elif merge_mode == "host" and not multi and n_closed_local and n_gaps - n_closed_local <= max(1000, n_gaps // 4):
+        # the host twin of the round (MergeContigs.merge_sets: two batched GPU calls + host path search), AFTER the timed region: comparison runs
         tm0 = time.perf_counter()
         mg = pipe.merge_open_gaps(res)
         tm = time.perf_counter() - tm0
         merge_round = {"gaps_tried": mg["gaps_tried"], "gaps_skipped_large": mg["gaps_skipped_large"], "gaps_with_new_contigs": mg["gaps_with_new_contigs"], "new_contigs": mg["new_contigs"],
-                       "gaps_closed_by_merging": len(mg["closed"]), "seconds_untimed": tm}
+                       "gaps_closed_by_merging": len(mg["closed"]), "seconds_untimed": tm, "inside_the_timed_step": False}
         if mg["closed"]:
             c2, s2, b2 = mg["arrays"]
             t2 = truth_check(cfg0, gaps, flanks, c2, s2, b2, GapFill)
@@ -483,7 +494,7 @@ def run(args):
                                    "collectives": "1 all-gather (counts) + 1 all-to-all (slots) + 1 all-gather per library (second-hop rows)"}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, libs, flanks, gaps, L, kk, asm_pool_t, asm_off_t, ctg, d_seq, n_seq, d_best, step_s,
-                                               n_screened, B, rb)
+                                               n_screened, B, rb, merge_n0=res.merge["contigs_before"] if res.merge is not None else None)
     for g_ in ctxs:
         g_.close()
     return (out if rank == 0 else None), rank, world
@@ -495,7 +506,7 @@ def truth_check(cfg, gaps, flanks, ctg, seq, best, GapFill):
     (gf_synth_truth; the reference evaluates its fills against the true sequences too, validate_gap_seqs.py:5-75)."""
     from gappadder_amd.pick_contigs import pick_gap_sequence
     closed = correct = 0
-    wrong, causes = [], {}
+    wrong, causes, wrong_gaps = [], {}, []
     for g in np.nonzero(best)[0]:
         b = int(best[g])
         a_len, span1, ci, rev = b >> 56, (b >> 32) & 0xFFFFFF, 0x7FFFFFFF - ((b >> 1) & 0x7FFFFFFF), b & 1
@@ -513,10 +524,11 @@ def truth_check(cfg, gaps, flanks, ctg, seq, best, GapFill):
         else:
             cause = ("length %+d" % (len(r[1]) - len(true))) if len(r[1]) != len(true) else "substitutions"
             causes[cause] = causes.get(cause, 0) + 1
+            wrong_gaps.append(int(g))
             if len(wrong) < 64:
                 nd = sum(1 for x, y in zip(r[1], true) if x != y) if len(r[1]) == len(true) else None
                 wrong.append({"gap": int(g), "anchor": a_len, "k": int(c["k"]), "picked_len": len(r[1]), "true_len": len(true), "mismatches": nd})
-    return {"closed": closed, "correct": correct, "wrong": wrong, "causes": causes}
+    return {"closed": closed, "correct": correct, "wrong": wrong, "causes": causes, "wrong_gaps": wrong_gaps}
 
 
 def open_gap_census(cfg, gaps, ctg, seq, best, GapFill, max_gaps=256, W=25):
@@ -667,7 +679,7 @@ def pmc_traffic(config, reads_per_launch, L, k, launch_ms, launched):
     return None
 
 
-def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_seq, d_best, gpu_step_s, n_screened, B, rb):
+def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_seq, d_best, gpu_step_s, n_screened, B, rb, merge_n0=None):
     """The oracle (oracle/gp_oracle.c, OpenMP over all host cores; kind "port") on a bounded sample of the same step:
     k-mer screen + alignment tagger on --cpu-sample-reads reads of the first library (a quarter of that of every further one) taken in
     stripes over the whole library, and the assembly of --cpu-sample-gaps gaps' pools, drawn over the whole gap list, at every (k, kv).
@@ -746,6 +758,20 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
     best = d_best.cpu().numpy().view(np.uint64)
     ok_asm = SC.contigs_equal(ctg, seq, exp, kk, gsel)
     ok_pick = SC.picks_equal(ctg, seq, best, flanks, kk, gsel)
+    # the merge round inside the step: the merged contigs of a seeded sample of the gaps it produced some for (and of sampled gaps it left
+    # without any) against the oracle's merger on those gaps' own contigs; the picks over them are part of ok_pick above only for the
+    # sampled gaps, so the gaps checked here go through the pick check too
+    ok_merge, n_merge_checked = None, 0
+    if merge_n0 is not None:
+        has_merged = np.unique(ctg["gap"][merge_n0:]) if len(ctg) > merge_n0 else np.zeros(0, dtype=np.int64)
+        rng = np.random.RandomState(20260620)
+        pick_m = sorted(int(x) for x in (has_merged if len(has_merged) <= 32 else rng.choice(has_merged, 32, replace=False)))
+        open_first = [g for g in gsel if int(best[g]) == 0][:8]          # sampled gaps that stayed open: the round must have appended exactly what the oracle says (often nothing)
+        tmg = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            oks = list(ex.map(lambda g: SC.merged_equal(ctg, seq, [g], merge_n0) and SC.picks_equal(ctg, seq, best, flanks, kk, [g]), pick_m + open_first))
+        ok_merge, n_merge_checked = all(oks), len(oks)
+        notes.append("merge round: %d gaps (%.2f s)" % (n_merge_checked, time.perf_counter() - tmg))
     striped = not all(w["complete"] for w in where.values()) or n_g < len(gaps)
     # whole-step CPU time extrapolated from the two samples (recruit scales with reads, assembly with gaps).  The flank k-mer table is
     # built once per run on either side (the GPU's index build is outside the timed step too): reported beside, not charged per step
@@ -759,8 +785,8 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
             "parity_sample_ranges": dict(where, gaps={"n": n_g, "of": len(gaps), "first": gsel[0], "last": gsel[-1],
                                                       "scaffolds_touched": int(len(np.unique(gaps["scaffold"][gsel])))}),
             "recruit_reads_per_s": n_rec / t_rec, "table_build_s": t_build, "assembly_gaps_per_s": n_g / (t4 - t3),
-            "parity_on_sample": bool(ok and ok_asm and ok_pick), "parity_recruit": bool(ok), "parity_assembly": bool(ok_asm),
-            "parity_pick": bool(ok_pick), "sample_hits": int(n_ohits), "sample_contigs": int(sum(len(e) for ee in exp for e in ee))}
+            "parity_on_sample": bool(ok and ok_asm and ok_pick and ok_merge is not False), "parity_recruit": bool(ok), "parity_assembly": bool(ok_asm),
+            "parity_pick": bool(ok_pick), "parity_merge_round": ok_merge, "merge_round_gaps_checked": n_merge_checked, "sample_hits": int(n_ohits), "sample_contigs": int(sum(len(e) for ee in exp for e in ee))}
 
 
 if __name__ == "__main__":

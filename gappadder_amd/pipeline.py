@@ -15,6 +15,7 @@ What the reference does with files between processes —
     gf_pools_merge_dev                                         libraries in order (a-5)    [N > 1: sharding.OwnerExchange]
     gf_assemble_multi_dev                                      every (k, kv) pair (a-6)
     gf_pick_anchored2_dev                                      closed gaps (f-1)
+    gf_merge_open_gaps_dev + gf_pick_anchored2_from_dev        contig merger for the gaps still open, second pick (f-3; merge_in_step)
 
 `Pipeline` owns the sizing pass (capacities follow what the libraries actually recruit), every intermediate buffer, the stream
 wiring and — in a multi-rank run — the one exchange step.  Two callers: bench.py (libraries synthesised on the
@@ -63,7 +64,7 @@ class Results:
 class Pipeline:
     def __init__(self, gf, n_gaps, read_len, k_pairs, device=None, world=1, rank=0, backend="nccl", force_exchange=False,
                  min_count=2, min_contig=40, anchors=(30, 15), clip_dist=250, anchor_mapq=30, k_screen=None, keep_read_ids=False,
-                 key_column=True):
+                 key_column=True, merge_in_step=False, merge_max_set=128):
         """gf: a GapFill whose gaps (and flanks, when a library is screened) are set.  k_pairs: [(k, k_velvet)] of
         assemble_gaps.py:87-122.  The screen runs at the SMALLEST k of the list: a read that shares a 51-mer with a flank shares
         its 31-mers too, so this is the superset every assembly k needs (the reference recruits once, then assembles at every k).
@@ -84,6 +85,11 @@ class Pipeline:
         self.k_screen = int(k_screen) if k_screen else (min(a for a, _ in self.kk) if self.kk else 31)
         self.keep_read_ids = bool(keep_read_ids)
         self.key_column = bool(key_column)
+        # merge_in_step: the contig-merge round (assemble_gaps.py:301-306 run_contigs_merge: dedup + ContigsMerger per gap) runs INSIDE the
+        # step, on the device, for the gaps the first pick leaves open, followed by a second pick over the merged contigs — the reference
+        # merges before it picks (:335-339); a gap the pick closes from its own contigs gains nothing from merging.  Merged contigs are
+        # appended to the step's contig list with k = kv = 0.  Sets of more than merge_max_set contigs after the dedup are left alone.
+        self.merge_in_step, self.merge_max_set = bool(merge_in_step), int(merge_max_set)
         self.libs = []
         self.batch = SH.owner_batch(self.n_gaps, self.world)
         self.stream = None
@@ -380,6 +386,10 @@ class Pipeline:
         # assembly counters: 0 contigs (u32), 2-3 contig bases (u64), 4 gaps closed (u32)
         self.d_acnt = torch.zeros(8, dtype=torch.int32, device=dev)
         self.ap = self.d_acnt.data_ptr()
+        self.d_mstats = torch.zeros(B.MG_WORDS, dtype=torch.int32, device=dev)      # statistics of the merge round (gf_merge_open_gaps_dev)
+        pr = np.zeros(1, dtype=B.OVL_PARAMS)
+        pr[0] = tuple(self.gf.MERGER_PARAMS)[:7] + (0.0,)       # ContigsMerger's options as GAPPadder sets them (MergeContigs.py:75)
+        self.merge_params = pr
         self.k_arr = (C.c_int * nk)(*[a for a, _ in self.kk])
         self.kv_arr = (C.c_int * nk)(*[b for _, b in self.kk])
         torch.cuda.synchronize()
@@ -463,6 +473,14 @@ class Pipeline:
         a0, a1 = self.anchors[0], (self.anchors[1] if len(self.anchors) > 1 else 0)
         self._chk(lib.gf_pick_anchored2_dev(h, self.d_ctg.data_ptr(), self.ap, self.contig_cap, self.d_seq.data_ptr(), a0, a1,
                                             self.d_best.data_ptr(), self.ap + 16), "gf_pick_anchored2_dev")
+        if self.merge_in_step:
+            # the open gaps' contigs through the contig merger, merged contigs appended (k = kv = 0), second pick over THEM only
+            self._chk(lib.gf_merge_open_gaps_dev(h, self.d_ctg.data_ptr(), self.ap, self.contig_cap, self.d_seq.data_ptr(), self.ap + 8, self.seq_cap,
+                                                 self.d_best.data_ptr(), self.n_gaps, B._p(self.merge_params), 10, self.merge_max_set,
+                                                 self.d_mstats.data_ptr()), "gf_merge_open_gaps_dev")
+            self._chk(lib.gf_pick_anchored2_from_dev(h, self.d_ctg.data_ptr(), self.ap, self.contig_cap, self.d_seq.data_ptr(), a0, a1,
+                                                     self.d_mstats.data_ptr() + 4 * B.MG_N0, self.d_best.data_ptr(), self.ap + 16),
+                      "gf_pick_anchored2_from_dev")
 
     def step(self, n=1):
         assert self.prepared, "Pipeline.prepare() first"
@@ -508,12 +526,23 @@ class Pipeline:
         if xerr or n_err or r.n_contigs > self.contig_cap or r.n_seq > self.seq_cap:
             raise RuntimeError("step overflow: exchange/merge flag %#x, %d gap errors, %d contigs (cap %d), %d contig bases (cap %d)"
                                % (xerr & 0xFFFFFFFF, n_err, r.n_contigs, self.contig_cap, r.n_seq, self.seq_cap))
+        r.merge = None
+        if self.merge_in_step and self.kk:
+            ms = self.d_mstats.cpu().numpy().view(np.uint32)
+            if int(ms[B.MG_ERR]):
+                raise RuntimeError("merge round: capacity flags %#x" % int(ms[B.MG_ERR]))
+            r.merge = {"gaps_tried": int(ms[B.MG_N_SETS]), "gaps_skipped_large": int(ms[B.MG_SKIPPED]), "candidate_pairs": int(ms[B.MG_N_PAIRS]),
+                       "edges": int(ms[B.MG_N_EDGES]), "new_contigs": int(ms[B.MG_N_JOBS]), "gaps_with_new_contigs": int(ms[B.MG_SETS_WITH_JOBS]),
+                       "contigs_before": int(ms[B.MG_N0])}
         r.asm_off_t = self.d_moff if self.need_merge else self.libs[0].d_pool_off
         r.asm_pool_t = self.d_merged if self.need_merge else self.d_pools
         r.asm_rows_total = int(r.asm_off_t[-1])
         r.contigs = np.frombuffer(self.d_ctg[:r.n_contigs * 32].cpu().numpy().tobytes(), dtype=B.CONTIG)
         r.seq = self.d_seq[:r.n_seq].cpu().numpy().tobytes()
         r.best = self.d_best[:self.n_gaps].cpu().numpy().view(np.uint64)
+        if r.merge is not None:      # gaps whose winning contig is a merged one
+            idx = 0x7FFFFFFF - ((r.best >> np.uint64(1)) & np.uint64(0x7FFFFFFF)).astype(np.int64)
+            r.merge["gaps_closed_by_merging"] = int(((r.best != 0) & (idx >= r.merge["contigs_before"])).sum())
         if pools:
             r.pool_off = r.asm_off_t.cpu().numpy().astype(np.int64)
             r.pool_rows = r.asm_pool_t[:r.asm_rows_total * self.rb].cpu().numpy().reshape(-1, self.rb)

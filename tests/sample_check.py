@@ -134,16 +134,56 @@ def expected_pick_word(ctg, seq, g, flanks, kk):
     exact-anchor stand-in's hits; scores 30 then 15 (assemble_gaps.py:336, 365).  The picker sees the gap's contigs in the order the
     device listed them (ties between equal spans go to the earlier contig)."""
     from oracle import gp_oracle as PO
-    idx = sorted(int(i) for (k, kv) in kk for i in np.nonzero((ctg["gap"] == g) & (ctg["k"] == k) & (ctg["kv"] == kv))[0])
-    want = [("c%d" % i, _contig_text(ctg, seq, i)) for i in idx]
-    for a_len in (30, 15):
-        seqs, ctgs_txt = PO.pick_gap("0_1", want, flanks[g][0], flanks[g][1], a_len)
-        if seqs:
-            hdr, body = seqs.split("\n")[:2]
-            ci = idx[[n for n, _ in want].index(hdr[len(">0_1_"):])]
-            rev = int(ctgs_txt.split("\n")[1] != dict(want)["c%d" % ci])
-            return (a_len << 56) | (len(body) << 32) | ((0x7FFFFFFF - ci) << 1) | rev
+    own = sorted(int(i) for (k, kv) in kk for i in np.nonzero((ctg["gap"] == g) & (ctg["k"] == k) & (ctg["kv"] == kv))[0])
+    # the contigs a merge round appended for the gap (k = kv = 0): picked from only when the gap's own contigs leave it open — the step
+    # merges the open gaps' contigs and picks a second time over the merged ones (Pipeline.assemble, assemble_gaps.py:301-306, 335-339)
+    merged = sorted(int(i) for i in np.nonzero((ctg["gap"] == g) & (ctg["k"] == 0) & (ctg["kv"] == 0))[0])
+    for idx in (own, merged):
+        want = [("c%d" % i, _contig_text(ctg, seq, i)) for i in idx]
+        for a_len in (30, 15):
+            seqs, ctgs_txt = PO.pick_gap("0_1", want, flanks[g][0], flanks[g][1], a_len)
+            if seqs:
+                hdr, body = seqs.split("\n")[:2]
+                ci = idx[[n for n, _ in want].index(hdr[len(">0_1_"):])]
+                rev = int(ctgs_txt.split("\n")[1] != dict(want)["c%d" % ci])
+                return (a_len << 56) | (len(body) << 32) | ((0x7FFFFFFF - ci) << 1) | rev
     return 0
+
+
+def expected_merged_contigs(own, max_set=128):
+    """What the step's merge round must append for a gap whose own contigs (all (k, kv), record order) the first pick left open:
+    exact-containment dedup (a contig that occurs, on either strand, inside another one goes; of identical ones the first stays), then —
+    for 2 .. max_set contigs left — ContigsMerger's NEW_CONTIG_MERGE sequences by oracle/gp_oracle.py::merger_new_contigs (prefilter,
+    overlap evaluation, path search and merged strings restated from the reference and pinned on its binary's answers) over the
+    contigs of 30 .. 8190 bases."""
+    from oracle import c_oracle as CO
+    from oracle import gp_oracle as PO
+    comp = str.maketrans("ACGT", "TGCA")
+    if not 2 <= len(own) <= 1024:
+        return []
+    order = sorted(range(len(own)), key=lambda i: (-len(own[i]), i))
+    kept = []
+    for i in order:
+        q = own[i]
+        if not any(q in own[j] or q in own[j].translate(comp)[::-1] for j in kept):
+            kept.append(i)
+    kept.sort()
+    if not 2 <= len(kept) <= max_set:
+        return []
+    nodes = [own[i] for i in kept if 30 <= len(own[i]) <= 8190]
+    return [s_ for _, s_ in PO.merger_new_contigs(nodes, CO.GAPPADDER_OVL)] if len(nodes) >= 2 else []
+
+
+def merged_equal(ctg, seq, gaps, n0):
+    """The merged contigs (k = kv = 0, records from n0 on) the device appended for the listed gaps against expected_merged_contigs of
+    the gaps' own contigs (records before n0, record order)."""
+    for g in _gap_list(gaps):
+        rows = np.nonzero(ctg["gap"] == g)[0]
+        own = [_contig_text(ctg, seq, i) for i in rows if i < n0]
+        got = [_contig_text(ctg, seq, i) for i in rows if i >= n0]
+        if got != expected_merged_contigs(own):
+            return False
+    return True
 
 
 def picks_equal(ctg, seq, best, flanks, kk, gaps):

@@ -189,3 +189,38 @@ def test_range_samples_renumber_the_gpu_ids_and_catch_defects_in_any_stripe():
     assert not SC.contigs_equal(bad, seq, [expected[g] for g in sel], KK, sel)
     j = int(np.nonzero(ctg["gap"] % 2 == 0)[0][0]); ok_elsewhere = ctg.copy(); ok_elsewhere["cov_sum"][j] += 1
     assert SC.contigs_equal(ok_elsewhere, seq, [expected[g] for g in sel], KK, sel)       # a gap outside the sample
+
+
+def test_merge_round_check_catches_a_wrong_missing_or_extra_merged_contig():
+    """The merged contigs a step appends (k = kv = 0, behind the assembly's own) against the oracle's merger on the gap's own contigs —
+    and the pick over them: a gap its own contigs leave open is picked from the merged ones."""
+    rng = np.random.RandomState(9)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.randint(0, 4, n)].tobytes().decode()
+    g = rnd(1400)
+    flanks = [(g[100:395], g[1005:1300]), (rnd(295), rnd(295))]
+    own = [(0, g[60:520]), (0, g[450:900]), (0, g[830:1340]), (0, g[450:900]), (0, g[500:560]), (1, rnd(300)), (1, rnd(200))]
+    exp0 = SC.expected_merged_contigs([s for gp, s in own if gp == 0])
+    assert len(exp0) == 1 and exp0[0] in (g[60:1340], g[60:1340][::-1].translate(str.maketrans("ACGT", "TGCA")))   # duplicate + contained piece dropped, the three chained
+    assert SC.expected_merged_contigs([s for gp, s in own if gp == 1]) == []
+    recs = own + [(0, exp0[0])]
+    n0 = len(own)
+    ctg = np.zeros(len(recs), dtype=B.CONTIG)
+    seq = bytearray()
+    for i, (gp, s) in enumerate(recs):
+        ctg[i] = (gp, 31 if i < n0 else 0, 29 if i < n0 else 0, max(1, len(s) - 28), len(s), 0, 0, len(seq))
+        seq += s.encode()
+    seq = bytes(seq)
+    assert SC.merged_equal(ctg, seq, [0, 1], n0)
+    wrong = bytearray(seq); at = int(ctg[n0]["seq_off"]) + 700; wrong[at] = ord("A") if wrong[at] != ord("A") else ord("C")
+    assert not SC.merged_equal(ctg, bytes(wrong), [0], n0)                       # ONE wrong base in a merged contig
+    assert not SC.merged_equal(ctg[:n0], seq, [0], n0)                           # the merged contig is missing
+    extra = np.concatenate([ctg, ctg[n0:]]); extra["gap"][-1] = 1
+    assert not SC.merged_equal(extra, seq, [1], n0)                              # a merged contig for a gap that has nothing to merge
+    # the pick: no own contig carries both anchors, the merged one does
+    kk = [(31, 29)]
+    w = SC.expected_pick_word(ctg, seq, 0, flanks, kk)
+    assert w >> 56 == 30 and 0x7FFFFFFF - ((w >> 1) & 0x7FFFFFFF) == n0 and ((w >> 32) & 0xFFFFFF) == 1005 - 395 + 1
+    assert SC.expected_pick_word(ctg[:n0], seq, 0, flanks, kk) == 0
+    best = np.array([w, 0], dtype=np.uint64)
+    assert SC.picks_equal(ctg, seq, best, flanks, kk, [0, 1]) and not SC.picks_equal(ctg, seq, np.array([0, 0], dtype=np.uint64), flanks, kk, [0])
