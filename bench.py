@@ -304,7 +304,8 @@ def run(args):
         return sum(t for t, _ in tt), sum(n for _, n in tt)
     kt = {name: ktime(idx) for name, idx in (("screen_filter", B.KERNEL_SCREEN), ("screen_verify", B.KERNEL_VERIFY),
                                              ("tag_alignments", B.KERNEL_TAG), ("tag_low_mapq", B.KERNEL_LOWMAPQ),
-                                             ("pools", B.KERNEL_POOL), ("assemble", B.KERNEL_ASSEMBLE), ("pick_anchored", B.KERNEL_PICK))}
+                                             ("pools", B.KERNEL_POOL), ("assemble", B.KERNEL_ASSEMBLE), ("pick_anchored", B.KERNEL_PICK),
+                                             ("merge_round", B.KERNEL_MERGE))}
     [g_.timing(False) for g_ in ctxs]
     if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)

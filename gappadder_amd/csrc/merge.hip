@@ -215,7 +215,11 @@ struct OvLds {
         b = a + OV_ROW;
     }
 };
-// node n1 (S.a) against node n2 (S.b), both staged in LDS; all 256 threads; the result is in *res (shared memory) after the call
+// node n1 (S.a) against node n2 (S.b), both staged in LDS; all NT threads of the workgroup; the result is in *res (shared memory) after
+// the call.  NT = 1 024: a diagonal of a 2-kb pair is 2-3 cells per thread and sixteen waves hide each other's LDS latency — the sweep
+// is a chain of ~(n1 + n2) barriers, 19.3 ms per 6 600 pairs with 256 threads (C5's merge round), measured again in DESIGN.md
+constexpr int OV_NT = 1024;
+template <int NT>
 __device__ void ov_evaluate(const OvLds& S, int n1, int n2, const gf_ovl_params& pr, long long* s_best_sc, unsigned long long* s_best_rk,
                             gf_ovl_result* res) {
     constexpr uint32_t ROW = OV_ROW;
@@ -236,7 +240,7 @@ __device__ void ov_evaluate(const OvLds& S, int n1, int n2, const gf_ovl_params&
         const uint8_t* f1 = fl + ((d + 2) % 3) * ROW;
         const uint8_t* f2 = fl + ((d + 1) % 3) * ROW;
         const int ilo = d > n2 ? d - n2 : 0, ihi = d < n1 ? d : n1;
-        for (int i = ilo + (int)tid; i <= ihi; i += 256) {
+        for (int i = ilo + (int)tid; i <= ihi; i += NT) {
             const int j = d - i;
             int s;
             uint32_t f;
@@ -262,13 +266,18 @@ __device__ void ov_evaluate(const OvLds& S, int n1, int n2, const gf_ovl_params&
         }
         __syncthreads();
     }
-    s_best_sc[tid] = best_sc;
-    s_best_rk[tid] = best_rk;
+    // the best end cell: (score descending, rank ascending) — first inside every wave, then over the waves
+    for (int d = 32; d >= 1; d >>= 1) {
+        const long long osc = __shfl_xor(best_sc, d);
+        const unsigned long long ork = __shfl_xor(best_rk, d);
+        if (osc > best_sc || (osc == best_sc && (ork & ~3ull) < (best_rk & ~3ull))) { best_sc = osc; best_rk = ork; }
+    }
+    if ((tid & 63) == 0) { s_best_sc[tid >> 6] = best_sc; s_best_rk[tid >> 6] = best_rk; }
     __syncthreads();
     if (tid == 0) {
         gf_ovl_result r;
         memset(&r, 0, sizeof r);
-        for (uint32_t t = 1; t < 256; ++t)
+        for (uint32_t t = 1; t < NT / 64; ++t)
             if (s_best_sc[t] > best_sc || (s_best_sc[t] == best_sc && (s_best_rk[t] & ~3ull) < (best_rk & ~3ull))) { best_sc = s_best_sc[t]; best_rk = s_best_rk[t]; }
         const int nclip = (int)(best_rk >> 40);
         const bool rowc = (best_rk >> 39) & 1u;
@@ -308,7 +317,7 @@ __device__ void ov_evaluate(const OvLds& S, int n1, int n2, const gf_ovl_params&
 }
 // stages `n` bases from global memory into LDS: upper-cased, reverse-complemented when rc (other symbols stay themselves)
 __device__ __forceinline__ void ov_load_node(char* dst, const char* src, int n, bool rc) {
-    for (int i = (int)threadIdx.x; i < n; i += 256) {
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
         char ch = src[rc ? n - 1 - i : i];
         if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
         if (rc) ch = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
@@ -316,11 +325,11 @@ __device__ __forceinline__ void ov_load_node(char* dst, const char* src, int n, 
     }
 }
 
-__global__ __launch_bounds__(256) void overlap_eval_kernel(OvParams P) {
+__global__ __launch_bounds__(OV_NT) void overlap_eval_kernel(OvParams P) {
     extern __shared__ uint32_t sm[];   // [3 x (OV_MAXLEN + 2) scores][3 x (OV_MAXLEN + 2) start flags (bytes)][node 1][node 2]
     __shared__ uint32_t s_pair;
-    __shared__ long long s_best_sc[256];
-    __shared__ unsigned long long s_best_rk[256];
+    __shared__ long long s_best_sc[OV_NT / 64];
+    __shared__ unsigned long long s_best_rk[OV_NT / 64];
     __shared__ gf_ovl_result s_res;
     const OvLds S(sm);
     const uint32_t tid = threadIdx.x;
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(256) void overlap_eval_kernel(OvParams P) {
         }
         ov_load_node(S.a, P.seq + o1, n1, q.i & 1);
         ov_load_node(S.b, P.seq + o2, n2, q.j & 1);
-        ov_evaluate(S, n1, n2, P.pr, s_best_sc, s_best_rk, &s_res);
+        ov_evaluate<OV_NT>(S, n1, n2, P.pr, s_best_sc, s_best_rk, &s_res);
         if (tid == 0) P.out[pi] = s_res;
     }
 }
@@ -526,6 +535,15 @@ __global__ __launch_bounds__(1024) void mg_dedup_kernel(MgParams P) {
         for (uint32_t q = wv; q < n; q += blockDim.x >> 6) {
             const uint32_t lq = s_len[q];
             const char* sq = P.seq + s_off[q];
+            // the first min(8, lq) bases of q and of its reverse complement as one word each: ONE (unaligned) 8-byte load per offset of p
+            // decides both strands; the byte loops run only behind a matching head
+            const uint32_t hb = lq < 8 ? lq : 8;
+            unsigned long long hf = 0, hr = 0;
+            for (uint32_t t = 0; t < hb; ++t) {
+                hf |= (unsigned long long)(uint8_t)sq[t] << (8 * t);
+                hr |= (unsigned long long)(uint8_t)mg_comp(sq[lq - 1 - t]) << (8 * t);
+            }
+            const unsigned long long hmask = hb == 8 ? ~0ull : ((1ull << (8 * hb)) - 1);
             bool gone = false;
             for (uint32_t p = 0; p < n && !gone; ++p) {
                 const uint32_t lp = s_len[p];
@@ -535,11 +553,17 @@ __global__ __launch_bounds__(1024) void mg_dedup_kernel(MgParams P) {
                     const uint32_t at = o0 + lane;
                     bool hit = false;
                     if (at + lq <= lp) {
-                        uint32_t t = 0;
-                        while (t < lq && sq[t] == sp[at + t]) ++t;
-                        hit = t == lq;
-                        if (!hit) {
-                            t = 0;
+                        unsigned long long w = 0;
+                        if (at + 8 <= lp) memcpy(&w, sp + at, 8);
+                        else for (uint32_t t = 0; at + t < lp; ++t) w |= (unsigned long long)(uint8_t)sp[at + t] << (8 * t);
+                        w &= hmask;
+                        if (w == hf) {
+                            uint32_t t = hb;
+                            while (t < lq && sq[t] == sp[at + t]) ++t;
+                            hit = t == lq;
+                        }
+                        if (!hit && w == hr) {
+                            uint32_t t = hb;
                             while (t < lq && mg_comp(sq[lq - 1 - t]) == sp[at + t]) ++t;
                             hit = t == lq;
                         }
@@ -972,11 +996,11 @@ __global__ __launch_bounds__(1024) void mg_scan_jobs_kernel(MgParams P) {
 }
 
 // FormMergedSeqFromPath (ContigsCompactor.cpp:1456-1520; MergeContigs.merged_strings): one workgroup per path
-__global__ __launch_bounds__(256) void mg_strings_kernel(MgParams P) {
+__global__ __launch_bounds__(OV_NT) void mg_strings_kernel(MgParams P) {
     extern __shared__ uint32_t sm[];
     __shared__ uint32_t s_job;
-    __shared__ long long s_best_sc[256];
-    __shared__ unsigned long long s_best_rk[256];
+    __shared__ long long s_best_sc[OV_NT / 64];
+    __shared__ unsigned long long s_best_rk[OV_NT / 64];
     __shared__ gf_ovl_result s_res;
     __shared__ unsigned long long s_out;
     const OvLds S(sm);
@@ -1002,31 +1026,31 @@ __global__ __launch_bounds__(256) void mg_strings_kernel(MgParams P) {
         {
             const char* src = node_src(path[0], &n1);
             const bool rc = path[0] & 1;
-            for (int i = (int)tid; i < n1; i += 256) { const char ch = src[rc ? n1 - 1 - i : i]; cur[i] = rc ? mg_comp(ch) : ch; }
+            for (int i = (int)tid; i < n1; i += OV_NT) { const char ch = src[rc ? n1 - 1 - i : i]; cur[i] = rc ? mg_comp(ch) : ch; }
         }
         __syncthreads();
         for (uint32_t step = 1; step < job.len; ++step) {
             int n2;
             const char* src2 = node_src(path[step], &n2);
             if (n1 > (int)MG_MAX_NODE || n2 > (int)MG_MAX_NODE) break;      // grown beyond the kernel's reach: the path ends here
-            for (int i = (int)tid; i < n1; i += 256) S.a[i] = cur[i];
+            for (int i = (int)tid; i < n1; i += OV_NT) S.a[i] = cur[i];
             ov_load_node(S.b, src2, n2, path[step] & 1);
-            ov_evaluate(S, n1, n2, pr, s_best_sc, s_best_rk, &s_res);
+            ov_evaluate<OV_NT>(S, n1, n2, pr, s_best_sc, s_best_rk, &s_res);
             const gf_ovl_result r = s_res;
             const int re = r.row_end, ce = r.col_end, nc = r.nclip;
             int nn;
             if (r.contained && re + nc == n1 && n1 < n2) {                 // the running string lies inside the node: the node
                 nn = n2;
-                for (int i = (int)tid; i < nn; i += 256) nxt[i] = S.b[i];
+                for (int i = (int)tid; i < nn; i += OV_NT) nxt[i] = S.b[i];
             } else if (r.contained && ce + nc == n2 && n2 < n1) {          // the node lies inside the running string: unchanged
                 nn = n1;
-                for (int i = (int)tid; i < nn; i += 256) nxt[i] = S.a[i];
+                for (int i = (int)tid; i < nn; i += OV_NT) nxt[i] = S.a[i];
             } else if (re + nc == n1) {                                    // SetMergedStringConcat, MODE_1_2
                 nn = (n1 - nc) + (n2 - ce);
-                for (int i = (int)tid; i < nn; i += 256) nxt[i] = i < n1 - nc ? S.a[i] : S.b[ce + (i - (n1 - nc))];
+                for (int i = (int)tid; i < nn; i += OV_NT) nxt[i] = i < n1 - nc ? S.a[i] : S.b[ce + (i - (n1 - nc))];
             } else {                                                       // MODE_2_1
                 nn = (n2 - nc) + (n1 - re);
-                for (int i = (int)tid; i < nn; i += 256) nxt[i] = i < n2 - nc ? S.b[i] : S.a[re + (i - (n2 - nc))];
+                for (int i = (int)tid; i < nn; i += OV_NT) nxt[i] = i < n2 - nc ? S.b[i] : S.a[re + (i - (n2 - nc))];
             }
             __syncthreads();
             char* t = cur; cur = nxt; nxt = t;
@@ -1039,7 +1063,7 @@ __global__ __launch_bounds__(256) void mg_strings_kernel(MgParams P) {
         const unsigned long long so = s_out;
         const bool fits = so + (unsigned long long)n1 <= P.seq_cap;
         if (!fits && tid == 0) atomicOr(&P.stats[MG_ERR], MG_E_OUTSEQ);
-        if (fits) for (int i = (int)tid; i < n1; i += 256) P.seq[so + i] = cur[i];
+        if (fits) for (int i = (int)tid; i < n1; i += OV_NT) P.seq[so + i] = cur[i];
         if (tid == 0 && rec < P.contig_cap) {
             gf_contig c;
             memset(&c, 0, sizeof c);
@@ -1123,11 +1147,11 @@ int launch_merge_round(gf_ctx* ctx, void* d_contigs, void* d_n_contigs, size_t c
         OvParams O;
         O.seq = P.mseq; O.contig_off = P.contig_off; O.set_off = P.set_off; O.pairs = P.pairs; O.n_pairs = (uint32_t)pair_cap; O.pr = P.pr;
         O.out = (gf_ovl_result*)(W + o_res); O.next = d_next_ov; O.d_n_pairs = P.stats + MG_N_PAIRS;
-        hipLaunchKernelGGL(overlap_eval_kernel, dim3(grid), dim3(256), OV_LDS_BYTES, ctx->stream, O);
+        hipLaunchKernelGGL(overlap_eval_kernel, dim3(grid), dim3(OV_NT), OV_LDS_BYTES, ctx->stream, O);
     }
     hipLaunchKernelGGL(mg_paths_kernel, dim3(grid), dim3(256), (size_t)MG_MAX_EDGES * 8, ctx->stream, P);
     hipLaunchKernelGGL(mg_scan_jobs_kernel, dim3(1), dim3(1024), 0, ctx->stream, P);
-    hipLaunchKernelGGL(mg_strings_kernel, dim3(grid), dim3(256), OV_LDS_BYTES, ctx->stream, P);
+    hipLaunchKernelGGL(mg_strings_kernel, dim3(grid), dim3(OV_NT), OV_LDS_BYTES, ctx->stream, P);
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
 }
@@ -1253,7 +1277,7 @@ int gf_overlap_evaluate_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig
     const size_t lds = OV_LDS_BYTES;
     {
         LaunchTimer tm(ctx, GF_KERNEL_MERGE);
-        hipLaunchKernelGGL(overlap_eval_kernel, dim3((unsigned)std::min<size_t>(n_pairs, (size_t)ctx->n_cu)), dim3(256), lds, ctx->stream, P);
+        hipLaunchKernelGGL(overlap_eval_kernel, dim3((unsigned)std::min<size_t>(n_pairs, (size_t)ctx->n_cu)), dim3(OV_NT), lds, ctx->stream, P);
     }
     GF_HIP(ctx, hipGetLastError());
     return GF_OK;
