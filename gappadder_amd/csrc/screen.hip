@@ -558,7 +558,10 @@ __device__ __forceinline__ void vm_wait_range(uint32_t n) {   // s_waitcnt vmcnt
         if (n >= (uint32_t)MID) vm_wait_range<MID, HI>(n); else vm_wait_range<LO, MID - 1>(n);
     }
 }
-template <uint32_t G, bool BYTES>   // BYTES: the probes start at byte boundaries (k = 51, 31, ... at 2 bits per base): one byte permute fetches them
+// NG = groups per tile iteration: a read's G x NG probe slots are taken from the staged tile at once and sorted G at a time — k = 31 on
+// 150-base reads has eight probes per read = two groups of four through the same branch-free machinery (before: pf4_scatter_kernel<4>,
+// 16.1 ms per launch at C5 against this kernel's 9.8 ms for C4's three probes).  Probe slots beyond np (np < G x NG) are dead.
+template <uint32_t G, bool BYTES, uint32_t NG = 1>   // BYTES: the probes start at byte boundaries (k = 51, 31, ... at 2 bits per base): one byte permute fetches them
 __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4Params Q, uint32_t slice_words) {
     extern __shared__ uint32_t sm[];   // [16 waves x 1 tile][sent][carry 2 x 256 x 32][fill stage 256 x (ST + 1)][hist 3 x 256][written 2 x 256][desc 256][offs 256][lga, lsrc: 2 x (256 + sent lines)][cnt 8]
     const FilterParams& P = Q.F;
@@ -608,14 +611,11 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
     uint32_t hsel = 0, wsel = 0;
     uint32_t stores_since = 0;   // copy-out stores this wave has issued since its last prefetch (wave-uniform)
     __syncthreads();
-    for (uint64_t it = 0; it < n_iter; ++it) {   // one group per iteration: g = it
+    for (uint64_t it = 0; it < n_iter; ++it) {   // NG groups per iteration: g = it * NG + gi
         asm volatile("" : "+v"(tid), "+v"(lane));   // (opaque: what derives from them is computed where it is used, not kept in registers across the iteration)
-        const uint32_t g = (uint32_t)it;
         const uint64_t t0 = it * t_step + ((uint64_t)blockIdx.x * PF2_WAVES + wv) * PF2_TILES;
         const uint32_t octet0 = (uint32_t)((it * t_step + (uint64_t)blockIdx.x * PF2_WAVES * PF2_TILES) * 8);   // octet of batch index 0
-        uint32_t* hist = hist3 + hsel * PF2_NB;        // all zero (start / zeroed during the copy-out before last)
-        const uint32_t* written = written2 + wsel * PF2_NB;
-        uint32_t pk[PF2_TILES][G], rank[PF2_TILES][G];
+        uint32_t pka[PF2_TILES][G * NG];      // the raw 16-mers of every probe slot of the iteration's tiles
         const uint32_t bit0 = lane * P.rb * 8;
 #pragma unroll
         for (uint32_t q = 0; q < PF2_TILES; ++q) {
@@ -640,19 +640,30 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
             wave_lds_sync();
             prefetch(t + t_step, q);
 #pragma unroll
-            for (uint32_t u = 0; u < G; ++u) pk[q][u] = BYTES ? stream32_bytes(tile, (bit0 + P.first2 + u * P.stride2) >> 3) : stream32(tile, bit0 + P.first2 + u * P.stride2);
+            for (uint32_t u = 0; u < G * NG; ++u)     // (a slot beyond np reads inside the staged tile + pad all the same; its pair is never ranked)
+                pka[q][u] = BYTES ? stream32_bytes(tile, (bit0 + P.first2 + (NG == 1 || u < P.np ? u : 0u) * P.stride2) >> 3)
+                                  : stream32(tile, bit0 + P.first2 + (NG == 1 || u < P.np ? u : 0u) * P.stride2);
             wave_lds_sync();   // the tile's probes are taken (LDS operations of a wave execute in order): the next tile may take its place
         }
         stores_since = 0;
 #pragma unroll
+      for (uint32_t gi = 0; gi < NG; ++gi) {
+        const uint32_t g = (uint32_t)it * NG + gi;
+        uint32_t* hist = hist3 + hsel * PF2_NB;        // all zero (start / zeroed during the copy-out before last)
+        const uint32_t* written = written2 + wsel * PF2_NB;
+        uint32_t pk[PF2_TILES][G], rank[PF2_TILES][G];
+#pragma unroll
         for (uint32_t q = 0; q < PF2_TILES; ++q) {
             const bool live = t0 + q < n_tiles && (t0 + q) * 64 + lane < P.n_reads;
-            // (this kernel is launched with G == np — all probes of a read in one group —, so a tile's probes share ONE execution mask)
+            // (with NG == 1 the kernel is launched with G == np — all probes of a read in one group —; a tile's probes share ONE execution
+            // mask; the test against np below is the same for every lane)
             if (live) {
 #pragma unroll
                 for (uint32_t u = 0; u < G; ++u) {
-                    pk[q][u] = canon16(pk[q][u]) * S16_MUL;
-                    rank[q][u] = atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u);
+                    if (NG == 1 || gi * G + u < P.np) {
+                        pk[q][u] = canon16(pka[q][gi * G + u]) * S16_MUL;
+                        rank[q][u] = atomicAdd(&hist[pk[q][u] >> (32 - PF2_NB_LOG2)], 1u);
+                    } else { pk[q][u] = 0u; rank[q][u] = EMPTY32; }
                 }
             } else {
 #pragma unroll
@@ -770,6 +781,7 @@ __global__ __launch_bounds__(64 * PF2_WAVES) void pf4_scatter_lines_kernel(Part4
         }
         hsel = hsel == 2 ? 0 : hsel + 1;
         wsel ^= 1u;
+      }
     }
     vm_wait<0>();   // the last prefetch (idle tiles) still targets this wave's registers
     __syncthreads();
@@ -2000,7 +2012,7 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         // and a line's index in `pairs` fits 32 bits (screen_variant 17: the unaligned form all the same)
         const uint32_t grp = F.np < PF2_GROUP ? (F.np ? F.np : 1u) : PF2_GROUP;   // probes per sorted group
         Q.n_grp = (F.np + grp - 1) / grp;
-        const bool lines = Q.n_grp == 1 && pf4_lines_lds_bytes(slice_words, grp) <= 160 * 1024 && ctx->screen_variant != 17 &&
+        const bool lines = Q.n_grp <= 2 && pf4_lines_lds_bytes(slice_words, grp) <= 160 * 1024 && ctx->screen_variant != 17 &&
                            (uint64_t)PF2_NB * Q.n_writers * (Q.cap >> 5) + 1 < 0xFFFFFFFFull;
         Q.n_groups = (uint32_t)(n_iter * Q.n_grp);
         Q.gs = (Q.n_groups + 1 + 15) & ~15u;
@@ -2022,11 +2034,13 @@ int launch_screen(gf_ctx* ctx, const FlankIndex& ix, const void* d_reads, const 
         Q.pairs = (uint32_t*)(ws + b_cnt + b_seen + b_fill + b_c8);
         GF_HIP(ctx, hipMemsetAsync(ws + b_cnt - 256, 0, 256 + b_seen, ctx->stream));
         ctx->screen_kernels = std::string(lines ? "pf4_scatter_lines_kernel<" : "pf4_scatter_kernel<") + std::to_string(grp) + "u, " +
-                              (((F.first2 & 7u) == 0 && (F.stride2 & 7u) == 0) ? "true" : "false") + ">,pf4_probe_kernel,pf4_resolve_kernel,pf4_list_kernel";
+                              (((F.first2 & 7u) == 0 && (F.stride2 & 7u) == 0) ? "true" : "false") + (lines ? (Q.n_grp == 2 ? ", 2u" : ", 1u") : "") +
+                              ">,pf4_probe_kernel,pf4_resolve_kernel,pf4_list_kernel";
         LaunchTimer tm(ctx, GF_KERNEL_SCREEN);
         if (lines) {
             const bool bytes = (F.first2 & 7u) == 0 && (F.stride2 & 7u) == 0;
             void (*scatter)(Part4Params, uint32_t) =
+                Q.n_grp == 2 ? (bytes ? pf4_scatter_lines_kernel<4, true, 2> : pf4_scatter_lines_kernel<4, false, 2>) :      // (five to eight probes per read: grp == 4)
                 bytes ? (grp == 1 ? pf4_scatter_lines_kernel<1, true> : grp == 2 ? pf4_scatter_lines_kernel<2, true> : grp == 3 ? pf4_scatter_lines_kernel<3, true> : pf4_scatter_lines_kernel<4, true>)
                       : (grp == 1 ? pf4_scatter_lines_kernel<1, false> : grp == 2 ? pf4_scatter_lines_kernel<2, false> : grp == 3 ? pf4_scatter_lines_kernel<3, false> : pf4_scatter_lines_kernel<4, false>);
             hipLaunchKernelGGL(scatter, dim3(Q.n_writers), dim3(64 * PF2_WAVES), pf4_lines_lds_bytes(slice_words, grp), ctx->stream, Q, (uint32_t)slice_words);

@@ -398,6 +398,15 @@ def test_screen_filter_variants_agree(gf, variant):
             for k in (61, 45):
                 assert _same(gf.screen_reads(packed, c["L"], k), CO.screen_reads(c["reads_blob"], c["L"], c["flanks"], k)), k
                 assert "pf4_scatter_lines_kernel<%du" % {61: 2, 45: 4}[k] in B.lib().gf_screen_kernels(gf.handle).decode()
+            # five to eight probes per read (k = 41 ... 31 on 150-base reads): TWO groups of four per tile iteration through the same whole-line
+            # kernel, the slots beyond the read's probe count dead
+            for k in (31, 33, 36, 41):
+                assert _same(gf.screen_reads(packed, c["L"], k), CO.screen_reads(c["reads_blob"], c["L"], c["flanks"], k)), k
+                names = B.lib().gf_screen_kernels(gf.handle).decode()
+                assert "pf4_scatter_lines_kernel<4u, " in names and ", 2u>" in names, (k, names)
+                for n in (1000, 769, 1):
+                    e_k = CO.screen_reads(c["reads_blob"][:n * c["L"]], c["L"], c["flanks"], k)
+                    assert _same(gf.screen_reads(packed[:n], c["L"], k), e_k), (k, n)
             c2 = S.small_case(seed=42, n_pairs=12000, L=100)
             gf.set_gaps(c2["gaps"], c2["n_scaffolds"], c2["flanks"])
             packed2, _ = GapFill.pack_reads(c2["reads_blob"], 100)
