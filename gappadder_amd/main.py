@@ -110,6 +110,9 @@ def main_func(command, sf_config):
         folders = prepare_folders(cfg["alignments"], wf)
         if len(cfg["alignments"]) != len(cfg["raw_reads"]):
             raise SystemExit("# of alignment files and # of raw reads do not match!!!!!")
+        # FASTQ(.gz): gzip / BGZF read files are inflated once into {wf}tmp_fastq/; every path below reads plain text
+        from .fastq_io import plain_fastq
+        cfg["raw_reads"] = [(plain_fastq(l, wf + "tmp_fastq"), plain_fastq(r, wf + "tmp_fastq")) for l, r in cfg["raw_reads"]]
         done = False
         if bam_io.is_builtin(cfg["samtools"]) and os.environ.get("GF_DEVICE_COLLECT", "1") != "0":
             # libraries resident in HBM, one pass over every file, the pipeline bench.py times (device_collect.py); with `-c All` the

@@ -394,6 +394,27 @@ def test_an_allocation_failure_inside_the_resident_path_ends_in_the_fallback(run
         _run_stages(cfgp, ["Collect"])
 
 
+def test_gzip_fastq_inputs_write_the_same_tree(run, tmp_path):
+    """FASTQ(.gz): the read files gzip-compressed — `-c All` on resident libraries inflates them once into
+    {wf}tmp_fastq/ and writes the tree of the plain-text run (the per-gap FASTQ records are cut out of the plain copies)."""
+    import gzip
+    import json
+    case, _, ref_tree = run
+    cfgp, wf, _ = PU.materialise(case, str(tmp_path), kmers=((31, 29), (41, 39), (41, 38)), builtin_bam=True)
+    cfg = json.load(open(cfgp))
+    for rr in cfg["raw_reads"]:
+        for side in ("left", "right"):
+            raw = open(rr[side], "rb").read()
+            open(rr[side] + ".gz", "wb").write(gzip.compress(raw[:len(raw) // 2]) + gzip.compress(raw[len(raw) // 2:]))
+            os.remove(rr[side])
+            rr[side] += ".gz"
+    json.dump(cfg, open(cfgp, "w"))
+    _run_stages(cfgp, ["All"])
+    got = {k: v for k, v in PU.tree(wf).items() if not k.startswith("tmp_fastq/")}
+    _same_tree(got, ref_tree)
+    assert len([f for f in os.listdir(wf + "tmp_fastq")]) == 2 * len(case.libs)
+
+
 def test_resident_path_with_n_bases_ragged_reads_and_a_late_long_read(tmp_path):
     """Reads with N, reads of different lengths (packed at the longest, the tail masked) and a read longer than the first ones promised
     (the ingest restarts at its length): the N masks travel with the pooled reads through the library merge into the first assembly

@@ -517,3 +517,36 @@ def test_both_unmapped_dictionary_and_mate_files_follow_the_line_loop(tmp_path, 
     open(bam + ".both_unmapped.fq", "w").write("@z_1\nAC\n+\nII\n")
     with pytest.raises(KeyError):
         c.collect_both_unmapped_reads([bam], [])
+
+
+def test_gzip_and_bgzf_fastq_files_are_inflated_once(tmp_path):
+    """fastq_io.plain_fastq (SURVEY.md §8f-4 FASTQ(.gz)): plain gzip, concatenated members and BGZF (a chain of small gzip members with an
+    empty one at the end) come back as one plain copy; plain text passes through; the copy is reused while it is newer than its source."""
+    import gzip
+    import struct
+    import zlib
+    from gappadder_amd import fastq_io as F
+    text = "".join("@r%d/1\n%s\n+\n%s\n" % (i, "ACGT" * 25, "I" * 100) for i in range(3000)).encode()
+    plain = tmp_path / "a.fq"
+    plain.write_bytes(text)
+    assert F.plain_fastq(str(plain), str(tmp_path / "t")) == str(plain) and not (tmp_path / "t").exists()
+    gz = tmp_path / "b.fq.gz"
+    gz.write_bytes(gzip.compress(text[:100000]) + gzip.compress(text[100000:]))          # two members (`cat x.gz y.gz`)
+
+    def bgzf(data, block=30000):
+        out = b""
+        for a in list(range(0, len(data), block)) + [len(data)]:      # the last, empty block = BGZF's end-of-file marker
+            raw = data[a:a + block] if a < len(data) else b""
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = co.compress(raw) + co.flush()
+            bsize = 12 + 6 + len(body) + 8
+            out += b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) + body + \
+                struct.pack("<II", zlib.crc32(raw), len(raw))
+        return out
+    bz = tmp_path / "c.fastq.gz"
+    bz.write_bytes(bgzf(text))
+    for src in (gz, bz):
+        out = F.plain_fastq(str(src), str(tmp_path / "t"))
+        assert out != str(src) and open(out, "rb").read() == text
+        m = os.path.getmtime(out)
+        assert F.plain_fastq(str(src), str(tmp_path / "t")) == out and os.path.getmtime(out) == m      # reused, not written again
