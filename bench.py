@@ -77,6 +77,11 @@ def parse_args():
     ap.add_argument("--asm-tiebreak", default="counts", choices=["counts", "none"],
                     help="error removal between branches of equal coverage: counts (default: fewer weak k-mers win) or none (reference-shaped: "
                          "sequence order alone, nothing Velvet could not have known, assemble_gaps.py:56-79); the oracle follows")
+    ap.add_argument("--merge-round", default="auto", choices=["auto", "on", "off", "host"],
+                    help="the contig-merge round (assemble_gaps.py:301-306) for the gaps the first pick leaves open, on the device, INSIDE the timed step: "
+                         "auto (default) = on where a library can span the gaps (the configurations with the mate-pair library: C5, C2RM) — with the "
+                         "300-bp library alone every 2-kb gap stays open by construction, nothing can be closed by merging, and the round over all "
+                         "gaps is measured once behind the timed region instead (`contig_merge_round_all_gaps`); host = the host twin, untimed")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C5 child runs that the default N=1 run appends as `extras`")
     ap.add_argument("--e2e-only", default="", help="run only the file-based end-to-end extra on this configuration (C2 / C3) and print its object")
@@ -231,10 +236,10 @@ def run(args):
     # merge / owner exchange -> assembly -> pick): this file generates the inputs, calls it and times it
     # GF_BENCH_TAG_KEYS=0: the tagger streams the 32-byte records themselves instead of their 8-byte key column (ablation)
     key_column = os.environ.get("GF_BENCH_TAG_KEYS", "1") != "0"
-    # the contig-merge round runs inside the step (GF_BENCH_MERGE=0: off; GF_BENCH_MERGE=host: off in the step, the host round behind it, untimed)
-    merge_mode = os.environ.get("GF_BENCH_MERGE", "1")
+    merge_mode = args.merge_round
+    merge_on = merge_mode == "on" or (merge_mode == "auto" and args.config in MATE_PAIRS and (args.mp_reads != 0))
     pipe = Pipeline(gf, n_gaps, L, kk, device=dev, world=world, rank=rank, backend=backend, force_exchange=multi and world == 1, key_column=key_column,
-                    merge_in_step=merge_mode not in ("0", "host"))
+                    merge_in_step=merge_on)
     pipe.tag_after_filter = not serial and os.environ.get("GF_BENCH_TAG_AFTER_FILTER", "0") == "1"
     pipe.tag_ahead = tag_ahead
     h = gf.handle
@@ -496,6 +501,22 @@ def run(args):
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, libs, flanks, gaps, L, kk, asm_pool_t, asm_off_t, ctg, d_seq, n_seq, d_best, step_s,
                                                n_screened, B, rb, merge_n0=res.merge["contigs_before"] if res.merge is not None else None)
+    if rank == 0 and merge_mode == "auto" and not merge_on and not multi and kk:
+        # no library spans the gaps (C2 / C3 / C4): the step above ran without the merge round; ONE more step with it, behind the timed region
+        # (and behind every check of the timed steps' results), says what merging every open gap's contigs costs and yields — the reference
+        # merges every gap (assemble_gaps.py:301-306)
+        pipe.merge_in_step = True
+        torch.cuda.synchronize()
+        tm0 = time.perf_counter()
+        pipe.step(1)
+        pipe.barrier()
+        tm = time.perf_counter() - tm0
+        r2 = pipe.fetch()
+        pipe.merge_in_step = False
+        out["contig_merge_round_all_gaps"] = dict(r2.merge, inside_the_timed_step=False, ms_of_one_step_with_the_round=tm * 1e3,
+                                                  ms_of_the_round=tm * 1e3 - step_s * 1e3, gaps_closed_with_it=r2.n_closed,
+                                                  note="measured once behind the timed region: no library of this configuration spans a gap, "
+                                                       "so merging the open gaps' contigs closes nothing here")
     for g_ in ctxs:
         g_.close()
     return (out if rank == 0 else None), rank, world
@@ -648,6 +669,7 @@ def child_run(argv):
                                         "phases_ms", "counts", "closed_truth_check", "assembly")} | \
                ({"open_gap_census": d["open_gap_census"]} if "open_gap_census" in d else {}) | \
                ({"contig_merge_round": d["contig_merge_round"]} if "contig_merge_round" in d else {}) | \
+               ({"contig_merge_round_all_gaps": d["contig_merge_round_all_gaps"]} if "contig_merge_round_all_gaps" in d else {}) | \
                {"workload": d["config"]["workload"], "roofline_frac": d["roofline"]["frac"], "filter_ms": d["roofline"]["avg_launch_ms"]}
     except Exception as e:      # the headline line must not depend on an extra
         return {"error": repr(e)[:300], "stderr_tail": (r.stderr.decode()[-400:] if r is not None else "")}

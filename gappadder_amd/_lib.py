@@ -34,6 +34,7 @@ KERNEL_SCREEN, KERNEL_TAG, KERNEL_LOWMAPQ, KERNEL_ASSEMBLE, KERNEL_POOL, KERNEL_
 
 # words of the merge round's statistics (gf_merge_open_gaps_dev, u32[32])
 MG_N_PRE, MG_N_SETS, MG_SKIPPED, MG_N_PAIRS, MG_QC_FLAGS, MG_N_JOBS, MG_ERR, MG_N0, MG_N_EDGES, MG_SETS_WITH_JOBS = range(10)
+MG_SKIPPED_GRAPH = 16
 MG_WORDS = 32
 
 _lib = None

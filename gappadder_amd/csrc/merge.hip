@@ -378,9 +378,12 @@ constexpr uint32_t MG_PATH_BYTES = 1u << 17;   // their nodes (bytes) per workgr
 constexpr uint32_t MG_MIN_NODE = 30, MG_MAX_NODE = OV_MAXLEN;
 constexpr uint32_t MG_PER_ROOT = 21;      // MAX_CONTIG_IN_PATH_COUNT + 1 (ContigsCompactor.cpp:34; MergeContigs.find_paths)
 enum { MG_N_PRE = 0, MG_N_SETS = 1, MG_SKIPPED = 2, MG_N_PAIRS = 3, MG_QC_FLAGS = 4, MG_N_JOBS = 5, MG_ERR = 6, MG_N0 = 7, MG_N_EDGES = 8,
-       MG_SETS_WITH_JOBS = 9, MG_Q_JOBS = 10, MG_Q_SETS = 11, MG_JOB_NODES = 12, MG_Q_DEDUP = 13, MG_Q_COPY = 14, MG_N_NODES = 15, MG_WORDS = 32 };
-// error bits
-constexpr uint32_t MG_E_SEQ = 1, MG_E_PAIRS = 2, MG_E_EDGES = 4, MG_E_PATHS = 8, MG_E_JOBS = 16, MG_E_CONTIGS = 32, MG_E_OUTSEQ = 64;
+       MG_SETS_WITH_JOBS = 9, MG_Q_JOBS = 10, MG_Q_SETS = 11, MG_JOB_NODES = 12, MG_Q_DEDUP = 13, MG_Q_COPY = 14, MG_N_NODES = 15, MG_SKIPPED_GRAPH = 16,
+       MG_WORDS = 32 };
+// error bits: capacities of this call (the caller sizes them: raise).  A set whose GRAPH outgrows the round's own limits — more than
+// MG_MAX_EDGES edges, MG_MAX_PATHS paths or MG_PATH_BYTES path nodes (the contig graph of a repeat-bearing gap has thousands of paths) —
+// is left alone and counted in stats[MG_SKIPPED_GRAPH], like the sets of more than max_set contigs in stats[MG_SKIPPED]
+constexpr uint32_t MG_E_SEQ = 1, MG_E_PAIRS = 2, MG_E_JOBS = 16, MG_E_CONTIGS = 32, MG_E_OUTSEQ = 64;
 
 struct MgJob { uint32_t set, off, len; };   // path = job_nodes[off .. off + len)
 
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(256) void mg_paths_kernel(MgParams P) {
         }
         __syncthreads();
         const uint32_t E = s_n_edges;
-        if (E > MG_MAX_EDGES) { if (tid == 0) atomicOr(&P.stats[MG_ERR], MG_E_EDGES); continue; }
+        if (E > MG_MAX_EDGES) { if (tid == 0) atomicAdd(&P.stats[MG_SKIPPED_GRAPH], 1u); continue; }
         if (E == 0) continue;
         if (tid == 0) atomicAdd(&P.stats[MG_N_EDGES], E);
         // adjacency lists in the order the reference adds the edges: pairs (i, j) ascending -> sort by (src, i, j)
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(256) void mg_paths_kernel(MgParams P) {
             }
         }
         __syncthreads();
-        if (s_bad) { if (tid == 0) atomicOr(&P.stats[MG_ERR], MG_E_PATHS); continue; }
+        if (s_bad) { if (tid == 0) atomicAdd(&P.stats[MG_SKIPPED_GRAPH], 1u); continue; }
         const uint32_t NP = s_n_paths;
         if (NP == 0) continue;
         __threadfence_block();
@@ -1089,7 +1092,7 @@ int launch_merge_round(gf_ctx* ctx, void* d_contigs, void* d_n_contigs, size_t c
     const size_t node_cap = contig_cap;
     const size_t mseq_cap = std::min<size_t>(seq_cap, (size_t)512 << 20);
     const size_t pair_cap = std::min<size_t>((size_t)4 << 20, std::max<size_t>(65536, 16 * contig_cap));
-    const size_t job_cap = 65536, job_node_cap = (size_t)4 << 20;
+    const size_t job_cap = std::max<size_t>(65536, 16 * ng), job_node_cap = std::max<size_t>((size_t)4 << 20, 512 * ng);
     // one workspace, carved
     size_t at = 0;
     auto take = [&](size_t bytes) { const size_t o = at; at += mg_align(bytes); return o; };

@@ -328,7 +328,7 @@ class GapFill:
             self._chk(self._L.gf_memcpy_d2h(self._h, B._p(st), d_stats, st.nbytes), "gf_memcpy_d2h")
             self._chk(self._L.gf_memcpy_d2h(self._h, B._p(cnt), d_cnt, cnt.nbytes), "gf_memcpy_d2h")
             n1, sl = int(cnt[0]), int(cnt[2:4].view(np.uint64)[0])
-            stats = {"gaps_tried": int(st[B.MG_N_SETS]), "gaps_skipped_large": int(st[B.MG_SKIPPED]), "pairs": int(st[B.MG_N_PAIRS]), "edges": int(st[B.MG_N_EDGES]),
+            stats = {"gaps_tried": int(st[B.MG_N_SETS]), "gaps_skipped_large": int(st[B.MG_SKIPPED]), "gaps_skipped_graph": int(st[B.MG_SKIPPED_GRAPH]), "pairs": int(st[B.MG_N_PAIRS]), "edges": int(st[B.MG_N_EDGES]),
                      "new_contigs": int(st[B.MG_N_JOBS]), "gaps_with_new_contigs": int(st[B.MG_SETS_WITH_JOBS]), "error_bits": int(st[B.MG_ERR]),
                      "prefilter_flags": int(st[B.MG_QC_FLAGS]), "contigs_before": int(st[B.MG_N0])}
             if st[B.MG_ERR] or n1 > cap or sl > seq_cap:

@@ -531,7 +531,7 @@ class Pipeline:
             ms = self.d_mstats.cpu().numpy().view(np.uint32)
             if int(ms[B.MG_ERR]):
                 raise RuntimeError("merge round: capacity flags %#x" % int(ms[B.MG_ERR]))
-            r.merge = {"gaps_tried": int(ms[B.MG_N_SETS]), "gaps_skipped_large": int(ms[B.MG_SKIPPED]), "candidate_pairs": int(ms[B.MG_N_PAIRS]),
+            r.merge = {"gaps_tried": int(ms[B.MG_N_SETS]), "gaps_skipped_large": int(ms[B.MG_SKIPPED]), "gaps_skipped_graph": int(ms[B.MG_SKIPPED_GRAPH]), "candidate_pairs": int(ms[B.MG_N_PAIRS]),
                        "edges": int(ms[B.MG_N_EDGES]), "new_contigs": int(ms[B.MG_N_JOBS]), "gaps_with_new_contigs": int(ms[B.MG_SETS_WITH_JOBS]),
                        "contigs_before": int(ms[B.MG_N0])}
         r.asm_off_t = self.d_moff if self.need_merge else self.libs[0].d_pool_off
