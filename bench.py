@@ -516,7 +516,7 @@ def run(args):
         out["contig_merge_round_all_gaps"] = dict(r2.merge, inside_the_timed_step=False, ms_of_one_step_with_the_round=tm * 1e3,
                                                   ms_of_the_round=tm * 1e3 - step_s * 1e3, gaps_closed_with_it=r2.n_closed,
                                                   note="measured once behind the timed region: no library of this configuration spans a gap, "
-                                                       "so merging the open gaps' contigs closes nothing here")
+                                                       "so merging the open gaps' contigs closes (next to) nothing here")
     for g_ in ctxs:
         g_.close()
     return (out if rank == 0 else None), rank, world

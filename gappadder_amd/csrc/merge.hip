@@ -383,7 +383,7 @@ enum { MG_N_PRE = 0, MG_N_SETS = 1, MG_SKIPPED = 2, MG_N_PAIRS = 3, MG_QC_FLAGS 
 // error bits: capacities of this call (the caller sizes them: raise).  A set whose GRAPH outgrows the round's own limits — more than
 // MG_MAX_EDGES edges, MG_MAX_PATHS paths or MG_PATH_BYTES path nodes (the contig graph of a repeat-bearing gap has thousands of paths) —
 // is left alone and counted in stats[MG_SKIPPED_GRAPH], like the sets of more than max_set contigs in stats[MG_SKIPPED]
-constexpr uint32_t MG_E_SEQ = 1, MG_E_PAIRS = 2, MG_E_JOBS = 16, MG_E_CONTIGS = 32, MG_E_OUTSEQ = 64;
+constexpr uint32_t MG_E_SEQ = 1, MG_E_PAIRS = 2, MG_E_CONTIGS = 32, MG_E_OUTSEQ = 64;
 
 struct MgJob { uint32_t set, off, len; };   // path = job_nodes[off .. off + len)
 
@@ -959,7 +959,9 @@ __global__ __launch_bounds__(256) void mg_paths_kernel(MgParams P) {
             for (uint32_t a = 0; a < NP; ++a) if (s_keep[a]) { ++nj; nb += s_plen[a]; }
             uint32_t jb = 0, bb = 0;
             if (nj) { jb = atomicAdd(&P.stats[MG_N_JOBS], nj); bb = atomicAdd(&P.stats[MG_JOB_NODES], nb); }
-            if (nj && (jb + nj > P.job_cap || bb + nb > P.job_node_cap)) { atomicOr(&P.stats[MG_ERR], MG_E_JOBS); nj = 0; }
+            // (no room in the job list — a repeat-bearing draft with thousands of paths per gap: the set is left alone and counted; its
+            // reserved slots stay EMPTY and the string kernel passes over them)
+            if (nj && (jb + nj > P.job_cap || bb + nb > P.job_node_cap)) { atomicAdd(&P.stats[MG_SKIPPED_GRAPH], 1u); nj = 0; }
             s_n_edges = jb; s_n_comp = bb; s_n_roots = nj;      // (reused as broadcast slots)
             if (nj) { P.set_jobs[2 * st] = jb; P.set_jobs[2 * st + 1] = nj; atomicAdd(&P.stats[MG_SETS_WITH_JOBS], 1u); }
         }
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(OV_NT) void mg_strings_kernel(MgParams P) {
         if (ji >= n_jobs) break;
         const MgJob job = P.jobs[ji];
         const uint32_t st = job.set;
-        if (P.set_jobs[2 * st + 1] == 0) continue;
+        if (st == EMPTY32 || P.set_jobs[2 * st + 1] == 0) continue;      // (a slot of a reservation that did not fit)
         const unsigned long long c0 = P.set_off[st];
         const uint8_t* path = P.job_nodes + job.off;
         auto node_src = [&](uint32_t v, int* n) { const unsigned long long o = P.contig_off[c0 + (v >> 1)]; *n = (int)(P.contig_off[c0 + (v >> 1) + 1] - o); return P.mseq + o; };
@@ -1126,6 +1128,7 @@ int launch_merge_round(gf_ctx* ctx, void* d_contigs, void* d_n_contigs, size_t c
     LaunchTimer tm(ctx, GF_KERNEL_MERGE);
     GF_HIP(ctx, hipMemsetAsync(d_stats, 0, MG_WORDS * 4, ctx->stream));
     GF_HIP(ctx, hipMemsetAsync(P.cnt, 0, ng * 4, ctx->stream));
+    GF_HIP(ctx, hipMemsetAsync(P.jobs, 0xFF, job_cap * sizeof(MgJob), ctx->stream));
     uint32_t* d_next_qc = (uint32_t*)ctx->counters.p + 9;
     uint32_t* d_next_ov = (uint32_t*)ctx->counters.p + 11;
     zero_regions(ctx, ZeroList{{d_next_qc, d_next_ov, nullptr, nullptr}, {1, 1, 0, 0}});
