@@ -792,7 +792,7 @@ def cpu_baseline(args, libs, flanks, gaps, L, kk, pool_t, off_t, ctg, d_seq, n_s
         open_first = [g for g in gsel if int(best[g]) == 0][:8]          # sampled gaps that stayed open: the round must have appended exactly what the oracle says (often nothing)
         tmg = time.perf_counter()
         with ThreadPoolExecutor(max_workers=cores) as ex:
-            oks = list(ex.map(lambda g: SC.merged_equal(ctg, seq, [g], merge_n0) and SC.picks_equal(ctg, seq, best, flanks, kk, [g]), pick_m + open_first))
+            oks = list(ex.map(lambda g: SC.merged_equal(ctg, seq, [g], merge_n0, kk) and SC.picks_equal(ctg, seq, best, flanks, kk, [g]), pick_m + open_first))
         ok_merge, n_merge_checked = all(oks), len(oks)
         notes.append("merge round: %d gaps (%.2f s)" % (n_merge_checked, time.perf_counter() - tmg))
     striped = not all(w["complete"] for w in where.values()) or n_g < len(gaps)

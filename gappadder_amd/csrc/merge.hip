@@ -430,6 +430,10 @@ struct MgParams {
     uint32_t* set_rec;                // [set]: contig record of the set's first job
     char* cur_ws;                     // per workgroup: 2 x 16 384 bytes (the running string and its successor)
     gf_ovl_params pr;
+    // order of a gap's contigs = the order of its contigs.fa (assemble_gaps.py:124-135): the (k, kv) pairs in list order, inside a pair by
+    // (length descending, sequence) — n_k > 0; n_k == 0: record order (contig index)
+    uint32_t n_k;
+    uint16_t k_list[16], kv_list[16];
 };
 
 __device__ __forceinline__ uint32_t mg_block_scan_excl(uint32_t v, uint32_t* s_w, uint32_t* total) {   // blockDim.x a multiple of 64, <= 1024
@@ -501,7 +505,7 @@ __device__ __forceinline__ char mg_comp(char c) { return c == 'A' ? 'T' : c == '
 // index ascending) order — containment is transitive, so this is drop_contained's "inside a KEPT contig" without its serial order
 __global__ __launch_bounds__(1024) void mg_dedup_kernel(MgParams P) {
     __shared__ uint32_t s_id[MG_MAX_IN], s_len[MG_MAX_IN];
-    __shared__ unsigned long long s_off[MG_MAX_IN];
+    __shared__ unsigned long long s_off[MG_MAX_IN], s_key[MG_MAX_IN];
     __shared__ uint8_t s_drop[MG_MAX_IN];
     __shared__ uint32_t s_w[20], s_set;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -515,15 +519,36 @@ __global__ __launch_bounds__(1024) void mg_dedup_kernel(MgParams P) {
         uint32_t np2 = 2;
         while (np2 < n) np2 <<= 1;
         s_id[tid] = tid < n ? P.ids[o + tid] : EMPTY32;
+        // sort key: (pair index, length descending) — or, without a pair list, the contig index; ties by sequence, then index
+        {
+            unsigned long long key = ~0ull;
+            if (tid < n) {
+                const gf_contig c = P.contigs[s_id[tid]];
+                uint32_t pi = 0xFFFFu;
+                for (uint32_t q = 0; q < P.n_k; ++q) if (P.k_list[q] == c.k && P.kv_list[q] == c.kv) { pi = q; break; }
+                key = P.n_k ? ((unsigned long long)pi << 32) | (0xFFFFFFFFu - c.length) : (unsigned long long)s_id[tid];
+            }
+            s_key[tid] = key;
+        }
         __syncthreads();
-        for (uint32_t k = 2; k <= np2; k <<= 1)         // bitonic sort, ascending contig index
+        auto before = [&](uint32_t ia, unsigned long long ka, uint32_t ib, unsigned long long kb) {   // does (ia, ka) stand before (ib, kb)?
+            if (ka != kb) return ka < kb;
+            if (ia == EMPTY32 || ib == EMPTY32 || !P.n_k) return ia < ib;
+            const gf_contig ca = P.contigs[ia], cb = P.contigs[ib];
+            const char* sa = P.seq + ca.seq_off;
+            const char* sb = P.seq + cb.seq_off;
+            for (uint32_t t = 0; t < ca.length; ++t) if (sa[t] != sb[t]) return sa[t] < sb[t];      // (equal keys: equal lengths)
+            return ia < ib;
+        };
+        for (uint32_t k = 2; k <= np2; k <<= 1)         // bitonic sort
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
                 if (tid < np2) {
                     const uint32_t x = tid ^ j;
                     if (x > tid) {
                         const uint32_t a = s_id[tid], b = s_id[x];
+                        const unsigned long long ka = s_key[tid], kb = s_key[x];
                         const bool up = (tid & k) == 0;
-                        if ((a > b) == up) { s_id[tid] = b; s_id[x] = a; }
+                        if (before(b, kb, a, ka) == up) { s_id[tid] = b; s_id[x] = a; s_key[tid] = kb; s_key[x] = ka; }
                     }
                 }
                 __syncthreads();
@@ -590,7 +615,7 @@ __global__ __launch_bounds__(1024) void mg_dedup_kernel(MgParams P) {
         if (lane == 0 && bytes) atomicAdd(&P.node_bytes[pre], bytes);
         const uint32_t my_id = tid < n ? s_id[tid] : 0;
         __syncthreads();
-        if (keep) P.ids[o + ek] = my_id;       // kept contigs, ascending index, at the front of the gap's list
+        if (keep) P.ids[o + ek] = my_id;       // kept contigs, in the gap's contig order, at the front of the gap's list
         if (tid == 0) { P.kept_n[pre] = tk; P.node_n[pre] = tn; }
     }
 }
@@ -1088,7 +1113,8 @@ __global__ __launch_bounds__(OV_NT) void mg_strings_kernel(MgParams P) {
 static inline size_t mg_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 int launch_merge_round(gf_ctx* ctx, void* d_contigs, void* d_n_contigs, size_t contig_cap, void* d_seq, void* d_seq_len, size_t seq_cap,
-                       const void* d_gap_best, size_t n_gaps, const gf_ovl_params* params, int kq, int max_set, void* d_stats) {
+                       const void* d_gap_best, size_t n_gaps, const gf_ovl_params* params, int kq, int max_set, const int* k_list, const int* kv_list,
+                       int n_k, void* d_stats) {
     const unsigned grid = (unsigned)ctx->n_cu;
     const size_t ng = n_gaps;
     const size_t node_cap = contig_cap;
@@ -1125,6 +1151,8 @@ int launch_merge_round(gf_ctx* ctx, void* d_contigs, void* d_n_contigs, size_t c
     P.set_jobs = (uint32_t*)(W + o_sjobs); P.set_rec = (uint32_t*)(W + o_srec); P.cur_ws = (char*)(W + o_cur);
     P.pr = *params;
     P.pr.relax = 0.0;
+    P.n_k = (uint32_t)n_k;
+    for (int q = 0; q < n_k; ++q) { P.k_list[q] = (uint16_t)k_list[q]; P.kv_list[q] = (uint16_t)kv_list[q]; }
     LaunchTimer tm(ctx, GF_KERNEL_MERGE);
     GF_HIP(ctx, hipMemsetAsync(d_stats, 0, MG_WORDS * 4, ctx->stream));
     GF_HIP(ctx, hipMemsetAsync(P.cnt, 0, ng * 4, ctx->stream));
@@ -1329,7 +1357,9 @@ int gf_overlap_evaluate(gf_ctx* ctx, const char* seq, const uint64_t* contig_off
 }
 
 int gf_merge_open_gaps_dev(gf_ctx* ctx, void* d_contigs, void* d_n_contigs, size_t contig_cap, void* d_seq, void* d_seq_len, size_t seq_cap,
-                           const void* d_gap_best, size_t n_gaps, const gf_ovl_params* params, int kmer_len_quick, int max_set, void* d_stats) {
+                           const void* d_gap_best, size_t n_gaps, const gf_ovl_params* params, int kmer_len_quick, int max_set, const int* k_list,
+                           const int* kv_list, int n_k, void* d_stats) {
+    if (n_k < 0 || n_k > 16 || (n_k && (!k_list || !kv_list))) return GF_E_INVAL;
     if (!ctx || !d_contigs || !d_n_contigs || !d_seq || !d_seq_len || !d_gap_best || !params || !d_stats || contig_cap > 0x7FFFFFFFull ||
         n_gaps > 0xFFFFFFF0ull || kmer_len_quick < 4 || kmer_len_quick > 16 || max_set < 2 || max_set > (int)(MG_MAX_NODES / 2))
         return GF_E_INVAL;
@@ -1340,7 +1370,7 @@ int gf_merge_open_gaps_dev(gf_ctx* ctx, void* d_contigs, void* d_n_contigs, size
     GF_HIP(ctx, hipSetDevice(ctx->device));
     if (!n_gaps) { GF_HIP(ctx, hipMemsetAsync(d_stats, 0, MG_WORDS * 4, ctx->stream)); return GF_OK; }
     return launch_merge_round(ctx, d_contigs, d_n_contigs, contig_cap, d_seq, d_seq_len, seq_cap, d_gap_best, n_gaps, params, kmer_len_quick, max_set,
-                              d_stats);
+                              k_list, kv_list, n_k, d_stats);
 }
 
 }  // extern "C"

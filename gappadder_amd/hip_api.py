@@ -285,18 +285,24 @@ class GapFill:
                   "gf_overlap_evaluate")
         return out
 
-    def merge_round(self, contig_sets, params=None, kmer_len_quick=10, max_set=128, open_gaps=None):
+    def merge_round(self, contig_sets, params=None, kmer_len_quick=10, max_set=128, open_gaps=None, k_pairs=None):
         """The contig-merge round of the step (gf_merge_open_gaps_dev) on contig sets given from the host: contig_sets[g] = the contigs
         of gap g; every gap counts as open unless open_gaps (booleans) says otherwise.  Returns (per gap the merged sequences in record
-        order, stats dict).  A test / tool entry: the pipeline calls the device function on the step's own contig list."""
+        order, stats dict).  k_pairs = [(k, kv)]: the contigs are (k, kv, sequence) triples in ANY record order and the round takes them in
+        the order of the gap's contigs.fa (pairs in list order, inside a pair by length descending, then sequence); without it: the order
+        given.  A test / tool entry: the pipeline calls the device function on the step's own contig list."""
         n_gaps = len(contig_sets)
+        kinfo = None
+        if k_pairs is not None:
+            kinfo = [(int(k), int(kv)) for g, cs in enumerate(contig_sets) for (k, kv, _) in cs]
+            contig_sets = [[c for (_, _, c) in cs] for cs in contig_sets]
         flat = [(g, c) for g, cs in enumerate(contig_sets) for c in cs]
         n0 = len(flat)
         cap = n0 + 4096 + 4 * n0
         ctg = np.zeros(cap, dtype=B.CONTIG)
         off = 0
         for i, (g, c) in enumerate(flat):
-            ctg[i] = (g, 31, 29, max(1, len(c) - 28), len(c), 0, 0, off)
+            ctg[i] = (g, kinfo[i][0] if kinfo else 31, kinfo[i][1] if kinfo else 29, max(1, len(c) - 28), len(c), 0, 0, off)
             off += len(c)
         blob = np.frombuffer("".join(c for _, c in flat).encode(), dtype=np.uint8)
         seq_cap = off + (1 << 20) + 8 * off
@@ -322,7 +328,10 @@ class GapFill:
             d_ctg, d_seq = dev(cap * 32, ctg[:max(1, n0)]), dev(seq_cap, blob)
             d_cnt, d_best, d_stats = dev(16, cnt), dev(best.nbytes, best), dev(4 * B.MG_WORDS)
             self._chk(self._L.gf_merge_open_gaps_dev(self._h, d_ctg, d_cnt, cap, d_seq, C.c_void_p(d_cnt.value + 8), seq_cap, d_best, n_gaps, B._p(pr),
-                                                     kmer_len_quick, max_set, d_stats), "gf_merge_open_gaps_dev")
+                                                     kmer_len_quick, max_set,
+                                                     (C.c_int * len(k_pairs))(*[int(k) for k, _ in k_pairs]) if k_pairs else None,
+                                                     (C.c_int * len(k_pairs))(*[int(kv) for _, kv in k_pairs]) if k_pairs else None,
+                                                     len(k_pairs) if k_pairs else 0, d_stats), "gf_merge_open_gaps_dev")
             self.sync()
             st = np.zeros(B.MG_WORDS, dtype=np.uint32)
             self._chk(self._L.gf_memcpy_d2h(self._h, B._p(st), d_stats, st.nbytes), "gf_memcpy_d2h")

@@ -477,7 +477,7 @@ class Pipeline:
             # the open gaps' contigs through the contig merger, merged contigs appended (k = kv = 0), second pick over THEM only
             self._chk(lib.gf_merge_open_gaps_dev(h, self.d_ctg.data_ptr(), self.ap, self.contig_cap, self.d_seq.data_ptr(), self.ap + 8, self.seq_cap,
                                                  self.d_best.data_ptr(), self.n_gaps, B._p(self.merge_params), 10, self.merge_max_set,
-                                                 self.d_mstats.data_ptr()), "gf_merge_open_gaps_dev")
+                                                 self.k_arr, self.kv_arr, min(16, len(self.kk)), self.d_mstats.data_ptr()), "gf_merge_open_gaps_dev")
             self._chk(lib.gf_pick_anchored2_from_dev(h, self.d_ctg.data_ptr(), self.ap, self.contig_cap, self.d_seq.data_ptr(), a0, a1,
                                                      self.d_mstats.data_ptr() + 4 * B.MG_N0, self.d_best.data_ptr(), self.ap + 16),
                       "gf_pick_anchored2_from_dev")

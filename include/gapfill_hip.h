@@ -508,6 +508,30 @@ int gf_overlap_evaluate(gf_ctx* ctx, const char* seq, const uint64_t* contig_off
 int gf_overlap_evaluate_dev(gf_ctx* ctx, const void* d_seq, const void* d_contig_off, const void* d_set_off, const void* d_pairs, size_t n_pairs,
                             const gf_ovl_params* params, void* d_out);
 
+/* ---- §8f-3 inside the step: the contig-merge ROUND for the gaps the pick left open (assemble_gaps.py:301-306 run_contigs_merge, which the
+ * reference runs before it picks, :335-339; a gap its own contigs close gains nothing from merging).  For every gap g with
+ * d_gap_best[g] == 0 and 2 .. 1 024 contigs in the list: exact-containment dedup (MergeContigs.drop_contained: a contig that occurs, on
+ * either strand, inside another one goes; of identical ones the first stays), then — 2 .. max_set (<= 128) contigs left, those of
+ * 30 .. 8 190 bases taking part — ContigsMerger itself: gf_quick_check's prefilter, gf_overlap_evaluate's edges (class 2, no containment),
+ * strongly connected components in topological order, candidate roots and ends, a shortest-path DP per root with -overlap as edge length
+ * (the 21 longest paths per root), removal of reverse-complement twin paths, and FormMergedSeqFromPath per path with Evaluate in its
+ * relaxed mode (GraphUtils.cpp:625-859, 1028-1178, 1258-1344, 1422-1454; ContigsCompactor.cpp:773-983, 1456-1520).  The merged strings are
+ * APPENDED to the contig list as records {gap, k = 0, kv = 0, n_nodes = nodes of the path, length, seq_off} in (gap, sorted path) order
+ * (NEW_CONTIG_MERGE_1, _2, ... of each gap); *d_n_contigs and *d_seq_len grow.  Everything is enqueued on the context's stream, no host
+ * synchronisation.  A gap's contigs are taken in the order of its contigs.fa: the (k_list[i], kv_list[i]) pairs in list order, inside a pair
+ * by (length descending, sequence) — n_k <= 16; n_k == 0: record order.
+ * d_stats: u32[32] — [0] open gaps with 2 .. 1 024 contigs, [1] gaps that went through the merger, [2] gaps left alone for their size
+ * (more than 1 024 contigs, or more than max_set after the dedup), [3] candidate pairs, [4] prefilter flags, [5] merged contigs, [6] capacity
+ * flags of THIS call (1 node buffer, 2 pair list, 32 contig list, 64 sequence buffer: the caller raises), [7] contigs before the round,
+ * [8] edges, [9] gaps that got merged contigs, [16] gaps left alone because their graph outgrew the round's limits (4 096 edges, 2 048
+ * paths, the job list).  Follow with gf_pick_anchored2_from_dev(d_first = d_stats + 7) to pick among the merged contigs only. */
+int gf_merge_open_gaps_dev(gf_ctx* ctx, void* d_contigs, void* d_n_contigs, size_t contig_cap, void* d_seq, void* d_seq_len,
+                           size_t seq_cap, const void* d_gap_best, size_t n_gaps, const gf_ovl_params* params, int kmer_len_quick,
+                           int max_set, const int* k_list, const int* kv_list, int n_k, void* d_stats);
+/* gf_pick_anchored2_dev over the contigs from *d_first (u32, device) on: the pick words of earlier calls stay and compete (atomicMax) */
+int gf_pick_anchored2_from_dev(gf_ctx* ctx, const void* d_contigs, const void* d_n_contigs, size_t contig_cap, const void* d_seq,
+                               int anchor_len, int anchor_len_short, const void* d_first, void* d_gap_best, void* d_n_closed);
+
 /* ---- device memory + timing helpers (so a ctypes host needs no other HIP binding) ---------------------- */
 int gf_dev_alloc(gf_ctx* ctx, size_t bytes, void** d_ptr);
 int gf_dev_free(gf_ctx* ctx, void* d_ptr);

@@ -174,12 +174,17 @@ def expected_merged_contigs(own, max_set=128):
     return [s_ for _, s_ in PO.merger_new_contigs(nodes, CO.GAPPADDER_OVL)] if len(nodes) >= 2 else []
 
 
-def merged_equal(ctg, seq, gaps, n0):
+def merged_equal(ctg, seq, gaps, n0, kk=None):
     """The merged contigs (k = kv = 0, records from n0 on) the device appended for the listed gaps against expected_merged_contigs of
-    the gaps' own contigs (records before n0, record order)."""
+    the gaps' own contigs (records before n0) in the order of the gap's contigs.fa (assemble_gaps.py:124-135): the (k, kv) pairs in list
+    order, inside a pair by (length descending, sequence); kk = None: record order."""
     for g in _gap_list(gaps):
         rows = np.nonzero(ctg["gap"] == g)[0]
-        own = [_contig_text(ctg, seq, i) for i in rows if i < n0]
+        mine = [i for i in rows if i < n0]
+        if kk is not None:
+            pair = {(int(k), int(kv)): q for q, (k, kv) in enumerate(kk)}
+            mine.sort(key=lambda i: (pair.get((int(ctg[i]["k"]), int(ctg[i]["kv"])), 0xFFFF), -int(ctg[i]["length"]), _contig_text(ctg, seq, i), i))
+        own = [_contig_text(ctg, seq, i) for i in mine]
         got = [_contig_text(ctg, seq, i) for i in rows if i >= n0]
         if got != expected_merged_contigs(own):
             return False

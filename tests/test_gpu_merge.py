@@ -402,3 +402,34 @@ def test_device_merge_round_leaves_oversized_sets_alone(gf):
     assert got[1] == _oracle_round(sets)[1] and len(got[1]) >= 1 and g in (got[1][0], got[1][0][::-1].translate(str.maketrans("ACGT", "TGCA")))
     got8, stats8 = gf.merge_round(sets, max_set=2)
     assert got8 == [[], []] and stats8["gaps_skipped_large"] == 2
+
+
+def test_device_merge_round_takes_a_gaps_contigs_in_contigs_fa_order(gf):
+    """With the (k, kv) list the round orders a gap's contigs like its contigs.fa (assemble_gaps.py:124-135: pairs in list order, inside a
+    pair by length descending, then sequence) whatever order the records stand in — the assembly appends them in an unspecified order —,
+    so the merged contigs do not depend on it: every shuffle of the records gives the oracle's answer for the contigs.fa order."""
+    rng = np.random.default_rng(21)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.integers(0, 4, n)].tobytes().decode()
+    kk = [(41, 39), (31, 29), (51, 49)]                      # list order, not sorted
+    sets = []
+    for s in range(40):
+        g = rnd(int(rng.integers(800, 2500)))
+        recs, at = [], 0
+        while at < len(g) - 100:
+            ln = int(rng.integers(100, 600))
+            k, kv = kk[int(rng.integers(0, 3))]
+            recs.append((k, kv, g[at:at + ln]))
+            at += max(30, ln - int(rng.integers(20, 90)))
+        recs.append((31, 29, recs[0][2]))                    # the same sequence under another pair: of identical contigs the FIRST in order stays
+        sets.append(recs)
+    order_of = {p: q for q, p in enumerate(kk)}
+    canon = [[c for (_, _, c) in sorted(recs, key=lambda r: (order_of[(r[0], r[1])], -len(r[2]), r[2]))] for recs in sets]
+    want = _oracle_round(canon)
+    n_new = 0
+    for trial in range(3):
+        shuffled = [[recs[i] for i in rng.permutation(len(recs))] for recs in sets]
+        got, stats = gf.merge_round(shuffled, k_pairs=kk)
+        assert got == want, trial
+        n_new += sum(len(x) for x in got)
+    assert n_new > 60 and stats["error_bits"] == 0
