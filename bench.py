@@ -484,8 +484,8 @@ def run(args):
             out["final_gather_ms"] = gather_ms
         if multi:
             out["fixed_ms"] = dict(fixed_ms, note="per step and rank, HIP-event spans on the step's stream: second_hop_union = all-gather of the "
-                                                  "ranks' second-hop rows + their merge, the same on every rank whatever their number; owner_exchange = pack + "
-                                                  "all-gather of counts + all-to-all + merge of the per-gap pools (exists only in multi-rank runs)")
+                                                  "ranks' second-hop rows (one packed slot per rank) + their merge, the same on every rank whatever their number; owner_exchange = pack + "
+                                                  "the one all-to-all (rows + per-gap counts, exact split sizes) + merge of the per-gap pools (exists only in multi-rank runs)")
             out["config"]["forced_exchange_at_world_1"] = world == 1
             n_lib_ = len(libs)
             if getattr(pipe, "exact_exchange", False):
