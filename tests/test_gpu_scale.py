@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _dev(t):
     import torch
-    return torch.from_numpy(np.ascontiguousarray(t)).cuda()
+    return torch.from_numpy(np.array(t, copy=True, order="C")).cuda()
 
 
 def _random_pools(rng, n_gaps, rb, max_rows):
