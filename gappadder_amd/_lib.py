@@ -123,6 +123,7 @@ def lib():
         "gf_pick_anchored_dev": (i32, [vp, vp, vp, sz, vp, i32, vp, vp]),
         "gf_pick_anchored2_dev": (i32, [vp, vp, vp, sz, vp, i32, i32, vp, vp]),
         "gf_pick_anchored2_from_dev": (i32, [vp, vp, vp, sz, vp, i32, i32, vp, vp, vp]),
+        "gf_bridging_reads": (i32, [vp, C.c_char_p, vp, vp, C.c_char_p, vp, vp, sz, i32, i32, vp]),
         "gf_merge_open_gaps_dev": (i32, [vp, vp, vp, sz, vp, vp, sz, vp, sz, vp, i32, i32, vp, vp, i32, vp]),
         "gf_count_kmers": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp, sz, szp]),
         "gf_pool_keys_reset": (i32, [vp, vp]),

@@ -240,6 +240,42 @@ def bridging_reads(contigs, reads, seed_len=30):
     return bridges
 
 
+def bridging_reads_batch(items, seed_len=30, budget=2):
+    """bridging_reads for many gaps in ONE host call of the library (gf_bridging_reads, csrc/textio.hip: the definition above in C++,
+    hashing instead of per-gap numpy sorts).  items = [(contigs [(name, SEQUENCE)], reads {id: sequence})] -> per item [(id, sequence)] of
+    the bridging reads, in the order of `reads`."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib as B
+    ctext, coff, cset, rtext, roff, rset = [], [0], [0], [], [0], [0]
+    read_items = []
+    for contigs, reads in items:
+        for _, s_ in contigs:
+            ctext.append(s_)
+            coff.append(coff[-1] + len(s_))
+        cset.append(len(coff) - 1)
+        it = list(reads.items())
+        read_items.append(it)
+        for _, s_ in it:
+            rtext.append(s_)
+            roff.append(roff[-1] + len(s_))
+        rset.append(len(roff) - 1)
+    out = np.zeros(max(1, len(roff) - 1), dtype=np.uint8)
+    a = lambda x: np.asarray(x, dtype=np.uint64)
+    co, cs, ro, rs = a(coff), a(cset), a(roff), a(rset)
+    rc = B.lib().gf_bridging_reads(None, "".join(ctext).encode(), B._p(co), B._p(cs), "".join(rtext).encode(), B._p(ro), B._p(rs), len(items),
+                                   int(seed_len), int(budget), B._p(out))
+    if rc:
+        raise B.GapFillError(rc, "gf_bridging_reads")
+    res, at = [], 0
+    for it in read_items:
+        res.append([it[q] for q in range(len(it)) if out[at + q]])
+        at += len(it)
+    return res
+
+
 class GapAssembler:
     def __init__(self, sf_fai, sf_pos, n_jobs, working_space, kmer_list=None, gf=None, bam_list=None, samtools_path=None):
         global kmer_len_list, working_folder, _gf
@@ -293,8 +329,8 @@ class GapAssembler:
         inside a contig with a sequencing error or two is an end-to-end alignment for bwa and no bridge.  One deviation in
         the file handling: the reference removes contigs.fa when original_contigs_before_merging.fa is missing (:206-210); here the
         merged file stays.  Returns the number of reads appended."""
-        from .pick_contigs import read_fasta, revcomp
-        n_added = 0
+        from .pick_contigs import read_fasta
+        work = []                                                                         # (folder, contigs, reads) of the gaps that take part
         for gid in id_list:
             d = "%svelvet_temp/%s/" % (working_folder, gid)
             sf_reads = "%sgap_reads_high_quality/%s.fastq" % (working_folder, gid)
@@ -303,15 +339,15 @@ class GapAssembler:
             contigs = [(n, s.upper()) for n, s in read_fasta(d + "contigs.fa")]
             reads = {}                                                                    # first record of an id counts (:188-191)
             with open(sf_reads) as f:
-                while True:
-                    h = f.readline()
-                    if not h:
-                        break
-                    seq = f.readline().strip()
-                    f.readline()
-                    f.readline()
-                    reads.setdefault(h[1:].split()[0], seq)
-            bridges = bridging_reads(contigs, reads, seed_len)
+                lines = f.read().split("\n")
+            for q in range(0, len(lines) - 1, 4):
+                if lines[q]:
+                    reads.setdefault(lines[q][1:].split()[0], lines[q + 1].strip() if q + 1 < len(lines) else "")
+            work.append((d, contigs, reads))
+        # all gaps of the round through ONE library call (the reference runs bwa per gap; the numpy form of this module took 2 ms per gap)
+        bridges_of = bridging_reads_batch([(c, r) for _, c, r in work], seed_len) if work else []
+        n_added = 0
+        for (d, _, _), bridges in zip(work, bridges_of):
             if os.path.exists(d + "original_contigs_before_merging.fa"):                  # (:206-210)
                 os.replace(d + "original_contigs_before_merging.fa", d + "contigs.fa")
             with open(d + "contigs.fa", "a") as f:

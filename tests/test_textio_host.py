@@ -115,3 +115,59 @@ def test_fastq_records_text_equals_the_per_record_rewrite(tmp_path):
     assert len(out3) == 0 and len(end3) == 0
     with pytest.raises(B.GapFillError):
         textio.fastq_records_text(files, [0], [len(files[0]) + 1], [0], suffix)
+
+
+def test_bridging_reads_in_one_library_call_equal_the_python_definition():
+    """gf_bridging_reads (host code of the library, all gaps of a round in one call) against gappadder_amd/assemble_gaps.py::bridging_reads — the
+    definition of the rescue round's alignment stand-in (assemble_gaps.py:166-217): reads that bridge two contigs, reads inside one contig with and
+    without sequencing errors, strangers, reverse-complemented reads, a seed repeated more than eight times in a contig, N in reads and contigs
+    (the definition then runs its text look-up instead of the 2-bit sort), lower case, reads shorter than the seed, gaps with one contig."""
+    import random
+    from gappadder_amd import assemble_gaps as AG
+    rng = random.Random(5)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    rc = lambda x: x[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+    items = []
+    for g in range(60):
+        genome = rnd(rng.randint(600, 2500))
+        if g % 6 == 0:
+            genome = genome[:200] + "ACGTTGCA" * 20 + genome[200:]                    # a low-complexity stretch: windows that repeat > 8 times
+        cuts = sorted(rng.sample(range(100, len(genome) - 100), rng.randint(1, 4)))
+        contigs, a = [], 0
+        for c in cuts + [len(genome)]:
+            piece = genome[a:c - rng.randint(0, 40)]                                 # holes between the contigs
+            if len(piece) > 40:
+                contigs.append(("c%d" % len(contigs), rc(piece) if rng.random() < 0.5 else piece))
+            a = c
+        if g % 9 == 0:
+            contigs = contigs[:1]                                                     # one contig: nothing to bridge
+        if g % 7 == 0 and contigs:
+            n, s_ = contigs[0]
+            contigs[0] = (n, s_[:30] + "N" + s_[31:])
+        reads = {}
+        for r in range(rng.randint(5, 60)):
+            kind = rng.random()
+            at = rng.randint(0, len(genome) - 151)
+            s_ = genome[at:at + rng.choice((150, 150, 100, 25))]
+            if kind < 0.25:
+                p = rng.randint(0, len(s_) - 1)
+                s_ = s_[:p] + rng.choice("ACGT") + s_[p + 1:]
+            elif kind < 0.35:
+                s_ = rnd(len(s_))
+            elif kind < 0.45:
+                s_ = s_[:len(s_) // 2] + rnd(len(s_) - len(s_) // 2)                  # chimeric: clipped wherever it lands
+            if rng.random() < 0.5:
+                s_ = rc(s_)
+            if rng.random() < 0.1:
+                s_ = s_.lower()
+            if rng.random() < 0.05 and len(s_) > 40:
+                s_ = s_[:40] + "N" + s_[41:]
+            reads["r%d" % r] = s_
+        items.append(([(n, s_.upper()) for n, s_ in contigs], reads))
+    got = AG.bridging_reads_batch(items)
+    want = [AG.bridging_reads(c, r) for c, r in items]
+    assert got == want
+    assert sum(len(w) for w in want) > 40 and any(not w for w in want) and sum(1 for w in want if w) > 20
+    for seed, budget_items in ((20, items[:10]), (32, items[10:20])):               # other seed lengths
+        assert AG.bridging_reads_batch(budget_items, seed_len=seed) == [AG.bridging_reads(c, r, seed) for c, r in budget_items]
+    assert AG.bridging_reads_batch([]) == [] and AG.bridging_reads_batch([([], {})]) == [[]]
