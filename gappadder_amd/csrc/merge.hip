@@ -200,18 +200,18 @@ struct OvParams {
     const uint32_t* d_n_pairs;   // or null: the number of pairs is this device word (n_pairs is then an upper bound = the capacity of `pairs`)
 };
 
-// LDS of one evaluation: three rolling diagonals of scores and of start flags, the two nodes
+// LDS of one evaluation: three rolling diagonals of cells, the two nodes.  A cell is ONE word, score << 2 | start flags (bit 0: the path
+// starts on row 0, bit 1: on column 0): three 4-byte reads + two base reads and one write per cell (score and flags in separate arrays were
+// eight LDS reads and two writes per cell, and the sweep is bound by them: DESIGN.md §4)
 constexpr uint32_t OV_ROW = OV_MAXLEN + 2;
-constexpr size_t OV_LDS_BYTES = (size_t)3 * OV_ROW * 4 + (size_t)3 * OV_ROW + (size_t)2 * OV_ROW + 16;
+constexpr size_t OV_LDS_BYTES = (size_t)3 * OV_ROW * 4 + (size_t)2 * OV_ROW + 16;
 struct OvLds {
     int32_t* sc;
-    uint8_t* fl;
     char* a;
     char* b;
     __device__ explicit OvLds(uint32_t* sm) {
         sc = reinterpret_cast<int32_t*>(sm);
-        fl = reinterpret_cast<uint8_t*>(sm + 3 * OV_ROW);
-        a = reinterpret_cast<char*>(fl + 3 * OV_ROW);
+        a = reinterpret_cast<char*>(sm + 3 * OV_ROW);
         b = a + OV_ROW;
     }
 };
@@ -224,11 +224,10 @@ __device__ void ov_evaluate(const OvLds& S, int n1, int n2, const gf_ovl_params&
                             gf_ovl_result* res) {
     constexpr uint32_t ROW = OV_ROW;
     int32_t* sc = S.sc;
-    uint8_t* fl = S.fl;
     const char* a = S.a;
     const char* b = S.b;
     const uint32_t tid = threadIdx.x;
-    const int mis = (int)pr.mismatch, ind = (int)pr.indel, clip = (int)pr.max_clip;
+    const int mis4 = 4 * (int)pr.mismatch, ind4 = 4 * (int)pr.indel, clip = (int)pr.max_clip;
     long long best_sc = -1000000000ll;
     unsigned long long best_rk = ~0ull;   // c << 40 | (row candidate) << 39 | index << 2 | start flags
     __syncthreads();
@@ -236,33 +235,31 @@ __device__ void ov_evaluate(const OvLds& S, int n1, int n2, const gf_ovl_params&
         int32_t* cur = sc + (d % 3) * ROW;
         const int32_t* p1 = sc + ((d + 2) % 3) * ROW;   // diagonal d - 1
         const int32_t* p2 = sc + ((d + 1) % 3) * ROW;   // diagonal d - 2
-        uint8_t* fcur = fl + (d % 3) * ROW;
-        const uint8_t* f1 = fl + ((d + 2) % 3) * ROW;
-        const uint8_t* f2 = fl + ((d + 1) % 3) * ROW;
         const int ilo = d > n2 ? d - n2 : 0, ihi = d < n1 ? d : n1;
         for (int i = ilo + (int)tid; i <= ihi; i += NT) {
             const int j = d - i;
-            int s;
-            uint32_t f;
-            if (i == 0) { s = 0; f = 1u | (j == 0 ? 2u : 0u); }
-            else if (j == 0) { s = 0; f = 2u; }
+            int v;                                      // score << 2 | flags
+            if (i == 0) v = 1 | (j == 0 ? 2 : 0);
+            else if (j == 0) v = 2;
             else {
-                s = p2[i - 1] + (a[i - 1] == b[j - 1] ? 1 : mis);
-                f = f2[i - 1];
-                const int up = p1[i - 1] + ind, lf = p1[i] + ind;
-                if (s < up) { s = up; f = f1[i - 1]; }
-                if (s < lf) { s = lf; f = f1[i]; }
+                // predecessor order diagonal, up, left, each only on a strictly larger SCORE: x.score < y.score <=> (x | 3) < (y & ~3)
+                v = p2[i - 1] + (a[i - 1] == b[j - 1] ? 4 : mis4);
+                const int up = p1[i - 1] + ind4, lf = p1[i] + ind4;
+                if ((v | 3) < (up & ~3)) v = up;
+                if ((v | 3) < (lf & ~3)) v = lf;
             }
-            cur[i] = s;
-            fcur[i] = (uint8_t)f;
+            cur[i] = v;
             // end-cell candidates: column n2 - c (scanned over i) before row n1 - c (scanned over j), c ascending
-            unsigned long long rk = ~0ull;
-            if (n2 - j <= clip) rk = ((unsigned long long)(n2 - j) << 40) | ((unsigned long long)i << 2);
-            if (n1 - i <= clip) {
-                const unsigned long long rr = ((unsigned long long)(n1 - i) << 40) | (1ull << 39) | ((unsigned long long)j << 2);
-                if (rr < rk) rk = rr;
+            if (n2 - j <= clip || n1 - i <= clip) {
+                const int s = v >> 2;
+                unsigned long long rk = ~0ull;
+                if (n2 - j <= clip) rk = ((unsigned long long)(n2 - j) << 40) | ((unsigned long long)i << 2);
+                if (n1 - i <= clip) {
+                    const unsigned long long rr = ((unsigned long long)(n1 - i) << 40) | (1ull << 39) | ((unsigned long long)j << 2);
+                    if (rr < rk) rk = rr;
+                }
+                if (s > best_sc || (s == best_sc && rk < (best_rk & ~3ull))) { best_sc = s; best_rk = rk | (unsigned)(v & 3); }
             }
-            if (rk != ~0ull && (s > best_sc || (s == best_sc && rk < (best_rk & ~3ull)))) { best_sc = s; best_rk = rk | f; }
         }
         __syncthreads();
     }
@@ -326,7 +323,7 @@ __device__ __forceinline__ void ov_load_node(char* dst, const char* src, int n, 
 }
 
 __global__ __launch_bounds__(OV_NT) void overlap_eval_kernel(OvParams P) {
-    extern __shared__ uint32_t sm[];   // [3 x (OV_MAXLEN + 2) scores][3 x (OV_MAXLEN + 2) start flags (bytes)][node 1][node 2]
+    extern __shared__ uint32_t sm[];   // [3 x (OV_MAXLEN + 2) cells: score << 2 | start flags][node 1][node 2]
     __shared__ uint32_t s_pair;
     __shared__ long long s_best_sc[OV_NT / 64];
     __shared__ unsigned long long s_best_rk[OV_NT / 64];
