@@ -433,3 +433,20 @@ def test_device_merge_round_takes_a_gaps_contigs_in_contigs_fa_order(gf):
         assert got == want, trial
         n_new += sum(len(x) for x in got)
     assert n_new > 60 and stats["error_bits"] == 0
+
+
+def test_device_merge_round_skips_a_graph_beyond_its_limits_and_is_repeatable(gf):
+    """A set whose overlap graph outgrows the round's own limits (more than 4 096 edges: a hundred windows of one short sequence, every
+    pair overlapping) is left alone and counted — no error, the gap beside it is merged; and the round gives the same answer when it
+    runs again on the same records (every order-dependent step follows the contigs' order, not the launch's)."""
+    rng = np.random.default_rng(31)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: lut[rng.integers(0, 4, n)].tobytes().decode()
+    g0, g1 = rnd(700), rnd(1500)
+    dense = [g0[a:a + 400] for a in range(0, 300, 3)]                  # 100 contigs, every pair overlaps by 100+ bases
+    sparse = [g1[0:500], g1[430:1000], g1[930:1500]]
+    got, stats = gf.merge_round([dense, sparse])
+    assert got[0] == [] and stats["gaps_skipped_graph"] == 1 and stats["error_bits"] == 0 and stats["gaps_tried"] == 2
+    assert got[1] == _oracle_round([dense[:2], sparse])[1] and len(got[1]) == 1
+    again, stats2 = gf.merge_round([dense, sparse])
+    assert again == got and {k: v for k, v in stats2.items()} == {k: v for k, v in stats.items()}
