@@ -23,6 +23,7 @@ import subprocess
 from . import bam_io
 from . import fastq_io
 from .gnrt_pos_true_seqs import read_fasta
+from .pick_contigs import _cached_fasta
 from .hip_api import GapFill
 
 
@@ -142,7 +143,7 @@ class BothUnmappedReadsCollector:
                 sf_ctg = wf + "velvet_temp/%s/contigs.fa" % key
                 if not os.path.exists(sf_ctg):
                     continue
-                recs = list(read_fasta(sf_ctg))
+                recs = _cached_fasta(sf_ctg, lambda p_: list(read_fasta(p_)))
                 for name, seq in recs:
                     fout.write(">" + key + "-" + name + "\n" + seq + "\n")
                 if recs:

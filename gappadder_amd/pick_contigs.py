@@ -18,7 +18,33 @@ def revcomp(s):
     return s.translate(_COMP)[::-1]
 
 
+# The reference's rounds read a gap's small FASTA files again and again (flanks: twice per pick and round; contigs.fa: every merge, pick
+# and recruit step — 23 000 parses for 1 000 gaps).  A parse is kept per path and handed out again while the file's (mtime, size, inode) stay
+# what they were: one stat instead of open + read + split.  Files beyond 1 MB (a draft) are never kept.
+_FASTA_CACHE, _FASTA_CACHE_BYTES = {}, [0]
+
+
+def _cached_fasta(path, parse):
+    st = os.stat(path)
+    key = (st.st_mtime_ns, st.st_size, st.st_ino)
+    hit = _FASTA_CACHE.get(path)
+    if hit is not None and hit[0] == key:
+        return list(hit[1])
+    recs = parse(path)
+    if st.st_size <= (1 << 20):
+        if _FASTA_CACHE_BYTES[0] > (1 << 30):      # (a human-scale run: 20 000 gaps x a few files x tens of kB stay far below)
+            _FASTA_CACHE.clear()
+            _FASTA_CACHE_BYTES[0] = 0
+        _FASTA_CACHE[path] = (key, recs)
+        _FASTA_CACHE_BYTES[0] += st.st_size
+    return list(recs)
+
+
 def read_fasta(path):
+    return _cached_fasta(path, _parse_fasta)
+
+
+def _parse_fasta(path):
     out, name, chunks = [], None, []
     with open(path) as f:
         for line in f:
