@@ -513,7 +513,20 @@ def run(args):
             pipe.barrier()
             tm = time.perf_counter() - tm0
             r2 = pipe.fetch()
-            out["contig_merge_round_all_gaps"] = dict(r2.merge, inside_the_timed_step=False, ms_of_one_step_with_the_round=tm * 1e3,
+            parity = None
+            if not args.no_cpu and world == 1:      # a seeded sample of the gaps through the oracle's merger (tests/sample_check.py::merged_equal)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import sample_check as SC
+                from concurrent.futures import ThreadPoolExecutor
+                n0_ = r2.merge["contigs_before"]
+                rng = np.random.RandomState(20260630)
+                with_m = np.unique(r2.contigs["gap"][n0_:]) if len(r2.contigs) > n0_ else np.zeros(0, dtype=np.int64)
+                pick_ = sorted(int(x) for x in (with_m if len(with_m) <= 24 else rng.choice(with_m, 24, replace=False)))
+                without = [int(g_) for g_ in rng.choice(n_gaps, min(n_gaps, 64), replace=False) if g_ not in set(with_m.tolist())][:8]
+                with ThreadPoolExecutor(max_workers=max(1, (os.cpu_count() or 2))) as ex:
+                    oks = list(ex.map(lambda g_: SC.merged_equal(r2.contigs, r2.seq, [g_], n0_, kk), pick_ + without))
+                parity = {"gaps_checked": len(oks), "merged_contigs_equal_the_oracles": bool(all(oks))}
+            out["contig_merge_round_all_gaps"] = dict(r2.merge, inside_the_timed_step=False, ms_of_one_step_with_the_round=tm * 1e3, parity=parity,
                                                       ms_of_the_round=tm * 1e3 - step_s * 1e3, gaps_closed_with_it=r2.n_closed,
                                                       note="measured once behind the timed region: no library of this configuration spans a gap, "
                                                            "so merging the open gaps' contigs closes (next to) nothing here")
